@@ -1,0 +1,439 @@
+#!/usr/bin/env python3
+"""Capture golden vectors from the reference's own Python (build container only).
+
+Runs ONLY where ``/root/reference`` is mounted.  The reference source is
+imported, never copied; nothing here travels to the GPU box except the small
+``tests/golden/*.npz`` data files this script writes (inputs + expected
+outputs).
+
+Third-party packages the reference imports but that are not installed here get
+container-only stand-ins registered in ``sys.modules``:
+
+  * ``torchaudio`` / ``torchaudio.transforms.MelSpectrogram`` -- a module built on
+    ``torch.stft`` + the htk/no-norm filterbank (torchaudio's published
+    definition; this is the "parity unpinned" part of the log-mel row: the
+    golden pins the reference-owned post-processing ``model.py:91-97`` and the
+    module tree / buffer names only).
+  * ``h5py`` -- a dict-backed ``File`` (a data container: no arithmetic).
+  * ``pedalboard``, ``wandb``, ``pretty_midi`` -- inert names (FX is off:
+    ``use_fx_prob=0``).
+  * ``omegaconf`` -- PyYAML + recursive merge.
+
+Usage: ``python tools/make_golden.py`` (writes tests/golden/).
+"""
+from __future__ import annotations
+
+import os
+import random
+import sys
+import types
+
+import numpy as np
+import torch
+
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+REF = "/root/reference"
+OUT = os.path.join(REPO, "tests", "golden")
+sys.path.insert(0, REPO)
+
+from oracle import logmel as o_logmel  # noqa: E402  (stand-in torchaudio reuses the restated STFT/fb)
+from oracle.bank import synthetic_bank  # noqa: E402
+
+
+# --------------------------------------------------------------------------- stand-ins
+def _install_standins(h5_store: dict):
+    from transformers import PreTrainedModel, PretrainedConfig  # noqa: F401  (resolve lazily-imported parts before faking anything they probe)
+    from importlib.machinery import ModuleSpec
+
+    def _mod(name):
+        m = types.ModuleType(name)
+        m.__spec__ = ModuleSpec(name, None)
+        return m
+
+    ta = _mod("torchaudio")
+    tat = _mod("torchaudio.transforms")
+
+    class _Spectrogram(torch.nn.Module):
+        def __init__(self, n_fft):
+            super().__init__()
+            self.register_buffer("window", o_logmel.hann_window(n_fft))
+
+    class _MelScale(torch.nn.Module):
+        def __init__(self, sr, n_fft, n_mels, f_min):
+            super().__init__()
+            self.register_buffer("fb", o_logmel.mel_filterbank(sr, n_fft, n_mels, f_min))
+
+    class MelSpectrogram(torch.nn.Module):
+        def __init__(self, sample_rate, n_fft, hop_length, n_mels, f_min=0.0, power=2):
+            super().__init__()
+            assert power == 2
+            self.n_fft, self.hop_length = n_fft, hop_length
+            self.spectrogram = _Spectrogram(n_fft)
+            self.mel_scale = _MelScale(sample_rate, n_fft, n_mels, f_min)
+
+        def forward(self, wave):
+            return o_logmel.mel_power(wave, self.n_fft, self.hop_length,
+                                      self.spectrogram.window, self.mel_scale.fb)
+
+    tat.MelSpectrogram = MelSpectrogram
+    tat.Resample = lambda *a, **k: (lambda x: x)
+    ta.transforms = tat
+    ta.load = lambda *a, **k: (_ for _ in ()).throw(RuntimeError("stand-in"))
+    sys.modules["torchaudio"] = ta
+    sys.modules["torchaudio.transforms"] = tat
+
+    h5 = _mod("h5py")
+
+    class _Group:
+        def __init__(self, d):
+            self._d = d
+
+        def __contains__(self, key):
+            node = self._d
+            for part in key.split("/"):
+                if not isinstance(node, dict) or part not in node:
+                    return False
+                node = node[part]
+            return True
+
+        def __getitem__(self, key):
+            node = self._d
+            for part in key.split("/"):
+                node = node[part]
+            return _Group(node) if isinstance(node, dict) else node
+
+        def keys(self):
+            return self._d.keys()
+
+    class File(_Group):
+        def __init__(self, path, mode="r"):
+            super().__init__(h5_store[path])
+
+        def __enter__(self):
+            return self
+
+        def __exit__(self, *a):
+            return False
+
+    h5.File = File
+    sys.modules["h5py"] = h5
+
+    pb = _mod("pedalboard")
+    for name in ("Pedalboard", "Reverb", "Compressor", "Limiter"):
+        setattr(pb, name, type(name, (), {"__init__": lambda self, *a, **k: None}))
+    sys.modules["pedalboard"] = pb
+    sys.modules["wandb"] = _mod("wandb")
+    sys.modules["pretty_midi"] = _mod("pretty_midi")
+
+    oc = _mod("omegaconf")
+    import yaml
+
+    def _merge(a, b):
+        out = dict(a)
+        for k, v in b.items():
+            out[k] = _merge(out[k], v) if isinstance(v, dict) and isinstance(out.get(k), dict) else v
+        return out
+
+    class OmegaConf:
+        load = staticmethod(lambda p: yaml.safe_load(open(p)))
+        create = staticmethod(lambda d: d)
+        merge = staticmethod(_merge)
+        to_container = staticmethod(lambda c, resolve=True: c)
+
+    oc.OmegaConf = OmegaConf
+    sys.modules["omegaconf"] = oc
+
+
+class _RecordingRandom:
+    """Proxy for the ``random`` module inside modules/synthetiser.py that logs
+    every draw the renderer makes (synthetiser.py:194,197,199,217)."""
+
+    def __init__(self, seed):
+        self._r = random.Random(seed)
+        self.choices: list = []
+        self.uniforms: list = []
+
+    def choice(self, seq):
+        v = self._r.choice(seq)
+        self.choices.append(v)
+        return v
+
+    def uniform(self, a, b):
+        v = self._r.uniform(a, b)
+        self.uniforms.append(v)
+        return v
+
+    def random(self):
+        return self._r.random()
+
+
+# --------------------------------------------------------------------------- G1 log-mel
+def g1_logmel(model_mod):
+    cases = {}
+    rng = np.random.default_rng(1234)
+    specs = [("16k", 16000, 8000, 2), ("24k", 24000, 61440, 1), ("16k_edge", 16000, 5000, 3)]
+    for name, sr, L, B in specs:
+        wave = (rng.standard_normal((B, L)) * 0.05).astype(np.float32)
+        t = np.arange(L) / sr
+        for b in range(B):
+            for _ in range(6):
+                t0 = rng.uniform(0, L / sr * 0.9)
+                f = rng.uniform(60, 6000)
+                env = np.where(t >= t0, np.exp(-(t - t0) * rng.uniform(8, 60)), 0.0)
+                wave[b] += (0.5 * env * np.sin(2 * np.pi * f * (t - t0))).astype(np.float32)
+        wave = np.clip(wave, -1, 1)
+        if name == "16k_edge":
+            wave[1] = 0.0                                         # all-zero clip -> clamp floor
+            wave[2] = np.where((np.arange(L) // 40) % 2 == 0, 1.0, -1.0)  # full-scale square
+        m = model_mod.ComputeMelSpectrogram(sample_rate=sr, win_length=2048, time_res=0.01, n_mels=128)
+        out = m(torch.from_numpy(wave)).contiguous().numpy()
+        cases[f"{name}_wave"] = wave
+        cases[f"{name}_out"] = out
+        cases[f"{name}_sr"] = np.int64(sr)
+        keys = sorted(k for k in m.state_dict().keys())
+        cases[f"{name}_state_keys"] = np.array(keys)
+    np.savez_compressed(os.path.join(OUT, "logmel.npz"), **cases)
+    print("G1 logmel:", {k: v.shape for k, v in cases.items() if k.endswith("_out")})
+
+
+# --------------------------------------------------------------------------- G2 tokenizer
+def g2_tokenizer():
+    from modules.midi_tokenizer import MidiTokenizer, MidiTokenizerConfig
+    out = {}
+    rng = np.random.default_rng(7)
+    idx = 0
+    for adtof in (False, True):
+        for add_vel in (False, True):
+            tk = MidiTokenizer(MidiTokenizerConfig(ADTOF_mapping=adtof, BOS_token=2, EOS_token=3,
+                                                   pad_token=1, silence_token=0, add_velocity=add_vel))
+            for n in (0, 1, 7, 40):
+                onset = np.sort(rng.uniform(0, 2.95, n)).astype(np.float32)
+                pitch = rng.integers(35, 82, n).astype(np.float32)
+                vel = rng.integers(1, 128, n).astype(np.float32)
+                notes = np.stack([onset, onset + 0.1, pitch, vel], 1).astype(np.float32) if n else np.zeros((0, 4), np.float32)
+                mapped = tk.map_notes_to_Gm_custom(torch.from_numpy(notes.copy()), random_velocity=False).numpy() if n else notes
+                toks = tk.notes_to_adt_tokens(torch.from_numpy(mapped.copy())).numpy()
+                dec = tk.decode(toks.tolist()).numpy()
+                out[f"c{idx}_cfg"] = np.array([int(adtof), int(add_vel)])
+                out[f"c{idx}_notes"] = notes
+                out[f"c{idx}_mapped"] = mapped
+                out[f"c{idx}_tokens"] = toks
+                out[f"c{idx}_decoded"] = dec.reshape(-1, 4) if dec.size else np.zeros((0, 4), np.float32)
+                idx += 1
+    tk = MidiTokenizer(MidiTokenizerConfig(False, 2, 3, 1, 0, True))
+    out["empty_tokens"] = tk.empty_adt_tokens().numpy()
+    # malformed sequences through decode (midi_tokenizer.py:69-100)
+    bad = [[2, 340, 10, 335, 450, 3], [2, 10, 20, 335, 3], [2, 450, 10, 335, 3, 3], [2, 0, 3], [2, 10, 335, 12, 338, 3]]
+    for i, seq in enumerate(bad):
+        for add_vel in (False, True):
+            tk = MidiTokenizer(MidiTokenizerConfig(False, 2, 3, 1, 0, add_vel))
+            dec = tk.decode(seq).numpy()
+            out[f"bad{i}_{int(add_vel)}_tokens"] = np.array(seq)
+            out[f"bad{i}_{int(add_vel)}_decoded"] = dec.reshape(-1, 4) if dec.size else np.zeros((0, 4), np.float32)
+    out["n_cases"] = np.int64(idx)
+    out["n_bad"] = np.int64(len(bad))
+    np.savez_compressed(os.path.join(OUT, "tokenizer.npz"), **out)
+    print("G2 tokenizer:", idx, "cases")
+
+
+# --------------------------------------------------------------------------- G3 masks / collate
+def g3_masks_collate():
+    from utils.utils import create_mask_plain
+    sys.argv = ["x", "dummy.yaml"]          # train_dataset.py parses argv at import (train_dataset.py:232-234)
+    from data_modules.train_dataset import collate_fn
+    out = {}
+    for i, (T, lens) in enumerate([(5, [5, 3, 1]), (1, [1]), (9, [0, 9, 4, 8])]):
+        cm, pm = create_mask_plain(T, torch.tensor(lens), None)
+        out[f"m{i}_T"] = np.int64(T)
+        out[f"m{i}_lens"] = np.array(lens)
+        out[f"m{i}_causal"] = cm.numpy()
+        out[f"m{i}_pad"] = pm.numpy()
+    rng = np.random.default_rng(3)
+    batches = [[(100, 5), (80, 9), (100, 9), (60, 2)], [(10, 3)], [(7, 4), (9, 4)]]
+    for i, spec in enumerate(batches):
+        batch = [(torch.from_numpy(rng.standard_normal(w).astype(np.float32)),
+                  torch.from_numpy(rng.integers(0, 1400, t))) for w, t in spec]
+        res = collate_fn([(w, t.tolist()) for w, t in batch])
+        out[f"c{i}_n"] = np.int64(len(spec))
+        for j, (w, t) in enumerate(batch):
+            out[f"c{i}_wav{j}"] = w.numpy()
+            out[f"c{i}_tok{j}"] = t.numpy()
+        out[f"c{i}_wavs"] = res["wavs"].numpy()
+        out[f"c{i}_tokens"] = res["tokens"].numpy()
+        out[f"c{i}_token_lengths"] = res["token_lengths"].numpy()
+    out["n_masks"] = np.int64(3)
+    out["n_collate"] = np.int64(len(batches))
+    np.savez_compressed(os.path.join(OUT, "masks_collate.npz"), **out)
+    print("G3 masks/collate ok")
+
+
+# --------------------------------------------------------------------------- G4 mixer
+def g4_mixer(h5_store):
+    import modules.synthetiser as synth_mod
+    out = {}
+    sr = 16000
+    bank = synthetic_bank(seed=11, sample_rate=sr)
+    path = f"/fake/oneshot@{sr}.hdf5"
+    h5_store[path] = bank.as_tree()
+    case = 0
+    for adtof, thr, mixup_range, input_sec, n_notes, seed in [
+        (False, 0.8, 0.8, 1.0, 12, 0), (False, 1.0, 0.0, 1.0, 5, 1), (True, 0.8, 0.5, 1.0, 10, 2),
+        (False, 0.8, 0.8, 0.5, 6, 3), (False, 0.9, 0.3, 1.0, 0, 4),
+    ]:
+        cfg = synth_mod.SynthDrumConfig(
+            input_sec=input_sec, time_res=0.01, win_length=2048, sample_rate=sr,
+            oneshot_path="/fake/oneshot", similarity_threshold=thr, max_hat_std_velocity=0.15,
+            max_hat_mean_velocity=0.1, max_cymbals_std_velocity=0.15, max_cymbals_mean_velocity=0.65,
+            ADTOF_mapping=adtof, mixup_range=mixup_range, use_fx_prob=0.0, use_reverb_prob=0.5,
+            use_limiter_prob=0.5, use_compression_prob=0.5)
+        sd = synth_mod.SynthDrum(cfg)
+        rng = np.random.default_rng(100 + seed)
+        onset = np.sort(rng.uniform(0, input_sec * 0.95 if case != 3 else 0.9, n_notes)).astype(np.float32)
+        if adtof:
+            pitch = rng.choice([35, 38, 41, 42, 48, 52, 58, 61], n_notes).astype(np.float32)
+        else:
+            pitch = rng.integers(35, 61, n_notes).astype(np.float32)
+        vel = rng.integers(0, 128, n_notes).astype(np.float32)
+        if n_notes:
+            vel[0] = 0.0 if case == 1 else vel[0]          # velocity 0 -> volume 0 (synthetiser.py:205-206)
+        notes = np.stack([onset, onset + 0.1, pitch, vel], 1).astype(np.float32) if n_notes else np.zeros((0, 4), np.float32)
+        rec = _RecordingRandom(seed)
+        synth_mod.random = rec
+        wav = sd(notes.tolist())
+        synth_mod.random = random
+        out[f"s{case}_cfg"] = np.array([int(adtof), thr, mixup_range, input_sec, sr], np.float64)
+        out[f"s{case}_notes"] = notes
+        out[f"s{case}_wav"] = wav.numpy().astype(np.float32)
+        out[f"s{case}_uniforms"] = np.array(rec.uniforms, np.float64)
+        out[f"s{case}_choices"] = np.array([str(c) for c in rec.choices])
+        out[f"s{case}_seed"] = np.int64(seed)
+        case += 1
+    out["n_cases"] = np.int64(case)
+    out["bank_seed"] = np.int64(11)
+    np.savez_compressed(os.path.join(OUT, "mixer.npz"), **out)
+    print("G4 mixer:", case, "cases")
+
+
+# --------------------------------------------------------------------------- G5/G6 ADT network
+def _adt_config(tiny: bool):
+    from config import ADTModelConfig
+    if tiny:
+        return ADTModelConfig(input_sec=0.5, time_res=0.01, win_length=2048, sample_rate=16000, enc_layers=1,
+                              dec_layers=1, nhead=2, d_query=16, dropout=0.0, tgt_vocab_size=1400, enc_lr=1e-4,
+                              dec_lr=1e-4, plain=True, n_mels=128)
+    return ADTModelConfig(input_sec=2.56, time_res=0.01, win_length=2048, sample_rate=16000, enc_layers=4,
+                          dec_layers=4, nhead=6, d_query=128, dropout=0.0, tgt_vocab_size=1400, enc_lr=1e-4,
+                          dec_lr=1e-4, plain=True, n_mels=128)
+
+
+def _make_batch(rng, B, L, T):
+    wave = np.clip(rng.standard_normal((B, L)) * 0.1, -1, 1).astype(np.float32)
+    lens = rng.integers(max(T // 3, 2), T + 2, B)
+    lens[0] = T + 1
+    tokens = np.full((B, T + 1), 1, np.int64)
+    for b in range(B):
+        n = int(lens[b])
+        body = rng.integers(4, 530, n - 2)
+        tokens[b, :n] = np.concatenate([[2], body, [3]])
+    token_lengths = np.where(lens == lens.max(), lens - 1, lens)   # collate rule (train_dataset.py:46-51)
+    return wave, tokens, token_lengths.astype(np.int64)
+
+
+def g5_adt_tiny(model_mod):
+    from utils.utils import create_mask_plain
+    torch.manual_seed(0)
+    cfg = _adt_config(tiny=True)
+    model = model_mod.ADTModel(cfg)
+    with torch.no_grad():      # non-trivial biases / LN affine so every term is exercised
+        for n, p in model.named_parameters():
+            if p.ndim == 1:
+                p.add_(torch.randn_like(p) * 0.05)
+    rng = np.random.default_rng(5)
+    B, L, T = 3, 8000, 12
+    wave, tokens, token_lengths = _make_batch(rng, B, L, T)
+    model.train()
+    src = torch.from_numpy(wave)
+    tok = torch.from_numpy(tokens)
+    tgt_in, labels = tok[:, :-1], tok[:, 1:]
+    _, pad_mask = create_mask_plain(tgt_in.size(1), torch.from_numpy(token_lengths), None)
+    cap = {}
+    h1 = model.encoder.register_forward_hook(lambda m, i, o: cap.__setitem__("memory", o.detach()))
+    h2 = model.decoder.register_forward_hook(lambda m, i, o: cap.__setitem__("logits", o.detach()))
+    h3 = model.compute_spectrogram.register_forward_hook(lambda m, i, o: cap.__setitem__("logmel", o.detach()))
+    loss = model(src=src, tgt=tgt_in, tgt_mask=None, tgt_padding_mask=pad_mask, labels=labels)
+    loss.backward()
+    for h in (h1, h2, h3):
+        h.remove()
+    out = {"wave": wave, "tokens": tokens, "token_lengths": token_lengths,
+           "logmel": cap["logmel"].contiguous().numpy(), "memory": cap["memory"].numpy(),
+           "logits": cap["logits"].numpy(), "loss": loss.detach().numpy()}
+    sd = model.state_dict()
+    out["state_keys"] = np.array(list(sd.keys()))
+    for k, v in sd.items():
+        if "pos_embedding" in k or k.startswith("compute_spectrogram."):
+            continue                              # constants: regenerated, not stored
+        out["w::" + k] = v.numpy()
+    for name in ("project_to_mel.weight", "encoder.encoder.layers.0.self_attn.in_proj_weight",
+                 "encoder.encoder.layers.0.linear1.bias", "encoder.layer_norm.weight",
+                 "decoder.decoder.layers.0.multihead_attn.in_proj_weight",
+                 "decoder.decoder.layers.0.norm3.bias", "decoder.tgt_tok_emb.embedding.weight",
+                 "decoder.generator.bias", "encoder.dense_layer.weight"):
+        out["g::" + name] = dict(model.named_parameters())[name].grad.numpy()
+    # greedy sample (model.py:260-324) -- eval mode, grad enabled as in the reference
+    gen = model.sample(src=src, src_mask=None, tgt_mask=None, max_length=10, start_token=2, end_token=3)
+    out["sample_ids"] = gen.numpy()
+    np.savez_compressed(os.path.join(OUT, "adt_tiny.npz"), **out)
+    print("G5 adt tiny: loss", float(loss), "logits", cap["logits"].shape, "sample", gen.shape)
+
+
+def g6_adt_full(model_mod):
+    """Full-size (setting-1 architecture) statistics only; weights are seeded
+    by a portable numpy recipe that tests re-create (oracle/adt.py:seeded_state)."""
+    from utils.utils import create_mask_plain
+    from oracle.adt import seeded_state
+    cfg = _adt_config(tiny=False)
+    model = model_mod.ADTModel(cfg)
+    state = seeded_state(model.state_dict(), seed=0)
+    model.load_state_dict(state)
+    rng = np.random.default_rng(6)
+    B, L, T = 2, 40960, 24
+    wave, tokens, token_lengths = _make_batch(rng, B, L, T)
+    model.train()
+    tok = torch.from_numpy(tokens)
+    tgt_in, labels = tok[:, :-1], tok[:, 1:]
+    _, pad_mask = create_mask_plain(tgt_in.size(1), torch.from_numpy(token_lengths), None)
+    cap = {}
+    h2 = model.decoder.register_forward_hook(lambda m, i, o: cap.__setitem__("logits", o.detach()))
+    with torch.no_grad():
+        loss = model(src=torch.from_numpy(wave), tgt=tgt_in, tgt_mask=None, tgt_padding_mask=pad_mask, labels=labels)
+    h2.remove()
+    lg = cap["logits"].double()
+    out = {"seed": np.int64(0), "batch_seed": np.int64(6), "B": np.int64(B), "L": np.int64(L), "T": np.int64(T),
+           "loss": loss.numpy(), "logits_mean": lg.mean().numpy(), "logits_std": lg.std().numpy(),
+           "logits_absmax": lg.abs().max().numpy(), "logits_sample": cap["logits"][:, ::5, ::97].numpy(),
+           "state_keys": np.array(list(model.state_dict().keys())),
+           "state_shapes": np.array([str(tuple(v.shape)) for v in model.state_dict().values()]),
+           "n_params": np.int64(sum(p.numel() for p in model.parameters()))}
+    np.savez_compressed(os.path.join(OUT, "adt_full_stats.npz"), **out)
+    print("G6 adt full: loss", float(loss), "params", int(out["n_params"]))
+
+
+def main():
+    os.makedirs(OUT, exist_ok=True)
+    torch.set_num_threads(8)
+    h5_store: dict = {}
+    _install_standins(h5_store)
+    sys.path.insert(0, REF)
+    sys.argv = ["make_golden", "dummy.yaml"]
+    import model as model_mod                      # /root/reference/model.py
+    which = set(sys.argv[2:]) if len(sys.argv) > 2 else None
+    g1_logmel(model_mod)
+    g2_tokenizer()
+    g3_masks_collate()
+    g4_mixer(h5_store)
+    g5_adt_tiny(model_mod)
+    g6_adt_full(model_mod)
+
+
+if __name__ == "__main__":
+    main()
