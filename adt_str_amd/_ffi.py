@@ -1,0 +1,81 @@
+"""ctypes binding of ``libadt_hip.so`` (C ABI: ``include/adt_hip.h``).
+
+The library is built in-tree by ``__graft_entry__.build()`` /
+``make -C adt_str_amd/csrc``.  Loading is lazy and fails loudly: there is no
+fallback implementation behind these calls.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import threading
+
+_LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "libadt_hip.so")
+_lock = threading.Lock()
+_lib = None
+
+ABI_VERSION = 1
+
+i32, i64, f32, ptr = C.c_int32, C.c_int64, C.c_float, C.c_void_p
+
+# name -> argtypes; every entry must be declared in include/adt_hip.h (tests check both ways)
+SIGNATURES = {
+    "adt_version": [],
+    "adt_last_error": [],
+    "adt_logmel_f32": [ptr, i64, i64, i64, i32, i32, i32, i32, ptr, ptr, ptr, i32, i32, f32, f32, f32, ptr, ptr],
+}
+
+
+class AdtError(RuntimeError):
+    """A libadt_hip call returned a negative ADT_E* code."""
+
+    def __init__(self, fn: str, code: int, msg: str):
+        super().__init__(f"{fn} failed with code {code}: {msg}")
+        self.code = code
+
+
+def lib_path() -> str:
+    return _LIB_PATH
+
+
+def load() -> C.CDLL:
+    """Load (once) and return the library; raises if it has not been built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    with _lock:
+        if _lib is None:
+            if not os.path.exists(_LIB_PATH):
+                raise RuntimeError(
+                    f"{_LIB_PATH} not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+                    "(or `make -C adt_str_amd/csrc`). adt_str_amd has no fallback path.")
+            lib = C.CDLL(_LIB_PATH)
+            for name, argtypes in SIGNATURES.items():
+                fn = getattr(lib, name)
+                fn.argtypes = argtypes
+                fn.restype = C.c_char_p if name == "adt_last_error" else C.c_int
+            v = lib.adt_version()
+            if v != ABI_VERSION:
+                raise RuntimeError(f"libadt_hip.so ABI version {v} != expected {ABI_VERSION}; rebuild it")
+            _lib = lib
+    return _lib
+
+
+def call(name: str, *args) -> None:
+    """Invoke an ``int``-returning entry point and raise ``AdtError`` on failure."""
+    lib = load()
+    rc = getattr(lib, name)(*args)
+    if rc != 0:
+        raise AdtError(name, rc, lib.adt_last_error().decode("utf-8", "replace"))
+
+
+def dptr(t) -> int:
+    """Device pointer of a CUDA(HIP) tensor; refuses anything else."""
+    if not t.is_cuda:
+        raise RuntimeError("adt_str_amd kernels take GPU tensors only (there is no CPU path)")
+    return t.data_ptr()
+
+
+def current_stream() -> int:
+    import torch
+    return torch.cuda.current_stream().cuda_stream

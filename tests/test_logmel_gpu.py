@@ -1,0 +1,117 @@
+"""K1 parity on the GPU: adt_logmel_f32 (through the ComputeMelSpectrogram
+drop-in and the raw C ABI) vs the oracle and the golden vectors.
+
+Tolerance (fp32 path, stated on the normalised [0,1] output): 2e-5 absolute on
+ordinary audio; for signals where fp32 rounding dominates weak bands (full-scale
+square wave) both implementations are judged against a float64 evaluation."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import logmel as o_logmel
+
+pytestmark = pytest.mark.gpu
+TOL = 2e-5
+
+
+@pytest.fixture(scope="module")
+def dev():
+    assert torch.cuda.is_available(), "GPU tests need a GPU"
+    return torch.device("cuda:0")
+
+
+def gpu_logmel(wave, sr, dev, n_mels=128):
+    from adt_str_amd.frontend import ComputeMelSpectrogram
+    m = ComputeMelSpectrogram(sr, 2048, 0.01, n_mels)
+    return m(torch.as_tensor(wave).to(dev)).cpu().numpy()
+
+
+def test_golden_vectors(dev, golden_dir):
+    g = np.load(os.path.join(golden_dir, "logmel.npz"))
+    for name in ("16k", "24k", "16k_edge"):
+        got = gpu_logmel(g[f"{name}_wave"], int(g[f"{name}_sr"]), dev)
+        ref = g[f"{name}_out"]
+        assert got.shape == ref.shape
+        if name == "16k_edge":
+            assert np.all(got[1] == 0.0)
+            assert np.abs(got[:2] - ref[:2]).max() < TOL
+            ref64 = o_logmel.logmel_f64(g[f"{name}_wave"][2:3], 16000, 2048, 0.01, 128)[0]
+            assert np.abs(got[2] - ref64).max() < max(2.0 * np.abs(ref[2] - ref64).max(), 1e-3)
+        else:
+            assert np.abs(got - ref).max() < TOL
+
+
+@pytest.mark.parametrize("sr,L,B", [(16000, 160000, 3), (24000, 61440, 5), (16000, 4000, 2), (16000, 2600, 1),
+                                    (70000, 9000, 2), (16000, 8161, 4)])
+def test_against_oracle(dev, sr, L, B):
+    rng = np.random.default_rng(L + B)
+    wave = np.clip(rng.standard_normal((B, L)) * 0.1, -1, 1).astype(np.float32)
+    got = gpu_logmel(wave, sr, dev)
+    ref = o_logmel.logmel(torch.from_numpy(wave), sr, 2048, 0.01, 128).numpy()
+    assert got.shape == ref.shape
+    if ref.size:
+        assert np.abs(got - ref).max() < TOL
+
+
+def test_empty_and_strided_inputs(dev):
+    from adt_str_amd.frontend import ComputeMelSpectrogram
+    m = ComputeMelSpectrogram(16000, 2048, 0.01, 128)
+    assert m(torch.zeros(0, 16000, device=dev)).shape == (0, 85, 128)
+    assert m(torch.zeros(2, 2000, device=dev)).shape[1] == 0          # fewer frames than the trim removes
+    rng = np.random.default_rng(0)
+    big = torch.from_numpy((rng.standard_normal((4, 20000)) * 0.1).astype(np.float32)).to(dev)
+    view = big[:, :16000]                                               # row stride 20000
+    got = m(view).cpu().numpy()
+    ref = o_logmel.logmel(view.cpu(), 16000, 2048, 0.01, 128).numpy()
+    assert np.abs(got - ref).max() < TOL
+    half = m(view.half()).cpu().numpy()                                 # any float dtype is cast to fp32 (model.py:88)
+    ref_h = o_logmel.logmel(view.half().float().cpu(), 16000, 2048, 0.01, 128).numpy()
+    assert np.abs(half - ref_h).max() < TOL
+
+
+def test_full_size_config2(dev):
+    """BASELINE config 2: 256 x 10 s @ 16 kHz.  Size-independent checks: bit-equal
+    across two launches, every clip equals the same clip run alone (batch
+    independence), a sample of clips equals the oracle, zero clips give zeros."""
+    from adt_str_amd.frontend import ComputeMelSpectrogram
+    g = torch.Generator().manual_seed(1234)
+    wave = (torch.randn(256, 160000, generator=g) * 0.05).clamp_(-1, 1)
+    wave[::16] = 0.0
+    m = ComputeMelSpectrogram(16000, 2048, 0.01, 128)
+    w = wave.to(dev)
+    a = m(w)
+    b = m(w)
+    assert a.shape == (256, 986, 128)
+    assert torch.equal(a, b)
+    assert torch.all(a[::16] == 0)
+    for i in (1, 77, 255):
+        assert torch.equal(m(w[i:i + 1])[0], a[i])
+    idx = [1, 100, 255]
+    ref = o_logmel.logmel(wave[idx], 16000, 2048, 0.01, 128)
+    assert (a[idx].cpu() - ref).abs().max() < TOL
+
+
+def test_state_dict_names_and_fb_reload(dev, golden_dir):
+    from adt_str_amd.frontend import ComputeMelSpectrogram
+    g = np.load(os.path.join(golden_dir, "logmel.npz"))
+    m = ComputeMelSpectrogram(16000, 2048, 0.01, 128).to(dev)
+    assert sorted(m.state_dict()) == sorted(str(k) for k in g["16k_state_keys"])
+    wave = torch.from_numpy(g["16k_wave"]).to(dev)
+    base = m(wave)
+    sd = {k: v.clone() for k, v in m.state_dict().items()}
+    sd["compute_spec.mel_scale.fb"] *= 2.0                              # a checkpoint with a different filterbank
+    m.load_state_dict(sd)
+    doubled = m(wave)
+    expect = (torch.clamp(torch.log((torch.exp(base * 35 - 23) - 1e-10) * 2 + 1e-10), -23, 12) + 23) / 35
+    assert (doubled - expect).abs().max() < 1e-4
+
+
+def test_c_abi_rejects_bad_shapes(dev):
+    from adt_str_amd import _ffi
+    x = torch.zeros(1, 4096, device=dev)
+    with pytest.raises(_ffi.AdtError) as e:
+        _ffi.call("adt_logmel_f32", x.data_ptr(), 1, 4096, 4096, 1024, 160, 7, 1, x.data_ptr(), x.data_ptr(),
+                  x.data_ptr(), 128, 0, 1e-10, -23.0, 12.0, x.data_ptr(), 0)
+    assert e.value.code == -2
