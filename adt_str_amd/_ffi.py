@@ -23,7 +23,10 @@ SIGNATURES = {
     "adt_version": [],
     "adt_last_error": [],
     "adt_logmel_f32": [ptr, i64, i64, i64, i32, i32, i32, i32, ptr, ptr, ptr, i32, i32, f32, f32, f32, ptr, ptr],
+    "adt_mix_workspace_bytes": [i64, i64],
+    "adt_mix_render_f32": [ptr, ptr, i64, ptr, i64, ptr, ptr, ptr, i64, i64, ptr, i64, ptr, C.c_size_t, ptr],
 }
+_RESTYPES = {"adt_last_error": C.c_char_p, "adt_mix_workspace_bytes": C.c_size_t}
 
 
 class AdtError(RuntimeError):
@@ -53,7 +56,7 @@ def load() -> C.CDLL:
             for name, argtypes in SIGNATURES.items():
                 fn = getattr(lib, name)
                 fn.argtypes = argtypes
-                fn.restype = C.c_char_p if name == "adt_last_error" else C.c_int
+                fn.restype = _RESTYPES.get(name, C.c_int)
             v = lib.adt_version()
             if v != ABI_VERSION:
                 raise RuntimeError(f"libadt_hip.so ABI version {v} != expected {ABI_VERSION}; rebuild it")

@@ -1,0 +1,97 @@
+"""Flat, HBM-resident one-shot bank.
+
+The reference keeps one-shots in an HDF5 file ``<prefix>@<sr>.hdf5`` laid out
+``/<gm_custom_pitch>/<similarity_group>/<name>`` (1-D float32, gzip;
+``data_modules/convert_augmented_to_hdf5.py:69-141``) and re-opens it for every
+note (``modules/synthetiser.py:273``).  Here the same content is one contiguous
+float32 array plus offsets, uploaded to the GPU once:
+
+  data      float32 [total_samples]
+  offsets   int64   [n_shots + 1]
+  pitch/group/name per shot; ``cells[(pitch, group)]`` = shot ids in name order
+  (h5py lists group members in name order, which is the order
+  ``random.choice(list(...keys()))`` indexes, synthetiser.py:199).
+
+On disk it is an ``.npz`` with those arrays (``save`` / ``load``).
+"""
+from __future__ import annotations
+
+from dataclasses import dataclass, field
+from typing import Dict, List, Tuple
+
+import numpy as np
+import torch
+
+# similarity groups from best to worst (synthetiser.py:172-184)
+GROUPS = ["gold", "100-90", "90-80", "80-70", "70-60", "60-50", "50-40", "40-30", "30-20", "20-10", "10-0"]
+
+
+@dataclass
+class OneShotBank:
+    data: np.ndarray
+    offsets: np.ndarray
+    pitch: np.ndarray            # int32 [n_shots]
+    group: np.ndarray            # int32 [n_shots] index into GROUPS
+    names: List[str]
+    sample_rate: int
+    cells: Dict[Tuple[int, str], List[int]] = field(default_factory=dict)
+    _dev: dict = field(default_factory=dict, repr=False)
+
+    def __post_init__(self):
+        if not self.cells:
+            order = sorted(range(len(self.names)), key=lambda i: (int(self.pitch[i]), int(self.group[i]), self.names[i]))
+            for i in order:
+                self.cells.setdefault((int(self.pitch[i]), GROUPS[int(self.group[i])]), []).append(i)
+
+    @property
+    def n_shots(self) -> int:
+        return len(self.names)
+
+    def shot(self, i: int) -> np.ndarray:
+        return self.data[self.offsets[i]:self.offsets[i + 1]]
+
+    def has_cell(self, pitch: int, group: str) -> bool:
+        return (int(pitch), group) in self.cells
+
+    def cell_names(self, pitch: int, group: str) -> List[str]:
+        return [self.names[i] for i in self.cells[(int(pitch), group)]]
+
+    def shot_id(self, pitch: int, group: str, name: str) -> int:
+        for i in self.cells[(int(pitch), group)]:
+            if self.names[i] == name:
+                return i
+        raise KeyError(f"{pitch}/{group}/{name}")
+
+    @staticmethod
+    def from_tree(tree: dict, sample_rate: int) -> "OneShotBank":
+        """Build from the HDF5-shaped nested dict ``{pitch: {group: {name: array}}}``."""
+        chunks, offsets, pitch, group, names = [], [0], [], [], []
+        for p in sorted(tree, key=lambda s: int(s)):
+            for g in sorted(tree[p], key=GROUPS.index):
+                for name in sorted(tree[p][g]):
+                    x = np.asarray(tree[p][g][name], dtype=np.float32).reshape(-1)
+                    chunks.append(x)
+                    offsets.append(offsets[-1] + x.size)
+                    pitch.append(int(p))
+                    group.append(GROUPS.index(g))
+                    names.append(name)
+        data = np.concatenate(chunks) if chunks else np.zeros(0, np.float32)
+        return OneShotBank(data=data, offsets=np.asarray(offsets, np.int64), pitch=np.asarray(pitch, np.int32),
+                           group=np.asarray(group, np.int32), names=names, sample_rate=sample_rate)
+
+    def save(self, path: str) -> None:
+        np.savez(path, data=self.data, offsets=self.offsets, pitch=self.pitch, group=self.group,
+                 names=np.array(self.names), sample_rate=np.int64(self.sample_rate))
+
+    @staticmethod
+    def load(path: str) -> "OneShotBank":
+        z = np.load(path, allow_pickle=False)
+        return OneShotBank(data=z["data"], offsets=z["offsets"], pitch=z["pitch"], group=z["group"],
+                           names=[str(n) for n in z["names"]], sample_rate=int(z["sample_rate"]))
+
+    def device_arrays(self, device) -> Tuple[torch.Tensor, torch.Tensor]:
+        """(data, offsets) on ``device``; uploaded once per device."""
+        key = str(device)
+        if key not in self._dev:
+            self._dev[key] = (torch.from_numpy(self.data).to(device), torch.from_numpy(self.offsets).to(device))
+        return self._dev[key]

@@ -21,9 +21,8 @@ constexpr int kWavesPerBlock = 8;
 constexpr int kThreads = 64 * kWavesPerBlock;
 constexpr int kMaxMelNnz = 2304;
 constexpr size_t kLdsMelw = 1024 * sizeof(cf);
-constexpr size_t kLdsWin = kLdsMelw + kMaxMelNnz * sizeof(float);
-constexpr size_t kLdsBufs = kLdsWin + kNfft * sizeof(float);
-constexpr size_t kLdsTotal = kLdsBufs + kWavesPerBlock * kBufElems * sizeof(cf);   // 158,720 B
+constexpr size_t kLdsBufs = kLdsMelw + kMaxMelNnz * sizeof(float);
+constexpr size_t kLdsTotal = kLdsBufs + kWavesPerBlock * kBufElems * sizeof(cf);   // 150,528 B
 static_assert(kLdsTotal <= 160 * 1024, "LDS budget");
 
 struct LogmelArgs {
@@ -35,11 +34,20 @@ struct LogmelArgs {
   long n_items; int n_iter;
 };
 
+// Every LDS exchange below is private to one wave (buf is the wave's own buffer), so a
+// workgroup barrier is not needed: the LDS unit executes one wave's DS instructions in issue
+// order, and this fence/wave_barrier pair keeps the compiler from moving them across the
+// phase boundary.  Waves of a workgroup therefore drift apart and overlap LDS with VALU phases.
+__device__ __forceinline__ void wave_sync() {
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
 __global__ __launch_bounds__(kThreads) void logmel_kernel(LogmelArgs a) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   cf* tw = reinterpret_cast<cf*>(smem);                                  // [1024]
   float* melw = reinterpret_cast<float*>(smem + kLdsMelw);               // [kMaxMelNnz]
-  float* win = reinterpret_cast<float*>(smem + kLdsWin);                 // [2048]
   cf* bufs = reinterpret_cast<cf*>(smem + kLdsBufs);
 
   const int tid = threadIdx.x;
@@ -55,7 +63,12 @@ __global__ __launch_bounds__(kThreads) void logmel_kernel(LogmelArgs a) {
   }
   for (int j = tid; j < a.mel_nnz; j += kThreads) melw[j] = a.mel_w[j];
 
-  for (int j = tid; j < kNfft; j += kThreads) win[j] = a.window[j];
+  // per-lane window values of the two pass-1 items (m = lane + 64*it, n1 = 0..15)
+  float win[2][16];
+#pragma unroll
+  for (int it = 0; it < 2; ++it)
+#pragma unroll
+    for (int n1 = 0; n1 < 16; ++n1) win[it][n1] = a.window[lane + 64 * it + 128 * n1];
 
   // per-lane constants: the mel bands of the 8 mel items, packed lo | cnt << 11 | off << 18
   const int g = lane >> 2, s = lane & 3;
@@ -91,31 +104,31 @@ __global__ __launch_bounds__(kThreads) void logmel_kernel(LogmelArgs a) {
 
     if (active) {
       if (interior) {
-        pass1<true>(lane, 0, clip, a.n_samples, base0, base1, has1, win, tw, buf);
+        pass1<true>(lane, 0, clip, a.n_samples, base0, base1, has1, win[0], tw, buf);
         __builtin_amdgcn_sched_barrier(0);
-        pass1<true>(lane, 1, clip, a.n_samples, base0, base1, has1, win, tw, buf);
+        pass1<true>(lane, 1, clip, a.n_samples, base0, base1, has1, win[1], tw, buf);
       } else {
-        pass1<false>(lane, 0, clip, a.n_samples, base0, base1, has1, win, tw, buf);
+        pass1<false>(lane, 0, clip, a.n_samples, base0, base1, has1, win[0], tw, buf);
         __builtin_amdgcn_sched_barrier(0);
-        pass1<false>(lane, 1, clip, a.n_samples, base0, base1, has1, win, tw, buf);
+        pass1<false>(lane, 1, clip, a.n_samples, base0, base1, has1, win[1], tw, buf);
       }
     }
-    __syncthreads();
+    wave_sync();
     if (active) { pass2(lane, 0, tw, buf); __builtin_amdgcn_sched_barrier(0); pass2(lane, 1, tw, buf); }
-    __syncthreads();
+    wave_sync();
     cf z[4][8];
     if (active) {
 #pragma unroll
       for (int it = 0; it < 4; ++it) pass3_load(lane, it, buf, z[it]);
     }
-    __syncthreads();
+    wave_sync();
     if (active) {
 #pragma unroll
       for (int it = 0; it < 4; ++it) pass3_store(lane, it, z[it], buf);
     }
-    __syncthreads();
+    wave_sync();
     if (active) untangle(lane, buf);
-    __syncthreads();
+    wave_sync();
     if (active) {
       float* stage = reinterpret_cast<float*>(buf + kStageBase);
 #pragma unroll
@@ -130,14 +143,14 @@ __global__ __launch_bounds__(kThreads) void logmel_kernel(LogmelArgs a) {
         }
       }
     }
-    __syncthreads();
+    wave_sync();
     if (active) {
       const float4* stage4 = reinterpret_cast<const float4*>(buf + kStageBase);
       const int quads = (has1 ? 2 : 1) * a.n_mels / 4;   // rows f0, f0+1 are contiguous in out
       float4* dst = reinterpret_cast<float4*>(a.out + (clip_i * a.n_out + f0) * a.n_mels);
       if (lane < quads) dst[lane] = stage4[lane];
     }
-    __syncthreads();
+    wave_sync();
   }
 }
 

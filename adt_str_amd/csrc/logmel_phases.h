@@ -105,7 +105,7 @@ ADT_HD int reflect_index(int s, int L) {
 // past L when kInterior is false).  win: the 2048-entry window table.
 template <bool kInterior>
 ADT_HD void pass1(int lane, int it, const float* clip, int L, int base0, int base1, bool has1,
-                  const float* win, const cf* tw, cf* buf) {
+                  const float* win16 /*window at m + 128*n1, n1 = 0..15*/, const cf* tw, cf* buf) {
   const int m = lane + 64 * it;          // 8*n2 + n3
   const int n2 = m >> 3;
   cf z[16];
@@ -114,14 +114,22 @@ ADT_HD void pass1(int lane, int it, const float* clip, int L, int base0, int bas
     const int o = m + 128 * n1;
     int s0 = base0 + o, s1 = base1 + o;
     if (!kInterior) { s0 = reflect_index(s0, L); s1 = reflect_index(s1, L); }
-    const float w = win[o];
+    const float w = win16[n1];
     z[n1].x = w * clip[s0];
     z[n1].y = has1 ? w * clip[s1] : 0.0f;
   }
   dft16(z);
+  // twiddle W_256^(n2*k1), k1 = 4q + r, as table[W^(n2*4q)] * table[W^(n2*r)]: 6 table reads, not 15
+  cf sr[4], bq[4];
+  _Pragma("unroll")
+  for (int r = 1; r < 4; ++r) { sr[r] = twiddle(tw, 8 * n2 * r); bq[r] = twiddle(tw, 32 * n2 * r); }
   _Pragma("unroll")
   for (int k1 = 0; k1 < 16; ++k1) {
-    cf v = (k1 == 0) ? z[k1] : cmul(z[k1], twiddle(tw, 8 * n2 * k1));
+    const int q = k1 >> 2, r = k1 & 3;
+    cf v = z[k1];
+    if (q != 0 && r != 0) v = cmul(v, cmul(bq[q], sr[r]));
+    else if (q != 0) v = cmul(v, bq[q]);
+    else if (r != 0) v = cmul(v, sr[r]);
     buf[n2 * kRowPitch + 8 * k1 + (m & 7)] = v;
   }
 }
@@ -134,10 +142,17 @@ ADT_HD void pass2(int lane, int it, const cf* tw, cf* buf) {
   _Pragma("unroll")
   for (int n2 = 0; n2 < 16; ++n2) z[n2] = buf[n2 * kRowPitch + c];
   dft16(z);
+  // twiddle W_2048^(n3*(k1 + 16*k2)), k2 = 4q + r, as table[W^(n3*(k1 + 64q))] * table[W^(16*n3*r)]
+  cf sr[4], bq[4];
+  _Pragma("unroll")
+  for (int r = 1; r < 4; ++r) sr[r] = twiddle(tw, 16 * n3 * r);
+  _Pragma("unroll")
+  for (int q = 0; q < 4; ++q) bq[q] = twiddle(tw, n3 * (k1 + 64 * q));
   _Pragma("unroll")
   for (int k2 = 0; k2 < 16; ++k2) {
-    cf v = cmul(z[k2], twiddle(tw, n3 * (k1 + 16 * k2)));
-    buf[k2 * kRowPitch + c] = v;
+    const int q = k2 >> 2, r = k2 & 3;
+    const cf t = (r == 0) ? bq[q] : cmul(bq[q], sr[r]);
+    buf[k2 * kRowPitch + c] = cmul(z[k2], t);
   }
 }
 

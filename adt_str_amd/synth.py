@@ -1,0 +1,231 @@
+"""On-GPU one-shot drum renderer: drop-in for the reference's ``SynthDrum``
+(``modules/synthetiser.py:159-292``) on top of ``adt_mix_render_f32``.
+
+``SynthDrum(config)(notes) -> wav[W]`` keeps the reference call; the batch entry
+point ``render_batch(list_of_notes)`` renders every clip of a training batch in
+one C-ABI call from the HBM-resident flat bank (``bank.OneShotBank``) instead of
+re-opening an HDF5 file per note (``synthetiser.py:273``).
+
+Random draws come from Python's ``random`` in exactly the order the reference
+consumes them (timbre picks once per pitch and clip ``:192-202,274-281``, then
+one ``uniform(0, mixup_range)`` per note ``:217``), so seeding ``random`` gives
+the reference's clip.  FX (``use_fx_prob``, pedalboard) is not implemented:
+a non-zero probability raises.
+"""
+from __future__ import annotations
+
+import math
+import os
+import random
+from dataclasses import dataclass
+from typing import List, Optional, Sequence
+
+import numpy as np
+import torch
+
+from . import _ffi
+from .bank import OneShotBank
+from .mapping import ADTOF_INVERSE_MAPPING, ADTOF_LABEL, ADTOF_MAPPING
+
+# per-instrument mix volume (synthetiser.py:104-113)
+VOLUME_PER_INSTRUMENT = {"BD": 1.0, "SD": 1.0, "TT": 1.0, "HH": 0.7, "CY + RD": 0.7, "Cowbell": 0.7, "Claves": 0.7,
+                         "Other": 1.0}
+_THR_GROUP = {1.0: "gold", 0.9: "100-90", 0.8: "90-80", 0.7: "80-70", 0.6: "70-60", 0.5: "60-50", 0.4: "50-40",
+              0.3: "40-30", 0.2: "30-20", 0.1: "20-10", 0.0: "10-0"}
+
+NOTE_DTYPE = np.dtype([("start", "<i4"), ("main_shot", "<i4"), ("sub_shot", "<i4"), ("track", "<i4"),
+                       ("one_minus_mixup", "<f4"), ("mixup", "<f4"), ("vol", "<f4"), ("track_gain", "<f4")])
+assert NOTE_DTYPE.itemsize == 32          # struct adt_note in include/adt_hip.h
+
+
+@dataclass
+class SynthDrumConfig:
+    """Same fields as the reference's ``SynthDrumConfig(SharedConfig)`` (synthetiser.py:14-27, config.py:8-13)."""
+    input_sec: float
+    time_res: float
+    win_length: int
+    sample_rate: int
+    oneshot_path: str
+    similarity_threshold: float
+    max_hat_std_velocity: float
+    max_hat_mean_velocity: float
+    max_cymbals_std_velocity: float
+    max_cymbals_mean_velocity: float
+    ADTOF_mapping: bool
+    mixup_range: float
+    use_fx_prob: float
+    use_reverb_prob: float
+    use_limiter_prob: float
+    use_compression_prob: float
+
+
+def _velocity_table() -> np.ndarray:
+    """``_vel_to_vol`` (synthetiser.py:204-212) for velocities 0..127, evaluated
+    with the reference's own scalar fp32 tensor arithmetic."""
+    tab = np.zeros(128, np.float32)
+    for v in range(1, 128):
+        nv = torch.clamp(torch.tensor(float(v)), 0, 127) / 127.0
+        tab[v] = float(0.1 + (1.0 - 0.1) * (6 ** nv - 1) / (6 - 1))
+    return tab
+
+
+_VEL_TABLE = _velocity_table()
+
+
+def vel_to_vol(velocity: float) -> np.float32:
+    if velocity == 0:
+        return np.float32(0.0)
+    if float(velocity).is_integer() and 0 < velocity <= 127:
+        return _VEL_TABLE[int(velocity)]
+    nv = torch.clamp(torch.tensor(float(velocity)), 0, 127) / 127.0
+    return np.float32(float(0.1 + (1.0 - 0.1) * (6 ** nv - 1) / (6 - 1)))
+
+
+@dataclass
+class MixPlan:
+    """Host-side description of one batch for ``adt_mix_render_f32``."""
+    notes: np.ndarray           # NOTE_DTYPE [n_notes], clip by clip, grouped by track
+    clip_note_off: np.ndarray   # int32 [B + 1]
+    clip_len: np.ndarray        # int32 [B]
+    clip_gain: np.ndarray       # float32 [B]
+    picks: list                 # per clip: {pitch: ((pitch, group, name), (pitch, group, name))}
+    mixups: list                # per clip: list of per-note mixup draws (input order)
+
+    @property
+    def width(self) -> int:
+        return int(self.clip_len.max()) if self.clip_len.size else 0
+
+
+class SynthDrum:
+    def __init__(self, config: SynthDrumConfig, bank: Optional[OneShotBank] = None, device: Optional[str] = None):
+        self.config = config
+        self.sample_rate = config.sample_rate
+        self.oneshot_path = f"{config.oneshot_path}@{self.sample_rate}.npz"
+        self.similarity_threshold = config.similarity_threshold
+        self.ADTOF_mapping = config.ADTOF_mapping
+        if config.use_fx_prob:
+            raise NotImplementedError("the FX chain (use_fx_prob > 0, pedalboard) is outside the MI355X hot path; set use_fx_prob: 0")
+        if bank is None:
+            if not os.path.exists(self.oneshot_path):
+                raise FileNotFoundError(f"one-shot bank {self.oneshot_path} not found (flat .npz; see adt_str_amd/bank.py)")
+            bank = OneShotBank.load(self.oneshot_path)
+        if bank.sample_rate != self.sample_rate:
+            raise ValueError(f"bank is {bank.sample_rate} Hz, config asks for {self.sample_rate} Hz")
+        self.bank = bank
+        self.device = torch.device(device) if device is not None else torch.device("cuda", torch.cuda.current_device()) \
+            if torch.cuda.is_available() else None
+        self._thr_groups = self.tolerance_thr_to_h5_group()
+
+    # ---- reference-named helpers -------------------------------------------------
+    def floor_to_tenth(self, x: float) -> float:
+        return math.floor(x * 10) / 10
+
+    def tolerance_thr_to_h5_group(self) -> List[str]:
+        """Groups from "gold" down to the one containing the threshold (synthetiser.py:171-190)."""
+        groups, level = [], 1.0
+        floor = self.floor_to_tenth(self.similarity_threshold)
+        while level >= floor:
+            groups.append(_THR_GROUP[round(level, 1)])
+            level -= 0.1
+        return groups
+
+    def random_choice_timbre(self, group: int):
+        """One timbre pick (synthetiser.py:192-202): optional ADTOF member pitch,
+        then a similarity group that exists for it, then a one-shot name."""
+        pitch = int(group)
+        if self.ADTOF_mapping:
+            pitch = int(random.choice(ADTOF_INVERSE_MAPPING[pitch]))
+        valid = [g for g in self._thr_groups if self.bank.has_cell(pitch, g)]
+        g = random.choice(valid)
+        name = random.choice(self.bank.cell_names(pitch, g))
+        return pitch, g, name
+
+    def _vel_to_vol(self, velocity):
+        return vel_to_vol(float(velocity))
+
+    # ---- planning (host) -----------------------------------------------------------
+    def _clip_length(self, notes32: np.ndarray) -> int:
+        """``int(max(max_offset + 0.1, input_sec) * sr)`` in the reference's mixed
+        fp32-tensor / Python-float arithmetic (synthetiser.py:262-263,243)."""
+        end32 = np.float32(notes32[:, 1].max()) + np.float32(0.1)
+        if np.float32(self.config.input_sec) > end32:
+            return int(self.config.input_sec * self.config.sample_rate)
+        return int(np.float32(end32 * np.float32(self.config.sample_rate)))
+
+    def plan(self, batch: Sequence[Sequence[Sequence[float]]]) -> MixPlan:
+        sr = self.config.sample_rate
+        recs, offs, lens, gains, picks_all, mix_all = [], [0], [], [], [], []
+        for notes in batch:
+            n = len(notes)
+            if n == 0:                                             # synthetiser.py:257-258
+                offs.append(offs[-1]); lens.append(int(self.config.input_sec * sr)); gains.append(0.0)
+                picks_all.append({}); mix_all.append([])
+                continue
+            a = np.asarray(notes, dtype=np.float32).reshape(n, 4)
+            tracks: dict = {}
+            picks: dict = {}
+            clip = np.zeros(n, NOTE_DTYPE)
+            mixups = []
+            max_vel = np.float32(0)
+            for i in range(n):
+                onset, offset, pitch, vel = a[i]
+                max_vel = max(max_vel, vel)
+                if not (35 <= pitch <= 61 and offset >= onset):
+                    raise ValueError(f"Invalid note: {a[i]}")
+                p = int(pitch)
+                if p not in picks:
+                    picks[p] = (self.random_choice_timbre(p), self.random_choice_timbre(p))
+                    tracks[p] = len(tracks)
+                m = random.uniform(0, self.config.mixup_range)     # drum_rendering's first statement (:217)
+                mixups.append(m)
+                (mp, mg, mn), (sp, sg, sn) = picks[p]
+                key = ADTOF_MAPPING[p] if not self.ADTOF_mapping else p
+                clip[i] = (int(np.float32(onset) * np.float32(sr)), self.bank.shot_id(mp, mg, mn),
+                           self.bank.shot_id(sp, sg, sn), tracks[p], np.float32(1 - m), np.float32(m),
+                           vel_to_vol(float(vel)), VOLUME_PER_INSTRUMENT[ADTOF_LABEL[key]])
+            clip = clip[np.argsort(clip["track"], kind="stable")]
+            recs.append(clip)
+            offs.append(offs[-1] + n)
+            lens.append(self._clip_length(a))
+            gains.append(float(vel_to_vol(float(max_vel))))
+            picks_all.append(picks)
+            mix_all.append(mixups)
+        notes_arr = np.concatenate(recs) if recs else np.zeros(0, NOTE_DTYPE)
+        return MixPlan(notes=notes_arr, clip_note_off=np.asarray(offs, np.int32), clip_len=np.asarray(lens, np.int32),
+                       clip_gain=np.asarray(gains, np.float32), picks=picks_all, mixups=mix_all)
+
+    # ---- rendering (GPU) -----------------------------------------------------------
+    def render_plan(self, plan: MixPlan, width: Optional[int] = None, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+        if self.device is None or self.device.type != "cuda":
+            raise RuntimeError("SynthDrum renders on the GPU only (there is no CPU path)")
+        dev = self.device
+        B = len(plan.clip_len)
+        width = plan.width if width is None else width
+        if out is None:
+            out = torch.empty((B, width), dtype=torch.float32, device=dev)
+        if B == 0 or width == 0:
+            return out
+        data, offsets = self.bank.device_arrays(dev)
+        n_notes = int(plan.notes.shape[0])
+        notes_d = torch.from_numpy(plan.notes.view(np.uint8).reshape(-1)).to(dev, non_blocking=True) if n_notes else \
+            torch.zeros(32, dtype=torch.uint8, device=dev)
+        off_d = torch.from_numpy(plan.clip_note_off).to(dev, non_blocking=True)
+        len_d = torch.from_numpy(plan.clip_len).to(dev, non_blocking=True)
+        gain_d = torch.from_numpy(plan.clip_gain).to(dev, non_blocking=True)
+        ws_bytes = _ffi.load().adt_mix_workspace_bytes(n_notes, B)
+        ws = torch.empty(ws_bytes, dtype=torch.uint8, device=dev)
+        _ffi.call("adt_mix_render_f32", _ffi.dptr(data), _ffi.dptr(offsets), self.bank.n_shots, _ffi.dptr(notes_d),
+                  n_notes, _ffi.dptr(off_d), _ffi.dptr(len_d), _ffi.dptr(gain_d), B, width, _ffi.dptr(out),
+                  out.stride(0), _ffi.dptr(ws), ws_bytes, _ffi.current_stream())
+        return out
+
+    def render_batch(self, batch: Sequence[Sequence[Sequence[float]]], width: Optional[int] = None):
+        """-> (wavs[B, width or max W] on the GPU, zero-padded like collate_fn; lengths[B])."""
+        plan = self.plan(batch)
+        return self.render_plan(plan, width), torch.from_numpy(plan.clip_len.astype(np.int64))
+
+    def __call__(self, notes, eval_rendering: bool = False) -> torch.Tensor:
+        if eval_rendering:
+            raise NotImplementedError("eval_rendering relies on default_timbre_path, which the reference never defines")
+        wavs, lens = self.render_batch([list(notes)])
+        return wavs[0, : int(lens[0])]

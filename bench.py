@@ -60,7 +60,7 @@ def logmel_setup(dev, seed):
 
 def logmel_cpu_baseline(wave, budget_s=12.0):
     from oracle import logmel as o_logmel
-    torch.set_num_threads(os.cpu_count() or 1)
+    torch.set_num_threads(min(os.cpu_count() or 1, 16))   # 16 = the reference's DataLoader worker count (setting-1.yaml:11)
     n = 64
     o_logmel.logmel(wave[:8], 16000, 2048, 0.01, 128)
     done, t0 = 0, time.perf_counter()

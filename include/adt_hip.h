@@ -65,6 +65,49 @@ int adt_logmel_f32(const float* wave, int64_t n_clips, int64_t n_samples, int64_
                    float log_eps, float clamp_lo, float clamp_hi,
                    float* out, void* stream);
 
+/* ---------------------------------------------------------------------------
+ * K2  batched one-shot drum mixer
+ *
+ * Replaces the per-note Python loop of SynthDrum.__call__ (reference
+ * modules/synthetiser.py:255-292), drum_rendering (:214-239) and
+ * VolumeMixer.instrument_mixer / _normalize_audio (:142-156) for a whole batch
+ * of clips.  All random draws (timbre choice :192-202, mixup :217) and the
+ * velocity->volume law (:204-212) are evaluated by the host and arrive as
+ * explicit per-note fields, so the call is a pure function of its inputs.
+ *
+ *   bank, bank_off   flat one-shot bank: shot i = bank[bank_off[i] .. bank_off[i+1])
+ *   notes            n_notes records, clip by clip (clip c owns
+ *                    notes[clip_note_off[c] .. clip_note_off[c+1])); inside a clip
+ *                    they are grouped by track in track order (track = order of
+ *                    first appearance of the pitch, synthetiser.py:146-147) and
+ *                    keep note order inside a track
+ *   clip_len[c]      rendered length W_c of clip c (synthetiser.py:262-263,243);
+ *                    samples >= W_c are written as 0 (collate padding)
+ *   clip_gain[c]     volume of the clip's maximum velocity (synthetiser.py:266,292)
+ *   out              [n_clips, ld_out] fp32, columns [0, width) fully overwritten:
+ *                    wav = sum_tracks gain_t * sum_{notes of t} vol * o / max|o|,
+ *                    o = main*(1-mixup) + mixup*sub (zero-padded to equal length),
+ *                    out = wav / max|wav| * clip_gain; a clip without notes is all 0
+ *   ws               scratch of adt_mix_workspace_bytes(n_notes, n_clips) bytes
+ */
+typedef struct adt_note {
+  int32_t start;            /* first output sample: int(onset * sample_rate)   */
+  int32_t main_shot;        /* index into bank_off                              */
+  int32_t sub_shot;
+  int32_t track;            /* 0-based track id inside the clip                 */
+  float   one_minus_mixup;  /* fp32(1 - mixup)                                  */
+  float   mixup;            /* fp32(mixup)                                      */
+  float   vol;              /* velocity -> volume                               */
+  float   track_gain;       /* per-class volume of the note's track             */
+} adt_note;
+
+size_t adt_mix_workspace_bytes(int64_t n_notes, int64_t n_clips);
+
+int adt_mix_render_f32(const float* bank, const int64_t* bank_off, int64_t n_shots,
+                       const adt_note* notes, int64_t n_notes, const int32_t* clip_note_off,
+                       const int32_t* clip_len, const float* clip_gain, int64_t n_clips, int64_t width,
+                       float* out, int64_t ld_out, void* ws, size_t ws_bytes, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

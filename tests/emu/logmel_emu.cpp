@@ -29,8 +29,10 @@ extern "C" int emu_logmel(const float* wave, long n_clips, int n_samples, long l
       const bool interior = base0 >= 0 && base1 + kNfft <= n_samples;
       for (int it = 0; it < 2; ++it)
         for (int lane = 0; lane < 64; ++lane) {
-          if (interior) pass1<true>(lane, it, clip, n_samples, base0, base1, has1, window, tw.data(), buf.data());
-          else pass1<false>(lane, it, clip, n_samples, base0, base1, has1, window, tw.data(), buf.data());
+          float win16[16];
+          for (int n1 = 0; n1 < 16; ++n1) win16[n1] = window[lane + 64 * it + 128 * n1];
+          if (interior) pass1<true>(lane, it, clip, n_samples, base0, base1, has1, win16, tw.data(), buf.data());
+          else pass1<false>(lane, it, clip, n_samples, base0, base1, has1, win16, tw.data(), buf.data());
         }
       // pass 2 is in place per lane (each lane reads and writes the same 16 slots)
       for (int it = 0; it < 2; ++it)
