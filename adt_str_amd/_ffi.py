@@ -18,15 +18,41 @@ ABI_VERSION = 1
 
 i32, i64, f32, ptr = C.c_int32, C.c_int64, C.c_float, C.c_void_p
 
+class GemmEpilogue(C.Structure):
+    """struct adt_gemm_epilogue (include/adt_hip.h)."""
+    _fields_ = [("bias", C.c_void_p), ("gelu_grad_of", C.c_void_p), ("ld_gelu_grad", C.c_int64),
+                ("pre_act_out", C.c_void_p), ("ld_pre_act", C.c_int64), ("residual", C.c_void_p),
+                ("ld_res", C.c_int64), ("res_row_mod", C.c_int32), ("act", C.c_int32), ("alpha", C.c_float),
+                ("out_fp32", C.c_int32)]
+
+
 # name -> argtypes; every entry must be declared in include/adt_hip.h (tests check both ways)
 SIGNATURES = {
     "adt_version": [],
     "adt_last_error": [],
     "adt_logmel_f32": [ptr, i64, i64, i64, i32, i32, i32, i32, ptr, ptr, ptr, i32, i32, f32, f32, f32, ptr, ptr],
     "adt_mix_workspace_bytes": [i64, i64],
+    "adt_gemm_workspace_bytes": [i32, i64, i64, i64],
+    "adt_gemm_bf16": [i32, i64, i64, i64, ptr, i64, ptr, i64, ptr, i64, ptr, ptr, C.c_size_t, ptr],
+    "adt_layernorm_fwd": [ptr, i64, ptr, ptr, f32, ptr, ptr, i64, ptr, ptr, i64, i64, ptr],
+    "adt_layernorm_bwd_workspace_bytes": [i64, i64],
+    "adt_layernorm_bwd": [ptr, i64, ptr, i64, ptr, ptr, ptr, ptr, ptr, i64, ptr, ptr, ptr, i64, i64, ptr, C.c_size_t, ptr],
+    "adt_colsum_workspace_bytes": [i64, i64],
+    "adt_colsum_bf16": [ptr, i64, i64, i64, ptr, ptr, C.c_size_t, ptr],
+    "adt_embed_pe_fwd": [ptr, ptr, ptr, f32, ptr, ptr, i64, i64, i64, i64, ptr],
+    "adt_embed_bwd": [ptr, ptr, f32, ptr, i64, i64, i64, ptr],
+    "adt_cross_entropy_workspace_bytes": [i64],
+    "adt_cross_entropy": [ptr, i64, ptr, i64, i64, i64, ptr, ptr, i64, ptr, C.c_size_t, ptr],
+    "adt_cast_bf16": [ptr, ptr, ptr, i64, i64, ptr],
+    "adt_grad_norm_workspace_bytes": [],
+    "adt_grad_norm": [ptr, i64, f32, ptr, ptr, C.c_size_t, ptr],
+    "adt_adamw_step": [ptr, ptr, ptr, ptr, ptr, i64, f32, f32, f32, f32, f32, i64, ptr, ptr],
     "adt_mix_render_f32": [ptr, ptr, i64, ptr, i64, ptr, ptr, ptr, i64, i64, ptr, i64, ptr, C.c_size_t, ptr],
 }
-_RESTYPES = {"adt_last_error": C.c_char_p, "adt_mix_workspace_bytes": C.c_size_t}
+_RESTYPES = {"adt_last_error": C.c_char_p}
+_RESTYPES.update({n: C.c_size_t for n in ("adt_mix_workspace_bytes", "adt_gemm_workspace_bytes",
+                                          "adt_layernorm_bwd_workspace_bytes", "adt_colsum_workspace_bytes",
+                                          "adt_cross_entropy_workspace_bytes", "adt_grad_norm_workspace_bytes")})
 
 
 class AdtError(RuntimeError):

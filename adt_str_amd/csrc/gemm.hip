@@ -1,0 +1,298 @@
+// gemm.hip -- K3/K5: bf16 MFMA GEMM with fused epilogues (gfx950).
+//
+// Stands behind every nn.Linear of the ADT network (reference model.py:111,157,224 and the
+// in_proj/out_proj/linear1/linear2 of nn.TransformerEncoderLayer / nn.TransformerDecoderLayer
+// built at model.py:118-127,159-168) and their backward passes.
+//
+//   trans = 0 (NT):  C[M,N] = A[M,K] . B[N,K]^T     forward  y = x W^T ; dgrad  dx = dy (W^T)^T
+//   trans = 1 (TN):  C[M,N] = A[K,M]^T . B[K,N]     wgrad    dW = dy^T x   (K = rows of dy and x)
+//
+// Tile 128x128x64, 256 threads = 4 waves in a 2x2 grid, each wave 64x64 = 4x4 MFMA
+// v_mfma_f32_16x16x32_bf16 blocks (64 fp32 accumulators).  Operands are staged
+// global -> registers -> LDS (16-byte loads, padded rows so fragment reads are bank-conflict
+// free), double-buffered with one barrier per K-tile; the next tile's global loads are issued
+// before the current tile's MFMAs.
+//   NT fragments: ds_read_b128 of 8 consecutive k of one row (row pitch 144 B).
+//   TN fragments: two ds_read_b64_tr_b16 per operand from a [k][m] image (row pitch 288 B);
+//                 element j of lane group g holds k = 4g + (j&3) + 16*(j>>2) for both operands,
+//                 which makes the two lane groups of a half-wave read 8 distinct 32-byte rows.
+// TN with split-K writes fp32 partial slabs that reduce_slabs_kernel sums in a fixed order
+// (bitwise reproducible, no float atomics).
+#include <hip/hip_runtime.h>
+
+#include "adt_common.h"
+
+namespace adt {
+
+typedef __attribute__((ext_vector_type(8))) short bf16x8;
+typedef __attribute__((ext_vector_type(4))) short bf16x4;
+typedef __attribute__((ext_vector_type(4))) float f32x4;
+
+constexpr int kBM = 128, kBN = 128, kBK = 64;
+constexpr int kGemmThreads = 256;
+constexpr int kPitchNT = 144;                  // bytes per LDS row: 64 bf16 + 16 B pad
+constexpr int kPitchTN = 288;                  // bytes per LDS row: 128 bf16 + 32 B pad
+constexpr int kTileBytes = 128 * kPitchNT;     // 18,432 B (== 64 * kPitchTN)
+static_assert(kTileBytes == 64 * kPitchTN, "tile images have one size");
+constexpr int kStageBytes = 2 * kTileBytes;    // A + B
+constexpr int kGemmLds = 2 * kStageBytes;      // double buffered: 73,728 B
+
+__device__ __forceinline__ float bf2f(unsigned short v) { return __uint_as_float(static_cast<unsigned>(v) << 16); }
+__device__ __forceinline__ unsigned short f2bf(float f) {      // round-to-nearest-even, NaN stays NaN (v_cvt_pk_bf16_f32)
+  return __builtin_bit_cast(unsigned short, static_cast<__bf16>(f));
+}
+__device__ __forceinline__ unsigned lds_addr(const void* p) {  // byte offset inside the workgroup's LDS
+  return static_cast<unsigned>(reinterpret_cast<size_t>((__attribute__((address_space(3))) const void*)p));
+}
+__device__ __forceinline__ float gelu_erf(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752f)); }
+__device__ __forceinline__ float gelu_erf_grad(float x) {
+  return 0.5f * (1.0f + erff(x * 0.70710678118654752f)) + x * 0.3989422804014327f * __expf(-0.5f * x * x);
+}
+
+struct GemmArgs {
+  const unsigned short* A; long lda;
+  const unsigned short* B; long ldb;
+  void* C; long ldc;
+  int M, N, K;
+  int k_tiles_per_split;
+  float* slabs;                 // TN split-K partials [splits][M][N] (null when splits == 1)
+  adt_gemm_epilogue ep;
+};
+
+// ---- global -> register staging (4 x 16 B per thread per operand) -----------------------------
+// NT: the tile is 128 rows (m or n) x 64 k.  chunk c = tid + 256*i: row = c >> 3, 16-byte piece = c & 7.
+// TN: the tile is 64 rows (k) x 128 cols (m or n).  chunk: row = c >> 4, piece = c & 15.
+template <bool kTrans>
+__device__ __forceinline__ void stage_load(const unsigned short* __restrict__ src, long ld, int row0, int col0,
+                                           int n_rows, int n_cols, int tid, uint4 (&r)[4]) {
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int c = tid + kGemmThreads * i;
+    const int row = kTrans ? (c >> 4) : (c >> 3);
+    const int col = (kTrans ? (c & 15) : (c & 7)) * 8;
+    const int gr = row0 + row, gc = col0 + col;
+    uint4 v = make_uint4(0, 0, 0, 0);
+    if (gr < n_rows && gc < n_cols) v = *reinterpret_cast<const uint4*>(src + static_cast<long>(gr) * ld + gc);
+    r[i] = v;
+  }
+}
+template <bool kTrans>
+__device__ __forceinline__ void stage_store(unsigned char* lds, int tid, const uint4 (&r)[4]) {
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int c = tid + kGemmThreads * i;
+    const int row = kTrans ? (c >> 4) : (c >> 3);
+    const int piece = kTrans ? (c & 15) : (c & 7);
+    *reinterpret_cast<uint4*>(lds + row * (kTrans ? kPitchTN : kPitchNT) + piece * 16) = r[i];
+  }
+}
+
+// ---- LDS -> MFMA fragments ---------------------------------------------------------------------
+// NT: 16 rows x 32 k; lane l takes row (l & 15), k = 8*(l >> 4) .. +7.
+__device__ __forceinline__ bf16x8 frag_nt(const unsigned char* tile, int row0, int k0, int lane) {
+  return *reinterpret_cast<const bf16x8*>(tile + (row0 + (lane & 15)) * kPitchNT + (k0 + 8 * (lane >> 4)) * 2);
+}
+// TN: image is [k][col]; two transposed 8-byte reads give this lane column (col0 + (l & 15)) of
+// rows k0 + 4g + {0..3} and k0 + 16 + 4g + {0..3}, g = l >> 4.
+__device__ __forceinline__ bf16x8 frag_tn(const unsigned char* tile, int col0, int k0, int lane) {
+  const int t = lane & 15, g = lane >> 4;
+  const unsigned a0 = lds_addr(tile) + (k0 + 4 * g + (t >> 2)) * kPitchTN + (col0 + 4 * (t & 3)) * 2;
+  bf16x4 lo, hi;
+  asm volatile("ds_read_b64_tr_b16 %0, %2\n\tds_read_b64_tr_b16 %1, %2 offset:%3\n\ts_waitcnt lgkmcnt(0)"
+               : "=&v"(lo), "=&v"(hi) : "v"(a0), "i"(16 * kPitchTN) : "memory");
+  bf16x8 r;
+  r[0] = lo[0]; r[1] = lo[1]; r[2] = lo[2]; r[3] = lo[3];
+  r[4] = hi[0]; r[5] = hi[1]; r[6] = hi[2]; r[7] = hi[3];
+  return r;
+}
+
+template <bool kTrans>
+__global__ __launch_bounds__(kGemmThreads) void gemm_bf16_kernel(GemmArgs g) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave >> 1, wn = wave & 1;
+  const int m0 = blockIdx.y * kBM, n0 = blockIdx.x * kBN;
+  const int split = blockIdx.z;
+  const int kt0 = split * g.k_tiles_per_split;
+  int kt1 = kt0 + g.k_tiles_per_split;
+  const int k_tiles = (g.K + kBK - 1) / kBK;
+  if (kt1 > k_tiles) kt1 = k_tiles;
+
+  f32x4 acc[4][4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  uint4 ra[4], rb[4];
+  auto load_tile = [&](int kt) {
+    if (kTrans) {
+      stage_load<true>(g.A, g.lda, kt * kBK, m0, g.K, g.M, tid, ra);
+      stage_load<true>(g.B, g.ldb, kt * kBK, n0, g.K, g.N, tid, rb);
+    } else {
+      stage_load<false>(g.A, g.lda, m0, kt * kBK, g.M, g.K, tid, ra);
+      stage_load<false>(g.B, g.ldb, n0, kt * kBK, g.N, g.K, tid, rb);
+    }
+  };
+
+  if (kt0 < kt1) {
+    load_tile(kt0);
+    stage_store<kTrans>(smem, tid, ra);
+    stage_store<kTrans>(smem + kTileBytes, tid, rb);
+  }
+  __syncthreads();
+
+  for (int kt = kt0; kt < kt1; ++kt) {
+    const int cur = (kt - kt0) & 1;
+    const unsigned char* ta = smem + cur * kStageBytes;
+    const unsigned char* tb = ta + kTileBytes;
+    const bool more = kt + 1 < kt1;
+    if (more) load_tile(kt + 1);                       // in flight during the MFMAs below
+#pragma unroll
+    for (int ks = 0; ks < kBK / 32; ++ks) {
+      bf16x8 fa[4], fb[4];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        fa[i] = kTrans ? frag_tn(ta, wm * 64 + i * 16, ks * 32, lane) : frag_nt(ta, wm * 64 + i * 16, ks * 32, lane);
+        fb[i] = kTrans ? frag_tn(tb, wn * 64 + i * 16, ks * 32, lane) : frag_nt(tb, wn * 64 + i * 16, ks * 32, lane);
+      }
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+          acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[i], fb[j], acc[i][j], 0, 0, 0);
+    }
+    if (more) {
+      unsigned char* nxt = smem + (cur ^ 1) * kStageBytes;
+      stage_store<kTrans>(nxt, tid, ra);
+      stage_store<kTrans>(nxt + kTileBytes, tid, rb);
+    }
+    __syncthreads();
+  }
+
+  // ---- epilogue: C element (row, col) = acc[i][j][r] with row = .. + 4*(lane>>4) + r, col = .. + (lane&15)
+  const adt_gemm_epilogue& ep = g.ep;
+  const bool to_slab = g.slabs != nullptr;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int col = n0 + wn * 64 + j * 16 + (lane & 15);
+      if (col >= g.N) continue;
+      const float bias = (!to_slab && ep.bias) ? ep.bias[col] : 0.0f;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int row = m0 + wm * 64 + i * 16 + 4 * (lane >> 4) + r;
+        if (row >= g.M) continue;
+        float z = acc[i][j][r];
+        if (to_slab) {
+          g.slabs[(static_cast<long>(split) * g.M + row) * g.N + col] = z;
+          continue;
+        }
+        z = z * ep.alpha + bias;
+        if (ep.gelu_grad_of) {
+          const unsigned short u = reinterpret_cast<const unsigned short*>(ep.gelu_grad_of)[static_cast<long>(row) * ep.ld_gelu_grad + col];
+          z *= gelu_erf_grad(bf2f(u));
+        }
+        if (ep.pre_act_out)
+          reinterpret_cast<unsigned short*>(ep.pre_act_out)[static_cast<long>(row) * ep.ld_pre_act + col] = f2bf(z);
+        if (ep.act == 1) z = gelu_erf(ep.pre_act_out ? bf2f(f2bf(z)) : z);
+        if (ep.residual) {
+          const long rr = ep.res_row_mod > 0 ? (row % ep.res_row_mod) : row;
+          z += reinterpret_cast<const float*>(ep.residual)[rr * ep.ld_res + col];
+        }
+        if (ep.out_fp32) reinterpret_cast<float*>(g.C)[static_cast<long>(row) * g.ldc + col] = z;
+        else reinterpret_cast<unsigned short*>(g.C)[static_cast<long>(row) * g.ldc + col] = f2bf(z);
+      }
+    }
+  }
+}
+
+// sums split-K slabs in slab order: out[m,n] = alpha * sum_s slab[s][m,n]   (fp32 out)
+__global__ __launch_bounds__(256) void reduce_slabs_kernel(const float* __restrict__ slabs, int splits, long mn, int N,
+                                                           float alpha, float* __restrict__ out, long ldc) {
+  const long i4 = (static_cast<long>(blockIdx.x) * 256 + threadIdx.x) * 4;
+  if (i4 >= mn) return;
+  float4 s = *reinterpret_cast<const float4*>(slabs + i4);
+  for (int k = 1; k < splits; ++k) {
+    const float4 v = *reinterpret_cast<const float4*>(slabs + k * mn + i4);
+    s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
+  }
+  const long row = i4 / N; const int col = static_cast<int>(i4 - row * N);   // N % 4 == 0: a float4 never straddles rows
+  float* o = out + row * ldc + col;
+  o[0] = s.x * alpha; o[1] = s.y * alpha; o[2] = s.z * alpha; o[3] = s.w * alpha;
+}
+
+static int pick_splits(int M, int N, int K, int n_cu) {
+  const int tiles = ((M + kBM - 1) / kBM) * ((N + kBN - 1) / kBN);
+  const int k_tiles = (K + kBK - 1) / kBK;
+  int s = 1;
+  while (tiles * s < 2 * n_cu && s * 2 <= k_tiles / 4 && s < 64) s *= 2;
+  return s;
+}
+
+}  // namespace adt
+
+extern "C" size_t adt_gemm_workspace_bytes(int32_t trans, int64_t M, int64_t N, int64_t K) {
+  if (!trans || M <= 0 || N <= 0 || K <= 0) return 0;
+  int n_cu = 256;
+  (void)adt::device_cu_count(&n_cu);
+  const int s = adt::pick_splits(static_cast<int>(M), static_cast<int>(N), static_cast<int>(K), n_cu);
+  return s > 1 ? static_cast<size_t>(s) * M * N * 4 : 0;
+}
+
+extern "C" int adt_gemm_bf16(int32_t trans, int64_t M, int64_t N, int64_t K, const void* A, int64_t lda,
+                             const void* B, int64_t ldb, void* C, int64_t ldc, const adt_gemm_epilogue* ep,
+                             void* ws, size_t ws_bytes, void* stream) {
+  using namespace adt;
+  if (!A || !B || !C) return set_error(ADT_EINVAL, "adt_gemm_bf16: null pointer");
+  if (M < 0 || N < 0 || K < 0) return set_error(ADT_EINVAL, "adt_gemm_bf16: negative size");
+  if (M >= (1ll << 31) || N >= (1ll << 31) || K >= (1ll << 31)) return set_error(ADT_ESHAPE, "adt_gemm_bf16: dimension >= 2^31");
+  const int64_t a_cols = trans ? M : K, b_cols = trans ? N : K;
+  if (lda < a_cols || ldb < b_cols || ldc < N) return set_error(ADT_EINVAL, "adt_gemm_bf16: leading dimension too small");
+  if ((a_cols & 7) || (b_cols & 7) || (lda & 7) || (ldb & 7) || !aligned16(A) || !aligned16(B))
+    return set_error(ADT_ESHAPE, "adt_gemm_bf16: operand rows must be 16-byte aligned multiples of 8 elements");
+  if (M == 0 || N == 0) return ADT_OK;
+  GemmArgs g;
+  g.A = static_cast<const unsigned short*>(A); g.lda = lda;
+  g.B = static_cast<const unsigned short*>(B); g.ldb = ldb;
+  g.C = C; g.ldc = ldc; g.M = static_cast<int>(M); g.N = static_cast<int>(N); g.K = static_cast<int>(K);
+  adt_gemm_epilogue e;
+  if (ep) e = *ep; else { e = adt_gemm_epilogue{}; e.alpha = 1.0f; }
+  g.ep = e;
+  const int k_tiles = static_cast<int>((K + kBK - 1) / kBK);
+  int splits = 1;
+  if (trans) {
+    int n_cu = 0;
+    if (int rc = device_cu_count(&n_cu)) return rc;
+    splits = pick_splits(g.M, g.N, g.K, n_cu);
+    if (splits > 1) {
+      if (!e.out_fp32 || e.bias || e.residual || e.act || e.pre_act_out || e.gelu_grad_of || (N & 3))
+        splits = 1;                                  // split-K only for the plain fp32 weight-gradient form
+      else if (!ws || ws_bytes < static_cast<size_t>(splits) * M * N * 4)
+        return set_error(ADT_EINVAL, "adt_gemm_bf16: workspace too small (see adt_gemm_workspace_bytes)");
+    }
+  }
+  g.k_tiles_per_split = (k_tiles + splits - 1) / splits;
+  g.slabs = splits > 1 ? static_cast<float*>(ws) : nullptr;
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  const dim3 grid(static_cast<unsigned>((N + kBN - 1) / kBN), static_cast<unsigned>((M + kBM - 1) / kBM), splits);
+  static thread_local int attr_dev = -1;
+  int dev = 0;
+  ADT_HIP_TRY(hipGetDevice(&dev));
+  if (attr_dev != dev) {
+    ADT_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_bf16_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, kGemmLds));
+    ADT_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_bf16_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, kGemmLds));
+    attr_dev = dev;
+  }
+  if (trans) hipLaunchKernelGGL(gemm_bf16_kernel<true>, grid, dim3(kGemmThreads), kGemmLds, st, g);
+  else hipLaunchKernelGGL(gemm_bf16_kernel<false>, grid, dim3(kGemmThreads), kGemmLds, st, g);
+  if (splits > 1) {
+    const long mn = static_cast<long>(M) * N;
+    hipLaunchKernelGGL(reduce_slabs_kernel, dim3(static_cast<unsigned>((mn / 4 + 255) / 256)), dim3(256), 0, st,
+                       g.slabs, splits, mn, g.N, e.alpha, static_cast<float*>(C), ldc);
+  }
+  ADT_HIP_TRY(hipGetLastError());
+  return ADT_OK;
+}

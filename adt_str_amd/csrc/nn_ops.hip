@@ -1,0 +1,518 @@
+// nn_ops.hip -- K6/K7/K8 and the optimizer: the HBM-bound row kernels of the ADT network (gfx950).
+//
+//   layernorm fwd/bwd   nn.LayerNorm(768) of the post-norm layers and Encoder.layer_norm
+//                       (reference model.py:113-115,118-127,159-168; eps 1e-5, fp32 statistics)
+//   embed + PE fwd/bwd  TokenEmbedding_plain * sqrt(d) + PositionalEncoding (model.py:42-65,171)
+//   cross-entropy       ADTModel._loss_fn (model.py:228-238): fp32, nan_to_num, ignore_index=1, mean
+//   colsum              bias gradients (sum over rows of a bf16 [M,N] gradient)
+//   cast / transpose    fp32 master weights -> bf16 W and W^T operands for the GEMMs
+//   sumsq + AdamW       torch.optim.AdamW step with global-norm clipping (train.py:219-249:
+//                       adamw_torch, weight_decay 1e-5, max_grad_norm 1.0) on flat fp32 buffers;
+//                       the clip factor stays on the device (no host sync)
+//
+// All are one-pass streaming kernels: 16-byte accesses, one wave per row for the row-wise ones,
+// two-stage (partials + fixed-order reduce) column/scalar reductions so results are reproducible.
+#include <hip/hip_runtime.h>
+
+#include "adt_common.h"
+
+namespace adt {
+
+__device__ __forceinline__ float bf2f_(unsigned short v) { return __uint_as_float(static_cast<unsigned>(v) << 16); }
+__device__ __forceinline__ unsigned short f2bf_(float f) { return __builtin_bit_cast(unsigned short, static_cast<__bf16>(f)); }
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+  return v;
+}
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o));
+  return v;
+}
+
+constexpr int kRowThreads = 256;            // 4 waves = 4 rows per block
+constexpr int kMaxD = 1024;                 // row width limit of the one-wave-per-row kernels (4 float4 per lane)
+
+// ------------------------------------------------------------------------------------ LayerNorm
+// y = (x - mean) * rstd * gamma + beta ; stats in fp32, biased variance (torch semantics).
+struct LnFwdArgs { const float* x; long ldx; const float* gamma; const float* beta; float eps;
+                   float* y32; unsigned short* y16; long ldy; float* mean; float* rstd; int M; int D; };
+
+__global__ __launch_bounds__(kRowThreads) void layernorm_fwd_kernel(LnFwdArgs a) {
+  const int lane = threadIdx.x & 63;
+  const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= a.M) return;
+  const float* x = a.x + static_cast<long>(row) * a.ldx;
+  float4 v[4];
+  const int nq = a.D >> 2;                  // float4 per row
+  float s = 0.f;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int q = lane + 64 * i;
+    v[i] = q < nq ? reinterpret_cast<const float4*>(x)[q] : make_float4(0, 0, 0, 0);
+    s += (v[i].x + v[i].y) + (v[i].z + v[i].w);
+  }
+  const float mean = wave_sum(s) / a.D;
+  float ss = 0.f;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    if (lane + 64 * i < nq) {
+      const float d0 = v[i].x - mean, d1 = v[i].y - mean, d2 = v[i].z - mean, d3 = v[i].w - mean;
+      ss += (d0 * d0 + d1 * d1) + (d2 * d2 + d3 * d3);
+    }
+  }
+  const float rstd = rsqrtf(wave_sum(ss) / a.D + a.eps);
+  if (lane == 0) { if (a.mean) a.mean[row] = mean; if (a.rstd) a.rstd[row] = rstd; }
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int q = lane + 64 * i;
+    if (q >= nq) continue;
+    const float4 g = reinterpret_cast<const float4*>(a.gamma)[q], b = reinterpret_cast<const float4*>(a.beta)[q];
+    float4 y;
+    y.x = (v[i].x - mean) * rstd * g.x + b.x; y.y = (v[i].y - mean) * rstd * g.y + b.y;
+    y.z = (v[i].z - mean) * rstd * g.z + b.z; y.w = (v[i].w - mean) * rstd * g.w + b.w;
+    if (a.y32) reinterpret_cast<float4*>(a.y32 + static_cast<long>(row) * a.ldy)[q] = y;
+    if (a.y16) {
+      ushort4 h = make_ushort4(f2bf_(y.x), f2bf_(y.y), f2bf_(y.z), f2bf_(y.w));
+      reinterpret_cast<ushort4*>(a.y16 + static_cast<long>(row) * a.ldy)[q] = h;
+    }
+  }
+}
+
+// dx = rstd * (g - mean(g) - xhat * mean(g * xhat)),  g = dy * gamma,  xhat = (x - mean) * rstd
+// Per block (kLnBwdRows rows) partial column sums: dgamma += dy * xhat, dbeta += dy, dxsum += dx
+// (dxsum = bias gradient of the linear layer that feeds this norm's input).
+constexpr int kLnBwdRows = 32;              // rows per block (8 per wave)
+struct LnBwdArgs { const float* dy; long lddy; const float* x; long ldx; const float* gamma; const float* mean;
+                   const float* rstd; float* dx32; unsigned short* dx16; long lddx; float* partial; int M; int D; };
+
+__global__ __launch_bounds__(kRowThreads) void layernorm_bwd_kernel(LnBwdArgs a) {
+  __shared__ float red[3][4][kMaxD];        // [dgamma|dbeta|dxsum][wave][col]  = 48 KiB
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int nq = a.D >> 2;
+  float4 pg[4], pb[4], px[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) pg[i] = pb[i] = px[i] = make_float4(0, 0, 0, 0);
+  for (int rr = 0; rr < kLnBwdRows / 4; ++rr) {
+    const int row = blockIdx.x * kLnBwdRows + wave * (kLnBwdRows / 4) + rr;
+    if (row >= a.M) break;
+    const float mean = a.mean[row], rstd = a.rstd[row];
+    const float4* xr = reinterpret_cast<const float4*>(a.x + static_cast<long>(row) * a.ldx);
+    const float4* dyr = reinterpret_cast<const float4*>(a.dy + static_cast<long>(row) * a.lddy);
+    float4 xh[4], g[4];
+    float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int q = lane + 64 * i;
+      xh[i] = g[i] = make_float4(0, 0, 0, 0);
+      if (q >= nq) continue;
+      const float4 xv = xr[q], dv = dyr[q], gm = reinterpret_cast<const float4*>(a.gamma)[q];
+      xh[i] = make_float4((xv.x - mean) * rstd, (xv.y - mean) * rstd, (xv.z - mean) * rstd, (xv.w - mean) * rstd);
+      g[i] = make_float4(dv.x * gm.x, dv.y * gm.y, dv.z * gm.z, dv.w * gm.w);
+      s1 += (g[i].x + g[i].y) + (g[i].z + g[i].w);
+      s2 += (g[i].x * xh[i].x + g[i].y * xh[i].y) + (g[i].z * xh[i].z + g[i].w * xh[i].w);
+      pg[i].x += dv.x * xh[i].x; pg[i].y += dv.y * xh[i].y; pg[i].z += dv.z * xh[i].z; pg[i].w += dv.w * xh[i].w;
+      pb[i].x += dv.x; pb[i].y += dv.y; pb[i].z += dv.z; pb[i].w += dv.w;
+    }
+    const float m1 = wave_sum(s1) / a.D, m2 = wave_sum(s2) / a.D;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int q = lane + 64 * i;
+      if (q >= nq) continue;
+      float4 d;
+      d.x = rstd * (g[i].x - m1 - xh[i].x * m2); d.y = rstd * (g[i].y - m1 - xh[i].y * m2);
+      d.z = rstd * (g[i].z - m1 - xh[i].z * m2); d.w = rstd * (g[i].w - m1 - xh[i].w * m2);
+      px[i].x += d.x; px[i].y += d.y; px[i].z += d.z; px[i].w += d.w;
+      if (a.dx32) reinterpret_cast<float4*>(a.dx32 + static_cast<long>(row) * a.lddx)[q] = d;
+      if (a.dx16) reinterpret_cast<ushort4*>(a.dx16 + static_cast<long>(row) * a.lddx)[q] =
+          make_ushort4(f2bf_(d.x), f2bf_(d.y), f2bf_(d.z), f2bf_(d.w));
+    }
+  }
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int q = lane + 64 * i;
+    if (q >= nq) continue;
+    reinterpret_cast<float4*>(red[0][wave])[q] = pg[i];
+    reinterpret_cast<float4*>(red[1][wave])[q] = pb[i];
+    reinterpret_cast<float4*>(red[2][wave])[q] = px[i];
+  }
+  __syncthreads();
+  float* out = a.partial + static_cast<long>(blockIdx.x) * 3 * a.D;
+  for (int c = threadIdx.x; c < 3 * a.D; c += kRowThreads) {
+    const int k = c / a.D, col = c - k * a.D;
+    out[c] = (red[k][0][col] + red[k][1][col]) + (red[k][2][col] + red[k][3][col]);
+  }
+}
+
+// out[c] = sum_p partial[p][c], p in fixed order; c < width.  One thread per column, coalesced over c.
+__global__ __launch_bounds__(256) void reduce_partials_kernel(const float* __restrict__ partial, int n_part, int width,
+                                                              float* __restrict__ out0, float* __restrict__ out1,
+                                                              float* __restrict__ out2, int D) {
+  const int c = blockIdx.x * 256 + threadIdx.x;
+  if (c >= width) return;
+  float s = 0.f;
+  for (int p = 0; p < n_part; ++p) s += partial[static_cast<long>(p) * width + c];
+  const int k = c / D, col = c - k * D;
+  float* o = k == 0 ? out0 : (k == 1 ? out1 : out2);
+  if (o) o[col] = s;
+}
+
+// ------------------------------------------------------------------------------------ column sums of a bf16 matrix
+constexpr int kColsumRows = 256;
+__global__ __launch_bounds__(256) void colsum_partial_kernel(const unsigned short* __restrict__ x, long ld, int M, int N,
+                                                             float* __restrict__ partial) {
+  // block = 256 threads: 32 column-groups of 8 columns x 8 row-lanes; grid.x = column blocks of 256, grid.y = row blocks
+  __shared__ float red[8][256];
+  const int cg = threadIdx.x & 31, rl = threadIdx.x >> 5;
+  const int col = blockIdx.x * 256 + cg * 8;
+  const int r0 = blockIdx.y * kColsumRows;
+  float s[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  if (col < N) {
+    for (int r = r0 + rl; r < r0 + kColsumRows && r < M; r += 8) {
+      const uint4 v = *reinterpret_cast<const uint4*>(x + static_cast<long>(r) * ld + col);
+      const unsigned w[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+      for (int i = 0; i < 4; ++i) { s[2 * i] += __uint_as_float(w[i] << 16); s[2 * i + 1] += __uint_as_float(w[i] & 0xffff0000u); }
+    }
+  }
+#pragma unroll
+  for (int i = 0; i < 8; ++i) red[rl][cg * 8 + i] = s[i];
+  __syncthreads();
+  const int c = threadIdx.x;
+  if (blockIdx.x * 256 + c < N) {
+    float t = 0.f;
+#pragma unroll
+    for (int r = 0; r < 8; ++r) t += red[r][c];
+    partial[static_cast<long>(blockIdx.y) * N + blockIdx.x * 256 + c] = t;
+  }
+}
+
+// ------------------------------------------------------------------------------------ embedding + positional encoding
+struct EmbedArgs { const long* tokens; const float* table; const float* pe; float scale; float* y32; unsigned short* y16;
+                   int n_rows; int T; int D; int vocab; };
+__global__ __launch_bounds__(kRowThreads) void embed_pe_fwd_kernel(EmbedArgs a) {
+  const int lane = threadIdx.x & 63;
+  const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= a.n_rows) return;
+  long tok = a.tokens[row];
+  tok = tok < 0 ? 0 : (tok >= a.vocab ? a.vocab - 1 : tok);     // clamp instead of faulting on a bad id
+  const float4* e = reinterpret_cast<const float4*>(a.table + tok * a.D);
+  const float4* p = reinterpret_cast<const float4*>(a.pe + static_cast<long>(row % a.T) * a.D);
+  for (int q = lane; q < (a.D >> 2); q += 64) {
+    const float4 ev = e[q], pv = p[q];
+    const float4 y = make_float4(ev.x * a.scale + pv.x, ev.y * a.scale + pv.y, ev.z * a.scale + pv.z, ev.w * a.scale + pv.w);
+    if (a.y32) reinterpret_cast<float4*>(a.y32 + static_cast<long>(row) * a.D)[q] = y;
+    if (a.y16) reinterpret_cast<ushort4*>(a.y16 + static_cast<long>(row) * a.D)[q] =
+        make_ushort4(f2bf_(y.x), f2bf_(y.y), f2bf_(y.z), f2bf_(y.w));
+  }
+}
+// dtable[token] += scale * dy[row]   (float atomics: tokens repeat inside a batch)
+__global__ __launch_bounds__(kRowThreads) void embed_bwd_kernel(const long* __restrict__ tokens, const float* __restrict__ dy,
+                                                                float scale, float* __restrict__ dtable, int n_rows, int D, int vocab) {
+  const int lane = threadIdx.x & 63;
+  const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= n_rows) return;
+  long tok = tokens[row];
+  tok = tok < 0 ? 0 : (tok >= vocab ? vocab - 1 : tok);
+  for (int c = lane; c < D; c += 64) atomicAdd(dtable + tok * D + c, scale * dy[static_cast<long>(row) * D + c]);
+}
+
+// ------------------------------------------------------------------------------------ cross-entropy (fwd + bwd in one pass)
+// row loss = logsumexp(z) - z[label] for label != ignore; dlogits = (softmax - onehot) * (1 / n_valid).
+// n_valid is counted on the device by count_valid_kernel so no host round trip is needed.
+__global__ __launch_bounds__(256) void count_valid_kernel(const long* __restrict__ labels, int n, long ignore, float* __restrict__ out) {
+  __shared__ int red[4];
+  int c = 0;
+  for (int i = threadIdx.x; i < n; i += 256) c += labels[i] != ignore;
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) c += __shfl_xor(c, o);
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = c;
+  __syncthreads();
+  if (threadIdx.x == 0) out[0] = static_cast<float>(red[0] + red[1] + red[2] + red[3]);
+}
+
+struct CeArgs { const float* logits; long ld; const long* labels; long ignore; const float* n_valid;
+                float* row_loss; unsigned short* dlogits; long ldd; int M; int V; };
+__device__ __forceinline__ float nan_to_num_(float z) {          // model.py:233
+  if (z != z) return 0.0f;
+  if (z > 3.0e38f) return 1e4f;
+  if (z < -3.0e38f) return -1e4f;
+  return z;
+}
+__global__ __launch_bounds__(kRowThreads) void cross_entropy_kernel(CeArgs a) {
+  const int lane = threadIdx.x & 63;
+  const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= a.M) return;
+  const float* z = a.logits + static_cast<long>(row) * a.ld;
+  const long label = a.labels[row];
+  float mx = -3.0e38f;
+  for (int c = lane; c < a.V; c += 64) mx = fmaxf(mx, nan_to_num_(z[c]));
+  mx = wave_max(mx);
+  float se = 0.f;
+  for (int c = lane; c < a.V; c += 64) se += __expf(nan_to_num_(z[c]) - mx);
+  se = wave_sum(se);
+  const float lse = mx + __logf(se);
+  const bool valid = label != a.ignore && label >= 0 && label < a.V;
+  if (lane == 0) a.row_loss[row] = valid ? lse - nan_to_num_(z[label]) : 0.0f;
+  if (a.dlogits) {
+    const float inv = valid ? 1.0f / fmaxf(a.n_valid[0], 1.0f) : 0.0f;
+    unsigned short* d = a.dlogits + static_cast<long>(row) * a.ldd;
+    for (int c = lane; c < a.V; c += 64) {
+      const float raw = z[c];
+      const bool finite = raw == raw && fabsf(raw) <= 3.0e38f;   // nan_to_num passes no gradient through non-finite inputs
+      float gr = (__expf(nan_to_num_(raw) - lse) - (c == label ? 1.0f : 0.0f)) * inv;
+      d[c] = f2bf_(finite ? gr : 0.0f);
+    }
+  }
+}
+// loss = sum(row_loss) / n_valid, summed in a fixed order by one block
+__global__ __launch_bounds__(256) void loss_reduce_kernel(const float* __restrict__ row_loss, int M, const float* __restrict__ n_valid,
+                                                          float* __restrict__ loss) {
+  __shared__ float red[4];
+  float s = 0.f;
+  for (int i = threadIdx.x; i < M; i += 256) s += row_loss[i];
+  s = wave_sum(s);
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
+  __syncthreads();
+  if (threadIdx.x == 0) loss[0] = ((red[0] + red[1]) + (red[2] + red[3])) / n_valid[0];   // 0/0 = NaN like torch when nothing is kept
+}
+
+// ------------------------------------------------------------------------------------ fp32 -> bf16 (and transposed copy)
+__global__ __launch_bounds__(256) void cast_bf16_kernel(const float* __restrict__ x, unsigned short* __restrict__ y, long n) {
+  const long i = (static_cast<long>(blockIdx.x) * 256 + threadIdx.x) * 8;
+  if (i + 8 <= n) {
+    const float4 a = *reinterpret_cast<const float4*>(x + i), b = *reinterpret_cast<const float4*>(x + i + 4);
+    uint4 o;
+    o.x = f2bf_(a.x) | (static_cast<unsigned>(f2bf_(a.y)) << 16); o.y = f2bf_(a.z) | (static_cast<unsigned>(f2bf_(a.w)) << 16);
+    o.z = f2bf_(b.x) | (static_cast<unsigned>(f2bf_(b.y)) << 16); o.w = f2bf_(b.z) | (static_cast<unsigned>(f2bf_(b.w)) << 16);
+    *reinterpret_cast<uint4*>(y + i) = o;
+  } else {
+    for (long j = i; j < n; ++j) y[j] = f2bf_(x[j]);
+  }
+}
+// y[c][r] = bf16(x[r][c]) through a 64x64 LDS tile (both sides coalesced)
+__global__ __launch_bounds__(256) void cast_transpose_bf16_kernel(const float* __restrict__ x, unsigned short* __restrict__ yt,
+                                                                  int R, int Cc) {
+  __shared__ unsigned short tile[64][66];
+  const int r0 = blockIdx.y * 64, c0 = blockIdx.x * 64;
+  for (int i = threadIdx.x; i < 64 * 64; i += 256) {
+    const int r = i >> 6, c = i & 63;
+    tile[r][c] = (r0 + r < R && c0 + c < Cc) ? f2bf_(x[static_cast<long>(r0 + r) * Cc + c0 + c]) : 0;
+  }
+  __syncthreads();
+  for (int i = threadIdx.x; i < 64 * 64; i += 256) {
+    const int c = i >> 6, r = i & 63;
+    if (c0 + c < Cc && r0 + r < R) yt[static_cast<long>(c0 + c) * R + r0 + r] = tile[r][c];
+  }
+}
+
+// ------------------------------------------------------------------------------------ grad-norm + AdamW on flat buffers
+constexpr int kSumsqBlocks = 1024;
+__global__ __launch_bounds__(256) void sumsq_partial_kernel(const float* __restrict__ g, long n, float* __restrict__ partial) {
+  __shared__ float red[4];
+  float s = 0.f;
+  const long n4 = n >> 2;
+  for (long i = static_cast<long>(blockIdx.x) * 256 + threadIdx.x; i < n4; i += static_cast<long>(gridDim.x) * 256) {
+    const float4 v = reinterpret_cast<const float4*>(g)[i];
+    s += (v.x * v.x + v.y * v.y) + (v.z * v.z + v.w * v.w);
+  }
+  if (blockIdx.x == 0 && threadIdx.x < (n & 3)) { const float v = g[(n4 << 2) + threadIdx.x]; s += v * v; }
+  s = wave_sum(s);
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
+  __syncthreads();
+  if (threadIdx.x == 0) partial[blockIdx.x] = (red[0] + red[1]) + (red[2] + red[3]);
+}
+// norm[0] = sqrt(sum partial); norm[1] = clip coefficient min(1, max_norm / (norm + 1e-6))  (torch clip_grad_norm_)
+__global__ __launch_bounds__(256) void gradnorm_finish_kernel(const float* __restrict__ partial, int n, float max_norm, float* __restrict__ norm) {
+  __shared__ float red[4];
+  float s = 0.f;
+  for (int i = threadIdx.x; i < n; i += 256) s += partial[i];
+  s = wave_sum(s);
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    const float nrm = sqrtf((red[0] + red[1]) + (red[2] + red[3]));
+    norm[0] = nrm;
+    const float c = max_norm / (nrm + 1e-6f);
+    norm[1] = max_norm > 0.f ? fminf(c, 1.0f) : 1.0f;
+  }
+}
+struct AdamArgs { float* p; const float* g; float* m; float* v; unsigned short* p16; long n; float lr, beta1, beta2, eps, wd;
+                  float bc1, bc2; const float* clip; };
+__global__ __launch_bounds__(256) void adamw_kernel(AdamArgs a) {
+  const long i = (static_cast<long>(blockIdx.x) * 256 + threadIdx.x) * 4;
+  if (i >= a.n) return;
+  const float clip = a.clip ? a.clip[1] : 1.0f;
+  float pv[4], gv[4], mv[4], vv[4];
+  const int cnt = (a.n - i) >= 4 ? 4 : static_cast<int>(a.n - i);
+  if (cnt == 4) {
+    *reinterpret_cast<float4*>(pv) = *reinterpret_cast<const float4*>(a.p + i);
+    *reinterpret_cast<float4*>(gv) = *reinterpret_cast<const float4*>(a.g + i);
+    *reinterpret_cast<float4*>(mv) = *reinterpret_cast<const float4*>(a.m + i);
+    *reinterpret_cast<float4*>(vv) = *reinterpret_cast<const float4*>(a.v + i);
+  } else {
+    for (int j = 0; j < cnt; ++j) { pv[j] = a.p[i + j]; gv[j] = a.g[i + j]; mv[j] = a.m[i + j]; vv[j] = a.v[i + j]; }
+  }
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const float gr = gv[j] * clip;
+    pv[j] *= 1.0f - a.lr * a.wd;                                   // decoupled weight decay (torch AdamW)
+    mv[j] = a.beta1 * mv[j] + (1.0f - a.beta1) * gr;
+    vv[j] = a.beta2 * vv[j] + (1.0f - a.beta2) * gr * gr;
+    const float denom = sqrtf(vv[j]) / sqrtf(a.bc2) + a.eps;
+    pv[j] -= (a.lr / a.bc1) * (mv[j] / denom);
+  }
+  if (cnt == 4) {
+    *reinterpret_cast<float4*>(a.p + i) = *reinterpret_cast<float4*>(pv);
+    *reinterpret_cast<float4*>(a.m + i) = *reinterpret_cast<float4*>(mv);
+    *reinterpret_cast<float4*>(a.v + i) = *reinterpret_cast<float4*>(vv);
+    if (a.p16) *reinterpret_cast<ushort4*>(a.p16 + i) = make_ushort4(f2bf_(pv[0]), f2bf_(pv[1]), f2bf_(pv[2]), f2bf_(pv[3]));
+  } else {
+    for (int j = 0; j < cnt; ++j) { a.p[i + j] = pv[j]; a.m[i + j] = mv[j]; a.v[i + j] = vv[j]; if (a.p16) a.p16[i + j] = f2bf_(pv[j]); }
+  }
+}
+
+}  // namespace adt
+
+using namespace adt;
+#define ST(s) static_cast<hipStream_t>(s)
+
+extern "C" int adt_layernorm_fwd(const float* x, int64_t ldx, const float* gamma, const float* beta, float eps,
+                                 float* y32, void* y16, int64_t ldy, float* mean, float* rstd, int64_t M, int64_t D,
+                                 void* stream) {
+  if (!x || !gamma || !beta || (!y32 && !y16)) return set_error(ADT_EINVAL, "adt_layernorm_fwd: null pointer");
+  if (D <= 0 || D > kMaxD || (D & 3) || (ldx & 3) || (ldy & 3)) return set_error(ADT_ESHAPE, "adt_layernorm_fwd: D must be a multiple of 4, <= 1024");
+  if (M < 0) return set_error(ADT_EINVAL, "adt_layernorm_fwd: negative M");
+  if (M == 0) return ADT_OK;
+  LnFwdArgs a{x, ldx, gamma, beta, eps, y32, static_cast<unsigned short*>(y16), ldy, mean, rstd, static_cast<int>(M), static_cast<int>(D)};
+  hipLaunchKernelGGL(layernorm_fwd_kernel, dim3(static_cast<unsigned>((M + 3) / 4)), dim3(kRowThreads), 0, ST(stream), a);
+  ADT_HIP_TRY(hipGetLastError());
+  return ADT_OK;
+}
+
+extern "C" size_t adt_layernorm_bwd_workspace_bytes(int64_t M, int64_t D) {
+  if (M <= 0 || D <= 0) return 0;
+  return static_cast<size_t>((M + kLnBwdRows - 1) / kLnBwdRows) * 3 * D * 4;
+}
+
+extern "C" int adt_layernorm_bwd(const float* dy, int64_t lddy, const float* x, int64_t ldx, const float* gamma,
+                                 const float* mean, const float* rstd, float* dx32, void* dx16, int64_t lddx,
+                                 float* dgamma, float* dbeta, float* dxsum, int64_t M, int64_t D, void* ws,
+                                 size_t ws_bytes, void* stream) {
+  if (!dy || !x || !gamma || !mean || !rstd || (!dx32 && !dx16)) return set_error(ADT_EINVAL, "adt_layernorm_bwd: null pointer");
+  if (D <= 0 || D > kMaxD || (D & 3) || (ldx & 3) || (lddy & 3) || (lddx & 3)) return set_error(ADT_ESHAPE, "adt_layernorm_bwd: D must be a multiple of 4, <= 1024");
+  if (M < 0) return set_error(ADT_EINVAL, "adt_layernorm_bwd: negative M");
+  if (M == 0) return ADT_OK;
+  if (!ws || ws_bytes < adt_layernorm_bwd_workspace_bytes(M, D)) return set_error(ADT_EINVAL, "adt_layernorm_bwd: workspace too small");
+  const int nb = static_cast<int>((M + kLnBwdRows - 1) / kLnBwdRows);
+  LnBwdArgs a{dy, lddy, x, ldx, gamma, mean, rstd, dx32, static_cast<unsigned short*>(dx16), lddx, static_cast<float*>(ws),
+              static_cast<int>(M), static_cast<int>(D)};
+  hipLaunchKernelGGL(layernorm_bwd_kernel, dim3(nb), dim3(kRowThreads), 0, ST(stream), a);
+  const int width = 3 * static_cast<int>(D);
+  hipLaunchKernelGGL(reduce_partials_kernel, dim3((width + 255) / 256), dim3(256), 0, ST(stream), static_cast<const float*>(ws), nb,
+                     width, dgamma, dbeta, dxsum, static_cast<int>(D));
+  ADT_HIP_TRY(hipGetLastError());
+  return ADT_OK;
+}
+
+extern "C" size_t adt_colsum_workspace_bytes(int64_t M, int64_t N) {
+  if (M <= 0 || N <= 0) return 0;
+  return static_cast<size_t>((M + kColsumRows - 1) / kColsumRows) * N * 4;
+}
+
+extern "C" int adt_colsum_bf16(const void* x, int64_t ld, int64_t M, int64_t N, float* out, void* ws, size_t ws_bytes, void* stream) {
+  if (!x || !out) return set_error(ADT_EINVAL, "adt_colsum_bf16: null pointer");
+  if (M < 0 || N <= 0 || (N & 7) || (ld & 7) || !aligned16(x)) return set_error(ADT_ESHAPE, "adt_colsum_bf16: N and ld must be multiples of 8");
+  if (M == 0) { ADT_HIP_TRY(hipMemsetAsync(out, 0, N * 4, ST(stream))); return ADT_OK; }
+  if (!ws || ws_bytes < adt_colsum_workspace_bytes(M, N)) return set_error(ADT_EINVAL, "adt_colsum_bf16: workspace too small");
+  const int nb = static_cast<int>((M + kColsumRows - 1) / kColsumRows);
+  hipLaunchKernelGGL(colsum_partial_kernel, dim3(static_cast<unsigned>((N + 255) / 256), nb), dim3(256), 0, ST(stream),
+                     static_cast<const unsigned short*>(x), ld, static_cast<int>(M), static_cast<int>(N), static_cast<float*>(ws));
+  hipLaunchKernelGGL(reduce_partials_kernel, dim3(static_cast<unsigned>((N + 255) / 256)), dim3(256), 0, ST(stream),
+                     static_cast<const float*>(ws), nb, static_cast<int>(N), out, static_cast<float*>(nullptr), static_cast<float*>(nullptr),
+                     static_cast<int>(N));
+  ADT_HIP_TRY(hipGetLastError());
+  return ADT_OK;
+}
+
+extern "C" int adt_embed_pe_fwd(const int64_t* tokens, const float* table, const float* pe, float scale, float* y32, void* y16,
+                                int64_t n_rows, int64_t T, int64_t D, int64_t vocab, void* stream) {
+  if (!tokens || !table || !pe || (!y32 && !y16)) return set_error(ADT_EINVAL, "adt_embed_pe_fwd: null pointer");
+  if (D <= 0 || (D & 3) || T <= 0 || vocab <= 0 || n_rows < 0) return set_error(ADT_ESHAPE, "adt_embed_pe_fwd: D must be a multiple of 4; T, vocab > 0");
+  if (n_rows == 0) return ADT_OK;
+  EmbedArgs a{reinterpret_cast<const long*>(tokens), table, pe, scale, y32, static_cast<unsigned short*>(y16), static_cast<int>(n_rows),
+              static_cast<int>(T), static_cast<int>(D), static_cast<int>(vocab)};
+  hipLaunchKernelGGL(embed_pe_fwd_kernel, dim3(static_cast<unsigned>((n_rows + 3) / 4)), dim3(kRowThreads), 0, ST(stream), a);
+  ADT_HIP_TRY(hipGetLastError());
+  return ADT_OK;
+}
+
+extern "C" int adt_embed_bwd(const int64_t* tokens, const float* dy, float scale, float* dtable, int64_t n_rows, int64_t D,
+                             int64_t vocab, void* stream) {
+  if (!tokens || !dy || !dtable) return set_error(ADT_EINVAL, "adt_embed_bwd: null pointer");
+  if (D <= 0 || vocab <= 0 || n_rows < 0) return set_error(ADT_ESHAPE, "adt_embed_bwd: bad shape");
+  if (n_rows == 0) return ADT_OK;
+  hipLaunchKernelGGL(embed_bwd_kernel, dim3(static_cast<unsigned>((n_rows + 3) / 4)), dim3(kRowThreads), 0, ST(stream),
+                     reinterpret_cast<const long*>(tokens), dy, scale, dtable, static_cast<int>(n_rows), static_cast<int>(D), static_cast<int>(vocab));
+  ADT_HIP_TRY(hipGetLastError());
+  return ADT_OK;
+}
+
+extern "C" size_t adt_cross_entropy_workspace_bytes(int64_t M) { return M > 0 ? static_cast<size_t>(M + 4) * 4 : 16; }
+
+extern "C" int adt_cross_entropy(const float* logits, int64_t ld, const int64_t* labels, int64_t ignore_index, int64_t M, int64_t V,
+                                 float* loss, void* dlogits, int64_t ldd, void* ws, size_t ws_bytes, void* stream) {
+  if (!logits || !labels || !loss) return set_error(ADT_EINVAL, "adt_cross_entropy: null pointer");
+  if (M < 0 || V <= 0 || ld < V || (dlogits && ldd < V)) return set_error(ADT_EINVAL, "adt_cross_entropy: bad shape");
+  if (!ws || ws_bytes < adt_cross_entropy_workspace_bytes(M)) return set_error(ADT_EINVAL, "adt_cross_entropy: workspace too small");
+  float* n_valid = static_cast<float*>(ws);
+  float* row_loss = n_valid + 4;
+  hipLaunchKernelGGL(count_valid_kernel, dim3(1), dim3(256), 0, ST(stream), reinterpret_cast<const long*>(labels), static_cast<int>(M),
+                     static_cast<long>(ignore_index), n_valid);
+  if (M > 0) {
+    CeArgs a{logits, ld, reinterpret_cast<const long*>(labels), static_cast<long>(ignore_index), n_valid, row_loss,
+             static_cast<unsigned short*>(dlogits), ldd, static_cast<int>(M), static_cast<int>(V)};
+    hipLaunchKernelGGL(cross_entropy_kernel, dim3(static_cast<unsigned>((M + 3) / 4)), dim3(kRowThreads), 0, ST(stream), a);
+  }
+  hipLaunchKernelGGL(loss_reduce_kernel, dim3(1), dim3(256), 0, ST(stream), row_loss, static_cast<int>(M), n_valid, loss);
+  ADT_HIP_TRY(hipGetLastError());
+  return ADT_OK;
+}
+
+extern "C" int adt_cast_bf16(const float* x, void* y, void* y_t, int64_t rows, int64_t cols, void* stream) {
+  if (!x || (!y && !y_t)) return set_error(ADT_EINVAL, "adt_cast_bf16: null pointer");
+  if (rows < 0 || cols < 0) return set_error(ADT_EINVAL, "adt_cast_bf16: negative size");
+  const long n = rows * cols;
+  if (n == 0) return ADT_OK;
+  if (y) hipLaunchKernelGGL(cast_bf16_kernel, dim3(static_cast<unsigned>((n + 2047) / 2048)), dim3(256), 0, ST(stream), x,
+                            static_cast<unsigned short*>(y), n);
+  if (y_t) hipLaunchKernelGGL(cast_transpose_bf16_kernel, dim3(static_cast<unsigned>((cols + 63) / 64), static_cast<unsigned>((rows + 63) / 64)),
+                              dim3(256), 0, ST(stream), x, static_cast<unsigned short*>(y_t), static_cast<int>(rows), static_cast<int>(cols));
+  ADT_HIP_TRY(hipGetLastError());
+  return ADT_OK;
+}
+
+extern "C" size_t adt_grad_norm_workspace_bytes(void) { return kSumsqBlocks * 4; }
+
+extern "C" int adt_grad_norm(const float* g, int64_t n, float max_norm, float* norm_and_clip, void* ws, size_t ws_bytes, void* stream) {
+  if (!g || !norm_and_clip) return set_error(ADT_EINVAL, "adt_grad_norm: null pointer");
+  if (n < 0) return set_error(ADT_EINVAL, "adt_grad_norm: negative n");
+  if (!ws || ws_bytes < adt_grad_norm_workspace_bytes()) return set_error(ADT_EINVAL, "adt_grad_norm: workspace too small");
+  hipLaunchKernelGGL(sumsq_partial_kernel, dim3(kSumsqBlocks), dim3(256), 0, ST(stream), g, static_cast<long>(n), static_cast<float*>(ws));
+  hipLaunchKernelGGL(gradnorm_finish_kernel, dim3(1), dim3(256), 0, ST(stream), static_cast<const float*>(ws), kSumsqBlocks, max_norm, norm_and_clip);
+  ADT_HIP_TRY(hipGetLastError());
+  return ADT_OK;
+}
+
+extern "C" int adt_adamw_step(float* p, const float* g, float* m, float* v, void* p_bf16, int64_t n, float lr, float beta1,
+                              float beta2, float eps, float weight_decay, int64_t step, const float* norm_and_clip, void* stream) {
+  if (!p || !g || !m || !v) return set_error(ADT_EINVAL, "adt_adamw_step: null pointer");
+  if (n < 0 || step < 1) return set_error(ADT_EINVAL, "adt_adamw_step: n < 0 or step < 1");
+  if (n == 0) return ADT_OK;
+  AdamArgs a{p, g, m, v, static_cast<unsigned short*>(p_bf16), static_cast<long>(n), lr, beta1, beta2, eps, weight_decay,
+             1.0f - powf(beta1, static_cast<float>(step)), 1.0f - powf(beta2, static_cast<float>(step)), norm_and_clip};
+  hipLaunchKernelGGL(adamw_kernel, dim3(static_cast<unsigned>((n + 1023) / 1024)), dim3(256), 0, ST(stream), a);
+  ADT_HIP_TRY(hipGetLastError());
+  return ADT_OK;
+}

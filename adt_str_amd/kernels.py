@@ -1,0 +1,169 @@
+"""Thin Python wrappers over the C ABI (one function per entry point).
+
+Tensors are PyTorch GPU tensors used as plain device buffers; every call runs
+on PyTorch's current HIP stream.  No autograd here (see ``adt_str_amd.network``).
+"""
+from __future__ import annotations
+
+import ctypes as C
+from typing import Optional
+
+import torch
+
+from . import _ffi
+
+_ws_cache: dict = {}
+
+
+def _workspace(nbytes: int, device) -> torch.Tensor:
+    """Grow-only scratch buffer per device (never freed: stream-ordered reuse)."""
+    key = str(device)
+    buf = _ws_cache.get(key)
+    if buf is None or buf.numel() < nbytes:
+        buf = torch.empty(max(nbytes, 1 << 20), dtype=torch.uint8, device=device)
+        _ws_cache[key] = buf
+    return buf
+
+
+def gemm(a: torch.Tensor, b: torch.Tensor, *, trans: bool = False, out: Optional[torch.Tensor] = None,
+         out_dtype=torch.bfloat16, bias: Optional[torch.Tensor] = None, residual: Optional[torch.Tensor] = None,
+         res_row_mod: int = 0, act: int = 0, pre_act_out: Optional[torch.Tensor] = None,
+         gelu_grad_of: Optional[torch.Tensor] = None, alpha: float = 1.0) -> torch.Tensor:
+    """``trans=False``: ``a[M,K] @ b[N,K].T``; ``trans=True``: ``a[K,M].T @ b[K,N]`` (bf16 in, fp32 accumulate)."""
+    assert a.dtype == torch.bfloat16 and b.dtype == torch.bfloat16 and a.dim() == 2 and b.dim() == 2
+    assert a.stride(1) == 1 and b.stride(1) == 1
+    if trans:
+        K, M = a.shape
+        K2, N = b.shape
+    else:
+        M, K = a.shape
+        N, K2 = b.shape
+    assert K == K2, (a.shape, b.shape)
+    if out is None:
+        out = torch.empty((M, N), dtype=out_dtype, device=a.device)
+    assert out.shape == (M, N) and out.stride(1) == 1 and out.dtype in (torch.bfloat16, torch.float32)
+    ep = _ffi.GemmEpilogue()
+    ep.alpha = alpha
+    ep.act = act
+    ep.out_fp32 = 1 if out.dtype == torch.float32 else 0
+    if bias is not None:
+        assert bias.dtype == torch.float32 and bias.numel() == N
+        ep.bias = _ffi.dptr(bias)
+    if residual is not None:
+        assert residual.dtype == torch.float32 and residual.stride(-1) == 1
+        ep.residual, ep.ld_res, ep.res_row_mod = _ffi.dptr(residual), residual.stride(-2), res_row_mod
+    if pre_act_out is not None:
+        assert pre_act_out.dtype == torch.bfloat16 and pre_act_out.shape == (M, N)
+        ep.pre_act_out, ep.ld_pre_act = _ffi.dptr(pre_act_out), pre_act_out.stride(0)
+    if gelu_grad_of is not None:
+        assert gelu_grad_of.dtype == torch.bfloat16 and gelu_grad_of.shape == (M, N)
+        ep.gelu_grad_of, ep.ld_gelu_grad = _ffi.dptr(gelu_grad_of), gelu_grad_of.stride(0)
+    ws_bytes = _ffi.load().adt_gemm_workspace_bytes(int(trans), M, N, K) if trans else 0
+    ws = _workspace(ws_bytes, a.device) if ws_bytes else None
+    _ffi.call("adt_gemm_bf16", int(trans), M, N, K, _ffi.dptr(a), a.stride(0), _ffi.dptr(b), b.stride(0),
+              _ffi.dptr(out), out.stride(0), C.byref(ep), _ffi.dptr(ws) if ws is not None else None, ws_bytes,
+              _ffi.current_stream())
+    return out
+
+
+def _p(t: Optional[torch.Tensor]):
+    return _ffi.dptr(t) if t is not None else None
+
+
+def layernorm_fwd(x, gamma, beta, eps=1e-5, want32=True, want16=True):
+    """x fp32 [M, D] -> (y32 | None, y16 | None, mean[M], rstd[M])."""
+    assert x.dtype == torch.float32 and x.dim() == 2 and x.stride(1) == 1
+    M, D = x.shape
+    y32 = torch.empty((M, D), dtype=torch.float32, device=x.device) if want32 else None
+    y16 = torch.empty((M, D), dtype=torch.bfloat16, device=x.device) if want16 else None
+    mean = torch.empty(M, dtype=torch.float32, device=x.device)
+    rstd = torch.empty(M, dtype=torch.float32, device=x.device)
+    _ffi.call("adt_layernorm_fwd", _ffi.dptr(x), x.stride(0), _ffi.dptr(gamma), _ffi.dptr(beta), eps, _p(y32), _p(y16), D,
+              _ffi.dptr(mean), _ffi.dptr(rstd), M, D, _ffi.current_stream())
+    return y32, y16, mean, rstd
+
+
+def layernorm_bwd(dy, x, gamma, mean, rstd, dgamma=None, dbeta=None, dxsum=None, want32=True, want16=True):
+    """-> (dx32 | None, dx16 | None); dgamma/dbeta/dxsum [D] fp32 are overwritten when given."""
+    assert dy.dtype == torch.float32 and x.dtype == torch.float32 and dy.shape == x.shape
+    M, D = x.shape
+    dx32 = torch.empty((M, D), dtype=torch.float32, device=x.device) if want32 else None
+    dx16 = torch.empty((M, D), dtype=torch.bfloat16, device=x.device) if want16 else None
+    nb = _ffi.load().adt_layernorm_bwd_workspace_bytes(M, D)
+    ws = _workspace(nb, x.device)
+    _ffi.call("adt_layernorm_bwd", _ffi.dptr(dy), dy.stride(0), _ffi.dptr(x), x.stride(0), _ffi.dptr(gamma), _ffi.dptr(mean),
+              _ffi.dptr(rstd), _p(dx32), _p(dx16), D, _p(dgamma), _p(dbeta), _p(dxsum), M, D, _ffi.dptr(ws), nb,
+              _ffi.current_stream())
+    return dx32, dx16
+
+
+def colsum(x, out=None):
+    assert x.dtype == torch.bfloat16 and x.dim() == 2 and x.stride(1) == 1
+    M, N = x.shape
+    if out is None:
+        out = torch.empty(N, dtype=torch.float32, device=x.device)
+    nb = _ffi.load().adt_colsum_workspace_bytes(M, N)
+    ws = _workspace(nb, x.device)
+    _ffi.call("adt_colsum_bf16", _ffi.dptr(x), x.stride(0), M, N, _ffi.dptr(out), _ffi.dptr(ws), nb, _ffi.current_stream())
+    return out
+
+
+def embed_pe_fwd(tokens, table, pe, scale, want32=True, want16=True):
+    """tokens int64 [B, T] -> (y32, y16) [B*T, D]."""
+    assert tokens.dtype == torch.int64 and tokens.is_contiguous()
+    B, T = tokens.shape
+    V, D = table.shape
+    y32 = torch.empty((B * T, D), dtype=torch.float32, device=table.device) if want32 else None
+    y16 = torch.empty((B * T, D), dtype=torch.bfloat16, device=table.device) if want16 else None
+    _ffi.call("adt_embed_pe_fwd", _ffi.dptr(tokens), _ffi.dptr(table), _ffi.dptr(pe), scale, _p(y32), _p(y16), B * T, T, D, V,
+              _ffi.current_stream())
+    return y32, y16
+
+
+def embed_bwd(tokens, dy, scale, dtable):
+    n, D = dy.shape
+    assert dy.dtype == torch.float32 and dy.is_contiguous() and dtable.dtype == torch.float32
+    _ffi.call("adt_embed_bwd", _ffi.dptr(tokens), _ffi.dptr(dy), scale, _ffi.dptr(dtable), n, D, dtable.shape[0],
+              _ffi.current_stream())
+
+
+def cross_entropy(logits, labels, ignore_index=1, want_grad=True):
+    """logits fp32 [M, V], labels int64 [M] -> (loss[1] fp32 on device, dlogits bf16 [M, Vpad] | None)."""
+    assert logits.dtype == torch.float32 and logits.dim() == 2 and logits.stride(1) == 1
+    M, V = logits.shape
+    labels = labels.reshape(-1).contiguous()
+    loss = torch.empty(1, dtype=torch.float32, device=logits.device)
+    Vp = (V + 7) // 8 * 8
+    dl = torch.zeros((M, Vp), dtype=torch.bfloat16, device=logits.device) if want_grad else None
+    nb = _ffi.load().adt_cross_entropy_workspace_bytes(M)
+    ws = _workspace(nb, logits.device)
+    _ffi.call("adt_cross_entropy", _ffi.dptr(logits), logits.stride(0), _ffi.dptr(labels), ignore_index, M, V, _ffi.dptr(loss),
+              _p(dl), Vp, _ffi.dptr(ws), nb, _ffi.current_stream())
+    return loss, (dl[:, :V] if dl is not None else None)
+
+
+def cast_bf16(x, want=True, want_t=False):
+    """fp32 [R, C] -> (bf16 [R, C] | None, bf16 [C, R] | None)."""
+    assert x.dtype == torch.float32 and x.is_contiguous()
+    R, Cc = (x.shape if x.dim() == 2 else (1, x.numel()))
+    y = torch.empty((R, Cc), dtype=torch.bfloat16, device=x.device) if want else None
+    yt = torch.empty((Cc, R), dtype=torch.bfloat16, device=x.device) if want_t else None
+    _ffi.call("adt_cast_bf16", _ffi.dptr(x), _p(y), _p(yt), R, Cc, _ffi.current_stream())
+    return y, yt
+
+
+def grad_norm(g, max_norm, out=None):
+    assert g.dtype == torch.float32 and g.is_contiguous()
+    if out is None:
+        out = torch.empty(2, dtype=torch.float32, device=g.device)
+    nb = _ffi.load().adt_grad_norm_workspace_bytes()
+    ws = _workspace(nb, g.device)
+    _ffi.call("adt_grad_norm", _ffi.dptr(g), g.numel(), max_norm, _ffi.dptr(out), _ffi.dptr(ws), nb, _ffi.current_stream())
+    return out
+
+
+def adamw_step(p, g, m, v, step, lr, beta1=0.9, beta2=0.999, eps=1e-8, weight_decay=0.0, norm_and_clip=None, p_bf16=None):
+    for t in (p, g, m, v):
+        assert t.dtype == torch.float32 and t.is_contiguous() and t.numel() == p.numel()
+    _ffi.call("adt_adamw_step", _ffi.dptr(p), _ffi.dptr(g), _ffi.dptr(m), _ffi.dptr(v), _p(p_bf16), p.numel(), lr, beta1, beta2,
+              eps, weight_decay, step, _p(norm_and_clip), _ffi.current_stream())

@@ -108,6 +108,116 @@ int adt_mix_render_f32(const float* bank, const int64_t* bank_off, int64_t n_sho
                        const int32_t* clip_len, const float* clip_gain, int64_t n_clips, int64_t width,
                        float* out, int64_t ld_out, void* ws, size_t ws_bytes, void* stream);
 
+/* ---------------------------------------------------------------------------
+ * K3/K5  bf16 MFMA GEMM with fused epilogue (fp32 accumulate)
+ *
+ * Replaces the GEMMs of every nn.Linear on the path -- project_to_mel
+ * (reference model.py:224), Encoder.dense_layer (:111), Decoder.generator (:157),
+ * and in_proj / out_proj / linear1 / linear2 inside nn.TransformerEncoderLayer /
+ * nn.TransformerDecoderLayer (:118-127, :159-168) -- forward and backward.
+ *
+ *   trans = 0:  C[M,N] = A[M,K] . B[N,K]^T        (y = x W^T;  dx = dy . (W^T)^T)
+ *   trans = 1:  C[M,N] = A[K,M]^T . B[K,N]        (dW = dy^T x; K = number of rows)
+ * A, B are bf16 row-major with leading dimensions lda/ldb (elements), rows
+ * 16-byte aligned and a multiple of 8 elements long.
+ *
+ * Epilogue, applied in this order to z = alpha * acc:
+ *   + bias[col]                          (fp32, may be null)
+ *   * gelu'(gelu_grad_of[row,col])       (bf16 pre-activation u; dgrad through GELU)
+ *   pre_act_out[row,col] = bf16(z)       (saved pre-activation, may be null)
+ *   act == 1: z = gelu_erf(z)            (exact erf GELU, activation="gelu")
+ *   + residual[row % res_row_mod, col]   (fp32; res_row_mod == 0: plain row) --
+ *                                         residual stream, or the sinusoidal PE
+ *                                         table with res_row_mod = frames per clip
+ *   C = out_fp32 ? z : bf16(z)
+ * trans = 1 may split K across workgroups; partial fp32 slabs go to `ws`
+ * (adt_gemm_workspace_bytes) and are summed in slab order (reproducible).
+ */
+typedef struct adt_gemm_epilogue {
+  const float* bias;
+  const void*  gelu_grad_of;  int64_t ld_gelu_grad;
+  void*        pre_act_out;   int64_t ld_pre_act;
+  const void*  residual;      int64_t ld_res;      int32_t res_row_mod;
+  int32_t      act;
+  float        alpha;
+  int32_t      out_fp32;
+} adt_gemm_epilogue;
+
+size_t adt_gemm_workspace_bytes(int32_t trans, int64_t M, int64_t N, int64_t K);
+
+int adt_gemm_bf16(int32_t trans, int64_t M, int64_t N, int64_t K, const void* A, int64_t lda,
+                  const void* B, int64_t ldb, void* C, int64_t ldc, const adt_gemm_epilogue* ep,
+                  void* ws, size_t ws_bytes, void* stream);
+
+/* ---------------------------------------------------------------------------
+ * K6  LayerNorm forward / backward  (nn.LayerNorm(d), eps 1e-5, fp32 statistics)
+ *
+ * Replaces norm1/norm2/norm3 of the post-norm transformer layers and
+ * Encoder.layer_norm (reference model.py:113-115,118-127,159-168).
+ *   fwd: y = (x - mean) * rstd * gamma + beta, written as fp32 (y32) and/or
+ *        bf16 (y16, the next GEMM's operand); mean/rstd [M] are kept for backward.
+ *   bwd: dx from dy, the saved input x and statistics; dx as fp32 and/or bf16;
+ *        dgamma, dbeta and dxsum[D] = column sums of dx (the bias gradient of the
+ *        linear layer that produced x's branch); any of the three may be null.
+ */
+int adt_layernorm_fwd(const float* x, int64_t ldx, const float* gamma, const float* beta, float eps,
+                      float* y32, void* y16, int64_t ldy, float* mean, float* rstd, int64_t M, int64_t D,
+                      void* stream);
+size_t adt_layernorm_bwd_workspace_bytes(int64_t M, int64_t D);
+int adt_layernorm_bwd(const float* dy, int64_t lddy, const float* x, int64_t ldx, const float* gamma,
+                      const float* mean, const float* rstd, float* dx32, void* dx16, int64_t lddx,
+                      float* dgamma, float* dbeta, float* dxsum, int64_t M, int64_t D, void* ws,
+                      size_t ws_bytes, void* stream);
+
+/* Column sums of a bf16 [M,N] matrix -> fp32 [N] (bias gradients of in_proj, linear1,
+ * generator, project_to_mel).  Fixed-order two-stage reduction. */
+size_t adt_colsum_workspace_bytes(int64_t M, int64_t N);
+int adt_colsum_bf16(const void* x, int64_t ld, int64_t M, int64_t N, float* out, void* ws, size_t ws_bytes, void* stream);
+
+/* ---------------------------------------------------------------------------
+ * K7  token embedding * sqrt(d) + positional encoding
+ *
+ * Replaces TokenEmbedding_plain.forward and PositionalEncoding.forward
+ * (reference model.py:42-65) as used by Decoder.forward (:171).
+ *   fwd: y[row] = table[tokens[row]] * scale + pe[row % T]   (rows = B*T, row-major)
+ *   bwd: dtable[tokens[row]] += scale * dy[row]              (dtable pre-zeroed by the caller)
+ */
+int adt_embed_pe_fwd(const int64_t* tokens, const float* table, const float* pe, float scale, float* y32, void* y16,
+                     int64_t n_rows, int64_t T, int64_t D, int64_t vocab, void* stream);
+int adt_embed_bwd(const int64_t* tokens, const float* dy, float scale, float* dtable, int64_t n_rows, int64_t D,
+                  int64_t vocab, void* stream);
+
+/* ---------------------------------------------------------------------------
+ * K8  cross-entropy forward + backward
+ *
+ * Replaces ADTModel._loss_fn (reference model.py:228-238): fp32 logits,
+ * nan_to_num(nan=0, +-inf=+-1e4), F.cross_entropy(ignore_index, mean over kept rows).
+ *   loss[0]  scalar fp32
+ *   dlogits  (optional) bf16 [M, ldd]: d loss / d logits
+ */
+size_t adt_cross_entropy_workspace_bytes(int64_t M);
+int adt_cross_entropy(const float* logits, int64_t ld, const int64_t* labels, int64_t ignore_index, int64_t M, int64_t V,
+                      float* loss, void* dlogits, int64_t ldd, void* ws, size_t ws_bytes, void* stream);
+
+/* ---------------------------------------------------------------------------
+ * Parameter plumbing for the bf16 compute path: fp32 master weight [rows, cols]
+ * -> bf16 copy y (same layout) and/or y_t [cols, rows] (the NT operand of dgrad).
+ */
+int adt_cast_bf16(const float* x, void* y, void* y_t, int64_t rows, int64_t cols, void* stream);
+
+/* ---------------------------------------------------------------------------
+ * Optimizer step on flat fp32 buffers: torch.nn.utils.clip_grad_norm_(max_norm)
+ * followed by torch.optim.AdamW (reference train.py:219-249, HF Trainer defaults).
+ *   adt_grad_norm: norm_and_clip[0] = ||g||_2, [1] = min(1, max_norm/(norm+1e-6))
+ *                  (1 when max_norm <= 0); both stay on the device.
+ *   adt_adamw_step: p, m, v updated in place with g * norm_and_clip[1]
+ *                  (norm_and_clip may be null); p_bf16 (optional) = bf16(p).
+ */
+size_t adt_grad_norm_workspace_bytes(void);
+int adt_grad_norm(const float* g, int64_t n, float max_norm, float* norm_and_clip, void* ws, size_t ws_bytes, void* stream);
+int adt_adamw_step(float* p, const float* g, float* m, float* v, void* p_bf16, int64_t n, float lr, float beta1,
+                   float beta2, float eps, float weight_decay, int64_t step, const float* norm_and_clip, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

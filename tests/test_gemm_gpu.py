@@ -1,0 +1,106 @@
+"""K3/K5 GEMM parity on the GPU.  The check is against an fp32 torch matmul of the
+same bf16-rounded operands (the kernel accumulates in fp32), so the tolerance only
+has to cover accumulation order: |err| <= 2e-3 * sqrt(K) * scale for bf16 outputs
+(bf16 rounding of the result, 2^-8 relative) and 1e-4 relative for fp32 outputs."""
+import math
+
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+
+def rnd(shape, seed, scale=1.0):
+    g = torch.Generator().manual_seed(seed)
+    return (torch.randn(shape, generator=g) * scale).to(DEV)
+
+
+def close(got, ref, rel, what=""):
+    err = (got.float() - ref).abs().max().item()
+    tol = rel * ref.abs().max().item() + 1e-6
+    assert err <= tol, f"{what}: max err {err} > {tol}"
+
+
+@pytest.mark.parametrize("M,N,K", [(128, 128, 64), (256, 384, 128), (300, 200, 192), (63104 // 8, 768, 768),
+                                   (1000, 1400, 768), (64, 2304, 768), (8192, 768, 3072), (77, 24, 64)])
+def test_nt_plain(M, N, K):
+    from adt_str_amd import kernels as k
+    a, b = rnd((M, K), 1).bfloat16(), rnd((N, K), 2).bfloat16()
+    ref = a.float() @ b.float().t()
+    close(k.gemm(a, b, out_dtype=torch.float32), ref, 1e-4, "fp32 out")
+    close(k.gemm(a, b), ref, 6e-3, "bf16 out")
+
+
+def test_nt_exact_integers_asymmetric():
+    """A = I-like selector and small integers: any row/col swap or k mix-up shows up exactly."""
+    from adt_str_amd import kernels as k
+    M, N, K = 256, 256, 128
+    g = torch.Generator().manual_seed(0)
+    a = torch.randint(-3, 4, (M, K), generator=g).float().to(DEV).bfloat16()
+    b = torch.randint(-2, 3, (N, K), generator=g).float().to(DEV).bfloat16()
+    out = k.gemm(a, b, out_dtype=torch.float32)
+    assert torch.equal(out, a.float() @ b.float().t())
+
+
+@pytest.mark.parametrize("K,M,N", [(64, 128, 128), (256, 128, 256), (1000, 200, 136), (63104 // 4, 768, 768),
+                                   (8192, 1400, 768), (2048, 768, 3072), (70, 40, 24)])
+def test_tn_wgrad(K, M, N):
+    from adt_str_amd import kernels as k
+    a, b = rnd((K, M), 3).bfloat16(), rnd((K, N), 4).bfloat16()
+    ref = a.float().t() @ b.float()
+    got = k.gemm(a, b, trans=True, out_dtype=torch.float32)
+    close(got, ref, 2e-4, "tn fp32")
+    again = k.gemm(a, b, trans=True, out_dtype=torch.float32)
+    assert torch.equal(got, again)                      # split-K slabs are summed in a fixed order
+
+
+def test_tn_exact_integers():
+    from adt_str_amd import kernels as k
+    K, M, N = 192, 144, 136
+    g = torch.Generator().manual_seed(1)
+    a = torch.randint(-3, 4, (K, M), generator=g).float().to(DEV).bfloat16()
+    b = torch.randint(-2, 3, (K, N), generator=g).float().to(DEV).bfloat16()
+    assert torch.equal(k.gemm(a, b, trans=True, out_dtype=torch.float32), a.float().t() @ b.float())
+
+
+def test_epilogues():
+    from adt_str_amd import kernels as k
+    M, N, K = 384, 512, 256
+    a, b = rnd((M, K), 5).bfloat16(), rnd((N, K), 6, 0.1).bfloat16()
+    bias = rnd((N,), 7)
+    res = rnd((M, N), 8)
+    z = a.float() @ b.float().t()
+    close(k.gemm(a, b, bias=bias, out_dtype=torch.float32), z + bias, 1e-4, "bias")
+    close(k.gemm(a, b, bias=bias, residual=res, out_dtype=torch.float32), z + bias + res, 1e-4, "bias+residual")
+    pe = rnd((96, N), 9)                                             # row-periodic table (positional encoding)
+    close(k.gemm(a, b, residual=pe, res_row_mod=96, out_dtype=torch.float32),
+          z + pe.repeat(M // 96, 1), 1e-4, "periodic residual")
+    close(k.gemm(a, b, alpha=0.25, out_dtype=torch.float32), 0.25 * z, 1e-4, "alpha")
+    # GELU forward with saved pre-activation
+    u = torch.empty((M, N), dtype=torch.bfloat16, device=DEV)
+    h = k.gemm(a, b, bias=bias, act=1, pre_act_out=u)
+    uref = (z + bias)
+    close(u, uref, 6e-3, "pre-activation")
+    close(h, torch.nn.functional.gelu(u.float()), 6e-3, "gelu(u)")
+    # dgrad through GELU: out = z * gelu'(u)
+    uu = u.float().requires_grad_(True)
+    torch.nn.functional.gelu(uu).sum().backward()
+    close(k.gemm(a, b, gelu_grad_of=u, out_dtype=torch.float32), z * uu.grad, 2e-4, "gelu grad")
+
+
+def test_views_with_leading_dimension():
+    from adt_str_amd import kernels as k
+    big_a, big_b = rnd((200, 512), 10).bfloat16(), rnd((300, 512), 11).bfloat16()
+    a, b = big_a[:, 128:384], big_b[:, 128:384]
+    out = torch.zeros((200, 400), dtype=torch.float32, device=DEV)
+    k.gemm(a, b, out=out[:, 50:350])
+    assert torch.all(out[:, :50] == 0) and torch.all(out[:, 350:] == 0)
+    close(out[:, 50:350], a.float() @ b.float().t(), 1e-4, "strided")
+
+
+def test_rejects_misaligned():
+    from adt_str_amd import _ffi, kernels as k
+    a, b = rnd((64, 68), 1).bfloat16(), rnd((64, 68), 2).bfloat16()
+    with pytest.raises(_ffi.AdtError):
+        k.gemm(a, b)
