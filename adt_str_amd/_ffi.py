@@ -26,6 +26,14 @@ class GemmEpilogue(C.Structure):
                 ("out_fp32", C.c_int32)]
 
 
+class AttnDesc(C.Structure):
+    """struct adt_attn_desc (include/adt_hip.h)."""
+    _fields_ = [("batch", C.c_int32), ("heads", C.c_int32), ("q_len", C.c_int32), ("k_len", C.c_int32),
+                ("head_dim", C.c_int32), ("causal", C.c_int32), ("ldq", C.c_int64), ("ldk", C.c_int64),
+                ("ldv", C.c_int64), ("ldo", C.c_int64), ("scale", C.c_float), ("mask_value", C.c_float),
+                ("key_len", C.c_void_p)]
+
+
 # name -> argtypes; every entry must be declared in include/adt_hip.h (tests check both ways)
 SIGNATURES = {
     "adt_version": [],
@@ -34,6 +42,9 @@ SIGNATURES = {
     "adt_mix_workspace_bytes": [i64, i64],
     "adt_gemm_workspace_bytes": [i32, i64, i64, i64],
     "adt_gemm_bf16": [i32, i64, i64, i64, ptr, i64, ptr, i64, ptr, i64, ptr, ptr, C.c_size_t, ptr],
+    "adt_attn_fwd": [ptr, ptr, ptr, ptr, ptr, ptr, ptr],
+    "adt_attn_bwd_workspace_bytes": [ptr],
+    "adt_attn_bwd": [ptr, ptr, ptr, ptr, ptr, ptr, ptr, ptr, ptr, ptr, ptr, C.c_size_t, ptr],
     "adt_layernorm_fwd": [ptr, i64, ptr, ptr, f32, ptr, ptr, i64, ptr, ptr, i64, i64, ptr],
     "adt_layernorm_bwd_workspace_bytes": [i64, i64],
     "adt_layernorm_bwd": [ptr, i64, ptr, i64, ptr, ptr, ptr, ptr, ptr, i64, ptr, ptr, ptr, i64, i64, ptr, C.c_size_t, ptr],
@@ -50,7 +61,7 @@ SIGNATURES = {
     "adt_mix_render_f32": [ptr, ptr, i64, ptr, i64, ptr, ptr, ptr, i64, i64, ptr, i64, ptr, C.c_size_t, ptr],
 }
 _RESTYPES = {"adt_last_error": C.c_char_p}
-_RESTYPES.update({n: C.c_size_t for n in ("adt_mix_workspace_bytes", "adt_gemm_workspace_bytes",
+_RESTYPES.update({n: C.c_size_t for n in ("adt_mix_workspace_bytes", "adt_gemm_workspace_bytes", "adt_attn_bwd_workspace_bytes",
                                           "adt_layernorm_bwd_workspace_bytes", "adt_colsum_workspace_bytes",
                                           "adt_cross_entropy_workspace_bytes", "adt_grad_norm_workspace_bytes")})
 

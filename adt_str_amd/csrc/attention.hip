@@ -1,0 +1,508 @@
+// attention.hip -- K4: flash-style multi-head attention forward / backward on MFMA (gfx950).
+//
+// Stands behind nn.MultiheadAttention inside the reference's nn.TransformerEncoderLayer /
+// nn.TransformerDecoderLayer (model.py:118-127 encoder self-attention, no mask; :159-168 decoder
+// self-attention with the additive causal + key-padding masks built at :173-181, and
+// cross-attention onto the encoder memory, no mask).  head_dim = 128.
+//
+// Layout: Q, K, V, O, dO are bf16 matrices [B*S, ld] whose head h occupies columns
+// [h*128, h*128+128) -- i.e. the packed in_proj output is consumed in place, no head permute.
+//
+// Every product uses v_mfma_f32_32x32x16_bf16 with the *softmax axis on the lane*:
+//   forward / dQ kernel : lane <-> query.  S^T = K Q^T  (A = K rows from LDS, B = Q^T held in
+//       registers), so one lane owns its query's scores, the row max/sum are in-register plus one
+//       cross-half shuffle, and the accumulator (keys on rows) is directly the B operand of
+//       O^T += V^T P^T  (A = V^T through ds_read_b64_tr_b16).  dQ^T += K^T dS^T the same way.
+//   dK/dV kernel        : lane <-> key.  S = Q K^T, dP = dO V^T (A = Q / dO rows from LDS,
+//       B = K^T / V^T in registers); P and dS (queries on rows) are the B operands of
+//       dV^T += dO^T P and dK^T += Q^T dS (A through transposed LDS reads).
+// K/V (or Q/dO) tiles of 64 rows x 256 B live in LDS under the XOR swizzle
+//   off(row, chunk) = 256*row + 16*(chunk ^ (((row&3)<<2) | ((row>>2)&3)))
+// which makes both the 16-byte row reads and the transposed 8-byte reads bank-conflict free.
+// Tiles are double-buffered: the next tile's global loads are issued before the MFMAs of the
+// current one and written to the other buffer afterwards (one barrier per tile).
+// The backward recomputes P from the saved log-sum-exp; dQ and dK/dV are separate kernels so no
+// float atomics are needed (bitwise reproducible).
+#include <hip/hip_runtime.h>
+
+#include "adt_common.h"
+
+namespace adt {
+
+typedef __attribute__((ext_vector_type(8))) short bf16x8;
+typedef __attribute__((ext_vector_type(4))) short bf16x4;
+typedef __attribute__((ext_vector_type(16))) float f32x16;
+
+constexpr int kDh = 128;
+constexpr int kAttnThreads = 256;
+constexpr int kRowsPerTile = 64;
+constexpr int kAttnTileBytes = kRowsPerTile * 256;   // 16 KiB
+constexpr float kLog2e = 1.4426950408889634f;
+constexpr float kLn2 = 0.6931471805599453f;
+constexpr float kNegBig = -1.0e30f;
+
+__device__ __forceinline__ unsigned lds_off(const void* p) {
+  return static_cast<unsigned>(reinterpret_cast<size_t>((__attribute__((address_space(3))) const void*)p));
+}
+__device__ __forceinline__ int swz(int row, int chunk) {
+  return 256 * row + 16 * (chunk ^ (((row & 3) << 2) | ((row >> 2) & 3)));
+}
+__device__ __forceinline__ unsigned pack2(float lo, float hi) {
+  const unsigned a = __builtin_bit_cast(unsigned short, static_cast<__bf16>(lo));
+  const unsigned b = __builtin_bit_cast(unsigned short, static_cast<__bf16>(hi));
+  return a | (b << 16);
+}
+// accumulator registers 8s .. 8s+7 of a 32x32 tile -> the bf16 B operand of k-step s (rows 16s..16s+15 of the tile)
+__device__ __forceinline__ bf16x8 acc_to_b(const f32x16& x, int s) {
+  union { unsigned u[4]; bf16x8 v; } r;
+  r.u[0] = pack2(x[8 * s + 0], x[8 * s + 1]); r.u[1] = pack2(x[8 * s + 2], x[8 * s + 3]);
+  r.u[2] = pack2(x[8 * s + 4], x[8 * s + 5]); r.u[3] = pack2(x[8 * s + 6], x[8 * s + 7]);
+  return r.v;
+}
+__device__ __forceinline__ int acc_row(int i, int h) { return (i & 3) + 8 * (i >> 2) + 4 * h; }
+
+// ---- tile staging: 64 rows x 128 bf16 of one head, rows >= n_rows read as zero --------------------
+__device__ __forceinline__ void tile_load(const unsigned short* __restrict__ base, long row_stride, int row0, int n_rows,
+                                          int tid, uint4 (&r)[4]) {
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int c = tid + kAttnThreads * i;
+    const int row = c >> 4, ch = c & 15;
+    uint4 v = make_uint4(0, 0, 0, 0);
+    if (row0 + row < n_rows) v = *reinterpret_cast<const uint4*>(base + static_cast<long>(row0 + row) * row_stride + ch * 8);
+    r[i] = v;
+  }
+}
+__device__ __forceinline__ void tile_store(unsigned char* tile, int tid, const uint4 (&r)[4]) {
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int c = tid + kAttnThreads * i;
+    *reinterpret_cast<uint4*>(tile + swz(c >> 4, c & 15)) = r[i];
+  }
+}
+// A operand, rows of the tile: tile row (rb*32 + lane&31), d = 16s + 8h .. +7
+__device__ __forceinline__ bf16x8 frag_rows(const unsigned char* tile, int rb, int s, int lane) {
+  return *reinterpret_cast<const bf16x8*>(tile + swz(rb * 32 + (lane & 31), 2 * s + (lane >> 5)));
+}
+// A operand, transposed tile: A[row = d = 32db + lane&31][element j] = tile[R0 + 8(j>>2) + 4h + (j&3)][d]
+__device__ __forceinline__ bf16x8 frag_tr(const unsigned char* tile, int R0, int db, int lane) {
+  const int i = lane & 15, g4 = (lane >> 4) & 1, h = lane >> 5;
+  const int row = R0 + 4 * h + (i >> 2);
+  const int chunk = 4 * db + 2 * g4 + ((i & 3) >> 1);
+  const unsigned base = lds_off(tile) + 8 * (i & 1);
+  const unsigned a0 = base + swz(row, chunk), a1 = base + swz(row + 8, chunk);
+  bf16x4 lo, hi;
+  asm volatile("ds_read_b64_tr_b16 %0, %2\n\tds_read_b64_tr_b16 %1, %3\n\ts_waitcnt lgkmcnt(0)"
+               : "=&v"(lo), "=&v"(hi) : "v"(a0), "v"(a1) : "memory");
+  bf16x8 r;
+  r[0] = lo[0]; r[1] = lo[1]; r[2] = lo[2]; r[3] = lo[3];
+  r[4] = hi[0]; r[5] = hi[1]; r[6] = hi[2]; r[7] = hi[3];
+  return r;
+}
+// B operand held in registers: row `row` of a global [*, stride] matrix, d = 16s + 8h .. +7, s = 0..7
+__device__ __forceinline__ void frags_from_global(const unsigned short* __restrict__ base, long row_stride, int row, int n_rows,
+                                                  int lane, bf16x8 (&f)[8]) {
+  const int h = lane >> 5;
+#pragma unroll
+  for (int s = 0; s < 8; ++s) {
+    uint4 v = make_uint4(0, 0, 0, 0);
+    if (row < n_rows) v = *reinterpret_cast<const uint4*>(base + static_cast<long>(row) * row_stride + 16 * s + 8 * h);
+    f[s] = *reinterpret_cast<bf16x8*>(&v);
+  }
+}
+// transposed accumulator [d][x] (4 blocks of 32 d) -> bf16 rows out[x][d]; lane owns x = lane&31
+__device__ __forceinline__ void store_transposed(const f32x16 (&acc)[4], float mul, unsigned short* __restrict__ base, long row_stride,
+                                                 int row, int n_rows, int lane) {
+  if (row >= n_rows) return;
+  const int h = lane >> 5;
+  unsigned short* p = base + static_cast<long>(row) * row_stride;
+#pragma unroll
+  for (int db = 0; db < 4; ++db)
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+      uint2 v;
+      v.x = pack2(acc[db][4 * g + 0] * mul, acc[db][4 * g + 1] * mul);
+      v.y = pack2(acc[db][4 * g + 2] * mul, acc[db][4 * g + 3] * mul);
+      *reinterpret_cast<uint2*>(p + 32 * db + 8 * g + 4 * h) = v;
+    }
+}
+
+struct AttnArgs {
+  const unsigned short *q, *k, *v, *o, *dout;
+  unsigned short *out, *dq, *dk, *dv;
+  float* lse; const float* delta;
+  long ldq, ldk, ldv, ldo;          // row strides (elements); gradients share the strides of their tensors
+  int B, H, Sq, Sk;
+  float scale, mask_value; int causal; const int* key_len;
+};
+
+// additive mask of the reference (model.py:173-181): causal and key-padding contributions add up
+__device__ __forceinline__ float mask_add(const AttnArgs& a, int qi, int ki, int klen) {
+  float m = 0.f;
+  if (a.causal && ki > qi) m += a.mask_value;
+  if (ki >= klen) m += a.mask_value;
+  return m;
+}
+
+// =============================================================================== forward
+__global__ __launch_bounds__(kAttnThreads) void attn_fwd_kernel(AttnArgs a) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];     // [2 stages][K tile | V tile]
+  const int tid = threadIdx.x, lane = tid & 63, r = lane & 31, h = lane >> 5;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int b = blockIdx.y / a.H, head = blockIdx.y % a.H;
+  const int q0 = blockIdx.x * 128 + wave * 32;
+  const int qi = q0 + r;
+  const unsigned short* qb = a.q + static_cast<long>(b) * a.Sq * a.ldq + head * kDh;
+  const unsigned short* kb_ = a.k + static_cast<long>(b) * a.Sk * a.ldk + head * kDh;
+  const unsigned short* vb = a.v + static_cast<long>(b) * a.Sk * a.ldv + head * kDh;
+  const int klen = a.key_len ? a.key_len[b] : a.Sk;
+  const float sl2 = a.scale * kLog2e;
+
+  bf16x8 qf[8];
+  frags_from_global(qb, a.ldq, qi, a.Sq, lane, qf);
+  f32x16 o[4];
+#pragma unroll
+  for (int db = 0; db < 4; ++db)
+#pragma unroll
+    for (int i = 0; i < 16; ++i) o[db][i] = 0.f;
+  float m = kNegBig, l = 0.f;
+
+  const int n_tiles = (a.Sk + kRowsPerTile - 1) / kRowsPerTile;
+  uint4 rk[4], rv[4];
+  tile_load(kb_, a.ldk, 0, a.Sk, tid, rk);
+  tile_load(vb, a.ldv, 0, a.Sk, tid, rv);
+  tile_store(smem, tid, rk);
+  tile_store(smem + kAttnTileBytes, tid, rv);
+  __syncthreads();
+
+  for (int t = 0; t < n_tiles; ++t) {
+    const unsigned char* tk = smem + (t & 1) * 2 * kAttnTileBytes;
+    const unsigned char* tv = tk + kAttnTileBytes;
+    const bool more = t + 1 < n_tiles;
+    if (more) {
+      tile_load(kb_, a.ldk, (t + 1) * kRowsPerTile, a.Sk, tid, rk);
+      tile_load(vb, a.ldv, (t + 1) * kRowsPerTile, a.Sk, tid, rv);
+    }
+    f32x16 st[2];
+#pragma unroll
+    for (int kb = 0; kb < 2; ++kb) {
+#pragma unroll
+      for (int i = 0; i < 16; ++i) st[kb][i] = 0.f;
+#pragma unroll
+      for (int s = 0; s < 8; ++s) st[kb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_rows(tk, kb, s, lane), qf[s], st[kb], 0, 0, 0);
+    }
+    float mloc = kNegBig;
+#pragma unroll
+    for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+      for (int i = 0; i < 16; ++i) {
+        const int ki = t * kRowsPerTile + kb * 32 + acc_row(i, h);
+        float tt = st[kb][i] * sl2 + mask_add(a, qi, ki, klen) * kLog2e;
+        if (ki >= a.Sk) tt = kNegBig;
+        st[kb][i] = tt;
+        mloc = fmaxf(mloc, tt);
+      }
+    mloc = fmaxf(mloc, __shfl_xor(mloc, 32));
+    const float m_new = fmaxf(m, mloc);
+    const float alpha = exp2f(m - m_new);
+    m = m_new;
+    l *= alpha;
+#pragma unroll
+    for (int db = 0; db < 4; ++db)
+#pragma unroll
+      for (int i = 0; i < 16; ++i) o[db][i] *= alpha;
+    float psum = 0.f;
+#pragma unroll
+    for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+      for (int i = 0; i < 16; ++i) { const float p = exp2f(st[kb][i] - m); st[kb][i] = p; psum += p; }
+    l += psum;
+#pragma unroll
+    for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+      for (int s2 = 0; s2 < 2; ++s2) {
+        const bf16x8 pf = acc_to_b(st[kb], s2);
+#pragma unroll
+        for (int db = 0; db < 4; ++db)
+          o[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_tr(tv, kb * 32 + 16 * s2, db, lane), pf, o[db], 0, 0, 0);
+      }
+    if (more) {
+      unsigned char* nk = smem + ((t + 1) & 1) * 2 * kAttnTileBytes;
+      tile_store(nk, tid, rk);
+      tile_store(nk + kAttnTileBytes, tid, rv);
+    }
+    __syncthreads();
+  }
+  const float lt = l + __shfl_xor(l, 32);
+  const float inv = 1.0f / lt;
+  store_transposed(o, inv, a.out + static_cast<long>(b) * a.Sq * a.ldo + head * kDh, a.ldo, qi, a.Sq, lane);
+  if (h == 0 && qi < a.Sq && a.lse) a.lse[(static_cast<long>(b) * a.H + head) * a.Sq + qi] = (m + log2f(lt)) * kLn2;
+}
+
+// =============================================================================== backward: delta = rowsum(dO * O)
+__global__ __launch_bounds__(256) void attn_delta_kernel(const unsigned short* __restrict__ o, const unsigned short* __restrict__ dout,
+                                                         long ldo, int B, int H, int Sq, float* __restrict__ delta) {
+  const int lane = threadIdx.x & 63;
+  const long idx = static_cast<long>(blockIdx.x) * 4 + (threadIdx.x >> 6);       // (b, q, head)
+  const long total = static_cast<long>(B) * Sq * H;
+  if (idx >= total) return;
+  const int head = static_cast<int>(idx % H);
+  const long bq = idx / H;
+  const int qi = static_cast<int>(bq % Sq), b = static_cast<int>(bq / Sq);
+  const long off = bq * ldo + head * kDh + 2 * lane;
+  const unsigned ov = *reinterpret_cast<const unsigned*>(o + off), dv = *reinterpret_cast<const unsigned*>(dout + off);
+  float s = __uint_as_float(ov << 16) * __uint_as_float(dv << 16) + __uint_as_float(ov & 0xffff0000u) * __uint_as_float(dv & 0xffff0000u);
+#pragma unroll
+  for (int k = 32; k > 0; k >>= 1) s += __shfl_xor(s, k);
+  if (lane == 0) delta[(static_cast<long>(b) * H + head) * Sq + qi] = s;
+}
+
+// =============================================================================== backward: dQ  (lane <-> query)
+__global__ __launch_bounds__(kAttnThreads) void attn_bwd_dq_kernel(AttnArgs a) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  const int tid = threadIdx.x, lane = tid & 63, r = lane & 31, h = lane >> 5;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int b = blockIdx.y / a.H, head = blockIdx.y % a.H;
+  const int qi = blockIdx.x * 128 + wave * 32 + r;
+  const unsigned short* qb = a.q + static_cast<long>(b) * a.Sq * a.ldq + head * kDh;
+  const unsigned short* dob = a.dout + static_cast<long>(b) * a.Sq * a.ldo + head * kDh;
+  const unsigned short* kb_ = a.k + static_cast<long>(b) * a.Sk * a.ldk + head * kDh;
+  const unsigned short* vb = a.v + static_cast<long>(b) * a.Sk * a.ldv + head * kDh;
+  const int klen = a.key_len ? a.key_len[b] : a.Sk;
+  const float sl2 = a.scale * kLog2e;
+  const long stat = (static_cast<long>(b) * a.H + head) * a.Sq + (qi < a.Sq ? qi : 0);
+  const float lse2 = a.lse[stat] * kLog2e, dlt = a.delta[stat];
+
+  bf16x8 qf[8], dof[8];
+  frags_from_global(qb, a.ldq, qi, a.Sq, lane, qf);
+  frags_from_global(dob, a.ldo, qi, a.Sq, lane, dof);
+  f32x16 dq[4];
+#pragma unroll
+  for (int db = 0; db < 4; ++db)
+#pragma unroll
+    for (int i = 0; i < 16; ++i) dq[db][i] = 0.f;
+
+  const int n_tiles = (a.Sk + kRowsPerTile - 1) / kRowsPerTile;
+  uint4 rk[4], rv[4];
+  tile_load(kb_, a.ldk, 0, a.Sk, tid, rk);
+  tile_load(vb, a.ldv, 0, a.Sk, tid, rv);
+  tile_store(smem, tid, rk);
+  tile_store(smem + kAttnTileBytes, tid, rv);
+  __syncthreads();
+  for (int t = 0; t < n_tiles; ++t) {
+    const unsigned char* tk = smem + (t & 1) * 2 * kAttnTileBytes;
+    const unsigned char* tv = tk + kAttnTileBytes;
+    const bool more = t + 1 < n_tiles;
+    if (more) {
+      tile_load(kb_, a.ldk, (t + 1) * kRowsPerTile, a.Sk, tid, rk);
+      tile_load(vb, a.ldv, (t + 1) * kRowsPerTile, a.Sk, tid, rv);
+    }
+#pragma unroll
+    for (int kb = 0; kb < 2; ++kb) {
+      f32x16 st, dp;
+#pragma unroll
+      for (int i = 0; i < 16; ++i) { st[i] = 0.f; dp[i] = 0.f; }
+#pragma unroll
+      for (int s = 0; s < 8; ++s) {
+        st = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_rows(tk, kb, s, lane), qf[s], st, 0, 0, 0);
+        dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_rows(tv, kb, s, lane), dof[s], dp, 0, 0, 0);
+      }
+#pragma unroll
+      for (int i = 0; i < 16; ++i) {
+        const int ki = t * kRowsPerTile + kb * 32 + acc_row(i, h);
+        const float tt = st[i] * sl2 + mask_add(a, qi, ki, klen) * kLog2e;
+        const float p = ki < a.Sk ? exp2f(tt - lse2) : 0.f;
+        st[i] = p * (dp[i] - dlt) * a.scale;                 // dS^T
+      }
+#pragma unroll
+      for (int s2 = 0; s2 < 2; ++s2) {
+        const bf16x8 dsf = acc_to_b(st, s2);
+#pragma unroll
+        for (int db = 0; db < 4; ++db)
+          dq[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_tr(tk, kb * 32 + 16 * s2, db, lane), dsf, dq[db], 0, 0, 0);
+      }
+    }
+    if (more) {
+      unsigned char* nk = smem + ((t + 1) & 1) * 2 * kAttnTileBytes;
+      tile_store(nk, tid, rk);
+      tile_store(nk + kAttnTileBytes, tid, rv);
+    }
+    __syncthreads();
+  }
+  store_transposed(dq, 1.0f, a.dq + static_cast<long>(b) * a.Sq * a.ldq + head * kDh, a.ldq, qi, a.Sq, lane);
+}
+
+// =============================================================================== backward: dK, dV  (lane <-> key)
+__global__ __launch_bounds__(kAttnThreads, 1) void attn_bwd_dkv_kernel(AttnArgs a) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];     // [2 stages][Q tile | dO tile | lse2[64] | delta[64]]
+  constexpr int kStage = 2 * kAttnTileBytes + 512;
+  const int tid = threadIdx.x, lane = tid & 63, r = lane & 31, h = lane >> 5;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int b = blockIdx.y / a.H, head = blockIdx.y % a.H;
+  const int ki = blockIdx.x * 128 + wave * 32 + r;
+  const unsigned short* qb = a.q + static_cast<long>(b) * a.Sq * a.ldq + head * kDh;
+  const unsigned short* dob = a.dout + static_cast<long>(b) * a.Sq * a.ldo + head * kDh;
+  const unsigned short* kb_ = a.k + static_cast<long>(b) * a.Sk * a.ldk + head * kDh;
+  const unsigned short* vb = a.v + static_cast<long>(b) * a.Sk * a.ldv + head * kDh;
+  const int klen = a.key_len ? a.key_len[b] : a.Sk;
+  const float sl2 = a.scale * kLog2e;
+  const float* lse_b = a.lse + (static_cast<long>(b) * a.H + head) * a.Sq;
+  const float* dl_b = a.delta + (static_cast<long>(b) * a.H + head) * a.Sq;
+
+  bf16x8 kf[8], vf[8];
+  frags_from_global(kb_, a.ldk, ki, a.Sk, lane, kf);
+  frags_from_global(vb, a.ldv, ki, a.Sk, lane, vf);
+  f32x16 dk[4], dv[4];
+#pragma unroll
+  for (int db = 0; db < 4; ++db)
+#pragma unroll
+    for (int i = 0; i < 16; ++i) { dk[db][i] = 0.f; dv[db][i] = 0.f; }
+
+  const int n_tiles = (a.Sq + kRowsPerTile - 1) / kRowsPerTile;
+  uint4 rq[4], rd[4];
+  float rs = 0.f;
+  auto load_stats = [&](int t) {                      // threads 0..63: lse2, 64..127: delta of the tile's 64 queries
+    const int qq = t * kRowsPerTile + (tid & 63);
+    rs = 0.f;
+    if (tid < 128 && qq < a.Sq) rs = tid < 64 ? lse_b[qq] * kLog2e : dl_b[qq];
+  };
+  auto store_stats = [&](unsigned char* stage) {
+    if (tid < 128) reinterpret_cast<float*>(stage + 2 * kAttnTileBytes)[tid] = rs;
+  };
+  tile_load(qb, a.ldq, 0, a.Sq, tid, rq);
+  tile_load(dob, a.ldo, 0, a.Sq, tid, rd);
+  load_stats(0);
+  tile_store(smem, tid, rq);
+  tile_store(smem + kAttnTileBytes, tid, rd);
+  store_stats(smem);
+  __syncthreads();
+  for (int t = 0; t < n_tiles; ++t) {
+    const unsigned char* tq = smem + (t & 1) * kStage;
+    const unsigned char* td = tq + kAttnTileBytes;
+    const float* stats = reinterpret_cast<const float*>(tq + 2 * kAttnTileBytes);
+    const bool more = t + 1 < n_tiles;
+    if (more) {
+      tile_load(qb, a.ldq, (t + 1) * kRowsPerTile, a.Sq, tid, rq);
+      tile_load(dob, a.ldo, (t + 1) * kRowsPerTile, a.Sq, tid, rd);
+      load_stats(t + 1);
+    }
+#pragma unroll
+    for (int qblk = 0; qblk < 2; ++qblk) {
+      f32x16 st, dp;
+#pragma unroll
+      for (int i = 0; i < 16; ++i) { st[i] = 0.f; dp[i] = 0.f; }
+#pragma unroll
+      for (int s = 0; s < 8; ++s) {
+        st = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_rows(tq, qblk, s, lane), kf[s], st, 0, 0, 0);
+        dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_rows(td, qblk, s, lane), vf[s], dp, 0, 0, 0);
+      }
+#pragma unroll
+      for (int i = 0; i < 16; ++i) {
+        const int ql = qblk * 32 + acc_row(i, h);
+        const int qi = t * kRowsPerTile + ql;
+        const float tt = st[i] * sl2 + mask_add(a, qi, ki, klen) * kLog2e;
+        const float p = (qi < a.Sq && ki < a.Sk) ? exp2f(tt - stats[ql]) : 0.f;
+        st[i] = p;                                           // P
+        dp[i] = p * (dp[i] - stats[64 + ql]) * a.scale;      // dS
+      }
+#pragma unroll
+      for (int s2 = 0; s2 < 2; ++s2) {
+        const bf16x8 pf = acc_to_b(st, s2), dsf = acc_to_b(dp, s2);
+#pragma unroll
+        for (int db = 0; db < 4; ++db) {
+          dv[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_tr(td, qblk * 32 + 16 * s2, db, lane), pf, dv[db], 0, 0, 0);
+          dk[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_tr(tq, qblk * 32 + 16 * s2, db, lane), dsf, dk[db], 0, 0, 0);
+        }
+      }
+    }
+    if (more) {
+      unsigned char* ns = smem + ((t + 1) & 1) * kStage;
+      tile_store(ns, tid, rq);
+      tile_store(ns + kAttnTileBytes, tid, rd);
+      store_stats(ns);
+    }
+    __syncthreads();
+  }
+  store_transposed(dk, 1.0f, a.dk + static_cast<long>(b) * a.Sk * a.ldk + head * kDh, a.ldk, ki, a.Sk, lane);
+  store_transposed(dv, 1.0f, a.dv + static_cast<long>(b) * a.Sk * a.ldv + head * kDh, a.ldv, ki, a.Sk, lane);
+}
+
+static int check_desc(const adt_attn_desc* d, const char* who) {
+  if (!d) return set_error(ADT_EINVAL, "attention: null descriptor");
+  if (d->head_dim != kDh) return set_error(ADT_ESHAPE, "attention: head_dim must be 128");
+  if (d->batch < 0 || d->heads <= 0 || d->q_len < 0 || d->k_len < 0) return set_error(ADT_EINVAL, "attention: bad sizes");
+  const int64_t need = static_cast<int64_t>(d->heads) * kDh;
+  if (d->ldq < need || d->ldk < need || d->ldv < need || d->ldo < need || (d->ldq & 7) || (d->ldk & 7) || (d->ldv & 7) || (d->ldo & 7))
+    return set_error(ADT_ESHAPE, "attention: row strides must cover heads*128 columns and be multiples of 8");
+  if (static_cast<int64_t>(d->batch) * d->heads > 65535) return set_error(ADT_ESHAPE, "attention: batch*heads must be <= 65535");
+  (void)who;
+  return ADT_OK;
+}
+static AttnArgs make_args(const adt_attn_desc* d) {
+  AttnArgs a{};
+  a.ldq = d->ldq; a.ldk = d->ldk; a.ldv = d->ldv; a.ldo = d->ldo;
+  a.B = d->batch; a.H = d->heads; a.Sq = d->q_len; a.Sk = d->k_len;
+  a.scale = d->scale; a.mask_value = d->mask_value; a.causal = d->causal; a.key_len = d->key_len;
+  return a;
+}
+static int set_lds_once() {      // raise the dynamic-LDS limit of the three kernels once per device and thread
+  static thread_local int done_for = -1;
+  int dev = 0;
+  ADT_HIP_TRY(hipGetDevice(&dev));
+  if (done_for == dev) return ADT_OK;
+  ADT_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(attn_fwd_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 4 * kAttnTileBytes));
+  ADT_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(attn_bwd_dq_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 4 * kAttnTileBytes));
+  ADT_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(attn_bwd_dkv_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                  2 * (2 * kAttnTileBytes + 512)));
+  done_for = dev;
+  return ADT_OK;
+}
+
+}  // namespace adt
+
+using namespace adt;
+
+extern "C" int adt_attn_fwd(const adt_attn_desc* d, const void* q, const void* k, const void* v, void* o, float* lse, void* stream) {
+  if (int rc = check_desc(d, "adt_attn_fwd")) return rc;
+  if (!q || !k || !v || !o) return set_error(ADT_EINVAL, "adt_attn_fwd: null pointer");
+  if (!aligned16(q) || !aligned16(k) || !aligned16(v) || !aligned16(o)) return set_error(ADT_EINVAL, "adt_attn_fwd: tensors must be 16-byte aligned");
+  if (d->batch == 0 || d->q_len == 0) return ADT_OK;
+  if (d->k_len == 0) return set_error(ADT_ESHAPE, "adt_attn_fwd: k_len must be > 0");
+  AttnArgs a = make_args(d);
+  a.q = static_cast<const unsigned short*>(q); a.k = static_cast<const unsigned short*>(k); a.v = static_cast<const unsigned short*>(v);
+  a.out = static_cast<unsigned short*>(o); a.lse = lse;
+  const int lds = 4 * kAttnTileBytes;
+  if (int rc = set_lds_once()) return rc;
+  hipLaunchKernelGGL(attn_fwd_kernel, dim3((d->q_len + 127) / 128, d->batch * d->heads), dim3(kAttnThreads), lds,
+                     static_cast<hipStream_t>(stream), a);
+  ADT_HIP_TRY(hipGetLastError());
+  return ADT_OK;
+}
+
+extern "C" size_t adt_attn_bwd_workspace_bytes(const adt_attn_desc* d) {
+  if (!d || d->batch <= 0 || d->heads <= 0 || d->q_len <= 0) return 16;
+  return static_cast<size_t>(d->batch) * d->heads * d->q_len * 4 + 16;
+}
+
+extern "C" int adt_attn_bwd(const adt_attn_desc* d, const void* q, const void* k, const void* v, const void* o, const void* dout,
+                            const float* lse, void* dq, void* dk, void* dv, void* ws, size_t ws_bytes, void* stream) {
+  if (int rc = check_desc(d, "adt_attn_bwd")) return rc;
+  if (!q || !k || !v || !o || !dout || !lse || !dq || !dk || !dv) return set_error(ADT_EINVAL, "adt_attn_bwd: null pointer");
+  if (!ws || ws_bytes < adt_attn_bwd_workspace_bytes(d)) return set_error(ADT_EINVAL, "adt_attn_bwd: workspace too small");
+  if (d->batch == 0 || d->q_len == 0 || d->k_len == 0) return ADT_OK;
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  AttnArgs a = make_args(d);
+  a.q = static_cast<const unsigned short*>(q); a.k = static_cast<const unsigned short*>(k); a.v = static_cast<const unsigned short*>(v);
+  a.o = static_cast<const unsigned short*>(o); a.dout = static_cast<const unsigned short*>(dout);
+  a.lse = const_cast<float*>(lse); a.delta = static_cast<const float*>(ws);
+  a.dq = static_cast<unsigned short*>(dq); a.dk = static_cast<unsigned short*>(dk); a.dv = static_cast<unsigned short*>(dv);
+  const long rows = static_cast<long>(d->batch) * d->q_len * d->heads;
+  hipLaunchKernelGGL(attn_delta_kernel, dim3(static_cast<unsigned>((rows + 3) / 4)), dim3(256), 0, st, a.o, a.dout, a.ldo, a.B, a.H, a.Sq,
+                     static_cast<float*>(ws));
+  const int lds_dq = 4 * kAttnTileBytes, lds_dkv = 2 * (2 * kAttnTileBytes + 512);
+  if (int rc = set_lds_once()) return rc;
+  hipLaunchKernelGGL(attn_bwd_dq_kernel, dim3((d->q_len + 127) / 128, d->batch * d->heads), dim3(kAttnThreads), lds_dq, st, a);
+  hipLaunchKernelGGL(attn_bwd_dkv_kernel, dim3((d->k_len + 127) / 128, d->batch * d->heads), dim3(kAttnThreads), lds_dkv, st, a);
+  ADT_HIP_TRY(hipGetLastError());
+  return ADT_OK;
+}

@@ -167,3 +167,39 @@ def adamw_step(p, g, m, v, step, lr, beta1=0.9, beta2=0.999, eps=1e-8, weight_de
         assert t.dtype == torch.float32 and t.is_contiguous() and t.numel() == p.numel()
     _ffi.call("adt_adamw_step", _ffi.dptr(p), _ffi.dptr(g), _ffi.dptr(m), _ffi.dptr(v), _p(p_bf16), p.numel(), lr, beta1, beta2,
               eps, weight_decay, step, _p(norm_and_clip), _ffi.current_stream())
+
+
+def _attn_desc(B, H, Sq, Sk, q, k, v, o, scale, causal, key_len, mask_value):
+    d = _ffi.AttnDesc()
+    d.batch, d.heads, d.q_len, d.k_len, d.head_dim = B, H, Sq, Sk, 128
+    d.causal = 1 if causal else 0
+    d.ldq, d.ldk, d.ldv, d.ldo = q.stride(0), k.stride(0), v.stride(0), o.stride(0)
+    d.scale, d.mask_value = scale, mask_value
+    if key_len is not None:
+        assert key_len.dtype == torch.int32 and key_len.numel() == B
+        d.key_len = _ffi.dptr(key_len)
+    return d
+
+
+def attn_fwd(q, k, v, B, H, Sq, Sk, scale, causal=False, key_len=None, mask_value=-1e4, out=None):
+    """q [B*Sq, >=H*128], k/v [B*Sk, >=H*128] bf16 (row-strided views allowed) -> (o [B*Sq, H*128] bf16, lse [B,H,Sq] fp32)."""
+    for t in (q, k, v):
+        assert t.dtype == torch.bfloat16 and t.dim() == 2 and t.stride(1) == 1
+    if out is None:
+        out = torch.empty((B * Sq, H * 128), dtype=torch.bfloat16, device=q.device)
+    lse = torch.empty((B, H, Sq), dtype=torch.float32, device=q.device)
+    d = _attn_desc(B, H, Sq, Sk, q, k, v, out, scale, causal, key_len, mask_value)
+    _ffi.call("adt_attn_fwd", C.byref(d), _ffi.dptr(q), _ffi.dptr(k), _ffi.dptr(v), _ffi.dptr(out), _ffi.dptr(lse),
+              _ffi.current_stream())
+    return out, lse
+
+
+def attn_bwd(q, k, v, o, dout, lse, dq, dk, dv, B, H, Sq, Sk, scale, causal=False, key_len=None, mask_value=-1e4):
+    """Writes dq/dk/dv (bf16 views with the strides of q/k/v)."""
+    assert dq.stride(0) == q.stride(0) and dk.stride(0) == k.stride(0) and dv.stride(0) == v.stride(0)
+    assert dout.stride(0) == o.stride(0)
+    d = _attn_desc(B, H, Sq, Sk, q, k, v, o, scale, causal, key_len, mask_value)
+    nb = _ffi.load().adt_attn_bwd_workspace_bytes(C.byref(d))
+    ws = _workspace(nb, q.device)
+    _ffi.call("adt_attn_bwd", C.byref(d), _ffi.dptr(q), _ffi.dptr(k), _ffi.dptr(v), _ffi.dptr(o), _ffi.dptr(dout),
+              _ffi.dptr(lse), _ffi.dptr(dq), _ffi.dptr(dk), _ffi.dptr(dv), _ffi.dptr(ws), nb, _ffi.current_stream())

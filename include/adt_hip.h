@@ -150,6 +150,41 @@ int adt_gemm_bf16(int32_t trans, int64_t M, int64_t N, int64_t K, const void* A,
                   void* ws, size_t ws_bytes, void* stream);
 
 /* ---------------------------------------------------------------------------
+ * K4  multi-head attention forward / backward (flash-style, MFMA, head_dim 128)
+ *
+ * Replaces nn.MultiheadAttention's scaled-dot-product core inside the reference's
+ * transformer layers: encoder self-attention (reference model.py:118-127,133; no mask),
+ * decoder self-attention with the ADDITIVE causal and key-padding masks of
+ * model.py:173-181 (0 / mask_value = -1e4, the two add up), and cross-attention
+ * onto the encoder memory (:182-189; no mask).
+ *
+ * q, k, v, o (and dout, dq, dk, dv) are bf16 matrices of B*q_len or B*k_len rows;
+ * row r of batch b is b*len + r, head h occupies columns [h*128, h*128+128), and
+ * ldq/ldk/ldv/ldo are the row strides in elements -- so a packed in_proj output
+ * [B*S, 3*d] is consumed in place (q at column 0, k at d, v at 2d; ld = 3d).
+ * dq/dk/dv use the strides of q/k/v.
+ *   o   = softmax(q k^T * scale + mask) v
+ *   lse = log-sum-exp of each score row, fp32 [B, heads, q_len] (kept for backward)
+ *   key_len (optional, int32 [B]): keys >= key_len[b] get mask_value added
+ *   causal != 0: keys > query index get mask_value added
+ * The backward recomputes the probabilities from lse (two kernels: dq; dk+dv),
+ * without float atomics.  ws: adt_attn_bwd_workspace_bytes.
+ */
+typedef struct adt_attn_desc {
+  int32_t batch, heads, q_len, k_len, head_dim;
+  int32_t causal;
+  int64_t ldq, ldk, ldv, ldo;
+  float   scale;
+  float   mask_value;
+  const int32_t* key_len;
+} adt_attn_desc;
+
+int adt_attn_fwd(const adt_attn_desc* d, const void* q, const void* k, const void* v, void* o, float* lse, void* stream);
+size_t adt_attn_bwd_workspace_bytes(const adt_attn_desc* d);
+int adt_attn_bwd(const adt_attn_desc* d, const void* q, const void* k, const void* v, const void* o, const void* dout,
+                 const float* lse, void* dq, void* dk, void* dv, void* ws, size_t ws_bytes, void* stream);
+
+/* ---------------------------------------------------------------------------
  * K6  LayerNorm forward / backward  (nn.LayerNorm(d), eps 1e-5, fp32 statistics)
  *
  * Replaces norm1/norm2/norm3 of the post-norm transformer layers and

@@ -1,0 +1,102 @@
+"""K4 attention parity on the GPU vs a plain PyTorch fp32 reference of the same op
+(softmax(q k^T * scale + additive mask) v on the same bf16-rounded q, k, v).
+
+Tolerances: the kernel rounds P (and dS) to bf16 before the second product and
+stores bf16, so |o - ref| <= 2e-2 * max|ref| and gradients within 4e-2 of their
+max; log-sum-exp is fp32 (1e-3 absolute on scores that are bf16 products)."""
+import math
+
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+
+def rnd(shape, seed, scale=1.0):
+    g = torch.Generator().manual_seed(seed)
+    return (torch.randn(shape, generator=g) * scale).to(DEV)
+
+
+def reference(q, k, v, B, H, Sq, Sk, scale, causal, key_len, mask_value=-1e4):
+    qh = q.float().view(B, Sq, H, 128).transpose(1, 2)
+    kh = k.float().view(B, Sk, H, 128).transpose(1, 2)
+    vh = v.float().view(B, Sk, H, 128).transpose(1, 2)
+    s = qh @ kh.transpose(-1, -2) * scale
+    if causal:
+        s = s + torch.triu(torch.ones(Sq, Sk, device=DEV, dtype=torch.bool), 1).float() * mask_value
+    if key_len is not None:
+        pad = (torch.arange(Sk, device=DEV)[None, :] >= key_len[:, None]).float() * mask_value
+        s = s + pad[:, None, None, :]
+    p = torch.softmax(s, dim=-1)
+    o = (p @ vh).transpose(1, 2).reshape(B * Sq, H * 128)
+    return o, torch.logsumexp(s, dim=-1)
+
+
+CASES = [  # B, H, Sq, Sk, causal, padded
+    (2, 2, 128, 128, False, False),
+    (1, 1, 32, 64, False, False),
+    (2, 6, 986, 986, False, False),      # encoder self-attention shape (10 s clip)
+    (3, 6, 128, 986, False, False),      # cross-attention
+    (4, 6, 128, 128, True, True),        # decoder self-attention with both additive masks
+    (2, 3, 77, 50, True, True),          # ragged sizes
+    (1, 2, 1, 200, False, False),        # single query row (greedy decode step)
+]
+
+
+@pytest.mark.parametrize("B,H,Sq,Sk,causal,padded", CASES)
+def test_forward_and_backward(B, H, Sq, Sk, causal, padded):
+    from adt_str_amd import kernels as k
+    d = H * 128
+    # packed projections: q from a [B*Sq, 3d] buffer, k/v from a [B*Sk, 3d] buffer (row-strided views)
+    qkv_q = rnd((B * Sq, 3 * d), 1).bfloat16()
+    qkv_k = qkv_q if Sq == Sk else rnd((B * Sk, 3 * d), 2).bfloat16()
+    q, kk, v = qkv_q[:, :d], qkv_k[:, d:2 * d], qkv_k[:, 2 * d:]
+    key_len = None
+    if padded:
+        key_len = torch.tensor([max(1, Sk - 7 * (i + 1)) for i in range(B)], dtype=torch.int32, device=DEV)
+    scale = 1.0 / math.sqrt(128)
+    o, lse = k.attn_fwd(q, kk, v, B, H, Sq, Sk, scale, causal, key_len)
+    qr, kr, vr = (t.float().clone().requires_grad_(True) for t in (q, kk, v))
+    ref_o, ref_lse = reference(qr, kr, vr, B, H, Sq, Sk, scale, causal, key_len.long() if padded else None)
+    assert (o.float() - ref_o).abs().max() <= 2e-2 * ref_o.abs().max()
+    assert (lse - ref_lse).abs().max() <= 2e-3
+    dout = rnd((B * Sq, d), 3).bfloat16()
+    ref_o.backward(dout.float())
+    dqkv_q = torch.zeros_like(qkv_q)
+    dqkv_k = dqkv_q if Sq == Sk else torch.zeros_like(qkv_k)
+    dq, dk, dv = dqkv_q[:, :d], dqkv_k[:, d:2 * d], dqkv_k[:, 2 * d:]
+    k.attn_bwd(q, kk, v, o, dout, lse, dq, dk, dv, B, H, Sq, Sk, scale, causal, key_len)
+    for name, got, ref in (("dq", dq, qr.grad), ("dk", dk, kr.grad), ("dv", dv, vr.grad)):
+        err = (got.float() - ref).abs().max().item()
+        assert err <= 4e-2 * ref.abs().max().item() + 1e-6, f"{name}: {err} vs max {ref.abs().max().item()}"
+    # reproducible: no atomics anywhere
+    o2, lse2 = k.attn_fwd(q, kk, v, B, H, Sq, Sk, scale, causal, key_len)
+    assert torch.equal(o, o2) and torch.equal(lse, lse2)
+
+
+def test_exact_selector():
+    """One-hot keys and integer values: P is exactly one-hot after softmax of a huge score gap,
+    so the output must equal the selected V row bit for bit (catches any key/lane permutation)."""
+    from adt_str_amd import kernels as k
+    B, H, S = 1, 1, 128
+    q = torch.zeros((S, 128), device=DEV)
+    kk = torch.zeros((S, 128), device=DEV)
+    perm = torch.randperm(S, generator=torch.Generator().manual_seed(0)).to(DEV)
+    q[torch.arange(S), torch.arange(S) % 128] = 64.0                    # query i looks along axis i
+    kk[perm, torch.arange(S) % 128] = 64.0                              # key perm[i] answers it
+    v = torch.randint(-8, 9, (S, 128), generator=torch.Generator().manual_seed(1)).float().to(DEV)
+    o, _ = k.attn_fwd(q.bfloat16(), kk.bfloat16(), v.bfloat16(), B, H, S, S, 1.0)
+    assert torch.equal(o.float(), v[perm])
+
+
+def test_rejects_other_head_dims():
+    from adt_str_amd import _ffi
+    import ctypes as C
+    d = _ffi.AttnDesc()
+    d.batch, d.heads, d.q_len, d.k_len, d.head_dim = 1, 1, 8, 8, 64
+    d.ldq = d.ldk = d.ldv = d.ldo = 64
+    x = torch.zeros(64, device=DEV)
+    with pytest.raises(_ffi.AdtError) as e:
+        _ffi.call("adt_attn_fwd", C.byref(d), x.data_ptr(), x.data_ptr(), x.data_ptr(), x.data_ptr(), x.data_ptr(), 0)
+    assert e.value.code == -2
