@@ -23,7 +23,7 @@ class GemmEpilogue(C.Structure):
     _fields_ = [("bias", C.c_void_p), ("gelu_grad_of", C.c_void_p), ("ld_gelu_grad", C.c_int64),
                 ("pre_act_out", C.c_void_p), ("ld_pre_act", C.c_int64), ("residual", C.c_void_p),
                 ("ld_res", C.c_int64), ("res_row_mod", C.c_int32), ("act", C.c_int32), ("alpha", C.c_float),
-                ("out_fp32", C.c_int32)]
+                ("out_fp32", C.c_int32), ("aux_bf16_out", C.c_void_p), ("ld_aux", C.c_int64)]
 
 
 class AttnDesc(C.Structure):

@@ -202,6 +202,7 @@ __global__ __launch_bounds__(kGemmThreads) void gemm_bf16_kernel(GemmArgs g) {
           const long rr = ep.res_row_mod > 0 ? (row % ep.res_row_mod) : row;
           z += reinterpret_cast<const float*>(ep.residual)[rr * ep.ld_res + col];
         }
+        if (ep.aux_bf16_out) reinterpret_cast<unsigned short*>(ep.aux_bf16_out)[static_cast<long>(row) * ep.ld_aux + col] = f2bf(z);
         if (ep.out_fp32) reinterpret_cast<float*>(g.C)[static_cast<long>(row) * g.ldc + col] = z;
         else reinterpret_cast<unsigned short*>(g.C)[static_cast<long>(row) * g.ldc + col] = f2bf(z);
       }
@@ -268,7 +269,7 @@ extern "C" int adt_gemm_bf16(int32_t trans, int64_t M, int64_t N, int64_t K, con
     if (int rc = device_cu_count(&n_cu)) return rc;
     splits = pick_splits(g.M, g.N, g.K, n_cu);
     if (splits > 1) {
-      if (!e.out_fp32 || e.bias || e.residual || e.act || e.pre_act_out || e.gelu_grad_of || (N & 3))
+      if (!e.out_fp32 || e.bias || e.residual || e.act || e.pre_act_out || e.gelu_grad_of || e.aux_bf16_out || (N & 3))
         splits = 1;                                  // split-K only for the plain fp32 weight-gradient form
       else if (!ws || ws_bytes < static_cast<size_t>(splits) * M * N * 4)
         return set_error(ADT_EINVAL, "adt_gemm_bf16: workspace too small (see adt_gemm_workspace_bytes)");

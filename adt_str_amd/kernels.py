@@ -28,7 +28,8 @@ def _workspace(nbytes: int, device) -> torch.Tensor:
 def gemm(a: torch.Tensor, b: torch.Tensor, *, trans: bool = False, out: Optional[torch.Tensor] = None,
          out_dtype=torch.bfloat16, bias: Optional[torch.Tensor] = None, residual: Optional[torch.Tensor] = None,
          res_row_mod: int = 0, act: int = 0, pre_act_out: Optional[torch.Tensor] = None,
-         gelu_grad_of: Optional[torch.Tensor] = None, alpha: float = 1.0) -> torch.Tensor:
+         gelu_grad_of: Optional[torch.Tensor] = None, alpha: float = 1.0,
+         aux_bf16_out: Optional[torch.Tensor] = None) -> torch.Tensor:
     """``trans=False``: ``a[M,K] @ b[N,K].T``; ``trans=True``: ``a[K,M].T @ b[K,N]`` (bf16 in, fp32 accumulate)."""
     assert a.dtype == torch.bfloat16 and b.dtype == torch.bfloat16 and a.dim() == 2 and b.dim() == 2
     assert a.stride(1) == 1 and b.stride(1) == 1
@@ -58,6 +59,9 @@ def gemm(a: torch.Tensor, b: torch.Tensor, *, trans: bool = False, out: Optional
     if gelu_grad_of is not None:
         assert gelu_grad_of.dtype == torch.bfloat16 and gelu_grad_of.shape == (M, N)
         ep.gelu_grad_of, ep.ld_gelu_grad = _ffi.dptr(gelu_grad_of), gelu_grad_of.stride(0)
+    if aux_bf16_out is not None:
+        assert aux_bf16_out.dtype == torch.bfloat16 and aux_bf16_out.shape == (M, N)
+        ep.aux_bf16_out, ep.ld_aux = _ffi.dptr(aux_bf16_out), aux_bf16_out.stride(0)
     ws_bytes = _ffi.load().adt_gemm_workspace_bytes(int(trans), M, N, K) if trans else 0
     ws = _workspace(ws_bytes, a.device) if ws_bytes else None
     _ffi.call("adt_gemm_bf16", int(trans), M, N, K, _ffi.dptr(a), a.stride(0), _ffi.dptr(b), b.stride(0),

@@ -1,0 +1,480 @@
+"""ADT network on the gfx950 kernels: drop-in for the reference's ``ADTModel``
+(``model.py:193-324``), ``Encoder`` (``:100-135``), ``Decoder`` (``:138-190``),
+``TokenEmbedding_plain`` (``:42-49``) and ``PositionalEncoding`` (``:52-65``).
+
+The module tree (and therefore every state-dict key and the default
+initialisation) is the reference's: ``nn.TransformerEncoder/Decoder`` objects are
+instantiated as *parameter containers* only.  All arithmetic -- forward,
+backward, loss -- is done by ``_Engine`` below through the C ABI
+(``libadt_hip.so``): bf16 MFMA GEMMs with fused bias/GELU/residual epilogues,
+flash-style attention, fp32 LayerNorm / cross-entropy.  fp32 master weights,
+bf16 operand copies (refreshed when a parameter changes), fp32 gradients; this
+is what ``bf16`` autocast does in the reference (``train.py:233-234``).
+
+``forward(src, tgt, tgt_mask, tgt_padding_mask, labels) -> loss`` keeps the
+reference signature and plugs into autograd through one ``autograd.Function``
+whose backward is the hand-written backward pass, so HF ``Trainer`` /
+``accelerate`` work unchanged.  ``loss_and_grads`` is the same computation
+without autograd, writing gradients into one flat fp32 buffer (what
+``adt_str_amd.trainer`` and ``bench.py`` use, with a single bucketed all-reduce).
+"""
+from __future__ import annotations
+
+import math
+from typing import Dict, List, Optional
+
+import torch
+import torch.nn as nn
+from transformers import PretrainedConfig, PreTrainedModel
+
+from . import kernels as K
+from .frontend import ComputeMelSpectrogram
+
+F32, BF16 = torch.float32, torch.bfloat16
+
+
+class ADTModelConfig(PretrainedConfig):
+    """Same fields and defaults as the reference's ``ADTModelConfig`` (config.py:81-119)."""
+    model_type = "adt_model"
+
+    def __init__(self, input_sec: float = 0.0, time_res: float = 0.0, win_length: int = 0, sample_rate: int = 0,
+                 enc_layers: int = 0, dec_layers: int = 0, nhead: int = 0, d_query: int = 0, dropout: float = 0.0,
+                 tgt_vocab_size: int = 0, enc_lr: float = 0.0, dec_lr: float = 0.0, plain: bool = False,
+                 n_mels: int = 0, **kwargs):
+        super().__init__(**kwargs)
+        self.input_sec, self.time_res, self.win_length, self.sample_rate = input_sec, time_res, win_length, sample_rate
+        self.enc_layers, self.dec_layers, self.nhead, self.d_query = enc_layers, dec_layers, nhead, d_query
+        self.dropout, self.tgt_vocab_size, self.enc_lr, self.dec_lr = dropout, tgt_vocab_size, enc_lr, dec_lr
+        self.plain, self.n_mels = plain, n_mels
+
+
+# ----------------------------------------------------------------------------- parameter containers
+class TokenEmbedding_plain(nn.Module):
+    def __init__(self, vocab_size, emb_size):
+        super().__init__()
+        self.embedding = nn.Embedding(vocab_size, emb_size)
+        self.emb_size = emb_size
+
+
+class PositionalEncoding(nn.Module):
+    """Sinusoidal table ``pos_embedding[1, maxlen, d]`` (model.py:55-62), persistent buffer."""
+
+    def __init__(self, emb_size: int, maxlen: int = 2048):
+        super().__init__()
+        freq = torch.exp(-torch.arange(0, emb_size, 2) * math.log(10000) / emb_size)
+        pos = torch.arange(0, maxlen).reshape(maxlen, 1)
+        table = torch.zeros((maxlen, emb_size))
+        table[:, 0::2] = torch.sin(pos * freq)
+        table[:, 1::2] = torch.cos(pos * freq)
+        self.register_buffer("pos_embedding", table.unsqueeze(0))
+
+
+def _no_call(self, *a, **k):
+    raise RuntimeError("container module: the ADT network runs through adt_str_amd's HIP engine, not nn.Module.forward")
+
+
+class Encoder(nn.Module):
+    def __init__(self, enc_layers, d_query, nhead, ffn_hid_dim, dropout):
+        super().__init__()
+        self.num_features = d_query * nhead
+        self.dense_layer = nn.Linear(self.num_features, self.num_features, bias=False)
+        self.positional_encoding = PositionalEncoding(self.num_features)
+        self.layer_norm = nn.LayerNorm(self.num_features, elementwise_affine=True)
+        self.dropout_layer = nn.Dropout(p=dropout)
+        layer = nn.TransformerEncoderLayer(d_model=self.num_features, nhead=nhead, dim_feedforward=ffn_hid_dim,
+                                           dropout=dropout, activation="gelu", batch_first=True, norm_first=False)
+        self.encoder = nn.TransformerEncoder(layer, num_layers=enc_layers, enable_nested_tensor=False)
+
+    forward = _no_call
+
+
+class Decoder(nn.Module):
+    def __init__(self, dec_layers, d_query, nhead, ffn_hid_dim, tgt_vocab_size, dropout, plain=False):
+        super().__init__()
+        if not plain:
+            raise NotImplementedError("only plain token embedding is supported (model.py:42-49; configs use plain: true)")
+        self.num_features = d_query * nhead
+        self.tgt_tok_emb = TokenEmbedding_plain(tgt_vocab_size, self.num_features)
+        self.positional_encoding = PositionalEncoding(self.num_features)
+        self.dropout_layer = nn.Dropout(p=dropout)
+        self.generator = nn.Linear(self.num_features, tgt_vocab_size)
+        layer = nn.TransformerDecoderLayer(d_model=self.num_features, nhead=nhead, dim_feedforward=ffn_hid_dim,
+                                           dropout=dropout, activation="gelu", batch_first=True, norm_first=False)
+        self.decoder = nn.TransformerDecoder(layer, num_layers=dec_layers)
+
+    forward = _no_call
+
+
+# ----------------------------------------------------------------------------- engine
+class _Lin:
+    """A linear layer's fp32 parameters plus its bf16 operands W [N,K] and W^T [K,N]."""
+
+    def __init__(self, name: str, weight: nn.Parameter, bias: Optional[nn.Parameter]):
+        self.name, self.weight, self.bias = name, weight, bias
+        self.w16 = self.wt16 = None
+
+    def refresh(self):
+        self.w16, self.wt16 = K.cast_bf16(self.weight.data.contiguous(), True, True)
+
+    @property
+    def b(self):
+        return None if self.bias is None else self.bias.data
+
+
+class _Engine:
+    def __init__(self, model: "ADTModel"):
+        self.m = model
+        cfg = model.config
+        self.H, self.d = cfg.nhead, cfg.nhead * cfg.d_query
+        if cfg.d_query != 128:
+            raise NotImplementedError("the attention kernels are built for head_dim (d_query) = 128")
+        self.scale = 1.0 / math.sqrt(cfg.d_query)
+        self.V = cfg.tgt_vocab_size
+        if self.V % 8 or cfg.n_mels % 8:
+            raise NotImplementedError("tgt_vocab_size and n_mels must be multiples of 8 (16-byte bf16 rows for the GEMMs)")
+        self.lins: Dict[str, _Lin] = {}
+        named = dict(model.named_parameters())
+
+        def lin(prefix, wname="weight", bname="bias"):
+            w = named[f"{prefix}.{wname}" if wname == "weight" else f"{prefix}.{wname}"]
+            b = named.get(f"{prefix}.{bname}")
+            self.lins[prefix + "." + wname] = _Lin(prefix + "." + wname, w, b)
+            return self.lins[prefix + "." + wname]
+
+        self.proj = lin("project_to_mel")
+        self.dense = lin("encoder.dense_layer")
+        self.gen = lin("decoder.generator")
+        self.enc, self.dec = [], []
+        for i in range(cfg.enc_layers):
+            p = f"encoder.encoder.layers.{i}"
+            self.enc.append(dict(p=p, sa=lin(p + ".self_attn", "in_proj_weight", "in_proj_bias"), sa_o=lin(p + ".self_attn.out_proj"),
+                                 l1=lin(p + ".linear1"), l2=lin(p + ".linear2")))
+        for i in range(cfg.dec_layers):
+            p = f"decoder.decoder.layers.{i}"
+            self.dec.append(dict(p=p, sa=lin(p + ".self_attn", "in_proj_weight", "in_proj_bias"), sa_o=lin(p + ".self_attn.out_proj"),
+                                 ca=lin(p + ".multihead_attn", "in_proj_weight", "in_proj_bias"),
+                                 ca_o=lin(p + ".multihead_attn.out_proj"), l1=lin(p + ".linear1"), l2=lin(p + ".linear2")))
+        self.named = named
+        self._versions = None
+        self.gflat: Optional[torch.Tensor] = None
+        self.G: Dict[str, torch.Tensor] = {}
+        self.grad_ready_hook = None      # callable(lo, hi): flat gradient range [lo, hi) is final (used to overlap all-reduce)
+
+    # ---- parameter plumbing -------------------------------------------------------
+    def P(self, name):
+        return self.named[name].data
+
+    def refresh_weights(self, force=False):
+        """Re-derive the bf16 operands when any parameter was modified in place (optimizer step, load_state_dict)."""
+        ver = tuple(p._version for p in self.named.values()) + (str(next(iter(self.named.values())).device),)
+        if force or ver != self._versions:
+            for l in self.lins.values():
+                l.refresh()
+            self._versions = tuple(p._version for p in self.named.values()) + (ver[-1],)
+
+    def grad_buffers(self):
+        """One flat fp32 gradient buffer with a view per parameter, in parameter order."""
+        dev = next(iter(self.named.values())).device
+        n = sum(p.numel() for p in self.named.values())
+        if self.gflat is None or self.gflat.device != dev or self.gflat.numel() != n:
+            self.gflat = torch.zeros(n, dtype=F32, device=dev)
+            off = 0
+            self.G = {}
+            for name, p in self.named.items():
+                self.G[name] = self.gflat[off:off + p.numel()].view_as(p)
+                off += p.numel()
+        return self.gflat, self.G
+
+    # ---- forward pieces -------------------------------------------------------------
+    def _encoder_fwd(self, src, save: Optional[list]):
+        m, d, H = self.m, self.d, self.H
+        mel = m.compute_spectrogram(src)                                   # K1: [B, S, n_mels] fp32
+        B, S, n_mels = mel.shape
+        M = B * S
+        mel16, _ = K.cast_bf16(mel.view(M, n_mels))
+        x0 = K.gemm(mel16, self.proj.w16, bias=self.proj.b)                # project_to_mel (model.py:249)
+        pe = self.m.encoder.positional_encoding.pos_embedding[0]
+        x16 = torch.empty((M, d), dtype=BF16, device=src.device)
+        x32 = K.gemm(x0, self.dense.w16, residual=pe, res_row_mod=S, out_dtype=F32, aux_bf16_out=x16)   # dense + PE (:130-131)
+        if save is not None:
+            save.append(dict(mel16=mel16, x0=x0, B=B, S=S))
+        for L in self.enc:
+            p = L["p"]
+            qkv = K.gemm(x16, L["sa"].w16, bias=L["sa"].b)
+            attn, lse = K.attn_fwd(qkv[:, :d], qkv[:, d:2 * d], qkv[:, 2 * d:], B, H, S, S, self.scale)
+            y1 = K.gemm(attn, L["sa_o"].w16, bias=L["sa_o"].b, residual=x32, out_dtype=F32)
+            x1_32, x1_16, mean1, rstd1 = K.layernorm_fwd(y1, self.P(p + ".norm1.weight"), self.P(p + ".norm1.bias"))
+            u = torch.empty((M, L["l1"].w16.shape[0]), dtype=BF16, device=src.device)
+            h = K.gemm(x1_16, L["l1"].w16, bias=L["l1"].b, act=1, pre_act_out=u)
+            y2 = K.gemm(h, L["l2"].w16, bias=L["l2"].b, residual=x1_32, out_dtype=F32)
+            x2_32, x2_16, mean2, rstd2 = K.layernorm_fwd(y2, self.P(p + ".norm2.weight"), self.P(p + ".norm2.bias"))
+            if save is not None:
+                save.append(dict(x16=x16, qkv=qkv, attn=attn, lse=lse, y1=y1, mean1=mean1, rstd1=rstd1, x1_16=x1_16, u=u, h=h,
+                                 y2=y2, mean2=mean2, rstd2=rstd2))
+            x32, x16 = x2_32, x2_16
+        _, mem16, meanf, rstdf = K.layernorm_fwd(x32, self.P("encoder.layer_norm.weight"), self.P("encoder.layer_norm.bias"),
+                                                 want32=False)
+        if save is not None:
+            save.append(dict(x32=x32, mean=meanf, rstd=rstdf))
+        return mem16, B, S
+
+    def _decoder_fwd(self, tgt, mem16, B, S, key_len, save: Optional[list]):
+        d, H = self.d, self.H
+        tgt = tgt.long().contiguous()
+        T = tgt.shape[1]
+        Md = B * T
+        emb = self.P("decoder.tgt_tok_emb.embedding.weight")
+        pe = self.m.decoder.positional_encoding.pos_embedding[0]
+        x32, x16 = K.embed_pe_fwd(tgt, emb, pe, math.sqrt(d))             # model.py:171
+        dev = tgt.device
+        for L in self.dec:
+            p = L["p"]
+            qkv = K.gemm(x16, L["sa"].w16, bias=L["sa"].b)
+            sa, lse_s = K.attn_fwd(qkv[:, :d], qkv[:, d:2 * d], qkv[:, 2 * d:], B, H, T, T, self.scale, causal=True, key_len=key_len)
+            y1 = K.gemm(sa, L["sa_o"].w16, bias=L["sa_o"].b, residual=x32, out_dtype=F32)
+            x1_32, x1_16, mean1, rstd1 = K.layernorm_fwd(y1, self.P(p + ".norm1.weight"), self.P(p + ".norm1.bias"))
+            ca_w, ca_b = L["ca"].w16, L["ca"].b
+            qc = K.gemm(x1_16, ca_w[:d], bias=ca_b[:d])
+            kvc = K.gemm(mem16, ca_w[d:], bias=ca_b[d:])
+            ca, lse_c = K.attn_fwd(qc, kvc[:, :d], kvc[:, d:], B, H, T, S, self.scale)
+            y2 = K.gemm(ca, L["ca_o"].w16, bias=L["ca_o"].b, residual=x1_32, out_dtype=F32)
+            x2_32, x2_16, mean2, rstd2 = K.layernorm_fwd(y2, self.P(p + ".norm2.weight"), self.P(p + ".norm2.bias"))
+            u = torch.empty((Md, L["l1"].w16.shape[0]), dtype=BF16, device=dev)
+            h = K.gemm(x2_16, L["l1"].w16, bias=L["l1"].b, act=1, pre_act_out=u)
+            y3 = K.gemm(h, L["l2"].w16, bias=L["l2"].b, residual=x2_32, out_dtype=F32)
+            x3_32, x3_16, mean3, rstd3 = K.layernorm_fwd(y3, self.P(p + ".norm3.weight"), self.P(p + ".norm3.bias"))
+            if save is not None:
+                save.append(dict(x16=x16, qkv=qkv, sa=sa, lse_s=lse_s, y1=y1, mean1=mean1, rstd1=rstd1, x1_16=x1_16, qc=qc, kvc=kvc,
+                                 ca=ca, lse_c=lse_c, y2=y2, mean2=mean2, rstd2=rstd2, x2_16=x2_16, u=u, h=h, y3=y3, mean3=mean3,
+                                 rstd3=rstd3))
+            x32, x16 = x3_32, x3_16
+        logits = K.gemm(x16, self.gen.w16, bias=self.gen.b, out_dtype=F32)  # generator (model.py:190), fp32 for the loss
+        if save is not None:
+            save.append(dict(xo16=x16, T=T, tgt=tgt))
+        return logits
+
+    @staticmethod
+    def key_len_from_mask(tgt_padding_mask, B, T, device):
+        """The kernels take per-sequence valid lengths; the reference passes the bool mask
+        ``arange(T) >= length`` (utils/utils.py:36-43), i.e. padding is always a suffix."""
+        if tgt_padding_mask is None:
+            return None
+        if tgt_padding_mask.dtype != torch.bool:
+            raise NotImplementedError("float key-padding masks are not supported; pass the bool mask of create_mask_plain")
+        return (T - tgt_padding_mask.to(device).sum(dim=1)).to(torch.int32).contiguous()
+
+    # ---- loss + gradients ---------------------------------------------------------------
+    def loss_and_grads(self, src, tgt, tgt_padding_mask, labels, want_grads=True, return_logits=False):
+        """Full training step arithmetic.  Gradients land in ``self.G`` (views of ``self.gflat``)."""
+        self.refresh_weights()
+        if self.m.training and self.m.config.dropout > 0:
+            raise NotImplementedError("dropout > 0 is not implemented in the HIP engine yet; set model.dropout: 0.0")
+        dev = src.device
+        B, T = tgt.shape
+        key_len = self.key_len_from_mask(tgt_padding_mask, B, T, dev)
+        enc_save: Optional[list] = [] if want_grads else None
+        dec_save: Optional[list] = [] if want_grads else None
+        mem16, B, S = self._encoder_fwd(src, enc_save)
+        logits = self._decoder_fwd(tgt, mem16, B, S, key_len, dec_save)
+        loss, dlogits = K.cross_entropy(logits, labels.long().reshape(-1), ignore_index=1, want_grad=want_grads)
+        out = {"loss": loss[0]}
+        if return_logits:
+            out["logits"] = logits.view(B, T, -1)
+            out["memory"] = mem16
+        if not want_grads:
+            return out
+        self._backward(dlogits, mem16, B, S, key_len, enc_save, dec_save)
+        return out
+
+    def _backward(self, dlogits, mem16, B, S, key_len, enc_save, dec_save):
+        d, H = self.d, self.H
+        _, G = self.grad_buffers()
+        tail = dec_save[-1]
+        T, tgt, xo16 = tail["T"], tail["tgt"], tail["xo16"]
+        # generator
+        K.gemm(dlogits, xo16, trans=True, out=G["decoder.generator.weight"])
+        K.colsum(dlogits, out=G["decoder.generator.bias"])
+        dx32 = K.gemm(dlogits, self.gen.wt16, out_dtype=F32)
+        dmem32 = None
+        for li in range(len(self.dec) - 1, -1, -1):
+            L, s = self.dec[li], dec_save[li]
+            p = L["p"]
+            dy3_32, dy3_16 = K.layernorm_bwd(dx32, s["y3"], self.P(p + ".norm3.weight"), s["mean3"], s["rstd3"], G[p + ".norm3.weight"],
+                                             G[p + ".norm3.bias"], G[p + ".linear2.bias"])
+            du = K.gemm(dy3_16, L["l2"].wt16, gelu_grad_of=s["u"])
+            K.gemm(dy3_16, s["h"], trans=True, out=G[p + ".linear2.weight"])
+            K.gemm(du, s["x2_16"], trans=True, out=G[p + ".linear1.weight"])
+            K.colsum(du, out=G[p + ".linear1.bias"])
+            dx2_32 = K.gemm(du, L["l1"].wt16, residual=dy3_32, out_dtype=F32)
+            dy2_32, dy2_16 = K.layernorm_bwd(dx2_32, s["y2"], self.P(p + ".norm2.weight"), s["mean2"], s["rstd2"], G[p + ".norm2.weight"],
+                                             G[p + ".norm2.bias"], G[p + ".multihead_attn.out_proj.bias"])
+            dca = K.gemm(dy2_16, L["ca_o"].wt16)
+            K.gemm(dy2_16, s["ca"], trans=True, out=G[p + ".multihead_attn.out_proj.weight"])
+            dqc = torch.empty_like(s["qc"])
+            dkvc = torch.empty_like(s["kvc"])
+            K.attn_bwd(s["qc"], s["kvc"][:, :d], s["kvc"][:, d:], s["ca"], dca, s["lse_c"], dqc, dkvc[:, :d], dkvc[:, d:], B, H, T, S,
+                       self.scale)
+            gw, gb = G[p + ".multihead_attn.in_proj_weight"], G[p + ".multihead_attn.in_proj_bias"]
+            K.gemm(dqc, s["x1_16"], trans=True, out=gw[:d])
+            K.gemm(dkvc, mem16, trans=True, out=gw[d:])
+            K.colsum(dqc, out=gb[:d])
+            K.colsum(dkvc, out=gb[d:])
+            cat = L["ca"].wt16                                              # [d, 3d]
+            if dmem32 is None:
+                dmem32 = K.gemm(dkvc, cat[:, d:], out_dtype=F32)
+            else:
+                K.gemm(dkvc, cat[:, d:], residual=dmem32, out=dmem32)
+            dx1_32 = K.gemm(dqc, cat[:, :d], residual=dy2_32, out_dtype=F32)
+            dy1_32, dy1_16 = K.layernorm_bwd(dx1_32, s["y1"], self.P(p + ".norm1.weight"), s["mean1"], s["rstd1"], G[p + ".norm1.weight"],
+                                             G[p + ".norm1.bias"], G[p + ".self_attn.out_proj.bias"])
+            dsa = K.gemm(dy1_16, L["sa_o"].wt16)
+            K.gemm(dy1_16, s["sa"], trans=True, out=G[p + ".self_attn.out_proj.weight"])
+            dqkv = torch.empty_like(s["qkv"])
+            q = s["qkv"]
+            K.attn_bwd(q[:, :d], q[:, d:2 * d], q[:, 2 * d:], s["sa"], dsa, s["lse_s"], dqkv[:, :d], dqkv[:, d:2 * d], dqkv[:, 2 * d:],
+                       B, H, T, T, self.scale, causal=True, key_len=key_len)
+            K.gemm(dqkv, s["x16"], trans=True, out=G[p + ".self_attn.in_proj_weight"])
+            K.colsum(dqkv, out=G[p + ".self_attn.in_proj_bias"])
+            dx32 = K.gemm(dqkv, L["sa"].wt16, residual=dy1_32, out_dtype=F32)
+        gemb = G["decoder.tgt_tok_emb.embedding.weight"]
+        gemb.zero_()
+        K.embed_bwd(tgt, dx32, math.sqrt(d), gemb)
+        self._ready("decoder.")
+        # encoder
+        fin = enc_save[-1]
+        dx32, _ = K.layernorm_bwd(dmem32, fin["x32"], self.P("encoder.layer_norm.weight"), fin["mean"], fin["rstd"],
+                                  G["encoder.layer_norm.weight"], G["encoder.layer_norm.bias"], None, want16=False)
+        dx16 = None
+        for li in range(len(self.enc) - 1, -1, -1):
+            L, s = self.enc[li], enc_save[li + 1]
+            p = L["p"]
+            dy2_32, dy2_16 = K.layernorm_bwd(dx32, s["y2"], self.P(p + ".norm2.weight"), s["mean2"], s["rstd2"], G[p + ".norm2.weight"],
+                                             G[p + ".norm2.bias"], G[p + ".linear2.bias"])
+            du = K.gemm(dy2_16, L["l2"].wt16, gelu_grad_of=s["u"])
+            K.gemm(dy2_16, s["h"], trans=True, out=G[p + ".linear2.weight"])
+            K.gemm(du, s["x1_16"], trans=True, out=G[p + ".linear1.weight"])
+            K.colsum(du, out=G[p + ".linear1.bias"])
+            dx1_32 = K.gemm(du, L["l1"].wt16, residual=dy2_32, out_dtype=F32)
+            dy1_32, dy1_16 = K.layernorm_bwd(dx1_32, s["y1"], self.P(p + ".norm1.weight"), s["mean1"], s["rstd1"], G[p + ".norm1.weight"],
+                                             G[p + ".norm1.bias"], G[p + ".self_attn.out_proj.bias"])
+            dattn = K.gemm(dy1_16, L["sa_o"].wt16)
+            K.gemm(dy1_16, s["attn"], trans=True, out=G[p + ".self_attn.out_proj.weight"])
+            dqkv = torch.empty_like(s["qkv"])
+            q = s["qkv"]
+            K.attn_bwd(q[:, :d], q[:, d:2 * d], q[:, 2 * d:], s["attn"], dattn, s["lse"], dqkv[:, :d], dqkv[:, d:2 * d], dqkv[:, 2 * d:],
+                       B, H, S, S, self.scale)
+            K.gemm(dqkv, s["x16"], trans=True, out=G[p + ".self_attn.in_proj_weight"])
+            K.colsum(dqkv, out=G[p + ".self_attn.in_proj_bias"])
+            if li == 0:
+                dx16 = torch.empty((dqkv.shape[0], d), dtype=BF16, device=dqkv.device)
+            dx32 = K.gemm(dqkv, L["sa"].wt16, residual=dy1_32, out_dtype=F32, aux_bf16_out=dx16 if li == 0 else None)
+            self._ready(p + ".")
+        head = enc_save[0]
+        K.gemm(dx16, head["x0"], trans=True, out=G["encoder.dense_layer.weight"])
+        dx0 = K.gemm(dx16, self.dense.wt16)
+        K.gemm(dx0, head["mel16"], trans=True, out=G["project_to_mel.weight"])
+        K.colsum(dx0, out=G["project_to_mel.bias"])
+        self._ready("encoder.dense_layer.", "encoder.layer_norm.", "project_to_mel.")
+
+    def _ready(self, *prefixes):
+        if self.grad_ready_hook is None:
+            return
+        for pre in prefixes:
+            lo, hi = self.flat_range(pre)
+            self.grad_ready_hook(lo, hi)
+
+    def flat_range(self, prefix: str):
+        """[lo, hi) of the flat parameter / gradient buffers covered by parameters whose name starts with ``prefix``."""
+        off, lo, hi = 0, None, None
+        for name, p in self.named.items():
+            if name.startswith(prefix):
+                lo = off if lo is None else lo
+                hi = off + p.numel()
+            off += p.numel()
+        if lo is None:
+            raise KeyError(prefix)
+        return lo, hi
+
+    # ---- inference --------------------------------------------------------------------------
+    @torch.no_grad()
+    def encode(self, src):
+        self.refresh_weights()
+        return self._encoder_fwd(src, None)
+
+    @torch.no_grad()
+    def decode_logits(self, tgt, mem16, B, S, key_len=None):
+        return self._decoder_fwd(tgt, mem16, B, S, key_len, None).view(B, tgt.shape[1], -1)
+
+
+class _ADTLossFn(torch.autograd.Function):
+    """Bridges the hand-written backward into autograd: forward runs forward+backward of the
+    engine (gradients are a by-product of the fused cross-entropy kernel), backward hands the
+    parameter gradients to autograd scaled by the incoming gradient."""
+
+    @staticmethod
+    def forward(ctx, engine, src, tgt, pad_mask, labels, *params):
+        out = engine.loss_and_grads(src, tgt, pad_mask, labels, want_grads=True)
+        ctx.engine = engine
+        return out["loss"].clone()
+
+    @staticmethod
+    def backward(ctx, g):
+        eng = ctx.engine
+        grads = tuple(eng.G[name] * g for name in eng.named)
+        return (None, None, None, None, None) + grads
+
+
+class ADTModel(PreTrainedModel):
+    config_class = ADTModelConfig
+
+    def __init__(self, config: ADTModelConfig) -> None:
+        super().__init__(config)
+        self.config = config
+        ffn = int(config.d_query * config.nhead * 4)
+        self.encoder = Encoder(config.enc_layers, config.d_query, config.nhead, ffn, config.dropout)
+        self.decoder = Decoder(config.dec_layers, config.d_query, config.nhead, ffn, config.tgt_vocab_size, config.dropout,
+                               plain=config.plain)
+        self.compute_spectrogram = ComputeMelSpectrogram(config.sample_rate, config.win_length, config.time_res, config.n_mels)
+        self.project_to_mel = nn.Linear(config.n_mels, int(config.d_query * config.nhead))
+        self._engine_obj: Optional[_Engine] = None
+
+    @property
+    def engine(self) -> _Engine:
+        if self._engine_obj is None:
+            self._engine_obj = _Engine(self)
+        return self._engine_obj
+
+    def _apply(self, fn, *a, **k):                 # .to(device) / .float(): parameters are replaced -> rebuild the engine
+        r = super()._apply(fn, *a, **k)
+        self._engine_obj = None
+        return r
+
+    def forward(self, src, tgt, tgt_mask, tgt_padding_mask, labels):
+        """Scalar CE loss (model.py:240-258).  ``tgt_mask`` must be None or the causal mask."""
+        if tgt_mask is not None and tgt_mask.shape != (tgt.shape[1], tgt.shape[1]):
+            raise ValueError("tgt_mask must be the [T, T] causal mask (or None)")
+        eng = self.engine
+        if torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters()):
+            return _ADTLossFn.apply(eng, src, tgt, tgt_padding_mask, labels, *eng.named.values())
+        return eng.loss_and_grads(src, tgt, tgt_padding_mask, labels, want_grads=False)["loss"]
+
+    @torch.no_grad()
+    def sample(self, src, src_mask=None, tgt_mask=None, max_length: int = 1000, start_token: int = 2, end_token: int = 3):
+        """Greedy decoding (model.py:260-324): encoder once, the full decoder over the prefix at
+        every step, argmax of the last position, finished rows pinned to ``end_token``."""
+        if not self.config.plain:
+            raise NotImplementedError("Non-plain mode is not implemented")
+        self.eval()
+        eng = self.engine
+        mem16, B, S = eng.encode(src)
+        gen = torch.full((B, 1), start_token, dtype=torch.long, device=src.device)
+        finished = torch.zeros(B, dtype=torch.bool, device=src.device)
+        for _ in range(max_length - 1):
+            logits = eng.decode_logits(gen, mem16, B, S)
+            nxt = torch.argmax(logits[:, -1, :], dim=-1)
+            nxt = torch.where(finished, torch.full_like(nxt, end_token), nxt)
+            gen = torch.cat([gen, nxt.unsqueeze(1)], dim=1)
+            finished = finished | (nxt == end_token)
+            if bool(torch.all(finished)):
+                break
+        return gen

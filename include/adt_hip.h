@@ -129,7 +129,8 @@ int adt_mix_render_f32(const float* bank, const int64_t* bank_off, int64_t n_sho
  *   + residual[row % res_row_mod, col]   (fp32; res_row_mod == 0: plain row) --
  *                                         residual stream, or the sinusoidal PE
  *                                         table with res_row_mod = frames per clip
- *   C = out_fp32 ? z : bf16(z)
+ *   C = out_fp32 ? z : bf16(z);  aux_bf16_out[row,col] = bf16(z) as well when given
+ *   (an fp32 residual-stream output plus the bf16 operand of the next GEMM in one pass)
  * trans = 1 may split K across workgroups; partial fp32 slabs go to `ws`
  * (adt_gemm_workspace_bytes) and are summed in slab order (reproducible).
  */
@@ -141,6 +142,7 @@ typedef struct adt_gemm_epilogue {
   int32_t      act;
   float        alpha;
   int32_t      out_fp32;
+  void*        aux_bf16_out;  int64_t ld_aux;
 } adt_gemm_epilogue;
 
 size_t adt_gemm_workspace_bytes(int32_t trans, int64_t M, int64_t N, int64_t K);

@@ -77,6 +77,9 @@ def test_epilogues():
     close(k.gemm(a, b, residual=pe, res_row_mod=96, out_dtype=torch.float32),
           z + pe.repeat(M // 96, 1), 1e-4, "periodic residual")
     close(k.gemm(a, b, alpha=0.25, out_dtype=torch.float32), 0.25 * z, 1e-4, "alpha")
+    aux = torch.empty((M, N), dtype=torch.bfloat16, device=DEV)
+    full = k.gemm(a, b, bias=bias, residual=res, out_dtype=torch.float32, aux_bf16_out=aux)
+    assert torch.equal(aux, full.bfloat16())
     # GELU forward with saved pre-activation
     u = torch.empty((M, N), dtype=torch.bfloat16, device=DEV)
     h = k.gemm(a, b, bias=bias, act=1, pre_act_out=u)
