@@ -95,3 +95,23 @@ class OneShotBank:
         if key not in self._dev:
             self._dev[key] = (torch.from_numpy(self.data).to(device), torch.from_numpy(self.offsets).to(device))
         return self._dev[key]
+
+
+def synthetic_tree(seed: int, sample_rate: int, pitches=range(35, 62), groups=("gold", "100-90", "90-80"),
+                   shots_per_group: int = 4, min_sec: float = 0.15, max_sec: float = 1.0) -> dict:
+    """Procedural stand-in for a curated one-shot library (decaying noise + a sine partial,
+    peak-normalised like convert_augmented_to_hdf5.py:101-103).  Used by bench.py / demos, where
+    no real sample pack is available."""
+    rng = np.random.default_rng(seed)
+    tree: dict = {}
+    for p in pitches:
+        tree[str(p)] = {}
+        for gi, g in enumerate(groups):
+            cell = {}
+            for s in range(shots_per_group):
+                n = int(rng.uniform(min_sec, max_sec) * sample_rate)
+                t = np.arange(n) / sample_rate
+                x = np.exp(-rng.uniform(6.0, 60.0) * t) * (0.6 * rng.standard_normal(n) + np.sin(2 * np.pi * rng.uniform(50.0, 5000.0) * t))
+                cell[f"synth_{p}_{gi}_{s}.wav"] = (x / np.abs(x).max()).astype(np.float32)
+            tree[str(p)][g] = cell
+    return tree

@@ -106,6 +106,47 @@ __device__ __forceinline__ bf16x8 frag_tn(const unsigned char* tile, int col0, i
   return r;
 }
 
+// ---- epilogue shared by the kernels: C element (row, col) = acc[i][j][r] with
+// row = m0 + wm*64 + i*16 + 4*(lane>>4) + r, col = n0 + wn*64 + j*16 + (lane&15)
+__device__ __forceinline__ void gemm_epilogue(const GemmArgs& g, f32x4 (&acc)[4][4], int m0, int n0, int wm, int wn, int lane, int split) {
+  const adt_gemm_epilogue& ep = g.ep;
+  const bool to_slab = g.slabs != nullptr;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int col = n0 + wn * 64 + j * 16 + (lane & 15);
+      if (col >= g.N) continue;
+      const float bias = (!to_slab && ep.bias) ? ep.bias[col] : 0.0f;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int row = m0 + wm * 64 + i * 16 + 4 * (lane >> 4) + r;
+        if (row >= g.M) continue;
+        float z = acc[i][j][r];
+        if (to_slab) {
+          g.slabs[(static_cast<long>(split) * g.M + row) * g.N + col] = z;
+          continue;
+        }
+        z = z * ep.alpha + bias;
+        if (ep.gelu_grad_of) {
+          const unsigned short u = reinterpret_cast<const unsigned short*>(ep.gelu_grad_of)[static_cast<long>(row) * ep.ld_gelu_grad + col];
+          z *= gelu_erf_grad(bf2f(u));
+        }
+        if (ep.pre_act_out)
+          reinterpret_cast<unsigned short*>(ep.pre_act_out)[static_cast<long>(row) * ep.ld_pre_act + col] = f2bf(z);
+        if (ep.act == 1) z = gelu_erf(ep.pre_act_out ? bf2f(f2bf(z)) : z);
+        if (ep.residual) {
+          const long rr = ep.res_row_mod > 0 ? (row % ep.res_row_mod) : row;
+          z += reinterpret_cast<const float*>(ep.residual)[rr * ep.ld_res + col];
+        }
+        if (ep.aux_bf16_out) reinterpret_cast<unsigned short*>(ep.aux_bf16_out)[static_cast<long>(row) * ep.ld_aux + col] = f2bf(z);
+        if (ep.out_fp32) reinterpret_cast<float*>(g.C)[static_cast<long>(row) * g.ldc + col] = z;
+        else reinterpret_cast<unsigned short*>(g.C)[static_cast<long>(row) * g.ldc + col] = f2bf(z);
+      }
+    }
+  }
+}
+
 template <bool kTrans>
 __global__ __launch_bounds__(kGemmThreads) void gemm_bf16_kernel(GemmArgs g) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -171,43 +212,170 @@ __global__ __launch_bounds__(kGemmThreads) void gemm_bf16_kernel(GemmArgs g) {
     __syncthreads();
   }
 
-  // ---- epilogue: C element (row, col) = acc[i][j][r] with row = .. + 4*(lane>>4) + r, col = .. + (lane&15)
+  gemm_epilogue(g, acc, m0, n0, wm, wn, lane, split);
+}
+
+// ---- row-vector epilogue (LDS-DMA kernel): the 128x128 fp32 accumulator tile is transposed through
+// LDS (row pitch 132 floats: conflict-free 4-byte writes from the MFMA layout), then each thread
+// owns 8 consecutive columns of a row, so bias / residual / pre-activation are 16- and 32-byte
+// vector accesses and every output row is written as whole 16-byte pieces.
+constexpr int kEpiPitch = 132;
+constexpr int kEpiLds = 128 * kEpiPitch * 4;          // 67,584 B
+__device__ __forceinline__ void gemm_epilogue_rows(const GemmArgs& g, f32x4 (&acc)[4][4], float* ct, int m0, int n0,
+                                                   int wm, int wn, int tid, int lane) {
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+      for (int r = 0; r < 4; ++r)
+        ct[(wm * 64 + i * 16 + 4 * (lane >> 4) + r) * kEpiPitch + wn * 64 + j * 16 + (lane & 15)] = acc[i][j][r];
+  __syncthreads();
   const adt_gemm_epilogue& ep = g.ep;
-  const bool to_slab = g.slabs != nullptr;
+  const int c8 = (tid & 15) * 8;
+  const int col = n0 + c8;
+  const bool full = col + 8 <= g.N;                     // N % 8 == 0 is guaranteed for bf16 C (checked on the host)
+  float bias[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  if (ep.bias && full) {
+    *reinterpret_cast<float4*>(bias) = *reinterpret_cast<const float4*>(ep.bias + col);
+    *reinterpret_cast<float4*>(bias + 4) = *reinterpret_cast<const float4*>(ep.bias + col + 4);
+  }
+#pragma unroll 2
+  for (int pass = 0; pass < 8; ++pass) {
+    const int lr = pass * 16 + (tid >> 4);
+    const int row = m0 + lr;
+    if (row >= g.M || !full) continue;
+    float z[8];
+    *reinterpret_cast<float4*>(z) = *reinterpret_cast<const float4*>(ct + lr * kEpiPitch + c8);
+    *reinterpret_cast<float4*>(z + 4) = *reinterpret_cast<const float4*>(ct + lr * kEpiPitch + c8 + 4);
 #pragma unroll
-  for (int i = 0; i < 4; ++i) {
+    for (int e = 0; e < 8; ++e) z[e] = z[e] * ep.alpha + bias[e];
+    if (ep.gelu_grad_of) {
+      const uint4 uv = *reinterpret_cast<const uint4*>(reinterpret_cast<const unsigned short*>(ep.gelu_grad_of) + static_cast<long>(row) * ep.ld_gelu_grad + col);
+      const unsigned w[4] = {uv.x, uv.y, uv.z, uv.w};
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      const int col = n0 + wn * 64 + j * 16 + (lane & 15);
-      if (col >= g.N) continue;
-      const float bias = (!to_slab && ep.bias) ? ep.bias[col] : 0.0f;
-#pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const int row = m0 + wm * 64 + i * 16 + 4 * (lane >> 4) + r;
-        if (row >= g.M) continue;
-        float z = acc[i][j][r];
-        if (to_slab) {
-          g.slabs[(static_cast<long>(split) * g.M + row) * g.N + col] = z;
-          continue;
-        }
-        z = z * ep.alpha + bias;
-        if (ep.gelu_grad_of) {
-          const unsigned short u = reinterpret_cast<const unsigned short*>(ep.gelu_grad_of)[static_cast<long>(row) * ep.ld_gelu_grad + col];
-          z *= gelu_erf_grad(bf2f(u));
-        }
-        if (ep.pre_act_out)
-          reinterpret_cast<unsigned short*>(ep.pre_act_out)[static_cast<long>(row) * ep.ld_pre_act + col] = f2bf(z);
-        if (ep.act == 1) z = gelu_erf(ep.pre_act_out ? bf2f(f2bf(z)) : z);
-        if (ep.residual) {
-          const long rr = ep.res_row_mod > 0 ? (row % ep.res_row_mod) : row;
-          z += reinterpret_cast<const float*>(ep.residual)[rr * ep.ld_res + col];
-        }
-        if (ep.aux_bf16_out) reinterpret_cast<unsigned short*>(ep.aux_bf16_out)[static_cast<long>(row) * ep.ld_aux + col] = f2bf(z);
-        if (ep.out_fp32) reinterpret_cast<float*>(g.C)[static_cast<long>(row) * g.ldc + col] = z;
-        else reinterpret_cast<unsigned short*>(g.C)[static_cast<long>(row) * g.ldc + col] = f2bf(z);
+      for (int e = 0; e < 4; ++e) {
+        z[2 * e] *= gelu_erf_grad(__uint_as_float(w[e] << 16));
+        z[2 * e + 1] *= gelu_erf_grad(__uint_as_float(w[e] & 0xffff0000u));
       }
     }
+    if (ep.pre_act_out) {
+      uint4 o;
+      o.x = f2bf(z[0]) | (static_cast<unsigned>(f2bf(z[1])) << 16); o.y = f2bf(z[2]) | (static_cast<unsigned>(f2bf(z[3])) << 16);
+      o.z = f2bf(z[4]) | (static_cast<unsigned>(f2bf(z[5])) << 16); o.w = f2bf(z[6]) | (static_cast<unsigned>(f2bf(z[7])) << 16);
+      *reinterpret_cast<uint4*>(reinterpret_cast<unsigned short*>(ep.pre_act_out) + static_cast<long>(row) * ep.ld_pre_act + col) = o;
+#pragma unroll
+      for (int e = 0; e < 8; ++e) z[e] = bf2f(f2bf(z[e]));       // the activation sees the value the backward will read
+    }
+    if (ep.act == 1) {
+#pragma unroll
+      for (int e = 0; e < 8; ++e) z[e] = gelu_erf(z[e]);
+    }
+    if (ep.residual) {
+      const long rr = ep.res_row_mod > 0 ? (row % ep.res_row_mod) : row;
+      const float* rp = reinterpret_cast<const float*>(ep.residual) + rr * ep.ld_res + col;
+      const float4 r0 = *reinterpret_cast<const float4*>(rp), r1 = *reinterpret_cast<const float4*>(rp + 4);
+      z[0] += r0.x; z[1] += r0.y; z[2] += r0.z; z[3] += r0.w; z[4] += r1.x; z[5] += r1.y; z[6] += r1.z; z[7] += r1.w;
+    }
+    uint4 o16;
+    o16.x = f2bf(z[0]) | (static_cast<unsigned>(f2bf(z[1])) << 16); o16.y = f2bf(z[2]) | (static_cast<unsigned>(f2bf(z[3])) << 16);
+    o16.z = f2bf(z[4]) | (static_cast<unsigned>(f2bf(z[5])) << 16); o16.w = f2bf(z[6]) | (static_cast<unsigned>(f2bf(z[7])) << 16);
+    if (ep.aux_bf16_out)
+      *reinterpret_cast<uint4*>(reinterpret_cast<unsigned short*>(ep.aux_bf16_out) + static_cast<long>(row) * ep.ld_aux + col) = o16;
+    if (ep.out_fp32) {
+      float* cp = reinterpret_cast<float*>(g.C) + static_cast<long>(row) * g.ldc + col;
+      *reinterpret_cast<float4*>(cp) = *reinterpret_cast<float4*>(z);
+      *reinterpret_cast<float4*>(cp + 4) = *reinterpret_cast<float4*>(z + 4);
+    } else {
+      *reinterpret_cast<uint4*>(reinterpret_cast<unsigned short*>(g.C) + static_cast<long>(row) * g.ldc + col) = o16;
+    }
   }
+}
+
+// =========================================================================================
+// NT kernel, LDS-DMA staging (used whenever K % 64 == 0).
+// Both operand tiles are 128 rows x 128 B and are filled by global_load_lds_dwordx4 (no VGPR
+// round trip): one wave-instruction writes 1 KiB = 8 rows, lane l -> row (l >> 3), 16-byte
+// position (l & 7).  The LDS image must stay lane-linear, so the bank swizzle is applied to the
+// SOURCE: position p of row r holds the row's chunk p ^ ((r >> 1) & 7), and fragment reads apply
+// the same XOR -- 16 consecutive rows then hit 16 distinct 16-byte bank slots (conflict free).
+// Two stages: the next K-tile's DMA is issued before the current tile's MFMAs and retired by the
+// vmcnt(0) + barrier that ends the iteration.  Rows past M / N are clamped (read, never stored).
+// Blocks are renumbered so that the blocks sharing an XCD (id % 8) work on consecutive tiles of
+// one row-panel, which keeps the A panel in that XCD's L2.
+constexpr int kTileNT = 128 * 128;               // 16 KiB per operand tile
+__device__ __forceinline__ int swz_nt(int row) { return (row >> 1) & 7; }
+
+__device__ __forceinline__ void glds_tile(const unsigned short* __restrict__ src, long ld, int row0, int n_rows, int k0,
+                                          unsigned char* tile, int wave, int lane) {
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int row = 8 * (4 * wave + i) + (lane >> 3);
+    int gr = row0 + row;
+    gr = gr < n_rows ? gr : n_rows - 1;
+    const int chunk = (lane & 7) ^ swz_nt(row);
+    const unsigned short* p = src + static_cast<long>(gr) * ld + k0 + chunk * 8;
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)p,
+                                     (__attribute__((address_space(3))) void*)(tile + (4 * wave + i) * 1024), 16, 0, 0);
+  }
+}
+__device__ __forceinline__ bf16x8 frag_glds(const unsigned char* tile, int row0, int ks, int lane) {
+  const int row = row0 + (lane & 15);
+  const int chunk = (4 * ks + (lane >> 4)) ^ swz_nt(row);
+  return *reinterpret_cast<const bf16x8*>(tile + row * 128 + chunk * 16);
+}
+
+__global__ __launch_bounds__(kGemmThreads) void gemm_nt_glds_kernel(GemmArgs g, int tiles_m, int tiles_n) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];      // [2 stages][A tile | B tile]
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave >> 1, wn = wave & 1;
+  // XCD-aware renumbering (bijective for any grid size)
+  const int nwg = tiles_m * tiles_n, bid = blockIdx.x;
+  const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7;
+  const int logical = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
+  const int m0 = (logical / tiles_n) * kBM, n0 = (logical % tiles_n) * kBN;
+  const int k_tiles = g.K / kBK;
+
+  f32x4 acc[4][4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  glds_tile(g.A, g.lda, m0, g.M, 0, smem, wave, lane);
+  glds_tile(g.B, g.ldb, n0, g.N, 0, smem + kTileNT, wave, lane);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+
+  for (int kt = 0; kt < k_tiles; ++kt) {
+    const unsigned char* ta = smem + (kt & 1) * 2 * kTileNT;
+    const unsigned char* tb = ta + kTileNT;
+    if (kt + 1 < k_tiles) {
+      unsigned char* na = smem + ((kt + 1) & 1) * 2 * kTileNT;
+      glds_tile(g.A, g.lda, m0, g.M, (kt + 1) * kBK, na, wave, lane);
+      glds_tile(g.B, g.ldb, n0, g.N, (kt + 1) * kBK, na + kTileNT, wave, lane);
+    }
+#pragma unroll
+    for (int ks = 0; ks < kBK / 32; ++ks) {
+      bf16x8 fa[4], fb[4];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        fa[i] = frag_glds(ta, wm * 64 + i * 16, ks, lane);
+        fb[i] = frag_glds(tb, wn * 64 + i * 16, ks, lane);
+      }
+      __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+          acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[i], fb[j], acc[i][j], 0, 0, 0);
+      __builtin_amdgcn_s_setprio(0);
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+  }
+  gemm_epilogue_rows(g, acc, reinterpret_cast<float*>(smem), m0, n0, wm, wn, tid, lane);
 }
 
 // sums split-K slabs in slab order: out[m,n] = alpha * sum_s slab[s][m,n]   (fp32 out)
@@ -223,6 +391,13 @@ __global__ __launch_bounds__(256) void reduce_slabs_kernel(const float* __restri
   const long row = i4 / N; const int col = static_cast<int>(i4 - row * N);   // N % 4 == 0: a float4 never straddles rows
   float* o = out + row * ldc + col;
   o[0] = s.x * alpha; o[1] = s.y * alpha; o[2] = s.z * alpha; o[3] = s.w * alpha;
+}
+
+// the row-vector epilogue moves 8 columns at a time: everything it touches must be 16-byte aligned
+static bool vector_epilogue_ok(const GemmArgs& g, const adt_gemm_epilogue& e) {
+  auto ok = [](const void* p, long ld, int elem) { return !p || (aligned16(p) && (ld * elem) % 16 == 0); };
+  return (g.N % 8) == 0 && ok(g.C, g.ldc, e.out_fp32 ? 4 : 2) && ok(e.bias, 4, 4) && ok(e.residual, e.ld_res, 4) &&
+         ok(e.pre_act_out, e.ld_pre_act, 2) && ok(e.gelu_grad_of, e.ld_gelu_grad, 2) && ok(e.aux_bf16_out, e.ld_aux, 2);
 }
 
 static int pick_splits(int M, int N, int K, int n_cu) {
@@ -285,10 +460,17 @@ extern "C" int adt_gemm_bf16(int32_t trans, int64_t M, int64_t N, int64_t K, con
   if (attr_dev != dev) {
     ADT_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_bf16_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, kGemmLds));
     ADT_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_bf16_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, kGemmLds));
+    ADT_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_nt_glds_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, kEpiLds));
     attr_dev = dev;
   }
-  if (trans) hipLaunchKernelGGL(gemm_bf16_kernel<true>, grid, dim3(kGemmThreads), kGemmLds, st, g);
-  else hipLaunchKernelGGL(gemm_bf16_kernel<false>, grid, dim3(kGemmThreads), kGemmLds, st, g);
+  if (trans) {
+    hipLaunchKernelGGL(gemm_bf16_kernel<true>, grid, dim3(kGemmThreads), kGemmLds, st, g);
+  } else if ((K % kBK) == 0 && K > 0 && vector_epilogue_ok(g, e)) {
+    const int tm = static_cast<int>((M + kBM - 1) / kBM), tn = static_cast<int>((N + kBN - 1) / kBN);
+    hipLaunchKernelGGL(gemm_nt_glds_kernel, dim3(static_cast<unsigned>(tm) * tn), dim3(kGemmThreads), kEpiLds, st, g, tm, tn);
+  } else {
+    hipLaunchKernelGGL(gemm_bf16_kernel<false>, grid, dim3(kGemmThreads), kGemmLds, st, g);
+  }
   if (splits > 1) {
     const long mn = static_cast<long>(M) * N;
     hipLaunchKernelGGL(reduce_slabs_kernel, dim3(static_cast<unsigned>((mn / 4 + 255) / 256)), dim3(256), 0, st,

@@ -83,7 +83,7 @@ __global__ __launch_bounds__(kRowThreads) void layernorm_fwd_kernel(LnFwdArgs a)
 // dx = rstd * (g - mean(g) - xhat * mean(g * xhat)),  g = dy * gamma,  xhat = (x - mean) * rstd
 // Per block (kLnBwdRows rows) partial column sums: dgamma += dy * xhat, dbeta += dy, dxsum += dx
 // (dxsum = bias gradient of the linear layer that feeds this norm's input).
-constexpr int kLnBwdRows = 32;              // rows per block (8 per wave)
+constexpr int kLnBwdRows = 64;              // rows per block (16 per wave)
 struct LnBwdArgs { const float* dy; long lddy; const float* x; long ldx; const float* gamma; const float* mean;
                    const float* rstd; float* dx32; unsigned short* dx16; long lddx; float* partial; int M; int D; };
 
@@ -145,17 +145,27 @@ __global__ __launch_bounds__(kRowThreads) void layernorm_bwd_kernel(LnBwdArgs a)
   }
 }
 
-// out[c] = sum_p partial[p][c], p in fixed order; c < width.  One thread per column, coalesced over c.
+// out[c] = sum_p partial[p][c] in a fixed order; c < width.  A block owns 32 columns and splits the
+// partial rows over 8 row-lanes (coalesced 128-byte reads), then combines the 8 sums through LDS.
 __global__ __launch_bounds__(256) void reduce_partials_kernel(const float* __restrict__ partial, int n_part, int width,
                                                               float* __restrict__ out0, float* __restrict__ out1,
                                                               float* __restrict__ out2, int D) {
-  const int c = blockIdx.x * 256 + threadIdx.x;
-  if (c >= width) return;
+  __shared__ float red[8][33];
+  const int cl = threadIdx.x & 31, rl = threadIdx.x >> 5;
+  const int c = blockIdx.x * 32 + cl;
   float s = 0.f;
-  for (int p = 0; p < n_part; ++p) s += partial[static_cast<long>(p) * width + c];
-  const int k = c / D, col = c - k * D;
-  float* o = k == 0 ? out0 : (k == 1 ? out1 : out2);
-  if (o) o[col] = s;
+  if (c < width)
+    for (int p = rl; p < n_part; p += 8) s += partial[static_cast<long>(p) * width + c];
+  red[rl][cl] = s;
+  __syncthreads();
+  if (rl == 0 && c < width) {
+    float t = 0.f;
+#pragma unroll
+    for (int r = 0; r < 8; ++r) t += red[r][cl];
+    const int k = c / D, col = c - k * D;
+    float* o = k == 0 ? out0 : (k == 1 ? out1 : out2);
+    if (o) o[col] = t;
+  }
 }
 
 // ------------------------------------------------------------------------------------ column sums of a bf16 matrix
@@ -410,7 +420,7 @@ extern "C" int adt_layernorm_bwd(const float* dy, int64_t lddy, const float* x, 
               static_cast<int>(M), static_cast<int>(D)};
   hipLaunchKernelGGL(layernorm_bwd_kernel, dim3(nb), dim3(kRowThreads), 0, ST(stream), a);
   const int width = 3 * static_cast<int>(D);
-  hipLaunchKernelGGL(reduce_partials_kernel, dim3((width + 255) / 256), dim3(256), 0, ST(stream), static_cast<const float*>(ws), nb,
+  hipLaunchKernelGGL(reduce_partials_kernel, dim3((width + 31) / 32), dim3(256), 0, ST(stream), static_cast<const float*>(ws), nb,
                      width, dgamma, dbeta, dxsum, static_cast<int>(D));
   ADT_HIP_TRY(hipGetLastError());
   return ADT_OK;
@@ -429,7 +439,7 @@ extern "C" int adt_colsum_bf16(const void* x, int64_t ld, int64_t M, int64_t N, 
   const int nb = static_cast<int>((M + kColsumRows - 1) / kColsumRows);
   hipLaunchKernelGGL(colsum_partial_kernel, dim3(static_cast<unsigned>((N + 255) / 256), nb), dim3(256), 0, ST(stream),
                      static_cast<const unsigned short*>(x), ld, static_cast<int>(M), static_cast<int>(N), static_cast<float*>(ws));
-  hipLaunchKernelGGL(reduce_partials_kernel, dim3(static_cast<unsigned>((N + 255) / 256)), dim3(256), 0, ST(stream),
+  hipLaunchKernelGGL(reduce_partials_kernel, dim3(static_cast<unsigned>((N + 31) / 32)), dim3(256), 0, ST(stream),
                      static_cast<const float*>(ws), nb, static_cast<int>(N), out, static_cast<float*>(nullptr), static_cast<float*>(nullptr),
                      static_cast<int>(N));
   ADT_HIP_TRY(hipGetLastError());

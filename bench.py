@@ -6,21 +6,25 @@ is launched under ``torch.distributed.run`` with one rank per GPU.  W untimed
 steps, then exactly K timed steps bracketed by barrier + synchronize, MAX over
 ranks, rank 0 prints ONE JSON line.
 
-A "step" is one pass of the hot path over one batch of synthetic input that is
-already resident in HBM.  Workloads (``--workload``):
+Workloads (``--workload``):
 
-  logmel  BASELINE config 2: fused STFT->log-mel, 256 clips x 10 s @ 16 kHz per GPU.
+  train   (default) BASELINE config[3]: one ADT training step per GPU on 64 clips of
+          10 s @ 16 kHz -- the on-GPU one-shot mixer renders the batch (K2), fused
+          log-mel (K1), setting-1 network forward + backward in bf16/fp32-accumulate
+          (K3-K8), gradient all-reduce over RCCL when N > 1, global-norm clip + AdamW.
+          Weak scaling: 64 clips per GPU, value = clips/s over all GPUs.
+  logmel  BASELINE config[1]: the fused STFT->log-mel kernel alone, 256 clips per GPU.
 
-Every rank works on its own batch (weak scaling, no data-path collective).
-The line also carries ``roofline`` (dominant kernel: algorithmic bytes per launch /
-HIP-event time per launch, vs the 8 TB/s HBM peak) and, at N = 1, ``cpu_baseline``
-(the oracle restatement timed on the host cores on a bounded sample).
+The JSON line also carries ``roofline`` (dominant kernel measured live with HIP
+events on the stream it runs on) and, at N = 1, ``cpu_baseline`` (the oracle
+restatement of the same step timed on the host cores on a bounded sample).
 """
 from __future__ import annotations
 
 import argparse
 import json
 import os
+import random
 import sys
 import time
 
@@ -28,13 +32,18 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
+import numpy as np  # noqa: E402
 import torch  # noqa: E402
 import torch.distributed as dist  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 FP32_VECTOR_PEAK_TF = 157.3
+BF16_MFMA_PEAK_TF = 2500.0     # dense bf16 MFMA peak (no sparsity)
+
+SETTING1 = dict(enc_layers=4, dec_layers=4, nhead=6, d_query=128, tgt_vocab_size=1400, n_mels=128)
 
 
+# ----------------------------------------------------------------------------- log-mel workload (config[1])
 def logmel_setup(dev, seed):
     from adt_str_amd.frontend import ComputeMelSpectrogram
     B, L, sr = 256, 160000, 16000
@@ -52,33 +61,169 @@ def logmel_setup(dev, seed):
     algo_bytes = B * (4 * L + 4 * F * 128)        # read the wave once + write the output once
     # per frame: real FFT 2.5*N*log2(N) + power 3/bin + banded mel 4/bin + log/scale 3/mel
     algo_flops = B * F * (2.5 * 2048 * 11 + 3 * 1025 + 4 * 1025 + 3 * 128)
-    return {"step": lambda: mod(wave_d), "units": B, "unit_name": "clips", "algo_bytes": algo_bytes,
-            "algo_flops": algo_flops, "cpu_input": wave, "F": F,
+
+    def roofline():
+        ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        ev0.record()
+        for _ in range(20):
+            mod(wave_d)
+        ev1.record()
+        torch.cuda.synchronize()
+        ms = ev0.elapsed_time(ev1) / 20
+        ach = algo_bytes / (ms * 1e-3) / 1e9
+        return {"bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS,
+                "traffic": None, "kernel": "adt::logmel_kernel", "kernel_ms": ms, "algorithmic_bytes_per_launch": algo_bytes,
+                "fp32_vector_tflops": algo_flops / (ms * 1e-3) / 1e12,
+                "fp32_vector_frac": algo_flops / (ms * 1e-3) / 1e12 / FP32_VECTOR_PEAK_TF}
+
+    def cpu_baseline(budget_s=12.0):
+        from oracle import logmel as o_logmel
+        torch.set_num_threads(min(os.cpu_count() or 1, 16))   # 16 = the reference's DataLoader worker count (setting-1.yaml:11)
+        n = 64
+        o_logmel.logmel(wave[:8], 16000, 2048, 0.01, 128)
+        done, t0 = 0, time.perf_counter()
+        while time.perf_counter() - t0 < budget_s:
+            i = (done // n) % (wave.shape[0] // n)
+            o_logmel.logmel(wave[i * n:(i + 1) * n], 16000, 2048, 0.01, 128)
+            done += n
+        dt = time.perf_counter() - t0
+        return {"value": done / dt, "unit": "clips/s", "cores": torch.get_num_threads(), "kind": "port",
+                "sample": f"{done} clips of the same batch in {dt:.1f} s (oracle/logmel.py: torch.stft + dense mel matmul, fp32)"}
+
+    return {"step": lambda: mod(wave_d), "units": B, "dtype": "f32", "roofline": roofline, "cpu_baseline": cpu_baseline,
+            "metric": "ADT hot path clips/sec (10 s @16 kHz), log-mel front end stage",
             "config": {"workload": "logmel config[1]: 256 clips x 10 s @ 16 kHz -> [256,986,128], n_fft 2048, hop 160",
                        "clips_per_gpu": B, "samples": L, "sample_rate": sr}}
 
 
-def logmel_cpu_baseline(wave, budget_s=12.0):
-    from oracle import logmel as o_logmel
-    torch.set_num_threads(min(os.cpu_count() or 1, 16))   # 16 = the reference's DataLoader worker count (setting-1.yaml:11)
-    n = 64
-    o_logmel.logmel(wave[:8], 16000, 2048, 0.01, 128)
-    done, t0 = 0, time.perf_counter()
-    while time.perf_counter() - t0 < budget_s:
-        i = (done // n) % (wave.shape[0] // n)
-        o_logmel.logmel(wave[i * n:(i + 1) * n], 16000, 2048, 0.01, 128)
-        done += n
-    dt = time.perf_counter() - t0
-    return {"value": done / dt, "unit": "clips/s", "cores": torch.get_num_threads(), "kind": "port",
-            "sample": f"{done} clips of the same batch in {dt:.1f} s (oracle/logmel.py: torch.stft + dense mel matmul, fp32)"}
+# ----------------------------------------------------------------------------- training-step workload (config[3])
+def synthetic_notes(rng, n_clips, n_notes=40):
+    """Onsets in [0, 2.95] s (the tokenizer's range, midi_tokenizer.py:54-56), custom-GM pitches, velocities 1..127."""
+    batch = []
+    for _ in range(n_clips):
+        onset = np.sort(rng.uniform(0.0, 2.95, n_notes))
+        batch.append([[float(o), float(o + 0.1), float(rng.integers(35, 61)), float(rng.integers(1, 128))] for o in onset])
+    return batch
+
+
+def synthetic_tokens(rng, B, T):
+    """tokens[B, T+1] with PAD=1 tails, lengths U[32, T+1]; collate's max -> max-1 rule applied."""
+    lens = rng.integers(32, T + 2, B)
+    lens[0] = T + 1
+    tokens = np.full((B, T + 1), 1, np.int64)
+    for b in range(B):
+        n = int(lens[b])
+        body = np.empty(n - 2, np.int64)
+        body[0::3] = rng.integers(4, 300, len(body[0::3]))
+        body[1::3] = rng.integers(335, 361, len(body[1::3]))
+        body[2::3] = rng.integers(410, 527, len(body[2::3]))
+        tokens[b, :n] = np.concatenate([[2], body, [3]])
+    tl = np.where(lens == lens.max(), lens - 1, lens).astype(np.int64)
+    return tokens, tl
+
+
+def train_flops_per_clip(F, T, d=768, ffn=3072, V=1400, n_mels=128, enc=4, dec=4):
+    """Forward MACs of one clip (SURVEY 8d formula) -> fwd+bwd FLOPs = 2 * 3 * MACs."""
+    macs = F * n_mels * d + F * d * d
+    macs += enc * (F * d * 3 * d + 2 * F * F * d + F * d * d + 2 * F * d * ffn)
+    macs += dec * (T * d * 3 * d + 2 * T * T * d + T * d * d + T * d * d + F * d * 2 * d + 2 * T * F * d + T * d * d + 2 * T * d * ffn)
+    macs += T * d * V
+    return 6.0 * macs
+
+
+def train_setup(dev, seed, world):
+    from adt_str_amd import kernels as K
+    from adt_str_amd.bank import OneShotBank, synthetic_tree
+    from adt_str_amd.network import ADTModel, ADTModelConfig
+    from adt_str_amd.synth import SynthDrum, SynthDrumConfig
+    from adt_str_amd.trainer import FlatTrainer
+    B, L, sr, T = 64, 160000, 16000, 128
+    torch.manual_seed(0)                                   # same initial weights on every rank (then broadcast anyway)
+    cfg = ADTModelConfig(input_sec=10.0, time_res=0.01, win_length=2048, sample_rate=sr, dropout=0.0, plain=True, **SETTING1)
+    model = ADTModel(cfg).to(dev)
+    trainer = FlatTrainer(model, lr=1e-4, weight_decay=1e-5, max_grad_norm=1.0, total_steps=10000, warmup_ratio=0.1)
+    bank = OneShotBank.from_tree(synthetic_tree(7, sr), sr)
+    synth = SynthDrum(SynthDrumConfig(input_sec=10.0, time_res=0.01, win_length=2048, sample_rate=sr, oneshot_path="synthetic",
+                                      similarity_threshold=0.8, max_hat_std_velocity=0.15, max_hat_mean_velocity=0.1,
+                                      max_cymbals_std_velocity=0.15, max_cymbals_mean_velocity=0.65, ADTOF_mapping=False,
+                                      mixup_range=0.8, use_fx_prob=0.0, use_reverb_prob=0.5, use_limiter_prob=0.5,
+                                      use_compression_prob=0.5), bank=bank, device=str(dev))
+    rng = np.random.default_rng(100 + seed)
+    random.seed(100 + seed)
+    n_plans = 4                                             # distinct synthetic batches, cycled
+    plans = [synth.plan(synthetic_notes(rng, B)) for _ in range(n_plans)]
+    toks = [synthetic_tokens(rng, B, T) for _ in range(n_plans)]
+    toks_d = [(torch.from_numpy(t).to(dev), torch.from_numpy(l).to(dev)) for t, l in toks]
+    wav_buf = torch.empty((B, L), dtype=torch.float32, device=dev)
+    state = {"i": 0, "loss": None}
+
+    def step():
+        i = state["i"] % n_plans
+        state["i"] += 1
+        synth.render_plan(plans[i], width=L, out=wav_buf)                  # K2: render the batch on the GPU
+        tok, tl = toks_d[i]
+        state["loss"] = trainer.train_step(wav_buf, tok, tl)               # K1 + network fwd/bwd + all-reduce + clip + AdamW
+
+    F = model.compute_spectrogram(wav_buf[:1].zero_()).shape[1]
+    flops_clip = train_flops_per_clip(F, T)
+
+    def roofline():
+        # dominant kernel: the NT bf16 GEMM; measured on the FFN-1 shape of this very step
+        M, N, Kd = B * F, 3072, 768
+        a = torch.randn((M, Kd), device=dev).bfloat16()
+        w = torch.randn((N, Kd), device=dev).bfloat16()
+        bias = torch.zeros(N, device=dev)
+        u = torch.empty((M, N), dtype=torch.bfloat16, device=dev)
+        for _ in range(3):
+            K.gemm(a, w, bias=bias, act=1, pre_act_out=u)
+        ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        ev0.record()
+        for _ in range(20):
+            K.gemm(a, w, bias=bias, act=1, pre_act_out=u)
+        ev1.record()
+        torch.cuda.synchronize()
+        ms = ev0.elapsed_time(ev1) / 20
+        fl = 2.0 * M * N * Kd
+        ach = fl / (ms * 1e-3) / 1e12
+        return {"bound": "mfma", "achieved": ach, "peak": BF16_MFMA_PEAK_TF, "unit": "TFLOP/s", "frac": ach / BF16_MFMA_PEAK_TF,
+                "traffic": None, "kernel": "adt::gemm_bf16_kernel<false> (FFN linear1 + bias + GELU, M=%d N=%d K=%d)" % (M, N, Kd),
+                "kernel_ms": ms, "algorithmic_flops_per_launch": fl}
+
+    def cpu_baseline(budget_s=20.0):
+        from oracle import adt as o_adt
+        torch.set_num_threads(min(os.cpu_count() or 1, 16))
+        sd = {k: v.detach().float().cpu().clone() for k, v in model.state_dict().items()}
+        st = {k: (v.requires_grad_(True) if v.is_floating_point() and "pos_embedding" not in k and "compute_spec" not in k else v)
+              for k, v in sd.items()}
+        ocfg = dict(nhead=6, sample_rate=sr, win_length=2048, time_res=0.01, n_mels=128)
+        nb = 2
+        wav = wav_buf[:nb].cpu()
+        batch = {"wavs": wav.numpy(), "tokens": toks[0][0][:nb], "token_lengths": toks[0][1][:nb]}
+        done, t0 = 0, time.perf_counter()
+        while time.perf_counter() - t0 < budget_s or done == 0:
+            out = o_adt.compute_loss(st, ocfg, batch)
+            out["loss"].backward()
+            done += nb
+        dt = time.perf_counter() - t0
+        return {"value": done / dt, "unit": "clips/s", "cores": torch.get_num_threads(), "kind": "port",
+                "sample": f"{done} clips (batches of {nb}) forward+backward in {dt:.1f} s, fp32, no optimizer step "
+                          "(oracle/adt.py restatement of model.py:240-258)"}
+
+    return {"step": step, "units": B, "dtype": "bf16", "roofline": roofline, "cpu_baseline": cpu_baseline, "state": state,
+            "flops_per_step": flops_clip * B,
+            "metric": "ADT training clips/sec (10 s @16 kHz)",
+            "config": {"workload": "train config[3]: ADT train step, setting-1 network (69.0M params), per-GPU batch 64 x 10 s @ 16 kHz "
+                                   "mixer-rendered clips (F=%d frames), T=128 target tokens, bf16 GEMM/attention with fp32 accumulate, "
+                                   "AdamW + clip 1.0, dropout 0.0" % F,
+                       "global_batch": B * world, "clips_per_gpu": B, "samples": L, "sample_rate": sr, "target_len": T}}
 
 
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=50)
-    ap.add_argument("--warmup", type=int, default=10)
-    ap.add_argument("--workload", default="logmel", choices=["logmel"])
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--workload", default="train", choices=["train", "logmel"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
 
@@ -93,7 +238,7 @@ def main():
     if world > 1:
         dist.init_process_group("nccl", device_id=dev)
 
-    wl = logmel_setup(dev, seed=rank)
+    wl = train_setup(dev, rank, world) if args.workload == "train" else logmel_setup(dev, rank)
     step = wl["step"]
 
     def fence():
@@ -104,15 +249,11 @@ def main():
     for _ in range(args.warmup):
         step()
     fence()
-    ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     t0 = time.perf_counter()
-    ev0.record()
     for _ in range(args.steps):
         step()
-    ev1.record()
     fence()
     dt = time.perf_counter() - t0
-    kern_ms = ev0.elapsed_time(ev1) / args.steps          # HIP events on the stream the kernel runs on
     if world > 1:
         tt = torch.tensor([dt], device=dev, dtype=torch.float64)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
@@ -120,21 +261,19 @@ def main():
 
     if rank == 0:
         units = wl["units"] * world * args.steps
-        achieved = wl["algo_bytes"] / (kern_ms * 1e-3) / 1e9
-        line = {
-            "metric": "ADT hot path clips/sec (10 s @16 kHz), log-mel front end stage",
-            "value": units / dt, "unit": "clips/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "f32", "data": "synthetic", "config": dict(wl["config"], parallelism=f"dp{world}"),
-            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": None,
-                         "kernel": "adt::logmel_kernel", "kernel_ms": kern_ms,
-                         "algorithmic_bytes_per_launch": wl["algo_bytes"],
-                         "fp32_vector_tflops": wl["algo_flops"] / (kern_ms * 1e-3) / 1e12,
-                         "fp32_vector_frac": wl["algo_flops"] / (kern_ms * 1e-3) / 1e12 / FP32_VECTOR_PEAK_TF},
-        }
+        line = {"metric": wl["metric"], "value": units / dt, "unit": "clips/s", "n_gpus": world, "steps": args.steps,
+                "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
+                "vs_baseline": None, "dtype": wl["dtype"], "data": "synthetic",
+                "config": dict(wl["config"], parallelism=f"dp{world}")}
+        if "flops_per_step" in wl:
+            tf = wl["flops_per_step"] / (dt / args.steps) / 1e12
+            line["step_tflops_per_gpu"] = tf
+            line["step_mfma_frac"] = tf / BF16_MFMA_PEAK_TF
+            loss = wl["state"]["loss"]
+            line["final_loss"] = float(loss.item()) if loss is not None else None
+        line["roofline"] = wl["roofline"]()
         if world == 1 and not args.no_cpu_baseline:
-            line["cpu_baseline"] = logmel_cpu_baseline(wl["cpu_input"])
+            line["cpu_baseline"] = wl["cpu_baseline"]()
         print(json.dumps(line), flush=True)
     if world > 1:
         dist.barrier()

@@ -1,0 +1,71 @@
+#!/usr/bin/env python3
+"""Micro-benchmarks of the hot kernels at the training-step shapes (GPU box only).
+Prints one line per kernel/shape: average ms (HIP events, 20 launches) and TFLOP/s or GB/s."""
+import math
+import sys
+import os
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+from adt_str_amd import kernels as K
+
+dev = "cuda:0"
+
+
+def timeit(fn, n=20, warm=3):
+    for _ in range(warm):
+        fn()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(n):
+        fn()
+    e1.record()
+    torch.cuda.synchronize()
+    return e0.elapsed_time(e1) / n
+
+
+def main():
+    M = 64 * 986
+    print("== NT GEMM (forward / dgrad) ==")
+    for (m, n, k) in [(M, 3072, 768), (M, 768, 3072), (M, 2304, 768), (M, 768, 768), (M, 768, 2304), (M, 1536, 768), (8192, 1400, 768),
+                      (8192, 768, 1400), (8192, 3072, 768), (4096, 4096, 4096), (8192, 8192, 8192)]:
+        a = torch.randn((m, k), device=dev).bfloat16()
+        b = torch.randn((n, k), device=dev).bfloat16()
+        ms = timeit(lambda: K.gemm(a, b))
+        print(f"NT M={m} N={n} K={k}: {ms:.3f} ms  {2.0*m*n*k/ms/1e9:.1f} TFLOP/s")
+    print("== TN GEMM (wgrad) ==")
+    for (kk, m, n) in [(M, 768, 3072), (M, 3072, 768), (M, 2304, 768), (M, 768, 768), (M, 1536, 768), (8192, 1400, 768)]:
+        a = torch.randn((kk, m), device=dev).bfloat16()
+        b = torch.randn((kk, n), device=dev).bfloat16()
+        out = torch.empty((m, n), device=dev)
+        ms = timeit(lambda: K.gemm(a, b, trans=True, out=out))
+        print(f"TN K={kk} M={m} N={n}: {ms:.3f} ms  {2.0*m*n*kk/ms/1e9:.1f} TFLOP/s")
+    print("== attention (encoder self-attention shape) ==")
+    B, H, S = 64, 6, 986
+    d = H * 128
+    qkv = torch.randn((B * S, 3 * d), device=dev).bfloat16()
+    scale = 1 / math.sqrt(128)
+    o, lse = K.attn_fwd(qkv[:, :d], qkv[:, d:2 * d], qkv[:, 2 * d:], B, H, S, S, scale)
+    ms = timeit(lambda: K.attn_fwd(qkv[:, :d], qkv[:, d:2 * d], qkv[:, 2 * d:], B, H, S, S, scale))
+    fl = 4.0 * B * H * S * S * 128
+    print(f"attn fwd B={B} H={H} S={S}: {ms:.3f} ms  {fl/ms/1e9:.1f} TFLOP/s")
+    do = torch.randn((B * S, d), device=dev).bfloat16()
+    dqkv = torch.empty_like(qkv)
+    ms = timeit(lambda: K.attn_bwd(qkv[:, :d], qkv[:, d:2 * d], qkv[:, 2 * d:], o, do, lse, dqkv[:, :d], dqkv[:, d:2 * d], dqkv[:, 2 * d:],
+                                   B, H, S, S, scale))
+    print(f"attn bwd (dq + dkdv kernels, 7 matmuls): {ms:.3f} ms  {fl*3.5/ms/1e9:.1f} TFLOP/s executed, {fl*2.5/ms/1e9:.1f} algorithmic")
+    print("== row kernels ==")
+    x = torch.randn((M, 768), device=dev)
+    g, b_ = torch.ones(768, device=dev), torch.zeros(768, device=dev)
+    ms = timeit(lambda: K.layernorm_fwd(x, g, b_))
+    print(f"layernorm fwd [{M},768]: {ms:.3f} ms  {(M*768*(4+4+2))/ms/1e6:.0f} GB/s")
+    y32, y16, mean, rstd = K.layernorm_fwd(x, g, b_)
+    dg, db, dxs = (torch.empty(768, device=dev) for _ in range(3))
+    ms = timeit(lambda: K.layernorm_bwd(x, x, g, mean, rstd, dg, db, dxs))
+    print(f"layernorm bwd [{M},768]: {ms:.3f} ms  {(M*768*(4+4+4+2))/ms/1e6:.0f} GB/s")
+    xb = torch.randn((M, 3072), device=dev).bfloat16()
+    ms = timeit(lambda: K.colsum(xb))
+    print(f"colsum [{M},3072] bf16: {ms:.3f} ms  {(M*3072*2)/ms/1e6:.0f} GB/s")
+
+
+if __name__ == "__main__":
+    main()

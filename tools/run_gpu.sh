@@ -1,13 +1,13 @@
-# usage: bash tools/run_gpu.sh <tag>   (runs on the GPU box through gpurun)
+# usage: bash tools/run_gpu.sh <tag> [pytest]   (runs on the GPU box through gpurun)
 TAG=${1:-rXX}
 R=$GRAFT_REPO_ROOT
 mkdir -p $R/gpurun_out
 cd $R
-timeout 900 python -m pytest tests -m gpu -x -q > gpurun_out/pytest_gpu_$TAG.log 2>&1; tail -8 gpurun_out/pytest_gpu_$TAG.log
-timeout 600 python bench.py --steps 50 --warmup 10 > gpurun_out/bench_$TAG.log 2>&1; tail -2 gpurun_out/bench_$TAG.log
+if [ "$2" = "pytest" ]; then
+  timeout 1200 python -m pytest tests -m gpu -x -q > gpurun_out/pytest_gpu_$TAG.log 2>&1; tail -5 gpurun_out/pytest_gpu_$TAG.log
+fi
+timeout 900 python bench.py --steps 10 --warmup 3 > gpurun_out/bench_$TAG.log 2>&1; tail -3 gpurun_out/bench_$TAG.log | cut -c1-2500
 cd /tmp && export TMPDIR=/tmp
-timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/prof_$TAG -- python3 $R/bench.py --steps 20 --warmup 5 --no-cpu-baseline > $R/gpurun_out/prof_$TAG.log 2>&1
-timeout 600 rocprofv3 --kernel-trace --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_INSTS_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAIT_INST_LDS SQ_ACTIVE_INST_VALU --output-format csv -d $R/gpurun_out/pmc1_$TAG -- python3 $R/bench.py --steps 3 --warmup 1 --no-cpu-baseline > $R/gpurun_out/pmc1_$TAG.log 2>&1
-timeout 600 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $R/gpurun_out/pmc2_$TAG -- python3 $R/bench.py --steps 3 --warmup 1 --no-cpu-baseline > $R/gpurun_out/pmc2_$TAG.log 2>&1
-timeout 600 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $R/gpurun_out/pmc3_$TAG -- python3 $R/bench.py --steps 3 --warmup 1 --no-cpu-baseline > $R/gpurun_out/pmc3_$TAG.log 2>&1
-ls $R/gpurun_out/pmc1_$TAG/*/ | head
+timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/prof_$TAG -- python3 $R/bench.py --steps 5 --warmup 2 --no-cpu-baseline > $R/gpurun_out/prof_$TAG.log 2>&1
+tail -2 $R/gpurun_out/prof_$TAG.log | cut -c1-300
+cat $R/gpurun_out/prof_$TAG/*/*kernel_stats.csv | head -30
