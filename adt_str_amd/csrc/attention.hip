@@ -61,42 +61,54 @@ __device__ __forceinline__ bf16x8 acc_to_b(const f32x16& x, int s) {
 }
 __device__ __forceinline__ int acc_row(int i, int h) { return (i & 3) + 8 * (i >> 2) + 4 * h; }
 
-// ---- tile staging: 64 rows x 128 bf16 of one head, rows >= n_rows read as zero --------------------
-__device__ __forceinline__ void tile_load(const unsigned short* __restrict__ base, long row_stride, int row0, int n_rows,
-                                          int tid, uint4 (&r)[4]) {
+// ---- tile staging by LDS-DMA: 64 rows x 128 bf16 of one head; one wave-instruction (1 KiB) fills 4 rows.
+// The LDS image must be lane-linear, so the swizzle sits on the SOURCE address: position p of row r
+// receives the row's chunk p ^ f(r) (an involution, so reads use swz()).  Rows past n_rows are clamped
+// to the last valid row: their scores are masked / their probabilities are zero, and 0 * finite = 0.
+__device__ __forceinline__ void tile_dma(const unsigned short* __restrict__ base, long row_stride, int row0, int n_rows,
+                                         unsigned char* tile, int wave, int lane) {
 #pragma unroll
   for (int i = 0; i < 4; ++i) {
-    const int c = tid + kAttnThreads * i;
-    const int row = c >> 4, ch = c & 15;
-    uint4 v = make_uint4(0, 0, 0, 0);
-    if (row0 + row < n_rows) v = *reinterpret_cast<const uint4*>(base + static_cast<long>(row0 + row) * row_stride + ch * 8);
-    r[i] = v;
+    const int row = 4 * (4 * wave + i) + (lane >> 4);
+    const int chunk = (lane & 15) ^ (((row & 3) << 2) | ((row >> 2) & 3));
+    int gr = row0 + row;
+    gr = gr < n_rows ? gr : n_rows - 1;
+    const unsigned short* p = base + static_cast<long>(gr) * row_stride + chunk * 8;
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)p,
+                                     (__attribute__((address_space(3))) void*)(tile + (4 * wave + i) * 1024), 16, 0, 0);
   }
 }
-__device__ __forceinline__ void tile_store(unsigned char* tile, int tid, const uint4 (&r)[4]) {
-#pragma unroll
-  for (int i = 0; i < 4; ++i) {
-    const int c = tid + kAttnThreads * i;
-    *reinterpret_cast<uint4*>(tile + swz(c >> 4, c & 15)) = r[i];
-  }
+__device__ __forceinline__ void dma_wait_and_sync() {
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
 }
 // A operand, rows of the tile: tile row (rb*32 + lane&31), d = 16s + 8h .. +7
 __device__ __forceinline__ bf16x8 frag_rows(const unsigned char* tile, int rb, int s, int lane) {
   return *reinterpret_cast<const bf16x8*>(tile + swz(rb * 32 + (lane & 31), 2 * s + (lane >> 5)));
 }
-// A operand, transposed tile: A[row = d = 32db + lane&31][element j] = tile[R0 + 8(j>>2) + 4h + (j&3)][d]
-__device__ __forceinline__ bf16x8 frag_tr(const unsigned char* tile, int R0, int db, int lane) {
+// A operand, transposed tile: A[row = d = 32db + lane&31][element j] = tile[R0 + 8(j>>2) + 4h + (j&3)][d].
+// tr4_issue starts the 8 transposed reads of the four 32-d blocks of one 16-row k-step; tr_wait retires
+// them (one lgkmcnt(0) for all, then a scheduling fence so no MFMA is hoisted above the wait).
+struct TrFrag { bf16x4 lo, hi; };
+__device__ __forceinline__ void tr4_issue(const unsigned char* tile, int R0, int lane, TrFrag (&f)[4]) {
   const int i = lane & 15, g4 = (lane >> 4) & 1, h = lane >> 5;
   const int row = R0 + 4 * h + (i >> 2);
-  const int chunk = 4 * db + 2 * g4 + ((i & 3) >> 1);
   const unsigned base = lds_off(tile) + 8 * (i & 1);
-  const unsigned a0 = base + swz(row, chunk), a1 = base + swz(row + 8, chunk);
-  bf16x4 lo, hi;
-  asm volatile("ds_read_b64_tr_b16 %0, %2\n\tds_read_b64_tr_b16 %1, %3\n\ts_waitcnt lgkmcnt(0)"
-               : "=&v"(lo), "=&v"(hi) : "v"(a0), "v"(a1) : "memory");
+#pragma unroll
+  for (int db = 0; db < 4; ++db) {
+    const int chunk = 4 * db + 2 * g4 + ((i & 3) >> 1);
+    const unsigned a0 = base + swz(row, chunk), a1 = base + swz(row + 8, chunk);
+    asm volatile("ds_read_b64_tr_b16 %0, %2\n\tds_read_b64_tr_b16 %1, %3" : "=&v"(f[db].lo), "=&v"(f[db].hi) : "v"(a0), "v"(a1) : "memory");
+  }
+}
+__device__ __forceinline__ void tr_wait() {
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  __builtin_amdgcn_sched_barrier(0);
+}
+__device__ __forceinline__ bf16x8 tr_get(const TrFrag& f) {
   bf16x8 r;
-  r[0] = lo[0]; r[1] = lo[1]; r[2] = lo[2]; r[3] = lo[3];
-  r[4] = hi[0]; r[5] = hi[1]; r[6] = hi[2]; r[7] = hi[3];
+  r[0] = f.lo[0]; r[1] = f.lo[1]; r[2] = f.lo[2]; r[3] = f.lo[3];
+  r[4] = f.hi[0]; r[5] = f.hi[1]; r[6] = f.hi[2]; r[7] = f.hi[3];
   return r;
 }
 // B operand held in registers: row `row` of a global [*, stride] matrix, d = 16s + 8h .. +7, s = 0..7
@@ -168,20 +180,17 @@ __global__ __launch_bounds__(kAttnThreads) void attn_fwd_kernel(AttnArgs a) {
   float m = kNegBig, l = 0.f;
 
   const int n_tiles = (a.Sk + kRowsPerTile - 1) / kRowsPerTile;
-  uint4 rk[4], rv[4];
-  tile_load(kb_, a.ldk, 0, a.Sk, tid, rk);
-  tile_load(vb, a.ldv, 0, a.Sk, tid, rv);
-  tile_store(smem, tid, rk);
-  tile_store(smem + kAttnTileBytes, tid, rv);
-  __syncthreads();
+  tile_dma(kb_, a.ldk, 0, a.Sk, smem, wave, lane);
+  tile_dma(vb, a.ldv, 0, a.Sk, smem + kAttnTileBytes, wave, lane);
+  dma_wait_and_sync();
 
   for (int t = 0; t < n_tiles; ++t) {
     const unsigned char* tk = smem + (t & 1) * 2 * kAttnTileBytes;
     const unsigned char* tv = tk + kAttnTileBytes;
-    const bool more = t + 1 < n_tiles;
-    if (more) {
-      tile_load(kb_, a.ldk, (t + 1) * kRowsPerTile, a.Sk, tid, rk);
-      tile_load(vb, a.ldv, (t + 1) * kRowsPerTile, a.Sk, tid, rv);
+    if (t + 1 < n_tiles) {
+      unsigned char* nk = smem + ((t + 1) & 1) * 2 * kAttnTileBytes;
+      tile_dma(kb_, a.ldk, (t + 1) * kRowsPerTile, a.Sk, nk, wave, lane);
+      tile_dma(vb, a.ldv, (t + 1) * kRowsPerTile, a.Sk, nk + kAttnTileBytes, wave, lane);
     }
     f32x16 st[2];
 #pragma unroll
@@ -204,7 +213,7 @@ __global__ __launch_bounds__(kAttnThreads) void attn_fwd_kernel(AttnArgs a) {
       }
     mloc = fmaxf(mloc, __shfl_xor(mloc, 32));
     const float m_new = fmaxf(m, mloc);
-    const float alpha = exp2f(m - m_new);
+    const float alpha = __builtin_amdgcn_exp2f(m - m_new);
     m = m_new;
     l *= alpha;
 #pragma unroll
@@ -215,23 +224,21 @@ __global__ __launch_bounds__(kAttnThreads) void attn_fwd_kernel(AttnArgs a) {
 #pragma unroll
     for (int kb = 0; kb < 2; ++kb)
 #pragma unroll
-      for (int i = 0; i < 16; ++i) { const float p = exp2f(st[kb][i] - m); st[kb][i] = p; psum += p; }
+      for (int i = 0; i < 16; ++i) { const float p = __builtin_amdgcn_exp2f(st[kb][i] - m); st[kb][i] = p; psum += p; }
     l += psum;
 #pragma unroll
     for (int kb = 0; kb < 2; ++kb)
 #pragma unroll
       for (int s2 = 0; s2 < 2; ++s2) {
+        TrFrag vt[4];
+        tr4_issue(tv, kb * 32 + 16 * s2, lane, vt);
         const bf16x8 pf = acc_to_b(st[kb], s2);
+        tr_wait();
 #pragma unroll
         for (int db = 0; db < 4; ++db)
-          o[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_tr(tv, kb * 32 + 16 * s2, db, lane), pf, o[db], 0, 0, 0);
+          o[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(tr_get(vt[db]), pf, o[db], 0, 0, 0);
       }
-    if (more) {
-      unsigned char* nk = smem + ((t + 1) & 1) * 2 * kAttnTileBytes;
-      tile_store(nk, tid, rk);
-      tile_store(nk + kAttnTileBytes, tid, rv);
-    }
-    __syncthreads();
+    dma_wait_and_sync();
   }
   const float lt = l + __shfl_xor(l, 32);
   const float inv = 1.0f / lt;
@@ -283,19 +290,16 @@ __global__ __launch_bounds__(kAttnThreads) void attn_bwd_dq_kernel(AttnArgs a) {
     for (int i = 0; i < 16; ++i) dq[db][i] = 0.f;
 
   const int n_tiles = (a.Sk + kRowsPerTile - 1) / kRowsPerTile;
-  uint4 rk[4], rv[4];
-  tile_load(kb_, a.ldk, 0, a.Sk, tid, rk);
-  tile_load(vb, a.ldv, 0, a.Sk, tid, rv);
-  tile_store(smem, tid, rk);
-  tile_store(smem + kAttnTileBytes, tid, rv);
-  __syncthreads();
+  tile_dma(kb_, a.ldk, 0, a.Sk, smem, wave, lane);
+  tile_dma(vb, a.ldv, 0, a.Sk, smem + kAttnTileBytes, wave, lane);
+  dma_wait_and_sync();
   for (int t = 0; t < n_tiles; ++t) {
     const unsigned char* tk = smem + (t & 1) * 2 * kAttnTileBytes;
     const unsigned char* tv = tk + kAttnTileBytes;
-    const bool more = t + 1 < n_tiles;
-    if (more) {
-      tile_load(kb_, a.ldk, (t + 1) * kRowsPerTile, a.Sk, tid, rk);
-      tile_load(vb, a.ldv, (t + 1) * kRowsPerTile, a.Sk, tid, rv);
+    if (t + 1 < n_tiles) {
+      unsigned char* nk = smem + ((t + 1) & 1) * 2 * kAttnTileBytes;
+      tile_dma(kb_, a.ldk, (t + 1) * kRowsPerTile, a.Sk, nk, wave, lane);
+      tile_dma(vb, a.ldv, (t + 1) * kRowsPerTile, a.Sk, nk + kAttnTileBytes, wave, lane);
     }
 #pragma unroll
     for (int kb = 0; kb < 2; ++kb) {
@@ -311,23 +315,21 @@ __global__ __launch_bounds__(kAttnThreads) void attn_bwd_dq_kernel(AttnArgs a) {
       for (int i = 0; i < 16; ++i) {
         const int ki = t * kRowsPerTile + kb * 32 + acc_row(i, h);
         const float tt = st[i] * sl2 + mask_add(a, qi, ki, klen) * kLog2e;
-        const float p = ki < a.Sk ? exp2f(tt - lse2) : 0.f;
+        const float p = ki < a.Sk ? __builtin_amdgcn_exp2f(tt - lse2) : 0.f;
         st[i] = p * (dp[i] - dlt) * a.scale;                 // dS^T
       }
 #pragma unroll
       for (int s2 = 0; s2 < 2; ++s2) {
+        TrFrag kt[4];
+        tr4_issue(tk, kb * 32 + 16 * s2, lane, kt);
         const bf16x8 dsf = acc_to_b(st, s2);
+        tr_wait();
 #pragma unroll
         for (int db = 0; db < 4; ++db)
-          dq[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_tr(tk, kb * 32 + 16 * s2, db, lane), dsf, dq[db], 0, 0, 0);
+          dq[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(tr_get(kt[db]), dsf, dq[db], 0, 0, 0);
       }
     }
-    if (more) {
-      unsigned char* nk = smem + ((t + 1) & 1) * 2 * kAttnTileBytes;
-      tile_store(nk, tid, rk);
-      tile_store(nk + kAttnTileBytes, tid, rv);
-    }
-    __syncthreads();
+    dma_wait_and_sync();
   }
   store_transposed(dq, 1.0f, a.dq + static_cast<long>(b) * a.Sq * a.ldq + head * kDh, a.ldq, qi, a.Sq, lane);
 }
@@ -359,7 +361,6 @@ __global__ __launch_bounds__(kAttnThreads, 1) void attn_bwd_dkv_kernel(AttnArgs 
     for (int i = 0; i < 16; ++i) { dk[db][i] = 0.f; dv[db][i] = 0.f; }
 
   const int n_tiles = (a.Sq + kRowsPerTile - 1) / kRowsPerTile;
-  uint4 rq[4], rd[4];
   float rs = 0.f;
   auto load_stats = [&](int t) {                      // threads 0..63: lse2, 64..127: delta of the tile's 64 queries
     const int qq = t * kRowsPerTile + (tid & 63);
@@ -369,21 +370,20 @@ __global__ __launch_bounds__(kAttnThreads, 1) void attn_bwd_dkv_kernel(AttnArgs 
   auto store_stats = [&](unsigned char* stage) {
     if (tid < 128) reinterpret_cast<float*>(stage + 2 * kAttnTileBytes)[tid] = rs;
   };
-  tile_load(qb, a.ldq, 0, a.Sq, tid, rq);
-  tile_load(dob, a.ldo, 0, a.Sq, tid, rd);
+  tile_dma(qb, a.ldq, 0, a.Sq, smem, wave, lane);
+  tile_dma(dob, a.ldo, 0, a.Sq, smem + kAttnTileBytes, wave, lane);
   load_stats(0);
-  tile_store(smem, tid, rq);
-  tile_store(smem + kAttnTileBytes, tid, rd);
   store_stats(smem);
-  __syncthreads();
+  dma_wait_and_sync();
   for (int t = 0; t < n_tiles; ++t) {
     const unsigned char* tq = smem + (t & 1) * kStage;
     const unsigned char* td = tq + kAttnTileBytes;
     const float* stats = reinterpret_cast<const float*>(tq + 2 * kAttnTileBytes);
     const bool more = t + 1 < n_tiles;
     if (more) {
-      tile_load(qb, a.ldq, (t + 1) * kRowsPerTile, a.Sq, tid, rq);
-      tile_load(dob, a.ldo, (t + 1) * kRowsPerTile, a.Sq, tid, rd);
+      unsigned char* ns = smem + ((t + 1) & 1) * kStage;
+      tile_dma(qb, a.ldq, (t + 1) * kRowsPerTile, a.Sq, ns, wave, lane);
+      tile_dma(dob, a.ldo, (t + 1) * kRowsPerTile, a.Sq, ns + kAttnTileBytes, wave, lane);
       load_stats(t + 1);
     }
 #pragma unroll
@@ -401,27 +401,26 @@ __global__ __launch_bounds__(kAttnThreads, 1) void attn_bwd_dkv_kernel(AttnArgs 
         const int ql = qblk * 32 + acc_row(i, h);
         const int qi = t * kRowsPerTile + ql;
         const float tt = st[i] * sl2 + mask_add(a, qi, ki, klen) * kLog2e;
-        const float p = (qi < a.Sq && ki < a.Sk) ? exp2f(tt - stats[ql]) : 0.f;
+        const float p = (qi < a.Sq && ki < a.Sk) ? __builtin_amdgcn_exp2f(tt - stats[ql]) : 0.f;
         st[i] = p;                                           // P
         dp[i] = p * (dp[i] - stats[64 + ql]) * a.scale;      // dS
       }
 #pragma unroll
       for (int s2 = 0; s2 < 2; ++s2) {
+        TrFrag dot[4], qt[4];
+        tr4_issue(td, qblk * 32 + 16 * s2, lane, dot);
+        tr4_issue(tq, qblk * 32 + 16 * s2, lane, qt);
         const bf16x8 pf = acc_to_b(st, s2), dsf = acc_to_b(dp, s2);
+        tr_wait();
 #pragma unroll
         for (int db = 0; db < 4; ++db) {
-          dv[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_tr(td, qblk * 32 + 16 * s2, db, lane), pf, dv[db], 0, 0, 0);
-          dk[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_tr(tq, qblk * 32 + 16 * s2, db, lane), dsf, dk[db], 0, 0, 0);
+          dv[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(tr_get(dot[db]), pf, dv[db], 0, 0, 0);
+          dk[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(tr_get(qt[db]), dsf, dk[db], 0, 0, 0);
         }
       }
     }
-    if (more) {
-      unsigned char* ns = smem + ((t + 1) & 1) * kStage;
-      tile_store(ns, tid, rq);
-      tile_store(ns + kAttnTileBytes, tid, rd);
-      store_stats(ns);
-    }
-    __syncthreads();
+    if (more) store_stats(smem + ((t + 1) & 1) * kStage);
+    dma_wait_and_sync();
   }
   store_transposed(dk, 1.0f, a.dk + static_cast<long>(b) * a.Sk * a.ldk + head * kDh, a.ldk, ki, a.Sk, lane);
   store_transposed(dv, 1.0f, a.dv + static_cast<long>(b) * a.Sk * a.ldv + head * kDh, a.ldv, ki, a.Sk, lane);

@@ -378,6 +378,112 @@ __global__ __launch_bounds__(kGemmThreads) void gemm_nt_glds_kernel(GemmArgs g, 
   gemm_epilogue_rows(g, acc, reinterpret_cast<float*>(smem), m0, n0, wm, wn, tid, lane);
 }
 
+// =========================================================================================
+// TN kernel (weight gradients), LDS-DMA staging (used when K % 64 == 0).
+// Operand tiles are [64 k][128 cols] (256-byte rows); one wave-instruction of global_load_lds
+// fills 4 rows.  Position p of row r holds the row's 16-byte chunk p ^ (2*(r & 7)), which puts
+// the 8 consecutive rows a half-wave reads with ds_read_b64_tr_b16 on 8 distinct 32-byte bank
+// slots.  All 16 transposed reads of a 32-deep k-step are issued back to back and retired by one
+// lgkmcnt(0) before the 16 MFMAs.  Columns past M / N are clamped (read, never stored).
+__device__ __forceinline__ int swz_tn(int row) { return (row & 7) << 1; }
+
+__device__ __forceinline__ void glds_tile_tn(const unsigned short* __restrict__ src, long ld, int k0, int col0, int n_cols,
+                                             unsigned char* tile, int wave, int lane) {
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int row = 4 * (4 * wave + i) + (lane >> 4);
+    const int chunk = (lane & 15) ^ swz_tn(row);
+    int gc = col0 + chunk * 8;
+    gc = gc + 8 <= n_cols ? gc : n_cols - 8;
+    const unsigned short* p = src + static_cast<long>(k0 + row) * ld + gc;
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)p,
+                                     (__attribute__((address_space(3))) void*)(tile + (4 * wave + i) * 1024), 16, 0, 0);
+  }
+}
+// issue the two transposed reads of one 16-column x 32-k fragment (no wait)
+__device__ __forceinline__ void tr_issue(unsigned tile_base, int col0, int ks, int lane, bf16x4& lo, bf16x4& hi) {
+  const int t = lane & 15, g = lane >> 4;
+  const int row = ks * 32 + 4 * g + (t >> 2);
+  const int chunk = ((col0 + 4 * (t & 3)) >> 3) ^ swz_tn(row);
+  const unsigned a0 = tile_base + row * 256 + chunk * 16 + 8 * (t & 1);
+  asm volatile("ds_read_b64_tr_b16 %0, %2\n\tds_read_b64_tr_b16 %1, %2 offset:4096" : "=&v"(lo), "=&v"(hi) : "v"(a0) : "memory");
+}
+__device__ __forceinline__ bf16x8 join8(const bf16x4& lo, const bf16x4& hi) {
+  bf16x8 r;
+  r[0] = lo[0]; r[1] = lo[1]; r[2] = lo[2]; r[3] = lo[3]; r[4] = hi[0]; r[5] = hi[1]; r[6] = hi[2]; r[7] = hi[3];
+  return r;
+}
+
+__global__ __launch_bounds__(kGemmThreads) void gemm_tn_glds_kernel(GemmArgs g, int tiles_m, int tiles_n) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];      // [2 stages][A tile | B tile], reused by the epilogue
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave >> 1, wn = wave & 1;
+  const int nwg = tiles_m * tiles_n, bid = blockIdx.x;
+  const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7;
+  const int logical = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
+  const int m0 = (logical / tiles_n) * kBM, n0 = (logical % tiles_n) * kBN;
+  const int split = blockIdx.y;
+  const int k_tiles = g.K / kBK;
+  const int kt0 = split * g.k_tiles_per_split;
+  int kt1 = kt0 + g.k_tiles_per_split;
+  if (kt1 > k_tiles) kt1 = k_tiles;
+
+  f32x4 acc[4][4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  if (kt0 < kt1) {
+    glds_tile_tn(g.A, g.lda, kt0 * kBK, m0, g.M, smem, wave, lane);
+    glds_tile_tn(g.B, g.ldb, kt0 * kBK, n0, g.N, smem + kTileNT, wave, lane);
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+  for (int kt = kt0; kt < kt1; ++kt) {
+    const int cur = (kt - kt0) & 1;
+    const unsigned ta = lds_addr(smem + cur * 2 * kTileNT), tb = ta + kTileNT;
+    if (kt + 1 < kt1) {
+      unsigned char* na = smem + (cur ^ 1) * 2 * kTileNT;
+      glds_tile_tn(g.A, g.lda, (kt + 1) * kBK, m0, g.M, na, wave, lane);
+      glds_tile_tn(g.B, g.ldb, (kt + 1) * kBK, n0, g.N, na + kTileNT, wave, lane);
+    }
+#pragma unroll
+    for (int ks = 0; ks < kBK / 32; ++ks) {
+      bf16x4 alo[4], ahi[4], blo[4], bhi[4];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        tr_issue(ta, wm * 64 + i * 16, ks, lane, alo[i], ahi[i]);
+        tr_issue(tb, wn * 64 + i * 16, ks, lane, blo[i], bhi[i]);
+      }
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      __builtin_amdgcn_sched_barrier(0);
+      bf16x8 fa[4], fb[4];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) { fa[i] = join8(alo[i], ahi[i]); fb[i] = join8(blo[i], bhi[i]); }
+      __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+          acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[i], fb[j], acc[i][j], 0, 0, 0);
+      __builtin_amdgcn_s_setprio(0);
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+  }
+  GemmArgs o = g;
+  if (g.slabs) {                       // split-K partial: plain fp32 tile into this split's slab
+    o.C = g.slabs + static_cast<long>(split) * g.M * g.N;
+    o.ldc = g.N;
+    o.ep = adt_gemm_epilogue{};
+    o.ep.alpha = 1.0f;
+    o.ep.out_fp32 = 1;
+  }
+  gemm_epilogue_rows(o, acc, reinterpret_cast<float*>(smem), m0, n0, wm, wn, tid, lane);
+}
+
 // sums split-K slabs in slab order: out[m,n] = alpha * sum_s slab[s][m,n]   (fp32 out)
 __global__ __launch_bounds__(256) void reduce_slabs_kernel(const float* __restrict__ slabs, int splits, long mn, int N,
                                                            float alpha, float* __restrict__ out, long ldc) {
@@ -461,9 +567,13 @@ extern "C" int adt_gemm_bf16(int32_t trans, int64_t M, int64_t N, int64_t K, con
     ADT_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_bf16_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, kGemmLds));
     ADT_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_bf16_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, kGemmLds));
     ADT_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_nt_glds_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, kEpiLds));
+    ADT_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_tn_glds_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, kEpiLds));
     attr_dev = dev;
   }
-  if (trans) {
+  if (trans && (K % kBK) == 0 && K > 0 && vector_epilogue_ok(g, e) && M >= 8 && (splits == 1 || aligned16(ws))) {
+    const int tm = static_cast<int>((M + kBM - 1) / kBM), tn = static_cast<int>((N + kBN - 1) / kBN);
+    hipLaunchKernelGGL(gemm_tn_glds_kernel, dim3(static_cast<unsigned>(tm) * tn, splits), dim3(kGemmThreads), kEpiLds, st, g, tm, tn);
+  } else if (trans) {
     hipLaunchKernelGGL(gemm_bf16_kernel<true>, grid, dim3(kGemmThreads), kGemmLds, st, g);
   } else if ((K % kBK) == 0 && K > 0 && vector_epilogue_ok(g, e)) {
     const int tm = static_cast<int>((M + kBM - 1) / kBM), tn = static_cast<int>((N + kBN - 1) / kBN);
