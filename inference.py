@@ -1,0 +1,73 @@
+"""Drop-in for the reference's ``inference.py``: ``python inference.py <in.wav> <config.yaml> [-o dir] [-s]``.
+
+load -> mono -> fixed chunks of ``input_sec`` (last one zero padded, inference.py:35-48) -> greedy ``sample`` ->
+``decode`` -> notes shifted by the chunk start -> unique rows -> Standard MIDI File (+ optional re-synthesis).
+WAV reading and MIDI writing are in adt_str_amd/audio_io.py (no torchaudio / pretty_midi on the GPU box).
+"""
+import argparse
+import os
+
+import numpy as np
+import torch
+
+from adt_str_amd.audio_io import read_wav, write_drum_midi, write_wav
+from adt_str_amd.tokenizer import MidiTokenizer, MidiTokenizerConfig
+from build_model import build_model
+
+
+def _chunk_audio(wav: torch.Tensor, chunk_samples: int):
+    """[samples] -> [n_chunks, chunk_samples], the tail zero padded."""
+    n = max(1, -(-wav.numel() // chunk_samples))
+    out = torch.zeros(n * chunk_samples, dtype=wav.dtype, device=wav.device)
+    out[: wav.numel()] = wav
+    return out.view(n, chunk_samples)
+
+
+def transcribe(model, cfg: dict, wav: torch.Tensor, batch_size: int = 8):
+    shared, inf = cfg["shared"], cfg["inference"]
+    tok_cfg = cfg.get("tokenizer") or dict(ADTOF_mapping=False, BOS_token=2, EOS_token=3, pad_token=1, silence_token=0, add_velocity=True)
+    tokenizer = MidiTokenizer(MidiTokenizerConfig(**tok_cfg))
+    chunk = int(round(shared["input_sec"] * shared["sample_rate"]))
+    chunks = _chunk_audio(wav, chunk)
+    notes = []
+    for i in range(0, chunks.shape[0], batch_size):
+        ids = model.sample(src=chunks[i:i + batch_size], src_mask=None, tgt_mask=None, max_length=inf["max_length"],
+                           start_token=tok_cfg["BOS_token"], end_token=tok_cfg["EOS_token"]).cpu()
+        for j, row in enumerate(ids):
+            dec = tokenizer.decode(row.tolist())
+            if dec.numel():
+                dec = dec.clone()
+                dec[:, :2] += (i + j) * shared["input_sec"]
+                notes.append(dec)
+    if not notes:
+        return np.zeros((0, 4), np.float32)
+    return np.unique(torch.cat(notes).numpy(), axis=0)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("input_path")
+    ap.add_argument("config_path")
+    ap.add_argument("-o", "--output_dir", default="outputs")
+    ap.add_argument("-s", "--synthesize", action="store_true", help="also render the transcription with the one-shot mixer")
+    a = ap.parse_args()
+    model, cfg = build_model(a.config_path, device="cuda")
+    audio, sr = read_wav(a.input_path)
+    if sr != cfg["shared"]["sample_rate"]:
+        raise NotImplementedError(f"{a.input_path} is {sr} Hz but the model runs at {cfg['shared']['sample_rate']} Hz; "
+                                  "resample the file first (the polyphase resampler is a later hot-path row)")
+    wav = torch.from_numpy(audio.mean(axis=0)).cuda()
+    notes = transcribe(model, cfg, wav, cfg["inference"]["batch_size"])
+    os.makedirs(a.output_dir, exist_ok=True)
+    stem = os.path.splitext(os.path.basename(a.input_path))[0]
+    write_drum_midi(os.path.join(a.output_dir, stem + ".mid"), notes.tolist())
+    print(f"{len(notes)} notes -> {os.path.join(a.output_dir, stem + '.mid')}")
+    if a.synthesize and len(notes):
+        from train import build_components
+        _, _, synth = build_components(cfg)
+        ok = [n for n in notes.tolist() if 35 <= n[2] <= 61]
+        write_wav(os.path.join(a.output_dir, stem + "_resynth.wav"), synth(ok).cpu().numpy(), cfg["shared"]["sample_rate"])
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,95 @@
+"""Data-parallel path with world_size 2 on the gloo backend (CPU): the flat gradient buffer is
+tiled exactly by the backward segments, each segment is all-reduced once, the result is the mean
+over ranks, and rank 0's parameters reach every rank."""
+import os
+import socket
+
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _worker(rank, world, port, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from adt_str_amd.network import ADTModel, ADTModelConfig
+        from adt_str_amd.trainer import GradReducer, backward_segments
+        torch.manual_seed(rank)                       # different initial weights per rank
+        model = ADTModel(ADTModelConfig(input_sec=0.5, time_res=0.01, win_length=2048, sample_rate=16000, enc_layers=2, dec_layers=1,
+                                        nhead=1, d_query=128, dropout=0.0, tgt_vocab_size=1400, plain=True, n_mels=128))
+        eng = model.engine
+        gflat, G = eng.grad_buffers()
+        n = gflat.numel()
+        segs = backward_segments(eng)
+        # the segments tile [0, n) without overlap
+        marks = torch.zeros(n, dtype=torch.int32)
+        for lo, hi in segs:
+            marks[lo:hi] += 1
+        assert bool((marks == 1).all()), "backward segments must cover every gradient element exactly once"
+        # rank-dependent gradients -> mean
+        base = torch.arange(n, dtype=torch.float32) % 1000
+        gflat.copy_(base * (rank + 1))
+        red = GradReducer(gflat)
+        for lo, hi in segs:
+            red.segment_ready(lo, hi)
+        red.finish()
+        expect = base * (sum(r + 1 for r in range(world)) / world)
+        assert torch.allclose(gflat, expect)
+        # views stay aliased to the flat buffer
+        name = "decoder.generator.bias"
+        lo, hi = eng.flat_range(name)
+        assert torch.equal(G[name], gflat[lo:hi])
+        # a missing segment is detected
+        red2 = GradReducer(gflat)
+        red2.segment_ready(*segs[0])
+        try:
+            red2.finish()
+            ok = False
+        except RuntimeError:
+            ok = True
+        assert ok
+        # parameter broadcast from rank 0 (what FlatTrainer does once at construction)
+        pflat = torch.cat([p.data.reshape(-1) for p in model.parameters()])
+        dist.broadcast(pflat, src=0)
+        ref = [pflat.clone() for _ in range(world)]
+        dist.all_gather(ref, pflat)
+        assert all(torch.equal(ref[0], r) for r in ref)
+        q.put((rank, "ok"))
+    except Exception as e:                              # pragma: no cover
+        q.put((rank, repr(e)))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_gradient_reduction_world_size_2():
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=180) for _ in procs]
+    for p in procs:
+        p.join(timeout=60)
+    assert sorted(res) == [(0, "ok"), (1, "ok")], res
+
+
+def test_lr_schedule_matches_hf_cosine():
+    from transformers.optimization import get_cosine_schedule_with_warmup
+    from adt_str_amd.trainer import cosine_with_warmup
+    p = torch.nn.Parameter(torch.zeros(1))
+    opt = torch.optim.SGD([p], lr=1.0)
+    sch = get_cosine_schedule_with_warmup(opt, num_warmup_steps=10, num_training_steps=100)
+    for step in range(100):
+        assert abs(sch.get_last_lr()[0] - cosine_with_warmup(step, 100, 10)) < 1e-7, step
+        opt.step(); sch.step()

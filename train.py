@@ -1,0 +1,99 @@
+"""Drop-in for the reference's ``train.py``: ``python train.py <experiment.yaml>`` (or ``accelerate launch``).
+
+``ADTTrainer.compute_loss`` keeps the reference hook signature (train.py:40-78) so HF ``Trainer`` drives the
+hand-written gfx950 forward/backward through autograd; ``--native`` instead runs the flat-buffer loop of
+``adt_str_amd.trainer.FlatTrainer`` (one fused clip + AdamW launch, bucketed RCCL all-reduce overlapped with
+backward), which is what ``bench.py`` measures.
+"""
+import argparse
+import logging
+import os
+import random
+from typing import Optional
+
+import torch
+
+from adt_str_amd.config_utils import load_merged
+from adt_str_amd.masks import create_mask_plain
+from adt_str_amd.network import ADTModel
+from adt_str_amd.synth import SynthDrum, SynthDrumConfig
+from adt_str_amd.tokenizer import MidiTokenizer, MidiTokenizerConfig
+from build_model import model_config_from
+
+try:
+    from transformers import Trainer, TrainingArguments
+except Exception:                                     # pragma: no cover - transformers is part of the image
+    Trainer = object
+    TrainingArguments = None
+
+
+class ADTTrainer(Trainer):
+    """HF Trainer subclass of the reference (train.py:33-78)."""
+
+    def compute_loss(self, model, inputs, return_outputs=False, **kwargs):
+        model.train()
+        device = next(model.parameters()).device
+        tokens = inputs["tokens"].to(device)
+        wavs = inputs["wavs"].to(device)
+        token_lengths = inputs["token_lengths"].to(device)
+        tgt_input, labels = tokens[:, :-1], tokens[:, 1:]                     # teacher forcing (train.py:56-57)
+        _, tgt_padding_mask = create_mask_plain(tgt_input.size(1), token_lengths, device)
+        loss = model(src=wavs, tgt=tgt_input, tgt_mask=None, tgt_padding_mask=tgt_padding_mask, labels=labels)
+        # the reference also runs gc.collect() + empty_cache() here every step (train.py:73-76): a host stall
+        # and an allocator flush per step with no effect on the result -- deliberately not reproduced
+        return (loss, None) if return_outputs else loss
+
+
+def create_training_arguments(cfg: dict) -> "TrainingArguments":
+    t, lg, ex, ck = cfg["training"], cfg["logging"], cfg["experiment"], cfg["checkpoint"]
+    kw = dict(output_dir=lg["output_dir"], per_device_train_batch_size=t["batch_size"], num_train_epochs=t["num_epochs"] or 1,
+              learning_rate=t["learning_rate"], warmup_ratio=t["warmup_ratio"], weight_decay=t["weight_decay"],
+              max_grad_norm=t["max_grad_norm"], gradient_accumulation_steps=t["gradient_accumulation_steps"], optim=t["optim"],
+              lr_scheduler_type=t["lr_scheduler_type"], logging_steps=lg["logging_steps"], seed=ex["seed"],
+              bf16=False,                     # the engine already computes in bf16 with fp32 accumulation; autocast has nothing to wrap
+              dataloader_num_workers=0, remove_unused_columns=False, report_to=[], save_total_limit=ck["max_checkpoints"],
+              ddp_broadcast_buffers=False,     # PE tables / window / filterbank are constants (the reference re-broadcasts them each forward)
+              save_strategy="steps" if lg.get("save_every_n_steps") else "epoch")
+    if lg.get("save_every_n_steps"):
+        kw["save_steps"] = lg["save_every_n_steps"]
+    import inspect
+    if "warmup_ratio" not in inspect.signature(TrainingArguments.__init__).parameters:
+        kw["warmup_steps"] = kw.pop("warmup_ratio")       # transformers >= 5: a float < 1 in warmup_steps is the ratio
+    if t.get("min_learning_rate"):
+        kw["lr_scheduler_type"] = "cosine_warmup_with_min_lr"
+        kw["lr_scheduler_kwargs"] = {"min_lr": t["min_learning_rate"]}
+    return TrainingArguments(**kw)
+
+
+def build_components(cfg: dict, device: str = "cuda"):
+    shared = cfg["shared"]
+    tokenizer = MidiTokenizer(MidiTokenizerConfig(**cfg["tokenizer"]))
+    synth_cfg = dict(cfg["synthetiser"])
+    synth_cfg.setdefault("ADTOF_mapping", cfg["tokenizer"]["ADTOF_mapping"])
+    synth = SynthDrum(SynthDrumConfig(**shared, **synth_cfg), device=device)
+    model = ADTModel(model_config_from(cfg))
+    return model, tokenizer, synth
+
+
+def train(cfg: dict, native: bool = False):
+    from data_modules.train_dataset import LakhDataset, LakhDatasetConfig
+    logging.basicConfig(level=getattr(logging, cfg["logging"].get("log_level", "INFO")))
+    random.seed(cfg["experiment"]["seed"])
+    torch.manual_seed(cfg["experiment"]["seed"])
+    model, tokenizer, synth = build_components(cfg)
+    ds = LakhDataset(LakhDatasetConfig(**cfg["shared"], **cfg["TrainDatasetConfig"]), tokenizer, synth)
+    if native:
+        from adt_str_amd.trainer import run_native_training
+        return run_native_training(model.cuda(), ds, cfg)
+    trainer = ADTTrainer(model=model, args=create_training_arguments(cfg), train_dataset=ds, data_collator=ds.collate)
+    trainer.train(resume_from_checkpoint=cfg["checkpoint"].get("resume_from_checkpoint"))
+    trainer.save_model()
+    return trainer
+
+
+if __name__ == "__main__":
+    ap = argparse.ArgumentParser()
+    ap.add_argument("config", type=str)
+    ap.add_argument("--native", action="store_true", help="flat-buffer training loop instead of HF Trainer")
+    a = ap.parse_args()
+    train(load_merged(a.config), native=a.native)
