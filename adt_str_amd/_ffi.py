@@ -14,16 +14,22 @@ _LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "libadt_hip
 _lock = threading.Lock()
 _lib = None
 
-ABI_VERSION = 1
+ABI_VERSION = 2
 
 i32, i64, f32, ptr = C.c_int32, C.c_int64, C.c_float, C.c_void_p
+
+class Dropout(C.Structure):
+    """struct adt_dropout (include/adt_hip.h)."""
+    _fields_ = [("p", C.c_float), ("key", C.c_uint32)]
+
 
 class GemmEpilogue(C.Structure):
     """struct adt_gemm_epilogue (include/adt_hip.h)."""
     _fields_ = [("bias", C.c_void_p), ("gelu_grad_of", C.c_void_p), ("ld_gelu_grad", C.c_int64),
                 ("pre_act_out", C.c_void_p), ("ld_pre_act", C.c_int64), ("residual", C.c_void_p),
                 ("ld_res", C.c_int64), ("res_row_mod", C.c_int32), ("act", C.c_int32), ("alpha", C.c_float),
-                ("out_fp32", C.c_int32), ("aux_bf16_out", C.c_void_p), ("ld_aux", C.c_int64)]
+                ("out_fp32", C.c_int32), ("aux_bf16_out", C.c_void_p), ("ld_aux", C.c_int64), ("drop", Dropout),
+                ("drop_after_residual", C.c_int32)]
 
 
 class AttnDesc(C.Structure):
@@ -31,7 +37,7 @@ class AttnDesc(C.Structure):
     _fields_ = [("batch", C.c_int32), ("heads", C.c_int32), ("q_len", C.c_int32), ("k_len", C.c_int32),
                 ("head_dim", C.c_int32), ("causal", C.c_int32), ("ldq", C.c_int64), ("ldk", C.c_int64),
                 ("ldv", C.c_int64), ("ldo", C.c_int64), ("scale", C.c_float), ("mask_value", C.c_float),
-                ("key_len", C.c_void_p)]
+                ("key_len", C.c_void_p), ("drop", Dropout)]
 
 
 # name -> argtypes; every entry must be declared in include/adt_hip.h (tests check both ways)
@@ -45,13 +51,13 @@ SIGNATURES = {
     "adt_attn_fwd": [ptr, ptr, ptr, ptr, ptr, ptr, ptr],
     "adt_attn_bwd_workspace_bytes": [ptr],
     "adt_attn_bwd": [ptr, ptr, ptr, ptr, ptr, ptr, ptr, ptr, ptr, ptr, ptr, C.c_size_t, ptr],
-    "adt_layernorm_fwd": [ptr, i64, ptr, ptr, f32, ptr, ptr, i64, ptr, ptr, i64, i64, ptr],
+    "adt_layernorm_fwd": [ptr, i64, ptr, ptr, f32, ptr, ptr, i64, ptr, ptr, i64, i64, ptr, ptr],
     "adt_layernorm_bwd_workspace_bytes": [i64, i64],
-    "adt_layernorm_bwd": [ptr, i64, ptr, i64, ptr, ptr, ptr, ptr, ptr, i64, ptr, ptr, ptr, i64, i64, ptr, C.c_size_t, ptr],
+    "adt_layernorm_bwd": [ptr, i64, ptr, i64, ptr, ptr, ptr, ptr, ptr, i64, ptr, ptr, ptr, i64, i64, ptr, ptr, ptr, C.c_size_t, ptr],
     "adt_colsum_workspace_bytes": [i64, i64],
     "adt_colsum_bf16": [ptr, i64, i64, i64, ptr, ptr, C.c_size_t, ptr],
-    "adt_embed_pe_fwd": [ptr, ptr, ptr, f32, ptr, ptr, i64, i64, i64, i64, ptr],
-    "adt_embed_bwd": [ptr, ptr, f32, ptr, i64, i64, i64, ptr],
+    "adt_embed_pe_fwd": [ptr, ptr, ptr, f32, ptr, ptr, i64, i64, i64, i64, ptr, ptr],
+    "adt_embed_bwd": [ptr, ptr, f32, ptr, i64, i64, i64, ptr, ptr],
     "adt_cross_entropy_workspace_bytes": [i64],
     "adt_cross_entropy": [ptr, i64, ptr, i64, i64, i64, ptr, ptr, i64, ptr, C.c_size_t, ptr],
     "adt_cast_bf16": [ptr, ptr, ptr, i64, i64, ptr],

@@ -26,6 +26,7 @@
 #include <hip/hip_runtime.h>
 
 #include "adt_common.h"
+#include "dropout.h"
 
 namespace adt {
 
@@ -146,6 +147,7 @@ struct AttnArgs {
   long ldq, ldk, ldv, ldo;          // row strides (elements); gradients share the strides of their tensors
   int B, H, Sq, Sk;
   float scale, mask_value; int causal; const int* key_len;
+  Drop drop;
 };
 
 // additive mask of the reference (model.py:173-181): causal and key-padding contributions add up
@@ -226,6 +228,13 @@ __global__ __launch_bounds__(kAttnThreads) void attn_fwd_kernel(AttnArgs a) {
 #pragma unroll
       for (int i = 0; i < 16; ++i) { const float p = __builtin_amdgcn_exp2f(st[kb][i] - m); st[kb][i] = p; psum += p; }
     l += psum;
+    if (a.drop.on()) {                       // dropout on the probabilities (the normaliser keeps the un-dropped sum)
+      const uint64_t rowbase = ((static_cast<uint64_t>(b) * a.H + head) * a.Sq + qi) * a.Sk;
+#pragma unroll
+      for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+        for (int i = 0; i < 16; ++i) st[kb][i] *= a.drop.scale(rowbase + t * kRowsPerTile + kb * 32 + acc_row(i, h));
+    }
 #pragma unroll
     for (int kb = 0; kb < 2; ++kb)
 #pragma unroll
@@ -316,7 +325,8 @@ __global__ __launch_bounds__(kAttnThreads) void attn_bwd_dq_kernel(AttnArgs a) {
         const int ki = t * kRowsPerTile + kb * 32 + acc_row(i, h);
         const float tt = st[i] * sl2 + mask_add(a, qi, ki, klen) * kLog2e;
         const float p = ki < a.Sk ? __builtin_amdgcn_exp2f(tt - lse2) : 0.f;
-        st[i] = p * (dp[i] - dlt) * a.scale;                 // dS^T
+        const float keep = a.drop.on() ? a.drop.scale(((static_cast<uint64_t>(b) * a.H + head) * a.Sq + qi) * a.Sk + ki) : 1.0f;
+        st[i] = p * (dp[i] * keep - dlt) * a.scale;          // dS^T
       }
 #pragma unroll
       for (int s2 = 0; s2 < 2; ++s2) {
@@ -402,8 +412,9 @@ __global__ __launch_bounds__(kAttnThreads, 1) void attn_bwd_dkv_kernel(AttnArgs 
         const int qi = t * kRowsPerTile + ql;
         const float tt = st[i] * sl2 + mask_add(a, qi, ki, klen) * kLog2e;
         const float p = (qi < a.Sq && ki < a.Sk) ? __builtin_amdgcn_exp2f(tt - stats[ql]) : 0.f;
-        st[i] = p;                                           // P
-        dp[i] = p * (dp[i] - stats[64 + ql]) * a.scale;      // dS
+        const float keep = a.drop.on() ? a.drop.scale(((static_cast<uint64_t>(b) * a.H + head) * a.Sq + qi) * a.Sk + ki) : 1.0f;
+        st[i] = p * keep;                                    // dropped P (what multiplied V in the forward)
+        dp[i] = p * (dp[i] * keep - stats[64 + ql]) * a.scale;   // dS
       }
 #pragma unroll
       for (int s2 = 0; s2 < 2; ++s2) {
@@ -442,6 +453,7 @@ static AttnArgs make_args(const adt_attn_desc* d) {
   a.ldq = d->ldq; a.ldk = d->ldk; a.ldv = d->ldv; a.ldo = d->ldo;
   a.B = d->batch; a.H = d->heads; a.Sq = d->q_len; a.Sk = d->k_len;
   a.scale = d->scale; a.mask_value = d->mask_value; a.causal = d->causal; a.key_len = d->key_len;
+  a.drop = make_drop(d->drop.p, d->drop.key);
   return a;
 }
 static int set_lds_once() {      // raise the dynamic-LDS limit of the three kernels once per device and thread

@@ -38,5 +38,5 @@ int device_cu_count(int* n_cu) {
 
 }  // namespace adt
 
-extern "C" int adt_version(void) { return 1; }
+extern "C" int adt_version(void) { return 2; }
 extern "C" const char* adt_last_error(void) { return adt::g_err; }

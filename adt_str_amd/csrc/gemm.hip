@@ -21,6 +21,7 @@
 #include <hip/hip_runtime.h>
 
 #include "adt_common.h"
+#include "dropout.h"
 
 namespace adt {
 
@@ -57,6 +58,7 @@ struct GemmArgs {
   int k_tiles_per_split;
   float* slabs;                 // TN split-K partials [splits][M][N] (null when splits == 1)
   adt_gemm_epilogue ep;
+  Drop drop;
 };
 
 // ---- global -> register staging (4 x 16 B per thread per operand) -----------------------------
@@ -135,10 +137,13 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& g, f32x4 (&acc)[4]
         if (ep.pre_act_out)
           reinterpret_cast<unsigned short*>(ep.pre_act_out)[static_cast<long>(row) * ep.ld_pre_act + col] = f2bf(z);
         if (ep.act == 1) z = gelu_erf(ep.pre_act_out ? bf2f(f2bf(z)) : z);
+        const float keep = g.drop.on() ? g.drop.scale(static_cast<uint64_t>(row) * g.N + col) : 1.0f;
+        if (!ep.drop_after_residual) z *= keep;
         if (ep.residual) {
           const long rr = ep.res_row_mod > 0 ? (row % ep.res_row_mod) : row;
           z += reinterpret_cast<const float*>(ep.residual)[rr * ep.ld_res + col];
         }
+        if (ep.drop_after_residual) z *= keep;
         if (ep.aux_bf16_out) reinterpret_cast<unsigned short*>(ep.aux_bf16_out)[static_cast<long>(row) * ep.ld_aux + col] = f2bf(z);
         if (ep.out_fp32) reinterpret_cast<float*>(g.C)[static_cast<long>(row) * g.ldc + col] = z;
         else reinterpret_cast<unsigned short*>(g.C)[static_cast<long>(row) * g.ldc + col] = f2bf(z);
@@ -271,11 +276,25 @@ __device__ __forceinline__ void gemm_epilogue_rows(const GemmArgs& g, f32x4 (&ac
 #pragma unroll
       for (int e = 0; e < 8; ++e) z[e] = gelu_erf(z[e]);
     }
+    float keep[8] = {1.f, 1.f, 1.f, 1.f, 1.f, 1.f, 1.f, 1.f};
+    if (g.drop.on()) {
+      const uint64_t base = static_cast<uint64_t>(row) * g.N + col;
+#pragma unroll
+      for (int e = 0; e < 8; ++e) keep[e] = g.drop.scale(base + e);
+    }
+    if (!ep.drop_after_residual) {
+#pragma unroll
+      for (int e = 0; e < 8; ++e) z[e] *= keep[e];
+    }
     if (ep.residual) {
       const long rr = ep.res_row_mod > 0 ? (row % ep.res_row_mod) : row;
       const float* rp = reinterpret_cast<const float*>(ep.residual) + rr * ep.ld_res + col;
       const float4 r0 = *reinterpret_cast<const float4*>(rp), r1 = *reinterpret_cast<const float4*>(rp + 4);
       z[0] += r0.x; z[1] += r0.y; z[2] += r0.z; z[3] += r0.w; z[4] += r1.x; z[5] += r1.y; z[6] += r1.z; z[7] += r1.w;
+    }
+    if (ep.drop_after_residual) {
+#pragma unroll
+      for (int e = 0; e < 8; ++e) z[e] *= keep[e];
     }
     uint4 o16;
     o16.x = f2bf(z[0]) | (static_cast<unsigned>(f2bf(z[1])) << 16); o16.y = f2bf(z[2]) | (static_cast<unsigned>(f2bf(z[3])) << 16);
@@ -480,6 +499,7 @@ __global__ __launch_bounds__(kGemmThreads) void gemm_tn_glds_kernel(GemmArgs g, 
     o.ep = adt_gemm_epilogue{};
     o.ep.alpha = 1.0f;
     o.ep.out_fp32 = 1;
+    o.drop = Drop{0u, 0u, 1.0f};
   }
   gemm_epilogue_rows(o, acc, reinterpret_cast<float*>(smem), m0, n0, wm, wn, tid, lane);
 }
@@ -543,6 +563,7 @@ extern "C" int adt_gemm_bf16(int32_t trans, int64_t M, int64_t N, int64_t K, con
   adt_gemm_epilogue e;
   if (ep) e = *ep; else { e = adt_gemm_epilogue{}; e.alpha = 1.0f; }
   g.ep = e;
+  g.drop = make_drop(e.drop.p, e.drop.key);
   const int k_tiles = static_cast<int>((K + kBK - 1) / kBK);
   int splits = 1;
   if (trans) {
@@ -550,7 +571,7 @@ extern "C" int adt_gemm_bf16(int32_t trans, int64_t M, int64_t N, int64_t K, con
     if (int rc = device_cu_count(&n_cu)) return rc;
     splits = pick_splits(g.M, g.N, g.K, n_cu);
     if (splits > 1) {
-      if (!e.out_fp32 || e.bias || e.residual || e.act || e.pre_act_out || e.gelu_grad_of || e.aux_bf16_out || (N & 3))
+      if (!e.out_fp32 || e.bias || e.residual || e.act || e.pre_act_out || e.gelu_grad_of || e.aux_bf16_out || e.drop.p > 0.f || (N & 3))
         splits = 1;                                  // split-K only for the plain fp32 weight-gradient form
       else if (!ws || ws_bytes < static_cast<size_t>(splits) * M * N * 4)
         return set_error(ADT_EINVAL, "adt_gemm_bf16: workspace too small (see adt_gemm_workspace_bytes)");

@@ -15,6 +15,7 @@
 #include <hip/hip_runtime.h>
 
 #include "adt_common.h"
+#include "dropout.h"
 
 namespace adt {
 
@@ -37,7 +38,7 @@ constexpr int kMaxD = 1024;                 // row width limit of the one-wave-p
 // ------------------------------------------------------------------------------------ LayerNorm
 // y = (x - mean) * rstd * gamma + beta ; stats in fp32, biased variance (torch semantics).
 struct LnFwdArgs { const float* x; long ldx; const float* gamma; const float* beta; float eps;
-                   float* y32; unsigned short* y16; long ldy; float* mean; float* rstd; int M; int D; };
+                   float* y32; unsigned short* y16; long ldy; float* mean; float* rstd; int M; int D; Drop drop; };
 
 __global__ __launch_bounds__(kRowThreads) void layernorm_fwd_kernel(LnFwdArgs a) {
   const int lane = threadIdx.x & 63;
@@ -72,6 +73,10 @@ __global__ __launch_bounds__(kRowThreads) void layernorm_fwd_kernel(LnFwdArgs a)
     float4 y;
     y.x = (v[i].x - mean) * rstd * g.x + b.x; y.y = (v[i].y - mean) * rstd * g.y + b.y;
     y.z = (v[i].z - mean) * rstd * g.z + b.z; y.w = (v[i].w - mean) * rstd * g.w + b.w;
+    if (a.drop.on()) {
+      const uint64_t e0 = static_cast<uint64_t>(row) * a.D + 4 * q;
+      y.x *= a.drop.scale(e0); y.y *= a.drop.scale(e0 + 1); y.z *= a.drop.scale(e0 + 2); y.w *= a.drop.scale(e0 + 3);
+    }
     if (a.y32) reinterpret_cast<float4*>(a.y32 + static_cast<long>(row) * a.ldy)[q] = y;
     if (a.y16) {
       ushort4 h = make_ushort4(f2bf_(y.x), f2bf_(y.y), f2bf_(y.z), f2bf_(y.w));
@@ -85,7 +90,8 @@ __global__ __launch_bounds__(kRowThreads) void layernorm_fwd_kernel(LnFwdArgs a)
 // (dxsum = bias gradient of the linear layer that feeds this norm's input).
 constexpr int kLnBwdRows = 64;              // rows per block (16 per wave)
 struct LnBwdArgs { const float* dy; long lddy; const float* x; long ldx; const float* gamma; const float* mean;
-                   const float* rstd; float* dx32; unsigned short* dx16; long lddx; float* partial; int M; int D; };
+                   const float* rstd; float* dx32; unsigned short* dx16; long lddx; float* partial; int M; int D;
+                   Drop dy_drop, dx_drop; };
 
 __global__ __launch_bounds__(kRowThreads) void layernorm_bwd_kernel(LnBwdArgs a) {
   __shared__ float red[3][4][kMaxD];        // [dgamma|dbeta|dxsum][wave][col]  = 48 KiB
@@ -107,7 +113,12 @@ __global__ __launch_bounds__(kRowThreads) void layernorm_bwd_kernel(LnBwdArgs a)
       const int q = lane + 64 * i;
       xh[i] = g[i] = make_float4(0, 0, 0, 0);
       if (q >= nq) continue;
-      const float4 xv = xr[q], dv = dyr[q], gm = reinterpret_cast<const float4*>(a.gamma)[q];
+      const float4 xv = xr[q], gm = reinterpret_cast<const float4*>(a.gamma)[q];
+      float4 dv = dyr[q];
+      if (a.dy_drop.on()) {
+        const uint64_t e0 = static_cast<uint64_t>(row) * a.D + 4 * q;
+        dv.x *= a.dy_drop.scale(e0); dv.y *= a.dy_drop.scale(e0 + 1); dv.z *= a.dy_drop.scale(e0 + 2); dv.w *= a.dy_drop.scale(e0 + 3);
+      }
       xh[i] = make_float4((xv.x - mean) * rstd, (xv.y - mean) * rstd, (xv.z - mean) * rstd, (xv.w - mean) * rstd);
       g[i] = make_float4(dv.x * gm.x, dv.y * gm.y, dv.z * gm.z, dv.w * gm.w);
       s1 += (g[i].x + g[i].y) + (g[i].z + g[i].w);
@@ -123,8 +134,12 @@ __global__ __launch_bounds__(kRowThreads) void layernorm_bwd_kernel(LnBwdArgs a)
       float4 d;
       d.x = rstd * (g[i].x - m1 - xh[i].x * m2); d.y = rstd * (g[i].y - m1 - xh[i].y * m2);
       d.z = rstd * (g[i].z - m1 - xh[i].z * m2); d.w = rstd * (g[i].w - m1 - xh[i].w * m2);
-      px[i].x += d.x; px[i].y += d.y; px[i].z += d.z; px[i].w += d.w;
       if (a.dx32) reinterpret_cast<float4*>(a.dx32 + static_cast<long>(row) * a.lddx)[q] = d;
+      if (a.dx_drop.on()) {           // gradient of the dropped branch: bf16 dx and the bias gradient see the mask
+        const uint64_t e0 = static_cast<uint64_t>(row) * a.D + 4 * q;
+        d.x *= a.dx_drop.scale(e0); d.y *= a.dx_drop.scale(e0 + 1); d.z *= a.dx_drop.scale(e0 + 2); d.w *= a.dx_drop.scale(e0 + 3);
+      }
+      px[i].x += d.x; px[i].y += d.y; px[i].z += d.z; px[i].w += d.w;
       if (a.dx16) reinterpret_cast<ushort4*>(a.dx16 + static_cast<long>(row) * a.lddx)[q] =
           make_ushort4(f2bf_(d.x), f2bf_(d.y), f2bf_(d.z), f2bf_(d.w));
     }
@@ -200,7 +215,7 @@ __global__ __launch_bounds__(256) void colsum_partial_kernel(const unsigned shor
 
 // ------------------------------------------------------------------------------------ embedding + positional encoding
 struct EmbedArgs { const long* tokens; const float* table; const float* pe; float scale; float* y32; unsigned short* y16;
-                   int n_rows; int T; int D; int vocab; };
+                   int n_rows; int T; int D; int vocab; Drop drop; };
 __global__ __launch_bounds__(kRowThreads) void embed_pe_fwd_kernel(EmbedArgs a) {
   const int lane = threadIdx.x & 63;
   const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
@@ -211,7 +226,11 @@ __global__ __launch_bounds__(kRowThreads) void embed_pe_fwd_kernel(EmbedArgs a) 
   const float4* p = reinterpret_cast<const float4*>(a.pe + static_cast<long>(row % a.T) * a.D);
   for (int q = lane; q < (a.D >> 2); q += 64) {
     const float4 ev = e[q], pv = p[q];
-    const float4 y = make_float4(ev.x * a.scale + pv.x, ev.y * a.scale + pv.y, ev.z * a.scale + pv.z, ev.w * a.scale + pv.w);
+    float4 y = make_float4(ev.x * a.scale + pv.x, ev.y * a.scale + pv.y, ev.z * a.scale + pv.z, ev.w * a.scale + pv.w);
+    if (a.drop.on()) {
+      const uint64_t e0 = static_cast<uint64_t>(row) * a.D + 4 * q;
+      y.x *= a.drop.scale(e0); y.y *= a.drop.scale(e0 + 1); y.z *= a.drop.scale(e0 + 2); y.w *= a.drop.scale(e0 + 3);
+    }
     if (a.y32) reinterpret_cast<float4*>(a.y32 + static_cast<long>(row) * a.D)[q] = y;
     if (a.y16) reinterpret_cast<ushort4*>(a.y16 + static_cast<long>(row) * a.D)[q] =
         make_ushort4(f2bf_(y.x), f2bf_(y.y), f2bf_(y.z), f2bf_(y.w));
@@ -219,13 +238,16 @@ __global__ __launch_bounds__(kRowThreads) void embed_pe_fwd_kernel(EmbedArgs a) 
 }
 // dtable[token] += scale * dy[row]   (float atomics: tokens repeat inside a batch)
 __global__ __launch_bounds__(kRowThreads) void embed_bwd_kernel(const long* __restrict__ tokens, const float* __restrict__ dy,
-                                                                float scale, float* __restrict__ dtable, int n_rows, int D, int vocab) {
+                                                                float scale, float* __restrict__ dtable, int n_rows, int D, int vocab, Drop drop) {
   const int lane = threadIdx.x & 63;
   const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
   if (row >= n_rows) return;
   long tok = tokens[row];
   tok = tok < 0 ? 0 : (tok >= vocab ? vocab - 1 : tok);
-  for (int c = lane; c < D; c += 64) atomicAdd(dtable + tok * D + c, scale * dy[static_cast<long>(row) * D + c]);
+  for (int c = lane; c < D; c += 64) {
+    const float keep = drop.on() ? drop.scale(static_cast<uint64_t>(row) * D + c) : 1.0f;
+    atomicAdd(dtable + tok * D + c, scale * keep * dy[static_cast<long>(row) * D + c]);
+  }
 }
 
 // ------------------------------------------------------------------------------------ cross-entropy (fwd + bwd in one pass)
@@ -390,12 +412,13 @@ using namespace adt;
 
 extern "C" int adt_layernorm_fwd(const float* x, int64_t ldx, const float* gamma, const float* beta, float eps,
                                  float* y32, void* y16, int64_t ldy, float* mean, float* rstd, int64_t M, int64_t D,
-                                 void* stream) {
+                                 const adt_dropout* out_drop, void* stream) {
   if (!x || !gamma || !beta || (!y32 && !y16)) return set_error(ADT_EINVAL, "adt_layernorm_fwd: null pointer");
   if (D <= 0 || D > kMaxD || (D & 3) || (ldx & 3) || (ldy & 3)) return set_error(ADT_ESHAPE, "adt_layernorm_fwd: D must be a multiple of 4, <= 1024");
   if (M < 0) return set_error(ADT_EINVAL, "adt_layernorm_fwd: negative M");
   if (M == 0) return ADT_OK;
-  LnFwdArgs a{x, ldx, gamma, beta, eps, y32, static_cast<unsigned short*>(y16), ldy, mean, rstd, static_cast<int>(M), static_cast<int>(D)};
+  LnFwdArgs a{x, ldx, gamma, beta, eps, y32, static_cast<unsigned short*>(y16), ldy, mean, rstd, static_cast<int>(M), static_cast<int>(D),
+              out_drop ? make_drop(out_drop->p, out_drop->key) : Drop{0u, 0u, 1.0f}};
   hipLaunchKernelGGL(layernorm_fwd_kernel, dim3(static_cast<unsigned>((M + 3) / 4)), dim3(kRowThreads), 0, ST(stream), a);
   ADT_HIP_TRY(hipGetLastError());
   return ADT_OK;
@@ -408,7 +431,8 @@ extern "C" size_t adt_layernorm_bwd_workspace_bytes(int64_t M, int64_t D) {
 
 extern "C" int adt_layernorm_bwd(const float* dy, int64_t lddy, const float* x, int64_t ldx, const float* gamma,
                                  const float* mean, const float* rstd, float* dx32, void* dx16, int64_t lddx,
-                                 float* dgamma, float* dbeta, float* dxsum, int64_t M, int64_t D, void* ws,
+                                 float* dgamma, float* dbeta, float* dxsum, int64_t M, int64_t D,
+                                 const adt_dropout* dy_drop, const adt_dropout* dx16_drop, void* ws,
                                  size_t ws_bytes, void* stream) {
   if (!dy || !x || !gamma || !mean || !rstd || (!dx32 && !dx16)) return set_error(ADT_EINVAL, "adt_layernorm_bwd: null pointer");
   if (D <= 0 || D > kMaxD || (D & 3) || (ldx & 3) || (lddy & 3) || (lddx & 3)) return set_error(ADT_ESHAPE, "adt_layernorm_bwd: D must be a multiple of 4, <= 1024");
@@ -417,7 +441,8 @@ extern "C" int adt_layernorm_bwd(const float* dy, int64_t lddy, const float* x, 
   if (!ws || ws_bytes < adt_layernorm_bwd_workspace_bytes(M, D)) return set_error(ADT_EINVAL, "adt_layernorm_bwd: workspace too small");
   const int nb = static_cast<int>((M + kLnBwdRows - 1) / kLnBwdRows);
   LnBwdArgs a{dy, lddy, x, ldx, gamma, mean, rstd, dx32, static_cast<unsigned short*>(dx16), lddx, static_cast<float*>(ws),
-              static_cast<int>(M), static_cast<int>(D)};
+              static_cast<int>(M), static_cast<int>(D), dy_drop ? make_drop(dy_drop->p, dy_drop->key) : Drop{0u, 0u, 1.0f},
+              dx16_drop ? make_drop(dx16_drop->p, dx16_drop->key) : Drop{0u, 0u, 1.0f}};
   hipLaunchKernelGGL(layernorm_bwd_kernel, dim3(nb), dim3(kRowThreads), 0, ST(stream), a);
   const int width = 3 * static_cast<int>(D);
   hipLaunchKernelGGL(reduce_partials_kernel, dim3((width + 31) / 32), dim3(256), 0, ST(stream), static_cast<const float*>(ws), nb,
@@ -447,24 +472,25 @@ extern "C" int adt_colsum_bf16(const void* x, int64_t ld, int64_t M, int64_t N, 
 }
 
 extern "C" int adt_embed_pe_fwd(const int64_t* tokens, const float* table, const float* pe, float scale, float* y32, void* y16,
-                                int64_t n_rows, int64_t T, int64_t D, int64_t vocab, void* stream) {
+                                int64_t n_rows, int64_t T, int64_t D, int64_t vocab, const adt_dropout* drop, void* stream) {
   if (!tokens || !table || !pe || (!y32 && !y16)) return set_error(ADT_EINVAL, "adt_embed_pe_fwd: null pointer");
   if (D <= 0 || (D & 3) || T <= 0 || vocab <= 0 || n_rows < 0) return set_error(ADT_ESHAPE, "adt_embed_pe_fwd: D must be a multiple of 4; T, vocab > 0");
   if (n_rows == 0) return ADT_OK;
   EmbedArgs a{reinterpret_cast<const long*>(tokens), table, pe, scale, y32, static_cast<unsigned short*>(y16), static_cast<int>(n_rows),
-              static_cast<int>(T), static_cast<int>(D), static_cast<int>(vocab)};
+              static_cast<int>(T), static_cast<int>(D), static_cast<int>(vocab), drop ? make_drop(drop->p, drop->key) : Drop{0u, 0u, 1.0f}};
   hipLaunchKernelGGL(embed_pe_fwd_kernel, dim3(static_cast<unsigned>((n_rows + 3) / 4)), dim3(kRowThreads), 0, ST(stream), a);
   ADT_HIP_TRY(hipGetLastError());
   return ADT_OK;
 }
 
 extern "C" int adt_embed_bwd(const int64_t* tokens, const float* dy, float scale, float* dtable, int64_t n_rows, int64_t D,
-                             int64_t vocab, void* stream) {
+                             int64_t vocab, const adt_dropout* drop, void* stream) {
   if (!tokens || !dy || !dtable) return set_error(ADT_EINVAL, "adt_embed_bwd: null pointer");
   if (D <= 0 || vocab <= 0 || n_rows < 0) return set_error(ADT_ESHAPE, "adt_embed_bwd: bad shape");
   if (n_rows == 0) return ADT_OK;
   hipLaunchKernelGGL(embed_bwd_kernel, dim3(static_cast<unsigned>((n_rows + 3) / 4)), dim3(kRowThreads), 0, ST(stream),
-                     reinterpret_cast<const long*>(tokens), dy, scale, dtable, static_cast<int>(n_rows), static_cast<int>(D), static_cast<int>(vocab));
+                     reinterpret_cast<const long*>(tokens), dy, scale, dtable, static_cast<int>(n_rows), static_cast<int>(D), static_cast<int>(vocab),
+                     drop ? make_drop(drop->p, drop->key) : Drop{0u, 0u, 1.0f});
   ADT_HIP_TRY(hipGetLastError());
   return ADT_OK;
 }

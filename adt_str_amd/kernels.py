@@ -15,6 +15,25 @@ from . import _ffi
 _ws_cache: dict = {}
 
 
+def mix32(x):
+    """The integer hash of adt_str_amd/csrc/dropout.h, on Python ints (host-side key derivation)."""
+    x &= 0xFFFFFFFF
+    x ^= x >> 16; x = (x * 0x7FEB352D) & 0xFFFFFFFF; x ^= x >> 15; x = (x * 0x846CA68B) & 0xFFFFFFFF; x ^= x >> 16
+    return x
+
+
+def drop_site(p: float, seed: int, site: int):
+    """(p, key) of one dropout site for one training step; None when dropout is off."""
+    return (float(p), mix32(mix32(seed) ^ (site * 0x9E3779B9 & 0xFFFFFFFF))) if p and p > 0 else None
+
+
+def _drop_ptr(d):
+    if d is None:
+        return None, None
+    obj = _ffi.Dropout(d[0], d[1])
+    return obj, C.byref(obj)
+
+
 def _workspace(nbytes: int, device) -> torch.Tensor:
     """Grow-only scratch buffer per device (never freed: stream-ordered reuse)."""
     key = str(device)
@@ -29,7 +48,7 @@ def gemm(a: torch.Tensor, b: torch.Tensor, *, trans: bool = False, out: Optional
          out_dtype=torch.bfloat16, bias: Optional[torch.Tensor] = None, residual: Optional[torch.Tensor] = None,
          res_row_mod: int = 0, act: int = 0, pre_act_out: Optional[torch.Tensor] = None,
          gelu_grad_of: Optional[torch.Tensor] = None, alpha: float = 1.0,
-         aux_bf16_out: Optional[torch.Tensor] = None) -> torch.Tensor:
+         aux_bf16_out: Optional[torch.Tensor] = None, drop=None, drop_after_residual: bool = False) -> torch.Tensor:
     """``trans=False``: ``a[M,K] @ b[N,K].T``; ``trans=True``: ``a[K,M].T @ b[K,N]`` (bf16 in, fp32 accumulate)."""
     assert a.dtype == torch.bfloat16 and b.dtype == torch.bfloat16 and a.dim() == 2 and b.dim() == 2
     assert a.stride(1) == 1 and b.stride(1) == 1
@@ -47,6 +66,9 @@ def gemm(a: torch.Tensor, b: torch.Tensor, *, trans: bool = False, out: Optional
     ep.alpha = alpha
     ep.act = act
     ep.out_fp32 = 1 if out.dtype == torch.float32 else 0
+    if drop is not None:
+        ep.drop.p, ep.drop.key = drop
+        ep.drop_after_residual = 1 if drop_after_residual else 0
     if bias is not None:
         assert bias.dtype == torch.float32 and bias.numel() == N
         ep.bias = _ffi.dptr(bias)
@@ -74,7 +96,7 @@ def _p(t: Optional[torch.Tensor]):
     return _ffi.dptr(t) if t is not None else None
 
 
-def layernorm_fwd(x, gamma, beta, eps=1e-5, want32=True, want16=True):
+def layernorm_fwd(x, gamma, beta, eps=1e-5, want32=True, want16=True, drop=None):
     """x fp32 [M, D] -> (y32 | None, y16 | None, mean[M], rstd[M])."""
     assert x.dtype == torch.float32 and x.dim() == 2 and x.stride(1) == 1
     M, D = x.shape
@@ -82,12 +104,14 @@ def layernorm_fwd(x, gamma, beta, eps=1e-5, want32=True, want16=True):
     y16 = torch.empty((M, D), dtype=torch.bfloat16, device=x.device) if want16 else None
     mean = torch.empty(M, dtype=torch.float32, device=x.device)
     rstd = torch.empty(M, dtype=torch.float32, device=x.device)
+    _keep, dp = _drop_ptr(drop)
     _ffi.call("adt_layernorm_fwd", _ffi.dptr(x), x.stride(0), _ffi.dptr(gamma), _ffi.dptr(beta), eps, _p(y32), _p(y16), D,
-              _ffi.dptr(mean), _ffi.dptr(rstd), M, D, _ffi.current_stream())
+              _ffi.dptr(mean), _ffi.dptr(rstd), M, D, dp, _ffi.current_stream())
     return y32, y16, mean, rstd
 
 
-def layernorm_bwd(dy, x, gamma, mean, rstd, dgamma=None, dbeta=None, dxsum=None, want32=True, want16=True):
+def layernorm_bwd(dy, x, gamma, mean, rstd, dgamma=None, dbeta=None, dxsum=None, want32=True, want16=True, dy_drop=None,
+                  dx16_drop=None):
     """-> (dx32 | None, dx16 | None); dgamma/dbeta/dxsum [D] fp32 are overwritten when given."""
     assert dy.dtype == torch.float32 and x.dtype == torch.float32 and dy.shape == x.shape
     M, D = x.shape
@@ -95,8 +119,10 @@ def layernorm_bwd(dy, x, gamma, mean, rstd, dgamma=None, dbeta=None, dxsum=None,
     dx16 = torch.empty((M, D), dtype=torch.bfloat16, device=x.device) if want16 else None
     nb = _ffi.load().adt_layernorm_bwd_workspace_bytes(M, D)
     ws = _workspace(nb, x.device)
+    _k1, p1 = _drop_ptr(dy_drop)
+    _k2, p2 = _drop_ptr(dx16_drop)
     _ffi.call("adt_layernorm_bwd", _ffi.dptr(dy), dy.stride(0), _ffi.dptr(x), x.stride(0), _ffi.dptr(gamma), _ffi.dptr(mean),
-              _ffi.dptr(rstd), _p(dx32), _p(dx16), D, _p(dgamma), _p(dbeta), _p(dxsum), M, D, _ffi.dptr(ws), nb,
+              _ffi.dptr(rstd), _p(dx32), _p(dx16), D, _p(dgamma), _p(dbeta), _p(dxsum), M, D, p1, p2, _ffi.dptr(ws), nb,
               _ffi.current_stream())
     return dx32, dx16
 
@@ -112,22 +138,24 @@ def colsum(x, out=None):
     return out
 
 
-def embed_pe_fwd(tokens, table, pe, scale, want32=True, want16=True):
+def embed_pe_fwd(tokens, table, pe, scale, want32=True, want16=True, drop=None):
     """tokens int64 [B, T] -> (y32, y16) [B*T, D]."""
     assert tokens.dtype == torch.int64 and tokens.is_contiguous()
     B, T = tokens.shape
     V, D = table.shape
     y32 = torch.empty((B * T, D), dtype=torch.float32, device=table.device) if want32 else None
     y16 = torch.empty((B * T, D), dtype=torch.bfloat16, device=table.device) if want16 else None
-    _ffi.call("adt_embed_pe_fwd", _ffi.dptr(tokens), _ffi.dptr(table), _ffi.dptr(pe), scale, _p(y32), _p(y16), B * T, T, D, V,
+    _keep, dp = _drop_ptr(drop)
+    _ffi.call("adt_embed_pe_fwd", _ffi.dptr(tokens), _ffi.dptr(table), _ffi.dptr(pe), scale, _p(y32), _p(y16), B * T, T, D, V, dp,
               _ffi.current_stream())
     return y32, y16
 
 
-def embed_bwd(tokens, dy, scale, dtable):
+def embed_bwd(tokens, dy, scale, dtable, drop=None):
     n, D = dy.shape
     assert dy.dtype == torch.float32 and dy.is_contiguous() and dtable.dtype == torch.float32
-    _ffi.call("adt_embed_bwd", _ffi.dptr(tokens), _ffi.dptr(dy), scale, _ffi.dptr(dtable), n, D, dtable.shape[0],
+    _keep, dp = _drop_ptr(drop)
+    _ffi.call("adt_embed_bwd", _ffi.dptr(tokens), _ffi.dptr(dy), scale, _ffi.dptr(dtable), n, D, dtable.shape[0], dp,
               _ffi.current_stream())
 
 
@@ -173,36 +201,38 @@ def adamw_step(p, g, m, v, step, lr, beta1=0.9, beta2=0.999, eps=1e-8, weight_de
               eps, weight_decay, step, _p(norm_and_clip), _ffi.current_stream())
 
 
-def _attn_desc(B, H, Sq, Sk, q, k, v, o, scale, causal, key_len, mask_value):
+def _attn_desc(B, H, Sq, Sk, q, k, v, o, scale, causal, key_len, mask_value, drop=None):
     d = _ffi.AttnDesc()
     d.batch, d.heads, d.q_len, d.k_len, d.head_dim = B, H, Sq, Sk, 128
     d.causal = 1 if causal else 0
     d.ldq, d.ldk, d.ldv, d.ldo = q.stride(0), k.stride(0), v.stride(0), o.stride(0)
     d.scale, d.mask_value = scale, mask_value
+    if drop is not None:
+        d.drop.p, d.drop.key = drop
     if key_len is not None:
         assert key_len.dtype == torch.int32 and key_len.numel() == B
         d.key_len = _ffi.dptr(key_len)
     return d
 
 
-def attn_fwd(q, k, v, B, H, Sq, Sk, scale, causal=False, key_len=None, mask_value=-1e4, out=None):
+def attn_fwd(q, k, v, B, H, Sq, Sk, scale, causal=False, key_len=None, mask_value=-1e4, out=None, drop=None):
     """q [B*Sq, >=H*128], k/v [B*Sk, >=H*128] bf16 (row-strided views allowed) -> (o [B*Sq, H*128] bf16, lse [B,H,Sq] fp32)."""
     for t in (q, k, v):
         assert t.dtype == torch.bfloat16 and t.dim() == 2 and t.stride(1) == 1
     if out is None:
         out = torch.empty((B * Sq, H * 128), dtype=torch.bfloat16, device=q.device)
     lse = torch.empty((B, H, Sq), dtype=torch.float32, device=q.device)
-    d = _attn_desc(B, H, Sq, Sk, q, k, v, out, scale, causal, key_len, mask_value)
+    d = _attn_desc(B, H, Sq, Sk, q, k, v, out, scale, causal, key_len, mask_value, drop)
     _ffi.call("adt_attn_fwd", C.byref(d), _ffi.dptr(q), _ffi.dptr(k), _ffi.dptr(v), _ffi.dptr(out), _ffi.dptr(lse),
               _ffi.current_stream())
     return out, lse
 
 
-def attn_bwd(q, k, v, o, dout, lse, dq, dk, dv, B, H, Sq, Sk, scale, causal=False, key_len=None, mask_value=-1e4):
+def attn_bwd(q, k, v, o, dout, lse, dq, dk, dv, B, H, Sq, Sk, scale, causal=False, key_len=None, mask_value=-1e4, drop=None):
     """Writes dq/dk/dv (bf16 views with the strides of q/k/v)."""
     assert dq.stride(0) == q.stride(0) and dk.stride(0) == k.stride(0) and dv.stride(0) == v.stride(0)
     assert dout.stride(0) == o.stride(0)
-    d = _attn_desc(B, H, Sq, Sk, q, k, v, o, scale, causal, key_len, mask_value)
+    d = _attn_desc(B, H, Sq, Sk, q, k, v, o, scale, causal, key_len, mask_value, drop)
     nb = _ffi.load().adt_attn_bwd_workspace_bytes(C.byref(d))
     ws = _workspace(nb, q.device)
     _ffi.call("adt_attn_bwd", C.byref(d), _ffi.dptr(q), _ffi.dptr(k), _ffi.dptr(v), _ffi.dptr(o), _ffi.dptr(dout),

@@ -159,6 +159,16 @@ class _Engine:
         self.gflat: Optional[torch.Tensor] = None
         self.G: Dict[str, torch.Tensor] = {}
         self.grad_ready_hook = None      # callable(lo, hi): flat gradient range [lo, hi) is final (used to overlap all-reduce)
+        self.drop_p = 0.0                # active dropout probability of the current pass (0 in eval)
+        self.drop_seed = 0               # changes every training step; masks are regenerated from it in the backward
+        self._sites: Dict[str, int] = {}
+
+    def D(self, site: str):
+        """(p, key) of a named dropout site for the current step, or None when dropout is off."""
+        if self.drop_p <= 0.0:
+            return None
+        idx = self._sites.setdefault(site, len(self._sites) + 1)
+        return K.drop_site(self.drop_p, self.drop_seed, idx)
 
     # ---- parameter plumbing -------------------------------------------------------
     def P(self, name):
@@ -195,25 +205,26 @@ class _Engine:
         x0 = K.gemm(mel16, self.proj.w16, bias=self.proj.b)                # project_to_mel (model.py:249)
         pe = self.m.encoder.positional_encoding.pos_embedding[0]
         x16 = torch.empty((M, d), dtype=BF16, device=src.device)
-        x32 = K.gemm(x0, self.dense.w16, residual=pe, res_row_mod=S, out_dtype=F32, aux_bf16_out=x16)   # dense + PE (:130-131)
+        x32 = K.gemm(x0, self.dense.w16, residual=pe, res_row_mod=S, out_dtype=F32, aux_bf16_out=x16,
+                     drop=self.D("enc.pe"), drop_after_residual=True)          # dense + PE + dropout (model.py:130-132)
         if save is not None:
             save.append(dict(mel16=mel16, x0=x0, B=B, S=S))
         for L in self.enc:
             p = L["p"]
             qkv = K.gemm(x16, L["sa"].w16, bias=L["sa"].b)
-            attn, lse = K.attn_fwd(qkv[:, :d], qkv[:, d:2 * d], qkv[:, 2 * d:], B, H, S, S, self.scale)
-            y1 = K.gemm(attn, L["sa_o"].w16, bias=L["sa_o"].b, residual=x32, out_dtype=F32)
+            attn, lse = K.attn_fwd(qkv[:, :d], qkv[:, d:2 * d], qkv[:, 2 * d:], B, H, S, S, self.scale, drop=self.D(p + ".attn"))
+            y1 = K.gemm(attn, L["sa_o"].w16, bias=L["sa_o"].b, residual=x32, out_dtype=F32, drop=self.D(p + ".drop1"))
             x1_32, x1_16, mean1, rstd1 = K.layernorm_fwd(y1, self.P(p + ".norm1.weight"), self.P(p + ".norm1.bias"))
             u = torch.empty((M, L["l1"].w16.shape[0]), dtype=BF16, device=src.device)
-            h = K.gemm(x1_16, L["l1"].w16, bias=L["l1"].b, act=1, pre_act_out=u)
-            y2 = K.gemm(h, L["l2"].w16, bias=L["l2"].b, residual=x1_32, out_dtype=F32)
+            h = K.gemm(x1_16, L["l1"].w16, bias=L["l1"].b, act=1, pre_act_out=u, drop=self.D(p + ".ffn"))
+            y2 = K.gemm(h, L["l2"].w16, bias=L["l2"].b, residual=x1_32, out_dtype=F32, drop=self.D(p + ".drop2"))
             x2_32, x2_16, mean2, rstd2 = K.layernorm_fwd(y2, self.P(p + ".norm2.weight"), self.P(p + ".norm2.bias"))
             if save is not None:
                 save.append(dict(x16=x16, qkv=qkv, attn=attn, lse=lse, y1=y1, mean1=mean1, rstd1=rstd1, x1_16=x1_16, u=u, h=h,
                                  y2=y2, mean2=mean2, rstd2=rstd2))
             x32, x16 = x2_32, x2_16
         _, mem16, meanf, rstdf = K.layernorm_fwd(x32, self.P("encoder.layer_norm.weight"), self.P("encoder.layer_norm.bias"),
-                                                 want32=False)
+                                                 want32=False, drop=self.D("enc.final"))      # LN + dropout (model.py:134)
         if save is not None:
             save.append(dict(x32=x32, mean=meanf, rstd=rstdf))
         return mem16, B, S
@@ -225,23 +236,24 @@ class _Engine:
         Md = B * T
         emb = self.P("decoder.tgt_tok_emb.embedding.weight")
         pe = self.m.decoder.positional_encoding.pos_embedding[0]
-        x32, x16 = K.embed_pe_fwd(tgt, emb, pe, math.sqrt(d))             # model.py:171
+        x32, x16 = K.embed_pe_fwd(tgt, emb, pe, math.sqrt(d), drop=self.D("dec.emb"))   # model.py:171-172
         dev = tgt.device
         for L in self.dec:
             p = L["p"]
             qkv = K.gemm(x16, L["sa"].w16, bias=L["sa"].b)
-            sa, lse_s = K.attn_fwd(qkv[:, :d], qkv[:, d:2 * d], qkv[:, 2 * d:], B, H, T, T, self.scale, causal=True, key_len=key_len)
-            y1 = K.gemm(sa, L["sa_o"].w16, bias=L["sa_o"].b, residual=x32, out_dtype=F32)
+            sa, lse_s = K.attn_fwd(qkv[:, :d], qkv[:, d:2 * d], qkv[:, 2 * d:], B, H, T, T, self.scale, causal=True, key_len=key_len,
+                                   drop=self.D(p + ".sattn"))
+            y1 = K.gemm(sa, L["sa_o"].w16, bias=L["sa_o"].b, residual=x32, out_dtype=F32, drop=self.D(p + ".drop1"))
             x1_32, x1_16, mean1, rstd1 = K.layernorm_fwd(y1, self.P(p + ".norm1.weight"), self.P(p + ".norm1.bias"))
             ca_w, ca_b = L["ca"].w16, L["ca"].b
             qc = K.gemm(x1_16, ca_w[:d], bias=ca_b[:d])
             kvc = K.gemm(mem16, ca_w[d:], bias=ca_b[d:])
-            ca, lse_c = K.attn_fwd(qc, kvc[:, :d], kvc[:, d:], B, H, T, S, self.scale)
-            y2 = K.gemm(ca, L["ca_o"].w16, bias=L["ca_o"].b, residual=x1_32, out_dtype=F32)
+            ca, lse_c = K.attn_fwd(qc, kvc[:, :d], kvc[:, d:], B, H, T, S, self.scale, drop=self.D(p + ".cattn"))
+            y2 = K.gemm(ca, L["ca_o"].w16, bias=L["ca_o"].b, residual=x1_32, out_dtype=F32, drop=self.D(p + ".drop2"))
             x2_32, x2_16, mean2, rstd2 = K.layernorm_fwd(y2, self.P(p + ".norm2.weight"), self.P(p + ".norm2.bias"))
             u = torch.empty((Md, L["l1"].w16.shape[0]), dtype=BF16, device=dev)
-            h = K.gemm(x2_16, L["l1"].w16, bias=L["l1"].b, act=1, pre_act_out=u)
-            y3 = K.gemm(h, L["l2"].w16, bias=L["l2"].b, residual=x2_32, out_dtype=F32)
+            h = K.gemm(x2_16, L["l1"].w16, bias=L["l1"].b, act=1, pre_act_out=u, drop=self.D(p + ".ffn"))
+            y3 = K.gemm(h, L["l2"].w16, bias=L["l2"].b, residual=x2_32, out_dtype=F32, drop=self.D(p + ".drop3"))
             x3_32, x3_16, mean3, rstd3 = K.layernorm_fwd(y3, self.P(p + ".norm3.weight"), self.P(p + ".norm3.bias"))
             if save is not None:
                 save.append(dict(x16=x16, qkv=qkv, sa=sa, lse_s=lse_s, y1=y1, mean1=mean1, rstd1=rstd1, x1_16=x1_16, qc=qc, kvc=kvc,
@@ -267,8 +279,9 @@ class _Engine:
     def loss_and_grads(self, src, tgt, tgt_padding_mask, labels, want_grads=True, return_logits=False):
         """Full training step arithmetic.  Gradients land in ``self.G`` (views of ``self.gflat``)."""
         self.refresh_weights()
-        if self.m.training and self.m.config.dropout > 0:
-            raise NotImplementedError("dropout > 0 is not implemented in the HIP engine yet; set model.dropout: 0.0")
+        self.drop_p = float(self.m.config.dropout) if self.m.training else 0.0
+        if self.drop_p > 0.0:
+            self.drop_seed += 1
         dev = src.device
         B, T = tgt.shape
         key_len = self.key_len_from_mask(tgt_padding_mask, B, T, dev)
@@ -300,20 +313,20 @@ class _Engine:
             L, s = self.dec[li], dec_save[li]
             p = L["p"]
             dy3_32, dy3_16 = K.layernorm_bwd(dx32, s["y3"], self.P(p + ".norm3.weight"), s["mean3"], s["rstd3"], G[p + ".norm3.weight"],
-                                             G[p + ".norm3.bias"], G[p + ".linear2.bias"])
-            du = K.gemm(dy3_16, L["l2"].wt16, gelu_grad_of=s["u"])
+                                             G[p + ".norm3.bias"], G[p + ".linear2.bias"], dx16_drop=self.D(p + ".drop3"))
+            du = K.gemm(dy3_16, L["l2"].wt16, gelu_grad_of=s["u"], drop=self.D(p + ".ffn"))
             K.gemm(dy3_16, s["h"], trans=True, out=G[p + ".linear2.weight"])
             K.gemm(du, s["x2_16"], trans=True, out=G[p + ".linear1.weight"])
             K.colsum(du, out=G[p + ".linear1.bias"])
             dx2_32 = K.gemm(du, L["l1"].wt16, residual=dy3_32, out_dtype=F32)
             dy2_32, dy2_16 = K.layernorm_bwd(dx2_32, s["y2"], self.P(p + ".norm2.weight"), s["mean2"], s["rstd2"], G[p + ".norm2.weight"],
-                                             G[p + ".norm2.bias"], G[p + ".multihead_attn.out_proj.bias"])
+                                             G[p + ".norm2.bias"], G[p + ".multihead_attn.out_proj.bias"], dx16_drop=self.D(p + ".drop2"))
             dca = K.gemm(dy2_16, L["ca_o"].wt16)
             K.gemm(dy2_16, s["ca"], trans=True, out=G[p + ".multihead_attn.out_proj.weight"])
             dqc = torch.empty_like(s["qc"])
             dkvc = torch.empty_like(s["kvc"])
             K.attn_bwd(s["qc"], s["kvc"][:, :d], s["kvc"][:, d:], s["ca"], dca, s["lse_c"], dqc, dkvc[:, :d], dkvc[:, d:], B, H, T, S,
-                       self.scale)
+                       self.scale, drop=self.D(p + ".cattn"))
             gw, gb = G[p + ".multihead_attn.in_proj_weight"], G[p + ".multihead_attn.in_proj_bias"]
             K.gemm(dqc, s["x1_16"], trans=True, out=gw[:d])
             K.gemm(dkvc, mem16, trans=True, out=gw[d:])
@@ -326,48 +339,50 @@ class _Engine:
                 K.gemm(dkvc, cat[:, d:], residual=dmem32, out=dmem32)
             dx1_32 = K.gemm(dqc, cat[:, :d], residual=dy2_32, out_dtype=F32)
             dy1_32, dy1_16 = K.layernorm_bwd(dx1_32, s["y1"], self.P(p + ".norm1.weight"), s["mean1"], s["rstd1"], G[p + ".norm1.weight"],
-                                             G[p + ".norm1.bias"], G[p + ".self_attn.out_proj.bias"])
+                                             G[p + ".norm1.bias"], G[p + ".self_attn.out_proj.bias"], dx16_drop=self.D(p + ".drop1"))
             dsa = K.gemm(dy1_16, L["sa_o"].wt16)
             K.gemm(dy1_16, s["sa"], trans=True, out=G[p + ".self_attn.out_proj.weight"])
             dqkv = torch.empty_like(s["qkv"])
             q = s["qkv"]
             K.attn_bwd(q[:, :d], q[:, d:2 * d], q[:, 2 * d:], s["sa"], dsa, s["lse_s"], dqkv[:, :d], dqkv[:, d:2 * d], dqkv[:, 2 * d:],
-                       B, H, T, T, self.scale, causal=True, key_len=key_len)
+                       B, H, T, T, self.scale, causal=True, key_len=key_len, drop=self.D(p + ".sattn"))
             K.gemm(dqkv, s["x16"], trans=True, out=G[p + ".self_attn.in_proj_weight"])
             K.colsum(dqkv, out=G[p + ".self_attn.in_proj_bias"])
             dx32 = K.gemm(dqkv, L["sa"].wt16, residual=dy1_32, out_dtype=F32)
         gemb = G["decoder.tgt_tok_emb.embedding.weight"]
         gemb.zero_()
-        K.embed_bwd(tgt, dx32, math.sqrt(d), gemb)
+        K.embed_bwd(tgt, dx32, math.sqrt(d), gemb, drop=self.D("dec.emb"))
         self._ready("decoder.")
         # encoder
         fin = enc_save[-1]
         dx32, _ = K.layernorm_bwd(dmem32, fin["x32"], self.P("encoder.layer_norm.weight"), fin["mean"], fin["rstd"],
-                                  G["encoder.layer_norm.weight"], G["encoder.layer_norm.bias"], None, want16=False)
+                                  G["encoder.layer_norm.weight"], G["encoder.layer_norm.bias"], None, want16=False,
+                                  dy_drop=self.D("enc.final"))
         dx16 = None
         for li in range(len(self.enc) - 1, -1, -1):
             L, s = self.enc[li], enc_save[li + 1]
             p = L["p"]
             dy2_32, dy2_16 = K.layernorm_bwd(dx32, s["y2"], self.P(p + ".norm2.weight"), s["mean2"], s["rstd2"], G[p + ".norm2.weight"],
-                                             G[p + ".norm2.bias"], G[p + ".linear2.bias"])
-            du = K.gemm(dy2_16, L["l2"].wt16, gelu_grad_of=s["u"])
+                                             G[p + ".norm2.bias"], G[p + ".linear2.bias"], dx16_drop=self.D(p + ".drop2"))
+            du = K.gemm(dy2_16, L["l2"].wt16, gelu_grad_of=s["u"], drop=self.D(p + ".ffn"))
             K.gemm(dy2_16, s["h"], trans=True, out=G[p + ".linear2.weight"])
             K.gemm(du, s["x1_16"], trans=True, out=G[p + ".linear1.weight"])
             K.colsum(du, out=G[p + ".linear1.bias"])
             dx1_32 = K.gemm(du, L["l1"].wt16, residual=dy2_32, out_dtype=F32)
             dy1_32, dy1_16 = K.layernorm_bwd(dx1_32, s["y1"], self.P(p + ".norm1.weight"), s["mean1"], s["rstd1"], G[p + ".norm1.weight"],
-                                             G[p + ".norm1.bias"], G[p + ".self_attn.out_proj.bias"])
+                                             G[p + ".norm1.bias"], G[p + ".self_attn.out_proj.bias"], dx16_drop=self.D(p + ".drop1"))
             dattn = K.gemm(dy1_16, L["sa_o"].wt16)
             K.gemm(dy1_16, s["attn"], trans=True, out=G[p + ".self_attn.out_proj.weight"])
             dqkv = torch.empty_like(s["qkv"])
             q = s["qkv"]
             K.attn_bwd(q[:, :d], q[:, d:2 * d], q[:, 2 * d:], s["attn"], dattn, s["lse"], dqkv[:, :d], dqkv[:, d:2 * d], dqkv[:, 2 * d:],
-                       B, H, S, S, self.scale)
+                       B, H, S, S, self.scale, drop=self.D(p + ".attn"))
             K.gemm(dqkv, s["x16"], trans=True, out=G[p + ".self_attn.in_proj_weight"])
             K.colsum(dqkv, out=G[p + ".self_attn.in_proj_bias"])
             if li == 0:
                 dx16 = torch.empty((dqkv.shape[0], d), dtype=BF16, device=dqkv.device)
-            dx32 = K.gemm(dqkv, L["sa"].wt16, residual=dy1_32, out_dtype=F32, aux_bf16_out=dx16 if li == 0 else None)
+            dx32 = K.gemm(dqkv, L["sa"].wt16, residual=dy1_32, out_dtype=F32, aux_bf16_out=dx16 if li == 0 else None,
+                          drop=self.D("enc.pe") if li == 0 else None, drop_after_residual=True)   # layer 0: back through the PE dropout
             self._ready(p + ".")
         head = enc_save[0]
         K.gemm(dx16, head["x0"], trans=True, out=G["encoder.dense_layer.weight"])

@@ -131,7 +131,7 @@ def train_flops_per_clip(F, T, d=768, ffn=3072, V=1400, n_mels=128, enc=4, dec=4
     return 6.0 * macs
 
 
-def train_setup(dev, seed, world):
+def train_setup(dev, seed, world, dropout):
     from adt_str_amd import kernels as K
     from adt_str_amd.bank import OneShotBank, synthetic_tree
     from adt_str_amd.network import ADTModel, ADTModelConfig
@@ -139,7 +139,7 @@ def train_setup(dev, seed, world):
     from adt_str_amd.trainer import FlatTrainer
     B, L, sr, T = 64, 160000, 16000, 128
     torch.manual_seed(0)                                   # same initial weights on every rank (then broadcast anyway)
-    cfg = ADTModelConfig(input_sec=10.0, time_res=0.01, win_length=2048, sample_rate=sr, dropout=0.0, plain=True, **SETTING1)
+    cfg = ADTModelConfig(input_sec=10.0, time_res=0.01, win_length=2048, sample_rate=sr, dropout=dropout, plain=True, **SETTING1)
     model = ADTModel(cfg).to(dev)
     trainer = FlatTrainer(model, lr=1e-4, weight_decay=1e-5, max_grad_norm=1.0, total_steps=10000, warmup_ratio=0.1)
     bank = OneShotBank.from_tree(synthetic_tree(7, sr), sr)
@@ -214,7 +214,7 @@ def train_setup(dev, seed, world):
             "metric": "ADT training clips/sec (10 s @16 kHz)",
             "config": {"workload": "train config[3]: ADT train step, setting-1 network (69.0M params), per-GPU batch 64 x 10 s @ 16 kHz "
                                    "mixer-rendered clips (F=%d frames), T=128 target tokens, bf16 GEMM/attention with fp32 accumulate, "
-                                   "AdamW + clip 1.0, dropout 0.0" % F,
+                                   "AdamW + clip 1.0, dropout %.2f" % (F, dropout),
                        "global_batch": B * world, "clips_per_gpu": B, "samples": L, "sample_rate": sr, "target_len": T}}
 
 
@@ -224,6 +224,7 @@ def main():
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--workload", default="train", choices=["train", "logmel"])
+    ap.add_argument("--dropout", type=float, default=0.1, help="model dropout (0.1 = configs/train/setting-1.yaml of the reference)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
 
@@ -238,7 +239,7 @@ def main():
     if world > 1:
         dist.init_process_group("nccl", device_id=dev)
 
-    wl = train_setup(dev, rank, world) if args.workload == "train" else logmel_setup(dev, rank)
+    wl = train_setup(dev, rank, world, args.dropout) if args.workload == "train" else logmel_setup(dev, rank)
     step = wl["step"]
 
     def fence():

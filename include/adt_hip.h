@@ -33,6 +33,12 @@ extern "C" {
 #define ADT_ESHAPE  -2   /* shape the kernels do not support                  */
 #define ADT_EHIP    -3   /* HIP runtime error (launch failed, no device ...)  */
 
+/* Dropout site: element idx is kept iff hash(idx, key) >= p * 2^32 and then scaled by 1/(1-p)
+ * (adt_str_amd/csrc/dropout.h).  Replaces nn.Dropout / the SDPA dropout of the reference
+ * (model.py:116,132,134,156,172 and inside nn.Transformer*Layer); masks are never stored, the
+ * backward entry points regenerate them from the same (p, key).  p == 0 or a null pointer: off. */
+typedef struct adt_dropout { float p; uint32_t key; } adt_dropout;
+
 /* ABI version: bumped whenever a signature below changes. */
 int adt_version(void);
 
@@ -126,9 +132,11 @@ int adt_mix_render_f32(const float* bank, const int64_t* bank_off, int64_t n_sho
  *   * gelu'(gelu_grad_of[row,col])       (bf16 pre-activation u; dgrad through GELU)
  *   pre_act_out[row,col] = bf16(z)       (saved pre-activation, may be null)
  *   act == 1: z = gelu_erf(z)            (exact erf GELU, activation="gelu")
+ *   dropout (drop.p > 0, drop_after_residual == 0), element index row*N + col
  *   + residual[row % res_row_mod, col]   (fp32; res_row_mod == 0: plain row) --
  *                                         residual stream, or the sinusoidal PE
  *                                         table with res_row_mod = frames per clip
+ *   dropout (drop.p > 0, drop_after_residual != 0)
  *   C = out_fp32 ? z : bf16(z);  aux_bf16_out[row,col] = bf16(z) as well when given
  *   (an fp32 residual-stream output plus the bf16 operand of the next GEMM in one pass)
  * trans = 1 may split K across workgroups; partial fp32 slabs go to `ws`
@@ -143,6 +151,7 @@ typedef struct adt_gemm_epilogue {
   float        alpha;
   int32_t      out_fp32;
   void*        aux_bf16_out;  int64_t ld_aux;
+  adt_dropout  drop;          int32_t drop_after_residual;
 } adt_gemm_epilogue;
 
 size_t adt_gemm_workspace_bytes(int32_t trans, int64_t M, int64_t N, int64_t K);
@@ -179,6 +188,7 @@ typedef struct adt_attn_desc {
   float   scale;
   float   mask_value;
   const int32_t* key_len;
+  adt_dropout drop;       /* dropout on the attention probabilities; element index ((b*heads+h)*q_len+q)*k_len+k */
 } adt_attn_desc;
 
 int adt_attn_fwd(const adt_attn_desc* d, const void* q, const void* k, const void* v, void* o, float* lse, void* stream);
@@ -196,14 +206,18 @@ int adt_attn_bwd(const adt_attn_desc* d, const void* q, const void* k, const voi
  *   bwd: dx from dy, the saved input x and statistics; dx as fp32 and/or bf16;
  *        dgamma, dbeta and dxsum[D] = column sums of dx (the bias gradient of the
  *        linear layer that produced x's branch); any of the three may be null.
+ *   Dropout: out_drop masks the forward output (element index row*D + col); in the backward dy_drop
+ *   re-applies that mask to dy, and dx16_drop masks the bf16 dx and dxsum (the gradient of a branch
+ *   whose output was dropped before the residual add) while dx32 stays the residual-stream gradient.
  */
 int adt_layernorm_fwd(const float* x, int64_t ldx, const float* gamma, const float* beta, float eps,
                       float* y32, void* y16, int64_t ldy, float* mean, float* rstd, int64_t M, int64_t D,
-                      void* stream);
+                      const adt_dropout* out_drop, void* stream);
 size_t adt_layernorm_bwd_workspace_bytes(int64_t M, int64_t D);
 int adt_layernorm_bwd(const float* dy, int64_t lddy, const float* x, int64_t ldx, const float* gamma,
                       const float* mean, const float* rstd, float* dx32, void* dx16, int64_t lddx,
-                      float* dgamma, float* dbeta, float* dxsum, int64_t M, int64_t D, void* ws,
+                      float* dgamma, float* dbeta, float* dxsum, int64_t M, int64_t D,
+                      const adt_dropout* dy_drop, const adt_dropout* dx16_drop, void* ws,
                       size_t ws_bytes, void* stream);
 
 /* Column sums of a bf16 [M,N] matrix -> fp32 [N] (bias gradients of in_proj, linear1,
@@ -220,9 +234,9 @@ int adt_colsum_bf16(const void* x, int64_t ld, int64_t M, int64_t N, float* out,
  *   bwd: dtable[tokens[row]] += scale * dy[row]              (dtable pre-zeroed by the caller)
  */
 int adt_embed_pe_fwd(const int64_t* tokens, const float* table, const float* pe, float scale, float* y32, void* y16,
-                     int64_t n_rows, int64_t T, int64_t D, int64_t vocab, void* stream);
+                     int64_t n_rows, int64_t T, int64_t D, int64_t vocab, const adt_dropout* drop, void* stream);
 int adt_embed_bwd(const int64_t* tokens, const float* dy, float scale, float* dtable, int64_t n_rows, int64_t D,
-                  int64_t vocab, void* stream);
+                  int64_t vocab, const adt_dropout* drop, void* stream);
 
 /* ---------------------------------------------------------------------------
  * K8  cross-entropy forward + backward

@@ -80,7 +80,7 @@ def key_padding_mask(lengths, T: int) -> torch.Tensor:
     return torch.arange(T).unsqueeze(0) >= lengths.unsqueeze(1)
 
 
-def mha(x_q, x_kv, in_w, in_b, out_w, out_b, nhead, add_mask=None, bf16=False):
+def mha(x_q, x_kv, in_w, in_b, out_w, out_b, nhead, add_mask=None, bf16=False, pdrop=None):
     """nn.MultiheadAttention forward (batch_first).  ``add_mask`` is an additive
     float mask broadcastable to [B, H, Tq, Tk]."""
     B, Tq, d = x_q.shape
@@ -96,36 +96,52 @@ def mha(x_q, x_kv, in_w, in_b, out_w, out_b, nhead, add_mask=None, bf16=False):
     if add_mask is not None:
         s = s + add_mask
     p = torch.softmax(s, dim=-1)
+    if pdrop is not None:                      # dropout on the attention probabilities (nn.MultiheadAttention dropout)
+        p = p * pdrop(p.shape)
     o = _r(p, bf16) @ _r(v, bf16)
     o = o.transpose(1, 2).reshape(B, Tq, d)
     return linear(o, out_w, out_b, bf16)
 
 
 # ----------------------------------------------------------------------------- network
-def encoder(state: State, x: torch.Tensor, nhead: int, n_layers: int, bf16=False) -> torch.Tensor:
-    """model.py:129-135: dense (no bias) -> +PE -> (dropout) -> layers -> LN -> (dropout)."""
+def _nodrop(site):
+    return None
+
+
+def _apply(x, d):
+    return x if d is None else x * d(x.shape)
+
+
+def encoder(state: State, x: torch.Tensor, nhead: int, n_layers: int, bf16=False, drop=_nodrop) -> torch.Tensor:
+    """model.py:129-135: dense (no bias) -> +PE -> dropout -> layers -> LN -> dropout.
+    ``drop(site)`` returns None or a function shape -> scale tensor (mask / (1-p)); the sites are the
+    dropout modules of the reference (Encoder.dropout_layer, and dropout / dropout1 / dropout2 + the
+    attention dropout inside nn.TransformerEncoderLayer)."""
     p = "encoder."
     x = linear(x, state[p + "dense_layer.weight"], None, bf16)
     x = x + state[p + "positional_encoding.pos_embedding"][:, : x.size(1), :]
+    x = _apply(x, drop("enc.pe"))
     for i in range(n_layers):
         q = f"{p}encoder.layers.{i}."
+        s_ = q[:-1]
         a = mha(x, x, state[q + "self_attn.in_proj_weight"], state[q + "self_attn.in_proj_bias"],
-                state[q + "self_attn.out_proj.weight"], state[q + "self_attn.out_proj.bias"], nhead, None, bf16)
-        x = layer_norm(x + a, state[q + "norm1.weight"], state[q + "norm1.bias"])
-        h = gelu(linear(x, state[q + "linear1.weight"], state[q + "linear1.bias"], bf16))
+                state[q + "self_attn.out_proj.weight"], state[q + "self_attn.out_proj.bias"], nhead, None, bf16, drop(s_ + ".attn"))
+        x = layer_norm(x + _apply(a, drop(s_ + ".drop1")), state[q + "norm1.weight"], state[q + "norm1.bias"])
+        h = _apply(gelu(linear(x, state[q + "linear1.weight"], state[q + "linear1.bias"], bf16)), drop(s_ + ".ffn"))
         h = linear(h, state[q + "linear2.weight"], state[q + "linear2.bias"], bf16)
-        x = layer_norm(x + h, state[q + "norm2.weight"], state[q + "norm2.bias"])
-    return layer_norm(x, state[p + "layer_norm.weight"], state[p + "layer_norm.bias"])
+        x = layer_norm(x + _apply(h, drop(s_ + ".drop2")), state[q + "norm2.weight"], state[q + "norm2.bias"])
+    return _apply(layer_norm(x, state[p + "layer_norm.weight"], state[p + "layer_norm.bias"]), drop("enc.final"))
 
 
 def decoder(state: State, tgt: torch.Tensor, memory: torch.Tensor, nhead: int, n_layers: int,
-            tgt_mask: Optional[torch.Tensor], tgt_padding_mask: Optional[torch.Tensor], bf16=False) -> torch.Tensor:
+            tgt_mask: Optional[torch.Tensor], tgt_padding_mask: Optional[torch.Tensor], bf16=False, drop=_nodrop) -> torch.Tensor:
     """model.py:170-190.  Bool masks become additive 0 / -1e4 floats (:173-181);
     PyTorch adds the causal and the key-padding mask."""
     p = "decoder."
     d = state[p + "tgt_tok_emb.embedding.weight"].shape[1]
     x = state[p + "tgt_tok_emb.embedding.weight"][tgt.long()] * math.sqrt(d)
     x = x + state[p + "positional_encoding.pos_embedding"][:, : x.size(1), :]
+    x = _apply(x, drop("dec.emb"))
     add = None
     if tgt_mask is not None:
         add = torch.zeros(tgt_mask.shape).masked_fill(tgt_mask, -1e4)[None, None]
@@ -134,15 +150,17 @@ def decoder(state: State, tgt: torch.Tensor, memory: torch.Tensor, nhead: int, n
         add = kp if add is None else add + kp
     for i in range(n_layers):
         q = f"{p}decoder.layers.{i}."
+        s_ = q[:-1]
         a = mha(x, x, state[q + "self_attn.in_proj_weight"], state[q + "self_attn.in_proj_bias"],
-                state[q + "self_attn.out_proj.weight"], state[q + "self_attn.out_proj.bias"], nhead, add, bf16)
-        x = layer_norm(x + a, state[q + "norm1.weight"], state[q + "norm1.bias"])
+                state[q + "self_attn.out_proj.weight"], state[q + "self_attn.out_proj.bias"], nhead, add, bf16, drop(s_ + ".sattn"))
+        x = layer_norm(x + _apply(a, drop(s_ + ".drop1")), state[q + "norm1.weight"], state[q + "norm1.bias"])
         c = mha(x, memory, state[q + "multihead_attn.in_proj_weight"], state[q + "multihead_attn.in_proj_bias"],
-                state[q + "multihead_attn.out_proj.weight"], state[q + "multihead_attn.out_proj.bias"], nhead, None, bf16)
-        x = layer_norm(x + c, state[q + "norm2.weight"], state[q + "norm2.bias"])
-        h = gelu(linear(x, state[q + "linear1.weight"], state[q + "linear1.bias"], bf16))
+                state[q + "multihead_attn.out_proj.weight"], state[q + "multihead_attn.out_proj.bias"], nhead, None, bf16,
+                drop(s_ + ".cattn"))
+        x = layer_norm(x + _apply(c, drop(s_ + ".drop2")), state[q + "norm2.weight"], state[q + "norm2.bias"])
+        h = _apply(gelu(linear(x, state[q + "linear1.weight"], state[q + "linear1.bias"], bf16)), drop(s_ + ".ffn"))
         h = linear(h, state[q + "linear2.weight"], state[q + "linear2.bias"], bf16)
-        x = layer_norm(x + h, state[q + "norm3.weight"], state[q + "norm3.bias"])
+        x = layer_norm(x + _apply(h, drop(s_ + ".drop3")), state[q + "norm3.weight"], state[q + "norm3.bias"])
     return linear(x, state[p + "generator.weight"], state[p + "generator.bias"], bf16)
 
 
@@ -163,27 +181,27 @@ def n_layers_of(state: State, prefix: str) -> int:
 
 
 def forward(state: State, cfg: dict, src: torch.Tensor, tgt: torch.Tensor,
-            tgt_padding_mask: Optional[torch.Tensor], labels: torch.Tensor, bf16=False) -> dict:
+            tgt_padding_mask: Optional[torch.Tensor], labels: torch.Tensor, bf16=False, drop=_nodrop) -> dict:
     """``ADTModel.forward`` (model.py:240-258) with ``tgt_mask=None`` as
     ``ADTTrainer.compute_loss`` calls it (train.py:64-70).  Returns every
     intermediate the parity tests compare."""
     nhead = cfg["nhead"]
     mel = o_logmel.logmel(src, cfg["sample_rate"], cfg["win_length"], cfg["time_res"], cfg["n_mels"])
     x = linear(mel, state["project_to_mel.weight"], state["project_to_mel.bias"], bf16)
-    memory = encoder(state, x, nhead, n_layers_of(state, "encoder.encoder.layers."), bf16)
+    memory = encoder(state, x, nhead, n_layers_of(state, "encoder.encoder.layers."), bf16, drop)
     cm = causal_mask(tgt.size(1))
     logits = decoder(state, tgt, memory, nhead, n_layers_of(state, "decoder.decoder.layers."), cm,
-                     tgt_padding_mask, bf16)
+                     tgt_padding_mask, bf16, drop)
     return {"logmel": mel, "memory": memory, "logits": logits, "loss": loss_fn(logits, labels)}
 
 
-def compute_loss(state: State, cfg: dict, batch: dict, bf16=False) -> dict:
+def compute_loss(state: State, cfg: dict, batch: dict, bf16=False, drop=_nodrop) -> dict:
     """``ADTTrainer.compute_loss`` (train.py:40-78): teacher-forcing shift and
     padding mask from ``token_lengths``."""
     tokens = torch.as_tensor(batch["tokens"])
     tgt_in, labels = tokens[:, :-1], tokens[:, 1:]
     pad = key_padding_mask(torch.as_tensor(batch["token_lengths"]), tgt_in.size(1))
-    return forward(state, cfg, torch.as_tensor(batch["wavs"]), tgt_in, pad, labels, bf16)
+    return forward(state, cfg, torch.as_tensor(batch["wavs"]), tgt_in, pad, labels, bf16, drop)
 
 
 def greedy_sample(state: State, cfg: dict, src: torch.Tensor, max_length: int = 1000,

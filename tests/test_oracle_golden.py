@@ -1,0 +1,68 @@
+"""The oracle against the golden vectors captured from the reference's own Python
+(tools/make_golden.py): this is what pins the checker before it is trusted."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import adt as o_adt
+from oracle import logmel as o_logmel
+
+
+def test_logmel_oracle_reproduces_reference_outputs(golden_dir):
+    g = np.load(os.path.join(golden_dir, "logmel.npz"))
+    for name in ("16k", "24k", "16k_edge"):
+        out = o_logmel.logmel(torch.from_numpy(g[f"{name}_wave"]), int(g[f"{name}_sr"]), 2048, 0.01, 128).numpy()
+        assert out.shape == g[f"{name}_out"].shape
+        assert np.abs(out - g[f"{name}_out"]).max() < 1e-6
+        assert sorted(str(k) for k in g[f"{name}_state_keys"]) == ["compute_spec.mel_scale.fb", "compute_spec.spectrogram.window"]
+    # frame geometry (model.py:79,95-97): 10 s @ 16 kHz -> 986 frames, 2.56 s @ 24 kHz -> 246
+    assert o_logmel.n_out_frames(160000, 160, 2048) == 986 and o_logmel.n_out_frames(61440, 240, 2048) == 246
+    assert g["24k_out"].shape[1] == 246
+
+
+def test_mel_filterbank_cross_check_with_hf():
+    """torchaudio's filterbank is third party and absent: cross-check the restatement against HF's
+    documented equivalent (float64) -- the "parity unpinned" part of the log-mel row."""
+    from transformers.audio_utils import mel_filter_bank
+    for sr in (16000, 24000):
+        fb = o_logmel.mel_filterbank(sr, 2048, 128).numpy()
+        hf = mel_filter_bank(1025, 128, 20.0, float(sr // 2), sr, norm=None, mel_scale="htk")
+        assert np.abs(fb - hf).max() < 5e-5
+        assert ((fb > 0).sum(axis=0) >= 1).all() and ((fb > 0).sum(axis=1) <= 2).all()     # banded: <= 2 filters per bin
+
+
+def tiny_state(g):
+    state = {k[3:]: torch.from_numpy(g[k]) for k in g.files if k.startswith("w::")}
+    d = state["encoder.dense_layer.weight"].shape[0]
+    state["encoder.positional_encoding.pos_embedding"] = o_adt.positional_encoding(d)
+    state["decoder.positional_encoding.pos_embedding"] = o_adt.positional_encoding(d)
+    return state
+
+
+def test_adt_oracle_reproduces_reference_modules(golden_dir):
+    g = np.load(os.path.join(golden_dir, "adt_tiny.npz"))
+    state = tiny_state(g)
+    cfg = dict(nhead=2, sample_rate=16000, win_length=2048, time_res=0.01, n_mels=128)
+    st = {k: v.clone().requires_grad_(True) if "pos_embedding" not in k else v for k, v in state.items()}
+    res = o_adt.compute_loss(st, cfg, {"wavs": g["wave"], "tokens": g["tokens"], "token_lengths": g["token_lengths"]})
+    assert (res["logmel"] - torch.from_numpy(g["logmel"])).abs().max() < 1e-6
+    assert (res["memory"].detach() - torch.from_numpy(g["memory"])).abs().max() < 5e-6
+    assert (res["logits"].detach() - torch.from_numpy(g["logits"])).abs().max() < 5e-6
+    assert abs(res["loss"].item() - float(g["loss"])) < 1e-5
+    res["loss"].backward()
+    for k in g.files:
+        if k.startswith("g::"):
+            ref = torch.from_numpy(g[k])
+            assert (st[k[3:]].grad - ref).abs().max() <= 2e-5 * max(1.0, ref.abs().max().item()), k
+    ids = o_adt.greedy_sample(state, cfg, torch.from_numpy(g["wave"]), max_length=10)
+    assert np.array_equal(ids.numpy(), g["sample_ids"])
+
+
+def test_positional_encoding_and_masks():
+    pe = o_adt.positional_encoding(8, 16)[0]
+    assert pe[0].tolist() == [0, 1, 0, 1, 0, 1, 0, 1]
+    assert torch.allclose(pe[3, 0], torch.sin(torch.tensor(3.0))) and torch.allclose(pe[3, 1], torch.cos(torch.tensor(3.0)))
+    assert o_adt.causal_mask(3).tolist() == [[False, True, True], [False, False, True], [False, False, False]]
+    assert o_adt.key_padding_mask([1, 3], 3).tolist() == [[False, True, True], [False, False, False]]
