@@ -159,6 +159,7 @@ __device__ __forceinline__ float mask_add(const AttnArgs& a, int qi, int ki, int
 }
 
 // =============================================================================== forward
+template <bool kDrop>
 __global__ __launch_bounds__(kAttnThreads) void attn_fwd_kernel(AttnArgs a) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];     // [2 stages][K tile | V tile]
   const int tid = threadIdx.x, lane = tid & 63, r = lane & 31, h = lane >> 5;
@@ -228,7 +229,7 @@ __global__ __launch_bounds__(kAttnThreads) void attn_fwd_kernel(AttnArgs a) {
 #pragma unroll
       for (int i = 0; i < 16; ++i) { const float p = __builtin_amdgcn_exp2f(st[kb][i] - m); st[kb][i] = p; psum += p; }
     l += psum;
-    if (a.drop.on()) {                       // dropout on the probabilities (the normaliser keeps the un-dropped sum)
+    if (kDrop) {                             // dropout on the probabilities (the normaliser keeps the un-dropped sum)
       const uint64_t rowbase = ((static_cast<uint64_t>(b) * a.H + head) * a.Sq + qi) * a.Sk;
 #pragma unroll
       for (int kb = 0; kb < 2; ++kb)
@@ -274,6 +275,7 @@ __global__ __launch_bounds__(256) void attn_delta_kernel(const unsigned short* _
 }
 
 // =============================================================================== backward: dQ  (lane <-> query)
+template <bool kDrop>
 __global__ __launch_bounds__(kAttnThreads) void attn_bwd_dq_kernel(AttnArgs a) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const int tid = threadIdx.x, lane = tid & 63, r = lane & 31, h = lane >> 5;
@@ -325,7 +327,7 @@ __global__ __launch_bounds__(kAttnThreads) void attn_bwd_dq_kernel(AttnArgs a) {
         const int ki = t * kRowsPerTile + kb * 32 + acc_row(i, h);
         const float tt = st[i] * sl2 + mask_add(a, qi, ki, klen) * kLog2e;
         const float p = ki < a.Sk ? __builtin_amdgcn_exp2f(tt - lse2) : 0.f;
-        const float keep = a.drop.on() ? a.drop.scale(((static_cast<uint64_t>(b) * a.H + head) * a.Sq + qi) * a.Sk + ki) : 1.0f;
+        const float keep = kDrop ? a.drop.scale(((static_cast<uint64_t>(b) * a.H + head) * a.Sq + qi) * a.Sk + ki) : 1.0f;
         st[i] = p * (dp[i] * keep - dlt) * a.scale;          // dS^T
       }
 #pragma unroll
@@ -345,6 +347,7 @@ __global__ __launch_bounds__(kAttnThreads) void attn_bwd_dq_kernel(AttnArgs a) {
 }
 
 // =============================================================================== backward: dK, dV  (lane <-> key)
+template <bool kDrop>
 __global__ __launch_bounds__(kAttnThreads, 1) void attn_bwd_dkv_kernel(AttnArgs a) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];     // [2 stages][Q tile | dO tile | lse2[64] | delta[64]]
   constexpr int kStage = 2 * kAttnTileBytes + 512;
@@ -412,7 +415,7 @@ __global__ __launch_bounds__(kAttnThreads, 1) void attn_bwd_dkv_kernel(AttnArgs 
         const int qi = t * kRowsPerTile + ql;
         const float tt = st[i] * sl2 + mask_add(a, qi, ki, klen) * kLog2e;
         const float p = (qi < a.Sq && ki < a.Sk) ? __builtin_amdgcn_exp2f(tt - stats[ql]) : 0.f;
-        const float keep = a.drop.on() ? a.drop.scale(((static_cast<uint64_t>(b) * a.H + head) * a.Sq + qi) * a.Sk + ki) : 1.0f;
+        const float keep = kDrop ? a.drop.scale(((static_cast<uint64_t>(b) * a.H + head) * a.Sq + qi) * a.Sk + ki) : 1.0f;
         st[i] = p * keep;                                    // dropped P (what multiplied V in the forward)
         dp[i] = p * (dp[i] * keep - stats[64 + ql]) * a.scale;   // dS
       }
@@ -461,10 +464,13 @@ static int set_lds_once() {      // raise the dynamic-LDS limit of the three ker
   int dev = 0;
   ADT_HIP_TRY(hipGetDevice(&dev));
   if (done_for == dev) return ADT_OK;
-  ADT_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(attn_fwd_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 4 * kAttnTileBytes));
-  ADT_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(attn_bwd_dq_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 4 * kAttnTileBytes));
-  ADT_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(attn_bwd_dkv_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                  2 * (2 * kAttnTileBytes + 512)));
+  const int l4 = 4 * kAttnTileBytes, ldkv = 2 * (2 * kAttnTileBytes + 512);
+  ADT_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(attn_fwd_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, l4));
+  ADT_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(attn_fwd_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, l4));
+  ADT_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(attn_bwd_dq_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, l4));
+  ADT_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(attn_bwd_dq_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, l4));
+  ADT_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(attn_bwd_dkv_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, ldkv));
+  ADT_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(attn_bwd_dkv_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, ldkv));
   done_for = dev;
   return ADT_OK;
 }
@@ -484,8 +490,9 @@ extern "C" int adt_attn_fwd(const adt_attn_desc* d, const void* q, const void* k
   a.out = static_cast<unsigned short*>(o); a.lse = lse;
   const int lds = 4 * kAttnTileBytes;
   if (int rc = set_lds_once()) return rc;
-  hipLaunchKernelGGL(attn_fwd_kernel, dim3((d->q_len + 127) / 128, d->batch * d->heads), dim3(kAttnThreads), lds,
-                     static_cast<hipStream_t>(stream), a);
+  const dim3 grid((d->q_len + 127) / 128, d->batch * d->heads);
+  if (a.drop.on()) hipLaunchKernelGGL(attn_fwd_kernel<true>, grid, dim3(kAttnThreads), lds, static_cast<hipStream_t>(stream), a);
+  else hipLaunchKernelGGL(attn_fwd_kernel<false>, grid, dim3(kAttnThreads), lds, static_cast<hipStream_t>(stream), a);
   ADT_HIP_TRY(hipGetLastError());
   return ADT_OK;
 }
@@ -512,8 +519,14 @@ extern "C" int adt_attn_bwd(const adt_attn_desc* d, const void* q, const void* k
                      static_cast<float*>(ws));
   const int lds_dq = 4 * kAttnTileBytes, lds_dkv = 2 * (2 * kAttnTileBytes + 512);
   if (int rc = set_lds_once()) return rc;
-  hipLaunchKernelGGL(attn_bwd_dq_kernel, dim3((d->q_len + 127) / 128, d->batch * d->heads), dim3(kAttnThreads), lds_dq, st, a);
-  hipLaunchKernelGGL(attn_bwd_dkv_kernel, dim3((d->k_len + 127) / 128, d->batch * d->heads), dim3(kAttnThreads), lds_dkv, st, a);
+  const dim3 gq((d->q_len + 127) / 128, d->batch * d->heads), gk((d->k_len + 127) / 128, d->batch * d->heads);
+  if (a.drop.on()) {
+    hipLaunchKernelGGL(attn_bwd_dq_kernel<true>, gq, dim3(kAttnThreads), lds_dq, st, a);
+    hipLaunchKernelGGL(attn_bwd_dkv_kernel<true>, gk, dim3(kAttnThreads), lds_dkv, st, a);
+  } else {
+    hipLaunchKernelGGL(attn_bwd_dq_kernel<false>, gq, dim3(kAttnThreads), lds_dq, st, a);
+    hipLaunchKernelGGL(attn_bwd_dkv_kernel<false>, gk, dim3(kAttnThreads), lds_dkv, st, a);
+  }
   ADT_HIP_TRY(hipGetLastError());
   return ADT_OK;
 }

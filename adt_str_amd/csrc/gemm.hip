@@ -110,6 +110,7 @@ __device__ __forceinline__ bf16x8 frag_tn(const unsigned char* tile, int col0, i
 
 // ---- epilogue shared by the kernels: C element (row, col) = acc[i][j][r] with
 // row = m0 + wm*64 + i*16 + 4*(lane>>4) + r, col = n0 + wn*64 + j*16 + (lane&15)
+template <bool kDrop>
 __device__ __forceinline__ void gemm_epilogue(const GemmArgs& g, f32x4 (&acc)[4][4], int m0, int n0, int wm, int wn, int lane, int split) {
   const adt_gemm_epilogue& ep = g.ep;
   const bool to_slab = g.slabs != nullptr;
@@ -137,13 +138,13 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& g, f32x4 (&acc)[4]
         if (ep.pre_act_out)
           reinterpret_cast<unsigned short*>(ep.pre_act_out)[static_cast<long>(row) * ep.ld_pre_act + col] = f2bf(z);
         if (ep.act == 1) z = gelu_erf(ep.pre_act_out ? bf2f(f2bf(z)) : z);
-        const float keep = g.drop.on() ? g.drop.scale(static_cast<uint64_t>(row) * g.N + col) : 1.0f;
-        if (!ep.drop_after_residual) z *= keep;
+        const float keep = kDrop ? g.drop.scale(static_cast<uint64_t>(row) * g.N + col) : 1.0f;
+        if (kDrop && !ep.drop_after_residual) z *= keep;
         if (ep.residual) {
           const long rr = ep.res_row_mod > 0 ? (row % ep.res_row_mod) : row;
           z += reinterpret_cast<const float*>(ep.residual)[rr * ep.ld_res + col];
         }
-        if (ep.drop_after_residual) z *= keep;
+        if (kDrop && ep.drop_after_residual) z *= keep;
         if (ep.aux_bf16_out) reinterpret_cast<unsigned short*>(ep.aux_bf16_out)[static_cast<long>(row) * ep.ld_aux + col] = f2bf(z);
         if (ep.out_fp32) reinterpret_cast<float*>(g.C)[static_cast<long>(row) * g.ldc + col] = z;
         else reinterpret_cast<unsigned short*>(g.C)[static_cast<long>(row) * g.ldc + col] = f2bf(z);
@@ -152,7 +153,7 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& g, f32x4 (&acc)[4]
   }
 }
 
-template <bool kTrans>
+template <bool kTrans, bool kDrop>
 __global__ __launch_bounds__(kGemmThreads) void gemm_bf16_kernel(GemmArgs g) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const int tid = threadIdx.x, lane = tid & 63;
@@ -217,7 +218,7 @@ __global__ __launch_bounds__(kGemmThreads) void gemm_bf16_kernel(GemmArgs g) {
     __syncthreads();
   }
 
-  gemm_epilogue(g, acc, m0, n0, wm, wn, lane, split);
+  gemm_epilogue<kDrop>(g, acc, m0, n0, wm, wn, lane, split);
 }
 
 // ---- row-vector epilogue (LDS-DMA kernel): the 128x128 fp32 accumulator tile is transposed through
@@ -226,6 +227,7 @@ __global__ __launch_bounds__(kGemmThreads) void gemm_bf16_kernel(GemmArgs g) {
 // vector accesses and every output row is written as whole 16-byte pieces.
 constexpr int kEpiPitch = 132;
 constexpr int kEpiLds = 128 * kEpiPitch * 4;          // 67,584 B
+template <bool kDrop>
 __device__ __forceinline__ void gemm_epilogue_rows(const GemmArgs& g, f32x4 (&acc)[4][4], float* ct, int m0, int n0,
                                                    int wm, int wn, int tid, int lane) {
 #pragma unroll
@@ -277,14 +279,14 @@ __device__ __forceinline__ void gemm_epilogue_rows(const GemmArgs& g, f32x4 (&ac
       for (int e = 0; e < 8; ++e) z[e] = gelu_erf(z[e]);
     }
     float keep[8] = {1.f, 1.f, 1.f, 1.f, 1.f, 1.f, 1.f, 1.f};
-    if (g.drop.on()) {
+    if (kDrop) {
       const uint64_t base = static_cast<uint64_t>(row) * g.N + col;
 #pragma unroll
       for (int e = 0; e < 8; ++e) keep[e] = g.drop.scale(base + e);
-    }
-    if (!ep.drop_after_residual) {
+      if (!ep.drop_after_residual) {
 #pragma unroll
-      for (int e = 0; e < 8; ++e) z[e] *= keep[e];
+        for (int e = 0; e < 8; ++e) z[e] *= keep[e];
+      }
     }
     if (ep.residual) {
       const long rr = ep.res_row_mod > 0 ? (row % ep.res_row_mod) : row;
@@ -292,7 +294,7 @@ __device__ __forceinline__ void gemm_epilogue_rows(const GemmArgs& g, f32x4 (&ac
       const float4 r0 = *reinterpret_cast<const float4*>(rp), r1 = *reinterpret_cast<const float4*>(rp + 4);
       z[0] += r0.x; z[1] += r0.y; z[2] += r0.z; z[3] += r0.w; z[4] += r1.x; z[5] += r1.y; z[6] += r1.z; z[7] += r1.w;
     }
-    if (ep.drop_after_residual) {
+    if (kDrop && ep.drop_after_residual) {
 #pragma unroll
       for (int e = 0; e < 8; ++e) z[e] *= keep[e];
     }
@@ -344,6 +346,7 @@ __device__ __forceinline__ bf16x8 frag_glds(const unsigned char* tile, int row0,
   return *reinterpret_cast<const bf16x8*>(tile + row * 128 + chunk * 16);
 }
 
+template <bool kDrop>
 __global__ __launch_bounds__(kGemmThreads) void gemm_nt_glds_kernel(GemmArgs g, int tiles_m, int tiles_n) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];      // [2 stages][A tile | B tile]
   const int tid = threadIdx.x, lane = tid & 63;
@@ -394,7 +397,7 @@ __global__ __launch_bounds__(kGemmThreads) void gemm_nt_glds_kernel(GemmArgs g, 
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
   }
-  gemm_epilogue_rows(g, acc, reinterpret_cast<float*>(smem), m0, n0, wm, wn, tid, lane);
+  gemm_epilogue_rows<kDrop>(g, acc, reinterpret_cast<float*>(smem), m0, n0, wm, wn, tid, lane);
 }
 
 // =========================================================================================
@@ -501,7 +504,7 @@ __global__ __launch_bounds__(kGemmThreads) void gemm_tn_glds_kernel(GemmArgs g, 
     o.ep.out_fp32 = 1;
     o.drop = Drop{0u, 0u, 1.0f};
   }
-  gemm_epilogue_rows(o, acc, reinterpret_cast<float*>(smem), m0, n0, wm, wn, tid, lane);
+  gemm_epilogue_rows<false>(o, acc, reinterpret_cast<float*>(smem), m0, n0, wm, wn, tid, lane);
 }
 
 // sums split-K slabs in slab order: out[m,n] = alpha * sum_s slab[s][m,n]   (fp32 out)
@@ -585,9 +588,11 @@ extern "C" int adt_gemm_bf16(int32_t trans, int64_t M, int64_t N, int64_t K, con
   int dev = 0;
   ADT_HIP_TRY(hipGetDevice(&dev));
   if (attr_dev != dev) {
-    ADT_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_bf16_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, kGemmLds));
-    ADT_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_bf16_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, kGemmLds));
-    ADT_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_nt_glds_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, kEpiLds));
+    ADT_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_bf16_kernel<false, false>), hipFuncAttributeMaxDynamicSharedMemorySize, kGemmLds));
+    ADT_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_bf16_kernel<false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, kGemmLds));
+    ADT_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_bf16_kernel<true, false>), hipFuncAttributeMaxDynamicSharedMemorySize, kGemmLds));
+    ADT_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_nt_glds_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, kEpiLds));
+    ADT_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_nt_glds_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, kEpiLds));
     ADT_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_tn_glds_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, kEpiLds));
     attr_dev = dev;
   }
@@ -595,12 +600,16 @@ extern "C" int adt_gemm_bf16(int32_t trans, int64_t M, int64_t N, int64_t K, con
     const int tm = static_cast<int>((M + kBM - 1) / kBM), tn = static_cast<int>((N + kBN - 1) / kBN);
     hipLaunchKernelGGL(gemm_tn_glds_kernel, dim3(static_cast<unsigned>(tm) * tn, splits), dim3(kGemmThreads), kEpiLds, st, g, tm, tn);
   } else if (trans) {
-    hipLaunchKernelGGL(gemm_bf16_kernel<true>, grid, dim3(kGemmThreads), kGemmLds, st, g);
+    if (g.drop.on()) return set_error(ADT_EINVAL, "adt_gemm_bf16: dropout is not supported with trans = 1");
+    hipLaunchKernelGGL((gemm_bf16_kernel<true, false>), grid, dim3(kGemmThreads), kGemmLds, st, g);
   } else if ((K % kBK) == 0 && K > 0 && vector_epilogue_ok(g, e)) {
     const int tm = static_cast<int>((M + kBM - 1) / kBM), tn = static_cast<int>((N + kBN - 1) / kBN);
-    hipLaunchKernelGGL(gemm_nt_glds_kernel, dim3(static_cast<unsigned>(tm) * tn), dim3(kGemmThreads), kEpiLds, st, g, tm, tn);
+    const dim3 g1(static_cast<unsigned>(tm) * tn);
+    if (g.drop.on()) hipLaunchKernelGGL(gemm_nt_glds_kernel<true>, g1, dim3(kGemmThreads), kEpiLds, st, g, tm, tn);
+    else hipLaunchKernelGGL(gemm_nt_glds_kernel<false>, g1, dim3(kGemmThreads), kEpiLds, st, g, tm, tn);
   } else {
-    hipLaunchKernelGGL(gemm_bf16_kernel<false>, grid, dim3(kGemmThreads), kGemmLds, st, g);
+    if (g.drop.on()) hipLaunchKernelGGL((gemm_bf16_kernel<false, true>), grid, dim3(kGemmThreads), kGemmLds, st, g);
+    else hipLaunchKernelGGL((gemm_bf16_kernel<false, false>), grid, dim3(kGemmThreads), kGemmLds, st, g);
   }
   if (splits > 1) {
     const long mn = static_cast<long>(M) * N;
