@@ -41,6 +41,7 @@ constexpr int kAttnTileBytes = kRowsPerTile * 256;   // 16 KiB
 constexpr float kLog2e = 1.4426950408889634f;
 constexpr float kLn2 = 0.6931471805599453f;
 constexpr float kNegBig = -1.0e30f;
+constexpr float kRescaleThr = 5.0f;          // log2 units: lazy online-softmax rescale threshold
 
 __device__ __forceinline__ unsigned lds_off(const void* p) {
   return static_cast<unsigned>(reinterpret_cast<size_t>((__attribute__((address_space(3))) const void*)p));
@@ -160,7 +161,7 @@ __device__ __forceinline__ float mask_add(const AttnArgs& a, int qi, int ki, int
 
 // =============================================================================== forward
 template <bool kDrop>
-__global__ __launch_bounds__(kAttnThreads) void attn_fwd_kernel(AttnArgs a) {
+__global__ __launch_bounds__(kAttnThreads, 2) void attn_fwd_kernel(AttnArgs a) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];     // [2 stages][K tile | V tile]
   const int tid = threadIdx.x, lane = tid & 63, r = lane & 31, h = lane >> 5;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -181,6 +182,8 @@ __global__ __launch_bounds__(kAttnThreads) void attn_fwd_kernel(AttnArgs a) {
 #pragma unroll
     for (int i = 0; i < 16; ++i) o[db][i] = 0.f;
   float m = kNegBig, l = 0.f;
+  const unsigned rowbase = static_cast<unsigned>(((static_cast<uint64_t>(b) * a.H + head) * a.Sq + qi) * a.Sk);
+  const unsigned key2 = mix32(a.drop.key);
 
   const int n_tiles = (a.Sk + kRowsPerTile - 1) / kRowsPerTile;
   tile_dma(kb_, a.ldk, 0, a.Sk, smem, wave, lane);
@@ -195,59 +198,68 @@ __global__ __launch_bounds__(kAttnThreads) void attn_fwd_kernel(AttnArgs a) {
       tile_dma(kb_, a.ldk, (t + 1) * kRowsPerTile, a.Sk, nk, wave, lane);
       tile_dma(vb, a.ldv, (t + 1) * kRowsPerTile, a.Sk, nk + kAttnTileBytes, wave, lane);
     }
-    f32x16 st[2];
+    const int tile0 = t * kRowsPerTile;
+    const bool need_mask = a.causal || tile0 + kRowsPerTile > klen || tile0 + kRowsPerTile > a.Sk;   // block-uniform
 #pragma unroll
     for (int kb = 0; kb < 2; ++kb) {
+      f32x16 st;
 #pragma unroll
-      for (int i = 0; i < 16; ++i) st[kb][i] = 0.f;
+      for (int i = 0; i < 16; ++i) st[i] = 0.f;
 #pragma unroll
-      for (int s = 0; s < 8; ++s) st[kb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_rows(tk, kb, s, lane), qf[s], st[kb], 0, 0, 0);
-    }
-    float mloc = kNegBig;
+      for (int s = 0; s < 8; ++s) st = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_rows(tk, kb, s, lane), qf[s], st, 0, 0, 0);
+      // scores in the log2 domain; interior tiles (no mask, all keys valid) skip the per-element mask arithmetic
+      float mloc = kNegBig;
+      if (need_mask) {
 #pragma unroll
-    for (int kb = 0; kb < 2; ++kb)
+        for (int i = 0; i < 16; ++i) {
+          const int ki = tile0 + kb * 32 + acc_row(i, h);
+          float tt = fmaf(st[i], sl2, mask_add(a, qi, ki, klen) * kLog2e);
+          if (ki >= a.Sk) tt = kNegBig;
+          st[i] = tt;
+          mloc = fmaxf(mloc, tt);
+        }
+      } else {
 #pragma unroll
-      for (int i = 0; i < 16; ++i) {
-        const int ki = t * kRowsPerTile + kb * 32 + acc_row(i, h);
-        float tt = st[kb][i] * sl2 + mask_add(a, qi, ki, klen) * kLog2e;
-        if (ki >= a.Sk) tt = kNegBig;
-        st[kb][i] = tt;
-        mloc = fmaxf(mloc, tt);
+        for (int i = 0; i < 16; ++i) mloc = fmaxf(mloc, st[i]);
+        mloc *= sl2;
       }
-    mloc = fmaxf(mloc, __shfl_xor(mloc, 32));
-    const float m_new = fmaxf(m, mloc);
-    const float alpha = __builtin_amdgcn_exp2f(m - m_new);
-    m = m_new;
-    l *= alpha;
+      mloc = fmaxf(mloc, __shfl_xor(mloc, 32));
+      // lazy rescale: the running max is only raised (and O, l rescaled) when some query's block max exceeds it
+      // by more than kRescaleThr; until then probabilities are bounded by 2^kRescaleThr, harmless in fp32/bf16
+      if (__any(mloc > m + kRescaleThr)) {
+        const float m_new = fmaxf(m, mloc);
+        const float alpha = __builtin_amdgcn_exp2f(m - m_new);
+        m = m_new;
+        l *= alpha;
 #pragma unroll
-    for (int db = 0; db < 4; ++db)
+        for (int db = 0; db < 4; ++db)
 #pragma unroll
-      for (int i = 0; i < 16; ++i) o[db][i] *= alpha;
-    float psum = 0.f;
+          for (int i = 0; i < 16; ++i) o[db][i] *= alpha;
+      }
+      float psum = 0.f;
+      if (need_mask) {
 #pragma unroll
-    for (int kb = 0; kb < 2; ++kb)
+        for (int i = 0; i < 16; ++i) { const float p = __builtin_amdgcn_exp2f(st[i] - m); st[i] = p; psum += p; }
+      } else {
 #pragma unroll
-      for (int i = 0; i < 16; ++i) { const float p = __builtin_amdgcn_exp2f(st[kb][i] - m); st[kb][i] = p; psum += p; }
-    l += psum;
-    if (kDrop) {                             // dropout on the probabilities (the normaliser keeps the un-dropped sum)
-      const uint64_t rowbase = ((static_cast<uint64_t>(b) * a.H + head) * a.Sq + qi) * a.Sk;
+        for (int i = 0; i < 16; ++i) { const float p = __builtin_amdgcn_exp2f(fmaf(st[i], sl2, -m)); st[i] = p; psum += p; }
+      }
+      l += psum;
+      if (kDrop) {                           // dropout on the probabilities (the normaliser keeps the un-dropped sum)
 #pragma unroll
-      for (int kb = 0; kb < 2; ++kb)
-#pragma unroll
-        for (int i = 0; i < 16; ++i) st[kb][i] *= a.drop.scale(rowbase + t * kRowsPerTile + kb * 32 + acc_row(i, h));
-    }
-#pragma unroll
-    for (int kb = 0; kb < 2; ++kb)
+        for (int i = 0; i < 16; ++i) st[i] *= a.drop.scale32(rowbase + tile0 + kb * 32 + acc_row(i, h), key2);
+      }
 #pragma unroll
       for (int s2 = 0; s2 < 2; ++s2) {
         TrFrag vt[4];
         tr4_issue(tv, kb * 32 + 16 * s2, lane, vt);
-        const bf16x8 pf = acc_to_b(st[kb], s2);
+        const bf16x8 pf = acc_to_b(st, s2);
         tr_wait();
 #pragma unroll
         for (int db = 0; db < 4; ++db)
           o[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(tr_get(vt[db]), pf, o[db], 0, 0, 0);
       }
+    }
     dma_wait_and_sync();
   }
   const float lt = l + __shfl_xor(l, 32);
@@ -276,7 +288,7 @@ __global__ __launch_bounds__(256) void attn_delta_kernel(const unsigned short* _
 
 // =============================================================================== backward: dQ  (lane <-> query)
 template <bool kDrop>
-__global__ __launch_bounds__(kAttnThreads) void attn_bwd_dq_kernel(AttnArgs a) {
+__global__ __launch_bounds__(kAttnThreads, 2) void attn_bwd_dq_kernel(AttnArgs a) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const int tid = threadIdx.x, lane = tid & 63, r = lane & 31, h = lane >> 5;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -290,6 +302,8 @@ __global__ __launch_bounds__(kAttnThreads) void attn_bwd_dq_kernel(AttnArgs a) {
   const float sl2 = a.scale * kLog2e;
   const long stat = (static_cast<long>(b) * a.H + head) * a.Sq + (qi < a.Sq ? qi : 0);
   const float lse2 = a.lse[stat] * kLog2e, dlt = a.delta[stat];
+  const unsigned rowbase = static_cast<unsigned>(((static_cast<uint64_t>(b) * a.H + head) * a.Sq + qi) * a.Sk);
+  const unsigned key2 = mix32(a.drop.key);
 
   bf16x8 qf[8], dof[8];
   frags_from_global(qb, a.ldq, qi, a.Sq, lane, qf);
@@ -312,6 +326,8 @@ __global__ __launch_bounds__(kAttnThreads) void attn_bwd_dq_kernel(AttnArgs a) {
       tile_dma(kb_, a.ldk, (t + 1) * kRowsPerTile, a.Sk, nk, wave, lane);
       tile_dma(vb, a.ldv, (t + 1) * kRowsPerTile, a.Sk, nk + kAttnTileBytes, wave, lane);
     }
+    const int tile0 = t * kRowsPerTile;
+    const bool need_mask = a.causal || tile0 + kRowsPerTile > klen || tile0 + kRowsPerTile > a.Sk;
 #pragma unroll
     for (int kb = 0; kb < 2; ++kb) {
       f32x16 st, dp;
@@ -322,13 +338,21 @@ __global__ __launch_bounds__(kAttnThreads) void attn_bwd_dq_kernel(AttnArgs a) {
         st = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_rows(tk, kb, s, lane), qf[s], st, 0, 0, 0);
         dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_rows(tv, kb, s, lane), dof[s], dp, 0, 0, 0);
       }
+      if (need_mask) {
 #pragma unroll
-      for (int i = 0; i < 16; ++i) {
-        const int ki = t * kRowsPerTile + kb * 32 + acc_row(i, h);
-        const float tt = st[i] * sl2 + mask_add(a, qi, ki, klen) * kLog2e;
-        const float p = ki < a.Sk ? __builtin_amdgcn_exp2f(tt - lse2) : 0.f;
-        const float keep = kDrop ? a.drop.scale(((static_cast<uint64_t>(b) * a.H + head) * a.Sq + qi) * a.Sk + ki) : 1.0f;
-        st[i] = p * (dp[i] * keep - dlt) * a.scale;          // dS^T
+        for (int i = 0; i < 16; ++i) {
+          const int ki = tile0 + kb * 32 + acc_row(i, h);
+          const float tt = fmaf(st[i], sl2, mask_add(a, qi, ki, klen) * kLog2e);
+          st[i] = ki < a.Sk ? __builtin_amdgcn_exp2f(tt - lse2) : 0.f;
+        }
+      } else {
+#pragma unroll
+        for (int i = 0; i < 16; ++i) st[i] = __builtin_amdgcn_exp2f(fmaf(st[i], sl2, -lse2));
+      }
+#pragma unroll
+      for (int i = 0; i < 16; ++i) {         // dS^T / scale (the softmax scale is applied once, when dQ is stored)
+        const float keep = kDrop ? a.drop.scale32(rowbase + tile0 + kb * 32 + acc_row(i, h), key2) : 1.0f;
+        st[i] *= fmaf(dp[i], keep, -dlt);
       }
 #pragma unroll
       for (int s2 = 0; s2 < 2; ++s2) {
@@ -343,7 +367,7 @@ __global__ __launch_bounds__(kAttnThreads) void attn_bwd_dq_kernel(AttnArgs a) {
     }
     dma_wait_and_sync();
   }
-  store_transposed(dq, 1.0f, a.dq + static_cast<long>(b) * a.Sq * a.ldq + head * kDh, a.ldq, qi, a.Sq, lane);
+  store_transposed(dq, a.scale, a.dq + static_cast<long>(b) * a.Sq * a.ldq + head * kDh, a.ldq, qi, a.Sq, lane);
 }
 
 // =============================================================================== backward: dK, dV  (lane <-> key)
@@ -363,6 +387,10 @@ __global__ __launch_bounds__(kAttnThreads, 1) void attn_bwd_dkv_kernel(AttnArgs 
   const float sl2 = a.scale * kLog2e;
   const float* lse_b = a.lse + (static_cast<long>(b) * a.H + head) * a.Sq;
   const float* dl_b = a.delta + (static_cast<long>(b) * a.H + head) * a.Sq;
+  const unsigned headbase = static_cast<unsigned>((static_cast<uint64_t>(b) * a.H + head) * a.Sq * a.Sk) + static_cast<unsigned>(ki);
+  const unsigned key2 = mix32(a.drop.key);
+  const int k_end = blockIdx.x * 128 + 128;
+  const bool key_mask = a.causal || k_end > klen || k_end > a.Sk;
 
   bf16x8 kf[8], vf[8];
   frags_from_global(kb_, a.ldk, ki, a.Sk, lane, kf);
@@ -409,15 +437,21 @@ __global__ __launch_bounds__(kAttnThreads, 1) void attn_bwd_dkv_kernel(AttnArgs 
         st = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_rows(tq, qblk, s, lane), kf[s], st, 0, 0, 0);
         dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_rows(td, qblk, s, lane), vf[s], dp, 0, 0, 0);
       }
+      const bool need_mask = key_mask || (t + 1) * kRowsPerTile > a.Sq;     // block-uniform
 #pragma unroll
       for (int i = 0; i < 16; ++i) {
         const int ql = qblk * 32 + acc_row(i, h);
         const int qi = t * kRowsPerTile + ql;
-        const float tt = st[i] * sl2 + mask_add(a, qi, ki, klen) * kLog2e;
-        const float p = (qi < a.Sq && ki < a.Sk) ? __builtin_amdgcn_exp2f(tt - stats[ql]) : 0.f;
-        const float keep = kDrop ? a.drop.scale(((static_cast<uint64_t>(b) * a.H + head) * a.Sq + qi) * a.Sk + ki) : 1.0f;
+        float p;
+        if (need_mask) {
+          const float tt = fmaf(st[i], sl2, mask_add(a, qi, ki, klen) * kLog2e);
+          p = (qi < a.Sq && ki < a.Sk) ? __builtin_amdgcn_exp2f(tt - stats[ql]) : 0.f;
+        } else {
+          p = __builtin_amdgcn_exp2f(fmaf(st[i], sl2, -stats[ql]));
+        }
+        const float keep = kDrop ? a.drop.scale32(headbase + static_cast<unsigned>(qi) * static_cast<unsigned>(a.Sk), key2) : 1.0f;
         st[i] = p * keep;                                    // dropped P (what multiplied V in the forward)
-        dp[i] = p * (dp[i] * keep - stats[64 + ql]) * a.scale;   // dS
+        dp[i] = p * fmaf(dp[i], keep, -stats[64 + ql]);      // dS / scale (scale applied when dK is stored)
       }
 #pragma unroll
       for (int s2 = 0; s2 < 2; ++s2) {
@@ -436,7 +470,7 @@ __global__ __launch_bounds__(kAttnThreads, 1) void attn_bwd_dkv_kernel(AttnArgs 
     if (more) store_stats(smem + ((t + 1) & 1) * kStage);
     dma_wait_and_sync();
   }
-  store_transposed(dk, 1.0f, a.dk + static_cast<long>(b) * a.Sk * a.ldk + head * kDh, a.ldk, ki, a.Sk, lane);
+  store_transposed(dk, a.scale, a.dk + static_cast<long>(b) * a.Sk * a.ldk + head * kDh, a.ldk, ki, a.Sk, lane);
   store_transposed(dv, 1.0f, a.dv + static_cast<long>(b) * a.Sk * a.ldv + head * kDh, a.ldv, ki, a.Sk, lane);
 }
 
@@ -448,6 +482,8 @@ static int check_desc(const adt_attn_desc* d, const char* who) {
   if (d->ldq < need || d->ldk < need || d->ldv < need || d->ldo < need || (d->ldq & 7) || (d->ldk & 7) || (d->ldv & 7) || (d->ldo & 7))
     return set_error(ADT_ESHAPE, "attention: row strides must cover heads*128 columns and be multiples of 8");
   if (static_cast<int64_t>(d->batch) * d->heads > 65535) return set_error(ADT_ESHAPE, "attention: batch*heads must be <= 65535");
+  if (d->drop.p > 0.f && static_cast<double>(d->batch) * d->heads * d->q_len * d->k_len >= 4294967296.0)
+    return set_error(ADT_ESHAPE, "attention: dropout needs batch*heads*q_len*k_len < 2^32");
   (void)who;
   return ADT_OK;
 }

@@ -26,6 +26,8 @@ struct Drop {
     const uint32_t h = mix32(static_cast<uint32_t>(idx) ^ mix32(static_cast<uint32_t>(idx >> 32) ^ key));
     return h >= thr ? inv_keep : 0.0f;
   }
+  // same function for indices below 2^32 (idx_hi == 0): the inner hash is the constant key2 = mix32(key)
+  ADT_DROP_HD float scale32(uint32_t idx, uint32_t key2) const { return mix32(idx ^ key2) >= thr ? inv_keep : 0.0f; }
   ADT_DROP_HD bool on() const { return thr != 0; }
 };
 inline Drop make_drop(float p, uint32_t key) {
