@@ -1,0 +1,83 @@
+// curation.hip -- K12: cosine similarity of every sample embedding against the class-mean embeddings
+// and the per-sample best class (gfx950).
+//
+// Stands behind the similarity loop of the reference's curation driver
+// (data_modules/augment_data_with_CLAP.py:139-151: F.cosine_similarity per class, 4.8 M Python tuples at
+// 100 k samples) and the "first occurrence wins" assignment (:182-193), which is a per-sample argmax with
+// the lowest class position winning ties.  HBM-bound: 4*D bytes per sample are read once; the <= 64 class
+// vectors live in LDS.  One wave per sample, fp32 throughout.
+#include <hip/hip_runtime.h>
+
+#include "adt_common.h"
+
+namespace adt {
+
+constexpr int kCurThreads = 256;
+constexpr int kCurMaxRefFloats = 36 * 1024;          // 144 KiB of LDS for the class vectors
+
+__global__ __launch_bounds__(kCurThreads) void cosine_argmax_kernel(const float* __restrict__ emb, long ld, const float* __restrict__ refs,
+                                                                    int N, int D, int C, float eps, int* __restrict__ best_class,
+                                                                    float* __restrict__ best_score, float* __restrict__ scores) {
+  extern __shared__ __attribute__((aligned(16))) float sm[];
+  float* r = sm;                        // [C][D]
+  float* rnorm2 = sm + C * D;           // [C]
+  for (int i = threadIdx.x; i < C * D; i += kCurThreads) r[i] = refs[i];
+  __syncthreads();
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  for (int c = wave; c < C; c += kCurThreads / 64) {
+    float s = 0.f;
+    for (int i = lane; i < D; i += 64) s += r[c * D + i] * r[c * D + i];
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
+    if (lane == 0) rnorm2[c] = s;
+  }
+  __syncthreads();
+  const int waves_total = gridDim.x * (kCurThreads / 64);
+  for (int n = blockIdx.x * (kCurThreads / 64) + wave; n < N; n += waves_total) {
+    const float* x = emb + static_cast<long>(n) * ld;
+    float xx = 0.f;
+    for (int i = lane; i < D; i += 64) { const float v = x[i]; xx += v * v; }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) xx += __shfl_xor(xx, o);
+    float best = -3.0e38f;
+    int bc = 0;
+    for (int c = 0; c < C; ++c) {
+      float dot = 0.f;
+      for (int i = lane; i < D; i += 64) dot += x[i] * r[c * D + i];
+#pragma unroll
+      for (int o = 32; o > 0; o >>= 1) dot += __shfl_xor(dot, o);
+      const float cs = dot / sqrtf(fmaxf(xx * rnorm2[c], eps * eps));
+      if (scores && lane == 0) scores[static_cast<long>(n) * C + c] = cs;
+      if (cs > best) { best = cs; bc = c; }          // strict: the lowest class position wins ties
+    }
+    if (lane == 0) { best_class[n] = bc; best_score[n] = best; }
+  }
+}
+
+}  // namespace adt
+
+extern "C" int adt_cosine_argmax_f32(const float* emb, int64_t ld, const float* refs, int64_t N, int64_t D, int64_t C, float eps,
+                                     int32_t* best_class, float* best_score, float* scores, void* stream) {
+  using namespace adt;
+  if (!emb || !refs || !best_class || !best_score) return set_error(ADT_EINVAL, "adt_cosine_argmax_f32: null pointer");
+  if (N < 0 || D <= 0 || C <= 0 || ld < D) return set_error(ADT_EINVAL, "adt_cosine_argmax_f32: bad sizes");
+  if (C * D + C > kCurMaxRefFloats) return set_error(ADT_ESHAPE, "adt_cosine_argmax_f32: class vectors exceed the LDS budget (C*D + C <= 36864 floats)");
+  if (N == 0) return ADT_OK;
+  const int lds = static_cast<int>((C * D + C) * sizeof(float));
+  static thread_local int done_for = -1;
+  int dev = 0;
+  ADT_HIP_TRY(hipGetDevice(&dev));
+  if (done_for != dev) {
+    ADT_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(cosine_argmax_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                    kCurMaxRefFloats * 4));
+    done_for = dev;
+  }
+  int n_cu = 0;
+  if (int rc = device_cu_count(&n_cu)) return rc;
+  long blocks = (N + 3) / 4;
+  if (blocks > n_cu) blocks = n_cu;
+  hipLaunchKernelGGL(cosine_argmax_kernel, dim3(static_cast<unsigned>(blocks)), dim3(kCurThreads), lds, static_cast<hipStream_t>(stream),
+                     emb, ld, refs, static_cast<int>(N), static_cast<int>(D), static_cast<int>(C), eps, best_class, best_score, scores);
+  ADT_HIP_TRY(hipGetLastError());
+  return ADT_OK;
+}

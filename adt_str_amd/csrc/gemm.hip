@@ -378,20 +378,24 @@ __global__ __launch_bounds__(kGemmThreads) void gemm_nt_glds_kernel(GemmArgs g, 
       glds_tile(g.A, g.lda, m0, g.M, (kt + 1) * kBK, na, wave, lane);
       glds_tile(g.B, g.ldb, n0, g.N, (kt + 1) * kBK, na + kTileNT, wave, lane);
     }
+    // both 32-deep k-steps' fragments are requested up front, so the second step's LDS reads
+    // are in flight under the first step's MFMAs
+    bf16x8 fa[2][4], fb[2][4];
 #pragma unroll
-    for (int ks = 0; ks < kBK / 32; ++ks) {
-      bf16x8 fa[4], fb[4];
+    for (int ks = 0; ks < 2; ++ks)
 #pragma unroll
       for (int i = 0; i < 4; ++i) {
-        fa[i] = frag_glds(ta, wm * 64 + i * 16, ks, lane);
-        fb[i] = frag_glds(tb, wn * 64 + i * 16, ks, lane);
+        fa[ks][i] = frag_glds(ta, wm * 64 + i * 16, ks, lane);
+        fb[ks][i] = frag_glds(tb, wn * 64 + i * 16, ks, lane);
       }
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
       __builtin_amdgcn_s_setprio(1);
 #pragma unroll
       for (int i = 0; i < 4; ++i)
 #pragma unroll
         for (int j = 0; j < 4; ++j)
-          acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[i], fb[j], acc[i][j], 0, 0, 0);
+          acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[ks][i], fb[ks][j], acc[i][j], 0, 0, 0);
       __builtin_amdgcn_s_setprio(0);
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");

@@ -269,6 +269,19 @@ int adt_grad_norm(const float* g, int64_t n, float max_norm, float* norm_and_cli
 int adt_adamw_step(float* p, const float* g, float* m, float* v, void* p_bf16, int64_t n, float lr, float beta1,
                    float beta2, float eps, float weight_decay, int64_t step, const float* norm_and_clip, void* stream);
 
+/* ---------------------------------------------------------------------------
+ * K12  CLAP curation: cosine similarity to the class means + per-sample best class
+ *
+ * Replaces the similarity loop and the greedy "first occurrence wins" assignment of the
+ * reference's curation driver (data_modules/augment_data_with_CLAP.py:139-151,182-193).
+ *   emb [N, ld] fp32 sample embeddings, refs [C, D] fp32 class-mean embeddings
+ *   cos(n, c) = <x_n, r_c> / sqrt(max(|x_n|^2 |r_c|^2, eps^2))      (F.cosine_similarity, eps 1e-8)
+ *   best_class[n] = lowest c with the maximum cos(n, c); best_score[n] = that maximum
+ *   scores (optional) [N, C] = every cos(n, c)
+ */
+int adt_cosine_argmax_f32(const float* emb, int64_t ld, const float* refs, int64_t N, int64_t D, int64_t C, float eps,
+                          int32_t* best_class, float* best_score, float* scores, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

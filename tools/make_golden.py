@@ -418,6 +418,69 @@ def g6_adt_full(model_mod):
     print("G6 adt full: loss", float(loss), "params", int(out["n_params"]))
 
 
+# --------------------------------------------------------------------------- G8 curation
+def g8_curation():
+    """Runs the reference's own curation lines (augment_data_with_CLAP.py:139-151 similarity + sort,
+    :160-193 binning + greedy copy) on synthetic embeddings.  The script keeps that logic inline under
+    ``__main__``, so the lines are executed from the mounted file with file copying / progress bars faked."""
+    src = open(os.path.join(REF, "data_modules", "augment_data_with_CLAP.py")).read().split("\n")
+    sim_block = "\n".join(l[4:] for l in src[138:151])            # "# Compute cosine similarity" .. scores.sort
+    bin_block = "\n".join(l[4:] for l in src[159:193])            # bin_size .. pbar.close()
+    assert "cosine_similarity" in sim_block and "scores.sort" in sim_block and "score_to_bin_label" in bin_block
+    rng = np.random.default_rng(8)
+    out = {}
+    for case, (n_u, labels, num_bins, dim) in enumerate([(300, list(range(35, 47)), 10, 64), (64, [35, 38, 42, 421], 5, 512),
+                                                          (500, list(range(35, 82)) + [421], 10, 32)]):
+        C = len(labels)
+        protos = rng.standard_normal((C, dim)).astype(np.float32)
+        refs = {k: [] for k in labels}
+        for ci, k in enumerate(labels):
+            for _ in range(3):
+                v = protos[ci] + 0.5 * rng.standard_normal(dim).astype(np.float32)
+                refs[k].append(torch.from_numpy(v / np.linalg.norm(v)))
+        means = torch.stack([torch.mean(torch.stack(refs[k]), dim=0) for k in labels])
+        samp = protos[rng.integers(0, C, n_u)] * rng.uniform(0.2, 1.5, (n_u, 1)).astype(np.float32) + \
+            rng.standard_normal((n_u, dim)).astype(np.float32) * rng.uniform(0.3, 3.0, (n_u, 1)).astype(np.float32)
+        samp = samp / np.linalg.norm(samp, axis=1, keepdims=True)
+        samp[5] = samp[4]                                               # exact duplicate -> tie handling
+        samp_t = torch.from_numpy(samp.astype(np.float32))
+        copies = []
+
+        class _Bar:
+            def __init__(self, *a, **k): pass
+            def update(self, n=1): pass
+            def close(self): pass
+
+        class _Shutil:
+            @staticmethod
+            def copy2(srcp, dst): copies.append((srcp, str(dst)))
+
+        class _P:                                                       # pathlib.Path stand-in without filesystem access
+            def __init__(self, p): self.p = str(p)
+            def __truediv__(self, o): return _P(self.p + "/" + str(o))
+            def mkdir(self, **k): pass
+            @property
+            def name(self): return self.p.split("/")[-1]
+            def __str__(self): return self.p
+
+        ns = dict(torch=torch, tqdm=_Bar, reference_embeddings=means, non_empty_keys=labels, sample_pack_embeddings=samp_t,
+                  wav_files=[f"/packs/s{i:05d}.wav" for i in range(n_u)], num_bins=num_bins, shutil=_Shutil, Path=_P,
+                  augmented_root=_P("/aug"), print=lambda *a, **k: None)
+        exec(compile(sim_block, "ref_sim", "exec"), ns)
+        exec(compile(bin_block, "ref_bin", "exec"), ns)
+        assert len(copies) == n_u
+        out[f"c{case}_labels"] = np.array(labels)
+        out[f"c{case}_num_bins"] = np.int64(num_bins)
+        out[f"c{case}_means"] = means.numpy()
+        out[f"c{case}_samples"] = samp_t.numpy()
+        out[f"c{case}_order"] = np.array([int(c[0][-9:-4]) for c in copies])
+        out[f"c{case}_class"] = np.array([int(c[1].split("/")[2]) for c in copies])
+        out[f"c{case}_bin"] = np.array([c[1].split("/")[3] for c in copies])
+    out["n_cases"] = np.int64(3)
+    np.savez_compressed(os.path.join(OUT, "curation.npz"), **out)
+    print("G8 curation: 3 cases")
+
+
 def main():
     os.makedirs(OUT, exist_ok=True)
     torch.set_num_threads(8)
@@ -433,6 +496,7 @@ def main():
     g4_mixer(h5_store)
     g5_adt_tiny(model_mod)
     g6_adt_full(model_mod)
+    g8_curation()
 
 
 if __name__ == "__main__":
