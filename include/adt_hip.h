@@ -270,6 +270,22 @@ int adt_adamw_step(float* p, const float* g, float* m, float* v, void* p_bf16, i
                    float beta2, float eps, float weight_decay, int64_t step, const float* norm_and_clip, void* stream);
 
 /* ---------------------------------------------------------------------------
+ * K9  CLAP log-mel (dB) feature extractor
+ *
+ * Replaces ClapProcessor(audio=..., sampling_rate=48000) as the reference calls it
+ * (modules/clap_encoder.py:22-23; transformers ClapFeatureExtractor, float64 numpy per clip):
+ * "repeatpad" each clip to target_len samples (tile floor(target/n) times, then zeros),
+ * STFT n_fft 1024 / hop, periodic Hann, center=True reflect, power, banded mel filterbank
+ * (same CSR form as K1: mel_meta [n_mels][4], mel_w), 10*log10(max(mel, amin)).
+ *   waves    concatenated fp32 clips; clip c = waves[offsets[c] .. offsets[c+1]), each 1..target_len samples
+ *   out      [n_clips, n_frames, n_mels] fp32 (the reference stacks this 4x for the fusion model)
+ * Supported: n_fft == 1024, n_mels <= 64 and a multiple of 4.
+ */
+int adt_clap_logmel_db_f32(const float* waves, const int64_t* offsets, int64_t n_clips, int32_t target_len, int32_t n_fft,
+                           int32_t hop, int32_t n_frames, const float* window, const int32_t* mel_meta, const float* mel_w,
+                           int32_t n_mels, int32_t mel_nnz, float amin, float* out, void* stream);
+
+/* ---------------------------------------------------------------------------
  * K12  CLAP curation: cosine similarity to the class means + per-sample best class
  *
  * Replaces the similarity loop and the greedy "first occurrence wins" assignment of the

@@ -1,0 +1,81 @@
+"""K9 CLAP log-mel: device logic on the CPU (host emulation of the kernel's phases) and the kernel on the GPU, both
+against transformers' ClapFeatureExtractor (float64), the code the reference calls (clap_encoder.py:22-23).
+Tolerance: 2e-3 dB (fp32 FFT vs float64) on a dB scale that spans ~100 dB."""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+import pytest
+import torch
+
+from adt_str_amd.clap_frontend import HOP, MAX_SAMPLES, N_FFT, N_FRAMES, N_MELS, htk_mel_filterbank
+from adt_str_amd.frontend import MelBands
+from oracle import clap as o_clap
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+
+
+def make_clips(seed, lengths):
+    rng = np.random.default_rng(seed)
+    clips = []
+    for n in lengths:
+        t = np.arange(n) / 48000.0
+        x = np.exp(-t * rng.uniform(5, 60)) * (0.5 * rng.standard_normal(n) + np.sin(2 * np.pi * rng.uniform(60, 9000) * t))
+        clips.append((x / np.abs(x).max()).astype(np.float32))
+    return clips
+
+
+def check_db(got, ref):
+    """Every value is within 2e-3 dB of the float64 extractor, or -- for frames whose energy sits 100 dB below the
+    clip peak, where fp32 rounding is visible -- within 3e-11 in power (a third of the 1e-10 floor value)."""
+    db_ok = np.abs(got - ref) < 2e-3
+    pw_ok = np.abs(10.0 ** (got / 10.0) - 10.0 ** (ref / 10.0)) < 3e-11
+    assert np.all(db_ok | pw_ok), float(np.abs(got - ref)[~(db_ok | pw_ok)].max())
+    assert db_ok.mean() > 0.995
+
+
+def test_filterbank_matches_hf():
+    fe = o_clap.feature_extractor()
+    assert np.allclose(htk_mel_filterbank(), fe.mel_filters, atol=1e-12)
+    assert (fe.fft_window_size, fe.hop_length, fe.nb_max_samples, fe.feature_size) == (N_FFT, HOP, MAX_SAMPLES, N_MELS)
+    assert MelBands.from_dense(htk_mel_filterbank().astype(np.float32)).weights.size <= 1536
+
+
+@pytest.fixture(scope="module")
+def emu(tmp_path_factory):
+    so = str(tmp_path_factory.mktemp("emu") / "libclap_emu.so")
+    subprocess.check_call(["g++", "-O2", "-shared", "-fPIC", "-o", so, os.path.join(HERE, "emu", "clap_logmel_emu.cpp")])
+    lib = C.CDLL(so)
+    lib.emu_clap_logmel.restype = C.c_int
+    return lib
+
+
+def test_emu_matches_hf_extractor(emu):
+    clips = make_clips(0, [4800, 30011, 777])
+    n_frames = 40                                                 # first frames (incl. the reflected left edge) of each clip
+    ref = o_clap.logmel_db(clips)[:, :n_frames]
+    bands = MelBands.from_dense(htk_mel_filterbank().astype(np.float32))
+    win = (0.5 - 0.5 * np.cos(2.0 * np.pi * np.arange(N_FFT) / N_FFT)).astype(np.float32)
+    flat = np.concatenate(clips)
+    offs = np.zeros(len(clips) + 1, np.int64); offs[1:] = np.cumsum([len(c) for c in clips])
+    out = np.zeros((len(clips), n_frames, N_MELS), np.float32)
+    P = lambda a: a.ctypes.data_as(C.c_void_p)
+    emu.emu_clap_logmel(P(flat), P(offs), C.c_long(len(clips)), C.c_int(MAX_SAMPLES), C.c_int(HOP), C.c_int(n_frames), P(win),
+                        P(bands.meta), P(bands.weights), C.c_int(N_MELS), C.c_float(1e-10), P(out))
+    check_db(out, ref)
+
+
+@pytest.mark.gpu
+def test_gpu_matches_hf_extractor():
+    from adt_str_amd.clap_frontend import ClapLogMel
+    clips = make_clips(1, [4800, 96000, 31337, 480000, 1000, 239999])
+    fe = ClapLogMel("cuda:0")
+    feats, is_longer = fe([torch.from_numpy(c) for c in clips])
+    assert feats.shape == (6, 4, N_FRAMES, N_MELS) and is_longer.shape == (6, 1) and not is_longer.any()
+    ref = o_clap.logmel_db(clips)
+    got = feats[:, 0].cpu().numpy()
+    check_db(got, ref)
+    assert torch.equal(feats[:, 1], feats[:, 0])
+    with pytest.raises(NotImplementedError):
+        fe([torch.zeros(480001)])
