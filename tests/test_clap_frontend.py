@@ -27,10 +27,19 @@ def make_clips(seed, lengths):
 
 
 def check_db(got, ref):
-    """Every value is within 2e-3 dB of the float64 extractor, or -- for frames whose energy sits 100 dB below the
-    clip peak, where fp32 rounding is visible -- within 3e-11 in power (a third of the 1e-10 floor value)."""
+    """Every value is within 2e-3 dB of the float64 extractor, or within an absolute power error of
+    max(3e-11, 1e-13 * P) where P is the largest mel power of the two frames that share one packed FFT: the kernel
+    transforms frames 2p and 2p+1 as one complex signal, so in fp32 a silent frame next to a loud onset (110 dB apart
+    in a repeat-padded one-shot) inherits rounding noise ~140 dB below the loud frame."""
+    pw_got, pw_ref = 10.0 ** (got / 10.0), 10.0 ** (ref / 10.0)
+    frames = ref.shape[1]
+    pair_peak = np.zeros_like(ref)
+    peak = pw_ref.max(axis=2)
+    for f in range(frames):
+        mate = f + 1 if f % 2 == 0 else f - 1
+        pair_peak[:, f, :] = np.maximum(peak[:, f], peak[:, min(mate, frames - 1)])[:, None]
     db_ok = np.abs(got - ref) < 2e-3
-    pw_ok = np.abs(10.0 ** (got / 10.0) - 10.0 ** (ref / 10.0)) < 3e-11
+    pw_ok = np.abs(pw_got - pw_ref) < np.maximum(3e-11, 1e-13 * pair_peak)
     assert np.all(db_ok | pw_ok), float(np.abs(got - ref)[~(db_ok | pw_ok)].max())
     assert db_ok.mean() > 0.995
 
