@@ -1,0 +1,161 @@
+"""CLAP audio tower on the gfx950 kernels: drop-in for the reference's ``ClapWrapper`` audio path
+(``modules/clap_encoder.py:8-54``): ``get_audio_features(list of [1, L] clips @ 48 kHz) -> [B, 512]`` unit vectors.
+
+The reference delegates to ``transformers``: ``ClapProcessor`` (float64 numpy features on the host),
+``ClapModel.audio_model`` (HTSAT = Swin transformer over a 256 x 256 folded mel image) and
+``ClapModel.audio_projection``.  Here the features come from ``adt_clap_logmel_db_f32`` (K9) and the encoder runs on
+``adt_htsat_*`` / ``adt_window_attn_fwd`` / ``adt_patch_merge_ln`` (K10, K11), ``adt_gemm_bf16`` and
+``adt_layernorm_fwd``, with bf16 GEMM/attention operands and fp32 accumulation / residual stream.  Weights are taken
+from a ``transformers.ClapModel`` state dict (same keys), so a pretrained ``laion/clap-htsat-fused`` checkpoint loads
+unchanged.  The text tower is not part of the hot path (never called by the curation pipeline).
+"""
+from __future__ import annotations
+
+import math
+from typing import Dict, List, Optional, Sequence
+
+import numpy as np
+import torch
+from torch import nn
+
+from . import _ffi
+from . import kernels as K
+from .clap_frontend import N_FRAMES, N_MELS, ClapLogMel
+
+F32, BF16 = torch.float32, torch.bfloat16
+WINDOW = 8
+
+
+def _shift_mask(R: int, shift: int) -> torch.Tensor:
+    """[nW, 64, 64] additive 0 / -100 mask of a shifted-window layer (ClapAudioLayer.get_attn_mask)."""
+    idx = torch.arange(R)
+    region = (idx >= R - WINDOW).long() + (idx >= R - shift).long()
+    img = region[:, None] * 3 + region[None, :]                                   # [R, R]
+    win = img.view(R // WINDOW, WINDOW, R // WINDOW, WINDOW).permute(0, 2, 1, 3).reshape(-1, WINDOW * WINDOW).float()
+    diff = win.unsqueeze(1) - win.unsqueeze(2)
+    return torch.where(diff != 0, torch.full_like(diff, -100.0), torch.zeros_like(diff))
+
+
+class HtsatEncoder:
+    """Forward-only HTSAT + projection head.  ``sd``: state dict of a ``transformers.ClapModel``."""
+
+    def __init__(self, sd: Dict[str, torch.Tensor], audio_config, device="cuda"):
+        self.dev = torch.device(device)
+        c = audio_config
+        if c.window_size != WINDOW or c.patch_size != 4 or tuple(np.atleast_1d(c.patch_stride).tolist()) not in ((4,), (4, 4)):
+            raise NotImplementedError("HTSAT kernels are built for window 8 and 4x4/stride-4 patches")
+        self.depths, self.heads = list(c.depths), list(c.num_attention_heads)
+        self.C0, self.spec, self.n_mels, self.eps = c.patch_embeds_hidden_size, c.spec_size, c.num_mel_bins, c.layer_norm_eps
+        if any(self.C0 * 2 ** s != self.heads[s] * 24 for s in range(len(self.depths))):
+            raise NotImplementedError("window attention kernel is built for head_dim 24")
+        self.enable_fusion = bool(c.enable_fusion)
+        p = "audio_model.audio_encoder."
+        g = lambda k: sd[k].detach().to(self.dev, F32).contiguous()
+        bn_scale = g(p + "batch_norm.weight") / torch.sqrt(g(p + "batch_norm.running_var") + 1e-5)
+        self.bn_scale, self.bn_shift = bn_scale.contiguous(), (g(p + "batch_norm.bias") - g(p + "batch_norm.running_mean") * bn_scale).contiguous()
+        self.pe_w = g(p + "patch_embed.proj.weight").reshape(self.C0, 16).contiguous()
+        self.pe_b, self.pe_g, self.pe_beta = g(p + "patch_embed.proj.bias"), g(p + "patch_embed.norm.weight"), g(p + "patch_embed.norm.bias")
+        b16 = lambda t: t.to(BF16).contiguous()
+        self.stages = []
+        R = self.spec // 4
+        for s, depth in enumerate(self.depths):
+            C, nh = self.C0 * 2 ** s, self.heads[s]
+            layers = []
+            for i in range(depth):
+                q = f"{p}layers.{s}.blocks.{i}."
+                a = q + "attention.self."
+                table, index = g(a + "relative_position_bias_table"), sd[a + "relative_position_index"].to(self.dev).long()
+                bias = table[index.view(-1)].view(64, 64, nh).permute(2, 0, 1).contiguous()             # [nh, 64, 64]
+                shift = 0 if (i % 2 == 0 or R <= WINDOW) else WINDOW // 2
+                if shift:
+                    bias = (bias.unsqueeze(0) + _shift_mask(R, shift).to(self.dev).unsqueeze(1)).contiguous()   # [nW, nh, 64, 64]
+                layers.append(dict(
+                    shift=shift, bias=bias, n_bias=bias.shape[0] if shift else 1,
+                    ln1=(g(q + "layernorm_before.weight"), g(q + "layernorm_before.bias")),
+                    wqkv=b16(torch.cat([g(a + "query.weight"), g(a + "key.weight"), g(a + "value.weight")], 0)),
+                    bqkv=torch.cat([g(a + "query.bias"), g(a + "key.bias"), g(a + "value.bias")], 0).contiguous(),
+                    wo=b16(g(q + "attention.output.dense.weight")), bo=g(q + "attention.output.dense.bias"),
+                    ln2=(g(q + "layernorm_after.weight"), g(q + "layernorm_after.bias")),
+                    w1=b16(g(q + "intermediate.dense.weight")), b1=g(q + "intermediate.dense.bias"),
+                    w2=b16(g(q + "output.dense.weight")), b2=g(q + "output.dense.bias")))
+            merge = None
+            if s < len(self.depths) - 1:
+                d = f"{p}layers.{s}.downsample."
+                merge = dict(norm=(g(d + "norm.weight"), g(d + "norm.bias")), w=b16(g(d + "reduction.weight")))
+            self.stages.append(dict(C=C, nh=nh, R=R, layers=layers, merge=merge))
+            R //= 2
+        self.final_ln = (g(p + "norm.weight"), g(p + "norm.bias"))
+        self.proj = (b16(g("audio_projection.linear1.weight")), g("audio_projection.linear1.bias"),
+                     b16(g("audio_projection.linear2.weight")), g("audio_projection.linear2.bias"))
+
+    @torch.no_grad()
+    def forward(self, mel: torch.Tensor, is_longer: Optional[torch.Tensor] = None) -> Dict[str, torch.Tensor]:
+        """mel [B, 1001, 64] fp32 (fusion channel 0) -> {"pooled": [B, 768], "embedding": [B, 512]} fp32."""
+        if is_longer is not None and bool(torch.as_tensor(is_longer).any()):
+            raise NotImplementedError("is_longer items take the AFF fusion branch of the patch embedding, which is not built yet; "
+                                      "pass is_longer=None / all False (clips of at most 10 s carry four identical mel channels)")
+        mel = mel.to(self.dev, F32).contiguous()
+        B, T, M = mel.shape
+        st = _ffi.current_stream()
+        side = self.spec
+        img = torch.empty((B, side, side), dtype=F32, device=self.dev)
+        _ffi.call("adt_htsat_front_f32", _ffi.dptr(mel), T * M, B, T, M, side * (side // M), side, _ffi.dptr(self.bn_scale),
+                  _ffi.dptr(self.bn_shift), _ffi.dptr(img), st)
+        x = torch.empty((B * (side // 4) ** 2, self.C0), dtype=F32, device=self.dev)
+        _ffi.call("adt_htsat_patch_embed", _ffi.dptr(img), B, side, _ffi.dptr(self.pe_w), _ffi.dptr(self.pe_b), _ffi.dptr(self.pe_g),
+                  _ffi.dptr(self.pe_beta), self.eps, self.C0, _ffi.dptr(x), None, st)
+        for S in self.stages:
+            C, nh, R = S["C"], S["nh"], S["R"]
+            for L in S["layers"]:
+                _, xn, _, _ = K.layernorm_fwd(x, *L["ln1"], eps=self.eps, want32=False)
+                qkv = K.gemm(xn, L["wqkv"], bias=L["bqkv"])
+                ctx = torch.empty((x.shape[0], C), dtype=BF16, device=self.dev)
+                _ffi.call("adt_window_attn_fwd", _ffi.dptr(qkv), qkv.stride(0), _ffi.dptr(ctx), C, _ffi.dptr(L["bias"]), L["n_bias"], B, R, C,
+                          nh, L["shift"], 1.0 / math.sqrt(24.0), st)
+                K.gemm(ctx, L["wo"], bias=L["bo"], residual=x, out=x)
+                _, xn, _, _ = K.layernorm_fwd(x, *L["ln2"], eps=self.eps, want32=False)
+                h = K.gemm(xn, L["w1"], bias=L["b1"], act=1)
+                K.gemm(h, L["w2"], bias=L["b2"], residual=x, out=x)
+            if S["merge"] is not None:
+                m16 = torch.empty((x.shape[0] // 4, 4 * C), dtype=BF16, device=self.dev)
+                _ffi.call("adt_patch_merge_ln", _ffi.dptr(x), B, R, C, _ffi.dptr(S["merge"]["norm"][0]), _ffi.dptr(S["merge"]["norm"][1]),
+                          1e-5, _ffi.dptr(m16), st)
+                x = K.gemm(m16, S["merge"]["w"], out_dtype=F32)
+        xf, _, _, _ = K.layernorm_fwd(x, *self.final_ln, eps=1e-5, want16=False)
+        Cf, Tf = xf.shape[1], xf.shape[0] // B
+        pooled = torch.empty((B, Cf), dtype=F32, device=self.dev)
+        pooled16 = torch.empty((B, Cf), dtype=BF16, device=self.dev)
+        _ffi.call("adt_mean_tokens", _ffi.dptr(xf), B, Tf, Cf, _ffi.dptr(pooled), _ffi.dptr(pooled16), st)
+        w1, b1, w2, b2 = self.proj
+        p1 = K.gemm(pooled16, w1, bias=b1, act=2)
+        p2 = K.gemm(p1, w2, bias=b2, out_dtype=F32)
+        emb = torch.empty_like(p2)
+        _ffi.call("adt_l2_normalize", _ffi.dptr(p2), B, p2.shape[1], _ffi.dptr(emb), st)
+        return {"pooled": pooled, "embedding": emb}
+
+
+class ClapWrapper(nn.Module):
+    """``ClapWrapper(model_name, device, sample_rate)`` of the reference (clap_encoder.py:9-19), audio path only.
+
+    ``clap_model``: an already constructed ``transformers.ClapModel`` (offline / random weights); otherwise
+    ``ClapModel.from_pretrained(model_name)`` is used exactly like the reference does."""
+
+    def __init__(self, model_name: str, device, sample_rate: int, clap_model=None, **kwargs):
+        super().__init__()
+        if clap_model is None:
+            from transformers import ClapModel
+            clap_model = ClapModel.from_pretrained(model_name)
+        if sample_rate != 48000:
+            raise ValueError("the CLAP audio tower runs at 48 kHz (ClapFeatureExtractor.sampling_rate)")
+        self.device, self.sample_rate, self.config = torch.device(device), sample_rate, clap_model.config
+        self.encoder = HtsatEncoder(clap_model.state_dict(), clap_model.config.audio_config, self.device)
+        self.features = ClapLogMel(self.device)
+
+    @torch.no_grad()
+    def get_audio_features(self, audios: Sequence[torch.Tensor]) -> torch.Tensor:
+        """list of [1, L] (or [L]) 48 kHz clips -> [B, 512] L2-normalised embeddings (clap_encoder.py:21-24, 30-54)."""
+        mel = self.features.mel([a.reshape(-1) for a in audios])
+        return self.encoder.forward(mel)["embedding"]
+
+    def get_text_features(self, text):
+        raise NotImplementedError("the text tower is outside the MI355X hot path (the curation pipeline never calls it)")

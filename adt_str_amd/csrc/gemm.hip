@@ -138,6 +138,7 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& g, f32x4 (&acc)[4]
         if (ep.pre_act_out)
           reinterpret_cast<unsigned short*>(ep.pre_act_out)[static_cast<long>(row) * ep.ld_pre_act + col] = f2bf(z);
         if (ep.act == 1) z = gelu_erf(ep.pre_act_out ? bf2f(f2bf(z)) : z);
+        else if (ep.act == 2) z = fmaxf(z, 0.0f);
         const float keep = kDrop ? g.drop.scale(static_cast<uint64_t>(row) * g.N + col) : 1.0f;
         if (kDrop && !ep.drop_after_residual) z *= keep;
         if (ep.residual) {
@@ -277,6 +278,9 @@ __device__ __forceinline__ void gemm_epilogue_rows(const GemmArgs& g, f32x4 (&ac
     if (ep.act == 1) {
 #pragma unroll
       for (int e = 0; e < 8; ++e) z[e] = gelu_erf(z[e]);
+    } else if (ep.act == 2) {
+#pragma unroll
+      for (int e = 0; e < 8; ++e) z[e] = fmaxf(z[e], 0.0f);
     }
     float keep[8] = {1.f, 1.f, 1.f, 1.f, 1.f, 1.f, 1.f, 1.f};
     if (kDrop) {

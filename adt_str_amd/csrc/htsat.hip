@@ -1,0 +1,393 @@
+// htsat.hip -- K10/K11: the Swin-specific kernels of the CLAP HTSAT audio encoder, forward only (gfx950).
+//
+// Stands behind ClapAudioEncoder.forward as the reference reaches it through ClapWrapper._get_audio_features
+// (modules/clap_encoder.py:45-49 -> transformers modeling_clap.py ClapAudioEncoder / ClapAudioLayer /
+// ClapAudioSelfAttention / ClapAudioPatchMerging).  The dense layers of the encoder run on adt_gemm_bf16 and
+// adt_layernorm_fwd; this file holds what is specific to the audio Swin:
+//
+//   htsat_front_kernel        BatchNorm2d over the 64 mel bins (eval), bicubic time resize 1001 -> 1024
+//                             (align_corners, A = -0.75) and the freq-stacking fold to a 256 x 256 image
+//   htsat_patch_embed_kernel  4x4 / stride-4 patch embedding conv (1 -> 96 channels) + LayerNorm
+//   window_attn_kernel        8x8-window multi-head attention, head_dim 24, with the learned relative position
+//                             bias and the shifted-window mask; window partition, cyclic shift and their inverses
+//                             are index arithmetic (tokens are read from / written to their image rows directly)
+//   patch_merge_ln_kernel     2x2 neighbourhood gather (Swin patch merging order) + LayerNorm(4C)
+//   mean_tokens_kernel        mean over the tokens of a clip (the grouped avg-pool head reduces to it)
+//   l2_normalize_kernel       rows / ||row||_2
+//
+// Window attention uses v_mfma_f32_32x32x16_bf16 with the query on the lane (S^T = K Q^T, d padded 24 -> 32 with
+// zero operands), so the softmax is in-register and the probabilities are directly the B operand of
+// O^T += V^T P^T; V^T fragments come from a 4 KiB LDS tile through ds_read_b64_tr_b16.  One wave per (window, head).
+#include <hip/hip_runtime.h>
+
+#include "adt_common.h"
+
+namespace adt {
+
+typedef __attribute__((ext_vector_type(8))) short bf16x8;
+typedef __attribute__((ext_vector_type(4))) short bf16x4;
+typedef __attribute__((ext_vector_type(16))) float f32x16;
+
+__device__ __forceinline__ unsigned short f2bf_h(float f) { return __builtin_bit_cast(unsigned short, static_cast<__bf16>(f)); }
+__device__ __forceinline__ unsigned pack2_h(float lo, float hi) { return f2bf_h(lo) | (static_cast<unsigned>(f2bf_h(hi)) << 16); }
+__device__ __forceinline__ int acc_row_h(int i, int h) { return (i & 3) + 8 * (i >> 2) + 4 * h; }
+__device__ __forceinline__ float wsum(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+  return v;
+}
+
+// ------------------------------------------------------------------------------------ front: BN + bicubic + fold
+// img[b][F = r*n_mels + f][t'] = resize(bn(x))[t = r*(W) + t'][f],  r = 0..(H/n_mels - 1),  W = out_t / (H/n_mels)
+__device__ __forceinline__ float cubic1(float x, float A) { return ((A + 2.f) * x - (A + 3.f)) * x * x + 1.f; }
+__device__ __forceinline__ float cubic2(float x, float A) { return ((A * x - 5.f * A) * x + 8.f * A) * x - 4.f * A; }
+
+__global__ __launch_bounds__(256) void htsat_front_kernel(const float* __restrict__ mel, long ld_clip, int in_t, int n_mels, int out_t, int img,
+                                                          const float* __restrict__ bn_scale, const float* __restrict__ bn_shift,
+                                                          float* __restrict__ out, long total) {
+  const long idx = static_cast<long>(blockIdx.x) * 256 + threadIdx.x;     // over b * img * img, fastest = f (coalesced reads)
+  if (idx >= total) return;
+  const int f = static_cast<int>(idx % n_mels);
+  const long rest = idx / n_mels;
+  const int t = static_cast<int>(rest % out_t);
+  const long b = rest / out_t;
+  const float scale = static_cast<float>(in_t - 1) / static_cast<float>(out_t - 1);
+  const float real = scale * t;
+  const int ix = static_cast<int>(floorf(real));
+  const float tt = real - ix;
+  const float A = -0.75f;
+  const float w[4] = {cubic2(tt + 1.f, A), cubic1(tt, A), cubic1(1.f - tt, A), cubic2(2.f - tt, A)};
+  const float* src = mel + b * ld_clip;
+  const float sc = bn_scale[f], sh = bn_shift[f];
+  float v = 0.f;
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    int j = ix - 1 + k;
+    j = j < 0 ? 0 : (j > in_t - 1 ? in_t - 1 : j);
+    v += w[k] * (src[static_cast<long>(j) * n_mels + f] * sc + sh);
+  }
+  const int W = img;                         // time columns per folded row-block
+  const int r = t / W, tp = t - r * W;
+  out[(b * img + (r * n_mels + f)) * img + tp] = v;
+}
+
+// ------------------------------------------------------------------------------------ patch embedding + LayerNorm
+// token (i, j) of clip b: y[o] = bias[o] + sum_{di,dj} W[o][di*4+dj] * img[b][4i+di][4j+dj], then LayerNorm over o.
+// One wave per token; lane o and o+64 hold the channels (C <= 128).
+__global__ __launch_bounds__(256) void htsat_patch_embed_kernel(const float* __restrict__ img, int side, const float* __restrict__ w,
+                                                                const float* __restrict__ bias, const float* __restrict__ gamma,
+                                                                const float* __restrict__ beta, float eps, int C, float* __restrict__ out32,
+                                                                unsigned short* __restrict__ out16, long n_tokens) {
+  const int lane = threadIdx.x & 63;
+  const long tok = static_cast<long>(blockIdx.x) * 4 + (threadIdx.x >> 6);
+  if (tok >= n_tokens) return;
+  const int grid = side / 4;
+  const int j = static_cast<int>(tok % grid);
+  const int i = static_cast<int>((tok / grid) % grid);
+  const long b = tok / (static_cast<long>(grid) * grid);
+  float px[16];
+#pragma unroll
+  for (int di = 0; di < 4; ++di)
+#pragma unroll
+    for (int dj = 0; dj < 4; ++dj) px[di * 4 + dj] = img[(b * side + 4 * i + di) * side + 4 * j + dj];
+  float y[2] = {0.f, 0.f};
+  float s = 0.f;
+#pragma unroll
+  for (int k = 0; k < 2; ++k) {
+    const int o = lane + 64 * k;
+    if (o < C) {
+      float a = bias[o];
+#pragma unroll
+      for (int e = 0; e < 16; ++e) a += w[o * 16 + e] * px[e];
+      y[k] = a;
+      s += a;
+    }
+  }
+  const float mean = wsum(s) / C;
+  float ss = 0.f;
+#pragma unroll
+  for (int k = 0; k < 2; ++k)
+    if (lane + 64 * k < C) ss += (y[k] - mean) * (y[k] - mean);
+  const float rstd = rsqrtf(wsum(ss) / C + eps);
+#pragma unroll
+  for (int k = 0; k < 2; ++k) {
+    const int o = lane + 64 * k;
+    if (o < C) {
+      const float v = (y[k] - mean) * rstd * gamma[o] + beta[o];
+      if (out32) out32[tok * C + o] = v;
+      if (out16) out16[tok * C + o] = f2bf_h(v);
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------ window attention (head_dim 24)
+struct WinAttnArgs {
+  const unsigned short* qkv; long ld;          // [B*R*R, 3C] bf16: q | k | v, head h at columns h*24
+  unsigned short* ctx; long ldc;               // [B*R*R, C]
+  const float* bias; int n_bias_windows;       // [n_bias_windows][heads][64][64]: rel-pos bias (+ shift mask per window)
+  int B, R, C, heads, shift; float scale;
+};
+
+__device__ __forceinline__ long token_row(const WinAttnArgs& a, int b, int wy, int wx, int t) {
+  const int y = (wy * 8 + (t >> 3) + a.shift) % a.R, x = (wx * 8 + (t & 7) + a.shift) % a.R;
+  return (static_cast<long>(b) * a.R + y) * a.R + x;
+}
+// 8 bf16 of a head slice at d = 8*c .. 8*c+7 (c = 0..3; c == 3 is the zero padding 24..31)
+__device__ __forceinline__ bf16x8 head_chunk(const unsigned short* p, int c) {
+  uint4 v = make_uint4(0, 0, 0, 0);
+  if (c < 3) v = *reinterpret_cast<const uint4*>(p + 8 * c);
+  return *reinterpret_cast<bf16x8*>(&v);
+}
+
+__global__ __launch_bounds__(256) void window_attn_kernel(WinAttnArgs a) {
+  __shared__ __attribute__((aligned(16))) unsigned char vt_all[4][64 * 64];      // per wave: V tile [64 keys][32 d] bf16
+  const int lane = threadIdx.x & 63, r = lane & 31, h = lane >> 5;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const long item = static_cast<long>(blockIdx.x) * 4 + wave;                     // (b, wy, wx, head)
+  const int nw = a.R / 8;
+  const long total = static_cast<long>(a.B) * nw * nw * a.heads;
+  if (item >= total) return;
+  const int head = static_cast<int>(item % a.heads);
+  long rest = item / a.heads;
+  const int wx = static_cast<int>(rest % nw); rest /= nw;
+  const int wy = static_cast<int>(rest % nw);
+  const int b = static_cast<int>(rest / nw);
+  unsigned char* vt = vt_all[wave];
+
+  // operands: token t0 = r (tile 0) and t1 = r + 32 (tile 1) of the window
+  const long row0 = token_row(a, b, wy, wx, r), row1 = token_row(a, b, wy, wx, r + 32);
+  const unsigned short* q0 = a.qkv + row0 * a.ld + head * 24;
+  const unsigned short* q1 = a.qkv + row1 * a.ld + head * 24;
+  bf16x8 kf[2][2], qf[2][2];
+#pragma unroll
+  for (int s = 0; s < 2; ++s) {                       // k-step s covers d = 16s .. 16s+15; this lane holds 8h..8h+7 of it
+    qf[0][s] = head_chunk(q0, 2 * s + h);           qf[1][s] = head_chunk(q1, 2 * s + h);
+    kf[0][s] = head_chunk(q0 + a.C, 2 * s + h);     kf[1][s] = head_chunk(q1 + a.C, 2 * s + h);
+  }
+  // V tile: keys r and r+32, 32 d each (d >= 24 zero); lane half h writes chunks 2h, 2h+1 of both rows
+#pragma unroll
+  for (int c = 0; c < 2; ++c) {
+    const int ch = 2 * h + c;
+    const bf16x8 v0 = head_chunk(q0 + 2 * a.C, ch), v1 = head_chunk(q1 + 2 * a.C, ch);
+    *reinterpret_cast<bf16x8*>(vt + r * 64 + ch * 16) = v0;
+    *reinterpret_cast<bf16x8*>(vt + (r + 32) * 64 + ch * 16) = v1;
+  }
+  f32x16 st[2][2];                                   // st[kt][qt] = S^T tile: rows keys, lane = query
+#pragma unroll
+  for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+    for (int qt = 0; qt < 2; ++qt) {
+#pragma unroll
+      for (int i = 0; i < 16; ++i) st[kt][qt][i] = 0.f;
+#pragma unroll
+      for (int s = 0; s < 2; ++s) st[kt][qt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf[kt][s], qf[qt][s], st[kt][qt], 0, 0, 0);
+    }
+  const int wsel = a.n_bias_windows > 1 ? (wy * nw + wx) : 0;
+  const float* bias = a.bias + (static_cast<long>(wsel) * a.heads + head) * 4096;
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+  f32x16 o[2];
+#pragma unroll
+  for (int qt = 0; qt < 2; ++qt) {
+    const int q = qt * 32 + r;
+    float mx = -3.0e38f;
+#pragma unroll
+    for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        const float4 bv = *reinterpret_cast<const float4*>(bias + q * 64 + kt * 32 + 8 * g + 4 * h);
+        const float bb[4] = {bv.x, bv.y, bv.z, bv.w};
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const float v = st[kt][qt][4 * g + e] * a.scale + bb[e];
+          st[kt][qt][4 * g + e] = v;
+          mx = fmaxf(mx, v);
+        }
+      }
+    mx = fmaxf(mx, __shfl_xor(mx, 32));
+    float sum = 0.f;
+#pragma unroll
+    for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+      for (int i = 0; i < 16; ++i) { const float p = __expf(st[kt][qt][i] - mx); st[kt][qt][i] = p; sum += p; }
+    sum += __shfl_xor(sum, 32);
+    const float inv = 1.0f / sum;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) o[qt][i] = 0.f;
+#pragma unroll
+    for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+      for (int s2 = 0; s2 < 2; ++s2) {
+        // A = V^T: A[row d = lane&31][element j] = V[key = kt*32 + 16*s2 + 8*(j>>2) + 4h + (j&3)][d]
+        const int i16 = lane & 15, g4 = (lane >> 4) & 1;
+        const int krow = kt * 32 + 16 * s2 + 4 * h + (i16 >> 2);
+        const unsigned base = static_cast<unsigned>(reinterpret_cast<size_t>((__attribute__((address_space(3))) const void*)vt)) +
+                              krow * 64 + (16 * g4 + 4 * (i16 & 3)) * 2;
+        bf16x4 lo, hi;
+        asm volatile("ds_read_b64_tr_b16 %0, %2\n\tds_read_b64_tr_b16 %1, %2 offset:512\n\ts_waitcnt lgkmcnt(0)"
+                     : "=&v"(lo), "=&v"(hi) : "v"(base) : "memory");
+        bf16x8 af;
+        af[0] = lo[0]; af[1] = lo[1]; af[2] = lo[2]; af[3] = lo[3]; af[4] = hi[0]; af[5] = hi[1]; af[6] = hi[2]; af[7] = hi[3];
+        union { unsigned u[4]; bf16x8 v; } pf;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) pf.u[e] = pack2_h(st[kt][qt][8 * s2 + 2 * e] * inv, st[kt][qt][8 * s2 + 2 * e + 1] * inv);
+        o[qt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af, pf.v, o[qt], 0, 0, 0);
+      }
+    // O^T[d][query]: this lane owns d = 8g + 4h + (0..3); d >= 24 is padding
+    unsigned short* dst = a.ctx + (qt == 0 ? row0 : row1) * a.ldc + head * 24;
+#pragma unroll
+    for (int g = 0; g < 3; ++g) {
+      uint2 v;
+      v.x = pack2_h(o[qt][4 * g + 0], o[qt][4 * g + 1]);
+      v.y = pack2_h(o[qt][4 * g + 2], o[qt][4 * g + 3]);
+      *reinterpret_cast<uint2*>(dst + 8 * g + 4 * h) = v;
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------ patch merging gather + LayerNorm(4C)
+// out token (b, i, j) = LN(concat[x(2i,2j), x(2i+1,2j), x(2i,2j+1), x(2i+1,2j+1)])   (ClapAudioPatchMerging order)
+__global__ __launch_bounds__(256) void patch_merge_ln_kernel(const float* __restrict__ x, int R, int C, const float* __restrict__ gamma,
+                                                             const float* __restrict__ beta, float eps, unsigned short* __restrict__ out,
+                                                             long n_out) {
+  const int lane = threadIdx.x & 63;
+  const long tok = static_cast<long>(blockIdx.x) * 4 + (threadIdx.x >> 6);
+  if (tok >= n_out) return;
+  const int Ro = R / 2;
+  const int j = static_cast<int>(tok % Ro), i = static_cast<int>((tok / Ro) % Ro);
+  const long b = tok / (static_cast<long>(Ro) * Ro);
+  const int D = 4 * C, nq = D / 4;
+  float4 v[6];
+  float s = 0.f;
+#pragma unroll
+  for (int k = 0; k < 6; ++k) {
+    const int q = lane + 64 * k;
+    v[k] = make_float4(0, 0, 0, 0);
+    if (q < nq) {
+      const int e = 4 * q, part = e / C, c = e - part * C;              // part: 0 (r0,c0) 1 (r1,c0) 2 (r0,c1) 3 (r1,c1)
+      const int yy = 2 * i + (part & 1), xx = 2 * j + (part >> 1);
+      v[k] = *reinterpret_cast<const float4*>(x + ((b * R + yy) * R + xx) * C + c);
+      s += (v[k].x + v[k].y) + (v[k].z + v[k].w);
+    }
+  }
+  const float mean = wsum(s) / D;
+  float ss = 0.f;
+#pragma unroll
+  for (int k = 0; k < 6; ++k)
+    if (lane + 64 * k < nq) {
+      const float d0 = v[k].x - mean, d1 = v[k].y - mean, d2 = v[k].z - mean, d3 = v[k].w - mean;
+      ss += (d0 * d0 + d1 * d1) + (d2 * d2 + d3 * d3);
+    }
+  const float rstd = rsqrtf(wsum(ss) / D + eps);
+#pragma unroll
+  for (int k = 0; k < 6; ++k) {
+    const int q = lane + 64 * k;
+    if (q >= nq) continue;
+    const float4 g = reinterpret_cast<const float4*>(gamma)[q], bt = reinterpret_cast<const float4*>(beta)[q];
+    uint2 o;
+    o.x = pack2_h((v[k].x - mean) * rstd * g.x + bt.x, (v[k].y - mean) * rstd * g.y + bt.y);
+    o.y = pack2_h((v[k].z - mean) * rstd * g.z + bt.z, (v[k].w - mean) * rstd * g.w + bt.w);
+    reinterpret_cast<uint2*>(out + tok * D)[q] = o;
+  }
+}
+
+// ------------------------------------------------------------------------------------ mean over tokens, L2 normalise
+__global__ __launch_bounds__(256) void mean_tokens_kernel(const float* __restrict__ x, int T, int C, float* __restrict__ out32,
+                                                          unsigned short* __restrict__ out16) {
+  const int b = blockIdx.x;
+  for (int c = threadIdx.x; c < C; c += 256) {
+    float s = 0.f;
+    for (int t = 0; t < T; ++t) s += x[(static_cast<long>(b) * T + t) * C + c];
+    s /= T;
+    if (out32) out32[static_cast<long>(b) * C + c] = s;
+    if (out16) out16[static_cast<long>(b) * C + c] = f2bf_h(s);
+  }
+}
+__global__ __launch_bounds__(256) void l2_normalize_kernel(const float* __restrict__ x, int D, float* __restrict__ out, long n_rows) {
+  const int lane = threadIdx.x & 63;
+  const long row = static_cast<long>(blockIdx.x) * 4 + (threadIdx.x >> 6);
+  if (row >= n_rows) return;
+  float s = 0.f;
+  for (int c = lane; c < D; c += 64) { const float v = x[row * D + c]; s += v * v; }
+  const float inv = 1.0f / sqrtf(wsum(s));
+  for (int c = lane; c < D; c += 64) out[row * D + c] = x[row * D + c] * inv;
+}
+
+}  // namespace adt
+
+using namespace adt;
+#define STR(s) static_cast<hipStream_t>(s)
+
+extern "C" int adt_htsat_front_f32(const float* mel, int64_t ld_clip, int64_t B, int32_t in_frames, int32_t n_mels, int32_t out_frames,
+                                   int32_t img_side, const float* bn_scale, const float* bn_shift, float* img, void* stream) {
+  if (!mel || !bn_scale || !bn_shift || !img) return set_error(ADT_EINVAL, "adt_htsat_front_f32: null pointer");
+  if (B < 0 || in_frames < 2 || n_mels <= 0 || out_frames < 2 || img_side <= 0 || img_side % n_mels || out_frames != img_side * (img_side / n_mels))
+    return set_error(ADT_ESHAPE, "adt_htsat_front_f32: need img_side % n_mels == 0 and out_frames == img_side * img_side / n_mels");
+  const long total = B * static_cast<long>(out_frames) * n_mels;
+  if (total == 0) return ADT_OK;
+  hipLaunchKernelGGL(htsat_front_kernel, dim3(static_cast<unsigned>((total + 255) / 256)), dim3(256), 0, STR(stream), mel, ld_clip, in_frames,
+                     n_mels, out_frames, img_side, bn_scale, bn_shift, img, total);
+  ADT_HIP_TRY(hipGetLastError());
+  return ADT_OK;
+}
+
+extern "C" int adt_htsat_patch_embed(const float* img, int64_t B, int32_t img_side, const float* w, const float* bias, const float* gamma,
+                                     const float* beta, float eps, int32_t C, float* out32, void* out16, void* stream) {
+  if (!img || !w || !bias || !gamma || !beta || (!out32 && !out16)) return set_error(ADT_EINVAL, "adt_htsat_patch_embed: null pointer");
+  if (B < 0 || img_side <= 0 || (img_side & 3) || C <= 0 || C > 128) return set_error(ADT_ESHAPE, "adt_htsat_patch_embed: img_side % 4 == 0, C <= 128");
+  const long n = B * static_cast<long>(img_side / 4) * (img_side / 4);
+  if (n == 0) return ADT_OK;
+  hipLaunchKernelGGL(htsat_patch_embed_kernel, dim3(static_cast<unsigned>((n + 3) / 4)), dim3(256), 0, STR(stream), img, img_side, w, bias, gamma,
+                     beta, eps, C, out32, static_cast<unsigned short*>(out16), n);
+  ADT_HIP_TRY(hipGetLastError());
+  return ADT_OK;
+}
+
+extern "C" int adt_window_attn_fwd(const void* qkv, int64_t ld_qkv, void* ctx, int64_t ld_ctx, const float* bias, int32_t n_bias_windows,
+                                   int64_t B, int32_t R, int32_t C, int32_t heads, int32_t shift, float scale, void* stream) {
+  if (!qkv || !ctx || !bias) return set_error(ADT_EINVAL, "adt_window_attn_fwd: null pointer");
+  if (B < 0 || R <= 0 || (R & 7) || heads <= 0 || C != heads * 24 || shift < 0 || shift >= 8)
+    return set_error(ADT_ESHAPE, "adt_window_attn_fwd: window 8, head_dim 24 (C == heads*24), R % 8 == 0");
+  if (ld_qkv < 3 * C || ld_ctx < C || (ld_qkv & 7) || (ld_ctx & 3) || !aligned16(qkv))
+    return set_error(ADT_ESHAPE, "adt_window_attn_fwd: bad leading dimensions");
+  const int nw = R / 8;
+  if (n_bias_windows != 1 && n_bias_windows != nw * nw) return set_error(ADT_EINVAL, "adt_window_attn_fwd: n_bias_windows must be 1 or (R/8)^2");
+  const long total = B * nw * nw * heads;
+  if (total == 0) return ADT_OK;
+  WinAttnArgs a{static_cast<const unsigned short*>(qkv), ld_qkv, static_cast<unsigned short*>(ctx), ld_ctx, bias, n_bias_windows,
+                static_cast<int>(B), R, C, heads, shift, scale};
+  hipLaunchKernelGGL(window_attn_kernel, dim3(static_cast<unsigned>((total + 3) / 4)), dim3(256), 0, STR(stream), a);
+  ADT_HIP_TRY(hipGetLastError());
+  return ADT_OK;
+}
+
+extern "C" int adt_patch_merge_ln(const float* x, int64_t B, int32_t R, int32_t C, const float* gamma, const float* beta, float eps,
+                                  void* out_bf16, void* stream) {
+  if (!x || !gamma || !beta || !out_bf16) return set_error(ADT_EINVAL, "adt_patch_merge_ln: null pointer");
+  if (B < 0 || R <= 0 || (R & 1) || C <= 0 || (C & 3) || 4 * C > 1536) return set_error(ADT_ESHAPE, "adt_patch_merge_ln: R even, C % 4 == 0, 4C <= 1536");
+  const long n = B * static_cast<long>(R / 2) * (R / 2);
+  if (n == 0) return ADT_OK;
+  hipLaunchKernelGGL(patch_merge_ln_kernel, dim3(static_cast<unsigned>((n + 3) / 4)), dim3(256), 0, STR(stream), x, R, C, gamma, beta, eps,
+                     static_cast<unsigned short*>(out_bf16), n);
+  ADT_HIP_TRY(hipGetLastError());
+  return ADT_OK;
+}
+
+extern "C" int adt_mean_tokens(const float* x, int64_t B, int32_t T, int32_t C, float* out32, void* out16, void* stream) {
+  if (!x || (!out32 && !out16)) return set_error(ADT_EINVAL, "adt_mean_tokens: null pointer");
+  if (B < 0 || T <= 0 || C <= 0) return set_error(ADT_EINVAL, "adt_mean_tokens: bad sizes");
+  if (B == 0) return ADT_OK;
+  hipLaunchKernelGGL(mean_tokens_kernel, dim3(static_cast<unsigned>(B)), dim3(256), 0, STR(stream), x, T, C, out32, static_cast<unsigned short*>(out16));
+  ADT_HIP_TRY(hipGetLastError());
+  return ADT_OK;
+}
+
+extern "C" int adt_l2_normalize(const float* x, int64_t n_rows, int32_t D, float* out, void* stream) {
+  if (!x || !out) return set_error(ADT_EINVAL, "adt_l2_normalize: null pointer");
+  if (n_rows < 0 || D <= 0) return set_error(ADT_EINVAL, "adt_l2_normalize: bad sizes");
+  if (n_rows == 0) return ADT_OK;
+  hipLaunchKernelGGL(l2_normalize_kernel, dim3(static_cast<unsigned>((n_rows + 3) / 4)), dim3(256), 0, STR(stream), x, D, out, n_rows);
+  ADT_HIP_TRY(hipGetLastError());
+  return ADT_OK;
+}

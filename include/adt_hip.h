@@ -131,7 +131,7 @@ int adt_mix_render_f32(const float* bank, const int64_t* bank_off, int64_t n_sho
  *   + bias[col]                          (fp32, may be null)
  *   * gelu'(gelu_grad_of[row,col])       (bf16 pre-activation u; dgrad through GELU)
  *   pre_act_out[row,col] = bf16(z)       (saved pre-activation, may be null)
- *   act == 1: z = gelu_erf(z)            (exact erf GELU, activation="gelu")
+ *   act == 1: z = gelu_erf(z)            (exact erf GELU, activation="gelu"); act == 2: z = max(z, 0) (ReLU)
  *   dropout (drop.p > 0, drop_after_residual == 0), element index row*N + col
  *   + residual[row % res_row_mod, col]   (fp32; res_row_mod == 0: plain row) --
  *                                         residual stream, or the sinusoidal PE
@@ -284,6 +284,34 @@ int adt_adamw_step(float* p, const float* g, float* m, float* v, void* p_bf16, i
 int adt_clap_logmel_db_f32(const float* waves, const int64_t* offsets, int64_t n_clips, int32_t target_len, int32_t n_fft,
                            int32_t hop, int32_t n_frames, const float* window, const int32_t* mel_meta, const float* mel_w,
                            int32_t n_mels, int32_t mel_nnz, float amin, float* out, void* stream);
+
+/* ---------------------------------------------------------------------------
+ * K10/K11  HTSAT (audio Swin) specific kernels, forward only
+ *
+ * Replace the non-GEMM parts of transformers' ClapAudioEncoder.forward, which the reference runs through
+ * ClapWrapper._get_audio_features (modules/clap_encoder.py:45-49): the dense layers use adt_gemm_bf16 and
+ * adt_layernorm_fwd.
+ *   adt_htsat_front_f32    mel [B, in_frames, n_mels] fp32 -> image [B, img_side, img_side] fp32:
+ *                          eval BatchNorm2d per mel bin (y = x * bn_scale[f] + bn_shift[f]), bicubic resize of the
+ *                          time axis to out_frames (align_corners, A = -0.75), freq-stacking fold (reshape_mel2img)
+ *   adt_htsat_patch_embed  4x4/stride-4 conv, 1 -> C channels (w [C,16], bias [C]) + LayerNorm -> tokens [B*(side/4)^2, C]
+ *   adt_window_attn_fwd    8x8-window attention, head_dim 24: qkv [B*R*R, >= 3C] bf16 (q | k | v, head h at column
+ *                          24h) -> ctx [B*R*R, C] bf16; cyclic shift `shift` and the window partition are index math;
+ *                          bias [n_bias_windows][heads][64][64] fp32 = relative position bias (+ the -100 shifted-window
+ *                          mask of each window when n_bias_windows == (R/8)^2)
+ *   adt_patch_merge_ln     Swin patch merging gather (2x2 -> 4C, order (0,0),(1,0),(0,1),(1,1)) + LayerNorm -> bf16
+ *   adt_mean_tokens        mean over the T tokens of each clip;  adt_l2_normalize  rows / ||row||
+ */
+int adt_htsat_front_f32(const float* mel, int64_t ld_clip, int64_t B, int32_t in_frames, int32_t n_mels, int32_t out_frames,
+                        int32_t img_side, const float* bn_scale, const float* bn_shift, float* img, void* stream);
+int adt_htsat_patch_embed(const float* img, int64_t B, int32_t img_side, const float* w, const float* bias, const float* gamma,
+                          const float* beta, float eps, int32_t C, float* out32, void* out16, void* stream);
+int adt_window_attn_fwd(const void* qkv, int64_t ld_qkv, void* ctx, int64_t ld_ctx, const float* bias, int32_t n_bias_windows,
+                        int64_t B, int32_t R, int32_t C, int32_t heads, int32_t shift, float scale, void* stream);
+int adt_patch_merge_ln(const float* x, int64_t B, int32_t R, int32_t C, const float* gamma, const float* beta, float eps,
+                       void* out_bf16, void* stream);
+int adt_mean_tokens(const float* x, int64_t B, int32_t T, int32_t C, float* out32, void* out16, void* stream);
+int adt_l2_normalize(const float* x, int64_t n_rows, int32_t D, float* out, void* stream);
 
 /* ---------------------------------------------------------------------------
  * K12  CLAP curation: cosine similarity to the class means + per-sample best class

@@ -1,0 +1,112 @@
+"""K10/K11 + CLAP audio tower (a9) on the GPU against transformers' own ClapAudioModel / audio_projection run on the
+CPU in fp32 (the code the reference calls, clap_encoder.py:45-54), with randomly initialised weights.
+
+The HIP path uses bf16 GEMM/attention operands with fp32 accumulation and an fp32 residual stream; tolerances:
+front image and patch embedding (fp32 kernels) 2e-4 / 2e-3 absolute; pooled features 3e-2 of their max;
+final unit-norm embedding: cosine >= 0.9995 with the reference and 1.5e-2 absolute per component."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import clap as o_clap
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+
+@pytest.fixture(scope="module")
+def setup():
+    model = o_clap.random_clap_model(0)
+    from tests.test_clap_frontend import make_clips
+    clips = make_clips(3, [9000, 48000, 20000])
+    mel = torch.from_numpy(o_clap.logmel_db(clips)).contiguous()         # [3, 1001, 64] (the oracle returns a transposed view)
+    feats = mel.unsqueeze(1).repeat(1, 4, 1, 1)
+    return model, clips, mel, feats
+
+
+def test_front_and_patch_embed_match_hf(setup):
+    from adt_str_amd import _ffi
+    from adt_str_amd.clap_encoder import HtsatEncoder
+    model, _, mel, feats = setup
+    enc_hf = model.audio_model.audio_encoder
+    with torch.no_grad():
+        x = enc_hf.batch_norm(feats.transpose(1, 3)).transpose(1, 3)
+        img_ref = enc_hf.reshape_mel2img(x)[:, 0]                        # [B, 256, 256]
+        tok_ref = enc_hf.patch_embed(enc_hf.reshape_mel2img(x), torch.tensor([], dtype=torch.long))
+    enc = HtsatEncoder(model.state_dict(), model.config.audio_config, DEV)
+    m = mel.to(DEV)
+    B = m.shape[0]
+    img = torch.empty((B, 256, 256), device=DEV)
+    _ffi.call("adt_htsat_front_f32", m.data_ptr(), 1001 * 64, B, 1001, 64, 1024, 256, enc.bn_scale.data_ptr(), enc.bn_shift.data_ptr(),
+              img.data_ptr(), 0)
+    assert (img.cpu() - img_ref).abs().max() < 2e-4 * img_ref.abs().max()
+    tok = torch.empty((B * 4096, 96), device=DEV)
+    _ffi.call("adt_htsat_patch_embed", img.data_ptr(), B, 256, enc.pe_w.data_ptr(), enc.pe_b.data_ptr(), enc.pe_g.data_ptr(),
+              enc.pe_beta.data_ptr(), 1e-5, 96, tok.data_ptr(), None, 0)
+    assert (tok.cpu().view(B, 4096, 96) - tok_ref).abs().max() < 2e-3
+
+
+def test_window_attention_matches_hf_layer(setup):
+    """One shifted and one unshifted ClapAudioSelfAttention call (stage 1: R = 32, C = 192, 8 heads)."""
+    import math
+    from adt_str_amd import _ffi
+    from adt_str_amd.clap_encoder import HtsatEncoder
+    model, *_ = setup
+    enc = HtsatEncoder(model.state_dict(), model.config.audio_config, DEV)
+    for li in (0, 1):
+        hf_layer = model.audio_model.audio_encoder.layers[1].blocks[li]
+        L = enc.stages[1]["layers"][li]
+        B, R, C, nh = 2, 32, 192, 8
+        g = torch.Generator().manual_seed(li)
+        xn = torch.randn(B, R * R, C, generator=g)
+        with torch.no_grad():
+            # HF: (shift) -> window partition -> attention -> reverse -> (unshift)
+            from transformers.models.clap.modeling_clap import window_partition, window_reverse
+            h = xn.view(B, R, R, C)
+            sh = hf_layer.shift_size
+            hs = torch.roll(h, shifts=(-sh, -sh), dims=(1, 2)) if sh > 0 else h
+            win = window_partition(hs, 8).view(-1, 64, C)
+            mask = hf_layer.get_attn_mask(R, R, dtype=win.dtype, device=win.device)
+            att = hf_layer.attention.self(win, mask)[0].view(-1, 8, 8, C)
+            rev = window_reverse(att, 8, R, R)
+            ref = (torch.roll(rev, shifts=(sh, sh), dims=(1, 2)) if sh > 0 else rev).reshape(B * R * R, C)
+        assert L["shift"] == sh
+        x16 = xn.reshape(B * R * R, C).to(DEV).bfloat16()
+        from adt_str_amd import kernels as K
+        qkv = K.gemm(x16, L["wqkv"], bias=L["bqkv"])
+        ctx = torch.empty((B * R * R, C), dtype=torch.bfloat16, device=DEV)
+        _ffi.call("adt_window_attn_fwd", qkv.data_ptr(), qkv.stride(0), ctx.data_ptr(), C, L["bias"].data_ptr(), L["n_bias"], B, R, C, nh,
+                  L["shift"], 1.0 / math.sqrt(24.0), 0)
+        err = (ctx.float().cpu() - ref).abs().max().item()
+        assert err < 3e-2 * ref.abs().max().item() + 1e-3, (li, err, ref.abs().max().item())
+
+
+def test_embeddings_match_hf(setup):
+    from adt_str_amd.clap_encoder import HtsatEncoder
+    model, _, mel, feats = setup
+    ref = o_clap.audio_embeddings(model, feats, torch.zeros(3, 1, dtype=torch.bool))
+    enc = HtsatEncoder(model.state_dict(), model.config.audio_config, DEV)
+    out = enc.forward(mel.to(DEV))
+    pooled, emb = out["pooled"].cpu(), out["embedding"].cpu()
+    assert pooled.shape == ref["pooled"].shape == (3, 768) and emb.shape == (3, 512)
+    assert (pooled - ref["pooled"]).abs().max() < 3e-2 * ref["pooled"].abs().max()
+    cos = (emb * ref["embedding"]).sum(-1)
+    assert cos.min() > 0.9995, cos
+    assert (emb - ref["embedding"]).abs().max() < 1.5e-2
+    assert torch.allclose(emb.norm(dim=-1), torch.ones(3), atol=1e-5)
+
+
+def test_wrapper_end_to_end_and_curation(setup):
+    """ClapWrapper.get_audio_features on raw clips (K9 + encoder), then the curation assignment on those embeddings."""
+    from adt_str_amd.clap_encoder import ClapWrapper
+    from adt_str_amd.curation import assign, class_mean_embeddings
+    model, clips, mel, feats = setup
+    w = ClapWrapper("unused", DEV, 48000, clap_model=model)
+    emb = w.get_audio_features([torch.from_numpy(c).unsqueeze(0) for c in clips])
+    ref = o_clap.audio_embeddings(model, feats, torch.zeros(3, 1, dtype=torch.bool))["embedding"]
+    assert ((emb.cpu() * ref).sum(-1)).min() > 0.9995
+    labels, means = class_mean_embeddings({35: [emb[0].cpu()], 38: [emb[1].cpu(), emb[2].cpu()]})
+    res = assign(emb, means.to(DEV), labels)
+    assert sorted(res.order.tolist()) == [0, 1, 2] and set(res.label.tolist()) <= {35, 38}
+    with pytest.raises(NotImplementedError):
+        w.encoder.forward(mel.to(DEV), torch.tensor([[True], [False], [False]]))
