@@ -40,6 +40,12 @@ class AttnDesc(C.Structure):
                 ("key_len", C.c_void_p), ("drop", Dropout)]
 
 
+class AffWeights(C.Structure):
+    """struct adt_aff_weights (include/adt_hip.h)."""
+    _fields_ = [(n, C.c_void_p) for n in ("proj_w", "proj_b", "conv_w", "conv_b", "local_w1", "local_b1", "local_w2", "local_b2",
+                                          "global_w1", "global_b1", "global_w2", "global_b2", "ln_gamma", "ln_beta")]
+
+
 # name -> argtypes; every entry must be declared in include/adt_hip.h (tests check both ways)
 SIGNATURES = {
     "adt_version": [],
@@ -67,6 +73,8 @@ SIGNATURES = {
     "adt_clap_logmel_db_f32": [ptr, ptr, i64, i32, i32, i32, i32, ptr, ptr, ptr, i32, i32, f32, ptr, ptr],
     "adt_htsat_front_f32": [ptr, i64, i64, i32, i32, i32, i32, ptr, ptr, ptr, ptr],
     "adt_htsat_patch_embed": [ptr, i64, i32, ptr, ptr, ptr, ptr, f32, i32, ptr, ptr, ptr],
+    "adt_htsat_fusion_embed_workspace_bytes": [i32, i32],
+    "adt_htsat_fusion_embed": [ptr, ptr, i32, ptr, f32, i32, i32, ptr, C.c_size_t, ptr, ptr],
     "adt_window_attn_fwd": [ptr, i64, ptr, i64, ptr, i32, i64, i32, i32, i32, i32, f32, ptr],
     "adt_patch_merge_ln": [ptr, i64, i32, i32, ptr, ptr, f32, ptr, ptr],
     "adt_mean_tokens": [ptr, i64, i32, i32, ptr, ptr, ptr],
@@ -77,7 +85,8 @@ SIGNATURES = {
 _RESTYPES = {"adt_last_error": C.c_char_p}
 _RESTYPES.update({n: C.c_size_t for n in ("adt_mix_workspace_bytes", "adt_gemm_workspace_bytes", "adt_attn_bwd_workspace_bytes",
                                           "adt_layernorm_bwd_workspace_bytes", "adt_colsum_workspace_bytes",
-                                          "adt_cross_entropy_workspace_bytes", "adt_grad_norm_workspace_bytes")})
+                                          "adt_cross_entropy_workspace_bytes", "adt_grad_norm_workspace_bytes",
+                                          "adt_htsat_fusion_embed_workspace_bytes")})
 
 
 class AdtError(RuntimeError):

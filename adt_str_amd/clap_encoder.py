@@ -55,6 +55,11 @@ class HtsatEncoder:
         self.bn_scale, self.bn_shift = bn_scale.contiguous(), (g(p + "batch_norm.bias") - g(p + "batch_norm.running_mean") * bn_scale).contiguous()
         self.pe_w = g(p + "patch_embed.proj.weight").reshape(self.C0, 16).contiguous()
         self.pe_b, self.pe_g, self.pe_beta = g(p + "patch_embed.proj.bias"), g(p + "patch_embed.norm.weight"), g(p + "patch_embed.norm.bias")
+        self.aff = None
+        if self.enable_fusion:
+            if c.fusion_type != "aff_2d":
+                raise NotImplementedError("only the aff_2d fusion of laion/clap-htsat-fused is built")
+            self.aff = self._fold_aff(g, p + "patch_embed.")
         b16 = lambda t: t.to(BF16).contiguous()
         self.stages = []
         R = self.spec // 4
@@ -88,22 +93,62 @@ class HtsatEncoder:
         self.proj = (b16(g("audio_projection.linear1.weight")), g("audio_projection.linear1.bias"),
                      b16(g("audio_projection.linear2.weight")), g("audio_projection.linear2.bias"))
 
+    def _fold_aff(self, g, pe: str):
+        """Weights of mel_conv2d + ClapAudioAFFBlock with the eval-mode BatchNorms folded into the 1x1 convolutions."""
+        def conv_bn(prefix, conv, bn):
+            w, b = g(f"{prefix}{conv}.weight").flatten(1), g(f"{prefix}{conv}.bias")
+            s = g(f"{prefix}{bn}.weight") / torch.sqrt(g(f"{prefix}{bn}.running_var") + 1e-5)
+            return (w * s[:, None]).contiguous(), ((b - g(f"{prefix}{bn}.running_mean")) * s + g(f"{prefix}{bn}.bias")).contiguous()
+        la, ga = pe + "fusion_model.local_att.", pe + "fusion_model.global_att."
+        t = dict(conv_w=g(pe + "mel_conv2d.weight").reshape(self.C0, 48).contiguous(), conv_b=g(pe + "mel_conv2d.bias"))
+        t["local_w1"], t["local_b1"] = conv_bn(la, "0", "1")
+        t["local_w2"], t["local_b2"] = conv_bn(la, "3", "4")
+        t["global_w1"], t["global_b1"] = conv_bn(ga, "1", "2")
+        t["global_w2"], t["global_b2"] = conv_bn(ga, "4", "5")
+        t["inter"] = t["local_w1"].shape[0]
+        return t
+
+    def _fusion_tokens(self, img_global: torch.Tensor, img_local: torch.Tensor, out_rows: torch.Tensor, st) -> None:
+        """AFF branch for one clip: img_global [side, side], img_local [3, side, side] -> out_rows [(side/4)^2, C0] (in place)."""
+        a = self.aff
+        w = _ffi.AffWeights(**{k: _ffi.dptr(v) for k, v in dict(
+            proj_w=self.pe_w, proj_b=self.pe_b, conv_w=a["conv_w"], conv_b=a["conv_b"], local_w1=a["local_w1"], local_b1=a["local_b1"],
+            local_w2=a["local_w2"], local_b2=a["local_b2"], global_w1=a["global_w1"], global_b1=a["global_b1"], global_w2=a["global_w2"],
+            global_b2=a["global_b2"], ln_gamma=self.pe_g, ln_beta=self.pe_beta).items()})
+        nbytes = _ffi.load().adt_htsat_fusion_embed_workspace_bytes(self.spec, self.C0)
+        ws = torch.empty(nbytes, dtype=torch.uint8, device=self.dev)
+        import ctypes
+        _ffi.call("adt_htsat_fusion_embed", _ffi.dptr(img_global), _ffi.dptr(img_local), self.spec, ctypes.byref(w), self.eps, self.C0,
+                  a["inter"], _ffi.dptr(ws), nbytes, _ffi.dptr(out_rows), st)
+
     @torch.no_grad()
     def forward(self, mel: torch.Tensor, is_longer: Optional[torch.Tensor] = None) -> Dict[str, torch.Tensor]:
-        """mel [B, 1001, 64] fp32 (fusion channel 0) -> {"pooled": [B, 768], "embedding": [B, 512]} fp32."""
-        if is_longer is not None and bool(torch.as_tensor(is_longer).any()):
-            raise NotImplementedError("is_longer items take the AFF fusion branch of the patch embedding, which is not built yet; "
-                                      "pass is_longer=None / all False (clips of at most 10 s carry four identical mel channels)")
+        """mel [B, 1001, 64] (the four fusion channels are identical: clips of at most 10 s) or [B, 4, 1001, 64] fp32,
+        is_longer [B] / [B, 1] bool (items routed through the AFF fusion patch embedding, as the feature extractor marks them)
+        -> {"pooled": [B, 768], "embedding": [B, 512]} fp32."""
         mel = mel.to(self.dev, F32).contiguous()
-        B, T, M = mel.shape
+        four = mel.dim() == 4
+        B, T, M = mel.shape[0], mel.shape[-2], mel.shape[-1]
+        long_idx = [] if is_longer is None else torch.as_tensor(is_longer).reshape(-1).nonzero().reshape(-1).tolist()
+        if long_idx and self.aff is None:
+            raise ValueError("is_longer items need a fusion model (audio_config.enable_fusion)")
         st = _ffi.current_stream()
         side = self.spec
         img = torch.empty((B, side, side), dtype=F32, device=self.dev)
-        _ffi.call("adt_htsat_front_f32", _ffi.dptr(mel), T * M, B, T, M, side * (side // M), side, _ffi.dptr(self.bn_scale),
+        _ffi.call("adt_htsat_front_f32", _ffi.dptr(mel), mel.stride(0), B, T, M, side * (side // M), side, _ffi.dptr(self.bn_scale),
                   _ffi.dptr(self.bn_shift), _ffi.dptr(img), st)
-        x = torch.empty((B * (side // 4) ** 2, self.C0), dtype=F32, device=self.dev)
+        n_tok = (side // 4) ** 2
+        x = torch.empty((B * n_tok, self.C0), dtype=F32, device=self.dev)
         _ffi.call("adt_htsat_patch_embed", _ffi.dptr(img), B, side, _ffi.dptr(self.pe_w), _ffi.dptr(self.pe_b), _ffi.dptr(self.pe_g),
                   _ffi.dptr(self.pe_beta), self.eps, self.C0, _ffi.dptr(x), None, st)
+        for b in long_idx:
+            if four:
+                loc = torch.empty((3, side, side), dtype=F32, device=self.dev)
+                _ffi.call("adt_htsat_front_f32", _ffi.dptr(mel[b, 1:]), T * M, 3, T, M, side * (side // M), side, _ffi.dptr(self.bn_scale),
+                          _ffi.dptr(self.bn_shift), _ffi.dptr(loc), st)
+            else:
+                loc = img[b].unsqueeze(0).expand(3, side, side).contiguous()
+            self._fusion_tokens(img[b], loc, x[b * n_tok:(b + 1) * n_tok], st)
         for S in self.stages:
             C, nh, R = S["C"], S["nh"], S["R"]
             for L in S["layers"]:
@@ -152,10 +197,32 @@ class ClapWrapper(nn.Module):
         self.features = ClapLogMel(self.device)
 
     @torch.no_grad()
-    def get_audio_features(self, audios: Sequence[torch.Tensor]) -> torch.Tensor:
-        """list of [1, L] (or [L]) 48 kHz clips -> [B, 512] L2-normalised embeddings (clap_encoder.py:21-24, 30-54)."""
-        mel = self.features.mel([a.reshape(-1) for a in audios])
-        return self.encoder.forward(mel)["embedding"]
+    def get_audio_features(self, audios: Sequence[torch.Tensor], is_longer: Optional[torch.Tensor] = None) -> torch.Tensor:
+        """list of [1, L] (or [L]) 48 kHz clips -> [B, 512] L2-normalised embeddings (clap_encoder.py:21-24, 30-54).
+
+        ``is_longer``: the flags the reference's ClapProcessor would hand to the model.  Its feature extractor marks every clip
+        longer than 10 s and, when a batch has none, ONE RANDOM clip (feature_extraction_clap.py:347-350, ``np.random.randint``);
+        that draw is part of the reference's result, so pass the recorded flags to reproduce it.  Default (None): the same rule with
+        this module's own ``numpy`` draw, like the reference."""
+        flat = [a.reshape(-1) for a in audios]
+        if any(a.numel() > 10 * self.sample_rate for a in flat):
+            raise NotImplementedError("clips longer than 10 s take the extractor's random-crop mel fusion, which is outside the "
+                                      "curation path (one-shots are at most a few seconds, augment_data_with_CLAP.py:51-63)")
+        if is_longer is None:
+            is_longer = torch.zeros(len(flat), dtype=torch.bool)
+            if len(flat) and self.encoder.enable_fusion:
+                is_longer[np.random.randint(0, len(flat))] = True
+        mel = self.features.mel(flat)
+        return self.encoder.forward(mel, is_longer)["embedding"]
+
+    @torch.no_grad()
+    def _get_audio_features(self, input_features: Optional[torch.Tensor] = None, is_longer: Optional[torch.Tensor] = None,
+                            attention_mask=None, output_attentions=None, output_hidden_states=None, return_dict=None) -> torch.Tensor:
+        """``input_features [B, 4, 1001, 64]`` + ``is_longer [B, 1]`` (what ClapProcessor returns) -> [B, 512]
+        (clap_encoder.py:30-54; the attention / hidden-state outputs of the reference signature are never read by its callers)."""
+        if output_attentions or output_hidden_states:
+            raise NotImplementedError("attention maps / hidden states are not produced by the fused kernels")
+        return self.encoder.forward(input_features, is_longer)["embedding"]
 
     def get_text_features(self, text):
         raise NotImplementedError("the text tower is outside the MI355X hot path (the curation pipeline never calls it)")

@@ -120,6 +120,142 @@ __global__ __launch_bounds__(256) void htsat_patch_embed_kernel(const float* __r
   }
 }
 
+// ------------------------------------------------------------------------------------ AFF fusion patch embedding
+// The `is_longer` branch of ClapAudioPatchEmbed.forward for ONE clip: global = proj(img channel 0) (4x4/4), local =
+// mel_conv2d(img channels 1..3) (4x12 / stride 4x12, 21 columns per channel, channel-major along the width, column 63 zero),
+// fused by ClapAudioAFFBlock (eval BatchNorms folded into the 1x1 convs by the host) and LayerNorm'd.
+// Three launches: conv (per token) -> global attention vector (per clip) -> apply (per token).
+struct AffArgs {
+  const float *pw, *pb;          // proj [C,16], [C]
+  const float *cw, *cb;          // mel_conv2d [C,48], [C]
+  const float *lw1, *lb1, *lw2, *lb2;   // local_att  1x1 convs with BN folded: [I,C],[I],[C,I],[C]
+  const float *gw1, *gb1, *gw2, *gb2;   // global_att
+  const float *gamma, *beta;
+  float eps;
+  int C, I, side;
+};
+
+__global__ __launch_bounds__(256) void aff_conv_kernel(const float* __restrict__ img_g, const float* __restrict__ img_l, AffArgs a,
+                                                       float* __restrict__ ws_g, float* __restrict__ ws_l, int n_tokens) {
+  const int lane = threadIdx.x & 63;
+  const int tok = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (tok >= n_tokens) return;
+  const int grid = a.side / 4, lw = a.side / 12;           // 64 tokens per row; 21 local columns per channel
+  const int j = tok % grid, i = tok / grid;
+  float px[16];
+#pragma unroll
+  for (int di = 0; di < 4; ++di)
+#pragma unroll
+    for (int dj = 0; dj < 4; ++dj) px[di * 4 + dj] = img_g[(4 * i + di) * a.side + 4 * j + dj];
+  const int ch = j / lw, jj = j - ch * lw;
+  const bool has_local = ch < 3;
+  float pl[48];
+#pragma unroll
+  for (int di = 0; di < 4; ++di)
+#pragma unroll
+    for (int dj = 0; dj < 12; ++dj)
+      pl[di * 12 + dj] = has_local ? img_l[(static_cast<long>(ch) * a.side + 4 * i + di) * a.side + 12 * jj + dj] : 0.f;
+  for (int o = lane; o < a.C; o += 64) {
+    float g = a.pb[o];
+#pragma unroll
+    for (int e = 0; e < 16; ++e) g += a.pw[o * 16 + e] * px[e];
+    float l = 0.f;
+    if (has_local) {
+      l = a.cb[o];
+#pragma unroll
+      for (int e = 0; e < 48; ++e) l += a.cw[o * 48 + e] * pl[e];
+    }
+    ws_g[static_cast<long>(tok) * a.C + o] = g;
+    ws_l[static_cast<long>(tok) * a.C + o] = l;
+  }
+}
+
+// one block: mean over the tokens of (g + l), then the global_att MLP -> ga[C]
+__global__ __launch_bounds__(1024) void aff_global_kernel(const float* __restrict__ ws_g, const float* __restrict__ ws_l, AffArgs a, int n_tokens,
+                                                          float* __restrict__ ga) {
+  __shared__ float part[1024];
+  __shared__ float mean[128];
+  __shared__ float hid[64];
+  const int groups = 1024 / a.C;                       // row groups (C = 96 -> 10)
+  const int c = threadIdx.x % a.C, gidx = threadIdx.x / a.C;
+  float s = 0.f;
+  if (gidx < groups)
+    for (int t = gidx; t < n_tokens; t += groups) s += ws_g[static_cast<long>(t) * a.C + c] + ws_l[static_cast<long>(t) * a.C + c];
+  part[threadIdx.x] = gidx < groups ? s : 0.f;
+  __syncthreads();
+  if (threadIdx.x < a.C) {
+    float m = 0.f;
+    for (int g2 = 0; g2 < groups; ++g2) m += part[g2 * a.C + threadIdx.x];
+    mean[threadIdx.x] = m / n_tokens;
+  }
+  __syncthreads();
+  if (threadIdx.x < a.I) {
+    float h = a.gb1[threadIdx.x];
+    for (int k = 0; k < a.C; ++k) h += a.gw1[threadIdx.x * a.C + k] * mean[k];
+    hid[threadIdx.x] = h > 0.f ? h : 0.f;
+  }
+  __syncthreads();
+  if (threadIdx.x < a.C) {
+    float z = a.gb2[threadIdx.x];
+    for (int k = 0; k < a.I; ++k) z += a.gw2[threadIdx.x * a.I + k] * hid[k];
+    ga[threadIdx.x] = z;
+  }
+}
+
+__global__ __launch_bounds__(256) void aff_apply_kernel(const float* __restrict__ ws_g, const float* __restrict__ ws_l, const float* __restrict__ ga,
+                                                        AffArgs a, float* __restrict__ out32, int n_tokens) {
+  __shared__ float sa[4][128];
+  __shared__ float sh[4][64];
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  const int tok = blockIdx.x * 4 + w;
+  if (tok >= n_tokens) return;                         // whole waves leave together; LDS below is wave-private
+  float g[2] = {0.f, 0.f}, l[2] = {0.f, 0.f};
+#pragma unroll
+  for (int k = 0; k < 2; ++k) {
+    const int o = lane + 64 * k;
+    if (o < a.C) {
+      g[k] = ws_g[static_cast<long>(tok) * a.C + o];
+      l[k] = ws_l[static_cast<long>(tok) * a.C + o];
+      sa[w][o] = g[k] + l[k];
+    }
+  }
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+  if (lane < a.I) {
+    float h = a.lb1[lane];
+    for (int k = 0; k < a.C; ++k) h += a.lw1[lane * a.C + k] * sa[w][k];
+    sh[w][lane] = h > 0.f ? h : 0.f;
+  }
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+  float y[2] = {0.f, 0.f};
+  float s = 0.f;
+#pragma unroll
+  for (int k = 0; k < 2; ++k) {
+    const int o = lane + 64 * k;
+    if (o < a.C) {
+      float z = a.lb2[o] + ga[o];
+      for (int q = 0; q < a.I; ++q) z += a.lw2[o * a.I + q] * sh[w][q];
+      const float wgt = 1.f / (1.f + expf(-z));
+      y[k] = 2.f * g[k] * wgt + 2.f * l[k] * (1.f - wgt);
+      s += y[k];
+    }
+  }
+  const float mean = wsum(s) / a.C;
+  float ss = 0.f;
+#pragma unroll
+  for (int k = 0; k < 2; ++k)
+    if (lane + 64 * k < a.C) ss += (y[k] - mean) * (y[k] - mean);
+  const float rstd = rsqrtf(wsum(ss) / a.C + a.eps);
+#pragma unroll
+  for (int k = 0; k < 2; ++k) {
+    const int o = lane + 64 * k;
+    if (o < a.C) out32[static_cast<long>(tok) * a.C + o] = (y[k] - mean) * rstd * a.gamma[o] + a.beta[o];
+  }
+}
+
 // ------------------------------------------------------------------------------------ window attention (head_dim 24)
 struct WinAttnArgs {
   const unsigned short* qkv; long ld;          // [B*R*R, 3C] bf16: q | k | v, head h at columns h*24
@@ -340,6 +476,34 @@ extern "C" int adt_htsat_patch_embed(const float* img, int64_t B, int32_t img_si
   if (n == 0) return ADT_OK;
   hipLaunchKernelGGL(htsat_patch_embed_kernel, dim3(static_cast<unsigned>((n + 3) / 4)), dim3(256), 0, STR(stream), img, img_side, w, bias, gamma,
                      beta, eps, C, out32, static_cast<unsigned short*>(out16), n);
+  ADT_HIP_TRY(hipGetLastError());
+  return ADT_OK;
+}
+
+extern "C" size_t adt_htsat_fusion_embed_workspace_bytes(int32_t img_side, int32_t C) {
+  if (img_side <= 0 || C <= 0) return 0;
+  const size_t n = static_cast<size_t>(img_side / 4) * (img_side / 4);
+  return (2 * n * C + 128) * sizeof(float);
+}
+
+extern "C" int adt_htsat_fusion_embed(const float* img_global, const float* img_local, int32_t img_side, const adt_aff_weights* w, float eps,
+                                      int32_t C, int32_t inter, void* ws, size_t ws_bytes, float* out32, void* stream) {
+  if (!img_global || !img_local || !w || !ws || !out32) return set_error(ADT_EINVAL, "adt_htsat_fusion_embed: null pointer");
+  const float* const* wp = reinterpret_cast<const float* const*>(w);
+  for (int i = 0; i < 14; ++i)
+    if (!wp[i]) return set_error(ADT_EINVAL, "adt_htsat_fusion_embed: null weight pointer");
+  if (img_side <= 0 || (img_side & 3) || img_side / 12 * 3 > img_side / 4 || C <= 0 || C > 128 || inter <= 0 || inter > 64 || C * (1024 / C) > 1024)
+    return set_error(ADT_ESHAPE, "adt_htsat_fusion_embed: img_side % 4 == 0, C <= 128, inter <= 64");
+  if (ws_bytes < adt_htsat_fusion_embed_workspace_bytes(img_side, C)) return set_error(ADT_EINVAL, "adt_htsat_fusion_embed: workspace too small");
+  const int n = (img_side / 4) * (img_side / 4);
+  float* ws_g = static_cast<float*>(ws);
+  float* ws_l = ws_g + static_cast<size_t>(n) * C;
+  float* ga = ws_l + static_cast<size_t>(n) * C;
+  AffArgs a{w->proj_w, w->proj_b, w->conv_w, w->conv_b, w->local_w1, w->local_b1, w->local_w2, w->local_b2,
+            w->global_w1, w->global_b1, w->global_w2, w->global_b2, w->ln_gamma, w->ln_beta, eps, C, inter, img_side};
+  hipLaunchKernelGGL(aff_conv_kernel, dim3((n + 3) / 4), dim3(256), 0, STR(stream), img_global, img_local, a, ws_g, ws_l, n);
+  hipLaunchKernelGGL(aff_global_kernel, dim3(1), dim3(1024), 0, STR(stream), ws_g, ws_l, a, n, ga);
+  hipLaunchKernelGGL(aff_apply_kernel, dim3((n + 3) / 4), dim3(256), 0, STR(stream), ws_g, ws_l, ga, a, out32, n);
   ADT_HIP_TRY(hipGetLastError());
   return ADT_OK;
 }

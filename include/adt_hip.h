@@ -306,6 +306,21 @@ int adt_htsat_front_f32(const float* mel, int64_t ld_clip, int64_t B, int32_t in
                         int32_t img_side, const float* bn_scale, const float* bn_shift, float* img, void* stream);
 int adt_htsat_patch_embed(const float* img, int64_t B, int32_t img_side, const float* w, const float* bias, const float* gamma,
                           const float* beta, float eps, int32_t C, float* out32, void* out16, void* stream);
+/* AFF fusion branch of ClapAudioPatchEmbed.forward (transformers modeling_clap.py, `is_longer` items; reached from
+ * clap_encoder.py:45-49 because the feature extractor marks at least one clip per batch) for ONE clip:
+ * img_global [side, side] (mel channel 0 after adt_htsat_front_f32), img_local [3, side, side] (channels 1..3) ->
+ * tokens out32 [(side/4)^2, C] after proj / mel_conv2d (4 x 12, stride 4 x 12) / ClapAudioAFFBlock / LayerNorm.
+ * The 1x1 convolutions of local_att / global_att carry their eval-mode BatchNorm folded in (w' = w * s, b' = (b - mean) * s + beta). */
+struct adt_aff_weights {
+  const float *proj_w, *proj_b;        /* [C,16], [C] */
+  const float *conv_w, *conv_b;        /* [C,48], [C] */
+  const float *local_w1, *local_b1, *local_w2, *local_b2;     /* [I,C], [I], [C,I], [C] */
+  const float *global_w1, *global_b1, *global_w2, *global_b2; /* [I,C], [I], [C,I], [C] */
+  const float *ln_gamma, *ln_beta;     /* [C] */
+};
+size_t adt_htsat_fusion_embed_workspace_bytes(int32_t img_side, int32_t C);
+int adt_htsat_fusion_embed(const float* img_global, const float* img_local, int32_t img_side, const struct adt_aff_weights* w, float eps,
+                           int32_t C, int32_t inter, void* ws, size_t ws_bytes, float* out32, void* stream);
 int adt_window_attn_fwd(const void* qkv, int64_t ld_qkv, void* ctx, int64_t ld_ctx, const float* bias, int32_t n_bias_windows,
                         int64_t B, int32_t R, int32_t C, int32_t heads, int32_t shift, float scale, void* stream);
 int adt_patch_merge_ln(const float* x, int64_t B, int32_t R, int32_t C, const float* gamma, const float* beta, float eps,

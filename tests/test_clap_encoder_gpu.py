@@ -102,11 +102,61 @@ def test_wrapper_end_to_end_and_curation(setup):
     from adt_str_amd.curation import assign, class_mean_embeddings
     model, clips, mel, feats = setup
     w = ClapWrapper("unused", DEV, 48000, clap_model=model)
-    emb = w.get_audio_features([torch.from_numpy(c).unsqueeze(0) for c in clips])
+    emb = w.get_audio_features([torch.from_numpy(c).unsqueeze(0) for c in clips], is_longer=torch.zeros(3, dtype=torch.bool))
     ref = o_clap.audio_embeddings(model, feats, torch.zeros(3, 1, dtype=torch.bool))["embedding"]
     assert ((emb.cpu() * ref).sum(-1)).min() > 0.9995
     labels, means = class_mean_embeddings({35: [emb[0].cpu()], 38: [emb[1].cpu(), emb[2].cpu()]})
     res = assign(emb, means.to(DEV), labels)
     assert sorted(res.order.tolist()) == [0, 1, 2] and set(res.label.tolist()) <= {35, 38}
+    # default flags: like the reference's feature extractor, one random clip of an all-short batch goes through the fusion branch
+    np.random.seed(5)
+    pick = np.random.randint(0, 3)
+    np.random.seed(5)
+    emb_r = w.get_audio_features([torch.from_numpy(c).unsqueeze(0) for c in clips])
+    flags = torch.zeros(3, 1, dtype=torch.bool)
+    flags[pick] = True
+    ref_r = o_clap.audio_embeddings(model, feats, flags)["embedding"]
+    assert ((emb_r.cpu() * ref_r).sum(-1)).min() > 0.9995
     with pytest.raises(NotImplementedError):
-        w.encoder.forward(mel.to(DEV), torch.tensor([[True], [False], [False]]))
+        w.get_audio_features([torch.zeros(1, 480001)])
+
+
+@pytest.mark.parametrize("distinct_channels", [False, True])
+def test_fusion_branch_matches_hf(setup, distinct_channels):
+    """`is_longer` items: proj + mel_conv2d + ClapAudioAFFBlock + LayerNorm (modeling_clap.py ClapAudioPatchEmbed.forward)."""
+    from adt_str_amd.clap_encoder import HtsatEncoder
+    model, _, mel, feats = setup
+    feats = feats.clone()
+    if distinct_channels:                  # what a >10 s clip would carry: three different crops next to the global mel
+        g = torch.Generator().manual_seed(3)
+        feats[:, 1:] += 4.0 * torch.randn(feats[:, 1:].shape, generator=g)
+    flags = torch.tensor([[False], [True], [True]])
+    enc_hf = model.audio_model.audio_encoder
+    with torch.no_grad():
+        x = enc_hf.batch_norm(feats.transpose(1, 3)).transpose(1, 3)
+        tok_ref = enc_hf.patch_embed(enc_hf.reshape_mel2img(x), torch.tensor([1, 2]))
+    ref = o_clap.audio_embeddings(model, feats, flags)
+    enc = HtsatEncoder(model.state_dict(), model.config.audio_config, DEV)
+    inp = feats if distinct_channels else mel
+    # token level (fp32 kernels)
+    B, n_tok = 3, 4096
+    img = torch.empty((B, 256, 256), device=DEV)
+    m = inp.to(DEV).contiguous()
+    from adt_str_amd import _ffi
+    _ffi.call("adt_htsat_front_f32", m.data_ptr(), m.stride(0), B, 1001, 64, 1024, 256, enc.bn_scale.data_ptr(), enc.bn_shift.data_ptr(),
+              img.data_ptr(), 0)
+    for b in (1, 2):
+        if distinct_channels:
+            loc = torch.empty((3, 256, 256), device=DEV)
+            _ffi.call("adt_htsat_front_f32", m[b, 1:].data_ptr(), 1001 * 64, 3, 1001, 64, 1024, 256, enc.bn_scale.data_ptr(),
+                      enc.bn_shift.data_ptr(), loc.data_ptr(), 0)
+        else:
+            loc = img[b].unsqueeze(0).expand(3, 256, 256).contiguous()
+        rows = torch.empty((n_tok, 96), device=DEV)
+        enc._fusion_tokens(img[b], loc, rows, 0)
+        assert (rows.cpu() - tok_ref[b]).abs().max() < 2e-3, b
+    out = enc.forward(inp.to(DEV), flags)
+    emb = out["embedding"].cpu()
+    assert (out["pooled"].cpu() - ref["pooled"]).abs().max() < 3e-2 * ref["pooled"].abs().max()
+    assert ((emb * ref["embedding"]).sum(-1)).min() > 0.9995
+    assert (emb - ref["embedding"]).abs().max() < 1.5e-2

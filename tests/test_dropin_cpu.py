@@ -13,6 +13,7 @@ def test_reference_import_paths_resolve():
     from data_modules.train_dataset import LakhDataset, collate_fn  # noqa: F401
     from modules.midi_tokenizer import MidiTokenizer, MidiTokenizerConfig  # noqa: F401
     from modules.synthetiser import SynthDrum, SynthDrumConfig  # noqa: F401
+    from modules.clap_encoder import ClapWrapper  # noqa: F401
     from utils.config_utils import deep_merge_dicts, load_config_from_yaml  # noqa: F401
     from utils.mapping_utils import MappingUtils
     from utils.utils import create_mask_plain  # noqa: F401
