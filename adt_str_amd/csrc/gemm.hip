@@ -318,7 +318,7 @@ __device__ __forceinline__ void gemm_epilogue_rows(const GemmArgs& g, f32x4 (&ac
 }
 
 // =========================================================================================
-// NT kernel, LDS-DMA staging (used whenever K % 64 == 0).
+// NT kernel, LDS-DMA staging (used whenever K % 32 == 0).
 // Both operand tiles are 128 rows x 128 B and are filled by global_load_lds_dwordx4 (no VGPR
 // round trip): one wave-instruction writes 1 KiB = 8 rows, lane l -> row (l >> 3), 16-byte
 // position (l & 7).  The LDS image must stay lane-linear, so the bank swizzle is applied to the
@@ -331,7 +331,7 @@ __device__ __forceinline__ void gemm_epilogue_rows(const GemmArgs& g, f32x4 (&ac
 constexpr int kTileNT = 128 * 128;               // 16 KiB per operand tile
 __device__ __forceinline__ int swz_nt(int row) { return (row >> 1) & 7; }
 
-__device__ __forceinline__ void glds_tile(const unsigned short* __restrict__ src, long ld, int row0, int n_rows, int k0,
+__device__ __forceinline__ void glds_tile(const unsigned short* __restrict__ src, long ld, int row0, int n_rows, int k0, int k_end,
                                           unsigned char* tile, int wave, int lane) {
 #pragma unroll
   for (int i = 0; i < 4; ++i) {
@@ -339,7 +339,9 @@ __device__ __forceinline__ void glds_tile(const unsigned short* __restrict__ src
     int gr = row0 + row;
     gr = gr < n_rows ? gr : n_rows - 1;
     const int chunk = (lane & 7) ^ swz_nt(row);
-    const unsigned short* p = src + static_cast<long>(gr) * ld + k0 + chunk * 8;
+    int kc = k0 + chunk * 8;
+    kc = kc < k_end ? kc : k_end - 8;              // half-filled last tile (K % 64 == 32): re-read valid data, never multiplied
+    const unsigned short* p = src + static_cast<long>(gr) * ld + kc;
     __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)p,
                                      (__attribute__((address_space(3))) void*)(tile + (4 * wave + i) * 1024), 16, 0, 0);
   }
@@ -361,7 +363,8 @@ __global__ __launch_bounds__(kGemmThreads) void gemm_nt_glds_kernel(GemmArgs g, 
   const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7;
   const int logical = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
   const int m0 = (logical / tiles_n) * kBM, n0 = (logical % tiles_n) * kBN;
-  const int k_tiles = g.K / kBK;
+  const int k_tiles = (g.K + kBK - 1) / kBK;
+  const bool half_tail = (g.K & 32) != 0;          // K % 64 == 32: the last tile carries one 32-deep k-step
 
   f32x4 acc[4][4];
 #pragma unroll
@@ -369,8 +372,8 @@ __global__ __launch_bounds__(kGemmThreads) void gemm_nt_glds_kernel(GemmArgs g, 
 #pragma unroll
     for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-  glds_tile(g.A, g.lda, m0, g.M, 0, smem, wave, lane);
-  glds_tile(g.B, g.ldb, n0, g.N, 0, smem + kTileNT, wave, lane);
+  glds_tile(g.A, g.lda, m0, g.M, 0, g.K, smem, wave, lane);
+  glds_tile(g.B, g.ldb, n0, g.N, 0, g.K, smem + kTileNT, wave, lane);
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
 
@@ -379,8 +382,8 @@ __global__ __launch_bounds__(kGemmThreads) void gemm_nt_glds_kernel(GemmArgs g, 
     const unsigned char* tb = ta + kTileNT;
     if (kt + 1 < k_tiles) {
       unsigned char* na = smem + ((kt + 1) & 1) * 2 * kTileNT;
-      glds_tile(g.A, g.lda, m0, g.M, (kt + 1) * kBK, na, wave, lane);
-      glds_tile(g.B, g.ldb, n0, g.N, (kt + 1) * kBK, na + kTileNT, wave, lane);
+      glds_tile(g.A, g.lda, m0, g.M, (kt + 1) * kBK, g.K, na, wave, lane);
+      glds_tile(g.B, g.ldb, n0, g.N, (kt + 1) * kBK, g.K, na + kTileNT, wave, lane);
     }
     // both 32-deep k-steps' fragments are requested up front, so the second step's LDS reads
     // are in flight under the first step's MFMAs
@@ -394,6 +397,7 @@ __global__ __launch_bounds__(kGemmThreads) void gemm_nt_glds_kernel(GemmArgs g, 
       }
 #pragma unroll
     for (int ks = 0; ks < 2; ++ks) {
+      if (ks == 1 && half_tail && kt + 1 == k_tiles) break;
       __builtin_amdgcn_s_setprio(1);
 #pragma unroll
       for (int i = 0; i < 4; ++i)
@@ -610,7 +614,7 @@ extern "C" int adt_gemm_bf16(int32_t trans, int64_t M, int64_t N, int64_t K, con
   } else if (trans) {
     if (g.drop.on()) return set_error(ADT_EINVAL, "adt_gemm_bf16: dropout is not supported with trans = 1");
     hipLaunchKernelGGL((gemm_bf16_kernel<true, false>), grid, dim3(kGemmThreads), kGemmLds, st, g);
-  } else if ((K % kBK) == 0 && K > 0 && vector_epilogue_ok(g, e)) {
+  } else if ((K % 32) == 0 && K > 0 && vector_epilogue_ok(g, e)) {
     const int tm = static_cast<int>((M + kBM - 1) / kBM), tn = static_cast<int>((N + kBN - 1) / kBN);
     const dim3 g1(static_cast<unsigned>(tm) * tn);
     if (g.drop.on()) hipLaunchKernelGGL(gemm_nt_glds_kernel<true>, g1, dim3(kGemmThreads), kEpiLds, st, g, tm, tn);

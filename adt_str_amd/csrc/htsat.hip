@@ -74,48 +74,59 @@ __global__ __launch_bounds__(256) void htsat_front_kernel(const float* __restric
 // ------------------------------------------------------------------------------------ patch embedding + LayerNorm
 // token (i, j) of clip b: y[o] = bias[o] + sum_{di,dj} W[o][di*4+dj] * img[b][4i+di][4j+dj], then LayerNorm over o.
 // One wave per token; lane o and o+64 hold the channels (C <= 128).
+constexpr int kPeTok = 16;       // consecutive tokens of one image row per wave: the lane's 2 x 16 conv weights stay in registers
 __global__ __launch_bounds__(256) void htsat_patch_embed_kernel(const float* __restrict__ img, int side, const float* __restrict__ w,
                                                                 const float* __restrict__ bias, const float* __restrict__ gamma,
                                                                 const float* __restrict__ beta, float eps, int C, float* __restrict__ out32,
-                                                                unsigned short* __restrict__ out16, long n_tokens) {
+                                                                unsigned short* __restrict__ out16, long n_groups) {
   const int lane = threadIdx.x & 63;
-  const long tok = static_cast<long>(blockIdx.x) * 4 + (threadIdx.x >> 6);
-  if (tok >= n_tokens) return;
-  const int grid = side / 4;
-  const int j = static_cast<int>(tok % grid);
-  const int i = static_cast<int>((tok / grid) % grid);
-  const long b = tok / (static_cast<long>(grid) * grid);
-  float px[16];
-#pragma unroll
-  for (int di = 0; di < 4; ++di)
-#pragma unroll
-    for (int dj = 0; dj < 4; ++dj) px[di * 4 + dj] = img[(b * side + 4 * i + di) * side + 4 * j + dj];
-  float y[2] = {0.f, 0.f};
-  float s = 0.f;
+  const long grp = static_cast<long>(blockIdx.x) * 4 + (threadIdx.x >> 6);
+  if (grp >= n_groups) return;
+  const int grid = side / 4, gpr = grid / kPeTok;           // token grid side; groups per token row
+  const int j0 = static_cast<int>(grp % gpr) * kPeTok;
+  const int i = static_cast<int>((grp / gpr) % grid);
+  const long b = grp / (static_cast<long>(gpr) * grid);
+  float wr[2][16], bs[2], ga[2], be[2];
 #pragma unroll
   for (int k = 0; k < 2; ++k) {
     const int o = lane + 64 * k;
-    if (o < C) {
-      float a = bias[o];
+    const bool on = o < C;
+    bs[k] = on ? bias[o] : 0.f; ga[k] = on ? gamma[o] : 0.f; be[k] = on ? beta[o] : 0.f;
 #pragma unroll
-      for (int e = 0; e < 16; ++e) a += w[o * 16 + e] * px[e];
-      y[k] = a;
-      s += a;
-    }
+    for (int e = 0; e < 16; ++e) wr[k][e] = on ? w[o * 16 + e] : 0.f;
   }
-  const float mean = wsum(s) / C;
-  float ss = 0.f;
+  const float* rowp = img + (b * side + 4 * i) * side + 4 * j0;
+  const long tok0 = (b * grid + i) * grid + j0;
+  for (int t = 0; t < kPeTok; ++t) {
+    float px[16];
 #pragma unroll
-  for (int k = 0; k < 2; ++k)
-    if (lane + 64 * k < C) ss += (y[k] - mean) * (y[k] - mean);
-  const float rstd = rsqrtf(wsum(ss) / C + eps);
+    for (int di = 0; di < 4; ++di) {
+      const float4 v = *reinterpret_cast<const float4*>(rowp + di * side + 4 * t);
+      px[di * 4] = v.x; px[di * 4 + 1] = v.y; px[di * 4 + 2] = v.z; px[di * 4 + 3] = v.w;
+    }
+    float y[2];
 #pragma unroll
-  for (int k = 0; k < 2; ++k) {
-    const int o = lane + 64 * k;
-    if (o < C) {
-      const float v = (y[k] - mean) * rstd * gamma[o] + beta[o];
-      if (out32) out32[tok * C + o] = v;
-      if (out16) out16[tok * C + o] = f2bf_h(v);
+    for (int k = 0; k < 2; ++k) {
+      float acc = bs[k];
+#pragma unroll
+      for (int e = 0; e < 16; ++e) acc += wr[k][e] * px[e];
+      y[k] = acc;
+    }
+    const float s = y[0] + (lane + 64 < C ? y[1] : 0.f);           // lanes >= C hold exact zeros in slot 0 (zero weights and bias)
+    const float mean = wsum(s) / C;
+    float ss = 0.f;
+#pragma unroll
+    for (int k = 0; k < 2; ++k)
+      if (lane + 64 * k < C) ss += (y[k] - mean) * (y[k] - mean);
+    const float rstd = rsqrtf(wsum(ss) / C + eps);
+#pragma unroll
+    for (int k = 0; k < 2; ++k) {
+      const int o = lane + 64 * k;
+      if (o < C) {
+        const float v = (y[k] - mean) * rstd * ga[k] + be[k];
+        if (out32) out32[(tok0 + t) * C + o] = v;
+        if (out16) out16[(tok0 + t) * C + o] = f2bf_h(v);
+      }
     }
   }
 }
@@ -471,8 +482,9 @@ extern "C" int adt_htsat_front_f32(const float* mel, int64_t ld_clip, int64_t B,
 extern "C" int adt_htsat_patch_embed(const float* img, int64_t B, int32_t img_side, const float* w, const float* bias, const float* gamma,
                                      const float* beta, float eps, int32_t C, float* out32, void* out16, void* stream) {
   if (!img || !w || !bias || !gamma || !beta || (!out32 && !out16)) return set_error(ADT_EINVAL, "adt_htsat_patch_embed: null pointer");
-  if (B < 0 || img_side <= 0 || (img_side & 3) || C <= 0 || C > 128) return set_error(ADT_ESHAPE, "adt_htsat_patch_embed: img_side % 4 == 0, C <= 128");
-  const long n = B * static_cast<long>(img_side / 4) * (img_side / 4);
+  if (B < 0 || img_side <= 0 || (img_side % (4 * kPeTok)) || C <= 0 || C > 128 || !aligned16(img))
+    return set_error(ADT_ESHAPE, "adt_htsat_patch_embed: img_side % 64 == 0, C <= 128, 16-byte aligned image");
+  const long n = B * static_cast<long>(img_side / 4) * (img_side / 4) / kPeTok;
   if (n == 0) return ADT_OK;
   hipLaunchKernelGGL(htsat_patch_embed_kernel, dim3(static_cast<unsigned>((n + 3) / 4)), dim3(256), 0, STR(stream), img, img_side, w, bias, gamma,
                      beta, eps, C, out32, static_cast<unsigned short*>(out16), n);

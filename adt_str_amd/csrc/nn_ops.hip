@@ -85,6 +85,44 @@ __global__ __launch_bounds__(kRowThreads) void layernorm_fwd_kernel(LnFwdArgs a)
   }
 }
 
+// Narrow rows (D <= 4 * G, G = 16 or 32 lanes per row): 64 / G rows per wave, one float4 per lane, so the 96- and
+// 192-channel stages of the audio Swin keep the wave's lanes and its memory pipeline busy.
+template <int G>
+__global__ __launch_bounds__(kRowThreads) void layernorm_fwd_narrow_kernel(LnFwdArgs a) {
+  constexpr int kRowsPerBlock = kRowThreads / G;
+  const int sub = threadIdx.x % G;
+  const long row = static_cast<long>(blockIdx.x) * kRowsPerBlock + threadIdx.x / G;
+  const bool live = row < a.M;
+  const int nq = a.D >> 2;
+  const bool has = live && sub < nq;
+  float4 v = make_float4(0, 0, 0, 0);
+  if (has) v = reinterpret_cast<const float4*>(a.x + row * a.ldx)[sub];
+  float s = (v.x + v.y) + (v.z + v.w);
+#pragma unroll
+  for (int o = G / 2; o > 0; o >>= 1) s += __shfl_xor(s, o);
+  const float mean = s / a.D;
+  float ss = 0.f;
+  if (has) {
+    const float d0 = v.x - mean, d1 = v.y - mean, d2 = v.z - mean, d3 = v.w - mean;
+    ss = (d0 * d0 + d1 * d1) + (d2 * d2 + d3 * d3);
+  }
+#pragma unroll
+  for (int o = G / 2; o > 0; o >>= 1) ss += __shfl_xor(ss, o);
+  const float rstd = rsqrtf(ss / a.D + a.eps);
+  if (live && sub == 0) { if (a.mean) a.mean[row] = mean; if (a.rstd) a.rstd[row] = rstd; }
+  if (!has) return;
+  const float4 g = reinterpret_cast<const float4*>(a.gamma)[sub], b = reinterpret_cast<const float4*>(a.beta)[sub];
+  float4 y;
+  y.x = (v.x - mean) * rstd * g.x + b.x; y.y = (v.y - mean) * rstd * g.y + b.y;
+  y.z = (v.z - mean) * rstd * g.z + b.z; y.w = (v.w - mean) * rstd * g.w + b.w;
+  if (a.drop.on()) {
+    const uint64_t e0 = static_cast<uint64_t>(row) * a.D + 4 * sub;
+    y.x *= a.drop.scale(e0); y.y *= a.drop.scale(e0 + 1); y.z *= a.drop.scale(e0 + 2); y.w *= a.drop.scale(e0 + 3);
+  }
+  if (a.y32) reinterpret_cast<float4*>(a.y32 + row * a.ldy)[sub] = y;
+  if (a.y16) reinterpret_cast<ushort4*>(a.y16 + row * a.ldy)[sub] = make_ushort4(f2bf_(y.x), f2bf_(y.y), f2bf_(y.z), f2bf_(y.w));
+}
+
 // dx = rstd * (g - mean(g) - xhat * mean(g * xhat)),  g = dy * gamma,  xhat = (x - mean) * rstd
 // Per block (kLnBwdRows rows) partial column sums: dgamma += dy * xhat, dbeta += dy, dxsum += dx
 // (dxsum = bias gradient of the linear layer that feeds this norm's input).
@@ -419,7 +457,12 @@ extern "C" int adt_layernorm_fwd(const float* x, int64_t ldx, const float* gamma
   if (M == 0) return ADT_OK;
   LnFwdArgs a{x, ldx, gamma, beta, eps, y32, static_cast<unsigned short*>(y16), ldy, mean, rstd, static_cast<int>(M), static_cast<int>(D),
               out_drop ? make_drop(out_drop->p, out_drop->key) : Drop{0u, 0u, 1.0f}};
-  hipLaunchKernelGGL(layernorm_fwd_kernel, dim3(static_cast<unsigned>((M + 3) / 4)), dim3(kRowThreads), 0, ST(stream), a);
+  if (D <= 64)
+    hipLaunchKernelGGL(layernorm_fwd_narrow_kernel<16>, dim3(static_cast<unsigned>((M + 15) / 16)), dim3(kRowThreads), 0, ST(stream), a);
+  else if (D <= 128)
+    hipLaunchKernelGGL(layernorm_fwd_narrow_kernel<32>, dim3(static_cast<unsigned>((M + 7) / 8)), dim3(kRowThreads), 0, ST(stream), a);
+  else
+    hipLaunchKernelGGL(layernorm_fwd_kernel, dim3(static_cast<unsigned>((M + 3) / 4)), dim3(kRowThreads), 0, ST(stream), a);
   ADT_HIP_TRY(hipGetLastError());
   return ADT_OK;
 }

@@ -14,6 +14,8 @@ Workloads (``--workload``):
           (K3-K8), gradient all-reduce over RCCL when N > 1, global-norm clip + AdamW.
           Weak scaling: 64 clips per GPU, value = clips/s over all GPUs.
   logmel  BASELINE config[1]: the fused STFT->log-mel kernel alone, 256 clips per GPU.
+  clap    BASELINE config[2]: CLAP curation embedding pass, 512 one-shots @ 48 kHz per GPU -> HF-extractor log-mel (K9),
+          fused HTSAT audio tower + projection (K10/K11 + GEMMs), cosine arg-max against 48 class means (K12); embeds/s.
 
 The JSON line also carries ``roofline`` (dominant kernel measured live with HIP
 events on the stream it runs on) and, at N = 1, ``cpu_baseline`` (the oracle
@@ -94,6 +96,77 @@ def logmel_setup(dev, seed):
             "metric": "ADT hot path clips/sec (10 s @16 kHz), log-mel front end stage",
             "config": {"workload": "logmel config[1]: 256 clips x 10 s @ 16 kHz -> [256,986,128], n_fft 2048, hop 160",
                        "clips_per_gpu": B, "samples": L, "sample_rate": sr}}
+
+
+# ----------------------------------------------------------------------------- CLAP curation workload (config[2])
+HTSAT_FLOPS_PER_CLIP = 2 * 5.91e9          # 5.91 GMAC per clip
+
+
+def clap_setup(dev, seed):
+    from adt_str_amd.clap_encoder import ClapWrapper
+    from adt_str_amd import _ffi
+    from oracle import clap as o_clap         # only for the random-init model factory and the cpu_baseline leg
+    B, n_classes = 512, 48
+    rng = np.random.default_rng(7 + seed)
+    clips = []
+    for _ in range(B):                        # decaying noise / sine one-shots, peak-normalised
+        n = int(rng.integers(4800, 96001))
+        t = np.arange(n, dtype=np.float32) / 48000.0
+        x = np.exp(-t * rng.uniform(5.0, 40.0)) * (rng.standard_normal(n).astype(np.float32) * rng.uniform(0.0, 1.0)
+                                                    + np.sin(2 * np.pi * rng.uniform(40.0, 4000.0) * t))
+        clips.append(torch.from_numpy((x / np.abs(x).max()).astype(np.float32)).unsqueeze(0))
+    model = o_clap.random_clap_model(0)
+    wrap = ClapWrapper("random-init laion/clap-htsat-fused architecture", dev, 48000, clap_model=model)
+    is_longer = torch.zeros(B, dtype=torch.bool)
+    is_longer[int(rng.integers(0, B))] = True  # the extractor flags one random clip of an all-short batch
+    means = torch.nn.functional.normalize(torch.randn(n_classes, 512, generator=torch.Generator().manual_seed(1)), dim=-1).to(dev)
+    clips_d = [c.to(dev) for c in clips]
+    best = torch.empty(B, dtype=torch.int32, device=dev)
+    score = torch.empty(B, dtype=torch.float32, device=dev)
+    state = {}
+
+    def step():
+        emb = wrap.get_audio_features(clips_d, is_longer=is_longer)
+        _ffi.call("adt_cosine_argmax_f32", _ffi.dptr(emb), emb.stride(0), _ffi.dptr(means), B, 512, n_classes, 1e-8, _ffi.dptr(best),
+                  _ffi.dptr(score), None, _ffi.current_stream())
+        state["emb"] = emb
+
+    def roofline():
+        mel = wrap.features.mel(clips_d)
+        for _ in range(2):
+            wrap.encoder.forward(mel, is_longer)
+        ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        ev0.record()
+        for _ in range(5):
+            wrap.encoder.forward(mel, is_longer)
+        ev1.record()
+        torch.cuda.synchronize()
+        ms = ev0.elapsed_time(ev1) / 5
+        fl = HTSAT_FLOPS_PER_CLIP * B
+        ach = fl / (ms * 1e-3) / 1e12
+        return {"bound": "mfma", "achieved": ach, "peak": BF16_MFMA_PEAK_TF, "unit": "TFLOP/s", "frac": ach / BF16_MFMA_PEAK_TF, "traffic": None,
+                "kernel": "HTSAT encoder forward (all launches of HtsatEncoder.forward, %d clips)" % B, "kernel_ms": ms,
+                "algorithmic_flops_per_launch": fl}
+
+    def cpu_baseline(budget_s=20.0):
+        torch.set_num_threads(min(os.cpu_count() or 1, 16))
+        nb = 4
+        done, t0 = 0, time.perf_counter()
+        while time.perf_counter() - t0 < budget_s or done == 0:
+            sub = [c.reshape(-1).numpy() for c in clips[done % B:done % B + nb]]
+            mel = torch.from_numpy(o_clap.logmel_db(sub)).contiguous()
+            o_clap.audio_embeddings(model, mel.unsqueeze(1).repeat(1, 4, 1, 1), torch.zeros(len(sub), 1, dtype=torch.bool))
+            done += len(sub)
+        dt = time.perf_counter() - t0
+        return {"value": done / dt, "unit": "embeds/s", "cores": torch.get_num_threads(), "kind": "port",
+                "sample": f"{done} clips (batches of {nb}) in {dt:.1f} s: transformers ClapFeatureExtractor (float64 numpy) + "
+                          "ClapAudioModel + audio_projection, fp32 (oracle/clap.py)"}
+
+    return {"step": step, "units": B, "unit": "embeds/s", "dtype": "bf16", "roofline": roofline, "cpu_baseline": cpu_baseline,
+            "metric": "CLAP embeds/sec",
+            "config": {"workload": "clap config[2]: 512 one-shots @ 48 kHz (4 800..96 000 samples) per GPU -> HF-extractor log-mel -> fused "
+                                   "HTSAT (random-init laion/clap-htsat-fused architecture, one is_longer item) -> [512,512] unit embeddings",
+                       "clips_per_gpu": B, "sample_rate": 48000}}
 
 
 # ----------------------------------------------------------------------------- training-step workload (config[3])
@@ -223,7 +296,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=5)
-    ap.add_argument("--workload", default="train", choices=["train", "logmel"])
+    ap.add_argument("--workload", default="train", choices=["train", "logmel", "clap"])
     ap.add_argument("--dropout", type=float, default=0.1, help="model dropout (0.1 = configs/train/setting-1.yaml of the reference)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
@@ -239,7 +312,8 @@ def main():
     if world > 1:
         dist.init_process_group("nccl", device_id=dev)
 
-    wl = train_setup(dev, rank, world, args.dropout) if args.workload == "train" else logmel_setup(dev, rank)
+    wl = {"train": lambda: train_setup(dev, rank, world, args.dropout), "logmel": lambda: logmel_setup(dev, rank),
+          "clap": lambda: clap_setup(dev, rank)}[args.workload]()
     step = wl["step"]
 
     def fence():
@@ -262,7 +336,7 @@ def main():
 
     if rank == 0:
         units = wl["units"] * world * args.steps
-        line = {"metric": wl["metric"], "value": units / dt, "unit": "clips/s", "n_gpus": world, "steps": args.steps,
+        line = {"metric": wl["metric"], "value": units / dt, "unit": wl.get("unit", "clips/s"), "n_gpus": world, "steps": args.steps,
                 "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
                 "vs_baseline": None, "dtype": wl["dtype"], "data": "synthetic",
                 "config": dict(wl["config"], parallelism=f"dp{world}")}

@@ -23,7 +23,8 @@ def close(got, ref, rel, what=""):
 
 
 @pytest.mark.parametrize("M,N,K", [(128, 128, 64), (256, 384, 128), (300, 200, 192), (63104 // 8, 768, 768),
-                                   (1000, 1400, 768), (64, 2304, 768), (8192, 768, 3072), (77, 24, 64)])
+                                   (1000, 1400, 768), (64, 2304, 768), (8192, 768, 3072), (77, 24, 64),
+                                   (4096, 288, 96), (1000, 96, 96), (513, 384, 32), (300, 96, 160), (200, 40, 72)])
 def test_nt_plain(M, N, K):
     from adt_str_amd import kernels as k
     a, b = rnd((M, K), 1).bfloat16(), rnd((N, K), 2).bfloat16()

@@ -15,7 +15,7 @@ def rnd(shape, seed, scale=1.0):
     return (torch.randn(shape, generator=g) * scale).to(DEV)
 
 
-@pytest.mark.parametrize("M,D", [(1, 768), (37, 768), (4096, 768), (63, 32), (130, 1024)])
+@pytest.mark.parametrize("M,D", [(1, 768), (37, 768), (4096, 768), (63, 32), (130, 1024), (1001, 96), (77, 128), (50, 64), (33, 192)])
 def test_layernorm_fwd_bwd(M, D):
     from adt_str_amd import kernels as k
     x = rnd((M, D), 1, 2.0) + 0.5
