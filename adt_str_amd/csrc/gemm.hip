@@ -20,6 +20,8 @@
 // (bitwise reproducible, no float atomics).
 #include <hip/hip_runtime.h>
 
+#include <cstdlib>
+
 #include "adt_common.h"
 #include "dropout.h"
 
@@ -45,10 +47,19 @@ __device__ __forceinline__ unsigned short f2bf(float f) {      // round-to-neare
 __device__ __forceinline__ unsigned lds_addr(const void* p) {  // byte offset inside the workgroup's LDS
   return static_cast<unsigned>(reinterpret_cast<size_t>((__attribute__((address_space(3))) const void*)p));
 }
-__device__ __forceinline__ float gelu_erf(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752f)); }
-__device__ __forceinline__ float gelu_erf_grad(float x) {
-  return 0.5f * (1.0f + erff(x * 0.70710678118654752f)) + x * 0.3989422804014327f * __expf(-0.5f * x * x);
+// Exact-erf GELU (torch default) through erfc(a) ~= t * P5(t) * exp(-a^2), t = 1 / (1 + 0.3275911 a) (Abramowitz-Stegun 7.1.26,
+// |error| <= 1.5e-7 on erf): one v_exp, one v_rcp, straight-line; the same exp(-x^2/2) is the Gaussian of the derivative.
+// Phi(x) is formed from erfc on the side where it does not cancel.
+__device__ __forceinline__ float gauss_cdf(float x, float& e) {
+  const float a = fabsf(x) * 0.70710678118654752f;
+  const float t = __builtin_amdgcn_rcpf(fmaf(0.3275911f, a, 1.0f));
+  e = __expf(-0.5f * x * x);
+  const float poly = t * fmaf(t, fmaf(t, fmaf(t, fmaf(t, 1.061405429f, -1.453152027f), 1.421413741f), -0.284496736f), 0.254829592f);
+  const float hq = 0.5f * poly * e;
+  return x < 0.f ? hq : 1.0f - hq;
 }
+__device__ __forceinline__ float gelu_erf(float x) { float e; return x * gauss_cdf(x, e); }
+__device__ __forceinline__ float gelu_erf_grad(float x) { float e; const float c = gauss_cdf(x, e); return fmaf(x * 0.3989422804014327f, e, c); }
 
 struct GemmArgs {
   const unsigned short* A; long lda;
@@ -228,6 +239,71 @@ __global__ __launch_bounds__(kGemmThreads) void gemm_bf16_kernel(GemmArgs g) {
 // vector accesses and every output row is written as whole 16-byte pieces.
 constexpr int kEpiPitch = 132;
 constexpr int kEpiLds = 128 * kEpiPitch * 4;          // 67,584 B
+// One row piece of 8 consecutive columns: z = acc * alpha + bias -> [gelu'] -> [pre-act out] -> act -> dropout / residual -> stores.
+template <bool kDrop>
+__device__ __forceinline__ void epilogue_apply8(const GemmArgs& g, float (&z)[8], const float (&bias)[8], int row, int col) {
+  const adt_gemm_epilogue& ep = g.ep;
+#pragma unroll
+  for (int e = 0; e < 8; ++e) z[e] = z[e] * ep.alpha + bias[e];
+  if (ep.gelu_grad_of) {
+    const uint4 uv = *reinterpret_cast<const uint4*>(reinterpret_cast<const unsigned short*>(ep.gelu_grad_of) + static_cast<long>(row) * ep.ld_gelu_grad + col);
+    const unsigned w[4] = {uv.x, uv.y, uv.z, uv.w};
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      z[2 * e] *= gelu_erf_grad(__uint_as_float(w[e] << 16));
+      z[2 * e + 1] *= gelu_erf_grad(__uint_as_float(w[e] & 0xffff0000u));
+    }
+  }
+  if (ep.pre_act_out) {
+    uint4 o;
+    o.x = f2bf(z[0]) | (static_cast<unsigned>(f2bf(z[1])) << 16); o.y = f2bf(z[2]) | (static_cast<unsigned>(f2bf(z[3])) << 16);
+    o.z = f2bf(z[4]) | (static_cast<unsigned>(f2bf(z[5])) << 16); o.w = f2bf(z[6]) | (static_cast<unsigned>(f2bf(z[7])) << 16);
+    *reinterpret_cast<uint4*>(reinterpret_cast<unsigned short*>(ep.pre_act_out) + static_cast<long>(row) * ep.ld_pre_act + col) = o;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) z[e] = bf2f(f2bf(z[e]));       // the activation sees the value the backward will read
+  }
+  if (ep.act == 1) {
+#pragma unroll
+    for (int e = 0; e < 8; ++e) z[e] = gelu_erf(z[e]);
+  } else if (ep.act == 2) {
+#pragma unroll
+    for (int e = 0; e < 8; ++e) z[e] = fmaxf(z[e], 0.0f);
+  }
+  float keep[8] = {1.f, 1.f, 1.f, 1.f, 1.f, 1.f, 1.f, 1.f};
+  if (kDrop) {
+    const uint64_t base = static_cast<uint64_t>(row) * g.N + col;       // multiple of 8: the 8 elements share the index's high word
+    const uint32_t key2 = mix32(static_cast<uint32_t>(base >> 32) ^ g.drop.key), lo = static_cast<uint32_t>(base);
+#pragma unroll
+    for (int e = 0; e < 8; ++e) keep[e] = g.drop.scale32(lo + e, key2);
+    if (!ep.drop_after_residual) {
+#pragma unroll
+      for (int e = 0; e < 8; ++e) z[e] *= keep[e];
+    }
+  }
+  if (ep.residual) {
+    const long rr = ep.res_row_mod > 0 ? (row % ep.res_row_mod) : row;
+    const float* rp = reinterpret_cast<const float*>(ep.residual) + rr * ep.ld_res + col;
+    const float4 r0 = *reinterpret_cast<const float4*>(rp), r1 = *reinterpret_cast<const float4*>(rp + 4);
+    z[0] += r0.x; z[1] += r0.y; z[2] += r0.z; z[3] += r0.w; z[4] += r1.x; z[5] += r1.y; z[6] += r1.z; z[7] += r1.w;
+  }
+  if (kDrop && ep.drop_after_residual) {
+#pragma unroll
+    for (int e = 0; e < 8; ++e) z[e] *= keep[e];
+  }
+  uint4 o16;
+  o16.x = f2bf(z[0]) | (static_cast<unsigned>(f2bf(z[1])) << 16); o16.y = f2bf(z[2]) | (static_cast<unsigned>(f2bf(z[3])) << 16);
+  o16.z = f2bf(z[4]) | (static_cast<unsigned>(f2bf(z[5])) << 16); o16.w = f2bf(z[6]) | (static_cast<unsigned>(f2bf(z[7])) << 16);
+  if (ep.aux_bf16_out)
+    *reinterpret_cast<uint4*>(reinterpret_cast<unsigned short*>(ep.aux_bf16_out) + static_cast<long>(row) * ep.ld_aux + col) = o16;
+  if (ep.out_fp32) {
+    float* cp = reinterpret_cast<float*>(g.C) + static_cast<long>(row) * g.ldc + col;
+    *reinterpret_cast<float4*>(cp) = *reinterpret_cast<float4*>(z);
+    *reinterpret_cast<float4*>(cp + 4) = *reinterpret_cast<float4*>(z + 4);
+  } else {
+    *reinterpret_cast<uint4*>(reinterpret_cast<unsigned short*>(g.C) + static_cast<long>(row) * g.ldc + col) = o16;
+  }
+}
+
 template <bool kDrop>
 __device__ __forceinline__ void gemm_epilogue_rows(const GemmArgs& g, f32x4 (&acc)[4][4], float* ct, int m0, int n0,
                                                    int wm, int wn, int tid, int lane) {
@@ -239,14 +315,13 @@ __device__ __forceinline__ void gemm_epilogue_rows(const GemmArgs& g, f32x4 (&ac
       for (int r = 0; r < 4; ++r)
         ct[(wm * 64 + i * 16 + 4 * (lane >> 4) + r) * kEpiPitch + wn * 64 + j * 16 + (lane & 15)] = acc[i][j][r];
   __syncthreads();
-  const adt_gemm_epilogue& ep = g.ep;
   const int c8 = (tid & 15) * 8;
   const int col = n0 + c8;
   const bool full = col + 8 <= g.N;                     // N % 8 == 0 is guaranteed for bf16 C (checked on the host)
   float bias[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-  if (ep.bias && full) {
-    *reinterpret_cast<float4*>(bias) = *reinterpret_cast<const float4*>(ep.bias + col);
-    *reinterpret_cast<float4*>(bias + 4) = *reinterpret_cast<const float4*>(ep.bias + col + 4);
+  if (g.ep.bias && full) {
+    *reinterpret_cast<float4*>(bias) = *reinterpret_cast<const float4*>(g.ep.bias + col);
+    *reinterpret_cast<float4*>(bias + 4) = *reinterpret_cast<const float4*>(g.ep.bias + col + 4);
   }
 #pragma unroll 2
   for (int pass = 0; pass < 8; ++pass) {
@@ -256,64 +331,7 @@ __device__ __forceinline__ void gemm_epilogue_rows(const GemmArgs& g, f32x4 (&ac
     float z[8];
     *reinterpret_cast<float4*>(z) = *reinterpret_cast<const float4*>(ct + lr * kEpiPitch + c8);
     *reinterpret_cast<float4*>(z + 4) = *reinterpret_cast<const float4*>(ct + lr * kEpiPitch + c8 + 4);
-#pragma unroll
-    for (int e = 0; e < 8; ++e) z[e] = z[e] * ep.alpha + bias[e];
-    if (ep.gelu_grad_of) {
-      const uint4 uv = *reinterpret_cast<const uint4*>(reinterpret_cast<const unsigned short*>(ep.gelu_grad_of) + static_cast<long>(row) * ep.ld_gelu_grad + col);
-      const unsigned w[4] = {uv.x, uv.y, uv.z, uv.w};
-#pragma unroll
-      for (int e = 0; e < 4; ++e) {
-        z[2 * e] *= gelu_erf_grad(__uint_as_float(w[e] << 16));
-        z[2 * e + 1] *= gelu_erf_grad(__uint_as_float(w[e] & 0xffff0000u));
-      }
-    }
-    if (ep.pre_act_out) {
-      uint4 o;
-      o.x = f2bf(z[0]) | (static_cast<unsigned>(f2bf(z[1])) << 16); o.y = f2bf(z[2]) | (static_cast<unsigned>(f2bf(z[3])) << 16);
-      o.z = f2bf(z[4]) | (static_cast<unsigned>(f2bf(z[5])) << 16); o.w = f2bf(z[6]) | (static_cast<unsigned>(f2bf(z[7])) << 16);
-      *reinterpret_cast<uint4*>(reinterpret_cast<unsigned short*>(ep.pre_act_out) + static_cast<long>(row) * ep.ld_pre_act + col) = o;
-#pragma unroll
-      for (int e = 0; e < 8; ++e) z[e] = bf2f(f2bf(z[e]));       // the activation sees the value the backward will read
-    }
-    if (ep.act == 1) {
-#pragma unroll
-      for (int e = 0; e < 8; ++e) z[e] = gelu_erf(z[e]);
-    } else if (ep.act == 2) {
-#pragma unroll
-      for (int e = 0; e < 8; ++e) z[e] = fmaxf(z[e], 0.0f);
-    }
-    float keep[8] = {1.f, 1.f, 1.f, 1.f, 1.f, 1.f, 1.f, 1.f};
-    if (kDrop) {
-      const uint64_t base = static_cast<uint64_t>(row) * g.N + col;
-#pragma unroll
-      for (int e = 0; e < 8; ++e) keep[e] = g.drop.scale(base + e);
-      if (!ep.drop_after_residual) {
-#pragma unroll
-        for (int e = 0; e < 8; ++e) z[e] *= keep[e];
-      }
-    }
-    if (ep.residual) {
-      const long rr = ep.res_row_mod > 0 ? (row % ep.res_row_mod) : row;
-      const float* rp = reinterpret_cast<const float*>(ep.residual) + rr * ep.ld_res + col;
-      const float4 r0 = *reinterpret_cast<const float4*>(rp), r1 = *reinterpret_cast<const float4*>(rp + 4);
-      z[0] += r0.x; z[1] += r0.y; z[2] += r0.z; z[3] += r0.w; z[4] += r1.x; z[5] += r1.y; z[6] += r1.z; z[7] += r1.w;
-    }
-    if (kDrop && ep.drop_after_residual) {
-#pragma unroll
-      for (int e = 0; e < 8; ++e) z[e] *= keep[e];
-    }
-    uint4 o16;
-    o16.x = f2bf(z[0]) | (static_cast<unsigned>(f2bf(z[1])) << 16); o16.y = f2bf(z[2]) | (static_cast<unsigned>(f2bf(z[3])) << 16);
-    o16.z = f2bf(z[4]) | (static_cast<unsigned>(f2bf(z[5])) << 16); o16.w = f2bf(z[6]) | (static_cast<unsigned>(f2bf(z[7])) << 16);
-    if (ep.aux_bf16_out)
-      *reinterpret_cast<uint4*>(reinterpret_cast<unsigned short*>(ep.aux_bf16_out) + static_cast<long>(row) * ep.ld_aux + col) = o16;
-    if (ep.out_fp32) {
-      float* cp = reinterpret_cast<float*>(g.C) + static_cast<long>(row) * g.ldc + col;
-      *reinterpret_cast<float4*>(cp) = *reinterpret_cast<float4*>(z);
-      *reinterpret_cast<float4*>(cp + 4) = *reinterpret_cast<float4*>(z + 4);
-    } else {
-      *reinterpret_cast<uint4*>(reinterpret_cast<unsigned short*>(g.C) + static_cast<long>(row) * g.ldc + col) = o16;
-    }
+    epilogue_apply8<kDrop>(g, z, bias, row, col);
   }
 }
 
@@ -363,8 +381,9 @@ __global__ __launch_bounds__(kGemmThreads) void gemm_nt_glds_kernel(GemmArgs g, 
   const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7;
   const int logical = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
   const int m0 = (logical / tiles_n) * kBM, n0 = (logical % tiles_n) * kBN;
-  const int k_tiles = (g.K + kBK - 1) / kBK;
-  const bool half_tail = (g.K & 32) != 0;          // K % 64 == 32: the last tile carries one 32-deep k-step
+  const int k_full = g.K / kBK;
+  const bool half_tail = (g.K & 32) != 0;          // K % 64 == 32: one more tile that carries a single 32-deep k-step
+  const int k_tiles = k_full + (half_tail ? 1 : 0);
 
   f32x4 acc[4][4];
 #pragma unroll
@@ -377,7 +396,7 @@ __global__ __launch_bounds__(kGemmThreads) void gemm_nt_glds_kernel(GemmArgs g, 
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
 
-  for (int kt = 0; kt < k_tiles; ++kt) {
+  for (int kt = 0; kt < k_full; ++kt) {
     const unsigned char* ta = smem + (kt & 1) * 2 * kTileNT;
     const unsigned char* tb = ta + kTileNT;
     if (kt + 1 < k_tiles) {
@@ -397,7 +416,6 @@ __global__ __launch_bounds__(kGemmThreads) void gemm_nt_glds_kernel(GemmArgs g, 
       }
 #pragma unroll
     for (int ks = 0; ks < 2; ++ks) {
-      if (ks == 1 && half_tail && kt + 1 == k_tiles) break;
       __builtin_amdgcn_s_setprio(1);
 #pragma unroll
       for (int i = 0; i < 4; ++i)
@@ -409,7 +427,203 @@ __global__ __launch_bounds__(kGemmThreads) void gemm_nt_glds_kernel(GemmArgs g, 
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
   }
+  if (half_tail) {
+    const unsigned char* ta = smem + (k_full & 1) * 2 * kTileNT;
+    const unsigned char* tb = ta + kTileNT;
+    bf16x8 fa[4], fb[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      fa[i] = frag_glds(ta, wm * 64 + i * 16, 0, lane);
+      fb[i] = frag_glds(tb, wn * 64 + i * 16, 0, lane);
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[i], fb[j], acc[i][j], 0, 0, 0);
+    __syncthreads();
+  }
   gemm_epilogue_rows<kDrop>(g, acc, reinterpret_cast<float*>(smem), m0, n0, wm, wn, tid, lane);
+}
+
+// =========================================================================================
+// NT kernel, 256 x 256 x 64 tile, 8 waves (2 x 4), LDS-DMA staging with the DMA in flight across barriers.
+//
+// Used for the large forward / dgrad GEMMs (>= 2 blocks per CU, K % 64 == 0).  Each wave owns a 128 x 64 output
+// (8 x 4 MFMA blocks, 128 fp32 accumulators) and walks it in four 64 x 32 quadrants per K-tile; one quadrant = one
+// "phase" = 16 MFMAs.  LDS (128 KiB) = 2 buffers x 4 half-tiles of 128 rows x 128 B:
+//     A_h : rows {wr * 128 + h * 64 + 0..63} of the block tile for wr = 0, 1        (the A rows of quadrant half h)
+//     B_h : rows {wc * 64 + h * 32 + 0..31} of the B tile for wc = 0..3             (the B rows of quadrant half h)
+// so every half-tile is consumed in exactly one phase by all waves:
+//     phase 1: read B_0 (4 x ds_read_b128) + A_0 (8)   MFMA (a0, b0)      DMA issue: A_1 of tile t+1
+//     phase 2: read B_1 (4)                            MFMA (a0, b1)      DMA issue: B_0 of tile t+2
+//     phase 3: read A_1 (8)                            MFMA (a1, b1)      DMA issue: A_0 of tile t+2
+//     phase 4: --                                      MFMA (a1, b0)      DMA issue: B_1 of tile t+2, then s_waitcnt vmcnt(6)
+// Three half-tiles (6 DMA instructions per wave) stay in flight across the phase-4 wait, which retires tile t+1 (read
+// from phase 1 of the next tile on).  The two wave rows run one barrier apart (wr == 1 takes an extra s_barrier up
+// front, wr == 0 one at the end): while one group issues LDS reads / DMA the other one runs its MFMAs on the same SIMDs.
+// Hazards under that stagger (G0 = ahead): a DMA-filled half is read >= 1 phase after the counted vmcnt that retires it;
+// a half is refilled >= 2 phases after its last ds_read, or 1 phase after when the reads were retired before the reading
+// phase's first barrier (B_0: lgkmcnt(8) in phase 1).  All barriers are raw s_barrier (a __syncthreads would drain
+// the DMA queue).  Past-the-end tiles re-fetch the last tile into halves nobody reads again, so the counts stay exact.
+// Swizzle as in the 128^2 kernel: position p of LDS row r holds the row's 16-byte chunk p ^ ((r >> 1) & 7).
+constexpr int kBig = 256;
+constexpr int kBigThreads = 512;
+constexpr int kHalfTile = 128 * 128;                 // 16 KiB
+constexpr int kBigBuf = 4 * kHalfTile;               // A_0 | A_1 | B_0 | B_1
+constexpr int kBigLds = 2 * kBigBuf;                 // 131,072 B
+constexpr int kEpi2Pitch = 68;                       // floats; wave-private 32 x 64 transposition tile
+
+#define ADT_DS_READ_B128(dst, addr, imm) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(dst) : "v"(addr), "i"(imm))
+
+template <bool kDrop>
+__global__ __launch_bounds__(kBigThreads) void gemm_nt_256_kernel(GemmArgs g, int tiles_m, int tiles_n) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wr = wave >> 2, wc = wave & 3;
+  const int nwg = tiles_m * tiles_n, bid = blockIdx.x;
+  const int q8 = nwg >> 3, r8 = nwg & 7, xcd = bid & 7;
+  const int logical = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + (bid >> 3);
+  const int m0 = (logical / tiles_n) * kBig, n0 = (logical % tiles_n) * kBig;
+  const int k_tiles = g.K / kBK;
+
+  // ---- DMA source pointers: wave w, instruction j fills LDS rows 8 * (2w + j) + (lane >> 3) of a half-tile
+  const unsigned short* pa[2][2];      // [h][j]
+  const unsigned short* pb[2][2];
+#pragma unroll
+  for (int j = 0; j < 2; ++j) {
+    const int r = 8 * (2 * wave + j) + (lane >> 3);
+    const int chunk = (lane & 7) ^ ((r >> 1) & 7);
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+      int ar = m0 + (r >> 6) * 128 + h * 64 + (r & 63);
+      ar = ar < g.M ? ar : g.M - 1;
+      pa[h][j] = g.A + static_cast<long>(ar) * g.lda + chunk * 8;
+      int br = n0 + (r >> 5) * 64 + h * 32 + (r & 31);
+      br = br < g.N ? br : g.N - 1;
+      pb[h][j] = g.B + static_cast<long>(br) * g.ldb + chunk * 8;
+    }
+  }
+  auto dma = [&](const unsigned short* const (&p)[2], int tile, int buf, int half_slot) {
+    const int tt = tile < k_tiles ? tile : k_tiles - 1;
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(p[j] + static_cast<long>(tt) * kBK),
+                                       (__attribute__((address_space(3))) void*)(smem + buf * kBigBuf + half_slot * kHalfTile + (2 * wave + j) * 1024),
+                                       16, 0, 0);
+  };
+
+  // ---- fragment read addresses (bytes inside a half-tile): row = base + 16 i + (lane & 15), chunk (4 ks + (lane >> 4)) ^ swz
+  const unsigned base0 = lds_addr(smem);
+  const int sw = ((lane & 15) >> 1) & 7;
+  const unsigned c0 = static_cast<unsigned>(((lane >> 4) ^ sw) * 16), c1 = c0 ^ 64u;
+  const unsigned a_row = static_cast<unsigned>((wr * 64 + (lane & 15)) * 128), b_row = static_cast<unsigned>((wc * 32 + (lane & 15)) * 128);
+  const unsigned a_k0 = base0 + a_row + c0, a_k1 = base0 + a_row + c1;            // + h * kHalfTile + i * 2048 (+ buffer)
+  const unsigned b_k0 = base0 + 2 * kHalfTile + b_row + c0, b_k1 = base0 + 2 * kHalfTile + b_row + c1;
+
+  f32x4 acc[8][4];
+#pragma unroll
+  for (int i = 0; i < 8; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  // ---- prologue: tile 0 complete, B_0 / A_0 / B_1 of tile 1 in flight
+  dma(pa[0], 0, 0, 0); dma(pb[0], 0, 0, 2); dma(pa[1], 0, 0, 1); dma(pb[1], 0, 0, 3);
+  dma(pb[0], 1, 1, 2); dma(pa[0], 1, 1, 0); dma(pb[1], 1, 1, 3);
+  asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+  asm volatile("s_barrier" ::: "memory");
+  if (wr == 1) asm volatile("s_barrier" ::: "memory");
+
+  bf16x8 fa[4][2], fb0[2][2], fb1[2][2];
+#define ADT_MFMA_QUAD(I0, FB, J0)                                                                                  \
+  do {                                                                                                             \
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                                                             \
+    __builtin_amdgcn_sched_barrier(0);                                                                             \
+    __builtin_amdgcn_s_setprio(1);                                                                                 \
+    _Pragma("unroll") for (int ks = 0; ks < 2; ++ks)                                                               \
+      _Pragma("unroll") for (int i = 0; i < 4; ++i)                                                                \
+        _Pragma("unroll") for (int j = 0; j < 2; ++j)                                                              \
+          acc[I0 + i][J0 + j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[i][ks], FB[j][ks], acc[I0 + i][J0 + j], 0, 0, 0); \
+    __builtin_amdgcn_s_setprio(0);                                                                                 \
+    __builtin_amdgcn_sched_barrier(0);                                                                             \
+    asm volatile("s_barrier" ::: "memory");                                                                        \
+  } while (0)
+
+  for (int t = 0; t < k_tiles; ++t) {
+    const int buf = t & 1;
+    const unsigned bo = static_cast<unsigned>(buf) * kBigBuf;
+    const unsigned ak0 = a_k0 + bo, ak1 = a_k1 + bo, bk0 = b_k0 + bo, bk1 = b_k1 + bo;
+    // ---------------- phase 1: B_0 then A_0; DMA A_1(t+1)
+    ADT_DS_READ_B128(fb0[0][0], bk0, 0);    ADT_DS_READ_B128(fb0[0][1], bk1, 0);
+    ADT_DS_READ_B128(fb0[1][0], bk0, 2048); ADT_DS_READ_B128(fb0[1][1], bk1, 2048);
+    __builtin_amdgcn_sched_barrier(0);
+    ADT_DS_READ_B128(fa[0][0], ak0, 0);     ADT_DS_READ_B128(fa[0][1], ak1, 0);
+    ADT_DS_READ_B128(fa[1][0], ak0, 2048);  ADT_DS_READ_B128(fa[1][1], ak1, 2048);
+    ADT_DS_READ_B128(fa[2][0], ak0, 4096);  ADT_DS_READ_B128(fa[2][1], ak1, 4096);
+    ADT_DS_READ_B128(fa[3][0], ak0, 6144);  ADT_DS_READ_B128(fa[3][1], ak1, 6144);
+    dma(pa[1], t + 1, buf ^ 1, 1);
+    asm volatile("s_waitcnt lgkmcnt(8)" ::: "memory");           // B_0 reads retired before the barrier: B_0 may be refilled in phase 2
+    asm volatile("s_barrier" ::: "memory");
+    ADT_MFMA_QUAD(0, fb0, 0);
+    // ---------------- phase 2: B_1; DMA B_0(t+2)
+    ADT_DS_READ_B128(fb1[0][0], bk0, kHalfTile);        ADT_DS_READ_B128(fb1[0][1], bk1, kHalfTile);
+    ADT_DS_READ_B128(fb1[1][0], bk0, kHalfTile + 2048); ADT_DS_READ_B128(fb1[1][1], bk1, kHalfTile + 2048);
+    dma(pb[0], t + 2, buf, 2);
+    asm volatile("s_barrier" ::: "memory");
+    ADT_MFMA_QUAD(0, fb1, 2);
+    // ---------------- phase 3: A_1; DMA A_0(t+2)
+    ADT_DS_READ_B128(fa[0][0], ak0, kHalfTile);         ADT_DS_READ_B128(fa[0][1], ak1, kHalfTile);
+    ADT_DS_READ_B128(fa[1][0], ak0, kHalfTile + 2048);  ADT_DS_READ_B128(fa[1][1], ak1, kHalfTile + 2048);
+    ADT_DS_READ_B128(fa[2][0], ak0, kHalfTile + 4096);  ADT_DS_READ_B128(fa[2][1], ak1, kHalfTile + 4096);
+    ADT_DS_READ_B128(fa[3][0], ak0, kHalfTile + 6144);  ADT_DS_READ_B128(fa[3][1], ak1, kHalfTile + 6144);
+    dma(pa[0], t + 2, buf, 0);
+    asm volatile("s_barrier" ::: "memory");
+    ADT_MFMA_QUAD(4, fb1, 2);
+    // ---------------- phase 4: DMA B_1(t+2); retire tile t+1
+    dma(pb[1], t + 2, buf, 3);
+    asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+    asm volatile("s_barrier" ::: "memory");
+    ADT_MFMA_QUAD(4, fb0, 0);
+  }
+#undef ADT_MFMA_QUAD
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  if (wr == 0) asm volatile("s_barrier" ::: "memory");
+  asm volatile("s_barrier" ::: "memory");              // every DMA has landed and every fragment read is done: LDS is free
+
+  // ---- epilogue: wave-private 32 x 64 transposition passes, then 8-column row pieces (as the 128^2 kernel)
+  float* ct = reinterpret_cast<float*>(smem) + wave * (32 * kEpi2Pitch);
+  const int c8 = (lane & 7) * 8;
+  const int col = n0 + wc * 64 + c8;
+  const bool full = col + 8 <= g.N;
+  float bias[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  if (g.ep.bias && full) {
+    *reinterpret_cast<float4*>(bias) = *reinterpret_cast<const float4*>(g.ep.bias + col);
+    *reinterpret_cast<float4*>(bias + 4) = *reinterpret_cast<const float4*>(g.ep.bias + col + 4);
+  }
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+#pragma unroll
+    for (int ii = 0; ii < 2; ++ii)
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) ct[(ii * 16 + 4 * (lane >> 4) + r) * kEpi2Pitch + j * 16 + (lane & 15)] = acc[2 * q + ii][j][r];
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+#pragma unroll
+    for (int pass = 0; pass < 4; ++pass) {
+      const int lr = pass * 8 + (lane >> 3);
+      const int row = m0 + wr * 128 + q * 32 + lr;
+      float z[8];
+      *reinterpret_cast<float4*>(z) = *reinterpret_cast<const float4*>(ct + lr * kEpi2Pitch + c8);
+      *reinterpret_cast<float4*>(z + 4) = *reinterpret_cast<const float4*>(ct + lr * kEpi2Pitch + c8 + 4);
+      if (row < g.M && full) epilogue_apply8<kDrop>(g, z, bias, row, col);
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+  }
 }
 
 // =========================================================================================
@@ -541,6 +755,16 @@ static bool vector_epilogue_ok(const GemmArgs& g, const adt_gemm_epilogue& e) {
          ok(e.pre_act_out, e.ld_pre_act, 2) && ok(e.gelu_grad_of, e.ld_gelu_grad, 2) && ok(e.aux_bf16_out, e.ld_aux, 2);
 }
 
+// 256^2 tile: when there are at least two blocks per CU of it and the K loop is long enough to amortise its prologue.
+// ADT_GEMM_TILE=128 / 256 in the environment forces one structure (A/B measurements, tests).
+static bool use_big_tile(int64_t M, int64_t N, int64_t K) {
+  static const int forced = [] { const char* v = getenv("ADT_GEMM_TILE"); return v ? atoi(v) : 0; }();
+  if (K <= 0 || (K % kBK) != 0 || K < 2 * kBK || forced == 128) return false;
+  if (forced == 256) return true;
+  const int64_t tiles = ((M + kBig - 1) / kBig) * ((N + kBig - 1) / kBig);
+  return tiles >= 512 && K >= 256;
+}
+
 static int pick_splits(int M, int N, int K, int n_cu) {
   const int tiles = ((M + kBM - 1) / kBM) * ((N + kBN - 1) / kBN);
   const int k_tiles = (K + kBK - 1) / kBK;
@@ -606,6 +830,8 @@ extern "C" int adt_gemm_bf16(int32_t trans, int64_t M, int64_t N, int64_t K, con
     ADT_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_nt_glds_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, kEpiLds));
     ADT_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_nt_glds_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, kEpiLds));
     ADT_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_tn_glds_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, kEpiLds));
+    ADT_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_nt_256_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, kBigLds));
+    ADT_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_nt_256_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, kBigLds));
     attr_dev = dev;
   }
   if (trans && (K % kBK) == 0 && K > 0 && vector_epilogue_ok(g, e) && M >= 8 && (splits == 1 || aligned16(ws))) {
@@ -614,6 +840,11 @@ extern "C" int adt_gemm_bf16(int32_t trans, int64_t M, int64_t N, int64_t K, con
   } else if (trans) {
     if (g.drop.on()) return set_error(ADT_EINVAL, "adt_gemm_bf16: dropout is not supported with trans = 1");
     hipLaunchKernelGGL((gemm_bf16_kernel<true, false>), grid, dim3(kGemmThreads), kGemmLds, st, g);
+  } else if (use_big_tile(M, N, K) && vector_epilogue_ok(g, e)) {
+    const int tm = static_cast<int>((M + kBig - 1) / kBig), tn = static_cast<int>((N + kBig - 1) / kBig);
+    const dim3 g1(static_cast<unsigned>(tm) * tn);
+    if (g.drop.on()) hipLaunchKernelGGL(gemm_nt_256_kernel<true>, g1, dim3(kBigThreads), kBigLds, st, g, tm, tn);
+    else hipLaunchKernelGGL(gemm_nt_256_kernel<false>, g1, dim3(kBigThreads), kBigLds, st, g, tm, tn);
   } else if ((K % 32) == 0 && K > 0 && vector_epilogue_ok(g, e)) {
     const int tm = static_cast<int>((M + kBM - 1) / kBM), tn = static_cast<int>((N + kBN - 1) / kBN);
     const dim3 g1(static_cast<unsigned>(tm) * tn);

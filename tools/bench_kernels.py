@@ -25,13 +25,22 @@ def timeit(fn, n=20, warm=3):
 
 def main():
     M = 64 * 986
-    print("== NT GEMM (forward / dgrad) ==")
+    only = sys.argv[1] if len(sys.argv) > 1 else ""
+    print("== NT GEMM (forward / dgrad) ==  ADT_GEMM_TILE=%s" % os.environ.get("ADT_GEMM_TILE", "auto"))
     for (m, n, k) in [(M, 3072, 768), (M, 768, 3072), (M, 2304, 768), (M, 768, 768), (M, 768, 2304), (M, 1536, 768), (8192, 1400, 768),
                       (8192, 768, 1400), (8192, 3072, 768), (4096, 4096, 4096), (8192, 8192, 8192)]:
         a = torch.randn((m, k), device=dev).bfloat16()
         b = torch.randn((n, k), device=dev).bfloat16()
         ms = timeit(lambda: K.gemm(a, b))
         print(f"NT M={m} N={n} K={k}: {ms:.3f} ms  {2.0*m*n*k/ms/1e9:.1f} TFLOP/s")
+    bias = torch.zeros(3072, device=dev)
+    a = torch.randn((M, 768), device=dev).bfloat16()
+    b = torch.randn((3072, 768), device=dev).bfloat16()
+    u = torch.empty((M, 3072), device=dev, dtype=torch.bfloat16)
+    ms = timeit(lambda: K.gemm(a, b, bias=bias, act=1, pre_act_out=u))
+    print(f"NT FFN1 + bias + GELU + pre-act: {ms:.3f} ms  {2.0*M*3072*768/ms/1e9:.1f} TFLOP/s")
+    if only == "nt":
+        return
     print("== TN GEMM (wgrad) ==")
     for (kk, m, n) in [(M, 768, 3072), (M, 3072, 768), (M, 2304, 768), (M, 768, 768), (M, 1536, 768), (8192, 1400, 768)]:
         a = torch.randn((kk, m), device=dev).bfloat16()
