@@ -42,6 +42,19 @@ HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 FP32_VECTOR_PEAK_TF = 157.3
 BF16_MFMA_PEAK_TF = 2500.0     # dense bf16 MFMA peak (no sparsity)
 
+def pmc_traffic_bytes(name):
+    """HBM-side bytes per launch of the roofline kernel from the committed rocprofv3 --pmc summary of the same launch
+    (tools/run_pmc_*.sh; FETCH_SIZE / WRITE_SIZE are in KiB, and gfx950 tallies 128-byte read requests at 64 bytes:
+    MI355X_MICROARCH.md, HBM section).  None when the summary is not there."""
+    path = os.path.join(ROOT, "profiles", "r01", name)
+    try:
+        with open(path) as f:
+            d = json.load(f)
+        return (2.0 * d["FETCH_SIZE"]["mean"] + d["WRITE_SIZE"]["mean"]) * 1024.0
+    except (OSError, KeyError, ValueError):
+        return None
+
+
 SETTING1 = dict(enc_layers=4, dec_layers=4, nhead=6, d_query=128, tgt_vocab_size=1400, n_mels=128)
 
 
@@ -74,7 +87,7 @@ def logmel_setup(dev, seed):
         ms = ev0.elapsed_time(ev1) / 20
         ach = algo_bytes / (ms * 1e-3) / 1e9
         return {"bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS,
-                "traffic": None, "kernel": "adt::logmel_kernel", "kernel_ms": ms, "algorithmic_bytes_per_launch": algo_bytes,
+                "traffic": pmc_traffic_bytes("logmel_pmc_summary.json"), "kernel": "adt::logmel_kernel", "kernel_ms": ms, "algorithmic_bytes_per_launch": algo_bytes,
                 "fp32_vector_tflops": algo_flops / (ms * 1e-3) / 1e12,
                 "fp32_vector_frac": algo_flops / (ms * 1e-3) / 1e12 / FP32_VECTOR_PEAK_TF}
 
@@ -259,8 +272,10 @@ def train_setup(dev, seed, world, dropout):
         fl = 2.0 * M * N * Kd
         ach = fl / (ms * 1e-3) / 1e12
         return {"bound": "mfma", "achieved": ach, "peak": BF16_MFMA_PEAK_TF, "unit": "TFLOP/s", "frac": ach / BF16_MFMA_PEAK_TF,
-                "traffic": None, "kernel": "adt::gemm_bf16_kernel<false> (FFN linear1 + bias + GELU, M=%d N=%d K=%d)" % (M, N, Kd),
-                "kernel_ms": ms, "algorithmic_flops_per_launch": fl}
+                "traffic": pmc_traffic_bytes("gemm_pmc_summary.json"),
+                "kernel": "adt::gemm_nt_256_kernel<false> (FFN linear1 + bias + GELU + saved pre-activation, M=%d N=%d K=%d)" % (M, N, Kd),
+                "kernel_ms": ms, "algorithmic_flops_per_launch": fl,
+                "algorithmic_bytes_per_launch": 2.0 * (M * Kd + N * Kd + 2 * M * N)}
 
     def cpu_baseline(budget_s=20.0):
         from oracle import adt as o_adt

@@ -27,7 +27,7 @@ def main():
     M = 64 * 986
     only = sys.argv[1] if len(sys.argv) > 1 else ""
     print("== NT GEMM (forward / dgrad) ==  ADT_GEMM_TILE=%s" % os.environ.get("ADT_GEMM_TILE", "auto"))
-    for (m, n, k) in [(M, 3072, 768), (M, 768, 3072), (M, 2304, 768), (M, 768, 768), (M, 768, 2304), (M, 1536, 768), (8192, 1400, 768),
+    for (m, n, k) in [] if only == "attn" else [(M, 3072, 768), (M, 768, 3072), (M, 2304, 768), (M, 768, 768), (M, 768, 2304), (M, 1536, 768), (8192, 1400, 768),
                       (8192, 768, 1400), (8192, 3072, 768), (4096, 4096, 4096), (8192, 8192, 8192)]:
         a = torch.randn((m, k), device=dev).bfloat16()
         b = torch.randn((n, k), device=dev).bfloat16()
@@ -42,7 +42,7 @@ def main():
     if only == "nt":
         return
     print("== TN GEMM (wgrad) ==")
-    for (kk, m, n) in [(M, 768, 3072), (M, 3072, 768), (M, 2304, 768), (M, 768, 768), (M, 1536, 768), (8192, 1400, 768)]:
+    for (kk, m, n) in ([] if only == "attn" else [(M, 768, 3072), (M, 3072, 768), (M, 2304, 768), (M, 768, 768), (M, 1536, 768), (8192, 1400, 768)]):
         a = torch.randn((kk, m), device=dev).bfloat16()
         b = torch.randn((kk, n), device=dev).bfloat16()
         out = torch.empty((m, n), device=dev)
@@ -62,6 +62,14 @@ def main():
     ms = timeit(lambda: K.attn_bwd(qkv[:, :d], qkv[:, d:2 * d], qkv[:, 2 * d:], o, do, lse, dqkv[:, :d], dqkv[:, d:2 * d], dqkv[:, 2 * d:],
                                    B, H, S, S, scale))
     print(f"attn bwd (dq + dkdv kernels, 7 matmuls): {ms:.3f} ms  {fl*3.5/ms/1e9:.1f} TFLOP/s executed, {fl*2.5/ms/1e9:.1f} algorithmic")
+    for drop in ((0.1, 12345),):
+        ms = timeit(lambda: K.attn_fwd(qkv[:, :d], qkv[:, d:2 * d], qkv[:, 2 * d:], B, H, S, S, scale, drop=drop))
+        print(f"attn fwd dropout {drop[0]}: {ms:.3f} ms  {fl/ms/1e9:.1f} TFLOP/s")
+        ms = timeit(lambda: K.attn_bwd(qkv[:, :d], qkv[:, d:2 * d], qkv[:, 2 * d:], o, do, lse, dqkv[:, :d], dqkv[:, d:2 * d], dqkv[:, 2 * d:],
+                                       B, H, S, S, scale, drop=drop))
+        print(f"attn bwd dropout {drop[0]}: {ms:.3f} ms  {fl*2.5/ms/1e9:.1f} TFLOP/s algorithmic")
+    if only == "attn":
+        return
     print("== row kernels ==")
     x = torch.randn((M, 768), device=dev)
     g, b_ = torch.ones(768, device=dev), torch.zeros(768, device=dev)

@@ -1,0 +1,18 @@
+#!/usr/bin/env python3
+"""Launch the roofline kernel of the train workload (NT GEMM, FFN linear1 + bias + GELU + saved pre-activation,
+M = 64 * 986, N = 3072, K = 768) a few times; run under `rocprofv3 --pmc ...` to read its counters."""
+import os
+import sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+from adt_str_amd import kernels as K
+
+dev = "cuda:0"
+M, N, Kd = 64 * 986, 3072, 768
+a = torch.randn((M, Kd), device=dev).bfloat16()
+w = torch.randn((N, Kd), device=dev).bfloat16()
+bias = torch.zeros(N, device=dev)
+u = torch.empty((M, N), dtype=torch.bfloat16, device=dev)
+for _ in range(6):
+    K.gemm(a, w, bias=bias, act=1, pre_act_out=u)
+torch.cuda.synchronize()
