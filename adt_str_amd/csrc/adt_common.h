@@ -11,6 +11,10 @@ int set_error(int code, const char* msg);
 int set_hip_error(hipError_t e, const char* what);
 // Number of compute units of the current device (cached per device).
 int device_cu_count(int* n_cu);
+// Work counters of the persistent GEMM on (current device, stream): eight device words (one per XCD group, 64 bytes apart) that
+// only ever count up.  base[x] is the value counter x will have when the launch being prepared starts; the call reserves
+// fetches[x] increments of it for that launch.
+int sched_counters(void* stream, const unsigned (&fetches)[8], unsigned** counters, unsigned (&base)[8]);
 
 inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
 

@@ -1,7 +1,9 @@
 // common.hip -- version, thread-local error string, device queries.
 #include <cstdio>
 #include <cstring>
+#include <map>
 #include <mutex>
+#include <utility>
 
 #include "adt_common.h"
 
@@ -33,6 +35,30 @@ int device_cu_count(int* n_cu) {
     cache[dev] = v > 0 ? v : 1;
   }
   *n_cu = cache[dev];
+  return ADT_OK;
+}
+
+int sched_counters(void* stream, const unsigned (&fetches)[8], unsigned** counters, unsigned (&base)[8]) {
+  struct Slot { unsigned* dev_words; unsigned next[8]; };
+  static std::mutex mu;
+  static std::map<std::pair<int, void*>, Slot> slots;
+  int dev = 0;
+  ADT_HIP_TRY(hipGetDevice(&dev));
+  std::lock_guard<std::mutex> lock(mu);
+  auto key = std::make_pair(dev, stream);
+  auto it = slots.find(key);
+  if (it == slots.end()) {            // first use of this stream: 8 x 64 bytes of device memory, zeroed before anything can read them
+    unsigned* w = nullptr;
+    ADT_HIP_TRY(hipMalloc(&w, 512));
+    ADT_HIP_TRY(hipMemset(w, 0, 512));
+    ADT_HIP_TRY(hipDeviceSynchronize());
+    it = slots.emplace(key, Slot{w, {0, 0, 0, 0, 0, 0, 0, 0}}).first;
+  }
+  *counters = it->second.dev_words;
+  for (int x = 0; x < 8; ++x) {
+    base[x] = it->second.next[x];
+    it->second.next[x] += fetches[x];   // wraps mod 2^32 exactly like the device counter
+  }
   return ADT_OK;
 }
 

@@ -70,6 +70,7 @@ struct GemmArgs {
   float* slabs;                 // TN split-K partials [splits][M][N] (null when splits == 1)
   adt_gemm_epilogue ep;
   Drop drop;
+  unsigned* sched; unsigned sched_base[8];   // persistent NT kernel: per-XCD-group work counters (16 words apart) and their values at launch
 };
 
 // ---- global -> register staging (4 x 16 B per thread per operand) -----------------------------
@@ -470,40 +471,58 @@ constexpr int kBig = 256;
 constexpr int kBigThreads = 512;
 constexpr int kHalfTile = 128 * 128;                 // 16 KiB
 constexpr int kBigBuf = 4 * kHalfTile;               // A_0 | A_1 | B_0 | B_1
-constexpr int kBigLds = 2 * kBigBuf;                 // 131,072 B
-constexpr int kEpi2Pitch = 68;                       // floats; wave-private 32 x 64 transposition tile
+constexpr int kBigStage = 2 * kBigBuf;               // 131,072 B of operand staging
+constexpr int kEpi2Bytes = 16 * 64 * 4;              // per wave: 16 x 64 fp32 transposition tile (XOR-swizzled, no padding)
+constexpr int kBigLds = kBigStage + 8 * kEpi2Bytes;  // 163,840 B = the whole LDS of a CU
 
 #define ADT_DS_READ_B128(dst, addr, imm) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(dst) : "v"(addr), "i"(imm))
 
+// Persistent: one workgroup per CU.  The tiles are cut into eight contiguous slices (row-major over the tile grid), slice x
+// is worked off by the workgroups with blockIdx.x % 8 == x -- the ones that share an XCD and its L2 -- which take tiles
+// from the slice's device work counter: dynamic, so a CU held by another stream's kernel (an RCCL all-reduce under DDP)
+// delays no tile.  The counters only count up: the host passes the values they have at launch (sched_base), a block ends
+// on its first fetch >= its slice's size.  The fetch for the next tile is issued by thread 0 before the K loop and handed
+// over through the one staging slot the prologue DMAs do not touch (A_1 of buffer 1).
+// After a tile's K loop the staging buffers are free, so the NEXT tile's first seven half-tile
+// DMAs are issued before this tile's epilogue, which works from a separate 32 KiB of wave-private LDS: the epilogue's
+// LDS transposes, activation math and global stores hide the next tile's DMA latency (and there is no workgroup
+// turn-around between tiles).
 template <bool kDrop>
 __global__ __launch_bounds__(kBigThreads) void gemm_nt_256_kernel(GemmArgs g, int tiles_m, int tiles_n) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wr = wave >> 2, wc = wave & 3;
-  const int nwg = tiles_m * tiles_n, bid = blockIdx.x;
-  const int q8 = nwg >> 3, r8 = nwg & 7, xcd = bid & 7;
-  const int logical = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + (bid >> 3);
-  const int m0 = (logical / tiles_n) * kBig, n0 = (logical % tiles_n) * kBig;
+  const int nwg = tiles_m * tiles_n;
+  const int q8 = nwg >> 3, r8 = nwg & 7;
   const int k_tiles = g.K / kBK;
 
   // ---- DMA source pointers: wave w, instruction j fills LDS rows 8 * (2w + j) + (lane >> 3) of a half-tile
   const unsigned short* pa[2][2];      // [h][j]
   const unsigned short* pb[2][2];
+  const int xg = blockIdx.x & 7;
+  const int slice0 = xg < r8 ? xg * (q8 + 1) : r8 * (q8 + 1) + (xg - r8) * q8, slice_n = q8 + (xg < r8 ? 1 : 0);
+  unsigned* const counter = g.sched + xg * 16;
+  const unsigned cbase = g.sched_base[xg];
+  auto set_tile = [&](int v, int& m0, int& n0) {
+    const int logical = slice0 + v;
+    m0 = (logical / tiles_n) * kBig;
+    n0 = (logical % tiles_n) * kBig;
 #pragma unroll
-  for (int j = 0; j < 2; ++j) {
-    const int r = 8 * (2 * wave + j) + (lane >> 3);
-    const int chunk = (lane & 7) ^ ((r >> 1) & 7);
+    for (int j = 0; j < 2; ++j) {
+      const int r = 8 * (2 * wave + j) + (lane >> 3);
+      const int chunk = (lane & 7) ^ ((r >> 1) & 7);
 #pragma unroll
-    for (int h = 0; h < 2; ++h) {
-      int ar = m0 + (r >> 6) * 128 + h * 64 + (r & 63);
-      ar = ar < g.M ? ar : g.M - 1;
-      pa[h][j] = g.A + static_cast<long>(ar) * g.lda + chunk * 8;
-      int br = n0 + (r >> 5) * 64 + h * 32 + (r & 31);
-      br = br < g.N ? br : g.N - 1;
-      pb[h][j] = g.B + static_cast<long>(br) * g.ldb + chunk * 8;
+      for (int h = 0; h < 2; ++h) {
+        int ar = m0 + (r >> 6) * 128 + h * 64 + (r & 63);
+        ar = ar < g.M ? ar : g.M - 1;
+        pa[h][j] = g.A + static_cast<long>(ar) * g.lda + chunk * 8;
+        int br = n0 + (r >> 5) * 64 + h * 32 + (r & 31);
+        br = br < g.N ? br : g.N - 1;
+        pb[h][j] = g.B + static_cast<long>(br) * g.ldb + chunk * 8;
+      }
     }
-  }
+  };
   auto dma = [&](const unsigned short* const (&p)[2], int tile, int buf, int half_slot) {
     const int tt = tile < k_tiles ? tile : k_tiles - 1;
 #pragma unroll
@@ -511,6 +530,10 @@ __global__ __launch_bounds__(kBigThreads) void gemm_nt_256_kernel(GemmArgs g, in
       __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(p[j] + static_cast<long>(tt) * kBK),
                                        (__attribute__((address_space(3))) void*)(smem + buf * kBigBuf + half_slot * kHalfTile + (2 * wave + j) * 1024),
                                        16, 0, 0);
+  };
+  auto prologue_dma = [&]() {          // tile 0 complete + B_0 / A_0 / B_1 of tile 1: what the K loop expects to be in flight
+    dma(pa[0], 0, 0, 0); dma(pb[0], 0, 0, 2); dma(pa[1], 0, 0, 1); dma(pb[1], 0, 0, 3);
+    dma(pb[0], 1, 1, 2); dma(pa[0], 1, 1, 0); dma(pb[1], 1, 1, 3);
   };
 
   // ---- fragment read addresses (bytes inside a half-tile): row = base + 16 i + (lane & 15), chunk (4 ks + (lane >> 4)) ^ swz
@@ -520,19 +543,18 @@ __global__ __launch_bounds__(kBigThreads) void gemm_nt_256_kernel(GemmArgs g, in
   const unsigned a_row = static_cast<unsigned>((wr * 64 + (lane & 15)) * 128), b_row = static_cast<unsigned>((wc * 32 + (lane & 15)) * 128);
   const unsigned a_k0 = base0 + a_row + c0, a_k1 = base0 + a_row + c1;            // + h * kHalfTile + i * 2048 (+ buffer)
   const unsigned b_k0 = base0 + 2 * kHalfTile + b_row + c0, b_k1 = base0 + 2 * kHalfTile + b_row + c1;
+  float* ct = reinterpret_cast<float*>(smem + kBigStage + wave * kEpi2Bytes);
 
-  f32x4 acc[8][4];
-#pragma unroll
-  for (int i = 0; i < 8; ++i)
-#pragma unroll
-    for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
-
-  // ---- prologue: tile 0 complete, B_0 / A_0 / B_1 of tile 1 in flight
-  dma(pa[0], 0, 0, 0); dma(pb[0], 0, 0, 2); dma(pa[1], 0, 0, 1); dma(pb[1], 0, 0, 3);
-  dma(pb[0], 1, 1, 2); dma(pa[0], 1, 1, 0); dma(pb[1], 1, 1, 3);
+  unsigned* const flag = reinterpret_cast<unsigned*>(smem + kBigBuf + kHalfTile);
+  if (tid == 0) *flag = __hip_atomic_fetch_add(counter, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - cbase;
+  __syncthreads();
+  int v = static_cast<int>(*flag), m0, n0;
+  if (v >= slice_n) return;                             // block-uniform (the slice is already handed out)
+  __syncthreads();
+  set_tile(v, m0, n0);
+  prologue_dma();
   asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
   asm volatile("s_barrier" ::: "memory");
-  if (wr == 1) asm volatile("s_barrier" ::: "memory");
 
   bf16x8 fa[4][2], fb0[2][2], fb1[2][2];
 #define ADT_MFMA_QUAD(I0, FB, J0)                                                                                  \
@@ -549,81 +571,123 @@ __global__ __launch_bounds__(kBigThreads) void gemm_nt_256_kernel(GemmArgs g, in
     asm volatile("s_barrier" ::: "memory");                                                                        \
   } while (0)
 
-  for (int t = 0; t < k_tiles; ++t) {
-    const int buf = t & 1;
-    const unsigned bo = static_cast<unsigned>(buf) * kBigBuf;
-    const unsigned ak0 = a_k0 + bo, ak1 = a_k1 + bo, bk0 = b_k0 + bo, bk1 = b_k1 + bo;
-    // ---------------- phase 1: B_0 then A_0; DMA A_1(t+1)
-    ADT_DS_READ_B128(fb0[0][0], bk0, 0);    ADT_DS_READ_B128(fb0[0][1], bk1, 0);
-    ADT_DS_READ_B128(fb0[1][0], bk0, 2048); ADT_DS_READ_B128(fb0[1][1], bk1, 2048);
-    __builtin_amdgcn_sched_barrier(0);
-    ADT_DS_READ_B128(fa[0][0], ak0, 0);     ADT_DS_READ_B128(fa[0][1], ak1, 0);
-    ADT_DS_READ_B128(fa[1][0], ak0, 2048);  ADT_DS_READ_B128(fa[1][1], ak1, 2048);
-    ADT_DS_READ_B128(fa[2][0], ak0, 4096);  ADT_DS_READ_B128(fa[2][1], ak1, 4096);
-    ADT_DS_READ_B128(fa[3][0], ak0, 6144);  ADT_DS_READ_B128(fa[3][1], ak1, 6144);
-    dma(pa[1], t + 1, buf ^ 1, 1);
-    asm volatile("s_waitcnt lgkmcnt(8)" ::: "memory");           // B_0 reads retired before the barrier: B_0 may be refilled in phase 2
+  unsigned ct_w[4], ct_r[2];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) ct_w[j] = lds_addr(ct) + static_cast<unsigned>(((4 * (lane >> 4)) * 64 + ((j ^ (lane >> 4)) << 4) + (lane & 15)) * 4);
+#pragma unroll
+  for (int pass = 0; pass < 2; ++pass) {
+    const int lr = pass * 8 + (lane >> 3);
+    ct_r[pass] = lds_addr(ct) + static_cast<unsigned>((lr * 64 + ((((lane & 7) >> 1) ^ ((lr >> 2) & 3)) << 4) + (lane & 1) * 8) * 4);
+  }
+
+  while (true) {
+    f32x4 acc[8][4];
+#pragma unroll
+    for (int i = 0; i < 8; ++i)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    // This tile's bias piece and the next tile's index are requested before the K loop and first used after the
+    // s_waitcnt vmcnt(0) that ends it.  Inline asm: the compiler would wait for its own loads right here (a loop with
+    // VMEM traffic follows), which puts their latency in front of every tile's first MFMA.
+    const int ecol = n0 + wc * 64 + (lane & 7) * 8;
+    const bool efull = ecol + 8 <= g.N;
+    const bool has_bias = g.ep.bias != nullptr && efull;
+    const float* bptr = has_bias ? g.ep.bias + ecol : reinterpret_cast<const float*>(g.A);     // always a readable 32 bytes
+    f32x4 braw0, braw1;
+    asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(braw0) : "v"(bptr) : "memory");
+    asm volatile("global_load_dwordx4 %0, %1, off offset:16" : "=v"(braw1) : "v"(bptr) : "memory");
+    unsigned v_next;
+    if (tid == 0) asm volatile("global_atomic_add %0, %1, %2, %3 sc0" : "=v"(v_next) : "v"(0u), "v"(1u), "s"(counter) : "memory");
+    if (wr == 1) asm volatile("s_barrier" ::: "memory");
+
+    for (int t = 0; t < k_tiles; ++t) {
+      const int buf = t & 1;
+      const unsigned bo = static_cast<unsigned>(buf) * kBigBuf;
+      const unsigned ak0 = a_k0 + bo, ak1 = a_k1 + bo, bk0 = b_k0 + bo, bk1 = b_k1 + bo;
+      // ---------------- phase 1: B_0 then A_0; DMA A_1(t+1)
+      ADT_DS_READ_B128(fb0[0][0], bk0, 0);    ADT_DS_READ_B128(fb0[0][1], bk1, 0);
+      ADT_DS_READ_B128(fb0[1][0], bk0, 2048); ADT_DS_READ_B128(fb0[1][1], bk1, 2048);
+      __builtin_amdgcn_sched_barrier(0);
+      ADT_DS_READ_B128(fa[0][0], ak0, 0);     ADT_DS_READ_B128(fa[0][1], ak1, 0);
+      ADT_DS_READ_B128(fa[1][0], ak0, 2048);  ADT_DS_READ_B128(fa[1][1], ak1, 2048);
+      ADT_DS_READ_B128(fa[2][0], ak0, 4096);  ADT_DS_READ_B128(fa[2][1], ak1, 4096);
+      ADT_DS_READ_B128(fa[3][0], ak0, 6144);  ADT_DS_READ_B128(fa[3][1], ak1, 6144);
+      dma(pa[1], t + 1, buf ^ 1, 1);
+      asm volatile("s_waitcnt lgkmcnt(8)" ::: "memory");           // B_0 reads retired before the barrier: B_0 may be refilled in phase 2
+      asm volatile("s_barrier" ::: "memory");
+      ADT_MFMA_QUAD(0, fb0, 0);
+      // ---------------- phase 2: B_1; DMA B_0(t+2)
+      ADT_DS_READ_B128(fb1[0][0], bk0, kHalfTile);        ADT_DS_READ_B128(fb1[0][1], bk1, kHalfTile);
+      ADT_DS_READ_B128(fb1[1][0], bk0, kHalfTile + 2048); ADT_DS_READ_B128(fb1[1][1], bk1, kHalfTile + 2048);
+      dma(pb[0], t + 2, buf, 2);
+      asm volatile("s_barrier" ::: "memory");
+      ADT_MFMA_QUAD(0, fb1, 2);
+      // ---------------- phase 3: A_1; DMA A_0(t+2)
+      ADT_DS_READ_B128(fa[0][0], ak0, kHalfTile);         ADT_DS_READ_B128(fa[0][1], ak1, kHalfTile);
+      ADT_DS_READ_B128(fa[1][0], ak0, kHalfTile + 2048);  ADT_DS_READ_B128(fa[1][1], ak1, kHalfTile + 2048);
+      ADT_DS_READ_B128(fa[2][0], ak0, kHalfTile + 4096);  ADT_DS_READ_B128(fa[2][1], ak1, kHalfTile + 4096);
+      ADT_DS_READ_B128(fa[3][0], ak0, kHalfTile + 6144);  ADT_DS_READ_B128(fa[3][1], ak1, kHalfTile + 6144);
+      dma(pa[0], t + 2, buf, 0);
+      asm volatile("s_barrier" ::: "memory");
+      ADT_MFMA_QUAD(4, fb1, 2);
+      // ---------------- phase 4: DMA B_1(t+2); retire tile t+1
+      dma(pb[1], t + 2, buf, 3);
+      asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+      asm volatile("s_barrier" ::: "memory");
+      ADT_MFMA_QUAD(4, fb0, 0);
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    if (wr == 0) asm volatile("s_barrier" ::: "memory");
+    asm volatile("s_barrier" ::: "memory");            // every DMA has landed and every fragment read is done: staging is free
+
+    const int em0 = m0;
+    if (tid == 0) *flag = v_next - cbase;
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     asm volatile("s_barrier" ::: "memory");
-    ADT_MFMA_QUAD(0, fb0, 0);
-    // ---------------- phase 2: B_1; DMA B_0(t+2)
-    ADT_DS_READ_B128(fb1[0][0], bk0, kHalfTile);        ADT_DS_READ_B128(fb1[0][1], bk1, kHalfTile);
-    ADT_DS_READ_B128(fb1[1][0], bk0, kHalfTile + 2048); ADT_DS_READ_B128(fb1[1][1], bk1, kHalfTile + 2048);
-    dma(pb[0], t + 2, buf, 2);
+    v = static_cast<int>(*flag);
+    const bool more = v < slice_n;                      // block-uniform
+    if (more) {
+      set_tile(v, m0, n0);
+      prologue_dma();                                   // flies under the epilogue below
+    }
+
+    // ---- epilogue: wave-private 16 x 64 transposition passes (element (row, col) at row * 64 + ((col >> 4) ^ ((row >> 2) & 3)) * 16
+    //      + (col & 15): conflict-free writes from the MFMA layout), then 8-column row pieces as in the 128^2 kernel.
+    //      LDS traffic is inline asm: the compiler would otherwise order it behind the DMAs in flight with a vmcnt(0).
+    float bias[8];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) { bias[e] = has_bias ? braw0[e] : 0.f; bias[4 + e] = has_bias ? braw1[e] : 0.f; }
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        asm volatile("ds_write_b32 %0, %1" :: "v"(ct_w[j]), "v"(acc[i][j][0]));
+        asm volatile("ds_write_b32 %0, %1 offset:256" :: "v"(ct_w[j]), "v"(acc[i][j][1]));
+        asm volatile("ds_write_b32 %0, %1 offset:512" :: "v"(ct_w[j]), "v"(acc[i][j][2]));
+        asm volatile("ds_write_b32 %0, %1 offset:768" :: "v"(ct_w[j]), "v"(acc[i][j][3]));
+      }
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      __builtin_amdgcn_wave_barrier();
+      f32x4 zz[2][2];
+      asm volatile("ds_read_b128 %0, %1" : "=v"(zz[0][0]) : "v"(ct_r[0]));
+      asm volatile("ds_read_b128 %0, %1 offset:16" : "=v"(zz[0][1]) : "v"(ct_r[0]));
+      asm volatile("ds_read_b128 %0, %1" : "=v"(zz[1][0]) : "v"(ct_r[1]));
+      asm volatile("ds_read_b128 %0, %1 offset:16" : "=v"(zz[1][1]) : "v"(ct_r[1]));
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      __builtin_amdgcn_sched_barrier(0);
+      __builtin_amdgcn_wave_barrier();                  // every lane's reads are done before the next pass overwrites the tile
+#pragma unroll
+      for (int pass = 0; pass < 2; ++pass) {
+        const int row = em0 + wr * 128 + i * 16 + pass * 8 + (lane >> 3);
+        float z[8] = {zz[pass][0][0], zz[pass][0][1], zz[pass][0][2], zz[pass][0][3], zz[pass][1][0], zz[pass][1][1], zz[pass][1][2], zz[pass][1][3]};
+        if (row < g.M && efull) epilogue_apply8<kDrop>(g, z, bias, row, ecol);
+      }
+    }
+    if (!more) break;
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");    // next tile's first k-tiles have landed (and this tile's stores are out)
     asm volatile("s_barrier" ::: "memory");
-    ADT_MFMA_QUAD(0, fb1, 2);
-    // ---------------- phase 3: A_1; DMA A_0(t+2)
-    ADT_DS_READ_B128(fa[0][0], ak0, kHalfTile);         ADT_DS_READ_B128(fa[0][1], ak1, kHalfTile);
-    ADT_DS_READ_B128(fa[1][0], ak0, kHalfTile + 2048);  ADT_DS_READ_B128(fa[1][1], ak1, kHalfTile + 2048);
-    ADT_DS_READ_B128(fa[2][0], ak0, kHalfTile + 4096);  ADT_DS_READ_B128(fa[2][1], ak1, kHalfTile + 4096);
-    ADT_DS_READ_B128(fa[3][0], ak0, kHalfTile + 6144);  ADT_DS_READ_B128(fa[3][1], ak1, kHalfTile + 6144);
-    dma(pa[0], t + 2, buf, 0);
-    asm volatile("s_barrier" ::: "memory");
-    ADT_MFMA_QUAD(4, fb1, 2);
-    // ---------------- phase 4: DMA B_1(t+2); retire tile t+1
-    dma(pb[1], t + 2, buf, 3);
-    asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
-    asm volatile("s_barrier" ::: "memory");
-    ADT_MFMA_QUAD(4, fb0, 0);
   }
 #undef ADT_MFMA_QUAD
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  if (wr == 0) asm volatile("s_barrier" ::: "memory");
-  asm volatile("s_barrier" ::: "memory");              // every DMA has landed and every fragment read is done: LDS is free
-
-  // ---- epilogue: wave-private 32 x 64 transposition passes, then 8-column row pieces (as the 128^2 kernel)
-  float* ct = reinterpret_cast<float*>(smem) + wave * (32 * kEpi2Pitch);
-  const int c8 = (lane & 7) * 8;
-  const int col = n0 + wc * 64 + c8;
-  const bool full = col + 8 <= g.N;
-  float bias[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-  if (g.ep.bias && full) {
-    *reinterpret_cast<float4*>(bias) = *reinterpret_cast<const float4*>(g.ep.bias + col);
-    *reinterpret_cast<float4*>(bias + 4) = *reinterpret_cast<const float4*>(g.ep.bias + col + 4);
-  }
-#pragma unroll
-  for (int q = 0; q < 4; ++q) {
-#pragma unroll
-    for (int ii = 0; ii < 2; ++ii)
-#pragma unroll
-      for (int j = 0; j < 4; ++j)
-#pragma unroll
-        for (int r = 0; r < 4; ++r) ct[(ii * 16 + 4 * (lane >> 4) + r) * kEpi2Pitch + j * 16 + (lane & 15)] = acc[2 * q + ii][j][r];
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-    __builtin_amdgcn_wave_barrier();
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-#pragma unroll
-    for (int pass = 0; pass < 4; ++pass) {
-      const int lr = pass * 8 + (lane >> 3);
-      const int row = m0 + wr * 128 + q * 32 + lr;
-      float z[8];
-      *reinterpret_cast<float4*>(z) = *reinterpret_cast<const float4*>(ct + lr * kEpi2Pitch + c8);
-      *reinterpret_cast<float4*>(z + 4) = *reinterpret_cast<const float4*>(ct + lr * kEpi2Pitch + c8 + 4);
-      if (row < g.M && full) epilogue_apply8<kDrop>(g, z, bias, row, col);
-    }
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-    __builtin_amdgcn_wave_barrier();
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-  }
 }
 
 // =========================================================================================
@@ -842,7 +906,14 @@ extern "C" int adt_gemm_bf16(int32_t trans, int64_t M, int64_t N, int64_t K, con
     hipLaunchKernelGGL((gemm_bf16_kernel<true, false>), grid, dim3(kGemmThreads), kGemmLds, st, g);
   } else if (use_big_tile(M, N, K) && vector_epilogue_ok(g, e)) {
     const int tm = static_cast<int>((M + kBig - 1) / kBig), tn = static_cast<int>((N + kBig - 1) / kBig);
-    const dim3 g1(static_cast<unsigned>(tm) * tn);
+    int n_cu = 0;
+    if (int rc = device_cu_count(&n_cu)) return rc;
+    const long nt = static_cast<long>(tm) * tn;
+    const dim3 g1(static_cast<unsigned>(nt < n_cu ? nt : n_cu));          // persistent: one workgroup per CU
+    unsigned fetches[8];                 // per slice: one fetch per tile + the ending fetch of each of its workgroups
+    for (int x = 0; x < 8; ++x)
+      fetches[x] = static_cast<unsigned>(nt / 8 + (x < nt % 8 ? 1 : 0)) + g1.x / 8 + (static_cast<unsigned>(x) < g1.x % 8 ? 1u : 0u);
+    if (int rc = sched_counters(stream, fetches, &g.sched, g.sched_base)) return rc;
     if (g.drop.on()) hipLaunchKernelGGL(gemm_nt_256_kernel<true>, g1, dim3(kBigThreads), kBigLds, st, g, tm, tn);
     else hipLaunchKernelGGL(gemm_nt_256_kernel<false>, g1, dim3(kBigThreads), kBigLds, st, g, tm, tn);
   } else if ((K % 32) == 0 && K > 0 && vector_epilogue_ok(g, e)) {
