@@ -597,7 +597,9 @@ __global__ __launch_bounds__(kBigThreads) void gemm_nt_256_kernel(GemmArgs g, in
     asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(braw0) : "v"(bptr) : "memory");
     asm volatile("global_load_dwordx4 %0, %1, off offset:16" : "=v"(braw1) : "v"(bptr) : "memory");
     unsigned v_next;
-    if (tid == 0) asm volatile("global_atomic_add %0, %1, %2, %3 sc0" : "=v"(v_next) : "v"(0u), "v"(1u), "s"(counter) : "memory");
+    // (address in VGPRs: an SGPR pair the compiler has just re-read from a spill lane would need wait states before a VMEM
+    //  instruction, which it cannot know this asm is)
+    if (tid == 0) asm volatile("global_atomic_add %0, %1, %2, off sc0" : "=v"(v_next) : "v"(counter), "v"(1u) : "memory");
     if (wr == 1) asm volatile("s_barrier" ::: "memory");
 
     for (int t = 0; t < k_tiles; ++t) {

@@ -126,7 +126,8 @@ __global__ __launch_bounds__(kRowThreads) void layernorm_fwd_narrow_kernel(LnFwd
 // dx = rstd * (g - mean(g) - xhat * mean(g * xhat)),  g = dy * gamma,  xhat = (x - mean) * rstd
 // Per block (kLnBwdRows rows) partial column sums: dgamma += dy * xhat, dbeta += dy, dxsum += dx
 // (dxsum = bias gradient of the linear layer that feeds this norm's input).
-constexpr int kLnBwdRows = 64;              // rows per block (16 per wave)
+// rows per block (a quarter per wave): 64 for the long encoder streams, 16 when 64 would leave most CUs without a block
+__host__ __device__ inline int ln_bwd_rows(long M) { return M >= 32768 ? 64 : 16; }
 struct LnBwdArgs { const float* dy; long lddy; const float* x; long ldx; const float* gamma; const float* mean;
                    const float* rstd; float* dx32; unsigned short* dx16; long lddx; float* partial; int M; int D;
                    Drop dy_drop, dx_drop; };
@@ -138,8 +139,9 @@ __global__ __launch_bounds__(kRowThreads) void layernorm_bwd_kernel(LnBwdArgs a)
   float4 pg[4], pb[4], px[4];
 #pragma unroll
   for (int i = 0; i < 4; ++i) pg[i] = pb[i] = px[i] = make_float4(0, 0, 0, 0);
-  for (int rr = 0; rr < kLnBwdRows / 4; ++rr) {
-    const int row = blockIdx.x * kLnBwdRows + wave * (kLnBwdRows / 4) + rr;
+  const int rpb = ln_bwd_rows(a.M);
+  for (int rr = 0; rr < rpb / 4; ++rr) {
+    const int row = blockIdx.x * rpb + wave * (rpb / 4) + rr;
     if (row >= a.M) break;
     const float mean = a.mean[row], rstd = a.rstd[row];
     const float4* xr = reinterpret_cast<const float4*>(a.x + static_cast<long>(row) * a.ldx);
@@ -469,7 +471,8 @@ extern "C" int adt_layernorm_fwd(const float* x, int64_t ldx, const float* gamma
 
 extern "C" size_t adt_layernorm_bwd_workspace_bytes(int64_t M, int64_t D) {
   if (M <= 0 || D <= 0) return 0;
-  return static_cast<size_t>((M + kLnBwdRows - 1) / kLnBwdRows) * 3 * D * 4;
+  const int rpb = ln_bwd_rows(M);
+  return static_cast<size_t>((M + rpb - 1) / rpb) * 3 * D * 4;
 }
 
 extern "C" int adt_layernorm_bwd(const float* dy, int64_t lddy, const float* x, int64_t ldx, const float* gamma,
@@ -482,7 +485,7 @@ extern "C" int adt_layernorm_bwd(const float* dy, int64_t lddy, const float* x, 
   if (M < 0) return set_error(ADT_EINVAL, "adt_layernorm_bwd: negative M");
   if (M == 0) return ADT_OK;
   if (!ws || ws_bytes < adt_layernorm_bwd_workspace_bytes(M, D)) return set_error(ADT_EINVAL, "adt_layernorm_bwd: workspace too small");
-  const int nb = static_cast<int>((M + kLnBwdRows - 1) / kLnBwdRows);
+  const int nb = static_cast<int>((M + ln_bwd_rows(M) - 1) / ln_bwd_rows(M));
   LnBwdArgs a{dy, lddy, x, ldx, gamma, mean, rstd, dx32, static_cast<unsigned short*>(dx16), lddx, static_cast<float*>(ws),
               static_cast<int>(M), static_cast<int>(D), dy_drop ? make_drop(dy_drop->p, dy_drop->key) : Drop{0u, 0u, 1.0f},
               dx16_drop ? make_drop(dx16_drop->p, dx16_drop->key) : Drop{0u, 0u, 1.0f}};

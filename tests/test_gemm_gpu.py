@@ -108,3 +108,30 @@ def test_rejects_misaligned():
     a, b = rnd((64, 68), 1).bfloat16(), rnd((64, 68), 2).bfloat16()
     with pytest.raises(_ffi.AdtError):
         k.gemm(a, b)
+
+
+def test_big_tile_persistent_kernel_epilogues_and_dropout():
+    """Shapes that select the persistent 256 x 256 kernel on their own (>= 512 tiles, K >= 256): plain, ragged M / N edges,
+    bias + residual, GELU with the saved pre-activation, and the dropout instantiation checked against the oracle's mask."""
+    from adt_str_amd import kernels as k
+    from oracle import dropout as o_drop
+    M, N, K = 8192 - 40, 4096 + 64, 256                      # 32 x 17 tiles, last tile row / column partly outside
+    a, b = rnd((M, K), 21).bfloat16(), (rnd((N, K), 22) * 0.1).bfloat16()
+    bias, res = rnd((N,), 23), rnd((M, N), 24)
+    z = a.float() @ b.float().t()
+    close(k.gemm(a, b, out_dtype=torch.float32), z, 1e-4, "plain fp32")
+    close(k.gemm(a, b), z, 6e-3, "plain bf16")
+    plain = k.gemm(a, b, bias=bias, residual=res, out_dtype=torch.float32)
+    close(plain, z + bias + res, 1e-4, "bias + residual")
+    u = torch.empty((M, N), dtype=torch.bfloat16, device=DEV)
+    h = k.gemm(a, b, bias=bias, act=1, pre_act_out=u)
+    close(u, z + bias, 6e-3, "pre-activation")
+    close(h, torch.nn.functional.gelu(u.float()), 6e-3, "gelu(u)")
+    for rep in range(3):                                     # several launches: the work counters carry over between them
+        nb = k.gemm(a, b, bias=bias, out_dtype=torch.float32)
+        dropped = k.gemm(a, b, bias=bias, out_dtype=torch.float32, drop=(0.1, 1000 + rep))
+        mask = o_drop.scale((M, N), 0.1, 1000 + rep).to(DEV)
+        assert torch.equal(dropped, nb * mask)
+    y = k.gemm(a, b, bias=bias, residual=res, out_dtype=torch.float32, drop=(0.25, 9), drop_after_residual=False)
+    mask = o_drop.scale((M, N), 0.25, 9).to(DEV)
+    close(y, (z + bias) * mask + res, 1e-4, "dropout then residual")
