@@ -51,7 +51,9 @@ def create_training_arguments(cfg: dict) -> "TrainingArguments":
               max_grad_norm=t["max_grad_norm"], gradient_accumulation_steps=t["gradient_accumulation_steps"], optim=t["optim"],
               lr_scheduler_type=t["lr_scheduler_type"], logging_steps=lg["logging_steps"], seed=ex["seed"],
               bf16=False,                     # the engine already computes in bf16 with fp32 accumulation; autocast has nothing to wrap
-              dataloader_num_workers=0, remove_unused_columns=False, report_to=[], save_total_limit=ck["max_checkpoints"],
+              dataloader_num_workers=0,       # the batch is rendered on the GPU inside collate: no CPU workers to feed
+              dataloader_pin_memory=False,    # ... and it is already device memory (pinning a CUDA tensor raises)
+              remove_unused_columns=False, report_to=[], save_total_limit=ck["max_checkpoints"],
               ddp_broadcast_buffers=False,     # PE tables / window / filterbank are constants (the reference re-broadcasts them each forward)
               save_strategy="steps" if lg.get("save_every_n_steps") else "epoch")
     if lg.get("save_every_n_steps"):
