@@ -11,3 +11,12 @@ class SharedConfig:
     time_res: float
     win_length: int
     sample_rate: int
+
+
+@dataclass
+class ClapConfig(SharedConfig):
+    """``clap_config`` section + the shared keys (reference config.py:17-21)."""
+    model_name: str
+    batch_size: int
+    sample_pack_root: str
+    reference_root: str

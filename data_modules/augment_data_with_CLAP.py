@@ -1,0 +1,134 @@
+"""Drop-in for the reference's ``data_modules/augment_data_with_CLAP.py``:
+``python data_modules/augment_data_with_CLAP.py <config.yaml> [--num_bins 10]``.
+
+Same inputs and outputs: every ``*.wav`` under ``clap_config.reference_root/<GM pitch>/`` defines the class means, every
+``*.wav`` under ``clap_config.sample_pack_root`` is embedded, scored against the means and copied once into
+``<reference_root>_clap_augmented/<class>/<upper>-<lower>/`` in descending score order (reference lines 84-199).
+What moved to the GPU: the feature extractor (K9), the HTSAT tower (K10/K11 + GEMMs), the cosine arg-max (K12); the
+O(N x C) Python tuple list + sort of the reference becomes a sort of N items with the same order (adt_str_amd/curation.py).
+Under ``torchrun`` every rank embeds a strided slice of the files and the embeddings are all-gathered; rank 0 copies.
+
+Audio must already be 48 kHz WAV: the resampler (``torchaudio.transforms.Resample`` in the reference, :55-58) is hot-path
+row f4 and not built yet -- other rates raise instead of being silently mis-embedded."""
+import argparse
+import os
+import shutil
+import sys
+from glob import glob
+from pathlib import Path
+
+sys.path.append(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+
+import torch  # noqa: E402
+import torch.distributed as dist  # noqa: E402
+
+from adt_str_amd.audio_io import read_wav  # noqa: E402
+from adt_str_amd.config_utils import load_merged  # noqa: E402
+from adt_str_amd.curation import assign, class_mean_embeddings  # noqa: E402
+from config import ClapConfig  # noqa: E402
+from modules.clap_encoder import ClapWrapper  # noqa: E402
+
+
+def sort_paths_by_parent_folder(file_paths):
+    """Numeric parent folders first (by value), then the others by name; file name breaks ties (reference :38-48)."""
+    def sort_key(path):
+        parent = Path(path).parent.name
+        try:
+            return (0, int(parent), Path(path).name.lower())
+        except ValueError:
+            return (1, parent, Path(path).name.lower())
+    return sorted(file_paths, key=sort_key)
+
+
+def load_audio(path, target_sample_rate: int) -> torch.Tensor:
+    """[1, L] mono fp32 (reference :51-59)."""
+    audio, sr = read_wav(path)
+    if sr != target_sample_rate:
+        raise NotImplementedError(f"{path} is {sr} Hz; resample to {target_sample_rate} Hz first (polyphase resampler = hot-path row f4)")
+    return torch.from_numpy(audio.mean(axis=0, keepdims=True))
+
+
+def normalize(waveform: torch.Tensor) -> torch.Tensor:
+    return waveform / torch.max(torch.abs(waveform))
+
+
+def _embed(wrapper, files, batch_size, sample_rate):
+    """Embeddings [len(files), 512] on the wrapper's device, this rank's strided slice computed here, the rest gathered."""
+    world = dist.get_world_size() if dist.is_initialized() else 1
+    rank = dist.get_rank() if dist.is_initialized() else 0
+    mine = list(range(rank, len(files), world))
+    chunks = []
+    for i in range(0, len(mine), batch_size):
+        batch = [normalize(load_audio(files[j], sample_rate)) for j in mine[i:i + batch_size]]
+        chunks.append(wrapper.get_audio_features(batch).float())
+    local = torch.cat(chunks) if chunks else torch.zeros((0, 512), device=wrapper.device)
+    if world == 1:
+        return local
+    per = -(-len(files) // world)
+    padded = torch.zeros((per, local.shape[1]), device=local.device)
+    padded[: local.shape[0]] = local
+    parts = [torch.empty_like(padded) for _ in range(world)]
+    dist.all_gather(parts, padded)
+    out = torch.empty((len(files), local.shape[1]), device=local.device)
+    for r in range(world):
+        idx = list(range(r, len(files), world))
+        out[idx] = parts[r][: len(idx)]
+    return out
+
+
+def run(cfg: dict, num_bins: int = 10, clap_model=None, copy: bool = True):
+    """The reference's ``__main__`` body.  ``clap_model``: an already built ``transformers.ClapModel`` (offline use).
+    Returns ``(assignment, wav_files, augmented_root)``."""
+    if num_bins <= 0 or 100 % num_bins != 0:
+        raise ValueError("--num_bins must be a positive integer that divides 100 evenly")
+    section = dict(cfg["clap_config"])
+    section.update(cfg["shared"])
+    c = ClapConfig(**section)
+    device = torch.device("cuda", torch.cuda.current_device())
+    wrapper = ClapWrapper(device=device, model_name=c.model_name, sample_rate=c.sample_rate, clap_model=clap_model)
+    wav_files = glob(f"{c.sample_pack_root}/**/*.[Ww][Aa][Vv]", recursive=True)
+    print(f"Total: {len(wav_files)}")
+    reference_files = sort_paths_by_parent_folder(glob(f"{c.reference_root}/**/*.[Ww][Aa][Vv]", recursive=True))
+    print(f"Total: {len(reference_files)}")
+
+    reference_dict = {k: [] for k in range(35, 82)}
+    reference_dict.update({421: []})                      # electric hi-hat
+    for file, emb in zip(reference_files, _embed(wrapper, reference_files, c.batch_size, c.sample_rate)):
+        reference_dict[int(Path(file).parent.name)].append(emb)
+    labels, reference_embeddings = class_mean_embeddings(reference_dict)
+    print(f"Reference embeddings shape: {tuple(reference_embeddings.shape)}")
+    sample_pack_embeddings = _embed(wrapper, wav_files, c.batch_size, c.sample_rate)
+    print(f"Sample pack embeddings shape: {tuple(sample_pack_embeddings.shape)}")
+    res = assign(sample_pack_embeddings, reference_embeddings, labels, num_bins)
+
+    augmented_root = Path(f"{c.reference_root}_clap_augmented")
+    if copy and (not dist.is_initialized() or dist.get_rank() == 0):
+        if augmented_root.exists():
+            shutil.rmtree(augmented_root)
+        augmented_root.mkdir(parents=True, exist_ok=True)
+        copied = 0
+        for i, label, bin_label in zip(res.order.tolist(), res.label.tolist(), res.bin):
+            dest_dir = augmented_root / str(label) / bin_label
+            dest_dir.mkdir(parents=True, exist_ok=True)
+            try:
+                shutil.copy2(wav_files[i], dest_dir / Path(wav_files[i]).name)
+                copied += 1
+            except Exception as e:                         # the reference logs and carries on (:195-196)
+                print(f"Failed to copy {wav_files[i]} -> {dest_dir}: {e}")
+        print(f"Copied: {copied}, Skipped (duplicates): {len(wav_files) * (len(labels) - 1)}")
+    return res, wav_files, augmented_root
+
+
+parser = argparse.ArgumentParser()
+parser.add_argument("config_path", type=str, help="Path to the config file")
+parser.add_argument("--num_bins", type=int, default=10, help="Number of bins for discretization (must evenly divide 100)")
+if __name__ == "__main__":
+    args = parser.parse_args()
+    if args.num_bins <= 0 or 100 % args.num_bins != 0:
+        parser.error("--num_bins must be a positive integer that divides 100 evenly")
+    if "RANK" in os.environ and int(os.environ.get("WORLD_SIZE", "1")) > 1:
+        torch.cuda.set_device(int(os.environ.get("LOCAL_RANK", "0")))
+        dist.init_process_group("nccl")
+    run(load_merged(args.config_path), args.num_bins)
+    if dist.is_initialized():
+        dist.destroy_process_group()

@@ -4,6 +4,8 @@ CPU in fp32 (the code the reference calls, clap_encoder.py:45-54), with randomly
 The HIP path uses bf16 GEMM/attention operands with fp32 accumulation and an fp32 residual stream; tolerances:
 front image and patch embedding (fp32 kernels) 2e-4 / 2e-3 absolute; pooled features 3e-2 of their max;
 final unit-norm embedding: cosine >= 0.9995 with the reference and 1.5e-2 absolute per component."""
+import os
+
 import numpy as np
 import pytest
 import torch
@@ -160,3 +162,38 @@ def test_fusion_branch_matches_hf(setup, distinct_channels):
     assert (out["pooled"].cpu() - ref["pooled"]).abs().max() < 3e-2 * ref["pooled"].abs().max()
     assert ((emb * ref["embedding"]).sum(-1)).min() > 0.9995
     assert (emb - ref["embedding"]).abs().max() < 1.5e-2
+
+
+def test_curation_driver_end_to_end(setup, tmp_path):
+    """``data_modules/augment_data_with_CLAP.py`` on a synthetic library: reference folders by GM pitch, a sample pack, the
+    augmented tree holds every pack file exactly once under <class>/<bin>/, in agreement with the oracle's assignment of
+    the same embeddings."""
+    import importlib
+    from adt_str_amd.audio_io import write_wav
+    model, *_ = setup
+    rng = np.random.default_rng(11)
+
+    def shot(f0, n):
+        t = np.arange(n, dtype=np.float32) / 48000.0
+        return (np.exp(-t * 18.0) * (np.sin(2 * np.pi * f0 * t) + 0.2 * rng.standard_normal(n))).astype(np.float32)
+
+    ref_root, pack_root = tmp_path / "GM", tmp_path / "packs"
+    for pitch, f0 in ((36, 60.0), (38, 190.0), (42, 6000.0)):
+        os.makedirs(ref_root / str(pitch))
+        for k in range(2):
+            write_wav(str(ref_root / str(pitch) / f"r{k}.wav"), shot(f0 * (1 + 0.05 * k), 9000 + 500 * k), 48000)
+    os.makedirs(pack_root / "a" / "b")
+    for i in range(9):
+        write_wav(str(pack_root / "a" / ("b" if i % 2 else "") / f"p{i}.wav"), shot([55, 200, 5500][i % 3] * (1 + 0.02 * i), 7000 + 300 * i), 48000)
+    cfg = {"shared": {"sample_rate": 48000, "input_sec": 2.56, "time_res": 0.01, "win_length": 2048},
+           "clap_config": {"model_name": "unused", "batch_size": 4, "sample_pack_root": str(pack_root), "reference_root": str(ref_root)}}
+    mod = importlib.import_module("data_modules.augment_data_with_CLAP")
+    np.random.seed(0)
+    res, wav_files, out_root = mod.run(cfg, num_bins=10, clap_model=model)
+    assert len(wav_files) == 9 and sorted(res.order.tolist()) == list(range(9)) and set(res.label.tolist()) <= {36, 38, 42}
+    copied = sorted(str(p.relative_to(out_root)) for p in out_root.rglob("*.wav"))
+    expect = sorted(os.path.join(str(l), b, os.path.basename(wav_files[i])) for i, l, b in zip(res.order.tolist(), res.label.tolist(), res.bin))
+    assert copied == expect
+    with pytest.raises(NotImplementedError):
+        write_wav(str(pack_root / "bad.wav"), shot(100.0, 4000), 44100)
+        mod.run(cfg, clap_model=model, copy=False)

@@ -93,3 +93,49 @@ def test_lr_schedule_matches_hf_cosine():
     for step in range(100):
         assert abs(sch.get_last_lr()[0] - cosine_with_warmup(step, 100, 10)) < 1e-7, step
         opt.step(); sch.step()
+
+
+class _StubWrapper:
+    """Stands in for ClapWrapper in the sharding test: a deterministic 'embedding' of each clip, on the CPU."""
+    device = torch.device("cpu")
+
+    def get_audio_features(self, audios):
+        return torch.stack([torch.tensor([float(a.numel()), float(a.abs().sum()), float(a[0, 0])] + [0.0] * 509) for a in audios])
+
+
+def _curation_worker(rank, world, port, q, files):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        import importlib
+        mod = importlib.import_module("data_modules.augment_data_with_CLAP")
+        got = mod._embed(_StubWrapper(), files, 2, 48000)
+        want = torch.cat([_StubWrapper().get_audio_features([mod.normalize(mod.load_audio(f, 48000))]) for f in files])
+        assert got.shape == want.shape and torch.equal(got, want), "gathered embeddings must be in file order on every rank"
+        q.put((rank, "ok"))
+    except Exception as e:                              # pragma: no cover
+        q.put((rank, repr(e)))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_curation_embedding_shards_and_gathers_world_size_2(tmp_path):
+    """CLAP curation under torchrun: strided file shards per rank, one all_gather, file order restored."""
+    import numpy as np
+    from adt_str_amd.audio_io import write_wav
+    rng = np.random.default_rng(0)
+    files = []
+    for i in range(7):                                  # odd count: the last rank's shard is one short
+        path = str(tmp_path / f"s{i}.wav")
+        write_wav(path, (rng.standard_normal(600 + 50 * i) * 0.3).astype(np.float32), 48000)
+        files.append(path)
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_curation_worker, args=(r, 2, port, q, files)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=180) for _ in procs]
+    for p in procs:
+        p.join(timeout=60)
+    assert sorted(res) == [(0, "ok"), (1, "ok")], res
