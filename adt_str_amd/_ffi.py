@@ -80,6 +80,7 @@ SIGNATURES = {
     "adt_mean_tokens": [ptr, i64, i32, i32, ptr, ptr, ptr],
     "adt_l2_normalize": [ptr, i64, i32, ptr, ptr],
     "adt_cosine_argmax_f32": [ptr, i64, ptr, i64, i64, i64, f32, ptr, ptr, ptr, ptr],
+    "adt_resample_f32": [ptr, i64, i64, i64, ptr, ptr, i32, i32, i32, i32, ptr, i64, i64, ptr],
     "adt_mix_render_f32": [ptr, ptr, i64, ptr, i64, ptr, ptr, ptr, i64, i64, ptr, i64, ptr, C.c_size_t, ptr],
 }
 _RESTYPES = {"adt_last_error": C.c_char_p}

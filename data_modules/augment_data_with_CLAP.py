@@ -8,8 +8,7 @@ What moved to the GPU: the feature extractor (K9), the HTSAT tower (K10/K11 + GE
 O(N x C) Python tuple list + sort of the reference becomes a sort of N items with the same order (adt_str_amd/curation.py).
 Under ``torchrun`` every rank embeds a strided slice of the files and the embeddings are all-gathered; rank 0 copies.
 
-Audio must already be 48 kHz WAV: the resampler (``torchaudio.transforms.Resample`` in the reference, :55-58) is hot-path
-row f4 and not built yet -- other rates raise instead of being silently mis-embedded."""
+Files at other rates are resampled on the GPU (K13, the reference's ``torchaudio.transforms.Resample`` at :55-58)."""
 import argparse
 import os
 import shutil
@@ -40,12 +39,19 @@ def sort_paths_by_parent_folder(file_paths):
     return sorted(file_paths, key=sort_key)
 
 
+_RESAMPLERS = {}
+
+
 def load_audio(path, target_sample_rate: int) -> torch.Tensor:
-    """[1, L] mono fp32 (reference :51-59)."""
+    """[1, L] mono fp32 at the target rate (reference :51-59)."""
     audio, sr = read_wav(path)
+    waveform = torch.from_numpy(audio.mean(axis=0, keepdims=True))
     if sr != target_sample_rate:
-        raise NotImplementedError(f"{path} is {sr} Hz; resample to {target_sample_rate} Hz first (polyphase resampler = hot-path row f4)")
-    return torch.from_numpy(audio.mean(axis=0, keepdims=True))
+        from adt_str_amd.resample import Resample
+        if (sr, target_sample_rate) not in _RESAMPLERS:
+            _RESAMPLERS[(sr, target_sample_rate)] = Resample(sr, target_sample_rate)
+        waveform = _RESAMPLERS[(sr, target_sample_rate)](waveform.cuda()).cpu()
+    return waveform
 
 
 def normalize(waveform: torch.Tensor) -> torch.Tensor:

@@ -341,6 +341,20 @@ int adt_l2_normalize(const float* x, int64_t n_rows, int32_t D, float* out, void
 int adt_cosine_argmax_f32(const float* emb, int64_t ld, const float* refs, int64_t N, int64_t D, int64_t C, float eps,
                           int32_t* best_class, float* best_score, float* scores, void* stream);
 
+/* ---------------------------------------------------------------------------
+ * K13  Polyphase sinc resampler
+ *
+ * Replaces torchaudio.transforms.Resample(orig_freq, new_freq)(waveform) with default arguments
+ * (utils/audio_utils.py:18-20, inference.py:89-90, data_modules/augment_data_with_CLAP.py:56-59).
+ *   in  [B, L_in] fp32 (row stride ld_in) -> out [B, L_out] fp32, L_out <= ceil(new * L_in / orig)
+ *   orig, neu   the two rates divided by their gcd
+ *   bank        [neu][K] fp32, K = 2 * width + orig: torchaudio's sinc_interp_hann kernel bank
+ *   tap_range   [neu][2] int32: first / one-past-last tap of each phase that is not an exact zero
+ * out[b][m * neu + p] = sum_k bank[p][k] * in_padded[b][m * orig + k], in_padded = in shifted by `width` zeros.
+ */
+int adt_resample_f32(const float* in, int64_t B, int64_t L_in, int64_t ld_in, const float* bank, const int32_t* tap_range,
+                     int32_t K, int32_t width, int32_t orig, int32_t neu, float* out, int64_t L_out, int64_t ld_out, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

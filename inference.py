@@ -53,10 +53,10 @@ def main():
     a = ap.parse_args()
     model, cfg = build_model(a.config_path, device="cuda")
     audio, sr = read_wav(a.input_path)
-    if sr != cfg["shared"]["sample_rate"]:
-        raise NotImplementedError(f"{a.input_path} is {sr} Hz but the model runs at {cfg['shared']['sample_rate']} Hz; "
-                                  "resample the file first (the polyphase resampler is a later hot-path row)")
     wav = torch.from_numpy(audio.mean(axis=0)).cuda()
+    if sr != cfg["shared"]["sample_rate"]:                 # reference inference.py:88-90
+        from adt_str_amd.resample import Resample
+        wav = Resample(sr, cfg["shared"]["sample_rate"])(wav)
     notes = transcribe(model, cfg, wav, cfg["inference"]["batch_size"])
     os.makedirs(a.output_dir, exist_ok=True)
     stem = os.path.splitext(os.path.basename(a.input_path))[0]

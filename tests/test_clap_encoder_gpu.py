@@ -194,6 +194,6 @@ def test_curation_driver_end_to_end(setup, tmp_path):
     copied = sorted(str(p.relative_to(out_root)) for p in out_root.rglob("*.wav"))
     expect = sorted(os.path.join(str(l), b, os.path.basename(wav_files[i])) for i, l, b in zip(res.order.tolist(), res.label.tolist(), res.bin))
     assert copied == expect
-    with pytest.raises(NotImplementedError):
-        write_wav(str(pack_root / "bad.wav"), shot(100.0, 4000), 44100)
-        mod.run(cfg, clap_model=model, copy=False)
+    write_wav(str(pack_root / "other_rate.wav"), shot(100.0, 4000), 44100)       # resampled to 48 kHz on the GPU (K13)
+    res2, files2, _ = mod.run(cfg, clap_model=model, copy=False)
+    assert len(files2) == 10 and sorted(res2.order.tolist()) == list(range(10))

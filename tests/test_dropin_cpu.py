@@ -17,6 +17,7 @@ def test_reference_import_paths_resolve():
     from utils.config_utils import deep_merge_dicts, load_config_from_yaml  # noqa: F401
     from utils.mapping_utils import MappingUtils
     from utils.utils import create_mask_plain  # noqa: F401
+    from utils.audio_utils import load_and_resample, normalize, resample  # noqa: F401
     assert MappingUtils().ADTOF_label_mapping[42] == "HH"
     assert model.ADTModel.config_class is config.ADTModelConfig and config.ADTModelConfig.model_type == "adt_model"
 
