@@ -105,6 +105,35 @@ def test_greedy_sample_matches_oracle():
     assert agree >= 0.9, (got, ref)
 
 
+def test_cached_greedy_decode_is_the_full_recompute_decode():
+    """f1: one position per step against K/V caches == the reference-style full-prefix decode (teacher-forced check:
+    every generated token is the arg-max of the full decoder's logits for its prefix, up to bf16 near-ties)."""
+    model, state, cfg = make_model(2, 2, 2, seed=5)
+    batch = make_batch(4, 8000, 6, 3)
+    src = torch.from_numpy(batch["wavs"]).to(DEV)
+    L = 24
+    got = model.sample(src, None, None, max_length=L, use_cache=True)
+    assert got.shape[0] == 4 and 2 <= got.shape[1] <= L and got[:, 0].eq(2).all()
+    eng = model.engine
+    mem16, B, S = eng.encode(src)
+    logits = eng.decode_logits(got[:, :-1].contiguous(), mem16, B, S)             # [B, n-1, V] full recompute, causal
+    top2 = logits.topk(2, dim=-1)
+    margin_small = (top2.values[..., 0] - top2.values[..., 1]) < 5e-2
+    pred = top2.indices[..., 0]
+    fin = torch.zeros(B, dtype=torch.bool, device=DEV)
+    for t in range(got.shape[1] - 1):
+        tok = got[:, t + 1]
+        ok = fin & (tok == 3) | ~fin & ((tok == pred[:, t]) | margin_small[:, t])
+        assert bool(ok.all()), (t, tok, pred[:, t])
+        fin = fin | (tok == 3)
+    # the stopping rule: an all-EOS model output ends after one step, like the reference's loop
+    full = model.sample(src, None, None, max_length=L, use_cache=False)
+    if torch.equal(full[:, :got.shape[1]], got[:, :full.shape[1]]):
+        assert full.shape == got.shape
+    with pytest.raises(ValueError):
+        model.sample(src, None, None, max_length=5000)
+
+
 def test_full_size_statistics(golden_dir):
     """Setting-1 architecture (69.0 M parameters) with the portable seeded weights: loss and logit
     statistics recorded from the reference's own ADTModel (tests/golden/adt_full_stats.npz)."""
