@@ -132,6 +132,10 @@ def test_cached_greedy_decode_is_the_full_recompute_decode():
         assert full.shape == got.shape
     with pytest.raises(ValueError):
         model.sample(src, None, None, max_length=5000)
+    # HIP-graph replay of the step (taken for decodes of >= 64 steps) produces exactly the eager tokens
+    eager = eng.greedy_decode_cached(mem16, B, S, 72, 2, -1, use_graph=False)
+    replay = eng.greedy_decode_cached(mem16, B, S, 72, 2, -1, use_graph=True)
+    assert eager.shape == (4, 72) and torch.equal(eager, replay)
 
 
 def test_full_size_statistics(golden_dir):
