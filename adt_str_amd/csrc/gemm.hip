@@ -799,6 +799,235 @@ __global__ __launch_bounds__(kGemmThreads) void gemm_tn_glds_kernel(GemmArgs g, 
   gemm_epilogue_rows<false>(o, acc, reinterpret_cast<float*>(smem), m0, n0, wm, wn, tid, lane);
 }
 
+// =========================================================================================
+// TN kernel (weight gradients), persistent 256 x 256 x 64 tiles: the schedule of gemm_nt_256_kernel (8 waves, 4 phases of
+// 16 MFMAs per K-tile, three half-tile DMAs in flight across raw barriers, staggered wave rows, per-XCD-slice work counters,
+// next item's prologue under the epilogue) with the TN operand path: half-tiles are [64 k][128 columns] images (256-byte
+// rows, chunk p of row r at position p ^ (2 * (r & 7))) of
+//     A_h : columns {wr * 128 + h * 64 + 0..63} of the A tile for wr = 0, 1
+//     B_h : columns {wc * 64 + h * 32 + 0..31} of the B tile for wc = 0..3
+// read as MFMA fragments by pairs of ds_read_b64_tr_b16.  A work item is (tile, K split); splits write fp32 slabs that
+// reduce_slabs_kernel sums in slab order.
+#define ADT_TR_PAIR(lo, hi, addr, imm)                                                                  \
+  asm volatile("ds_read_b64_tr_b16 %0, %2 offset:%3\n\tds_read_b64_tr_b16 %1, %2 offset:%4"            \
+               : "=&v"(lo), "=&v"(hi) : "v"(addr), "i"(imm), "i"((imm) + 4096))
+
+__global__ __launch_bounds__(kBigThreads) void gemm_tn_256_kernel(GemmArgs g, int tiles_m, int tiles_n, int splits) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wr = wave >> 2, wc = wave & 3;
+  const int nwg = tiles_m * tiles_n * splits;
+  const int q8 = nwg >> 3, r8 = nwg & 7;
+  const int k_tiles_all = g.K / kBK;
+
+  const unsigned short* pa[2][2];      // [h][j]: wave w, instruction j fills LDS rows 4 * (2w + j) + (lane >> 4) of a half-tile
+  const unsigned short* pb[2][2];
+  const int xg = blockIdx.x & 7;
+  const int slice0 = xg < r8 ? xg * (q8 + 1) : r8 * (q8 + 1) + (xg - r8) * q8, slice_n = q8 + (xg < r8 ? 1 : 0);
+  unsigned* const counter = g.sched + xg * 16;
+  const unsigned cbase = g.sched_base[xg];
+  int k_tiles = 0;                     // K-tiles of the current item
+  auto set_item = [&](int v, int& m0, int& n0, int& split) {
+    const int logical = slice0 + v;              // split-major: an XCD slice holds neighbouring tiles of ONE K range (they share
+    const int n_tiles = tiles_m * tiles_n;       // A / B panels through that XCD's L2)
+    split = logical / n_tiles;
+    const int tile = logical - split * n_tiles;
+    m0 = (tile / tiles_n) * kBig;
+    n0 = (tile % tiles_n) * kBig;
+    const int kt0 = split * g.k_tiles_per_split;
+    int kt1 = kt0 + g.k_tiles_per_split;
+    kt1 = kt1 < k_tiles_all ? kt1 : k_tiles_all;
+    k_tiles = kt1 - kt0;               // >= 1: the host sizes the splits so that the last one is not empty
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const int r = 4 * (2 * wave + j) + (lane >> 4);
+      const int c = (((lane & 15) ^ ((r & 7) << 1))) * 8;                 // first LDS column of this lane's 16-byte chunk
+      const long krow = static_cast<long>(kt0) * kBK + r;
+#pragma unroll
+      for (int h = 0; h < 2; ++h) {
+        int ac = m0 + (c >> 6) * 128 + h * 64 + (c & 63);
+        ac = ac + 8 <= g.M ? ac : g.M - 8;
+        pa[h][j] = g.A + krow * g.lda + ac;
+        int bc = n0 + (c >> 5) * 64 + h * 32 + (c & 31);
+        bc = bc + 8 <= g.N ? bc : g.N - 8;
+        pb[h][j] = g.B + krow * g.ldb + bc;
+      }
+    }
+  };
+  auto dma = [&](const unsigned short* const (&p)[2], long ld, int tile, int buf, int half_slot) {
+    const int tt = tile < k_tiles ? tile : k_tiles - 1;
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(p[j] + static_cast<long>(tt) * kBK * ld),
+                                       (__attribute__((address_space(3))) void*)(smem + buf * kBigBuf + half_slot * kHalfTile + (2 * wave + j) * 1024),
+                                       16, 0, 0);
+  };
+  auto prologue_dma = [&]() {
+    dma(pa[0], g.lda, 0, 0, 0); dma(pb[0], g.ldb, 0, 0, 2); dma(pa[1], g.lda, 0, 0, 1); dma(pb[1], g.ldb, 0, 0, 3);
+    dma(pb[0], g.ldb, 1, 1, 2); dma(pa[0], g.lda, 1, 1, 0); dma(pb[1], g.ldb, 1, 1, 3);
+  };
+
+  // ---- transposed fragment reads: 16 columns x 32 k per pair; lane (t = lane & 15, q = lane >> 4) reads row ks*32 + 4q + (t >> 2)
+  // (+16 for the second half), 8 bytes at column chunk ((col0 + 4 (t & 3)) >> 3) ^ swz
+  const unsigned base0 = lds_addr(smem);
+  const int tq = lane & 15, gq = lane >> 4;
+  const int frow = 4 * gq + (tq >> 2);
+  const unsigned fsw = static_cast<unsigned>((frow & 7) << 1);
+  unsigned a_ad[4], b_ad[2];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+    a_ad[i] = base0 + static_cast<unsigned>(frow * 256) + ((static_cast<unsigned>(wr * 8 + 2 * i + ((tq & 3) >> 1)) ^ fsw) << 4) + 8u * (tq & 1);
+#pragma unroll
+  for (int n = 0; n < 2; ++n)
+    b_ad[n] = base0 + 2 * kHalfTile + static_cast<unsigned>(frow * 256) + ((static_cast<unsigned>(wc * 4 + 2 * n + ((tq & 3) >> 1)) ^ fsw) << 4) + 8u * (tq & 1);
+  float* ct = reinterpret_cast<float*>(smem + kBigStage + wave * kEpi2Bytes);
+  unsigned ct_w[4], ct_r[2];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) ct_w[j] = lds_addr(ct) + static_cast<unsigned>(((4 * (lane >> 4)) * 64 + ((j ^ (lane >> 4)) << 4) + (lane & 15)) * 4);
+#pragma unroll
+  for (int pass = 0; pass < 2; ++pass) {
+    const int lr = pass * 8 + (lane >> 3);
+    ct_r[pass] = lds_addr(ct) + static_cast<unsigned>((lr * 64 + ((((lane & 7) >> 1) ^ ((lr >> 2) & 3)) << 4) + (lane & 1) * 8) * 4);
+  }
+
+  unsigned* const flag = reinterpret_cast<unsigned*>(smem + kBigBuf + kHalfTile);
+  if (tid == 0) *flag = __hip_atomic_fetch_add(counter, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - cbase;
+  __syncthreads();
+  int v = static_cast<int>(*flag), m0, n0, split;
+  if (v >= slice_n) return;
+  __syncthreads();
+  set_item(v, m0, n0, split);
+  prologue_dma();
+  asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+  asm volatile("s_barrier" ::: "memory");
+
+  bf16x4 alo[4][2], ahi[4][2], b0lo[2][2], b0hi[2][2], b1lo[2][2], b1hi[2][2];
+#define ADT_TN_QUAD(I0, BLO, BHI, J0)                                                                              \
+  do {                                                                                                             \
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                                                             \
+    __builtin_amdgcn_sched_barrier(0);                                                                             \
+    __builtin_amdgcn_s_setprio(1);                                                                                 \
+    _Pragma("unroll") for (int ks = 0; ks < 2; ++ks)                                                               \
+      _Pragma("unroll") for (int i = 0; i < 4; ++i)                                                                \
+        _Pragma("unroll") for (int j = 0; j < 2; ++j)                                                              \
+          acc[I0 + i][J0 + j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(join8(alo[i][ks], ahi[i][ks]), join8(BLO[j][ks], BHI[j][ks]), \
+                                                                        acc[I0 + i][J0 + j], 0, 0, 0);            \
+    __builtin_amdgcn_s_setprio(0);                                                                                 \
+    __builtin_amdgcn_sched_barrier(0);                                                                             \
+    asm volatile("s_barrier" ::: "memory");                                                                        \
+  } while (0)
+
+  while (true) {
+    f32x4 acc[8][4];
+#pragma unroll
+    for (int i = 0; i < 8; ++i)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    unsigned v_next;
+    if (tid == 0) asm volatile("global_atomic_add %0, %1, %2, off sc0" : "=v"(v_next) : "v"(counter), "v"(1u) : "memory");
+    if (wr == 1) asm volatile("s_barrier" ::: "memory");
+
+    for (int t = 0; t < k_tiles; ++t) {
+      const int buf = t & 1;
+      const unsigned bo = static_cast<unsigned>(buf) * kBigBuf;
+      const unsigned a0 = a_ad[0] + bo, a1 = a_ad[1] + bo, a2 = a_ad[2] + bo, a3 = a_ad[3] + bo, bb0 = b_ad[0] + bo, bb1 = b_ad[1] + bo;
+      // ---------------- phase 1: B_0, A_0; DMA A_1(t+1)
+      ADT_TR_PAIR(b0lo[0][0], b0hi[0][0], bb0, 0);    ADT_TR_PAIR(b0lo[0][1], b0hi[0][1], bb0, 8192);
+      ADT_TR_PAIR(b0lo[1][0], b0hi[1][0], bb1, 0);    ADT_TR_PAIR(b0lo[1][1], b0hi[1][1], bb1, 8192);
+      __builtin_amdgcn_sched_barrier(0);
+      ADT_TR_PAIR(alo[0][0], ahi[0][0], a0, 0);       ADT_TR_PAIR(alo[0][1], ahi[0][1], a0, 8192);
+      ADT_TR_PAIR(alo[1][0], ahi[1][0], a1, 0);       ADT_TR_PAIR(alo[1][1], ahi[1][1], a1, 8192);
+      asm volatile("s_waitcnt lgkmcnt(8)" ::: "memory");           // the 8 B_0 reads are retired: B_0 may be refilled in phase 2
+      ADT_TR_PAIR(alo[2][0], ahi[2][0], a2, 0);       ADT_TR_PAIR(alo[2][1], ahi[2][1], a2, 8192);
+      ADT_TR_PAIR(alo[3][0], ahi[3][0], a3, 0);       ADT_TR_PAIR(alo[3][1], ahi[3][1], a3, 8192);
+      dma(pa[1], g.lda, t + 1, buf ^ 1, 1);
+      asm volatile("s_barrier" ::: "memory");
+      ADT_TN_QUAD(0, b0lo, b0hi, 0);
+      // ---------------- phase 2: B_1; DMA B_0(t+2)
+      ADT_TR_PAIR(b1lo[0][0], b1hi[0][0], bb0, kHalfTile);    ADT_TR_PAIR(b1lo[0][1], b1hi[0][1], bb0, kHalfTile + 8192);
+      ADT_TR_PAIR(b1lo[1][0], b1hi[1][0], bb1, kHalfTile);    ADT_TR_PAIR(b1lo[1][1], b1hi[1][1], bb1, kHalfTile + 8192);
+      dma(pb[0], g.ldb, t + 2, buf, 2);
+      asm volatile("s_barrier" ::: "memory");
+      ADT_TN_QUAD(0, b1lo, b1hi, 2);
+      // ---------------- phase 3: A_1; DMA A_0(t+2)
+      ADT_TR_PAIR(alo[0][0], ahi[0][0], a0, kHalfTile);       ADT_TR_PAIR(alo[0][1], ahi[0][1], a0, kHalfTile + 8192);
+      ADT_TR_PAIR(alo[1][0], ahi[1][0], a1, kHalfTile);       ADT_TR_PAIR(alo[1][1], ahi[1][1], a1, kHalfTile + 8192);
+      ADT_TR_PAIR(alo[2][0], ahi[2][0], a2, kHalfTile);       ADT_TR_PAIR(alo[2][1], ahi[2][1], a2, kHalfTile + 8192);
+      ADT_TR_PAIR(alo[3][0], ahi[3][0], a3, kHalfTile);       ADT_TR_PAIR(alo[3][1], ahi[3][1], a3, kHalfTile + 8192);
+      dma(pa[0], g.lda, t + 2, buf, 0);
+      asm volatile("s_barrier" ::: "memory");
+      ADT_TN_QUAD(4, b1lo, b1hi, 2);
+      // ---------------- phase 4: DMA B_1(t+2); retire tile t+1
+      dma(pb[1], g.ldb, t + 2, buf, 3);
+      asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+      asm volatile("s_barrier" ::: "memory");
+      ADT_TN_QUAD(4, b0lo, b0hi, 0);
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    if (wr == 0) asm volatile("s_barrier" ::: "memory");
+    asm volatile("s_barrier" ::: "memory");
+
+    const int em0 = m0, en0 = n0, esplit = split;
+    if (tid == 0) *flag = v_next - cbase;
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    asm volatile("s_barrier" ::: "memory");
+    v = static_cast<int>(*flag);
+    const bool more = v < slice_n;
+    if (more) {
+      set_item(v, m0, n0, split);
+      prologue_dma();
+    }
+
+    // ---- epilogue (as gemm_nt_256_kernel): split-K items write the plain fp32 tile into their slab
+    GemmArgs o = g;
+    if (g.slabs) {
+      o.C = g.slabs + static_cast<long>(esplit) * g.M * g.N;
+      o.ldc = g.N;
+      o.ep = adt_gemm_epilogue{};
+      o.ep.alpha = 1.0f;
+      o.ep.out_fp32 = 1;
+    }
+    const int ecol = en0 + wc * 64 + (lane & 7) * 8;
+    const bool efull = ecol + 8 <= g.N;
+    float bias[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    if (o.ep.bias && efull) {            // (weight gradients carry no bias: this load is not on the hot path)
+      *reinterpret_cast<float4*>(bias) = *reinterpret_cast<const float4*>(o.ep.bias + ecol);
+      *reinterpret_cast<float4*>(bias + 4) = *reinterpret_cast<const float4*>(o.ep.bias + ecol + 4);
+    }
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        asm volatile("ds_write_b32 %0, %1" :: "v"(ct_w[j]), "v"(acc[i][j][0]));
+        asm volatile("ds_write_b32 %0, %1 offset:256" :: "v"(ct_w[j]), "v"(acc[i][j][1]));
+        asm volatile("ds_write_b32 %0, %1 offset:512" :: "v"(ct_w[j]), "v"(acc[i][j][2]));
+        asm volatile("ds_write_b32 %0, %1 offset:768" :: "v"(ct_w[j]), "v"(acc[i][j][3]));
+      }
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      __builtin_amdgcn_wave_barrier();
+      f32x4 zz[2][2];
+      asm volatile("ds_read_b128 %0, %1" : "=v"(zz[0][0]) : "v"(ct_r[0]));
+      asm volatile("ds_read_b128 %0, %1 offset:16" : "=v"(zz[0][1]) : "v"(ct_r[0]));
+      asm volatile("ds_read_b128 %0, %1" : "=v"(zz[1][0]) : "v"(ct_r[1]));
+      asm volatile("ds_read_b128 %0, %1 offset:16" : "=v"(zz[1][1]) : "v"(ct_r[1]));
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      __builtin_amdgcn_sched_barrier(0);
+      __builtin_amdgcn_wave_barrier();
+#pragma unroll
+      for (int pass = 0; pass < 2; ++pass) {
+        const int row = em0 + wr * 128 + i * 16 + pass * 8 + (lane >> 3);
+        float z[8] = {zz[pass][0][0], zz[pass][0][1], zz[pass][0][2], zz[pass][0][3], zz[pass][1][0], zz[pass][1][1], zz[pass][1][2], zz[pass][1][3]};
+        if (row < g.M && efull) epilogue_apply8<false>(o, z, bias, row, ecol);
+      }
+    }
+    if (!more) break;
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    asm volatile("s_barrier" ::: "memory");
+  }
+#undef ADT_TN_QUAD
+}
+
 // sums split-K slabs in slab order: out[m,n] = alpha * sum_s slab[s][m,n]   (fp32 out)
 __global__ __launch_bounds__(256) void reduce_slabs_kernel(const float* __restrict__ slabs, int splits, long mn, int N,
                                                            float alpha, float* __restrict__ out, long ldc) {
@@ -812,6 +1041,18 @@ __global__ __launch_bounds__(256) void reduce_slabs_kernel(const float* __restri
   const long row = i4 / N; const int col = static_cast<int>(i4 - row * N);   // N % 4 == 0: a float4 never straddles rows
   float* o = out + row * ldc + col;
   o[0] = s.x * alpha; o[1] = s.y * alpha; o[2] = s.z * alpha; o[3] = s.w * alpha;
+}
+
+static int set_big_lds_once() {      // the persistent kernels use the CU's whole LDS
+  static thread_local int done_for = -1;
+  int dev = 0;
+  ADT_HIP_TRY(hipGetDevice(&dev));
+  if (done_for == dev) return ADT_OK;
+  ADT_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_nt_256_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, kBigLds));
+  ADT_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_nt_256_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, kBigLds));
+  ADT_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_tn_256_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, kBigLds));
+  done_for = dev;
+  return ADT_OK;
 }
 
 // the row-vector epilogue moves 8 columns at a time: everything it touches must be 16-byte aligned
@@ -839,13 +1080,37 @@ static int pick_splits(int M, int N, int K, int n_cu) {
   return s;
 }
 
+
+// Weight-gradient form on the persistent 256^2 kernel: worth it when the output has enough 256^2 tiles that few K splits fill the
+// chip (each split costs a full fp32 slab round trip).  Returns the number of splits (0: use the 128^2 kernel) and K-tiles per split.
+static int plan_tn_big(int64_t M, int64_t N, int64_t K, int n_cu, bool may_split, int* per_split) {
+  static const int forced = [] { const char* v = getenv("ADT_GEMM_TILE"); return v ? atoi(v) : 0; }();
+  if (K <= 0 || (K % kBK) != 0 || forced == 128) return 0;
+  const int k_tiles = static_cast<int>(K / kBK);
+  const int64_t tiles = ((M + kBig - 1) / kBig) * ((N + kBig - 1) / kBig);
+  if (forced != 256 && (tiles < 8 || k_tiles < 64)) return 0;
+  if (k_tiles < 2) return 0;
+  int s = 1;
+  if (may_split) {
+    s = static_cast<int>(n_cu / tiles);          // one item per CU, as many CUs as possible: every extra split is a slab round trip
+    const int max_s = k_tiles / 16 > 1 ? k_tiles / 16 : 1;
+    s = s < 1 ? 1 : (s > max_s ? max_s : s);
+  }
+  int per = (k_tiles + s - 1) / s;
+  per = per < 2 ? 2 : per;
+  s = (k_tiles + per - 1) / per;          // no empty trailing split
+  *per_split = per;
+  return s;
+}
 }  // namespace adt
 
 extern "C" size_t adt_gemm_workspace_bytes(int32_t trans, int64_t M, int64_t N, int64_t K) {
   if (!trans || M <= 0 || N <= 0 || K <= 0) return 0;
   int n_cu = 256;
   (void)adt::device_cu_count(&n_cu);
-  const int s = adt::pick_splits(static_cast<int>(M), static_cast<int>(N), static_cast<int>(K), n_cu);
+  int s = adt::pick_splits(static_cast<int>(M), static_cast<int>(N), static_cast<int>(K), n_cu), per = 0;
+  const int sb = adt::plan_tn_big(M, N, K, n_cu, true, &per);
+  s = sb > s ? sb : s;
   return s > 1 ? static_cast<size_t>(s) * M * N * 4 : 0;
 }
 
@@ -871,6 +1136,35 @@ extern "C" int adt_gemm_bf16(int32_t trans, int64_t M, int64_t N, int64_t K, con
   g.drop = make_drop(e.drop.p, e.drop.key);
   const int k_tiles = static_cast<int>((K + kBK - 1) / kBK);
   int splits = 1;
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  if (trans && vector_epilogue_ok(g, e) && M >= 8 && N >= 8) {
+    int n_cu = 0, per = 0;
+    if (int rc = device_cu_count(&n_cu)) return rc;
+    const bool plain = e.out_fp32 && !e.bias && !e.residual && !e.act && !e.pre_act_out && !e.gelu_grad_of && !e.aux_bf16_out && e.drop.p <= 0.f && !(N & 3);
+    const int sb = plan_tn_big(M, N, K, n_cu, plain, &per);
+    if (sb >= 1 && !g.drop.on() && (sb == 1 || (ws && aligned16(ws)))) {
+      if (sb > 1 && ws_bytes < static_cast<size_t>(sb) * M * N * 4)
+        return set_error(ADT_EINVAL, "adt_gemm_bf16: workspace too small (see adt_gemm_workspace_bytes)");
+      if (int rc = set_big_lds_once()) return rc;
+      g.k_tiles_per_split = per;
+      g.slabs = sb > 1 ? static_cast<float*>(ws) : nullptr;
+      const int tm = static_cast<int>((M + kBig - 1) / kBig), tn = static_cast<int>((N + kBig - 1) / kBig);
+      const long items = static_cast<long>(tm) * tn * sb;
+      const dim3 g1(static_cast<unsigned>(items < n_cu ? items : n_cu));
+      unsigned fetches[8];
+      for (int x = 0; x < 8; ++x)
+        fetches[x] = static_cast<unsigned>(items / 8 + (x < items % 8 ? 1 : 0)) + g1.x / 8 + (static_cast<unsigned>(x) < g1.x % 8 ? 1u : 0u);
+      if (int rc = sched_counters(stream, fetches, &g.sched, g.sched_base)) return rc;
+      hipLaunchKernelGGL(gemm_tn_256_kernel, g1, dim3(kBigThreads), kBigLds, st, g, tm, tn, sb);
+      if (sb > 1) {
+        const long mn = static_cast<long>(M) * N;
+        hipLaunchKernelGGL(reduce_slabs_kernel, dim3(static_cast<unsigned>((mn / 4 + 255) / 256)), dim3(256), 0, st,
+                           g.slabs, sb, mn, g.N, e.alpha, static_cast<float*>(C), ldc);
+      }
+      ADT_HIP_TRY(hipGetLastError());
+      return ADT_OK;
+    }
+  }
   if (trans) {
     int n_cu = 0;
     if (int rc = device_cu_count(&n_cu)) return rc;
@@ -884,7 +1178,6 @@ extern "C" int adt_gemm_bf16(int32_t trans, int64_t M, int64_t N, int64_t K, con
   }
   g.k_tiles_per_split = (k_tiles + splits - 1) / splits;
   g.slabs = splits > 1 ? static_cast<float*>(ws) : nullptr;
-  hipStream_t st = static_cast<hipStream_t>(stream);
   const dim3 grid(static_cast<unsigned>((N + kBN - 1) / kBN), static_cast<unsigned>((M + kBM - 1) / kBM), splits);
   static thread_local int attr_dev = -1;
   int dev = 0;
@@ -896,8 +1189,7 @@ extern "C" int adt_gemm_bf16(int32_t trans, int64_t M, int64_t N, int64_t K, con
     ADT_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_nt_glds_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, kEpiLds));
     ADT_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_nt_glds_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, kEpiLds));
     ADT_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_tn_glds_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, kEpiLds));
-    ADT_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_nt_256_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, kBigLds));
-    ADT_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_nt_256_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, kBigLds));
+    if (int rc = set_big_lds_once()) return rc;
     attr_dev = dev;
   }
   if (trans && (K % kBK) == 0 && K > 0 && vector_epilogue_ok(g, e) && M >= 8 && (splits == 1 || aligned16(ws))) {

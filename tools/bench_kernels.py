@@ -42,7 +42,7 @@ def main():
     if only == "nt":
         return
     print("== TN GEMM (wgrad) ==")
-    for (kk, m, n) in ([] if only == "attn" else [(M, 768, 3072), (M, 3072, 768), (M, 2304, 768), (M, 768, 768), (M, 1536, 768), (8192, 1400, 768)]):
+    for (kk, m, n) in ([] if only == "attn" else [(M, 768, 3072), (M, 3072, 768), (M, 2304, 768), (M, 768, 768), (M, 1536, 768), (8192, 1400, 768), (8192, 768, 3072), (8192, 2304, 768), (8192, 768, 768)]):
         a = torch.randn((kk, m), device=dev).bfloat16()
         b = torch.randn((kk, n), device=dev).bfloat16()
         out = torch.empty((m, n), device=dev)
