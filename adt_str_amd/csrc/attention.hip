@@ -437,6 +437,21 @@ __global__ __launch_bounds__(kAttnThreads, 1) void attn_bwd_dkv_kernel(AttnArgs 
         st = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_rows(tq, qblk, s, lane), kf[s], st, 0, 0, 0);
         dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_rows(td, qblk, s, lane), vf[s], dp, 0, 0, 0);
       }
+      // the transposed dO / Q fragments of both 16-row k-steps are requested now: they only depend on the tile, and land
+      // under the softmax / dropout arithmetic below instead of being waited for in front of the dV / dK MFMAs
+      TrFrag dot[2][4], qt[2][4];
+#pragma unroll
+      for (int s2 = 0; s2 < 2; ++s2) {
+        tr4_issue(td, qblk * 32 + 16 * s2, lane, dot[s2]);
+        tr4_issue(tq, qblk * 32 + 16 * s2, lane, qt[s2]);
+      }
+      // per-query statistics of this lane's 16 rows: rows 8j + 4h + (0..3) are four consecutive floats
+      float lse4[16], dl4[16];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        *reinterpret_cast<float4*>(lse4 + 4 * j) = *reinterpret_cast<const float4*>(stats + qblk * 32 + 8 * j + 4 * h);
+        *reinterpret_cast<float4*>(dl4 + 4 * j) = *reinterpret_cast<const float4*>(stats + 64 + qblk * 32 + 8 * j + 4 * h);
+      }
       const bool need_mask = key_mask || (t + 1) * kRowsPerTile > a.Sq;     // block-uniform
 #pragma unroll
       for (int i = 0; i < 16; ++i) {
@@ -445,26 +460,25 @@ __global__ __launch_bounds__(kAttnThreads, 1) void attn_bwd_dkv_kernel(AttnArgs 
         float p;
         if (need_mask) {
           const float tt = fmaf(st[i], sl2, mask_add(a, qi, ki, klen) * kLog2e);
-          p = (qi < a.Sq && ki < a.Sk) ? __builtin_amdgcn_exp2f(tt - stats[ql]) : 0.f;
+          p = (qi < a.Sq && ki < a.Sk) ? __builtin_amdgcn_exp2f(tt - lse4[i]) : 0.f;
         } else {
-          p = __builtin_amdgcn_exp2f(fmaf(st[i], sl2, -stats[ql]));
+          p = __builtin_amdgcn_exp2f(fmaf(st[i], sl2, -lse4[i]));
         }
         const float keep = kDrop ? a.drop.scale32(headbase + static_cast<unsigned>(qi) * static_cast<unsigned>(a.Sk), key2) : 1.0f;
         st[i] = p * keep;                                    // dropped P (what multiplied V in the forward)
-        dp[i] = p * fmaf(dp[i], keep, -stats[64 + ql]);      // dS / scale (scale applied when dK is stored)
+        dp[i] = p * fmaf(dp[i], keep, -dl4[i]);              // dS / scale (scale applied when dK is stored)
+      }
+      const bf16x8 pf0 = acc_to_b(st, 0), dsf0 = acc_to_b(dp, 0), pf1 = acc_to_b(st, 1), dsf1 = acc_to_b(dp, 1);
+      tr_wait();
+#pragma unroll
+      for (int db = 0; db < 4; ++db) {
+        dv[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(tr_get(dot[0][db]), pf0, dv[db], 0, 0, 0);
+        dk[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(tr_get(qt[0][db]), dsf0, dk[db], 0, 0, 0);
       }
 #pragma unroll
-      for (int s2 = 0; s2 < 2; ++s2) {
-        TrFrag dot[4], qt[4];
-        tr4_issue(td, qblk * 32 + 16 * s2, lane, dot);
-        tr4_issue(tq, qblk * 32 + 16 * s2, lane, qt);
-        const bf16x8 pf = acc_to_b(st, s2), dsf = acc_to_b(dp, s2);
-        tr_wait();
-#pragma unroll
-        for (int db = 0; db < 4; ++db) {
-          dv[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(tr_get(dot[db]), pf, dv[db], 0, 0, 0);
-          dk[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(tr_get(qt[db]), dsf, dk[db], 0, 0, 0);
-        }
+      for (int db = 0; db < 4; ++db) {
+        dv[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(tr_get(dot[1][db]), pf1, dv[db], 0, 0, 0);
+        dk[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(tr_get(qt[1][db]), dsf1, dk[db], 0, 0, 0);
       }
     }
     if (more) store_stats(smem + ((t + 1) & 1) * kStage);
