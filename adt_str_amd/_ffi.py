@@ -14,7 +14,7 @@ _LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "libadt_hip
 _lock = threading.Lock()
 _lib = None
 
-ABI_VERSION = 2
+ABI_VERSION = 3
 
 i32, i64, f32, ptr = C.c_int32, C.c_int64, C.c_float, C.c_void_p
 
@@ -67,6 +67,7 @@ SIGNATURES = {
     "adt_cross_entropy_workspace_bytes": [i64],
     "adt_cross_entropy": [ptr, i64, ptr, i64, i64, i64, ptr, ptr, i64, ptr, C.c_size_t, ptr],
     "adt_cast_bf16": [ptr, ptr, ptr, i64, i64, ptr],
+    "adt_cast_bf16_batched": [ptr, i32, i32, ptr],
     "adt_grad_norm_workspace_bytes": [],
     "adt_grad_norm": [ptr, i64, f32, ptr, ptr, C.c_size_t, ptr],
     "adt_adamw_step": [ptr, ptr, ptr, ptr, ptr, i64, f32, f32, f32, f32, f32, i64, ptr, ptr],

@@ -7,15 +7,17 @@
 //   trans = 0 (NT):  C[M,N] = A[M,K] . B[N,K]^T     forward  y = x W^T ; dgrad  dx = dy (W^T)^T
 //   trans = 1 (TN):  C[M,N] = A[K,M]^T . B[K,N]     wgrad    dW = dy^T x   (K = rows of dy and x)
 //
-// Tile 128x128x64, 256 threads = 4 waves in a 2x2 grid, each wave 64x64 = 4x4 MFMA
-// v_mfma_f32_16x16x32_bf16 blocks (64 fp32 accumulators).  Operands are staged
-// global -> registers -> LDS (16-byte loads, padded rows so fragment reads are bank-conflict
-// free), double-buffered with one barrier per K-tile; the next tile's global loads are issued
-// before the current tile's MFMAs.
-//   NT fragments: ds_read_b128 of 8 consecutive k of one row (row pitch 144 B).
-//   TN fragments: two ds_read_b64_tr_b16 per operand from a [k][m] image (row pitch 288 B);
-//                 element j of lane group g holds k = 4g + (j&3) + 16*(j>>2) for both operands,
-//                 which makes the two lane groups of a half-wave read 8 distinct 32-byte rows.
+// Three kernel structures, picked per call by adt_gemm_bf16 (all v_mfma_f32_16x16x32_bf16, fp32 accumulate):
+//   * persistent 256x256x64 kernels (gemm_nt_256_kernel, gemm_tn_256_kernel) for the large GEMMs of the training step:
+//     8 waves, 4 phases of 16 MFMAs per K-tile, LDS-DMA (global_load_lds_dwordx4) half-tiles in flight across raw
+//     barriers, staggered wave rows, per-XCD-slice work counters, next tile's prologue under the epilogue;
+//   * 128x128x64 LDS-DMA kernels (gemm_nt_glds_kernel: any K % 32 == 0; gemm_tn_glds_kernel: split-K through fp32 slabs)
+//     for everything smaller: 4 waves in a 2x2 grid, each 64x64 = 4x4 MFMA blocks, 2-stage pipeline, XCD-aware tile order;
+//   * a register-staged 128x128x64 kernel (gemm_bf16_kernel) for the remaining shapes (K % 32 != 0, unaligned views).
+//   NT fragments: ds_read_b128 of 8 consecutive k of one row.
+//   TN fragments: two ds_read_b64_tr_b16 per operand from a [k][m] image.
+// Epilogues transpose the accumulators through LDS so that bias / GELU / GELU' / ReLU / dropout / residual / dual-dtype
+// stores work on 8 consecutive columns of a row (16- and 32-byte accesses).
 // TN with split-K writes fp32 partial slabs that reduce_slabs_kernel sums in a fixed order
 // (bitwise reproducible, no float atomics).
 #include <hip/hip_runtime.h>

@@ -379,6 +379,32 @@ __global__ __launch_bounds__(256) void cast_transpose_bf16_kernel(const float* _
   }
 }
 
+// every weight of the network in ONE launch: block (tile, item) casts a 64x64 tile of item's matrix once and writes it
+// both ways (row-major copy and transposed copy); blocks past an item's tile count leave at once
+struct CastItem { const float* x; unsigned short* y; unsigned short* y_t; int rows, cols; };
+__global__ __launch_bounds__(256) void cast_bf16_batched_kernel(const CastItem* __restrict__ items) {
+  __shared__ unsigned short tile[64][66];
+  const CastItem it = items[blockIdx.y];
+  const int tc = (it.cols + 63) >> 6, tr = (it.rows + 63) >> 6;
+  if (static_cast<int>(blockIdx.x) >= tc * tr) return;
+  const int r0 = (blockIdx.x / tc) * 64, c0 = (blockIdx.x % tc) * 64;
+  for (int i = threadIdx.x; i < 64 * 64; i += 256) {
+    const int r = i >> 6, c = i & 63;
+    unsigned short v = 0;
+    if (r0 + r < it.rows && c0 + c < it.cols) {
+      v = f2bf_(it.x[static_cast<long>(r0 + r) * it.cols + c0 + c]);
+      if (it.y) it.y[static_cast<long>(r0 + r) * it.cols + c0 + c] = v;
+    }
+    tile[r][c] = v;
+  }
+  if (!it.y_t) return;
+  __syncthreads();
+  for (int i = threadIdx.x; i < 64 * 64; i += 256) {
+    const int c = i >> 6, r = i & 63;
+    if (c0 + c < it.cols && r0 + r < it.rows) it.y_t[static_cast<long>(c0 + c) * it.rows + r0 + r] = tile[r][c];
+  }
+}
+
 // ------------------------------------------------------------------------------------ grad-norm + AdamW on flat buffers
 constexpr int kSumsqBlocks = 1024;
 __global__ __launch_bounds__(256) void sumsq_partial_kernel(const float* __restrict__ g, long n, float* __restrict__ partial) {
@@ -571,6 +597,17 @@ extern "C" int adt_cast_bf16(const float* x, void* y, void* y_t, int64_t rows, i
                             static_cast<unsigned short*>(y), n);
   if (y_t) hipLaunchKernelGGL(cast_transpose_bf16_kernel, dim3(static_cast<unsigned>((cols + 63) / 64), static_cast<unsigned>((rows + 63) / 64)),
                               dim3(256), 0, ST(stream), x, static_cast<unsigned short*>(y_t), static_cast<int>(rows), static_cast<int>(cols));
+  ADT_HIP_TRY(hipGetLastError());
+  return ADT_OK;
+}
+
+static_assert(sizeof(CastItem) == sizeof(adt_cast_item), "CastItem mirrors adt_cast_item");
+extern "C" int adt_cast_bf16_batched(const adt_cast_item* items_dev, int32_t n_items, int32_t max_tiles, void* stream) {
+  if (!items_dev) return set_error(ADT_EINVAL, "adt_cast_bf16_batched: null pointer");
+  if (n_items < 0 || max_tiles < 0 || n_items > 65535) return set_error(ADT_EINVAL, "adt_cast_bf16_batched: bad counts");
+  if (n_items == 0 || max_tiles == 0) return ADT_OK;
+  hipLaunchKernelGGL(cast_bf16_batched_kernel, dim3(static_cast<unsigned>(max_tiles), static_cast<unsigned>(n_items)), dim3(256), 0, ST(stream),
+                     reinterpret_cast<const CastItem*>(items_dev));
   ADT_HIP_TRY(hipGetLastError());
   return ADT_OK;
 }

@@ -184,6 +184,31 @@ def cast_bf16(x, want=True, want_t=False):
     return y, yt
 
 
+class CastTable:
+    """Device table for ``adt_cast_bf16_batched``: every (fp32 weight -> bf16 copy + transposed copy) of a model, one launch."""
+
+    def __init__(self, weights):
+        import numpy as np
+        dev = weights[0].device
+        self.src_ptrs = tuple(w.data_ptr() for w in weights)
+        self.y = [torch.empty(w.shape, dtype=torch.bfloat16, device=dev) for w in weights]
+        self.y_t = [torch.empty((w.shape[1], w.shape[0]), dtype=torch.bfloat16, device=dev) for w in weights]
+        rec = np.zeros(len(weights), dtype=np.dtype([("x", "<u8"), ("y", "<u8"), ("yt", "<u8"), ("rows", "<i4"), ("cols", "<i4")]))
+        self.max_tiles = 0
+        for i, w in enumerate(weights):
+            assert w.dtype == torch.float32 and w.dim() == 2 and w.is_contiguous()
+            rec[i] = (w.data_ptr(), self.y[i].data_ptr(), self.y_t[i].data_ptr(), w.shape[0], w.shape[1])
+            self.max_tiles = max(self.max_tiles, -(-w.shape[0] // 64) * -(-w.shape[1] // 64))
+        self.items = torch.from_numpy(rec.view(np.uint8).reshape(-1).copy()).to(dev)
+        self.n = len(weights)
+
+    def matches(self, weights) -> bool:
+        return self.src_ptrs == tuple(w.data_ptr() for w in weights)
+
+    def run(self):
+        _ffi.call("adt_cast_bf16_batched", _ffi.dptr(self.items), self.n, self.max_tiles, _ffi.current_stream())
+
+
 def grad_norm(g, max_norm, out=None):
     assert g.dtype == torch.float32 and g.is_contiguous()
     if out is None:

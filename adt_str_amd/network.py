@@ -156,6 +156,7 @@ class _Engine:
                                  ca_o=lin(p + ".multihead_attn.out_proj"), l1=lin(p + ".linear1"), l2=lin(p + ".linear2")))
         self.named = named
         self._versions = None
+        self._cast_table = None
         self.gflat: Optional[torch.Tensor] = None
         self.G: Dict[str, torch.Tensor] = {}
         self.grad_ready_hook = None      # callable(lo, hi): flat gradient range [lo, hi) is final (used to overlap all-reduce)
@@ -178,8 +179,17 @@ class _Engine:
         """Re-derive the bf16 operands when any parameter was modified in place (optimizer step, load_state_dict)."""
         ver = tuple(p._version for p in self.named.values()) + (str(next(iter(self.named.values())).device),)
         if force or ver != self._versions:
-            for l in self.lins.values():
-                l.refresh()
+            lins = list(self.lins.values())
+            ws = [l.weight.data for l in lins]
+            if any(not w.is_contiguous() for w in ws):
+                for l in lins:
+                    l.refresh()
+            else:                                         # one launch for every weight (pointers are stable between steps)
+                if self._cast_table is None or not self._cast_table.matches(ws):
+                    self._cast_table = K.CastTable(ws)
+                    for l, y, yt in zip(lins, self._cast_table.y, self._cast_table.y_t):
+                        l.w16, l.wt16 = y, yt
+                self._cast_table.run()
             self._versions = tuple(p._version for p in self.named.values()) + (ver[-1],)
 
     def grad_buffers(self):

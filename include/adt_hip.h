@@ -39,7 +39,7 @@ extern "C" {
  * backward entry points regenerate them from the same (p, key).  p == 0 or a null pointer: off. */
 typedef struct adt_dropout { float p; uint32_t key; } adt_dropout;
 
-/* ABI version: bumped whenever a signature below changes. */
+/* ABI version (3): bumped whenever a signature below changes or entries are added. */
 int adt_version(void);
 
 /* Message of the last failing call on this thread ("" if none). */
@@ -255,6 +255,17 @@ int adt_cross_entropy(const float* logits, int64_t ld, const int64_t* labels, in
  * -> bf16 copy y (same layout) and/or y_t [cols, rows] (the NT operand of dgrad).
  */
 int adt_cast_bf16(const float* x, void* y, void* y_t, int64_t rows, int64_t cols, void* stream);
+
+/* The same for a whole table of matrices in one launch (the per-step refresh of every weight's bf16 operands):
+ * items_dev is a DEVICE array of n_items records; max_tiles = max over items of ceil(rows/64) * ceil(cols/64).
+ * y and/or y_t may be null per item. */
+typedef struct adt_cast_item {
+  const float* x;       /* fp32 [rows, cols], contiguous */
+  void* y;              /* bf16 [rows, cols] or null     */
+  void* y_t;            /* bf16 [cols, rows] or null     */
+  int32_t rows, cols;
+} adt_cast_item;
+int adt_cast_bf16_batched(const adt_cast_item* items_dev, int32_t n_items, int32_t max_tiles, void* stream);
 
 /* ---------------------------------------------------------------------------
  * Optimizer step on flat fp32 buffers: torch.nn.utils.clip_grad_norm_(max_norm)

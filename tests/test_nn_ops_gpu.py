@@ -102,6 +102,21 @@ def test_cast_and_transpose():
     assert torch.equal(y2, x2.bfloat16()) and torch.equal(yt2, x2.bfloat16().t().contiguous())
 
 
+def test_batched_cast_table():
+    """One launch for a whole list of weights: every row-major and transposed bf16 copy equals the single-matrix path."""
+    from adt_str_amd import kernels as k
+    ws = [rnd(shape, 20 + i) for i, shape in enumerate([(768, 128), (2304, 768), (1400, 768), (64, 64), (77, 136), (3072, 768)])]
+    tab = k.CastTable(ws)
+    tab.run()
+    for w, y, yt in zip(ws, tab.y, tab.y_t):
+        assert torch.equal(y, w.bfloat16()) and torch.equal(yt, w.bfloat16().t().contiguous())
+    ws[1].mul_(2.0)                                       # in-place update (optimizer step): same pointers, same table
+    assert tab.matches(ws)
+    tab.run()
+    assert torch.equal(tab.y[1], ws[1].bfloat16())
+    assert not tab.matches([w.clone() for w in ws])
+
+
 def test_grad_norm_and_adamw_match_torch():
     from adt_str_amd import kernels as k
     n = 1_000_003
