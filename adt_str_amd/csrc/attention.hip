@@ -21,8 +21,8 @@
 // which makes both the 16-byte row reads and the transposed 8-byte reads bank-conflict free.
 // Tiles are double-buffered: the next tile's global loads are issued before the MFMAs of the
 // current one and written to the other buffer afterwards (one barrier per tile).
-// The backward recomputes P from the saved log-sum-exp; dQ and dK/dV are separate kernels so no
-// float atomics are needed (bitwise reproducible).
+// The backward recomputes P from the saved log-sum-exp; dQ (which also produces delta = rowsum(O * dO) for its queries)
+// and dK/dV are separate kernels so no float atomics are needed (bitwise reproducible).
 #include <hip/hip_runtime.h>
 
 #include "adt_common.h"
@@ -268,24 +268,6 @@ __global__ __launch_bounds__(kAttnThreads, 2) void attn_fwd_kernel(AttnArgs a) {
   if (h == 0 && qi < a.Sq && a.lse) a.lse[(static_cast<long>(b) * a.H + head) * a.Sq + qi] = (m + log2f(lt)) * kLn2;
 }
 
-// =============================================================================== backward: delta = rowsum(dO * O)
-__global__ __launch_bounds__(256) void attn_delta_kernel(const unsigned short* __restrict__ o, const unsigned short* __restrict__ dout,
-                                                         long ldo, int B, int H, int Sq, float* __restrict__ delta) {
-  const int lane = threadIdx.x & 63;
-  const long idx = static_cast<long>(blockIdx.x) * 4 + (threadIdx.x >> 6);       // (b, q, head)
-  const long total = static_cast<long>(B) * Sq * H;
-  if (idx >= total) return;
-  const int head = static_cast<int>(idx % H);
-  const long bq = idx / H;
-  const int qi = static_cast<int>(bq % Sq), b = static_cast<int>(bq / Sq);
-  const long off = bq * ldo + head * kDh + 2 * lane;
-  const unsigned ov = *reinterpret_cast<const unsigned*>(o + off), dv = *reinterpret_cast<const unsigned*>(dout + off);
-  float s = __uint_as_float(ov << 16) * __uint_as_float(dv << 16) + __uint_as_float(ov & 0xffff0000u) * __uint_as_float(dv & 0xffff0000u);
-#pragma unroll
-  for (int k = 32; k > 0; k >>= 1) s += __shfl_xor(s, k);
-  if (lane == 0) delta[(static_cast<long>(b) * H + head) * Sq + qi] = s;
-}
-
 // =============================================================================== backward: dQ  (lane <-> query)
 template <bool kDrop>
 __global__ __launch_bounds__(kAttnThreads, 2) void attn_bwd_dq_kernel(AttnArgs a) {
@@ -301,13 +283,28 @@ __global__ __launch_bounds__(kAttnThreads, 2) void attn_bwd_dq_kernel(AttnArgs a
   const int klen = a.key_len ? a.key_len[b] : a.Sk;
   const float sl2 = a.scale * kLog2e;
   const long stat = (static_cast<long>(b) * a.H + head) * a.Sq + (qi < a.Sq ? qi : 0);
-  const float lse2 = a.lse[stat] * kLog2e, dlt = a.delta[stat];
+  const float lse2 = a.lse[stat] * kLog2e;
   const unsigned rowbase = static_cast<unsigned>(((static_cast<uint64_t>(b) * a.H + head) * a.Sq + qi) * a.Sk);
   const unsigned key2 = mix32(a.drop.key);
 
   bf16x8 qf[8], dof[8];
   frags_from_global(qb, a.ldq, qi, a.Sq, lane, qf);
   frags_from_global(dob, a.ldo, qi, a.Sq, lane, dof);
+  // delta = rowsum(O * dO) of this lane's query: the lane already holds half of its dO row (d = 16s + 8h .. +7), the partner
+  // lane (lane ^ 32) the other half.  Written out for the dK/dV kernel, which runs after this one on the same stream.
+  float dlt = 0.f;
+  {
+    bf16x8 of[8];
+    frags_from_global(a.o + static_cast<long>(b) * a.Sq * a.ldo + head * kDh, a.ldo, qi, a.Sq, lane, of);
+#pragma unroll
+    for (int s = 0; s < 8; ++s)
+#pragma unroll
+      for (int e = 0; e < 8; ++e)
+        dlt = fmaf(__uint_as_float(static_cast<unsigned>(static_cast<unsigned short>(of[s][e])) << 16),
+                   __uint_as_float(static_cast<unsigned>(static_cast<unsigned short>(dof[s][e])) << 16), dlt);
+    dlt += __shfl_xor(dlt, 32);
+    if (h == 0 && qi < a.Sq) const_cast<float*>(a.delta)[stat] = dlt;
+  }
   f32x16 dq[4];
 #pragma unroll
   for (int db = 0; db < 4; ++db)
@@ -564,9 +561,6 @@ extern "C" int adt_attn_bwd(const adt_attn_desc* d, const void* q, const void* k
   a.o = static_cast<const unsigned short*>(o); a.dout = static_cast<const unsigned short*>(dout);
   a.lse = const_cast<float*>(lse); a.delta = static_cast<const float*>(ws);
   a.dq = static_cast<unsigned short*>(dq); a.dk = static_cast<unsigned short*>(dk); a.dv = static_cast<unsigned short*>(dv);
-  const long rows = static_cast<long>(d->batch) * d->q_len * d->heads;
-  hipLaunchKernelGGL(attn_delta_kernel, dim3(static_cast<unsigned>((rows + 3) / 4)), dim3(256), 0, st, a.o, a.dout, a.ldo, a.B, a.H, a.Sq,
-                     static_cast<float*>(ws));
   const int lds_dq = 4 * kAttnTileBytes, lds_dkv = 2 * (2 * kAttnTileBytes + 512);
   if (int rc = set_lds_once()) return rc;
   const dim3 gq((d->q_len + 127) / 128, d->batch * d->heads), gk((d->k_len + 127) / 128, d->batch * d->heads);
