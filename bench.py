@@ -322,10 +322,18 @@ def main():
     if args.gpus > 1 and world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} needs torch.distributed.run with {args.gpus} ranks (WORLD_SIZE={world})")
     assert torch.cuda.is_available(), "bench.py needs a GPU (there is no CPU path)"
+    # ADT_BENCH_SHARE_GPU=1 (debug only): every rank on GPU 0 with the gloo backend, to exercise the N > 1 code path on a
+    # one-GPU box; numbers from that mode are meaningless and the JSON line says so
+    share = os.environ.get("ADT_BENCH_SHARE_GPU") == "1"
+    if share:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     if world > 1:
-        dist.init_process_group("nccl", device_id=dev)
+        if share:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=dev)
 
     wl = {"train": lambda: train_setup(dev, rank, world, args.dropout), "logmel": lambda: logmel_setup(dev, rank),
           "clap": lambda: clap_setup(dev, rank)}[args.workload]()
@@ -361,6 +369,8 @@ def main():
             line["step_mfma_frac"] = tf / BF16_MFMA_PEAK_TF
             loss = wl["state"]["loss"]
             line["final_loss"] = float(loss.item()) if loss is not None else None
+        if os.environ.get("ADT_BENCH_SHARE_GPU") == "1":
+            line["data"] = "synthetic; DEBUG RUN: all ranks share GPU 0 over gloo (ADT_BENCH_SHARE_GPU=1), not a measurement"
         line["roofline"] = wl["roofline"]()
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = wl["cpu_baseline"]()
