@@ -197,3 +197,27 @@ def test_curation_driver_end_to_end(setup, tmp_path):
     write_wav(str(pack_root / "other_rate.wav"), shot(100.0, 4000), 44100)       # resampled to 48 kHz on the GPU (K13)
     res2, files2, _ = mod.run(cfg, clap_model=model, copy=False)
     assert len(files2) == 10 and sorted(res2.order.tolist()) == list(range(10))
+
+
+def test_full_size_batch_properties(setup):
+    """BASELINE config[2] size (512 one-shots): unit-norm outputs, and a clip's embedding does not depend on what else is in
+    the batch (the tower has no cross-clip operation; different batch sizes select different GEMM tilings, hence the tolerance)."""
+    from adt_str_amd.clap_encoder import ClapWrapper
+    model, *_ = setup
+    rng = np.random.default_rng(21)
+    clips = []
+    for _ in range(512):
+        n = int(rng.integers(4800, 96001))
+        t = np.arange(n, dtype=np.float32) / 48000.0
+        x = np.exp(-t * rng.uniform(5.0, 40.0)) * (rng.standard_normal(n).astype(np.float32) * 0.5 + np.sin(2 * np.pi * rng.uniform(40.0, 4000.0) * t))
+        clips.append(torch.from_numpy((x / np.abs(x).max()).astype(np.float32)).unsqueeze(0))
+    w = ClapWrapper("unused", DEV, 48000, clap_model=model)
+    flags = torch.zeros(512, dtype=torch.bool)
+    flags[37] = True
+    emb = w.get_audio_features(clips, is_longer=flags)
+    assert emb.shape == (512, 512) and torch.isfinite(emb).all()
+    assert torch.allclose(emb.norm(dim=-1), torch.ones(512, device=emb.device), atol=1e-5)
+    pick = [0, 37, 300, 511]
+    small = w.get_audio_features([clips[i] for i in pick], is_longer=flags[pick])
+    cos = (emb[pick] * small).sum(-1)
+    assert cos.min() > 0.9999 and (emb[pick] - small).abs().max() < 5e-3
