@@ -141,6 +141,10 @@ int adt_mix_render_f32(const float* bank, const int64_t* bank_off, int64_t n_sho
  *   (an fp32 residual-stream output plus the bf16 operand of the next GEMM in one pass)
  * trans = 1 may split K across workgroups; partial fp32 slabs go to `ws`
  * (adt_gemm_workspace_bytes) and are summed in slab order (reproducible).
+ * Large problems run on persistent kernels that take tiles from device work counters owned by the library: one
+ * 512-byte allocation per (device, stream), made on the first large call on that stream (the only allocation this
+ * library ever makes; it synchronises the device once).  As for any stream-ordered API, calls that target the same
+ * stream must not race each other from different host threads.
  */
 typedef struct adt_gemm_epilogue {
   const float* bias;
