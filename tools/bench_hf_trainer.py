@@ -1,0 +1,53 @@
+#!/usr/bin/env python3
+"""Step time of the HF-Trainer-style path (ADTTrainer.compute_loss hook -> autograd bridge -> clip_grad_norm_ -> torch AdamW)
+next to the native flat-buffer loop, on the model / batch shape of bench.py's train workload.  GPU box only."""
+import os
+import sys
+import time
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np
+import torch
+import bench
+from adt_str_amd.masks import create_mask_plain
+from adt_str_amd.network import ADTModel, ADTModelConfig
+
+dev = torch.device("cuda:0")
+B, L, T = 64, 160000, 128
+torch.manual_seed(0)
+cfg = ADTModelConfig(input_sec=10.0, time_res=0.01, win_length=2048, sample_rate=16000, dropout=0.1, plain=True, **bench.SETTING1)
+model = ADTModel(cfg).to(dev).train()
+rng = np.random.default_rng(0)
+tok, tl = bench.synthetic_tokens(rng, B, T)
+tokens, lens = torch.from_numpy(tok).to(dev), torch.from_numpy(tl).to(dev)
+wavs = torch.randn(B, L, device=dev) * 0.1
+opt = torch.optim.AdamW(model.parameters(), lr=1e-4, weight_decay=1e-5)
+
+
+def hf_step():
+    tgt_input, labels = tokens[:, :-1], tokens[:, 1:]
+    _, pad = create_mask_plain(tgt_input.size(1), lens, dev)
+    loss = model(src=wavs, tgt=tgt_input, tgt_mask=None, tgt_padding_mask=pad, labels=labels)
+    loss.backward()
+    torch.nn.utils.clip_grad_norm_(model.parameters(), 1.0)
+    opt.step()
+    opt.zero_grad(set_to_none=True)
+    return loss
+
+
+for _ in range(3):
+    hf_step()
+torch.cuda.synchronize(); t0 = time.perf_counter()
+for _ in range(10):
+    hf_step()
+torch.cuda.synchronize()
+print(f"HF-style step (autograd bridge + clip_grad_norm_ + torch AdamW): {(time.perf_counter() - t0) * 100:.2f} ms/step")
+
+from adt_str_amd.trainer import FlatTrainer
+tr = FlatTrainer(model, lr=1e-4, weight_decay=1e-5, max_grad_norm=1.0, total_steps=10000, warmup_ratio=0.1)
+for _ in range(3):
+    tr.train_step(wavs, tokens, lens)
+torch.cuda.synchronize(); t0 = time.perf_counter()
+for _ in range(10):
+    tr.train_step(wavs, tokens, lens)
+torch.cuda.synchronize()
+print(f"native FlatTrainer step (same batch, no mixer): {(time.perf_counter() - t0) * 100:.2f} ms/step")
