@@ -13,7 +13,7 @@
 //       registers), so one lane owns its query's scores, the row max/sum are in-register plus one
 //       cross-half shuffle, and the accumulator (keys on rows) is directly the B operand of
 //       O^T += V^T P^T  (A = V^T through ds_read_b64_tr_b16).  dQ^T += K^T dS^T the same way.
-//   dK/dV kernel        : lane <-> key.  S = Q K^T, dP = dO V^T (A = Q / dO rows from LDS,
+//   dK/dV kernels       : lane <-> key.  S = Q K^T, dP = dO V^T (A = Q / dO rows from LDS,
 //       B = K^T / V^T in registers); P and dS (queries on rows) are the B operands of
 //       dV^T += dO^T P and dK^T += Q^T dS (A through transposed LDS reads).
 // K/V (or Q/dO) tiles of 64 rows x 256 B live in LDS under the XOR swizzle
@@ -25,6 +25,8 @@
 // and dK/dV are separate kernels so no float atomics are needed (bitwise reproducible).
 #include <hip/hip_runtime.h>
 
+#include <cstdlib>
+
 #include "adt_common.h"
 #include "dropout.h"
 
@@ -33,6 +35,7 @@ namespace adt {
 typedef __attribute__((ext_vector_type(8))) short bf16x8;
 typedef __attribute__((ext_vector_type(4))) short bf16x4;
 typedef __attribute__((ext_vector_type(16))) float f32x16;
+typedef __attribute__((ext_vector_type(4))) float f32x4;
 
 constexpr int kDh = 128;
 constexpr int kAttnThreads = 256;
@@ -485,6 +488,238 @@ __global__ __launch_bounds__(kAttnThreads, 1) void attn_bwd_dkv_kernel(AttnArgs 
   store_transposed(dv, 1.0f, a.dv + static_cast<long>(b) * a.Sk * a.ldv + head * kDh, a.ldv, ki, a.Sk, lane);
 }
 
+// =============================================================================== backward: dK, dV, producer / consumer waves
+// The kernel above keeps everything in one wave (S, dP, softmax / dropout arithmetic, dV, dK): ~400 registers = one wave per
+// SIMD, whose MFMAs, VALU work and LDS waits serialise (PMC: 13 % MFMA-busy, 44 % of wave-cycles parked in waits).  Here a
+// workgroup has 8 waves = 2 per SIMD with different jobs for the same 32 keys:
+//   * S-wave  w (0..3): K^T, V^T fragments in registers; per 32-query block S = Q K^T, dP = dO V^T (16 MFMAs), then all the
+//     VALU work (exp2, dropout hash, dS), packs P_drop and dS as MFMA B operands and hands them over through LDS;
+//   * acc-wave w + 4 : dV^T += dO^T P, dK^T += Q^T dS (16 MFMAs from transposed LDS reads), accumulators in registers.
+// Both fit 256 registers, and the acc-wave's MFMAs run in the shadow of the S-wave's VALU stream on the same SIMD.
+// The acc-wave works one query block behind its S-wave; one s_barrier per block orders the hand-over buffers (double
+// buffered) and the three Q / dO tile stages (a stage is refilled by LDS-DMA three blocks before it is needed again).
+constexpr int kDkv2Threads = 512;
+constexpr int kDkv2Stage = 2 * kAttnTileBytes + 512;          // Q tile | dO tile | lse2[64] | delta[64]
+constexpr int kDkv2Hand = 4 * 1024;                           // P(s2=0) | P(s2=1) | dS(s2=0) | dS(s2=1), one 16-byte operand per lane
+constexpr int kDkv2Mask = 256;                                // keep bits of one 32-query block: one dword per lane
+constexpr int kDkv2Lds = 3 * kDkv2Stage + 4 * 2 * kDkv2Hand + 4 * 2 * kDkv2Mask;  // 134,656 B
+
+__device__ __forceinline__ void tile_dma8(const unsigned short* __restrict__ base, long row_stride, int row0, int n_rows,
+                                          unsigned char* tile, int wave, int lane) {     // 8 waves x 2 instructions x 4 rows
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    const int row = 4 * (2 * wave + i) + (lane >> 4);
+    const int chunk = (lane & 15) ^ (((row & 3) << 2) | ((row >> 2) & 3));
+    int gr = row0 + row;
+    gr = gr < n_rows ? gr : n_rows - 1;
+    const unsigned short* p = base + static_cast<long>(gr) * row_stride + chunk * 8;
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)p,
+                                     (__attribute__((address_space(3))) void*)(tile + (2 * wave + i) * 1024), 16, 0, 0);
+  }
+}
+
+template <bool kDrop>
+__global__ __launch_bounds__(kDkv2Threads) void attn_bwd_dkv2_kernel(AttnArgs a) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  const int tid = threadIdx.x, lane = tid & 63, r = lane & 31, h = lane >> 5;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int role = wave >> 2, pair = wave & 3;                    // role 0: S-wave, 1: acc-wave
+  const int b = blockIdx.y / a.H, head = blockIdx.y % a.H;
+  const int ki = blockIdx.x * 128 + pair * 32 + r;
+  const unsigned short* qb = a.q + static_cast<long>(b) * a.Sq * a.ldq + head * kDh;
+  const unsigned short* dob = a.dout + static_cast<long>(b) * a.Sq * a.ldo + head * kDh;
+  const float* lse_b = a.lse + (static_cast<long>(b) * a.H + head) * a.Sq;
+  const float* dl_b = a.delta + (static_cast<long>(b) * a.H + head) * a.Sq;
+  unsigned char* hand = smem + 3 * kDkv2Stage + pair * 2 * kDkv2Hand;
+  unsigned* keepbits = reinterpret_cast<unsigned*>(smem + 3 * kDkv2Stage + 4 * 2 * kDkv2Hand + pair * 2 * kDkv2Mask);
+  const int n_tiles = (a.Sq + kRowsPerTile - 1) / kRowsPerTile;
+  const int n_iter = 2 * n_tiles + 1;
+  // dropout: the keep decisions depend on indices only, so the (mostly idle) acc-wave hashes them one block AHEAD of its
+  // S-wave and hands over 16 bits per lane (bit i = element i kept); the S-wave then spends two instructions per element
+  // instead of the whole hash.  Block 0's bits are produced before the loop.
+  const unsigned headbase = static_cast<unsigned>((static_cast<uint64_t>(b) * a.H + head) * a.Sq * a.Sk) + static_cast<unsigned>(ki);
+  const unsigned key2 = mix32(a.drop.key);
+  auto keep_mask_of_block = [&](int jb) {
+    unsigned bits = 0;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+      const int qi = jb * 32 + acc_row(i, h);
+      bits |= (mix32((headbase + static_cast<unsigned>(qi) * static_cast<unsigned>(a.Sk)) ^ key2) >= a.drop.thr ? 1u : 0u) << i;
+    }
+    return bits;
+  };
+  if (kDrop && role == 1) keepbits[lane] = keep_mask_of_block(0);
+
+  float rs = 0.f;
+  auto load_stats = [&](int t) {                                   // threads 0..63: lse2, 64..127: delta of tile t's 64 queries
+    const int qq = t * kRowsPerTile + (tid & 63);
+    rs = 0.f;
+    if (tid < 128 && qq < a.Sq) rs = tid < 64 ? lse_b[qq] * kLog2e : dl_b[qq];
+  };
+  auto store_stats = [&](int t) {
+    if (tid < 128) reinterpret_cast<float*>(smem + (t % 3) * kDkv2Stage + 2 * kAttnTileBytes)[tid] = rs;
+  };
+  auto issue_tile = [&](int t) {                                   // stats first: the DMAs behind them stay in flight longer
+    load_stats(t);
+    unsigned char* st = smem + (t % 3) * kDkv2Stage;
+    tile_dma8(qb, a.ldq, t * kRowsPerTile, a.Sq, st, wave, lane);
+    tile_dma8(dob, a.ldo, t * kRowsPerTile, a.Sq, st + kAttnTileBytes, wave, lane);
+  };
+  // prologue: tiles 0..2 resident (stats of a tile are stored once its loads have returned)
+  for (int t = 0; t < 3 && t < n_tiles; ++t) {
+    issue_tile(t);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    store_stats(t);
+  }
+  __syncthreads();
+
+  // Every wave runs n_iter iterations with ONE barrier each.  In iteration j the S-waves work on query block j (j < 2 n_tiles),
+  // the acc-waves on block j - 1 (j >= 1).  Odd iterations j >= 3 start the refill of the stage that block j - 1 was the last to
+  // use (tile (j + 3) / 2); the even iteration after it waits for the refill (it then has had a whole iteration to land).
+#define ADT_DKV2_END_OF_ITERATION(j)                                                      \
+  do {                                                                                     \
+    const int tn_ = ((j) + 3) >> 1;                                                        \
+    if (((j) & 1) && (j) >= 3 && tn_ < n_tiles) issue_tile(tn_);                           \
+    if (!((j) & 1) && (j) >= 4 && (((j) + 2) >> 1) < n_tiles) {                            \
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                                     \
+      store_stats(((j) + 2) >> 1);                                                         \
+    }                                                                                      \
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                                     \
+    asm volatile("s_barrier" ::: "memory");                                                \
+  } while (0)
+
+  if (role == 0) {
+    // ------------------------------------------------------------------ S-waves
+    const unsigned short* kb_ = a.k + static_cast<long>(b) * a.Sk * a.ldk + head * kDh;
+    const unsigned short* vb = a.v + static_cast<long>(b) * a.Sk * a.ldv + head * kDh;
+    const int klen = a.key_len ? a.key_len[b] : a.Sk;
+    const float sl2 = a.scale * kLog2e;
+    const int k_end = blockIdx.x * 128 + 128;
+    const bool key_mask = a.causal || k_end > klen || k_end > a.Sk;
+    bf16x8 kf[8], vf[8];
+    frags_from_global(kb_, a.ldk, ki, a.Sk, lane, kf);
+    frags_from_global(vb, a.ldv, ki, a.Sk, lane, vf);
+#pragma unroll
+    for (int s = 0; s < 8; ++s) asm volatile("" :: "v"(kf[s]), "v"(vf[s]));      // first use here: the compiler's wait for these loads
+                                                                                // lands before the loop, not in front of its MFMAs
+    // LDS reads of the S-waves are inline asm with hand-placed lgkmcnt waits: compiler-generated reads would be ordered behind
+    // the tile DMAs in flight with a vmcnt(0), and come two at a time.  Per-lane byte offsets of the eight 16-byte row chunks:
+    unsigned foff[8];
+    {
+      const int x = ((r & 3) << 2) | ((r >> 2) & 3);
+#pragma unroll
+      for (int s = 0; s < 8; ++s) foff[s] = static_cast<unsigned>(256 * r + 16 * ((2 * s + h) ^ x));
+    }
+    const unsigned smem_base = lds_off(smem);
+    for (int j = 0; j < n_iter; ++j) {
+      if (j < 2 * n_tiles) {
+        const int t = j >> 1, qblk = j & 1;
+        const unsigned tq_a = smem_base + static_cast<unsigned>((t % 3) * kDkv2Stage + qblk * 32 * 256);
+        const unsigned td_a = tq_a + kAttnTileBytes;
+        const unsigned st_a = smem_base + static_cast<unsigned>((t % 3) * kDkv2Stage + 2 * kAttnTileBytes + (qblk * 32 + 4 * h) * 4);
+        bf16x8 fq[8], fd[8];
+#pragma unroll
+        for (int s = 0; s < 8; ++s) {
+          asm volatile("ds_read_b128 %0, %1" : "=v"(fq[s]) : "v"(tq_a + foff[s]));
+          asm volatile("ds_read_b128 %0, %1" : "=v"(fd[s]) : "v"(td_a + foff[s]));
+        }
+        f32x16 st, dp;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) { st[i] = 0.f; dp[i] = 0.f; }
+#define ADT_S_STEP(S, CNT)                                                                        \
+        asm volatile("s_waitcnt lgkmcnt(" #CNT ")" ::: "memory");                                  \
+        __builtin_amdgcn_sched_barrier(0);                                                         \
+        st = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fq[S], kf[S], st, 0, 0, 0);                   \
+        dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fd[S], vf[S], dp, 0, 0, 0);                   \
+        __builtin_amdgcn_sched_barrier(0);
+        ADT_S_STEP(0, 14) ADT_S_STEP(1, 12) ADT_S_STEP(2, 10) ADT_S_STEP(3, 8)
+        ADT_S_STEP(4, 6) ADT_S_STEP(5, 4) ADT_S_STEP(6, 2) ADT_S_STEP(7, 0)
+#undef ADT_S_STEP
+        // per-query statistics of this lane's 16 rows: rows 8 q4 + 4h + (0..3) are four consecutive floats
+        f32x4 l4[4], d4[4];
+        asm volatile("ds_read_b128 %0, %1" : "=v"(l4[0]) : "v"(st_a));
+        asm volatile("ds_read_b128 %0, %1 offset:32" : "=v"(l4[1]) : "v"(st_a));
+        asm volatile("ds_read_b128 %0, %1 offset:64" : "=v"(l4[2]) : "v"(st_a));
+        asm volatile("ds_read_b128 %0, %1 offset:96" : "=v"(l4[3]) : "v"(st_a));
+        asm volatile("ds_read_b128 %0, %1 offset:256" : "=v"(d4[0]) : "v"(st_a));
+        asm volatile("ds_read_b128 %0, %1 offset:288" : "=v"(d4[1]) : "v"(st_a));
+        asm volatile("ds_read_b128 %0, %1 offset:320" : "=v"(d4[2]) : "v"(st_a));
+        asm volatile("ds_read_b128 %0, %1 offset:352" : "=v"(d4[3]) : "v"(st_a));
+        unsigned kbits = 0xffffu;
+        if (kDrop) asm volatile("ds_read_b32 %0, %1" : "=v"(kbits) : "v"(lds_off(keepbits + (j & 1) * (kDkv2Mask / 4) + lane)));
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_sched_barrier(0);
+        float lse4[16], dl4[16];
+#pragma unroll
+        for (int q4 = 0; q4 < 4; ++q4)
+#pragma unroll
+          for (int e = 0; e < 4; ++e) { lse4[4 * q4 + e] = l4[q4][e]; dl4[4 * q4 + e] = d4[q4][e]; }
+        const bool need_mask = key_mask || (t + 1) * kRowsPerTile > a.Sq;     // block-uniform
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+          const int ql = qblk * 32 + acc_row(i, h);
+          const int qi = t * kRowsPerTile + ql;
+          float p;
+          if (need_mask) {
+            const float tt = fmaf(st[i], sl2, mask_add(a, qi, ki, klen) * kLog2e);
+            p = (qi < a.Sq && ki < a.Sk) ? __builtin_amdgcn_exp2f(tt - lse4[i]) : 0.f;
+          } else {
+            p = __builtin_amdgcn_exp2f(fmaf(st[i], sl2, -lse4[i]));
+          }
+          const float keep = kDrop ? (((kbits >> i) & 1u) ? a.drop.inv_keep : 0.0f) : 1.0f;
+          st[i] = p * keep;                                    // dropped P (what multiplied V in the forward)
+          dp[i] = p * fmaf(dp[i], keep, -dl4[i]);              // dS / scale (scale applied when dK is stored)
+        }
+        unsigned char* hb = hand + (j & 1) * kDkv2Hand + lane * 16;
+        *reinterpret_cast<bf16x8*>(hb) = acc_to_b(st, 0);
+        *reinterpret_cast<bf16x8*>(hb + 1024) = acc_to_b(st, 1);
+        *reinterpret_cast<bf16x8*>(hb + 2048) = acc_to_b(dp, 0);
+        *reinterpret_cast<bf16x8*>(hb + 3072) = acc_to_b(dp, 1);
+      }
+      ADT_DKV2_END_OF_ITERATION(j);
+    }
+  } else {
+    // ------------------------------------------------------------------ acc-waves
+    f32x16 dk[4], dv[4];
+#pragma unroll
+    for (int db = 0; db < 4; ++db)
+#pragma unroll
+      for (int i = 0; i < 16; ++i) { dk[db][i] = 0.f; dv[db][i] = 0.f; }
+    for (int j = 0; j < n_iter; ++j) {
+      if (kDrop && j + 1 < 2 * n_tiles) keepbits[((j + 1) & 1) * (kDkv2Mask / 4) + lane] = keep_mask_of_block(j + 1);
+      if (j >= 1) {
+        const int jj = j - 1, t = jj >> 1, qblk = jj & 1;
+        const unsigned char* tq = smem + (t % 3) * kDkv2Stage;
+        const unsigned char* td = tq + kAttnTileBytes;
+        TrFrag dot[2][4], qt[2][4];
+#pragma unroll
+        for (int s2 = 0; s2 < 2; ++s2) {
+          tr4_issue(td, qblk * 32 + 16 * s2, lane, dot[s2]);
+          tr4_issue(tq, qblk * 32 + 16 * s2, lane, qt[s2]);
+        }
+        const unsigned char* hb = hand + (jj & 1) * kDkv2Hand + lane * 16;
+        const bf16x8 pf0 = *reinterpret_cast<const bf16x8*>(hb), pf1 = *reinterpret_cast<const bf16x8*>(hb + 1024);
+        const bf16x8 dsf0 = *reinterpret_cast<const bf16x8*>(hb + 2048), dsf1 = *reinterpret_cast<const bf16x8*>(hb + 3072);
+        tr_wait();
+#pragma unroll
+        for (int db = 0; db < 4; ++db) {
+          dv[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(tr_get(dot[0][db]), pf0, dv[db], 0, 0, 0);
+          dk[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(tr_get(qt[0][db]), dsf0, dk[db], 0, 0, 0);
+        }
+#pragma unroll
+        for (int db = 0; db < 4; ++db) {
+          dv[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(tr_get(dot[1][db]), pf1, dv[db], 0, 0, 0);
+          dk[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(tr_get(qt[1][db]), dsf1, dk[db], 0, 0, 0);
+        }
+      }
+      ADT_DKV2_END_OF_ITERATION(j);
+    }
+    store_transposed(dk, a.scale, a.dk + static_cast<long>(b) * a.Sk * a.ldk + head * kDh, a.ldk, ki, a.Sk, lane);
+    store_transposed(dv, 1.0f, a.dv + static_cast<long>(b) * a.Sk * a.ldv + head * kDh, a.ldv, ki, a.Sk, lane);
+  }
+#undef ADT_DKV2_END_OF_ITERATION
+}
+
 static int check_desc(const adt_attn_desc* d, const char* who) {
   if (!d) return set_error(ADT_EINVAL, "attention: null descriptor");
   if (d->head_dim != kDh) return set_error(ADT_ESHAPE, "attention: head_dim must be 128");
@@ -518,6 +753,8 @@ static int set_lds_once() {      // raise the dynamic-LDS limit of the three ker
   ADT_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(attn_bwd_dq_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, l4));
   ADT_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(attn_bwd_dkv_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, ldkv));
   ADT_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(attn_bwd_dkv_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, ldkv));
+  ADT_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(attn_bwd_dkv2_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, kDkv2Lds));
+  ADT_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(attn_bwd_dkv2_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, kDkv2Lds));
   done_for = dev;
   return ADT_OK;
 }
@@ -564,12 +801,15 @@ extern "C" int adt_attn_bwd(const adt_attn_desc* d, const void* q, const void* k
   const int lds_dq = 4 * kAttnTileBytes, lds_dkv = 2 * (2 * kAttnTileBytes + 512);
   if (int rc = set_lds_once()) return rc;
   const dim3 gq((d->q_len + 127) / 128, d->batch * d->heads), gk((d->k_len + 127) / 128, d->batch * d->heads);
+  static const int dkv_variant = [] { const char* v = getenv("ADT_ATTN_DKV"); return v ? atoi(v) : 2; }();   // 1: single-wave kernel (A/B arm)
   if (a.drop.on()) {
     hipLaunchKernelGGL(attn_bwd_dq_kernel<true>, gq, dim3(kAttnThreads), lds_dq, st, a);
-    hipLaunchKernelGGL(attn_bwd_dkv_kernel<true>, gk, dim3(kAttnThreads), lds_dkv, st, a);
+    if (dkv_variant == 1) hipLaunchKernelGGL(attn_bwd_dkv_kernel<true>, gk, dim3(kAttnThreads), lds_dkv, st, a);
+    else hipLaunchKernelGGL(attn_bwd_dkv2_kernel<true>, gk, dim3(kDkv2Threads), kDkv2Lds, st, a);
   } else {
     hipLaunchKernelGGL(attn_bwd_dq_kernel<false>, gq, dim3(kAttnThreads), lds_dq, st, a);
-    hipLaunchKernelGGL(attn_bwd_dkv_kernel<false>, gk, dim3(kAttnThreads), lds_dkv, st, a);
+    if (dkv_variant == 1) hipLaunchKernelGGL(attn_bwd_dkv_kernel<false>, gk, dim3(kAttnThreads), lds_dkv, st, a);
+    else hipLaunchKernelGGL(attn_bwd_dkv2_kernel<false>, gk, dim3(kDkv2Threads), kDkv2Lds, st, a);
   }
   ADT_HIP_TRY(hipGetLastError());
   return ADT_OK;
