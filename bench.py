@@ -275,7 +275,9 @@ def train_setup(dev, seed, world, dropout):
                 "traffic": pmc_traffic_bytes("gemm_pmc_summary.json"),
                 "kernel": "adt::gemm_nt_256_kernel<false> (FFN linear1 + bias + GELU + saved pre-activation, M=%d N=%d K=%d)" % (M, N, Kd),
                 "kernel_ms": ms, "algorithmic_flops_per_launch": fl,
-                "algorithmic_bytes_per_launch": 2.0 * (M * Kd + N * Kd + 2 * M * N)}
+                "algorithmic_bytes_per_launch": 2.0 * (M * Kd + N * Kd + 2 * M * N),
+                "profile": "profiles/r01/roofline_gemm_kernel_stats.csv (rocprofv3 --kernel-trace --stats of tools/pmc_gemm.py: this kernel "
+                           "alone at this shape)"}
 
     def cpu_baseline(budget_s=20.0):
         from oracle import adt as o_adt
