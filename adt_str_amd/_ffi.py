@@ -83,6 +83,7 @@ SIGNATURES = {
     "adt_cosine_argmax_f32": [ptr, i64, ptr, i64, i64, i64, f32, ptr, ptr, ptr, ptr],
     "adt_resample_f32": [ptr, i64, i64, i64, ptr, ptr, i32, i32, i32, i32, ptr, i64, i64, ptr],
     "adt_mix_render_f32": [ptr, ptr, i64, ptr, i64, ptr, ptr, ptr, i64, i64, ptr, i64, ptr, C.c_size_t, ptr],
+    "adt_mix_render_fx_f32": [ptr, ptr, i64, ptr, i64, ptr, ptr, ptr, i64, i64, ptr, i32, ptr, i64, ptr, C.c_size_t, ptr],
 }
 _RESTYPES = {"adt_last_error": C.c_char_p}
 _RESTYPES.update({n: C.c_size_t for n in ("adt_mix_workspace_bytes", "adt_gemm_workspace_bytes", "adt_attn_bwd_workspace_bytes",

@@ -11,6 +11,9 @@ int set_error(int code, const char* msg);
 int set_hip_error(hipError_t e, const char* what);
 // Number of compute units of the current device (cached per device).
 int device_cu_count(int* n_cu);
+// fx.hip: reverb / compressor / limiter over the un-normalised clips flagged in fx[], then the new clip peaks (mixer.hip calls it)
+int launch_fx_chain(float* wav, long ld, const int32_t* clip_len, const adt_fx_params* fx, int n_clips, int sample_rate, int width,
+                    unsigned* clip_peak, hipStream_t st);
 // Work counters of the persistent GEMM on (current device, stream): eight device words (one per XCD group, 64 bytes apart) that
 // only ever count up.  base[x] is the value counter x will have when the launch being prepared starts; the call reserves
 // fetches[x] increments of it for that launch.

@@ -158,6 +158,15 @@ extern "C" int adt_mix_render_f32(const float* bank, const int64_t* bank_off, in
                                   const adt_note* notes, int64_t n_notes, const int32_t* clip_note_off,
                                   const int32_t* clip_len, const float* clip_gain, int64_t n_clips, int64_t width,
                                   float* out, int64_t ld_out, void* ws, size_t ws_bytes, void* stream) {
+  return adt_mix_render_fx_f32(bank, bank_off, n_shots, notes, n_notes, clip_note_off, clip_len, clip_gain, n_clips, width, nullptr, 0, out,
+                               ld_out, ws, ws_bytes, stream);
+}
+
+extern "C" int adt_mix_render_fx_f32(const float* bank, const int64_t* bank_off, int64_t n_shots,
+                                     const adt_note* notes, int64_t n_notes, const int32_t* clip_note_off,
+                                     const int32_t* clip_len, const float* clip_gain, int64_t n_clips, int64_t width,
+                                     const adt_fx_params* fx, int32_t sample_rate,
+                                     float* out, int64_t ld_out, void* ws, size_t ws_bytes, void* stream) {
   using namespace adt;
   if (!out || !clip_note_off || !clip_len || !clip_gain) return set_error(ADT_EINVAL, "adt_mix_render_f32: null pointer");
   if (n_notes > 0 && (!bank || !bank_off || !notes)) return set_error(ADT_EINVAL, "adt_mix_render_f32: null bank/notes");
@@ -178,6 +187,9 @@ extern "C" int adt_mix_render_f32(const float* bank, const int64_t* bank_off, in
             static_cast<int>(n_clips), static_cast<int>(width)};
   const dim3 grid(static_cast<unsigned>((width + kMixTile - 1) / kMixTile), static_cast<unsigned>(n_clips));
   hipLaunchKernelGGL(mix_render_kernel, grid, dim3(kMixThreads), 0, st, a);
+  if (fx) {                            // FX works on the un-normalised mix and replaces the peaks of the clips it touched
+    if (int rc = launch_fx_chain(out, ld_out, clip_len, fx, static_cast<int>(n_clips), sample_rate, static_cast<int>(width), clip_peak, st)) return rc;
+  }
   hipLaunchKernelGGL(mix_scale_kernel, grid, dim3(kMixThreads), 0, st, a);
   ADT_HIP_TRY(hipGetLastError());
   return ADT_OK;

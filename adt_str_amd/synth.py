@@ -9,8 +9,11 @@ re-opening an HDF5 file per note (``synthetiser.py:273``).
 Random draws come from Python's ``random`` in exactly the order the reference
 consumes them (timbre picks once per pitch and clip ``:192-202,274-281``, then
 one ``uniform(0, mixup_range)`` per note ``:217``), so seeding ``random`` gives
-the reference's clip.  FX (``use_fx_prob``, pedalboard) is not implemented:
-a non-zero probability raises.
+the reference's clip.  The optional FX chain (``use_fx_prob``; pedalboard Reverb / Compressor / Limiter in the
+reference, ``:30-87,121-137,154-155``) is drawn here in the reference's order too (``random`` for the coin flips and
+the reverb, ``torch.randn`` for the compressor / limiter, ``utils/utils.py:266-269``) and processed on the GPU by K14
+(``adt_mix_render_fx_f32``) between the mix and its peak normalisation.  Every clip gets a fresh chain: the reference
+appends to one shared ``Pedalboard`` on every call, so its chain grows during a run -- not reproduced.
 """
 from __future__ import annotations
 
@@ -36,6 +39,60 @@ _THR_GROUP = {1.0: "gold", 0.9: "100-90", 0.8: "90-80", 0.7: "80-70", 0.6: "70-6
 NOTE_DTYPE = np.dtype([("start", "<i4"), ("main_shot", "<i4"), ("sub_shot", "<i4"), ("track", "<i4"),
                        ("one_minus_mixup", "<f4"), ("mixup", "<f4"), ("vol", "<f4"), ("track_gain", "<f4")])
 assert NOTE_DTYPE.itemsize == 32          # struct adt_note in include/adt_hip.h
+FX_DTYPE = np.dtype([("flags", "<i4"), ("room_size", "<f4"), ("damping", "<f4"), ("wet_level", "<f4"), ("dry_level", "<f4"),
+                     ("width", "<f4"), ("c_threshold_db", "<f4"), ("c_ratio", "<f4"), ("c_attack_ms", "<f4"), ("c_release_ms", "<f4"),
+                     ("l_threshold_db", "<f4"), ("l_release_ms", "<f4")])
+assert FX_DTYPE.itemsize == 48            # struct adt_fx_params
+LIMITER_RELEASE_MS = 100.0                # pedalboard.Limiter default (the reference passes threshold_db only, synthetiser.py:78)
+
+
+def draw_from_normal_distribution(std: float, mean: float, high_bound: float, low_bound: float) -> float:
+    """utils/utils.py:266-269: one ``torch.randn(1)`` from the global CPU generator."""
+    return torch.clamp(torch.clamp(torch.randn(1) * std + mean, -1.0, 1.0).abs() * high_bound, low_bound, high_bound).item()
+
+
+def draw_board(use_reverb_prob: float, use_compression_prob: float, use_limiter_prob: float):
+    """``BoardChain.get_board`` on a fresh board (synthetiser.py:44-87) -> list of (effect name, kwargs), same draws in the same order."""
+    board = []
+    if random.random() < use_reverb_prob:
+        room_size = random.uniform(0.2, 0.8)
+        damping = random.uniform(0.2, 0.8)
+        wet_level = random.uniform(0.1, 0.4)
+        width = random.uniform(0.6, 1.0)
+        board.append(("Reverb", dict(room_size=room_size, damping=damping, wet_level=wet_level, dry_level=1 - wet_level, width=width,
+                                     freeze_mode=0.0)))
+    if random.random() < use_compression_prob:
+        threshold = -draw_from_normal_distribution(std=0.15, mean=0.5, high_bound=10, low_bound=0)
+        ratio = draw_from_normal_distribution(std=0.15, mean=0.5, high_bound=10, low_bound=1.0)
+        attack = draw_from_normal_distribution(std=0.05, mean=0.1, high_bound=1000, low_bound=0)
+        release = draw_from_normal_distribution(std=0.15, mean=0.2, high_bound=1000, low_bound=0)
+        board.append(("Compressor", dict(threshold_db=threshold, ratio=ratio, attack_ms=attack, release_ms=release)))
+    if random.random() < use_limiter_prob:
+        threshold = -draw_from_normal_distribution(std=0.2, mean=0.4, high_bound=3, low_bound=0)
+        board.append(("Limiter", dict(threshold_db=threshold)))
+    return board
+
+
+def board_to_record(board) -> np.ndarray:
+    """[(name, kwargs)] -> one FX_DTYPE record (struct adt_fx_params)."""
+    rec = np.zeros((), FX_DTYPE)
+    rec["c_ratio"], rec["l_release_ms"] = 1.0, LIMITER_RELEASE_MS
+    for name, kw in board:
+        if name == "Reverb":
+            rec["flags"] |= 1
+            for k in ("room_size", "damping", "wet_level", "dry_level", "width"):
+                rec[k] = kw[k]
+        elif name == "Compressor":
+            rec["flags"] |= 2
+            rec["c_threshold_db"], rec["c_ratio"], rec["c_attack_ms"], rec["c_release_ms"] = (kw["threshold_db"], kw["ratio"], kw["attack_ms"],
+                                                                                              kw["release_ms"])
+        elif name == "Limiter":
+            rec["flags"] |= 4
+            rec["l_threshold_db"] = kw["threshold_db"]
+            rec["l_release_ms"] = kw.get("release_ms", LIMITER_RELEASE_MS)
+        else:
+            raise ValueError(f"unknown effect {name}")
+    return rec
 
 
 @dataclass
@@ -90,6 +147,8 @@ class MixPlan:
     clip_gain: np.ndarray       # float32 [B]
     picks: list                 # per clip: {pitch: ((pitch, group, name), (pitch, group, name))}
     mixups: list                # per clip: list of per-note mixup draws (input order)
+    fx: Optional[np.ndarray] = None   # FX_DTYPE [B] (flags == 0: clip without FX); None when use_fx_prob == 0
+    boards: Optional[list] = None     # per clip: the drawn [(effect, kwargs)] (for inspection / tests)
 
     @property
     def width(self) -> int:
@@ -103,8 +162,8 @@ class SynthDrum:
         self.oneshot_path = f"{config.oneshot_path}@{self.sample_rate}.npz"
         self.similarity_threshold = config.similarity_threshold
         self.ADTOF_mapping = config.ADTOF_mapping
-        if config.use_fx_prob:
-            raise NotImplementedError("the FX chain (use_fx_prob > 0, pedalboard) is outside the MI355X hot path; set use_fx_prob: 0")
+        if config.use_fx_prob and not 12544 <= config.sample_rate <= 96000:
+            raise ValueError("the FX chain needs a sample rate in [12544, 96000] Hz")
         if bank is None:
             if not os.path.exists(self.oneshot_path):
                 raise FileNotFoundError(f"one-shot bank {self.oneshot_path} not found (flat .npz; see adt_str_amd/bank.py)")
@@ -115,6 +174,7 @@ class SynthDrum:
         self.device = torch.device(device) if device is not None else torch.device("cuda", torch.cuda.current_device()) \
             if torch.cuda.is_available() else None
         self._thr_groups = self.tolerance_thr_to_h5_group()
+        self._stream = None               # side stream for batches with FX (render_plan)
 
     # ---- reference-named helpers -------------------------------------------------
     def floor_to_tenth(self, x: float) -> float:
@@ -155,11 +215,14 @@ class SynthDrum:
     def plan(self, batch: Sequence[Sequence[Sequence[float]]]) -> MixPlan:
         sr = self.config.sample_rate
         recs, offs, lens, gains, picks_all, mix_all = [], [0], [], [], [], []
+        use_fx = float(self.config.use_fx_prob) > 0.0
+        fx_recs, boards = [], []
         for notes in batch:
             n = len(notes)
-            if n == 0:                                             # synthetiser.py:257-258
+            if n == 0:                                             # synthetiser.py:257-258 (returns before any draw)
                 offs.append(offs[-1]); lens.append(int(self.config.input_sec * sr)); gains.append(0.0)
                 picks_all.append({}); mix_all.append([])
+                fx_recs.append(np.zeros((), FX_DTYPE)); boards.append([])
                 continue
             a = np.asarray(notes, dtype=np.float32).reshape(n, 4)
             tracks: dict = {}
@@ -190,14 +253,37 @@ class SynthDrum:
             gains.append(float(vel_to_vol(float(max_vel))))
             picks_all.append(picks)
             mix_all.append(mixups)
+            # instrument_mixer (synthetiser.py:154-155): the FX coin flip comes after every note of the clip has been rendered
+            board = []
+            if random.random() < self.config.use_fx_prob:
+                board = draw_board(self.config.use_reverb_prob, self.config.use_compression_prob, self.config.use_limiter_prob)
+            boards.append(board)
+            fx_recs.append(board_to_record(board))
         notes_arr = np.concatenate(recs) if recs else np.zeros(0, NOTE_DTYPE)
+        fx = np.stack(fx_recs).astype(FX_DTYPE) if (use_fx and fx_recs) else None
         return MixPlan(notes=notes_arr, clip_note_off=np.asarray(offs, np.int32), clip_len=np.asarray(lens, np.int32),
-                       clip_gain=np.asarray(gains, np.float32), picks=picks_all, mixups=mix_all)
+                       clip_gain=np.asarray(gains, np.float32), picks=picks_all, mixups=mix_all, fx=fx, boards=boards)
 
     # ---- rendering (GPU) -----------------------------------------------------------
     def render_plan(self, plan: MixPlan, width: Optional[int] = None, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+        """Render a planned batch.  A batch with FX clips and no caller-provided buffer is rendered on this object's own HIP stream
+        and the caller's stream only waits for the result: the FX kernels are latency-bound chains on a handful of waves
+        (6.5 ms for a 64 x 10 s batch), and issued this way they run underneath whatever the caller's stream still has queued --
+        in a training loop, the previous step."""
         if self.device is None or self.device.type != "cuda":
             raise RuntimeError("SynthDrum renders on the GPU only (there is no CPU path)")
+        if out is None and plan.fx is not None and bool(plan.fx["flags"].any()) and len(plan.clip_len) and (width or plan.width):
+            if self._stream is None:
+                self._stream = torch.cuda.Stream(device=self.device)
+            main = torch.cuda.current_stream(self.device)
+            with torch.cuda.stream(self._stream):
+                res = self._render_plan(plan, width, None)
+            main.wait_stream(self._stream)
+            res.record_stream(main)
+            return res
+        return self._render_plan(plan, width, out)
+
+    def _render_plan(self, plan: MixPlan, width: Optional[int], out: Optional[torch.Tensor]) -> torch.Tensor:
         dev = self.device
         B = len(plan.clip_len)
         width = plan.width if width is None else width
@@ -214,9 +300,15 @@ class SynthDrum:
         gain_d = torch.from_numpy(plan.clip_gain).to(dev, non_blocking=True)
         ws_bytes = _ffi.load().adt_mix_workspace_bytes(n_notes, B)
         ws = torch.empty(ws_bytes, dtype=torch.uint8, device=dev)
-        _ffi.call("adt_mix_render_f32", _ffi.dptr(data), _ffi.dptr(offsets), self.bank.n_shots, _ffi.dptr(notes_d),
-                  n_notes, _ffi.dptr(off_d), _ffi.dptr(len_d), _ffi.dptr(gain_d), B, width, _ffi.dptr(out),
-                  out.stride(0), _ffi.dptr(ws), ws_bytes, _ffi.current_stream())
+        if plan.fx is not None and bool(plan.fx["flags"].any()):
+            fx_d = torch.from_numpy(plan.fx.view(np.uint8).reshape(-1).copy()).to(dev, non_blocking=True)
+            _ffi.call("adt_mix_render_fx_f32", _ffi.dptr(data), _ffi.dptr(offsets), self.bank.n_shots, _ffi.dptr(notes_d),
+                      n_notes, _ffi.dptr(off_d), _ffi.dptr(len_d), _ffi.dptr(gain_d), B, width, _ffi.dptr(fx_d), self.sample_rate,
+                      _ffi.dptr(out), out.stride(0), _ffi.dptr(ws), ws_bytes, _ffi.current_stream())
+        else:
+            _ffi.call("adt_mix_render_f32", _ffi.dptr(data), _ffi.dptr(offsets), self.bank.n_shots, _ffi.dptr(notes_d),
+                      n_notes, _ffi.dptr(off_d), _ffi.dptr(len_d), _ffi.dptr(gain_d), B, width, _ffi.dptr(out),
+                      out.stride(0), _ffi.dptr(ws), ws_bytes, _ffi.current_stream())
         return out
 
     def render_batch(self, batch: Sequence[Sequence[Sequence[float]]], width: Optional[int] = None):

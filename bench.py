@@ -217,7 +217,7 @@ def train_flops_per_clip(F, T, d=768, ffn=3072, V=1400, n_mels=128, enc=4, dec=4
     return 6.0 * macs
 
 
-def train_setup(dev, seed, world, dropout):
+def train_setup(dev, seed, world, dropout, fx_prob=0.0):
     from adt_str_amd import kernels as K
     from adt_str_amd.bank import OneShotBank, synthetic_tree
     from adt_str_amd.network import ADTModel, ADTModelConfig
@@ -232,7 +232,7 @@ def train_setup(dev, seed, world, dropout):
     synth = SynthDrum(SynthDrumConfig(input_sec=10.0, time_res=0.01, win_length=2048, sample_rate=sr, oneshot_path="synthetic",
                                       similarity_threshold=0.8, max_hat_std_velocity=0.15, max_hat_mean_velocity=0.1,
                                       max_cymbals_std_velocity=0.15, max_cymbals_mean_velocity=0.65, ADTOF_mapping=False,
-                                      mixup_range=0.8, use_fx_prob=0.0, use_reverb_prob=0.5, use_limiter_prob=0.5,
+                                      mixup_range=0.8, use_fx_prob=fx_prob, use_reverb_prob=0.5, use_limiter_prob=0.5,
                                       use_compression_prob=0.5), bank=bank, device=str(dev))
     rng = np.random.default_rng(100 + seed)
     random.seed(100 + seed)
@@ -246,9 +246,10 @@ def train_setup(dev, seed, world, dropout):
     def step():
         i = state["i"] % n_plans
         state["i"] += 1
-        synth.render_plan(plans[i], width=L, out=wav_buf)                  # K2: render the batch on the GPU
+        # K2: render the batch on the GPU (with FX: on the synth's own stream into a fresh buffer, see SynthDrum.render_plan)
+        wav = synth.render_plan(plans[i], width=L) if fx_prob > 0 else synth.render_plan(plans[i], width=L, out=wav_buf)
         tok, tl = toks_d[i]
-        state["loss"] = trainer.train_step(wav_buf, tok, tl)               # K1 + network fwd/bwd + all-reduce + clip + AdamW
+        state["loss"] = trainer.train_step(wav, tok, tl)                   # K1 + network fwd/bwd + all-reduce + clip + AdamW
 
     F = model.compute_spectrogram(wav_buf[:1].zero_()).shape[1]
     flops_clip = train_flops_per_clip(F, T)
@@ -304,7 +305,7 @@ def train_setup(dev, seed, world, dropout):
             "metric": "ADT training clips/sec (10 s @16 kHz)",
             "config": {"workload": "train config[3]: ADT train step, setting-1 network (69.0M params), per-GPU batch 64 x 10 s @ 16 kHz "
                                    "mixer-rendered clips (F=%d frames), T=128 target tokens, bf16 GEMM/attention with fp32 accumulate, "
-                                   "AdamW + clip 1.0, dropout %.2f" % (F, dropout),
+                                   "AdamW + clip 1.0, dropout %.2f, use_fx_prob %.2f" % (F, dropout, fx_prob),
                        "global_batch": B * world, "clips_per_gpu": B, "samples": L, "sample_rate": sr, "target_len": T}}
 
 
@@ -315,6 +316,8 @@ def main():
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--workload", default="train", choices=["train", "logmel", "clap"])
     ap.add_argument("--dropout", type=float, default=0.1, help="model dropout (0.1 = configs/train/setting-1.yaml of the reference)")
+    ap.add_argument("--fx-prob", type=float, default=0.0, help="use_fx_prob of the mixer (the reference's setting-1 trains with 0.3; SURVEY's "
+                                                                 "benchmark configuration is 0)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
 
@@ -337,7 +340,7 @@ def main():
         else:
             dist.init_process_group("nccl", device_id=dev)
 
-    wl = {"train": lambda: train_setup(dev, rank, world, args.dropout), "logmel": lambda: logmel_setup(dev, rank),
+    wl = {"train": lambda: train_setup(dev, rank, world, args.dropout, args.fx_prob), "logmel": lambda: logmel_setup(dev, rank),
           "clap": lambda: clap_setup(dev, rank)}[args.workload]()
     step = wl["step"]
 

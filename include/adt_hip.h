@@ -114,6 +114,24 @@ int adt_mix_render_f32(const float* bank, const int64_t* bank_off, int64_t n_sho
                        const int32_t* clip_len, const float* clip_gain, int64_t n_clips, int64_t width,
                        float* out, int64_t ld_out, void* ws, size_t ws_bytes, void* stream);
 
+/* K14: the same with the reference's optional FX chain (VolumeMixer._add_fx, synthetiser.py:121-137,154-155) applied to the
+ * un-normalised mix of the clips whose fx[c].flags != 0, in the reference's order Reverb -> Compressor -> Limiter, before the
+ * peak normalisation.  The host draws which effects and their parameters (BoardChain, synthetiser.py:30-87); the processing
+ * restates what pedalboard's JUCE effects do to a mono signal (juce::Reverb::processMono, juce::dsp::Compressor,
+ * juce::dsp::Limiter with pedalboard's default 100 ms release).  fx: DEVICE array of n_clips records, or null (= adt_mix_render_f32).
+ * sample_rate must be in [12544, 96000]. */
+typedef struct adt_fx_params {
+  int32_t flags;                /* bit 0 reverb, bit 1 compressor, bit 2 limiter */
+  float room_size, damping, wet_level, dry_level, width;
+  float c_threshold_db, c_ratio, c_attack_ms, c_release_ms;
+  float l_threshold_db, l_release_ms;
+} adt_fx_params;
+int adt_mix_render_fx_f32(const float* bank, const int64_t* bank_off, int64_t n_shots,
+                          const adt_note* notes, int64_t n_notes, const int32_t* clip_note_off,
+                          const int32_t* clip_len, const float* clip_gain, int64_t n_clips, int64_t width,
+                          const adt_fx_params* fx, int32_t sample_rate,
+                          float* out, int64_t ld_out, void* ws, size_t ws_bytes, void* stream);
+
 /* ---------------------------------------------------------------------------
  * K3/K5  bf16 MFMA GEMM with fused epilogue (fp32 accumulate)
  *

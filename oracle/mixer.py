@@ -10,7 +10,7 @@ Pinned by tests/golden/mixer.npz (reference outputs + recorded draws).
 """
 from __future__ import annotations
 
-from typing import Callable, List, Sequence
+from typing import Optional, Callable, List, Sequence
 
 import torch
 
@@ -38,9 +38,10 @@ def clip_length(notes: torch.Tensor, input_sec: float, sample_rate: int) -> int:
 
 
 def render(notes: Sequence[Sequence[float]], input_sec: float, sample_rate: int, adtof_mapping: bool,
-           timbres: Callable[[int], tuple], mixups: List[float]) -> torch.Tensor:
+           timbres: Callable[[int], tuple], mixups: List[float], fx: Optional[Callable] = None) -> torch.Tensor:
     """``timbres(pitch) -> (main, sub)`` float32 arrays for a pitch (asked once
-    per pitch, in order of first appearance); ``mixups[i]`` is note i's draw."""
+    per pitch, in order of first appearance); ``mixups[i]`` is note i's draw; ``fx(wav) -> wav`` stands for
+    ``VolumeMixer._add_fx`` on the un-normalised mix (synthetiser.py:154-155)."""
     if len(notes) == 0:
         return torch.zeros(int(input_sec * sample_rate))
     notes = torch.tensor(notes)
@@ -77,5 +78,7 @@ def render(notes: Sequence[Sequence[float]], input_sec: float, sample_rate: int,
     for p, tr in tracks.items():
         key = ADTOF_MAP[int(p)] if not adtof_mapping else int(p)
         wav += tr * CLASS_VOLUME[key]
+    if fx is not None:
+        wav = torch.as_tensor(fx(wav.numpy().copy()), dtype=torch.float32)
     wav = wav / wav.abs().max()
     return wav * vel_to_vol(max_vel)

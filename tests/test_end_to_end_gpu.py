@@ -42,7 +42,7 @@ def _make_workspace(tmp_path, n_items=16, batch=4):
         "tokenizer": {"ADTOF_mapping": False, "BOS_token": 2, "EOS_token": 3, "pad_token": 1, "silence_token": 0, "add_velocity": True},
         "synthetiser": {"oneshot_path": str(tmp_path / "oneshot"), "similarity_threshold": 0.8, "max_hat_std_velocity": 0.15,
                         "max_hat_mean_velocity": 0.1, "max_cymbals_std_velocity": 0.15, "max_cymbals_mean_velocity": 0.65,
-                        "mixup_range": 0.8, "use_fx_prob": 0.0, "use_reverb_prob": 0.5, "use_compression_prob": 0.5, "use_limiter_prob": 0.5},
+                        "mixup_range": 0.8, "use_fx_prob": 0.3, "use_reverb_prob": 0.5, "use_compression_prob": 0.5, "use_limiter_prob": 0.5},
     }
     return cfg
 

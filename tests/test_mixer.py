@@ -87,8 +87,8 @@ def test_plan_layout_and_errors(golden):
         sd.plan([[[0.5, 0.4, 40, 100]]])
     with pytest.raises(ValueError, match="Invalid note"):
         sd.plan([[[0.5, 0.6, 62, 100]]])
-    with pytest.raises(NotImplementedError):
-        SynthDrum(SynthDrumConfig(**{**make_cfg(16000, 1.0, 0.8, 0.5, False).__dict__, "use_fx_prob": 0.3}), bank=bank)
+    with pytest.raises(ValueError, match="sample rate"):           # the FX chain needs >= 12544 Hz (64-sample reverb chunks)
+        SynthDrum(SynthDrumConfig(**{**make_cfg(16000, 1.0, 0.8, 0.5, False).__dict__, "use_fx_prob": 0.3, "sample_rate": 8000}), bank=bank)
 
 
 def test_threshold_groups(golden):

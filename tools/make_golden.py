@@ -15,8 +15,8 @@ container-only stand-ins registered in ``sys.modules``:
     golden pins the reference-owned post-processing ``model.py:91-97`` and the
     module tree / buffer names only).
   * ``h5py`` -- a dict-backed ``File`` (a data container: no arithmetic).
-  * ``pedalboard``, ``wandb``, ``pretty_midi`` -- inert names (FX is off:
-    ``use_fx_prob=0``).
+  * ``pedalboard`` -- recording stand-ins (an effect remembers its constructor arguments; no audio processing);
+    ``wandb``, ``pretty_midi`` -- inert names.
   * ``omegaconf`` -- PyYAML + recursive merge.
 
 Usage: ``python tools/make_golden.py`` (writes tests/golden/).
@@ -119,8 +119,18 @@ def _install_standins(h5_store: dict):
     sys.modules["h5py"] = h5
 
     pb = _mod("pedalboard")
-    for name in ("Pedalboard", "Reverb", "Compressor", "Limiter"):
-        setattr(pb, name, type(name, (), {"__init__": lambda self, *a, **k: None}))
+    # recording stand-ins: a board is a list, an effect remembers its constructor arguments (G9 pins the reference's parameter
+    # sampling, synthetiser.py:44-87; the audio processing itself is C++/JUCE inside pedalboard and cannot be captured here)
+    class _Effect:
+        def __init__(self, *a, **k):
+            assert not a
+            self.kwargs = dict(k)
+    for name in ("Reverb", "Compressor", "Limiter"):
+        setattr(pb, name, type(name, (_Effect,), {}))
+
+    class Pedalboard(list):
+        pass
+    pb.Pedalboard = Pedalboard
     sys.modules["pedalboard"] = pb
     sys.modules["wandb"] = _mod("wandb")
     sys.modules["pretty_midi"] = _mod("pretty_midi")
@@ -314,6 +324,24 @@ def g4_mixer(h5_store):
     print("G4 mixer:", case, "cases")
 
 
+def g9_fx_params():
+    """BoardChain.get_board (synthetiser.py:30-87) for seeded RNG states: which effects, in which order, with which parameters.
+    A fresh BoardChain per draw (the reference keeps ONE board per VolumeMixer and appends to it on every call, so its chain
+    grows over a run -- not reproduced)."""
+    import json
+    import modules.synthetiser as synth_mod
+    draws = []
+    for seed in range(24):
+        random.seed(seed)
+        torch.manual_seed(seed)
+        probs = [(0.5, 0.5, 0.5), (1.0, 1.0, 1.0), (0.0, 1.0, 0.3)][seed % 3]
+        board = synth_mod.BoardChain(16000, *probs).get_board()
+        draws.append({"seed": seed, "probs": list(probs),
+                      "effects": [[type(e).__name__, {k: float(v) for k, v in e.kwargs.items()}] for e in board]})
+    np.savez_compressed(os.path.join(OUT, "fx_params.npz"), draws=np.array(json.dumps(draws)))
+    print("G9 fx params:", len(draws), "boards,", sum(len(d["effects"]) for d in draws), "effects")
+
+
 # --------------------------------------------------------------------------- G5/G6 ADT network
 def _adt_config(tiny: bool):
     from config import ADTModelConfig
@@ -486,6 +514,12 @@ def main():
     torch.set_num_threads(8)
     h5_store: dict = {}
     _install_standins(h5_store)
+    # The reference's packages (modules/, utils/, data_modules/) are namespace packages; this repository has regular packages of
+    # the same names (its drop-in import paths), which would win.  Everything needed from this repository is imported above, so
+    # take it (and the cwd) off the path before the reference goes on.
+    sys.path[:] = [q for q in sys.path if os.path.abspath(q or ".") != REPO]
+    for name in [m for m in sys.modules if m.split(".")[0] in ("modules", "utils", "data_modules", "config", "model", "train", "build_model")]:
+        del sys.modules[name]
     sys.path.insert(0, REF)
     sys.argv = ["make_golden", "dummy.yaml"]
     import model as model_mod                      # /root/reference/model.py
@@ -497,6 +531,7 @@ def main():
     g5_adt_tiny(model_mod)
     g6_adt_full(model_mod)
     g8_curation()
+    g9_fx_params()
 
 
 if __name__ == "__main__":
