@@ -21,15 +21,30 @@ namespace adt {
 
 __device__ __forceinline__ float bf2f_(unsigned short v) { return __uint_as_float(static_cast<unsigned>(v) << 16); }
 __device__ __forceinline__ unsigned short f2bf_(float f) { return __builtin_bit_cast(unsigned short, static_cast<__bf16>(f)); }
-__device__ __forceinline__ float wave_sum(float v) {
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
-  return v;
+// Wave-wide reductions on the DPP network (row_shr 1/2/4/8 inside each row of 16 lanes, then row_bcast:15 / :31 carry the row
+// totals forward; the total ends up in lane 63 and is broadcast through an SGPR): ~7 VALU instructions instead of six
+// ds_bpermute round trips, which dominated the per-row latency of the LayerNorm kernels.
+template <int kCtrl, int kRowMask>
+__device__ __forceinline__ float dpp_mov(float old, float src) {
+  return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(__builtin_bit_cast(int, old), __builtin_bit_cast(int, src), kCtrl, kRowMask, 0xf, false));
 }
-__device__ __forceinline__ float wave_max(float v) {
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o));
-  return v;
+__device__ __forceinline__ float wave_sum(float v) {
+  v += dpp_mov<0x111, 0xf>(0.f, v);
+  v += dpp_mov<0x112, 0xf>(0.f, v);
+  v += dpp_mov<0x114, 0xf>(0.f, v);
+  v += dpp_mov<0x118, 0xf>(0.f, v);
+  v += dpp_mov<0x142, 0xa>(0.f, v);
+  v += dpp_mov<0x143, 0xc>(0.f, v);
+  return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 63));
+}
+__device__ __forceinline__ float wave_max(float v) {       // (identity for max over the sources a lane does not have: itself)
+  v = fmaxf(v, dpp_mov<0x111, 0xf>(v, v));
+  v = fmaxf(v, dpp_mov<0x112, 0xf>(v, v));
+  v = fmaxf(v, dpp_mov<0x114, 0xf>(v, v));
+  v = fmaxf(v, dpp_mov<0x118, 0xf>(v, v));
+  v = fmaxf(v, dpp_mov<0x142, 0xa>(v, v));
+  v = fmaxf(v, dpp_mov<0x143, 0xc>(v, v));
+  return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 63));
 }
 
 constexpr int kRowThreads = 256;            // 4 waves = 4 rows per block
