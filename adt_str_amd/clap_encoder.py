@@ -201,18 +201,20 @@ class ClapWrapper(nn.Module):
         """list of [1, L] (or [L]) 48 kHz clips -> [B, 512] L2-normalised embeddings (clap_encoder.py:21-24, 30-54).
 
         ``is_longer``: the flags the reference's ClapProcessor would hand to the model.  Its feature extractor marks every clip
-        longer than 10 s and, when a batch has none, ONE RANDOM clip (feature_extraction_clap.py:347-350, ``np.random.randint``);
-        that draw is part of the reference's result, so pass the recorded flags to reproduce it.  Default (None): the same rule with
-        this module's own ``numpy`` draw, like the reference."""
+        longer than 10 s (those carry three random crops + a shrunk mel, ``np.random.choice``) and, when a batch has none, ONE
+        RANDOM clip (feature_extraction_clap.py:347-350, ``np.random.randint``); those draws are part of the reference's result, so
+        seed ``numpy`` / pass the recorded flags to reproduce it.  Default (None): the same rules with the same ``numpy`` draws in the
+        same order."""
         flat = [a.reshape(-1) for a in audios]
-        if any(a.numel() > 10 * self.sample_rate for a in flat):
-            raise NotImplementedError("clips longer than 10 s take the extractor's random-crop mel fusion, which is outside the "
-                                      "curation path (one-shots are at most a few seconds, augment_data_with_CLAP.py:51-63)")
+        if all(a.numel() <= 10 * self.sample_rate for a in flat):
+            mel, auto_longer = self.features.mel(flat), torch.zeros(len(flat), dtype=torch.bool)      # one mel per clip: no 4-channel copy
+        else:
+            mel, auto_longer = self.features.features(flat)       # [B, 4, 1001, 64]: long clips carry three crops + a shrunk mel
         if is_longer is None:
-            is_longer = torch.zeros(len(flat), dtype=torch.bool)
-            if len(flat) and self.encoder.enable_fusion:
-                is_longer[np.random.randint(0, len(flat))] = True
-        mel = self.features.mel(flat)
+            is_longer = auto_longer
+            if len(flat) and self.encoder.enable_fusion and not bool(is_longer.any()):
+                is_longer = is_longer.clone()
+                is_longer[np.random.randint(0, len(flat))] = True                                    # feature_extraction_clap.py:347-350
         return self.encoder.forward(mel, is_longer)["embedding"]
 
     @torch.no_grad()

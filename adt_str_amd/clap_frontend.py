@@ -1,5 +1,8 @@
 """CLAP feature extraction on the GPU: what ``ClapProcessor(audio=list_of_clips, sampling_rate=48000)`` returns
-for clips of at most 10 s (reference ``modules/clap_encoder.py:22-23``), computed by ``adt_clap_logmel_db_f32``.
+(reference ``modules/clap_encoder.py:22-23``; ``truncation="fusion"``, ``padding="repeatpad"``, the class defaults),
+computed by ``adt_clap_logmel_db_f32``: clips of at most 10 s are repeat-padded and carry the same mel in all four
+fusion channels; longer clips get the mel of the whole clip, three random 1001-frame crops (front / middle / back third,
+``np.random.choice`` like the extractor) and a bilinearly shrunk copy, and are flagged ``is_longer``.
 """
 from __future__ import annotations
 
@@ -33,9 +36,7 @@ def htk_mel_filterbank(n_freqs: int = N_FFT // 2 + 1, n_mels: int = N_MELS, f_mi
 class ClapLogMel:
     """``ClapLogMel(device)(clips) -> (input_features [B, 4, 1001, 64] fp32 on the GPU, is_longer [B, 1] bool)``.
 
-    ``clips``: list of 1-D float tensors / arrays at 48 kHz, each at most 10 s.  ``is_longer`` is all False; the
-    HF extractor would flip one random entry to True (feature_extraction_clap.py:347-350) -- callers that want
-    that behaviour pass their own ``is_longer`` to the encoder."""
+    ``clips``: list of 1-D float tensors / arrays at 48 kHz of any length."""
 
     def __init__(self, device="cuda"):
         self.device = torch.device(device)
@@ -52,7 +53,7 @@ class ClapLogMel:
         arrs = [torch.as_tensor(c, dtype=torch.float32).reshape(-1) for c in clips]
         for a in arrs:
             if a.numel() == 0 or a.numel() > MAX_SAMPLES:
-                raise NotImplementedError("clips must have 1..480000 samples (longer clips use the fusion crop path, not built)")
+                raise ValueError("mel() takes clips of 1..480000 samples; features() handles longer ones")
         offs = np.zeros(len(arrs) + 1, np.int64)
         offs[1:] = np.cumsum([a.numel() for a in arrs])
         flat = torch.cat(arrs).to(self.device) if arrs else torch.zeros(1, device=self.device)
@@ -64,7 +65,49 @@ class ClapLogMel:
                       _ffi.current_stream())
         return out
 
+    def _full_mel(self, clip: torch.Tensor) -> torch.Tensor:
+        """[1 + L // 480, 64] fp32 of ONE clip of any length (no padding: target length = the clip's own)."""
+        L = clip.numel()
+        n_frames = 1 + L // HOP
+        x = clip.to(self.device)
+        off_d = torch.tensor([0, L], dtype=torch.int64, device=self.device)
+        out = torch.empty((n_frames, N_MELS), dtype=torch.float32, device=self.device)
+        _ffi.call("adt_clap_logmel_db_f32", _ffi.dptr(x), _ffi.dptr(off_d), 1, L, N_FFT, HOP, n_frames, _ffi.dptr(self.window),
+                  _ffi.dptr(self.meta), _ffi.dptr(self.weights), N_MELS, self.nnz, 1e-10, _ffi.dptr(out), _ffi.current_stream())
+        return out
+
+    def _fusion_of_long_clip(self, clip: torch.Tensor):
+        """``_get_input_mel`` for a clip longer than 10 s (feature_extraction_clap.py, truncation="fusion") -> ([4, 1001, 64], longer)."""
+        mel = self._full_mel(clip)
+        total = mel.shape[0]
+        if total == N_FRAMES:                                     # 480000 < L < 480480: "we just use the whole audio", not longer
+            return mel.unsqueeze(0).expand(4, -1, -1), False
+        ranges = np.array_split(list(range(0, total - N_FRAMES + 1)), 3)
+        if len(ranges[1]) == 0:
+            ranges[1] = [0]
+        if len(ranges[2]) == 0:
+            ranges[2] = [0]
+        i_front, i_mid, i_back = (int(np.random.choice(r)) for r in ranges)       # the extractor's draws, in its order
+        shrink = torch.nn.functional.interpolate(mel[None, None], size=[N_FRAMES, N_MELS], mode="bilinear", align_corners=False)[0, 0]
+        return torch.stack([shrink, mel[i_front:i_front + N_FRAMES], mel[i_mid:i_mid + N_FRAMES], mel[i_back:i_back + N_FRAMES]]), True
+
+    def features(self, clips: Sequence):
+        """list of 1-D clips (any length >= 1) -> (input_features [B, 4, 1001, 64] fp32, is_longer [B] bool on the CPU)."""
+        arrs = [torch.as_tensor(c, dtype=torch.float32).reshape(-1) for c in clips]
+        short = [i for i, a in enumerate(arrs) if a.numel() <= MAX_SAMPLES]
+        feats = torch.empty((len(arrs), 4, N_FRAMES, N_MELS), dtype=torch.float32, device=self.device)
+        longer = torch.zeros(len(arrs), dtype=torch.bool)
+        if short:
+            feats[short] = self.mel([arrs[i] for i in short]).unsqueeze(1).expand(-1, 4, -1, -1)
+        for i, a in enumerate(arrs):                              # in clip order: the crops consume numpy's global RNG like the extractor
+            if a.numel() > MAX_SAMPLES:
+                f, lg = self._fusion_of_long_clip(a)
+                feats[i] = f
+                longer[i] = lg
+        return feats, longer
+
     def __call__(self, clips: Sequence):
-        mel = self.mel(clips)
-        feats = mel.unsqueeze(1).expand(-1, 4, -1, -1)           # the 4 fusion channels are the same mel for short clips
-        return feats, torch.zeros((mel.shape[0], 1), dtype=torch.bool, device=self.device)
+        """-> (input_features [B, 4, 1001, 64], is_longer [B, 1] bool on the device): what the extractor computes per clip, without its
+        "flag one random clip of an all-short batch" step (``ClapWrapper.get_audio_features`` does that)."""
+        feats, longer = self.features(clips)
+        return feats, longer.view(-1, 1).to(self.device)

@@ -33,6 +33,13 @@ def logmel_db(clips: Sequence[np.ndarray]) -> np.ndarray:
     return np.stack(out).astype(np.float32)
 
 
+def features(clips: Sequence[np.ndarray]):
+    """The whole ``ClapFeatureExtractor.__call__`` (fusion truncation, repeatpad): (input_features [B, 4, 1001, 64] float32,
+    is_longer [B, 1] bool).  Consumes numpy's global RNG like the reference (crops of long clips, the forced flag)."""
+    out = feature_extractor()([np.asarray(c, dtype=np.float64) for c in clips], sampling_rate=48000, return_tensors="np")
+    return np.asarray(out["input_features"], dtype=np.float32), np.asarray(out["is_longer"], dtype=bool)
+
+
 def random_clap_model(seed: int = 0):
     """ClapModel with the fused-HTSAT audio tower of ``laion/clap-htsat-fused`` (enable_fusion, aff_2d), random weights."""
     from transformers import ClapConfig, ClapModel

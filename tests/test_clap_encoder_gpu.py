@@ -119,8 +119,35 @@ def test_wrapper_end_to_end_and_curation(setup):
     flags[pick] = True
     ref_r = o_clap.audio_embeddings(model, feats, flags)["embedding"]
     assert ((emb_r.cpu() * ref_r).sum(-1)).min() > 0.9995
-    with pytest.raises(NotImplementedError):
-        w.get_audio_features([torch.zeros(1, 480001)])
+
+
+def test_clips_longer_than_10_s_follow_the_extractor(setup):
+    """Long clips: mel of the whole clip, three random crops + a bilinearly shrunk copy, flagged is_longer
+    (feature_extraction_clap.py ``_random_mel_fusion``); numpy's global RNG is consumed in the extractor's order."""
+    from adt_str_amd.clap_encoder import ClapWrapper
+    model, *_ = setup
+    rng = np.random.default_rng(4)
+
+    def clip(n):
+        t = np.arange(n, dtype=np.float32) / 48000.0
+        env = np.exp(-((t % 0.5)) * 9.0)
+        return (env * (0.6 * np.sin(2 * np.pi * 220.0 * t) + 0.3 * rng.standard_normal(n))).astype(np.float32)
+
+    clips = [clip(30000), clip(700000), clip(480100), clip(1200000)]         # short, long, corner case (1001 frames), long
+    np.random.seed(123)
+    ref_f, ref_l = o_clap.features(clips)
+    w = ClapWrapper("unused", DEV, 48000, clap_model=model)
+    np.random.seed(123)
+    feats, longer = w.features.features([torch.from_numpy(c) for c in clips])
+    assert longer.tolist() == [False, True, False, True] and ref_l.reshape(-1).tolist() == [False, True, False, True]
+    f = feats.cpu().numpy()
+    assert f.shape == ref_f.shape == (4, 4, 1001, 64)
+    # crops are exact slices of the same mel (same indices drawn) -> the K9 tolerance; the shrunk channel adds fp32 interpolation
+    assert np.abs(f - ref_f).max() < 5e-3
+    np.random.seed(123)
+    emb = w.get_audio_features([torch.from_numpy(c).unsqueeze(0) for c in clips]).cpu()
+    ref = o_clap.audio_embeddings(model, torch.from_numpy(ref_f), torch.from_numpy(ref_l))["embedding"]
+    assert ((emb * ref).sum(-1)).min() > 0.9995
 
 
 @pytest.mark.parametrize("distinct_channels", [False, True])

@@ -86,5 +86,5 @@ def test_gpu_matches_hf_extractor():
     got = feats[:, 0].cpu().numpy()
     check_db(got, ref)
     assert torch.equal(feats[:, 1], feats[:, 0])
-    with pytest.raises(NotImplementedError):
-        fe([torch.zeros(480001)])
+    with pytest.raises(ValueError):                         # mel() is the <= 10 s path; features() takes any length
+        fe.mel([torch.zeros(480001)])
