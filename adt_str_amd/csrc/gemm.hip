@@ -1071,7 +1071,7 @@ static bool use_big_tile(int64_t M, int64_t N, int64_t K) {
   if (K <= 0 || (K % kBK) != 0 || K < 2 * kBK || forced == 128) return false;
   if (forced == 256) return true;
   const int64_t tiles = ((M + kBig - 1) / kBig) * ((N + kBig - 1) / kBig);
-  return tiles >= 512 && K >= 256;
+  return tiles >= 512 && K >= 256 && N >= 160;           // a 256-wide tile over a narrower output is mostly padding
 }
 
 static int pick_splits(int M, int N, int K, int n_cu) {
