@@ -31,7 +31,10 @@ namespace adt {
 struct cf { float x, y; };
 
 constexpr int kNfft = 2048;
-constexpr int kRowPitch = 130;                 // P, in cf units
+#ifndef ADT_LOGMEL_PITCH
+#define ADT_LOGMEL_PITCH 130
+#endif
+constexpr int kRowPitch = ADT_LOGMEL_PITCH;    // P, in cf units (even: 8-element runs stay 16-byte aligned)
 constexpr int kBufElems = 16 * kRowPitch;      // 2080 cf = 16,640 B per wave
 constexpr int kStageBase = 1100;               // cf slot where the 2 x n_mels output rows are staged
 
