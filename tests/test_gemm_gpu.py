@@ -4,6 +4,8 @@ has to cover accumulation order: |err| <= 2e-3 * sqrt(K) * scale for bf16 output
 (bf16 rounding of the result, 2^-8 relative) and 1e-4 relative for fp32 outputs."""
 import math
 
+import numpy as np
+
 import pytest
 import torch
 
@@ -135,3 +137,32 @@ def test_big_tile_persistent_kernel_epilogues_and_dropout():
     y = k.gemm(a, b, bias=bias, residual=res, out_dtype=torch.float32, drop=(0.25, 9), drop_after_residual=False)
     mask = o_drop.scale((M, N), 0.25, 9).to(DEV)
     close(y, (z + bias) * mask + res, 1e-4, "dropout then residual")
+
+
+def test_randomised_shapes_cover_every_kernel_choice():
+    """Random shapes around the dispatch thresholds (persistent 256^2 NT / TN, 128^2 LDS-DMA, register-staged) incl. ragged edges,
+    leading dimensions larger than the row, fp32 and bf16 outputs."""
+    from adt_str_amd import kernels as k
+    rng = np.random.default_rng(2024)
+    nt_shapes = [(int(rng.integers(4000, 9000)) // 8 * 8 + 8 * int(rng.integers(0, 2)), int(rng.integers(160, 4600)) // 8 * 8,
+                  int(rng.choice([256, 320, 384, 512, 768, 1024]))) for _ in range(6)]
+    nt_shapes += [(int(rng.integers(100, 3000)), int(rng.integers(8, 1200)) // 8 * 8, int(rng.integers(1, 40)) * 8) for _ in range(8)]
+    nt_shapes += [(66000, 1024, 256), (70000, 160, 512), (8192 * 4, 4096, 64 * 5)]
+    for (M, N, K) in nt_shapes:
+        big_a = rnd((M, K + 16), M + N).bfloat16()
+        a, b = big_a[:, 8:8 + K], (rnd((N, K), K) * 0.2).bfloat16()
+        ref = a.float() @ b.float().t()
+        out = torch.zeros((M, N + 8), dtype=torch.float32, device=DEV)
+        k.gemm(a, b, out=out[:, :N])
+        close(out[:, :N], ref, 2e-4, f"NT fp32 {M}x{N}x{K}")
+        assert not out[:, N:].any()
+        close(k.gemm(a, b), ref, 8e-3, f"NT bf16 {M}x{N}x{K}")
+    tn_shapes = [(int(rng.integers(64, 200)) * 64, int(rng.integers(300, 3200)) // 8 * 8, int(rng.integers(300, 1600)) // 8 * 8) for _ in range(5)]
+    tn_shapes += [(int(rng.integers(1, 60)) * 8, int(rng.integers(8, 900)) // 8 * 8, int(rng.integers(8, 900)) // 8 * 8) for _ in range(6)]
+    tn_shapes += [(64 * 70, 2048, 520), (64 * 64, 512, 1024), (64 * 200, 776, 776)]
+    for (K, M, N) in tn_shapes:
+        a, b = rnd((K, M), K + M).bfloat16(), (rnd((K, N), N) * 0.2).bfloat16()
+        ref = a.float().t() @ b.float()
+        got = k.gemm(a, b, trans=True, out_dtype=torch.float32)
+        close(got, ref, 3e-4, f"TN {K}x{M}x{N}")
+        assert torch.equal(got, k.gemm(a, b, trans=True, out_dtype=torch.float32)), "split-K slabs are summed in a fixed order"
