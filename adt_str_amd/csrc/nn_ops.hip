@@ -217,21 +217,31 @@ __global__ __launch_bounds__(kRowThreads) void layernorm_bwd_kernel(LnBwdArgs a)
 
 // out[c] = sum_p partial[p][c] in a fixed order; c < width.  A block owns 32 columns and splits the
 // partial rows over 8 row-lanes (coalesced 128-byte reads), then combines the 8 sums through LDS.
+constexpr int kRedCols = 16;                 // columns per block (64-byte row pieces), 16 row-lanes each
 __global__ __launch_bounds__(256) void reduce_partials_kernel(const float* __restrict__ partial, int n_part, int width,
                                                               float* __restrict__ out0, float* __restrict__ out1,
                                                               float* __restrict__ out2, int D) {
-  __shared__ float red[8][33];
-  const int cl = threadIdx.x & 31, rl = threadIdx.x >> 5;
-  const int c = blockIdx.x * 32 + cl;
-  float s = 0.f;
-  if (c < width)
-    for (int p = rl; p < n_part; p += 8) s += partial[static_cast<long>(p) * width + c];
-  red[rl][cl] = s;
+  __shared__ float red[16][kRedCols + 1];
+  const int cl = threadIdx.x & (kRedCols - 1), rl = threadIdx.x / kRedCols;
+  const int c = blockIdx.x * kRedCols + cl;
+  float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;                      // four independent chains: the loads of a lane overlap
+  if (c < width) {
+    const float* p0 = partial + c;
+    int p = rl;
+    for (; p + 48 < n_part; p += 64) {
+      s0 += p0[static_cast<long>(p) * width];
+      s1 += p0[static_cast<long>(p + 16) * width];
+      s2 += p0[static_cast<long>(p + 32) * width];
+      s3 += p0[static_cast<long>(p + 48) * width];
+    }
+    for (; p < n_part; p += 16) s0 += p0[static_cast<long>(p) * width];
+  }
+  red[rl][cl] = (s0 + s1) + (s2 + s3);
   __syncthreads();
   if (rl == 0 && c < width) {
     float t = 0.f;
 #pragma unroll
-    for (int r = 0; r < 8; ++r) t += red[r][cl];
+    for (int r = 0; r < 16; ++r) t += red[r][cl];
     const int k = c / D, col = c - k * D;
     float* o = k == 0 ? out0 : (k == 1 ? out1 : out2);
     if (o) o[col] = t;
@@ -532,7 +542,7 @@ extern "C" int adt_layernorm_bwd(const float* dy, int64_t lddy, const float* x, 
               dx16_drop ? make_drop(dx16_drop->p, dx16_drop->key) : Drop{0u, 0u, 1.0f}};
   hipLaunchKernelGGL(layernorm_bwd_kernel, dim3(nb), dim3(kRowThreads), 0, ST(stream), a);
   const int width = 3 * static_cast<int>(D);
-  hipLaunchKernelGGL(reduce_partials_kernel, dim3((width + 31) / 32), dim3(256), 0, ST(stream), static_cast<const float*>(ws), nb,
+  hipLaunchKernelGGL(reduce_partials_kernel, dim3((width + kRedCols - 1) / kRedCols), dim3(256), 0, ST(stream), static_cast<const float*>(ws), nb,
                      width, dgamma, dbeta, dxsum, static_cast<int>(D));
   ADT_HIP_TRY(hipGetLastError());
   return ADT_OK;
@@ -551,7 +561,7 @@ extern "C" int adt_colsum_bf16(const void* x, int64_t ld, int64_t M, int64_t N, 
   const int nb = static_cast<int>((M + kColsumRows - 1) / kColsumRows);
   hipLaunchKernelGGL(colsum_partial_kernel, dim3(static_cast<unsigned>((N + 255) / 256), nb), dim3(256), 0, ST(stream),
                      static_cast<const unsigned short*>(x), ld, static_cast<int>(M), static_cast<int>(N), static_cast<float*>(ws));
-  hipLaunchKernelGGL(reduce_partials_kernel, dim3(static_cast<unsigned>((N + 31) / 32)), dim3(256), 0, ST(stream),
+  hipLaunchKernelGGL(reduce_partials_kernel, dim3(static_cast<unsigned>((N + kRedCols - 1) / kRedCols)), dim3(256), 0, ST(stream),
                      static_cast<const float*>(ws), nb, static_cast<int>(N), out, static_cast<float*>(nullptr), static_cast<float*>(nullptr),
                      static_cast<int>(N));
   ADT_HIP_TRY(hipGetLastError());
