@@ -14,7 +14,7 @@ _LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "libadt_hip
 _lock = threading.Lock()
 _lib = None
 
-ABI_VERSION = 3
+ABI_VERSION = 4
 
 i32, i64, f32, ptr = C.c_int32, C.c_int64, C.c_float, C.c_void_p
 
@@ -29,7 +29,7 @@ class GemmEpilogue(C.Structure):
                 ("pre_act_out", C.c_void_p), ("ld_pre_act", C.c_int64), ("residual", C.c_void_p),
                 ("ld_res", C.c_int64), ("res_row_mod", C.c_int32), ("act", C.c_int32), ("alpha", C.c_float),
                 ("out_fp32", C.c_int32), ("aux_bf16_out", C.c_void_p), ("ld_aux", C.c_int64), ("drop", Dropout),
-                ("drop_after_residual", C.c_int32)]
+                ("drop_after_residual", C.c_int32), ("colsum_out", C.c_void_p)]
 
 
 class AttnDesc(C.Structure):
@@ -61,6 +61,7 @@ SIGNATURES = {
     "adt_layernorm_bwd_workspace_bytes": [i64, i64],
     "adt_layernorm_bwd": [ptr, i64, ptr, i64, ptr, ptr, ptr, ptr, ptr, i64, ptr, ptr, ptr, i64, i64, ptr, ptr, ptr, C.c_size_t, ptr],
     "adt_colsum_workspace_bytes": [i64, i64],
+    "adt_gemm_colsum_workspace_bytes": [i64, i64],
     "adt_colsum_bf16": [ptr, i64, i64, i64, ptr, ptr, C.c_size_t, ptr],
     "adt_embed_pe_fwd": [ptr, ptr, ptr, f32, ptr, ptr, i64, i64, i64, i64, ptr, ptr],
     "adt_embed_bwd": [ptr, ptr, f32, ptr, i64, i64, i64, ptr, ptr],
@@ -87,7 +88,7 @@ SIGNATURES = {
 }
 _RESTYPES = {"adt_last_error": C.c_char_p}
 _RESTYPES.update({n: C.c_size_t for n in ("adt_mix_workspace_bytes", "adt_gemm_workspace_bytes", "adt_attn_bwd_workspace_bytes",
-                                          "adt_layernorm_bwd_workspace_bytes", "adt_colsum_workspace_bytes",
+                                          "adt_layernorm_bwd_workspace_bytes", "adt_colsum_workspace_bytes", "adt_gemm_colsum_workspace_bytes",
                                           "adt_cross_entropy_workspace_bytes", "adt_grad_norm_workspace_bytes",
                                           "adt_htsat_fusion_embed_workspace_bytes")})
 

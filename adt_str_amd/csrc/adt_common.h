@@ -19,6 +19,9 @@ int launch_fx_chain(float* wav, long ld, const int32_t* clip_len, const adt_fx_p
 // fetches[x] increments of it for that launch.
 int sched_counters(void* stream, const unsigned (&fetches)[8], unsigned** counters, unsigned (&base)[8]);
 
+// nn_ops.hip: out[c] = sum over the n_part rows of partial[n_part][width] (fixed order)
+void launch_reduce_partials(const float* partial, int n_part, int width, float* out, hipStream_t st);
+
 inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
 
 }  // namespace adt

@@ -70,6 +70,7 @@ struct GemmArgs {
   int M, N, K;
   int k_tiles_per_split;
   float* slabs;                 // TN split-K partials [splits][M][N] (null when splits == 1)
+  float* colsum_ws;             // 256^2 NT kernel: column sums of each 128-row band of the output, [ceil(M/256)*2][N]
   adt_gemm_epilogue ep;
   Drop drop;
   unsigned* sched; unsigned sched_base[8];   // persistent NT kernel: per-XCD-group work counters (16 words apart) and their values at launch
@@ -489,7 +490,7 @@ constexpr int kBigLds = kBigStage + 8 * kEpi2Bytes;  // 163,840 B = the whole LD
 // DMAs are issued before this tile's epilogue, which works from a separate 32 KiB of wave-private LDS: the epilogue's
 // LDS transposes, activation math and global stores hide the next tile's DMA latency (and there is no workgroup
 // turn-around between tiles).
-template <bool kDrop>
+template <bool kDrop, bool kColsum>
 __global__ __launch_bounds__(kBigThreads) void gemm_nt_256_kernel(GemmArgs g, int tiles_m, int tiles_n) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const int tid = threadIdx.x, lane = tid & 63;
@@ -661,6 +662,7 @@ __global__ __launch_bounds__(kBigThreads) void gemm_nt_256_kernel(GemmArgs g, in
     float bias[8];
 #pragma unroll
     for (int e = 0; e < 4; ++e) { bias[e] = has_bias ? braw0[e] : 0.f; bias[4 + e] = has_bias ? braw1[e] : 0.f; }
+    float cs[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};        // kColsum: this lane's 16 rows of its 8 columns, as stored
 #pragma unroll
     for (int i = 0; i < 8; ++i) {
 #pragma unroll
@@ -684,7 +686,26 @@ __global__ __launch_bounds__(kBigThreads) void gemm_nt_256_kernel(GemmArgs g, in
       for (int pass = 0; pass < 2; ++pass) {
         const int row = em0 + wr * 128 + i * 16 + pass * 8 + (lane >> 3);
         float z[8] = {zz[pass][0][0], zz[pass][0][1], zz[pass][0][2], zz[pass][0][3], zz[pass][1][0], zz[pass][1][1], zz[pass][1][2], zz[pass][1][3]};
-        if (row < g.M && efull) epilogue_apply8<kDrop>(g, z, bias, row, ecol);
+        if (row < g.M && efull) {
+          epilogue_apply8<kDrop>(g, z, bias, row, ecol);
+          if (kColsum) {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) cs[e] += g.ep.out_fp32 ? z[e] : bf2f(f2bf(z[e]));
+          }
+        }
+      }
+    }
+    if (kColsum) {                                      // lanes l, l + 8, ..., l + 56 hold the same 8 columns
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        cs[e] += __shfl_xor(cs[e], 8);
+        cs[e] += __shfl_xor(cs[e], 16);
+        cs[e] += __shfl_xor(cs[e], 32);
+      }
+      if (lane < 8 && efull) {
+        float* cp = g.colsum_ws + static_cast<long>(em0 / 128 + wr) * g.N + ecol;
+        *reinterpret_cast<float4*>(cp) = float4{cs[0], cs[1], cs[2], cs[3]};
+        *reinterpret_cast<float4*>(cp + 4) = float4{cs[4], cs[5], cs[6], cs[7]};
       }
     }
     if (!more) break;
@@ -1050,8 +1071,10 @@ static int set_big_lds_once() {      // the persistent kernels use the CU's whol
   int dev = 0;
   ADT_HIP_TRY(hipGetDevice(&dev));
   if (done_for == dev) return ADT_OK;
-  ADT_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_nt_256_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, kBigLds));
-  ADT_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_nt_256_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, kBigLds));
+  ADT_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_nt_256_kernel<false, false>), hipFuncAttributeMaxDynamicSharedMemorySize, kBigLds));
+  ADT_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_nt_256_kernel<false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, kBigLds));
+  ADT_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_nt_256_kernel<true, false>), hipFuncAttributeMaxDynamicSharedMemorySize, kBigLds));
+  ADT_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_nt_256_kernel<true, true>), hipFuncAttributeMaxDynamicSharedMemorySize, kBigLds));
   ADT_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_tn_256_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, kBigLds));
   done_for = dev;
   return ADT_OK;
@@ -1116,6 +1139,12 @@ extern "C" size_t adt_gemm_workspace_bytes(int32_t trans, int64_t M, int64_t N, 
   return s > 1 ? static_cast<size_t>(s) * M * N * 4 : 0;
 }
 
+extern "C" size_t adt_gemm_colsum_workspace_bytes(int64_t M, int64_t N) {
+  if (M <= 0 || N <= 0) return 0;
+  const size_t fused = static_cast<size_t>((M + adt::kBig - 1) / adt::kBig) * 2 * N * 4, alone = adt_colsum_workspace_bytes(M, N);
+  return fused > alone ? fused : alone;
+}
+
 extern "C" int adt_gemm_bf16(int32_t trans, int64_t M, int64_t N, int64_t K, const void* A, int64_t lda,
                              const void* B, int64_t ldb, void* C, int64_t ldc, const adt_gemm_epilogue* ep,
                              void* ws, size_t ws_bytes, void* stream) {
@@ -1139,6 +1168,13 @@ extern "C" int adt_gemm_bf16(int32_t trans, int64_t M, int64_t N, int64_t K, con
   const int k_tiles = static_cast<int>((K + kBK - 1) / kBK);
   int splits = 1;
   hipStream_t st = static_cast<hipStream_t>(stream);
+  g.colsum_ws = nullptr;
+  bool colsum_done = false;
+  if (e.colsum_out) {
+    if (trans || e.out_fp32) return set_error(ADT_EINVAL, "adt_gemm_bf16: colsum_out needs trans = 0 and a bf16 output");
+    if (!ws || !aligned16(ws) || ws_bytes < adt_gemm_colsum_workspace_bytes(M, N))
+      return set_error(ADT_EINVAL, "adt_gemm_bf16: workspace too small (see adt_gemm_colsum_workspace_bytes)");
+  }
   if (trans && vector_epilogue_ok(g, e) && M >= 8 && N >= 8) {
     int n_cu = 0, per = 0;
     if (int rc = device_cu_count(&n_cu)) return rc;
@@ -1210,8 +1246,14 @@ extern "C" int adt_gemm_bf16(int32_t trans, int64_t M, int64_t N, int64_t K, con
     for (int x = 0; x < 8; ++x)
       fetches[x] = static_cast<unsigned>(nt / 8 + (x < nt % 8 ? 1 : 0)) + g1.x / 8 + (static_cast<unsigned>(x) < g1.x % 8 ? 1u : 0u);
     if (int rc = sched_counters(stream, fetches, &g.sched, g.sched_base)) return rc;
-    if (g.drop.on()) hipLaunchKernelGGL(gemm_nt_256_kernel<true>, g1, dim3(kBigThreads), kBigLds, st, g, tm, tn);
-    else hipLaunchKernelGGL(gemm_nt_256_kernel<false>, g1, dim3(kBigThreads), kBigLds, st, g, tm, tn);
+    if (e.colsum_out) {
+      g.colsum_ws = static_cast<float*>(ws);
+      if (g.drop.on()) hipLaunchKernelGGL((gemm_nt_256_kernel<true, true>), g1, dim3(kBigThreads), kBigLds, st, g, tm, tn);
+      else hipLaunchKernelGGL((gemm_nt_256_kernel<false, true>), g1, dim3(kBigThreads), kBigLds, st, g, tm, tn);
+      launch_reduce_partials(g.colsum_ws, 2 * tm, g.N, e.colsum_out, st);
+      colsum_done = true;
+    } else if (g.drop.on()) hipLaunchKernelGGL((gemm_nt_256_kernel<true, false>), g1, dim3(kBigThreads), kBigLds, st, g, tm, tn);
+    else hipLaunchKernelGGL((gemm_nt_256_kernel<false, false>), g1, dim3(kBigThreads), kBigLds, st, g, tm, tn);
   } else if ((K % 32) == 0 && K > 0 && vector_epilogue_ok(g, e)) {
     const int tm = static_cast<int>((M + kBM - 1) / kBM), tn = static_cast<int>((N + kBN - 1) / kBN);
     const dim3 g1(static_cast<unsigned>(tm) * tn);
@@ -1227,5 +1269,7 @@ extern "C" int adt_gemm_bf16(int32_t trans, int64_t M, int64_t N, int64_t K, con
                        g.slabs, splits, mn, g.N, e.alpha, static_cast<float*>(C), ldc);
   }
   ADT_HIP_TRY(hipGetLastError());
+  if (e.colsum_out && !colsum_done)                  // the smaller tilings leave the sums to the stand-alone kernel
+    return adt_colsum_bf16(C, ldc, M, N, e.colsum_out, ws, ws_bytes, stream);
   return ADT_OK;
 }

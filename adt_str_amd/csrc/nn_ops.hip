@@ -548,6 +548,13 @@ extern "C" int adt_layernorm_bwd(const float* dy, int64_t lddy, const float* x, 
   return ADT_OK;
 }
 
+namespace adt {
+void launch_reduce_partials(const float* partial, int n_part, int width, float* out, hipStream_t st) {
+  hipLaunchKernelGGL(reduce_partials_kernel, dim3(static_cast<unsigned>((width + kRedCols - 1) / kRedCols)), dim3(256), 0, st, partial, n_part,
+                     width, out, static_cast<float*>(nullptr), static_cast<float*>(nullptr), width);
+}
+}  // namespace adt
+
 extern "C" size_t adt_colsum_workspace_bytes(int64_t M, int64_t N) {
   if (M <= 0 || N <= 0) return 0;
   return static_cast<size_t>((M + kColsumRows - 1) / kColsumRows) * N * 4;

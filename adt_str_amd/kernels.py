@@ -48,8 +48,10 @@ def gemm(a: torch.Tensor, b: torch.Tensor, *, trans: bool = False, out: Optional
          out_dtype=torch.bfloat16, bias: Optional[torch.Tensor] = None, residual: Optional[torch.Tensor] = None,
          res_row_mod: int = 0, act: int = 0, pre_act_out: Optional[torch.Tensor] = None,
          gelu_grad_of: Optional[torch.Tensor] = None, alpha: float = 1.0,
-         aux_bf16_out: Optional[torch.Tensor] = None, drop=None, drop_after_residual: bool = False) -> torch.Tensor:
-    """``trans=False``: ``a[M,K] @ b[N,K].T``; ``trans=True``: ``a[K,M].T @ b[K,N]`` (bf16 in, fp32 accumulate)."""
+         aux_bf16_out: Optional[torch.Tensor] = None, drop=None, drop_after_residual: bool = False,
+         colsum_out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """``trans=False``: ``a[M,K] @ b[N,K].T``; ``trans=True``: ``a[K,M].T @ b[K,N]`` (bf16 in, fp32 accumulate).
+    ``colsum_out`` (fp32 [N]) also receives the column sums of the bf16 output."""
     assert a.dtype == torch.bfloat16 and b.dtype == torch.bfloat16 and a.dim() == 2 and b.dim() == 2
     assert a.stride(1) == 1 and b.stride(1) == 1
     if trans:
@@ -85,6 +87,11 @@ def gemm(a: torch.Tensor, b: torch.Tensor, *, trans: bool = False, out: Optional
         assert aux_bf16_out.dtype == torch.bfloat16 and aux_bf16_out.shape == (M, N)
         ep.aux_bf16_out, ep.ld_aux = _ffi.dptr(aux_bf16_out), aux_bf16_out.stride(0)
     ws_bytes = _ffi.load().adt_gemm_workspace_bytes(int(trans), M, N, K) if trans else 0
+    if colsum_out is not None:
+        assert not trans and colsum_out.dtype == torch.float32 and colsum_out.numel() == N
+        assert colsum_out.is_contiguous()
+        ep.colsum_out = _ffi.dptr(colsum_out)
+        ws_bytes = _ffi.load().adt_gemm_colsum_workspace_bytes(M, N)
     ws = _workspace(ws_bytes, a.device) if ws_bytes else None
     _ffi.call("adt_gemm_bf16", int(trans), M, N, K, _ffi.dptr(a), a.stride(0), _ffi.dptr(b), b.stride(0),
               _ffi.dptr(out), out.stride(0), C.byref(ep), _ffi.dptr(ws) if ws is not None else None, ws_bytes,

@@ -324,10 +324,9 @@ class _Engine:
             p = L["p"]
             dy3_32, dy3_16 = K.layernorm_bwd(dx32, s["y3"], self.P(p + ".norm3.weight"), s["mean3"], s["rstd3"], G[p + ".norm3.weight"],
                                              G[p + ".norm3.bias"], G[p + ".linear2.bias"], dx16_drop=self.D(p + ".drop3"))
-            du = K.gemm(dy3_16, L["l2"].wt16, gelu_grad_of=s["u"], drop=self.D(p + ".ffn"))
+            du = K.gemm(dy3_16, L["l2"].wt16, gelu_grad_of=s["u"], drop=self.D(p + ".ffn"), colsum_out=G[p + ".linear1.bias"])
             K.gemm(dy3_16, s["h"], trans=True, out=G[p + ".linear2.weight"])
             K.gemm(du, s["x2_16"], trans=True, out=G[p + ".linear1.weight"])
-            K.colsum(du, out=G[p + ".linear1.bias"])
             dx2_32 = K.gemm(du, L["l1"].wt16, residual=dy3_32, out_dtype=F32)
             dy2_32, dy2_16 = K.layernorm_bwd(dx2_32, s["y2"], self.P(p + ".norm2.weight"), s["mean2"], s["rstd2"], G[p + ".norm2.weight"],
                                              G[p + ".norm2.bias"], G[p + ".multihead_attn.out_proj.bias"], dx16_drop=self.D(p + ".drop2"))
@@ -374,10 +373,9 @@ class _Engine:
             p = L["p"]
             dy2_32, dy2_16 = K.layernorm_bwd(dx32, s["y2"], self.P(p + ".norm2.weight"), s["mean2"], s["rstd2"], G[p + ".norm2.weight"],
                                              G[p + ".norm2.bias"], G[p + ".linear2.bias"], dx16_drop=self.D(p + ".drop2"))
-            du = K.gemm(dy2_16, L["l2"].wt16, gelu_grad_of=s["u"], drop=self.D(p + ".ffn"))
+            du = K.gemm(dy2_16, L["l2"].wt16, gelu_grad_of=s["u"], drop=self.D(p + ".ffn"), colsum_out=G[p + ".linear1.bias"])
             K.gemm(dy2_16, s["h"], trans=True, out=G[p + ".linear2.weight"])
             K.gemm(du, s["x1_16"], trans=True, out=G[p + ".linear1.weight"])
-            K.colsum(du, out=G[p + ".linear1.bias"])
             dx1_32 = K.gemm(du, L["l1"].wt16, residual=dy2_32, out_dtype=F32)
             dy1_32, dy1_16 = K.layernorm_bwd(dx1_32, s["y1"], self.P(p + ".norm1.weight"), s["mean1"], s["rstd1"], G[p + ".norm1.weight"],
                                              G[p + ".norm1.bias"], G[p + ".self_attn.out_proj.bias"], dx16_drop=self.D(p + ".drop1"))

@@ -39,7 +39,7 @@ extern "C" {
  * backward entry points regenerate them from the same (p, key).  p == 0 or a null pointer: off. */
 typedef struct adt_dropout { float p; uint32_t key; } adt_dropout;
 
-/* ABI version (3): bumped whenever a signature below changes or entries are added. */
+/* ABI version (4): bumped whenever a signature below changes or entries are added. */
 int adt_version(void);
 
 /* Message of the last failing call on this thread ("" if none). */
@@ -159,6 +159,9 @@ int adt_mix_render_fx_f32(const float* bank, const int64_t* bank_off, int64_t n_
  *   (an fp32 residual-stream output plus the bf16 operand of the next GEMM in one pass)
  * trans = 1 may split K across workgroups; partial fp32 slabs go to `ws`
  * (adt_gemm_workspace_bytes) and are summed in slab order (reproducible).
+ * colsum_out (fp32 [N], may be null; trans = 0 and a bf16 C only): also receives the column sums of C as stored --
+ * the bias gradient of the layer whose output gradient this GEMM produces (dgrad through GELU) -- summed in a fixed
+ * order inside the epilogue, so C is not read again; `ws` must then hold adt_gemm_colsum_workspace_bytes(M, N).
  * Large problems run on persistent kernels that take tiles from device work counters owned by the library: one
  * 512-byte allocation per (device, stream), made on the first large call on that stream (the only allocation this
  * library ever makes; it synchronises the device once).  As for any stream-ordered API, calls that target the same
@@ -174,9 +177,11 @@ typedef struct adt_gemm_epilogue {
   int32_t      out_fp32;
   void*        aux_bf16_out;  int64_t ld_aux;
   adt_dropout  drop;          int32_t drop_after_residual;
+  float*       colsum_out;
 } adt_gemm_epilogue;
 
 size_t adt_gemm_workspace_bytes(int32_t trans, int64_t M, int64_t N, int64_t K);
+size_t adt_gemm_colsum_workspace_bytes(int64_t M, int64_t N);
 
 int adt_gemm_bf16(int32_t trans, int64_t M, int64_t N, int64_t K, const void* A, int64_t lda,
                   const void* B, int64_t ldb, void* C, int64_t ldc, const adt_gemm_epilogue* ep,

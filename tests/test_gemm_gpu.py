@@ -139,6 +139,27 @@ def test_big_tile_persistent_kernel_epilogues_and_dropout():
     close(y, (z + bias) * mask + res, 1e-4, "dropout then residual")
 
 
+def test_fused_column_sums():
+    """colsum_out: the column sums of the stored bf16 output (bias gradient of the producing layer), fused in the persistent kernel's
+    epilogue (ragged edges, GELU-gradient + dropout form of the FFN dgrad) and computed by the stand-alone kernel for smaller tilings."""
+    from adt_str_amd import _ffi, kernels as k
+    for (M, N, K, tag) in [(8192 - 40, 4096 + 64, 256, "256^2"), (4096 + 8, 3072, 768, "256^2 FFN"), (500, 264, 96, "128^2"), (77, 24, 64, "v1")]:
+        a, b = rnd((M, K), M).bfloat16(), (rnd((N, K), N) * 0.1).bfloat16()
+        u = rnd((M, N), 5).bfloat16()
+        for kw in ({}, {"gelu_grad_of": u, "drop": (0.1, 77)}):
+            cs = torch.full((N,), float("nan"), device=DEV)
+            y = k.gemm(a, b, colsum_out=cs, **kw)
+            assert torch.equal(y, k.gemm(a, b, **kw)), tag                   # the output itself does not change
+            ref = y.double().sum(0)
+            scale = y.float().abs().sum(0).max().item()
+            assert (cs.double() - ref).abs().max().item() <= 2e-6 * scale + 1e-6, tag
+            cs2 = torch.empty_like(cs)
+            k.gemm(a, b, colsum_out=cs2, **kw)
+            assert torch.equal(cs, cs2), "fixed summation order"
+    with pytest.raises(_ffi.AdtError, match="colsum_out"):
+        k.gemm(a, b, colsum_out=cs, out_dtype=torch.float32)
+
+
 def test_randomised_shapes_cover_every_kernel_choice():
     """Random shapes around the dispatch thresholds (persistent 256^2 NT / TN, 128^2 LDS-DMA, register-staged) incl. ragged edges,
     leading dimensions larger than the row, fp32 and bf16 outputs."""
