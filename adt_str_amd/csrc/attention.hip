@@ -655,17 +655,22 @@ __global__ __launch_bounds__(kDkv2Threads) void attn_bwd_dkv2_kernel(AttnArgs a)
 #pragma unroll
           for (int e = 0; e < 4; ++e) { lse4[4 * q4 + e] = l4[q4][e]; dl4[4 * q4 + e] = d4[q4][e]; }
         const bool need_mask = key_mask || (t + 1) * kRowsPerTile > a.Sq;     // block-uniform
+        // two straight-line blocks (the per-element form compiles to a scalar branch per element, which leaves every v_exp
+        // latency exposed); the masked one is select-only: exp2 of a hugely negative argument is the 0 of an out-of-range pair
+        if (need_mask) {
+#pragma unroll
+          for (int i = 0; i < 16; ++i) {
+            const int qi = t * kRowsPerTile + qblk * 32 + acc_row(i, h);
+            const float tt = fmaf(st[i], sl2, mask_add(a, qi, ki, klen) * kLog2e) - lse4[i];
+            st[i] = __builtin_amdgcn_exp2f((qi < a.Sq && ki < a.Sk) ? tt : kNegBig);
+          }
+        } else {
+#pragma unroll
+          for (int i = 0; i < 16; ++i) st[i] = __builtin_amdgcn_exp2f(fmaf(st[i], sl2, -lse4[i]));
+        }
 #pragma unroll
         for (int i = 0; i < 16; ++i) {
-          const int ql = qblk * 32 + acc_row(i, h);
-          const int qi = t * kRowsPerTile + ql;
-          float p;
-          if (need_mask) {
-            const float tt = fmaf(st[i], sl2, mask_add(a, qi, ki, klen) * kLog2e);
-            p = (qi < a.Sq && ki < a.Sk) ? __builtin_amdgcn_exp2f(tt - lse4[i]) : 0.f;
-          } else {
-            p = __builtin_amdgcn_exp2f(fmaf(st[i], sl2, -lse4[i]));
-          }
+          const float p = st[i];
           const float keep = kDrop ? (((kbits >> i) & 1u) ? a.drop.inv_keep : 0.0f) : 1.0f;
           st[i] = p * keep;                                    // dropped P (what multiplied V in the forward)
           dp[i] = p * fmaf(dp[i], keep, -dl4[i]);              // dS / scale (scale applied when dK is stored)
@@ -685,17 +690,34 @@ __global__ __launch_bounds__(kDkv2Threads) void attn_bwd_dkv2_kernel(AttnArgs a)
     for (int db = 0; db < 4; ++db)
 #pragma unroll
       for (int i = 0; i < 16; ++i) { dk[db][i] = 0.f; dv[db][i] = 0.f; }
+    // transposed-read addresses: the swizzle only involves row bits 0..3, so a lane's eight offsets (4 d-blocks x rows r, r + 8)
+    // inside a 16-row group are fixed; stage and query block go in with one add each, k-step and Q / dO tile as immediates
+    unsigned troff[4][2];
+    {
+      const int i = lane & 15, g4 = (lane >> 4) & 1, row = 4 * h + (i >> 2);
+#pragma unroll
+      for (int db = 0; db < 4; ++db) {
+        const int chunk = 4 * db + 2 * g4 + ((i & 3) >> 1);
+        troff[db][0] = lds_off(smem) + static_cast<unsigned>(8 * (i & 1) + swz(row, chunk));
+        troff[db][1] = lds_off(smem) + static_cast<unsigned>(8 * (i & 1) + swz(row + 8, chunk));
+      }
+    }
+#define ADT_TR2(F, A0, A1, IMM)                                                                               \
+    asm volatile("ds_read_b64_tr_b16 %0, %2 offset:%4\n\tds_read_b64_tr_b16 %1, %3 offset:%4"                 \
+                 : "=&v"((F).lo), "=&v"((F).hi) : "v"(A0), "v"(A1), "i"(IMM) : "memory")
     for (int j = 0; j < n_iter; ++j) {
       if (kDrop && j + 1 < 2 * n_tiles) keepbits[((j + 1) & 1) * (kDkv2Mask / 4) + lane] = keep_mask_of_block(j + 1);
       if (j >= 1) {
         const int jj = j - 1, t = jj >> 1, qblk = jj & 1;
-        const unsigned char* tq = smem + (t % 3) * kDkv2Stage;
-        const unsigned char* td = tq + kAttnTileBytes;
+        const unsigned blk = static_cast<unsigned>((t % 3) * kDkv2Stage + qblk * 32 * 256);
         TrFrag dot[2][4], qt[2][4];
 #pragma unroll
-        for (int s2 = 0; s2 < 2; ++s2) {
-          tr4_issue(td, qblk * 32 + 16 * s2, lane, dot[s2]);
-          tr4_issue(tq, qblk * 32 + 16 * s2, lane, qt[s2]);
+        for (int db = 0; db < 4; ++db) {
+          const unsigned a0 = troff[db][0] + blk, a1 = troff[db][1] + blk;
+          ADT_TR2(dot[0][db], a0, a1, kAttnTileBytes);
+          ADT_TR2(qt[0][db], a0, a1, 0);
+          ADT_TR2(dot[1][db], a0, a1, kAttnTileBytes + 16 * 256);
+          ADT_TR2(qt[1][db], a0, a1, 16 * 256);
         }
         const unsigned char* hb = hand + (jj & 1) * kDkv2Hand + lane * 16;
         const bf16x8 pf0 = *reinterpret_cast<const bf16x8*>(hb), pf1 = *reinterpret_cast<const bf16x8*>(hb + 1024);
@@ -714,6 +736,7 @@ __global__ __launch_bounds__(kDkv2Threads) void attn_bwd_dkv2_kernel(AttnArgs a)
       }
       ADT_DKV2_END_OF_ITERATION(j);
     }
+#undef ADT_TR2
     store_transposed(dk, a.scale, a.dk + static_cast<long>(b) * a.Sk * a.ldk + head * kDh, a.ldk, ki, a.Sk, lane);
     store_transposed(dv, 1.0f, a.dv + static_cast<long>(b) * a.Sk * a.ldv + head * kDh, a.ldv, ki, a.Sk, lane);
   }
