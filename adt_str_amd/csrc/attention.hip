@@ -36,6 +36,8 @@ typedef __attribute__((ext_vector_type(8))) short bf16x8;
 typedef __attribute__((ext_vector_type(4))) short bf16x4;
 typedef __attribute__((ext_vector_type(16))) float f32x16;
 typedef __attribute__((ext_vector_type(4))) float f32x4;
+typedef __attribute__((ext_vector_type(2))) float f32x2;
+typedef __attribute__((ext_vector_type(4))) unsigned u32x4;
 
 constexpr int kDh = 128;
 constexpr int kAttnThreads = 256;
@@ -501,7 +503,7 @@ __global__ __launch_bounds__(kAttnThreads, 1) void attn_bwd_dkv_kernel(AttnArgs 
 constexpr int kDkv2Threads = 512;
 constexpr int kDkv2Stage = 2 * kAttnTileBytes + 512;          // Q tile | dO tile | lse2[64] | delta[64]
 constexpr int kDkv2Hand = 4 * 1024;                           // P(s2=0) | P(s2=1) | dS(s2=0) | dS(s2=1), one 16-byte operand per lane
-constexpr int kDkv2Mask = 256;                                // keep bits of one 32-query block: one dword per lane
+constexpr int kDkv2Mask = 1024;                               // keep flags of one 32-query block: 16 bytes (0 / 1) per lane
 constexpr int kDkv2Lds = 3 * kDkv2Stage + 4 * 2 * kDkv2Hand + 4 * 2 * kDkv2Mask;  // 134,656 B
 
 __device__ __forceinline__ void tile_dma8(const unsigned short* __restrict__ base, long row_stride, int row0, int n_rows,
@@ -531,63 +533,70 @@ __global__ __launch_bounds__(kDkv2Threads) void attn_bwd_dkv2_kernel(AttnArgs a)
   const float* lse_b = a.lse + (static_cast<long>(b) * a.H + head) * a.Sq;
   const float* dl_b = a.delta + (static_cast<long>(b) * a.H + head) * a.Sq;
   unsigned char* hand = smem + 3 * kDkv2Stage + pair * 2 * kDkv2Hand;
-  unsigned* keepbits = reinterpret_cast<unsigned*>(smem + 3 * kDkv2Stage + 4 * 2 * kDkv2Hand + pair * 2 * kDkv2Mask);
+  unsigned char* keepflags = smem + 3 * kDkv2Stage + 4 * 2 * kDkv2Hand + pair * 2 * kDkv2Mask;
   const int n_tiles = (a.Sq + kRowsPerTile - 1) / kRowsPerTile;
   const int n_iter = 2 * n_tiles + 1;
   // dropout: the keep decisions depend on indices only, so the (mostly idle) acc-wave hashes them one block AHEAD of its
-  // S-wave and hands over 16 bits per lane (bit i = element i kept); the S-wave then spends two instructions per element
-  // instead of the whole hash.  Block 0's bits are produced before the loop.
+  // S-wave and hands over one byte per element (0 / 1; byte i of the lane's 16 = element i); the S-wave then spends one
+  // v_cvt_f32_ubyte per element instead of the whole hash.  Block 0's flags are produced before the loop.
   const unsigned headbase = static_cast<unsigned>((static_cast<uint64_t>(b) * a.H + head) * a.Sq * a.Sk) + static_cast<unsigned>(ki);
   const unsigned key2 = mix32(a.drop.key);
-  auto keep_mask_of_block = [&](int jb) {
-    unsigned bits = 0;
+  auto keep_flags_of_block = [&](int jb) {
+    unsigned w[4] = {0u, 0u, 0u, 0u};
+    unsigned vb = headbase + static_cast<unsigned>(jb * 32 + 4 * h) * static_cast<unsigned>(a.Sk);
+    asm volatile("" : "+v"(vb));            // opaque: otherwise 16 loop-invariant index registers are kept alive instead of 16 scalars
 #pragma unroll
     for (int i = 0; i < 16; ++i) {
-      const int qi = jb * 32 + acc_row(i, h);
-      bits |= (mix32((headbase + static_cast<unsigned>(qi) * static_cast<unsigned>(a.Sk)) ^ key2) >= a.drop.thr ? 1u : 0u) << i;
+      const unsigned idx = vb + static_cast<unsigned>((i & 3) + 8 * (i >> 2)) * static_cast<unsigned>(a.Sk);
+      w[i >> 2] |= (mix32(idx ^ key2) >= a.drop.thr ? 1u : 0u) << (8 * (i & 3));
     }
-    return bits;
+    return u32x4{w[0], w[1], w[2], w[3]};
   };
-  if (kDrop && role == 1) keepbits[lane] = keep_mask_of_block(0);
+  if (kDrop && role == 1) *reinterpret_cast<u32x4*>(keepflags + lane * 16) = keep_flags_of_block(0);
 
+  // ---- Q / dO tile staging and the per-query statistics belong to the acc-waves alone (they have the slack; the S-waves then
+  // have no vector-memory work in the loop at all).  Acc-wave w fills rows 16w .. 16w+15 of a tile with four LDS-DMA instructions.
+  const int aw = wave & 3;
   float rs = 0.f;
-  auto load_stats = [&](int t) {                                   // threads 0..63: lse2, 64..127: delta of tile t's 64 queries
-    const int qq = t * kRowsPerTile + (tid & 63);
-    rs = 0.f;
-    if (tid < 128 && qq < a.Sq) rs = tid < 64 ? lse_b[qq] * kLog2e : dl_b[qq];
+  auto load_stats = [&](int t) {                                   // acc-wave 0: -lse2, acc-wave 1: -delta of tile t's 64 queries
+    const int qq = t * kRowsPerTile + lane;
+    rs = 0.f;                                                      // raw values: any arithmetic here would wait for the load
+    if (aw == 0 && qq < a.Sq) rs = lse_b[qq];
+    if (aw == 1 && qq < a.Sq) rs = dl_b[qq];
   };
-  auto store_stats = [&](int t) {
-    if (tid < 128) reinterpret_cast<float*>(smem + (t % 3) * kDkv2Stage + 2 * kAttnTileBytes)[tid] = rs;
+  auto store_stats = [&](int t) {                                  // both enter the S-waves' arithmetic negated
+    if (aw < 2) reinterpret_cast<float*>(smem + (t % 3) * kDkv2Stage + 2 * kAttnTileBytes)[aw * 64 + lane] = aw == 0 ? -rs * kLog2e : -rs;
   };
   auto issue_tile = [&](int t) {                                   // stats first: the DMAs behind them stay in flight longer
     load_stats(t);
     unsigned char* st = smem + (t % 3) * kDkv2Stage;
-    tile_dma8(qb, a.ldq, t * kRowsPerTile, a.Sq, st, wave, lane);
-    tile_dma8(dob, a.ldo, t * kRowsPerTile, a.Sq, st + kAttnTileBytes, wave, lane);
+    const int row0 = t * kRowsPerTile;
+    const bool full = row0 + kRowsPerTile <= a.Sq;                 // otherwise rows past the end repeat the last valid row
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int row = 4 * (4 * aw + i) + (lane >> 4);
+      const int chunk = (lane & 15) ^ (((row & 3) << 2) | ((row >> 2) & 3));
+      int gr = row0 + row;
+      if (!full) gr = gr < a.Sq ? gr : a.Sq - 1;
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(qb + static_cast<long>(gr) * a.ldq + chunk * 8),
+                                       (__attribute__((address_space(3))) void*)(st + (4 * aw + i) * 1024), 16, 0, 0);
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(dob + static_cast<long>(gr) * a.ldo + chunk * 8),
+                                       (__attribute__((address_space(3))) void*)(st + kAttnTileBytes + (4 * aw + i) * 1024), 16, 0, 0);
+    }
   };
   // prologue: tiles 0..2 resident (stats of a tile are stored once its loads have returned)
-  for (int t = 0; t < 3 && t < n_tiles; ++t) {
-    issue_tile(t);
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    store_stats(t);
+  if (role == 1) {
+    for (int t = 0; t < 3 && t < n_tiles; ++t) {
+      issue_tile(t);
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      store_stats(t);
+    }
   }
   __syncthreads();
 
   // Every wave runs n_iter iterations with ONE barrier each.  In iteration j the S-waves work on query block j (j < 2 n_tiles),
   // the acc-waves on block j - 1 (j >= 1).  Odd iterations j >= 3 start the refill of the stage that block j - 1 was the last to
   // use (tile (j + 3) / 2); the even iteration after it waits for the refill (it then has had a whole iteration to land).
-#define ADT_DKV2_END_OF_ITERATION(j)                                                      \
-  do {                                                                                     \
-    const int tn_ = ((j) + 3) >> 1;                                                        \
-    if (((j) & 1) && (j) >= 3 && tn_ < n_tiles) issue_tile(tn_);                           \
-    if (!((j) & 1) && (j) >= 4 && (((j) + 2) >> 1) < n_tiles) {                            \
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                                     \
-      store_stats(((j) + 2) >> 1);                                                         \
-    }                                                                                      \
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                                     \
-    asm volatile("s_barrier" ::: "memory");                                                \
-  } while (0)
-
   if (role == 0) {
     // ------------------------------------------------------------------ S-waves
     const unsigned short* kb_ = a.k + static_cast<long>(b) * a.Sk * a.ldk + head * kDh;
@@ -602,8 +611,7 @@ __global__ __launch_bounds__(kDkv2Threads) void attn_bwd_dkv2_kernel(AttnArgs a)
 #pragma unroll
     for (int s = 0; s < 8; ++s) asm volatile("" :: "v"(kf[s]), "v"(vf[s]));      // first use here: the compiler's wait for these loads
                                                                                 // lands before the loop, not in front of its MFMAs
-    // LDS reads of the S-waves are inline asm with hand-placed lgkmcnt waits: compiler-generated reads would be ordered behind
-    // the tile DMAs in flight with a vmcnt(0), and come two at a time.  Per-lane byte offsets of the eight 16-byte row chunks:
+    // LDS traffic of the S-waves is inline asm with hand-placed lgkmcnt waits.  Per-lane byte offsets of the eight 16-byte row chunks:
     unsigned foff[8];
     {
       const int x = ((r & 3) << 2) | ((r >> 2) & 3);
@@ -611,31 +619,27 @@ __global__ __launch_bounds__(kDkv2Threads) void attn_bwd_dkv2_kernel(AttnArgs a)
       for (int s = 0; s < 8; ++s) foff[s] = static_cast<unsigned>(256 * r + 16 * ((2 * s + h) ^ x));
     }
     const unsigned smem_base = lds_off(smem);
+    // The Q fragments of block j + 1 are fetched while block j's softmax arithmetic runs (their registers are free once block j's
+    // S MFMAs have issued, and the tile of block j + 1 is resident: its refill was waited for before the previous barrier), so the
+    // S chain starts right after the barrier; the dO fragments arrive under it (prefetching both would not fit 256 registers).
+    bf16x8 fq[8];
+    auto issue_frags = [&](int jb) {
+      const unsigned tq_a = smem_base + static_cast<unsigned>(((jb >> 1) % 3) * kDkv2Stage + (jb & 1) * 32 * 256);
+#pragma unroll
+      for (int s = 0; s < 8; ++s) asm volatile("ds_read_b128 %0, %1" : "=v"(fq[s]) : "v"(tq_a + foff[s]));
+    };
+    static_assert(kAttnTileBytes == 16384, "immediate offset of the dO tile");
+    issue_frags(0);
     for (int j = 0; j < n_iter; ++j) {
       if (j < 2 * n_tiles) {
         const int t = j >> 1, qblk = j & 1;
-        const unsigned tq_a = smem_base + static_cast<unsigned>((t % 3) * kDkv2Stage + qblk * 32 * 256);
-        const unsigned td_a = tq_a + kAttnTileBytes;
         const unsigned st_a = smem_base + static_cast<unsigned>((t % 3) * kDkv2Stage + 2 * kAttnTileBytes + (qblk * 32 + 4 * h) * 4);
-        bf16x8 fq[8], fd[8];
+        const unsigned td_a = smem_base + static_cast<unsigned>((t % 3) * kDkv2Stage + qblk * 32 * 256);
+        bf16x8 fd[8];
 #pragma unroll
-        for (int s = 0; s < 8; ++s) {
-          asm volatile("ds_read_b128 %0, %1" : "=v"(fq[s]) : "v"(tq_a + foff[s]));
-          asm volatile("ds_read_b128 %0, %1" : "=v"(fd[s]) : "v"(td_a + foff[s]));
-        }
-        f32x16 st, dp;
-#pragma unroll
-        for (int i = 0; i < 16; ++i) { st[i] = 0.f; dp[i] = 0.f; }
-#define ADT_S_STEP(S, CNT)                                                                        \
-        asm volatile("s_waitcnt lgkmcnt(" #CNT ")" ::: "memory");                                  \
-        __builtin_amdgcn_sched_barrier(0);                                                         \
-        st = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fq[S], kf[S], st, 0, 0, 0);                   \
-        dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fd[S], vf[S], dp, 0, 0, 0);                   \
-        __builtin_amdgcn_sched_barrier(0);
-        ADT_S_STEP(0, 14) ADT_S_STEP(1, 12) ADT_S_STEP(2, 10) ADT_S_STEP(3, 8)
-        ADT_S_STEP(4, 6) ADT_S_STEP(5, 4) ADT_S_STEP(6, 2) ADT_S_STEP(7, 0)
-#undef ADT_S_STEP
-        // per-query statistics of this lane's 16 rows: rows 8 q4 + 4h + (0..3) are four consecutive floats
+        for (int s = 0; s < 8; ++s) asm volatile("ds_read_b128 %0, %1 offset:16384" : "=v"(fd[s]) : "v"(td_a + foff[s]));
+        // per-query statistics of this lane's 16 rows (rows 8 q4 + 4h + (0..3) are four consecutive floats) and the keep flags:
+        // queued behind the fragment reads, back long before the MFMA chain ends
         f32x4 l4[4], d4[4];
         asm volatile("ds_read_b128 %0, %1" : "=v"(l4[0]) : "v"(st_a));
         asm volatile("ds_read_b128 %0, %1 offset:32" : "=v"(l4[1]) : "v"(st_a));
@@ -645,43 +649,73 @@ __global__ __launch_bounds__(kDkv2Threads) void attn_bwd_dkv2_kernel(AttnArgs a)
         asm volatile("ds_read_b128 %0, %1 offset:288" : "=v"(d4[1]) : "v"(st_a));
         asm volatile("ds_read_b128 %0, %1 offset:320" : "=v"(d4[2]) : "v"(st_a));
         asm volatile("ds_read_b128 %0, %1 offset:352" : "=v"(d4[3]) : "v"(st_a));
-        unsigned kbits = 0xffffu;
-        if (kDrop) asm volatile("ds_read_b32 %0, %1" : "=v"(kbits) : "v"(lds_off(keepbits + (j & 1) * (kDkv2Mask / 4) + lane)));
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        u32x4 kfl = {0u, 0u, 0u, 0u};
+        if (kDrop) asm volatile("ds_read_b128 %0, %1" : "=v"(kfl) : "v"(lds_off(keepflags + (j & 1) * kDkv2Mask + lane * 16)));
+        f32x16 st, dp;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) { st[i] = 0.f; dp[i] = 0.f; }
         __builtin_amdgcn_sched_barrier(0);
-        float lse4[16], dl4[16];
 #pragma unroll
-        for (int q4 = 0; q4 < 4; ++q4)
+        for (int s = 0; s < 8; ++s) st = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fq[s], kf[s], st, 0, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);
+        if (kDrop) asm volatile("s_waitcnt lgkmcnt(9)" ::: "memory");          // the 8 dO fragment reads (older, in-order) are back
+        else asm volatile("s_waitcnt lgkmcnt(8)" ::: "memory");
+        __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-          for (int e = 0; e < 4; ++e) { lse4[4 * q4 + e] = l4[q4][e]; dl4[4 * q4 + e] = d4[q4][e]; }
+        for (int s = 0; s < 8; ++s) dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fd[s], vf[s], dp, 0, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        if (j + 1 < 2 * n_tiles) issue_frags(j + 1);
+        __builtin_amdgcn_sched_barrier(0);
         const bool need_mask = key_mask || (t + 1) * kRowsPerTile > a.Sq;     // block-uniform
-        // two straight-line blocks (the per-element form compiles to a scalar branch per element, which leaves every v_exp
-        // latency exposed); the masked one is select-only: exp2 of a hugely negative argument is the 0 of an out-of-range pair
+        // Everything below is written on register PAIRS (elements 2m, 2m + 1: adjacent accumulator registers, adjacent statistics,
+        // one packed bf16 dword of the hand-over operand) so that it compiles to v_pk_fma / v_pk_mul without register shuffles.
+        // Two straight-line exp blocks (a per-element `if` compiles to a scalar branch per element, which leaves every v_exp
+        // latency exposed); the masked one is select-only: exp2 of a hugely negative argument is the 0 of an out-of-range pair.
+        f32x2 pv[8];
         if (need_mask) {
 #pragma unroll
           for (int i = 0; i < 16; ++i) {
             const int qi = t * kRowsPerTile + qblk * 32 + acc_row(i, h);
-            const float tt = fmaf(st[i], sl2, mask_add(a, qi, ki, klen) * kLog2e) - lse4[i];
-            st[i] = __builtin_amdgcn_exp2f((qi < a.Sq && ki < a.Sk) ? tt : kNegBig);
+            const float tt = fmaf(st[i], sl2, mask_add(a, qi, ki, klen) * kLog2e) + l4[i >> 2][i & 3];
+            pv[i >> 1][i & 1] = __builtin_amdgcn_exp2f((qi < a.Sq && ki < a.Sk) ? tt : kNegBig);
           }
         } else {
 #pragma unroll
-          for (int i = 0; i < 16; ++i) st[i] = __builtin_amdgcn_exp2f(fmaf(st[i], sl2, -lse4[i]));
+          for (int m = 0; m < 8; ++m) {
+            const f32x2 sv = {st[2 * m], st[2 * m + 1]}, nl = {l4[m >> 1][2 * (m & 1)], l4[m >> 1][2 * (m & 1) + 1]};
+            const f32x2 arg = sv * sl2 + nl;
+            pv[m] = f32x2{__builtin_amdgcn_exp2f(arg[0]), __builtin_amdgcn_exp2f(arg[1])};
+          }
         }
-#pragma unroll
-        for (int i = 0; i < 16; ++i) {
-          const float p = st[i];
-          const float keep = kDrop ? (((kbits >> i) & 1u) ? a.drop.inv_keep : 0.0f) : 1.0f;
-          st[i] = p * keep;                                    // dropped P (what multiplied V in the forward)
-          dp[i] = p * fmaf(dp[i], keep, -dl4[i]);              // dS / scale (scale applied when dK is stored)
+        const unsigned kw[4] = {kfl[0], kfl[1], kfl[2], kfl[3]};
+        unsigned hp[8], hs[8];                                 // packed bf16 pairs: dropped P (what multiplied V in the forward),
+#pragma unroll                                                 // dS / scale (the scale is applied when dK is stored)
+        for (int m = 0; m < 8; ++m) {
+          const f32x2 dpv = {dp[2 * m], dp[2 * m + 1]}, nd = {d4[m >> 1][2 * (m & 1)], d4[m >> 1][2 * (m & 1) + 1]};
+          f32x2 pd = pv[m], ds;
+          if (kDrop) {
+            const unsigned w = kw[m >> 1];
+            const f32x2 k01 = (m & 1) ? f32x2{static_cast<float>((w >> 16) & 0xffu), static_cast<float>(w >> 24)}
+                                      : f32x2{static_cast<float>(w & 0xffu), static_cast<float>((w >> 8) & 0xffu)};
+            const f32x2 ks = k01 * a.drop.inv_keep;            // 0 or exactly 1 / (1 - p)
+            pd = pv[m] * ks;
+            ds = pv[m] * (dpv * ks + nd);
+          } else {
+            ds = pv[m] * (dpv + nd);
+          }
+          // (asm: the compiler's own pairing of the conversions picks elements 0,2 / 1,3 and re-interleaves with four more instructions)
+          asm("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(hp[m]) : "v"(pd[0]), "v"(pd[1]));
+          asm("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(hs[m]) : "v"(ds[0]), "v"(ds[1]));
         }
-        unsigned char* hb = hand + (j & 1) * kDkv2Hand + lane * 16;
-        *reinterpret_cast<bf16x8*>(hb) = acc_to_b(st, 0);
-        *reinterpret_cast<bf16x8*>(hb + 1024) = acc_to_b(st, 1);
-        *reinterpret_cast<bf16x8*>(hb + 2048) = acc_to_b(dp, 0);
-        *reinterpret_cast<bf16x8*>(hb + 3072) = acc_to_b(dp, 1);
+        const unsigned hb = lds_off(hand + (j & 1) * kDkv2Hand + lane * 16);
+        asm volatile("ds_write_b128 %0, %1" :: "v"(hb), "v"(u32x4{hp[0], hp[1], hp[2], hp[3]}) : "memory");
+        asm volatile("ds_write_b128 %0, %1 offset:1024" :: "v"(hb), "v"(u32x4{hp[4], hp[5], hp[6], hp[7]}) : "memory");
+        asm volatile("ds_write_b128 %0, %1 offset:2048" :: "v"(hb), "v"(u32x4{hs[0], hs[1], hs[2], hs[3]}) : "memory");
+        asm volatile("ds_write_b128 %0, %1 offset:3072" :: "v"(hb), "v"(u32x4{hs[4], hs[5], hs[6], hs[7]}) : "memory");
       }
-      ADT_DKV2_END_OF_ITERATION(j);
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      asm volatile("s_barrier" ::: "memory");
     }
   } else {
     // ------------------------------------------------------------------ acc-waves
@@ -705,42 +739,67 @@ __global__ __launch_bounds__(kDkv2Threads) void attn_bwd_dkv2_kernel(AttnArgs a)
 #define ADT_TR2(F, A0, A1, IMM)                                                                               \
     asm volatile("ds_read_b64_tr_b16 %0, %2 offset:%4\n\tds_read_b64_tr_b16 %1, %3 offset:%4"                 \
                  : "=&v"((F).lo), "=&v"((F).hi) : "v"(A0), "v"(A1), "i"(IMM) : "memory")
+    // All LDS traffic of the loop is inline asm (compiler-generated accesses would be ordered behind the tile DMAs in flight with a
+    // vmcnt(0)).  Order inside an iteration: the reads of block j - 1's first k-step go out, the dropout hashes of block j + 1 run
+    // while they are in flight, the second k-step's reads follow (all 36 at once next to the hash temporaries would not fit 256
+    // registers), then 8 + 8 MFMAs, then this wave's share of the tile refill.
     for (int j = 0; j < n_iter; ++j) {
-      if (kDrop && j + 1 < 2 * n_tiles) keepbits[((j + 1) & 1) * (kDkv2Mask / 4) + lane] = keep_mask_of_block(j + 1);
+      TrFrag dot[2][4], qt[2][4];
+      bf16x8 pf0, pf1, dsf0, dsf1;
+      const int jj = j - 1;
+      const unsigned blk = static_cast<unsigned>(((jj >> 1) % 3) * kDkv2Stage + (jj & 1) * 32 * 256);
+      const unsigned hb = lds_off(hand + (jj & 1) * kDkv2Hand + lane * 16);
       if (j >= 1) {
-        const int jj = j - 1, t = jj >> 1, qblk = jj & 1;
-        const unsigned blk = static_cast<unsigned>((t % 3) * kDkv2Stage + qblk * 32 * 256);
-        TrFrag dot[2][4], qt[2][4];
 #pragma unroll
         for (int db = 0; db < 4; ++db) {
-          const unsigned a0 = troff[db][0] + blk, a1 = troff[db][1] + blk;
-          ADT_TR2(dot[0][db], a0, a1, kAttnTileBytes);
-          ADT_TR2(qt[0][db], a0, a1, 0);
-          ADT_TR2(dot[1][db], a0, a1, kAttnTileBytes + 16 * 256);
-          ADT_TR2(qt[1][db], a0, a1, 16 * 256);
+          ADT_TR2(dot[0][db], troff[db][0] + blk, troff[db][1] + blk, kAttnTileBytes);
+          ADT_TR2(qt[0][db], troff[db][0] + blk, troff[db][1] + blk, 0);
         }
-        const unsigned char* hb = hand + (jj & 1) * kDkv2Hand + lane * 16;
-        const bf16x8 pf0 = *reinterpret_cast<const bf16x8*>(hb), pf1 = *reinterpret_cast<const bf16x8*>(hb + 1024);
-        const bf16x8 dsf0 = *reinterpret_cast<const bf16x8*>(hb + 2048), dsf1 = *reinterpret_cast<const bf16x8*>(hb + 3072);
-        tr_wait();
+        asm volatile("ds_read_b128 %0, %1" : "=v"(pf0) : "v"(hb) : "memory");
+        asm volatile("ds_read_b128 %0, %1 offset:2048" : "=v"(dsf0) : "v"(hb) : "memory");
+      }
+      __builtin_amdgcn_sched_barrier(0);
+      if (kDrop && j + 1 < 2 * n_tiles) {
+        const u32x4 kf_ = keep_flags_of_block(j + 1);
+        asm volatile("ds_write_b128 %0, %1" :: "v"(lds_off(keepflags + ((j + 1) & 1) * kDkv2Mask + lane * 16)), "v"(kf_) : "memory");
+      }
+      __builtin_amdgcn_sched_barrier(0);
+      if (j >= 1) {
+#pragma unroll
+        for (int db = 0; db < 4; ++db) {
+          ADT_TR2(dot[1][db], troff[db][0] + blk, troff[db][1] + blk, kAttnTileBytes + 16 * 256);
+          ADT_TR2(qt[1][db], troff[db][0] + blk, troff[db][1] + blk, 16 * 256);
+        }
+        asm volatile("ds_read_b128 %0, %1 offset:1024" : "=v"(pf1) : "v"(hb) : "memory");
+        asm volatile("ds_read_b128 %0, %1 offset:3072" : "=v"(dsf1) : "v"(hb) : "memory");
+        asm volatile("s_waitcnt lgkmcnt(15)" ::: "memory");       // 18 newer reads: everything of the first k-step is back
+        __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int db = 0; db < 4; ++db) {
           dv[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(tr_get(dot[0][db]), pf0, dv[db], 0, 0, 0);
           dk[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(tr_get(qt[0][db]), dsf0, dk[db], 0, 0, 0);
         }
+        __builtin_amdgcn_sched_barrier(0);
+        tr_wait();
 #pragma unroll
         for (int db = 0; db < 4; ++db) {
           dv[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(tr_get(dot[1][db]), pf1, dv[db], 0, 0, 0);
           dk[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(tr_get(qt[1][db]), dsf1, dk[db], 0, 0, 0);
         }
       }
-      ADT_DKV2_END_OF_ITERATION(j);
+      const int tn = (j + 3) >> 1;
+      if ((j & 1) && j >= 3 && tn < n_tiles) issue_tile(tn);
+      if (!(j & 1) && j >= 4 && ((j + 2) >> 1) < n_tiles) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        store_stats((j + 2) >> 1);
+      }
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      asm volatile("s_barrier" ::: "memory");
     }
 #undef ADT_TR2
     store_transposed(dk, a.scale, a.dk + static_cast<long>(b) * a.Sk * a.ldk + head * kDh, a.ldk, ki, a.Sk, lane);
     store_transposed(dv, 1.0f, a.dv + static_cast<long>(b) * a.Sk * a.ldv + head * kDh, a.ldv, ki, a.Sk, lane);
   }
-#undef ADT_DKV2_END_OF_ITERATION
 }
 
 static int check_desc(const adt_attn_desc* d, const char* who) {
