@@ -54,10 +54,11 @@ __device__ __forceinline__ unsigned lds_off(const void* p) {
 __device__ __forceinline__ int swz(int row, int chunk) {
   return 256 * row + 16 * (chunk ^ (((row & 3) << 2) | ((row >> 2) & 3)));
 }
+// (asm: left to itself the compiler pairs the conversions of elements 0,2 / 1,3 and re-interleaves with four more instructions)
 __device__ __forceinline__ unsigned pack2(float lo, float hi) {
-  const unsigned a = __builtin_bit_cast(unsigned short, static_cast<__bf16>(lo));
-  const unsigned b = __builtin_bit_cast(unsigned short, static_cast<__bf16>(hi));
-  return a | (b << 16);
+  unsigned r;
+  asm("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(r) : "v"(lo), "v"(hi));
+  return r;
 }
 // accumulator registers 8s .. 8s+7 of a 32x32 tile -> the bf16 B operand of k-step s (rows 16s..16s+15 of the tile)
 __device__ __forceinline__ bf16x8 acc_to_b(const f32x16& x, int s) {
@@ -107,6 +108,24 @@ __device__ __forceinline__ void tr4_issue(const unsigned char* tile, int R0, int
     const unsigned a0 = base + swz(row, chunk), a1 = base + swz(row + 8, chunk);
     asm volatile("ds_read_b64_tr_b16 %0, %2\n\tds_read_b64_tr_b16 %1, %3" : "=&v"(f[db].lo), "=&v"(f[db].hi) : "v"(a0), "v"(a1) : "memory");
   }
+}
+// The same reads from per-lane offsets computed once: the swizzle only involves row bits 0..3, so a lane's eight offsets (4 d-blocks
+// x rows r, r + 8) inside a 16-row group are loop constants; the tile base goes in with one add, the 16-row group as an immediate.
+__device__ __forceinline__ void tr_offsets(int lane, unsigned (&o)[4][2]) {
+  const int i = lane & 15, g4 = (lane >> 4) & 1, h = lane >> 5, row = 4 * h + (i >> 2);
+#pragma unroll
+  for (int db = 0; db < 4; ++db) {
+    const int chunk = 4 * db + 2 * g4 + ((i & 3) >> 1);
+    o[db][0] = static_cast<unsigned>(8 * (i & 1) + swz(row, chunk));
+    o[db][1] = static_cast<unsigned>(8 * (i & 1) + swz(row + 8, chunk));
+  }
+}
+template <int kR0>
+__device__ __forceinline__ void tr4_issue_at(const unsigned (&a)[4][2], TrFrag (&f)[4]) {      // a = tr_offsets + LDS address of the tile
+#pragma unroll
+  for (int db = 0; db < 4; ++db)
+    asm volatile("ds_read_b64_tr_b16 %0, %2 offset:%4\n\tds_read_b64_tr_b16 %1, %3 offset:%4"
+                 : "=&v"(f[db].lo), "=&v"(f[db].hi) : "v"(a[db][0]), "v"(a[db][1]), "i"(kR0 * 256) : "memory");
 }
 __device__ __forceinline__ void tr_wait() {
   asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
@@ -194,10 +213,15 @@ __global__ __launch_bounds__(kAttnThreads, 2) void attn_fwd_kernel(AttnArgs a) {
   tile_dma(kb_, a.ldk, 0, a.Sk, smem, wave, lane);
   tile_dma(vb, a.ldv, 0, a.Sk, smem + kAttnTileBytes, wave, lane);
   dma_wait_and_sync();
+  unsigned troff[4][2];
+  tr_offsets(lane, troff);
 
   for (int t = 0; t < n_tiles; ++t) {
     const unsigned char* tk = smem + (t & 1) * 2 * kAttnTileBytes;
     const unsigned char* tv = tk + kAttnTileBytes;
+    unsigned tva[4][2];
+#pragma unroll
+    for (int db = 0; db < 4; ++db) { tva[db][0] = troff[db][0] + lds_off(tv); tva[db][1] = troff[db][1] + lds_off(tv); }
     if (t + 1 < n_tiles) {
       unsigned char* nk = smem + ((t + 1) & 1) * 2 * kAttnTileBytes;
       tile_dma(kb_, a.ldk, (t + 1) * kRowsPerTile, a.Sk, nk, wave, lane);
@@ -257,7 +281,10 @@ __global__ __launch_bounds__(kAttnThreads, 2) void attn_fwd_kernel(AttnArgs a) {
 #pragma unroll
       for (int s2 = 0; s2 < 2; ++s2) {
         TrFrag vt[4];
-        tr4_issue(tv, kb * 32 + 16 * s2, lane, vt);
+        if (kb == 0 && s2 == 0) tr4_issue_at<0>(tva, vt);
+        else if (kb == 0) tr4_issue_at<16>(tva, vt);
+        else if (s2 == 0) tr4_issue_at<32>(tva, vt);
+        else tr4_issue_at<48>(tva, vt);
         const bf16x8 pf = acc_to_b(st, s2);
         tr_wait();
 #pragma unroll
@@ -320,9 +347,14 @@ __global__ __launch_bounds__(kAttnThreads, 2) void attn_bwd_dq_kernel(AttnArgs a
   tile_dma(kb_, a.ldk, 0, a.Sk, smem, wave, lane);
   tile_dma(vb, a.ldv, 0, a.Sk, smem + kAttnTileBytes, wave, lane);
   dma_wait_and_sync();
+  unsigned troff[4][2];
+  tr_offsets(lane, troff);
   for (int t = 0; t < n_tiles; ++t) {
     const unsigned char* tk = smem + (t & 1) * 2 * kAttnTileBytes;
     const unsigned char* tv = tk + kAttnTileBytes;
+    unsigned tka[4][2];
+#pragma unroll
+    for (int db = 0; db < 4; ++db) { tka[db][0] = troff[db][0] + lds_off(tk); tka[db][1] = troff[db][1] + lds_off(tk); }
     if (t + 1 < n_tiles) {
       unsigned char* nk = smem + ((t + 1) & 1) * 2 * kAttnTileBytes;
       tile_dma(kb_, a.ldk, (t + 1) * kRowsPerTile, a.Sk, nk, wave, lane);
@@ -359,7 +391,10 @@ __global__ __launch_bounds__(kAttnThreads, 2) void attn_bwd_dq_kernel(AttnArgs a
 #pragma unroll
       for (int s2 = 0; s2 < 2; ++s2) {
         TrFrag kt[4];
-        tr4_issue(tk, kb * 32 + 16 * s2, lane, kt);
+        if (kb == 0 && s2 == 0) tr4_issue_at<0>(tka, kt);
+        else if (kb == 0) tr4_issue_at<16>(tka, kt);
+        else if (s2 == 0) tr4_issue_at<32>(tka, kt);
+        else tr4_issue_at<48>(tka, kt);
         const bf16x8 dsf = acc_to_b(st, s2);
         tr_wait();
 #pragma unroll
@@ -704,9 +739,8 @@ __global__ __launch_bounds__(kDkv2Threads) void attn_bwd_dkv2_kernel(AttnArgs a)
           } else {
             ds = pv[m] * (dpv + nd);
           }
-          // (asm: the compiler's own pairing of the conversions picks elements 0,2 / 1,3 and re-interleaves with four more instructions)
-          asm("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(hp[m]) : "v"(pd[0]), "v"(pd[1]));
-          asm("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(hs[m]) : "v"(ds[0]), "v"(ds[1]));
+          hp[m] = pack2(pd[0], pd[1]);
+          hs[m] = pack2(ds[0], ds[1]);
         }
         const unsigned hb = lds_off(hand + (j & 1) * kDkv2Hand + lane * 16);
         asm volatile("ds_write_b128 %0, %1" :: "v"(hb), "v"(u32x4{hp[0], hp[1], hp[2], hp[3]}) : "memory");
