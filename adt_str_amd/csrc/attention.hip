@@ -86,6 +86,28 @@ __device__ __forceinline__ void tile_dma(const unsigned short* __restrict__ base
                                      (__attribute__((address_space(3))) void*)(tile + (4 * wave + i) * 1024), 16, 0, 0);
   }
 }
+// The same staging with the per-lane part of the source address (row inside the tile, swizzled chunk) computed once per kernel:
+// off[i] = row_i * row_stride + chunk_i * 8 elements; a full tile then costs one 64-bit add per instruction.
+__device__ __forceinline__ void tile_dma_offsets(long row_stride, int wave, int lane, unsigned (&off)[4]) {
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int row = 4 * (4 * wave + i) + (lane >> 4);
+    const int chunk = (lane & 15) ^ (((row & 3) << 2) | ((row >> 2) & 3));
+    off[i] = static_cast<unsigned>(row * row_stride + chunk * 8);
+  }
+}
+__device__ __forceinline__ void tile_dma_pre(const unsigned short* __restrict__ base, long row_stride, int row0, int n_rows,
+                                             unsigned char* tile, int wave, int lane, const unsigned (&off)[4]) {
+  if (row0 + kRowsPerTile <= n_rows) {                  // block-uniform
+    const unsigned short* b0 = base + static_cast<long>(row0) * row_stride;
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(b0 + off[i]),
+                                       (__attribute__((address_space(3))) void*)(tile + (4 * wave + i) * 1024), 16, 0, 0);
+  } else {
+    tile_dma(base, row_stride, row0, n_rows, tile, wave, lane);
+  }
+}
 __device__ __forceinline__ void dma_wait_and_sync() {
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
@@ -210,6 +232,9 @@ __global__ __launch_bounds__(kAttnThreads, 2) void attn_fwd_kernel(AttnArgs a) {
   const unsigned key2 = mix32(a.drop.key);
 
   const int n_tiles = (a.Sk + kRowsPerTile - 1) / kRowsPerTile;
+  unsigned koff[4], voff[4];
+  tile_dma_offsets(a.ldk, wave, lane, koff);
+  tile_dma_offsets(a.ldv, wave, lane, voff);
   tile_dma(kb_, a.ldk, 0, a.Sk, smem, wave, lane);
   tile_dma(vb, a.ldv, 0, a.Sk, smem + kAttnTileBytes, wave, lane);
   dma_wait_and_sync();
@@ -224,8 +249,8 @@ __global__ __launch_bounds__(kAttnThreads, 2) void attn_fwd_kernel(AttnArgs a) {
     for (int db = 0; db < 4; ++db) { tva[db][0] = troff[db][0] + lds_off(tv); tva[db][1] = troff[db][1] + lds_off(tv); }
     if (t + 1 < n_tiles) {
       unsigned char* nk = smem + ((t + 1) & 1) * 2 * kAttnTileBytes;
-      tile_dma(kb_, a.ldk, (t + 1) * kRowsPerTile, a.Sk, nk, wave, lane);
-      tile_dma(vb, a.ldv, (t + 1) * kRowsPerTile, a.Sk, nk + kAttnTileBytes, wave, lane);
+      tile_dma_pre(kb_, a.ldk, (t + 1) * kRowsPerTile, a.Sk, nk, wave, lane, koff);
+      tile_dma_pre(vb, a.ldv, (t + 1) * kRowsPerTile, a.Sk, nk + kAttnTileBytes, wave, lane, voff);
     }
     const int tile0 = t * kRowsPerTile;
     const bool need_mask = a.causal || tile0 + kRowsPerTile > klen || tile0 + kRowsPerTile > a.Sk;   // block-uniform
@@ -344,6 +369,9 @@ __global__ __launch_bounds__(kAttnThreads, 2) void attn_bwd_dq_kernel(AttnArgs a
     for (int i = 0; i < 16; ++i) dq[db][i] = 0.f;
 
   const int n_tiles = (a.Sk + kRowsPerTile - 1) / kRowsPerTile;
+  unsigned koff[4], voff[4];
+  tile_dma_offsets(a.ldk, wave, lane, koff);
+  tile_dma_offsets(a.ldv, wave, lane, voff);
   tile_dma(kb_, a.ldk, 0, a.Sk, smem, wave, lane);
   tile_dma(vb, a.ldv, 0, a.Sk, smem + kAttnTileBytes, wave, lane);
   dma_wait_and_sync();
@@ -357,8 +385,8 @@ __global__ __launch_bounds__(kAttnThreads, 2) void attn_bwd_dq_kernel(AttnArgs a
     for (int db = 0; db < 4; ++db) { tka[db][0] = troff[db][0] + lds_off(tk); tka[db][1] = troff[db][1] + lds_off(tk); }
     if (t + 1 < n_tiles) {
       unsigned char* nk = smem + ((t + 1) & 1) * 2 * kAttnTileBytes;
-      tile_dma(kb_, a.ldk, (t + 1) * kRowsPerTile, a.Sk, nk, wave, lane);
-      tile_dma(vb, a.ldv, (t + 1) * kRowsPerTile, a.Sk, nk + kAttnTileBytes, wave, lane);
+      tile_dma_pre(kb_, a.ldk, (t + 1) * kRowsPerTile, a.Sk, nk, wave, lane, koff);
+      tile_dma_pre(vb, a.ldv, (t + 1) * kRowsPerTile, a.Sk, nk + kAttnTileBytes, wave, lane, voff);
     }
     const int tile0 = t * kRowsPerTile;
     const bool need_mask = a.causal || tile0 + kRowsPerTile > klen || tile0 + kRowsPerTile > a.Sk;
