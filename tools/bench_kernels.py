@@ -39,6 +39,21 @@ def main():
     u = torch.empty((M, 3072), device=dev, dtype=torch.bfloat16)
     ms = timeit(lambda: K.gemm(a, b, bias=bias, act=1, pre_act_out=u))
     print(f"NT FFN1 + bias + GELU + pre-act: {ms:.3f} ms  {2.0*M*3072*768/ms/1e9:.1f} TFLOP/s")
+    res = torch.randn((M, 768), device=dev)
+    x16 = torch.empty((M, 768), device=dev, dtype=torch.bfloat16)
+    wo = torch.randn((768, 768), device=dev).bfloat16()
+    b768 = torch.zeros(768, device=dev)
+    ms = timeit(lambda: K.gemm(a, wo, bias=b768, residual=res, out_dtype=torch.float32, aux_bf16_out=x16, drop=(0.1, 3)))
+    print(f"NT out-proj + bias + dropout + residual (fp32 + bf16 out): {ms:.3f} ms  {2.0*M*768*768/ms/1e9:.1f} TFLOP/s")
+    h = torch.randn((M, 3072), device=dev).bfloat16()
+    w2 = torch.randn((768, 3072), device=dev).bfloat16()
+    ms = timeit(lambda: K.gemm(h, w2, bias=b768, residual=res, out_dtype=torch.float32, aux_bf16_out=x16, drop=(0.1, 3)))
+    print(f"NT FFN2 + bias + dropout + residual (fp32 + bf16 out): {ms:.3f} ms  {2.0*M*768*3072/ms/1e9:.1f} TFLOP/s")
+    du = torch.empty((M, 3072), device=dev, dtype=torch.bfloat16)
+    ms = timeit(lambda: K.gemm(a, b, gelu_grad_of=u, drop=(0.1, 3), out=du))
+    print(f"NT FFN dgrad through GELU + dropout: {ms:.3f} ms  {2.0*M*3072*768/ms/1e9:.1f} TFLOP/s")
+    ms = timeit(lambda: K.gemm(du, w2.t().contiguous(), residual=res, out_dtype=torch.float32))
+    print(f"NT dx (K=3072) + residual fp32: {ms:.3f} ms  {2.0*M*3072*768/ms/1e9:.1f} TFLOP/s")
     if only == "nt":
         return
     print("== TN GEMM (wgrad) ==")
