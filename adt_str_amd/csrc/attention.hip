@@ -647,30 +647,26 @@ __global__ __launch_bounds__(kDkv2Threads) void attn_bwd_dkv2_kernel(AttnArgs a)
                                        (__attribute__((address_space(3))) void*)(st + kAttnTileBytes + (4 * aw + i) * 1024), 16, 0, 0);
     }
   };
-  // prologue: tiles 0..2 resident (stats of a tile are stored once its loads have returned)
-  if (role == 1) {
-    for (int t = 0; t < 3 && t < n_tiles; ++t) {
-      issue_tile(t);
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-      store_stats(t);
-    }
-  }
-  __syncthreads();
+  // prologue: tiles 0..2 resident -- the acc-waves start all of them before waiting once (stats of a tile are stored once its
+  // loads have returned) while the S-waves fetch their K^T / V^T fragments, so the kernel pays one memory round trip, not five
+  const unsigned short* kb_ = a.k + static_cast<long>(b) * a.Sk * a.ldk + head * kDh;
+  const unsigned short* vb = a.v + static_cast<long>(b) * a.Sk * a.ldv + head * kDh;
+  // (each role has its own copy of the barrier that ends the prologue: K^T / V^T stay out of the acc-waves' register budget)
 
   // Every wave runs n_iter iterations with ONE barrier each.  In iteration j the S-waves work on query block j (j < 2 n_tiles),
   // the acc-waves on block j - 1 (j >= 1).  Odd iterations j >= 3 start the refill of the stage that block j - 1 was the last to
   // use (tile (j + 3) / 2); the even iteration after it waits for the refill (it then has had a whole iteration to land).
   if (role == 0) {
     // ------------------------------------------------------------------ S-waves
-    const unsigned short* kb_ = a.k + static_cast<long>(b) * a.Sk * a.ldk + head * kDh;
-    const unsigned short* vb = a.v + static_cast<long>(b) * a.Sk * a.ldv + head * kDh;
+    bf16x8 kf[8], vf[8];
+    frags_from_global(kb_, a.ldk, ki, a.Sk, lane, kf);
+    frags_from_global(vb, a.ldv, ki, a.Sk, lane, vf);
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+    asm volatile("s_barrier" ::: "memory");
     const int klen = a.key_len ? a.key_len[b] : a.Sk;
     const float sl2 = a.scale * kLog2e;
     const int k_end = blockIdx.x * 128 + 128;
     const bool key_mask = a.causal || k_end > klen || k_end > a.Sk;
-    bf16x8 kf[8], vf[8];
-    frags_from_global(kb_, a.ldk, ki, a.Sk, lane, kf);
-    frags_from_global(vb, a.ldv, ki, a.Sk, lane, vf);
 #pragma unroll
     for (int s = 0; s < 8; ++s) asm volatile("" :: "v"(kf[s]), "v"(vf[s]));      // first use here: the compiler's wait for these loads
                                                                                 // lands before the loop, not in front of its MFMAs
@@ -781,6 +777,18 @@ __global__ __launch_bounds__(kDkv2Threads) void attn_bwd_dkv2_kernel(AttnArgs a)
     }
   } else {
     // ------------------------------------------------------------------ acc-waves
+    {
+      float rs3[3] = {0.f, 0.f, 0.f};
+#pragma unroll
+      for (int t = 0; t < 3; ++t)
+        if (t < n_tiles) { issue_tile(t); rs3[t] = rs; }
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#pragma unroll
+      for (int t = 0; t < 3; ++t)
+        if (t < n_tiles) { rs = rs3[t]; store_stats(t); }
+      asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+      asm volatile("s_barrier" ::: "memory");
+    }
     f32x16 dk[4], dv[4];
 #pragma unroll
     for (int db = 0; db < 4; ++db)

@@ -52,7 +52,7 @@ def main():
     du = torch.empty((M, 3072), device=dev, dtype=torch.bfloat16)
     ms = timeit(lambda: K.gemm(a, b, gelu_grad_of=u, drop=(0.1, 3), out=du))
     print(f"NT FFN dgrad through GELU + dropout: {ms:.3f} ms  {2.0*M*3072*768/ms/1e9:.1f} TFLOP/s")
-    ms = timeit(lambda: K.gemm(du, w2.t().contiguous(), residual=res, out_dtype=torch.float32))
+    ms = timeit(lambda: K.gemm(du, w2, residual=res, out_dtype=torch.float32))
     print(f"NT dx (K=3072) + residual fp32: {ms:.3f} ms  {2.0*M*3072*768/ms/1e9:.1f} TFLOP/s")
     if only == "nt":
         return
@@ -83,6 +83,23 @@ def main():
         ms = timeit(lambda: K.attn_bwd(qkv[:, :d], qkv[:, d:2 * d], qkv[:, 2 * d:], o, do, lse, dqkv[:, :d], dqkv[:, d:2 * d], dqkv[:, 2 * d:],
                                        B, H, S, S, scale, drop=drop))
         print(f"attn bwd dropout {drop[0]}: {ms:.3f} ms  {fl*2.5/ms/1e9:.1f} TFLOP/s algorithmic")
+    T = 128                                   # decoder shapes: cross-attention onto the memory, causal self-attention
+    qc = torch.randn((B * T, d), device=dev).bfloat16()
+    kvc = torch.randn((B * S, 2 * d), device=dev).bfloat16()
+    oc, lsec = K.attn_fwd(qc, kvc[:, :d], kvc[:, d:], B, H, T, S, scale, drop=(0.1, 7))
+    doc = torch.randn((B * T, d), device=dev).bfloat16()
+    dqc, dkvc = torch.empty_like(qc), torch.empty_like(kvc)
+    ms = timeit(lambda: K.attn_fwd(qc, kvc[:, :d], kvc[:, d:], B, H, T, S, scale, drop=(0.1, 7)))
+    print(f"cross-attn fwd T={T} S={S} dropout: {ms:.3f} ms")
+    ms = timeit(lambda: K.attn_bwd(qc, kvc[:, :d], kvc[:, d:], oc, doc, lsec, dqc, dkvc[:, :d], dkvc[:, d:], B, H, T, S, scale, drop=(0.1, 7)))
+    print(f"cross-attn bwd T={T} S={S} dropout: {ms:.3f} ms")
+    qs = torch.randn((B * T, 3 * d), device=dev).bfloat16()
+    klen = torch.full((B,), T - 9, dtype=torch.int32, device=dev)
+    os_, lses = K.attn_fwd(qs[:, :d], qs[:, d:2 * d], qs[:, 2 * d:], B, H, T, T, scale, causal=True, key_len=klen, drop=(0.1, 9))
+    dqs = torch.empty_like(qs)
+    ms = timeit(lambda: K.attn_bwd(qs[:, :d], qs[:, d:2 * d], qs[:, 2 * d:], os_, doc, lses, dqs[:, :d], dqs[:, d:2 * d], dqs[:, 2 * d:],
+                                   B, H, T, T, scale, causal=True, key_len=klen, drop=(0.1, 9)))
+    print(f"causal self-attn bwd T={T} dropout: {ms:.3f} ms")
     if only == "attn":
         return
     print("== row kernels ==")
