@@ -62,6 +62,30 @@ __device__ __forceinline__ float gauss_cdf(float x, float& e) {
 }
 __device__ __forceinline__ float gelu_erf(float x) { float e; return x * gauss_cdf(x, e); }
 __device__ __forceinline__ float gelu_erf_grad(float x) { float e; const float c = gauss_cdf(x, e); return fmaf(x * 0.3989422804014327f, e, c); }
+// The same arithmetic on register pairs (v_pk_fma_f32 / v_pk_mul_f32: two elements per instruction; only rcp and exp stay scalar):
+// hq = 0.5 erfc(|x| / sqrt 2) and e = exp(-x^2 / 2) of both elements.  GELU is then max(x, 0) - |x| hq on either side of 0.
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ f32x2 half_erfc2(f32x2 x, f32x2 ax, f32x2& e) {
+  const f32x2 den = ax * 0.23164190f + 1.0f;                               // 0.3275911 / sqrt 2
+  const f32x2 t = {__builtin_amdgcn_rcpf(den[0]), __builtin_amdgcn_rcpf(den[1])};
+  const f32x2 arg = (x * x) * -0.72134752f;                                // -0.5 log2 e
+  e = f32x2{__builtin_amdgcn_exp2f(arg[0]), __builtin_amdgcn_exp2f(arg[1])};
+  const f32x2 poly = t * ((((t * 0.5307027145f + -0.7265760135f) * t + 0.7107068705f) * t + -0.142248368f) * t + 0.127414796f);   // 0.5 P5
+  return poly * e;
+}
+__device__ __forceinline__ f32x2 abs2(f32x2 x) { return f32x2{fabsf(x[0]), fabsf(x[1])}; }
+__device__ __forceinline__ f32x2 gelu_erf2(f32x2 x) {
+  f32x2 e;
+  const f32x2 ax = abs2(x), hq = half_erfc2(x, ax, e);
+  return f32x2{fmaxf(x[0], 0.f), fmaxf(x[1], 0.f)} - ax * hq;
+}
+__device__ __forceinline__ f32x2 gelu_erf_grad2(f32x2 x) {               // Phi(x) + x phi(x)
+  f32x2 e;
+  const f32x2 ax = abs2(x), hq = half_erfc2(x, ax, e);
+  const f32x2 d = 0.5f - hq;                                              // Phi = 0.5 + sign(x) (0.5 - hq)
+  const f32x2 c = f32x2{copysignf(d[0], x[0]), copysignf(d[1], x[1])} + 0.5f;
+  return (x * 0.3989422804014327f) * e + c;
+}
 
 struct GemmArgs {
   const unsigned short* A; long lda;
@@ -254,8 +278,9 @@ __device__ __forceinline__ void epilogue_apply8(const GemmArgs& g, float (&z)[8]
     const unsigned w[4] = {uv.x, uv.y, uv.z, uv.w};
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
-      z[2 * e] *= gelu_erf_grad(__uint_as_float(w[e] << 16));
-      z[2 * e + 1] *= gelu_erf_grad(__uint_as_float(w[e] & 0xffff0000u));
+      const f32x2 gd = gelu_erf_grad2(f32x2{__uint_as_float(w[e] << 16), __uint_as_float(w[e] & 0xffff0000u)});
+      z[2 * e] *= gd[0];
+      z[2 * e + 1] *= gd[1];
     }
   }
   if (ep.pre_act_out) {
@@ -268,7 +293,11 @@ __device__ __forceinline__ void epilogue_apply8(const GemmArgs& g, float (&z)[8]
   }
   if (ep.act == 1) {
 #pragma unroll
-    for (int e = 0; e < 8; ++e) z[e] = gelu_erf(z[e]);
+    for (int e = 0; e < 4; ++e) {
+      const f32x2 gv = gelu_erf2(f32x2{z[2 * e], z[2 * e + 1]});
+      z[2 * e] = gv[0];
+      z[2 * e + 1] = gv[1];
+    }
   } else if (ep.act == 2) {
 #pragma unroll
     for (int e = 0; e < 8; ++e) z[e] = fmaxf(z[e], 0.0f);

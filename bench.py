@@ -274,7 +274,7 @@ def train_setup(dev, seed, world, dropout, fx_prob=0.0):
         ach = fl / (ms * 1e-3) / 1e12
         return {"bound": "mfma", "achieved": ach, "peak": BF16_MFMA_PEAK_TF, "unit": "TFLOP/s", "frac": ach / BF16_MFMA_PEAK_TF,
                 "traffic": pmc_traffic_bytes("gemm_pmc_summary.json"),
-                "kernel": "adt::gemm_nt_256_kernel<false> (FFN linear1 + bias + GELU + saved pre-activation, M=%d N=%d K=%d)" % (M, N, Kd),
+                "kernel": "adt::gemm_nt_256_kernel<false, false> (FFN linear1 + bias + GELU + saved pre-activation, M=%d N=%d K=%d)" % (M, N, Kd),
                 "kernel_ms": ms, "algorithmic_flops_per_launch": fl,
                 "algorithmic_bytes_per_launch": 2.0 * (M * Kd + N * Kd + 2 * M * N),
                 "profile": "profiles/r01/roofline_gemm_kernel_stats.csv (rocprofv3 --kernel-trace --stats of tools/pmc_gemm.py: this kernel "
