@@ -147,7 +147,7 @@ struct LnBwdArgs { const float* dy; long lddy; const float* x; long ldx; const f
                    const float* rstd; float* dx32; unsigned short* dx16; long lddx; float* partial; int M; int D;
                    Drop dy_drop, dx_drop; };
 
-__global__ __launch_bounds__(kRowThreads) void layernorm_bwd_kernel(LnBwdArgs a) {
+__global__ __launch_bounds__(kRowThreads, 3) void layernorm_bwd_kernel(LnBwdArgs a) {
   __shared__ float red[3][4][kMaxD];        // [dgamma|dbeta|dxsum][wave][col]  = 48 KiB
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int nq = a.D >> 2;
@@ -155,12 +155,31 @@ __global__ __launch_bounds__(kRowThreads) void layernorm_bwd_kernel(LnBwdArgs a)
 #pragma unroll
   for (int i = 0; i < 4; ++i) pg[i] = pb[i] = px[i] = make_float4(0, 0, 0, 0);
   const int rpb = ln_bwd_rows(a.M);
-  for (int rr = 0; rr < rpb / 4; ++rr) {
-    const int row = blockIdx.x * rpb + wave * (rpb / 4) + rr;
-    if (row >= a.M) break;
-    const float mean = a.mean[row], rstd = a.rstd[row];
+  // Rows are software-pipelined: the loads of the wave's next row are issued before this row's arithmetic, so two rows' worth of
+  // requests are in flight per wave (three waves per SIMD fit; one row each left the memory system under-subscribed at 3.7 TB/s).
+  const int row_first = blockIdx.x * rpb + wave * (rpb / 4);
+  float4 nxv[4], ndv[4];
+  float nmean = 0.f, nrstd = 0.f;
+  auto fetch = [&](int row) {
+    if (row >= a.M) return;
+    nmean = a.mean[row]; nrstd = a.rstd[row];
     const float4* xr = reinterpret_cast<const float4*>(a.x + static_cast<long>(row) * a.ldx);
     const float4* dyr = reinterpret_cast<const float4*>(a.dy + static_cast<long>(row) * a.lddy);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int q = lane + 64 * i;
+      if (q < nq) { nxv[i] = xr[q]; ndv[i] = dyr[q]; }
+    }
+  };
+  fetch(row_first);
+  for (int rr = 0; rr < rpb / 4; ++rr) {
+    const int row = row_first + rr;
+    if (row >= a.M) break;
+    const float mean = nmean, rstd = nrstd;
+    float4 cxv[4], cdv[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) { cxv[i] = nxv[i]; cdv[i] = ndv[i]; }
+    if (rr + 1 < rpb / 4) fetch(row + 1);
     float4 xh[4], g[4];
     float s1 = 0.f, s2 = 0.f;
 #pragma unroll
@@ -168,8 +187,8 @@ __global__ __launch_bounds__(kRowThreads) void layernorm_bwd_kernel(LnBwdArgs a)
       const int q = lane + 64 * i;
       xh[i] = g[i] = make_float4(0, 0, 0, 0);
       if (q >= nq) continue;
-      const float4 xv = xr[q], gm = reinterpret_cast<const float4*>(a.gamma)[q];
-      float4 dv = dyr[q];
+      const float4 xv = cxv[i], gm = reinterpret_cast<const float4*>(a.gamma)[q];
+      float4 dv = cdv[i];
       if (a.dy_drop.on()) {
         const uint64_t e0 = static_cast<uint64_t>(row) * a.D + 4 * q;
         dv.x *= a.dy_drop.scale(e0); dv.y *= a.dy_drop.scale(e0 + 1); dv.z *= a.dy_drop.scale(e0 + 2); dv.w *= a.dy_drop.scale(e0 + 3);
