@@ -259,6 +259,7 @@ int adt_colsum_bf16(const void* x, int64_t ld, int64_t M, int64_t N, float* out,
  * (reference model.py:42-65) as used by Decoder.forward (:171).
  *   fwd: y[row] = table[tokens[row]] * scale + pe[row % T]   (rows = B*T, row-major)
  *   bwd: dtable[tokens[row]] += scale * dy[row]              (dtable pre-zeroed by the caller)
+ *        (fp32 atomic adds: the one reduction on the path whose summation order is not fixed from run to run)
  */
 int adt_embed_pe_fwd(const int64_t* tokens, const float* table, const float* pe, float scale, float* y32, void* y16,
                      int64_t n_rows, int64_t T, int64_t D, int64_t vocab, const adt_dropout* drop, void* stream);
