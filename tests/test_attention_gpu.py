@@ -41,6 +41,10 @@ CASES = [  # B, H, Sq, Sk, causal, padded
     (4, 6, 128, 128, True, True),        # decoder self-attention with both additive masks
     (2, 3, 77, 50, True, True),          # ragged sizes
     (1, 2, 1, 200, False, False),        # single query row (greedy decode step)
+    (1, 1, 200, 96, False, False),       # 4 query tiles: the first refill of a dK/dV stage, last tile partial
+    (2, 2, 257, 300, True, True),        # 5 query tiles (one row in the last), 3 key blocks, both masks
+    (1, 1, 192, 33, False, True),        # exactly 3 query tiles (no refill), second key block almost empty
+    (1, 2, 449, 64, False, False),       # 8 query tiles (7 full + 1 row): every stage refilled twice
 ]
 
 
