@@ -92,7 +92,7 @@ def test_embedding_dropout():
     assert (dtab - ref_d).abs().max() < 1e-4 * ref_d.abs().max()
 
 
-@pytest.mark.parametrize("B,H,Sq,Sk,causal", [(2, 2, 128, 128, False), (2, 3, 77, 150, False), (2, 2, 96, 96, True)])
+@pytest.mark.parametrize("B,H,Sq,Sk,causal", [(2, 2, 128, 128, False), (2, 3, 77, 150, False), (2, 2, 96, 96, True), (1, 2, 300, 200, False), (1, 1, 449, 70, True)])
 def test_attention_dropout_forward_backward(B, H, Sq, Sk, causal):
     from adt_str_amd import kernels as k
     d = H * 128
