@@ -557,31 +557,23 @@ __global__ __launch_bounds__(kAttnThreads, 1) void attn_bwd_dkv_kernel(AttnArgs 
 // The kernel above keeps everything in one wave (S, dP, softmax / dropout arithmetic, dV, dK): ~400 registers = one wave per
 // SIMD, whose MFMAs, VALU work and LDS waits serialise (PMC: 13 % MFMA-busy, 44 % of wave-cycles parked in waits).  Here a
 // workgroup has 8 waves = 2 per SIMD with different jobs for the same 32 keys:
-//   * S-wave  w (0..3): K^T, V^T fragments in registers; per 32-query block S = Q K^T, dP = dO V^T (16 MFMAs), then all the
-//     VALU work (exp2, dropout hash, dS), packs P_drop and dS as MFMA B operands and hands them over through LDS;
-//   * acc-wave w + 4 : dV^T += dO^T P, dK^T += Q^T dS (16 MFMAs from transposed LDS reads), accumulators in registers.
+//   * S-wave  w (0..3): K^T, V^T fragments in registers; per 32-query block S = Q K^T, dP = dO V^T (16 MFMAs), then the softmax /
+//     dS arithmetic on register pairs, packs P_drop and dS as MFMA B operands and hands them over through LDS.  It is the
+//     critical path, so it does nothing else: no vector-memory work in its loop, the next block's Q fragments already in flight
+//     while it does this block's arithmetic;
+//   * acc-wave w + 4 : dV^T += dO^T P, dK^T += Q^T dS (16 MFMAs from transposed LDS reads), accumulators in registers; also
+//     everything that has slack to hide in: the Q / dO tile refills, the per-query statistics, the dropout hashes of the block
+//     after next (handed over as one byte per element).
 // Both fit 256 registers, and the acc-wave's MFMAs run in the shadow of the S-wave's VALU stream on the same SIMD.
 // The acc-wave works one query block behind its S-wave; one s_barrier per block orders the hand-over buffers (double
 // buffered) and the three Q / dO tile stages (a stage is refilled by LDS-DMA three blocks before it is needed again).
+// Cycle stamps of one block (encoder shape, ~1.75 GHz): S-wave 860 MFMA chains + 930 arithmetic + 150 hand-over, acc-wave
+// 370-1600 reads + hashes, 500 MFMAs, 430-870 refill; see profiles/r01/README.md for what the stamps found and fixed.
 constexpr int kDkv2Threads = 512;
 constexpr int kDkv2Stage = 2 * kAttnTileBytes + 512;          // Q tile | dO tile | lse2[64] | delta[64]
 constexpr int kDkv2Hand = 4 * 1024;                           // P(s2=0) | P(s2=1) | dS(s2=0) | dS(s2=1), one 16-byte operand per lane
 constexpr int kDkv2Mask = 1024;                               // keep flags of one 32-query block: 16 bytes (0 / 1) per lane
 constexpr int kDkv2Lds = 3 * kDkv2Stage + 4 * 2 * kDkv2Hand + 4 * 2 * kDkv2Mask;  // 134,656 B
-
-__device__ __forceinline__ void tile_dma8(const unsigned short* __restrict__ base, long row_stride, int row0, int n_rows,
-                                          unsigned char* tile, int wave, int lane) {     // 8 waves x 2 instructions x 4 rows
-#pragma unroll
-  for (int i = 0; i < 2; ++i) {
-    const int row = 4 * (2 * wave + i) + (lane >> 4);
-    const int chunk = (lane & 15) ^ (((row & 3) << 2) | ((row >> 2) & 3));
-    int gr = row0 + row;
-    gr = gr < n_rows ? gr : n_rows - 1;
-    const unsigned short* p = base + static_cast<long>(gr) * row_stride + chunk * 8;
-    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)p,
-                                     (__attribute__((address_space(3))) void*)(tile + (2 * wave + i) * 1024), 16, 0, 0);
-  }
-}
 
 template <bool kDrop>
 __global__ __launch_bounds__(kDkv2Threads) void attn_bwd_dkv2_kernel(AttnArgs a) {
