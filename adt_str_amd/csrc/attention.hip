@@ -228,7 +228,8 @@ __global__ __launch_bounds__(kAttnThreads, 2) void attn_fwd_kernel(AttnArgs a) {
 #pragma unroll
     for (int i = 0; i < 16; ++i) o[db][i] = 0.f;
   float m = kNegBig, l = 0.f;
-  const unsigned rowbase = static_cast<unsigned>(((static_cast<uint64_t>(b) * a.H + head) * a.Sq + qi) * a.Sk);
+  // dropout index of (row, key) is row * Sk2 + key (Sk2 = Sk rounded up to even; dropout.h): pair = row * Sk2 / 2 + key / 2
+  const unsigned pairbase = static_cast<unsigned>(((static_cast<uint64_t>(b) * a.H + head) * a.Sq + qi) * ((a.Sk + 1) >> 1));
   const unsigned key2 = mix32(a.drop.key);
 
   const int n_tiles = (a.Sk + kRowsPerTile - 1) / kRowsPerTile;
@@ -301,7 +302,13 @@ __global__ __launch_bounds__(kAttnThreads, 2) void attn_fwd_kernel(AttnArgs a) {
       l += psum;
       if (kDrop) {                           // dropout on the probabilities (the normaliser keeps the un-dropped sum)
 #pragma unroll
-        for (int i = 0; i < 16; ++i) st[i] *= a.drop.scale32(rowbase + tile0 + kb * 32 + acc_row(i, h), key2);
+        for (int g4 = 0; g4 < 4; ++g4)       // the lane's keys come in runs of four (tile0 + 32 kb + 8 g4 + 4 h ..+3): two hashes per run
+#pragma unroll
+          for (int u = 0; u < 2; ++u) {
+            const unsigned hh = a.drop.pair_hash32(pairbase + static_cast<unsigned>((tile0 + kb * 32 + 8 * g4 + 4 * h) >> 1) + u, key2);
+            st[4 * g4 + 2 * u] *= a.drop.lo(hh);
+            st[4 * g4 + 2 * u + 1] *= a.drop.hi(hh);
+          }
       }
 #pragma unroll
       for (int s2 = 0; s2 < 2; ++s2) {
@@ -341,7 +348,8 @@ __global__ __launch_bounds__(kAttnThreads, 2) void attn_bwd_dq_kernel(AttnArgs a
   const float sl2 = a.scale * kLog2e;
   const long stat = (static_cast<long>(b) * a.H + head) * a.Sq + (qi < a.Sq ? qi : 0);
   const float lse2 = a.lse[stat] * kLog2e;
-  const unsigned rowbase = static_cast<unsigned>(((static_cast<uint64_t>(b) * a.H + head) * a.Sq + qi) * a.Sk);
+  // dropout index of (row, key) is row * Sk2 + key (Sk2 = Sk rounded up to even; dropout.h): pair = row * Sk2 / 2 + key / 2
+  const unsigned pairbase = static_cast<unsigned>(((static_cast<uint64_t>(b) * a.H + head) * a.Sq + qi) * ((a.Sk + 1) >> 1));
   const unsigned key2 = mix32(a.drop.key);
 
   bf16x8 qf[8], dof[8];
@@ -411,11 +419,17 @@ __global__ __launch_bounds__(kAttnThreads, 2) void attn_bwd_dq_kernel(AttnArgs a
 #pragma unroll
         for (int i = 0; i < 16; ++i) st[i] = __builtin_amdgcn_exp2f(fmaf(st[i], sl2, -lse2));
       }
+      float keep[16];
 #pragma unroll
-      for (int i = 0; i < 16; ++i) {         // dS^T / scale (the softmax scale is applied once, when dQ is stored)
-        const float keep = kDrop ? a.drop.scale32(rowbase + tile0 + kb * 32 + acc_row(i, h), key2) : 1.0f;
-        st[i] *= fmaf(dp[i], keep, -dlt);
-      }
+      for (int g4 = 0; g4 < 4; ++g4)         // the lane's keys come in runs of four: two hashes per run (dropout.h)
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+          const unsigned hh = kDrop ? a.drop.pair_hash32(pairbase + static_cast<unsigned>((tile0 + kb * 32 + 8 * g4 + 4 * h) >> 1) + u, key2) : 0u;
+          keep[4 * g4 + 2 * u] = kDrop ? a.drop.lo(hh) : 1.0f;
+          keep[4 * g4 + 2 * u + 1] = kDrop ? a.drop.hi(hh) : 1.0f;
+        }
+#pragma unroll
+      for (int i = 0; i < 16; ++i) st[i] *= fmaf(dp[i], keep[i], -dlt);   // dS^T / scale (the softmax scale is applied once, when dQ is stored)
 #pragma unroll
       for (int s2 = 0; s2 < 2; ++s2) {
         TrFrag kt[4];
@@ -452,7 +466,9 @@ __global__ __launch_bounds__(kAttnThreads, 1) void attn_bwd_dkv_kernel(AttnArgs 
   const float sl2 = a.scale * kLog2e;
   const float* lse_b = a.lse + (static_cast<long>(b) * a.H + head) * a.Sq;
   const float* dl_b = a.delta + (static_cast<long>(b) * a.H + head) * a.Sq;
-  const unsigned headbase = static_cast<unsigned>((static_cast<uint64_t>(b) * a.H + head) * a.Sq * a.Sk) + static_cast<unsigned>(ki);
+  // pair index of (query q, this lane's key): headpair + q * (Sk2 / 2); the lane's half of the pair is ki & 1 (dropout.h)
+  const unsigned sk_pairs = static_cast<unsigned>((a.Sk + 1) >> 1);
+  const unsigned headpair = static_cast<unsigned>((static_cast<uint64_t>(b) * a.H + head) * a.Sq * sk_pairs) + static_cast<unsigned>(ki >> 1);
   const unsigned key2 = mix32(a.drop.key);
   const int k_end = blockIdx.x * 128 + 128;
   const bool key_mask = a.causal || k_end > klen || k_end > a.Sk;
@@ -529,7 +545,7 @@ __global__ __launch_bounds__(kAttnThreads, 1) void attn_bwd_dkv_kernel(AttnArgs 
         } else {
           p = __builtin_amdgcn_exp2f(fmaf(st[i], sl2, -lse4[i]));
         }
-        const float keep = kDrop ? a.drop.scale32(headbase + static_cast<unsigned>(qi) * static_cast<unsigned>(a.Sk), key2) : 1.0f;
+        const float keep = kDrop ? a.drop.pick(a.drop.pair_hash32(headpair + static_cast<unsigned>(qi) * sk_pairs, key2), static_cast<unsigned>(ki) & 1u) : 1.0f;
         st[i] = p * keep;                                    // dropped P (what multiplied V in the forward)
         dp[i] = p * fmaf(dp[i], keep, -dl4[i]);              // dS / scale (scale applied when dK is stored)
       }
@@ -594,16 +610,19 @@ __global__ __launch_bounds__(kDkv2Threads) void attn_bwd_dkv2_kernel(AttnArgs a)
   // dropout: the keep decisions depend on indices only, so the (mostly idle) acc-wave hashes them one block AHEAD of its
   // S-wave and hands over one byte per element (0 / 1; byte i of the lane's 16 = element i); the S-wave then spends one
   // v_cvt_f32_ubyte per element instead of the whole hash.  Block 0's flags are produced before the loop.
-  const unsigned headbase = static_cast<unsigned>((static_cast<uint64_t>(b) * a.H + head) * a.Sq * a.Sk) + static_cast<unsigned>(ki);
+  // pair index of (query q, this lane's key): headpair + q * (Sk2 / 2); the lane's half of the pair is ki & 1 (dropout.h)
+  const unsigned sk_pairs = static_cast<unsigned>((a.Sk + 1) >> 1);
+  const unsigned headpair = static_cast<unsigned>((static_cast<uint64_t>(b) * a.H + head) * a.Sq * sk_pairs) + static_cast<unsigned>(ki >> 1);
   const unsigned key2 = mix32(a.drop.key);
   auto keep_flags_of_block = [&](int jb) {
     unsigned w[4] = {0u, 0u, 0u, 0u};
-    unsigned vb = headbase + static_cast<unsigned>(jb * 32 + 4 * h) * static_cast<unsigned>(a.Sk);
+    unsigned vb = headpair + static_cast<unsigned>(jb * 32 + 4 * h) * sk_pairs;
     asm volatile("" : "+v"(vb));            // opaque: otherwise 16 loop-invariant index registers are kept alive instead of 16 scalars
+    const unsigned sh = (static_cast<unsigned>(ki) & 1u) * 16u;
 #pragma unroll
     for (int i = 0; i < 16; ++i) {
-      const unsigned idx = vb + static_cast<unsigned>((i & 3) + 8 * (i >> 2)) * static_cast<unsigned>(a.Sk);
-      w[i >> 2] |= (mix32(idx ^ key2) >= a.drop.thr ? 1u : 0u) << (8 * (i & 3));
+      const unsigned pr = vb + static_cast<unsigned>((i & 3) + 8 * (i >> 2)) * sk_pairs;
+      w[i >> 2] |= ((((mix32(pr ^ key2) >> sh) & 0xffffu) >= a.drop.thr) ? 1u : 0u) << (8 * (i & 3));
     }
     return u32x4{w[0], w[1], w[2], w[3]};
   };
@@ -872,8 +891,8 @@ static int check_desc(const adt_attn_desc* d, const char* who) {
   if (d->ldq < need || d->ldk < need || d->ldv < need || d->ldo < need || (d->ldq & 7) || (d->ldk & 7) || (d->ldv & 7) || (d->ldo & 7))
     return set_error(ADT_ESHAPE, "attention: row strides must cover heads*128 columns and be multiples of 8");
   if (static_cast<int64_t>(d->batch) * d->heads > 65535) return set_error(ADT_ESHAPE, "attention: batch*heads must be <= 65535");
-  if (d->drop.p > 0.f && static_cast<double>(d->batch) * d->heads * d->q_len * d->k_len >= 4294967296.0)
-    return set_error(ADT_ESHAPE, "attention: dropout needs batch*heads*q_len*k_len < 2^32");
+  if (d->drop.p > 0.f && static_cast<double>(d->batch) * d->heads * d->q_len * (d->k_len + 1) >= 4294967296.0)
+    return set_error(ADT_ESHAPE, "attention: dropout needs batch*heads*q_len*(k_len+1) < 2^32");
   (void)who;
   return ADT_OK;
 }

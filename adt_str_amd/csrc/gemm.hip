@@ -178,7 +178,7 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& g, f32x4 (&acc)[4]
           reinterpret_cast<unsigned short*>(ep.pre_act_out)[static_cast<long>(row) * ep.ld_pre_act + col] = f2bf(z);
         if (ep.act == 1) z = gelu_erf(ep.pre_act_out ? bf2f(f2bf(z)) : z);
         else if (ep.act == 2) z = fmaxf(z, 0.0f);
-        const float keep = kDrop ? g.drop.scale(static_cast<uint64_t>(row) * g.N + col) : 1.0f;
+        const float keep = kDrop ? g.drop.scale(static_cast<uint64_t>(row) * drop_ld(g.N) + col) : 1.0f;
         if (kDrop && !ep.drop_after_residual) z *= keep;
         if (ep.residual) {
           const long rr = ep.res_row_mod > 0 ? (row % ep.res_row_mod) : row;
@@ -304,10 +304,14 @@ __device__ __forceinline__ void epilogue_apply8(const GemmArgs& g, float (&z)[8]
   }
   float keep[8] = {1.f, 1.f, 1.f, 1.f, 1.f, 1.f, 1.f, 1.f};
   if (kDrop) {
-    const uint64_t base = static_cast<uint64_t>(row) * g.N + col;       // multiple of 8: the 8 elements share the index's high word
-    const uint32_t key2 = mix32(static_cast<uint32_t>(base >> 32) ^ g.drop.key), lo = static_cast<uint32_t>(base);
+    const uint64_t pair0 = (static_cast<uint64_t>(row) * g.N + col) >> 1;   // multiple of 4: the 4 pairs share the index's high word
+    const uint32_t key2 = mix32(static_cast<uint32_t>(pair0 >> 32) ^ g.drop.key), lo = static_cast<uint32_t>(pair0);
 #pragma unroll
-    for (int e = 0; e < 8; ++e) keep[e] = g.drop.scale32(lo + e, key2);
+    for (int e = 0; e < 4; ++e) {
+      const uint32_t hh = g.drop.pair_hash32(lo + e, key2);
+      keep[2 * e] = g.drop.lo(hh);
+      keep[2 * e + 1] = g.drop.hi(hh);
+    }
     if (!ep.drop_after_residual) {
 #pragma unroll
       for (int e = 0; e < 8; ++e) z[e] *= keep[e];

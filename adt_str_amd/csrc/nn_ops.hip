@@ -90,7 +90,7 @@ __global__ __launch_bounds__(kRowThreads) void layernorm_fwd_kernel(LnFwdArgs a)
     y.z = (v[i].z - mean) * rstd * g.z + b.z; y.w = (v[i].w - mean) * rstd * g.w + b.w;
     if (a.drop.on()) {
       const uint64_t e0 = static_cast<uint64_t>(row) * a.D + 4 * q;
-      y.x *= a.drop.scale(e0); y.y *= a.drop.scale(e0 + 1); y.z *= a.drop.scale(e0 + 2); y.w *= a.drop.scale(e0 + 3);
+      float k4[4]; a.drop.scale4(e0, k4); y.x *= k4[0]; y.y *= k4[1]; y.z *= k4[2]; y.w *= k4[3];
     }
     if (a.y32) reinterpret_cast<float4*>(a.y32 + static_cast<long>(row) * a.ldy)[q] = y;
     if (a.y16) {
@@ -132,7 +132,7 @@ __global__ __launch_bounds__(kRowThreads) void layernorm_fwd_narrow_kernel(LnFwd
   y.z = (v.z - mean) * rstd * g.z + b.z; y.w = (v.w - mean) * rstd * g.w + b.w;
   if (a.drop.on()) {
     const uint64_t e0 = static_cast<uint64_t>(row) * a.D + 4 * sub;
-    y.x *= a.drop.scale(e0); y.y *= a.drop.scale(e0 + 1); y.z *= a.drop.scale(e0 + 2); y.w *= a.drop.scale(e0 + 3);
+    float k4[4]; a.drop.scale4(e0, k4); y.x *= k4[0]; y.y *= k4[1]; y.z *= k4[2]; y.w *= k4[3];
   }
   if (a.y32) reinterpret_cast<float4*>(a.y32 + row * a.ldy)[sub] = y;
   if (a.y16) reinterpret_cast<ushort4*>(a.y16 + row * a.ldy)[sub] = make_ushort4(f2bf_(y.x), f2bf_(y.y), f2bf_(y.z), f2bf_(y.w));
@@ -191,7 +191,7 @@ __global__ __launch_bounds__(kRowThreads, 3) void layernorm_bwd_kernel(LnBwdArgs
       float4 dv = cdv[i];
       if (a.dy_drop.on()) {
         const uint64_t e0 = static_cast<uint64_t>(row) * a.D + 4 * q;
-        dv.x *= a.dy_drop.scale(e0); dv.y *= a.dy_drop.scale(e0 + 1); dv.z *= a.dy_drop.scale(e0 + 2); dv.w *= a.dy_drop.scale(e0 + 3);
+        float k4[4]; a.dy_drop.scale4(e0, k4); dv.x *= k4[0]; dv.y *= k4[1]; dv.z *= k4[2]; dv.w *= k4[3];
       }
       xh[i] = make_float4((xv.x - mean) * rstd, (xv.y - mean) * rstd, (xv.z - mean) * rstd, (xv.w - mean) * rstd);
       g[i] = make_float4(dv.x * gm.x, dv.y * gm.y, dv.z * gm.z, dv.w * gm.w);
@@ -211,7 +211,7 @@ __global__ __launch_bounds__(kRowThreads, 3) void layernorm_bwd_kernel(LnBwdArgs
       if (a.dx32) reinterpret_cast<float4*>(a.dx32 + static_cast<long>(row) * a.lddx)[q] = d;
       if (a.dx_drop.on()) {           // gradient of the dropped branch: bf16 dx and the bias gradient see the mask
         const uint64_t e0 = static_cast<uint64_t>(row) * a.D + 4 * q;
-        d.x *= a.dx_drop.scale(e0); d.y *= a.dx_drop.scale(e0 + 1); d.z *= a.dx_drop.scale(e0 + 2); d.w *= a.dx_drop.scale(e0 + 3);
+        float k4[4]; a.dx_drop.scale4(e0, k4); d.x *= k4[0]; d.y *= k4[1]; d.z *= k4[2]; d.w *= k4[3];
       }
       px[i].x += d.x; px[i].y += d.y; px[i].z += d.z; px[i].w += d.w;
       if (a.dx16) reinterpret_cast<ushort4*>(a.dx16 + static_cast<long>(row) * a.lddx)[q] =
@@ -313,7 +313,7 @@ __global__ __launch_bounds__(kRowThreads) void embed_pe_fwd_kernel(EmbedArgs a) 
     float4 y = make_float4(ev.x * a.scale + pv.x, ev.y * a.scale + pv.y, ev.z * a.scale + pv.z, ev.w * a.scale + pv.w);
     if (a.drop.on()) {
       const uint64_t e0 = static_cast<uint64_t>(row) * a.D + 4 * q;
-      y.x *= a.drop.scale(e0); y.y *= a.drop.scale(e0 + 1); y.z *= a.drop.scale(e0 + 2); y.w *= a.drop.scale(e0 + 3);
+      float k4[4]; a.drop.scale4(e0, k4); y.x *= k4[0]; y.y *= k4[1]; y.z *= k4[2]; y.w *= k4[3];
     }
     if (a.y32) reinterpret_cast<float4*>(a.y32 + static_cast<long>(row) * a.D)[q] = y;
     if (a.y16) reinterpret_cast<ushort4*>(a.y16 + static_cast<long>(row) * a.D)[q] =
@@ -329,7 +329,7 @@ __global__ __launch_bounds__(kRowThreads) void embed_bwd_kernel(const long* __re
   long tok = tokens[row];
   tok = tok < 0 ? 0 : (tok >= vocab ? vocab - 1 : tok);
   for (int c = lane; c < D; c += 64) {
-    const float keep = drop.on() ? drop.scale(static_cast<uint64_t>(row) * D + c) : 1.0f;
+    const float keep = drop.on() ? drop.scale(static_cast<uint64_t>(row) * drop_ld(D) + c) : 1.0f;
     atomicAdd(dtable + tok * D + c, scale * keep * dy[static_cast<long>(row) * D + c]);
   }
 }

@@ -14,13 +14,19 @@ def mix32(x: np.ndarray) -> np.ndarray:
 
 
 def scale(shape, p: float, key: int) -> torch.Tensor:
-    """mask / (1 - p) for a contiguous tensor of ``shape`` whose element index is its flat offset."""
-    n = int(np.prod(shape))
-    idx = np.arange(n, dtype=np.uint64)
+    """mask / (1 - p) for a tensor of ``shape``: element index = row * L2 + col (rows = leading dimensions flattened, L2 = last
+    dimension rounded up to even); two neighbouring elements take the 16-bit halves of one hash (dropout.h)."""
+    shape = tuple(int(s) for s in shape)
+    L = shape[-1]
+    rows = int(np.prod(shape[:-1])) if len(shape) > 1 else 1
+    L2 = L + (L & 1)
+    idx = (np.arange(rows, dtype=np.uint64)[:, None] * np.uint64(L2) + np.arange(L, dtype=np.uint64)[None, :]).reshape(-1)
+    pair = idx >> np.uint64(1)
     with np.errstate(over="ignore"):
-        inner = mix32((idx >> np.uint64(32)).astype(np.uint32) ^ np.uint32(key))
-        h = mix32(idx.astype(np.uint32) ^ inner)
+        inner = mix32((pair >> np.uint64(32)).astype(np.uint32) ^ np.uint32(key))
+        h = mix32(pair.astype(np.uint32) ^ inner)
+    half = np.where((idx & np.uint64(1)).astype(bool), h >> np.uint32(16), h & np.uint32(0xFFFF))
     pp = min(p, 0.999999)
-    thr = np.uint32(int(pp * 4294967296.0))
-    keep = (h >= thr).astype(np.float32) * np.float32(1.0 / (1.0 - pp))
+    thr = min(65535, max(1, int(pp * 65536.0 + 0.5)))
+    keep = (half >= np.uint32(thr)).astype(np.float32) * np.float32(1.0 / (1.0 - pp))
     return torch.from_numpy(keep.reshape(shape))
