@@ -33,8 +33,9 @@ extern "C" {
 #define ADT_ESHAPE  -2   /* shape the kernels do not support                  */
 #define ADT_EHIP    -3   /* HIP runtime error (launch failed, no device ...)  */
 
-/* Dropout site: element idx is kept iff hash(idx, key) >= p * 2^32 and then scaled by 1/(1-p)
- * (adt_str_amd/csrc/dropout.h).  Replaces nn.Dropout / the SDPA dropout of the reference
+/* Dropout site: element (row, col) of a tensor with last dimension L has index row * even(L) + col; elements 2m and 2m + 1
+ * share hash(m, key) and each is kept iff its 16-bit half >= round(p * 65536), then scaled by 1/(1-p)
+ * (adt_str_amd/csrc/dropout.h; oracle/dropout.py mirrors it).  Replaces nn.Dropout / the SDPA dropout of the reference
  * (model.py:116,132,134,156,172 and inside nn.Transformer*Layer); masks are never stored, the
  * backward entry points regenerate them from the same (p, key).  p == 0 or a null pointer: off. */
 typedef struct adt_dropout { float p; uint32_t key; } adt_dropout;
