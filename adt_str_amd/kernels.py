@@ -35,8 +35,9 @@ def _drop_ptr(d):
 
 
 def _workspace(nbytes: int, device) -> torch.Tensor:
-    """Grow-only scratch buffer per device (never freed: stream-ordered reuse)."""
-    key = str(device)
+    """Grow-only scratch buffer per (device, stream) (never freed: stream-ordered reuse; kernels on different streams
+    may be in flight at the same time, so they must not share one)."""
+    key = (str(device), _ffi.current_stream() if torch.device(device).type == "cuda" else 0)
     buf = _ws_cache.get(key)
     if buf is None or buf.numel() < nbytes:
         buf = torch.empty(max(nbytes, 1 << 20), dtype=torch.uint8, device=device)
