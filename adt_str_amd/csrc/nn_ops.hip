@@ -320,6 +320,31 @@ __global__ __launch_bounds__(kRowThreads) void embed_pe_fwd_kernel(EmbedArgs a) 
         make_ushort4(f2bf_(y.x), f2bf_(y.y), f2bf_(y.z), f2bf_(y.w));
   }
 }
+// Operands of the embedding gradient as a TN GEMM, dtable = onehot^T . dy16 (fixed summation order, MFMA rate): one wave writes
+// row r of the one-hot matrix [n_rows, vocab] (bf16 1.0 at the row's token) and of dy16 = bf16(scale * keep * dy).
+__global__ __launch_bounds__(kRowThreads) void embed_bwd_operands_kernel(const long* __restrict__ tokens, const float* __restrict__ dy, float scale,
+                                                                         unsigned short* __restrict__ onehot, long ld_oh,
+                                                                         unsigned short* __restrict__ dy16, int n_rows, int D, int vocab, Drop drop) {
+  const int lane = threadIdx.x & 63;
+  const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= n_rows) return;
+  long tok = tokens[row];
+  tok = tok < 0 ? 0 : (tok >= vocab ? vocab - 1 : tok);
+  uint4* oh = reinterpret_cast<uint4*>(onehot + static_cast<long>(row) * ld_oh);
+  const int hot = static_cast<int>(tok >> 3), pos = static_cast<int>(tok & 7);
+  for (int q = lane; q < (vocab >> 3); q += 64) {
+    unsigned w[4] = {0u, 0u, 0u, 0u};
+    if (q == hot) w[pos >> 1] = 0x3f80u << (16 * (pos & 1));
+    oh[q] = make_uint4(w[0], w[1], w[2], w[3]);
+  }
+  for (int q = lane; q < (D >> 2); q += 64) {
+    float4 v = reinterpret_cast<const float4*>(dy + static_cast<long>(row) * D)[q];
+    float k4[4] = {1.f, 1.f, 1.f, 1.f};
+    if (drop.on()) drop.scale4(static_cast<uint64_t>(row) * D + 4 * q, k4);
+    reinterpret_cast<ushort4*>(dy16 + static_cast<long>(row) * D)[q] =
+        make_ushort4(f2bf_(scale * k4[0] * v.x), f2bf_(scale * k4[1] * v.y), f2bf_(scale * k4[2] * v.z), f2bf_(scale * k4[3] * v.w));
+  }
+}
 // dtable[token] += scale * dy[row]   (float atomics: tokens repeat inside a batch)
 __global__ __launch_bounds__(kRowThreads) void embed_bwd_kernel(const long* __restrict__ tokens, const float* __restrict__ dy,
                                                                 float scale, float* __restrict__ dtable, int n_rows, int D, int vocab, Drop drop) {
@@ -613,6 +638,21 @@ extern "C" int adt_embed_bwd(const int64_t* tokens, const float* dy, float scale
   if (n_rows == 0) return ADT_OK;
   hipLaunchKernelGGL(embed_bwd_kernel, dim3(static_cast<unsigned>((n_rows + 3) / 4)), dim3(kRowThreads), 0, ST(stream),
                      reinterpret_cast<const long*>(tokens), dy, scale, dtable, static_cast<int>(n_rows), static_cast<int>(D), static_cast<int>(vocab),
+                     drop ? make_drop(drop->p, drop->key) : Drop{0u, 0u, 1.0f});
+  ADT_HIP_TRY(hipGetLastError());
+  return ADT_OK;
+}
+
+extern "C" int adt_embed_bwd_operands(const int64_t* tokens, const float* dy, float scale, void* onehot, int64_t ld_onehot, void* dy16,
+                                      int64_t n_rows, int64_t D, int64_t vocab, const adt_dropout* drop, void* stream) {
+  if (!tokens || !dy || !onehot || !dy16) return set_error(ADT_EINVAL, "adt_embed_bwd_operands: null pointer");
+  if (D <= 0 || (D & 3) || vocab <= 0 || (vocab & 7) || ld_onehot < vocab || (ld_onehot & 7) || n_rows < 0 || !aligned16(onehot) || !aligned16(dy) ||
+      !aligned16(dy16))
+    return set_error(ADT_ESHAPE, "adt_embed_bwd_operands: D % 4, vocab % 8, ld_onehot % 8 must be 0, buffers 16-byte aligned");
+  if (n_rows == 0) return ADT_OK;
+  hipLaunchKernelGGL(embed_bwd_operands_kernel, dim3(static_cast<unsigned>((n_rows + 3) / 4)), dim3(kRowThreads), 0, ST(stream),
+                     reinterpret_cast<const long*>(tokens), dy, scale, static_cast<unsigned short*>(onehot), ld_onehot,
+                     static_cast<unsigned short*>(dy16), static_cast<int>(n_rows), static_cast<int>(D), static_cast<int>(vocab),
                      drop ? make_drop(drop->p, drop->key) : Drop{0u, 0u, 1.0f});
   ADT_HIP_TRY(hipGetLastError());
   return ADT_OK;

@@ -160,11 +160,22 @@ def embed_pe_fwd(tokens, table, pe, scale, want32=True, want16=True, drop=None):
 
 
 def embed_bwd(tokens, dy, scale, dtable, drop=None):
+    """dtable[v] = scale * sum of the (dropped) rows of dy whose token is v; dtable is overwritten.  The sum runs as a TN GEMM
+    of a one-hot matrix with the bf16 gradient rows (fixed order, like every other weight gradient); vocabularies or widths
+    that are not multiples of 8 take the fp32-atomics kernel."""
     n, D = dy.shape
-    assert dy.dtype == torch.float32 and dy.is_contiguous() and dtable.dtype == torch.float32
+    V = dtable.shape[0]
+    assert dy.dtype == torch.float32 and dy.is_contiguous() and dtable.dtype == torch.float32 and dtable.is_contiguous()
     _keep, dp = _drop_ptr(drop)
-    _ffi.call("adt_embed_bwd", _ffi.dptr(tokens), _ffi.dptr(dy), scale, _ffi.dptr(dtable), n, D, dtable.shape[0], dp,
-              _ffi.current_stream())
+    if n > 0 and V % 8 == 0 and D % 8 == 0:
+        onehot = torch.empty((n, V), dtype=torch.bfloat16, device=dy.device)
+        dy16 = torch.empty((n, D), dtype=torch.bfloat16, device=dy.device)
+        _ffi.call("adt_embed_bwd_operands", _ffi.dptr(tokens), _ffi.dptr(dy), scale, _ffi.dptr(onehot), V, _ffi.dptr(dy16), n, D, V, dp,
+                  _ffi.current_stream())
+        gemm(onehot, dy16, trans=True, out=dtable)
+        return
+    dtable.zero_()
+    _ffi.call("adt_embed_bwd", _ffi.dptr(tokens), _ffi.dptr(dy), scale, _ffi.dptr(dtable), n, D, V, dp, _ffi.current_stream())
 
 
 def cross_entropy(logits, labels, ignore_index=1, want_grad=True):

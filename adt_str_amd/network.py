@@ -358,9 +358,7 @@ class _Engine:
             K.gemm(dqkv, s["x16"], trans=True, out=G[p + ".self_attn.in_proj_weight"])
             K.colsum(dqkv, out=G[p + ".self_attn.in_proj_bias"])
             dx32 = K.gemm(dqkv, L["sa"].wt16, residual=dy1_32, out_dtype=F32)
-        gemb = G["decoder.tgt_tok_emb.embedding.weight"]
-        gemb.zero_()
-        K.embed_bwd(tgt, dx32, math.sqrt(d), gemb, drop=self.D("dec.emb"))
+        K.embed_bwd(tgt, dx32, math.sqrt(d), G["decoder.tgt_tok_emb.embedding.weight"], drop=self.D("dec.emb"))
         self._ready("decoder.")
         # encoder
         fin = enc_save[-1]

@@ -40,7 +40,7 @@ extern "C" {
  * backward entry points regenerate them from the same (p, key).  p == 0 or a null pointer: off. */
 typedef struct adt_dropout { float p; uint32_t key; } adt_dropout;
 
-/* ABI version (4): bumped whenever a signature below changes or entries are added. */
+/* ABI version (5): bumped whenever a signature below changes or entries are added. */
 int adt_version(void);
 
 /* Message of the last failing call on this thread ("" if none). */
@@ -260,12 +260,17 @@ int adt_colsum_bf16(const void* x, int64_t ld, int64_t M, int64_t N, float* out,
  * (reference model.py:42-65) as used by Decoder.forward (:171).
  *   fwd: y[row] = table[tokens[row]] * scale + pe[row % T]   (rows = B*T, row-major)
  *   bwd: dtable[tokens[row]] += scale * dy[row]              (dtable pre-zeroed by the caller)
- *        (fp32 atomic adds: the one reduction on the path whose summation order is not fixed from run to run)
+ *        adt_embed_bwd does it with fp32 atomic adds (summation order not fixed from run to run; any vocab / D).
+ *        adt_embed_bwd_operands instead writes the two bf16 operands of dtable = onehot^T . dy16 -- onehot [n_rows, vocab]
+ *        (1.0 at the row's token) and dy16 = bf16(scale * keep * dy) -- for adt_gemm_bf16(trans = 1, M = vocab, N = D,
+ *        K = n_rows): fixed summation order and MFMA rate, the form the training step uses (vocab % 8 == 0, D % 8 == 0).
  */
 int adt_embed_pe_fwd(const int64_t* tokens, const float* table, const float* pe, float scale, float* y32, void* y16,
                      int64_t n_rows, int64_t T, int64_t D, int64_t vocab, const adt_dropout* drop, void* stream);
 int adt_embed_bwd(const int64_t* tokens, const float* dy, float scale, float* dtable, int64_t n_rows, int64_t D,
                   int64_t vocab, const adt_dropout* drop, void* stream);
+int adt_embed_bwd_operands(const int64_t* tokens, const float* dy, float scale, void* onehot, int64_t ld_onehot, void* dy16,
+                           int64_t n_rows, int64_t D, int64_t vocab, const adt_dropout* drop, void* stream);
 
 /* ---------------------------------------------------------------------------
  * K8  cross-entropy forward + backward

@@ -88,8 +88,8 @@ def test_embedding_dropout():
     dy = rnd((B * T, D), 2)
     dtab = torch.zeros_like(table)
     k.embed_bwd(tokens, dy, math.sqrt(D), dtab, drop=site)
-    ref_d = torch.zeros_like(table).index_add_(0, tokens.reshape(-1), dy * sc * math.sqrt(D))
-    assert (dtab - ref_d).abs().max() < 1e-4 * ref_d.abs().max()
+    ref_d = torch.zeros_like(table, dtype=torch.float64).index_add_(0, tokens.reshape(-1), (dy * sc * math.sqrt(D)).bfloat16().double())
+    assert (dtab.double() - ref_d).abs().max() < 1e-5 * ref_d.abs().max()      # bf16 gradient rows, summed on the TN GEMM
 
 
 @pytest.mark.parametrize("B,H,Sq,Sk,causal", [(2, 2, 128, 128, False), (2, 3, 77, 150, False), (2, 2, 96, 96, True), (1, 2, 300, 200, False), (1, 1, 449, 70, True)])
@@ -154,6 +154,11 @@ def test_network_with_dropout_matches_oracle_with_same_masks():
         rg = st[name].grad
         rel = (g.cpu() - rg).abs().max().item() / (rg.abs().max().item() + 1e-12)
         assert rel < 6e-2, f"{name}: grad rel err {rel}"
+    # the same step again (same masks): every reduction on the path has a fixed order, so loss and gradients repeat bit for bit
+    g1, loss1 = eng.gflat.clone(), out["loss"].clone()
+    eng.drop_seed = seed - 1
+    again = eng.loss_and_grads(torch.from_numpy(batch["wavs"]).to(DEV), tok[:, :-1], pad, tok[:, 1:], want_grads=True)
+    assert eng.drop_seed == seed and torch.equal(again["loss"], loss1) and torch.equal(eng.gflat, g1)
     # a second step draws new masks; eval mode has none
     out2 = eng.loss_and_grads(torch.from_numpy(batch["wavs"]).to(DEV), tok[:, :-1], pad, tok[:, 1:], want_grads=False)
     assert eng.drop_seed == seed + 1 and abs(out2["loss"].item() - out["loss"].item()) > 1e-6
