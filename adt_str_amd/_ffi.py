@@ -14,7 +14,7 @@ _LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "libadt_hip
 _lock = threading.Lock()
 _lib = None
 
-ABI_VERSION = 5
+ABI_VERSION = 6
 
 i32, i64, f32, ptr = C.c_int32, C.c_int64, C.c_float, C.c_void_p
 
@@ -37,7 +37,8 @@ class AttnDesc(C.Structure):
     _fields_ = [("batch", C.c_int32), ("heads", C.c_int32), ("q_len", C.c_int32), ("k_len", C.c_int32),
                 ("head_dim", C.c_int32), ("causal", C.c_int32), ("ldq", C.c_int64), ("ldk", C.c_int64),
                 ("ldv", C.c_int64), ("ldo", C.c_int64), ("scale", C.c_float), ("mask_value", C.c_float),
-                ("key_len", C.c_void_p), ("drop", Dropout)]
+                ("key_len", C.c_void_p), ("drop", Dropout), ("dq_colsum", C.c_void_p), ("dk_colsum", C.c_void_p),
+                ("dv_colsum", C.c_void_p)]
 
 
 class AffWeights(C.Structure):

@@ -187,6 +187,30 @@ __device__ __forceinline__ void store_transposed(const f32x16 (&acc)[4], float m
     }
 }
 
+// Sum over the 32 lanes of each half-wave on the DPP network (row_shr 1/2/4/8, then row_bcast:15): lanes 31 and 63 hold the sums.
+template <int kCtrl, int kRowMask>
+__device__ __forceinline__ float dpp_add(float v) {
+  return v + __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), kCtrl, kRowMask, 0xf, false));
+}
+__device__ __forceinline__ float half_wave_sum(float v) {
+  v = dpp_add<0x111, 0xf>(v); v = dpp_add<0x112, 0xf>(v); v = dpp_add<0x114, 0xf>(v); v = dpp_add<0x118, 0xf>(v);
+  return dpp_add<0x142, 0xa>(v);
+}
+// Column sums of a transposed accumulator as store_transposed writes it (bf16-rounded acc * mul; rows >= n_rows count as 0)
+// over this wave's 32 rows: lane 31 / 63 leaves them in red[32 db + 8 g + 4 h + e].  The bias gradient of the in-projection
+// is the column sum of dQ | dK | dV; taking it here saves a pass over those matrices.
+__device__ __forceinline__ void colsum_transposed(const f32x16 (&acc)[4], float mul, bool row_ok, int lane, float* __restrict__ red) {
+  const int h = lane >> 5;
+#pragma unroll
+  for (int db = 0; db < 4; ++db)
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+      float v = row_ok ? __uint_as_float(static_cast<unsigned>(__builtin_bit_cast(unsigned short, static_cast<__bf16>(acc[db][i] * mul))) << 16) : 0.f;
+      v = half_wave_sum(v);
+      if ((lane & 31) == 31) red[32 * db + 8 * (i >> 2) + 4 * h + (i & 3)] = v;
+    }
+}
+
 struct AttnArgs {
   const unsigned short *q, *k, *v, *o, *dout;
   unsigned short *out, *dq, *dk, *dv;
@@ -195,6 +219,7 @@ struct AttnArgs {
   int B, H, Sq, Sk;
   float scale, mask_value; int causal; const int* key_len;
   Drop drop;
+  float* cs_dq;        // column sums of dQ per (batch, 128-query block): [B * ceil(Sq/128)][H*128], null: off
 };
 
 // additive mask of the reference (model.py:173-181): causal and key-padding contributions add up
@@ -447,6 +472,14 @@ __global__ __launch_bounds__(kAttnThreads, 2) void attn_bwd_dq_kernel(AttnArgs a
     dma_wait_and_sync();
   }
   store_transposed(dq, a.scale, a.dq + static_cast<long>(b) * a.Sq * a.ldq + head * kDh, a.ldq, qi, a.Sq, lane);
+  if (a.cs_dq) {                                            // block-uniform
+    float* red = reinterpret_cast<float*>(smem);            // [4 waves][128]; the tiles are dead after the loop's last barrier
+    colsum_transposed(dq, a.scale, qi < a.Sq, lane, red + wave * kDh);
+    __syncthreads();
+    if (tid < kDh)
+      a.cs_dq[(static_cast<long>(b) * gridDim.x + blockIdx.x) * (a.H * kDh) + head * kDh + tid] =
+          (red[tid] + red[kDh + tid]) + (red[2 * kDh + tid] + red[3 * kDh + tid]);
+  }
 }
 
 // =============================================================================== backward: dK, dV  (lane <-> key)
@@ -902,6 +935,7 @@ static AttnArgs make_args(const adt_attn_desc* d) {
   a.B = d->batch; a.H = d->heads; a.Sq = d->q_len; a.Sk = d->k_len;
   a.scale = d->scale; a.mask_value = d->mask_value; a.causal = d->causal; a.key_len = d->key_len;
   a.drop = make_drop(d->drop.p, d->drop.key);
+  a.cs_dq = nullptr;
   return a;
 }
 static int set_lds_once() {      // raise the dynamic-LDS limit of the three kernels once per device and thread
@@ -944,9 +978,14 @@ extern "C" int adt_attn_fwd(const adt_attn_desc* d, const void* q, const void* k
   return ADT_OK;
 }
 
+static size_t delta_floats(const adt_attn_desc* d) { return (static_cast<size_t>(d->batch) * d->heads * d->q_len + 4 + 3) & ~static_cast<size_t>(3); }
 extern "C" size_t adt_attn_bwd_workspace_bytes(const adt_attn_desc* d) {
   if (!d || d->batch <= 0 || d->heads <= 0 || d->q_len <= 0) return 16;
-  return static_cast<size_t>(d->batch) * d->heads * d->q_len * 4 + 16;
+  size_t bytes = delta_floats(d) * 4;
+  if (d->dq_colsum || d->dk_colsum || d->dv_colsum)        // dQ partial sums per (batch, 128-query block) + the dV column-sum scratch
+    bytes += static_cast<size_t>(d->batch) * d->heads * kDh * ((d->q_len + 127) / 128) * 4 +
+             adt_colsum_workspace_bytes(static_cast<int64_t>(d->batch) * d->k_len, static_cast<int64_t>(d->heads) * kDh);
+  return bytes;
 }
 
 extern "C" int adt_attn_bwd(const adt_attn_desc* d, const void* q, const void* k, const void* v, const void* o, const void* dout,
@@ -961,10 +1000,15 @@ extern "C" int adt_attn_bwd(const adt_attn_desc* d, const void* q, const void* k
   a.o = static_cast<const unsigned short*>(o); a.dout = static_cast<const unsigned short*>(dout);
   a.lse = const_cast<float*>(lse); a.delta = static_cast<const float*>(ws);
   a.dq = static_cast<unsigned short*>(dq); a.dk = static_cast<unsigned short*>(dk); a.dv = static_cast<unsigned short*>(dv);
+  const bool want_cs = d->dq_colsum || d->dk_colsum || d->dv_colsum;
+  if (want_cs && !(d->dq_colsum && d->dk_colsum && d->dv_colsum)) return set_error(ADT_EINVAL, "adt_attn_bwd: give all three column-sum outputs or none");
+  const int nqb = (d->q_len + 127) / 128, hd = d->heads * kDh;
+  if (want_cs) a.cs_dq = static_cast<float*>(ws) + delta_floats(d);
   const int lds_dq = 4 * kAttnTileBytes, lds_dkv = 2 * (2 * kAttnTileBytes + 512);
   if (int rc = set_lds_once()) return rc;
   const dim3 gq((d->q_len + 127) / 128, d->batch * d->heads), gk((d->k_len + 127) / 128, d->batch * d->heads);
-  static const int dkv_variant = [] { const char* v = getenv("ADT_ATTN_DKV"); return v ? atoi(v) : 2; }();   // 1: single-wave kernel (A/B arm)
+  static const int dkv_env = [] { const char* v = getenv("ADT_ATTN_DKV"); return v ? atoi(v) : 2; }();   // 1: single-wave kernel (A/B arm)
+  const int dkv_variant = want_cs ? 2 : dkv_env;             // the column sums live in the producer / consumer kernel only
   if (a.drop.on()) {
     hipLaunchKernelGGL(attn_bwd_dq_kernel<true>, gq, dim3(kAttnThreads), lds_dq, st, a);
     if (dkv_variant == 1) hipLaunchKernelGGL(attn_bwd_dkv_kernel<true>, gk, dim3(kAttnThreads), lds_dkv, st, a);
@@ -973,6 +1017,17 @@ extern "C" int adt_attn_bwd(const adt_attn_desc* d, const void* q, const void* k
     hipLaunchKernelGGL(attn_bwd_dq_kernel<false>, gq, dim3(kAttnThreads), lds_dq, st, a);
     if (dkv_variant == 1) hipLaunchKernelGGL(attn_bwd_dkv_kernel<false>, gk, dim3(kAttnThreads), lds_dkv, st, a);
     else hipLaunchKernelGGL(attn_bwd_dkv2_kernel<false>, gk, dim3(kDkv2Threads), kDkv2Lds, st, a);
+  }
+  if (want_cs) {
+    // dQ: partial sums out of the dQ kernel's epilogue.  dK: every row of dS sums to zero (softmax), so the column sums of
+    // dK = dS^T Q vanish identically -- the key bias does not change the attention output; what a sum over the stored dK would
+    // return is rounding noise.  dV: a pass over the dV columns (taking it in the dK/dV kernel's epilogue costs more than that
+    // pass: its one workgroup per CU has nothing to hide the cross-lane sums under).
+    launch_reduce_partials(a.cs_dq, d->batch * nqb, hd, d->dq_colsum, st);
+    ADT_HIP_TRY(hipMemsetAsync(d->dk_colsum, 0, static_cast<size_t>(hd) * 4, st));
+    float* cws = a.cs_dq + static_cast<size_t>(d->batch) * nqb * hd;
+    const int64_t rows = static_cast<int64_t>(d->batch) * d->k_len;
+    if (int rc = adt_colsum_bf16(dv, d->ldv, rows, hd, d->dv_colsum, cws, adt_colsum_workspace_bytes(rows, hd), stream)) return rc;
   }
   ADT_HIP_TRY(hipGetLastError());
   return ADT_OK;

@@ -272,11 +272,18 @@ def attn_fwd(q, k, v, B, H, Sq, Sk, scale, causal=False, key_len=None, mask_valu
     return out, lse
 
 
-def attn_bwd(q, k, v, o, dout, lse, dq, dk, dv, B, H, Sq, Sk, scale, causal=False, key_len=None, mask_value=-1e4, drop=None):
-    """Writes dq/dk/dv (bf16 views with the strides of q/k/v)."""
+def attn_bwd(q, k, v, o, dout, lse, dq, dk, dv, B, H, Sq, Sk, scale, causal=False, key_len=None, mask_value=-1e4, drop=None,
+             bias_grad=None):
+    """Writes dq/dk/dv (bf16 views with the strides of q/k/v).  ``bias_grad`` (fp32 [3 * H * 128], contiguous): also receives the
+    column sums of dq | dk | dv, i.e. the gradient of the in-projection bias."""
     assert dq.stride(0) == q.stride(0) and dk.stride(0) == k.stride(0) and dv.stride(0) == v.stride(0)
     assert dout.stride(0) == o.stride(0)
     d = _attn_desc(B, H, Sq, Sk, q, k, v, o, scale, causal, key_len, mask_value, drop)
+    if bias_grad is not None:
+        hd = H * 128
+        assert bias_grad.dtype == torch.float32 and bias_grad.is_contiguous() and bias_grad.numel() == 3 * hd
+        base = _ffi.dptr(bias_grad)
+        d.dq_colsum, d.dk_colsum, d.dv_colsum = base, base + 4 * hd, base + 8 * hd
     nb = _ffi.load().adt_attn_bwd_workspace_bytes(C.byref(d))
     ws = _workspace(nb, q.device)
     _ffi.call("adt_attn_bwd", C.byref(d), _ffi.dptr(q), _ffi.dptr(k), _ffi.dptr(v), _ffi.dptr(o), _ffi.dptr(dout),

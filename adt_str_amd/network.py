@@ -334,13 +334,11 @@ class _Engine:
             K.gemm(dy2_16, s["ca"], trans=True, out=G[p + ".multihead_attn.out_proj.weight"])
             dqc = torch.empty_like(s["qc"])
             dkvc = torch.empty_like(s["kvc"])
-            K.attn_bwd(s["qc"], s["kvc"][:, :d], s["kvc"][:, d:], s["ca"], dca, s["lse_c"], dqc, dkvc[:, :d], dkvc[:, d:], B, H, T, S,
-                       self.scale, drop=self.D(p + ".cattn"))
             gw, gb = G[p + ".multihead_attn.in_proj_weight"], G[p + ".multihead_attn.in_proj_bias"]
+            K.attn_bwd(s["qc"], s["kvc"][:, :d], s["kvc"][:, d:], s["ca"], dca, s["lse_c"], dqc, dkvc[:, :d], dkvc[:, d:], B, H, T, S,
+                       self.scale, drop=self.D(p + ".cattn"), bias_grad=gb)
             K.gemm(dqc, s["x1_16"], trans=True, out=gw[:d])
             K.gemm(dkvc, mem16, trans=True, out=gw[d:])
-            K.colsum(dqc, out=gb[:d])
-            K.colsum(dkvc, out=gb[d:])
             cat = L["ca"].wt16                                              # [d, 3d]
             if dmem32 is None:
                 dmem32 = K.gemm(dkvc, cat[:, d:], out_dtype=F32)
@@ -354,9 +352,9 @@ class _Engine:
             dqkv = torch.empty_like(s["qkv"])
             q = s["qkv"]
             K.attn_bwd(q[:, :d], q[:, d:2 * d], q[:, 2 * d:], s["sa"], dsa, s["lse_s"], dqkv[:, :d], dqkv[:, d:2 * d], dqkv[:, 2 * d:],
-                       B, H, T, T, self.scale, causal=True, key_len=key_len, drop=self.D(p + ".sattn"))
+                       B, H, T, T, self.scale, causal=True, key_len=key_len, drop=self.D(p + ".sattn"),
+                       bias_grad=G[p + ".self_attn.in_proj_bias"])
             K.gemm(dqkv, s["x16"], trans=True, out=G[p + ".self_attn.in_proj_weight"])
-            K.colsum(dqkv, out=G[p + ".self_attn.in_proj_bias"])
             dx32 = K.gemm(dqkv, L["sa"].wt16, residual=dy1_32, out_dtype=F32)
         K.embed_bwd(tgt, dx32, math.sqrt(d), G["decoder.tgt_tok_emb.embedding.weight"], drop=self.D("dec.emb"))
         self._ready("decoder.")
@@ -382,9 +380,8 @@ class _Engine:
             dqkv = torch.empty_like(s["qkv"])
             q = s["qkv"]
             K.attn_bwd(q[:, :d], q[:, d:2 * d], q[:, 2 * d:], s["attn"], dattn, s["lse"], dqkv[:, :d], dqkv[:, d:2 * d], dqkv[:, 2 * d:],
-                       B, H, S, S, self.scale, drop=self.D(p + ".attn"))
+                       B, H, S, S, self.scale, drop=self.D(p + ".attn"), bias_grad=G[p + ".self_attn.in_proj_bias"])
             K.gemm(dqkv, s["x16"], trans=True, out=G[p + ".self_attn.in_proj_weight"])
-            K.colsum(dqkv, out=G[p + ".self_attn.in_proj_bias"])
             if li == 0:
                 dx16 = torch.empty((dqkv.shape[0], d), dtype=BF16, device=dqkv.device)
             dx32 = K.gemm(dqkv, L["sa"].wt16, residual=dy1_32, out_dtype=F32, aux_bf16_out=dx16 if li == 0 else None,

@@ -40,7 +40,7 @@ extern "C" {
  * backward entry points regenerate them from the same (p, key).  p == 0 or a null pointer: off. */
 typedef struct adt_dropout { float p; uint32_t key; } adt_dropout;
 
-/* ABI version (5): bumped whenever a signature below changes or entries are added. */
+/* ABI version (6): bumped whenever a signature below changes or entries are added. */
 int adt_version(void);
 
 /* Message of the last failing call on this thread ("" if none). */
@@ -216,7 +216,11 @@ typedef struct adt_attn_desc {
   float   scale;
   float   mask_value;
   const int32_t* key_len;
-  adt_dropout drop;       /* dropout on the attention probabilities; element index ((b*heads+h)*q_len+q)*k_len+k */
+  adt_dropout drop;       /* dropout on the attention probabilities; row = (b*heads+h)*q_len+q, col = k (see adt_dropout) */
+  /* backward only, all three or none (may be null): fp32 [heads*128] bias gradient of the in-projection = column sums of
+   * dq (taken in the dQ kernel's epilogue, fixed order), dk (identically zero: the rows of dS sum to zero, so exact zeros are
+   * written instead of the rounding noise a sum over the stored dk would give) and dv (one pass over its columns) */
+  float* dq_colsum; float* dk_colsum; float* dv_colsum;
 } adt_attn_desc;
 
 int adt_attn_fwd(const adt_attn_desc* d, const void* q, const void* k, const void* v, void* o, float* lse, void* stream);

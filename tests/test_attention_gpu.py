@@ -74,6 +74,22 @@ def test_forward_and_backward(B, H, Sq, Sk, causal, padded):
     for name, got, ref in (("dq", dq, qr.grad), ("dk", dk, kr.grad), ("dv", dv, vr.grad)):
         err = (got.float() - ref).abs().max().item()
         assert err <= 4e-2 * ref.abs().max().item() + 1e-6, f"{name}: {err} vs max {ref.abs().max().item()}"
+    # the in-projection's bias gradient = column sums of dq | dk | dv as stored, taken in the kernels' epilogues
+    bg = torch.full((3 * d,), float("nan"), device=DEV)
+    dq2, dk2, dv2 = torch.zeros_like(dq), torch.zeros_like(dk), torch.zeros_like(dv)
+    if Sq == Sk:
+        buf = torch.zeros_like(qkv_q)
+        dq2, dk2, dv2 = buf[:, :d], buf[:, d:2 * d], buf[:, 2 * d:]
+    else:
+        bq, bk = torch.zeros_like(qkv_q), torch.zeros_like(qkv_k)
+        dq2, dk2, dv2 = bq[:, :d], bk[:, d:2 * d], bk[:, 2 * d:]
+    k.attn_bwd(q, kk, v, o, dout, lse, dq2, dk2, dv2, B, H, Sq, Sk, scale, causal, key_len, bias_grad=bg)
+    assert torch.equal(dq2, dq) and torch.equal(dk2, dk) and torch.equal(dv2, dv)
+    for name, got_sum, mat in (("dq", bg[:d], dq), ("dv", bg[2 * d:], dv)):
+        assert (got_sum.double() - mat.double().sum(0)).abs().max().item() <= 2e-6 * mat.float().abs().sum(0).max().item() + 1e-7, name
+    # the key bias gradient vanishes identically (rows of dS sum to zero): exact zeros, where summing the stored dk gives noise
+    assert not bg[d:2 * d].any()
+    assert kr.grad.sum(0).abs().max().item() <= 1e-4 * kr.grad.abs().sum(0).max().item() + 1e-6
     # reproducible: no atomics anywhere
     o2, lse2 = k.attn_fwd(q, kk, v, B, H, Sq, Sk, scale, causal, key_len)
     assert torch.equal(o, o2) and torch.equal(lse, lse2)
