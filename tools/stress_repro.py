@@ -1,0 +1,61 @@
+#!/usr/bin/env python3
+"""Race hunt (GPU box): the kernels are deterministic, so any run-to-run difference of the outputs of the hand-synchronised kernels
+(attention forward / backward at the encoder and decoder shapes, persistent NT / TN GEMMs) is a synchronisation bug.
+Usage: python tools/stress_repro.py [iterations]"""
+import math
+import os
+import sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+from adt_str_amd import kernels as K
+
+dev = "cuda:0"
+n_it = int(sys.argv[1]) if len(sys.argv) > 1 else 100
+bad = 0
+
+
+def check(name, fn):
+    global bad
+    ref = [t.clone() for t in fn()]
+    for it in range(n_it):
+        out = fn()
+        for a, b in zip(ref, out):
+            if not torch.equal(a, b):
+                bad += 1
+                print(f"MISMATCH {name} iteration {it}: max diff {(a.float() - b.float()).abs().max().item()}")
+                return
+    print(f"{name}: {n_it} identical runs")
+
+
+for (B, H, Sq, Sk, causal) in [(64, 6, 986, 986, False), (64, 6, 128, 986, False), (64, 6, 128, 128, True), (3, 2, 449, 200, False)]:
+    d = H * 128
+    g = torch.Generator().manual_seed(Sq + Sk)
+    q = torch.randn((B * Sq, d), generator=g).to(dev).bfloat16()
+    kv = torch.randn((B * Sk, 2 * d), generator=g).to(dev).bfloat16()
+    do = torch.randn((B * Sq, d), generator=g).to(dev).bfloat16()
+    scale, drop = 1 / math.sqrt(128), (0.1, 77)
+    o, lse = K.attn_fwd(q, kv[:, :d], kv[:, d:], B, H, Sq, Sk, scale, causal, drop=drop)
+    dq, dkv, bg = torch.empty_like(q), torch.empty_like(kv), torch.empty(3 * d, device=dev)
+
+    def fwd():
+        return K.attn_fwd(q, kv[:, :d], kv[:, d:], B, H, Sq, Sk, scale, causal, drop=drop)
+
+    def bwd():
+        K.attn_bwd(q, kv[:, :d], kv[:, d:], o, do, lse, dq, dkv[:, :d], dkv[:, d:], B, H, Sq, Sk, scale, causal, drop=drop, bias_grad=bg)
+        return dq, dkv, bg
+
+    check(f"attn fwd {B}x{H}x{Sq}x{Sk}", fwd)
+    check(f"attn bwd {B}x{H}x{Sq}x{Sk}", bwd)
+
+M = 64 * 986
+a = torch.randn((M, 768), device=dev).bfloat16()
+w = torch.randn((3072, 768), device=dev).bfloat16()
+bias = torch.randn(3072, device=dev)
+u = torch.empty((M, 3072), dtype=torch.bfloat16, device=dev)
+cs = torch.empty(3072, device=dev)
+check("NT 256^2 FFN1 + GELU + dropout + column sums", lambda: (K.gemm(a, w, bias=bias, act=1, pre_act_out=u, drop=(0.1, 5), colsum_out=cs), u, cs))
+x = torch.randn((M, 3072), device=dev).bfloat16()
+gw = torch.empty((768, 3072), device=dev)
+check("TN 256^2 split-K wgrad", lambda: (K.gemm(a, x, trans=True, out=gw),))
+print("FAILED" if bad else "all reproducible")
+sys.exit(1 if bad else 0)
