@@ -278,7 +278,8 @@ def train_setup(dev, seed, world, dropout, fx_prob=0.0):
                 "kernel_ms": ms, "algorithmic_flops_per_launch": fl,
                 "algorithmic_bytes_per_launch": 2.0 * (M * Kd + N * Kd + 2 * M * N),
                 "profile": "profiles/r01/roofline_gemm_kernel_stats.csv (rocprofv3 --kernel-trace --stats of tools/pmc_gemm.py: this kernel "
-                           "alone at this shape)"}
+                           "alone at this shape, 300 launches; it averages ~8 % less there than here, where it is timed right after the "
+                           "training steps at the clocks the chip holds under that load)"}
 
     def cpu_baseline(budget_s=20.0):
         from oracle import adt as o_adt
