@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Micro-benchmarks of the hot kernels at the training-step shapes (GPU box only).
-Prints one line per kernel/shape: average ms (HIP events, 20 launches) and TFLOP/s or GB/s."""
+Prints one line per kernel/shape: average ms (HIP events, 40 launches after 30 untimed ones) and TFLOP/s or GB/s."""
 import math
 import sys
 import os
@@ -11,7 +11,7 @@ from adt_str_amd import kernels as K
 dev = "cuda:0"
 
 
-def timeit(fn, n=20, warm=3):
+def timeit(fn, n=40, warm=30):      # the first ~30 launches after an idle gap are a boost -> throttle transient
     for _ in range(warm):
         fn()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
