@@ -14,7 +14,7 @@ _LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "libadt_hip
 _lock = threading.Lock()
 _lib = None
 
-ABI_VERSION = 6
+ABI_VERSION = 7
 
 i32, i64, f32, ptr = C.c_int32, C.c_int64, C.c_float, C.c_void_p
 
@@ -69,6 +69,15 @@ SIGNATURES = {
     "adt_embed_bwd_operands": [ptr, ptr, f32, ptr, i64, ptr, i64, i64, i64, ptr, ptr],
     "adt_cross_entropy_workspace_bytes": [i64],
     "adt_cross_entropy": [ptr, i64, ptr, i64, i64, i64, ptr, ptr, i64, ptr, C.c_size_t, ptr],
+    "adt_gemm_f32": [i32, i64, i64, i64, ptr, i64, ptr, i64, ptr, i64, ptr, ptr],
+    "adt_attn_fwd_f32": [ptr, ptr, ptr, ptr, ptr, ptr, ptr],
+    "adt_attn_bwd_f32_workspace_bytes": [ptr],
+    "adt_attn_bwd_f32": [ptr, ptr, ptr, ptr, ptr, ptr, ptr, ptr, ptr, ptr, ptr, C.c_size_t, ptr],
+    "adt_colsum_f32_workspace_bytes": [i64, i64],
+    "adt_colsum_f32": [ptr, i64, i64, i64, ptr, ptr, C.c_size_t, ptr],
+    "adt_layernorm_bwd_f32": [ptr, i64, ptr, i64, ptr, ptr, ptr, ptr, ptr, i64, ptr, ptr, ptr, i64, i64, ptr, ptr, ptr, C.c_size_t, ptr],
+    "adt_cross_entropy_f32": [ptr, i64, ptr, i64, i64, i64, ptr, ptr, i64, ptr, C.c_size_t, ptr],
+    "adt_embed_bwd_operands_f32": [ptr, ptr, f32, ptr, i64, ptr, i64, i64, i64, ptr, ptr],
     "adt_cast_bf16": [ptr, ptr, ptr, i64, i64, ptr],
     "adt_cast_bf16_batched": [ptr, i32, i32, ptr],
     "adt_grad_norm_workspace_bytes": [],
@@ -92,7 +101,8 @@ _RESTYPES = {"adt_last_error": C.c_char_p}
 _RESTYPES.update({n: C.c_size_t for n in ("adt_mix_workspace_bytes", "adt_gemm_workspace_bytes", "adt_attn_bwd_workspace_bytes",
                                           "adt_layernorm_bwd_workspace_bytes", "adt_colsum_workspace_bytes", "adt_gemm_colsum_workspace_bytes",
                                           "adt_cross_entropy_workspace_bytes", "adt_grad_norm_workspace_bytes",
-                                          "adt_htsat_fusion_embed_workspace_bytes")})
+                                          "adt_htsat_fusion_embed_workspace_bytes",
+                                          "adt_attn_bwd_f32_workspace_bytes", "adt_colsum_f32_workspace_bytes")})
 
 
 class AdtError(RuntimeError):

@@ -64,5 +64,5 @@ int sched_counters(void* stream, const unsigned (&fetches)[8], unsigned** counte
 
 }  // namespace adt
 
-extern "C" int adt_version(void) { return 6; }
+extern "C" int adt_version(void) { return 7; }
 extern "C" const char* adt_last_error(void) { return adt::g_err; }

@@ -143,10 +143,16 @@ __global__ __launch_bounds__(kRowThreads) void layernorm_fwd_narrow_kernel(LnFwd
 // (dxsum = bias gradient of the linear layer that feeds this norm's input).
 // rows per block (a quarter per wave): 64 for the long encoder streams, 16 when 64 would leave most CUs without a block
 __host__ __device__ inline int ln_bwd_rows(long M) { return M >= 32768 ? 64 : 16; }
+// dx16 is the branch-gradient output: bf16 (TB = unsigned short) on the default path, fp32 (TB = float) on the fp32-operand path
 struct LnBwdArgs { const float* dy; long lddy; const float* x; long ldx; const float* gamma; const float* mean;
-                   const float* rstd; float* dx32; unsigned short* dx16; long lddx; float* partial; int M; int D;
+                   const float* rstd; float* dx32; void* dx16; long lddx; float* partial; int M; int D;
                    Drop dy_drop, dx_drop; };
+__device__ __forceinline__ void store4_(unsigned short* p, const float4& d) {
+  *reinterpret_cast<ushort4*>(p) = make_ushort4(f2bf_(d.x), f2bf_(d.y), f2bf_(d.z), f2bf_(d.w));
+}
+__device__ __forceinline__ void store4_(float* p, const float4& d) { *reinterpret_cast<float4*>(p) = d; }
 
+template <typename TB>
 __global__ __launch_bounds__(kRowThreads, 3) void layernorm_bwd_kernel(LnBwdArgs a) {
   __shared__ float red[3][4][kMaxD];        // [dgamma|dbeta|dxsum][wave][col]  = 48 KiB
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -214,8 +220,7 @@ __global__ __launch_bounds__(kRowThreads, 3) void layernorm_bwd_kernel(LnBwdArgs
         float k4[4]; a.dx_drop.scale4(e0, k4); d.x *= k4[0]; d.y *= k4[1]; d.z *= k4[2]; d.w *= k4[3];
       }
       px[i].x += d.x; px[i].y += d.y; px[i].z += d.z; px[i].w += d.w;
-      if (a.dx16) reinterpret_cast<ushort4*>(a.dx16 + static_cast<long>(row) * a.lddx)[q] =
-          make_ushort4(f2bf_(d.x), f2bf_(d.y), f2bf_(d.z), f2bf_(d.w));
+      if (a.dx16) store4_(static_cast<TB*>(a.dx16) + static_cast<long>(row) * a.lddx + 4 * q, d);
     }
   }
 #pragma unroll
@@ -322,6 +327,29 @@ __global__ __launch_bounds__(kRowThreads) void embed_pe_fwd_kernel(EmbedArgs a) 
 }
 // Operands of the embedding gradient as a TN GEMM, dtable = onehot^T . dy16 (fixed summation order, MFMA rate): one wave writes
 // row r of the one-hot matrix [n_rows, vocab] (bf16 1.0 at the row's token) and of dy16 = bf16(scale * keep * dy).
+// fp32 operands (the fp32-operand parity path): same rows, one float per element
+__global__ __launch_bounds__(kRowThreads) void embed_bwd_operands_f32_kernel(const long* __restrict__ tokens, const float* __restrict__ dy, float scale,
+                                                                             float* __restrict__ onehot, long ld_oh, float* __restrict__ dys,
+                                                                             int n_rows, int D, int vocab, Drop drop) {
+  const int lane = threadIdx.x & 63;
+  const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= n_rows) return;
+  long tok = tokens[row];
+  tok = tok < 0 ? 0 : (tok >= vocab ? vocab - 1 : tok);
+  float4* oh = reinterpret_cast<float4*>(onehot + static_cast<long>(row) * ld_oh);
+  const int hot = static_cast<int>(tok >> 2), pos = static_cast<int>(tok & 3);
+  for (int q = lane; q < (vocab >> 2); q += 64) {
+    float4 w = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (q == hot) { if (pos == 0) w.x = 1.f; else if (pos == 1) w.y = 1.f; else if (pos == 2) w.z = 1.f; else w.w = 1.f; }
+    oh[q] = w;
+  }
+  for (int q = lane; q < (D >> 2); q += 64) {
+    const float4 v = reinterpret_cast<const float4*>(dy + static_cast<long>(row) * D)[q];
+    float k4[4] = {1.f, 1.f, 1.f, 1.f};
+    if (drop.on()) drop.scale4(static_cast<uint64_t>(row) * D + 4 * q, k4);
+    reinterpret_cast<float4*>(dys + static_cast<long>(row) * D)[q] = make_float4(scale * k4[0] * v.x, scale * k4[1] * v.y, scale * k4[2] * v.z, scale * k4[3] * v.w);
+  }
+}
 __global__ __launch_bounds__(kRowThreads) void embed_bwd_operands_kernel(const long* __restrict__ tokens, const float* __restrict__ dy, float scale,
                                                                          unsigned short* __restrict__ onehot, long ld_oh,
                                                                          unsigned short* __restrict__ dy16, int n_rows, int D, int vocab, Drop drop) {
@@ -374,14 +402,19 @@ __global__ __launch_bounds__(256) void count_valid_kernel(const long* __restrict
 }
 
 struct CeArgs { const float* logits; long ld; const long* labels; long ignore; const float* n_valid;
-                float* row_loss; unsigned short* dlogits; long ldd; int M; int V; };
+                float* row_loss; void* dlogits; long ldd; int M; int V; };
+__device__ __forceinline__ void store1_(unsigned short* p, float v) { *p = f2bf_(v); }
+__device__ __forceinline__ void store1_(float* p, float v) { *p = v; }
 __device__ __forceinline__ float nan_to_num_(float z) {          // model.py:233
   if (z != z) return 0.0f;
   if (z > 3.0e38f) return 1e4f;
   if (z < -3.0e38f) return -1e4f;
   return z;
 }
+// TG = unsigned short: bf16 gradients, fast exp/log (default path); TG = float: fp32 gradients, libm expf/logf (fp32-operand path)
+template <typename TG>
 __global__ __launch_bounds__(kRowThreads) void cross_entropy_kernel(CeArgs a) {
+  constexpr bool kPrecise = sizeof(TG) == 4;
   const int lane = threadIdx.x & 63;
   const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
   if (row >= a.M) return;
@@ -391,19 +424,20 @@ __global__ __launch_bounds__(kRowThreads) void cross_entropy_kernel(CeArgs a) {
   for (int c = lane; c < a.V; c += 64) mx = fmaxf(mx, nan_to_num_(z[c]));
   mx = wave_max(mx);
   float se = 0.f;
-  for (int c = lane; c < a.V; c += 64) se += __expf(nan_to_num_(z[c]) - mx);
+  for (int c = lane; c < a.V; c += 64) se += kPrecise ? expf(nan_to_num_(z[c]) - mx) : __expf(nan_to_num_(z[c]) - mx);
   se = wave_sum(se);
-  const float lse = mx + __logf(se);
+  const float lse = mx + (kPrecise ? logf(se) : __logf(se));
   const bool valid = label != a.ignore && label >= 0 && label < a.V;
   if (lane == 0) a.row_loss[row] = valid ? lse - nan_to_num_(z[label]) : 0.0f;
   if (a.dlogits) {
     const float inv = valid ? 1.0f / fmaxf(a.n_valid[0], 1.0f) : 0.0f;
-    unsigned short* d = a.dlogits + static_cast<long>(row) * a.ldd;
+    TG* d = static_cast<TG*>(a.dlogits) + static_cast<long>(row) * a.ldd;
     for (int c = lane; c < a.V; c += 64) {
       const float raw = z[c];
       const bool finite = raw == raw && fabsf(raw) <= 3.0e38f;   // nan_to_num passes no gradient through non-finite inputs
-      float gr = (__expf(nan_to_num_(raw) - lse) - (c == label ? 1.0f : 0.0f)) * inv;
-      d[c] = f2bf_(finite ? gr : 0.0f);
+      const float e = kPrecise ? expf(nan_to_num_(raw) - lse) : __expf(nan_to_num_(raw) - lse);
+      const float gr = (e - (c == label ? 1.0f : 0.0f)) * inv;
+      store1_(d + c, finite ? gr : 0.0f);
     }
   }
 }
@@ -570,26 +604,45 @@ extern "C" size_t adt_layernorm_bwd_workspace_bytes(int64_t M, int64_t D) {
   return static_cast<size_t>((M + rpb - 1) / rpb) * 3 * D * 4;
 }
 
-extern "C" int adt_layernorm_bwd(const float* dy, int64_t lddy, const float* x, int64_t ldx, const float* gamma,
-                                 const float* mean, const float* rstd, float* dx32, void* dx16, int64_t lddx,
-                                 float* dgamma, float* dbeta, float* dxsum, int64_t M, int64_t D,
-                                 const adt_dropout* dy_drop, const adt_dropout* dx16_drop, void* ws,
-                                 size_t ws_bytes, void* stream) {
-  if (!dy || !x || !gamma || !mean || !rstd || (!dx32 && !dx16)) return set_error(ADT_EINVAL, "adt_layernorm_bwd: null pointer");
+template <typename TB>
+static int layernorm_bwd_impl(const char* who, const float* dy, int64_t lddy, const float* x, int64_t ldx, const float* gamma,
+                              const float* mean, const float* rstd, float* dx32, void* dxb, int64_t lddx,
+                              float* dgamma, float* dbeta, float* dxsum, int64_t M, int64_t D,
+                              const adt_dropout* dy_drop, const adt_dropout* dxb_drop, void* ws, size_t ws_bytes, void* stream) {
+  (void)who;
+  if (!dy || !x || !gamma || !mean || !rstd || (!dx32 && !dxb)) return set_error(ADT_EINVAL, "adt_layernorm_bwd: null pointer");
   if (D <= 0 || D > kMaxD || (D & 3) || (ldx & 3) || (lddy & 3) || (lddx & 3)) return set_error(ADT_ESHAPE, "adt_layernorm_bwd: D must be a multiple of 4, <= 1024");
   if (M < 0) return set_error(ADT_EINVAL, "adt_layernorm_bwd: negative M");
   if (M == 0) return ADT_OK;
   if (!ws || ws_bytes < adt_layernorm_bwd_workspace_bytes(M, D)) return set_error(ADT_EINVAL, "adt_layernorm_bwd: workspace too small");
   const int nb = static_cast<int>((M + ln_bwd_rows(M) - 1) / ln_bwd_rows(M));
-  LnBwdArgs a{dy, lddy, x, ldx, gamma, mean, rstd, dx32, static_cast<unsigned short*>(dx16), lddx, static_cast<float*>(ws),
+  LnBwdArgs a{dy, lddy, x, ldx, gamma, mean, rstd, dx32, dxb, lddx, static_cast<float*>(ws),
               static_cast<int>(M), static_cast<int>(D), dy_drop ? make_drop(dy_drop->p, dy_drop->key) : Drop{0u, 0u, 1.0f},
-              dx16_drop ? make_drop(dx16_drop->p, dx16_drop->key) : Drop{0u, 0u, 1.0f}};
-  hipLaunchKernelGGL(layernorm_bwd_kernel, dim3(nb), dim3(kRowThreads), 0, ST(stream), a);
+              dxb_drop ? make_drop(dxb_drop->p, dxb_drop->key) : Drop{0u, 0u, 1.0f}};
+  hipLaunchKernelGGL(layernorm_bwd_kernel<TB>, dim3(nb), dim3(kRowThreads), 0, ST(stream), a);
   const int width = 3 * static_cast<int>(D);
   hipLaunchKernelGGL(reduce_partials_kernel, dim3((width + kRedCols - 1) / kRedCols), dim3(256), 0, ST(stream), static_cast<const float*>(ws), nb,
                      width, dgamma, dbeta, dxsum, static_cast<int>(D));
   ADT_HIP_TRY(hipGetLastError());
   return ADT_OK;
+}
+
+extern "C" int adt_layernorm_bwd(const float* dy, int64_t lddy, const float* x, int64_t ldx, const float* gamma,
+                                 const float* mean, const float* rstd, float* dx32, void* dx16, int64_t lddx,
+                                 float* dgamma, float* dbeta, float* dxsum, int64_t M, int64_t D,
+                                 const adt_dropout* dy_drop, const adt_dropout* dx16_drop, void* ws,
+                                 size_t ws_bytes, void* stream) {
+  return layernorm_bwd_impl<unsigned short>("adt_layernorm_bwd", dy, lddy, x, ldx, gamma, mean, rstd, dx32, dx16, lddx, dgamma, dbeta, dxsum, M, D,
+                                            dy_drop, dx16_drop, ws, ws_bytes, stream);
+}
+
+extern "C" int adt_layernorm_bwd_f32(const float* dy, int64_t lddy, const float* x, int64_t ldx, const float* gamma,
+                                     const float* mean, const float* rstd, float* dx32, float* dx_branch, int64_t lddx,
+                                     float* dgamma, float* dbeta, float* dxsum, int64_t M, int64_t D,
+                                     const adt_dropout* dy_drop, const adt_dropout* branch_drop, void* ws,
+                                     size_t ws_bytes, void* stream) {
+  return layernorm_bwd_impl<float>("adt_layernorm_bwd_f32", dy, lddy, x, ldx, gamma, mean, rstd, dx32, dx_branch, lddx, dgamma, dbeta, dxsum, M, D,
+                                   dy_drop, branch_drop, ws, ws_bytes, stream);
 }
 
 namespace adt {
@@ -658,10 +711,25 @@ extern "C" int adt_embed_bwd_operands(const int64_t* tokens, const float* dy, fl
   return ADT_OK;
 }
 
+extern "C" int adt_embed_bwd_operands_f32(const int64_t* tokens, const float* dy, float scale, float* onehot, int64_t ld_onehot, float* dy_scaled,
+                                          int64_t n_rows, int64_t D, int64_t vocab, const adt_dropout* drop, void* stream) {
+  if (!tokens || !dy || !onehot || !dy_scaled) return set_error(ADT_EINVAL, "adt_embed_bwd_operands_f32: null pointer");
+  if (D <= 0 || (D & 3) || vocab <= 0 || (vocab & 3) || ld_onehot < vocab || (ld_onehot & 3) || n_rows < 0 || !aligned16(onehot) || !aligned16(dy) ||
+      !aligned16(dy_scaled))
+    return set_error(ADT_ESHAPE, "adt_embed_bwd_operands_f32: D % 4, vocab % 4, ld_onehot % 4 must be 0, buffers 16-byte aligned");
+  if (n_rows == 0) return ADT_OK;
+  hipLaunchKernelGGL(embed_bwd_operands_f32_kernel, dim3(static_cast<unsigned>((n_rows + 3) / 4)), dim3(kRowThreads), 0, ST(stream),
+                     reinterpret_cast<const long*>(tokens), dy, scale, onehot, ld_onehot, dy_scaled, static_cast<int>(n_rows), static_cast<int>(D),
+                     static_cast<int>(vocab), drop ? make_drop(drop->p, drop->key) : Drop{0u, 0u, 1.0f});
+  ADT_HIP_TRY(hipGetLastError());
+  return ADT_OK;
+}
+
 extern "C" size_t adt_cross_entropy_workspace_bytes(int64_t M) { return M > 0 ? static_cast<size_t>(M + 4) * 4 : 16; }
 
-extern "C" int adt_cross_entropy(const float* logits, int64_t ld, const int64_t* labels, int64_t ignore_index, int64_t M, int64_t V,
-                                 float* loss, void* dlogits, int64_t ldd, void* ws, size_t ws_bytes, void* stream) {
+template <typename TG>
+static int cross_entropy_impl(const float* logits, int64_t ld, const int64_t* labels, int64_t ignore_index, int64_t M, int64_t V,
+                              float* loss, void* dlogits, int64_t ldd, void* ws, size_t ws_bytes, void* stream) {
   if (!logits || !labels || !loss) return set_error(ADT_EINVAL, "adt_cross_entropy: null pointer");
   if (M < 0 || V <= 0 || ld < V || (dlogits && ldd < V)) return set_error(ADT_EINVAL, "adt_cross_entropy: bad shape");
   if (!ws || ws_bytes < adt_cross_entropy_workspace_bytes(M)) return set_error(ADT_EINVAL, "adt_cross_entropy: workspace too small");
@@ -671,12 +739,22 @@ extern "C" int adt_cross_entropy(const float* logits, int64_t ld, const int64_t*
                      static_cast<long>(ignore_index), n_valid);
   if (M > 0) {
     CeArgs a{logits, ld, reinterpret_cast<const long*>(labels), static_cast<long>(ignore_index), n_valid, row_loss,
-             static_cast<unsigned short*>(dlogits), ldd, static_cast<int>(M), static_cast<int>(V)};
-    hipLaunchKernelGGL(cross_entropy_kernel, dim3(static_cast<unsigned>((M + 3) / 4)), dim3(kRowThreads), 0, ST(stream), a);
+             dlogits, ldd, static_cast<int>(M), static_cast<int>(V)};
+    hipLaunchKernelGGL(cross_entropy_kernel<TG>, dim3(static_cast<unsigned>((M + 3) / 4)), dim3(kRowThreads), 0, ST(stream), a);
   }
   hipLaunchKernelGGL(loss_reduce_kernel, dim3(1), dim3(256), 0, ST(stream), row_loss, static_cast<int>(M), n_valid, loss);
   ADT_HIP_TRY(hipGetLastError());
   return ADT_OK;
+}
+
+extern "C" int adt_cross_entropy(const float* logits, int64_t ld, const int64_t* labels, int64_t ignore_index, int64_t M, int64_t V,
+                                 float* loss, void* dlogits, int64_t ldd, void* ws, size_t ws_bytes, void* stream) {
+  return cross_entropy_impl<unsigned short>(logits, ld, labels, ignore_index, M, V, loss, dlogits, ldd, ws, ws_bytes, stream);
+}
+
+extern "C" int adt_cross_entropy_f32(const float* logits, int64_t ld, const int64_t* labels, int64_t ignore_index, int64_t M, int64_t V,
+                                     float* loss, float* dlogits, int64_t ldd, void* ws, size_t ws_bytes, void* stream) {
+  return cross_entropy_impl<float>(logits, ld, labels, ignore_index, M, V, loss, dlogits, ldd, ws, ws_bytes, stream);
 }
 
 extern "C" int adt_cast_bf16(const float* x, void* y, void* y_t, int64_t rows, int64_t cols, void* stream) {

@@ -50,10 +50,16 @@ def gemm(a: torch.Tensor, b: torch.Tensor, *, trans: bool = False, out: Optional
          res_row_mod: int = 0, act: int = 0, pre_act_out: Optional[torch.Tensor] = None,
          gelu_grad_of: Optional[torch.Tensor] = None, alpha: float = 1.0,
          aux_bf16_out: Optional[torch.Tensor] = None, drop=None, drop_after_residual: bool = False,
-         colsum_out: Optional[torch.Tensor] = None) -> torch.Tensor:
+         colsum_out: Optional[torch.Tensor] = None, b_kn: bool = False) -> torch.Tensor:
     """``trans=False``: ``a[M,K] @ b[N,K].T``; ``trans=True``: ``a[K,M].T @ b[K,N]`` (bf16 in, fp32 accumulate).
-    ``colsum_out`` (fp32 [N]) also receives the column sums of the bf16 output."""
-    assert a.dtype == torch.bfloat16 and b.dtype == torch.bfloat16 and a.dim() == 2 and b.dim() == 2
+    ``colsum_out`` (fp32 [N]) also receives the column sums of the bf16 output.
+    fp32 operands take the fp32-operand parity path (``adt_gemm_f32``: same epilogue, fp32 everywhere); there
+    ``b_kn=True`` reads ``b`` as ``[K, N]`` (``a[M,K] @ b[K,N]``, the data gradient against the master weight)."""
+    if a.dtype == torch.float32:
+        return _gemm_f32(a, b, trans=trans, b_kn=b_kn, out=out, bias=bias, residual=residual, res_row_mod=res_row_mod, act=act,
+                         pre_act_out=pre_act_out, gelu_grad_of=gelu_grad_of, alpha=alpha, drop=drop,
+                         drop_after_residual=drop_after_residual, colsum_out=colsum_out, aux_out=aux_bf16_out)
+    assert a.dtype == torch.bfloat16 and b.dtype == torch.bfloat16 and a.dim() == 2 and b.dim() == 2 and not b_kn
     assert a.stride(1) == 1 and b.stride(1) == 1
     if trans:
         K, M = a.shape
@@ -100,6 +106,45 @@ def gemm(a: torch.Tensor, b: torch.Tensor, *, trans: bool = False, out: Optional
     return out
 
 
+def _gemm_f32(a, b, *, trans, b_kn, out, bias, residual, res_row_mod, act, pre_act_out, gelu_grad_of, alpha, drop,
+              drop_after_residual, colsum_out, aux_out):
+    """fp32-operand GEMM (parity path).  Layout bits: 1 = a is [K, M], 2 = b is [K, N]."""
+    assert b.dtype == torch.float32 and a.dim() == 2 and b.dim() == 2 and a.stride(1) == 1 and b.stride(1) == 1
+    assert aux_out is None, "the fp32 path has a single (fp32) output"
+    if trans:
+        (K, M), (K2, N), layout = a.shape, b.shape, 3
+    elif b_kn:
+        (M, K), (K2, N), layout = a.shape, b.shape, 2
+    else:
+        (M, K), (N, K2), layout = a.shape, b.shape, 0
+    assert K == K2, (a.shape, b.shape)
+    if out is None:
+        out = torch.empty((M, N), dtype=torch.float32, device=a.device)
+    assert out.shape == (M, N) and out.stride(1) == 1 and out.dtype == torch.float32
+    ep = _ffi.GemmEpilogue()
+    ep.alpha, ep.act, ep.out_fp32 = alpha, act, 1
+    if drop is not None:
+        ep.drop.p, ep.drop.key = drop
+        ep.drop_after_residual = 1 if drop_after_residual else 0
+    if bias is not None:
+        assert bias.dtype == torch.float32 and bias.numel() == N
+        ep.bias = _ffi.dptr(bias)
+    if residual is not None:
+        assert residual.dtype == torch.float32 and residual.stride(-1) == 1
+        ep.residual, ep.ld_res, ep.res_row_mod = _ffi.dptr(residual), residual.stride(-2), res_row_mod
+    if pre_act_out is not None:
+        assert pre_act_out.dtype == torch.float32 and pre_act_out.shape == (M, N)
+        ep.pre_act_out, ep.ld_pre_act = _ffi.dptr(pre_act_out), pre_act_out.stride(0)
+    if gelu_grad_of is not None:
+        assert gelu_grad_of.dtype == torch.float32 and gelu_grad_of.shape == (M, N)
+        ep.gelu_grad_of, ep.ld_gelu_grad = _ffi.dptr(gelu_grad_of), gelu_grad_of.stride(0)
+    _ffi.call("adt_gemm_f32", layout, M, N, K, _ffi.dptr(a), a.stride(0), _ffi.dptr(b), b.stride(0), _ffi.dptr(out), out.stride(0),
+              C.byref(ep), _ffi.current_stream())
+    if colsum_out is not None:
+        colsum(out, out=colsum_out)
+    return out
+
+
 def _p(t: Optional[torch.Tensor]):
     return _ffi.dptr(t) if t is not None else None
 
@@ -119,10 +164,23 @@ def layernorm_fwd(x, gamma, beta, eps=1e-5, want32=True, want16=True, drop=None)
 
 
 def layernorm_bwd(dy, x, gamma, mean, rstd, dgamma=None, dbeta=None, dxsum=None, want32=True, want16=True, dy_drop=None,
-                  dx16_drop=None):
-    """-> (dx32 | None, dx16 | None); dgamma/dbeta/dxsum [D] fp32 are overwritten when given."""
+                  dx16_drop=None, branch_dtype=torch.bfloat16):
+    """-> (dx32 | None, dx16 | None); dgamma/dbeta/dxsum [D] fp32 are overwritten when given.  ``branch_dtype=float32``
+    (fp32-operand path): the branch gradient ``dx16`` is fp32; without a branch dropout it IS ``dx32``."""
     assert dy.dtype == torch.float32 and x.dtype == torch.float32 and dy.shape == x.shape
     M, D = x.shape
+    if branch_dtype == torch.float32:
+        alias = want16 and want32 and dx16_drop is None
+        dx32 = torch.empty((M, D), dtype=torch.float32, device=x.device) if want32 else None
+        dxb = None if (alias or not want16) else torch.empty((M, D), dtype=torch.float32, device=x.device)
+        nb = _ffi.load().adt_layernorm_bwd_workspace_bytes(M, D)
+        ws = _workspace(nb, x.device)
+        _k1, p1 = _drop_ptr(dy_drop)
+        _k2, p2 = _drop_ptr(dx16_drop)
+        _ffi.call("adt_layernorm_bwd_f32", _ffi.dptr(dy), dy.stride(0), _ffi.dptr(x), x.stride(0), _ffi.dptr(gamma), _ffi.dptr(mean),
+                  _ffi.dptr(rstd), _p(dx32), _p(dxb), D, _p(dgamma), _p(dbeta), _p(dxsum), M, D, p1, p2, _ffi.dptr(ws), nb,
+                  _ffi.current_stream())
+        return dx32, (dx32 if alias else dxb)
     dx32 = torch.empty((M, D), dtype=torch.float32, device=x.device) if want32 else None
     dx16 = torch.empty((M, D), dtype=torch.bfloat16, device=x.device) if want16 else None
     nb = _ffi.load().adt_layernorm_bwd_workspace_bytes(M, D)
@@ -136,10 +194,15 @@ def layernorm_bwd(dy, x, gamma, mean, rstd, dgamma=None, dbeta=None, dxsum=None,
 
 
 def colsum(x, out=None):
-    assert x.dtype == torch.bfloat16 and x.dim() == 2 and x.stride(1) == 1
+    assert x.dtype in (torch.bfloat16, torch.float32) and x.dim() == 2 and x.stride(1) == 1
     M, N = x.shape
     if out is None:
         out = torch.empty(N, dtype=torch.float32, device=x.device)
+    if x.dtype == torch.float32:
+        nb = _ffi.load().adt_colsum_f32_workspace_bytes(M, N)
+        ws = _workspace(nb, x.device)
+        _ffi.call("adt_colsum_f32", _ffi.dptr(x), x.stride(0), M, N, _ffi.dptr(out), _ffi.dptr(ws), nb, _ffi.current_stream())
+        return out
     nb = _ffi.load().adt_colsum_workspace_bytes(M, N)
     ws = _workspace(nb, x.device)
     _ffi.call("adt_colsum_bf16", _ffi.dptr(x), x.stride(0), M, N, _ffi.dptr(out), _ffi.dptr(ws), nb, _ffi.current_stream())
@@ -159,7 +222,7 @@ def embed_pe_fwd(tokens, table, pe, scale, want32=True, want16=True, drop=None):
     return y32, y16
 
 
-def embed_bwd(tokens, dy, scale, dtable, drop=None):
+def embed_bwd(tokens, dy, scale, dtable, drop=None, f32=False):
     """dtable[v] = scale * sum of the (dropped) rows of dy whose token is v; dtable is overwritten.  The sum runs as a TN GEMM
     of a one-hot matrix with the bf16 gradient rows (fixed order, like every other weight gradient); vocabularies or widths
     that are not multiples of 8 take the fp32-atomics kernel."""
@@ -167,6 +230,13 @@ def embed_bwd(tokens, dy, scale, dtable, drop=None):
     V = dtable.shape[0]
     assert dy.dtype == torch.float32 and dy.is_contiguous() and dtable.dtype == torch.float32 and dtable.is_contiguous()
     _keep, dp = _drop_ptr(drop)
+    if f32 and n > 0 and V % 4 == 0 and D % 4 == 0:              # fp32-operand path: the same one-hot TN GEMM on fp32 operands
+        onehot = torch.empty((n, V), dtype=torch.float32, device=dy.device)
+        dys = torch.empty((n, D), dtype=torch.float32, device=dy.device)
+        _ffi.call("adt_embed_bwd_operands_f32", _ffi.dptr(tokens), _ffi.dptr(dy), scale, _ffi.dptr(onehot), V, _ffi.dptr(dys), n, D, V, dp,
+                  _ffi.current_stream())
+        gemm(onehot, dys, trans=True, out=dtable)
+        return
     if n > 0 and V % 8 == 0 and D % 8 == 0:
         onehot = torch.empty((n, V), dtype=torch.bfloat16, device=dy.device)
         dy16 = torch.empty((n, D), dtype=torch.bfloat16, device=dy.device)
@@ -178,12 +248,20 @@ def embed_bwd(tokens, dy, scale, dtable, drop=None):
     _ffi.call("adt_embed_bwd", _ffi.dptr(tokens), _ffi.dptr(dy), scale, _ffi.dptr(dtable), n, D, V, dp, _ffi.current_stream())
 
 
-def cross_entropy(logits, labels, ignore_index=1, want_grad=True):
-    """logits fp32 [M, V], labels int64 [M] -> (loss[1] fp32 on device, dlogits bf16 [M, Vpad] | None)."""
+def cross_entropy(logits, labels, ignore_index=1, want_grad=True, grad_dtype=torch.bfloat16):
+    """logits fp32 [M, V], labels int64 [M] -> (loss[1] fp32 on device, dlogits bf16 [M, Vpad] | None).
+    ``grad_dtype=float32``: the fp32-operand path (fp32 dlogits [M, V], libm exp / log)."""
     assert logits.dtype == torch.float32 and logits.dim() == 2 and logits.stride(1) == 1
     M, V = logits.shape
     labels = labels.reshape(-1).contiguous()
     loss = torch.empty(1, dtype=torch.float32, device=logits.device)
+    if grad_dtype == torch.float32:
+        dl = torch.zeros((M, V), dtype=torch.float32, device=logits.device) if want_grad else None
+        nb = _ffi.load().adt_cross_entropy_workspace_bytes(M)
+        ws = _workspace(nb, logits.device)
+        _ffi.call("adt_cross_entropy_f32", _ffi.dptr(logits), logits.stride(0), _ffi.dptr(labels), ignore_index, M, V, _ffi.dptr(loss),
+                  _p(dl), V, _ffi.dptr(ws), nb, _ffi.current_stream())
+        return loss, dl
     Vp = (V + 7) // 8 * 8
     dl = torch.zeros((M, Vp), dtype=torch.bfloat16, device=logits.device) if want_grad else None
     nb = _ffi.load().adt_cross_entropy_workspace_bytes(M)
@@ -245,9 +323,9 @@ def adamw_step(p, g, m, v, step, lr, beta1=0.9, beta2=0.999, eps=1e-8, weight_de
               eps, weight_decay, step, _p(norm_and_clip), _ffi.current_stream())
 
 
-def _attn_desc(B, H, Sq, Sk, q, k, v, o, scale, causal, key_len, mask_value, drop=None):
+def _attn_desc(B, H, Sq, Sk, q, k, v, o, scale, causal, key_len, mask_value, drop=None, head_dim=128):
     d = _ffi.AttnDesc()
-    d.batch, d.heads, d.q_len, d.k_len, d.head_dim = B, H, Sq, Sk, 128
+    d.batch, d.heads, d.q_len, d.k_len, d.head_dim = B, H, Sq, Sk, head_dim
     d.causal = 1 if causal else 0
     d.ldq, d.ldk, d.ldv, d.ldo = q.stride(0), k.stride(0), v.stride(0), o.stride(0)
     d.scale, d.mask_value = scale, mask_value
@@ -259,26 +337,40 @@ def _attn_desc(B, H, Sq, Sk, q, k, v, o, scale, causal, key_len, mask_value, dro
     return d
 
 
-def attn_fwd(q, k, v, B, H, Sq, Sk, scale, causal=False, key_len=None, mask_value=-1e4, out=None, drop=None):
-    """q [B*Sq, >=H*128], k/v [B*Sk, >=H*128] bf16 (row-strided views allowed) -> (o [B*Sq, H*128] bf16, lse [B,H,Sq] fp32)."""
+def attn_fwd(q, k, v, B, H, Sq, Sk, scale, causal=False, key_len=None, mask_value=-1e4, out=None, drop=None, head_dim=128):
+    """q [B*Sq, >=H*128], k/v [B*Sk, >=H*128] bf16 (row-strided views allowed) -> (o [B*Sq, H*128] bf16, lse [B,H,Sq] fp32).
+    fp32 tensors take the fp32-operand path (``head_dim`` 16 / 32 / 64 / 128 there; the bf16 kernels are built for 128)."""
+    f32 = q.dtype == torch.float32
     for t in (q, k, v):
-        assert t.dtype == torch.bfloat16 and t.dim() == 2 and t.stride(1) == 1
+        assert t.dtype == q.dtype and t.dtype in (torch.bfloat16, torch.float32) and t.dim() == 2 and t.stride(1) == 1
     if out is None:
-        out = torch.empty((B * Sq, H * 128), dtype=torch.bfloat16, device=q.device)
+        out = torch.empty((B * Sq, H * head_dim), dtype=q.dtype, device=q.device)
     lse = torch.empty((B, H, Sq), dtype=torch.float32, device=q.device)
-    d = _attn_desc(B, H, Sq, Sk, q, k, v, out, scale, causal, key_len, mask_value, drop)
-    _ffi.call("adt_attn_fwd", C.byref(d), _ffi.dptr(q), _ffi.dptr(k), _ffi.dptr(v), _ffi.dptr(out), _ffi.dptr(lse),
+    d = _attn_desc(B, H, Sq, Sk, q, k, v, out, scale, causal, key_len, mask_value, drop, head_dim)
+    _ffi.call("adt_attn_fwd_f32" if f32 else "adt_attn_fwd", C.byref(d), _ffi.dptr(q), _ffi.dptr(k), _ffi.dptr(v), _ffi.dptr(out), _ffi.dptr(lse),
               _ffi.current_stream())
     return out, lse
 
 
 def attn_bwd(q, k, v, o, dout, lse, dq, dk, dv, B, H, Sq, Sk, scale, causal=False, key_len=None, mask_value=-1e4, drop=None,
-             bias_grad=None):
+             bias_grad=None, head_dim=128):
     """Writes dq/dk/dv (bf16 views with the strides of q/k/v).  ``bias_grad`` (fp32 [3 * H * 128], contiguous): also receives the
     column sums of dq | dk | dv, i.e. the gradient of the in-projection bias."""
     assert dq.stride(0) == q.stride(0) and dk.stride(0) == k.stride(0) and dv.stride(0) == v.stride(0)
     assert dout.stride(0) == o.stride(0)
-    d = _attn_desc(B, H, Sq, Sk, q, k, v, o, scale, causal, key_len, mask_value, drop)
+    d = _attn_desc(B, H, Sq, Sk, q, k, v, o, scale, causal, key_len, mask_value, drop, head_dim)
+    if q.dtype == torch.float32:                              # fp32-operand path; bias gradients by separate column sums
+        nb = _ffi.load().adt_attn_bwd_f32_workspace_bytes(C.byref(d))
+        ws = _workspace(nb, q.device)
+        _ffi.call("adt_attn_bwd_f32", C.byref(d), _ffi.dptr(q), _ffi.dptr(k), _ffi.dptr(v), _ffi.dptr(o), _ffi.dptr(dout),
+                  _ffi.dptr(lse), _ffi.dptr(dq), _ffi.dptr(dk), _ffi.dptr(dv), _ffi.dptr(ws), nb, _ffi.current_stream())
+        if bias_grad is not None:
+            hd = H * head_dim
+            assert bias_grad.dtype == torch.float32 and bias_grad.is_contiguous() and bias_grad.numel() == 3 * hd
+            colsum(dq[:, :hd], out=bias_grad[:hd])
+            bias_grad[hd:2 * hd].zero_()                      # the rows of dS sum to zero: the key-bias gradient vanishes identically
+            colsum(dv[:, :hd], out=bias_grad[2 * hd:])
+        return
     if bias_grad is not None:
         hd = H * 128
         assert bias_grad.dtype == torch.float32 and bias_grad.is_contiguous() and bias_grad.numel() == 3 * hd

@@ -21,6 +21,7 @@ without autograd, writing gradients into one flat fp32 buffer (what
 from __future__ import annotations
 
 import math
+import os
 from typing import Dict, List, Optional
 
 import torch
@@ -122,12 +123,23 @@ class _Lin:
 
 
 class _Engine:
-    def __init__(self, model: "ADTModel"):
+    """``precision``: ``"bf16"`` (default; bf16 GEMM / attention operands, fp32 accumulate = the reference's bf16 autocast) or
+    ``"fp32"`` (the parity arm: fp32 activations end to end on the f32-input MFMA kernels of ``csrc/precise.hip``, what
+    BASELINE's "logits within 1e-3 rel-tol of the CPU reference" is checked with).  Default from ``ADT_PRECISION``."""
+
+    def __init__(self, model: "ADTModel", precision: Optional[str] = None):
         self.m = model
         cfg = model.config
-        self.H, self.d = cfg.nhead, cfg.nhead * cfg.d_query
-        if cfg.d_query != 128:
-            raise NotImplementedError("the attention kernels are built for head_dim (d_query) = 128")
+        precision = (precision or os.environ.get("ADT_PRECISION", "bf16")).lower()
+        if precision not in ("bf16", "fp32"):
+            raise ValueError(f"precision must be 'bf16' or 'fp32', not {precision!r}")
+        self.precision = precision
+        self.fp32 = precision == "fp32"
+        self.adt = F32 if self.fp32 else BF16            # dtype of GEMM / attention operands and stored activations
+        self.H, self.d, self.dh = cfg.nhead, cfg.nhead * cfg.d_query, cfg.d_query
+        if cfg.d_query != 128 and not (self.fp32 and cfg.d_query in (16, 32, 64)):
+            raise NotImplementedError("the bf16 attention kernels are built for head_dim (d_query) = 128 "
+                                      "(the fp32 parity path also takes 16, 32 and 64)")
         self.scale = 1.0 / math.sqrt(cfg.d_query)
         self.V = cfg.tgt_vocab_size
         if self.V % 8 or cfg.n_mels % 8:
@@ -177,6 +189,12 @@ class _Engine:
 
     def refresh_weights(self, force=False):
         """Re-derive the bf16 operands when any parameter was modified in place (optimizer step, load_state_dict)."""
+        if self.fp32:                                     # the fp32 masters are the operands: nothing to derive
+            for l in self.lins.values():
+                if not l.weight.data.is_contiguous():
+                    raise RuntimeError(f"{l.name}: the fp32 path reads the master weight in place; it must be contiguous")
+                l.w16, l.wt16 = l.weight.data, None
+            return
         ver = tuple(p._version for p in self.named.values()) + (str(next(iter(self.named.values())).device),)
         if force or ver != self._versions:
             lins = list(self.lins.values())
@@ -205,35 +223,68 @@ class _Engine:
                 off += p.numel()
         return self.gflat, self.G
 
+    # ---- precision plumbing (the two modes share every line of the forward / backward below) --------------------
+    def _operand(self, x32):
+        """fp32 activation -> GEMM operand (a bf16 copy, or the tensor itself on the fp32 path)."""
+        return x32 if self.fp32 else K.cast_bf16(x32)[0]
+
+    def _gemm_dual(self, a, w, **kw):
+        """GEMM whose result is needed as the fp32 residual stream AND as the next GEMM's operand -> (x32, x16)."""
+        if self.fp32:
+            x32 = K.gemm(a, w, **kw)
+            return x32, x32
+        x16 = torch.empty((a.shape[0], w.shape[0]), dtype=BF16, device=a.device)
+        return K.gemm(a, w, out_dtype=F32, aux_bf16_out=x16, **kw), x16
+
+    def _dgrad(self, dy, lin: _Lin, lo=None, hi=None, **kw):
+        """Data gradient ``dy @ W[lo:hi]`` (bf16: NT GEMM against the transposed copy; fp32: NN GEMM against the master)."""
+        if self.fp32:
+            return K.gemm(dy, lin.w16[lo:hi], b_kn=True, **kw)
+        return K.gemm(dy, lin.wt16[:, lo:hi], **kw)
+
+    def _ln(self, x, g, b, want32=True, drop=None):
+        if self.fp32:
+            y32, _, mean, rstd = K.layernorm_fwd(x, g, b, want32=True, want16=False, drop=drop)
+            return (y32 if want32 else None), y32, mean, rstd
+        return K.layernorm_fwd(x, g, b, want32=want32, drop=drop)
+
+    def _ln_bwd(self, *a, **kw):
+        return K.layernorm_bwd(*a, branch_dtype=self.adt, **kw)
+
+    def _embed(self, tokens, emb, pe, scale, drop=None):
+        if self.fp32:
+            y32, _ = K.embed_pe_fwd(tokens, emb, pe, scale, want16=False, drop=drop)
+            return y32, y32
+        return K.embed_pe_fwd(tokens, emb, pe, scale, drop=drop)
+
     # ---- forward pieces -------------------------------------------------------------
     def _encoder_fwd(self, src, save: Optional[list]):
         m, d, H = self.m, self.d, self.H
         mel = m.compute_spectrogram(src)                                   # K1: [B, S, n_mels] fp32
         B, S, n_mels = mel.shape
         M = B * S
-        mel16, _ = K.cast_bf16(mel.view(M, n_mels))
+        mel16 = self._operand(mel.view(M, n_mels))
         x0 = K.gemm(mel16, self.proj.w16, bias=self.proj.b)                # project_to_mel (model.py:249)
         pe = self.m.encoder.positional_encoding.pos_embedding[0]
-        x16 = torch.empty((M, d), dtype=BF16, device=src.device)
-        x32 = K.gemm(x0, self.dense.w16, residual=pe, res_row_mod=S, out_dtype=F32, aux_bf16_out=x16,
-                     drop=self.D("enc.pe"), drop_after_residual=True)          # dense + PE + dropout (model.py:130-132)
+        x32, x16 = self._gemm_dual(x0, self.dense.w16, residual=pe, res_row_mod=S,
+                                   drop=self.D("enc.pe"), drop_after_residual=True)   # dense + PE + dropout (model.py:130-132)
         if save is not None:
             save.append(dict(mel16=mel16, x0=x0, B=B, S=S))
         for L in self.enc:
             p = L["p"]
             qkv = K.gemm(x16, L["sa"].w16, bias=L["sa"].b)
-            attn, lse = K.attn_fwd(qkv[:, :d], qkv[:, d:2 * d], qkv[:, 2 * d:], B, H, S, S, self.scale, drop=self.D(p + ".attn"))
+            attn, lse = K.attn_fwd(qkv[:, :d], qkv[:, d:2 * d], qkv[:, 2 * d:], B, H, S, S, self.scale, drop=self.D(p + ".attn"), head_dim=self.dh)
             y1 = K.gemm(attn, L["sa_o"].w16, bias=L["sa_o"].b, residual=x32, out_dtype=F32, drop=self.D(p + ".drop1"))
-            x1_32, x1_16, mean1, rstd1 = K.layernorm_fwd(y1, self.P(p + ".norm1.weight"), self.P(p + ".norm1.bias"))
-            u = torch.empty((M, L["l1"].w16.shape[0]), dtype=BF16, device=src.device)
+            x1_32, x1_16, mean1, rstd1 = self._ln(y1, self.P(p + ".norm1.weight"), self.P(p + ".norm1.bias"))
+            u = torch.empty((M, L["l1"].w16.shape[0]), dtype=self.adt, device=src.device)
             h = K.gemm(x1_16, L["l1"].w16, bias=L["l1"].b, act=1, pre_act_out=u, drop=self.D(p + ".ffn"))
             y2 = K.gemm(h, L["l2"].w16, bias=L["l2"].b, residual=x1_32, out_dtype=F32, drop=self.D(p + ".drop2"))
-            x2_32, x2_16, mean2, rstd2 = K.layernorm_fwd(y2, self.P(p + ".norm2.weight"), self.P(p + ".norm2.bias"))
+            x2_32, x2_16, mean2, rstd2 = self._ln(y2, self.P(p + ".norm2.weight"), self.P(p + ".norm2.bias"))
             if save is not None:
                 save.append(dict(x16=x16, qkv=qkv, attn=attn, lse=lse, y1=y1, mean1=mean1, rstd1=rstd1, x1_16=x1_16, u=u, h=h,
                                  y2=y2, mean2=mean2, rstd2=rstd2))
             x32, x16 = x2_32, x2_16
-        _, mem16, meanf, rstdf = K.layernorm_fwd(x32, self.P("encoder.layer_norm.weight"), self.P("encoder.layer_norm.bias"),
+        _, mem16, meanf, rstdf = self._ln(x32, self.P("encoder.layer_norm.weight"), self.P("encoder.layer_norm.bias"),
                                                  want32=False, drop=self.D("enc.final"))      # LN + dropout (model.py:134)
         if save is not None:
             save.append(dict(x32=x32, mean=meanf, rstd=rstdf))
@@ -246,25 +297,25 @@ class _Engine:
         Md = B * T
         emb = self.P("decoder.tgt_tok_emb.embedding.weight")
         pe = self.m.decoder.positional_encoding.pos_embedding[0]
-        x32, x16 = K.embed_pe_fwd(tgt, emb, pe, math.sqrt(d), drop=self.D("dec.emb"))   # model.py:171-172
+        x32, x16 = self._embed(tgt, emb, pe, math.sqrt(d), drop=self.D("dec.emb"))      # model.py:171-172
         dev = tgt.device
         for L in self.dec:
             p = L["p"]
             qkv = K.gemm(x16, L["sa"].w16, bias=L["sa"].b)
             sa, lse_s = K.attn_fwd(qkv[:, :d], qkv[:, d:2 * d], qkv[:, 2 * d:], B, H, T, T, self.scale, causal=True, key_len=key_len,
-                                   drop=self.D(p + ".sattn"))
+                                   drop=self.D(p + ".sattn"), head_dim=self.dh)
             y1 = K.gemm(sa, L["sa_o"].w16, bias=L["sa_o"].b, residual=x32, out_dtype=F32, drop=self.D(p + ".drop1"))
-            x1_32, x1_16, mean1, rstd1 = K.layernorm_fwd(y1, self.P(p + ".norm1.weight"), self.P(p + ".norm1.bias"))
+            x1_32, x1_16, mean1, rstd1 = self._ln(y1, self.P(p + ".norm1.weight"), self.P(p + ".norm1.bias"))
             ca_w, ca_b = L["ca"].w16, L["ca"].b
             qc = K.gemm(x1_16, ca_w[:d], bias=ca_b[:d])
             kvc = K.gemm(mem16, ca_w[d:], bias=ca_b[d:])
-            ca, lse_c = K.attn_fwd(qc, kvc[:, :d], kvc[:, d:], B, H, T, S, self.scale, drop=self.D(p + ".cattn"))
+            ca, lse_c = K.attn_fwd(qc, kvc[:, :d], kvc[:, d:], B, H, T, S, self.scale, drop=self.D(p + ".cattn"), head_dim=self.dh)
             y2 = K.gemm(ca, L["ca_o"].w16, bias=L["ca_o"].b, residual=x1_32, out_dtype=F32, drop=self.D(p + ".drop2"))
-            x2_32, x2_16, mean2, rstd2 = K.layernorm_fwd(y2, self.P(p + ".norm2.weight"), self.P(p + ".norm2.bias"))
-            u = torch.empty((Md, L["l1"].w16.shape[0]), dtype=BF16, device=dev)
+            x2_32, x2_16, mean2, rstd2 = self._ln(y2, self.P(p + ".norm2.weight"), self.P(p + ".norm2.bias"))
+            u = torch.empty((Md, L["l1"].w16.shape[0]), dtype=self.adt, device=dev)
             h = K.gemm(x2_16, L["l1"].w16, bias=L["l1"].b, act=1, pre_act_out=u, drop=self.D(p + ".ffn"))
             y3 = K.gemm(h, L["l2"].w16, bias=L["l2"].b, residual=x2_32, out_dtype=F32, drop=self.D(p + ".drop3"))
-            x3_32, x3_16, mean3, rstd3 = K.layernorm_fwd(y3, self.P(p + ".norm3.weight"), self.P(p + ".norm3.bias"))
+            x3_32, x3_16, mean3, rstd3 = self._ln(y3, self.P(p + ".norm3.weight"), self.P(p + ".norm3.bias"))
             if save is not None:
                 save.append(dict(x16=x16, qkv=qkv, sa=sa, lse_s=lse_s, y1=y1, mean1=mean1, rstd1=rstd1, x1_16=x1_16, qc=qc, kvc=kvc,
                                  ca=ca, lse_c=lse_c, y2=y2, mean2=mean2, rstd2=rstd2, x2_16=x2_16, u=u, h=h, y3=y3, mean3=mean3,
@@ -299,7 +350,7 @@ class _Engine:
         dec_save: Optional[list] = [] if want_grads else None
         mem16, B, S = self._encoder_fwd(src, enc_save)
         logits = self._decoder_fwd(tgt, mem16, B, S, key_len, dec_save)
-        loss, dlogits = K.cross_entropy(logits, labels.long().reshape(-1), ignore_index=1, want_grad=want_grads)
+        loss, dlogits = K.cross_entropy(logits, labels.long().reshape(-1), ignore_index=1, want_grad=want_grads, grad_dtype=self.adt)
         out = {"loss": loss[0]}
         if return_logits:
             out["logits"] = logits.view(B, T, -1)
@@ -317,79 +368,80 @@ class _Engine:
         # generator
         K.gemm(dlogits, xo16, trans=True, out=G["decoder.generator.weight"])
         K.colsum(dlogits, out=G["decoder.generator.bias"])
-        dx32 = K.gemm(dlogits, self.gen.wt16, out_dtype=F32)
+        dx32 = self._dgrad(dlogits, self.gen, out_dtype=F32)
         dmem32 = None
         for li in range(len(self.dec) - 1, -1, -1):
             L, s = self.dec[li], dec_save[li]
             p = L["p"]
-            dy3_32, dy3_16 = K.layernorm_bwd(dx32, s["y3"], self.P(p + ".norm3.weight"), s["mean3"], s["rstd3"], G[p + ".norm3.weight"],
+            dy3_32, dy3_16 = self._ln_bwd(dx32, s["y3"], self.P(p + ".norm3.weight"), s["mean3"], s["rstd3"], G[p + ".norm3.weight"],
                                              G[p + ".norm3.bias"], G[p + ".linear2.bias"], dx16_drop=self.D(p + ".drop3"))
-            du = K.gemm(dy3_16, L["l2"].wt16, gelu_grad_of=s["u"], drop=self.D(p + ".ffn"), colsum_out=G[p + ".linear1.bias"])
+            du = self._dgrad(dy3_16, L["l2"], gelu_grad_of=s["u"], drop=self.D(p + ".ffn"), colsum_out=G[p + ".linear1.bias"])
             K.gemm(dy3_16, s["h"], trans=True, out=G[p + ".linear2.weight"])
             K.gemm(du, s["x2_16"], trans=True, out=G[p + ".linear1.weight"])
-            dx2_32 = K.gemm(du, L["l1"].wt16, residual=dy3_32, out_dtype=F32)
-            dy2_32, dy2_16 = K.layernorm_bwd(dx2_32, s["y2"], self.P(p + ".norm2.weight"), s["mean2"], s["rstd2"], G[p + ".norm2.weight"],
+            dx2_32 = self._dgrad(du, L["l1"], residual=dy3_32, out_dtype=F32)
+            dy2_32, dy2_16 = self._ln_bwd(dx2_32, s["y2"], self.P(p + ".norm2.weight"), s["mean2"], s["rstd2"], G[p + ".norm2.weight"],
                                              G[p + ".norm2.bias"], G[p + ".multihead_attn.out_proj.bias"], dx16_drop=self.D(p + ".drop2"))
-            dca = K.gemm(dy2_16, L["ca_o"].wt16)
+            dca = self._dgrad(dy2_16, L["ca_o"])
             K.gemm(dy2_16, s["ca"], trans=True, out=G[p + ".multihead_attn.out_proj.weight"])
             dqc = torch.empty_like(s["qc"])
             dkvc = torch.empty_like(s["kvc"])
             gw, gb = G[p + ".multihead_attn.in_proj_weight"], G[p + ".multihead_attn.in_proj_bias"]
             K.attn_bwd(s["qc"], s["kvc"][:, :d], s["kvc"][:, d:], s["ca"], dca, s["lse_c"], dqc, dkvc[:, :d], dkvc[:, d:], B, H, T, S,
-                       self.scale, drop=self.D(p + ".cattn"), bias_grad=gb)
+                       self.scale, drop=self.D(p + ".cattn"), bias_grad=gb, head_dim=self.dh)
             K.gemm(dqc, s["x1_16"], trans=True, out=gw[:d])
             K.gemm(dkvc, mem16, trans=True, out=gw[d:])
-            cat = L["ca"].wt16                                              # [d, 3d]
             if dmem32 is None:
-                dmem32 = K.gemm(dkvc, cat[:, d:], out_dtype=F32)
+                dmem32 = self._dgrad(dkvc, L["ca"], d, None, out_dtype=F32)
             else:
-                K.gemm(dkvc, cat[:, d:], residual=dmem32, out=dmem32)
-            dx1_32 = K.gemm(dqc, cat[:, :d], residual=dy2_32, out_dtype=F32)
-            dy1_32, dy1_16 = K.layernorm_bwd(dx1_32, s["y1"], self.P(p + ".norm1.weight"), s["mean1"], s["rstd1"], G[p + ".norm1.weight"],
+                self._dgrad(dkvc, L["ca"], d, None, residual=dmem32, out=dmem32)
+            dx1_32 = self._dgrad(dqc, L["ca"], None, d, residual=dy2_32, out_dtype=F32)
+            dy1_32, dy1_16 = self._ln_bwd(dx1_32, s["y1"], self.P(p + ".norm1.weight"), s["mean1"], s["rstd1"], G[p + ".norm1.weight"],
                                              G[p + ".norm1.bias"], G[p + ".self_attn.out_proj.bias"], dx16_drop=self.D(p + ".drop1"))
-            dsa = K.gemm(dy1_16, L["sa_o"].wt16)
+            dsa = self._dgrad(dy1_16, L["sa_o"])
             K.gemm(dy1_16, s["sa"], trans=True, out=G[p + ".self_attn.out_proj.weight"])
             dqkv = torch.empty_like(s["qkv"])
             q = s["qkv"]
             K.attn_bwd(q[:, :d], q[:, d:2 * d], q[:, 2 * d:], s["sa"], dsa, s["lse_s"], dqkv[:, :d], dqkv[:, d:2 * d], dqkv[:, 2 * d:],
                        B, H, T, T, self.scale, causal=True, key_len=key_len, drop=self.D(p + ".sattn"),
-                       bias_grad=G[p + ".self_attn.in_proj_bias"])
+                       bias_grad=G[p + ".self_attn.in_proj_bias"], head_dim=self.dh)
             K.gemm(dqkv, s["x16"], trans=True, out=G[p + ".self_attn.in_proj_weight"])
-            dx32 = K.gemm(dqkv, L["sa"].wt16, residual=dy1_32, out_dtype=F32)
-        K.embed_bwd(tgt, dx32, math.sqrt(d), G["decoder.tgt_tok_emb.embedding.weight"], drop=self.D("dec.emb"))
+            dx32 = self._dgrad(dqkv, L["sa"], residual=dy1_32, out_dtype=F32)
+        K.embed_bwd(tgt, dx32, math.sqrt(d), G["decoder.tgt_tok_emb.embedding.weight"], drop=self.D("dec.emb"), f32=self.fp32)
         self._ready("decoder.")
         # encoder
         fin = enc_save[-1]
-        dx32, _ = K.layernorm_bwd(dmem32, fin["x32"], self.P("encoder.layer_norm.weight"), fin["mean"], fin["rstd"],
+        dx32, _ = self._ln_bwd(dmem32, fin["x32"], self.P("encoder.layer_norm.weight"), fin["mean"], fin["rstd"],
                                   G["encoder.layer_norm.weight"], G["encoder.layer_norm.bias"], None, want16=False,
                                   dy_drop=self.D("enc.final"))
         dx16 = None
         for li in range(len(self.enc) - 1, -1, -1):
             L, s = self.enc[li], enc_save[li + 1]
             p = L["p"]
-            dy2_32, dy2_16 = K.layernorm_bwd(dx32, s["y2"], self.P(p + ".norm2.weight"), s["mean2"], s["rstd2"], G[p + ".norm2.weight"],
+            dy2_32, dy2_16 = self._ln_bwd(dx32, s["y2"], self.P(p + ".norm2.weight"), s["mean2"], s["rstd2"], G[p + ".norm2.weight"],
                                              G[p + ".norm2.bias"], G[p + ".linear2.bias"], dx16_drop=self.D(p + ".drop2"))
-            du = K.gemm(dy2_16, L["l2"].wt16, gelu_grad_of=s["u"], drop=self.D(p + ".ffn"), colsum_out=G[p + ".linear1.bias"])
+            du = self._dgrad(dy2_16, L["l2"], gelu_grad_of=s["u"], drop=self.D(p + ".ffn"), colsum_out=G[p + ".linear1.bias"])
             K.gemm(dy2_16, s["h"], trans=True, out=G[p + ".linear2.weight"])
             K.gemm(du, s["x1_16"], trans=True, out=G[p + ".linear1.weight"])
-            dx1_32 = K.gemm(du, L["l1"].wt16, residual=dy2_32, out_dtype=F32)
-            dy1_32, dy1_16 = K.layernorm_bwd(dx1_32, s["y1"], self.P(p + ".norm1.weight"), s["mean1"], s["rstd1"], G[p + ".norm1.weight"],
+            dx1_32 = self._dgrad(du, L["l1"], residual=dy2_32, out_dtype=F32)
+            dy1_32, dy1_16 = self._ln_bwd(dx1_32, s["y1"], self.P(p + ".norm1.weight"), s["mean1"], s["rstd1"], G[p + ".norm1.weight"],
                                              G[p + ".norm1.bias"], G[p + ".self_attn.out_proj.bias"], dx16_drop=self.D(p + ".drop1"))
-            dattn = K.gemm(dy1_16, L["sa_o"].wt16)
+            dattn = self._dgrad(dy1_16, L["sa_o"])
             K.gemm(dy1_16, s["attn"], trans=True, out=G[p + ".self_attn.out_proj.weight"])
             dqkv = torch.empty_like(s["qkv"])
             q = s["qkv"]
             K.attn_bwd(q[:, :d], q[:, d:2 * d], q[:, 2 * d:], s["attn"], dattn, s["lse"], dqkv[:, :d], dqkv[:, d:2 * d], dqkv[:, 2 * d:],
-                       B, H, S, S, self.scale, drop=self.D(p + ".attn"), bias_grad=G[p + ".self_attn.in_proj_bias"])
+                       B, H, S, S, self.scale, drop=self.D(p + ".attn"), bias_grad=G[p + ".self_attn.in_proj_bias"], head_dim=self.dh)
             K.gemm(dqkv, s["x16"], trans=True, out=G[p + ".self_attn.in_proj_weight"])
-            if li == 0:
+            if li == 0 and not self.fp32:
                 dx16 = torch.empty((dqkv.shape[0], d), dtype=BF16, device=dqkv.device)
-            dx32 = K.gemm(dqkv, L["sa"].wt16, residual=dy1_32, out_dtype=F32, aux_bf16_out=dx16 if li == 0 else None,
-                          drop=self.D("enc.pe") if li == 0 else None, drop_after_residual=True)   # layer 0: back through the PE dropout
+            dx32 = self._dgrad(dqkv, L["sa"], residual=dy1_32, out_dtype=F32, aux_bf16_out=dx16,
+                               drop=self.D("enc.pe") if li == 0 else None, drop_after_residual=True)   # layer 0: back through the PE dropout
+            if li == 0 and self.fp32:
+                dx16 = dx32
             self._ready(p + ".")
         head = enc_save[0]
         K.gemm(dx16, head["x0"], trans=True, out=G["encoder.dense_layer.weight"])
-        dx0 = K.gemm(dx16, self.dense.wt16)
+        dx0 = self._dgrad(dx16, self.dense)
         K.gemm(dx0, head["mel16"], trans=True, out=G["project_to_mel.weight"])
         K.colsum(dx0, out=G["project_to_mel.bias"])
         self._ready("encoder.dense_layer.", "encoder.layer_norm.", "project_to_mel.")
@@ -445,7 +497,7 @@ class _Engine:
         pe = self.m.decoder.positional_encoding.pos_embedding[0]
         if Tmax > pe.shape[0]:
             raise ValueError(f"max_length {Tmax} exceeds the positional table ({pe.shape[0]})")
-        caches = [torch.zeros((B, Tmax, 3 * d), dtype=BF16, device=dev) for _ in self.dec]
+        caches = [torch.zeros((B, Tmax, 3 * d), dtype=self.adt, device=dev) for _ in self.dec]
         kvcs = [K.gemm(mem16, L["ca"].w16[d:], bias=L["ca"].b[d:]) for L in self.dec]
         gen = torch.full((B, Tmax), end_token, dtype=torch.long, device=dev)
         gen[:, 0] = start_token
@@ -457,22 +509,22 @@ class _Engine:
 
         def step():
             t = st["t"]
-            x32, x16 = K.embed_pe_fwd(st["tok"], emb, pe.index_select(0, t), scale_e)      # PE row t
+            x32, x16 = self._embed(st["tok"], emb, pe.index_select(0, t), scale_e)         # PE row t
             for L, cache, kvc in zip(self.dec, caches, kvcs):
                 p = L["p"]
                 qkv = K.gemm(x16, L["sa"].w16, bias=L["sa"].b)                             # [B, 3d] of position t
                 cache.index_copy_(1, t, qkv.unsqueeze(1))
                 flat = cache.view(B * Tmax, 3 * d)
-                sa, _ = K.attn_fwd(qkv[:, :d], flat[:, d:2 * d], flat[:, 2 * d:], B, H, 1, Tmax, self.scale, key_len=st["klen"])
+                sa, _ = K.attn_fwd(qkv[:, :d], flat[:, d:2 * d], flat[:, 2 * d:], B, H, 1, Tmax, self.scale, key_len=st["klen"], head_dim=self.dh)
                 y1 = K.gemm(sa, L["sa_o"].w16, bias=L["sa_o"].b, residual=x32, out_dtype=F32)
-                x1_32, x1_16, _, _ = K.layernorm_fwd(y1, self.P(p + ".norm1.weight"), self.P(p + ".norm1.bias"))
+                x1_32, x1_16, _, _ = self._ln(y1, self.P(p + ".norm1.weight"), self.P(p + ".norm1.bias"))
                 qc = K.gemm(x1_16, L["ca"].w16[:d], bias=L["ca"].b[:d])
-                ca, _ = K.attn_fwd(qc, kvc[:, :d], kvc[:, d:], B, H, 1, S, self.scale)
+                ca, _ = K.attn_fwd(qc, kvc[:, :d], kvc[:, d:], B, H, 1, S, self.scale, head_dim=self.dh)
                 y2 = K.gemm(ca, L["ca_o"].w16, bias=L["ca_o"].b, residual=x1_32, out_dtype=F32)
-                x2_32, x2_16, _, _ = K.layernorm_fwd(y2, self.P(p + ".norm2.weight"), self.P(p + ".norm2.bias"))
+                x2_32, x2_16, _, _ = self._ln(y2, self.P(p + ".norm2.weight"), self.P(p + ".norm2.bias"))
                 h = K.gemm(x2_16, L["l1"].w16, bias=L["l1"].b, act=1)
                 y3 = K.gemm(h, L["l2"].w16, bias=L["l2"].b, residual=x2_32, out_dtype=F32)
-                x32, x16, _, _ = K.layernorm_fwd(y3, self.P(p + ".norm3.weight"), self.P(p + ".norm3.bias"))
+                x32, x16, _, _ = self._ln(y3, self.P(p + ".norm3.weight"), self.P(p + ".norm3.bias"))
             logits = K.gemm(x16, self.gen.w16, bias=self.gen.b, out_dtype=F32)
             nxt = torch.where(st["finished"], eos, torch.argmax(logits, dim=-1))
             t.add_(1)
@@ -540,12 +592,20 @@ class ADTModel(PreTrainedModel):
         self.compute_spectrogram = ComputeMelSpectrogram(config.sample_rate, config.win_length, config.time_res, config.n_mels)
         self.project_to_mel = nn.Linear(config.n_mels, int(config.d_query * config.nhead))
         self._engine_obj: Optional[_Engine] = None
+        self._precision: Optional[str] = None          # None: ADT_PRECISION or "bf16"
 
     @property
     def engine(self) -> _Engine:
         if self._engine_obj is None:
-            self._engine_obj = _Engine(self)
+            self._engine_obj = _Engine(self, self._precision)
         return self._engine_obj
+
+    def set_precision(self, precision: str) -> "ADTModel":
+        """``"bf16"`` (throughput default) or ``"fp32"`` (parity arm, see ``_Engine``)."""
+        if precision not in ("bf16", "fp32"):
+            raise ValueError(f"precision must be 'bf16' or 'fp32', not {precision!r}")
+        self._precision, self._engine_obj = precision, None
+        return self
 
     def _apply(self, fn, *a, **k):                 # .to(device) / .float(): parameters are replaced -> rebuild the engine
         r = super()._apply(fn, *a, **k)

@@ -195,9 +195,13 @@ class SynthDrum:
         pitch = int(group)
         if self.ADTOF_mapping:
             pitch = int(random.choice(ADTOF_INVERSE_MAPPING[pitch]))
-        valid = [g for g in self._thr_groups if self.bank.has_cell(pitch, g)]
+        cache = self.__dict__.setdefault("_timbre_cache", {})
+        if pitch not in cache:                                    # the lists the reference rebuilds from the HDF5 file at every pick
+            valid = [g for g in self._thr_groups if self.bank.has_cell(pitch, g)]
+            cache[pitch] = (valid, {g: self.bank.cell_names(pitch, g) for g in valid})
+        valid, names = cache[pitch]
         g = random.choice(valid)
-        name = random.choice(self.bank.cell_names(pitch, g))
+        name = random.choice(names[g])
         return pitch, g, name
 
     def _vel_to_vol(self, velocity):
@@ -212,57 +216,96 @@ class SynthDrum:
             return int(self.config.input_sec * self.config.sample_rate)
         return int(np.float32(end32 * np.float32(self.config.sample_rate)))
 
+    def _pitch_tables(self):
+        """Per-pitch lookups that do not depend on the draws: the instrument's mix volume (synthetiser.py:104-113,151-153)."""
+        if getattr(self, "_gain_of", None) is None:
+            self._gain_of = {p: VOLUME_PER_INSTRUMENT[ADTOF_LABEL[ADTOF_MAPPING[p] if not self.ADTOF_mapping else p]]
+                             for p in range(35, 62) if (p in ADTOF_MAPPING if not self.ADTOF_mapping else p in ADTOF_LABEL)}
+            self._shot_of: dict = {}
+        return self._gain_of, self._shot_of
+
     def plan(self, batch: Sequence[Sequence[Sequence[float]]]) -> MixPlan:
+        """Host half of a batch render.  The only per-note Python work left is what has to stay sequential: the reference's
+        draws from ``random`` in its own order (two timbre picks at a pitch's first note ``:274-281``, then one
+        ``uniform(0, mixup_range)`` per note ``:217`` -- ``uniform(a, b)`` is ``a + (b - a) * random()``, evaluated below
+        for the whole batch at once, and the FX coin after a clip's last note ``:154-155``); every other field of the note
+        records is computed with numpy over all notes of the batch."""
         sr = self.config.sample_rate
-        recs, offs, lens, gains, picks_all, mix_all = [], [0], [], [], [], []
+        sr32, rng_mix = np.float32(sr), float(self.config.mixup_range)
+        rnd, pick = random.random, self.random_choice_timbre
+        gain_of, shot_of = self._pitch_tables()
         use_fx = float(self.config.use_fx_prob) > 0.0
-        fx_recs, boards = [], []
-        for notes in batch:
-            n = len(notes)
-            if n == 0:                                             # synthetiser.py:257-258 (returns before any draw)
-                offs.append(offs[-1]); lens.append(int(self.config.input_sec * sr)); gains.append(0.0)
-                picks_all.append({}); mix_all.append([])
-                fx_recs.append(np.zeros((), FX_DTYPE)); boards.append([])
-                continue
-            a = np.asarray(notes, dtype=np.float32).reshape(n, 4)
-            tracks: dict = {}
+        B = len(batch)
+        arrs = [np.asarray(notes, dtype=np.float32).reshape(-1, 4) for notes in batch]
+        counts = np.fromiter((x.shape[0] for x in arrs), np.int64, B)
+        offs = np.zeros(B + 1, np.int64)
+        np.cumsum(counts, out=offs[1:])
+        a = np.concatenate(arrs) if B else np.zeros((0, 4), np.float32)
+        pit, vel = a[:, 2], a[:, 3]
+        bad = ~((pit >= 35) & (pit <= 61) & (a[:, 1] >= a[:, 0]))
+        if bad.any():
+            raise ValueError(f"Invalid note: {a[int(np.argmax(bad))]}")
+        pl_all = pit.astype(np.int64).tolist()
+        u, main_id, sub_id, track, gain = [], [], [], [], []
+        picks_all, fx_recs, boards = [], [], []
+        for c in range(B):                                         # the sequential part: RNG draws in the reference's order
+            lo, hi = int(offs[c]), int(offs[c + 1])
             picks: dict = {}
-            clip = np.zeros(n, NOTE_DTYPE)
-            mixups = []
-            max_vel = np.float32(0)
-            for i in range(n):
-                onset, offset, pitch, vel = a[i]
-                max_vel = max(max_vel, vel)
-                if not (35 <= pitch <= 61 and offset >= onset):
-                    raise ValueError(f"Invalid note: {a[i]}")
-                p = int(pitch)
-                if p not in picks:
-                    picks[p] = (self.random_choice_timbre(p), self.random_choice_timbre(p))
-                    tracks[p] = len(tracks)
-                m = random.uniform(0, self.config.mixup_range)     # drum_rendering's first statement (:217)
-                mixups.append(m)
-                (mp, mg, mn), (sp, sg, sn) = picks[p]
-                key = ADTOF_MAPPING[p] if not self.ADTOF_mapping else p
-                clip[i] = (int(np.float32(onset) * np.float32(sr)), self.bank.shot_id(mp, mg, mn),
-                           self.bank.shot_id(sp, sg, sn), tracks[p], np.float32(1 - m), np.float32(m),
-                           vel_to_vol(float(vel)), VOLUME_PER_INSTRUMENT[ADTOF_LABEL[key]])
-            clip = clip[np.argsort(clip["track"], kind="stable")]
-            recs.append(clip)
-            offs.append(offs[-1] + n)
-            lens.append(self._clip_length(a))
-            gains.append(float(vel_to_vol(float(max_vel))))
+            if hi == lo:                                           # synthetiser.py:257-258 (returns before any draw)
+                picks_all.append(picks); fx_recs.append(np.zeros((), FX_DTYPE)); boards.append([])
+                continue
+            ids: dict = {}
+            for p in pl_all[lo:hi]:
+                e = ids.get(p)
+                if e is None:
+                    m_, s_ = pick(p), pick(p)
+                    picks[p] = (m_, s_)
+                    for t_ in (m_, s_):
+                        if t_ not in shot_of:
+                            shot_of[t_] = self.bank.shot_id(*t_)
+                    e = ids[p] = (shot_of[m_], shot_of[s_], len(ids), gain_of[p])
+                u.append(rnd())
+                main_id.append(e[0]); sub_id.append(e[1]); track.append(e[2]); gain.append(e[3])
             picks_all.append(picks)
-            mix_all.append(mixups)
-            # instrument_mixer (synthetiser.py:154-155): the FX coin flip comes after every note of the clip has been rendered
             board = []
-            if random.random() < self.config.use_fx_prob:
+            if rnd() < self.config.use_fx_prob:
                 board = draw_board(self.config.use_reverb_prob, self.config.use_compression_prob, self.config.use_limiter_prob)
             boards.append(board)
             fx_recs.append(board_to_record(board))
-        notes_arr = np.concatenate(recs) if recs else np.zeros(0, NOTE_DTYPE)
+        n = a.shape[0]
+        mixups = (0.0 + (rng_mix - 0.0) * np.asarray(u, np.float64))             # random.uniform(0, mixup_range)
+        rec = np.zeros(n, NOTE_DTYPE)
+        rec["start"] = (a[:, 0] * sr32).astype(np.int32)                          # int(onset * sr) in fp32 (synthetiser.py:229)
+        rec["main_shot"], rec["sub_shot"], rec["track"], rec["track_gain"] = main_id, sub_id, track, gain
+        rec["one_minus_mixup"] = (1 - mixups).astype(np.float32)
+        rec["mixup"] = mixups.astype(np.float32)
+        rec["vol"] = self._vols(vel)
+        clip_of = np.repeat(np.arange(B, dtype=np.int64), counts)
+        rec = rec[np.argsort(clip_of * 64 + rec["track"], kind="stable")]         # grouped by track inside each clip (< 64 tracks: 27 pitches)
+        lens = np.full(B, int(self.config.input_sec * sr), np.int64)
+        gains = np.zeros(B, np.float32)
+        live = np.nonzero(counts)[0]
+        if live.size:
+            # int(max(max_offset + 0.1, input_sec) * sr) in the reference's mixed fp32-tensor / Python-float arithmetic (:262-263,243)
+            end32 = np.maximum.reduceat(a[:, 1], offs[live]).astype(np.float32) + np.float32(0.1)
+            longer = ~(np.float32(self.config.input_sec) > end32)
+            lens[live[longer]] = (end32[longer] * sr32).astype(np.float32).astype(np.int64)
+            gains[live] = self._vols(np.maximum(np.float32(0), np.maximum.reduceat(vel, offs[live])))
+        mix_all = [mixups[int(offs[c]):int(offs[c + 1])].tolist() for c in range(B)]
         fx = np.stack(fx_recs).astype(FX_DTYPE) if (use_fx and fx_recs) else None
-        return MixPlan(notes=notes_arr, clip_note_off=np.asarray(offs, np.int32), clip_len=np.asarray(lens, np.int32),
-                       clip_gain=np.asarray(gains, np.float32), picks=picks_all, mixups=mix_all, fx=fx, boards=boards)
+        return MixPlan(notes=rec, clip_note_off=offs.astype(np.int32), clip_len=lens.astype(np.int32),
+                       clip_gain=gains, picks=picks_all, mixups=mix_all, fx=fx, boards=boards)
+
+    @staticmethod
+    def _vols(vel: np.ndarray) -> np.ndarray:
+        """``_vel_to_vol`` (synthetiser.py:204-212) over an array: the table for whole velocities, the scalar law otherwise."""
+        vel = np.asarray(vel, np.float32)
+        whole = (vel == np.floor(vel)) & (vel > 0) & (vel <= 127)
+        vol = np.zeros(vel.shape, np.float32)
+        vol[whole] = _VEL_TABLE[vel[whole].astype(np.int64)]
+        for i in np.nonzero(~whole & (vel != 0))[0]:
+            vol[i] = vel_to_vol(float(vel[i]))
+        return vol
 
     # ---- rendering (GPU) -----------------------------------------------------------
     def render_plan(self, plan: MixPlan, width: Optional[int] = None, out: Optional[torch.Tensor] = None) -> torch.Tensor:

@@ -9,6 +9,7 @@ from __future__ import annotations
 
 from dataclasses import dataclass
 
+import numpy as np
 import torch
 
 from .mapping import ADTOF_MAPPING, GM_TO_CUSTOM
@@ -35,30 +36,44 @@ class MidiTokenizer:
         self.BOS_token, self.EOS_token = config.BOS_token, config.EOS_token
         self.pad_token, self.silence_token = config.pad_token, config.silence_token
         self.add_velocity = config.add_velocity
+        lut = np.full(128, -1, np.int64)                    # GM key -> custom pitch (-> ADTOF class) as one table
+        for k, v in GM_TO_CUSTOM.items():
+            lut[k] = ADTOF_MAPPING[v] if self.ADTOF_mapping else v
+        self._key_lut = lut
 
     def map_notes_to_Gm_custom(self, notes: torch.Tensor, random_velocity: bool = False) -> torch.Tensor:
         """GM key -> custom pitch (-> ADTOF class); optional ``randint(10, 127)`` velocities (midi_tokenizer.py:36-47).
         Modifies and returns ``notes`` like the reference."""
-        keys = [self.GM_standard_midi_to_Gm_custom_map[int(k)] for k in notes[:, 2].tolist()]
-        if self.ADTOF_mapping:
-            keys = [self.ADTOF_map[k] for k in keys]
-        notes[:, 2] = torch.tensor(keys)
+        if notes.shape[0]:
+            src = notes[:, 2].numpy().astype(np.int64)      # int(k): truncation
+            if src.min() < 0 or src.max() > 127 or (self._key_lut[src] < 0).any():
+                raise KeyError(int(src[(src < 0) | (src > 127) | (self._key_lut[src.clip(0, 127)] < 0)][0]))
+            notes[:, 2] = torch.from_numpy(self._key_lut[src])
+        else:
+            notes[:, 2] = torch.tensor([])
         if random_velocity:
             notes[:, 3] = torch.randint(10, 127, (notes.shape[0],))
         return notes
 
     def notes_to_adt_tokens(self, notes, **kwargs) -> torch.Tensor:
         """[BOS, (time, pitch[, velocity])..., EOS] (midi_tokenizer.py:49-64)."""
-        out = [self.BOS_token]
-        for note in notes:
-            onset, _, pitch, velocity = note
-            t = int(onset * 100) + TIME_OFFSET
-            assert t < PITCH_OFFSET, "Time token is out of range"
-            out.extend([t, pitch + PITCH_OFFSET])
-            if self.add_velocity:
-                out.append(velocity + VELOCITY_OFFSET)
-        out.append(self.EOS_token)
-        return torch.tensor(out)
+        a = notes.detach().numpy() if isinstance(notes, torch.Tensor) else np.asarray(notes, dtype=np.float32)
+        a = a.reshape(-1, 4)
+        n = a.shape[0]
+        if n == 0:
+            return torch.tensor([self.BOS_token, self.EOS_token])
+        # int(onset * 100) + 4 on the fp32 element, as the reference's loop over tensor rows computes it
+        t = (a[:, 0].astype(np.float32) * np.float32(100)).astype(np.int64) + TIME_OFFSET
+        assert bool((t < PITCH_OFFSET).all()), "Time token is out of range"
+        per = 3 if self.add_velocity else 2
+        # the reference's list mixes Python ints with 0-dim float tensors (pitch + 300), so torch.tensor() makes it float32
+        out = np.empty(per * n + 2, np.float32)
+        out[0], out[-1] = self.BOS_token, self.EOS_token
+        out[1:-1:per] = t
+        out[2:-1:per] = a[:, 2] + np.float32(PITCH_OFFSET)
+        if self.add_velocity:
+            out[3:-1:per] = a[:, 3] + np.float32(VELOCITY_OFFSET)
+        return torch.from_numpy(out)
 
     def empty_adt_tokens(self) -> torch.Tensor:
         return torch.tensor([self.BOS_token, self.silence_token, self.EOS_token])

@@ -40,7 +40,7 @@ extern "C" {
  * backward entry points regenerate them from the same (p, key).  p == 0 or a null pointer: off. */
 typedef struct adt_dropout { float p; uint32_t key; } adt_dropout;
 
-/* ABI version (6): bumped whenever a signature below changes or entries are added. */
+/* ABI version (7): bumped whenever a signature below changes or entries are added. */
 int adt_version(void);
 
 /* Message of the last failing call on this thread ("" if none). */
@@ -287,6 +287,45 @@ int adt_embed_bwd_operands(const int64_t* tokens, const float* dy, float scale, 
 size_t adt_cross_entropy_workspace_bytes(int64_t M);
 int adt_cross_entropy(const float* logits, int64_t ld, const int64_t* labels, int64_t ignore_index, int64_t M, int64_t V,
                       float* loss, void* dlogits, int64_t ldd, void* ws, size_t ws_bytes, void* stream);
+
+/* ---------------------------------------------------------------------------
+ * fp32-operand parity path (adt_str_amd/csrc/precise.hip)
+ *
+ * BASELINE's parity target -- "logits within 1e-3 rel-tol of the CPU reference" -- is a statement about the reference's
+ * fp32 CPU path (ADTModel.forward, reference model.py:240-258, run without autocast).  The entries below are the fp32
+ * twins of K3-K8: every operand and activation is fp32 and every contraction runs on v_mfma_f32_32x32x2_f32 (exact f32
+ * products, f32 accumulate).  The engine selects them with precision="fp32" (adt_str_amd/network.py); they are the
+ * parity arm, never the throughput default (the f32 MFMA rate is 1/16 of the bf16 rate).
+ *
+ *   adt_gemm_f32   layout bit 0: A is stored [K, M] (else [M, K]); bit 1: B is stored [K, N] (else [N, K]);
+ *                  0 = y = x W^T, 2 = dx = dy W, 3 = dW = dy^T x.  C[M, N] fp32.  Same epilogue struct and order as
+ *                  adt_gemm_bf16 with gelu_grad_of / pre_act_out read and written as fp32; aux_bf16_out and colsum_out
+ *                  must be null (adt_colsum_f32 takes the bias gradients).  The contiguous extent of each operand and
+ *                  lda / ldb are multiples of 4 floats, operands 16-byte aligned.
+ *   adt_attn_fwd_f32 / adt_attn_bwd_f32   adt_attn_fwd / adt_attn_bwd on fp32 q, k, v, o (same descriptor, masks and
+ *                  dropout indices; row strides multiples of 4); the dq/dk/dv_colsum fields must be null.
+ *   adt_colsum_f32        column sums of an fp32 [M, N] matrix, fixed order.
+ *   adt_layernorm_bwd_f32 adt_layernorm_bwd with the branch gradient (dx16 there) written as fp32.
+ *   adt_cross_entropy_f32 adt_cross_entropy with fp32 dlogits and libm exp / log.
+ *   adt_embed_bwd_operands_f32  fp32 one-hot / scaled-gradient operands of dtable = onehot^T . dy (adt_gemm_f32 layout 3).
+ */
+int adt_gemm_f32(int32_t layout, int64_t M, int64_t N, int64_t K, const float* A, int64_t lda, const float* B, int64_t ldb,
+                 float* C, int64_t ldc, const adt_gemm_epilogue* ep, void* stream);
+int adt_attn_fwd_f32(const adt_attn_desc* d, const float* q, const float* k, const float* v, float* o, float* lse, void* stream);
+size_t adt_attn_bwd_f32_workspace_bytes(const adt_attn_desc* d);
+int adt_attn_bwd_f32(const adt_attn_desc* d, const float* q, const float* k, const float* v, const float* o, const float* dout,
+                     const float* lse, float* dq, float* dk, float* dv, void* ws, size_t ws_bytes, void* stream);
+size_t adt_colsum_f32_workspace_bytes(int64_t M, int64_t N);
+int adt_colsum_f32(const float* x, int64_t ld, int64_t M, int64_t N, float* out, void* ws, size_t ws_bytes, void* stream);
+int adt_layernorm_bwd_f32(const float* dy, int64_t lddy, const float* x, int64_t ldx, const float* gamma,
+                          const float* mean, const float* rstd, float* dx32, float* dx_branch, int64_t lddx,
+                          float* dgamma, float* dbeta, float* dxsum, int64_t M, int64_t D,
+                          const adt_dropout* dy_drop, const adt_dropout* branch_drop, void* ws,
+                          size_t ws_bytes, void* stream);
+int adt_cross_entropy_f32(const float* logits, int64_t ld, const int64_t* labels, int64_t ignore_index, int64_t M, int64_t V,
+                          float* loss, float* dlogits, int64_t ldd, void* ws, size_t ws_bytes, void* stream);
+int adt_embed_bwd_operands_f32(const int64_t* tokens, const float* dy, float scale, float* onehot, int64_t ld_onehot, float* dy_scaled,
+                               int64_t n_rows, int64_t D, int64_t vocab, const adt_dropout* drop, void* stream);
 
 /* ---------------------------------------------------------------------------
  * Parameter plumbing for the bf16 compute path: fp32 master weight [rows, cols]

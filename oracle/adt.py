@@ -227,6 +227,16 @@ def greedy_sample(state: State, cfg: dict, src: torch.Tensor, max_length: int = 
     return gen
 
 
+def teacher_forced_logits(state: State, cfg: dict, src: torch.Tensor, tokens: torch.Tensor, bf16=False) -> torch.Tensor:
+    """Decoder logits ``[B, n, V]`` for a given token prefix (causal mask, no padding mask) -- what ``ADTModel.sample``
+    (model.py:300-322) evaluates at each step; lets a test judge a greedy decode produced elsewhere position by position."""
+    nhead = cfg["nhead"]
+    mel = o_logmel.logmel(src, cfg["sample_rate"], cfg["win_length"], cfg["time_res"], cfg["n_mels"])
+    x = linear(mel, state["project_to_mel.weight"], state["project_to_mel.bias"], bf16)
+    memory = encoder(state, x, nhead, n_layers_of(state, "encoder.encoder.layers."), bf16)
+    return decoder(state, tokens, memory, nhead, n_layers_of(state, "decoder.decoder.layers."), causal_mask(tokens.shape[1]), None, bf16)
+
+
 # ----------------------------------------------------------------------------- seeded weights
 def seeded_state(template: State, seed: int) -> State:
     """Portable random init: numpy PCG64 keyed by ``seed``, walked over the

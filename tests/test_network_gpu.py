@@ -94,15 +94,30 @@ def test_autograd_bridge_and_reference_signature():
 
 
 def test_greedy_sample_matches_oracle():
-    model, state, cfg = make_model(1, 1, 2, seed=3)
-    batch = make_batch(3, 8000, 6, 3)
-    src = torch.from_numpy(batch["wavs"])
-    ref = o_adt.greedy_sample(state, cfg, src, max_length=8, bf16=True)
-    got = model.sample(src.to(DEV), None, None, max_length=8).cpu()
-    assert got.shape == ref.shape and got[:, 0].eq(2).all()
-    # argmax ties under bf16 rounding can differ; require agreement wherever the oracle's top-2 margin is clear
-    agree = (got == ref).float().mean().item()
-    assert agree >= 0.9, (got, ref)
+    """a7 on the bf16 path, margin-aware: the oracle (bf16 operands) is teacher-forced on the tokens the GPU produced, and every
+    token of an unfinished row must be the oracle's arg-max or lie within 6e-2 of its maximum (twice the stated bf16 logit
+    tolerance: both candidates can move by 3e-2); finished rows must emit EOS.  Exact identity of the ids is what the fp32
+    path is held to (tests/test_precision_gpu.py)."""
+    for seed in (3, 4):
+        model, state, cfg = make_model(1, 1, 2, seed=seed)
+        batch = make_batch(3, 8000, 6, seed)
+        src = torch.from_numpy(batch["wavs"])
+        ref = o_adt.greedy_sample(state, cfg, src, max_length=8, bf16=True)
+        got = model.sample(src.to(DEV), None, None, max_length=8).cpu()
+        assert got[:, 0].eq(2).all() and 2 <= got.shape[1] <= 8
+        logits = o_adt.teacher_forced_logits(state, cfg, src, got[:, :-1], bf16=True)          # [B, n-1, V]
+        fin = torch.zeros(got.shape[0], dtype=torch.bool)
+        n_tie = 0
+        for t in range(got.shape[1] - 1):
+            tok, row = got[:, t + 1], logits[:, t]
+            best = row.max(dim=-1)
+            chosen = row.gather(1, tok[:, None])[:, 0]
+            ok = torch.where(fin, tok == 3, chosen >= best.values - 6e-2)
+            assert bool(ok.all()), (seed, t, tok, best.indices, best.values - chosen)
+            n_tie += int((~fin & (tok != best.indices)).sum())
+            fin = fin | (tok == 3)
+        if n_tie == 0:                                   # no near-tie was resolved differently: the decodes are the same decode
+            assert got.shape == ref.shape and torch.equal(got, ref)
 
 
 def test_cached_greedy_decode_is_the_full_recompute_decode():
