@@ -82,7 +82,7 @@ SIGNATURES = {
     "adt_cast_bf16_batched": [ptr, i32, i32, ptr],
     "adt_grad_norm_workspace_bytes": [],
     "adt_grad_norm": [ptr, i64, f32, ptr, ptr, C.c_size_t, ptr],
-    "adt_adamw_step": [ptr, ptr, ptr, ptr, ptr, i64, f32, f32, f32, f32, f32, i64, ptr, ptr],
+    "adt_adamw_step": [ptr, ptr, ptr, ptr, ptr, i64, f32, f32, f32, f32, f32, i64, ptr, ptr, i32, ptr],
     "adt_clap_logmel_db_f32": [ptr, ptr, i64, i32, i32, i32, i32, ptr, ptr, ptr, i32, i32, f32, ptr, ptr],
     "adt_htsat_front_f32": [ptr, i64, i64, i32, i32, i32, i32, ptr, ptr, ptr, ptr],
     "adt_htsat_patch_embed": [ptr, i64, i32, ptr, ptr, ptr, ptr, f32, i32, ptr, ptr, ptr],

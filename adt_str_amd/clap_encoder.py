@@ -228,3 +228,21 @@ class ClapWrapper(nn.Module):
 
     def get_text_features(self, text):
         raise NotImplementedError("the text tower is outside the MI355X hot path (the curation pipeline never calls it)")
+
+
+def random_init_clap_model(seed: int = 0):
+    """A ``transformers.ClapModel`` with the architecture of ``laion/clap-htsat-fused`` (fused HTSAT audio tower, ``aff_2d``) and
+    random weights, with non-trivial BatchNorm statistics so the eval-mode affine is exercised.  For benchmarks and end-to-end
+    drivers on machines without the pretrained checkpoint (there is no network here); pass it as ``ClapWrapper(clap_model=...)``."""
+    import torch
+    from transformers import ClapConfig, ClapModel
+    torch.manual_seed(seed)
+    model = ClapModel(ClapConfig(audio_config={"enable_fusion": True, "fusion_type": "aff_2d"})).eval()
+    with torch.no_grad():
+        for m in model.modules():
+            if isinstance(m, torch.nn.BatchNorm2d):
+                m.running_mean.normal_(0.0, 0.5)
+                m.running_var.uniform_(0.5, 2.0)
+                m.weight.normal_(1.0, 0.1)
+                m.bias.normal_(0.0, 0.1)
+    return model

@@ -14,10 +14,10 @@ int device_cu_count(int* n_cu);
 // fx.hip: reverb / compressor / limiter over the un-normalised clips flagged in fx[], then the new clip peaks (mixer.hip calls it)
 int launch_fx_chain(float* wav, long ld, const int32_t* clip_len, const adt_fx_params* fx, int n_clips, int sample_rate, int width,
                     unsigned* clip_peak, hipStream_t st);
-// Work counters of the persistent GEMM on (current device, stream): eight device words (one per XCD group, 64 bytes apart) that
-// only ever count up.  base[x] is the value counter x will have when the launch being prepared starts; the call reserves
-// fetches[x] increments of it for that launch.
-int sched_counters(void* stream, const unsigned (&fetches)[8], unsigned** counters, unsigned (&base)[8]);
+// Work counters of the persistent GEMMs on (current device, stream): eight device words, one per XCD group, 64 bytes apart,
+// allocated and zeroed on first use.  They are zero whenever no such kernel runs on the stream: each launch hands out a known
+// number of tickets per counter and the workgroup that draws the last one resets it (gemm.hip), so nothing is tracked here.
+int sched_counters(void* stream, unsigned** counters);
 
 // nn_ops.hip: out[c] = sum over the n_part rows of partial[n_part][width] (fixed order)
 void launch_reduce_partials(const float* partial, int n_part, int width, float* out, hipStream_t st);

@@ -38,10 +38,9 @@ int device_cu_count(int* n_cu) {
   return ADT_OK;
 }
 
-int sched_counters(void* stream, const unsigned (&fetches)[8], unsigned** counters, unsigned (&base)[8]) {
-  struct Slot { unsigned* dev_words; unsigned next[8]; };
+int sched_counters(void* stream, unsigned** counters) {
   static std::mutex mu;
-  static std::map<std::pair<int, void*>, Slot> slots;
+  static std::map<std::pair<int, void*>, unsigned*> slots;
   int dev = 0;
   ADT_HIP_TRY(hipGetDevice(&dev));
   std::lock_guard<std::mutex> lock(mu);
@@ -52,13 +51,9 @@ int sched_counters(void* stream, const unsigned (&fetches)[8], unsigned** counte
     ADT_HIP_TRY(hipMalloc(&w, 512));
     ADT_HIP_TRY(hipMemset(w, 0, 512));
     ADT_HIP_TRY(hipDeviceSynchronize());
-    it = slots.emplace(key, Slot{w, {0, 0, 0, 0, 0, 0, 0, 0}}).first;
+    it = slots.emplace(key, w).first;
   }
-  *counters = it->second.dev_words;
-  for (int x = 0; x < 8; ++x) {
-    base[x] = it->second.next[x];
-    it->second.next[x] += fetches[x];   // wraps mod 2^32 exactly like the device counter
-  }
+  *counters = it->second;
   return ADT_OK;
 }
 

@@ -97,7 +97,7 @@ struct GemmArgs {
   float* colsum_ws;             // 256^2 NT kernel: column sums of each 128-row band of the output, [ceil(M/256)*2][N]
   adt_gemm_epilogue ep;
   Drop drop;
-  unsigned* sched; unsigned sched_base[8];   // persistent NT kernel: per-XCD-group work counters (16 words apart) and their values at launch
+  unsigned* sched; unsigned sched_total[8];  // persistent kernels: per-XCD-group work counters (16 words apart, zero between launches) and the number of tickets each hands out in this launch
 };
 
 // ---- global -> register staging (4 x 16 B per thread per operand) -----------------------------
@@ -511,13 +511,27 @@ constexpr int kBigStage = 2 * kBigBuf;               // 131,072 B of operand sta
 constexpr int kEpi2Bytes = 16 * 64 * 4;              // per wave: 16 x 64 fp32 transposition tile (XOR-swizzled, no padding)
 constexpr int kBigLds = kBigStage + 8 * kEpi2Bytes;  // 163,840 B = the whole LDS of a CU
 
+// Work-counter tickets of the persistent kernels (protocol: comment of gemm_nt_256_kernel).
+__device__ __forceinline__ void ticket_drawn(unsigned* counter, unsigned ticket, unsigned total) {
+  if (ticket + 1u == total) __hip_atomic_store(counter, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // the launch's last draw: ready for the next launch
+}
+__device__ __forceinline__ unsigned take_ticket(unsigned* counter, unsigned total) {
+  const unsigned t = __hip_atomic_fetch_add(counter, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  ticket_drawn(counter, t, total);
+  return t;
+}
+
 #define ADT_DS_READ_B128(dst, addr, imm) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(dst) : "v"(addr), "i"(imm))
 
 // Persistent: one workgroup per CU.  The tiles are cut into eight contiguous slices (row-major over the tile grid), slice x
 // is worked off by the workgroups with blockIdx.x % 8 == x -- the ones that share an XCD and its L2 -- which take tiles
 // from the slice's device work counter: dynamic, so a CU held by another stream's kernel (an RCCL all-reduce under DDP)
-// delays no tile.  The counters only count up: the host passes the values they have at launch (sched_base), a block ends
-// on its first fetch >= its slice's size.  The fetch for the next tile is issued by thread 0 before the K loop and handed
+// delays no tile.  A block ends on its first ticket >= its slice's size, so a launch draws a known number of tickets from
+// each counter (tiles of the slice + one ending ticket per workgroup of the slice: sched_total); whoever draws the LAST one
+// puts the counter back to zero -- every other draw has happened by then, and the next launch on the stream starts after this
+// one has finished.  The protocol is therefore self-contained: nothing on the host tracks the counters, a failed launch leaves
+// them untouched, and tickets are compared unsigned, so a counter that is off for any reason ends workgroups instead of sending
+// them to tiles outside the matrix.  The fetch for the next tile is issued by thread 0 before the K loop and handed
 // over through the one staging slot the prologue DMAs do not touch (A_1 of buffer 1).
 // After a tile's K loop the staging buffers are free, so the NEXT tile's first seven half-tile
 // DMAs are issued before this tile's epilogue, which works from a separate 32 KiB of wave-private LDS: the epilogue's
@@ -539,7 +553,7 @@ __global__ __launch_bounds__(kBigThreads) void gemm_nt_256_kernel(GemmArgs g, in
   const int xg = blockIdx.x & 7;
   const int slice0 = xg < r8 ? xg * (q8 + 1) : r8 * (q8 + 1) + (xg - r8) * q8, slice_n = q8 + (xg < r8 ? 1 : 0);
   unsigned* const counter = g.sched + xg * 16;
-  const unsigned cbase = g.sched_base[xg];
+  const unsigned ctotal = g.sched_total[xg];
   auto set_tile = [&](int v, int& m0, int& n0) {
     const int logical = slice0 + v;
     m0 = (logical / tiles_n) * kBig;
@@ -582,10 +596,10 @@ __global__ __launch_bounds__(kBigThreads) void gemm_nt_256_kernel(GemmArgs g, in
   float* ct = reinterpret_cast<float*>(smem + kBigStage + wave * kEpi2Bytes);
 
   unsigned* const flag = reinterpret_cast<unsigned*>(smem + kBigBuf + kHalfTile);
-  if (tid == 0) *flag = __hip_atomic_fetch_add(counter, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - cbase;
+  if (tid == 0) *flag = take_ticket(counter, ctotal);
   __syncthreads();
   int v = static_cast<int>(*flag), m0, n0;
-  if (v >= slice_n) return;                             // block-uniform (the slice is already handed out)
+  if (static_cast<unsigned>(v) >= static_cast<unsigned>(slice_n)) return;   // block-uniform (the slice is already handed out)
   __syncthreads();
   set_tile(v, m0, n0);
   prologue_dma();
@@ -679,11 +693,11 @@ __global__ __launch_bounds__(kBigThreads) void gemm_nt_256_kernel(GemmArgs g, in
     asm volatile("s_barrier" ::: "memory");            // every DMA has landed and every fragment read is done: staging is free
 
     const int em0 = m0;
-    if (tid == 0) *flag = v_next - cbase;
+    if (tid == 0) { ticket_drawn(counter, v_next, ctotal); *flag = v_next; }
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     asm volatile("s_barrier" ::: "memory");
     v = static_cast<int>(*flag);
-    const bool more = v < slice_n;                      // block-uniform
+    const bool more = static_cast<unsigned>(v) < static_cast<unsigned>(slice_n);   // block-uniform
     if (more) {
       set_tile(v, m0, n0);
       prologue_dma();                                   // flies under the epilogue below
@@ -882,7 +896,7 @@ __global__ __launch_bounds__(kBigThreads) void gemm_tn_256_kernel(GemmArgs g, in
   const int xg = blockIdx.x & 7;
   const int slice0 = xg < r8 ? xg * (q8 + 1) : r8 * (q8 + 1) + (xg - r8) * q8, slice_n = q8 + (xg < r8 ? 1 : 0);
   unsigned* const counter = g.sched + xg * 16;
-  const unsigned cbase = g.sched_base[xg];
+  const unsigned ctotal = g.sched_total[xg];
   int k_tiles = 0;                     // K-tiles of the current item
   auto set_item = [&](int v, int& m0, int& n0, int& split) {
     const int logical = slice0 + v;              // split-major: an XCD slice holds neighbouring tiles of ONE K range (they share
@@ -948,10 +962,10 @@ __global__ __launch_bounds__(kBigThreads) void gemm_tn_256_kernel(GemmArgs g, in
   }
 
   unsigned* const flag = reinterpret_cast<unsigned*>(smem + kBigBuf + kHalfTile);
-  if (tid == 0) *flag = __hip_atomic_fetch_add(counter, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - cbase;
+  if (tid == 0) *flag = take_ticket(counter, ctotal);
   __syncthreads();
   int v = static_cast<int>(*flag), m0, n0, split;
-  if (v >= slice_n) return;
+  if (static_cast<unsigned>(v) >= static_cast<unsigned>(slice_n)) return;
   __syncthreads();
   set_item(v, m0, n0, split);
   prologue_dma();
@@ -1025,11 +1039,11 @@ __global__ __launch_bounds__(kBigThreads) void gemm_tn_256_kernel(GemmArgs g, in
     asm volatile("s_barrier" ::: "memory");
 
     const int em0 = m0, en0 = n0, esplit = split;
-    if (tid == 0) *flag = v_next - cbase;
+    if (tid == 0) { ticket_drawn(counter, v_next, ctotal); *flag = v_next; }
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     asm volatile("s_barrier" ::: "memory");
     v = static_cast<int>(*flag);
-    const bool more = v < slice_n;
+    const bool more = static_cast<unsigned>(v) < static_cast<unsigned>(slice_n);
     if (more) {
       set_item(v, m0, n0, split);
       prologue_dma();
@@ -1208,7 +1222,12 @@ extern "C" int adt_gemm_bf16(int32_t trans, int64_t M, int64_t N, int64_t K, con
     if (!ws || !aligned16(ws) || ws_bytes < adt_gemm_colsum_workspace_bytes(M, N))
       return set_error(ADT_EINVAL, "adt_gemm_bf16: workspace too small (see adt_gemm_colsum_workspace_bytes)");
   }
-  if (trans && vector_epilogue_ok(g, e) && M >= 8 && N >= 8) {
+  // The persistent kernels share one set of work counters per (device, stream) and allocate it on first use: under stream
+  // capture (a graph may be replayed on any stream, concurrently with itself) they are not used; the tiled kernels are.
+  hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+  if (st != nullptr && hipStreamIsCapturing(st, &cap) != hipSuccess) { (void)hipGetLastError(); cap = hipStreamCaptureStatusNone; }
+  const bool persistent_ok = cap == hipStreamCaptureStatusNone;
+  if (trans && persistent_ok && vector_epilogue_ok(g, e) && M >= 8 && N >= 8) {
     int n_cu = 0, per = 0;
     if (int rc = device_cu_count(&n_cu)) return rc;
     const bool plain = e.out_fp32 && !e.bias && !e.residual && !e.act && !e.pre_act_out && !e.gelu_grad_of && !e.aux_bf16_out && e.drop.p <= 0.f && !(N & 3);
@@ -1222,10 +1241,9 @@ extern "C" int adt_gemm_bf16(int32_t trans, int64_t M, int64_t N, int64_t K, con
       const int tm = static_cast<int>((M + kBig - 1) / kBig), tn = static_cast<int>((N + kBig - 1) / kBig);
       const long items = static_cast<long>(tm) * tn * sb;
       const dim3 g1(static_cast<unsigned>(items < n_cu ? items : n_cu));
-      unsigned fetches[8];
-      for (int x = 0; x < 8; ++x)
-        fetches[x] = static_cast<unsigned>(items / 8 + (x < items % 8 ? 1 : 0)) + g1.x / 8 + (static_cast<unsigned>(x) < g1.x % 8 ? 1u : 0u);
-      if (int rc = sched_counters(stream, fetches, &g.sched, g.sched_base)) return rc;
+      for (int x = 0; x < 8; ++x)        // per slice: one ticket per work item + the ending ticket of each of its workgroups
+        g.sched_total[x] = static_cast<unsigned>(items / 8 + (x < items % 8 ? 1 : 0)) + g1.x / 8 + (static_cast<unsigned>(x) < g1.x % 8 ? 1u : 0u);
+      if (int rc = sched_counters(stream, &g.sched)) return rc;
       hipLaunchKernelGGL(gemm_tn_256_kernel, g1, dim3(kBigThreads), kBigLds, st, g, tm, tn, sb);
       if (sb > 1) {
         const long mn = static_cast<long>(M) * N;
@@ -1269,16 +1287,15 @@ extern "C" int adt_gemm_bf16(int32_t trans, int64_t M, int64_t N, int64_t K, con
   } else if (trans) {
     if (g.drop.on()) return set_error(ADT_EINVAL, "adt_gemm_bf16: dropout is not supported with trans = 1");
     hipLaunchKernelGGL((gemm_bf16_kernel<true, false>), grid, dim3(kGemmThreads), kGemmLds, st, g);
-  } else if (use_big_tile(M, N, K) && vector_epilogue_ok(g, e)) {
+  } else if (persistent_ok && use_big_tile(M, N, K) && vector_epilogue_ok(g, e)) {
     const int tm = static_cast<int>((M + kBig - 1) / kBig), tn = static_cast<int>((N + kBig - 1) / kBig);
     int n_cu = 0;
     if (int rc = device_cu_count(&n_cu)) return rc;
     const long nt = static_cast<long>(tm) * tn;
     const dim3 g1(static_cast<unsigned>(nt < n_cu ? nt : n_cu));          // persistent: one workgroup per CU
-    unsigned fetches[8];                 // per slice: one fetch per tile + the ending fetch of each of its workgroups
-    for (int x = 0; x < 8; ++x)
-      fetches[x] = static_cast<unsigned>(nt / 8 + (x < nt % 8 ? 1 : 0)) + g1.x / 8 + (static_cast<unsigned>(x) < g1.x % 8 ? 1u : 0u);
-    if (int rc = sched_counters(stream, fetches, &g.sched, g.sched_base)) return rc;
+    for (int x = 0; x < 8; ++x)          // per slice: one ticket per tile + the ending ticket of each of its workgroups
+      g.sched_total[x] = static_cast<unsigned>(nt / 8 + (x < nt % 8 ? 1 : 0)) + g1.x / 8 + (static_cast<unsigned>(x) < g1.x % 8 ? 1u : 0u);
+    if (int rc = sched_counters(stream, &g.sched)) return rc;
     if (e.colsum_out) {
       g.colsum_ws = static_cast<float*>(ws);
       if (g.drop.on()) hipLaunchKernelGGL((gemm_nt_256_kernel<true, true>), g1, dim3(kBigThreads), kBigLds, st, g, tm, tn);

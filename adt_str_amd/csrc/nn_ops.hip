@@ -540,11 +540,19 @@ __global__ __launch_bounds__(256) void gradnorm_finish_kernel(const float* __res
   }
 }
 struct AdamArgs { float* p; const float* g; float* m; float* v; unsigned short* p16; long n; float lr, beta1, beta2, eps, wd;
-                  float bc1, bc2; const float* clip; };
+                  float bc1, bc2; const float* clip; const long* nodecay; int n_nodecay; };
 __global__ __launch_bounds__(256) void adamw_kernel(AdamArgs a) {
   const long i = (static_cast<long>(blockIdx.x) * 256 + threadIdx.x) * 4;
   if (i >= a.n) return;
   const float clip = a.clip ? a.clip[1] : 1.0f;
+  // weight decay is skipped inside the sorted, disjoint ranges nodecay[r] = [lo, hi) (biases and LayerNorm weights:
+  // HF Trainer.get_decay_parameter_names); range bounds are multiples of 4, so the lane's 4 elements share the answer
+  float wd = a.wd;
+  if (a.n_nodecay > 0) {
+    int lo = 0, hi = a.n_nodecay;                       // first range with hi > i
+    while (lo < hi) { const int mid = (lo + hi) >> 1; if (a.nodecay[2 * mid + 1] > i) hi = mid; else lo = mid + 1; }
+    if (lo < a.n_nodecay && a.nodecay[2 * lo] <= i) wd = 0.f;
+  }
   float pv[4], gv[4], mv[4], vv[4];
   const int cnt = (a.n - i) >= 4 ? 4 : static_cast<int>(a.n - i);
   if (cnt == 4) {
@@ -558,7 +566,7 @@ __global__ __launch_bounds__(256) void adamw_kernel(AdamArgs a) {
 #pragma unroll
   for (int j = 0; j < 4; ++j) {
     const float gr = gv[j] * clip;
-    pv[j] *= 1.0f - a.lr * a.wd;                                   // decoupled weight decay (torch AdamW)
+    pv[j] *= 1.0f - a.lr * wd;                                     // decoupled weight decay (torch AdamW)
     mv[j] = a.beta1 * mv[j] + (1.0f - a.beta1) * gr;
     vv[j] = a.beta2 * vv[j] + (1.0f - a.beta2) * gr * gr;
     const float denom = sqrtf(vv[j]) / sqrtf(a.bc2) + a.eps;
@@ -794,12 +802,15 @@ extern "C" int adt_grad_norm(const float* g, int64_t n, float max_norm, float* n
 }
 
 extern "C" int adt_adamw_step(float* p, const float* g, float* m, float* v, void* p_bf16, int64_t n, float lr, float beta1,
-                              float beta2, float eps, float weight_decay, int64_t step, const float* norm_and_clip, void* stream) {
+                              float beta2, float eps, float weight_decay, int64_t step, const float* norm_and_clip,
+                              const int64_t* nodecay_ranges, int32_t n_nodecay, void* stream) {
   if (!p || !g || !m || !v) return set_error(ADT_EINVAL, "adt_adamw_step: null pointer");
-  if (n < 0 || step < 1) return set_error(ADT_EINVAL, "adt_adamw_step: n < 0 or step < 1");
+  if (n < 0 || step < 1 || n_nodecay < 0 || (n_nodecay > 0 && !nodecay_ranges)) return set_error(ADT_EINVAL, "adt_adamw_step: n < 0, step < 1 or bad no-decay ranges");
   if (n == 0) return ADT_OK;
   AdamArgs a{p, g, m, v, static_cast<unsigned short*>(p_bf16), static_cast<long>(n), lr, beta1, beta2, eps, weight_decay,
-             1.0f - powf(beta1, static_cast<float>(step)), 1.0f - powf(beta2, static_cast<float>(step)), norm_and_clip};
+             static_cast<float>(1.0 - pow(static_cast<double>(beta1), static_cast<double>(step))),
+             static_cast<float>(1.0 - pow(static_cast<double>(beta2), static_cast<double>(step))), norm_and_clip,
+             reinterpret_cast<const long*>(nodecay_ranges), n_nodecay};
   hipLaunchKernelGGL(adamw_kernel, dim3(static_cast<unsigned>((n + 1023) / 1024)), dim3(256), 0, ST(stream), a);
   ADT_HIP_TRY(hipGetLastError());
   return ADT_OK;

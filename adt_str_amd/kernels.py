@@ -316,11 +316,17 @@ def grad_norm(g, max_norm, out=None):
     return out
 
 
-def adamw_step(p, g, m, v, step, lr, beta1=0.9, beta2=0.999, eps=1e-8, weight_decay=0.0, norm_and_clip=None, p_bf16=None):
+def adamw_step(p, g, m, v, step, lr, beta1=0.9, beta2=0.999, eps=1e-8, weight_decay=0.0, norm_and_clip=None, p_bf16=None,
+               nodecay=None):
+    """``nodecay``: int64 GPU tensor [n, 2] of sorted flat ranges [lo, hi) (multiples of 4) that get no weight decay."""
     for t in (p, g, m, v):
         assert t.dtype == torch.float32 and t.is_contiguous() and t.numel() == p.numel()
+    n_nd = 0
+    if nodecay is not None:
+        assert nodecay.dtype == torch.int64 and nodecay.dim() == 2 and nodecay.shape[1] == 2 and nodecay.is_contiguous()
+        n_nd = nodecay.shape[0]
     _ffi.call("adt_adamw_step", _ffi.dptr(p), _ffi.dptr(g), _ffi.dptr(m), _ffi.dptr(v), _p(p_bf16), p.numel(), lr, beta1, beta2,
-              eps, weight_decay, step, _p(norm_and_clip), _ffi.current_stream())
+              eps, weight_decay, step, _p(norm_and_clip), _p(nodecay) if n_nd else None, n_nd, _ffi.current_stream())
 
 
 def _attn_desc(B, H, Sq, Sk, q, k, v, o, scale, causal, key_len, mask_value, drop=None, head_dim=128):

@@ -175,6 +175,13 @@ class _Engine:
         self.drop_p = 0.0                # active dropout probability of the current pass (0 in eval)
         self.drop_seed = 0               # changes every training step; masks are regenerated from it in the backward
         self._sites: Dict[str, int] = {}
+        self.generation = 0              # bumped by every pass that writes the gradient buffers (see _ADTLossFn.backward)
+
+    def seed_dropout(self, seed: int, rank: int = 0):
+        """Start the per-step dropout counter from a value derived from (experiment seed, data-parallel rank): ranks draw
+        different masks (as nn.Dropout does under DDP), a different seed gives a different run, and a checkpoint that stores
+        ``drop_seed`` resumes the sequence instead of replaying it from step 1."""
+        self.drop_seed = K.mix32(K.mix32(int(seed)) ^ ((int(rank) + 1) * 0x9E3779B9 & 0xFFFFFFFF)) & 0x3FFFFFFF
 
     def D(self, site: str):
         """(p, key) of a named dropout site for the current step, or None when dropout is off."""
@@ -357,6 +364,7 @@ class _Engine:
             out["memory"] = mem16
         if not want_grads:
             return out
+        self.generation += 1
         self._backward(dlogits, mem16, B, S, key_len, enc_save, dec_save)
         return out
 
@@ -569,12 +577,16 @@ class _ADTLossFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, engine, src, tgt, pad_mask, labels, *params):
         out = engine.loss_and_grads(src, tgt, pad_mask, labels, want_grads=True)
-        ctx.engine = engine
+        ctx.engine, ctx.generation = engine, engine.generation
         return out["loss"].clone()
 
     @staticmethod
     def backward(ctx, g):
         eng = ctx.engine
+        if ctx.generation != eng.generation:
+            raise RuntimeError("the engine's gradient buffers were overwritten by a later forward pass before this loss was "
+                               "back-propagated (two forwards, then backward): call backward() right after each forward, as "
+                               "HF Trainer.training_step does")
         grads = tuple(eng.G[name] * g for name in eng.named)
         return (None, None, None, None, None) + grads
 

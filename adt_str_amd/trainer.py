@@ -1,38 +1,124 @@
-"""Training step for the ADT network on one GPU per process.
+"""Training loop for the ADT network, one GPU per process.
 
-Mirrors what HF ``Trainer`` does for the reference (``train.py:163-250``:
-AdamW ``adamw_torch``, ``weight_decay`` 1e-5, ``max_grad_norm`` 1.0, warm-up +
-cosine schedule, data-parallel gradient averaging) with an MI355X-first layout:
+Mirrors what HF ``Trainer`` does for the reference (``train.py:163-250``: AdamW ``adamw_torch`` with HF's decay /
+no-decay parameter groups, ``weight_decay`` 1e-5, ``max_grad_norm`` 1.0, warm-up + cosine schedule, data-parallel
+gradient averaging, ``save_steps`` / ``save_total_limit`` / ``resume_from_checkpoint`` ``:179-190,228-232,319-323``)
+with an MI355X-first layout:
 
-  * parameters, gradients and both Adam moments are single flat fp32 buffers
-    (288 GB of HBM: no reason to keep 132 small tensors) -- one fused
-    clip + AdamW launch, no per-parameter loop;
-  * data parallelism = one ``all_reduce`` per finished segment of the flat gradient
-    buffer (decoder, then each encoder layer), issued from the backward pass as
-    soon as the segment is final so RCCL's xGMI traffic overlaps the remaining
-    backward kernels; constants (PE tables, Hann window, mel filterbank) are never
-    broadcast (the reference's DDP re-broadcasts them every forward);
-  * the global gradient norm and the clip factor stay on the device (no ``.item()``
-    per step; the reference syncs the host every step through ``logging_steps: 1``).
+  * parameters, gradients and both Adam moments are single flat fp32 buffers (288 GB of HBM: no reason to keep
+    132 small tensors) -- one fused clip + AdamW launch, no per-parameter loop;
+  * data parallelism = one ``all_reduce`` per finished segment of the flat gradient buffer (decoder, then each
+    encoder layer), issued from the backward pass as soon as the segment is final so RCCL's xGMI traffic overlaps
+    the remaining backward kernels; constants (PE tables, Hann window, mel filterbank) are never broadcast (the
+    reference's DDP re-broadcasts them every forward);
+  * the global gradient norm and the clip factor stay on the device, the loss is read back asynchronously (the
+    reference syncs the host every step through ``logging_steps``);
+  * the host half of a batch (note mapping, tokenising, mixer planning) runs one batch ahead on a background
+    thread (``data.Prefetcher``), where the reference uses up to 16 DataLoader worker processes (``train.py:235-238``).
 """
 from __future__ import annotations
 
+import collections
+import glob
+import json
 import math
-from typing import Optional
+import os
+import random
+import re
+import shutil
+from typing import Callable, Optional
 
 import torch
 import torch.distributed as dist
+import torch.nn as nn
 
 from . import kernels as K
-from .network import ADTModel
+from .data import Prefetcher
+
+
+# ----------------------------------------------------------------------------- schedules (HF optimization.py)
+def lr_multiplier(kind: str, step: int, total_steps: int, warmup_steps: int, min_ratio: float = 0.0) -> float:
+    """LR multiplier HF's ``LambdaLR`` applies at optimizer step ``step`` (0-based count of steps already taken):
+    ``cosine`` = ``get_cosine_schedule_with_warmup``; ``cosine_warmup_with_min_lr`` = ``get_cosine_with_min_lr_schedule_with_warmup_lr_rate``
+    (what ``create_training_arguments`` selects when ``min_learning_rate`` is set, train.py:239-244); ``linear``, ``constant``,
+    ``constant_with_warmup`` as in HF."""
+    if kind == "cosine":
+        if step < warmup_steps:
+            return float(step) / float(max(1, warmup_steps))
+        prog = float(step - warmup_steps) / float(max(1, total_steps - warmup_steps))
+        return max(0.0, 0.5 * (1.0 + math.cos(math.pi * 0.5 * 2.0 * prog)))
+    if kind == "cosine_warmup_with_min_lr":
+        s, w, t = float(step), float(warmup_steps), float(total_steps)
+        if s < w:
+            return (s + 1.0) / max(1.0, w)
+        prog = (s - w + 1.0) / max(1.0, t - w)
+        factor = 0.5 * (1.0 + math.cos(math.pi * 0.5 * 2.0 * prog))
+        return max(0, factor * (1 - min_ratio) + min_ratio)
+    if kind == "linear":
+        if step < warmup_steps:
+            return float(step) / float(max(1, warmup_steps))
+        return max(0.0, float(total_steps - step) / float(max(1, total_steps - warmup_steps)))
+    if kind == "constant":
+        return 1.0
+    if kind == "constant_with_warmup":
+        return float(step) / float(max(1.0, warmup_steps)) if step < warmup_steps else 1.0
+    raise ValueError(f"unsupported lr_scheduler_type {kind!r}")
 
 
 def cosine_with_warmup(step: int, total_steps: int, warmup_steps: int, min_ratio: float = 0.0) -> float:
-    """LR multiplier of HF ``get_cosine_schedule_with_warmup`` (and its ``min_lr`` variant)."""
-    if step < warmup_steps:
-        return step / max(1, warmup_steps)
-    prog = (step - warmup_steps) / max(1, total_steps - warmup_steps)
-    return min_ratio + (1.0 - min_ratio) * 0.5 * (1.0 + math.cos(math.pi * min(prog, 1.0)))
+    """Kept name: ``lr_multiplier`` of the scheduler the reference's config selects."""
+    return lr_multiplier("cosine_warmup_with_min_lr" if min_ratio > 0 else "cosine", step, total_steps, warmup_steps, min_ratio)
+
+
+_NO_DECAY_PATTERNS = [re.compile(p) for p in (r"bias", r"layernorm", r"rmsnorm", r"(?:^|\.)norm(?:$|\.)", r"_norm(?:$|\.)")]
+
+
+def no_decay_names(model: nn.Module):
+    """Parameter names HF ``Trainer.get_decay_parameter_names`` leaves OUT of the weight-decay group: parameters owned by an
+    ``nn.LayerNorm`` and names matching its forbidden patterns (any ``bias``, ``norm`` path components)."""
+    ln_owned = {id(p) for mod in model.modules() if isinstance(mod, nn.LayerNorm) for p in mod.parameters(recurse=False)}
+    return [name for name, p in model.named_parameters()
+            if id(p) in ln_owned or any(pat.search(name.lower()) for pat in _NO_DECAY_PATTERNS)]
+
+
+def no_decay_ranges(named_parameters, skip) -> torch.Tensor:
+    """Sorted, merged flat ranges [lo, hi) (int64 [n, 2]) of the parameters in ``skip``, for the flat buffer laid out in
+    ``named_parameters`` order."""
+    skip, out, off = set(skip), [], 0
+    for name, p in named_parameters:
+        n = p.numel()
+        if name in skip:
+            if off % 4 or n % 4:
+                raise ValueError(f"{name}: flat range [{off}, {off + n}) is not 4-aligned")
+            if out and out[-1][1] == off:
+                out[-1][1] = off + n
+            else:
+                out.append([off, off + n])
+        off += n
+    return torch.tensor(out, dtype=torch.int64).reshape(-1, 2)
+
+
+# ----------------------------------------------------------------------------- data parallel
+def init_distributed(backend: Optional[str] = None):
+    """One process per GPU: under ``torchrun`` / ``accelerate launch`` (RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* in the
+    environment) bind this process to its GPU and create the process group -- ``nccl`` IS RCCL on ROCm -- BEFORE any other
+    GPU work.  Returns (rank, local_rank, world); a no-op for a single process."""
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank, local = int(os.environ.get("RANK", "0")), int(os.environ.get("LOCAL_RANK", "0"))
+    if world <= 1:
+        return 0, 0, 1
+    if os.environ.get("ADT_SHARE_GPU") == "1":           # debug / one-GPU test boxes only: every rank on GPU 0, gloo transport
+        local, backend = 0, backend or "gloo"
+    if not dist.is_initialized():
+        if torch.cuda.is_available():
+            torch.cuda.set_device(local)
+            be = backend or "nccl"
+            dist.init_process_group(be, **({"device_id": torch.device("cuda", local)} if be == "nccl" else {}))
+        else:
+            dist.init_process_group(backend or "gloo")
+    elif torch.cuda.is_available():
+        torch.cuda.set_device(local)
+    return rank, local, world
 
 
 class GradReducer:
@@ -73,16 +159,23 @@ def backward_segments(engine):
 
 
 class FlatTrainer:
-    def __init__(self, model: ADTModel, lr: float = 1e-4, weight_decay: float = 1e-5, betas=(0.9, 0.999), eps: float = 1e-8,
+    """One optimisation step = ``grad_accum`` micro-steps of ``ADTTrainer.compute_loss`` (train.py:40-78) + backward, then
+    (data-parallel mean) + global-norm clip + AdamW on the flat buffers, with HF's schedule and decay groups."""
+
+    def __init__(self, model, lr: float = 1e-4, weight_decay: float = 1e-5, betas=(0.9, 0.999), eps: float = 1e-8,
                  max_grad_norm: float = 1.0, total_steps: int = 1000, warmup_ratio: float = 0.1, min_lr_ratio: float = 0.0,
-                 process_group=None):
+                 process_group=None, scheduler: Optional[str] = None, grad_accum: int = 1, seed: Optional[int] = None):
         self.model, self.eng = model, model.engine
         self.lr, self.wd, self.betas, self.eps, self.max_norm = lr, weight_decay, betas, eps, max_grad_norm
-        self.total_steps, self.warmup = total_steps, int(total_steps * warmup_ratio)
+        self.total_steps = total_steps
+        self.warmup = math.ceil(total_steps * warmup_ratio) if warmup_ratio < 1 else int(warmup_ratio)    # TrainingArguments.get_warmup_steps
         self.min_lr_ratio = min_lr_ratio
+        self.scheduler = scheduler or ("cosine_warmup_with_min_lr" if min_lr_ratio > 0 else "cosine")
+        self.grad_accum, self._micro = max(1, int(grad_accum)), 0
         self.step_no = 0
         self.pg = process_group
         self.world = dist.get_world_size(process_group) if dist.is_available() and dist.is_initialized() else 1
+        self.rank = dist.get_rank(process_group) if self.world > 1 else 0
         named = self.eng.named
         dev = next(iter(named.values())).device
         n = sum(p.numel() for p in named.values())
@@ -96,7 +189,11 @@ class FlatTrainer:
         self.m = torch.zeros_like(self.pflat)
         self.v = torch.zeros_like(self.pflat)
         self.gflat, _ = self.eng.grad_buffers()
+        self.gacc = torch.zeros_like(self.pflat) if self.grad_accum > 1 else None
         self.norm = torch.zeros(2, dtype=torch.float32, device=dev)
+        self.nodecay = no_decay_ranges(named.items(), no_decay_names(model)).to(dev)
+        if seed is not None:
+            self.eng.seed_dropout(seed, self.rank)
         self.reducer = None
         if self.world > 1:
             self.broadcast_parameters()
@@ -111,10 +208,11 @@ class FlatTrainer:
 
     # ---- one optimisation step ----------------------------------------------------------
     def current_lr(self) -> float:
-        return self.lr * cosine_with_warmup(self.step_no, self.total_steps, self.warmup, self.min_lr_ratio)
+        return self.lr * lr_multiplier(self.scheduler, self.step_no, self.total_steps, self.warmup, self.min_lr_ratio)
 
-    def train_step(self, wavs, tokens, token_lengths):
-        """``ADTTrainer.compute_loss`` (train.py:40-78) + backward + clip + AdamW.  Returns the loss (device scalar)."""
+    def micro_step(self, wavs, tokens, token_lengths):
+        """Forward + backward of one micro-batch; every ``grad_accum``-th call also applies the update.  Returns the loss
+        (device scalar)."""
         self.model.train()
         tgt_in, labels = tokens[:, :-1], tokens[:, 1:]
         T = tgt_in.shape[1]
@@ -122,34 +220,199 @@ class FlatTrainer:
         out = self.eng.loss_and_grads(wavs, tgt_in, pad, labels, want_grads=True)
         if self.reducer is not None:
             self.reducer.finish()
+        self._micro += 1
+        if self.grad_accum > 1:
+            self.gacc.add_(self.gflat)
+            if self._micro < self.grad_accum:
+                return out["loss"]
+            self.gflat.copy_(self.gacc).mul_(1.0 / self.grad_accum)       # HF scales each micro-batch loss by 1 / accumulation steps
+            self.gacc.zero_()
+        self._micro = 0
         K.grad_norm(self.gflat, self.max_norm, out=self.norm)
         lr = self.current_lr()
         self.step_no += 1
         K.adamw_step(self.pflat, self.gflat, self.m, self.v, self.step_no, lr, self.betas[0], self.betas[1], self.eps, self.wd,
-                     self.norm)
+                     self.norm, nodecay=self.nodecay)
         self.eng.refresh_weights(force=True)
         return out["loss"]
 
+    def train_step(self, wavs, tokens, token_lengths):
+        """One micro-step (= one optimisation step when ``grad_accum == 1``)."""
+        return self.micro_step(wavs, tokens, token_lengths)
 
-def run_native_training(model: ADTModel, dataset, cfg: dict):
-    """Epoch loop over a ``LakhDataset`` with ``FlatTrainer`` (the native counterpart of ``Trainer.train()``)."""
-    import random
-    t, lg = cfg["training"], cfg["logging"]
+    # ---- checkpoint state ------------------------------------------------------------------
+    def state_dict(self) -> dict:
+        return {"m": self.m.detach().cpu(), "v": self.v.detach().cpu(), "step_no": self.step_no, "drop_seed": self.eng.drop_seed,
+                "total_steps": self.total_steps, "scheduler": self.scheduler}
+
+    def load_state_dict(self, sd: dict):
+        self.m.copy_(sd["m"]); self.v.copy_(sd["v"])
+        self.step_no, self.eng.drop_seed = int(sd["step_no"]), int(sd["drop_seed"])
+        self._micro = 0
+        if self.gacc is not None:
+            self.gacc.zero_()
+        self.eng.refresh_weights(force=True)
+
+
+# ----------------------------------------------------------------------------- checkpoints (HF layout: checkpoint-<step>/)
+def _checkpoint_dirs(output_dir: str):
+    found = []
+    for d in glob.glob(os.path.join(output_dir, "checkpoint-*")):
+        m = re.fullmatch(r"checkpoint-(\d+)", os.path.basename(d))
+        if m and os.path.exists(os.path.join(d, "trainer_state.pt")):
+            found.append((int(m.group(1)), d))
+    return [d for _, d in sorted(found)]
+
+
+def latest_checkpoint(output_dir: str) -> Optional[str]:
+    dirs = _checkpoint_dirs(output_dir)
+    return dirs[-1] if dirs else None
+
+
+def save_model(model: nn.Module, directory: str):
+    """``trainer.save_model()`` (train.py:323): ``model.safetensors`` with the reference's state-dict keys (+ ``config.json`` when
+    the model has an HF config) -- what ``build_model.py`` loads."""
+    from safetensors.torch import save_file
+    os.makedirs(directory, exist_ok=True)
+    save_file({k: v.detach().to("cpu").contiguous().clone() for k, v in model.state_dict().items()}, os.path.join(directory, "model.safetensors"))
+    cfg = getattr(model, "config", None)
+    if cfg is not None and hasattr(cfg, "save_pretrained"):
+        cfg.save_pretrained(directory)
+
+
+def save_checkpoint(output_dir: str, model: nn.Module, trainer, progress: dict, rng_state, rank: int = 0, world: int = 1,
+                    keep: Optional[int] = None) -> str:
+    """Rank 0 writes weights + optimizer state + progress; every rank writes its own host RNG state (the data stream of a rank
+    is a function of it).  ``keep``: ``save_total_limit`` -- older checkpoints are removed."""
+    d = os.path.join(output_dir, f"checkpoint-{trainer.step_no}")
+    if rank == 0:
+        os.makedirs(d, exist_ok=True)
+        save_model(model, d)
+        torch.save({"trainer": trainer.state_dict(), "progress": dict(progress), "world": world}, os.path.join(d, "trainer_state.pt"))
+    if world > 1:
+        dist.barrier()
+    if rng_state is not None:
+        torch.save({"python": rng_state[0], "torch": rng_state[1]}, os.path.join(d, f"rng_state_{rank}.pth"))
+    if rank == 0 and keep:
+        for old in _checkpoint_dirs(output_dir)[:-keep]:
+            shutil.rmtree(old, ignore_errors=True)
+    if world > 1:
+        dist.barrier()
+    return d
+
+
+def load_checkpoint(directory: str, model: nn.Module, trainer, rank: int = 0, world: int = 1) -> dict:
+    """Restore weights (in place: the flat parameter buffer keeps its views), optimizer state and this rank's host RNG state.
+    Returns the saved progress dict."""
+    from safetensors.torch import load_file
+    st = torch.load(os.path.join(directory, "trainer_state.pt"), map_location="cpu", weights_only=False)
+    if st.get("world", 1) != world:
+        raise ValueError(f"checkpoint was written by {st.get('world', 1)} ranks, this run has {world}: the data sharding would differ")
+    weights = load_file(os.path.join(directory, "model.safetensors"))
+    own = dict(model.state_dict())
+    with torch.no_grad():
+        for k, v in weights.items():
+            if k in own:
+                own[k].copy_(v)
+        missing = [k for k, _ in model.named_parameters() if k not in weights]
+    if missing:
+        raise KeyError(f"checkpoint {directory} lacks parameters: {missing[:4]}...")
+    trainer.load_state_dict(st["trainer"])
+    rp = os.path.join(directory, f"rng_state_{rank}.pth")
+    if os.path.exists(rp):
+        r = torch.load(rp, map_location="cpu", weights_only=False)
+        random.setstate(r["python"])
+        torch.set_rng_state(r["torch"])
+    return st["progress"]
+
+
+class _LossLog:
+    """``logging_steps`` without a host stall: the loss is copied to pinned memory asynchronously and printed once it has landed."""
+
+    def __init__(self, every: int, rank: int, total: int, sink: Callable[[str], None] = print):
+        self.every, self.rank, self.total, self.sink = every, rank, total, sink
+        self.pending = collections.deque()
+        self.history = []                       # (step, loss) as printed
+
+    def push(self, step: int, epoch: int, loss: torch.Tensor, lr: float):
+        if not self.every or self.rank != 0 or step % self.every:
+            return
+        if loss.is_cuda:
+            host = torch.empty((), dtype=torch.float32, pin_memory=True)
+            host.copy_(loss.detach().reshape(()), non_blocking=True)
+            ev = torch.cuda.Event()
+            ev.record()
+        else:
+            host, ev = loss.detach().reshape(()).float().clone(), None
+        self.pending.append((step, epoch, host, lr, ev))
+        self.drain(False)
+
+    def drain(self, block: bool = True):
+        while self.pending and (block or self.pending[0][4] is None or self.pending[0][4].query()):
+            step, epoch, host, lr, ev = self.pending.popleft()
+            if ev is not None:
+                ev.synchronize()
+            self.history.append((step, float(host)))
+            self.sink(f"epoch {epoch} step {step}/{self.total} loss {float(host):.4f} lr {lr:.3e}")
+
+
+def run_native_training(model, dataset, cfg: dict, trainer_factory: Optional[Callable] = None, prefetch_depth: int = 2):
+    """Epoch loop over a ``NoteChunkDataset`` with ``FlatTrainer`` -- the native counterpart of ``Trainer.train()`` +
+    ``trainer.save_model()`` (train.py:319-323).  Call ``init_distributed()`` first in a multi-process launch: every rank walks
+    the same per-epoch permutation and takes its stride of it (``DistributedSampler`` semantics).  Honours
+    ``gradient_accumulation_steps``, ``save_every_n_steps``, ``max_checkpoints``, ``resume_from_checkpoint`` / ``auto_resume``."""
+    t, lg, ck = cfg["training"], cfg["logging"], cfg.get("checkpoint", {}) or {}
     world = dist.get_world_size() if dist.is_initialized() else 1
     rank = dist.get_rank() if dist.is_initialized() else 0
-    bs = t["batch_size"]
-    steps_per_epoch = len(dataset) // (bs * world)
-    total = steps_per_epoch * (t["num_epochs"] or 1)
+    bs, accum = t["batch_size"], max(1, int(t.get("gradient_accumulation_steps") or 1))
+    epochs = t["num_epochs"] or 1
+    micro_per_epoch = (len(dataset) // (bs * world * accum)) * accum
+    steps_per_epoch = micro_per_epoch // accum
+    total = steps_per_epoch * epochs
+    if total == 0:
+        raise ValueError(f"dataset of {len(dataset)} chunks is smaller than one global batch ({bs} x {world} ranks x {accum})")
     min_ratio = (t["min_learning_rate"] / t["learning_rate"]) if t.get("min_learning_rate") else 0.0
-    tr = FlatTrainer(model, lr=t["learning_rate"], weight_decay=t["weight_decay"], max_grad_norm=t["max_grad_norm"],
-                     total_steps=total, warmup_ratio=t["warmup_ratio"], min_lr_ratio=min_ratio)
+    sched = "cosine_warmup_with_min_lr" if min_ratio > 0 else t.get("lr_scheduler_type", "cosine")
+    seed = cfg["experiment"]["seed"]
+    factory = trainer_factory or FlatTrainer
+    tr = factory(model, lr=t["learning_rate"], weight_decay=t["weight_decay"], max_grad_norm=t["max_grad_norm"], total_steps=total,
+                 warmup_ratio=t["warmup_ratio"], min_lr_ratio=min_ratio, scheduler=sched, grad_accum=accum, seed=seed)
+    out_dir = lg.get("output_dir") or "./outputs"
+    save_every, keep = lg.get("save_every_n_steps"), ck.get("max_checkpoints")
+    start_epoch, start_micro = 0, 0
+    resume = ck.get("resume_from_checkpoint")
+    if resume is True or (not resume and ck.get("auto_resume")):
+        resume = latest_checkpoint(out_dir)            # the reference globs a name HF never writes (train.py:186); this finds checkpoint-<step>
+    if resume:
+        prog = load_checkpoint(resume, model, tr, rank, world)
+        start_epoch, start_micro = int(prog["epoch"]), int(prog["micro"])
+        if rank == 0:
+            print(f"resumed from {resume}: step {tr.step_no}, epoch {start_epoch}, micro-batch {start_micro}", flush=True)
+    log = _LossLog(lg.get("logging_steps") or 0, rank, total, lambda s: print(s, flush=True))
     order = list(range(len(dataset)))
-    for epoch in range(t["num_epochs"] or 1):
-        random.Random(cfg["experiment"]["seed"] + epoch).shuffle(order)          # same permutation on every rank
-        shard = order[rank::world]
-        for s in range(steps_per_epoch):
-            batch = dataset.collate([dataset[i] for i in shard[s * bs:(s + 1) * bs]])
-            loss = tr.train_step(batch["wavs"], batch["tokens"].to(batch["wavs"].device), batch["token_lengths"])
-            if rank == 0 and lg.get("logging_steps") and (tr.step_no % lg["logging_steps"] == 0):
-                print(f"epoch {epoch} step {tr.step_no}/{total} loss {loss.item():.4f} lr {tr.current_lr():.3e}", flush=True)
+    for epoch in range(start_epoch, epochs):
+        perm = list(order)
+        random.Random(seed + epoch).shuffle(perm)                          # same permutation on every rank
+        shard = perm[rank::world]
+        pf = Prefetcher(lambda s: dataset.host_batch(shard[s * bs:(s + 1) * bs], snapshot_rng=bool(save_every)), micro_per_epoch,
+                        start=start_micro, depth=prefetch_depth)
+        try:
+            for s, hb in zip(range(start_micro, micro_per_epoch), pf):
+                batch = dataset.batcher.upload(hb, device_tokens=True)
+                loss = tr.micro_step(batch["wavs"], batch["tokens"], batch["token_lengths"])
+                if (s + 1) % accum:
+                    continue
+                log.push(tr.step_no, epoch, loss, tr.current_lr())
+                if save_every and tr.step_no % save_every == 0:
+                    nxt = (epoch, s + 1) if s + 1 < micro_per_epoch else (epoch + 1, 0)
+                    save_checkpoint(out_dir, model, tr, {"epoch": nxt[0], "micro": nxt[1]}, hb.rng_state, rank, world, keep)
+        finally:
+            pf.close()
+        start_micro = 0
+    log.drain(True)
+    if rank == 0:
+        save_model(model, out_dir)
+    if world > 1:
+        dist.barrier()
+    tr.loss_history = log.history
     return tr

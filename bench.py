@@ -20,6 +20,14 @@ Workloads (``--workload``):
 The JSON line also carries ``roofline`` (dominant kernel measured live with HIP
 events on the stream it runs on) and, at N = 1, ``cpu_baseline`` (the oracle
 restatement of the same step timed on the host cores on a bounded sample).
+
+``value`` of the train workload is measured with the step's inputs (mixer plans, tokens, one-shot bank) resident in
+HBM, as the contract asks.  The same line carries ``e2e``: the same step fed by the real input pipeline -- synthetic
+note chunks -> ``GpuBatcher.item`` (pitch map, random velocities, tokenise) -> ``SynthDrum.plan`` -> upload -> render
+-> step, nothing pre-planned, host work one batch ahead on a background thread (what ``train.py --native`` runs).
+
+``python bench.py --gpus N`` without ``WORLD_SIZE`` in the environment starts the N ranks itself (a child
+``python -m torch.distributed.run``, spawned before anything touches the GPU) and relays rank 0's JSON line.
 """
 from __future__ import annotations
 
@@ -116,9 +124,8 @@ HTSAT_FLOPS_PER_CLIP = 2 * 5.91e9          # 5.91 GMAC per clip
 
 
 def clap_setup(dev, seed):
-    from adt_str_amd.clap_encoder import ClapWrapper
+    from adt_str_amd.clap_encoder import ClapWrapper, random_init_clap_model
     from adt_str_amd import _ffi
-    from oracle import clap as o_clap         # only for the random-init model factory and the cpu_baseline leg
     B, n_classes = 512, 48
     rng = np.random.default_rng(7 + seed)
     clips = []
@@ -128,7 +135,7 @@ def clap_setup(dev, seed):
         x = np.exp(-t * rng.uniform(5.0, 40.0)) * (rng.standard_normal(n).astype(np.float32) * rng.uniform(0.0, 1.0)
                                                     + np.sin(2 * np.pi * rng.uniform(40.0, 4000.0) * t))
         clips.append(torch.from_numpy((x / np.abs(x).max()).astype(np.float32)).unsqueeze(0))
-    model = o_clap.random_clap_model(0)
+    model = random_init_clap_model(0)
     wrap = ClapWrapper("random-init laion/clap-htsat-fused architecture", dev, 48000, clap_model=model)
     is_longer = torch.zeros(B, dtype=torch.bool)
     is_longer[int(rng.integers(0, B))] = True  # the extractor flags one random clip of an all-short batch
@@ -162,6 +169,7 @@ def clap_setup(dev, seed):
                 "algorithmic_flops_per_launch": fl}
 
     def cpu_baseline(budget_s=20.0):
+        from oracle import clap as o_clap          # the checker, timed as the CPU baseline (the only use of oracle/ here)
         torch.set_num_threads(min(os.cpu_count() or 1, 16))
         nb = 4
         done, t0 = 0, time.perf_counter()
@@ -254,6 +262,35 @@ def train_setup(dev, seed, world, dropout, fx_prob=0.0):
     F = model.compute_spectrogram(wav_buf[:1].zero_()).shape[1]
     flops_clip = train_flops_per_clip(F, T)
 
+    def e2e(steps, warmup, fence):
+        """The same step behind the real input pipeline (nothing pre-planned): note chunks -> item -> plan -> upload -> render ->
+        step, host work one batch ahead on a background thread.  Returns seconds for ``steps`` steps."""
+        from adt_str_amd.data import GpuBatcher, NoteChunkDataset, Prefetcher
+        from adt_str_amd.tokenizer import MidiTokenizer, MidiTokenizerConfig
+        r2 = np.random.default_rng(500 + seed)
+        gm_keys = np.array([35, 36, 38, 40, 41, 42, 43, 44, 45, 46, 47, 48, 49, 50, 51, 53, 57, 59], np.float32)   # GM drum keys
+        rows = []
+        for _ in range(B * (steps + warmup)):
+            n = 42                                                          # 3 * 42 + 2 = 128 tokens per clip
+            onset = np.sort(r2.uniform(0.0, 2.95, n)).astype(np.float32)
+            rows.append(np.stack([onset, onset + np.float32(0.1), r2.choice(gm_keys, n), r2.integers(1, 128, n).astype(np.float32)], 1)
+                        .astype(np.float32).tobytes())
+        tk = MidiTokenizer(MidiTokenizerConfig(ADTOF_mapping=False, BOS_token=2, EOS_token=3, pad_token=1, silence_token=0, add_velocity=True))
+        ds = NoteChunkDataset(rows, GpuBatcher(tk, synth, empty_tokens_percentage=0.05, random_velocity_prob=0.5))
+        pf = Prefetcher(lambda s: ds.host_batch(range(s * B, (s + 1) * B)), steps + warmup, depth=2)
+        t0 = None
+        try:
+            for s, hb in enumerate(pf):
+                if s == warmup:
+                    fence()
+                    t0 = time.perf_counter()
+                batch = ds.batcher.upload(hb, width=L, device_tokens=True)
+                state["loss"] = trainer.train_step(batch["wavs"], batch["tokens"], batch["token_lengths"])
+        finally:
+            pf.close()
+        fence()
+        return time.perf_counter() - t0
+
     def roofline():
         # dominant kernel: the NT bf16 GEMM; measured on the FFN-1 shape of this very step
         M, N, Kd = B * F, 3072, 768
@@ -304,12 +341,28 @@ def train_setup(dev, seed, world, dropout, fx_prob=0.0):
                           "(oracle/adt.py restatement of model.py:240-258)"}
 
     return {"step": step, "units": B, "dtype": "bf16", "roofline": roofline, "cpu_baseline": cpu_baseline, "state": state,
-            "flops_per_step": flops_clip * B,
+            "flops_per_step": flops_clip * B, "e2e": e2e,
             "metric": "ADT training clips/sec (10 s @16 kHz)",
             "config": {"workload": "train config[3]: ADT train step, setting-1 network (69.0M params), per-GPU batch 64 x 10 s @ 16 kHz "
                                    "mixer-rendered clips (F=%d frames), T=128 target tokens, bf16 GEMM/attention with fp32 accumulate, "
                                    "AdamW + clip 1.0, dropout %.2f, use_fx_prob %.2f" % (F, dropout, fx_prob),
                        "global_batch": B * world, "clips_per_gpu": B, "samples": L, "sample_rate": sr, "target_len": T}}
+
+
+def launcher_command(n_ranks: int, port: int, argv):
+    """The driver's own launch line (one rank per GPU of ONE node, rendezvous on 127.0.0.1)."""
+    return [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n_ranks}", "--master-addr", "127.0.0.1",
+            "--master-port", str(port), os.path.abspath(__file__)] + list(argv)
+
+
+def spawn_ranks(n_ranks: int, argv) -> int:
+    import socket
+    import subprocess
+    with socket.socket() as so:
+        so.bind(("127.0.0.1", 0))
+        port = so.getsockname()[1]
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+    return subprocess.call(launcher_command(n_ranks, port, argv), env=env)
 
 
 def main():
@@ -322,13 +375,18 @@ def main():
     ap.add_argument("--fx-prob", type=float, default=0.0, help="use_fx_prob of the mixer (the reference's setting-1 trains with 0.3; SURVEY's "
                                                                  "benchmark configuration is 0)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-e2e", action="store_true", help="skip the end-to-end (real input pipeline) leg of the train workload")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # Not under a launcher: start the N ranks ourselves, as a CHILD process and before this process has touched the GPU
+        # (never exec from a process that has initialised HIP), relay its output, exit with its code.
+        raise SystemExit(spawn_ranks(args.gpus, sys.argv[1:]))
     if args.gpus > 1 and world != args.gpus:
-        raise SystemExit(f"--gpus {args.gpus} needs torch.distributed.run with {args.gpus} ranks (WORLD_SIZE={world})")
+        raise SystemExit(f"--gpus {args.gpus} but the launcher started {world} ranks (WORLD_SIZE={world})")
     assert torch.cuda.is_available(), "bench.py needs a GPU (there is no CPU path)"
     # ADT_BENCH_SHARE_GPU=1 (debug only): every rank on GPU 0 with the gloo backend, to exercise the N > 1 code path on a
     # one-GPU box; numbers from that mode are meaningless and the JSON line says so
@@ -364,6 +422,13 @@ def main():
         tt = torch.tensor([dt], device=dev, dtype=torch.float64)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dt = float(tt.item())
+    dt_e2e = None
+    if "e2e" in wl and not args.no_e2e:
+        dt_e2e = wl["e2e"](args.steps, max(2, args.warmup), fence)
+        if world > 1:
+            tt = torch.tensor([dt_e2e], device=dev, dtype=torch.float64)
+            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+            dt_e2e = float(tt.item())
 
     if rank == 0:
         units = wl["units"] * world * args.steps
@@ -371,6 +436,14 @@ def main():
                 "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
                 "vs_baseline": None, "dtype": wl["dtype"], "data": "synthetic",
                 "config": dict(wl["config"], parallelism=f"dp{world}")}
+        if world > 1:                                    # what the collective library itself reports
+            line["collective"] = {"backend": dist.get_backend(), "world_size": dist.get_world_size()}
+        if dt_e2e is not None:
+            line["e2e"] = {"value": units / dt_e2e, "unit": wl.get("unit", "clips/s"), "ms_per_step": dt_e2e / args.steps * 1e3,
+                           "ratio_to_value": dt / dt_e2e,
+                           "pipeline": "synthetic note chunks (42 notes, GM keys) -> GpuBatcher.item (5 % empty, random velocities, tokenise) -> "
+                                       "SynthDrum.plan -> upload + render -> train step; host work one batch ahead on a background thread; "
+                                       "nothing pre-planned"}
         if "flops_per_step" in wl:
             tf = wl["flops_per_step"] / (dt / args.steps) / 1e12
             line["step_tflops_per_gpu"] = tf

@@ -165,8 +165,10 @@ int adt_mix_render_fx_f32(const float* bank, const int64_t* bank_off, int64_t n_
  * order inside the epilogue, so C is not read again; `ws` must then hold adt_gemm_colsum_workspace_bytes(M, N).
  * Large problems run on persistent kernels that take tiles from device work counters owned by the library: one
  * 512-byte allocation per (device, stream), made on the first large call on that stream (the only allocation this
- * library ever makes; it synchronises the device once).  As for any stream-ordered API, calls that target the same
- * stream must not race each other from different host threads.
+ * library ever makes; it synchronises the device once).  The counters are reset by the kernels themselves (the last
+ * ticket of a launch zeroes its counter), so no host state mirrors them.  While `stream` is being captured into a
+ * HIP graph the persistent kernels are not used (the tiled kernels are: no allocation, no shared counters).  As for
+ * any stream-ordered API, calls that target the same stream must not race each other from different host threads.
  */
 typedef struct adt_gemm_epilogue {
   const float* bias;
@@ -351,11 +353,15 @@ int adt_cast_bf16_batched(const adt_cast_item* items_dev, int32_t n_items, int32
  *                  (1 when max_norm <= 0); both stay on the device.
  *   adt_adamw_step: p, m, v updated in place with g * norm_and_clip[1]
  *                  (norm_and_clip may be null); p_bf16 (optional) = bf16(p).
+ *                  nodecay_ranges (DEVICE int64 [n_nodecay][2], sorted, disjoint, bounds multiples of 4; may be null):
+ *                  flat ranges [lo, hi) that get no weight decay -- biases and LayerNorm weights, the parameters HF
+ *                  Trainer.get_decay_parameter_names leaves out of the decayed group (the reference trains through it).
  */
 size_t adt_grad_norm_workspace_bytes(void);
 int adt_grad_norm(const float* g, int64_t n, float max_norm, float* norm_and_clip, void* ws, size_t ws_bytes, void* stream);
 int adt_adamw_step(float* p, const float* g, float* m, float* v, void* p_bf16, int64_t n, float lr, float beta1,
-                   float beta2, float eps, float weight_decay, int64_t step, const float* norm_and_clip, void* stream);
+                   float beta2, float eps, float weight_decay, int64_t step, const float* norm_and_clip,
+                   const int64_t* nodecay_ranges, int32_t n_nodecay, void* stream);
 
 /* ---------------------------------------------------------------------------
  * K9  CLAP log-mel (dB) feature extractor

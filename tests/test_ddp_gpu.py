@@ -91,6 +91,6 @@ def test_two_rank_step_equals_single_process_mean_gradient_step():
         grads.append(tr.gflat.clone())
     tr.gflat.copy_((grads[0] + grads[1]) * 0.5)
     K.grad_norm(tr.gflat, tr.max_norm, out=tr.norm)
-    K.adamw_step(tr.pflat, tr.gflat, tr.m, tr.v, 1, tr.current_lr(), tr.betas[0], tr.betas[1], tr.eps, tr.wd, tr.norm)
+    K.adamw_step(tr.pflat, tr.gflat, tr.m, tr.v, 1, tr.current_lr(), tr.betas[0], tr.betas[1], tr.eps, tr.wd, tr.norm, nodecay=tr.nodecay)
     ref = tr.pflat.detach().cpu().numpy()
     assert np.abs(ref - p0).max() < 1e-6, np.abs(ref - p0).max()

@@ -187,3 +187,35 @@ def test_randomised_shapes_cover_every_kernel_choice():
         got = k.gemm(a, b, trans=True, out_dtype=torch.float32)
         close(got, ref, 3e-4, f"TN {K}x{M}x{N}")
         assert torch.equal(got, k.gemm(a, b, trans=True, out_dtype=torch.float32)), "split-K slabs are summed in a fixed order"
+
+
+def test_persistent_work_counters_reset_themselves_and_capture_takes_the_tiled_kernels():
+    """The persistent 256^2 kernels draw tiles from device counters that the LAST ticket of each launch puts back to zero
+    (no host mirror): back-to-back launches of different shapes, NT and TN, on one stream stay exact; a GEMM captured into a HIP
+    graph uses the tiled kernels (no shared counters, nothing allocated under capture) and replays with fresh inputs; eager
+    persistent launches keep working afterwards."""
+    from adt_str_amd import kernels as k
+    a, b = rnd((8192, 768), 1).bfloat16(), rnd((3072, 768), 2).bfloat16()           # 32 x 12 tiles: the persistent NT kernel
+    a2, b2 = rnd((4096, 768), 3).bfloat16(), rnd((768, 768), 4).bfloat16()          # 16 x 3 tiles: fewer tiles than CUs
+    ref, ref2 = a.float() @ b.float().t(), a2.float() @ b2.float().t()
+    gw_ref = a.float().t() @ rnd((8192, 1024), 5).bfloat16().float()
+    dy = rnd((8192, 1024), 5).bfloat16()
+    for _ in range(3):
+        close(k.gemm(a, b, out_dtype=torch.float32), ref, 1e-4, "persistent NT")
+        close(k.gemm(a2, b2, out_dtype=torch.float32), ref2, 1e-4, "persistent NT, small grid")
+        close(k.gemm(a, dy, trans=True, out_dtype=torch.float32), gw_ref, 1e-4, "persistent TN")
+    out = torch.empty((8192, 3072), dtype=torch.float32, device=DEV)
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
+        k.gemm(a, b, out=out)                                                      # warm-up on the capture stream
+    torch.cuda.current_stream().wait_stream(side)
+    graph = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(graph):
+        k.gemm(a, b, out=out)
+    for seed in (7, 8, 9):
+        a.copy_(rnd((8192, 768), seed).bfloat16())
+        out.zero_()
+        graph.replay()
+        close(out, a.float() @ b.float().t(), 1e-4, "graph replay")
+    close(k.gemm(a, b, out_dtype=torch.float32), a.float() @ b.float().t(), 1e-4, "persistent NT after the replays")

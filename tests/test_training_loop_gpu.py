@@ -1,0 +1,119 @@
+"""The native training loop on the real kernels (GPU): the fused clip + AdamW step against ``torch.optim.AdamW`` with HF
+Trainer's parameter groups, ``run_native_training`` with and without the prefetch thread, checkpoint -> resume reproducing the
+uninterrupted run bit for bit, and two ranks launched the way ``torchrun train.py <yaml> --native`` launches them."""
+import os
+import random
+import socket
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+from tests.test_end_to_end_gpu import _make_workspace, _merged
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_flat_adamw_step_equals_torch_adamw_with_hf_groups():
+    from tests.test_ddp_gpu import _batch, _make
+    from adt_str_amd.trainer import FlatTrainer, no_decay_names
+    model = _make(seed=3)
+    ref_params = {n: p.detach().clone() for n, p in model.named_parameters()}
+    tr = FlatTrainer(model, lr=1e-3, weight_decay=0.1, max_grad_norm=0.5, total_steps=20, warmup_ratio=0.1)
+    assert tr.warmup == 2
+    skip = set(no_decay_names(model))
+    params = {n: torch.nn.Parameter(v.clone()) for n, v in ref_params.items()}
+    opt = torch.optim.AdamW([{"params": [p for n, p in params.items() if n not in skip], "weight_decay": 0.1},
+                             {"params": [p for n, p in params.items() if n in skip], "weight_decay": 0.0}],
+                            lr=1e-3, betas=(0.9, 0.999), eps=1e-8)
+    for step in range(3):
+        wav, tok, tl = _batch(seed=7 + step)
+        lr = tr.current_lr()
+        tr.train_step(wav, tok, tl)
+        for n, p in params.items():
+            p.grad = tr.eng.G[n].detach().clone()                       # the step's own (unclipped) gradients
+        torch.nn.utils.clip_grad_norm_(list(params.values()), 0.5)
+        for g in opt.param_groups:
+            g["lr"] = lr
+        opt.step()
+        for n, p in model.named_parameters():
+            err = (p.data - params[n].data).abs().max().item()
+            assert err <= 2e-7 + 1e-6 * params[n].data.abs().max().item(), (step, n, err)
+            params[n].data.copy_(p.data)                                 # keep the two trajectories on the same weights
+    # the decayed and the non-decayed groups really differ: a bias moved only by its gradient, a weight also shrank
+    assert float((model.decoder.generator.weight.data - ref_params["decoder.generator.weight"]).abs().max()) > 0
+
+
+def _losses(tr):
+    return [l for _, l in tr.loss_history]
+
+
+def test_prefetch_thread_changes_nothing_and_resume_is_bit_exact(tmp_path):
+    import train
+    from adt_str_amd.trainer import run_native_training
+    from data_modules.train_dataset import LakhDataset, LakhDatasetConfig
+
+    os.makedirs(tmp_path / "w")
+    base = _make_workspace(tmp_path / "w", n_items=48, batch=4)
+    base["training"]["num_epochs"] = 2
+    base["logging"]["save_every_n_steps"] = 5
+    base["checkpoint"] = {"max_checkpoints": 2}
+
+    def go(out_name, depth, resume=None, auto=False):
+        cfg_d = {**base, "logging": dict(base["logging"], output_dir=str(tmp_path / out_name)),
+                 "checkpoint": {"max_checkpoints": 2, "resume_from_checkpoint": resume, "auto_resume": auto}}
+        cfg, _ = _merged(cfg_d, tmp_path, f"{out_name}-{depth}-{bool(resume)}.yaml")
+        random.seed(cfg["experiment"]["seed"]); torch.manual_seed(cfg["experiment"]["seed"])
+        model, tokenizer, synth = train.build_components(cfg)
+        ds = LakhDataset(LakhDatasetConfig(**cfg["shared"], **cfg["TrainDatasetConfig"]), tokenizer, synth)
+        tr = run_native_training(model.cuda(), ds, cfg, prefetch_depth=depth)
+        torch.cuda.synchronize()
+        return tr
+
+    a = go("inline", 0)
+    b = go("thread", 2)
+    assert a.step_no == b.step_no == 2 * 12
+    assert _losses(a) == _losses(b) and torch.equal(a.pflat, b.pflat)             # same draws, same batches, same bits
+    assert sorted(d for d in os.listdir(tmp_path / "thread") if d.startswith("checkpoint-")) == ["checkpoint-15", "checkpoint-20"]
+    from safetensors.torch import load_file
+    final = load_file(str(tmp_path / "thread" / "model.safetensors"))
+    assert set(final) == set(b.model.state_dict()) and torch.equal(final["decoder.generator.bias"].cuda(), b.model.decoder.generator.bias.data)
+    # resume from step 15 (mid-epoch 2, with dropout 0.1 and the FX draws in the stream): steps 16..24 repeat bit for bit
+    c = go("thread", 2, resume=str(tmp_path / "thread" / "checkpoint-15"))
+    assert c.step_no == 24 and _losses(c) == _losses(b)[15:] and torch.equal(c.pflat, b.pflat)
+    assert torch.equal(c.m, b.m) and torch.equal(c.v, b.v)
+    # build_model loads what the loop saved (the reference's checkpoint contract, build_model.py:49-66)
+    from build_model import build_model
+    cfg_d = {**base, "inference": {"checkpoint_path": str(tmp_path / "thread"), "batch_size": 2, "max_length": 8}}
+    _, cfg_path = _merged(cfg_d, tmp_path, "infer.yaml")
+    m2, _ = build_model(cfg_path)
+    assert torch.equal(m2.state_dict()["decoder.generator.bias"].cpu(), final["decoder.generator.bias"])
+
+
+def _free_port():
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); p = s.getsockname()[1]; s.close()
+    return p
+
+
+def test_torchrun_two_ranks_train_native_share_one_model(tmp_path):
+    """``python -m torch.distributed.run --nproc-per-node 2 train.py cfg.yaml --native`` (the reference's ``accelerate launch
+    train.py``, README.md:53-57): both ranks join one process group, shard the data, and save ONE model.  On this one-GPU box
+    the two ranks share GPU 0 over gloo (ADT_SHARE_GPU=1: a one-GPU box cannot host two RCCL ranks); on a node they get
+    cuda:LOCAL_RANK and RCCL."""
+    os.makedirs(tmp_path / "w")
+    ws = _make_workspace(tmp_path / "w", n_items=32, batch=4)
+    ws["logging"]["save_every_n_steps"] = 2
+    cfg, cfg_path = _merged(ws, tmp_path, "ddp.yaml")
+    env = dict(os.environ, PYTHONPATH=ROOT + os.pathsep + os.environ.get("PYTHONPATH", ""), ADT_SHARE_GPU="1", ADT_DUMP_PARAMS=str(tmp_path))
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1",
+                        "--master-port", str(_free_port()), os.path.join(ROOT, "train.py"), cfg_path, "--native"],
+                       capture_output=True, text=True, env=env, timeout=900)
+    assert r.returncode == 0, (r.stdout[-1500:], r.stderr[-3000:])
+    p0, p1 = (torch.load(str(tmp_path / f"params_rank{i}.pt")) for i in range(2))
+    assert p0["world"] == p1["world"] == 2 and p0["steps"] == p1["steps"] == 32 // (4 * 2)
+    assert torch.equal(p0["pflat"], p1["pflat"]), "both ranks must hold the same model"
+    out = cfg["logging"]["output_dir"]
+    assert os.path.exists(os.path.join(out, "model.safetensors")) and os.path.exists(os.path.join(out, "checkpoint-4", "rng_state_1.pth"))

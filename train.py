@@ -3,7 +3,16 @@
 ``ADTTrainer.compute_loss`` keeps the reference hook signature (train.py:40-78) so HF ``Trainer`` drives the
 hand-written gfx950 forward/backward through autograd; ``--native`` instead runs the flat-buffer loop of
 ``adt_str_amd.trainer.FlatTrainer`` (one fused clip + AdamW launch, bucketed RCCL all-reduce overlapped with
-backward), which is what ``bench.py`` measures.
+backward, prefetched host pipeline, checkpoints + resume), which is what ``bench.py`` measures.
+
+Multi-GPU, one process per GPU on one node, exactly like the reference's ``accelerate launch train.py <yaml>``
+(README.md:53-57):
+
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node 8 --master-addr 127.0.0.1 train.py <yaml> --native
+    accelerate launch train.py <yaml> --native
+
+Both set RANK / LOCAL_RANK / WORLD_SIZE; ``train()`` binds the process to its GPU and creates the RCCL process group
+before any GPU work (``adt_str_amd.trainer.init_distributed``).
 """
 import argparse
 import logging
@@ -80,13 +89,22 @@ def build_components(cfg: dict, device: str = "cuda"):
 def train(cfg: dict, native: bool = False):
     from data_modules.train_dataset import LakhDataset, LakhDatasetConfig
     logging.basicConfig(level=getattr(logging, cfg["logging"].get("log_level", "INFO")))
+    device = "cuda"
+    if native:
+        from adt_str_amd.trainer import init_distributed, run_native_training
+        _, local_rank, _ = init_distributed()                 # set_device(LOCAL_RANK) + RCCL group, before any GPU work
+        device = f"cuda:{local_rank}"
     random.seed(cfg["experiment"]["seed"])
     torch.manual_seed(cfg["experiment"]["seed"])
-    model, tokenizer, synth = build_components(cfg)
+    model, tokenizer, synth = build_components(cfg, device=device)
     ds = LakhDataset(LakhDatasetConfig(**cfg["shared"], **cfg["TrainDatasetConfig"]), tokenizer, synth)
     if native:
-        from adt_str_amd.trainer import run_native_training
-        return run_native_training(model.cuda(), ds, cfg)
+        tr = run_native_training(model.to(device), ds, cfg)
+        if os.environ.get("ADT_DUMP_PARAMS"):                 # test hook: every rank's final flat parameters (tests/test_training_loop_gpu.py)
+            torch.cuda.synchronize()
+            torch.save({"pflat": tr.pflat.detach().cpu(), "steps": tr.step_no, "world": tr.world},
+                       os.path.join(os.environ["ADT_DUMP_PARAMS"], f"params_rank{tr.rank}.pt"))
+        return tr
     trainer = ADTTrainer(model=model, args=create_training_arguments(cfg), train_dataset=ds, data_collator=ds.collate)
     trainer.train(resume_from_checkpoint=cfg["checkpoint"].get("resume_from_checkpoint"))
     trainer.save_model()
