@@ -79,6 +79,52 @@ class OneShotBank:
         return OneShotBank(data=data, offsets=np.asarray(offsets, np.int64), pitch=np.asarray(pitch, np.int32),
                            group=np.asarray(group, np.int32), names=names, sample_rate=sample_rate)
 
+    @staticmethod
+    def from_directory(root: str, sample_rate: int, device=None) -> "OneShotBank":
+        """Build from a curated tree ``<root>/<label>/<bin>/<file>.wav`` -- what the reference's
+        ``augment_data_with_CLAP.py`` + ``copy_originals_to_augmented.py`` leave on disk and its
+        ``convert_augmented_to_hdf5.py:69-141`` packs into HDF5: every file is loaded as mono, resampled to ``sample_rate``
+        (K13 on the GPU when ``device`` is a GPU and the rate differs) and peak-normalised (``:101-103``); files are taken in
+        sorted path order, paths with fewer than three components are skipped (``:93-96``), and a repeated stem inside one
+        cell gets the ``_2``, ``_3`` ... suffix (``:113-118``).  Unreadable or silent files are skipped with a message, like
+        the reference's ``except``."""
+        import glob
+        import os
+        from .audio_io import read_wav
+        files = sorted(glob.glob(os.path.join(root, "**", "*.[Ww][Aa][Vv]"), recursive=True))
+        tree: dict = {}
+        resamplers: dict = {}
+        for path in files:
+            rel = os.path.relpath(path, root).split(os.sep)
+            if len(rel) < 3 or rel[1] not in GROUPS:
+                continue
+            label, group, stem = rel[0], rel[1], os.path.splitext(rel[-1])[0]
+            try:
+                int(label)
+                audio, sr = read_wav(path)
+                x = audio.mean(axis=0)
+                if sr != sample_rate:
+                    from .resample import Resample
+                    if device is None or torch.device(device).type != "cuda":
+                        raise RuntimeError(f"{path} is {sr} Hz: resampling to {sample_rate} Hz runs on the GPU (pass device=)")
+                    if sr not in resamplers:
+                        resamplers[sr] = Resample(sr, sample_rate)
+                    x = resamplers[sr](torch.from_numpy(x).to(device)[None])[0].cpu().numpy()
+                peak = float(np.abs(x).max()) if x.size else 0.0
+                if not peak > 0.0:
+                    raise ValueError("silent or empty file")
+                x = (x / peak).astype(np.float32)
+            except Exception as e:
+                print(f"Failed to load '{path}': {e}")
+                continue
+            cell = tree.setdefault(label, {}).setdefault(group, {})
+            name, k = stem, 1
+            while name in cell:
+                k += 1
+                name = f"{stem}_{k}"
+            cell[name] = x
+        return OneShotBank.from_tree(tree, sample_rate)
+
     def save(self, path: str) -> None:
         np.savez(path, data=self.data, offsets=self.offsets, pitch=self.pitch, group=self.group,
                  names=np.array(self.names), sample_rate=np.int64(self.sample_rate))

@@ -66,3 +66,33 @@ def test_positional_encoding_and_masks():
     assert torch.allclose(pe[3, 0], torch.sin(torch.tensor(3.0))) and torch.allclose(pe[3, 1], torch.cos(torch.tensor(3.0)))
     assert o_adt.causal_mask(3).tolist() == [[False, True, True], [False, False, True], [False, False, False]]
     assert o_adt.key_padding_mask([1, 3], 3).tolist() == [[False, True, True], [False, False, False]]
+
+
+def test_logmel_oracle_end_to_end_against_hf_audio_utils():
+    """a1's STFT + filterbank half is torchaudio's and torchaudio is not installable: an independent end-to-end check against
+    third-party code that documents itself as torchaudio-equivalent -- ``transformers.audio_utils.spectrogram`` (float64 numpy:
+    periodic Hann via ``window_function``, ``center=True`` reflect padding, one-sided power spectrum) with
+    ``mel_filter_bank(norm=None, mel_scale="htk")`` -- followed by the reference-owned post-processing (model.py:91-97)."""
+    from transformers.audio_utils import mel_filter_bank, spectrogram, window_function
+    rng = np.random.default_rng(3)
+    for sr, L in ((16000, 16000), (24000, 24000)):
+        hop = o_logmel.hop_length(0.01, sr)
+        t = np.arange(L) / sr
+        waves = [rng.standard_normal(L) * 0.05,
+                 0.6 * np.exp(-t * 25.0) * np.sin(2 * np.pi * 180.0 * t) + rng.standard_normal(L) * 0.01,
+                 np.clip(rng.standard_normal(L) * 0.6, -1, 1)]
+        fb = mel_filter_bank(1025, 128, 20.0, float(sr // 2), sr, norm=None, mel_scale="htk")            # [1025, 128] float64
+        win = window_function(2048, "hann", periodic=True)
+        pad = o_logmel.trim_pad(2048, hop)
+        for w in waves:
+            power = spectrogram(w.astype(np.float64), win, frame_length=2048, hop_length=hop, fft_length=2048, power=2.0, center=True,
+                                pad_mode="reflect", onesided=True)                                   # [1025, frames]
+            assert power.shape == (1025, 1 + L // hop)
+            mel = power.T @ fb                                                                       # [frames, 128]
+            ref = (np.clip(np.log(mel + 1e-10), -23.0, 12.0) + 23.0) / 35.0
+            ref = ref[pad:-(pad + 1)]
+            got = o_logmel.logmel(torch.from_numpy(w.astype(np.float32))[None], sr, 2048, 0.01, 128)[0].numpy()
+            assert got.shape == ref.shape
+            # fp32 torch.stft + fp32 filterbank vs float64: 1.3e-5 on the filterbank weights, amplified by the log only where a band
+            # is near silence; on the [0, 1] output the two agree to 2e-4 everywhere and 2e-5 in the mean
+            assert np.abs(got - ref).max() < 2e-4 and np.abs(got - ref).mean() < 2e-5, (sr, np.abs(got - ref).max())
