@@ -29,7 +29,7 @@ class GemmEpilogue(C.Structure):
                 ("pre_act_out", C.c_void_p), ("ld_pre_act", C.c_int64), ("residual", C.c_void_p),
                 ("ld_res", C.c_int64), ("res_row_mod", C.c_int32), ("act", C.c_int32), ("alpha", C.c_float),
                 ("out_fp32", C.c_int32), ("aux_bf16_out", C.c_void_p), ("ld_aux", C.c_int64), ("drop", Dropout),
-                ("drop_after_residual", C.c_int32), ("colsum_out", C.c_void_p)]
+                ("drop_after_residual", C.c_int32), ("colsum_out", C.c_void_p), ("act_grad_mode", C.c_int32)]
 
 
 class AttnDesc(C.Structure):

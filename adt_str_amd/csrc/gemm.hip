@@ -87,6 +87,15 @@ __device__ __forceinline__ f32x2 gelu_erf_grad2(f32x2 x) {               // Phi(
   return (x * 0.3989422804014327f) * e + c;
 }
 
+// GELU and its derivative from one erfc / exp evaluation (the saved-factor form of the FFN backward, adt_gemm_epilogue.act_grad_mode)
+__device__ __forceinline__ void gelu_and_grad2(f32x2 x, f32x2& gv, f32x2& gd) {
+  f32x2 e;
+  const f32x2 ax = abs2(x), hq = half_erfc2(x, ax, e);
+  gv = f32x2{fmaxf(x[0], 0.f), fmaxf(x[1], 0.f)} - ax * hq;
+  const f32x2 d = 0.5f - hq;
+  gd = (x * 0.3989422804014327f) * e + (f32x2{copysignf(d[0], x[0]), copysignf(d[1], x[1])} + 0.5f);
+}
+
 struct GemmArgs {
   const unsigned short* A; long lda;
   const unsigned short* B; long ldb;
@@ -97,7 +106,6 @@ struct GemmArgs {
   float* colsum_ws;             // 256^2 NT kernel: column sums of each 128-row band of the output, [ceil(M/256)*2][N]
   adt_gemm_epilogue ep;
   Drop drop;
-  int w2_stagger;               // gemm_nt_w2_kernel: start-up delay of the second workgroup per CU, in units of 4096 clocks
   unsigned* sched; unsigned sched_total[8];  // persistent kernels: per-XCD-group work counters (16 words apart, zero between launches) and the number of tickets each hands out in this launch
 };
 
@@ -173,13 +181,18 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& g, f32x4 (&acc)[4]
         z = z * ep.alpha + bias;
         if (ep.gelu_grad_of) {
           const unsigned short u = reinterpret_cast<const unsigned short*>(ep.gelu_grad_of)[static_cast<long>(row) * ep.ld_gelu_grad + col];
-          z *= gelu_erf_grad(bf2f(u));
+          z *= ep.act_grad_mode ? bf2f(u) : gelu_erf_grad(bf2f(u));
         }
-        if (ep.pre_act_out)
-          reinterpret_cast<unsigned short*>(ep.pre_act_out)[static_cast<long>(row) * ep.ld_pre_act + col] = f2bf(z);
-        if (ep.act == 1) z = gelu_erf(ep.pre_act_out ? bf2f(f2bf(z)) : z);
-        else if (ep.act == 2) z = fmaxf(z, 0.0f);
         const float keep = kDrop ? g.drop.scale(static_cast<uint64_t>(row) * drop_ld(g.N) + col) : 1.0f;
+        if (ep.act_grad_mode && ep.pre_act_out && ep.act == 1) {
+          reinterpret_cast<unsigned short*>(ep.pre_act_out)[static_cast<long>(row) * ep.ld_pre_act + col] = f2bf(gelu_erf_grad(z) * keep);
+          z = gelu_erf(z);
+        } else {
+          if (ep.pre_act_out)
+            reinterpret_cast<unsigned short*>(ep.pre_act_out)[static_cast<long>(row) * ep.ld_pre_act + col] = f2bf(z);
+          if (ep.act == 1) z = gelu_erf(ep.pre_act_out ? bf2f(f2bf(z)) : z);
+          else if (ep.act == 2) z = fmaxf(z, 0.0f);
+        }
         if (kDrop && !ep.drop_after_residual) z *= keep;
         if (ep.residual) {
           const long rr = ep.res_row_mod > 0 ? (row % ep.res_row_mod) : row;
@@ -279,29 +292,11 @@ __device__ __forceinline__ void epilogue_apply8(const GemmArgs& g, float (&z)[8]
     const unsigned w[4] = {uv.x, uv.y, uv.z, uv.w};
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
-      const f32x2 gd = gelu_erf_grad2(f32x2{__uint_as_float(w[e] << 16), __uint_as_float(w[e] & 0xffff0000u)});
+      f32x2 gd = f32x2{__uint_as_float(w[e] << 16), __uint_as_float(w[e] & 0xffff0000u)};
+      if (!ep.act_grad_mode) gd = gelu_erf_grad2(gd);        // act_grad_mode: the forward already stored gelu'(z) * keep
       z[2 * e] *= gd[0];
       z[2 * e + 1] *= gd[1];
     }
-  }
-  if (ep.pre_act_out) {
-    uint4 o;
-    o.x = f2bf(z[0]) | (static_cast<unsigned>(f2bf(z[1])) << 16); o.y = f2bf(z[2]) | (static_cast<unsigned>(f2bf(z[3])) << 16);
-    o.z = f2bf(z[4]) | (static_cast<unsigned>(f2bf(z[5])) << 16); o.w = f2bf(z[6]) | (static_cast<unsigned>(f2bf(z[7])) << 16);
-    *reinterpret_cast<uint4*>(reinterpret_cast<unsigned short*>(ep.pre_act_out) + static_cast<long>(row) * ep.ld_pre_act + col) = o;
-#pragma unroll
-    for (int e = 0; e < 8; ++e) z[e] = bf2f(f2bf(z[e]));       // the activation sees the value the backward will read
-  }
-  if (ep.act == 1) {
-#pragma unroll
-    for (int e = 0; e < 4; ++e) {
-      const f32x2 gv = gelu_erf2(f32x2{z[2 * e], z[2 * e + 1]});
-      z[2 * e] = gv[0];
-      z[2 * e + 1] = gv[1];
-    }
-  } else if (ep.act == 2) {
-#pragma unroll
-    for (int e = 0; e < 8; ++e) z[e] = fmaxf(z[e], 0.0f);
   }
   float keep[8] = {1.f, 1.f, 1.f, 1.f, 1.f, 1.f, 1.f, 1.f};
   if (kDrop) {
@@ -313,10 +308,45 @@ __device__ __forceinline__ void epilogue_apply8(const GemmArgs& g, float (&z)[8]
       keep[2 * e] = g.drop.lo(hh);
       keep[2 * e + 1] = g.drop.hi(hh);
     }
-    if (!ep.drop_after_residual) {
+  }
+  const bool save_factor = ep.act_grad_mode && ep.pre_act_out && ep.act == 1;
+  if (save_factor) {                                    // h = gelu(z), saved: gelu'(z) * keep (what the backward multiplies by)
+    float f[8];
 #pragma unroll
-      for (int e = 0; e < 8; ++e) z[e] *= keep[e];
+    for (int e = 0; e < 4; ++e) {
+      f32x2 gv, gd;
+      gelu_and_grad2(f32x2{z[2 * e], z[2 * e + 1]}, gv, gd);
+      z[2 * e] = gv[0]; z[2 * e + 1] = gv[1];
+      f[2 * e] = gd[0] * keep[2 * e]; f[2 * e + 1] = gd[1] * keep[2 * e + 1];
     }
+    uint4 o;
+    o.x = f2bf(f[0]) | (static_cast<unsigned>(f2bf(f[1])) << 16); o.y = f2bf(f[2]) | (static_cast<unsigned>(f2bf(f[3])) << 16);
+    o.z = f2bf(f[4]) | (static_cast<unsigned>(f2bf(f[5])) << 16); o.w = f2bf(f[6]) | (static_cast<unsigned>(f2bf(f[7])) << 16);
+    *reinterpret_cast<uint4*>(reinterpret_cast<unsigned short*>(ep.pre_act_out) + static_cast<long>(row) * ep.ld_pre_act + col) = o;
+  } else {
+    if (ep.pre_act_out) {
+      uint4 o;
+      o.x = f2bf(z[0]) | (static_cast<unsigned>(f2bf(z[1])) << 16); o.y = f2bf(z[2]) | (static_cast<unsigned>(f2bf(z[3])) << 16);
+      o.z = f2bf(z[4]) | (static_cast<unsigned>(f2bf(z[5])) << 16); o.w = f2bf(z[6]) | (static_cast<unsigned>(f2bf(z[7])) << 16);
+      *reinterpret_cast<uint4*>(reinterpret_cast<unsigned short*>(ep.pre_act_out) + static_cast<long>(row) * ep.ld_pre_act + col) = o;
+#pragma unroll
+      for (int e = 0; e < 8; ++e) z[e] = bf2f(f2bf(z[e]));       // the activation sees the value the backward will read
+    }
+    if (ep.act == 1) {
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const f32x2 gv = gelu_erf2(f32x2{z[2 * e], z[2 * e + 1]});
+        z[2 * e] = gv[0];
+        z[2 * e + 1] = gv[1];
+      }
+    } else if (ep.act == 2) {
+#pragma unroll
+      for (int e = 0; e < 8; ++e) z[e] = fmaxf(z[e], 0.0f);
+    }
+  }
+  if (kDrop && !ep.drop_after_residual) {
+#pragma unroll
+    for (int e = 0; e < 8; ++e) z[e] *= keep[e];
   }
   if (ep.residual) {
     const long rr = ep.res_row_mod > 0 ? (row % ep.res_row_mod) : row;
@@ -764,248 +794,6 @@ __global__ __launch_bounds__(kBigThreads) void gemm_nt_256_kernel(GemmArgs g, in
 }
 
 // =========================================================================================
-// NT kernel, 256 x 128 x 32 tiles, 4 waves, TWO workgroups per CU ("w2").
-//
-// Why a second persistent NT kernel: the 256^2 tile keeps 256 KB of fp32 accumulators = half of a CU's register file, so while
-// it is in its epilogue (LDS transposition, bias / GELU / dropout / residual arithmetic, 256-512 KB of global stores per tile)
-// nothing else can be resident and the matrix pipes idle -- a third of the kernel at K = 768, where the epilogue's traffic is as
-// large as the operands'.  A 256 x 128 tile is 128 KB of accumulators; with 72 KB of LDS two such workgroups fit on a CU, each
-// wave still owning the 128 x 64 output (8 x 4 MFMA blocks) of the 256^2 kernel, and the hardware runs one workgroup's epilogue
-// (VALU, LDS, stores) underneath the other one's K loop (MFMA) on the same SIMDs.  Price: 1.5x the L2 -> LDS bytes per FLOP.
-//
-// K loop: K-tiles of 32 (one MFMA k-step), a ring of three 24 KB stages (A 256 rows x 64 B | B 128 rows x 64 B) filled by
-// global_load_lds_dwordx4 two K-tiles ahead: per K-tile ONE raw s_barrier, a counted s_waitcnt vmcnt(6) (the next K-tile's six
-// DMAs stay in flight across it), six DMA issues, twelve ds_read_b128 and 32 MFMAs per wave.  64-byte LDS rows: position p of
-// row r holds the row's 16-byte chunk p ^ ((r >> 1) & 3) (swizzle on the DMA's SOURCE address; conflict-free for the four
-// 16-lane groups of ds_read_b128).  Past-the-end K-tiles re-fetch the last one into the stage nobody reads, so the counts stay
-// exact.  After a tile's K loop the first two K-tiles of the NEXT tile are requested before the epilogue, which transposes
-// through the third stage.  Tiles come from the per-XCD work counters of gemm_nt_256_kernel (same protocol).
-constexpr int kW2M = 256, kW2N = 128, kW2K = 32;
-constexpr int kW2Threads = 256;
-constexpr int kW2A = kW2M * 64, kW2B = kW2N * 64;      // bytes per stage: 16 KiB + 8 KiB
-constexpr int kW2Stage = kW2A + kW2B;                  // 24 KiB
-constexpr int kW2Lds = 3 * kW2Stage + 64;              // 73,792 B: two workgroups per CU
-
-template <bool kDrop, bool kColsum>
-__global__ __launch_bounds__(kW2Threads, 2) void gemm_nt_w2_kernel(GemmArgs g, int tiles_m, int tiles_n) {
-  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-  const int tid = threadIdx.x, lane = tid & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int wr = wave >> 1, wc = wave & 1;
-  const int nwg = tiles_m * tiles_n;
-  const int q8 = nwg >> 3, r8 = nwg & 7;
-  const int k_tiles = g.K / kW2K;
-  const int xg = blockIdx.x & 7;
-  const int slice0 = xg < r8 ? xg * (q8 + 1) : r8 * (q8 + 1) + (xg - r8) * q8, slice_n = q8 + (xg < r8 ? 1 : 0);
-  unsigned* const counter = g.sched + xg * 16;
-  const unsigned ctotal = g.sched_total[xg];
-
-  // ---- DMA sources: A piece p = 4 * wave + j (rows 16 p + (lane >> 2)), B piece p = 2 * wave + j; chunk (lane & 3) ^ swizzle
-  const unsigned short* pa[4];
-  const unsigned short* pb[2];
-  auto set_tile = [&](int v, int& m0, int& n0) {
-    const int logical = slice0 + v;
-    m0 = (logical / tiles_n) * kW2M;
-    n0 = (logical % tiles_n) * kW2N;
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      const int r = 16 * (4 * wave + j) + (lane >> 2);
-      int ar = m0 + r;
-      ar = ar < g.M ? ar : g.M - 1;
-      pa[j] = g.A + static_cast<long>(ar) * g.lda + (((lane & 3) ^ ((r >> 1) & 3)) << 3);
-    }
-#pragma unroll
-    for (int j = 0; j < 2; ++j) {
-      const int r = 16 * (2 * wave + j) + (lane >> 2);
-      int br = n0 + r;
-      br = br < g.N ? br : g.N - 1;
-      pb[j] = g.B + static_cast<long>(br) * g.ldb + (((lane & 3) ^ ((r >> 1) & 3)) << 3);
-    }
-  };
-  auto dma_tile = [&](int tile, int stage) {           // six 1-KiB pieces of K-tile `tile` into ring stage `stage`
-    const long ko = static_cast<long>(tile < k_tiles ? tile : k_tiles - 1) * kW2K;
-    unsigned char* sb = smem + stage * kW2Stage;
-#pragma unroll
-    for (int j = 0; j < 4; ++j)
-      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(pa[j] + ko),
-                                       (__attribute__((address_space(3))) void*)(sb + (4 * wave + j) * 1024), 16, 0, 0);
-#pragma unroll
-    for (int j = 0; j < 2; ++j)
-      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(pb[j] + ko),
-                                       (__attribute__((address_space(3))) void*)(sb + kW2A + (2 * wave + j) * 1024), 16, 0, 0);
-  };
-
-  // ---- fragment read addresses (bytes inside a stage): row * 64 + ((lane >> 4) ^ ((row >> 1) & 3)) * 16
-  const unsigned base0 = lds_addr(smem);
-  const unsigned cpos = static_cast<unsigned>(((lane >> 4) ^ (((lane & 15) >> 1) & 3)) * 16);
-  const unsigned a_fr = base0 + static_cast<unsigned>((wr * 128 + (lane & 15)) * 64) + cpos;                 // + i * 1024
-  const unsigned b_fr = base0 + kW2A + static_cast<unsigned>((wc * 64 + (lane & 15)) * 64) + cpos;            // + j * 1024
-  float* ct = reinterpret_cast<float*>(smem + 2 * kW2Stage + wave * kEpi2Bytes);       // epilogue scratch: inside ring stage 2
-  unsigned* const flag = reinterpret_cast<unsigned*>(smem + 3 * kW2Stage);
-
-  if (tid == 0) *flag = take_ticket(counter, ctotal);
-  __syncthreads();
-  int v = static_cast<int>(*flag), m0, n0;
-  if (static_cast<unsigned>(v) >= static_cast<unsigned>(slice_n)) return;   // block-uniform
-  __syncthreads();
-  set_tile(v, m0, n0);
-  dma_tile(0, 0);
-  dma_tile(1, 1);
-  // Two workgroups share a CU and every tile costs the same, so they would run in lockstep -- both in the K loop (halving each
-  // other's MFMA rate), then both in the epilogue (matrix pipes idle).  The second half of the grid (the workgroups that land in
-  // the second slot of each CU under round-robin placement; only speed depends on that) starts half a tile period late, which
-  // puts one workgroup's epilogue under the other's K loop from then on.
-  if (g.w2_stagger && blockIdx.x >= (gridDim.x >> 1)) {
-    for (int i = 0; i < g.w2_stagger; ++i) __builtin_amdgcn_s_sleep(64);     // 64 x 64 clocks each
-  }
-
-  unsigned ct_w[4], ct_r[2];
-#pragma unroll
-  for (int j = 0; j < 4; ++j) ct_w[j] = lds_addr(ct) + static_cast<unsigned>(((4 * (lane >> 4)) * 64 + ((j ^ (lane >> 4)) << 4) + (lane & 15)) * 4);
-#pragma unroll
-  for (int pass = 0; pass < 2; ++pass) {
-    const int lr = pass * 8 + (lane >> 3);
-    ct_r[pass] = lds_addr(ct) + static_cast<unsigned>((lr * 64 + ((((lane & 7) >> 1) ^ ((lr >> 2) & 3)) << 4) + (lane & 1) * 8) * 4);
-  }
-
-  while (true) {
-    f32x4 acc[8][4];
-#pragma unroll
-    for (int i = 0; i < 8; ++i)
-#pragma unroll
-      for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
-    // this tile's bias piece and the next tile's ticket: requested now, first used after the K loop (see gemm_nt_256_kernel)
-    const int ecol = n0 + wc * 64 + (lane & 7) * 8;
-    const bool efull = ecol + 8 <= g.N;
-    const bool has_bias = g.ep.bias != nullptr && efull;
-    const float* bptr = has_bias ? g.ep.bias + ecol : reinterpret_cast<const float*>(g.A);     // always a readable 32 bytes
-    f32x4 braw0, braw1;
-    asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(braw0) : "v"(bptr) : "memory");
-    asm volatile("global_load_dwordx4 %0, %1, off offset:16" : "=v"(braw1) : "v"(bptr) : "memory");
-    unsigned v_next;
-    if (tid == 0) asm volatile("global_atomic_add %0, %1, %2, off sc0" : "=v"(v_next) : "v"(counter), "v"(1u) : "memory");
-    // (these three requests are older than every K-tile the loop's counted waits leave in flight, so the counts below still hold)
-
-    int stage = 0, fill = 2;                           // ring positions of K-tile t and of K-tile t + 2
-    for (int t = 0; t < k_tiles; ++t) {
-      asm volatile("s_waitcnt vmcnt(6)" ::: "memory"); // K-tile t has landed (K-tile t + 1 may still be in flight)
-      asm volatile("s_barrier" ::: "memory");          // ... for every wave, and every wave is done reading the stage refilled next
-      const unsigned so = static_cast<unsigned>(stage) * kW2Stage;
-      bf16x8 fa[8], fb[4];
-      ADT_DS_READ_B128(fb[0], b_fr + so, 0);    ADT_DS_READ_B128(fb[1], b_fr + so, 1024);
-      ADT_DS_READ_B128(fb[2], b_fr + so, 2048); ADT_DS_READ_B128(fb[3], b_fr + so, 3072);
-      ADT_DS_READ_B128(fa[0], a_fr + so, 0);    ADT_DS_READ_B128(fa[1], a_fr + so, 1024);
-      ADT_DS_READ_B128(fa[2], a_fr + so, 2048); ADT_DS_READ_B128(fa[3], a_fr + so, 3072);
-      ADT_DS_READ_B128(fa[4], a_fr + so, 4096); ADT_DS_READ_B128(fa[5], a_fr + so, 5120);
-      ADT_DS_READ_B128(fa[6], a_fr + so, 6144); ADT_DS_READ_B128(fa[7], a_fr + so, 7168);
-      // the six DMA pieces of K-tile t + 2 go out in pairs between the MFMA batches: their issue time sits under MFMAs already queued
-      const long ko = static_cast<long>(t + 2 < k_tiles ? t + 2 : k_tiles - 1) * kW2K;
-      unsigned char* const fb_ = smem + fill * kW2Stage;
-#define ADT_W2_DMA_A(J) __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(pa[J] + ko), \
-                                                          (__attribute__((address_space(3))) void*)(fb_ + (4 * wave + J) * 1024), 16, 0, 0)
-#define ADT_W2_DMA_B(J) __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(pb[J] + ko), \
-                                                          (__attribute__((address_space(3))) void*)(fb_ + kW2A + (2 * wave + J) * 1024), 16, 0, 0)
-      ADT_W2_DMA_A(0); ADT_W2_DMA_A(1);
-      asm volatile("s_waitcnt lgkmcnt(4)" ::: "memory");             // B and the first four A fragments are here
-      __builtin_amdgcn_sched_barrier(0);
-      __builtin_amdgcn_s_setprio(1);
-#pragma unroll
-      for (int i = 0; i < 2; ++i)
-#pragma unroll
-        for (int j = 0; j < 4; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[i], fb[j], acc[i][j], 0, 0, 0);
-      __builtin_amdgcn_sched_barrier(0);
-      ADT_W2_DMA_A(2); ADT_W2_DMA_A(3);
-      __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-      for (int i = 2; i < 4; ++i)
-#pragma unroll
-        for (int j = 0; j < 4; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[i], fb[j], acc[i][j], 0, 0, 0);
-      __builtin_amdgcn_sched_barrier(0);
-      ADT_W2_DMA_B(0); ADT_W2_DMA_B(1);
-      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-      __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-      for (int i = 4; i < 8; ++i)
-#pragma unroll
-        for (int j = 0; j < 4; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[i], fb[j], acc[i][j], 0, 0, 0);
-      __builtin_amdgcn_s_setprio(0);
-      __builtin_amdgcn_sched_barrier(0);
-#undef ADT_W2_DMA_A
-#undef ADT_W2_DMA_B
-      stage = stage == 2 ? 0 : stage + 1;
-      fill = fill == 2 ? 0 : fill + 1;
-    }
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    asm volatile("s_barrier" ::: "memory");            // every DMA has landed and every fragment read is done: the ring is free
-
-    const int em0 = m0;
-    if (tid == 0) { ticket_drawn(counter, v_next, ctotal); *flag = v_next; }
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    asm volatile("s_barrier" ::: "memory");
-    v = static_cast<int>(*flag);
-    const bool more = static_cast<unsigned>(v) < static_cast<unsigned>(slice_n);   // block-uniform
-    if (more) {
-      set_tile(v, m0, n0);
-      dma_tile(0, 0);                                   // fly under the epilogue below (which works in stage 2)
-      dma_tile(1, 1);
-    }
-
-    // ---- epilogue: the wave-private 16 x 64 transposition passes of gemm_nt_256_kernel
-    float bias[8];
-#pragma unroll
-    for (int e = 0; e < 4; ++e) { bias[e] = has_bias ? braw0[e] : 0.f; bias[4 + e] = has_bias ? braw1[e] : 0.f; }
-    float cs[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-    for (int i = 0; i < 8; ++i) {
-#pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        asm volatile("ds_write_b32 %0, %1" :: "v"(ct_w[j]), "v"(acc[i][j][0]));
-        asm volatile("ds_write_b32 %0, %1 offset:256" :: "v"(ct_w[j]), "v"(acc[i][j][1]));
-        asm volatile("ds_write_b32 %0, %1 offset:512" :: "v"(ct_w[j]), "v"(acc[i][j][2]));
-        asm volatile("ds_write_b32 %0, %1 offset:768" :: "v"(ct_w[j]), "v"(acc[i][j][3]));
-      }
-      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-      __builtin_amdgcn_wave_barrier();
-      f32x4 zz[2][2];
-      asm volatile("ds_read_b128 %0, %1" : "=v"(zz[0][0]) : "v"(ct_r[0]));
-      asm volatile("ds_read_b128 %0, %1 offset:16" : "=v"(zz[0][1]) : "v"(ct_r[0]));
-      asm volatile("ds_read_b128 %0, %1" : "=v"(zz[1][0]) : "v"(ct_r[1]));
-      asm volatile("ds_read_b128 %0, %1 offset:16" : "=v"(zz[1][1]) : "v"(ct_r[1]));
-      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-      __builtin_amdgcn_sched_barrier(0);
-      __builtin_amdgcn_wave_barrier();
-#pragma unroll
-      for (int pass = 0; pass < 2; ++pass) {
-        const int row = em0 + wr * 128 + i * 16 + pass * 8 + (lane >> 3);
-        float z[8] = {zz[pass][0][0], zz[pass][0][1], zz[pass][0][2], zz[pass][0][3], zz[pass][1][0], zz[pass][1][1], zz[pass][1][2], zz[pass][1][3]};
-        if (row < g.M && efull) {
-          epilogue_apply8<kDrop>(g, z, bias, row, ecol);
-          if (kColsum) {
-#pragma unroll
-            for (int e = 0; e < 8; ++e) cs[e] += g.ep.out_fp32 ? z[e] : bf2f(f2bf(z[e]));
-          }
-        }
-      }
-    }
-    if (kColsum) {                                      // lanes l, l + 8, ..., l + 56 hold the same 8 columns
-#pragma unroll
-      for (int e = 0; e < 8; ++e) {
-        cs[e] += __shfl_xor(cs[e], 8);
-        cs[e] += __shfl_xor(cs[e], 16);
-        cs[e] += __shfl_xor(cs[e], 32);
-      }
-      if (lane < 8 && efull) {
-        float* cp = g.colsum_ws + static_cast<long>(em0 / 128 + wr) * g.N + ecol;
-        *reinterpret_cast<float4*>(cp) = float4{cs[0], cs[1], cs[2], cs[3]};
-        *reinterpret_cast<float4*>(cp + 4) = float4{cs[4], cs[5], cs[6], cs[7]};
-      }
-    }
-    if (!more) break;
-    asm volatile("s_barrier" ::: "memory");             // every wave is out of the scratch (stage 2) before the ring wraps into it
-  }
-}
-
-// =========================================================================================
 // TN kernel (weight gradients), LDS-DMA staging (used when K % 64 == 0).
 // Operand tiles are [64 k][128 cols] (256-byte rows); one wave-instruction of global_load_lds
 // fills 4 rows.  Position p of row r holds the row's 16-byte chunk p ^ (2*(r & 7)), which puts
@@ -1366,10 +1154,6 @@ static int set_big_lds_once() {      // the persistent kernels use the CU's whol
   ADT_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_nt_256_kernel<true, false>), hipFuncAttributeMaxDynamicSharedMemorySize, kBigLds));
   ADT_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_nt_256_kernel<true, true>), hipFuncAttributeMaxDynamicSharedMemorySize, kBigLds));
   ADT_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_tn_256_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, kBigLds));
-  ADT_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_nt_w2_kernel<false, false>), hipFuncAttributeMaxDynamicSharedMemorySize, kW2Lds));
-  ADT_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_nt_w2_kernel<false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, kW2Lds));
-  ADT_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_nt_w2_kernel<true, false>), hipFuncAttributeMaxDynamicSharedMemorySize, kW2Lds));
-  ADT_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_nt_w2_kernel<true, true>), hipFuncAttributeMaxDynamicSharedMemorySize, kW2Lds));
   done_for = dev;
   return ADT_OK;
 }
@@ -1389,17 +1173,6 @@ static bool use_big_tile(int64_t M, int64_t N, int64_t K) {
   if (forced == 256) return true;
   const int64_t tiles = ((M + kBig - 1) / kBig) * ((N + kBig - 1) / kBig);
   return tiles >= 512 && K >= 256 && N >= 160;           // a 256-wide tile over a narrower output is mostly padding
-}
-
-// 256 x 128 x 32 tiles, two workgroups per CU (gemm_nt_w2_kernel): ADT_GEMM_TILE=2 forces it, any other forced value excludes it.
-static bool use_w2_tile(int64_t M, int64_t N, int64_t K) {
-  static const int forced = [] { const char* v = getenv("ADT_GEMM_TILE"); return v ? atoi(v) : 0; }();
-  if (K <= 0 || (K % kW2K) != 0 || K < 2 * kW2K) return false;
-  if (forced) return forced == 2;
-  static const int dflt = [] { const char* v = getenv("ADT_GEMM_W2"); return v ? atoi(v) : 0; }();
-  if (!dflt) return false;
-  const int64_t tiles = ((M + kW2M - 1) / kW2M) * ((N + kW2N - 1) / kW2N);
-  return tiles >= 1024 && K >= 256 && N >= 96;
 }
 
 static int pick_splits(int M, int N, int K, int n_cu) {
@@ -1474,7 +1247,6 @@ extern "C" int adt_gemm_bf16(int32_t trans, int64_t M, int64_t N, int64_t K, con
   int splits = 1;
   hipStream_t st = static_cast<hipStream_t>(stream);
   g.colsum_ws = nullptr;
-  g.w2_stagger = 0;
   bool colsum_done = false;
   if (e.colsum_out) {
     if (trans || e.out_fp32) return set_error(ADT_EINVAL, "adt_gemm_bf16: colsum_out needs trans = 0 and a bf16 output");
@@ -1546,26 +1318,6 @@ extern "C" int adt_gemm_bf16(int32_t trans, int64_t M, int64_t N, int64_t K, con
   } else if (trans) {
     if (g.drop.on()) return set_error(ADT_EINVAL, "adt_gemm_bf16: dropout is not supported with trans = 1");
     hipLaunchKernelGGL((gemm_bf16_kernel<true, false>), grid, dim3(kGemmThreads), kGemmLds, st, g);
-  } else if (persistent_ok && use_w2_tile(M, N, K) && vector_epilogue_ok(g, e)) {
-    const int tm = static_cast<int>((M + kW2M - 1) / kW2M), tn = static_cast<int>((N + kW2N - 1) / kW2N);
-    int n_cu = 0;
-    if (int rc = device_cu_count(&n_cu)) return rc;
-    const long nt = static_cast<long>(tm) * tn;
-    const dim3 g1(static_cast<unsigned>(nt < 2L * n_cu ? nt : 2L * n_cu));          // persistent: two workgroups per CU
-    static const int stagger_pct = [] { const char* v = getenv("ADT_GEMM_W2_STAGGER"); return v ? atoi(v) : 100; }();
-    // half a tile period: K loop ~ 600 clocks per K-tile when it runs alone, epilogue of the same order
-    g.w2_stagger = static_cast<int>((K / kW2K) * 600L * stagger_pct / 100 / 4096);
-    for (int x = 0; x < 8; ++x)          // per slice: one ticket per tile + the ending ticket of each of its workgroups
-      g.sched_total[x] = static_cast<unsigned>(nt / 8 + (x < nt % 8 ? 1 : 0)) + g1.x / 8 + (static_cast<unsigned>(x) < g1.x % 8 ? 1u : 0u);
-    if (int rc = sched_counters(stream, &g.sched)) return rc;
-    if (e.colsum_out) {
-      g.colsum_ws = static_cast<float*>(ws);
-      if (g.drop.on()) hipLaunchKernelGGL((gemm_nt_w2_kernel<true, true>), g1, dim3(kW2Threads), kW2Lds, st, g, tm, tn);
-      else hipLaunchKernelGGL((gemm_nt_w2_kernel<false, true>), g1, dim3(kW2Threads), kW2Lds, st, g, tm, tn);
-      launch_reduce_partials(g.colsum_ws, 2 * tm, g.N, e.colsum_out, st);
-      colsum_done = true;
-    } else if (g.drop.on()) hipLaunchKernelGGL((gemm_nt_w2_kernel<true, false>), g1, dim3(kW2Threads), kW2Lds, st, g, tm, tn);
-    else hipLaunchKernelGGL((gemm_nt_w2_kernel<false, false>), g1, dim3(kW2Threads), kW2Lds, st, g, tm, tn);
   } else if (persistent_ok && use_big_tile(M, N, K) && vector_epilogue_ok(g, e)) {
     const int tm = static_cast<int>((M + kBig - 1) / kBig), tn = static_cast<int>((N + kBig - 1) / kBig);
     int n_cu = 0;
@@ -1601,13 +1353,4 @@ extern "C" int adt_gemm_bf16(int32_t trans, int64_t M, int64_t N, int64_t K, con
   if (e.colsum_out && !colsum_done)                  // the smaller tilings leave the sums to the stand-alone kernel
     return adt_colsum_bf16(C, ldc, M, N, e.colsum_out, ws, ws_bytes, stream);
   return ADT_OK;
-}
-
-// (diagnostic, not part of the C ABI) resident workgroups per CU the runtime computes for the w2 kernel
-extern "C" int adtdbg_w2_blocks_per_cu(void) {
-  using namespace adt;
-  if (set_big_lds_once() != ADT_OK) return -1;
-  int n = -1;
-  if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, gemm_nt_w2_kernel<false, false>, kW2Threads, kW2Lds) != hipSuccess) return -2;
-  return n;
 }

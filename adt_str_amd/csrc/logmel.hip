@@ -2,36 +2,41 @@
 //
 // Stands behind ComputeMelSpectrogram.forward (reference model.py:81-97).
 //
-// Launch shape: persistent, one 512-thread workgroup (8 waves) per CU.  Each wave owns
-// a 16,640-byte LDS buffer and walks (clip, frame-pair) work items with a grid stride;
-// the workgroup shares the half-circle twiddle table (8 KiB) and the non-zero mel
-// weights (<= 9 KiB).  150 KiB of the CU's 160 KiB LDS are used, so occupancy is
-// 2 waves per SIMD, set by LDS.  The waveform is read straight from global memory
-// (each sample is touched by ~n_fft/hop = 12.8 overlapping frames, which L2 absorbs);
-// the output rows are staged in LDS and written as whole 512-byte rows (float4/lane).
-// Phase bodies and index maps: logmel_phases.h.
+// Launch shape: persistent, one 1024-thread workgroup (16 waves, four per SIMD, <= 128 VGPRs) per CU.  Each wave owns an
+// 8 KiB LDS buffer and walks (clip, frame) work items with a grid stride: ONE real frame per wave, packed by even / odd samples
+// into a 1024-point complex FFT (logmel2_phases.h: the radix passes, the conflict-free LDS layouts, the real-FFT untangling).
+// The workgroup shares the half-circle twiddle table (8 KiB), the window as (even, odd) pairs (8 KiB) and the non-zero mel
+// weights (<= 9 KiB): 153 KiB of the CU's 160 KiB LDS.  The waveform is read straight from global memory (each sample is
+// touched by ~n_fft/hop = 12.8 overlapping frames, which neighbouring waves take from L2 / L1); an output row is staged in
+// LDS and written as one 512-byte row (float4 per lane).
+// (First generation, round 1: two frames per wave through a 2048-point complex FFT, 16.6 KiB per wave -> 8 waves per CU,
+// 252 VGPRs; 1.05 ms per 256 clips with 43 % of its LDS cycles lost to bank conflicts.)
 #include <hip/hip_runtime.h>
 
 #include "adt_common.h"
-#include "logmel_phases.h"
+#include "logmel2_phases.h"
 
 namespace adt {
 
-constexpr int kWavesPerBlock = 8;
+constexpr int kWavesPerBlock = 16;
 constexpr int kThreads = 64 * kWavesPerBlock;
 constexpr int kMaxMelNnz = 2304;
-constexpr size_t kLdsMelw = 1024 * sizeof(cf);
-constexpr size_t kLdsBufs = kLdsMelw + kMaxMelNnz * sizeof(float);
-constexpr size_t kLdsTotal = kLdsBufs + kWavesPerBlock * kBufElems * sizeof(cf);   // 150,528 B
+constexpr int kMaxMelPad = kMaxMelNnz + 3 * 128;      // every band padded with zero weights to a multiple of 4 bins
+constexpr size_t kLdsTw = (1024 + 520) * sizeof(cf);     // W_1024^j, j < 1024 | W_2048^k, k <= 512 (padded to 520)
+constexpr size_t kLdsWin = 1024 * sizeof(cf);
+constexpr size_t kLdsBands = (128 + 8) * sizeof(unsigned);   // per mel: first bin | padded weight offset << 11 | own trips << 24; then the trip count of each mel item
+constexpr size_t kLdsBufs = kLdsTw + kLdsWin + kMaxMelPad * sizeof(float) + kLdsBands;
+constexpr size_t kLdsTotal = kLdsBufs + kWavesPerBlock * kL2Buf * sizeof(cf);   // 162,912 B
 static_assert(kLdsTotal <= 160 * 1024, "LDS budget");
+static_assert(kL2Stage + 128 <= 2 * kL2Buf, "staged row fits behind the powers");
 
 struct LogmelArgs {
   const float* wave; long n_clips; int n_samples; long ld_wave;
-  int hop; int frame_lo; int n_out; int pairs_per_clip;
+  int hop; int frame_lo; int n_out;
   const float* window; const int4* mel_meta; const float* mel_w; int n_mels; int mel_nnz;
   float log_eps, clamp_lo, clamp_hi;
   float* out;
-  long n_items; int n_iter;
+  long n_items; int n_iter; int pair_loads;       // pair_loads: every clip row is 8-byte aligned (float2 sample loads for even frame starts)
 };
 
 // Every LDS exchange below is private to one wave (buf is the wave's own buffer), so a
@@ -44,111 +49,141 @@ __device__ __forceinline__ void wave_sync() {
   __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
 
+// value of lane (lane ^ 1) / (lane ^ 2): quad_perm [1,0,3,2] = 0xB1 / [2,3,0,1] = 0x4E
+template <int kCtrl>
+__device__ __forceinline__ float quad_xor(float v) {
+  return __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, v), kCtrl, 0xf, 0xf, true));
+}
+
 __global__ __launch_bounds__(kThreads) void logmel_kernel(LogmelArgs a) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-  cf* tw = reinterpret_cast<cf*>(smem);                                  // [1024]
-  float* melw = reinterpret_cast<float*>(smem + kLdsMelw);               // [kMaxMelNnz]
+  cf* t1k = reinterpret_cast<cf*>(smem);                                 // [1024]  W_1024^j, the whole circle
+  cf* t2k = t1k + 1024;                                                  // [513]   W_2048^k
+  cf* win2 = reinterpret_cast<cf*>(smem + kLdsTw);                       // [1024]  (window[2m], window[2m+1])
+  float* melw = reinterpret_cast<float*>(smem + kLdsTw + kLdsWin);       // [kMaxMelPad]  band weights, zero-padded to multiples of 4
+  unsigned* bands = reinterpret_cast<unsigned*>(smem + kLdsTw + kLdsWin + kMaxMelPad * sizeof(float));   // [128 + 8]
   cf* bufs = reinterpret_cast<cf*>(smem + kLdsBufs);
 
   const int tid = threadIdx.x;
-  const int lane = tid & 63;
+  const int lane_id = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // provably wave-uniform -> SGPR addressing
-  cf* buf = bufs + wave * kBufElems;
+  cf* buf = bufs + wave * kL2Buf;
 
-  // shared tables: W_2048^j = exp(-2*pi*i*j/2048), j < 1024; mel weights
+  // shared tables: W_1024^j = exp(-2*pi*i*j/1024), W_2048^k; the window in (even, odd) pairs; mel weights
   for (int j = tid; j < 1024; j += kThreads) {
     float s, c;
-    sincospif(static_cast<float>(j) * (1.0f / 1024.0f), &s, &c);
-    tw[j] = cf{c, -s};
+    sincospif(static_cast<float>(j) * (1.0f / 512.0f), &s, &c);
+    t1k[j] = cf{c, -s};
+    win2[j] = cf{a.window[2 * j], a.window[2 * j + 1]};
+    if (j <= 512) {
+      sincospif(static_cast<float>(j) * (1.0f / 1024.0f), &s, &c);
+      t2k[j] = cf{c, -s};
+    }
   }
-  for (int j = tid; j < a.mel_nnz; j += kThreads) melw[j] = a.mel_w[j];
-
-  // per-lane window values of the two pass-1 items (m = lane + 64*it, n1 = 0..15)
-  float win[2][16];
+  // Mel bands for the reduction: lane 4 g + s of mel item i sums weight * power over bins lo + s, lo + s + 4, ...  To keep that
+  // loop free of per-lane bounds (a divergent trip count costs more VALU than the sums themselves) every band's weights are
+  // padded with zeros to a multiple of four bins and all sixteen bands of an item run the item's longest trip count.
+  for (int j = tid; j < kMaxMelPad; j += kThreads) melw[j] = 0.f;
+  __syncthreads();
+  if (tid < 8) {                                        // trip count of item i = widest of its bands g + 16 i
+    int trips = 0;
+    for (int g = 0; g < 16; ++g) {
+      const int j = g + 16 * tid;
+      const int c = j < a.n_mels ? (a.mel_meta[j].y + 3) >> 2 : 0;
+      trips = c > trips ? c : trips;
+    }
+    bands[128 + tid] = static_cast<unsigned>(trips);
+  }
+  __syncthreads();
+  // Layout of the padded weights: every band of an item as long as the item's trip count when that fits (the loop then needs no
+  // per-lane bound at all: the usual 128-mel filterbanks); else every band padded to its own multiple of four and the loop
+  // masks the weight past the lane's own trips.
+  int item_total = 0;
 #pragma unroll
-  for (int it = 0; it < 2; ++it)
-#pragma unroll
-    for (int n1 = 0; n1 < 16; ++n1) win[it][n1] = a.window[lane + 64 * it + 128 * n1];
-
-  // per-lane constants: the mel bands of the 8 mel items, packed lo | cnt << 11 | off << 18
-  const int g = lane >> 2, s = lane & 3;
-  unsigned mband[8];
-#pragma unroll
-  for (int i = 0; i < 8; ++i) {
-    const int j = g + 16 * i;
-    int4 m = (j < a.n_mels) ? a.mel_meta[j] : make_int4(0, 0, 0, 0);
-    mband[i] = static_cast<unsigned>(m.x) | (static_cast<unsigned>(m.y) << 11) | (static_cast<unsigned>(m.z) << 18);
+  for (int i = 0; i < 8; ++i) item_total += 64 * static_cast<int>(bands[128 + i]);
+  const bool uniform_pad = item_total <= kMaxMelPad;   // block-uniform
+  if (tid < 128) {
+    int poff = 0;                                       // offset of band `tid` in the padded weight array
+    for (int j = 0; j < tid && j < a.n_mels; ++j) poff += uniform_pad ? 4 * static_cast<int>(bands[128 + (j >> 4)]) : (a.mel_meta[j].y + 3) & ~3;
+    const int4 m = (tid < a.n_mels) ? a.mel_meta[tid] : make_int4(0, 0, 0, 0);
+    bands[tid] = static_cast<unsigned>(m.x) | (static_cast<unsigned>(poff) << 11) | (static_cast<unsigned>((m.y + 3) >> 2) << 24);
+    for (int t = 0; t < m.y; ++t) melw[poff + t] = a.mel_w[m.z + t];
   }
   __syncthreads();
 
   const long total_waves = static_cast<long>(gridDim.x) * kWavesPerBlock;
   const long first = static_cast<long>(blockIdx.x) * kWavesPerBlock + wave;
-  const int halfn = kNfft / 2;
 
-  const int lane_id = lane;
   for (int iter = 0; iter < a.n_iter; ++iter) {
-    // Re-derive every per-lane LDS address inside the iteration: left to LICM, the ~150
-    // loop-invariant twiddle/buffer addresses are hoisted and then spilled to scratch.
+    // Re-derive every per-lane LDS address inside the iteration: left to LICM, the loop-invariant twiddle / buffer
+    // addresses are hoisted and then spilled to scratch.
     int lane = lane_id;
     asm volatile("" : "+v"(lane));
     const long item = first + static_cast<long>(iter) * total_waves;
-    const bool active = item < a.n_items;             // wave-uniform
-    long clip_i = 0; int pair = 0;
-    if (active) { clip_i = item / a.pairs_per_clip; pair = static_cast<int>(item - clip_i * a.pairs_per_clip); }
-    const int f0 = 2 * pair;                           // first output frame of the pair
-    const bool has1 = (f0 + 1) < a.n_out;
+    if (item >= a.n_items) break;                      // wave-uniform; no workgroup barrier inside the loop
+    const long clip_i = item / a.n_out;
+    const int f = static_cast<int>(item - clip_i * a.n_out);
     const float* clip = a.wave + clip_i * a.ld_wave;
-    const int base0 = (a.frame_lo + f0) * a.hop - halfn;
-    const int base1 = base0 + a.hop;
-    const bool interior = base0 >= 0 && (base1 + kNfft) <= a.n_samples;
-
-    if (active) {
-      if (interior) {
-        pass1<true>(lane, 0, clip, a.n_samples, base0, base1, has1, win[0], tw, buf);
-        __builtin_amdgcn_sched_barrier(0);
-        pass1<true>(lane, 1, clip, a.n_samples, base0, base1, has1, win[1], tw, buf);
-      } else {
-        pass1<false>(lane, 0, clip, a.n_samples, base0, base1, has1, win[0], tw, buf);
-        __builtin_amdgcn_sched_barrier(0);
-        pass1<false>(lane, 1, clip, a.n_samples, base0, base1, has1, win[1], tw, buf);
-      }
+    const int base = (a.frame_lo + f) * a.hop - kNfft / 2;
+    if (base >= 0 && base + kNfft <= a.n_samples) {
+      if (a.pair_loads && !(base & 1)) l2_pass1<true, true>(lane, clip, a.n_samples, base, win2, t1k, buf);     // 8-byte sample loads
+      else l2_pass1<true, false>(lane, clip, a.n_samples, base, win2, t1k, buf);
+    } else {
+      l2_pass1<false, false>(lane, clip, a.n_samples, base, win2, t1k, buf);
     }
     wave_sync();
-    if (active) { pass2(lane, 0, tw, buf); __builtin_amdgcn_sched_barrier(0); pass2(lane, 1, tw, buf); }
+    cf z[2][8];
+    l2_pass2_load(lane, 0, buf, z[0]);
+    l2_pass2_load(lane, 1, buf, z[1]);
     wave_sync();
-    cf z[4][8];
-    if (active) {
+    l2_pass2_store(lane, 0, z[0], t1k, buf);
+    __builtin_amdgcn_sched_barrier(0);
+    l2_pass2_store(lane, 1, z[1], t1k, buf);
+    wave_sync();
+    l2_pass3_load(lane, 0, buf, z[0]);
+    l2_pass3_load(lane, 1, buf, z[1]);
+    wave_sync();
+    l2_pass3_store(lane, 0, z[0], buf);
+    l2_pass3_store(lane, 1, z[1], buf);
+    wave_sync();
+    float pk[8], pnk[8], p512;
+    l2_untangle_load(lane, t2k, buf, pk, pnk, p512);
+    wave_sync();
+    float* pw = reinterpret_cast<float*>(buf);
+    l2_untangle_store(lane, pk, pnk, p512, pw);
+    wave_sync();
+    const int g = lane >> 2, s = lane & 3;
+    float* stage = pw + kL2Stage;
 #pragma unroll
-      for (int it = 0; it < 4; ++it) pass3_load(lane, it, buf, z[it]);
-    }
-    wave_sync();
-    if (active) {
-#pragma unroll
-      for (int it = 0; it < 4; ++it) pass3_store(lane, it, z[it], buf);
-    }
-    wave_sync();
-    if (active) untangle(lane, buf);
-    wave_sync();
-    if (active) {
-      float* stage = reinterpret_cast<float*>(buf + kStageBase);
-#pragma unroll
-      for (int i = 0; i < 8; ++i) {
-        cf acc = mel_partial(s, mband[i] & 2047u, (mband[i] >> 11) & 127u, mband[i] >> 18, melw, buf);
-        acc.x += __shfl_xor(acc.x, 1); acc.y += __shfl_xor(acc.y, 1);
-        acc.x += __shfl_xor(acc.x, 2); acc.y += __shfl_xor(acc.y, 2);
-        const int j = g + 16 * i;
-        if (s == 0 && j < a.n_mels) {
-          stage[j] = post(acc.x, a.log_eps, a.clamp_lo, a.clamp_hi);
-          stage[a.n_mels + j] = post(acc.y, a.log_eps, a.clamp_lo, a.clamp_hi);
+    for (int i = 0; i < 8; ++i) {
+      const unsigned mb = bands[g + 16 * i];
+      const int trips = __builtin_amdgcn_readfirstlane(static_cast<int>(bands[128 + i]));     // wave-uniform
+      const float* pp = pw + (mb & 2047u) + s;           // (bins past the band's end carry zero weights; they stay inside the wave's buffer)
+      const float* wp = melw + ((mb >> 11) & 8191u) + s;
+      float acc = 0.f;
+      if (uniform_pad) {
+        int t = 0;
+        for (; t + 4 <= trips; t += 4) {               // four independent read pairs in flight: the sum is a latency chain otherwise
+          const float w0 = wp[4 * t], w1 = wp[4 * t + 4], w2 = wp[4 * t + 8], w3 = wp[4 * t + 12];
+          const float p0 = pp[4 * t], p1 = pp[4 * t + 4], p2 = pp[4 * t + 8], p3 = pp[4 * t + 12];
+          acc = fmaf(w0, p0, acc); acc = fmaf(w1, p1, acc); acc = fmaf(w2, p2, acc); acc = fmaf(w3, p3, acc);
         }
+        for (; t < trips; ++t) acc = fmaf(wp[4 * t], pp[4 * t], acc);
+      } else {
+        const int own = static_cast<int>(mb >> 24);
+        for (int t = 0; t < trips; ++t) acc = fmaf(t < own ? wp[4 * t] : 0.f, pp[4 * t], acc);
       }
+      acc += quad_xor<0xB1>(acc);                        // lanes s ^ 1, then s ^ 2: DPP quad permutes (no LDS round trip)
+      acc += quad_xor<0x4E>(acc);
+      if (s == 0) stage[g + 16 * i] = acc;               // raw band energies; the logarithm is taken once per output element below
     }
     wave_sync();
-    if (active) {
-      const float4* stage4 = reinterpret_cast<const float4*>(buf + kStageBase);
-      const int quads = (has1 ? 2 : 1) * a.n_mels / 4;   // rows f0, f0+1 are contiguous in out
-      float4* dst = reinterpret_cast<float4*>(a.out + (clip_i * a.n_out + f0) * a.n_mels);
-      if (lane < quads) dst[lane] = stage4[lane];
+    if (lane < a.n_mels / 2) {                         // two mels per lane: log / clamp / scale (model.py:91-93) and the 512-byte row
+      const float2 e = reinterpret_cast<const float2*>(stage)[lane];
+      float2 y;
+      y.x = post_fast(e.x, a.log_eps, a.clamp_lo, a.clamp_hi);
+      y.y = post_fast(e.y, a.log_eps, a.clamp_lo, a.clamp_hi);
+      reinterpret_cast<float2*>(a.out + (clip_i * a.n_out + f) * a.n_mels)[lane] = y;
     }
     wave_sync();
   }
@@ -168,6 +203,7 @@ extern "C" int adt_logmel_f32(const float* wave, int64_t n_clips, int64_t n_samp
   if (n_fft != kNfft) return set_error(ADT_ESHAPE, "adt_logmel_f32: only n_fft == 2048 is supported");
   if (n_mels <= 0 || n_mels > 128 || (n_mels & 3)) return set_error(ADT_ESHAPE, "adt_logmel_f32: n_mels must be a multiple of 4 in [4,128]");
   if (mel_nnz < 0 || mel_nnz > kMaxMelNnz) return set_error(ADT_ESHAPE, "adt_logmel_f32: filterbank has too many non-zeros");
+  // (mel_meta is validated by the caller's MelBands: bands inside [0, n_fft/2], at most 127 bins each, offsets inside mel_w)
   if (n_samples >= (1ll << 30)) return set_error(ADT_ESHAPE, "adt_logmel_f32: n_samples must be below 2^30");
   if (n_samples <= n_fft / 2) return set_error(ADT_ESHAPE, "adt_logmel_f32: n_samples must exceed n_fft/2 (reflect padding)");
   // the last frame asked for must exist: frame t needs t*hop <= n_samples (1 + L//hop frames)
@@ -178,11 +214,12 @@ extern "C" int adt_logmel_f32(const float* wave, int64_t n_clips, int64_t n_samp
 
   LogmelArgs a;
   a.wave = wave; a.n_clips = n_clips; a.n_samples = static_cast<int>(n_samples); a.ld_wave = ld_wave;
-  a.hop = hop; a.frame_lo = frame_lo; a.n_out = n_out; a.pairs_per_clip = (n_out + 1) / 2;
+  a.hop = hop; a.frame_lo = frame_lo; a.n_out = n_out;
   a.window = window; a.mel_meta = reinterpret_cast<const int4*>(mel_meta); a.mel_w = mel_w;
   a.n_mels = n_mels; a.mel_nnz = mel_nnz;
   a.log_eps = log_eps; a.clamp_lo = clamp_lo; a.clamp_hi = clamp_hi; a.out = out;
-  a.n_items = n_clips * a.pairs_per_clip;
+  a.n_items = n_clips * n_out;
+  a.pair_loads = ((reinterpret_cast<uintptr_t>(wave) & 7u) == 0 && (ld_wave & 1) == 0) ? 1 : 0;
 
   int n_cu = 0;
   if (int e = device_cu_count(&n_cu)) return e;

@@ -34,7 +34,7 @@ constexpr int kBM = 128, kBN = 128, kBK = 16, kLdT = kBM + 4;       // LDS tiles
 struct GemmF32Args {
   const float *A, *B; float* C; long lda, ldb, ldc; int M, N, K;
   const float* bias; const float* gelu_grad_of; long ld_gg; float* pre_act_out; long ld_pa;
-  const float* residual; long ld_res; int res_row_mod; int act; float alpha; Drop drop; int drop_after_residual;
+  const float* residual; long ld_res; int res_row_mod; int act; float alpha; Drop drop; int drop_after_residual; int act_grad_mode;
 };
 
 // One 128 x 16 operand tile as two float4 per thread.  kKMajor = false: X is [rows][K] (k contiguous);
@@ -118,11 +118,14 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmF32Args g) {
         const int row = m0 + wm * 64 + mi * 32 + rowmap(e, h);
         if (row >= g.M) continue;
         float z = g.alpha * acc[mi][ni][e] + bias;
-        if (g.gelu_grad_of) z *= gelu_erf_grad(g.gelu_grad_of[static_cast<long>(row) * g.ld_gg + col]);
-        if (g.pre_act_out) g.pre_act_out[static_cast<long>(row) * g.ld_pa + col] = z;
+        if (g.gelu_grad_of) {
+          const float u = g.gelu_grad_of[static_cast<long>(row) * g.ld_gg + col];
+          z *= g.act_grad_mode ? u : gelu_erf_grad(u);                 // act_grad_mode: the forward stored gelu'(z) * keep
+        }
+        const float keep = g.drop.on() ? g.drop.scale(static_cast<uint64_t>(row) * dld + col) : 1.0f;
+        if (g.pre_act_out) g.pre_act_out[static_cast<long>(row) * g.ld_pa + col] = (g.act_grad_mode && g.act == 1) ? gelu_erf_grad(z) * keep : z;
         if (g.act == 1) z = gelu_erf(z);
         else if (g.act == 2) z = fmaxf(z, 0.f);
-        const float keep = g.drop.on() ? g.drop.scale(static_cast<uint64_t>(row) * dld + col) : 1.0f;
         if (!g.drop_after_residual) z *= keep;
         if (g.residual) {
           const long rr = g.res_row_mod > 0 ? row % g.res_row_mod : row;
@@ -456,6 +459,7 @@ extern "C" int adt_gemm_f32(int32_t layout, int64_t M, int64_t N, int64_t K, con
     g.pre_act_out = static_cast<float*>(ep->pre_act_out); g.ld_pa = ep->ld_pre_act;
     g.residual = static_cast<const float*>(ep->residual); g.ld_res = ep->ld_res; g.res_row_mod = ep->res_row_mod;
     g.act = ep->act; g.alpha = ep->alpha; g.drop = make_drop(ep->drop.p, ep->drop.key); g.drop_after_residual = ep->drop_after_residual;
+    g.act_grad_mode = ep->act_grad_mode;
   }
   const dim3 grid(static_cast<unsigned>((N + kBN - 1) / kBN), static_cast<unsigned>((M + kBM - 1) / kBM));
   if (!ak && !bk) hipLaunchKernelGGL((gemm_f32_kernel<false, false>), grid, dim3(256), 0, ST(stream), g);

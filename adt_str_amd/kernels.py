@@ -50,15 +50,22 @@ def gemm(a: torch.Tensor, b: torch.Tensor, *, trans: bool = False, out: Optional
          res_row_mod: int = 0, act: int = 0, pre_act_out: Optional[torch.Tensor] = None,
          gelu_grad_of: Optional[torch.Tensor] = None, alpha: float = 1.0,
          aux_bf16_out: Optional[torch.Tensor] = None, drop=None, drop_after_residual: bool = False,
-         colsum_out: Optional[torch.Tensor] = None, b_kn: bool = False) -> torch.Tensor:
+         colsum_out: Optional[torch.Tensor] = None, b_kn: bool = False, act_grad_out: Optional[torch.Tensor] = None,
+         act_grad: Optional[torch.Tensor] = None) -> torch.Tensor:
     """``trans=False``: ``a[M,K] @ b[N,K].T``; ``trans=True``: ``a[K,M].T @ b[K,N]`` (bf16 in, fp32 accumulate).
     ``colsum_out`` (fp32 [N]) also receives the column sums of the bf16 output.
+    ``act_grad_out`` (forward, with ``act=1``): receives ``gelu'(z) * dropout-keep`` instead of the pre-activation;
+    ``act_grad`` (backward): that saved factor, multiplied in as stored (``adt_gemm_epilogue.act_grad_mode``).
     fp32 operands take the fp32-operand parity path (``adt_gemm_f32``: same epilogue, fp32 everywhere); there
     ``b_kn=True`` reads ``b`` as ``[K, N]`` (``a[M,K] @ b[K,N]``, the data gradient against the master weight)."""
+    mode = 0
+    if act_grad_out is not None or act_grad is not None:
+        assert pre_act_out is None and gelu_grad_of is None and (act_grad_out is None or act == 1) and (act_grad is None or drop is None)
+        pre_act_out, gelu_grad_of, mode = act_grad_out, act_grad, 1
     if a.dtype == torch.float32:
         return _gemm_f32(a, b, trans=trans, b_kn=b_kn, out=out, bias=bias, residual=residual, res_row_mod=res_row_mod, act=act,
                          pre_act_out=pre_act_out, gelu_grad_of=gelu_grad_of, alpha=alpha, drop=drop,
-                         drop_after_residual=drop_after_residual, colsum_out=colsum_out, aux_out=aux_bf16_out)
+                         drop_after_residual=drop_after_residual, colsum_out=colsum_out, aux_out=aux_bf16_out, mode=mode)
     assert a.dtype == torch.bfloat16 and b.dtype == torch.bfloat16 and a.dim() == 2 and b.dim() == 2 and not b_kn
     assert a.stride(1) == 1 and b.stride(1) == 1
     if trans:
@@ -74,6 +81,7 @@ def gemm(a: torch.Tensor, b: torch.Tensor, *, trans: bool = False, out: Optional
     ep = _ffi.GemmEpilogue()
     ep.alpha = alpha
     ep.act = act
+    ep.act_grad_mode = mode
     ep.out_fp32 = 1 if out.dtype == torch.float32 else 0
     if drop is not None:
         ep.drop.p, ep.drop.key = drop
@@ -107,7 +115,7 @@ def gemm(a: torch.Tensor, b: torch.Tensor, *, trans: bool = False, out: Optional
 
 
 def _gemm_f32(a, b, *, trans, b_kn, out, bias, residual, res_row_mod, act, pre_act_out, gelu_grad_of, alpha, drop,
-              drop_after_residual, colsum_out, aux_out):
+              drop_after_residual, colsum_out, aux_out, mode=0):
     """fp32-operand GEMM (parity path).  Layout bits: 1 = a is [K, M], 2 = b is [K, N]."""
     assert b.dtype == torch.float32 and a.dim() == 2 and b.dim() == 2 and a.stride(1) == 1 and b.stride(1) == 1
     assert aux_out is None, "the fp32 path has a single (fp32) output"
@@ -122,7 +130,7 @@ def _gemm_f32(a, b, *, trans, b_kn, out, bias, residual, res_row_mod, act, pre_a
         out = torch.empty((M, N), dtype=torch.float32, device=a.device)
     assert out.shape == (M, N) and out.stride(1) == 1 and out.dtype == torch.float32
     ep = _ffi.GemmEpilogue()
-    ep.alpha, ep.act, ep.out_fp32 = alpha, act, 1
+    ep.alpha, ep.act, ep.out_fp32, ep.act_grad_mode = alpha, act, 1, mode
     if drop is not None:
         ep.drop.p, ep.drop.key = drop
         ep.drop_after_residual = 1 if drop_after_residual else 0

@@ -284,7 +284,7 @@ class _Engine:
             y1 = K.gemm(attn, L["sa_o"].w16, bias=L["sa_o"].b, residual=x32, out_dtype=F32, drop=self.D(p + ".drop1"))
             x1_32, x1_16, mean1, rstd1 = self._ln(y1, self.P(p + ".norm1.weight"), self.P(p + ".norm1.bias"))
             u = torch.empty((M, L["l1"].w16.shape[0]), dtype=self.adt, device=src.device)
-            h = K.gemm(x1_16, L["l1"].w16, bias=L["l1"].b, act=1, pre_act_out=u, drop=self.D(p + ".ffn"))
+            h = K.gemm(x1_16, L["l1"].w16, bias=L["l1"].b, act=1, act_grad_out=u, drop=self.D(p + ".ffn"))
             y2 = K.gemm(h, L["l2"].w16, bias=L["l2"].b, residual=x1_32, out_dtype=F32, drop=self.D(p + ".drop2"))
             x2_32, x2_16, mean2, rstd2 = self._ln(y2, self.P(p + ".norm2.weight"), self.P(p + ".norm2.bias"))
             if save is not None:
@@ -320,7 +320,7 @@ class _Engine:
             y2 = K.gemm(ca, L["ca_o"].w16, bias=L["ca_o"].b, residual=x1_32, out_dtype=F32, drop=self.D(p + ".drop2"))
             x2_32, x2_16, mean2, rstd2 = self._ln(y2, self.P(p + ".norm2.weight"), self.P(p + ".norm2.bias"))
             u = torch.empty((Md, L["l1"].w16.shape[0]), dtype=self.adt, device=dev)
-            h = K.gemm(x2_16, L["l1"].w16, bias=L["l1"].b, act=1, pre_act_out=u, drop=self.D(p + ".ffn"))
+            h = K.gemm(x2_16, L["l1"].w16, bias=L["l1"].b, act=1, act_grad_out=u, drop=self.D(p + ".ffn"))
             y3 = K.gemm(h, L["l2"].w16, bias=L["l2"].b, residual=x2_32, out_dtype=F32, drop=self.D(p + ".drop3"))
             x3_32, x3_16, mean3, rstd3 = self._ln(y3, self.P(p + ".norm3.weight"), self.P(p + ".norm3.bias"))
             if save is not None:
@@ -383,7 +383,7 @@ class _Engine:
             p = L["p"]
             dy3_32, dy3_16 = self._ln_bwd(dx32, s["y3"], self.P(p + ".norm3.weight"), s["mean3"], s["rstd3"], G[p + ".norm3.weight"],
                                              G[p + ".norm3.bias"], G[p + ".linear2.bias"], dx16_drop=self.D(p + ".drop3"))
-            du = self._dgrad(dy3_16, L["l2"], gelu_grad_of=s["u"], drop=self.D(p + ".ffn"), colsum_out=G[p + ".linear1.bias"])
+            du = self._dgrad(dy3_16, L["l2"], act_grad=s["u"], colsum_out=G[p + ".linear1.bias"])
             K.gemm(dy3_16, s["h"], trans=True, out=G[p + ".linear2.weight"])
             K.gemm(du, s["x2_16"], trans=True, out=G[p + ".linear1.weight"])
             dx2_32 = self._dgrad(du, L["l1"], residual=dy3_32, out_dtype=F32)
@@ -427,7 +427,7 @@ class _Engine:
             p = L["p"]
             dy2_32, dy2_16 = self._ln_bwd(dx32, s["y2"], self.P(p + ".norm2.weight"), s["mean2"], s["rstd2"], G[p + ".norm2.weight"],
                                              G[p + ".norm2.bias"], G[p + ".linear2.bias"], dx16_drop=self.D(p + ".drop2"))
-            du = self._dgrad(dy2_16, L["l2"], gelu_grad_of=s["u"], drop=self.D(p + ".ffn"), colsum_out=G[p + ".linear1.bias"])
+            du = self._dgrad(dy2_16, L["l2"], act_grad=s["u"], colsum_out=G[p + ".linear1.bias"])
             K.gemm(dy2_16, s["h"], trans=True, out=G[p + ".linear2.weight"])
             K.gemm(du, s["x1_16"], trans=True, out=G[p + ".linear1.weight"])
             dx1_32 = self._dgrad(du, L["l1"], residual=dy2_32, out_dtype=F32)

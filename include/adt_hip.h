@@ -151,6 +151,10 @@ int adt_mix_render_fx_f32(const float* bank, const int64_t* bank_off, int64_t n_
  *   * gelu'(gelu_grad_of[row,col])       (bf16 pre-activation u; dgrad through GELU)
  *   pre_act_out[row,col] = bf16(z)       (saved pre-activation, may be null)
  *   act == 1: z = gelu_erf(z)            (exact erf GELU, activation="gelu"); act == 2: z = max(z, 0) (ReLU)
+ *   act_grad_mode == 1 changes what is saved for / read by the backward of "dropout(gelu(z))": the forward call (act == 1,
+ *   pre_act_out given) stores bf16(gelu'(z) * keep) -- the derivative times the dropout factor of this very epilogue --
+ *   instead of z, and GELU sees the fp32 z; the backward call multiplies by gelu_grad_of[row,col] as stored (no erf, no
+ *   mask hashing: pass no dropout there).  One extra bf16 rounding on the factor, well inside the bf16 path's tolerance.
  *   dropout (drop.p > 0, drop_after_residual == 0), element index row*N + col
  *   + residual[row % res_row_mod, col]   (fp32; res_row_mod == 0: plain row) --
  *                                         residual stream, or the sinusoidal PE
@@ -181,6 +185,7 @@ typedef struct adt_gemm_epilogue {
   void*        aux_bf16_out;  int64_t ld_aux;
   adt_dropout  drop;          int32_t drop_after_residual;
   float*       colsum_out;
+  int32_t      act_grad_mode;
 } adt_gemm_epilogue;
 
 size_t adt_gemm_workspace_bytes(int32_t trans, int64_t M, int64_t N, int64_t K);

@@ -1,4 +1,4 @@
-// Host emulation of K9's phase bodies (adt_str_amd/csrc/fft1024_phases.h); see logmel_emu.cpp.
+// Host emulation of K9's phase bodies (adt_str_amd/csrc/fft1024_phases.h); see logmel2_emu.cpp.
 #include <cmath>
 #include <cstdint>
 #include <vector>

@@ -74,6 +74,23 @@ def test_hf_trainer_hook_runs_and_saves(tmp_path):
     assert losses and all(np.isfinite(losses))
     out = cfg["logging"]["output_dir"]
     assert os.path.exists(os.path.join(out, "model.safetensors")) or os.path.exists(os.path.join(out, "pytorch_model.bin"))
+    # the validation hook (reference train.py:80-141): mean of the per-batch eval-mode losses over an iterable of collated batches
+    ds = trainer.train_dataset
+    import random
+    random.seed(3)
+    batches = [ds.collate([ds[i] for i in range(k, k + 4)]) for k in (0, 4)]
+    assert trainer.evaluate() == {}
+    metrics = trainer.evaluate(eval_dataset=batches)
+    model = trainer.model.eval()
+    want = []
+    with torch.no_grad():
+        for b in batches:
+            tok = b["tokens"].cuda()
+            T = tok.shape[1] - 1
+            pad = torch.arange(T, device="cuda")[None, :] >= b["token_lengths"].cuda()[:, None]
+            want.append(float(model(src=b["wavs"], tgt=tok[:, :-1], tgt_mask=None, tgt_padding_mask=pad, labels=tok[:, 1:])))
+    assert "eval_loss" in metrics and abs(metrics["eval_loss"] - sum(want) / 2) < 1e-5      # (HF's log() adds "epoch" to the dict)
+    assert any("eval_loss" in h for h in trainer.state.log_history)
 
 
 def _parse_midi_note_ons(path):

@@ -219,3 +219,43 @@ def test_persistent_work_counters_reset_themselves_and_capture_takes_the_tiled_k
         graph.replay()
         close(out, a.float() @ b.float().t(), 1e-4, "graph replay")
     close(k.gemm(a, b, out_dtype=torch.float32), a.float() @ b.float().t(), 1e-4, "persistent NT after the replays")
+
+
+@pytest.mark.parametrize("M,N,Kd", [(8192, 3072, 768), (300, 264, 96)])      # persistent 256^2 kernel / 128^2 kernel
+def test_saved_activation_gradient_factor(M, N, Kd):
+    """adt_gemm_epilogue.act_grad_mode: the FFN forward saves gelu'(z) * dropout-keep (bf16) instead of z, the backward
+    multiplies by it as stored -- against autograd through dropout(gelu(z)) with the kernels' own mask."""
+    import torch.nn.functional as F
+    from adt_str_amd import kernels as k
+    from oracle import dropout as o_drop
+    a, w, bias = rnd((M, Kd), 1).bfloat16(), rnd((N, Kd), 2, 0.2).bfloat16(), rnd((N,), 3)
+    for site in (None, k.drop_site(0.1, 9, 2)):
+        keep = o_drop.scale((M, N), *site).to(DEV) if site else torch.ones((M, N), device=DEV)
+        z = (a.float() @ w.float().t() + bias).requires_grad_(True)
+        ref_h = F.gelu(z) * keep
+        dy = rnd((M, N), 4)
+        ref_h.backward(dy)
+        fac = torch.empty((M, N), dtype=torch.bfloat16, device=DEV)
+        h = k.gemm(a, w, bias=bias, act=1, act_grad_out=fac, drop=site)
+        close(h, ref_h.detach(), 6e-3, "h")
+        zd = z.detach().double()
+        ref_fac = ((0.5 * (1 + torch.erf(zd / math.sqrt(2))) + zd * torch.exp(-0.5 * zd * zd) / math.sqrt(2 * math.pi)) * keep).float()
+        assert (z.grad - dy * ref_fac).abs().max() <= 1e-5 * dy.abs().max()       # = gelu'(z) * keep, as autograd has it
+        assert (fac.float() - ref_fac).abs().max() <= 8e-3 * ref_fac.abs().max() + 1e-6
+        # backward: (dy16 @ W2^T) * factor, with the column sums of the result
+        dy16, w2t = rnd((M, 64), 5).bfloat16(), rnd((N, 64), 6, 0.3).bfloat16()
+        cs = torch.empty(N, device=DEV)
+        du = k.gemm(dy16, w2t, act_grad=fac, colsum_out=cs)
+        ref_du = (dy16.float() @ w2t.float().t()) * fac.float()
+        close(du, ref_du, 8e-3, "du")
+        assert (cs - du.float().sum(0)).abs().max() <= 2e-3 * du.float().abs().sum(0).max()
+    # fp32-operand path: the same contract in fp32
+    a32, w32 = a.float(), w.float()
+    fac32 = torch.empty((M, N), device=DEV)
+    h32 = k.gemm(a32, w32, bias=bias, act=1, act_grad_out=fac32)
+    z = (a32 @ w32.t() + bias).double().requires_grad_(True)
+    F.gelu(z).sum().backward()
+    assert (h32.double() - F.gelu(z.detach())).abs().max() < 2e-5 and (fac32.double() - z.grad).abs().max() < 2e-5
+    dy32 = rnd((M, N), 7)
+    got = k.gemm(dy32, torch.eye(N, device=DEV), act_grad=fac32)
+    assert (got - dy32 * fac32).abs().max() < 1e-5

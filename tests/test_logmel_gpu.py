@@ -115,3 +115,14 @@ def test_c_abi_rejects_bad_shapes(dev):
         _ffi.call("adt_logmel_f32", x.data_ptr(), 1, 4096, 4096, 1024, 160, 7, 1, x.data_ptr(), x.data_ptr(),
                   x.data_ptr(), 128, 0, 1e-10, -23.0, 12.0, x.data_ptr(), 0)
     assert e.value.code == -2
+
+
+@pytest.mark.parametrize("n_mels,sr", [(64, 16000), (40, 16000), (80, 22050), (128, 48000)])
+def test_other_filterbanks_take_both_band_layouts(dev, n_mels, sr):
+    """The mel reduction pads every band of an item to the item's trip count when that fits the LDS table (128-mel banks) and
+    otherwise masks per lane (few wide bands, e.g. 40 mels: the padded table would not fit): both against the oracle."""
+    rng = np.random.default_rng(5)
+    wave = (rng.standard_normal((3, 12000)) * 0.2).astype(np.float32)
+    got = gpu_logmel(wave, sr, dev, n_mels=n_mels)
+    ref = o_logmel.logmel(torch.from_numpy(wave), sr, 2048, 0.01, n_mels).numpy()
+    assert got.shape == ref.shape and np.abs(got - ref).max() < 2e-5

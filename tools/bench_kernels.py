@@ -52,6 +52,15 @@ def main():
     du = torch.empty((M, 3072), device=dev, dtype=torch.bfloat16)
     ms = timeit(lambda: K.gemm(a, b, gelu_grad_of=u, drop=(0.1, 3), out=du))
     print(f"NT FFN dgrad through GELU + dropout: {ms:.3f} ms  {2.0*M*3072*768/ms/1e9:.1f} TFLOP/s")
+    cs = torch.empty(3072, device=dev)
+    ms = timeit(lambda: K.gemm(a, b, gelu_grad_of=u, drop=(0.1, 3), out=du, colsum_out=cs))
+    print(f"NT FFN dgrad through GELU + dropout + colsum: {ms:.3f} ms  {2.0*M*3072*768/ms/1e9:.1f} TFLOP/s")
+    ms = timeit(lambda: K.gemm(a, b, act_grad=u, out=du, colsum_out=cs))
+    print(f"NT FFN dgrad x saved factor + colsum: {ms:.3f} ms  {2.0*M*3072*768/ms/1e9:.1f} TFLOP/s")
+    ms = timeit(lambda: K.gemm(a, b, bias=bias, act=1, act_grad_out=u, drop=(0.1, 3)))
+    print(f"NT FFN1 + bias + GELU + dropout + saved factor: {ms:.3f} ms  {2.0*M*3072*768/ms/1e9:.1f} TFLOP/s")
+    ms = timeit(lambda: K.gemm(a, b, bias=bias, act=1, pre_act_out=u, drop=(0.1, 3)))
+    print(f"NT FFN1 + bias + GELU + dropout + pre-act: {ms:.3f} ms  {2.0*M*3072*768/ms/1e9:.1f} TFLOP/s")
     ms = timeit(lambda: K.gemm(du, w2, residual=res, out_dtype=torch.float32))
     print(f"NT dx (K=3072) + residual fp32: {ms:.3f} ms  {2.0*M*3072*768/ms/1e9:.1f} TFLOP/s")
     if only == "nt":

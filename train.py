@@ -52,6 +52,33 @@ class ADTTrainer(Trainer):
         # and an allocator flush per step with no effect on the result -- deliberately not reproduced
         return (loss, None) if return_outputs else loss
 
+    def evaluate(self, eval_dataset=None, ignore_keys=None, metric_key_prefix="eval"):
+        """Validation loss over an iterable of collated batches (reference train.py:80-141): the mean of the per-batch
+        losses, logged as ``{prefix}_loss``; ``{}`` without an eval dataset (the shipped configs pass none, train.py:313).
+        The per-batch ``.item()`` / ``gc.collect()`` / ``empty_cache()`` of the reference are not reproduced: the batch
+        losses stay on the device and are read once at the end."""
+        eval_dataset = eval_dataset if eval_dataset is not None else self.eval_dataset
+        if eval_dataset is None:
+            return {}
+        model = self.model
+        was_training = model.training
+        model.eval()
+        device = next(model.parameters()).device
+        losses = []
+        with torch.no_grad():
+            for batch in eval_dataset:
+                tokens = batch["tokens"].to(device)
+                wavs = batch["wavs"].to(device)
+                token_lengths = batch["token_lengths"].to(device)
+                tgt_input, labels = tokens[:, :-1], tokens[:, 1:]
+                _, tgt_padding_mask = create_mask_plain(tgt_input.size(1), token_lengths, device)
+                losses.append(model(src=wavs, tgt=tgt_input, tgt_mask=None, tgt_padding_mask=tgt_padding_mask, labels=labels).reshape(()))
+        model.train(was_training)
+        avg_loss = float(torch.stack(losses).mean().item()) if losses else 0.0
+        metrics = {f"{metric_key_prefix}_loss": avg_loss}
+        self.log(metrics)
+        return metrics
+
 
 def create_training_arguments(cfg: dict) -> "TrainingArguments":
     t, lg, ex, ck = cfg["training"], cfg["logging"], cfg["experiment"], cfg["checkpoint"]
