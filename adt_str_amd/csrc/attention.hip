@@ -222,6 +222,19 @@ struct AttnArgs {
   float* cs_dq;        // column sums of dQ per (batch, 128-query block): [B * ceil(Sq/128)][H*128], null: off
 };
 
+// Tile coordinates of this workgroup.  The grids are 1-D: nx tiles (query or key blocks) per (batch, head) times ny = B * H.
+// Workgroups are dealt round-robin over the 8 XCDs (blocks b and b + 8 share one), so ids are renumbered to give every XCD a
+// CONTIGUOUS range of logical tiles, x fastest: all blocks of one (batch, head) then sit on one XCD at about the same time, and
+// that XCD's L2 fetches the head's K / V (or Q / dO) once instead of eight L2s fetching it once each.  Placement only changes
+// speed, never results; the map is a bijection for any grid size (same renumbering as the GEMMs).
+struct TileXY { int x, y; };
+__device__ __forceinline__ TileXY tile_coords(int nx) {
+  const int n = gridDim.x, id = blockIdx.x;
+  const int q = n >> 3, r = n & 7, xcd = id & 7;
+  const int logical = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (id >> 3);
+  return TileXY{logical % nx, logical / nx};
+}
+
 // additive mask of the reference (model.py:173-181): causal and key-padding contributions add up
 __device__ __forceinline__ float mask_add(const AttnArgs& a, int qi, int ki, int klen) {
   float m = 0.f;
@@ -236,8 +249,9 @@ __global__ __launch_bounds__(kAttnThreads, 2) void attn_fwd_kernel(AttnArgs a) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];     // [2 stages][K tile | V tile]
   const int tid = threadIdx.x, lane = tid & 63, r = lane & 31, h = lane >> 5;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int b = blockIdx.y / a.H, head = blockIdx.y % a.H;
-  const int q0 = blockIdx.x * 128 + wave * 32;
+  const TileXY tc = tile_coords((a.Sq + 127) / 128);
+  const int b = tc.y / a.H, head = tc.y % a.H;
+  const int q0 = tc.x * 128 + wave * 32;
   const int qi = q0 + r;
   const unsigned short* qb = a.q + static_cast<long>(b) * a.Sq * a.ldq + head * kDh;
   const unsigned short* kb_ = a.k + static_cast<long>(b) * a.Sk * a.ldk + head * kDh;
@@ -363,8 +377,9 @@ __global__ __launch_bounds__(kAttnThreads, 2) void attn_bwd_dq_kernel(AttnArgs a
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const int tid = threadIdx.x, lane = tid & 63, r = lane & 31, h = lane >> 5;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int b = blockIdx.y / a.H, head = blockIdx.y % a.H;
-  const int qi = blockIdx.x * 128 + wave * 32 + r;
+  const TileXY tc = tile_coords((a.Sq + 127) / 128);
+  const int b = tc.y / a.H, head = tc.y % a.H;
+  const int qi = tc.x * 128 + wave * 32 + r;
   const unsigned short* qb = a.q + static_cast<long>(b) * a.Sq * a.ldq + head * kDh;
   const unsigned short* dob = a.dout + static_cast<long>(b) * a.Sq * a.ldo + head * kDh;
   const unsigned short* kb_ = a.k + static_cast<long>(b) * a.Sk * a.ldk + head * kDh;
@@ -477,7 +492,7 @@ __global__ __launch_bounds__(kAttnThreads, 2) void attn_bwd_dq_kernel(AttnArgs a
     colsum_transposed(dq, a.scale, qi < a.Sq, lane, red + wave * kDh);
     __syncthreads();
     if (tid < kDh)
-      a.cs_dq[(static_cast<long>(b) * gridDim.x + blockIdx.x) * (a.H * kDh) + head * kDh + tid] =
+      a.cs_dq[(static_cast<long>(b) * ((a.Sq + 127) / 128) + tc.x) * (a.H * kDh) + head * kDh + tid] =
           (red[tid] + red[kDh + tid]) + (red[2 * kDh + tid] + red[3 * kDh + tid]);
   }
 }
@@ -489,8 +504,9 @@ __global__ __launch_bounds__(kAttnThreads, 1) void attn_bwd_dkv_kernel(AttnArgs 
   constexpr int kStage = 2 * kAttnTileBytes + 512;
   const int tid = threadIdx.x, lane = tid & 63, r = lane & 31, h = lane >> 5;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int b = blockIdx.y / a.H, head = blockIdx.y % a.H;
-  const int ki = blockIdx.x * 128 + wave * 32 + r;
+  const TileXY tc = tile_coords((a.Sk + 127) / 128);
+  const int b = tc.y / a.H, head = tc.y % a.H;
+  const int ki = tc.x * 128 + wave * 32 + r;
   const unsigned short* qb = a.q + static_cast<long>(b) * a.Sq * a.ldq + head * kDh;
   const unsigned short* dob = a.dout + static_cast<long>(b) * a.Sq * a.ldo + head * kDh;
   const unsigned short* kb_ = a.k + static_cast<long>(b) * a.Sk * a.ldk + head * kDh;
@@ -503,7 +519,7 @@ __global__ __launch_bounds__(kAttnThreads, 1) void attn_bwd_dkv_kernel(AttnArgs 
   const unsigned sk_pairs = static_cast<unsigned>((a.Sk + 1) >> 1);
   const unsigned headpair = static_cast<unsigned>((static_cast<uint64_t>(b) * a.H + head) * a.Sq * sk_pairs) + static_cast<unsigned>(ki >> 1);
   const unsigned key2 = mix32(a.drop.key);
-  const int k_end = blockIdx.x * 128 + 128;
+  const int k_end = tc.x * 128 + 128;
   const bool key_mask = a.causal || k_end > klen || k_end > a.Sk;
 
   bf16x8 kf[8], vf[8];
@@ -630,8 +646,9 @@ __global__ __launch_bounds__(kDkv2Threads) void attn_bwd_dkv2_kernel(AttnArgs a)
   const int tid = threadIdx.x, lane = tid & 63, r = lane & 31, h = lane >> 5;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int role = wave >> 2, pair = wave & 3;                    // role 0: S-wave, 1: acc-wave
-  const int b = blockIdx.y / a.H, head = blockIdx.y % a.H;
-  const int ki = blockIdx.x * 128 + pair * 32 + r;
+  const TileXY tc = tile_coords((a.Sk + 127) / 128);
+  const int b = tc.y / a.H, head = tc.y % a.H;
+  const int ki = tc.x * 128 + pair * 32 + r;
   const unsigned short* qb = a.q + static_cast<long>(b) * a.Sq * a.ldq + head * kDh;
   const unsigned short* dob = a.dout + static_cast<long>(b) * a.Sq * a.ldo + head * kDh;
   const float* lse_b = a.lse + (static_cast<long>(b) * a.H + head) * a.Sq;
@@ -709,7 +726,7 @@ __global__ __launch_bounds__(kDkv2Threads) void attn_bwd_dkv2_kernel(AttnArgs a)
     asm volatile("s_barrier" ::: "memory");
     const int klen = a.key_len ? a.key_len[b] : a.Sk;
     const float sl2 = a.scale * kLog2e;
-    const int k_end = blockIdx.x * 128 + 128;
+    const int k_end = tc.x * 128 + 128;
     const bool key_mask = a.causal || k_end > klen || k_end > a.Sk;
 #pragma unroll
     for (int s = 0; s < 8; ++s) asm volatile("" :: "v"(kf[s]), "v"(vf[s]));      // first use here: the compiler's wait for these loads
@@ -971,7 +988,7 @@ extern "C" int adt_attn_fwd(const adt_attn_desc* d, const void* q, const void* k
   a.out = static_cast<unsigned short*>(o); a.lse = lse;
   const int lds = 4 * kAttnTileBytes;
   if (int rc = set_lds_once()) return rc;
-  const dim3 grid((d->q_len + 127) / 128, d->batch * d->heads);
+  const dim3 grid(static_cast<unsigned>((d->q_len + 127) / 128) * d->batch * d->heads);      // 1-D: tile_coords() renumbers it
   if (a.drop.on()) hipLaunchKernelGGL(attn_fwd_kernel<true>, grid, dim3(kAttnThreads), lds, static_cast<hipStream_t>(stream), a);
   else hipLaunchKernelGGL(attn_fwd_kernel<false>, grid, dim3(kAttnThreads), lds, static_cast<hipStream_t>(stream), a);
   ADT_HIP_TRY(hipGetLastError());
@@ -1006,7 +1023,7 @@ extern "C" int adt_attn_bwd(const adt_attn_desc* d, const void* q, const void* k
   if (want_cs) a.cs_dq = static_cast<float*>(ws) + delta_floats(d);
   const int lds_dq = 4 * kAttnTileBytes, lds_dkv = 2 * (2 * kAttnTileBytes + 512);
   if (int rc = set_lds_once()) return rc;
-  const dim3 gq((d->q_len + 127) / 128, d->batch * d->heads), gk((d->k_len + 127) / 128, d->batch * d->heads);
+  const dim3 gq(static_cast<unsigned>((d->q_len + 127) / 128) * d->batch * d->heads), gk(static_cast<unsigned>((d->k_len + 127) / 128) * d->batch * d->heads);
   static const int dkv_env = [] { const char* v = getenv("ADT_ATTN_DKV"); return v ? atoi(v) : 2; }();   // 1: single-wave kernel (A/B arm)
   const int dkv_variant = want_cs ? 2 : dkv_env;             // the column sums live in the producer / consumer kernel only
   if (a.drop.on()) {
