@@ -111,16 +111,23 @@ __global__ __launch_bounds__(kThreads) void logmel_kernel(LogmelArgs a) {
   }
   __syncthreads();
 
-  const long total_waves = static_cast<long>(gridDim.x) * kWavesPerBlock;
-  const long first = static_cast<long>(blockIdx.x) * kWavesPerBlock + wave;
+  // Work split: the items (clip, frame) are cut into eight contiguous ranges, one per XCD group (workgroups b and b + 8 share an
+  // XCD under round-robin placement; only speed depends on that): neighbouring frames overlap by 1 - hop / n_fft = 92 % of their
+  // samples, so one XCD's L2 then fetches a stretch of waveform once instead of all eight fetching all of it.
+  const int ng = gridDim.x < 8 ? static_cast<int>(gridDim.x) : 8;               // groups (small launches: one workgroup each)
+  const int xg = blockIdx.x % ng, n_grp = (static_cast<int>(gridDim.x) + ng - 1 - xg) / ng;      // workgroups in this group
+  const long per = (a.n_items + ng - 1) / ng;
+  const long lo = per * xg, hi = lo + per < a.n_items ? lo + per : a.n_items;
+  const long group_waves = static_cast<long>(n_grp) * kWavesPerBlock;
+  const long first = lo + static_cast<long>(blockIdx.x / ng) * kWavesPerBlock + wave;
 
   for (int iter = 0; iter < a.n_iter; ++iter) {
     // Re-derive every per-lane LDS address inside the iteration: left to LICM, the loop-invariant twiddle / buffer
     // addresses are hoisted and then spilled to scratch.
     int lane = lane_id;
     asm volatile("" : "+v"(lane));
-    const long item = first + static_cast<long>(iter) * total_waves;
-    if (item >= a.n_items) break;                      // wave-uniform; no workgroup barrier inside the loop
+    const long item = first + static_cast<long>(iter) * group_waves;
+    if (item >= hi) break;                             // wave-uniform; no workgroup barrier inside the loop
     const long clip_i = item / a.n_out;
     const int f = static_cast<int>(item - clip_i * a.n_out);
     const float* clip = a.wave + clip_i * a.ld_wave;
@@ -225,8 +232,10 @@ extern "C" int adt_logmel_f32(const float* wave, int64_t n_clips, int64_t n_samp
   if (int e = device_cu_count(&n_cu)) return e;
   long blocks = (a.n_items + kWavesPerBlock - 1) / kWavesPerBlock;
   if (blocks > n_cu) blocks = n_cu;
-  const long total_waves = blocks * kWavesPerBlock;
-  a.n_iter = static_cast<int>((a.n_items + total_waves - 1) / total_waves);
+  // per XCD group: ceil(n_items / 8) items over floor(blocks / 8) (at least one) workgroups of 16 waves
+  const long ng = blocks < 8 ? blocks : 8;
+  const long per_group = (a.n_items + ng - 1) / ng, group_waves = (blocks / ng) * kWavesPerBlock;
+  a.n_iter = static_cast<int>((per_group + group_waves - 1) / group_waves);
 
   const size_t lds = kLdsTotal;
   static thread_local int attr_set_for_device = -1;

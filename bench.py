@@ -54,7 +54,7 @@ def pmc_traffic_bytes(name):
     """HBM-side bytes per launch of the roofline kernel from the committed rocprofv3 --pmc summary of the same launch
     (tools/run_pmc_*.sh; FETCH_SIZE / WRITE_SIZE are in KiB, and gfx950 tallies 128-byte read requests at 64 bytes:
     MI355X_MICROARCH.md, HBM section).  None when the summary is not there."""
-    path = os.path.join(ROOT, "profiles", "r01", name)
+    path = os.path.join(ROOT, "profiles", "r02", name)
     try:
         with open(path) as f:
             d = json.load(f)
@@ -301,12 +301,13 @@ def train_setup(dev, seed, world, dropout, fx_prob=0.0):
         # The chip idles while the operands above are made; the first ~30 launches after that are a boost -> throttle transient
         # (0.42 -> 0.54 -> 0.46 ms, profiles/r01/README.md), so they are not timed: what is reported is the sustained-load duration.
         n_warm, n_timed = 40, 60
+        site = K.drop_site(dropout, 1, 5)            # the step's own call: bias + GELU + dropout + saved gelu' * keep factor
         for _ in range(n_warm):
-            K.gemm(a, w, bias=bias, act=1, pre_act_out=u)
+            K.gemm(a, w, bias=bias, act=1, act_grad_out=u, drop=site)
         ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         ev0.record()
         for _ in range(n_timed):
-            K.gemm(a, w, bias=bias, act=1, pre_act_out=u)
+            K.gemm(a, w, bias=bias, act=1, act_grad_out=u, drop=site)
         ev1.record()
         torch.cuda.synchronize()
         ms = ev0.elapsed_time(ev1) / n_timed
@@ -314,10 +315,11 @@ def train_setup(dev, seed, world, dropout, fx_prob=0.0):
         ach = fl / (ms * 1e-3) / 1e12
         return {"bound": "mfma", "achieved": ach, "peak": BF16_MFMA_PEAK_TF, "unit": "TFLOP/s", "frac": ach / BF16_MFMA_PEAK_TF,
                 "traffic": pmc_traffic_bytes("gemm_pmc_summary.json"),
-                "kernel": "adt::gemm_nt_256_kernel<false, false> (FFN linear1 + bias + GELU + saved pre-activation, M=%d N=%d K=%d)" % (M, N, Kd),
+                "kernel": "adt::gemm_nt_256_kernel<%s, false> (FFN linear1 + bias + GELU%s + saved gelu' factor, M=%d N=%d K=%d)"
+                          % ("true" if site else "false", " + dropout" if site else "", M, N, Kd),
                 "kernel_ms": ms, "algorithmic_flops_per_launch": fl,
                 "algorithmic_bytes_per_launch": 2.0 * (M * Kd + N * Kd + 2 * M * N),
-                "profile": "profiles/r01/roofline_gemm_kernel_stats.csv (rocprofv3 --kernel-trace --stats of tools/pmc_gemm.py: this kernel "
+                "profile": "profiles/r02/roofline_gemm_kernel_stats.csv (rocprofv3 --kernel-trace --stats of tools/pmc_gemm.py: this kernel "
                            "alone at this shape, 300 launches)"}
 
     def cpu_baseline(budget_s=20.0):

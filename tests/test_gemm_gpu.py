@@ -255,7 +255,8 @@ def test_saved_activation_gradient_factor(M, N, Kd):
     h32 = k.gemm(a32, w32, bias=bias, act=1, act_grad_out=fac32)
     z = (a32 @ w32.t() + bias).double().requires_grad_(True)
     F.gelu(z).sum().backward()
-    assert (h32.double() - F.gelu(z.detach())).abs().max() < 2e-5 and (fac32.double() - z.grad).abs().max() < 2e-5
+    ref_h32 = F.gelu(z.detach())
+    assert (h32.double() - ref_h32).abs().max() <= 5e-6 * ref_h32.abs().max() and (fac32.double() - z.grad).abs().max() < 2e-5
     dy32 = rnd((M, N), 7)
     got = k.gemm(dy32, torch.eye(N, device=DEV), act_grad=fac32)
     assert (got - dy32 * fac32).abs().max() < 1e-5

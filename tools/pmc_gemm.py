@@ -1,6 +1,7 @@
 #!/usr/bin/env python3
-"""Launch the roofline kernel of the train workload (NT GEMM, FFN linear1 + bias + GELU + saved pre-activation,
-M = 64 * 986, N = 3072, K = 768) a few times; run under `rocprofv3 --pmc ...` to read its counters."""
+"""Launch the roofline kernel of the train workload (NT GEMM, FFN linear1 + bias + GELU + dropout + saved gelu' * keep factor,
+M = 64 * 986, N = 3072, K = 768: exactly the call the training step makes) a few times; run under `rocprofv3 --pmc ...` to read
+its counters."""
 import os
 import sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -16,5 +17,5 @@ u = torch.empty((M, N), dtype=torch.bfloat16, device=dev)
 # enough launches that the boost / throttle transient of the first ~30 (0.42 -> 0.54 -> 0.46 ms) is a small part of the per-kernel
 # average that `rocprofv3 --stats` reports: what remains is the sustained-load duration bench.py times after its training steps
 for _ in range(int(os.environ.get("ADT_PMC_LAUNCHES", "24"))):
-    K.gemm(a, w, bias=bias, act=1, pre_act_out=u)
+    K.gemm(a, w, bias=bias, act=1, act_grad_out=u, drop=K.drop_site(0.1, 1, 5))
 torch.cuda.synchronize()

@@ -1,19 +1,23 @@
-# usage: bash tools/run_round.sh <tag>   -- full GPU suite, smoke, the three bench workloads and their rocprofv3 kernel stats
+# usage: bash tools/run_round.sh <tag>   -- full GPU suite, smoke, the three bench workloads, kernel micro-benchmarks and their rocprofv3 kernel stats
 TAG=${1:-rXX}
 R=$GRAFT_REPO_ROOT
 O=$R/gpurun_out/round_$TAG
 mkdir -p $O
 cd $R
-timeout 1500 python -m pytest tests -m gpu -x -q > $O/pytest_gpu.log 2>&1; tail -3 $O/pytest_gpu.log
+timeout 1500 python -m pytest tests -m gpu -q > $O/pytest_gpu.log 2>&1; tail -3 $O/pytest_gpu.log | cut -c1-200
 timeout 300 python -c "import __graft_entry__ as g; g.smoke()" > $O/smoke.log 2>&1; tail -2 $O/smoke.log
-timeout 900 python bench.py --steps 20 --warmup 5 > $O/bench_train.log 2>&1; tail -1 $O/bench_train.log | cut -c1-300
-timeout 900 python bench.py --steps 20 --warmup 5 --dropout 0.0 --no-cpu-baseline > $O/bench_train_nodrop.log 2>&1; tail -1 $O/bench_train_nodrop.log | cut -c1-200
-timeout 900 python bench.py --workload logmel --steps 30 --warmup 5 > $O/bench_logmel.log 2>&1; tail -1 $O/bench_logmel.log | cut -c1-300
-timeout 900 python bench.py --workload clap --steps 5 --warmup 2 > $O/bench_clap.log 2>&1; tail -1 $O/bench_clap.log | cut -c1-300
-timeout 600 python tools/bench_kernels.py > $O/bench_kernels.log 2>&1
+timeout 900 python bench.py --steps 20 --warmup 5 > $O/bench_train.json 2> $O/bench_train.err; cut -c1-300 $O/bench_train.json
+timeout 900 python bench.py --steps 20 --warmup 5 --dropout 0.0 --no-cpu-baseline > $O/bench_train_nodropout.json 2> /dev/null; cut -c1-200 $O/bench_train_nodropout.json
+timeout 900 python bench.py --workload logmel --steps 30 --warmup 5 > $O/bench_logmel.json 2> /dev/null; cut -c1-300 $O/bench_logmel.json
+timeout 900 python bench.py --workload clap --steps 5 --warmup 2 > $O/bench_clap.json 2> /dev/null; cut -c1-300 $O/bench_clap.json
+timeout 600 python tools/bench_kernels.py > $O/bench_kernels.txt 2>&1
+timeout 600 python tools/e2e.py --shots 4000 --chunks 2048 --check-resume > $O/e2e_config4_scaled.json 2> $O/e2e.err; cut -c1-400 $O/e2e_config4_scaled.json
 cd /tmp && export TMPDIR=/tmp
-timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_train -- python3 $R/bench.py --steps 5 --warmup 2 --no-cpu-baseline > $O/prof_train.log 2>&1
+timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_train -- python3 $R/bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-e2e > $O/prof_train.log 2>&1
 timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_logmel -- python3 $R/bench.py --workload logmel --steps 5 --warmup 2 --no-cpu-baseline > $O/prof_logmel.log 2>&1
 timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_clap -- python3 $R/bench.py --workload clap --steps 3 --warmup 1 --no-cpu-baseline > $O/prof_clap.log 2>&1
+export ADT_PMC_LAUNCHES=300
+timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_roofline -- python3 $R/tools/pmc_gemm.py > $O/prof_roofline.log 2>&1
+unset ADT_PMC_LAUNCHES
 rm -f $O/prof_*/*/*kernel_trace.csv          # keep the merged output small: the stats tables are what is committed
-ls $O $O/prof_train/* | head -40
+ls $O
