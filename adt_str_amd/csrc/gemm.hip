@@ -96,6 +96,21 @@ __device__ __forceinline__ void gelu_and_grad2(f32x2 x, f32x2& gv, f32x2& gd) {
   gd = (x * 0.3989422804014327f) * e + (f32x2{copysignf(d[0], x[0]), copysignf(d[1], x[1])} + 0.5f);
 }
 
+
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+// 16-byte output stores.  kStream: non-temporal (the persistent kernels' outputs are hundreds of MB that nothing re-reads from the
+// L2; keeping them out of it leaves the operand slabs resident: -10 % on the K = 768 shapes).
+template <bool kStream>
+__device__ __forceinline__ void store16(void* p, uint4 v) {
+  if (kStream) __builtin_nontemporal_store(u32x4{v.x, v.y, v.z, v.w}, reinterpret_cast<u32x4*>(p));
+  else *reinterpret_cast<uint4*>(p) = v;
+}
+template <bool kStream>
+__device__ __forceinline__ void store16f(float* p, const float* z) {
+  if (kStream) __builtin_nontemporal_store(f32x4{z[0], z[1], z[2], z[3]}, reinterpret_cast<f32x4*>(p));
+  else *reinterpret_cast<float4*>(p) = float4{z[0], z[1], z[2], z[3]};
+}
+
 struct GemmArgs {
   const unsigned short* A; long lda;
   const unsigned short* B; long ldb;
@@ -282,18 +297,48 @@ __global__ __launch_bounds__(kGemmThreads) void gemm_bf16_kernel(GemmArgs g) {
 constexpr int kEpiPitch = 132;
 constexpr int kEpiLds = 128 * kEpiPitch * 4;          // 67,584 B
 // One row piece of 8 consecutive columns: z = acc * alpha + bias -> [gelu'] -> [pre-act out] -> act -> dropout / residual -> stores.
-template <bool kDrop>
+// Epilogue form as a compile-time mask (the persistent kernel is instantiated for the forms the training step launches, so an
+// output piece costs its arithmetic and not a dozen uniform branches, selects and register shuffles); kEpiGeneric reads the
+// flags of adt_gemm_epilogue at run time.
+enum : unsigned {
+  kEfBias = 1u, kEfGeluGrad = 2u, kEfFactor = 4u, kEfPreAct = 8u, kEfGelu = 16u, kEfRelu = 32u, kEfResidual = 64u, kEfRowMod = 128u,
+  kEfDropAfterRes = 256u, kEfAux = 512u, kEfFp32 = 1024u, kEpiGeneric = 0x80000000u
+};
+static unsigned epilogue_mask(const adt_gemm_epilogue& e) {
+  return (e.bias ? kEfBias : 0u) | (e.gelu_grad_of ? kEfGeluGrad : 0u) | (e.act_grad_mode ? kEfFactor : 0u) | (e.pre_act_out ? kEfPreAct : 0u) |
+         (e.act == 1 ? kEfGelu : 0u) | (e.act == 2 ? kEfRelu : 0u) | (e.residual ? kEfResidual : 0u) | (e.residual && e.res_row_mod > 0 ? kEfRowMod : 0u) |
+         (e.drop.p > 0.f && e.drop_after_residual ? kEfDropAfterRes : 0u) | (e.aux_bf16_out ? kEfAux : 0u) | (e.out_fp32 ? kEfFp32 : 0u);
+}
+template <unsigned kMask, unsigned kBit>
+__device__ __forceinline__ bool ef(bool at_run_time) {
+  if constexpr ((kMask & kEpiGeneric) != 0u) return at_run_time;
+  else return (kMask & kBit) != 0u;
+}
+typedef __bf16 bf16x2v __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ unsigned pack_bf2(float a, float b) {             // one v_cvt_pk_bf16_f32
+  return __builtin_bit_cast(unsigned, __builtin_convertvector(f32x2{a, b}, bf16x2v));
+}
+__device__ __forceinline__ uint4 pack_bf8(const float (&z)[8]) {
+  return uint4{pack_bf2(z[0], z[1]), pack_bf2(z[2], z[3]), pack_bf2(z[4], z[5]), pack_bf2(z[6], z[7])};
+}
+// One row piece of 8 consecutive columns: z = acc * alpha + bias -> [gelu'] -> [pre-act out] -> act -> dropout / residual -> stores.
+template <bool kDrop, bool kStream = false, unsigned kMask = kEpiGeneric>
 __device__ __forceinline__ void epilogue_apply8(const GemmArgs& g, float (&z)[8], const float (&bias)[8], int row, int col) {
   const adt_gemm_epilogue& ep = g.ep;
+  if (ef<kMask, kEfBias>(true)) {
 #pragma unroll
-  for (int e = 0; e < 8; ++e) z[e] = z[e] * ep.alpha + bias[e];
-  if (ep.gelu_grad_of) {
+    for (int e = 0; e < 8; ++e) z[e] = z[e] * ep.alpha + bias[e];
+  } else {
+#pragma unroll
+    for (int e = 0; e < 8; ++e) z[e] *= ep.alpha;
+  }
+  if (ef<kMask, kEfGeluGrad>(ep.gelu_grad_of != nullptr)) {
     const uint4 uv = *reinterpret_cast<const uint4*>(reinterpret_cast<const unsigned short*>(ep.gelu_grad_of) + static_cast<long>(row) * ep.ld_gelu_grad + col);
     const unsigned w[4] = {uv.x, uv.y, uv.z, uv.w};
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
       f32x2 gd = f32x2{__uint_as_float(w[e] << 16), __uint_as_float(w[e] & 0xffff0000u)};
-      if (!ep.act_grad_mode) gd = gelu_erf_grad2(gd);        // act_grad_mode: the forward already stored gelu'(z) * keep
+      if (!ef<kMask, kEfFactor>(ep.act_grad_mode != 0)) gd = gelu_erf_grad2(gd);        // act_grad_mode: the forward already stored gelu'(z) * keep
       z[2 * e] *= gd[0];
       z[2 * e + 1] *= gd[1];
     }
@@ -309,7 +354,8 @@ __device__ __forceinline__ void epilogue_apply8(const GemmArgs& g, float (&z)[8]
       keep[2 * e + 1] = g.drop.hi(hh);
     }
   }
-  const bool save_factor = ep.act_grad_mode && ep.pre_act_out && ep.act == 1;
+  const bool has_pre = ef<kMask, kEfPreAct>(ep.pre_act_out != nullptr), is_gelu = ef<kMask, kEfGelu>(ep.act == 1);
+  const bool save_factor = ef<kMask, kEfFactor>(ep.act_grad_mode != 0) && has_pre && is_gelu;
   if (save_factor) {                                    // h = gelu(z), saved: gelu'(z) * keep (what the backward multiplies by)
     float f[8];
 #pragma unroll
@@ -319,56 +365,52 @@ __device__ __forceinline__ void epilogue_apply8(const GemmArgs& g, float (&z)[8]
       z[2 * e] = gv[0]; z[2 * e + 1] = gv[1];
       f[2 * e] = gd[0] * keep[2 * e]; f[2 * e + 1] = gd[1] * keep[2 * e + 1];
     }
-    uint4 o;
-    o.x = f2bf(f[0]) | (static_cast<unsigned>(f2bf(f[1])) << 16); o.y = f2bf(f[2]) | (static_cast<unsigned>(f2bf(f[3])) << 16);
-    o.z = f2bf(f[4]) | (static_cast<unsigned>(f2bf(f[5])) << 16); o.w = f2bf(f[6]) | (static_cast<unsigned>(f2bf(f[7])) << 16);
-    *reinterpret_cast<uint4*>(reinterpret_cast<unsigned short*>(ep.pre_act_out) + static_cast<long>(row) * ep.ld_pre_act + col) = o;
+    store16<kStream>(reinterpret_cast<unsigned short*>(ep.pre_act_out) + static_cast<long>(row) * ep.ld_pre_act + col, pack_bf8(f));
   } else {
-    if (ep.pre_act_out) {
-      uint4 o;
-      o.x = f2bf(z[0]) | (static_cast<unsigned>(f2bf(z[1])) << 16); o.y = f2bf(z[2]) | (static_cast<unsigned>(f2bf(z[3])) << 16);
-      o.z = f2bf(z[4]) | (static_cast<unsigned>(f2bf(z[5])) << 16); o.w = f2bf(z[6]) | (static_cast<unsigned>(f2bf(z[7])) << 16);
-      *reinterpret_cast<uint4*>(reinterpret_cast<unsigned short*>(ep.pre_act_out) + static_cast<long>(row) * ep.ld_pre_act + col) = o;
+    if (has_pre) {
+      const uint4 o = pack_bf8(z);
+      store16<kStream>(reinterpret_cast<unsigned short*>(ep.pre_act_out) + static_cast<long>(row) * ep.ld_pre_act + col, o);
+      const unsigned w[4] = {o.x, o.y, o.z, o.w};       // the activation sees the value the backward will read
 #pragma unroll
-      for (int e = 0; e < 8; ++e) z[e] = bf2f(f2bf(z[e]));       // the activation sees the value the backward will read
+      for (int e = 0; e < 4; ++e) { z[2 * e] = __uint_as_float(w[e] << 16); z[2 * e + 1] = __uint_as_float(w[e] & 0xffff0000u); }
     }
-    if (ep.act == 1) {
+    if (is_gelu) {
 #pragma unroll
       for (int e = 0; e < 4; ++e) {
         const f32x2 gv = gelu_erf2(f32x2{z[2 * e], z[2 * e + 1]});
         z[2 * e] = gv[0];
         z[2 * e + 1] = gv[1];
       }
-    } else if (ep.act == 2) {
+    } else if (ef<kMask, kEfRelu>(ep.act == 2)) {
 #pragma unroll
       for (int e = 0; e < 8; ++e) z[e] = fmaxf(z[e], 0.0f);
     }
   }
-  if (kDrop && !ep.drop_after_residual) {
+  const bool drop_late = ef<kMask, kEfDropAfterRes>(ep.drop_after_residual != 0);
+  if (kDrop && !drop_late) {
 #pragma unroll
     for (int e = 0; e < 8; ++e) z[e] *= keep[e];
   }
-  if (ep.residual) {
-    const long rr = ep.res_row_mod > 0 ? (row % ep.res_row_mod) : row;
+  if (ef<kMask, kEfResidual>(ep.residual != nullptr)) {
+    const long rr = ef<kMask, kEfRowMod>(ep.res_row_mod > 0) ? (row % ep.res_row_mod) : row;
     const float* rp = reinterpret_cast<const float*>(ep.residual) + rr * ep.ld_res + col;
     const float4 r0 = *reinterpret_cast<const float4*>(rp), r1 = *reinterpret_cast<const float4*>(rp + 4);
     z[0] += r0.x; z[1] += r0.y; z[2] += r0.z; z[3] += r0.w; z[4] += r1.x; z[5] += r1.y; z[6] += r1.z; z[7] += r1.w;
   }
-  if (kDrop && ep.drop_after_residual) {
+  if (kDrop && drop_late) {
 #pragma unroll
     for (int e = 0; e < 8; ++e) z[e] *= keep[e];
   }
-  uint4 o16;
-  o16.x = f2bf(z[0]) | (static_cast<unsigned>(f2bf(z[1])) << 16); o16.y = f2bf(z[2]) | (static_cast<unsigned>(f2bf(z[3])) << 16);
-  o16.z = f2bf(z[4]) | (static_cast<unsigned>(f2bf(z[5])) << 16); o16.w = f2bf(z[6]) | (static_cast<unsigned>(f2bf(z[7])) << 16);
-  if (ep.aux_bf16_out)
-    *reinterpret_cast<uint4*>(reinterpret_cast<unsigned short*>(ep.aux_bf16_out) + static_cast<long>(row) * ep.ld_aux + col) = o16;
-  if (ep.out_fp32) {
+  const bool fp32_out = ef<kMask, kEfFp32>(ep.out_fp32 != 0), aux = ef<kMask, kEfAux>(ep.aux_bf16_out != nullptr);
+  if (aux || !fp32_out) {
+    const uint4 o16 = pack_bf8(z);
+    if (aux) store16<kStream>(reinterpret_cast<unsigned short*>(ep.aux_bf16_out) + static_cast<long>(row) * ep.ld_aux + col, o16);
+    if (!fp32_out) store16<kStream>(reinterpret_cast<unsigned short*>(g.C) + static_cast<long>(row) * g.ldc + col, o16);
+  }
+  if (fp32_out) {
     float* cp = reinterpret_cast<float*>(g.C) + static_cast<long>(row) * g.ldc + col;
-    *reinterpret_cast<float4*>(cp) = *reinterpret_cast<float4*>(z);
-    *reinterpret_cast<float4*>(cp + 4) = *reinterpret_cast<float4*>(z + 4);
-  } else {
-    *reinterpret_cast<uint4*>(reinterpret_cast<unsigned short*>(g.C) + static_cast<long>(row) * g.ldc + col) = o16;
+    store16f<kStream>(cp, z);
+    store16f<kStream>(cp + 4, z + 4);
   }
 }
 
@@ -541,6 +583,11 @@ constexpr int kBigBuf = 4 * kHalfTile;               // A_0 | A_1 | B_0 | B_1
 constexpr int kBigStage = 2 * kBigBuf;               // 131,072 B of operand staging
 constexpr int kEpi2Bytes = 16 * 64 * 4;              // per wave: 16 x 64 fp32 transposition tile (XOR-swizzled, no padding)
 constexpr int kBigLds = kBigStage + 8 * kEpi2Bytes;  // 163,840 B = the whole LDS of a CU
+// Epilogue paths of the persistent NT kernel (measured per form, tools/exp_gemm_epilogue.py; picked in ADT_NT256_FORMS):
+//   kEpiLdsPlain      accumulators -> wave-private LDS transposition -> 8-column row pieces, plain stores
+//   kEpiDirectStream  MFMA operands exchanged + v_permlane16_swap -> 8-column row pieces straight from registers, non-temporal stores
+//   kEpiDirect        the same with plain stores
+constexpr int kEpiLdsPlain = 0, kEpiDirectStream = 2, kEpiDirect = 3;
 
 // Work-counter tickets of the persistent kernels (protocol: comment of gemm_nt_256_kernel).
 __device__ __forceinline__ void ticket_drawn(unsigned* counter, unsigned ticket, unsigned total) {
@@ -568,8 +615,9 @@ __device__ __forceinline__ unsigned take_ticket(unsigned* counter, unsigned tota
 // DMAs are issued before this tile's epilogue, which works from a separate 32 KiB of wave-private LDS: the epilogue's
 // LDS transposes, activation math and global stores hide the next tile's DMA latency (and there is no workgroup
 // turn-around between tiles).
-template <bool kDrop, bool kColsum>
+template <bool kDrop, bool kColsum, int kEpi, unsigned kMask>      // kEpi: how the accumulators reach memory (kEpiLds / kEpiDirectStream / kEpiDirect)
 __global__ __launch_bounds__(kBigThreads) void gemm_nt_256_kernel(GemmArgs g, int tiles_m, int tiles_n) {
+  constexpr bool kDirect = kEpi != kEpiLdsPlain, kNt = kEpi == kEpiDirectStream;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -624,7 +672,6 @@ __global__ __launch_bounds__(kBigThreads) void gemm_nt_256_kernel(GemmArgs g, in
   const unsigned a_row = static_cast<unsigned>((wr * 64 + (lane & 15)) * 128), b_row = static_cast<unsigned>((wc * 32 + (lane & 15)) * 128);
   const unsigned a_k0 = base0 + a_row + c0, a_k1 = base0 + a_row + c1;            // + h * kHalfTile + i * 2048 (+ buffer)
   const unsigned b_k0 = base0 + 2 * kHalfTile + b_row + c0, b_k1 = base0 + 2 * kHalfTile + b_row + c1;
-  float* ct = reinterpret_cast<float*>(smem + kBigStage + wave * kEpi2Bytes);
 
   unsigned* const flag = reinterpret_cast<unsigned*>(smem + kBigBuf + kHalfTile);
   if (tid == 0) *flag = take_ticket(counter, ctotal);
@@ -646,12 +693,14 @@ __global__ __launch_bounds__(kBigThreads) void gemm_nt_256_kernel(GemmArgs g, in
     _Pragma("unroll") for (int ks = 0; ks < 2; ++ks)                                                               \
       _Pragma("unroll") for (int i = 0; i < 4; ++i)                                                                \
         _Pragma("unroll") for (int j = 0; j < 2; ++j)                                                              \
-          acc[I0 + i][J0 + j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[i][ks], FB[j][ks], acc[I0 + i][J0 + j], 0, 0, 0); \
+          acc[I0 + i][J0 + j] = kDirect ? __builtin_amdgcn_mfma_f32_16x16x32_bf16(FB[j][ks], fa[i][ks], acc[I0 + i][J0 + j], 0, 0, 0) \
+                                        : __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[i][ks], FB[j][ks], acc[I0 + i][J0 + j], 0, 0, 0); \
     __builtin_amdgcn_s_setprio(0);                                                                                 \
     __builtin_amdgcn_sched_barrier(0);                                                                             \
     asm volatile("s_barrier" ::: "memory");                                                                        \
   } while (0)
 
+  float* ct = reinterpret_cast<float*>(smem + kBigStage + wave * kEpi2Bytes);
   unsigned ct_w[4], ct_r[2];
 #pragma unroll
   for (int j = 0; j < 4; ++j) ct_w[j] = lds_addr(ct) + static_cast<unsigned>(((4 * (lane >> 4)) * 64 + ((j ^ (lane >> 4)) << 4) + (lane & 15)) * 4);
@@ -670,13 +719,28 @@ __global__ __launch_bounds__(kBigThreads) void gemm_nt_256_kernel(GemmArgs g, in
     // This tile's bias piece and the next tile's index are requested before the K loop and first used after the
     // s_waitcnt vmcnt(0) that ends it.  Inline asm: the compiler would wait for its own loads right here (a loop with
     // VMEM traffic follows), which puts their latency in front of every tile's first MFMA.
-    const int ecol = n0 + wc * 64 + (lane & 7) * 8;
-    const bool efull = ecol + 8 <= g.N;
-    const bool has_bias = g.ep.bias != nullptr && efull;
-    const float* bptr = has_bias ? g.ep.bias + ecol : reinterpret_cast<const float*>(g.A);     // always a readable 32 bytes
+    const int ecolL = n0 + wc * 64 + (lane & 7) * 8;
+    const bool efullL = ecolL + 8 <= g.N;
+    const bool has_bias = g.ep.bias != nullptr && efullL;
+    const float* bptr = has_bias ? g.ep.bias + ecolL : reinterpret_cast<const float*>(g.A);     // always a readable 32 bytes
     f32x4 braw0, braw1;
-    asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(braw0) : "v"(bptr) : "memory");
-    asm volatile("global_load_dwordx4 %0, %1, off offset:16" : "=v"(braw1) : "v"(bptr) : "memory");
+    if constexpr (!kDirect && (kMask & (kEpiGeneric | kEfBias)) != 0u) {   // (an asm load whose result is never read would land in a register the allocator has reused)
+      asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(braw0) : "v"(bptr) : "memory");
+      asm volatile("global_load_dwordx4 %0, %1, off offset:16" : "=v"(braw1) : "v"(bptr) : "memory");
+    }
+    // Output ownership (see the epilogue): row = 16 i + (lane & 15) of the wave's 128, columns = the 8-column piece ecol[jp] of
+    // each 32-column half jp of the wave's 64.
+    int ecol[2]; bool efull[2]; f32x4 braw[2][2];
+#pragma unroll
+    for (int jp = 0; jp < 2; ++jp) {
+      ecol[jp] = n0 + wc * 64 + (2 * jp + ((lane >> 4) & 1)) * 16 + (lane >> 5) * 8;
+      efull[jp] = ecol[jp] + 8 <= g.N;
+      const float* bptr = (g.ep.bias != nullptr && efull[jp]) ? g.ep.bias + ecol[jp] : reinterpret_cast<const float*>(g.A);   // always a readable 32 bytes
+      if constexpr (kDirect && (kMask & (kEpiGeneric | kEfBias)) != 0u) {
+        asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(braw[jp][0]) : "v"(bptr) : "memory");
+        asm volatile("global_load_dwordx4 %0, %1, off offset:16" : "=v"(braw[jp][1]) : "v"(bptr) : "memory");
+      }
+    }
     unsigned v_next;
     // (address in VGPRs: an SGPR pair the compiler has just re-read from a spill lane would need wait states before a VMEM
     //  instruction, which it cannot know this asm is)
@@ -722,7 +786,6 @@ __global__ __launch_bounds__(kBigThreads) void gemm_nt_256_kernel(GemmArgs g, in
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     if (wr == 0) asm volatile("s_barrier" ::: "memory");
     asm volatile("s_barrier" ::: "memory");            // every DMA has landed and every fragment read is done: staging is free
-
     const int em0 = m0;
     if (tid == 0) { ticket_drawn(counter, v_next, ctotal); *flag = v_next; }
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
@@ -734,13 +797,75 @@ __global__ __launch_bounds__(kBigThreads) void gemm_nt_256_kernel(GemmArgs g, in
       prologue_dma();                                   // flies under the epilogue below
     }
 
-    // ---- epilogue: wave-private 16 x 64 transposition passes (element (row, col) at row * 64 + ((col >> 4) ^ ((row >> 2) & 3)) * 16
-    //      + (col & 15): conflict-free writes from the MFMA layout), then 8-column row pieces as in the 128^2 kernel.
-    //      LDS traffic is inline asm: the compiler would otherwise order it behind the DMAs in flight with a vmcnt(0).
-    float bias[8];
+    if constexpr (kDirect) {
+    // ---- epilogue, straight from the accumulators.  The MFMAs run with the operands exchanged (W fragment first), so lane l
+    //      holds C[16 i + (l & 15)][16 j + 4 (l >> 4) + r]: four consecutive columns of one row per 16 x 16 block.  One
+    //      v_permlane16_swap per register pair of the blocks (2 jp, 2 jp + 1) turns that into eight consecutive columns:
+    //      lane row g = l >> 4 ends up with columns 8 (g >> 1) .. + 7 of block 2 jp + (g & 1), i.e. 16-byte bf16 / 32-byte
+    //      fp32 row pieces, 64 contiguous bytes of a row per four lanes -- no LDS round trip, and the staging LDS stays with
+    //      the next tile's DMAs.
+    float bias[2][8];
 #pragma unroll
-    for (int e = 0; e < 4; ++e) { bias[e] = has_bias ? braw0[e] : 0.f; bias[4 + e] = has_bias ? braw1[e] : 0.f; }
-    float cs[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};        // kColsum: this lane's 16 rows of its 8 columns, as stored
+    for (int jp = 0; jp < 2; ++jp) {
+      if constexpr ((kMask & kEpiGeneric) != 0u) {
+        const bool hb = g.ep.bias != nullptr && efull[jp];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { bias[jp][e] = hb ? braw[jp][0][e] : 0.f; bias[jp][4 + e] = hb ? braw[jp][1][e] : 0.f; }
+      } else if constexpr ((kMask & kEfBias) != 0u) {   // (pieces past N hold what the stand-in address held: they are never stored)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { bias[jp][e] = braw[jp][0][e]; bias[jp][4 + e] = braw[jp][1][e]; }
+      } else {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) bias[jp][e] = 0.f;
+      }
+    }
+    float cs[2][8] = {{0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f}};   // kColsum: this lane's 8 rows of its 16 columns, as stored
+#pragma unroll
+    for (int it = 0; it < 16; ++it) {
+      const int i = it >> 1, jp = it & 1;
+      const int row = em0 + wr * 128 + i * 16 + (lane & 15);
+      float z[8];
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const auto sw = __builtin_amdgcn_permlane16_swap(__float_as_uint(acc[i][2 * jp][r]), __float_as_uint(acc[i][2 * jp + 1][r]), false, false);
+        z[r] = __uint_as_float(sw[0]);
+        z[4 + r] = __uint_as_float(sw[1]);
+      }
+      if (row < g.M && efull[jp]) {
+        epilogue_apply8<kDrop, kNt, kMask>(g, z, bias[jp], row, ecol[jp]);
+        if (kColsum) {
+#pragma unroll
+          for (int e = 0; e < 8; ++e) cs[jp][e] += g.ep.out_fp32 ? z[e] : bf2f(f2bf(z[e]));
+        }
+      }
+    }
+    if (kColsum) {                                      // the 16 lanes of a lane row hold the same columns
+#pragma unroll
+      for (int jp = 0; jp < 2; ++jp) {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+          float c = cs[jp][e];
+          c += __shfl_xor(c, 1);
+          c += __shfl_xor(c, 2);
+          c += __shfl_xor(c, 4);
+          c += __shfl_xor(c, 8);
+          cs[jp][e] = c;
+        }
+        if ((lane & 15) == 0 && efull[jp]) {
+          float* cp = g.colsum_ws + static_cast<long>(em0 / 128 + wr) * g.N + ecol[jp];
+          *reinterpret_cast<float4*>(cp) = float4{cs[jp][0], cs[jp][1], cs[jp][2], cs[jp][3]};
+          *reinterpret_cast<float4*>(cp + 4) = float4{cs[jp][4], cs[jp][5], cs[jp][6], cs[jp][7]};
+        }
+      }
+    }
+    } else {
+    float biasL[8];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      if constexpr ((kMask & (kEpiGeneric | kEfBias)) != 0u) { biasL[e] = has_bias ? braw0[e] : 0.f; biasL[4 + e] = has_bias ? braw1[e] : 0.f; }
+      else { biasL[e] = 0.f; biasL[4 + e] = 0.f; }
+    }
+    float csL[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};        // kColsum: this lane's 16 rows of its 8 columns, as stored
 #pragma unroll
     for (int i = 0; i < 8; ++i) {
 #pragma unroll
@@ -764,11 +889,11 @@ __global__ __launch_bounds__(kBigThreads) void gemm_nt_256_kernel(GemmArgs g, in
       for (int pass = 0; pass < 2; ++pass) {
         const int row = em0 + wr * 128 + i * 16 + pass * 8 + (lane >> 3);
         float z[8] = {zz[pass][0][0], zz[pass][0][1], zz[pass][0][2], zz[pass][0][3], zz[pass][1][0], zz[pass][1][1], zz[pass][1][2], zz[pass][1][3]};
-        if (row < g.M && efull) {
-          epilogue_apply8<kDrop>(g, z, bias, row, ecol);
+        if (row < g.M && efullL) {
+          epilogue_apply8<kDrop, kNt, kMask>(g, z, biasL, row, ecolL);
           if (kColsum) {
 #pragma unroll
-            for (int e = 0; e < 8; ++e) cs[e] += g.ep.out_fp32 ? z[e] : bf2f(f2bf(z[e]));
+            for (int e = 0; e < 8; ++e) csL[e] += g.ep.out_fp32 ? z[e] : bf2f(f2bf(z[e]));
           }
         }
       }
@@ -776,15 +901,16 @@ __global__ __launch_bounds__(kBigThreads) void gemm_nt_256_kernel(GemmArgs g, in
     if (kColsum) {                                      // lanes l, l + 8, ..., l + 56 hold the same 8 columns
 #pragma unroll
       for (int e = 0; e < 8; ++e) {
-        cs[e] += __shfl_xor(cs[e], 8);
-        cs[e] += __shfl_xor(cs[e], 16);
-        cs[e] += __shfl_xor(cs[e], 32);
+        csL[e] += __shfl_xor(csL[e], 8);
+        csL[e] += __shfl_xor(csL[e], 16);
+        csL[e] += __shfl_xor(csL[e], 32);
       }
-      if (lane < 8 && efull) {
-        float* cp = g.colsum_ws + static_cast<long>(em0 / 128 + wr) * g.N + ecol;
-        *reinterpret_cast<float4*>(cp) = float4{cs[0], cs[1], cs[2], cs[3]};
-        *reinterpret_cast<float4*>(cp + 4) = float4{cs[4], cs[5], cs[6], cs[7]};
+      if (lane < 8 && efullL) {
+        float* cp = g.colsum_ws + static_cast<long>(em0 / 128 + wr) * g.N + ecolL;
+        *reinterpret_cast<float4*>(cp) = float4{csL[0], csL[1], csL[2], csL[3]};
+        *reinterpret_cast<float4*>(cp + 4) = float4{csL[4], csL[5], csL[6], csL[7]};
       }
+    }
     }
     if (!more) break;
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");    // next tile's first k-tiles have landed (and this tile's stores are out)
@@ -1144,15 +1270,58 @@ __global__ __launch_bounds__(256) void reduce_slabs_kernel(const float* __restri
   o[0] = s.x * alpha; o[1] = s.y * alpha; o[2] = s.z * alpha; o[3] = s.w * alpha;
 }
 
+// One instantiation of the persistent NT kernel: (dropout, column sums, epilogue variant, epilogue form).
+template <bool kDrop, bool kColsum, int kEpi, unsigned kMask>
+static int launch_nt_256(const GemmArgs& g, dim3 grid, int tm, int tn, hipStream_t st) {
+  static thread_local int attr_dev = -1;
+  int dev = 0;
+  ADT_HIP_TRY(hipGetDevice(&dev));
+  if (attr_dev != dev) {
+    ADT_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_nt_256_kernel<kDrop, kColsum, kEpi, kMask>), hipFuncAttributeMaxDynamicSharedMemorySize, kBigLds));
+    attr_dev = dev;
+  }
+  hipLaunchKernelGGL((gemm_nt_256_kernel<kDrop, kColsum, kEpi, kMask>), grid, dim3(kBigThreads), kBigLds, st, g, tm, tn);
+  return ADT_OK;
+}
+// The forms the training step launches (adt_str_amd/network.py; ADT_GEMM_LOG_FORMS=1 lists what a workload launches) get their own
+// instantiation with the epilogue path that measured fastest for the form (M = 63104, MI355X: plain 0.326 -> 0.284 ms, FFN
+// linear1 0.456 -> 0.396, FFN data gradient 0.435 -> 0.373 with the direct paths; the fp32 residual forms are fastest through
+// the LDS transposition, 0.134 vs 0.143-0.150 for the out-projection); anything else runs the generic kernel, which reads the flags at run time.
+//   X(dropout, colsum, path, mask)
+#define ADT_NT256_FORMS(X)                                                                                                            \
+  X(true, false, kEpiDirectStream, kEfBias | kEfFactor | kEfPreAct | kEfGelu)   /* FFN linear1: bias, GELU, dropout, saved factor */      \
+  X(false, false, kEpiDirectStream, kEfBias | kEfFactor | kEfPreAct | kEfGelu)  /* ... with dropout off */                                \
+  X(false, false, kEpiDirectStream, 0u)                                         /* plain data gradient */                                 \
+  X(false, false, kEpiDirectStream, kEfBias)                                    /* in-projections */                                      \
+  X(true, false, kEpiLdsPlain, kEfBias | kEfResidual | kEfFp32)                 /* out-proj / FFN linear2: bias, dropout, residual */     \
+  X(false, false, kEpiLdsPlain, kEfBias | kEfResidual | kEfFp32)                /* ... with dropout off */                                \
+  X(false, false, kEpiLdsPlain, kEfResidual | kEfFp32)                          /* data gradient added to the residual stream's */        \
+  X(false, true, kEpiDirect, kEfGeluGrad | kEfFactor)                           /* FFN data gradient x saved factor, + bias gradient */   \
+  X(false, false, kEpiDirect, kEfGeluGrad | kEfFactor)
+static int dispatch_nt_256(const GemmArgs& g, bool colsum, unsigned mask, dim3 grid, int tm, int tn, hipStream_t st) {
+  const bool drop = g.drop.on();
+  static const int forced = [] { const char* v = getenv("ADT_GEMM_EPI"); return v ? atoi(v) : -1; }();     // A/B measurements: force the generic kernel on one path
+  if (forced < 0) {
+#define ADT_NT256_CASE(D, C, E, MK) if (drop == D && colsum == C && mask == (MK)) return launch_nt_256<D, C, E, (MK)>(g, grid, tm, tn, st);
+    ADT_NT256_FORMS(ADT_NT256_CASE)
+#undef ADT_NT256_CASE
+  }
+#define ADT_NT256_GENERIC(E)                                                                                                                           \
+  do {                                                                                                                                                 \
+    if (colsum) return drop ? launch_nt_256<true, true, E, kEpiGeneric>(g, grid, tm, tn, st) : launch_nt_256<false, true, E, kEpiGeneric>(g, grid, tm, tn, st); \
+    return drop ? launch_nt_256<true, false, E, kEpiGeneric>(g, grid, tm, tn, st) : launch_nt_256<false, false, E, kEpiGeneric>(g, grid, tm, tn, st);           \
+  } while (0)
+  if (forced == kEpiDirectStream) ADT_NT256_GENERIC(kEpiDirectStream);
+  if (forced == kEpiDirect) ADT_NT256_GENERIC(kEpiDirect);
+  ADT_NT256_GENERIC(kEpiLdsPlain);
+#undef ADT_NT256_GENERIC
+}
+
 static int set_big_lds_once() {      // the persistent kernels use the CU's whole LDS
   static thread_local int done_for = -1;
   int dev = 0;
   ADT_HIP_TRY(hipGetDevice(&dev));
   if (done_for == dev) return ADT_OK;
-  ADT_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_nt_256_kernel<false, false>), hipFuncAttributeMaxDynamicSharedMemorySize, kBigLds));
-  ADT_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_nt_256_kernel<false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, kBigLds));
-  ADT_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_nt_256_kernel<true, false>), hipFuncAttributeMaxDynamicSharedMemorySize, kBigLds));
-  ADT_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_nt_256_kernel<true, true>), hipFuncAttributeMaxDynamicSharedMemorySize, kBigLds));
   ADT_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_tn_256_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, kBigLds));
   done_for = dev;
   return ADT_OK;
@@ -1327,14 +1496,16 @@ extern "C" int adt_gemm_bf16(int32_t trans, int64_t M, int64_t N, int64_t K, con
     for (int x = 0; x < 8; ++x)          // per slice: one ticket per tile + the ending ticket of each of its workgroups
       g.sched_total[x] = static_cast<unsigned>(nt / 8 + (x < nt % 8 ? 1 : 0)) + g1.x / 8 + (static_cast<unsigned>(x) < g1.x % 8 ? 1u : 0u);
     if (int rc = sched_counters(stream, &g.sched)) return rc;
+    static const bool log_forms = getenv("ADT_GEMM_LOG_FORMS") != nullptr;      // debugging aid: which forms does a workload launch?
+    const unsigned mask = epilogue_mask(e);
+    if (log_forms) fprintf(stderr, "adt_gemm nt256 form: drop=%d colsum=%d mask=0x%x M=%ld N=%ld K=%ld\n", g.drop.on() ? 1 : 0, e.colsum_out ? 1 : 0, mask, (long)M, (long)N, (long)K);
+    if (e.colsum_out) g.colsum_ws = static_cast<float*>(ws);
+    const int rc = dispatch_nt_256(g, e.colsum_out != nullptr, mask, g1, tm, tn, st);
+    if (rc) return rc;
     if (e.colsum_out) {
-      g.colsum_ws = static_cast<float*>(ws);
-      if (g.drop.on()) hipLaunchKernelGGL((gemm_nt_256_kernel<true, true>), g1, dim3(kBigThreads), kBigLds, st, g, tm, tn);
-      else hipLaunchKernelGGL((gemm_nt_256_kernel<false, true>), g1, dim3(kBigThreads), kBigLds, st, g, tm, tn);
       launch_reduce_partials(g.colsum_ws, 2 * tm, g.N, e.colsum_out, st);
       colsum_done = true;
-    } else if (g.drop.on()) hipLaunchKernelGGL((gemm_nt_256_kernel<true, false>), g1, dim3(kBigThreads), kBigLds, st, g, tm, tn);
-    else hipLaunchKernelGGL((gemm_nt_256_kernel<false, false>), g1, dim3(kBigThreads), kBigLds, st, g, tm, tn);
+    }
   } else if ((K % 32) == 0 && K > 0 && vector_epilogue_ok(g, e)) {
     const int tm = static_cast<int>((M + kBM - 1) / kBM), tn = static_cast<int>((N + kBN - 1) / kBN);
     const dim3 g1(static_cast<unsigned>(tm) * tn);
