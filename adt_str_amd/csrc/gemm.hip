@@ -302,12 +302,12 @@ constexpr int kEpiLds = 128 * kEpiPitch * 4;          // 67,584 B
 // flags of adt_gemm_epilogue at run time.
 enum : unsigned {
   kEfBias = 1u, kEfGeluGrad = 2u, kEfFactor = 4u, kEfPreAct = 8u, kEfGelu = 16u, kEfRelu = 32u, kEfResidual = 64u, kEfRowMod = 128u,
-  kEfDropAfterRes = 256u, kEfAux = 512u, kEfFp32 = 1024u, kEpiGeneric = 0x80000000u
+  kEfDropAfterRes = 256u, kEfAux = 512u, kEfFp32 = 1024u, kEfAlpha = 2048u, kEpiGeneric = 0x80000000u
 };
 static unsigned epilogue_mask(const adt_gemm_epilogue& e) {
   return (e.bias ? kEfBias : 0u) | (e.gelu_grad_of ? kEfGeluGrad : 0u) | (e.act_grad_mode ? kEfFactor : 0u) | (e.pre_act_out ? kEfPreAct : 0u) |
          (e.act == 1 ? kEfGelu : 0u) | (e.act == 2 ? kEfRelu : 0u) | (e.residual ? kEfResidual : 0u) | (e.residual && e.res_row_mod > 0 ? kEfRowMod : 0u) |
-         (e.drop.p > 0.f && e.drop_after_residual ? kEfDropAfterRes : 0u) | (e.aux_bf16_out ? kEfAux : 0u) | (e.out_fp32 ? kEfFp32 : 0u);
+         (e.drop.p > 0.f && e.drop_after_residual ? kEfDropAfterRes : 0u) | (e.aux_bf16_out ? kEfAux : 0u) | (e.out_fp32 ? kEfFp32 : 0u) | (e.alpha != 1.0f ? kEfAlpha : 0u);
 }
 template <unsigned kMask, unsigned kBit>
 __device__ __forceinline__ bool ef(bool at_run_time) {
@@ -322,18 +322,37 @@ __device__ __forceinline__ uint4 pack_bf8(const float (&z)[8]) {
   return uint4{pack_bf2(z[0], z[1]), pack_bf2(z[2], z[3]), pack_bf2(z[4], z[5]), pack_bf2(z[6], z[7])};
 }
 // One row piece of 8 consecutive columns: z = acc * alpha + bias -> [gelu'] -> [pre-act out] -> act -> dropout / residual -> stores.
-template <bool kDrop, bool kStream = false, unsigned kMask = kEpiGeneric>
-__device__ __forceinline__ void epilogue_apply8(const GemmArgs& g, float (&z)[8], const float (&bias)[8], int row, int col) {
+// Element offsets of one lane's (row0, col) in every array the epilogue touches: formed once per tile, outside the per-piece
+// conditionals, so that a piece at row0 + irow (irow a compile-time constant) costs one 64-bit add of a scalar per array.
+struct EpiAddr { long c, pre, gg, res, aux, hash; };
+template <bool kDrop, unsigned kMask>
+__device__ __forceinline__ EpiAddr epilogue_addr(const GemmArgs& g, int row0, int col) {
   const adt_gemm_epilogue& ep = g.ep;
-  if (ef<kMask, kEfBias>(true)) {
-#pragma unroll
-    for (int e = 0; e < 8; ++e) z[e] = z[e] * ep.alpha + bias[e];
-  } else {
+  const long r = row0;
+  EpiAddr a;
+  a.c = r * g.ldc + col;
+  a.pre = ef<kMask, kEfPreAct>(true) ? r * ep.ld_pre_act + col : 0;
+  a.gg = ef<kMask, kEfGeluGrad>(true) ? r * ep.ld_gelu_grad + col : 0;
+  a.res = ef<kMask, kEfResidual>(true) ? r * ep.ld_res + col : 0;
+  a.aux = ef<kMask, kEfAux>(true) ? r * ep.ld_aux + col : 0;
+  a.hash = kDrop ? r * g.N + col : 0;
+  return a;
+}
+template <bool kDrop, bool kStream = false, unsigned kMask = kEpiGeneric>
+__device__ __forceinline__ void epilogue_apply8(const GemmArgs& g, float (&z)[8], const float (&bias)[8], const EpiAddr& ea, int row0, int irow, int col) {
+  // The piece is row (row0 + irow), columns col .. col + 7; ea = epilogue_addr(row0, col).
+  const adt_gemm_epilogue& ep = g.ep;
+  const int row = row0 + irow;
+  if (ef<kMask, kEfAlpha>(true)) {
 #pragma unroll
     for (int e = 0; e < 8; ++e) z[e] *= ep.alpha;
   }
+  if (ef<kMask, kEfBias>(true)) {
+#pragma unroll
+    for (int e = 0; e < 8; ++e) z[e] += bias[e];
+  }
   if (ef<kMask, kEfGeluGrad>(ep.gelu_grad_of != nullptr)) {
-    const uint4 uv = *reinterpret_cast<const uint4*>(reinterpret_cast<const unsigned short*>(ep.gelu_grad_of) + static_cast<long>(row) * ep.ld_gelu_grad + col);
+    const uint4 uv = *reinterpret_cast<const uint4*>(reinterpret_cast<const unsigned short*>(ep.gelu_grad_of) + (ea.gg + static_cast<long>(irow) * ep.ld_gelu_grad));
     const unsigned w[4] = {uv.x, uv.y, uv.z, uv.w};
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
@@ -345,7 +364,7 @@ __device__ __forceinline__ void epilogue_apply8(const GemmArgs& g, float (&z)[8]
   }
   float keep[8] = {1.f, 1.f, 1.f, 1.f, 1.f, 1.f, 1.f, 1.f};
   if (kDrop) {
-    const uint64_t pair0 = (static_cast<uint64_t>(row) * g.N + col) >> 1;   // multiple of 4: the 4 pairs share the index's high word
+    const uint64_t pair0 = static_cast<uint64_t>(ea.hash + static_cast<long>(irow) * g.N) >> 1;   // multiple of 4: the 4 pairs share the index's high word
     const uint32_t key2 = mix32(static_cast<uint32_t>(pair0 >> 32) ^ g.drop.key), lo = static_cast<uint32_t>(pair0);
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
@@ -365,11 +384,11 @@ __device__ __forceinline__ void epilogue_apply8(const GemmArgs& g, float (&z)[8]
       z[2 * e] = gv[0]; z[2 * e + 1] = gv[1];
       f[2 * e] = gd[0] * keep[2 * e]; f[2 * e + 1] = gd[1] * keep[2 * e + 1];
     }
-    store16<kStream>(reinterpret_cast<unsigned short*>(ep.pre_act_out) + static_cast<long>(row) * ep.ld_pre_act + col, pack_bf8(f));
+    store16<kStream>(reinterpret_cast<unsigned short*>(ep.pre_act_out) + (ea.pre + static_cast<long>(irow) * ep.ld_pre_act), pack_bf8(f));
   } else {
     if (has_pre) {
       const uint4 o = pack_bf8(z);
-      store16<kStream>(reinterpret_cast<unsigned short*>(ep.pre_act_out) + static_cast<long>(row) * ep.ld_pre_act + col, o);
+      store16<kStream>(reinterpret_cast<unsigned short*>(ep.pre_act_out) + (ea.pre + static_cast<long>(irow) * ep.ld_pre_act), o);
       const unsigned w[4] = {o.x, o.y, o.z, o.w};       // the activation sees the value the backward will read
 #pragma unroll
       for (int e = 0; e < 4; ++e) { z[2 * e] = __uint_as_float(w[e] << 16); z[2 * e + 1] = __uint_as_float(w[e] & 0xffff0000u); }
@@ -392,8 +411,8 @@ __device__ __forceinline__ void epilogue_apply8(const GemmArgs& g, float (&z)[8]
     for (int e = 0; e < 8; ++e) z[e] *= keep[e];
   }
   if (ef<kMask, kEfResidual>(ep.residual != nullptr)) {
-    const long rr = ef<kMask, kEfRowMod>(ep.res_row_mod > 0) ? (row % ep.res_row_mod) : row;
-    const float* rp = reinterpret_cast<const float*>(ep.residual) + rr * ep.ld_res + col;
+    const float* rp = reinterpret_cast<const float*>(ep.residual) +
+                      (ef<kMask, kEfRowMod>(ep.res_row_mod > 0) ? static_cast<long>(row % ep.res_row_mod) * ep.ld_res + col : (ea.res + static_cast<long>(irow) * ep.ld_res));
     const float4 r0 = *reinterpret_cast<const float4*>(rp), r1 = *reinterpret_cast<const float4*>(rp + 4);
     z[0] += r0.x; z[1] += r0.y; z[2] += r0.z; z[3] += r0.w; z[4] += r1.x; z[5] += r1.y; z[6] += r1.z; z[7] += r1.w;
   }
@@ -404,11 +423,11 @@ __device__ __forceinline__ void epilogue_apply8(const GemmArgs& g, float (&z)[8]
   const bool fp32_out = ef<kMask, kEfFp32>(ep.out_fp32 != 0), aux = ef<kMask, kEfAux>(ep.aux_bf16_out != nullptr);
   if (aux || !fp32_out) {
     const uint4 o16 = pack_bf8(z);
-    if (aux) store16<kStream>(reinterpret_cast<unsigned short*>(ep.aux_bf16_out) + static_cast<long>(row) * ep.ld_aux + col, o16);
-    if (!fp32_out) store16<kStream>(reinterpret_cast<unsigned short*>(g.C) + static_cast<long>(row) * g.ldc + col, o16);
+    if (aux) store16<kStream>(reinterpret_cast<unsigned short*>(ep.aux_bf16_out) + (ea.aux + static_cast<long>(irow) * ep.ld_aux), o16);
+    if (!fp32_out) store16<kStream>(reinterpret_cast<unsigned short*>(g.C) + (ea.c + static_cast<long>(irow) * g.ldc), o16);
   }
   if (fp32_out) {
-    float* cp = reinterpret_cast<float*>(g.C) + static_cast<long>(row) * g.ldc + col;
+    float* cp = reinterpret_cast<float*>(g.C) + (ea.c + static_cast<long>(irow) * g.ldc);
     store16f<kStream>(cp, z);
     store16f<kStream>(cp + 4, z + 4);
   }
@@ -433,6 +452,7 @@ __device__ __forceinline__ void gemm_epilogue_rows(const GemmArgs& g, f32x4 (&ac
     *reinterpret_cast<float4*>(bias) = *reinterpret_cast<const float4*>(g.ep.bias + col);
     *reinterpret_cast<float4*>(bias + 4) = *reinterpret_cast<const float4*>(g.ep.bias + col + 4);
   }
+  const EpiAddr ea = epilogue_addr<kDrop, kEpiGeneric>(g, m0 + (tid >> 4), col);
 #pragma unroll 2
   for (int pass = 0; pass < 8; ++pass) {
     const int lr = pass * 16 + (tid >> 4);
@@ -441,7 +461,7 @@ __device__ __forceinline__ void gemm_epilogue_rows(const GemmArgs& g, f32x4 (&ac
     float z[8];
     *reinterpret_cast<float4*>(z) = *reinterpret_cast<const float4*>(ct + lr * kEpiPitch + c8);
     *reinterpret_cast<float4*>(z + 4) = *reinterpret_cast<const float4*>(ct + lr * kEpiPitch + c8 + 4);
-    epilogue_apply8<kDrop>(g, z, bias, row, col);
+    epilogue_apply8<kDrop>(g, z, bias, ea, m0 + (tid >> 4), pass * 16, col);
   }
 }
 
@@ -820,6 +840,7 @@ __global__ __launch_bounds__(kBigThreads) void gemm_nt_256_kernel(GemmArgs g, in
       }
     }
     float cs[2][8] = {{0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f}};   // kColsum: this lane's 8 rows of its 16 columns, as stored
+    const EpiAddr ea[2] = {epilogue_addr<kDrop, kMask>(g, em0 + wr * 128 + (lane & 15), ecol[0]), epilogue_addr<kDrop, kMask>(g, em0 + wr * 128 + (lane & 15), ecol[1])};
 #pragma unroll
     for (int it = 0; it < 16; ++it) {
       const int i = it >> 1, jp = it & 1;
@@ -832,7 +853,7 @@ __global__ __launch_bounds__(kBigThreads) void gemm_nt_256_kernel(GemmArgs g, in
         z[4 + r] = __uint_as_float(sw[1]);
       }
       if (row < g.M && efull[jp]) {
-        epilogue_apply8<kDrop, kNt, kMask>(g, z, bias[jp], row, ecol[jp]);
+        epilogue_apply8<kDrop, kNt, kMask>(g, z, bias[jp], ea[jp], em0 + wr * 128 + (lane & 15), i * 16, ecol[jp]);
         if (kColsum) {
 #pragma unroll
           for (int e = 0; e < 8; ++e) cs[jp][e] += g.ep.out_fp32 ? z[e] : bf2f(f2bf(z[e]));
@@ -866,6 +887,7 @@ __global__ __launch_bounds__(kBigThreads) void gemm_nt_256_kernel(GemmArgs g, in
       else { biasL[e] = 0.f; biasL[4 + e] = 0.f; }
     }
     float csL[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};        // kColsum: this lane's 16 rows of its 8 columns, as stored
+    const EpiAddr eaL = epilogue_addr<kDrop, kMask>(g, em0 + wr * 128 + (lane >> 3), ecolL);
 #pragma unroll
     for (int i = 0; i < 8; ++i) {
 #pragma unroll
@@ -890,7 +912,7 @@ __global__ __launch_bounds__(kBigThreads) void gemm_nt_256_kernel(GemmArgs g, in
         const int row = em0 + wr * 128 + i * 16 + pass * 8 + (lane >> 3);
         float z[8] = {zz[pass][0][0], zz[pass][0][1], zz[pass][0][2], zz[pass][0][3], zz[pass][1][0], zz[pass][1][1], zz[pass][1][2], zz[pass][1][3]};
         if (row < g.M && efullL) {
-          epilogue_apply8<kDrop, kNt, kMask>(g, z, biasL, row, ecolL);
+          epilogue_apply8<kDrop, kNt, kMask>(g, z, biasL, eaL, em0 + wr * 128 + (lane >> 3), i * 16 + pass * 8, ecolL);
           if (kColsum) {
 #pragma unroll
             for (int e = 0; e < 8; ++e) csL[e] += g.ep.out_fp32 ? z[e] : bf2f(f2bf(z[e]));
@@ -1217,6 +1239,7 @@ __global__ __launch_bounds__(kBigThreads) void gemm_tn_256_kernel(GemmArgs g, in
     }
     const int ecol = en0 + wc * 64 + (lane & 7) * 8;
     const bool efull = ecol + 8 <= g.N;
+    const EpiAddr ea = epilogue_addr<false, kEpiGeneric>(o, em0 + wr * 128 + (lane >> 3), ecol);
     float bias[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     if (o.ep.bias && efull) {            // (weight gradients carry no bias: this load is not on the hot path)
       *reinterpret_cast<float4*>(bias) = *reinterpret_cast<const float4*>(o.ep.bias + ecol);
@@ -1245,7 +1268,7 @@ __global__ __launch_bounds__(kBigThreads) void gemm_tn_256_kernel(GemmArgs g, in
       for (int pass = 0; pass < 2; ++pass) {
         const int row = em0 + wr * 128 + i * 16 + pass * 8 + (lane >> 3);
         float z[8] = {zz[pass][0][0], zz[pass][0][1], zz[pass][0][2], zz[pass][0][3], zz[pass][1][0], zz[pass][1][1], zz[pass][1][2], zz[pass][1][3]};
-        if (row < g.M && efull) epilogue_apply8<false>(o, z, bias, row, ecol);
+        if (row < g.M && efull) epilogue_apply8<false>(o, z, bias, ea, em0 + wr * 128 + (lane >> 3), i * 16 + pass * 8, ecol);
       }
     }
     if (!more) break;
