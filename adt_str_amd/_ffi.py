@@ -14,7 +14,7 @@ _LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "libadt_hip
 _lock = threading.Lock()
 _lib = None
 
-ABI_VERSION = 7
+ABI_VERSION = 8
 
 i32, i64, f32, ptr = C.c_int32, C.c_int64, C.c_float, C.c_void_p
 
@@ -30,6 +30,12 @@ class GemmEpilogue(C.Structure):
                 ("ld_res", C.c_int64), ("res_row_mod", C.c_int32), ("act", C.c_int32), ("alpha", C.c_float),
                 ("out_fp32", C.c_int32), ("aux_bf16_out", C.c_void_p), ("ld_aux", C.c_int64), ("drop", Dropout),
                 ("drop_after_residual", C.c_int32), ("colsum_out", C.c_void_p), ("act_grad_mode", C.c_int32)]
+
+
+class GemmTnItem(C.Structure):
+    """struct adt_gemm_tn_item (include/adt_hip.h)."""
+    _fields_ = [("A", C.c_void_p), ("lda", C.c_int64), ("B", C.c_void_p), ("ldb", C.c_int64), ("C", C.c_void_p), ("ldc", C.c_int64),
+                ("M", C.c_int64), ("N", C.c_int64), ("K", C.c_int64)]
 
 
 class AttnDesc(C.Structure):
@@ -55,6 +61,7 @@ SIGNATURES = {
     "adt_mix_workspace_bytes": [i64, i64],
     "adt_gemm_workspace_bytes": [i32, i64, i64, i64],
     "adt_gemm_bf16": [i32, i64, i64, i64, ptr, i64, ptr, i64, ptr, i64, ptr, ptr, C.c_size_t, ptr],
+    "adt_gemm_bf16_tn_grouped": [ptr, i32, ptr],
     "adt_attn_fwd": [ptr, ptr, ptr, ptr, ptr, ptr, ptr],
     "adt_attn_bwd_workspace_bytes": [ptr],
     "adt_attn_bwd": [ptr, ptr, ptr, ptr, ptr, ptr, ptr, ptr, ptr, ptr, ptr, C.c_size_t, ptr],

@@ -59,5 +59,5 @@ int sched_counters(void* stream, unsigned** counters) {
 
 }  // namespace adt
 
-extern "C" int adt_version(void) { return 7; }
+extern "C" int adt_version(void) { return 8; }
 extern "C" const char* adt_last_error(void) { return adt::g_err; }

@@ -882,16 +882,11 @@ __device__ __forceinline__ bf16x8 join8(const bf16x4& lo, const bf16x4& hi) {
   return r;
 }
 
-__global__ __launch_bounds__(kGemmThreads) void gemm_tn_glds_kernel(GemmArgs g, int tiles_m, int tiles_n) {
-  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];      // [2 stages][A tile | B tile], reused by the epilogue
+// One 128 x 128 output tile (rows m0.., columns n0..) of K-split `split`.
+__device__ __forceinline__ void gemm_tn_glds_tile(const GemmArgs& g, int m0, int n0, int split, unsigned char* smem) {
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wm = wave >> 1, wn = wave & 1;
-  const int nwg = tiles_m * tiles_n, bid = blockIdx.x;
-  const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7;
-  const int logical = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
-  const int m0 = (logical / tiles_n) * kBM, n0 = (logical % tiles_n) * kBN;
-  const int split = blockIdx.y;
   const int k_tiles = g.K / kBK;
   const int kt0 = split * g.k_tiles_per_split;
   int kt1 = kt0 + g.k_tiles_per_split;
@@ -951,6 +946,49 @@ __global__ __launch_bounds__(kGemmThreads) void gemm_tn_glds_kernel(GemmArgs g, 
     o.drop = Drop{0u, 0u, 1.0f};
   }
   gemm_epilogue_rows<false>(o, acc, reinterpret_cast<float*>(smem), m0, n0, wm, wn, tid, lane);
+}
+// XCD-aware renumbering of a 1-D grid (workgroups b and b + 8 share an XCD): every XCD gets a contiguous range of logical tiles
+__device__ __forceinline__ int xcd_logical(int nwg, int bid) {
+  const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7;
+  return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
+}
+__global__ __launch_bounds__(kGemmThreads) void gemm_tn_glds_kernel(GemmArgs g, int tiles_m, int tiles_n) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];      // [2 stages][A tile | B tile], reused by the epilogue
+  const int logical = xcd_logical(tiles_m * tiles_n, blockIdx.x);
+  gemm_tn_glds_tile(g, (logical / tiles_n) * kBM, (logical % tiles_n) * kBN, blockIdx.y, smem);
+}
+
+// Grouped form: several independent weight-gradient products C_i[M_i, N_i] = A_i[K_i, M_i]^T B_i[K_i, N_i] (fp32 out) in ONE
+// launch.  The decoder's weight gradients are 25 products with K = B * T = 8192 and 36-144 tiles each: alone, each needs a K
+// split over fp32 slabs plus a reduction launch to fill 256 CUs; together their ~2000 tiles fill the chip with whole-K tiles.
+constexpr int kMaxGroup = 32;
+struct TnGroupArgs {
+  int n;
+  int tile_start[kMaxGroup + 1];     // first logical tile of item i; tile_start[n] = total
+  int tiles_n[kMaxGroup];
+  int M[kMaxGroup], N[kMaxGroup], K[kMaxGroup];
+  const unsigned short* A[kMaxGroup]; const unsigned short* B[kMaxGroup]; float* C[kMaxGroup];
+  long lda[kMaxGroup], ldb[kMaxGroup], ldc[kMaxGroup];
+};
+__global__ __launch_bounds__(kGemmThreads) void gemm_tn_grouped_kernel(TnGroupArgs ga) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  const int logical = xcd_logical(ga.tile_start[ga.n], blockIdx.x);
+  int it = 0;
+  while (it + 1 < ga.n && logical >= ga.tile_start[it + 1]) ++it;      // block-uniform
+  const int local = logical - ga.tile_start[it];
+  GemmArgs g;
+  g.A = ga.A[it]; g.lda = ga.lda[it];
+  g.B = ga.B[it]; g.ldb = ga.ldb[it];
+  g.C = ga.C[it]; g.ldc = ga.ldc[it];
+  g.M = ga.M[it]; g.N = ga.N[it]; g.K = ga.K[it];
+  g.k_tiles_per_split = g.K / kBK;
+  g.slabs = nullptr; g.colsum_ws = nullptr;
+  g.ep = adt_gemm_epilogue{};
+  g.ep.alpha = 1.0f;
+  g.ep.out_fp32 = 1;
+  g.drop = Drop{0u, 0u, 1.0f}; g.drop_key2 = 0u;
+  g.sched = nullptr;
+  gemm_tn_glds_tile(g, (local / ga.tiles_n[it]) * kBM, (local % ga.tiles_n[it]) * kBN, 0, smem);
 }
 
 // =========================================================================================
@@ -1445,5 +1483,43 @@ extern "C" int adt_gemm_bf16(int32_t trans, int64_t M, int64_t N, int64_t K, con
   ADT_HIP_TRY(hipGetLastError());
   if (e.colsum_out && !colsum_done)                  // the smaller tilings leave the sums to the stand-alone kernel
     return adt_colsum_bf16(C, ldc, M, N, e.colsum_out, ws, ws_bytes, stream);
+  return ADT_OK;
+}
+
+extern "C" int adt_gemm_bf16_tn_grouped(const adt_gemm_tn_item* items, int32_t n, void* stream) {
+  using namespace adt;
+  if (n < 0 || (n > 0 && !items)) return set_error(ADT_EINVAL, "adt_gemm_bf16_tn_grouped: bad item list");
+  if (n == 0) return ADT_OK;
+  if (n > kMaxGroup) return set_error(ADT_EINVAL, "adt_gemm_bf16_tn_grouped: at most 32 items per call");
+  TnGroupArgs ga;
+  ga.n = n;
+  long total = 0;
+  for (int i = 0; i < n; ++i) {
+    const adt_gemm_tn_item& it = items[i];
+    if (it.M < 8 || it.N < 8 || it.K <= 0 || (it.K % kBK) != 0 || (it.N % 8) != 0 || (it.M % 8) != 0)
+      return set_error(ADT_ESHAPE, "adt_gemm_bf16_tn_grouped: M, N must be multiples of 8 (>= 8) and K a multiple of 64");
+    if (!it.A || !it.B || !it.C) return set_error(ADT_EINVAL, "adt_gemm_bf16_tn_grouped: null pointer");
+    if (!aligned16(it.A) || !aligned16(it.B) || !aligned16(it.C) || (it.lda % 8) != 0 || (it.ldb % 8) != 0 || (it.ldc % 4) != 0 ||
+        it.lda < it.M || it.ldb < it.N || it.ldc < it.N)
+      return set_error(ADT_EINVAL, "adt_gemm_bf16_tn_grouped: operands must be 16-byte aligned with 16-byte-multiple row strides");
+    const long tm = (it.M + kBM - 1) / kBM, tn = (it.N + kBN - 1) / kBN;
+    ga.tile_start[i] = static_cast<int>(total);
+    ga.tiles_n[i] = static_cast<int>(tn);
+    total += tm * tn;
+    if (total > (1l << 30)) return set_error(ADT_ESHAPE, "adt_gemm_bf16_tn_grouped: too many tiles");
+    ga.M[i] = static_cast<int>(it.M); ga.N[i] = static_cast<int>(it.N); ga.K[i] = static_cast<int>(it.K);
+    ga.A[i] = static_cast<const unsigned short*>(it.A); ga.B[i] = static_cast<const unsigned short*>(it.B); ga.C[i] = it.C;
+    ga.lda[i] = it.lda; ga.ldb[i] = it.ldb; ga.ldc[i] = it.ldc;
+  }
+  ga.tile_start[n] = static_cast<int>(total);
+  static thread_local int attr_dev = -1;
+  int dev = 0;
+  ADT_HIP_TRY(hipGetDevice(&dev));
+  if (attr_dev != dev) {
+    ADT_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_tn_grouped_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, kEpiLds));
+    attr_dev = dev;
+  }
+  hipLaunchKernelGGL(gemm_tn_grouped_kernel, dim3(static_cast<unsigned>(total)), dim3(kGemmThreads), kEpiLds, static_cast<hipStream_t>(stream), ga);
+  ADT_HIP_TRY(hipGetLastError());
   return ADT_OK;
 }

@@ -114,6 +114,22 @@ def gemm(a: torch.Tensor, b: torch.Tensor, *, trans: bool = False, out: Optional
     return out
 
 
+def gemm_tn_grouped(items) -> None:
+    """Weight gradients ``out_i = a_i.T @ b_i`` (``a_i`` [K, M] and ``b_i`` [K, N] bf16, ``out_i`` [M, N] fp32) for a list of
+    ``(a, b, out)`` in one launch per 32 items (``adt_gemm_bf16_tn_grouped``: whole-K tiles, no split-K slabs)."""
+    items = list(items)
+    for lo in range(0, len(items), 32):
+        chunk = items[lo:lo + 32]
+        arr = (_ffi.GemmTnItem * len(chunk))()
+        for it, (a, b, out) in zip(arr, chunk):
+            assert a.dtype == torch.bfloat16 and b.dtype == torch.bfloat16 and out.dtype == torch.float32
+            assert a.dim() == 2 and b.dim() == 2 and out.dim() == 2 and a.stride(1) == 1 and b.stride(1) == 1 and out.stride(1) == 1
+            assert a.shape[0] == b.shape[0] and out.shape == (a.shape[1], b.shape[1])
+            it.A, it.lda, it.B, it.ldb, it.C, it.ldc = _ffi.dptr(a), a.stride(0), _ffi.dptr(b), b.stride(0), _ffi.dptr(out), out.stride(0)
+            it.M, it.N, it.K = a.shape[1], b.shape[1], a.shape[0]
+        _ffi.call("adt_gemm_bf16_tn_grouped", C.byref(arr), len(chunk), _ffi.current_stream())
+
+
 def _gemm_f32(a, b, *, trans, b_kn, out, bias, residual, res_row_mod, act, pre_act_out, gelu_grad_of, alpha, drop,
               drop_after_residual, colsum_out, aux_out, mode=0):
     """fp32-operand GEMM (parity path).  Layout bits: 1 = a is [K, M], 2 = b is [K, N]."""

@@ -176,6 +176,7 @@ class _Engine:
         self.drop_seed = 0               # changes every training step; masks are regenerated from it in the backward
         self._sites: Dict[str, int] = {}
         self.generation = 0              # bumped by every pass that writes the gradient buffers (see _ADTLossFn.backward)
+        self._wg_pending = []            # deferred decoder weight-gradient products (see _wgrad)
 
     def seed_dropout(self, seed: int, rank: int = 0):
         """Start the per-step dropout counter from a value derived from (experiment seed, data-parallel rank): ranks draw
@@ -248,6 +249,22 @@ class _Engine:
         if self.fp32:
             return K.gemm(dy, lin.w16[lo:hi], b_kn=True, **kw)
         return K.gemm(dy, lin.wt16[:, lo:hi], **kw)
+
+    def _wgrad(self, dy, x, out, defer=False):
+        """Weight gradient ``out = dy.T @ x``.  ``defer``: queue it for one grouped launch (`_flush_wgrads`) -- the decoder's
+        products are too small to fill the chip one at a time (K = B * T rows)."""
+        ok = (defer and not self.fp32 and not os.environ.get("ADT_NO_GROUPED_WGRAD") and dy.shape[0] % 64 == 0 and dy.shape[1] % 8 == 0 and x.shape[1] % 8 == 0 and
+              dy.stride(0) % 8 == 0 and x.stride(0) % 8 == 0 and out.stride(0) % 4 == 0 and
+              dy.data_ptr() % 16 == 0 and x.data_ptr() % 16 == 0 and out.data_ptr() % 16 == 0)
+        if ok:
+            self._wg_pending.append((dy, x, out))
+        else:
+            K.gemm(dy, x, trans=True, out=out)
+
+    def _flush_wgrads(self):
+        if self._wg_pending:
+            K.gemm_tn_grouped(self._wg_pending)
+            self._wg_pending = []
 
     def _ln(self, x, g, b, want32=True, drop=None):
         if self.fp32:
@@ -374,7 +391,7 @@ class _Engine:
         tail = dec_save[-1]
         T, tgt, xo16 = tail["T"], tail["tgt"], tail["xo16"]
         # generator
-        K.gemm(dlogits, xo16, trans=True, out=G["decoder.generator.weight"])
+        self._wgrad(dlogits, xo16, G["decoder.generator.weight"], defer=True)
         K.colsum(dlogits, out=G["decoder.generator.bias"])
         dx32 = self._dgrad(dlogits, self.gen, out_dtype=F32)
         dmem32 = None
@@ -384,19 +401,19 @@ class _Engine:
             dy3_32, dy3_16 = self._ln_bwd(dx32, s["y3"], self.P(p + ".norm3.weight"), s["mean3"], s["rstd3"], G[p + ".norm3.weight"],
                                              G[p + ".norm3.bias"], G[p + ".linear2.bias"], dx16_drop=self.D(p + ".drop3"))
             du = self._dgrad(dy3_16, L["l2"], act_grad=s["u"], colsum_out=G[p + ".linear1.bias"])
-            K.gemm(dy3_16, s["h"], trans=True, out=G[p + ".linear2.weight"])
-            K.gemm(du, s["x2_16"], trans=True, out=G[p + ".linear1.weight"])
+            self._wgrad(dy3_16, s["h"], G[p + ".linear2.weight"], defer=True)
+            self._wgrad(du, s["x2_16"], G[p + ".linear1.weight"], defer=True)
             dx2_32 = self._dgrad(du, L["l1"], residual=dy3_32, out_dtype=F32)
             dy2_32, dy2_16 = self._ln_bwd(dx2_32, s["y2"], self.P(p + ".norm2.weight"), s["mean2"], s["rstd2"], G[p + ".norm2.weight"],
                                              G[p + ".norm2.bias"], G[p + ".multihead_attn.out_proj.bias"], dx16_drop=self.D(p + ".drop2"))
             dca = self._dgrad(dy2_16, L["ca_o"])
-            K.gemm(dy2_16, s["ca"], trans=True, out=G[p + ".multihead_attn.out_proj.weight"])
+            self._wgrad(dy2_16, s["ca"], G[p + ".multihead_attn.out_proj.weight"], defer=True)
             dqc = torch.empty_like(s["qc"])
             dkvc = torch.empty_like(s["kvc"])
             gw, gb = G[p + ".multihead_attn.in_proj_weight"], G[p + ".multihead_attn.in_proj_bias"]
             K.attn_bwd(s["qc"], s["kvc"][:, :d], s["kvc"][:, d:], s["ca"], dca, s["lse_c"], dqc, dkvc[:, :d], dkvc[:, d:], B, H, T, S,
                        self.scale, drop=self.D(p + ".cattn"), bias_grad=gb, head_dim=self.dh)
-            K.gemm(dqc, s["x1_16"], trans=True, out=gw[:d])
+            self._wgrad(dqc, s["x1_16"], gw[:d], defer=True)
             K.gemm(dkvc, mem16, trans=True, out=gw[d:])
             if dmem32 is None:
                 dmem32 = self._dgrad(dkvc, L["ca"], d, None, out_dtype=F32)
@@ -406,15 +423,16 @@ class _Engine:
             dy1_32, dy1_16 = self._ln_bwd(dx1_32, s["y1"], self.P(p + ".norm1.weight"), s["mean1"], s["rstd1"], G[p + ".norm1.weight"],
                                              G[p + ".norm1.bias"], G[p + ".self_attn.out_proj.bias"], dx16_drop=self.D(p + ".drop1"))
             dsa = self._dgrad(dy1_16, L["sa_o"])
-            K.gemm(dy1_16, s["sa"], trans=True, out=G[p + ".self_attn.out_proj.weight"])
+            self._wgrad(dy1_16, s["sa"], G[p + ".self_attn.out_proj.weight"], defer=True)
             dqkv = torch.empty_like(s["qkv"])
             q = s["qkv"]
             K.attn_bwd(q[:, :d], q[:, d:2 * d], q[:, 2 * d:], s["sa"], dsa, s["lse_s"], dqkv[:, :d], dqkv[:, d:2 * d], dqkv[:, 2 * d:],
                        B, H, T, T, self.scale, causal=True, key_len=key_len, drop=self.D(p + ".sattn"),
                        bias_grad=G[p + ".self_attn.in_proj_bias"], head_dim=self.dh)
-            K.gemm(dqkv, s["x16"], trans=True, out=G[p + ".self_attn.in_proj_weight"])
+            self._wgrad(dqkv, s["x16"], G[p + ".self_attn.in_proj_weight"], defer=True)
             dx32 = self._dgrad(dqkv, L["sa"], residual=dy1_32, out_dtype=F32)
         K.embed_bwd(tgt, dx32, math.sqrt(d), G["decoder.tgt_tok_emb.embedding.weight"], drop=self.D("dec.emb"), f32=self.fp32)
+        self._flush_wgrads()
         self._ready("decoder.")
         # encoder
         fin = enc_save[-1]

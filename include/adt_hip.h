@@ -40,7 +40,7 @@ extern "C" {
  * backward entry points regenerate them from the same (p, key).  p == 0 or a null pointer: off. */
 typedef struct adt_dropout { float p; uint32_t key; } adt_dropout;
 
-/* ABI version (7): bumped whenever a signature below changes or entries are added. */
+/* ABI version (8): bumped whenever a signature below changes or entries are added. */
 int adt_version(void);
 
 /* Message of the last failing call on this thread ("" if none). */
@@ -194,6 +194,20 @@ size_t adt_gemm_colsum_workspace_bytes(int64_t M, int64_t N);
 int adt_gemm_bf16(int32_t trans, int64_t M, int64_t N, int64_t K, const void* A, int64_t lda,
                   const void* B, int64_t ldb, void* C, int64_t ldc, const adt_gemm_epilogue* ep,
                   void* ws, size_t ws_bytes, void* stream);
+
+/* Grouped weight gradients: C_i[M_i, N_i] (fp32) = A_i[K_i, M_i]^T B_i[K_i, N_i] (bf16) for up to 32 independent items in ONE
+ * launch, whole-K tiles, no workspace.  Replaces the autograd weight-gradient GEMMs of the reference's decoder layers
+ * (nn.Linear / MultiheadAttention backward inside model.py:159-189): 25 products with K = B * T rows, each too small to fill
+ * the chip without a K split and a reduction launch of its own.  Results equal adt_gemm_bf16(trans = 1) up to the summation
+ * order over K (one chain per output element here; slab sums there).  M_i, N_i multiples of 8, K_i multiples of 64,
+ * pointers 16-byte aligned, lda / ldb multiples of 8 elements, ldc of 4; items is host memory. */
+typedef struct adt_gemm_tn_item {
+  const void* A; int64_t lda;      /* bf16 [K, M] */
+  const void* B; int64_t ldb;      /* bf16 [K, N] */
+  float*      C; int64_t ldc;      /* fp32 [M, N] */
+  int64_t     M, N, K;
+} adt_gemm_tn_item;
+int adt_gemm_bf16_tn_grouped(const adt_gemm_tn_item* items, int32_t n, void* stream);
 
 /* ---------------------------------------------------------------------------
  * K4  multi-head attention forward / backward (flash-style, MFMA, head_dim 128)

@@ -260,3 +260,38 @@ def test_saved_activation_gradient_factor(M, N, Kd):
     dy32 = rnd((M, N), 7)
     got = k.gemm(dy32, torch.eye(N, device=DEV), act_grad=fac32)
     assert (got - dy32 * fac32).abs().max() < 1e-5
+
+
+def test_grouped_weight_gradients_match_the_single_launches():
+    """adt_gemm_bf16_tn_grouped: many small trans = 1 products in one launch (the decoder's weight gradients) -- against fp32
+    torch, and against the single-launch path (which sums split-K slabs: same values up to fp32 summation order)."""
+    from adt_str_amd import kernels as K
+    dev = DEV
+    g = torch.Generator(device=dev).manual_seed(11)
+    Kd = 8192
+    shapes = [(768, 3072), (3072, 768), (768, 768), (2304, 768), (1400, 768), (8, 136), (264, 40)]
+    items, refs = [], []
+    flat = torch.zeros(sum(m * n for m, n in shapes), device=dev)
+    off = 0
+    for m, n in shapes:
+        a = (torch.randn(Kd, m, device=dev, generator=g) * 0.5).bfloat16()
+        b = (torch.randn(Kd, n, device=dev, generator=g) * 0.5).bfloat16()
+        out = flat[off:off + m * n].view(m, n); off += m * n
+        items.append((a, b, out))
+        refs.append(a.float().t() @ b.float())
+    K.gemm_tn_grouped(items)
+    for (a, b, out), ref in zip(items, refs):
+        scale = ref.abs().max().item()
+        assert (out - ref).abs().max().item() <= 2e-5 * scale + 1e-3, (a.shape, b.shape)
+        single = K.gemm(a, b, trans=True, out_dtype=torch.float32)
+        assert (out - single).abs().max().item() <= 2e-5 * scale + 1e-3
+    # strided operands and a strided destination (a slice of a packed in-projection gradient)
+    big_a = (torch.randn(Kd, 1536, device=dev, generator=g) * 0.5).bfloat16()
+    big_b = (torch.randn(Kd, 1024, device=dev, generator=g) * 0.5).bfloat16()
+    dst = torch.zeros(2304, 768, device=dev)
+    K.gemm_tn_grouped([(big_a[:, 768:], big_b[:, :768], dst[768:1536])])
+    ref = big_a[:, 768:].float().t() @ big_b[:, :768].float()
+    assert (dst[768:1536] - ref).abs().max().item() <= 2e-5 * ref.abs().max().item() + 1e-3
+    assert torch.all(dst[:768] == 0) and torch.all(dst[1536:] == 0)
+    with pytest.raises(Exception):
+        K.gemm_tn_grouped([(big_a[:100], big_b[:100], torch.zeros(1536, 1024, device=dev))])      # K not a multiple of 64
