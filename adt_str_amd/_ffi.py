@@ -57,6 +57,7 @@ class AffWeights(C.Structure):
 SIGNATURES = {
     "adt_version": [],
     "adt_last_error": [],
+    "adt_debug_occupy": [i32, i32, i32, ptr],
     "adt_logmel_f32": [ptr, i64, i64, i64, i32, i32, i32, i32, ptr, ptr, ptr, i32, i32, f32, f32, f32, ptr, ptr],
     "adt_mix_workspace_bytes": [i64, i64],
     "adt_gemm_workspace_bytes": [i32, i64, i64, i64],

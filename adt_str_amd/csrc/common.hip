@@ -38,6 +38,15 @@ int device_cu_count(int* n_cu) {
   return ADT_OK;
 }
 
+// Holds n_wg workgroups (each with lds_bytes of LDS) on the chip for about `micros` microseconds: the test double of a
+// communication kernel that occupies CUs while the training kernels run (adt_debug_occupy).
+__global__ __launch_bounds__(64) void occupy_kernel(unsigned long long ticks) {
+  extern __shared__ unsigned char smem[];
+  if (threadIdx.x == 0) smem[0] = 1;
+  const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();        // 100 MHz
+  while (__builtin_amdgcn_s_memrealtime() - t0 < ticks) __builtin_amdgcn_s_sleep(32);
+}
+
 int sched_counters(void* stream, unsigned** counters) {
   static std::mutex mu;
   static std::map<std::pair<int, void*>, unsigned*> slots;
@@ -61,3 +70,14 @@ int sched_counters(void* stream, unsigned** counters) {
 
 extern "C" int adt_version(void) { return 8; }
 extern "C" const char* adt_last_error(void) { return adt::g_err; }
+
+extern "C" int adt_debug_occupy(int32_t n_wg, int32_t lds_bytes, int32_t micros, void* stream) {
+  using namespace adt;
+  if (n_wg <= 0 || lds_bytes < 0 || lds_bytes > 160 * 1024 || micros < 0 || micros > 1000000)
+    return set_error(ADT_EINVAL, "adt_debug_occupy: bad arguments");
+  ADT_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(occupy_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+  hipLaunchKernelGGL(occupy_kernel, dim3(static_cast<unsigned>(n_wg)), dim3(64), static_cast<size_t>(lds_bytes), static_cast<hipStream_t>(stream),
+                     static_cast<unsigned long long>(micros) * 100ull);
+  ADT_HIP_TRY(hipGetLastError());
+  return ADT_OK;
+}

@@ -46,6 +46,12 @@ int adt_version(void);
 /* Message of the last failing call on this thread ("" if none). */
 const char* adt_last_error(void);
 
+/* Testing aid: occupy n_wg workgroup slots with lds_bytes of LDS each for about `micros` microseconds on `stream` -- the
+ * stand-in for a collective's kernel (RCCL under data parallelism) in single-GPU tests: the persistent GEMMs take tiles from
+ * work counters, so CUs held by another stream's kernel delay no tile, and a workgroup that cannot be placed at first lands
+ * on a CU one of its siblings has left (tests/test_gemm_gpu.py, tools/exp_occupy.py). */
+int adt_debug_occupy(int32_t n_wg, int32_t lds_bytes, int32_t micros, void* stream);
+
 /* ---------------------------------------------------------------------------
  * K1  fused STFT -> power -> mel -> log -> clamp -> scale -> trim
  *

@@ -295,3 +295,28 @@ def test_grouped_weight_gradients_match_the_single_launches():
     assert torch.all(dst[:768] == 0) and torch.all(dst[1536:] == 0)
     with pytest.raises(Exception):
         K.gemm_tn_grouped([(big_a[:100], big_b[:100], torch.zeros(1536, 1024, device=dev))])      # K not a multiple of 64
+
+
+def test_persistent_gemm_runs_beside_a_kernel_that_holds_cus():
+    """Data parallelism puts RCCL kernels on the chip while the backward's GEMMs run.  adt_debug_occupy stands in for one: 16
+    workgroups with 64 KB of LDS each for 40 ms on a side stream.  The persistent GEMM (one workgroup per CU, the whole LDS)
+    must give the same bits and must not wait for the occupier."""
+    import time
+    from adt_str_amd import kernels as K, _ffi
+    g = torch.Generator(device=DEV).manual_seed(3)
+    a = (torch.randn(63104 // 2, 768, device=DEV, generator=g) * 0.5).bfloat16()
+    w = (torch.randn(3072, 768, device=DEV, generator=g) * 0.03).bfloat16()
+    ref = K.gemm(a, w)
+    torch.cuda.synchronize()
+    side = torch.cuda.Stream()
+    _ffi.call("adt_debug_occupy", 16, 65536, 40000, side.cuda_stream)
+    time.sleep(0.003)
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    outs = [K.gemm(a, w) for _ in range(10)]
+    e1.record()
+    e1.synchronize()
+    busy = not side.query()                     # the occupier is still on the chip when the ten GEMMs are done
+    torch.cuda.synchronize()
+    assert all(torch.equal(o, ref) for o in outs)
+    assert busy and e0.elapsed_time(e1) < 20.0, (busy, e0.elapsed_time(e1))
