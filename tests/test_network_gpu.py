@@ -45,10 +45,15 @@ def make_batch(B, L, T, seed):
     return {"wavs": wave, "tokens": tokens, "token_lengths": token_lengths}
 
 
-@pytest.mark.parametrize("enc_layers,dec_layers,nhead", [(1, 1, 2), (2, 2, 3)])
-def test_logits_loss_and_grads_vs_oracle(enc_layers, dec_layers, nhead):
+@pytest.mark.parametrize("enc_layers,dec_layers,nhead,B,T", [(1, 1, 2, 3, 12), (2, 2, 3, 3, 12), (1, 2, 2, 4, 16)])
+def test_logits_loss_and_grads_vs_oracle(enc_layers, dec_layers, nhead, B, T, monkeypatch):
+    """(B * T = 64 in the last case: the decoder's weight gradients then go through the grouped launch, as at full size.)"""
+    from adt_str_amd import kernels as K
+    grouped_calls = []
+    real_grouped = K.gemm_tn_grouped
+    monkeypatch.setattr(K, "gemm_tn_grouped", lambda items: (grouped_calls.append(len(list(items))), real_grouped(items))[1])
     model, state, cfg = make_model(enc_layers, dec_layers, nhead)
-    batch = make_batch(3, 8000, 12, 1)
+    batch = make_batch(B, 8000, T, 1)
     ref_bf16 = o_adt.compute_loss(state, cfg, batch, bf16=True)
     st = {k: (v.clone().requires_grad_(True) if v.is_floating_point() and "pos_embedding" not in k and "compute_spec" not in k else v)
           for k, v in state.items()}
@@ -72,6 +77,9 @@ def test_logits_loss_and_grads_vs_oracle(enc_layers, dec_layers, nhead):
         worst = max(worst, rel)
         assert rel < 5e-2, f"{name}: grad rel err {rel}"
     print("worst grad rel err", worst)
+    assert bool(grouped_calls) == ((B * T) % 64 == 0) and not eng._wg_pending
+    if grouped_calls:
+        assert grouped_calls[0] == 6 * dec_layers + 1        # six products per decoder layer + the generator
 
 
 def test_autograd_bridge_and_reference_signature():
