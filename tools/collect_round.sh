@@ -1,0 +1,15 @@
+# usage: bash tools/collect_round.sh <tag> <dest>   -- copy what tools/run_round.sh / run_pmc_*.sh left under gpurun_out/ into profiles/<dest>/
+TAG=$1; P=profiles/$2; O=gpurun_out/round_$TAG
+mkdir -p $P
+for f in bench_train.json bench_train_nodropout.json bench_logmel.json bench_clap.json e2e_config4_scaled.json; do cp $O/$f $P/$f; done
+grep -v amdgpu.ids $O/bench_kernels.txt > $P/bench_kernels.txt
+cp $O/smoke.log $P/smoke.txt
+tail -3 $O/pytest_gpu.log > $P/pytest_gpu.txt
+cp $O/prof_train/*/*kernel_stats.csv $P/train_step_kernel_stats.csv
+cp $O/prof_logmel/*/*kernel_stats.csv $P/logmel_kernel_stats.csv
+cp $O/prof_clap/*/*kernel_stats.csv $P/clap_kernel_stats.csv
+cp $O/prof_roofline/*/*kernel_stats.csv $P/roofline_gemm_kernel_stats.csv
+[ -f gpurun_out/gemm_pmc_summary_$TAG.json ] && cp gpurun_out/gemm_pmc_summary_$TAG.json $P/gemm_pmc_summary.json
+[ -f gpurun_out/logmel_pmc_summary_$TAG.json ] && cp gpurun_out/logmel_pmc_summary_$TAG.json $P/logmel_pmc_summary.json
+[ -f gpurun_out/attn_pmc_$TAG.txt ] && cp gpurun_out/attn_pmc_$TAG.txt $P/attn_pmc.txt
+ls $P
