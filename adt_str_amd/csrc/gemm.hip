@@ -1300,7 +1300,10 @@ static bool use_big_tile(int64_t M, int64_t N, int64_t K) {
   if (K <= 0 || (K % kBK) != 0 || K < 2 * kBK || forced == 128) return false;
   if (forced == 256) return true;
   const int64_t tiles = ((M + kBig - 1) / kBig) * ((N + kBig - 1) / kBig);
-  return tiles >= 512 && K >= 256 && N >= 160;           // a 256-wide tile over a narrower output is mostly padding
+  if (K < 256) return false;
+  // a 256-wide tile over a narrower output is mostly padding; below 512 tiles (the decoder's M = 8192) the 256^2 kernel still
+  // wins from N = 1400 up -- 192 tiles on 256 CUs included -- and loses at N = 768 (tools/exp_small_gemm.py)
+  return (tiles >= 512 && N >= 160) || (tiles >= 192 && N >= 1024);
 }
 
 static int pick_splits(int M, int N, int K, int n_cu) {
