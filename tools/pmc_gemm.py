@@ -16,6 +16,11 @@ bias = torch.zeros(N, device=dev)
 u = torch.empty((M, N), dtype=torch.bfloat16, device=dev)
 # enough launches that the boost / throttle transient of the first ~30 (0.42 -> 0.54 -> 0.46 ms) is a small part of the per-kernel
 # average that `rocprofv3 --stats` reports: what remains is the sustained-load duration bench.py times after its training steps
-for _ in range(int(os.environ.get("ADT_PMC_LAUNCHES", "24"))):
+n = int(os.environ.get("ADT_PMC_LAUNCHES", "24"))
+for _ in range(n):
     K.gemm(a, w, bias=bias, act=1, act_grad_out=u, drop=K.drop_site(0.1, 1, 5))
 torch.cuda.synchronize()
+if os.environ.get("ADT_PMC_ALSO_NO_DROPOUT"):      # kernel-stats runs only: the same launch with dropout off (a second kernel name in
+    for _ in range(n):                              # the table: gemm_nt_256_kernel<false, false, 29u>), closest to round 1's roofline form
+        K.gemm(a, w, bias=bias, act=1, act_grad_out=u)
+    torch.cuda.synchronize()

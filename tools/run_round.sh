@@ -17,7 +17,8 @@ timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_trai
 timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_logmel -- python3 $R/bench.py --workload logmel --steps 5 --warmup 2 --no-cpu-baseline > $O/prof_logmel.log 2>&1
 timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_clap -- python3 $R/bench.py --workload clap --steps 3 --warmup 1 --no-cpu-baseline > $O/prof_clap.log 2>&1
 export ADT_PMC_LAUNCHES=300
+export ADT_PMC_ALSO_NO_DROPOUT=1
 timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_roofline -- python3 $R/tools/pmc_gemm.py > $O/prof_roofline.log 2>&1
-unset ADT_PMC_LAUNCHES
+unset ADT_PMC_LAUNCHES ADT_PMC_ALSO_NO_DROPOUT
 rm -f $O/prof_*/*/*kernel_trace.csv          # keep the merged output small: the stats tables are what is committed
 ls $O
