@@ -1,0 +1,60 @@
+"""bench.py's output contract on the GPU: one JSON line with the fields the driver parses (metric / value / unit / n_gpus /
+steps / warmup / ms_per_step / higher_is_better / scaling / vs_baseline / dtype / data / config.workload), a `roofline` object
+whose numbers are consistent with each other, the `e2e` leg, and `cpu_baseline` when asked for."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def run_bench(*args):
+    env = dict(os.environ)
+    env.pop("WORLD_SIZE", None)
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), *args], cwd=ROOT, env=env, capture_output=True, text=True, timeout=900)
+    assert out.returncode == 0, out.stderr[-2000:]
+    lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, out.stdout[-2000:]
+    return json.loads(lines[0])
+
+
+def check_common(d, steps, warmup):
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype",
+              "data", "config", "roofline"):
+        assert k in d, k
+    assert d["n_gpus"] == 1 and d["steps"] == steps and d["warmup"] == warmup and d["higher_is_better"] is True
+    assert d["scaling"] == "weak" and d["vs_baseline"] is None and "workload" in d["config"] and "model" not in d["config"]
+    r = d["roofline"]
+    for k in ("bound", "achieved", "peak", "unit", "frac", "traffic"):
+        assert k in r, k
+    assert r["bound"] in ("hbm", "mfma") and r["unit"] in ("GB/s", "TFLOP/s")
+    assert abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-9 and 0.0 < r["frac"] < 1.0
+    assert d["value"] > 0 and d["ms_per_step"] > 0
+
+
+def test_train_line():
+    d = run_bench("--steps", "3", "--warmup", "1", "--no-cpu-baseline")
+    check_common(d, 3, 1)
+    assert d["unit"] == "clips/s" and d["dtype"] == "bf16" and d["config"]["workload"].startswith("train config[3]")
+    # value = clips of all steps / timed seconds
+    assert abs(d["value"] - 64 * 3 / (d["ms_per_step"] * 3e-3)) / d["value"] < 1e-6
+    r = d["roofline"]
+    assert r["bound"] == "mfma" and r["peak"] == 2500.0
+    assert abs(r["achieved"] - r["algorithmic_flops_per_launch"] / (r["kernel_ms"] * 1e-3) / 1e12) / r["achieved"] < 1e-6
+    assert r["traffic"] is None or r["traffic"] > r["algorithmic_bytes_per_launch"] * 0.9
+    assert set(r["same_shape_other_epilogues"]) == {"bias_gelu_preact_no_dropout_r01_form", "plain_bf16_product"}
+    e = d["e2e"]
+    assert e["unit"] == "clips/s" and e["value"] > 0 and 0.5 < e["ratio_to_value"] < 1.5
+    assert "cpu_baseline" not in d
+
+
+def test_logmel_line_with_cpu_baseline():
+    d = run_bench("--workload", "logmel", "--steps", "3", "--warmup", "1")
+    check_common(d, 3, 1)
+    assert d["dtype"] == "f32" and d["roofline"]["bound"] == "hbm" and d["roofline"]["peak"] == 8000.0
+    c = d["cpu_baseline"]
+    assert c["kind"] in ("port", "reference") and c["cores"] >= 1 and c["value"] > 0 and c["unit"] == d["unit"] and c["sample"]
