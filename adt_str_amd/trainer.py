@@ -133,9 +133,12 @@ class GradReducer:
         self.gflat, self.pg = gflat, process_group
         self.world = dist.get_world_size(process_group)
         self._works, self.covered = [], 0
+        # RCCL averages inside the collective; gloo (CPU tests, shared-GPU debug runs) only sums, the mean is then one more pass
+        self.avg_in_collective = dist.get_backend(process_group) == "nccl"
 
     def segment_ready(self, lo: int, hi: int):
-        self._works.append(dist.all_reduce(self.gflat[lo:hi], op=dist.ReduceOp.SUM, group=self.pg, async_op=True))
+        op = dist.ReduceOp.AVG if self.avg_in_collective else dist.ReduceOp.SUM
+        self._works.append(dist.all_reduce(self.gflat[lo:hi], op=op, group=self.pg, async_op=True))
         self.covered += hi - lo
 
     def finish(self):
@@ -145,7 +148,8 @@ class GradReducer:
         if self.covered != self.gflat.numel():
             raise RuntimeError(f"gradient segments covered {self.covered} of {self.gflat.numel()} elements")
         self.covered = 0
-        self.gflat.mul_(1.0 / self.world)
+        if not self.avg_in_collective:
+            self.gflat.mul_(1.0 / self.world)
 
 
 def backward_segments(engine):
