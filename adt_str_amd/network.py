@@ -174,6 +174,7 @@ class _Engine:
         self.grad_ready_hook = None      # callable(lo, hi): flat gradient range [lo, hi) is final (used to overlap all-reduce)
         self.drop_p = 0.0                # active dropout probability of the current pass (0 in eval)
         self.drop_seed = 0               # changes every training step; masks are regenerated from it in the backward
+        self.drop_base = 0               # what seed_dropout() started the counter from (rank-specific); drop_seed - drop_base = passes drawn
         self._sites: Dict[str, int] = {}
         self.generation = 0              # bumped by every pass that writes the gradient buffers (see _ADTLossFn.backward)
         self._wg_pending = []            # deferred decoder weight-gradient products (see _wgrad)
@@ -182,7 +183,7 @@ class _Engine:
         """Start the per-step dropout counter from a value derived from (experiment seed, data-parallel rank): ranks draw
         different masks (as nn.Dropout does under DDP), a different seed gives a different run, and a checkpoint that stores
         ``drop_seed`` resumes the sequence instead of replaying it from step 1."""
-        self.drop_seed = K.mix32(K.mix32(int(seed)) ^ ((int(rank) + 1) * 0x9E3779B9 & 0xFFFFFFFF)) & 0x3FFFFFFF
+        self.drop_seed = self.drop_base = K.mix32(K.mix32(int(seed)) ^ ((int(rank) + 1) * 0x9E3779B9 & 0xFFFFFFFF)) & 0x3FFFFFFF
 
     def D(self, site: str):
         """(p, key) of a named dropout site for the current step, or None when dropout is off."""
@@ -605,8 +606,15 @@ class _ADTLossFn(torch.autograd.Function):
             raise RuntimeError("the engine's gradient buffers were overwritten by a later forward pass before this loss was "
                                "back-propagated (two forwards, then backward): call backward() right after each forward, as "
                                "HF Trainer.training_step does")
-        grads = tuple(eng.G[name] * g for name in eng.named)
-        return (None, None, None, None, None) + grads
+        # ONE pass over the flat gradient buffer (276 MB at setting-1) into a fresh buffer, then a view per parameter -- not 132
+        # multiplies / allocations.  The copy cannot be skipped: autograd may keep what it is handed as ``p.grad`` (or add the
+        # next micro-batch into it under accumulation) while the engine's own buffer is overwritten by the next forward pass.
+        scaled = eng.gflat * g.reshape(()).to(eng.gflat.dtype)
+        grads, off = [], 0
+        for p in eng.named.values():
+            grads.append(scaled[off:off + p.numel()].view(p.shape))
+            off += p.numel()
+        return (None, None, None, None, None) + tuple(grads)
 
 
 class ADTModel(PreTrainedModel):
@@ -623,12 +631,22 @@ class ADTModel(PreTrainedModel):
         self.project_to_mel = nn.Linear(config.n_mels, int(config.d_query * config.nhead))
         self._engine_obj: Optional[_Engine] = None
         self._precision: Optional[str] = None          # None: ADT_PRECISION or "bf16"
+        self._drop_seed_args = None                    # (seed, rank) re-applied whenever the engine is rebuilt (.to(device))
 
     @property
     def engine(self) -> _Engine:
         if self._engine_obj is None:
             self._engine_obj = _Engine(self, self._precision)
+            if self._drop_seed_args is not None:
+                self._engine_obj.seed_dropout(*self._drop_seed_args)
         return self._engine_obj
+
+    def seed_dropout(self, seed: int, rank: int = 0) -> "ADTModel":
+        """Key the dropout masks by (experiment seed, data-parallel rank); survives ``.to(device)`` (which rebuilds the engine)."""
+        self._drop_seed_args = (int(seed), int(rank))
+        if self._engine_obj is not None:
+            self._engine_obj.seed_dropout(seed, rank)
+        return self
 
     def set_precision(self, precision: str) -> "ADTModel":
         """``"bf16"`` (throughput default) or ``"fp32"`` (parity arm, see ``_Engine``)."""

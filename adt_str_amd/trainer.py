@@ -26,6 +26,8 @@ import os
 import random
 import re
 import shutil
+import threading
+import warnings
 from typing import Callable, Optional
 
 import torch
@@ -127,29 +129,94 @@ class GradReducer:
     ``segment_ready(lo, hi)`` is called by the backward pass as soon as ``gflat[lo:hi]`` is final and
     starts an asynchronous all-reduce of that slice (RCCL on the GPUs, gloo in the CPU tests);
     ``finish()`` waits for all of them and turns the sums into means.  Segments must tile the buffer
-    (the network's ``flat_range`` segments do); ``covered`` lets callers assert that."""
+    (the network's ``flat_range`` segments do); ``covered`` lets callers assert that.
 
-    def __init__(self, gflat: torch.Tensor, process_group=None):
+    ``enabled = False`` turns a pass into DDP's ``no_sync()``: nothing is sent (gradient accumulation reduces only on the
+    last micro-step).  ``addend``: a flat buffer added to each segment right before it is sent (the locally accumulated
+    gradients of the earlier micro-steps), so the overlap with the backward pass survives accumulation.
+    ``compress="bf16"`` sends bf16 copies of the segments (138 MB instead of 276 MB per step at setting-1; the mean is taken
+    BEFORE the cast, as ``torch.distributed``'s ``bf16_compress_hook`` does) and widens them back in ``finish()``.
+    ``timing=True`` brackets the waits of ``finish()`` with events on the compute stream: the time that stream sat behind
+    the collectives (``exposed_wait_ms``) without a host synchronisation per step."""
+
+    def __init__(self, gflat: torch.Tensor, process_group=None, compress: Optional[str] = None, timing: bool = False):
+        if compress not in (None, "", "none", "bf16"):
+            raise ValueError(f"compress must be None or 'bf16', not {compress!r}")
         self.gflat, self.pg = gflat, process_group
         self.world = dist.get_world_size(process_group)
         self._works, self.covered = [], 0
+        self._segs = []
         # RCCL averages inside the collective; gloo (CPU tests, shared-GPU debug runs) only sums, the mean is then one more pass
         self.avg_in_collective = dist.get_backend(process_group) == "nccl"
+        self.enabled = True
+        self.addend: Optional[torch.Tensor] = None
+        self.compress = "bf16" if compress == "bf16" else None
+        self.wire = torch.empty(gflat.numel(), dtype=torch.bfloat16, device=gflat.device) if self.compress else None
+        self.timing = bool(timing) and gflat.is_cuda
+        self._events = []
+        self.bytes_last_step = 0
+        self.steps = 0
 
     def segment_ready(self, lo: int, hi: int):
-        op = dist.ReduceOp.AVG if self.avg_in_collective else dist.ReduceOp.SUM
-        self._works.append(dist.all_reduce(self.gflat[lo:hi], op=op, group=self.pg, async_op=True))
+        if not self.enabled:
+            return
+        seg = self.gflat[lo:hi]
+        if self.addend is not None:
+            seg.add_(self.addend[lo:hi])
+        if self.compress:
+            buf = self.wire[lo:hi]
+            if self.avg_in_collective:
+                buf.copy_(seg)
+                op = dist.ReduceOp.AVG
+            else:
+                torch.mul(seg, 1.0 / self.world, out=seg)          # mean before the cast: the bf16 sum cannot overflow its range
+                buf.copy_(seg)
+                op = dist.ReduceOp.SUM
+        else:
+            buf, op = seg, (dist.ReduceOp.AVG if self.avg_in_collective else dist.ReduceOp.SUM)
+        self._works.append(dist.all_reduce(buf, op=op, group=self.pg, async_op=True))
+        self._segs.append((lo, hi))
         self.covered += hi - lo
 
     def finish(self):
+        if not self.enabled:
+            return
+        ev = None
+        if self.timing:
+            ev = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
+            ev[0].record()
         for w in self._works:
             w.wait()
+        if ev is not None:
+            ev[1].record()
+            self._events.append(ev)
         self._works.clear()
         if self.covered != self.gflat.numel():
             raise RuntimeError(f"gradient segments covered {self.covered} of {self.gflat.numel()} elements")
+        self.bytes_last_step = self.covered * (2 if self.compress else 4)
         self.covered = 0
-        if not self.avg_in_collective:
+        self.steps += 1
+        if self.compress:
+            for lo, hi in self._segs:
+                self.gflat[lo:hi].copy_(self.wire[lo:hi])
+        elif not self.avg_in_collective:
             self.gflat.mul_(1.0 / self.world)
+        self._segs.clear()
+
+    def comm_stats(self, reset: bool = True) -> dict:
+        """``bytes_per_step`` (what one rank hands to the collective library per optimisation step) and, with ``timing``, the mean
+        ``exposed_wait_ms`` over the steps since the last call (synchronises the device: call it outside timed regions)."""
+        out = {"bytes_per_step": int(self.bytes_last_step), "wire_dtype": "bf16" if self.compress else "f32",
+               "reduce_op": "avg" if self.avg_in_collective else "sum+scale", "exposed_wait_ms": None}
+        if self._events:
+            torch.cuda.synchronize()
+            ms = [a.elapsed_time(b) for a, b in self._events]
+            out["exposed_wait_ms"] = sum(ms) / len(ms)
+            out["exposed_wait_ms_max"] = max(ms)
+            out["steps_timed"] = len(ms)
+            if reset:
+                self._events.clear()
+        return out
 
 
 def backward_segments(engine):
@@ -168,7 +235,8 @@ class FlatTrainer:
 
     def __init__(self, model, lr: float = 1e-4, weight_decay: float = 1e-5, betas=(0.9, 0.999), eps: float = 1e-8,
                  max_grad_norm: float = 1.0, total_steps: int = 1000, warmup_ratio: float = 0.1, min_lr_ratio: float = 0.0,
-                 process_group=None, scheduler: Optional[str] = None, grad_accum: int = 1, seed: Optional[int] = None):
+                 process_group=None, scheduler: Optional[str] = None, grad_accum: int = 1, seed: Optional[int] = None,
+                 grad_compress: Optional[str] = None, comm_timing: bool = False):
         self.model, self.eng = model, model.engine
         self.lr, self.wd, self.betas, self.eps, self.max_norm = lr, weight_decay, betas, eps, max_grad_norm
         self.total_steps = total_steps
@@ -199,9 +267,12 @@ class FlatTrainer:
         if seed is not None:
             self.eng.seed_dropout(seed, self.rank)
         self.reducer = None
-        if self.world > 1:
+        # an explicit process group is honoured even at world size 1 (the collective path then runs end to end on one GPU:
+        # how tests and ``torchrun --nproc-per-node 1 bench.py`` exercise the RCCL branch); otherwise only when there are peers
+        if dist.is_available() and dist.is_initialized() and (self.world > 1 or process_group is not None):
             self.broadcast_parameters()
-            self.reducer = GradReducer(self.gflat, self.pg)
+            self.reducer = GradReducer(self.gflat, self.pg, compress=grad_compress or os.environ.get("ADT_GRAD_COMPRESS"),
+                                       timing=comm_timing)
             self.eng.grad_ready_hook = self.reducer.segment_ready
         self.eng.refresh_weights(force=True)
 
@@ -221,15 +292,23 @@ class FlatTrainer:
         tgt_in, labels = tokens[:, :-1], tokens[:, 1:]
         T = tgt_in.shape[1]
         pad = torch.arange(T, device=tokens.device).unsqueeze(0) >= token_lengths.to(tokens.device).unsqueeze(1)
+        last = self._micro + 1 >= self.grad_accum
+        if self.reducer is not None:
+            # DDP ``no_sync()`` semantics: only the LAST micro-step of an accumulation window talks to the other ranks; its
+            # segments carry the locally accumulated sum of the earlier ones (added per segment just before it is sent)
+            self.reducer.enabled = last
+            self.reducer.addend = self.gacc if (last and self.grad_accum > 1) else None
         out = self.eng.loss_and_grads(wavs, tgt_in, pad, labels, want_grads=True)
         if self.reducer is not None:
             self.reducer.finish()
         self._micro += 1
         if self.grad_accum > 1:
-            self.gacc.add_(self.gflat)
-            if self._micro < self.grad_accum:
+            if not last:
+                self.gacc.add_(self.gflat)
                 return out["loss"]
-            self.gflat.copy_(self.gacc).mul_(1.0 / self.grad_accum)       # HF scales each micro-batch loss by 1 / accumulation steps
+            if self.reducer is None:
+                self.gflat.add_(self.gacc)
+            self.gflat.mul_(1.0 / self.grad_accum)                         # HF scales each micro-batch loss by 1 / accumulation steps
             self.gacc.zero_()
         self._micro = 0
         K.grad_norm(self.gflat, self.max_norm, out=self.norm)
@@ -246,12 +325,29 @@ class FlatTrainer:
 
     # ---- checkpoint state ------------------------------------------------------------------
     def state_dict(self) -> dict:
-        return {"m": self.m.detach().cpu(), "v": self.v.detach().cpu(), "step_no": self.step_no, "drop_seed": self.eng.drop_seed,
-                "total_steps": self.total_steps, "scheduler": self.scheduler}
+        return dict(self.state_dict_meta(), m=self.m.detach().cpu(), v=self.v.detach().cpu())
+
+    def state_dict_meta(self) -> dict:
+        # ``drop_steps``: training passes drawn so far -- the rank-independent part of the dropout counter (``drop_seed`` itself is
+        # seeded per rank, so rank 0's value must not be handed to the other ranks on resume)
+        return {"step_no": self.step_no, "drop_seed": self.eng.drop_seed,
+                "drop_steps": self.eng.drop_seed - self.eng.drop_base, "total_steps": self.total_steps, "scheduler": self.scheduler,
+                "grad_accum": self.grad_accum, "warmup": self.warmup}
 
     def load_state_dict(self, sd: dict):
         self.m.copy_(sd["m"]); self.v.copy_(sd["v"])
-        self.step_no, self.eng.drop_seed = int(sd["step_no"]), int(sd["drop_seed"])
+        self.step_no = int(sd["step_no"])
+        if "drop_steps" in sd:
+            self.eng.drop_seed = self.eng.drop_base + int(sd["drop_steps"])      # this rank's own sequence, resumed
+        else:                                                                    # checkpoints written before drop_steps existed
+            self.eng.drop_seed = int(sd["drop_seed"])
+        for key, mine in (("scheduler", self.scheduler), ("grad_accum", self.grad_accum)):
+            if key in sd and sd[key] != mine:
+                raise ValueError(f"checkpoint was written with {key}={sd[key]!r}, this run has {mine!r}: the learning-rate curve and the "
+                                 "data order would silently differ from the interrupted run")
+        if "total_steps" in sd and sd["total_steps"] != self.total_steps:        # a longer / shorter schedule can be deliberate
+            warnings.warn(f"checkpoint was written for {sd['total_steps']} optimisation steps, this run plans {self.total_steps}: "
+                          "the learning-rate curve differs from the interrupted run's")
         self._micro = 0
         if self.gacc is not None:
             self.gacc.zero_()
@@ -259,6 +355,13 @@ class FlatTrainer:
 
 
 # ----------------------------------------------------------------------------- checkpoints (HF layout: checkpoint-<step>/)
+def output_path(cfg: dict) -> str:
+    """``logging.output_dir / experiment.run_name`` -- where the reference puts checkpoints and the final model
+    (train.py:171-176), so that two experiments sharing an ``output_dir`` never resume from each other."""
+    lg, ex = cfg.get("logging", {}) or {}, cfg.get("experiment", {}) or {}
+    return os.path.join(lg.get("output_dir") or "./outputs", str(ex.get("run_name") or "default"))
+
+
 def _checkpoint_dirs(output_dir: str):
     found = []
     for d in glob.glob(os.path.join(output_dir, "checkpoint-*")):
@@ -273,36 +376,133 @@ def latest_checkpoint(output_dir: str) -> Optional[str]:
     return dirs[-1] if dirs else None
 
 
-def save_model(model: nn.Module, directory: str):
-    """``trainer.save_model()`` (train.py:323): ``model.safetensors`` with the reference's state-dict keys (+ ``config.json`` when
-    the model has an HF config) -- what ``build_model.py`` loads."""
+def _write_model_files(state: dict, cfg, directory: str):
     from safetensors.torch import save_file
     os.makedirs(directory, exist_ok=True)
-    save_file({k: v.detach().to("cpu").contiguous().clone() for k, v in model.state_dict().items()}, os.path.join(directory, "model.safetensors"))
-    cfg = getattr(model, "config", None)
+    save_file(state, os.path.join(directory, "model.safetensors"))
     if cfg is not None and hasattr(cfg, "save_pretrained"):
         cfg.save_pretrained(directory)
 
 
+def save_model(model: nn.Module, directory: str):
+    """``trainer.save_model()`` (train.py:323): ``model.safetensors`` with the reference's state-dict keys (+ ``config.json`` when
+    the model has an HF config) -- what ``build_model.py`` loads."""
+    _write_model_files({k: v.detach().to("cpu").contiguous().clone() for k, v in model.state_dict().items()},
+                       getattr(model, "config", None), directory)
+
+
+def _prune_checkpoints(output_dir: str, keep: Optional[int], just_written: str):
+    """``save_total_limit``: remove the oldest checkpoints beyond ``keep`` -- never the one just written, whatever stale
+    higher-numbered directories a previous run left behind."""
+    if not keep:
+        return
+    just = os.path.abspath(just_written)
+    others = [d for d in _checkpoint_dirs(output_dir) if os.path.abspath(d) != just]
+    others.sort(key=lambda d: os.path.getmtime(os.path.join(d, "trainer_state.pt")))
+    for old in others[:max(0, len(others) - (keep - 1))]:
+        shutil.rmtree(old, ignore_errors=True)
+
+
+class CheckpointWriter:
+    """Writes checkpoints off the training thread.  ``save_checkpoint`` takes a DEVICE-side snapshot (three flat clones, stream
+    ordered, ~0.1 ms) and hands it over; this thread copies it to pinned host memory on its own HIP stream (so the 0.8 GB of
+    device -> host traffic never sits in front of a training kernel) and writes the files.  One write in flight: a second
+    request first waits for the previous one (back-pressure instead of unbounded host memory).  ``close()`` joins; an error
+    in the writer surfaces on the next ``submit`` / ``close``."""
+
+    def __init__(self):
+        self._thread: Optional[threading.Thread] = None
+        self._error: Optional[BaseException] = None
+        self._stream = None
+
+    def _run(self, job):
+        try:
+            job()
+        except BaseException as e:                       # surfaced on the training thread
+            self._error = e
+
+    def wait(self):
+        if self._thread is not None:
+            self._thread.join()
+            self._thread = None
+        if self._error is not None:
+            e, self._error = self._error, None
+            raise RuntimeError("background checkpoint write failed") from e
+
+    def submit(self, job: Callable[[], None]):
+        self.wait()
+        self._thread = threading.Thread(target=self._run, args=(job,), name="adt-checkpoint-writer", daemon=True)
+        self._thread.start()
+
+    def side_stream(self, device):
+        if self._stream is None:
+            self._stream = torch.cuda.Stream(device=device)
+        return self._stream
+
+    close = wait
+
+
+def _device_snapshot(model: nn.Module, trainer):
+    """(state-dict snapshot on the device, optimizer moments on the device): parameters as views of ONE clone of the flat
+    buffer, buffers (constants) cloned one by one."""
+    snap = {}
+    pflat = getattr(trainer, "pflat", None)
+    if pflat is not None:
+        flat = pflat.detach().clone()
+        off = 0
+        for name, p in trainer.eng.named.items():
+            snap[name] = flat[off:off + p.numel()].view(p.shape)
+            off += p.numel()
+    for k, v in model.state_dict().items():
+        if k not in snap:
+            snap[k] = v.detach().clone()
+    return snap, trainer.m.detach().clone(), trainer.v.detach().clone()
+
+
 def save_checkpoint(output_dir: str, model: nn.Module, trainer, progress: dict, rng_state, rank: int = 0, world: int = 1,
-                    keep: Optional[int] = None) -> str:
+                    keep: Optional[int] = None, writer: Optional[CheckpointWriter] = None) -> str:
     """Rank 0 writes weights + optimizer state + progress; every rank writes its own host RNG state (the data stream of a rank
-    is a function of it).  ``keep``: ``save_total_limit`` -- older checkpoints are removed."""
+    is a function of it).  ``keep``: ``save_total_limit`` -- older checkpoints are removed (by rank 0, after its own files are
+    complete; ``trainer_state.pt`` is written last and marks a checkpoint as complete).  With a ``writer`` the device -> host
+    copy and the file writes happen on its thread; without one, here."""
     d = os.path.join(output_dir, f"checkpoint-{trainer.step_no}")
-    if rank == 0:
-        os.makedirs(d, exist_ok=True)
-        save_model(model, d)
-        torch.save({"trainer": trainer.state_dict(), "progress": dict(progress), "world": world}, os.path.join(d, "trainer_state.pt"))
-    if world > 1:
-        dist.barrier()
+    os.makedirs(d, exist_ok=True)
     if rng_state is not None:
         torch.save({"python": rng_state[0], "torch": rng_state[1]}, os.path.join(d, f"rng_state_{rank}.pth"))
-    if rank == 0 and keep:
-        for old in _checkpoint_dirs(output_dir)[:-keep]:
-            shutil.rmtree(old, ignore_errors=True)
-    if world > 1:
-        dist.barrier()
+    if rank != 0:
+        return d
+    cfg = getattr(model, "config", None)
+    flat = getattr(trainer, "pflat", None)
+    if writer is None or flat is None or not flat.is_cuda or not hasattr(trainer, "state_dict_meta"):
+        state = {k: v.detach().to("cpu").contiguous().clone() for k, v in model.state_dict().items()}
+        _finish_checkpoint(d, state, cfg, trainer.state_dict(), progress, world, output_dir, keep)
+        return d
+    meta = trainer.state_dict_meta()
+    snap, m_dev, v_dev = _device_snapshot(model, trainer)
+    ready = torch.cuda.Event()
+    ready.record()                                          # the clones are stream ordered behind the step that produced them
+    side = writer.side_stream(trainer.pflat.device)
+    progress = dict(progress)
+
+    def job():
+        with torch.cuda.stream(side):
+            side.wait_event(ready)
+            host = {k: torch.empty(v.shape, dtype=v.dtype, pin_memory=True).copy_(v, non_blocking=True) for k, v in snap.items()}
+            m_h = torch.empty(m_dev.shape, dtype=m_dev.dtype, pin_memory=True).copy_(m_dev, non_blocking=True)
+            v_h = torch.empty(v_dev.shape, dtype=v_dev.dtype, pin_memory=True).copy_(v_dev, non_blocking=True)
+            side.synchronize()
+        _finish_checkpoint(d, {k: t.contiguous() for k, t in host.items()}, cfg, dict(meta, m=m_h, v=v_h), progress, world, output_dir, keep)
+
+    writer.submit(job)
     return d
+
+
+def _finish_checkpoint(d, state, cfg, tstate, progress, world, output_dir, keep):
+    _write_model_files(state, cfg, d)
+    tmp = os.path.join(d, "trainer_state.pt.tmp")
+    torch.save({"trainer": tstate, "progress": dict(progress), "world": world}, tmp)
+    os.replace(tmp, os.path.join(d, "trainer_state.pt"))
+    _prune_checkpoints(output_dir, keep, d)
 
 
 def load_checkpoint(directory: str, model: nn.Module, trainer, rank: int = 0, world: int = 1) -> dict:
@@ -327,6 +527,9 @@ def load_checkpoint(directory: str, model: nn.Module, trainer, rank: int = 0, wo
         r = torch.load(rp, map_location="cpu", weights_only=False)
         random.setstate(r["python"])
         torch.set_rng_state(r["torch"])
+    else:
+        warnings.warn(f"{rp} is missing: rank {rank} resumes with a fresh host RNG state, so its data stream (random velocities, "
+                      "timbre / mix-up / FX draws) will not repeat the interrupted run's")
     return st["progress"]
 
 
@@ -375,13 +578,17 @@ def run_native_training(model, dataset, cfg: dict, trainer_factory: Optional[Cal
     total = steps_per_epoch * epochs
     if total == 0:
         raise ValueError(f"dataset of {len(dataset)} chunks is smaller than one global batch ({bs} x {world} ranks x {accum})")
-    min_ratio = (t["min_learning_rate"] / t["learning_rate"]) if t.get("min_learning_rate") else 0.0
-    sched = "cosine_warmup_with_min_lr" if min_ratio > 0 else t.get("lr_scheduler_type", "cosine")
+    lr_type = t.get("lr_scheduler_type") or "cosine"
+    min_lr = float(t.get("min_learning_rate") or 0.0)
+    # the reference swaps in the min-LR cosine only for ``cosine`` with a positive floor (train.py:203-218); any other type keeps HF's own curve
+    min_ratio = (min_lr / t["learning_rate"]) if (lr_type == "cosine" and min_lr > 0) else 0.0
+    sched = "cosine_warmup_with_min_lr" if min_ratio > 0 else lr_type
     seed = cfg["experiment"]["seed"]
     factory = trainer_factory or FlatTrainer
     tr = factory(model, lr=t["learning_rate"], weight_decay=t["weight_decay"], max_grad_norm=t["max_grad_norm"], total_steps=total,
                  warmup_ratio=t["warmup_ratio"], min_lr_ratio=min_ratio, scheduler=sched, grad_accum=accum, seed=seed)
-    out_dir = lg.get("output_dir") or "./outputs"
+    out_dir = output_path(cfg)                              # output_dir / run_name, as the reference (train.py:171-176)
+    writer = None if os.environ.get("ADT_SYNC_CHECKPOINTS") == "1" else CheckpointWriter()
     save_every, keep = lg.get("save_every_n_steps"), ck.get("max_checkpoints")
     start_epoch, start_micro = 0, 0
     resume = ck.get("resume_from_checkpoint")
@@ -394,14 +601,15 @@ def run_native_training(model, dataset, cfg: dict, trainer_factory: Optional[Cal
             print(f"resumed from {resume}: step {tr.step_no}, epoch {start_epoch}, micro-batch {start_micro}", flush=True)
     log = _LossLog(lg.get("logging_steps") or 0, rank, total, lambda s: print(s, flush=True))
     order = list(range(len(dataset)))
-    for epoch in range(start_epoch, epochs):
+
+    def run_epoch(epoch: int, first_micro: int):
         perm = list(order)
         random.Random(seed + epoch).shuffle(perm)                          # same permutation on every rank
         shard = perm[rank::world]
         pf = Prefetcher(lambda s: dataset.host_batch(shard[s * bs:(s + 1) * bs], snapshot_rng=bool(save_every)), micro_per_epoch,
-                        start=start_micro, depth=prefetch_depth)
+                        start=first_micro, depth=prefetch_depth)
         try:
-            for s, hb in zip(range(start_micro, micro_per_epoch), pf):
+            for s, hb in zip(range(first_micro, micro_per_epoch), pf):
                 batch = dataset.batcher.upload(hb, device_tokens=True)
                 loss = tr.micro_step(batch["wavs"], batch["tokens"], batch["token_lengths"])
                 if (s + 1) % accum:
@@ -409,10 +617,17 @@ def run_native_training(model, dataset, cfg: dict, trainer_factory: Optional[Cal
                 log.push(tr.step_no, epoch, loss, tr.current_lr())
                 if save_every and tr.step_no % save_every == 0:
                     nxt = (epoch, s + 1) if s + 1 < micro_per_epoch else (epoch + 1, 0)
-                    save_checkpoint(out_dir, model, tr, {"epoch": nxt[0], "micro": nxt[1]}, hb.rng_state, rank, world, keep)
+                    save_checkpoint(out_dir, model, tr, {"epoch": nxt[0], "micro": nxt[1]}, hb.rng_state, rank, world, keep, writer)
         finally:
             pf.close()
-        start_micro = 0
+
+    try:
+        for epoch in range(start_epoch, epochs):
+            run_epoch(epoch, start_micro)
+            start_micro = 0
+    finally:
+        if writer is not None:
+            writer.close()                                 # the last checkpoint is on disk before anyone can ask for it
     log.drain(True)
     if rank == 0:
         save_model(model, out_dir)

@@ -50,17 +50,32 @@ HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 FP32_VECTOR_PEAK_TF = 157.3
 BF16_MFMA_PEAK_TF = 2500.0     # dense bf16 MFMA peak (no sparsity)
 
-def pmc_traffic_bytes(name):
-    """HBM-side bytes per launch of the roofline kernel from the committed rocprofv3 --pmc summary of the same launch
+def newest_profile(name):
+    """Path (relative to the repo root) of ``name`` in the newest ``profiles/rNN/`` that holds it, or None."""
+    import glob
+    import re
+    rounds = sorted((int(m.group(1)), d) for d in glob.glob(os.path.join(ROOT, "profiles", "r*"))
+                    for m in [re.fullmatch(r"r(\d+)", os.path.basename(d))] if m)
+    for _, d in reversed(rounds):
+        if os.path.exists(os.path.join(d, name)):
+            return os.path.relpath(os.path.join(d, name), ROOT)
+    return None
+
+
+def pmc_traffic(name):
+    """(HBM-side bytes per launch of the roofline kernel, where that number comes from).  PMC counters cannot be collected from
+    inside this process, so the figure is REPLAYED from the newest committed rocprofv3 --pmc summary of the same launch
     (tools/run_pmc_*.sh; FETCH_SIZE / WRITE_SIZE are in KiB, and gfx950 tallies 128-byte read requests at 64 bytes:
-    MI355X_MICROARCH.md, HBM section).  None when the summary is not there."""
-    path = os.path.join(ROOT, "profiles", "r02", name)
+    MI355X_MICROARCH.md, HBM section) and the bench line says so.  (None, None) when there is no summary."""
+    rel = newest_profile(name)
+    if rel is None:
+        return None, None
     try:
-        with open(path) as f:
+        with open(os.path.join(ROOT, rel)) as f:
             d = json.load(f)
-        return (2.0 * d["FETCH_SIZE"]["mean"] + d["WRITE_SIZE"]["mean"]) * 1024.0
+        return (2.0 * d["FETCH_SIZE"]["mean"] + d["WRITE_SIZE"]["mean"]) * 1024.0, f"replayed from {rel} (separate rocprofv3 --pmc passes of this launch; not measured in this run)"
     except (OSError, KeyError, ValueError):
-        return None
+        return None, None
 
 
 SETTING1 = dict(enc_layers=4, dec_layers=4, nhead=6, d_query=128, tgt_vocab_size=1400, n_mels=128)
@@ -94,8 +109,9 @@ def logmel_setup(dev, seed):
         torch.cuda.synchronize()
         ms = ev0.elapsed_time(ev1) / 20
         ach = algo_bytes / (ms * 1e-3) / 1e9
+        traffic, src = pmc_traffic("logmel_pmc_summary.json")
         return {"bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS,
-                "traffic": pmc_traffic_bytes("logmel_pmc_summary.json"), "kernel": "adt::logmel_kernel", "kernel_ms": ms, "algorithmic_bytes_per_launch": algo_bytes,
+                "traffic": traffic, "traffic_source": src, "kernel": "adt::logmel_kernel", "kernel_ms": ms, "algorithmic_bytes_per_launch": algo_bytes,
                 "fp32_vector_tflops": algo_flops / (ms * 1e-3) / 1e12,
                 "fp32_vector_frac": algo_flops / (ms * 1e-3) / 1e12 / FP32_VECTOR_PEAK_TF}
 
@@ -164,7 +180,9 @@ def clap_setup(dev, seed):
         ms = ev0.elapsed_time(ev1) / 5
         fl = HTSAT_FLOPS_PER_CLIP * B
         ach = fl / (ms * 1e-3) / 1e12
-        return {"bound": "mfma", "achieved": ach, "peak": BF16_MFMA_PEAK_TF, "unit": "TFLOP/s", "frac": ach / BF16_MFMA_PEAK_TF, "traffic": None,
+        traffic, src = pmc_traffic("clap_pmc_summary.json")
+        return {"bound": "mfma", "achieved": ach, "peak": BF16_MFMA_PEAK_TF, "unit": "TFLOP/s", "frac": ach / BF16_MFMA_PEAK_TF, "traffic": traffic,
+                "traffic_source": src,
                 "kernel": "HTSAT encoder forward (all launches of HtsatEncoder.forward, %d clips)" % B, "kernel_ms": ms,
                 "algorithmic_flops_per_launch": fl}
 
@@ -225,7 +243,7 @@ def train_flops_per_clip(F, T, d=768, ffn=3072, V=1400, n_mels=128, enc=4, dec=4
     return 6.0 * macs
 
 
-def train_setup(dev, seed, world, dropout, fx_prob=0.0):
+def train_setup(dev, seed, world, dropout, fx_prob=0.0, process_group=None, grad_compress=None):
     from adt_str_amd import kernels as K
     from adt_str_amd.bank import OneShotBank, synthetic_tree
     from adt_str_amd.network import ADTModel, ADTModelConfig
@@ -235,7 +253,8 @@ def train_setup(dev, seed, world, dropout, fx_prob=0.0):
     torch.manual_seed(0)                                   # same initial weights on every rank (then broadcast anyway)
     cfg = ADTModelConfig(input_sec=10.0, time_res=0.01, win_length=2048, sample_rate=sr, dropout=dropout, plain=True, **SETTING1)
     model = ADTModel(cfg).to(dev)
-    trainer = FlatTrainer(model, lr=1e-4, weight_decay=1e-5, max_grad_norm=1.0, total_steps=10000, warmup_ratio=0.1)
+    trainer = FlatTrainer(model, lr=1e-4, weight_decay=1e-5, max_grad_norm=1.0, total_steps=10000, warmup_ratio=0.1,
+                          process_group=process_group, grad_compress=grad_compress, comm_timing=True)
     bank = OneShotBank.from_tree(synthetic_tree(7, sr), sr)
     synth = SynthDrum(SynthDrumConfig(input_sec=10.0, time_res=0.01, win_length=2048, sample_rate=sr, oneshot_path="synthetic",
                                       similarity_threshold=0.8, max_hat_std_velocity=0.15, max_hat_mean_velocity=0.1,
@@ -328,14 +347,15 @@ def train_setup(dev, seed, world, dropout, fx_prob=0.0):
             torch.cuda.synchronize()
             t = ev0.elapsed_time(ev1) / 30
             also[name] = {"kernel_ms": t, "achieved": fl / (t * 1e-3) / 1e12}
+        traffic, traffic_src = pmc_traffic("gemm_pmc_summary.json")
         return {"bound": "mfma", "achieved": ach, "peak": BF16_MFMA_PEAK_TF, "unit": "TFLOP/s", "frac": ach / BF16_MFMA_PEAK_TF, "same_shape_other_epilogues": also,
-                "traffic": pmc_traffic_bytes("gemm_pmc_summary.json"),
+                "traffic": traffic, "traffic_source": traffic_src,
                 "kernel": "adt::gemm_nt_256_kernel<%s, false> (FFN linear1 + bias + GELU%s + saved gelu' factor, M=%d N=%d K=%d)"
                           % ("true" if site else "false", " + dropout" if site else "", M, N, Kd),
                 "kernel_ms": ms, "algorithmic_flops_per_launch": fl,
                 "algorithmic_bytes_per_launch": 2.0 * (M * Kd + N * Kd + 2 * M * N),
-                "profile": "profiles/r02/roofline_gemm_kernel_stats.csv (rocprofv3 --kernel-trace --stats of tools/pmc_gemm.py: this kernel "
-                           "alone at this shape, 300 launches)"}
+                "profile": "%s (rocprofv3 --kernel-trace --stats of tools/pmc_gemm.py: this kernel alone at this shape, 300 launches)"
+                           % (newest_profile("roofline_gemm_kernel_stats.csv") or "no committed profile")}
 
     def cpu_baseline(budget_s=20.0):
         from oracle import adt as o_adt
@@ -357,8 +377,11 @@ def train_setup(dev, seed, world, dropout, fx_prob=0.0):
                 "sample": f"{done} clips (batches of {nb}) forward+backward in {dt:.1f} s, fp32, no optimizer step "
                           "(oracle/adt.py restatement of model.py:240-258)"}
 
+    def comm():
+        return trainer.reducer.comm_stats() if trainer.reducer is not None else None
+
     return {"step": step, "units": B, "dtype": "bf16", "roofline": roofline, "cpu_baseline": cpu_baseline, "state": state,
-            "flops_per_step": flops_clip * B, "e2e": e2e,
+            "flops_per_step": flops_clip * B, "e2e": e2e, "comm": comm,
             "metric": "ADT training clips/sec (10 s @16 kHz)",
             "config": {"workload": "train config[3]: ADT train step, setting-1 network (69.0M params), per-GPU batch 64 x 10 s @ 16 kHz "
                                    "mixer-rendered clips (F=%d frames), T=128 target tokens, bf16 GEMM/attention with fp32 accumulate, "
@@ -393,6 +416,7 @@ def main():
                                                                  "benchmark configuration is 0)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-e2e", action="store_true", help="skip the end-to-end (real input pipeline) leg of the train workload")
+    ap.add_argument("--grad-compress", default=None, choices=["bf16"], help="send bf16 copies of the gradient segments (N > 1)")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -412,13 +436,17 @@ def main():
         local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
-    if world > 1:
+    # Under a launcher (RANK / WORLD_SIZE in the environment) the process group is created even for ONE rank, and the training step
+    # then goes through the gradient reducer: ``torchrun --nproc-per-node 1 bench.py`` runs the whole RCCL path on one GPU.
+    launched = "RANK" in os.environ and "WORLD_SIZE" in os.environ
+    if world > 1 or launched:
         if share:
             dist.init_process_group("gloo")
         else:
             dist.init_process_group("nccl", device_id=dev)
+    pg = dist.group.WORLD if dist.is_initialized() else None
 
-    wl = {"train": lambda: train_setup(dev, rank, world, args.dropout, args.fx_prob), "logmel": lambda: logmel_setup(dev, rank),
+    wl = {"train": lambda: train_setup(dev, rank, world, args.dropout, args.fx_prob, pg, args.grad_compress), "logmel": lambda: logmel_setup(dev, rank),
           "clap": lambda: clap_setup(dev, rank)}[args.workload]()
     step = wl["step"]
 
@@ -430,6 +458,8 @@ def main():
     for _ in range(args.warmup):
         step()
     fence()
+    if "comm" in wl:
+        wl["comm"]()                                     # drop the warm-up steps' wait events
     t0 = time.perf_counter()
     for _ in range(args.steps):
         step()
@@ -439,6 +469,7 @@ def main():
         tt = torch.tensor([dt], device=dev, dtype=torch.float64)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dt = float(tt.item())
+    comm = wl["comm"]() if "comm" in wl else None     # the timed steps' collective waits (read before the e2e leg adds its own)
     dt_e2e = None
     if "e2e" in wl and not args.no_e2e:
         dt_e2e = wl["e2e"](args.steps, max(2, args.warmup), fence)
@@ -453,8 +484,12 @@ def main():
                 "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
                 "vs_baseline": None, "dtype": wl["dtype"], "data": "synthetic",
                 "config": dict(wl["config"], parallelism=f"dp{world}")}
-        if world > 1:                                    # what the collective library itself reports
+        if dist.is_initialized():                        # what the collective library itself reports
             line["collective"] = {"backend": dist.get_backend(), "world_size": dist.get_world_size()}
+        if comm is not None:
+            # bytes one rank hands to the collective per step; exposed_wait_ms = time the compute stream sat behind the
+            # all-reduces in GradReducer.finish() (event-bracketed on that stream), mean over the timed steps on rank 0
+            line["comm"] = comm
         if dt_e2e is not None:
             line["e2e"] = {"value": units / dt_e2e, "unit": wl.get("unit", "clips/s"), "ms_per_step": dt_e2e / args.steps * 1e3,
                            "ratio_to_value": dt / dt_e2e,
@@ -473,7 +508,7 @@ def main():
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = wl["cpu_baseline"]()
         print(json.dumps(line), flush=True)
-    if world > 1:
+    if dist.is_initialized():
         dist.barrier()
         dist.destroy_process_group()
 

@@ -58,15 +58,32 @@ def normalize(waveform: torch.Tensor) -> torch.Tensor:
     return waveform / torch.max(torch.abs(waveform))
 
 
+IO_THREADS = int(os.environ.get("ADT_CURATION_IO_THREADS", "8"))
+
+
+def _load_normalized(path, sample_rate):
+    return normalize(load_audio(path, sample_rate))
+
+
 def _embed(wrapper, files, batch_size, sample_rate):
-    """Embeddings [len(files), 512] on the wrapper's device, this rank's strided slice computed here, the rest gathered."""
+    """Embeddings [len(files), 512] on the wrapper's device, this rank's strided slice computed here, the rest gathered.
+
+    The reference reads, resamples and normalises one file at a time on the thread that also drives the GPU
+    (augment_data_with_CLAP.py:66-68,124-137).  Here the files of batch i + 1 are read by a small thread pool (file reads and the
+    numpy decode release the GIL) while the GPU embeds batch i; the order of the results is the order of ``files``."""
+    from concurrent.futures import ThreadPoolExecutor
     world = dist.get_world_size() if dist.is_initialized() else 1
     rank = dist.get_rank() if dist.is_initialized() else 0
     mine = list(range(rank, len(files), world))
     chunks = []
-    for i in range(0, len(mine), batch_size):
-        batch = [normalize(load_audio(files[j], sample_rate)) for j in mine[i:i + batch_size]]
-        chunks.append(wrapper.get_audio_features(batch).float())
+    starts = list(range(0, len(mine), batch_size))
+    with ThreadPoolExecutor(max_workers=max(1, IO_THREADS), thread_name_prefix="adt-curation-io") as pool:
+        submit = lambda i: [pool.submit(_load_normalized, files[j], sample_rate) for j in mine[i:i + batch_size]]
+        pending = submit(starts[0]) if starts else None
+        for k, i in enumerate(starts):
+            batch = [f.result() for f in pending]
+            pending = submit(starts[k + 1]) if k + 1 < len(starts) else None      # read the next batch while this one is embedded
+            chunks.append(wrapper.get_audio_features(batch).float())
     local = torch.cat(chunks) if chunks else torch.zeros((0, 512), device=wrapper.device)
     if world == 1:
         return local
@@ -112,15 +129,25 @@ def run(cfg: dict, num_bins: int = 10, clap_model=None, copy: bool = True):
         if augmented_root.exists():
             shutil.rmtree(augmented_root)
         augmented_root.mkdir(parents=True, exist_ok=True)
-        copied = 0
+        # destination -> source in the reference's copy order (descending score; a later copy onto the same destination
+        # overwrites an earlier one, :184-196), then the copies themselves in parallel: every destination is written once
+        plan = {}
         for i, label, bin_label in zip(res.order.tolist(), res.label.tolist(), res.bin):
-            dest_dir = augmented_root / str(label) / bin_label
-            dest_dir.mkdir(parents=True, exist_ok=True)
+            plan[augmented_root / str(label) / bin_label / Path(wav_files[i]).name] = wav_files[i]
+        for d in {dst.parent for dst in plan}:
+            d.mkdir(parents=True, exist_ok=True)
+
+        def _copy(item):
+            dst, src = item
             try:
-                shutil.copy2(wav_files[i], dest_dir / Path(wav_files[i]).name)
-                copied += 1
+                shutil.copy2(src, dst)
+                return 1
             except Exception as e:                         # the reference logs and carries on (:195-196)
-                print(f"Failed to copy {wav_files[i]} -> {dest_dir}: {e}")
+                print(f"Failed to copy {src} -> {dst.parent}: {e}")
+                return 0
+        from concurrent.futures import ThreadPoolExecutor
+        with ThreadPoolExecutor(max_workers=max(1, IO_THREADS), thread_name_prefix="adt-curation-copy") as pool:
+            copied = sum(pool.map(_copy, plan.items(), chunksize=64))
         print(f"Copied: {copied}, Skipped (duplicates): {len(wav_files) * (len(labels) - 1)}")
     return res, wav_files, augmented_root
 

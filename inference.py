@@ -23,7 +23,8 @@ def _chunk_audio(wav: torch.Tensor, chunk_samples: int):
     return out.view(n, chunk_samples)
 
 
-def transcribe(model, cfg: dict, wav: torch.Tensor, batch_size: int = 8):
+def transcribe(model, cfg: dict, wav: torch.Tensor, batch_size: int = 8, token_sink=None):
+    """``token_sink``: a list that receives the generated token ids of every chunk (one list of ints per chunk, in order)."""
     shared, inf = cfg["shared"], cfg["inference"]
     tok_cfg = cfg.get("tokenizer") or dict(ADTOF_mapping=False, BOS_token=2, EOS_token=3, pad_token=1, silence_token=0, add_velocity=True)
     tokenizer = MidiTokenizer(MidiTokenizerConfig(**tok_cfg))
@@ -34,6 +35,8 @@ def transcribe(model, cfg: dict, wav: torch.Tensor, batch_size: int = 8):
         ids = model.sample(src=chunks[i:i + batch_size], src_mask=None, tgt_mask=None, max_length=inf["max_length"],
                            start_token=tok_cfg["BOS_token"], end_token=tok_cfg["EOS_token"]).cpu()
         for j, row in enumerate(ids):
+            if token_sink is not None:
+                token_sink.append(row.tolist())
             dec = tokenizer.decode(row.tolist())
             if dec.numel():
                 dec = dec.clone()
@@ -50,6 +53,7 @@ def main():
     ap.add_argument("config_path")
     ap.add_argument("-o", "--output_dir", default="outputs")
     ap.add_argument("-s", "--synthesize", action="store_true", help="also render the transcription with the one-shot mixer")
+    ap.add_argument("--save-tokens", action="store_true", help="also write <stem>.tokens.json: the generated token ids per chunk")
     a = ap.parse_args()
     model, cfg = build_model(a.config_path, device="cuda")
     audio, sr = read_wav(a.input_path)
@@ -57,9 +61,14 @@ def main():
     if sr != cfg["shared"]["sample_rate"]:                 # reference inference.py:88-90
         from adt_str_amd.resample import Resample
         wav = Resample(sr, cfg["shared"]["sample_rate"])(wav)
-    notes = transcribe(model, cfg, wav, cfg["inference"]["batch_size"])
+    tokens = [] if a.save_tokens else None
+    notes = transcribe(model, cfg, wav, cfg["inference"]["batch_size"], tokens)
     os.makedirs(a.output_dir, exist_ok=True)
     stem = os.path.splitext(os.path.basename(a.input_path))[0]
+    if tokens is not None:
+        import json
+        with open(os.path.join(a.output_dir, stem + ".tokens.json"), "w") as fh:
+            json.dump({"precision": model.engine.precision, "max_length": cfg["inference"]["max_length"], "chunks": tokens}, fh)
     write_drum_midi(os.path.join(a.output_dir, stem + ".mid"), notes.tolist())
     print(f"{len(notes)} notes -> {os.path.join(a.output_dir, stem + '.mid')}")
     if a.synthesize and len(notes):

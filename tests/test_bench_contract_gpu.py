@@ -58,3 +58,26 @@ def test_logmel_line_with_cpu_baseline():
     assert d["dtype"] == "f32" and d["roofline"]["bound"] == "hbm" and d["roofline"]["peak"] == 8000.0
     c = d["cpu_baseline"]
     assert c["kind"] in ("port", "reference") and c["cores"] >= 1 and c["value"] > 0 and c["unit"] == d["unit"] and c["sample"]
+
+
+def test_torchrun_one_rank_runs_the_rccl_path():
+    """``python -m torch.distributed.run --nproc-per-node=1 bench.py --gpus 1``: under a launcher the process group is created even
+    for one rank (backend nccl = RCCL), the step goes through ``GradReducer`` and the line reports what it sent."""
+    import socket
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK"):
+        env.pop(k, None)
+    out = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=1", "--master-addr", "127.0.0.1",
+                          "--master-port", str(port), os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "3", "--warmup", "1",
+                          "--no-cpu-baseline", "--no-e2e"], cwd=ROOT, env=env, capture_output=True, text=True, timeout=900)
+    assert out.returncode == 0, out.stderr[-3000:]
+    lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, out.stdout[-2000:]
+    d = json.loads(lines[0])
+    check_common(d, 3, 1)
+    assert d["collective"] == {"backend": "nccl", "world_size": 1}
+    c = d["comm"]
+    assert c["bytes_per_step"] == 4 * 69000824 and c["wire_dtype"] == "f32" and c["reduce_op"] == "avg"
+    assert c["exposed_wait_ms"] is not None and 0.0 <= c["exposed_wait_ms"] < 50.0 and c["steps_timed"] == 3
+    assert d["roofline"]["traffic_source"] is None or "replayed from profiles/r" in d["roofline"]["traffic_source"]

@@ -58,6 +58,35 @@ def _worker(rank, world, port, q):
         except RuntimeError:
             ok = True
         assert ok
+        # DDP no_sync(): a disabled pass sends nothing and finish() leaves the local gradients alone
+        gflat.copy_(base * (rank + 1))
+        red3 = GradReducer(gflat)
+        red3.enabled = False
+        for lo, hi in segs:
+            red3.segment_ready(lo, hi)
+        red3.finish()
+        assert torch.equal(gflat, base * (rank + 1)) and red3.steps == 0
+        # ... and the last micro-step of an accumulation window carries the local sum of the earlier ones, segment by segment
+        acc = torch.full_like(gflat, 3.0 * (rank + 1))
+        red3.enabled, red3.addend = True, acc
+        for lo, hi in segs:
+            red3.segment_ready(lo, hi)
+        red3.finish()
+        assert torch.allclose(gflat, (base + 3.0) * (sum(r + 1 for r in range(world)) / world))
+        assert red3.comm_stats()["bytes_per_step"] == 4 * n
+        # bf16-compressed segments: half the bytes, the mean within bf16 rounding of the fp32 path (|x| <= 1500 here: ulp 8)
+        gflat.copy_(base * (rank + 1))
+        red4 = GradReducer(gflat, compress="bf16")
+        for lo, hi in segs:
+            red4.segment_ready(lo, hi)
+        red4.finish()
+        st = red4.comm_stats()
+        assert st["bytes_per_step"] == 2 * n and st["wire_dtype"] == "bf16"
+        err = (gflat - expect).abs()
+        assert float(err.max()) <= 8.0 and bool((err <= expect.abs() * 2.0 ** -7 + 1e-6).all()), float(err.max())
+        both = [torch.zeros_like(gflat) for _ in range(world)]
+        dist.all_gather(both, gflat)
+        assert torch.equal(both[0], both[1]), "compressed reduction must still leave every rank with the same gradients"
         # parameter broadcast from rank 0 (what FlatTrainer does once at construction)
         pflat = torch.cat([p.data.reshape(-1) for p in model.parameters()])
         dist.broadcast(pflat, src=0)

@@ -72,7 +72,8 @@ def test_hf_trainer_hook_runs_and_saves(tmp_path):
     assert trainer.state.global_step == 4
     losses = [h["loss"] for h in trainer.state.log_history if "loss" in h]
     assert losses and all(np.isfinite(losses))
-    out = cfg["logging"]["output_dir"]
+    from adt_str_amd.trainer import output_path
+    out = output_path(cfg)                                    # output_dir / run_name, as the reference (train.py:171-176)
     assert os.path.exists(os.path.join(out, "model.safetensors")) or os.path.exists(os.path.join(out, "pytorch_model.bin"))
     # the validation hook (reference train.py:80-141): mean of the per-batch eval-mode losses over an iterable of collated batches
     ds = trainer.train_dataset
@@ -146,3 +147,70 @@ def test_inference_cli_writes_parsable_midi(tmp_path):
                        capture_output=True, text=True, env=env, timeout=600)
     assert r.returncode == 0, r.stderr[-2000:]
     _parse_midi_note_ons(str(tmp_path / "out" / "clip22.mid"))
+
+
+def test_config0_at_size_cli_token_ids_equal_the_oracle_greedy_decode(tmp_path):
+    """BASELINE config[0] at its stated size: ONE 10 s clip @ 16 kHz rendered by the mixer (30 notes, onsets
+    U[0, 2.95] s, seed 0), a random-init SETTING-1 checkpoint (4 + 4 layers, 6 heads of 128, 69.0 M parameters, seed 0) saved as
+    ``model.safetensors``, ``python inference.py clip.wav cfg.yaml`` with ``max_length`` 64 (reference inference.py:98-120,
+    model.py:260-324).  fp32 mode (``ADT_PRECISION=fp32``): the CLI's token ids ARE the oracle's greedy decode and the MIDI file
+    holds exactly the notes those ids decode to.  bf16 mode (the default): every token is the arg-max of the bf16-operand
+    oracle's teacher-forced logits or within twice the stated bf16 logit tolerance of it (near-ties)."""
+    import json
+    from safetensors.torch import save_file
+    from adt_str_amd.audio_io import read_wav, write_wav
+    from adt_str_amd.tokenizer import MidiTokenizer, MidiTokenizerConfig
+    from build_model import model_config_from
+    from model import ADTModel
+    from oracle import adt as o_adt
+    import train
+    cfg = _make_workspace(tmp_path)
+    cfg["shared"]["input_sec"] = 10.0
+    cfg["model"] = {"enc_layers": 4, "dec_layers": 4, "d_query": 128, "nhead": 6, "dropout": 0.1}
+    cfg["synthetiser"]["use_fx_prob"] = 0.0
+    cfg["inference"] = {"checkpoint_path": str(tmp_path / "ckpt"), "batch_size": 4, "max_length": 64}
+    merged, cfg_path = _merged(cfg, tmp_path, "c0.yaml")
+    model = ADTModel(model_config_from(merged))
+    assert sum(p.numel() for p in model.parameters()) == 69000824
+    state = o_adt.seeded_state(model.state_dict(), 0)
+    os.makedirs(tmp_path / "ckpt")
+    save_file({k: v.contiguous() for k, v in state.items()}, str(tmp_path / "ckpt" / "model.safetensors"))
+    import random
+    random.seed(0)
+    rng = np.random.default_rng(0)
+    on = np.sort(rng.uniform(0.0, 2.95, 30))
+    notes = [[float(o), float(o) + 0.1, float(rng.integers(35, 61)), float(rng.integers(20, 127))] for o in on]
+    _, _, synth = train.build_components(merged)
+    clip = synth(torch.tensor(notes, dtype=torch.float32)).cpu().numpy()
+    assert clip.shape == (160000,)
+    write_wav(str(tmp_path / "clip.wav"), clip, SR)
+    wav16, _ = read_wav(str(tmp_path / "clip.wav"))                         # what the CLI reads back (16-bit PCM)
+    src = torch.from_numpy(wav16.mean(axis=0))[None, :]
+    ocfg = dict(nhead=6, sample_rate=SR, win_length=2048, time_res=0.01, n_mels=128)
+    tok_cfg = MidiTokenizerConfig(**merged["tokenizer"])
+
+    def cli(precision, out):
+        env = dict(os.environ, PYTHONPATH=ROOT + os.pathsep + os.environ.get("PYTHONPATH", ""), ADT_PRECISION=precision)
+        r = subprocess.run([sys.executable, os.path.join(ROOT, "inference.py"), str(tmp_path / "clip.wav"), cfg_path, "-o", str(tmp_path / out),
+                            "--save-tokens"], capture_output=True, text=True, env=env, timeout=900)
+        assert r.returncode == 0, r.stderr[-2000:]
+        d = json.load(open(tmp_path / out / "clip.tokens.json"))
+        assert d["precision"] == precision and d["max_length"] == 64 and len(d["chunks"]) == 1
+        return torch.tensor(d["chunks"][0])[None, :], _parse_midi_note_ons(str(tmp_path / out / "clip.mid"))
+
+    want = o_adt.greedy_sample(state, ocfg, src, max_length=64)
+    got32, n_on32 = cli("fp32", "o32")
+    assert got32.shape == want.shape and torch.equal(got32, want), (got32, want)
+    dec = MidiTokenizer(tok_cfg).decode(want[0].tolist())
+    uniq = np.unique(dec.numpy(), axis=0) if dec.numel() else np.zeros((0, 4))
+    assert n_on32 == len(uniq)
+    assert want.shape[1] > 12, "the decode must be longer than the toy decodes checked elsewhere"
+
+    got16, _ = cli("bf16", "o16")
+    assert got16[0, 0] == 2 and 2 <= got16.shape[1] <= 64
+    logits = o_adt.teacher_forced_logits(state, ocfg, src, got16[:, :-1], bf16=True)      # [1, n-1, V]
+    fin = False
+    for t in range(got16.shape[1] - 1):
+        tok, row = int(got16[0, t + 1]), logits[0, t]
+        assert (tok == 3) if fin else bool(row[tok] >= row.max() - 6e-2), (t, tok, int(row.argmax()), float(row.max() - row[tok]))
+        fin = fin or tok == 3

@@ -211,7 +211,7 @@ def test_native_loop_prefetch_accumulation_and_final_save(tmp_path):
     assert all(torch.equal(a, b) for a, b in zip(m_inline.state_dict().values(), m_thread.state_dict().values()))
     assert len(t_thread.loss_history) == t_thread.step_no                                       # logging_steps = 1, drained at the end
     from safetensors.torch import load_file
-    saved = load_file(str(tmp_path / "b" / "model.safetensors"))                                # trainer.save_model()
+    saved = load_file(str(tmp_path / "b" / "default" / "model.safetensors"))       # output_dir / run_name                                # trainer.save_model()
     assert set(saved) == set(m_thread.state_dict()) and torch.equal(saved["lin.weight"], m_thread.lin.weight.data)
     _, t_acc = _run(_cfg(tmp_path / "c", training__gradient_accumulation_steps=3))
     assert t_acc.step_no == 2 * (50 // 12) and len(t_acc.seen) == 3 * t_acc.step_no and t_acc.seen == t_inline.seen[:12] + t_inline.seen[12:24]
@@ -221,12 +221,14 @@ def test_native_loop_prefetch_accumulation_and_final_save(tmp_path):
 
 def test_checkpoints_rotate_and_resume_reproduces_the_uninterrupted_run(tmp_path):
     full_model, full = _run(_cfg(tmp_path / "full", logging__save_every_n_steps=5, checkpoint__max_checkpoints=2))
-    dirs = sorted(os.listdir(tmp_path / "full"))
+    run_dir = tmp_path / "full" / "default"                                                     # output_dir / run_name (reference train.py:171-176)
+    assert T.output_path(_cfg(tmp_path / "full")) == str(run_dir)
+    dirs = sorted(os.listdir(run_dir))
     assert [d for d in dirs if d.startswith("checkpoint-")] == ["checkpoint-15", "checkpoint-20"]                # save_total_limit
-    assert os.path.exists(tmp_path / "full" / "checkpoint-20" / "rng_state_0.pth")
+    assert os.path.exists(run_dir / "checkpoint-20" / "rng_state_0.pth")
     # a run that stops after 15 steps (kept checkpoint), then resumes: mid-epoch (12 steps per epoch), same data stream afterwards
     cfg = _cfg(tmp_path / "full", logging__save_every_n_steps=5, checkpoint__max_checkpoints=2,
-               checkpoint__resume_from_checkpoint=str(tmp_path / "full" / "checkpoint-15"))
+               checkpoint__resume_from_checkpoint=str(run_dir / "checkpoint-15"))
     random.seed(999); torch.manual_seed(999)                                                  # resume must not depend on the ambient RNG
     model = _ToyModel()
     with torch.no_grad():
@@ -235,11 +237,49 @@ def test_checkpoints_rotate_and_resume_reproduces_the_uninterrupted_run(tmp_path
     tr = T.run_native_training(model, _dataset(), cfg, trainer_factory=_ToyTrainer)
     assert tr.step_no == full.step_no and tr.seen == full.seen[15:]
     assert all(torch.equal(a, b) for a, b in zip(model.state_dict().values(), full_model.state_dict().values()))
-    assert T.latest_checkpoint(str(tmp_path / "full")).endswith("checkpoint-20")
+    assert T.latest_checkpoint(str(run_dir)).endswith("checkpoint-20")
     cfg2 = _cfg(tmp_path / "full", checkpoint__auto_resume=True)
     model2 = _ToyModel()
     tr2 = T.run_native_training(model2, _dataset(), cfg2, trainer_factory=_ToyTrainer)
     assert tr2.seen == full.seen[20:]
+
+
+def test_pruning_never_removes_the_checkpoint_just_written(tmp_path):
+    """Resuming from a non-latest checkpoint leaves stale higher-numbered directories behind: ``save_total_limit`` must drop
+    those (oldest first), never the directory that was just written."""
+    import time
+    out = tmp_path / "run"
+    for step in (30, 40):                                                     # stale checkpoints of an earlier, longer run
+        d = out / f"checkpoint-{step}"
+        os.makedirs(d)
+        torch.save({}, d / "trainer_state.pt")
+        time.sleep(0.02)
+    new = out / "checkpoint-10"
+    os.makedirs(new)
+    torch.save({}, new / "trainer_state.pt")
+    T._prune_checkpoints(str(out), 2, str(new))
+    assert sorted(os.listdir(out)) == ["checkpoint-10", "checkpoint-40"]
+    T._prune_checkpoints(str(out), 1, str(new))
+    assert sorted(os.listdir(out)) == ["checkpoint-10"]
+
+
+def test_scheduler_selection_follows_the_reference(tmp_path):
+    """train.py:203-218 of the reference: the min-LR cosine replaces the schedule only for ``cosine`` with a positive floor."""
+    def sched(**kw):
+        _, tr = _run(_cfg(tmp_path / str(abs(hash(tuple(sorted(kw.items()))))), training__num_epochs=1, **{"training__" + k: v for k, v in kw.items()}))
+        return tr.scheduler, tr.min_lr_ratio
+    assert sched(lr_scheduler_type="cosine", min_learning_rate=0.005) == ("cosine_warmup_with_min_lr", pytest.approx(0.1))
+    assert sched(lr_scheduler_type="linear", min_learning_rate=0.005) == ("linear", 0.0)
+    assert sched(lr_scheduler_type="cosine", min_learning_rate=0.0) == ("cosine", 0.0)
+    assert sched(lr_scheduler_type="constant", min_learning_rate=None) == ("constant", 0.0)
+
+
+def test_missing_rank_rng_file_is_reported_on_resume(tmp_path):
+    _, full = _run(_cfg(tmp_path / "r", logging__save_every_n_steps=5))
+    ck = tmp_path / "r" / "default" / "checkpoint-10"
+    os.remove(ck / "rng_state_0.pth")
+    with pytest.warns(UserWarning, match="rng_state_0.pth is missing"):
+        T.run_native_training(_ToyModel(), _dataset(), _cfg(tmp_path / "r", checkpoint__resume_from_checkpoint=str(ck)), trainer_factory=_ToyTrainer)
 
 
 def _free_port():
@@ -260,7 +300,7 @@ def _rank_worker(rank, world, port, out_dir, q):
         both = [torch.zeros_like(flat) for _ in range(world)]
         dist.all_gather(both, flat)
         assert torch.equal(both[0], both[1]), "ranks must end with identical parameters"
-        q.put((rank, tr.step_no, tr.seen, os.path.exists(os.path.join(out_dir, "checkpoint-4", f"rng_state_{rank}.pth"))))
+        q.put((rank, tr.step_no, tr.seen, os.path.exists(os.path.join(out_dir, "default", "checkpoint-4", f"rng_state_{rank}.pth"))))
     except Exception as e:                                   # pragma: no cover
         import traceback
         q.put((rank, repr(e), traceback.format_exc(), False))

@@ -77,17 +77,18 @@ def test_prefetch_thread_changes_nothing_and_resume_is_bit_exact(tmp_path):
     b = go("thread", 2)
     assert a.step_no == b.step_no == 2 * 12
     assert _losses(a) == _losses(b) and torch.equal(a.pflat, b.pflat)             # same draws, same batches, same bits
-    assert sorted(d for d in os.listdir(tmp_path / "thread") if d.startswith("checkpoint-")) == ["checkpoint-15", "checkpoint-20"]
+    run_dir = tmp_path / "thread" / "t"                                        # output_dir / run_name (reference train.py:171-176)
+    assert sorted(d for d in os.listdir(run_dir) if d.startswith("checkpoint-")) == ["checkpoint-15", "checkpoint-20"]
     from safetensors.torch import load_file
-    final = load_file(str(tmp_path / "thread" / "model.safetensors"))
+    final = load_file(str(run_dir / "model.safetensors"))
     assert set(final) == set(b.model.state_dict()) and torch.equal(final["decoder.generator.bias"].cuda(), b.model.decoder.generator.bias.data)
     # resume from step 15 (mid-epoch 2, with dropout 0.1 and the FX draws in the stream): steps 16..24 repeat bit for bit
-    c = go("thread", 2, resume=str(tmp_path / "thread" / "checkpoint-15"))
+    c = go("thread", 2, resume=str(run_dir / "checkpoint-15"))
     assert c.step_no == 24 and _losses(c) == _losses(b)[15:] and torch.equal(c.pflat, b.pflat)
     assert torch.equal(c.m, b.m) and torch.equal(c.v, b.v)
     # build_model loads what the loop saved (the reference's checkpoint contract, build_model.py:49-66)
     from build_model import build_model
-    cfg_d = {**base, "inference": {"checkpoint_path": str(tmp_path / "thread"), "batch_size": 2, "max_length": 8}}
+    cfg_d = {**base, "inference": {"checkpoint_path": str(run_dir), "batch_size": 2, "max_length": 8}}
     _, cfg_path = _merged(cfg_d, tmp_path, "infer.yaml")
     m2, _ = build_model(cfg_path)
     assert torch.equal(m2.state_dict()["decoder.generator.bias"].cpu(), final["decoder.generator.bias"])
@@ -115,5 +116,65 @@ def test_torchrun_two_ranks_train_native_share_one_model(tmp_path):
     p0, p1 = (torch.load(str(tmp_path / f"params_rank{i}.pt")) for i in range(2))
     assert p0["world"] == p1["world"] == 2 and p0["steps"] == p1["steps"] == 32 // (4 * 2)
     assert torch.equal(p0["pflat"], p1["pflat"]), "both ranks must hold the same model"
-    out = cfg["logging"]["output_dir"]
+    from adt_str_amd.trainer import output_path
+    out = output_path(cfg)
     assert os.path.exists(os.path.join(out, "model.safetensors")) and os.path.exists(os.path.join(out, "checkpoint-4", "rng_state_1.pth"))
+
+
+def _torchrun_train(cfg_path, dump_dir, *extra, env_extra=None):
+    os.makedirs(dump_dir, exist_ok=True)
+    env = dict(os.environ, PYTHONPATH=ROOT + os.pathsep + os.environ.get("PYTHONPATH", ""), ADT_SHARE_GPU="1", ADT_DUMP_PARAMS=str(dump_dir),
+               **(env_extra or {}))
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1",
+                        "--master-port", str(_free_port()), os.path.join(ROOT, "train.py"), cfg_path, *extra],
+                       capture_output=True, text=True, env=env, timeout=900)
+    assert r.returncode == 0, (r.stdout[-1500:], r.stderr[-3000:])
+    return [torch.load(os.path.join(dump_dir, f"params_rank{i}.pt")) for i in range(2)]
+
+
+def test_two_rank_resume_keeps_each_ranks_own_dropout_stream(tmp_path):
+    """Data-parallel resume (dropout 0.1, FX draws in the stream): the run resumed from ``checkpoint-4`` ends with bitwise the
+    parameters of the uninterrupted run on BOTH ranks.  That needs every rank to continue ITS OWN dropout counter (seeded per
+    rank) and its own host RNG stream -- a checkpoint that handed rank 0's counter to rank 1 would fail here."""
+    os.makedirs(tmp_path / "w")
+    ws = _make_workspace(tmp_path / "w", n_items=64, batch=4)                 # 8 steps per rank pair
+    ws["logging"]["save_every_n_steps"] = 2
+    ws["checkpoint"] = {"max_checkpoints": 8}
+    cfg, cfg_path = _merged(ws, tmp_path, "full.yaml")
+    full = _torchrun_train(cfg_path, tmp_path / "dump_full", "--native")
+    assert full[0]["steps"] == 8 and torch.equal(full[0]["pflat"], full[1]["pflat"])
+    from adt_str_amd.trainer import output_path
+    ck = os.path.join(output_path(cfg), "checkpoint-4")
+    assert os.path.exists(os.path.join(ck, "trainer_state.pt")) and os.path.exists(os.path.join(ck, "rng_state_1.pth"))
+    st = torch.load(os.path.join(ck, "trainer_state.pt"), weights_only=False)["trainer"]
+    assert st["drop_steps"] == 4 and st["step_no"] == 4
+    ws2 = dict(ws, checkpoint={"max_checkpoints": 8, "resume_from_checkpoint": ck})
+    _, cfg_path2 = _merged(ws2, tmp_path, "resume.yaml")
+    res = _torchrun_train(cfg_path2, tmp_path / "dump_resume", "--native")
+    assert res[0]["steps"] == 8
+    assert torch.equal(res[0]["pflat"], full[0]["pflat"]) and torch.equal(res[1]["pflat"], full[1]["pflat"])
+
+
+def test_two_ranks_hf_trainer_ddp_without_native(tmp_path):
+    """The reference's own multi-GPU launch (README.md:53-57: ``accelerate launch train.py <yaml>`` -> HF ``Trainer`` -> DDP), two
+    ranks, NO ``--native``: ``train()`` creates the process group before any GPU work, accelerate adopts it, DDP averages the
+    gradients that ``_ADTLossFn.backward`` hands to autograd, and both ranks end with the same parameters -- which are not the
+    initial ones.  (One-GPU box: both ranks on GPU 0 over gloo, ADT_SHARE_GPU=1; on a node: cuda:LOCAL_RANK and RCCL.)"""
+    os.makedirs(tmp_path / "w")
+    ws = _make_workspace(tmp_path / "w", n_items=32, batch=4)
+    cfg, cfg_path = _merged(ws, tmp_path, "hf.yaml")
+    p0, p1 = _torchrun_train(cfg_path, tmp_path / "dump_hf")
+    assert p0["world"] == p1["world"] == 2 and p0["steps"] == p1["steps"] == 32 // (4 * 2)
+    assert torch.equal(p0["pflat"], p1["pflat"]), "DDP must leave both ranks with the same model"
+    assert bool(torch.isfinite(p0["pflat"]).all())
+    from adt_str_amd.trainer import output_path
+    out = output_path(cfg)
+    assert os.path.exists(os.path.join(out, "model.safetensors"))
+    from safetensors.torch import load_file
+    saved = load_file(os.path.join(out, "model.safetensors"))
+    from build_model import model_config_from
+    from adt_str_amd.network import ADTModel
+    torch.manual_seed(cfg["experiment"]["seed"])
+    fresh = ADTModel(model_config_from(cfg))
+    moved = max(float((saved[k].float() - v.detach().float()).abs().max()) for k, v in fresh.named_parameters())
+    assert moved > 1e-4, "training must have changed the weights"

@@ -63,12 +63,15 @@ def write_library(root, n_shots, refs_per_class, seed, rank=0, world=1):
     jobs = [("refs", str(p), f"ref_{i}.wav", p) for p in PITCHES for i in range(refs_per_class)]
     cls = rng.integers(0, len(PITCHES), n_shots)
     jobs += [("packs", f"pack_{j // 1000:03d}", f"shot_{j:06d}.wav", PITCHES[int(cls[j])]) for j in range(n_shots)]
-    for k, (top, sub, name, pitch) in enumerate(jobs):
-        if k % world != rank:
-            continue
-        d = os.path.join(root, top, sub)
+    for d in {os.path.join(root, top, sub) for top, sub, _, _ in jobs}:
         os.makedirs(d, exist_ok=True)
-        write_wav(os.path.join(d, name), _shot(np.random.default_rng(seed * 1000003 + k), protos[pitch], CLAP_SR), CLAP_SR)
+
+    def one(k):
+        top, sub, name, pitch = jobs[k]
+        write_wav(os.path.join(root, top, sub, name), _shot(np.random.default_rng(seed * 1000003 + k), protos[pitch], CLAP_SR), CLAP_SR)
+    from concurrent.futures import ThreadPoolExecutor
+    with ThreadPoolExecutor(max_workers=8) as pool:                 # numpy + file writes release the GIL
+        list(pool.map(one, range(rank, len(jobs), world), chunksize=256))
     return os.path.join(root, "refs"), os.path.join(root, "packs")
 
 
@@ -117,7 +120,7 @@ def main(argv=None):
     ap.add_argument("--seed", type=int, default=42)
     a = ap.parse_args(argv)
 
-    from adt_str_amd.trainer import init_distributed, latest_checkpoint, run_native_training, _checkpoint_dirs
+    from adt_str_amd.trainer import init_distributed, latest_checkpoint, output_path, run_native_training, _checkpoint_dirs
     rank, local_rank, world = init_distributed()
     assert torch.cuda.is_available(), "tools/e2e.py needs a GPU (there is no CPU path)"
     torch.cuda.set_device(local_rank)
@@ -178,7 +181,8 @@ def main(argv=None):
     cfg = {"training": dict(batch_size=a.batch_size, num_epochs=1, learning_rate=1e-4, weight_decay=1e-5, max_grad_norm=1.0, warmup_ratio=0.1,
                             gradient_accumulation_steps=1, min_learning_rate=None, lr_scheduler_type="cosine"),
            "logging": dict(output_dir=out_dir, logging_steps=max(1, steps // 10), save_every_n_steps=save_every),
-           "checkpoint": dict(resume_from_checkpoint=None, auto_resume=False, max_checkpoints=3), "experiment": dict(seed=a.seed)}
+           "checkpoint": dict(resume_from_checkpoint=None, auto_resume=False, max_checkpoints=3), "experiment": dict(seed=a.seed, run_name="e2e")}
+    run_dir = output_path(cfg)                            # output_dir / run_name
 
     def build():
         random.seed(a.seed); torch.manual_seed(a.seed)
@@ -202,12 +206,12 @@ def main(argv=None):
            "network": "tiny 1+1" if a.tiny else "setting-1 (69.0M)", "steps": tr.step_no, "times": times,
            "embeds_per_s": n_embedded / times["curate_s"], "train_clips_per_s": tr.step_no * a.batch_size * world / times["train_epoch_s"],
            "final_loss": tr.loss_history[-1][1] if getattr(tr, "loss_history", None) else None,
-           "checkpoints": [os.path.basename(d) for d in _checkpoint_dirs(out_dir)]}
+           "checkpoints": [os.path.basename(d) for d in _checkpoint_dirs(run_dir)]}
     if rank == 0:
         out["bank_shots"] = n_bank
         out["bins_used"] = sorted(set(res.bin))
     if a.check_resume:
-        dirs = _checkpoint_dirs(out_dir)
+        dirs = _checkpoint_dirs(run_dir)
         src = dirs[-2] if len(dirs) > 1 and int(dirs[-1].rsplit("-", 1)[1]) == tr.step_no else dirs[-1]
         final = tr.pflat.clone()
         cfg["checkpoint"]["resume_from_checkpoint"] = src

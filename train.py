@@ -11,8 +11,11 @@ Multi-GPU, one process per GPU on one node, exactly like the reference's ``accel
     python -m torch.distributed.run --nnodes=1 --nproc-per-node 8 --master-addr 127.0.0.1 train.py <yaml> --native
     accelerate launch train.py <yaml> --native
 
-Both set RANK / LOCAL_RANK / WORLD_SIZE; ``train()`` binds the process to its GPU and creates the RCCL process group
-before any GPU work (``adt_str_amd.trainer.init_distributed``).
+    accelerate launch train.py <yaml>                  # HF Trainer + DistributedDataParallel, the reference's own command
+
+All set RANK / LOCAL_RANK / WORLD_SIZE; ``train()`` binds the process to its GPU and creates the RCCL process group
+before any GPU work (``adt_str_amd.trainer.init_distributed``), with or without ``--native``: HF Trainer's accelerate
+state adopts that group and wraps the model in DDP over it.
 """
 import argparse
 import logging
@@ -81,8 +84,10 @@ class ADTTrainer(Trainer):
 
 
 def create_training_arguments(cfg: dict) -> "TrainingArguments":
+    from adt_str_amd.trainer import output_path
     t, lg, ex, ck = cfg["training"], cfg["logging"], cfg["experiment"], cfg["checkpoint"]
-    kw = dict(output_dir=lg["output_dir"], per_device_train_batch_size=t["batch_size"], num_train_epochs=t["num_epochs"] or 1,
+    kw = dict(output_dir=output_path(cfg),          # output_dir / run_name (reference train.py:171-176)
+              per_device_train_batch_size=t["batch_size"], num_train_epochs=t["num_epochs"] or 1,
               learning_rate=t["learning_rate"], warmup_ratio=t["warmup_ratio"], weight_decay=t["weight_decay"],
               max_grad_norm=t["max_grad_norm"], gradient_accumulation_steps=t["gradient_accumulation_steps"], optim=t["optim"],
               lr_scheduler_type=t["lr_scheduler_type"], logging_steps=lg["logging_steps"], seed=ex["seed"],
@@ -97,9 +102,9 @@ def create_training_arguments(cfg: dict) -> "TrainingArguments":
     import inspect
     if "warmup_ratio" not in inspect.signature(TrainingArguments.__init__).parameters:
         kw["warmup_steps"] = kw.pop("warmup_ratio")       # transformers >= 5: a float < 1 in warmup_steps is the ratio
-    if t.get("min_learning_rate"):
+    if (t.get("lr_scheduler_type") or "cosine") == "cosine" and float(t.get("min_learning_rate") or 0) > 0:   # reference train.py:203-218
         kw["lr_scheduler_type"] = "cosine_warmup_with_min_lr"
-        kw["lr_scheduler_kwargs"] = {"min_lr": t["min_learning_rate"]}
+        kw["lr_scheduler_kwargs"] = {"min_lr": float(t["min_learning_rate"])}
     return TrainingArguments(**kw)
 
 
@@ -114,27 +119,35 @@ def build_components(cfg: dict, device: str = "cuda"):
 
 
 def train(cfg: dict, native: bool = False):
+    from adt_str_amd.trainer import init_distributed, run_native_training
     from data_modules.train_dataset import LakhDataset, LakhDatasetConfig
     logging.basicConfig(level=getattr(logging, cfg["logging"].get("log_level", "INFO")))
-    device = "cuda"
-    if native:
-        from adt_str_amd.trainer import init_distributed, run_native_training
-        _, local_rank, _ = init_distributed()                 # set_device(LOCAL_RANK) + RCCL group, before any GPU work
-        device = f"cuda:{local_rank}"
-    random.seed(cfg["experiment"]["seed"])
-    torch.manual_seed(cfg["experiment"]["seed"])
+    # One process per GPU under ``accelerate launch`` / ``torchrun``: bind this process to cuda:LOCAL_RANK and create the RCCL
+    # process group BEFORE any GPU work -- for the native loop and for HF Trainer alike (accelerate's PartialState adopts an
+    # already-initialised process group instead of creating its own, and DDP then runs on it).  A no-op for a single process.
+    rank, local_rank, world = init_distributed()
+    device = f"cuda:{local_rank}" if world > 1 else "cuda"
+    seed = cfg["experiment"]["seed"]
+    random.seed(seed)
+    torch.manual_seed(seed)
     model, tokenizer, synth = build_components(cfg, device=device)
     ds = LakhDataset(LakhDatasetConfig(**cfg["shared"], **cfg["TrainDatasetConfig"]), tokenizer, synth)
+    dump = os.environ.get("ADT_DUMP_PARAMS")                  # test hook: every rank's final parameters
     if native:
         tr = run_native_training(model.to(device), ds, cfg)
-        if os.environ.get("ADT_DUMP_PARAMS"):                 # test hook: every rank's final flat parameters (tests/test_training_loop_gpu.py)
+        if dump:
             torch.cuda.synchronize()
-            torch.save({"pflat": tr.pflat.detach().cpu(), "steps": tr.step_no, "world": tr.world},
-                       os.path.join(os.environ["ADT_DUMP_PARAMS"], f"params_rank{tr.rank}.pt"))
+            torch.save({"pflat": tr.pflat.detach().cpu(), "steps": tr.step_no, "world": tr.world}, os.path.join(dump, f"params_rank{tr.rank}.pt"))
         return tr
+    # HF Trainer + DDP (the reference's own launch, README.md:53-57): ranks draw different dropout masks, as nn.Dropout does under DDP
+    model.seed_dropout(seed, rank)
     trainer = ADTTrainer(model=model, args=create_training_arguments(cfg), train_dataset=ds, data_collator=ds.collate)
     trainer.train(resume_from_checkpoint=cfg["checkpoint"].get("resume_from_checkpoint"))
     trainer.save_model()
+    if dump:
+        torch.cuda.synchronize()
+        flat = torch.cat([p.detach().reshape(-1).float().cpu() for _, p in model.named_parameters()])
+        torch.save({"pflat": flat, "steps": trainer.state.global_step, "world": world}, os.path.join(dump, f"params_rank{rank}.pt"))
     return trainer
 
 
