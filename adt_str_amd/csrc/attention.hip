@@ -170,20 +170,26 @@ __device__ __forceinline__ void frags_from_global(const unsigned short* __restri
     f[s] = *reinterpret_cast<bf16x8*>(&v);
   }
 }
-// transposed accumulator [d][x] (4 blocks of 32 d) -> bf16 rows out[x][d]; lane owns x = lane&31
+// transposed accumulator [d][x] (4 blocks of 32 d) -> bf16 rows out[x][d]; lane owns x = lane&31.
+// A row is split across the half-waves (lane x: columns 8k .. 8k+3, lane x + 32: columns 8k+4 .. 8k+7 of column group k), so the
+// natural store is 16 x 8 bytes per lane, and that tail is bound by the number of store instructions, not by bytes.  One
+// v_permlane32_swap per dword and pair of groups (k, k + 1) hands the upper half's group k to the lower lanes and the lower half's
+// group k + 1 to the upper lanes: 8 x 16-byte stores of the same bytes to the same addresses (cdna_hip_programming.md T21).
 __device__ __forceinline__ void store_transposed(const f32x16 (&acc)[4], float mul, unsigned short* __restrict__ base, long row_stride,
                                                  int row, int n_rows, int lane) {
-  if (row >= n_rows) return;
+  if (row >= n_rows) return;                           // lanes x and x + 32 own the same row: they leave together
   const int h = lane >> 5;
-  unsigned short* p = base + static_cast<long>(row) * row_stride;
+  unsigned short* p = base + static_cast<long>(row) * row_stride + 8 * h;
 #pragma unroll
   for (int db = 0; db < 4; ++db)
 #pragma unroll
-    for (int g = 0; g < 4; ++g) {
-      uint2 v;
-      v.x = pack2(acc[db][4 * g + 0] * mul, acc[db][4 * g + 1] * mul);
-      v.y = pack2(acc[db][4 * g + 2] * mul, acc[db][4 * g + 3] * mul);
-      *reinterpret_cast<uint2*>(p + 32 * db + 8 * g + 4 * h) = v;
+    for (int g = 0; g < 4; g += 2) {
+      unsigned ax = pack2(acc[db][4 * g + 0] * mul, acc[db][4 * g + 1] * mul), ay = pack2(acc[db][4 * g + 2] * mul, acc[db][4 * g + 3] * mul);
+      unsigned bx = pack2(acc[db][4 * g + 4] * mul, acc[db][4 * g + 5] * mul), by = pack2(acc[db][4 * g + 6] * mul, acc[db][4 * g + 7] * mul);
+      const auto rx = __builtin_amdgcn_permlane32_swap(ax, bx, false, false);
+      const auto ry = __builtin_amdgcn_permlane32_swap(ay, by, false, false);
+      // lower lanes: [own k | upper's k] = columns 8k .. 8k+7; upper lanes: [lower's k+1 | own k+1] = columns 8k+8 .. 8k+15
+      *reinterpret_cast<uint4*>(p + 32 * db + 8 * g) = make_uint4(rx[0], ry[0], rx[1], ry[1]);
     }
 }
 
@@ -933,6 +939,318 @@ __global__ __launch_bounds__(kDkv2Threads) void attn_bwd_dkv2_kernel(AttnArgs a)
   }
 }
 
+// =============================================================================== backward: dK, dV, eight symmetric waves, staggered
+// Third generation.  The producer / consumer kernel above is bound by its S-wave's serial chain (16 MFMAs -> softmax / dS arithmetic
+// -> hand-over: ~1900 cycles per 32 x 32 block for 1024 cycles of MFMA on the SIMD).  Here every wave does the whole block in its
+// own registers -- S = Q K^T and dP = dO V^T (16 MFMAs), the arithmetic, dV^T += dO^T P and dK^T += Q^T dS (16 MFMAs) -- so nothing
+// crosses LDS between roles.  What makes it fit 256 registers (two waves per SIMD) is that only the accumulators live in
+// registers (dK^T, dV^T: 128; S, dP: 32): K and V of the workgroup's 128 keys are LDS images (32 KiB each) read as MFMA operands,
+// the Q / dO / K / V fragments go through a two-deep ring of k-step units, the per-query statistics and the transposed Q / dO
+// fragments arrive in halves.
+//   * 8 waves = 4 key groups x 2: waves w and w + 4 own the SAME 32 keys and split the query blocks (the 64-query tile's first /
+//     second 32 rows); their partial dK / dV are added through LDS once, after the loop (fixed order: bitwise reproducible).
+//   * The two waves of a SIMD run the same program, so left alone they would want the matrix pipe together and the vector pipe
+//     together.  Waves 4-7 therefore run ONE PHASE behind (MI355X_MICROARCH.md, "two waves that run the same program": stagger
+//     by wave number >= 4): in iteration t they first finish block t - 1 (arithmetic, dV / dK MFMAs; S and dP were left in their
+//     accumulators across the barrier) and then run the S / dP chain of block t, while waves 0-3 go chain -> arithmetic -> MFMAs
+//     inside the iteration.  So the second half of a tile is read in two consecutive iterations: half-tiles are staged separately,
+//     two slots for the first halves, three for the second (80 KiB instead of three whole tiles).
+//   * Dropout: the two lanes of an even / odd key pair share every hash (dropout.h pairs keys), so each computes 8 of the block's
+//     16, both halves are compared against the threshold, and the per-element keep masks are assembled from the compare results
+//     with scalar mask arithmetic (shift by one lane) -- 8 hashes per lane and block instead of 16, no cross-lane data movement.
+constexpr int kDkv3Threads = 512;
+constexpr int kDkv3Img = 128 * 256;                           // K (and V) rows of the workgroup's 128 keys
+constexpr int kDkv3Half = 2 * 32 * 256;                       // one half-tile slot: 32 Q rows | 32 dO rows
+constexpr int kDkv3H0 = 2 * kDkv3Img, kDkv3H1 = kDkv3H0 + 2 * kDkv3Half, kDkv3Stats = kDkv3H1 + 3 * kDkv3Half;
+constexpr int kDkv3Lds = kDkv3Stats + 3 * 512;                // 148,992 B: K | V | 2 first-half slots | 3 second-half slots | 3 x (-lse2[64], -delta[64])
+
+template <bool kDrop, bool kStagger>
+__global__ __launch_bounds__(kDkv3Threads) void attn_bwd_dkv3_kernel(AttnArgs a) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  const int tid = threadIdx.x, lane = tid & 63, r = lane & 31, h = lane >> 5;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int pair = wave & 3, half = wave >> 2;
+  const bool skew = kStagger && half == 1;                        // wave-uniform
+  const TileXY tc = tile_coords((a.Sk + 127) / 128);
+  const int b = tc.y / a.H, head = tc.y % a.H;
+  const int key0 = tc.x * 128;
+  const int ki = key0 + pair * 32 + r;
+  const unsigned short* qb = a.q + static_cast<long>(b) * a.Sq * a.ldq + head * kDh;
+  const unsigned short* dob = a.dout + static_cast<long>(b) * a.Sq * a.ldo + head * kDh;
+  const unsigned short* kb_ = a.k + static_cast<long>(b) * a.Sk * a.ldk + head * kDh;
+  const unsigned short* vb = a.v + static_cast<long>(b) * a.Sk * a.ldv + head * kDh;
+  const float* lse_b = a.lse + (static_cast<long>(b) * a.H + head) * a.Sq;
+  const float* dl_b = a.delta + (static_cast<long>(b) * a.H + head) * a.Sq;
+  const int klen = a.key_len ? a.key_len[b] : a.Sk;
+  const float sl2 = a.scale * kLog2e;
+  const bool key_mask = a.causal || key0 + 128 > klen || key0 + 128 > a.Sk;
+  const int n_tiles = (a.Sq + kRowsPerTile - 1) / kRowsPerTile;
+  const unsigned smem_base = lds_off(smem);
+  // slot of (tile t, half): byte offset from smem
+  auto slot = [&](int t, int hf) { return hf ? kDkv3H1 + (t % 3) * kDkv3Half : kDkv3H0 + (t & 1) * kDkv3Half; };
+
+  // ---- staging (source addresses as a wave-uniform base + a 32-bit per-lane element offset: the saddr form of the load).
+  // K and V images once: 32 row groups of 4 rows each, 4 + 4 per wave; a Q / dO tile per iteration: 16 + 16 groups, 2 + 2 per wave.
+  const int lrow = lane >> 4, lchunk = lane & 15;
+  const int ldq_i = static_cast<int>(a.ldq), ldo_i = static_cast<int>(a.ldo), ldk_i = static_cast<int>(a.ldk), ldv_i = static_cast<int>(a.ldv);
+  auto issue_tile = [&](int t) {
+    const int row0 = t * kRowsPerTile;
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const int g = 2 * wave + i, row = 4 * g + lrow;              // g 0..7: first half, 8..15: second half (wave-uniform)
+      const int chunk = lchunk ^ (((row & 3) << 2) | ((row >> 2) & 3));
+      int gr = row0 + row;
+      gr = gr < a.Sq ? gr : a.Sq - 1;                              // rows past the end repeat the last valid row (their P is masked to 0)
+      const unsigned oq = static_cast<unsigned>(gr * ldq_i + chunk * 8), od = static_cast<unsigned>(gr * ldo_i + chunk * 8);
+      unsigned char* dst = smem + slot(t, g >> 3) + (g & 7) * 1024;
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(qb + oq), (__attribute__((address_space(3))) void*)dst, 16, 0, 0);
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(dob + od),
+                                       (__attribute__((address_space(3))) void*)(dst + 32 * 256), 16, 0, 0);
+    }
+  };
+  float rs = 0.f;
+  auto load_stats = [&](int t) {                                   // wave 0: lse, wave 1: delta of tile t's 64 queries (raw)
+    const int qq = t * kRowsPerTile + lane;
+    rs = 0.f;
+    if (wave == 0 && qq < a.Sq) rs = lse_b[qq];
+    if (wave == 1 && qq < a.Sq) rs = dl_b[qq];
+  };
+  auto store_stats = [&](int t) {                                  // both enter the arithmetic negated (fma-ready)
+    if (wave < 2) reinterpret_cast<float*>(smem + kDkv3Stats + (t % 3) * 512)[wave * 64 + lane] = wave == 0 ? -rs * kLog2e : -rs;
+  };
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int g = 4 * wave + i, row = 4 * g + lrow;
+    const int chunk = lchunk ^ (((row & 3) << 2) | ((row >> 2) & 3));
+    int gr = key0 + row;
+    gr = gr < a.Sk ? gr : a.Sk - 1;                                // keys past the end: masked in the arithmetic, their rows never stored
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(kb_ + static_cast<unsigned>(gr * ldk_i + chunk * 8)),
+                                     (__attribute__((address_space(3))) void*)(smem + g * 1024), 16, 0, 0);
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(vb + static_cast<unsigned>(gr * ldv_i + chunk * 8)),
+                                     (__attribute__((address_space(3))) void*)(smem + kDkv3Img + g * 1024), 16, 0, 0);
+  }
+  load_stats(0);
+  issue_tile(0);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  store_stats(0);
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  asm volatile("s_barrier" ::: "memory");
+
+  f32x16 dk[4], dv[4], st, dp;
+#pragma unroll
+  for (int db = 0; db < 4; ++db)
+#pragma unroll
+    for (int i = 0; i < 16; ++i) { dk[db][i] = 0.f; dv[db][i] = 0.f; }
+#pragma unroll
+  for (int i = 0; i < 16; ++i) { st[i] = 0.f; dp[i] = 0.f; }
+
+  // All LDS reads of the loop are inline asm with hand-placed lgkmcnt waits: a compiler-generated LDS access would be ordered behind
+  // the tile DMA in flight with a vmcnt(0).  Addresses are re-derived from two lane constants by XOR (the swizzle is an XOR of
+  // address bits 4..7, so the k-step / d-block enters as `^ 32 s` / `^ 64 db`): nothing per-lane but those two stays in registers.
+  // row-fragment address: chunk (2s + h) of row r = (256 r + 16 (h ^ x)) ^ 32 s,  x = swizzle bits of r
+  const unsigned rowbase = smem_base + static_cast<unsigned>(256 * r + 16 * (h ^ (((r & 3) << 2) | ((r >> 2) & 3))));
+  // transposed-read address of d-block db, rows (4h + i/4) and + 8 of a 16-row group: (trbase ^ 64 db) and ((trbase ^ 64 db) ^ 32) + 2048
+  unsigned trbase;
+  {
+    const int i = lane & 15, g4 = (lane >> 4) & 1, row = 4 * h + (i >> 2);
+    trbase = smem_base + static_cast<unsigned>(8 * (i & 1) + swz(row, 2 * g4 + ((i & 3) >> 1)));
+  }
+  const unsigned sk_pairs = static_cast<unsigned>((a.Sk + 1) >> 1);
+  const unsigned headpair = static_cast<unsigned>((static_cast<uint64_t>(b) * a.H + head) * a.Sq * sk_pairs) + static_cast<unsigned>(ki >> 1);
+  const unsigned key2 = mix32(a.drop.key);
+  const unsigned par = static_cast<unsigned>(lane) & 1u;
+  const unsigned thr16 = a.drop.thr << 16;
+
+  // ---- phase C: S = Q K^T, dP = dO V^T of block (tile t, this wave's 32 rows); operands through a ring of two k-step units
+  auto chain = [&](int t) {
+    const unsigned tq_a = rowbase + static_cast<unsigned>(slot(t, half));
+    const unsigned krow = rowbase + static_cast<unsigned>(pair * 32 * 256);
+    bf16x8 fq[2], fd[2], fk[2], fv[2];
+#define ADT_UNIT(U, S)                                                                                                              \
+    asm volatile("ds_read_b128 %0, %4\n\tds_read_b128 %1, %5\n\tds_read_b128 %2, %4 offset:8192\n\tds_read_b128 %3, %5 offset:32768"  \
+                 : "=&v"(fq[U]), "=&v"(fk[U]), "=&v"(fd[U]), "=&v"(fv[U])                                                           \
+                 : "v"(tq_a ^ static_cast<unsigned>(32 * (S))), "v"(krow ^ static_cast<unsigned>(32 * (S))) : "memory")
+    ADT_UNIT(0, 0); ADT_UNIT(1, 1);
+#pragma unroll
+    for (int i = 0; i < 16; ++i) { st[i] = 0.f; dp[i] = 0.f; }
+#pragma unroll
+    for (int s = 0; s < 8; ++s) {
+      if (s < 7) asm volatile("s_waitcnt lgkmcnt(4)" ::: "memory");
+      else asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      __builtin_amdgcn_sched_barrier(0);
+      st = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fq[s & 1], fk[s & 1], st, 0, 0, 0);
+      dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fd[s & 1], fv[s & 1], dp, 0, 0, 0);
+      __builtin_amdgcn_sched_barrier(0);
+      if (s + 2 < 8) {
+        if (s & 1) ADT_UNIT(1, s + 2);
+        else ADT_UNIT(0, s + 2);
+      }
+    }
+#undef ADT_UNIT
+    __builtin_amdgcn_sched_barrier(0);
+  };
+
+  // ---- phases E + D of block (tile t): softmax / dropout / dS arithmetic on st, dp (in halves of 8 elements = one k-step of the
+  // second products each, so that at most 16 statistics are live), then dV^T += dO^T P, dK^T += Q^T dS
+  auto finish = [&](int t) {
+    const unsigned st_a = smem_base + static_cast<unsigned>(kDkv3Stats + (t % 3) * 512 + (half * 32 + 4 * h) * 4);
+    const unsigned trb = trbase + static_cast<unsigned>(slot(t, half));
+    f32x4 la[2], da[2], lb[2], db_[2];
+    asm volatile("ds_read_b128 %0, %1" : "=v"(la[0]) : "v"(st_a) : "memory");
+    asm volatile("ds_read_b128 %0, %1 offset:256" : "=v"(da[0]) : "v"(st_a) : "memory");
+    asm volatile("ds_read_b128 %0, %1 offset:32" : "=v"(la[1]) : "v"(st_a) : "memory");
+    asm volatile("ds_read_b128 %0, %1 offset:288" : "=v"(da[1]) : "v"(st_a) : "memory");
+    // keep masks (one 64-bit lane mask per accumulator register) while the statistics are in flight
+    uint64_t km[16];
+    if (kDrop) {
+      const uint64_t even = 0x5555555555555555ull, odd = 0xaaaaaaaaaaaaaaaaull;
+      const unsigned vbq = headpair + static_cast<unsigned>(t * kRowsPerTile + half * 32 + 16 * static_cast<int>(par) + 4 * h) * sk_pairs;
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        const unsigned hh = mix32((vbq + static_cast<unsigned>((j & 3) + 8 * (j >> 2)) * sk_pairs) ^ key2);
+        const uint64_t c_lo = __builtin_amdgcn_ballot_w64((hh << 16) >= thr16);       // decision of the pair's even key
+        const uint64_t c_hi = __builtin_amdgcn_ballot_w64(hh >= thr16);               // ... of its odd key
+        // even lanes hashed query rows 0..15 of the block, odd lanes rows 16..31: element j comes from the even lanes, j + 8 from the odd
+        km[j] = (c_lo & even) | ((c_hi & even) << 1);
+        km[j + 8] = (c_hi & odd) | ((c_lo & odd) >> 1);
+      }
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    const bool need_mask = key_mask || (t + 1) * kRowsPerTile > a.Sq;     // block-uniform
+    unsigned hp[8], hs[8];
+    auto arith = [&](int m, const f32x2 nl, const f32x2 nd) {
+      f32x2 pv;
+      if (need_mask) {
+#pragma unroll
+        for (int e = 0; e < 2; ++e) {
+          const int i = 2 * m + e;
+          const int qi = t * kRowsPerTile + half * 32 + acc_row(i, h);
+          const float tt = fmaf(st[i], sl2, mask_add(a, qi, ki, klen) * kLog2e) + nl[e];
+          pv[e] = __builtin_amdgcn_exp2f((qi < a.Sq && ki < a.Sk) ? tt : kNegBig);
+        }
+      } else {
+        const f32x2 sv = {st[2 * m], st[2 * m + 1]};
+        const f32x2 arg = sv * sl2 + nl;
+        pv = f32x2{__builtin_amdgcn_exp2f(arg[0]), __builtin_amdgcn_exp2f(arg[1])};
+      }
+      const f32x2 dpv = {dp[2 * m], dp[2 * m + 1]};
+      f32x2 pd = pv, ds;
+      if (kDrop) {
+        f32x2 ks;
+        asm("v_cndmask_b32_e64 %0, 0, %1, %2" : "=v"(ks[0]) : "v"(a.drop.inv_keep), "s"(km[2 * m]));
+        asm("v_cndmask_b32_e64 %0, 0, %1, %2" : "=v"(ks[1]) : "v"(a.drop.inv_keep), "s"(km[2 * m + 1]));
+        pd = pv * ks;
+        ds = pv * (dpv * ks + nd);
+      } else {
+        ds = pv * (dpv + nd);
+      }
+      hp[m] = pack2(pd[0], pd[1]);
+      hs[m] = pack2(ds[0], ds[1]);
+    };
+#define ADT_TR2(F, DB, IMM)                                                                                    \
+    asm volatile("ds_read_b64_tr_b16 %0, %2 offset:%4\n\tds_read_b64_tr_b16 %1, %3 offset:%5"                  \
+                 : "=&v"((F).lo), "=&v"((F).hi) : "v"(trb ^ static_cast<unsigned>(64 * (DB))), "v"((trb ^ static_cast<unsigned>(64 * (DB))) ^ 32u), "i"(IMM), "i"((IMM) + 2048) : "memory")
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_sched_barrier(0);
+    asm volatile("ds_read_b128 %0, %1 offset:64" : "=v"(lb[0]) : "v"(st_a) : "memory");
+    asm volatile("ds_read_b128 %0, %1 offset:320" : "=v"(db_[0]) : "v"(st_a) : "memory");
+    asm volatile("ds_read_b128 %0, %1 offset:96" : "=v"(lb[1]) : "v"(st_a) : "memory");
+    asm volatile("ds_read_b128 %0, %1 offset:352" : "=v"(db_[1]) : "v"(st_a) : "memory");
+#pragma unroll
+    for (int m = 0; m < 4; ++m)
+      arith(m, f32x2{la[m >> 1][2 * (m & 1)], la[m >> 1][2 * (m & 1) + 1]}, f32x2{da[m >> 1][2 * (m & 1)], da[m >> 1][2 * (m & 1) + 1]});
+    __builtin_amdgcn_sched_barrier(0);
+    TrFrag dot[4], qt[4];
+#pragma unroll
+    for (int db = 0; db < 4; ++db) {
+      ADT_TR2(dot[db], db, 32 * 256);
+      ADT_TR2(qt[db], db, 0);
+    }
+    asm volatile("s_waitcnt lgkmcnt(15)" ::: "memory");           // 4 + 16 reads queued, in order: the four statistics reads are back
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int m = 4; m < 8; ++m)
+      arith(m, f32x2{lb[(m - 4) >> 1][2 * (m & 1)], lb[(m - 4) >> 1][2 * (m & 1) + 1]}, f32x2{db_[(m - 4) >> 1][2 * (m & 1)], db_[(m - 4) >> 1][2 * (m & 1) + 1]});
+    union { unsigned u[4]; bf16x8 v; } pf0, pf1, dsf0, dsf1;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) { pf0.u[e] = hp[e]; pf1.u[e] = hp[4 + e]; dsf0.u[e] = hs[e]; dsf1.u[e] = hs[4 + e]; }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int db = 0; db < 4; ++db) {                    // the registers of k-step 0's fragments take k-step 1's as soon as their MFMA has issued
+      dv[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(tr_get(dot[db]), pf0.v, dv[db], 0, 0, 0);
+      dk[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(tr_get(qt[db]), dsf0.v, dk[db], 0, 0, 0);
+      __builtin_amdgcn_sched_barrier(0);
+      ADT_TR2(dot[db], db, 32 * 256 + 16 * 256);
+      ADT_TR2(qt[db], db, 16 * 256);
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int db = 0; db < 4; ++db) {
+      dv[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(tr_get(dot[db]), pf1.v, dv[db], 0, 0, 0);
+      dk[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(tr_get(qt[db]), dsf1.v, dk[db], 0, 0, 0);
+    }
+#undef ADT_TR2
+    __builtin_amdgcn_sched_barrier(0);
+  };
+
+  // ---- main loop: n_tiles + 1 iterations with one barrier each.  Tile t + 1 is requested at the start of iteration t (its first-half
+  // slot held tile t - 1's, last read in iteration t - 1; its second-half slot tile t - 2's, last read by waves 4-7 in iteration
+  // t - 1 as well) and waited for at its end.  One loop per role so that each has a single path.
+  auto end_iter = [&](int it, bool more) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    if (more) store_stats(it + 1);
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    asm volatile("s_barrier" ::: "memory");
+  };
+  if (!skew) {
+    for (int it = 0; it <= n_tiles; ++it) {
+      const bool more = it + 1 < n_tiles;
+      if (more) { load_stats(it + 1); issue_tile(it + 1); }
+      if (it < n_tiles) { chain(it); finish(it); }
+      end_iter(it, more);
+    }
+  } else {
+    for (int it = 0; it <= n_tiles; ++it) {
+      const bool more = it + 1 < n_tiles;
+      if (more) { load_stats(it + 1); issue_tile(it + 1); }
+      if (it >= 1) finish(it - 1);
+      if (it < n_tiles) chain(it);
+      end_iter(it, more);
+    }
+  }
+
+  // ---- the two waves of a key group add their partial sums (waves 4-7 hand theirs over through LDS, dK then dV), waves 0-3 store
+  float* xch = reinterpret_cast<float*>(smem) + pair * (4 * 16 * 64);         // 16 KiB per key group; every image and tile is dead by now
+#pragma unroll
+  for (int which = 0; which < 2; ++which) {
+    f32x16 (&acc)[4] = which == 0 ? dk : dv;
+    if (half == 1) {
+#pragma unroll
+      for (int db = 0; db < 4; ++db)
+#pragma unroll
+        for (int g = 0; g < 4; ++g)
+          *reinterpret_cast<f32x4*>(xch + ((db * 4 + g) * 64 + lane) * 4) = f32x4{acc[db][4 * g], acc[db][4 * g + 1], acc[db][4 * g + 2], acc[db][4 * g + 3]};
+    }
+    __syncthreads();
+    if (half == 0) {
+#pragma unroll
+      for (int db = 0; db < 4; ++db)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+          const f32x4 o = *reinterpret_cast<const f32x4*>(xch + ((db * 4 + g) * 64 + lane) * 4);
+          acc[db][4 * g] += o[0]; acc[db][4 * g + 1] += o[1]; acc[db][4 * g + 2] += o[2]; acc[db][4 * g + 3] += o[3];
+        }
+    }
+    __syncthreads();
+  }
+  if (half == 0) {
+    store_transposed(dk, a.scale, a.dk + static_cast<long>(b) * a.Sk * a.ldk + head * kDh, a.ldk, ki, a.Sk, lane);
+    store_transposed(dv, 1.0f, a.dv + static_cast<long>(b) * a.Sk * a.ldv + head * kDh, a.ldv, ki, a.Sk, lane);
+  }
+}
+
 static int check_desc(const adt_attn_desc* d, const char* who) {
   if (!d) return set_error(ADT_EINVAL, "attention: null descriptor");
   if (d->head_dim != kDh) return set_error(ADT_ESHAPE, "attention: head_dim must be 128");
@@ -969,6 +1287,10 @@ static int set_lds_once() {      // raise the dynamic-LDS limit of the three ker
   ADT_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(attn_bwd_dkv_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, ldkv));
   ADT_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(attn_bwd_dkv2_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, kDkv2Lds));
   ADT_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(attn_bwd_dkv2_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, kDkv2Lds));
+  ADT_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(attn_bwd_dkv3_kernel<false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, kDkv3Lds));
+  ADT_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(attn_bwd_dkv3_kernel<true, true>), hipFuncAttributeMaxDynamicSharedMemorySize, kDkv3Lds));
+  ADT_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(attn_bwd_dkv3_kernel<false, false>), hipFuncAttributeMaxDynamicSharedMemorySize, kDkv3Lds));
+  ADT_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(attn_bwd_dkv3_kernel<true, false>), hipFuncAttributeMaxDynamicSharedMemorySize, kDkv3Lds));
   done_for = dev;
   return ADT_OK;
 }
@@ -1024,16 +1346,24 @@ extern "C" int adt_attn_bwd(const adt_attn_desc* d, const void* q, const void* k
   const int lds_dq = 4 * kAttnTileBytes, lds_dkv = 2 * (2 * kAttnTileBytes + 512);
   if (int rc = set_lds_once()) return rc;
   const dim3 gq(static_cast<unsigned>((d->q_len + 127) / 128) * d->batch * d->heads), gk(static_cast<unsigned>((d->k_len + 127) / 128) * d->batch * d->heads);
-  static const int dkv_env = [] { const char* v = getenv("ADT_ATTN_DKV"); return v ? atoi(v) : 2; }();   // 1: single-wave kernel (A/B arm)
-  const int dkv_variant = want_cs ? 2 : dkv_env;             // the column sums live in the producer / consumer kernel only
+  // dK / dV kernel: 2 = producer / consumer wave pairs (default), 3 = eight symmetric staggered waves, 4 = the same without the
+  // stagger, 1 = single-wave kernel; ADT_ATTN_DKV selects an A/B arm (read on every call: the tests switch it).  Measured on
+  // MI355X (tools/exp_attn_dkv.py, encoder shape, backward pair): 2: 0.917 / 1.030 ms without / with dropout, 3: 0.878 / 1.065,
+  // 4: 0.897 / 1.019 -- the symmetric kernel wins without dropout and loses with it (its hashes sit on every wave's own chain).
+  const char* dkv_env = getenv("ADT_ATTN_DKV");
+  const int dkv_variant = dkv_env ? atoi(dkv_env) : 2;
   if (a.drop.on()) {
     hipLaunchKernelGGL(attn_bwd_dq_kernel<true>, gq, dim3(kAttnThreads), lds_dq, st, a);
     if (dkv_variant == 1) hipLaunchKernelGGL(attn_bwd_dkv_kernel<true>, gk, dim3(kAttnThreads), lds_dkv, st, a);
-    else hipLaunchKernelGGL(attn_bwd_dkv2_kernel<true>, gk, dim3(kDkv2Threads), kDkv2Lds, st, a);
+    else if (dkv_variant == 2) hipLaunchKernelGGL(attn_bwd_dkv2_kernel<true>, gk, dim3(kDkv2Threads), kDkv2Lds, st, a);
+    else if (dkv_variant == 4) hipLaunchKernelGGL((attn_bwd_dkv3_kernel<true, false>), gk, dim3(kDkv3Threads), kDkv3Lds, st, a);
+    else hipLaunchKernelGGL((attn_bwd_dkv3_kernel<true, true>), gk, dim3(kDkv3Threads), kDkv3Lds, st, a);
   } else {
     hipLaunchKernelGGL(attn_bwd_dq_kernel<false>, gq, dim3(kAttnThreads), lds_dq, st, a);
     if (dkv_variant == 1) hipLaunchKernelGGL(attn_bwd_dkv_kernel<false>, gk, dim3(kAttnThreads), lds_dkv, st, a);
-    else hipLaunchKernelGGL(attn_bwd_dkv2_kernel<false>, gk, dim3(kDkv2Threads), kDkv2Lds, st, a);
+    else if (dkv_variant == 2) hipLaunchKernelGGL(attn_bwd_dkv2_kernel<false>, gk, dim3(kDkv2Threads), kDkv2Lds, st, a);
+    else if (dkv_variant == 4) hipLaunchKernelGGL((attn_bwd_dkv3_kernel<false, false>), gk, dim3(kDkv3Threads), kDkv3Lds, st, a);
+    else hipLaunchKernelGGL((attn_bwd_dkv3_kernel<false, true>), gk, dim3(kDkv3Threads), kDkv3Lds, st, a);
   }
   if (want_cs) {
     // dQ: partial sums out of the dQ kernel's epilogue.  dK: every row of dS sums to zero (softmax), so the column sums of

@@ -111,6 +111,7 @@ def init_distributed(backend: Optional[str] = None):
         return 0, 0, 1
     if os.environ.get("ADT_SHARE_GPU") == "1":           # debug / one-GPU test boxes only: every rank on GPU 0, gloo transport
         local, backend = 0, backend or "gloo"
+        os.environ["LOCAL_RANK"] = "0"                   # accelerate / DDP take device_ids from it: cuda:1 does not exist on such a box
     if not dist.is_initialized():
         if torch.cuda.is_available():
             torch.cuda.set_device(local)

@@ -22,7 +22,7 @@ def test_config4_end_to_end_scaled_down(tmp_path):
     assert np.isfinite(out["final_loss"]) and out["embeds_per_s"] > 0 and out["train_clips_per_s"] > 0
     assert out["resume"]["bitwise_identical"] and out["resume"]["steps"] == out["steps"]
     w = tmp_path / "w"
-    assert (w / "outputs" / "model.safetensors").exists() and (w / "oneshot@16000.npz").exists()
+    assert (w / "outputs" / "e2e" / "model.safetensors").exists() and (w / "oneshot@16000.npz").exists()
     aug = w / "refs_clap_augmented"
     assert all((aug / str(p) / "gold").is_dir() for p in range(35, 61))
     n_copied = sum(len(files) for d, _, files in os.walk(aug) if os.path.basename(d) != "gold")

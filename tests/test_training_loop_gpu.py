@@ -128,7 +128,10 @@ def _torchrun_train(cfg_path, dump_dir, *extra, env_extra=None):
     r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1",
                         "--master-port", str(_free_port()), os.path.join(ROOT, "train.py"), cfg_path, *extra],
                        capture_output=True, text=True, env=env, timeout=900)
-    assert r.returncode == 0, (r.stdout[-1500:], r.stderr[-3000:])
+    if r.returncode != 0:                                  # pytest abbreviates long assertion messages: show the ranks' own output
+        print(r.stdout[-3000:])
+        print(r.stderr[-12000:])
+    assert r.returncode == 0, "torchrun train.py failed (output above)"
     return [torch.load(os.path.join(dump_dir, f"params_rank{i}.pt")) for i in range(2)]
 
 

@@ -96,6 +96,7 @@ def create_training_arguments(cfg: dict) -> "TrainingArguments":
               dataloader_pin_memory=False,    # ... and it is already device memory (pinning a CUDA tensor raises)
               remove_unused_columns=False, report_to=[], save_total_limit=ck["max_checkpoints"],
               ddp_broadcast_buffers=False,     # PE tables / window / filterbank are constants (the reference re-broadcasts them each forward)
+              ddp_find_unused_parameters=False,  # every parameter receives a gradient from _ADTLossFn.backward: no graph traversal per step
               save_strategy="steps" if lg.get("save_every_n_steps") else "epoch")
     if lg.get("save_every_n_steps"):
         kw["save_steps"] = lg["save_every_n_steps"]
