@@ -26,6 +26,40 @@ F32, BF16 = torch.float32, torch.bfloat16
 WINDOW = 8
 
 
+ROWBLOCK_CHANNELS = (96, 192)        # stages whose layers run on the fused row-block kernels (csrc/htsat_fused.hip)
+
+
+def _frags_rows(w: torch.Tensor) -> torch.Tensor:
+    """W [N, K] (N % 32 == 0, K % 16 == 0) -> bf16 [N/32, K/16, 512]: per output tile n and k-step s the 1 KiB MFMA A fragment, lane
+    (r, h) = W[32n + r][16s + 8h + j] at position (32h + r) * 8 + j (include/adt_hip.h, K15)."""
+    N, K = w.shape
+    return w.to(BF16).view(N // 32, 32, K // 16, 2, 8).permute(0, 2, 3, 1, 4).reshape(N // 32, K // 16, 512).contiguous()
+
+
+def pack_rowblock_weights(mode: int, w1: torch.Tensor, w2: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """The weight stream ``adt_htsat_rowblock`` consumes, one fragment after the other (1-D bf16).  ``mode`` 0 / 1: ``w1`` [N, C]; ``mode`` 2:
+    ``w1`` = fc1 [4C, C], ``w2`` = fc2 [C, 4C]: per 32-unit hidden tile n the fragments of fc1, then for k-step s2 = 0, 1 and channel tile
+    ct those of fc2 with the hidden units of a k-step in accumulator order 8 (j>>2) + 4h + (j&3)."""
+    if mode != 2:
+        return _frags_rows(w1).reshape(-1)
+    C = w1.shape[1]
+    NT, CT = w1.shape[0] // 32, C // 32
+    f1 = _frags_rows(w1)                                                            # [NT, C/16, 512]
+    f2 = w2.to(BF16).view(CT, 32, NT, 2, 2, 2, 4).permute(2, 3, 0, 5, 1, 4, 6).reshape(NT, 2 * CT, 512)   # [n, (s2, ct), (h, r, jhi, jlo)]
+    return torch.cat([f1, f2], dim=1).reshape(-1).contiguous()
+
+
+def rowblock(mode: int, x: torch.Tensor, wpk: torch.Tensor, n_tiles: int, bias1: torch.Tensor, *, a16: Optional[torch.Tensor] = None,
+             ln=None, eps: float = 1e-5, bias2: Optional[torch.Tensor] = None, out16: Optional[torch.Tensor] = None) -> None:
+    """One fused half-layer on x [M, C] fp32 (see ``adt_htsat_rowblock``)."""
+    M, C = x.shape
+    assert x.dtype == F32 and x.is_contiguous() and wpk.dtype == BF16
+    _ffi.call("adt_htsat_rowblock", mode, _ffi.dptr(x), M, C, _ffi.dptr(a16) if a16 is not None else None,
+              a16.stride(0) if a16 is not None else 0, _ffi.dptr(ln[0]) if ln else None, _ffi.dptr(ln[1]) if ln else None, eps,
+              _ffi.dptr(wpk), n_tiles, _ffi.dptr(bias1), _ffi.dptr(bias2) if bias2 is not None else None,
+              _ffi.dptr(out16) if out16 is not None else None, out16.stride(0) if out16 is not None else 0, _ffi.current_stream())
+
+
 def _shift_mask(R: int, shift: int) -> torch.Tensor:
     """[nW, 64, 64] additive 0 / -100 mask of a shifted-window layer (ClapAudioLayer.get_attn_mask)."""
     idx = torch.arange(R)
@@ -83,6 +117,11 @@ class HtsatEncoder:
                     ln2=(g(q + "layernorm_after.weight"), g(q + "layernorm_after.bias")),
                     w1=b16(g(q + "intermediate.dense.weight")), b1=g(q + "intermediate.dense.bias"),
                     w2=b16(g(q + "output.dense.weight")), b2=g(q + "output.dense.bias")))
+                if C in ROWBLOCK_CHANNELS:                 # the same weights as the fragment streams of the fused kernels
+                    L = layers[-1]
+                    L["qkv_pk"] = pack_rowblock_weights(0, L["wqkv"].float()).to(self.dev)
+                    L["wo_pk"] = pack_rowblock_weights(1, L["wo"].float()).to(self.dev)
+                    L["mlp_pk"] = pack_rowblock_weights(2, L["w1"].float(), L["w2"].float()).to(self.dev)
             merge = None
             if s < len(self.depths) - 1:
                 d = f"{p}layers.{s}.downsample."
@@ -149,9 +188,21 @@ class HtsatEncoder:
             else:
                 loc = img[b].unsqueeze(0).expand(3, side, side).contiguous()
             self._fusion_tokens(img[b], loc, x[b * n_tok:(b + 1) * n_tok], st)
+        import os
+        fused = os.environ.get("ADT_HTSAT_FUSED", "1") != "0"
         for S in self.stages:
             C, nh, R = S["C"], S["nh"], S["R"]
             for L in S["layers"]:
+                if fused and "mlp_pk" in L:
+                    # bandwidth-bound stages: three launches per layer, the residual stream is read and written once per half
+                    qkv = torch.empty((x.shape[0], 3 * C), dtype=BF16, device=self.dev)
+                    rowblock(0, x, L["qkv_pk"], 3 * C // 32, L["bqkv"], ln=L["ln1"], eps=self.eps, out16=qkv)
+                    ctx = torch.empty((x.shape[0], C), dtype=BF16, device=self.dev)
+                    _ffi.call("adt_window_attn_fwd", _ffi.dptr(qkv), qkv.stride(0), _ffi.dptr(ctx), C, _ffi.dptr(L["bias"]), L["n_bias"], B, R, C,
+                              nh, L["shift"], 1.0 / math.sqrt(24.0), st)
+                    rowblock(1, x, L["wo_pk"], C // 32, L["bo"], a16=ctx)
+                    rowblock(2, x, L["mlp_pk"], C // 8, L["b1"], ln=L["ln2"], eps=self.eps, bias2=L["b2"])
+                    continue
                 _, xn, _, _ = K.layernorm_fwd(x, *L["ln1"], eps=self.eps, want32=False)
                 qkv = K.gemm(xn, L["wqkv"], bias=L["bqkv"])
                 ctx = torch.empty((x.shape[0], C), dtype=BF16, device=self.dev)

@@ -1346,12 +1346,13 @@ extern "C" int adt_attn_bwd(const adt_attn_desc* d, const void* q, const void* k
   const int lds_dq = 4 * kAttnTileBytes, lds_dkv = 2 * (2 * kAttnTileBytes + 512);
   if (int rc = set_lds_once()) return rc;
   const dim3 gq(static_cast<unsigned>((d->q_len + 127) / 128) * d->batch * d->heads), gk(static_cast<unsigned>((d->k_len + 127) / 128) * d->batch * d->heads);
-  // dK / dV kernel: 2 = producer / consumer wave pairs (default), 3 = eight symmetric staggered waves, 4 = the same without the
-  // stagger, 1 = single-wave kernel; ADT_ATTN_DKV selects an A/B arm (read on every call: the tests switch it).  Measured on
-  // MI355X (tools/exp_attn_dkv.py, encoder shape, backward pair): 2: 0.917 / 1.030 ms without / with dropout, 3: 0.878 / 1.065,
-  // 4: 0.897 / 1.019 -- the symmetric kernel wins without dropout and loses with it (its hashes sit on every wave's own chain).
+  // dK / dV kernel: 4 = eight symmetric waves (default), 3 = the same with waves 4-7 staggered by one phase, 2 = producer / consumer
+  // wave pairs, 1 = single-wave kernel; ADT_ATTN_DKV selects an A/B arm (read on every call: the tests switch it).  Measured on
+  // MI355X in one run (tools/exp_attn_dkv.py, backward pair incl. the dQ kernel, without / with dropout): encoder shape 2: 0.897 /
+  // 1.048 ms, 3: 0.898 / 1.046, 4: 0.884 / 0.990; cross-attention 2: 0.216 / 0.230, 3: 0.209 / 0.234, 4: 0.198 / 0.217.  The stagger
+  // pays without dropout only: with it the staggered build spills seven registers inside the loop.
   const char* dkv_env = getenv("ADT_ATTN_DKV");
-  const int dkv_variant = dkv_env ? atoi(dkv_env) : 2;
+  const int dkv_variant = dkv_env ? atoi(dkv_env) : 4;
   if (a.drop.on()) {
     hipLaunchKernelGGL(attn_bwd_dq_kernel<true>, gq, dim3(kAttnThreads), lds_dq, st, a);
     if (dkv_variant == 1) hipLaunchKernelGGL(attn_bwd_dkv_kernel<true>, gk, dim3(kAttnThreads), lds_dkv, st, a);

@@ -1,0 +1,353 @@
+// htsat_fused.hip -- K15: fused row-block kernels for the HBM-bound stages of the CLAP HTSAT audio encoder (gfx950).
+//
+// Stands behind the two halves of transformers' ClapAudioLayer.forward as the reference reaches it through
+// ClapWrapper._get_audio_features (modules/clap_encoder.py:45-49 -> modeling_clap.py ClapAudioLayer: layernorm_before -> q/k/v ->
+// window attention -> attention.output.dense -> + shortcut;  layernorm_after -> intermediate.dense -> GELU -> output.dense -> +).
+// In the first two stages (C = 96 / 192 channels, 4096 / 1024 tokens per clip) these layers are bandwidth problems: at 512 clips
+// the residual stream of stage 0 alone is 805 MB, and run as separate LayerNorm / GEMM launches a layer moves ~14 GB.  Here a
+// wave owns 32 token rows from the first load to the last store:
+//
+//   mode LN_GEMM   (q/k/v):      x fp32 -> LayerNorm -> bf16 operand in registers -> W[3C, C] -> + bias -> bf16 qkv
+//   mode GEMM_RES  (attn. out):  ctx bf16 -> W[C, C] -> + bias + x -> x            (in place)
+//   mode MLP:                    x fp32 -> LayerNorm -> W1[4C, C] -> + bias, exact GELU -> W2[C, 4C] -> + bias + x -> x   (in place;
+//                                the 4C-wide hidden activation never leaves the registers)
+//
+// MFMA orientation (v_mfma_f32_32x32x16_bf16): the TOKEN is the lane.  A operand = 32 weight rows, B operand = the lane's token row,
+// so the accumulator tile is [32 output units][32 tokens] with a token's outputs in its own lane -- bias / GELU are per-lane
+// arithmetic, and accumulator registers 8s .. 8s+7 ARE the bf16 B operand of k-step s of the next product (the hidden unit order
+// 16s + 8(j>>2) + 4h + (j&3) they come in is baked into the packing of W2).  Activations therefore never touch LDS.
+// Weights are pre-packed on the host into the order the kernel consumes them, one 1 KiB MFMA fragment (64 lanes x 16 bytes) after the
+// other, and streamed global -> LDS by LDS-DMA in chunks through a ring shared by the 8 waves (256 tokens) of a workgroup: one
+// barrier per chunk, chunks two to three ahead in flight.  LDS reads of the loop are inline asm (a compiler-generated LDS access
+// would be ordered behind the DMA in flight with a vmcnt(0)).
+#include <hip/hip_runtime.h>
+
+#include "adt_common.h"
+
+namespace adt {
+
+typedef __attribute__((ext_vector_type(8))) short bf16x8;
+typedef __attribute__((ext_vector_type(16))) float f32x16;
+typedef __attribute__((ext_vector_type(4))) float f32x4;
+#include "gelu.h"
+
+constexpr int kRbThreads = 512;           // 8 waves x 32 tokens
+constexpr int kRbRows = 256;
+enum { kRbLnGemm = 0, kRbGemmRes = 1, kRbMlp = 2 };
+
+struct RbArgs {
+  float* x;                      // [M, C] fp32 residual stream (read; written by GEMM_RES / MLP)
+  const unsigned short* a16;     // GEMM_RES: bf16 input [M, lda]
+  long lda;
+  const float *gamma, *beta;     // LayerNorm (LN_GEMM, MLP)
+  float eps;
+  const unsigned char* wpk;      // packed weight stream, n_chunks * chunk bytes
+  const float* bias1;            // [32 * n_tiles]: qkv bias / out-proj bias / fc1 bias
+  const float* bias2;            // MLP: fc2 bias [C]
+  unsigned short* out16;         // LN_GEMM: bf16 output [M, ldo]
+  long ldo;
+  long M;
+  int n_tiles;                   // 32-unit output tiles of the (first) product
+};
+
+__device__ __forceinline__ unsigned lds_off_f(const void* p) {
+  return static_cast<unsigned>(reinterpret_cast<size_t>((__attribute__((address_space(3))) const void*)p));
+}
+__device__ __forceinline__ unsigned pack2_f(float lo, float hi) {
+  unsigned r;
+  asm("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(r) : "v"(lo), "v"(hi));
+  return r;
+}
+template <int N> __device__ __forceinline__ void wait_vm() { asm volatile("s_waitcnt vmcnt(%0)" :: "n"(N) : "memory"); }
+template <int N> __device__ __forceinline__ void wait_lgkm() { asm volatile("s_waitcnt lgkmcnt(%0)" :: "n"(N) : "memory"); }
+
+template <int C, int MODE, int TPC>
+__global__ __launch_bounds__(kRbThreads) void htsat_rowblock_kernel(RbArgs a) {
+  constexpr int KS = C / 16;                                  // k-steps of the product over the C input channels
+  constexpr int CT = C / 32;                                  // 32-channel tiles of the MLP's second product
+  constexpr int kTileFrags = MODE == kRbMlp ? 2 * KS : KS;    // KiB of packed weights per 32-unit tile
+  constexpr int kChunkKb = TPC * kTileFrags;
+  constexpr int kChunkBytes = kChunkKb * 1024;
+  constexpr int kRing = 4 * kChunkBytes <= 128 * 1024 ? 4 : 3;
+  constexpr int kDepth = kRing - 1;                           // chunks in flight ahead of the one being consumed
+  // LDS-DMA work split: every participating wave issues IPW instructions per chunk (uniform counts keep vmcnt arithmetic uniform;
+  // a wave that issues none passes the counted waits trivially)
+  constexpr int IPW = kChunkKb % 8 == 0 ? kChunkKb / 8 : 3;
+  constexpr int kDmaWaves = kChunkKb / IPW;
+  static_assert(kDmaWaves * IPW == kChunkKb && kDmaWaves <= 8, "chunk size must split evenly over at most 8 waves");
+  static_assert(KS % 6 == 0, "C must be a multiple of 96");
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];   // [ring][chunk] | bias1 [32 * n_tiles] fp32
+  const int tid = threadIdx.x, lane = tid & 63, r = lane & 31, h = lane >> 5;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const long row0 = static_cast<long>(blockIdx.x) * kRbRows + wave * 32;
+  long tok = row0 + r;
+  const bool row_ok = tok < a.M;
+  if (!row_ok) tok = a.M - 1;                                  // clamped loads, predicated stores
+  float* bias_lds = reinterpret_cast<float*>(smem + kRing * kChunkBytes);
+  const int n_chunks = a.n_tiles / TPC;
+
+  auto issue_chunk = [&](int c) {
+    if (wave < kDmaWaves) {
+      const unsigned char* src = a.wpk + static_cast<long>(c) * kChunkBytes + (wave * IPW) * 1024 + lane * 16;
+      unsigned char* dst = smem + (c % kRing) * kChunkBytes + (wave * IPW) * 1024;
+#pragma unroll
+      for (int i = 0; i < IPW; ++i)
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + i * 1024),
+                                         (__attribute__((address_space(3))) void*)(dst + i * 1024), 16, 0, 0);
+    }
+  };
+
+  // ---- prologue: the token row -> bf16 B operands b[s] (lane holds channels 16s + 8h .. + 7 of its token)
+  bf16x8 b[KS];
+  if (MODE == kRbGemmRes) {
+    const unsigned short* ap = a.a16 + tok * a.lda + 8 * h;
+#pragma unroll
+    for (int s = 0; s < KS; ++s) {
+      const uint4 v = *reinterpret_cast<const uint4*>(ap + 16 * s);
+      b[s] = *reinterpret_cast<const bf16x8*>(&v);
+    }
+  } else {
+    const float* xp = a.x + tok * C + 8 * h;
+    float xv[KS][8];
+    float sum = 0.f;
+#pragma unroll
+    for (int s = 0; s < KS; ++s) {
+      const float4 v0 = *reinterpret_cast<const float4*>(xp + 16 * s), v1 = *reinterpret_cast<const float4*>(xp + 16 * s + 4);
+      xv[s][0] = v0.x; xv[s][1] = v0.y; xv[s][2] = v0.z; xv[s][3] = v0.w; xv[s][4] = v1.x; xv[s][5] = v1.y; xv[s][6] = v1.z; xv[s][7] = v1.w;
+#pragma unroll
+      for (int e = 0; e < 8; ++e) sum += xv[s][e];
+    }
+    sum += __shfl_xor(sum, 32);                                // the other half of the row lives in lane ^ 32
+    const float mean = sum * (1.0f / C);
+    float ss = 0.f;
+#pragma unroll
+    for (int s = 0; s < KS; ++s)
+#pragma unroll
+      for (int e = 0; e < 8; ++e) { const float d = xv[s][e] - mean; ss = fmaf(d, d, ss); }
+    ss += __shfl_xor(ss, 32);
+    const float rstd = rsqrtf(ss * (1.0f / C) + a.eps);
+#pragma unroll
+    for (int s = 0; s < KS; ++s) {
+      const float4 g0 = *reinterpret_cast<const float4*>(a.gamma + 16 * s + 8 * h), g1 = *reinterpret_cast<const float4*>(a.gamma + 16 * s + 8 * h + 4);
+      const float4 e0 = *reinterpret_cast<const float4*>(a.beta + 16 * s + 8 * h), e1 = *reinterpret_cast<const float4*>(a.beta + 16 * s + 8 * h + 4);
+      const float ga[8] = {g0.x, g0.y, g0.z, g0.w, g1.x, g1.y, g1.z, g1.w}, be[8] = {e0.x, e0.y, e0.z, e0.w, e1.x, e1.y, e1.z, e1.w};
+      union { unsigned u[4]; bf16x8 v; } pk;
+#pragma unroll
+      for (int e = 0; e < 4; ++e)
+        pk.u[e] = pack2_f(fmaf((xv[s][2 * e] - mean) * rstd, ga[2 * e], be[2 * e]), fmaf((xv[s][2 * e + 1] - mean) * rstd, ga[2 * e + 1], be[2 * e + 1]));
+      b[s] = pk.v;
+    }
+  }
+  // GEMM_RES: the residual in the accumulator layout (channel 32n + 8g + 4h + e of the lane's token), loaded before any DMA is in flight
+  f32x4 res[MODE == kRbGemmRes ? CT * 4 : 1];
+  if (MODE == kRbGemmRes) {
+#pragma unroll
+    for (int n = 0; n < CT; ++n)
+#pragma unroll
+      for (int g = 0; g < 4; ++g) res[n * 4 + g] = *reinterpret_cast<const f32x4*>(a.x + tok * C + 32 * n + 8 * g + 4 * h);
+  }
+  for (int i = tid; i < 32 * a.n_tiles; i += kRbThreads) bias_lds[i] = a.bias1[i];
+  asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+#pragma unroll
+  for (int s = 0; s < KS; ++s) asm volatile("" :: "v"(b[s]));
+  __syncthreads();
+#pragma unroll
+  for (int c = 0; c < kDepth; ++c)
+    if (c < n_chunks) issue_chunk(c);
+
+  f32x16 acc2[MODE == kRbMlp ? CT : 1];
+  if (MODE == kRbMlp) {
+#pragma unroll
+    for (int ct = 0; ct < CT; ++ct)
+#pragma unroll
+      for (int i = 0; i < 16; ++i) acc2[ct][i] = 0.f;
+  }
+  const unsigned ring_base = lds_off_f(smem) + lane * 16;
+  const unsigned bias_base = lds_off_f(bias_lds) + 16 * h;     // + 4 * (32 n + 8 g): four consecutive units 8g + 4h .. + 3
+
+  auto do_chunk = [&](const int c) {
+    // chunk c has landed once at most the DMAs of the chunks behind it remain in flight (in-order counters; the stores of the
+    // previous chunk's epilogue are younger still, so the count only errs on the safe side)
+    const int behind = n_chunks - 1 - c;
+    if (behind >= kDepth - 1) wait_vm<(kDepth - 1) * IPW>();
+    else if (kDepth >= 3 && behind == 1) wait_vm<IPW>();
+    else wait_vm<0>();
+    asm volatile("s_barrier" ::: "memory");
+    if (c + kDepth < n_chunks) issue_chunk(c + kDepth);
+    const unsigned chunk_a = ring_base + static_cast<unsigned>((c % kRing) * kChunkBytes);
+#pragma unroll
+    for (int tl = 0; tl < TPC; ++tl) {
+      const int n = c * TPC + tl;
+      const unsigned ta = chunk_a + static_cast<unsigned>(tl * kTileFrags * 1024);
+      // ---- first product: acc[32 units][32 tokens]
+      f32x16 acc;
+#pragma unroll
+      for (int i = 0; i < 16; ++i) acc[i] = 0.f;
+      f32x4 bv[4];
+#pragma unroll
+      for (int g0 = 0; g0 < KS; g0 += 6) {
+        bf16x8 f[6];
+        asm volatile("ds_read_b128 %0, %6\n\tds_read_b128 %1, %6 offset:1024\n\tds_read_b128 %2, %6 offset:2048\n\t"
+                     "ds_read_b128 %3, %6 offset:3072\n\tds_read_b128 %4, %6 offset:4096\n\tds_read_b128 %5, %6 offset:5120"
+                     : "=&v"(f[0]), "=&v"(f[1]), "=&v"(f[2]), "=&v"(f[3]), "=&v"(f[4]), "=&v"(f[5])
+                     : "v"(ta + static_cast<unsigned>(g0 * 1024)) : "memory");
+        if (g0 + 6 >= KS) {                                    // the bias of the tile's 16 units per lane, queued behind the last fragments
+          const unsigned ba = bias_base + static_cast<unsigned>(n * 128);
+          asm volatile("ds_read_b128 %0, %4\n\tds_read_b128 %1, %4 offset:32\n\tds_read_b128 %2, %4 offset:64\n\tds_read_b128 %3, %4 offset:96"
+                       : "=&v"(bv[0]), "=&v"(bv[1]), "=&v"(bv[2]), "=&v"(bv[3]) : "v"(ba) : "memory");
+        }
+        const bool last = g0 + 6 >= KS;
+#pragma unroll
+        for (int j = 0; j < 6; ++j) {
+          if (last) {
+            if (j == 0) wait_lgkm<9>(); else if (j == 1) wait_lgkm<8>(); else if (j == 2) wait_lgkm<7>();
+            else if (j == 3) wait_lgkm<6>(); else if (j == 4) wait_lgkm<5>(); else wait_lgkm<4>();
+          } else {
+            if (j == 0) wait_lgkm<5>(); else if (j == 1) wait_lgkm<4>(); else if (j == 2) wait_lgkm<3>();
+            else if (j == 3) wait_lgkm<2>(); else if (j == 4) wait_lgkm<1>(); else wait_lgkm<0>();
+          }
+          __builtin_amdgcn_sched_barrier(0);
+          acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f[j], b[g0 + j], acc, 0, 0, 0);
+          __builtin_amdgcn_sched_barrier(0);
+        }
+      }
+      wait_lgkm<0>();
+      __builtin_amdgcn_sched_barrier(0);
+      if (MODE == kRbLnGemm) {
+        // unit 32n + 8g + 4h + e of the lane's token -> bf16, four consecutive columns per group (the two halves of a wave interleave to
+        // whole 16-byte pieces of the row)
+        if (row_ok) {
+          unsigned short* op = a.out16 + tok * a.ldo + 32 * n + 4 * h;
+#pragma unroll
+          for (int g = 0; g < 4; ++g) {
+            uint2 v;
+            v.x = pack2_f(acc[4 * g] + bv[g][0], acc[4 * g + 1] + bv[g][1]);
+            v.y = pack2_f(acc[4 * g + 2] + bv[g][2], acc[4 * g + 3] + bv[g][3]);
+            *reinterpret_cast<uint2*>(op + 8 * g) = v;
+          }
+        }
+      } else if (MODE == kRbGemmRes) {
+        if (row_ok) {
+          float* op = a.x + tok * C + 32 * n + 4 * h;
+#pragma unroll
+          for (int g = 0; g < 4; ++g) {
+            const f32x4 rv = res[n * 4 + g];
+            *reinterpret_cast<f32x4*>(op + 8 * g) = f32x4{acc[4 * g] + bv[g][0] + rv[0], acc[4 * g + 1] + bv[g][1] + rv[1],
+                                                          acc[4 * g + 2] + bv[g][2] + rv[2], acc[4 * g + 3] + bv[g][3] + rv[3]};
+          }
+        }
+      } else {
+        // ---- MLP: hidden = gelu(acc + bias) stays in registers as the B operands of the second product (k-step s2 = registers 8 s2 ..)
+        union { unsigned u[4]; bf16x8 v; } hb[2];
+#pragma unroll
+        for (int m = 0; m < 8; ++m) {
+          const f32x2 z = {acc[2 * m] + bv[m >> 1][2 * (m & 1)], acc[2 * m + 1] + bv[m >> 1][2 * (m & 1) + 1]};
+          const f32x2 gv = gelu_erf2(z);
+          hb[m >> 2].u[m & 3] = pack2_f(gv[0], gv[1]);
+        }
+        const unsigned wa = ta + static_cast<unsigned>(KS * 1024);       // [s2][ct] fragments of W2 for this hidden tile
+#pragma unroll
+        for (int g0 = 0; g0 < 2 * CT; g0 += 6) {
+          bf16x8 f[6];
+          asm volatile("ds_read_b128 %0, %6\n\tds_read_b128 %1, %6 offset:1024\n\tds_read_b128 %2, %6 offset:2048\n\t"
+                       "ds_read_b128 %3, %6 offset:3072\n\tds_read_b128 %4, %6 offset:4096\n\tds_read_b128 %5, %6 offset:5120"
+                       : "=&v"(f[0]), "=&v"(f[1]), "=&v"(f[2]), "=&v"(f[3]), "=&v"(f[4]), "=&v"(f[5])
+                       : "v"(wa + static_cast<unsigned>(g0 * 1024)) : "memory");
+#pragma unroll
+          for (int j = 0; j < 6; ++j) {
+            if (j == 0) wait_lgkm<5>(); else if (j == 1) wait_lgkm<4>(); else if (j == 2) wait_lgkm<3>();
+            else if (j == 3) wait_lgkm<2>(); else if (j == 4) wait_lgkm<1>(); else wait_lgkm<0>();
+            __builtin_amdgcn_sched_barrier(0);
+            const int fi = g0 + j, s2 = fi / CT, ct = fi % CT;
+            acc2[ct] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f[j], hb[s2].v, acc2[ct], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+          }
+        }
+      }
+    }
+  };
+  if constexpr (MODE == kRbGemmRes) {                     // CT / TPC chunks, known at compile time: the residual registers are indexed statically
+#pragma unroll
+    for (int c = 0; c < CT / TPC; ++c) do_chunk(c);
+  } else {
+    for (int c = 0; c < n_chunks; ++c) do_chunk(c);
+  }
+  if (MODE == kRbMlp) {
+    // y = acc2 + fc2 bias + x, channel 32 ct + 8g + 4h + e of the lane's token (no DMA is in flight any more: plain loads)
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    if (row_ok) {
+      float* xp = a.x + tok * C + 4 * h;
+#pragma unroll
+      for (int ct = 0; ct < CT; ++ct)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+          const f32x4 xr = *reinterpret_cast<const f32x4*>(xp + 32 * ct + 8 * g);
+          const f32x4 b2 = *reinterpret_cast<const f32x4*>(a.bias2 + 32 * ct + 8 * g + 4 * h);
+          *reinterpret_cast<f32x4*>(xp + 32 * ct + 8 * g) = f32x4{acc2[ct][4 * g] + b2[0] + xr[0], acc2[ct][4 * g + 1] + b2[1] + xr[1],
+                                                                 acc2[ct][4 * g + 2] + b2[2] + xr[2], acc2[ct][4 * g + 3] + b2[3] + xr[3]};
+        }
+    }
+  }
+}
+
+template <int C, int MODE, int TPC>
+static int launch_rb(const RbArgs& a, hipStream_t st) {
+  constexpr int KS = C / 16;
+  constexpr int kTileFrags = MODE == kRbMlp ? 2 * KS : KS;
+  constexpr int kChunkBytes = TPC * kTileFrags * 1024;
+  constexpr int kRing = 4 * kChunkBytes <= 128 * 1024 ? 4 : 3;
+  const int lds = kRing * kChunkBytes + 32 * a.n_tiles * 4;
+  if (a.n_tiles % TPC) return set_error(ADT_ESHAPE, "htsat row-block kernel: tile count is not a multiple of the chunk size");
+  static thread_local int done_for = -1;
+  int dev = 0;
+  ADT_HIP_TRY(hipGetDevice(&dev));
+  if (done_for != dev) {
+    ADT_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(htsat_rowblock_kernel<C, MODE, TPC>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    done_for = dev;
+  }
+  const unsigned grid = static_cast<unsigned>((a.M + kRbRows - 1) / kRbRows);
+  hipLaunchKernelGGL((htsat_rowblock_kernel<C, MODE, TPC>), dim3(grid), dim3(kRbThreads), lds, st, a);
+  ADT_HIP_TRY(hipGetLastError());
+  return ADT_OK;
+}
+
+}  // namespace adt
+
+using namespace adt;
+
+// Tiles per chunk of each (mode, C): chunks of 12-24 KiB.  The host packs the weight stream with the same numbers
+// (adt_htsat_rowblock_chunk_tiles).
+static int chunk_tiles(int mode, int C) {
+  if (C == 96) return mode == kRbMlp ? 2 : 3;       // tiles of 12 / 6 KiB -> 24 / 18 KiB chunks (q/k/v: 9 tiles, out-proj: 3)
+  if (C == 192) return mode == kRbMlp ? 1 : 2;      // tiles of 24 / 12 KiB -> 24 KiB chunks
+  return 0;
+}
+extern "C" int adt_htsat_rowblock_chunk_tiles(int32_t mode, int32_t C) { return chunk_tiles(mode, C); }
+
+extern "C" int adt_htsat_rowblock(int32_t mode, float* x, int64_t M, int32_t C, const void* a16, int64_t lda, const float* ln_gamma,
+                                  const float* ln_beta, float eps, const void* w_packed, int32_t n_tiles, const float* bias1,
+                                  const float* bias2, void* out16, int64_t ldo, void* stream) {
+  if (mode < 0 || mode > 2) return set_error(ADT_EINVAL, "adt_htsat_rowblock: mode must be 0 (LN + GEMM), 1 (GEMM + residual) or 2 (MLP)");
+  if (C != 96 && C != 192) return set_error(ADT_ESHAPE, "adt_htsat_rowblock: built for C = 96 and C = 192");
+  if (M < 0 || n_tiles <= 0 || !x || !w_packed || !bias1) return set_error(ADT_EINVAL, "adt_htsat_rowblock: bad arguments");
+  if (mode != kRbGemmRes && (!ln_gamma || !ln_beta)) return set_error(ADT_EINVAL, "adt_htsat_rowblock: LayerNorm parameters missing");
+  if (mode == kRbGemmRes && (!a16 || lda < C || (lda & 7) || n_tiles != C / 32)) return set_error(ADT_ESHAPE, "adt_htsat_rowblock: bad bf16 input / tile count");
+  if (mode == kRbLnGemm && (!out16 || ldo < 32 * n_tiles || (ldo & 3))) return set_error(ADT_ESHAPE, "adt_htsat_rowblock: bad bf16 output");
+  if (mode == kRbMlp && (!bias2 || n_tiles != C / 8)) return set_error(ADT_ESHAPE, "adt_htsat_rowblock: the MLP has 4C hidden units");
+  if (!aligned16(x) || !aligned16(w_packed) || (a16 && !aligned16(a16)) || (out16 && (reinterpret_cast<uintptr_t>(out16) & 7)))
+    return set_error(ADT_EINVAL, "adt_htsat_rowblock: misaligned pointer");
+  if (M == 0) return ADT_OK;
+  RbArgs a{};
+  a.x = x; a.a16 = static_cast<const unsigned short*>(a16); a.lda = lda; a.gamma = ln_gamma; a.beta = ln_beta; a.eps = eps;
+  a.wpk = static_cast<const unsigned char*>(w_packed); a.bias1 = bias1; a.bias2 = bias2; a.out16 = static_cast<unsigned short*>(out16);
+  a.ldo = ldo; a.M = M; a.n_tiles = n_tiles;
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  if (C == 96) {
+    if (mode == kRbLnGemm) return launch_rb<96, kRbLnGemm, 3>(a, st);
+    if (mode == kRbGemmRes) return launch_rb<96, kRbGemmRes, 3>(a, st);
+    return launch_rb<96, kRbMlp, 2>(a, st);
+  }
+  if (mode == kRbLnGemm) return launch_rb<192, kRbLnGemm, 2>(a, st);
+  if (mode == kRbGemmRes) return launch_rb<192, kRbGemmRes, 2>(a, st);
+  return launch_rb<192, kRbMlp, 1>(a, st);
+}

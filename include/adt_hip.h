@@ -40,7 +40,7 @@ extern "C" {
  * backward entry points regenerate them from the same (p, key).  p == 0 or a null pointer: off. */
 typedef struct adt_dropout { float p; uint32_t key; } adt_dropout;
 
-/* ABI version (8): bumped whenever a signature below changes or entries are added. */
+/* ABI version (9): bumped whenever a signature below changes or entries are added. */
 int adt_version(void);
 
 /* Message of the last failing call on this thread ("" if none). */
@@ -445,6 +445,22 @@ int adt_window_attn_fwd(const void* qkv, int64_t ld_qkv, void* ctx, int64_t ld_c
 int adt_patch_merge_ln(const float* x, int64_t B, int32_t R, int32_t C, const float* gamma, const float* beta, float eps,
                        void* out_bf16, void* stream);
 int adt_mean_tokens(const float* x, int64_t B, int32_t T, int32_t C, float* out32, void* out16, void* stream);
+
+/* K15  fused row-block kernels for the bandwidth-bound Swin stages (C = 96, 192): one launch per half of a
+ * ClapAudioLayer (transformers modeling_clap.py ClapAudioLayer.forward, reached from modules/clap_encoder.py:45-49).
+ * x [M, C] fp32 is the residual stream (tokens in any order: the kernels are row-wise).
+ *   mode 0  LN + GEMM:        out16[M, 32 n_tiles] (bf16, row stride ldo) = LayerNorm(x) W^T + bias1        (layernorm_before + q|k|v)
+ *   mode 1  GEMM + residual:  x += a16[M, C] (bf16, row stride lda) W^T + bias1                             (attention.output.dense)
+ *   mode 2  MLP:              x += gelu(LayerNorm(x) W1^T + bias1) W2^T + bias2, W1 [4C, C], W2 [C, 4C]     (layernorm_after + MLP)
+ * w_packed: the weights as the stream of 1 KiB MFMA fragments the kernel consumes (adt_str_amd/clap_encoder.py:pack_rowblock_weights):
+ *   product over C, output tile n, k-step s:  64 lanes x 8 bf16, lane (r, h) = W[32n + r][16s + 8h + j], j = 0..7;
+ *   modes 0 / 1: tiles n = 0 .. n_tiles-1, k-steps s = 0 .. C/16-1 each;  mode 2: per hidden tile n its C/16 fragments of W1, then
+ *   for s2 = 0, 1 and channel tile ct = 0 .. C/32-1 the fragment lane (r, h) = W2[32ct + r][32n + 16 s2 + 8 (j>>2) + 4h + (j&3)];
+ *   n_tiles must be a multiple of adt_htsat_rowblock_chunk_tiles(mode, C) (the LDS-DMA chunk). */
+int adt_htsat_rowblock_chunk_tiles(int32_t mode, int32_t C);
+int adt_htsat_rowblock(int32_t mode, float* x, int64_t M, int32_t C, const void* a16, int64_t lda, const float* ln_gamma,
+                       const float* ln_beta, float eps, const void* w_packed, int32_t n_tiles, const float* bias1,
+                       const float* bias2, void* out16, int64_t ldo, void* stream);
 int adt_l2_normalize(const float* x, int64_t n_rows, int32_t D, float* out, void* stream);
 
 /* ---------------------------------------------------------------------------

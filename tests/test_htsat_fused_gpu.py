@@ -1,0 +1,73 @@
+"""K15 fused row-block kernels (csrc/htsat_fused.hip) against a plain PyTorch fp32 reference of the same half-layers with the
+same bf16 operand roundings (LayerNorm output, weights, hidden activation rounded to bf16; fp32 accumulation), for both channel
+counts, a row count with a ragged tail, and against the unfused kernel sequence on a whole HTSAT forward."""
+import os
+
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+
+def _bf(t):
+    return t.bfloat16().float()
+
+
+@pytest.mark.parametrize("C", [96, 192])
+def test_rowblock_modes_match_fp32_reference(C):
+    from adt_str_amd.clap_encoder import pack_rowblock_weights, rowblock
+    g = torch.Generator().manual_seed(C)
+    M = 256 * 3 + 40                                                    # three full workgroups + a partial one
+    x = torch.randn((M, C), generator=g).to(DEV) * 1.5 + 0.3
+    gamma, beta = (1 + 0.1 * torch.randn(C, generator=g)).to(DEV), (0.1 * torch.randn(C, generator=g)).to(DEV)
+    xn = _bf(torch.nn.functional.layer_norm(x, (C,), gamma, beta, 1e-5))
+    # mode 0: LayerNorm + q|k|v
+    wqkv = (torch.randn((3 * C, C), generator=g) / C ** 0.5).to(DEV)
+    bqkv = (0.1 * torch.randn(3 * C, generator=g)).to(DEV)
+    qkv = torch.zeros((M, 3 * C), dtype=torch.bfloat16, device=DEV)
+    x0 = x.clone()
+    rowblock(0, x0, pack_rowblock_weights(0, wqkv).to(DEV), 3 * C // 32, bqkv, ln=(gamma, beta), out16=qkv)
+    ref = xn @ _bf(wqkv).T + bqkv
+    assert torch.equal(x0, x)                                           # mode 0 only reads the residual stream
+    assert (qkv.float() - ref).abs().max() <= 8e-3 * ref.abs().max() + 1e-3
+    # mode 1: attention output projection + residual, in place
+    ctx = torch.randn((M, C), generator=g).to(DEV).bfloat16()
+    wo = (torch.randn((C, C), generator=g) / C ** 0.5).to(DEV)
+    bo = (0.1 * torch.randn(C, generator=g)).to(DEV)
+    x1 = x.clone()
+    rowblock(1, x1, pack_rowblock_weights(1, wo).to(DEV), C // 32, bo, a16=ctx)
+    ref = x + ctx.float() @ _bf(wo).T + bo
+    assert (x1 - ref).abs().max() <= 2e-5 * ref.abs().max() + 2e-5
+    # mode 2: LayerNorm + fc1 + exact GELU + fc2 + residual, in place
+    w1 = (torch.randn((4 * C, C), generator=g) / C ** 0.5).to(DEV)
+    b1 = (0.1 * torch.randn(4 * C, generator=g)).to(DEV)
+    w2 = (torch.randn((C, 4 * C), generator=g) / (4 * C) ** 0.5).to(DEV)
+    b2 = (0.1 * torch.randn(C, generator=g)).to(DEV)
+    x2 = x.clone()
+    rowblock(2, x2, pack_rowblock_weights(2, w1, w2).to(DEV), C // 8, b1, ln=(gamma, beta), bias2=b2)
+    hid = _bf(torch.nn.functional.gelu(xn @ _bf(w1).T + b1))
+    ref = x + hid @ _bf(w2).T + b2
+    assert (x2 - ref).abs().max() <= 2e-3 * ref.abs().max() + 2e-3       # hidden values on a bf16 rounding boundary may round the other way
+    assert (x2 - ref).abs().mean() <= 2e-4
+    # bit-repeatable
+    x3 = x.clone()
+    rowblock(2, x3, pack_rowblock_weights(2, w1, w2).to(DEV), C // 8, b1, ln=(gamma, beta), bias2=b2)
+    assert torch.equal(x2, x3)
+
+
+def test_fused_encoder_equals_unfused_kernel_sequence(monkeypatch):
+    """The whole HTSAT forward with the fused stages against the LayerNorm / GEMM / GEMM sequence it replaces (same weights, same
+    clips): the two differ only in where bf16 roundings fall."""
+    import numpy as np
+    from adt_str_amd.clap_encoder import ClapWrapper, random_init_clap_model
+    wrap = ClapWrapper("random-init", DEV, 48000, clap_model=random_init_clap_model(0))
+    rng = np.random.default_rng(0)
+    clips = [torch.from_numpy((rng.standard_normal(int(n)) * 0.2).astype(np.float32)).to(DEV) for n in rng.integers(4800, 96000, 6)]
+    flags = torch.tensor([False, True, False, False, False, False])
+    monkeypatch.setenv("ADT_HTSAT_FUSED", "1")
+    a = wrap.get_audio_features(clips, is_longer=flags)
+    monkeypatch.setenv("ADT_HTSAT_FUSED", "0")
+    b = wrap.get_audio_features(clips, is_longer=flags)
+    cos = torch.nn.functional.cosine_similarity(a, b, dim=-1)
+    assert float(cos.min()) > 0.9995, cos
