@@ -37,16 +37,21 @@ def _frags_rows(w: torch.Tensor) -> torch.Tensor:
 
 
 def pack_rowblock_weights(mode: int, w1: torch.Tensor, w2: Optional[torch.Tensor] = None) -> torch.Tensor:
-    """The weight stream ``adt_htsat_rowblock`` consumes, one fragment after the other (1-D bf16).  ``mode`` 0 / 1: ``w1`` [N, C]; ``mode`` 2:
-    ``w1`` = fc1 [4C, C], ``w2`` = fc2 [C, 4C]: per 32-unit hidden tile n the fragments of fc1, then for k-step s2 = 0, 1 and channel tile
-    ct those of fc2 with the hidden units of a k-step in accumulator order 8 (j>>2) + 4h + (j&3)."""
+    """The weight stream ``adt_htsat_rowblock`` consumes, one fragment after the other (1-D bf16).  ``mode`` 0 / 1: ``w1`` [N, C], tile by
+    tile.  ``mode`` 2 (``w1`` = fc1 [4C, C], ``w2`` = fc2 [C, 4C]): the software-pipelined MLP kernel consumes STEPS k = 0 .. 4C/32 + 1, each
+    the C/16 fragments of fc1(hidden tile k) interleaved with the C/16 fragments (k-step s2 = 0, 1, channel tile ct) of fc2(hidden tile
+    k - 2) -- fragment 2s = fc1, fragment 2(s2 CT + ct) + 1 = fc2, zeros where the tile index is out of range; the hidden units of an
+    fc2 k-step come in accumulator order 8 (j>>2) + 4h + (j&3)."""
     if mode != 2:
         return _frags_rows(w1).reshape(-1)
     C = w1.shape[1]
-    NT, CT = w1.shape[0] // 32, C // 32
-    f1 = _frags_rows(w1)                                                            # [NT, C/16, 512]
+    NT, CT, KS = w1.shape[0] // 32, C // 32, C // 16
+    f1 = _frags_rows(w1)                                                            # [NT, KS, 512]
     f2 = w2.to(BF16).view(CT, 32, NT, 2, 2, 2, 4).permute(2, 3, 0, 5, 1, 4, 6).reshape(NT, 2 * CT, 512)   # [n, (s2, ct), (h, r, jhi, jlo)]
-    return torch.cat([f1, f2], dim=1).reshape(-1).contiguous()
+    steps = torch.zeros((NT + 2, 2 * KS, 512), dtype=BF16, device=w1.device)
+    steps[:NT, 0::2] = f1
+    steps[2:, 1::2] = f2
+    return steps.reshape(-1).contiguous()
 
 
 def rowblock(mode: int, x: torch.Tensor, wpk: torch.Tensor, n_tiles: int, bias1: torch.Tensor, *, a16: Optional[torch.Tensor] = None,

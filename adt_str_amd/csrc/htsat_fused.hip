@@ -22,6 +22,8 @@
 // would be ordered behind the DMA in flight with a vmcnt(0)).
 #include <hip/hip_runtime.h>
 
+#include <type_traits>
+
 #include "adt_common.h"
 
 namespace adt {
@@ -290,6 +292,200 @@ __global__ __launch_bounds__(kRbThreads) void htsat_rowblock_kernel(RbArgs a) {
   }
 }
 
+// ---- MLP, software pipelined.  A 32-unit hidden tile costs 2 C/16 MFMAs and ~150 vector instructions (exact-erf GELU of 16 values per
+// lane), and run phase by phase (product, GELU, product) the two waves of a SIMD want the matrix pipe together and the vector
+// pipe together.  So the three phases of consecutive tiles share a STEP: step k issues the MFMAs of fc1(tile k) and of
+// fc2(tile k - 2), one at a time, with a slice of GELU(tile k - 1) behind each (an MFMA runs 32 cycles; the five or six vector
+// instructions behind it issue meanwhile), fc1 and fc2 MFMAs alternating so that the fc1 accumulation chain never waits for itself.
+// The fc1 bias is the initial value of the accumulator.  The weight stream is packed in exactly this order, one step after the
+// other -- [fc1(k) fragment s, fc2(k-2) fragment (s2, ct)] interleaved, zero fragments where k or k - 2 is out of range -- so the
+// LDS-DMA ring protocol is the one above; fragments go through a ring of six registers refilled as each MFMA issues.
+template <int C, int SPC>                    // SPC: steps per LDS-DMA chunk
+__global__ __launch_bounds__(kRbThreads) void htsat_mlp_kernel(RbArgs a) {
+  constexpr int KS = C / 16, CT = C / 32, NM = 2 * KS;         // MFMAs (= fragments, KiB) per step
+  constexpr int kChunkKb = SPC * NM;
+  constexpr int kChunkBytes = kChunkKb * 1024;
+  constexpr int kRing = 4;
+  constexpr int kDepth = 3;
+  constexpr int IPW = kChunkKb / 8;
+  static_assert(kChunkKb % 8 == 0 && kRing * kChunkBytes <= 128 * 1024, "chunks of 8n KiB, ring within 128 KiB");
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];   // [ring][chunk] | fc1 bias [4C] fp32
+  const int tid = threadIdx.x, lane = tid & 63, r = lane & 31, h = lane >> 5;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  long tok = static_cast<long>(blockIdx.x) * kRbRows + wave * 32 + r;
+  const bool row_ok = tok < a.M;
+  if (!row_ok) tok = a.M - 1;
+  float* bias_lds = reinterpret_cast<float*>(smem + kRing * kChunkBytes);
+  const int n_tiles = a.n_tiles;                               // hidden tiles (4C / 32)
+  const int n_steps = n_tiles + 2;
+  const int n_chunks = n_steps / SPC;
+
+  auto issue_chunk = [&](int c) {
+    const unsigned char* src = a.wpk + static_cast<long>(c) * kChunkBytes + (wave * IPW) * 1024 + lane * 16;
+    unsigned char* dst = smem + (c % kRing) * kChunkBytes + (wave * IPW) * 1024;
+#pragma unroll
+    for (int i = 0; i < IPW; ++i)
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + i * 1024),
+                                       (__attribute__((address_space(3))) void*)(dst + i * 1024), 16, 0, 0);
+  };
+  // the weight stream starts first: its latency hides under the row loads and the LayerNorm
+#pragma unroll
+  for (int c = 0; c < kDepth; ++c)
+    if (c < n_chunks) issue_chunk(c);
+
+  bf16x8 b[KS];
+  {
+    const float* xp = a.x + tok * C + 8 * h;
+    float xv[KS][8];
+    float sum = 0.f;
+#pragma unroll
+    for (int s = 0; s < KS; ++s) {
+      const float4 v0 = *reinterpret_cast<const float4*>(xp + 16 * s), v1 = *reinterpret_cast<const float4*>(xp + 16 * s + 4);
+      xv[s][0] = v0.x; xv[s][1] = v0.y; xv[s][2] = v0.z; xv[s][3] = v0.w; xv[s][4] = v1.x; xv[s][5] = v1.y; xv[s][6] = v1.z; xv[s][7] = v1.w;
+#pragma unroll
+      for (int e = 0; e < 8; ++e) sum += xv[s][e];
+    }
+    sum += __shfl_xor(sum, 32);
+    const float mean = sum * (1.0f / C);
+    float ss = 0.f;
+#pragma unroll
+    for (int s = 0; s < KS; ++s)
+#pragma unroll
+      for (int e = 0; e < 8; ++e) { const float d = xv[s][e] - mean; ss = fmaf(d, d, ss); }
+    ss += __shfl_xor(ss, 32);
+    const float rstd = rsqrtf(ss * (1.0f / C) + a.eps);
+#pragma unroll
+    for (int s = 0; s < KS; ++s) {
+      const float4 g0 = *reinterpret_cast<const float4*>(a.gamma + 16 * s + 8 * h), g1 = *reinterpret_cast<const float4*>(a.gamma + 16 * s + 8 * h + 4);
+      const float4 e0 = *reinterpret_cast<const float4*>(a.beta + 16 * s + 8 * h), e1 = *reinterpret_cast<const float4*>(a.beta + 16 * s + 8 * h + 4);
+      const float ga[8] = {g0.x, g0.y, g0.z, g0.w, g1.x, g1.y, g1.z, g1.w}, be[8] = {e0.x, e0.y, e0.z, e0.w, e1.x, e1.y, e1.z, e1.w};
+      union { unsigned u[4]; bf16x8 v; } pk;
+#pragma unroll
+      for (int e = 0; e < 4; ++e)
+        pk.u[e] = pack2_f(fmaf((xv[s][2 * e] - mean) * rstd, ga[2 * e], be[2 * e]), fmaf((xv[s][2 * e + 1] - mean) * rstd, ga[2 * e + 1], be[2 * e + 1]));
+      b[s] = pk.v;
+    }
+  }
+  // fc1 bias -> LDS.  (Compiler-generated LDS stores: they wait for the DMAs above, which chunk 0 needs anyway.)
+  for (int i = tid; i < 32 * n_tiles; i += kRbThreads) bias_lds[i] = a.bias1[i];
+  asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+#pragma unroll
+  for (int s = 0; s < KS; ++s) asm volatile("" :: "v"(b[s]));
+
+  f32x16 acc2[CT];
+#pragma unroll
+  for (int ct = 0; ct < CT; ++ct)
+#pragma unroll
+    for (int i = 0; i < 16; ++i) acc2[ct][i] = 0.f;
+  f32x16 acc1[2];                                              // [k & 1]: being accumulated by fc1(k); [1 - (k & 1)]: fc1(k - 1), being GELU'd
+  union HB { unsigned u[4]; bf16x8 v; };
+  HB hb[2][2];                                                 // [(k - 1) & 1][s2]: written by GELU(k - 1); [k & 1][s2]: GELU(k - 2), read by fc2(k - 2)
+#pragma unroll
+  for (int i = 0; i < 16; ++i) { acc1[0][i] = 0.f; acc1[1][i] = 0.f; }
+#pragma unroll
+  for (int p = 0; p < 2; ++p)
+#pragma unroll
+    for (int s2 = 0; s2 < 2; ++s2)
+#pragma unroll
+      for (int e = 0; e < 4; ++e) hb[p][s2].u[e] = 0u;
+  const unsigned ring_base = lds_off_f(smem) + lane * 16;
+  const unsigned bias_base = lds_off_f(bias_lds) + 16 * h;
+
+  auto pre_chunk = [&](int c) {                                // chunk c landed everywhere; its predecessor's slot is free again
+    const int behind = n_chunks - 1 - c;
+    if (behind >= 2) wait_vm<2 * IPW>();
+    else if (behind == 1) wait_vm<IPW>();
+    else wait_vm<0>();
+    asm volatile("s_barrier" ::: "memory");
+    if (c + kDepth < n_chunks) issue_chunk(c + kDepth);
+  };
+  auto step = [&](const int k, auto ph_tag) {
+    constexpr int PH = decltype(ph_tag)::value;
+    const unsigned ta = ring_base + static_cast<unsigned>(((k / SPC) % kRing) * kChunkBytes + (k % SPC) * NM * 1024);
+    // fc1(k) starts from its bias (tile index clamped: the out-of-range steps at either end run on zero weights and are never used)
+    int bt = k < n_tiles ? k : n_tiles - 1;
+    const unsigned ba = bias_base + static_cast<unsigned>(bt * 128);
+    f32x4 bq[4];
+    asm volatile("ds_read_b128 %0, %4\n\tds_read_b128 %1, %4 offset:32\n\tds_read_b128 %2, %4 offset:64\n\tds_read_b128 %3, %4 offset:96"
+                 : "=&v"(bq[0]), "=&v"(bq[1]), "=&v"(bq[2]), "=&v"(bq[3]) : "v"(ba) : "memory");
+    bf16x8 f[6];
+    asm volatile("ds_read_b128 %0, %6\n\tds_read_b128 %1, %6 offset:1024\n\tds_read_b128 %2, %6 offset:2048\n\t"
+                 "ds_read_b128 %3, %6 offset:3072\n\tds_read_b128 %4, %6 offset:4096\n\tds_read_b128 %5, %6 offset:5120"
+                 : "=&v"(f[0]), "=&v"(f[1]), "=&v"(f[2]), "=&v"(f[3]), "=&v"(f[4]), "=&v"(f[5]) : "v"(ta) : "memory");
+    wait_lgkm<6>();                                            // the bias (older than the six fragments) is back
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int g = 0; g < 4; ++g)
+#pragma unroll
+      for (int e = 0; e < 4; ++e) acc1[PH][4 * g + e] = bq[g][e];
+#pragma unroll
+    for (int i = 0; i < NM; ++i) {
+      // fragment i is the oldest of the (at most six) reads in flight
+      if (i + 6 <= NM) wait_lgkm<5>();
+      else if (i + 5 == NM) wait_lgkm<4>();
+      else if (i + 4 == NM) wait_lgkm<3>();
+      else if (i + 3 == NM) wait_lgkm<2>();
+      else if (i + 2 == NM) wait_lgkm<1>();
+      else wait_lgkm<0>();
+      __builtin_amdgcn_sched_barrier(0);
+      if ((i & 1) == 0) {
+        acc1[PH] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f[i % 6], b[i >> 1], acc1[PH], 0, 0, 0);
+      } else {
+        const int fi = i >> 1, s2 = fi / CT, ct = fi % CT;
+        acc2[ct] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f[i % 6], hb[PH][s2].v, acc2[ct], 0, 0, 0);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+      if (i + 6 < NM)                                          // the register of fragment i takes fragment i + 6
+        asm volatile("ds_read_b128 %0, %1" : "=v"(f[i % 6]) : "v"(ta + static_cast<unsigned>((i + 6) * 1024)) : "memory");
+      // a slice of GELU(k - 1): pairs ((i * 8) / NM .. ((i + 1) * 8) / NM - 1) of the 8 register pairs
+#pragma unroll
+      for (int m = (i * 8) / NM; m < ((i + 1) * 8) / NM; ++m) {
+        const f32x2 gv = gelu_erf2(f32x2{acc1[1 - PH][2 * m], acc1[1 - PH][2 * m + 1]});
+        hb[1 - PH][m >> 2].u[m & 3] = pack2_f(gv[0], gv[1]);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+    }
+  };
+  for (int k = 0; k < n_steps; k += 2) {                       // n_steps is even (4C / 32 + 2)
+    if (k % SPC == 0) pre_chunk(k / SPC);
+    step(k, std::integral_constant<int, 0>{});
+    if ((k + 1) % SPC == 0) pre_chunk((k + 1) / SPC);
+    step(k + 1, std::integral_constant<int, 1>{});
+  }
+  // y = acc2 + fc2 bias + x, channel 32 ct + 8g + 4h + e of the lane's token (no DMA is in flight any more: plain loads)
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  if (row_ok) {
+    float* xp = a.x + tok * C + 4 * h;
+#pragma unroll
+    for (int ct = 0; ct < CT; ++ct)
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        const f32x4 xr = *reinterpret_cast<const f32x4*>(xp + 32 * ct + 8 * g);
+        const f32x4 b2 = *reinterpret_cast<const f32x4*>(a.bias2 + 32 * ct + 8 * g + 4 * h);
+        *reinterpret_cast<f32x4*>(xp + 32 * ct + 8 * g) = f32x4{acc2[ct][4 * g] + b2[0] + xr[0], acc2[ct][4 * g + 1] + b2[1] + xr[1],
+                                                               acc2[ct][4 * g + 2] + b2[2] + xr[2], acc2[ct][4 * g + 3] + b2[3] + xr[3]};
+      }
+  }
+}
+
+template <int C, int SPC>
+static int launch_mlp(const RbArgs& a, hipStream_t st) {
+  constexpr int kChunkBytes = SPC * 2 * (C / 16) * 1024;
+  const int lds = 4 * kChunkBytes + 32 * a.n_tiles * 4;
+  if ((a.n_tiles + 2) % SPC || (a.n_tiles & 1)) return set_error(ADT_ESHAPE, "htsat MLP kernel: step count must be even and a multiple of the chunk size");
+  static thread_local int done_for = -1;
+  int dev = 0;
+  ADT_HIP_TRY(hipGetDevice(&dev));
+  if (done_for != dev) {
+    ADT_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(htsat_mlp_kernel<C, SPC>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    done_for = dev;
+  }
+  const unsigned grid = static_cast<unsigned>((a.M + kRbRows - 1) / kRbRows);
+  hipLaunchKernelGGL((htsat_mlp_kernel<C, SPC>), dim3(grid), dim3(kRbThreads), lds, st, a);
+  ADT_HIP_TRY(hipGetLastError());
+  return ADT_OK;
+}
+
 template <int C, int MODE, int TPC>
 static int launch_rb(const RbArgs& a, hipStream_t st) {
   constexpr int KS = C / 16;
@@ -345,9 +541,9 @@ extern "C" int adt_htsat_rowblock(int32_t mode, float* x, int64_t M, int32_t C, 
   if (C == 96) {
     if (mode == kRbLnGemm) return launch_rb<96, kRbLnGemm, 3>(a, st);
     if (mode == kRbGemmRes) return launch_rb<96, kRbGemmRes, 3>(a, st);
-    return launch_rb<96, kRbMlp, 2>(a, st);
+    return launch_mlp<96, 2>(a, st);
   }
   if (mode == kRbLnGemm) return launch_rb<192, kRbLnGemm, 2>(a, st);
   if (mode == kRbGemmRes) return launch_rb<192, kRbGemmRes, 2>(a, st);
-  return launch_rb<192, kRbMlp, 1>(a, st);
+  return launch_mlp<192, 1>(a, st);
 }
