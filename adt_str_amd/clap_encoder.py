@@ -42,12 +42,14 @@ def pack_rowblock_weights(mode: int, w1: torch.Tensor, w2: Optional[torch.Tensor
     the C/16 fragments of fc1(hidden tile k) interleaved with the C/16 fragments (k-step s2 = 0, 1, channel tile ct) of fc2(hidden tile
     k - 2) -- fragment 2s = fc1, fragment 2(s2 CT + ct) + 1 = fc2, zeros where the tile index is out of range; the hidden units of an
     fc2 k-step come in accumulator order 8 (j>>2) + 4h + (j&3)."""
-    if mode != 2:
+    if mode not in (2, 3):
         return _frags_rows(w1).reshape(-1)
     C = w1.shape[1]
     NT, CT, KS = w1.shape[0] // 32, C // 32, C // 16
     f1 = _frags_rows(w1)                                                            # [NT, KS, 512]
     f2 = w2.to(BF16).view(CT, 32, NT, 2, 2, 2, 4).permute(2, 3, 0, 5, 1, 4, 6).reshape(NT, 2 * CT, 512)   # [n, (s2, ct), (h, r, jhi, jlo)]
+    if mode == 3:                                       # A/B arm: the MLP phase by phase, per hidden tile [fc1 fragments | fc2 fragments]
+        return torch.cat([f1, f2], dim=1).reshape(-1).contiguous()
     steps = torch.zeros((NT + 2, 2 * KS, 512), dtype=BF16, device=w1.device)
     steps[:NT, 0::2] = f1
     steps[2:, 1::2] = f2
@@ -63,6 +65,15 @@ def rowblock(mode: int, x: torch.Tensor, wpk: torch.Tensor, n_tiles: int, bias1:
               a16.stride(0) if a16 is not None else 0, _ffi.dptr(ln[0]) if ln else None, _ffi.dptr(ln[1]) if ln else None, eps,
               _ffi.dptr(wpk), n_tiles, _ffi.dptr(bias1), _ffi.dptr(bias2) if bias2 is not None else None,
               _ffi.dptr(out16) if out16 is not None else None, out16.stride(0) if out16 is not None else 0, _ffi.current_stream())
+
+
+def window_bias_layout(bias: torch.Tensor) -> torch.Tensor:
+    """[..., 64 (query), 64 (key)] -> the lane-linear order ``adt_window_attn_fwd`` reads: [..., qt 2, kt 2, g 4, h 2, r 32, e 4] with
+    query = 32 qt + r and key = 32 kt + 8 g + 4 h + e (one contiguous KiB per wave-load of a (qt, kt, g) piece)."""
+    lead = bias.shape[:-2]
+    v = bias.reshape(*lead, 2, 32, 2, 4, 2, 4)                       # [..., qt, r, kt, g, h, e]
+    n = len(lead)
+    return v.permute(*range(n), n, n + 2, n + 3, n + 4, n + 1, n + 5).contiguous().reshape(*lead, 64, 64)
 
 
 def _shift_mask(R: int, shift: int) -> torch.Tensor:
@@ -113,8 +124,10 @@ class HtsatEncoder:
                 shift = 0 if (i % 2 == 0 or R <= WINDOW) else WINDOW // 2
                 if shift:
                     bias = (bias.unsqueeze(0) + _shift_mask(R, shift).to(self.dev).unsqueeze(1)).contiguous()   # [nW, nh, 64, 64]
+                n_bias = bias.shape[0] if shift else 1
+                bias = window_bias_layout(bias)
                 layers.append(dict(
-                    shift=shift, bias=bias, n_bias=bias.shape[0] if shift else 1,
+                    shift=shift, bias=bias, n_bias=n_bias,
                     ln1=(g(q + "layernorm_before.weight"), g(q + "layernorm_before.bias")),
                     wqkv=b16(torch.cat([g(a + "query.weight"), g(a + "key.weight"), g(a + "value.weight")], 0)),
                     bqkv=torch.cat([g(a + "query.bias"), g(a + "key.bias"), g(a + "value.bias")], 0).contiguous(),
@@ -127,6 +140,7 @@ class HtsatEncoder:
                     L["qkv_pk"] = pack_rowblock_weights(0, L["wqkv"].float()).to(self.dev)
                     L["wo_pk"] = pack_rowblock_weights(1, L["wo"].float()).to(self.dev)
                     L["mlp_pk"] = pack_rowblock_weights(2, L["w1"].float(), L["w2"].float()).to(self.dev)
+                    L["mlp_pk3"] = pack_rowblock_weights(3, L["w1"].float(), L["w2"].float()).to(self.dev)
             merge = None
             if s < len(self.depths) - 1:
                 d = f"{p}layers.{s}.downsample."
@@ -206,7 +220,10 @@ class HtsatEncoder:
                     _ffi.call("adt_window_attn_fwd", _ffi.dptr(qkv), qkv.stride(0), _ffi.dptr(ctx), C, _ffi.dptr(L["bias"]), L["n_bias"], B, R, C,
                               nh, L["shift"], 1.0 / math.sqrt(24.0), st)
                     rowblock(1, x, L["wo_pk"], C // 32, L["bo"], a16=ctx)
-                    rowblock(2, x, L["mlp_pk"], C // 8, L["b1"], ln=L["ln2"], eps=self.eps, bias2=L["b2"])
+                    if os.environ.get("ADT_HTSAT_MLP") == "3":
+                        rowblock(3, x, L["mlp_pk3"], C // 8, L["b1"], ln=L["ln2"], eps=self.eps, bias2=L["b2"])
+                    else:
+                        rowblock(2, x, L["mlp_pk"], C // 8, L["b1"], ln=L["ln2"], eps=self.eps, bias2=L["b2"])
                     continue
                 _, xn, _, _ = K.layernorm_fwd(x, *L["ln1"], eps=self.eps, want32=False)
                 qkv = K.gemm(xn, L["wqkv"], bias=L["bqkv"])

@@ -271,7 +271,7 @@ __global__ __launch_bounds__(256) void aff_apply_kernel(const float* __restrict_
 struct WinAttnArgs {
   const unsigned short* qkv; long ld;          // [B*R*R, 3C] bf16: q | k | v, head h at columns h*24
   unsigned short* ctx; long ldc;               // [B*R*R, C]
-  const float* bias; int n_bias_windows;       // [n_bias_windows][heads][64][64]: rel-pos bias (+ shift mask per window)
+  const float* bias; int n_bias_windows;       // [n_bias_windows][heads][qt 2][kt 2][g 4][lane 64][4]: rel-pos bias (+ shift mask per window), see adt_hip.h
   int B, R, C, heads, shift; float scale;
 };
 
@@ -330,7 +330,10 @@ __global__ __launch_bounds__(256) void window_attn_kernel(WinAttnArgs a) {
       for (int s = 0; s < 2; ++s) st[kt][qt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf[kt][s], qf[qt][s], st[kt][qt], 0, 0, 0);
     }
   const int wsel = a.n_bias_windows > 1 ? (wy * nw + wx) : 0;
-  const float* bias = a.bias + (static_cast<long>(wsel) * a.heads + head) * 4096;
+  // lane-linear bias: the 16 floats of (query tile qt, key tile kt) that this lane adds to its accumulator are four 16-byte
+  // pieces, each at lane * 16 inside a contiguous KiB -- one coalesced KiB per wave-load (a row-major [64][64] table costs 32
+  // loads of 64 scattered 16-byte pieces per (window, head): the kernel was bound by them)
+  const float* bias = a.bias + (static_cast<long>(wsel) * a.heads + head) * 4096 + lane * 4;
   __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
   __builtin_amdgcn_wave_barrier();
   __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
@@ -343,7 +346,7 @@ __global__ __launch_bounds__(256) void window_attn_kernel(WinAttnArgs a) {
     for (int kt = 0; kt < 2; ++kt)
 #pragma unroll
       for (int g = 0; g < 4; ++g) {
-        const float4 bv = *reinterpret_cast<const float4*>(bias + q * 64 + kt * 32 + 8 * g + 4 * h);
+        const float4 bv = *reinterpret_cast<const float4*>(bias + ((qt * 2 + kt) * 4 + g) * 256);
         const float bb[4] = {bv.x, bv.y, bv.z, bv.w};
 #pragma unroll
         for (int e = 0; e < 4; ++e) {

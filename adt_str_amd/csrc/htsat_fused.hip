@@ -9,7 +9,7 @@
 //
 //   mode LN_GEMM   (q/k/v):      x fp32 -> LayerNorm -> bf16 operand in registers -> W[3C, C] -> + bias -> bf16 qkv
 //   mode GEMM_RES  (attn. out):  ctx bf16 -> W[C, C] -> + bias + x -> x            (in place)
-//   mode MLP:                    x fp32 -> LayerNorm -> W1[4C, C] -> + bias, exact GELU -> W2[C, 4C] -> + bias + x -> x   (in place;
+//   mode MLP:                    x fp32 -> LayerNorm -> W1[4C, C] -> + bias, GELU (erf form, gelu.h) -> W2[C, 4C] -> + bias + x -> x   (in place;
 //                                the 4C-wide hidden activation never leaves the registers)
 //
 // MFMA orientation (v_mfma_f32_32x32x16_bf16): the TOKEN is the lane.  A operand = 32 weight rows, B operand = the lane's token row,
@@ -17,8 +17,8 @@
 // arithmetic, and accumulator registers 8s .. 8s+7 ARE the bf16 B operand of k-step s of the next product (the hidden unit order
 // 16s + 8(j>>2) + 4h + (j&3) they come in is baked into the packing of W2).  Activations therefore never touch LDS.
 // Weights are pre-packed on the host into the order the kernel consumes them, one 1 KiB MFMA fragment (64 lanes x 16 bytes) after the
-// other, and streamed global -> LDS by LDS-DMA in chunks through a ring shared by the 8 waves (256 tokens) of a workgroup: one
-// barrier per chunk, chunks two to three ahead in flight.  LDS reads of the loop are inline asm (a compiler-generated LDS access
+// other, and streamed global -> LDS by LDS-DMA in chunks through a ring shared by the 4 waves (128 tokens) of a workgroup: one
+// barrier per chunk, two chunks ahead in flight; two workgroups share a CU.  LDS reads of the loop are inline asm (a compiler-generated LDS access
 // would be ordered behind the DMA in flight with a vmcnt(0)).
 #include <hip/hip_runtime.h>
 
@@ -33,8 +33,9 @@ typedef __attribute__((ext_vector_type(16))) float f32x16;
 typedef __attribute__((ext_vector_type(4))) float f32x4;
 #include "gelu.h"
 
-constexpr int kRbThreads = 512;           // 8 waves x 32 tokens
-constexpr int kRbRows = 256;
+constexpr int kRbThreads = 256;           // 4 waves x 32 tokens; two workgroups per CU (<= 80 KiB of LDS, <= 256 registers): one loads /
+constexpr int kRbRows = 128;              // stores its rows while the other computes
+constexpr int kRbWaves = kRbThreads / 64;
 enum { kRbLnGemm = 0, kRbGemmRes = 1, kRbMlp = 2 };
 
 struct RbArgs {
@@ -64,19 +65,20 @@ template <int N> __device__ __forceinline__ void wait_vm() { asm volatile("s_wai
 template <int N> __device__ __forceinline__ void wait_lgkm() { asm volatile("s_waitcnt lgkmcnt(%0)" :: "n"(N) : "memory"); }
 
 template <int C, int MODE, int TPC>
-__global__ __launch_bounds__(kRbThreads) void htsat_rowblock_kernel(RbArgs a) {
+__global__ __launch_bounds__(kRbThreads, 2) void htsat_rowblock_kernel(RbArgs a) {
   constexpr int KS = C / 16;                                  // k-steps of the product over the C input channels
   constexpr int CT = C / 32;                                  // 32-channel tiles of the MLP's second product
   constexpr int kTileFrags = MODE == kRbMlp ? 2 * KS : KS;    // KiB of packed weights per 32-unit tile
   constexpr int kChunkKb = TPC * kTileFrags;
   constexpr int kChunkBytes = kChunkKb * 1024;
-  constexpr int kRing = 4 * kChunkBytes <= 128 * 1024 ? 4 : 3;
+  constexpr int kRing = 3;
   constexpr int kDepth = kRing - 1;                           // chunks in flight ahead of the one being consumed
   // LDS-DMA work split: every participating wave issues IPW instructions per chunk (uniform counts keep vmcnt arithmetic uniform;
   // a wave that issues none passes the counted waits trivially)
-  constexpr int IPW = kChunkKb % 8 == 0 ? kChunkKb / 8 : 3;
+  constexpr int IPW = kChunkKb % kRbWaves == 0 ? kChunkKb / kRbWaves : 6;
   constexpr int kDmaWaves = kChunkKb / IPW;
-  static_assert(kDmaWaves * IPW == kChunkKb && kDmaWaves <= 8, "chunk size must split evenly over at most 8 waves");
+  static_assert(kDmaWaves * IPW == kChunkKb && kDmaWaves <= kRbWaves, "chunk size must split evenly over the waves");
+  static_assert(kRing * kChunkBytes <= 76 * 1024, "two workgroups per CU");
   static_assert(KS % 6 == 0, "C must be a multiple of 96");
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];   // [ring][chunk] | bias1 [32 * n_tiles] fp32
   const int tid = threadIdx.x, lane = tid & 63, r = lane & 31, h = lane >> 5;
@@ -98,6 +100,11 @@ __global__ __launch_bounds__(kRbThreads) void htsat_rowblock_kernel(RbArgs a) {
                                          (__attribute__((address_space(3))) void*)(dst + i * 1024), 16, 0, 0);
     }
   };
+
+  // the weight stream starts first: its latency hides under the row loads and the LayerNorm
+#pragma unroll
+  for (int c = 0; c < kDepth; ++c)
+    if (c < n_chunks) issue_chunk(c);
 
   // ---- prologue: the token row -> bf16 B operands b[s] (lane holds channels 16s + 8h .. + 7 of its token)
   bf16x8 b[KS];
@@ -148,14 +155,10 @@ __global__ __launch_bounds__(kRbThreads) void htsat_rowblock_kernel(RbArgs a) {
 #pragma unroll
       for (int g = 0; g < 4; ++g) res[n * 4 + g] = *reinterpret_cast<const f32x4*>(a.x + tok * C + 32 * n + 8 * g + 4 * h);
   }
-  for (int i = tid; i < 32 * a.n_tiles; i += kRbThreads) bias_lds[i] = a.bias1[i];
+  for (int i = tid; i < 32 * a.n_tiles; i += kRbThreads) bias_lds[i] = a.bias1[i];       // (read after the loop's first barrier)
   asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
 #pragma unroll
   for (int s = 0; s < KS; ++s) asm volatile("" :: "v"(b[s]));
-  __syncthreads();
-#pragma unroll
-  for (int c = 0; c < kDepth; ++c)
-    if (c < n_chunks) issue_chunk(c);
 
   f32x16 acc2[MODE == kRbMlp ? CT : 1];
   if (MODE == kRbMlp) {
@@ -244,7 +247,7 @@ __global__ __launch_bounds__(kRbThreads) void htsat_rowblock_kernel(RbArgs a) {
 #pragma unroll
         for (int m = 0; m < 8; ++m) {
           const f32x2 z = {acc[2 * m] + bv[m >> 1][2 * (m & 1)], acc[2 * m + 1] + bv[m >> 1][2 * (m & 1) + 1]};
-          const f32x2 gv = gelu_erf2(z);
+          const f32x2 gv = gelu_bf16_2(z);
           hb[m >> 2].u[m & 3] = pack2_f(gv[0], gv[1]);
         }
         const unsigned wa = ta + static_cast<unsigned>(KS * 1024);       // [s2][ct] fragments of W2 for this hidden tile
@@ -297,18 +300,18 @@ __global__ __launch_bounds__(kRbThreads) void htsat_rowblock_kernel(RbArgs a) {
 // pipe together.  So the three phases of consecutive tiles share a STEP: step k issues the MFMAs of fc1(tile k) and of
 // fc2(tile k - 2), one at a time, with a slice of GELU(tile k - 1) behind each (an MFMA runs 32 cycles; the five or six vector
 // instructions behind it issue meanwhile), fc1 and fc2 MFMAs alternating so that the fc1 accumulation chain never waits for itself.
-// The fc1 bias is the initial value of the accumulator.  The weight stream is packed in exactly this order, one step after the
+// The weight stream is packed in exactly this order, one step after the
 // other -- [fc1(k) fragment s, fc2(k-2) fragment (s2, ct)] interleaved, zero fragments where k or k - 2 is out of range -- so the
 // LDS-DMA ring protocol is the one above; fragments go through a ring of six registers refilled as each MFMA issues.
 template <int C, int SPC>                    // SPC: steps per LDS-DMA chunk
-__global__ __launch_bounds__(kRbThreads) void htsat_mlp_kernel(RbArgs a) {
+__global__ __launch_bounds__(kRbThreads, 2) void htsat_mlp_kernel(RbArgs a) {
   constexpr int KS = C / 16, CT = C / 32, NM = 2 * KS;         // MFMAs (= fragments, KiB) per step
   constexpr int kChunkKb = SPC * NM;
   constexpr int kChunkBytes = kChunkKb * 1024;
-  constexpr int kRing = 4;
-  constexpr int kDepth = 3;
-  constexpr int IPW = kChunkKb / 8;
-  static_assert(kChunkKb % 8 == 0 && kRing * kChunkBytes <= 128 * 1024, "chunks of 8n KiB, ring within 128 KiB");
+  constexpr int kRing = 3;
+  constexpr int kDepth = 2;
+  constexpr int IPW = kChunkKb / kRbWaves;
+  static_assert(kChunkKb % kRbWaves == 0 && kRing * kChunkBytes <= 76 * 1024, "chunks split over the waves; two workgroups per CU");
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];   // [ring][chunk] | fc1 bias [4C] fp32
   const int tid = threadIdx.x, lane = tid & 63, r = lane & 31, h = lane >> 5;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -392,9 +395,7 @@ __global__ __launch_bounds__(kRbThreads) void htsat_mlp_kernel(RbArgs a) {
   const unsigned bias_base = lds_off_f(bias_lds) + 16 * h;
 
   auto pre_chunk = [&](int c) {                                // chunk c landed everywhere; its predecessor's slot is free again
-    const int behind = n_chunks - 1 - c;
-    if (behind >= 2) wait_vm<2 * IPW>();
-    else if (behind == 1) wait_vm<IPW>();
+    if (c + 1 < n_chunks) wait_vm<IPW>();
     else wait_vm<0>();
     asm volatile("s_barrier" ::: "memory");
     if (c + kDepth < n_chunks) issue_chunk(c + kDepth);
@@ -402,8 +403,8 @@ __global__ __launch_bounds__(kRbThreads) void htsat_mlp_kernel(RbArgs a) {
   auto step = [&](const int k, auto ph_tag) {
     constexpr int PH = decltype(ph_tag)::value;
     const unsigned ta = ring_base + static_cast<unsigned>(((k / SPC) % kRing) * kChunkBytes + (k % SPC) * NM * 1024);
-    // fc1(k) starts from its bias (tile index clamped: the out-of-range steps at either end run on zero weights and are never used)
-    int bt = k < n_tiles ? k : n_tiles - 1;
+    // bias of tile k - 1, whose GELU runs in this step (index clamped: the out-of-range steps at either end are never used)
+    const int bt = k < 1 ? 0 : (k - 1 < n_tiles ? k - 1 : n_tiles - 1);
     const unsigned ba = bias_base + static_cast<unsigned>(bt * 128);
     f32x4 bq[4];
     asm volatile("ds_read_b128 %0, %4\n\tds_read_b128 %1, %4 offset:32\n\tds_read_b128 %2, %4 offset:64\n\tds_read_b128 %3, %4 offset:96"
@@ -412,12 +413,14 @@ __global__ __launch_bounds__(kRbThreads) void htsat_mlp_kernel(RbArgs a) {
     asm volatile("ds_read_b128 %0, %6\n\tds_read_b128 %1, %6 offset:1024\n\tds_read_b128 %2, %6 offset:2048\n\t"
                  "ds_read_b128 %3, %6 offset:3072\n\tds_read_b128 %4, %6 offset:4096\n\tds_read_b128 %5, %6 offset:5120"
                  : "=&v"(f[0]), "=&v"(f[1]), "=&v"(f[2]), "=&v"(f[3]), "=&v"(f[4]), "=&v"(f[5]) : "v"(ta) : "memory");
-    wait_lgkm<6>();                                            // the bias (older than the six fragments) is back
-    __builtin_amdgcn_sched_barrier(0);
+    const f32x16 zero16 = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    wait_lgkm<6>();                                            // the bias (older than the six fragments) is back: it goes into fc1(k - 1)
+    __builtin_amdgcn_sched_barrier(0);                         // right away, so that its 16 registers are free during the loop
 #pragma unroll
     for (int g = 0; g < 4; ++g)
 #pragma unroll
-      for (int e = 0; e < 4; ++e) acc1[PH][4 * g + e] = bq[g][e];
+      for (int e = 0; e < 4; ++e) acc1[1 - PH][4 * g + e] += bq[g][e];
+    __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
     for (int i = 0; i < NM; ++i) {
       // fragment i is the oldest of the (at most six) reads in flight
@@ -429,7 +432,7 @@ __global__ __launch_bounds__(kRbThreads) void htsat_mlp_kernel(RbArgs a) {
       else wait_lgkm<0>();
       __builtin_amdgcn_sched_barrier(0);
       if ((i & 1) == 0) {
-        acc1[PH] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f[i % 6], b[i >> 1], acc1[PH], 0, 0, 0);
+        acc1[PH] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f[i % 6], b[i >> 1], i == 0 ? zero16 : acc1[PH], 0, 0, 0);
       } else {
         const int fi = i >> 1, s2 = fi / CT, ct = fi % CT;
         acc2[ct] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f[i % 6], hb[PH][s2].v, acc2[ct], 0, 0, 0);
@@ -440,7 +443,7 @@ __global__ __launch_bounds__(kRbThreads) void htsat_mlp_kernel(RbArgs a) {
       // a slice of GELU(k - 1): pairs ((i * 8) / NM .. ((i + 1) * 8) / NM - 1) of the 8 register pairs
 #pragma unroll
       for (int m = (i * 8) / NM; m < ((i + 1) * 8) / NM; ++m) {
-        const f32x2 gv = gelu_erf2(f32x2{acc1[1 - PH][2 * m], acc1[1 - PH][2 * m + 1]});
+        const f32x2 gv = gelu_bf16_2(f32x2{acc1[1 - PH][2 * m], acc1[1 - PH][2 * m + 1]});
         hb[1 - PH][m >> 2].u[m & 3] = pack2_f(gv[0], gv[1]);
       }
       __builtin_amdgcn_sched_barrier(0);
@@ -471,7 +474,7 @@ __global__ __launch_bounds__(kRbThreads) void htsat_mlp_kernel(RbArgs a) {
 template <int C, int SPC>
 static int launch_mlp(const RbArgs& a, hipStream_t st) {
   constexpr int kChunkBytes = SPC * 2 * (C / 16) * 1024;
-  const int lds = 4 * kChunkBytes + 32 * a.n_tiles * 4;
+  const int lds = 3 * kChunkBytes + 32 * a.n_tiles * 4;
   if ((a.n_tiles + 2) % SPC || (a.n_tiles & 1)) return set_error(ADT_ESHAPE, "htsat MLP kernel: step count must be even and a multiple of the chunk size");
   static thread_local int done_for = -1;
   int dev = 0;
@@ -491,7 +494,7 @@ static int launch_rb(const RbArgs& a, hipStream_t st) {
   constexpr int KS = C / 16;
   constexpr int kTileFrags = MODE == kRbMlp ? 2 * KS : KS;
   constexpr int kChunkBytes = TPC * kTileFrags * 1024;
-  constexpr int kRing = 4 * kChunkBytes <= 128 * 1024 ? 4 : 3;
+  constexpr int kRing = 3;
   const int lds = kRing * kChunkBytes + 32 * a.n_tiles * 4;
   if (a.n_tiles % TPC) return set_error(ADT_ESHAPE, "htsat row-block kernel: tile count is not a multiple of the chunk size");
   static thread_local int done_for = -1;
@@ -523,13 +526,14 @@ extern "C" int adt_htsat_rowblock_chunk_tiles(int32_t mode, int32_t C) { return 
 extern "C" int adt_htsat_rowblock(int32_t mode, float* x, int64_t M, int32_t C, const void* a16, int64_t lda, const float* ln_gamma,
                                   const float* ln_beta, float eps, const void* w_packed, int32_t n_tiles, const float* bias1,
                                   const float* bias2, void* out16, int64_t ldo, void* stream) {
-  if (mode < 0 || mode > 2) return set_error(ADT_EINVAL, "adt_htsat_rowblock: mode must be 0 (LN + GEMM), 1 (GEMM + residual) or 2 (MLP)");
+  // mode 3: the MLP phase by phase (no software pipeline; its own weight order) -- the A/B arm of mode 2
+  if (mode < 0 || mode > 3) return set_error(ADT_EINVAL, "adt_htsat_rowblock: mode must be 0 (LN + GEMM), 1 (GEMM + residual) or 2 (MLP)");
   if (C != 96 && C != 192) return set_error(ADT_ESHAPE, "adt_htsat_rowblock: built for C = 96 and C = 192");
   if (M < 0 || n_tiles <= 0 || !x || !w_packed || !bias1) return set_error(ADT_EINVAL, "adt_htsat_rowblock: bad arguments");
   if (mode != kRbGemmRes && (!ln_gamma || !ln_beta)) return set_error(ADT_EINVAL, "adt_htsat_rowblock: LayerNorm parameters missing");
   if (mode == kRbGemmRes && (!a16 || lda < C || (lda & 7) || n_tiles != C / 32)) return set_error(ADT_ESHAPE, "adt_htsat_rowblock: bad bf16 input / tile count");
   if (mode == kRbLnGemm && (!out16 || ldo < 32 * n_tiles || (ldo & 3))) return set_error(ADT_ESHAPE, "adt_htsat_rowblock: bad bf16 output");
-  if (mode == kRbMlp && (!bias2 || n_tiles != C / 8)) return set_error(ADT_ESHAPE, "adt_htsat_rowblock: the MLP has 4C hidden units");
+  if (mode >= kRbMlp && (!bias2 || n_tiles != C / 8)) return set_error(ADT_ESHAPE, "adt_htsat_rowblock: the MLP has 4C hidden units");
   if (!aligned16(x) || !aligned16(w_packed) || (a16 && !aligned16(a16)) || (out16 && (reinterpret_cast<uintptr_t>(out16) & 7)))
     return set_error(ADT_EINVAL, "adt_htsat_rowblock: misaligned pointer");
   if (M == 0) return ADT_OK;
@@ -541,9 +545,11 @@ extern "C" int adt_htsat_rowblock(int32_t mode, float* x, int64_t M, int32_t C, 
   if (C == 96) {
     if (mode == kRbLnGemm) return launch_rb<96, kRbLnGemm, 3>(a, st);
     if (mode == kRbGemmRes) return launch_rb<96, kRbGemmRes, 3>(a, st);
+    if (mode == 3) return launch_rb<96, kRbMlp, 2>(a, st);
     return launch_mlp<96, 2>(a, st);
   }
   if (mode == kRbLnGemm) return launch_rb<192, kRbLnGemm, 2>(a, st);
   if (mode == kRbGemmRes) return launch_rb<192, kRbGemmRes, 2>(a, st);
+  if (mode == 3) return launch_rb<192, kRbMlp, 1>(a, st);
   return launch_mlp<192, 1>(a, st);
 }

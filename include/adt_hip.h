@@ -416,8 +416,10 @@ int adt_clap_logmel_db_f32(const float* waves, const int64_t* offsets, int64_t n
  *   adt_htsat_patch_embed  4x4/stride-4 conv, 1 -> C channels (w [C,16], bias [C]) + LayerNorm -> tokens [B*(side/4)^2, C]
  *   adt_window_attn_fwd    8x8-window attention, head_dim 24: qkv [B*R*R, >= 3C] bf16 (q | k | v, head h at column
  *                          24h) -> ctx [B*R*R, C] bf16; cyclic shift `shift` and the window partition are index math;
- *                          bias [n_bias_windows][heads][64][64] fp32 = relative position bias (+ the -100 shifted-window
- *                          mask of each window when n_bias_windows == (R/8)^2)
+ *                          bias fp32 = relative position bias (+ the -100 shifted-window mask of each window when
+ *                          n_bias_windows == (R/8)^2) of query q, key k, stored lane-linear for the kernel's accumulator
+ *                          layout: [n_bias_windows][heads][qt 2][kt 2][g 4][h 2][r 32][e 4] with q = 32 qt + r,
+ *                          k = 32 kt + 8 g + 4 h + e (adt_str_amd/clap_encoder.py:window_bias_layout)
  *   adt_patch_merge_ln     Swin patch merging gather (2x2 -> 4C, order (0,0),(1,0),(0,1),(1,1)) + LayerNorm -> bf16
  *   adt_mean_tokens        mean over the T tokens of each clip;  adt_l2_normalize  rows / ||row||
  */

@@ -15,8 +15,9 @@ clips = [torch.from_numpy((rng.standard_normal(int(n)) * 0.2).astype(np.float32)
 mel = wrap.features.mel(clips)
 flags = torch.zeros(512, dtype=torch.bool)
 flags[3] = True
-for fused in ("0", "1", "0", "1"):
+for fused, mlp in (("0", "2"), ("1", "2"), ("1", "3"), ("0", "2"), ("1", "2"), ("1", "3")):
     os.environ["ADT_HTSAT_FUSED"] = fused
+    os.environ["ADT_HTSAT_MLP"] = mlp
     for _ in range(3):
         wrap.encoder.forward(mel, flags)
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -26,4 +27,4 @@ for fused in ("0", "1", "0", "1"):
     e1.record()
     torch.cuda.synchronize()
     ms = e0.elapsed_time(e1) / 8
-    print(f"ADT_HTSAT_FUSED={fused}: {ms:.2f} ms per 512 clips = {512 / ms * 1e3:.0f} embeds/s (tower only), {2 * 5.91e9 * 512 / ms / 1e9:.0f} TFLOP/s", flush=True)
+    print(f"ADT_HTSAT_FUSED={fused} MLP kernel {mlp}: {ms:.2f} ms per 512 clips = {512 / ms * 1e3:.0f} embeds/s (tower only), {2 * 5.91e9 * 512 / ms / 1e9:.0f} TFLOP/s", flush=True)
