@@ -26,7 +26,8 @@ F32, BF16 = torch.float32, torch.bfloat16
 WINDOW = 8
 
 
-ROWBLOCK_CHANNELS = (96, 192)        # stages whose layers run on the fused row-block kernels (csrc/htsat_fused.hip)
+ROWBLOCK_CHANNELS = (96, 192)        # stages whose layers run entirely on the fused row-block kernels (csrc/htsat_fused.hip)
+ROWBLOCK_PARTIAL = (384,)            # LN + q|k|v, attention output + residual and LN + fc1 + GELU fused; fc2 stays a plain GEMM
 
 
 def _frags_rows(w: torch.Tensor) -> torch.Tensor:
@@ -135,10 +136,14 @@ class HtsatEncoder:
                     ln2=(g(q + "layernorm_after.weight"), g(q + "layernorm_after.bias")),
                     w1=b16(g(q + "intermediate.dense.weight")), b1=g(q + "intermediate.dense.bias"),
                     w2=b16(g(q + "output.dense.weight")), b2=g(q + "output.dense.bias")))
-                if C in ROWBLOCK_CHANNELS:                 # the same weights as the fragment streams of the fused kernels
+                if C in ROWBLOCK_CHANNELS or C in ROWBLOCK_PARTIAL:     # the same weights as the fragment streams of the fused kernels
                     L = layers[-1]
                     L["qkv_pk"] = pack_rowblock_weights(0, L["wqkv"].float()).to(self.dev)
                     L["wo_pk"] = pack_rowblock_weights(1, L["wo"].float()).to(self.dev)
+                if C in ROWBLOCK_PARTIAL:
+                    L["fc1_pk"] = pack_rowblock_weights(0, L["w1"].float()).to(self.dev)
+                if C in ROWBLOCK_CHANNELS:
+                    L = layers[-1]
                     L["mlp_pk"] = pack_rowblock_weights(2, L["w1"].float(), L["w2"].float()).to(self.dev)
                     L["mlp_pk3"] = pack_rowblock_weights(3, L["w1"].float(), L["w2"].float()).to(self.dev)
             merge = None
@@ -224,6 +229,18 @@ class HtsatEncoder:
                         rowblock(3, x, L["mlp_pk3"], C // 8, L["b1"], ln=L["ln2"], eps=self.eps, bias2=L["b2"])
                     else:
                         rowblock(2, x, L["mlp_pk"], C // 8, L["b1"], ln=L["ln2"], eps=self.eps, bias2=L["b2"])
+                    continue
+                if fused and "fc1_pk" in L:
+                    # C = 384: the same three fusions, except that fc2 (K = 4C) runs as a plain GEMM with the residual in its epilogue
+                    qkv = torch.empty((x.shape[0], 3 * C), dtype=BF16, device=self.dev)
+                    rowblock(0, x, L["qkv_pk"], 3 * C // 32, L["bqkv"], ln=L["ln1"], eps=self.eps, out16=qkv)
+                    ctx = torch.empty((x.shape[0], C), dtype=BF16, device=self.dev)
+                    _ffi.call("adt_window_attn_fwd", _ffi.dptr(qkv), qkv.stride(0), _ffi.dptr(ctx), C, _ffi.dptr(L["bias"]), L["n_bias"], B, R, C,
+                              nh, L["shift"], 1.0 / math.sqrt(24.0), st)
+                    rowblock(1, x, L["wo_pk"], C // 32, L["bo"], a16=ctx)
+                    h = torch.empty((x.shape[0], 4 * C), dtype=BF16, device=self.dev)
+                    rowblock(4, x, L["fc1_pk"], 4 * C // 32, L["b1"], ln=L["ln2"], eps=self.eps, out16=h)
+                    K.gemm(h, L["w2"], bias=L["b2"], residual=x, out=x)
                     continue
                 _, xn, _, _ = K.layernorm_fwd(x, *L["ln1"], eps=self.eps, want32=False)
                 qkv = K.gemm(xn, L["wqkv"], bias=L["bqkv"])

@@ -53,11 +53,16 @@ __device__ __forceinline__ void gelu_and_grad2(f32x2 x, f32x2& gv, f32x2& gd) {
 
 // A cheaper GELU for activations that are rounded to bf16 right away (the fused HTSAT MLP, where the vector pipe is the bound):
 // Q(|x|) = 0.5 erfc(|x| / sqrt 2) = 2^P6(|x|) on [0, 5.5] (|x| clamped there: Q(5.5) = 2e-8), one v_exp and six packed FMAs per pair,
-// no reciprocal; GELU(x) = 0.5 x + |x| (0.5 - Q).  Against the exact-erf value: |error| <= 4e-6 absolute, <= 1.5e-3 relative wherever
+// no reciprocal; GELU(x) = max(x, 0) - |x| Q.  Against the exact-erf value: |error| <= 4e-6 absolute, <= 1.5e-3 relative wherever
 // |GELU| > 1e-4 -- below half a bf16 ulp (2e-3) everywhere (fit and bounds: Chebyshev fit of log2 Q, evaluated in fp32).
 __device__ __forceinline__ float absmin_(float x, float cap) {
   float r;
   asm("v_min_f32 %0, |%1|, %2" : "=v"(r) : "v"(x), "v"(cap));
+  return r;
+}
+__device__ __forceinline__ float max0_(float x) {            // (asm: fmaxf on an MFMA result gets a canonicalising v_max in front)
+  float r;
+  asm("v_max_f32 %0, %1, 0" : "=v"(r) : "v"(x));
   return r;
 }
 __device__ __forceinline__ f32x2 gelu_bf16_2(f32x2 x) {
@@ -68,7 +73,21 @@ __device__ __forceinline__ f32x2 gelu_bf16_2(f32x2 x) {
   p = p * ax + -0.46045857667922974f;
   p = p * ax + -1.150443434715271f;
   p = p * ax + -1.0000735521316528f;
-  const f32x2 w = 0.5f - f32x2{__builtin_amdgcn_exp2f(p[0]), __builtin_amdgcn_exp2f(p[1])};
-  const f32x2 hx = x * 0.5f;
-  return f32x2{fmaf(fabsf(x[0]), w[0], hx[0]), fmaf(fabsf(x[1]), w[1], hx[1])};
+  // GELU = max(x, 0) - |x| Q on either side of 0
+  return f32x2{fmaf(-fabsf(x[0]), __builtin_amdgcn_exp2f(p[0]), max0_(x[0])), fmaf(-fabsf(x[1]), __builtin_amdgcn_exp2f(p[1]), max0_(x[1]))};
+}
+// two pairs at once, the two polynomial chains written interleaved (one chain of dependent packed FMAs pays a wait state per instruction)
+__device__ __forceinline__ void gelu_bf16_4(f32x2 xa, f32x2 xb, f32x2& ga, f32x2& gb) {
+  const float ma0 = max0_(xa[0]), ma1 = max0_(xa[1]), mb0 = max0_(xb[0]), mb1 = max0_(xb[1]);       // (early: far from their use)
+  const f32x2 aa = {absmin_(xa[0], 5.5f), absmin_(xa[1], 5.5f)}, ab = {absmin_(xb[0], 5.5f), absmin_(xb[1], 5.5f)};
+  f32x2 pa = aa * 2.6412943043396808e-05f + -0.00066360057098791f;
+  f32x2 pb = ab * 2.6412943043396808e-05f + -0.00066360057098791f;
+  pa = pa * aa + 0.007492306642234325f;   pb = pb * ab + 0.007492306642234325f;
+  pa = pa * aa + -0.051936905831098557f;  pb = pb * ab + -0.051936905831098557f;
+  pa = pa * aa + -0.46045857667922974f;   pb = pb * ab + -0.46045857667922974f;
+  pa = pa * aa + -1.150443434715271f;     pb = pb * ab + -1.150443434715271f;
+  pa = pa * aa + -1.0000735521316528f;    pb = pb * ab + -1.0000735521316528f;
+  const float ea0 = __builtin_amdgcn_exp2f(pa[0]), eb0 = __builtin_amdgcn_exp2f(pb[0]), ea1 = __builtin_amdgcn_exp2f(pa[1]), eb1 = __builtin_amdgcn_exp2f(pb[1]);
+  ga = f32x2{fmaf(-fabsf(xa[0]), ea0, ma0), fmaf(-fabsf(xa[1]), ea1, ma1)};
+  gb = f32x2{fmaf(-fabsf(xb[0]), eb0, mb0), fmaf(-fabsf(xb[1]), eb1, mb1)};
 }

@@ -20,6 +20,8 @@
 // O^T += V^T P^T; V^T fragments come from a 4 KiB LDS tile through ds_read_b64_tr_b16.  One wave per (window, head).
 #include <hip/hip_runtime.h>
 
+#include <cstdlib>
+
 #include "adt_common.h"
 
 namespace adt {
@@ -340,7 +342,6 @@ __global__ __launch_bounds__(256) void window_attn_kernel(WinAttnArgs a) {
   f32x16 o[2];
 #pragma unroll
   for (int qt = 0; qt < 2; ++qt) {
-    const int q = qt * 32 + r;
     float mx = -3.0e38f;
 #pragma unroll
     for (int kt = 0; kt < 2; ++kt)
@@ -393,6 +394,134 @@ __global__ __launch_bounds__(256) void window_attn_kernel(WinAttnArgs a) {
       v.y = pack2_h(o[qt][4 * g + 2], o[qt][4 * g + 3]);
       *reinterpret_cast<uint2*>(dst + 8 * g + 4 * h) = v;
     }
+  }
+}
+
+// ---- window attention, four heads per workgroup with the window's q | k | v slices staged through LDS.
+// The kernel above reads a (window, head)'s operands straight from the packed qkv rows: 16-byte pieces 576+ bytes apart, twelve
+// wave-loads of 64 scattered pieces each, and writes its output the same way -- it is bound by the number of memory requests, not
+// by bytes.  Here a workgroup = one window x four consecutive heads (wave w = head 4 hg + w): the 64 tokens' three 192-byte runs
+// (q, k, v of the four heads) are fetched with 16-byte loads that walk the runs contiguously, parked in LDS (row pitch 592 bytes:
+// 37 sixteen-byte chunks, odd, so the row reads of 32 consecutive tokens are conflict-free), read from there as MFMA operands, and
+// the four heads' outputs go back through the same buffer to 192-byte coalesced stores.
+constexpr int kWa4Pitch = 592;                          // 3 x 192 + 16
+constexpr int kWa4Stage = 64 * kWa4Pitch;               // 37,888 B
+constexpr int kWa4Lds = kWa4Stage + 4 * 64 * 64;        // + a [64 keys][32 d] V tile per wave = 54,272 B
+
+__global__ __launch_bounds__(256) void window_attn4_kernel(WinAttnArgs a) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem4[];
+  const int tid = threadIdx.x, lane = tid & 63, r = lane & 31, h = lane >> 5;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int nw = a.R / 8, hgs = a.heads / 4;
+  long item = blockIdx.x;                                                          // (b, wy, wx, head group)
+  const int hg = static_cast<int>(item % hgs); item /= hgs;
+  const int wx = static_cast<int>(item % nw); item /= nw;
+  const int wy = static_cast<int>(item % nw);
+  const int b = static_cast<int>(item / nw);
+  const int head = 4 * hg + wave;
+  unsigned char* stage = smem4;
+  unsigned char* vt = smem4 + kWa4Stage + wave * 4096;
+  // ---- stage: 64 tokens x 36 chunks (q: 0..11, k: 12..23, v: 24..35 = the four heads' 24 values each)
+#pragma unroll
+  for (int j = 0; j < 9; ++j) {
+    const int id = j * 256 + tid, t = id / 36, c = id - t * 36, which = c / 12, cc = c - which * 12;
+    const unsigned short* src = a.qkv + token_row(a, b, wy, wx, t) * a.ld + which * a.C + hg * 96 + cc * 8;
+    *reinterpret_cast<uint4*>(stage + t * kWa4Pitch + c * 16) = *reinterpret_cast<const uint4*>(src);
+  }
+  if (tid < 64) *reinterpret_cast<uint4*>(stage + tid * kWa4Pitch + 576) = make_uint4(0, 0, 0, 0);      // the pad chunk (never an operand; kept finite)
+  __syncthreads();
+  // ---- operands of this wave's head: token r (tile 0) and r + 32 (tile 1); k-step s covers d = 16s .. 16s+15, the lane holds 8h .. 8h+7
+  auto chunk = [&](int t, int which, int c) -> bf16x8 {                             // d = 8c .. 8c+7 of the head; c == 3 is the zero padding 24..31
+    uint4 v = make_uint4(0, 0, 0, 0);
+    if (c < 3) v = *reinterpret_cast<const uint4*>(stage + t * kWa4Pitch + which * 192 + wave * 48 + c * 16);
+    return *reinterpret_cast<bf16x8*>(&v);
+  };
+  bf16x8 kf[2][2], qf[2][2];
+#pragma unroll
+  for (int s = 0; s < 2; ++s) {
+    qf[0][s] = chunk(r, 0, 2 * s + h);  qf[1][s] = chunk(r + 32, 0, 2 * s + h);
+    kf[0][s] = chunk(r, 1, 2 * s + h);  kf[1][s] = chunk(r + 32, 1, 2 * s + h);
+  }
+#pragma unroll
+  for (int c = 0; c < 2; ++c) {                       // V tile: keys r and r + 32, 32 d each (d >= 24 zero); lane half h writes chunks 2h, 2h+1
+    const int ch = 2 * h + c;
+    *reinterpret_cast<bf16x8*>(vt + r * 64 + ch * 16) = chunk(r, 2, ch);
+    *reinterpret_cast<bf16x8*>(vt + (r + 32) * 64 + ch * 16) = chunk(r + 32, 2, ch);
+  }
+  f32x16 st[2][2];                                   // st[kt][qt] = S^T tile: rows keys, lane = query
+#pragma unroll
+  for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+    for (int qt = 0; qt < 2; ++qt) {
+#pragma unroll
+      for (int i = 0; i < 16; ++i) st[kt][qt][i] = 0.f;
+#pragma unroll
+      for (int s = 0; s < 2; ++s) st[kt][qt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf[kt][s], qf[qt][s], st[kt][qt], 0, 0, 0);
+    }
+  const int wsel = a.n_bias_windows > 1 ? (wy * nw + wx) : 0;
+  const float* bias = a.bias + (static_cast<long>(wsel) * a.heads + head) * 4096 + lane * 4;
+  __syncthreads();                                    // every wave has its operands: the q | k part of the stage is free for the outputs
+  f32x16 o[2];
+#pragma unroll
+  for (int qt = 0; qt < 2; ++qt) {
+    float mx = -3.0e38f;
+#pragma unroll
+    for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        const float4 bv = *reinterpret_cast<const float4*>(bias + ((qt * 2 + kt) * 4 + g) * 256);
+        const float bb[4] = {bv.x, bv.y, bv.z, bv.w};
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const float v = st[kt][qt][4 * g + e] * a.scale + bb[e];
+          st[kt][qt][4 * g + e] = v;
+          mx = fmaxf(mx, v);
+        }
+      }
+    mx = fmaxf(mx, __shfl_xor(mx, 32));
+    float sum = 0.f;
+#pragma unroll
+    for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+      for (int i = 0; i < 16; ++i) { const float p = __expf(st[kt][qt][i] - mx); st[kt][qt][i] = p; sum += p; }
+    sum += __shfl_xor(sum, 32);
+    const float inv = 1.0f / sum;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) o[qt][i] = 0.f;
+#pragma unroll
+    for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+      for (int s2 = 0; s2 < 2; ++s2) {
+        const int i16 = lane & 15, g4 = (lane >> 4) & 1;
+        const int krow = kt * 32 + 16 * s2 + 4 * h + (i16 >> 2);
+        const unsigned base = static_cast<unsigned>(reinterpret_cast<size_t>((__attribute__((address_space(3))) const void*)vt)) +
+                              krow * 64 + (16 * g4 + 4 * (i16 & 3)) * 2;
+        bf16x4 lo, hi;
+        asm volatile("ds_read_b64_tr_b16 %0, %2\n\tds_read_b64_tr_b16 %1, %2 offset:512\n\ts_waitcnt lgkmcnt(0)"
+                     : "=&v"(lo), "=&v"(hi) : "v"(base) : "memory");
+        bf16x8 af;
+        af[0] = lo[0]; af[1] = lo[1]; af[2] = lo[2]; af[3] = lo[3]; af[4] = hi[0]; af[5] = hi[1]; af[6] = hi[2]; af[7] = hi[3];
+        union { unsigned u[4]; bf16x8 v; } pf;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) pf.u[e] = pack2_h(st[kt][qt][8 * s2 + 2 * e] * inv, st[kt][qt][8 * s2 + 2 * e + 1] * inv);
+        o[qt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af, pf.v, o[qt], 0, 0, 0);
+      }
+    // O^T[d][query]: this lane owns d = 8g + 4h + (0..3), d < 24 -> the output rows in LDS: [token][4 heads x 24] bf16 (192 B, pitch 592)
+    unsigned char* dst = stage + (qt * 32 + r) * kWa4Pitch + wave * 48;
+#pragma unroll
+    for (int g = 0; g < 3; ++g) {
+      uint2 v;
+      v.x = pack2_h(o[qt][4 * g + 0], o[qt][4 * g + 1]);
+      v.y = pack2_h(o[qt][4 * g + 2], o[qt][4 * g + 3]);
+      *reinterpret_cast<uint2*>(dst + (8 * g + 4 * h) * 2) = v;
+    }
+  }
+  __syncthreads();
+  // ---- 64 tokens x 12 chunks of 16 bytes -> ctx rows (192 contiguous bytes per token)
+#pragma unroll
+  for (int j = 0; j < 3; ++j) {
+    const int id = j * 256 + tid, t = id / 12, c = id - t * 12;
+    *reinterpret_cast<uint4*>(a.ctx + token_row(a, b, wy, wx, t) * a.ldc + hg * 96 + c * 8) = *reinterpret_cast<const uint4*>(stage + t * kWa4Pitch + c * 16);
   }
 }
 
@@ -536,7 +665,21 @@ extern "C" int adt_window_attn_fwd(const void* qkv, int64_t ld_qkv, void* ctx, i
   if (total == 0) return ADT_OK;
   WinAttnArgs a{static_cast<const unsigned short*>(qkv), ld_qkv, static_cast<unsigned short*>(ctx), ld_ctx, bias, n_bias_windows,
                 static_cast<int>(B), R, C, heads, shift, scale};
-  hipLaunchKernelGGL(window_attn_kernel, dim3(static_cast<unsigned>((total + 3) / 4)), dim3(256), 0, STR(stream), a);
+  // four heads per workgroup with LDS-staged operands (every HTSAT stage has a multiple of four heads); ADT_WINATTN=1: the
+  // one-wave-per-(window, head) kernel, kept as the A/B arm
+  static const int variant = [] { const char* v = getenv("ADT_WINATTN"); return v ? atoi(v) : 4; }();
+  if (variant == 4 && heads % 4 == 0 && !(ld_ctx & 7) && aligned16(ctx)) {
+    static thread_local int done_for = -1;
+    int dev = 0;
+    ADT_HIP_TRY(hipGetDevice(&dev));
+    if (done_for != dev) {
+      ADT_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(window_attn4_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, kWa4Lds));
+      done_for = dev;
+    }
+    hipLaunchKernelGGL(window_attn4_kernel, dim3(static_cast<unsigned>(total / 4)), dim3(256), kWa4Lds, STR(stream), a);
+  } else {
+    hipLaunchKernelGGL(window_attn_kernel, dim3(static_cast<unsigned>((total + 3) / 4)), dim3(256), 0, STR(stream), a);
+  }
   ADT_HIP_TRY(hipGetLastError());
   return ADT_OK;
 }

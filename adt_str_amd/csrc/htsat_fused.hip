@@ -36,7 +36,7 @@ typedef __attribute__((ext_vector_type(4))) float f32x4;
 constexpr int kRbThreads = 256;           // 4 waves x 32 tokens; two workgroups per CU (<= 80 KiB of LDS, <= 256 registers): one loads /
 constexpr int kRbRows = 128;              // stores its rows while the other computes
 constexpr int kRbWaves = kRbThreads / 64;
-enum { kRbLnGemm = 0, kRbGemmRes = 1, kRbMlp = 2 };
+enum { kRbLnGemm = 0, kRbGemmRes = 1, kRbMlp = 2, kRbLnGemmGelu = 4 };   // (3: the MLP phase by phase, an A/B arm of 2)
 
 struct RbArgs {
   float* x;                      // [M, C] fp32 residual stream (read; written by GEMM_RES / MLP)
@@ -148,8 +148,9 @@ __global__ __launch_bounds__(kRbThreads, 2) void htsat_rowblock_kernel(RbArgs a)
     }
   }
   // GEMM_RES: the residual in the accumulator layout (channel 32n + 8g + 4h + e of the lane's token), loaded before any DMA is in flight
-  f32x4 res[MODE == kRbGemmRes ? CT * 4 : 1];
-  if (MODE == kRbGemmRes) {
+  constexpr bool kPreloadRes = MODE == kRbGemmRes && CT * 16 <= 96;       // C = 384: 192 registers -- loaded per tile instead
+  f32x4 res[kPreloadRes ? CT * 4 : 1];
+  if (kPreloadRes) {
 #pragma unroll
     for (int n = 0; n < CT; ++n)
 #pragma unroll
@@ -218,16 +219,18 @@ __global__ __launch_bounds__(kRbThreads, 2) void htsat_rowblock_kernel(RbArgs a)
       }
       wait_lgkm<0>();
       __builtin_amdgcn_sched_barrier(0);
-      if (MODE == kRbLnGemm) {
+      if (MODE == kRbLnGemm || MODE == kRbLnGemmGelu) {
         // unit 32n + 8g + 4h + e of the lane's token -> bf16, four consecutive columns per group (the two halves of a wave interleave to
         // whole 16-byte pieces of the row)
         if (row_ok) {
           unsigned short* op = a.out16 + tok * a.ldo + 32 * n + 4 * h;
 #pragma unroll
           for (int g = 0; g < 4; ++g) {
+            f32x2 z0 = {acc[4 * g] + bv[g][0], acc[4 * g + 1] + bv[g][1]}, z1 = {acc[4 * g + 2] + bv[g][2], acc[4 * g + 3] + bv[g][3]};
+            if (MODE == kRbLnGemmGelu) gelu_bf16_4(z0, z1, z0, z1);
             uint2 v;
-            v.x = pack2_f(acc[4 * g] + bv[g][0], acc[4 * g + 1] + bv[g][1]);
-            v.y = pack2_f(acc[4 * g + 2] + bv[g][2], acc[4 * g + 3] + bv[g][3]);
+            v.x = pack2_f(z0[0], z0[1]);
+            v.y = pack2_f(z1[0], z1[1]);
             *reinterpret_cast<uint2*>(op + 8 * g) = v;
           }
         }
@@ -236,7 +239,7 @@ __global__ __launch_bounds__(kRbThreads, 2) void htsat_rowblock_kernel(RbArgs a)
           float* op = a.x + tok * C + 32 * n + 4 * h;
 #pragma unroll
           for (int g = 0; g < 4; ++g) {
-            const f32x4 rv = res[n * 4 + g];
+            const f32x4 rv = kPreloadRes ? res[(kPreloadRes ? n : 0) * 4 + g] : *reinterpret_cast<const f32x4*>(op + 8 * g);
             *reinterpret_cast<f32x4*>(op + 8 * g) = f32x4{acc[4 * g] + bv[g][0] + rv[0], acc[4 * g + 1] + bv[g][1] + rv[1],
                                                           acc[4 * g + 2] + bv[g][2] + rv[2], acc[4 * g + 3] + bv[g][3] + rv[3]};
           }
@@ -440,11 +443,14 @@ __global__ __launch_bounds__(kRbThreads, 2) void htsat_mlp_kernel(RbArgs a) {
       __builtin_amdgcn_sched_barrier(0);
       if (i + 6 < NM)                                          // the register of fragment i takes fragment i + 6
         asm volatile("ds_read_b128 %0, %1" : "=v"(f[i % 6]) : "v"(ta + static_cast<unsigned>((i + 6) * 1024)) : "memory");
-      // a slice of GELU(k - 1): pairs ((i * 8) / NM .. ((i + 1) * 8) / NM - 1) of the 8 register pairs
+      // a slice of GELU(k - 1): the 8 register pairs go two at a time (two independent polynomial chains: a single chain of dependent
+      // packed FMAs costs a wait state per instruction), i.e. four slices spread over the NM MFMAs
 #pragma unroll
-      for (int m = (i * 8) / NM; m < ((i + 1) * 8) / NM; ++m) {
-        const f32x2 gv = gelu_bf16_2(f32x2{acc1[1 - PH][2 * m], acc1[1 - PH][2 * m + 1]});
-        hb[1 - PH][m >> 2].u[m & 3] = pack2_f(gv[0], gv[1]);
+      for (int q = (i * 4) / NM; q < ((i + 1) * 4) / NM; ++q) {
+        f32x2 g0, g1;
+        gelu_bf16_4(f32x2{acc1[1 - PH][4 * q], acc1[1 - PH][4 * q + 1]}, f32x2{acc1[1 - PH][4 * q + 2], acc1[1 - PH][4 * q + 3]}, g0, g1);
+        hb[1 - PH][q >> 1].u[2 * (q & 1)] = pack2_f(g0[0], g0[1]);
+        hb[1 - PH][q >> 1].u[2 * (q & 1) + 1] = pack2_f(g1[0], g1[1]);
       }
       __builtin_amdgcn_sched_barrier(0);
     }
@@ -519,6 +525,7 @@ using namespace adt;
 static int chunk_tiles(int mode, int C) {
   if (C == 96) return mode == kRbMlp ? 2 : 3;       // tiles of 12 / 6 KiB -> 24 / 18 KiB chunks (q/k/v: 9 tiles, out-proj: 3)
   if (C == 192) return mode == kRbMlp ? 1 : 2;      // tiles of 24 / 12 KiB -> 24 KiB chunks
+  if (C == 384) return mode == kRbMlp ? 0 : 1;      // tiles of 24 KiB (no fused MLP: its 12 accumulator tiles do not fit the registers)
   return 0;
 }
 extern "C" int adt_htsat_rowblock_chunk_tiles(int32_t mode, int32_t C) { return chunk_tiles(mode, C); }
@@ -527,13 +534,14 @@ extern "C" int adt_htsat_rowblock(int32_t mode, float* x, int64_t M, int32_t C, 
                                   const float* ln_beta, float eps, const void* w_packed, int32_t n_tiles, const float* bias1,
                                   const float* bias2, void* out16, int64_t ldo, void* stream) {
   // mode 3: the MLP phase by phase (no software pipeline; its own weight order) -- the A/B arm of mode 2
-  if (mode < 0 || mode > 3) return set_error(ADT_EINVAL, "adt_htsat_rowblock: mode must be 0 (LN + GEMM), 1 (GEMM + residual) or 2 (MLP)");
-  if (C != 96 && C != 192) return set_error(ADT_ESHAPE, "adt_htsat_rowblock: built for C = 96 and C = 192");
+  if (mode < 0 || mode > 4) return set_error(ADT_EINVAL, "adt_htsat_rowblock: mode must be 0 (LN + GEMM), 1 (GEMM + residual), 2 (MLP) or 4 (LN + GEMM + GELU)");
+  if (C != 96 && C != 192 && C != 384) return set_error(ADT_ESHAPE, "adt_htsat_rowblock: built for C = 96, 192 and 384");
+  if (C == 384 && (mode == 2 || mode == 3)) return set_error(ADT_ESHAPE, "adt_htsat_rowblock: the fused MLP is built for C = 96 and 192");
   if (M < 0 || n_tiles <= 0 || !x || !w_packed || !bias1) return set_error(ADT_EINVAL, "adt_htsat_rowblock: bad arguments");
   if (mode != kRbGemmRes && (!ln_gamma || !ln_beta)) return set_error(ADT_EINVAL, "adt_htsat_rowblock: LayerNorm parameters missing");
   if (mode == kRbGemmRes && (!a16 || lda < C || (lda & 7) || n_tiles != C / 32)) return set_error(ADT_ESHAPE, "adt_htsat_rowblock: bad bf16 input / tile count");
-  if (mode == kRbLnGemm && (!out16 || ldo < 32 * n_tiles || (ldo & 3))) return set_error(ADT_ESHAPE, "adt_htsat_rowblock: bad bf16 output");
-  if (mode >= kRbMlp && (!bias2 || n_tiles != C / 8)) return set_error(ADT_ESHAPE, "adt_htsat_rowblock: the MLP has 4C hidden units");
+  if ((mode == kRbLnGemm || mode == kRbLnGemmGelu) && (!out16 || ldo < 32 * n_tiles || (ldo & 3))) return set_error(ADT_ESHAPE, "adt_htsat_rowblock: bad bf16 output");
+  if ((mode == 2 || mode == 3) && (!bias2 || n_tiles != C / 8)) return set_error(ADT_ESHAPE, "adt_htsat_rowblock: the MLP has 4C hidden units");
   if (!aligned16(x) || !aligned16(w_packed) || (a16 && !aligned16(a16)) || (out16 && (reinterpret_cast<uintptr_t>(out16) & 7)))
     return set_error(ADT_EINVAL, "adt_htsat_rowblock: misaligned pointer");
   if (M == 0) return ADT_OK;
@@ -542,13 +550,20 @@ extern "C" int adt_htsat_rowblock(int32_t mode, float* x, int64_t M, int32_t C, 
   a.wpk = static_cast<const unsigned char*>(w_packed); a.bias1 = bias1; a.bias2 = bias2; a.out16 = static_cast<unsigned short*>(out16);
   a.ldo = ldo; a.M = M; a.n_tiles = n_tiles;
   hipStream_t st = static_cast<hipStream_t>(stream);
+  if (C == 384) {
+    if (mode == kRbLnGemm) return launch_rb<384, kRbLnGemm, 1>(a, st);
+    if (mode == kRbLnGemmGelu) return launch_rb<384, kRbLnGemmGelu, 1>(a, st);
+    return launch_rb<384, kRbGemmRes, 1>(a, st);
+  }
   if (C == 96) {
     if (mode == kRbLnGemm) return launch_rb<96, kRbLnGemm, 3>(a, st);
+    if (mode == kRbLnGemmGelu) return launch_rb<96, kRbLnGemmGelu, 3>(a, st);
     if (mode == kRbGemmRes) return launch_rb<96, kRbGemmRes, 3>(a, st);
     if (mode == 3) return launch_rb<96, kRbMlp, 2>(a, st);
     return launch_mlp<96, 2>(a, st);
   }
   if (mode == kRbLnGemm) return launch_rb<192, kRbLnGemm, 2>(a, st);
+  if (mode == kRbLnGemmGelu) return launch_rb<192, kRbLnGemmGelu, 2>(a, st);
   if (mode == kRbGemmRes) return launch_rb<192, kRbGemmRes, 2>(a, st);
   if (mode == 3) return launch_rb<192, kRbMlp, 1>(a, st);
   return launch_mlp<192, 1>(a, st);

@@ -448,12 +448,14 @@ int adt_patch_merge_ln(const float* x, int64_t B, int32_t R, int32_t C, const fl
                        void* out_bf16, void* stream);
 int adt_mean_tokens(const float* x, int64_t B, int32_t T, int32_t C, float* out32, void* out16, void* stream);
 
-/* K15  fused row-block kernels for the bandwidth-bound Swin stages (C = 96, 192): one launch per half of a
+/* K15  fused row-block kernels for the bandwidth-bound Swin stages (C = 96, 192; modes 0, 1, 4 also C = 384): one launch per half of a
  * ClapAudioLayer (transformers modeling_clap.py ClapAudioLayer.forward, reached from modules/clap_encoder.py:45-49).
  * x [M, C] fp32 is the residual stream (tokens in any order: the kernels are row-wise).
  *   mode 0  LN + GEMM:        out16[M, 32 n_tiles] (bf16, row stride ldo) = LayerNorm(x) W^T + bias1        (layernorm_before + q|k|v)
  *   mode 1  GEMM + residual:  x += a16[M, C] (bf16, row stride lda) W^T + bias1                             (attention.output.dense)
  *   mode 2  MLP:              x += gelu(LayerNorm(x) W1^T + bias1) W2^T + bias2, W1 [4C, C], W2 [C, 4C]     (layernorm_after + MLP)
+ *   mode 4  LN + GEMM + GELU: out16 = gelu(LayerNorm(x) W^T + bias1)                                        (layernorm_after + intermediate)
+ *   (mode 3: mode 2 without its software pipeline, the A/B arm; GELU = the erf form to half a bf16 ulp, csrc/gelu.h)
  * w_packed: the weights as the stream of 1 KiB MFMA fragments the kernel consumes (adt_str_amd/clap_encoder.py:pack_rowblock_weights):
  *   product over C, output tile n, k-step s:  64 lanes x 8 bf16, lane (r, h) = W[32n + r][16s + 8h + j], j = 0..7;
  *   modes 0 / 1: tiles n = 0 .. n_tiles-1, k-steps s = 0 .. C/16-1 each;  mode 2: per hidden tile n its C/16 fragments of W1, then

@@ -14,7 +14,7 @@ def _bf(t):
     return t.bfloat16().float()
 
 
-@pytest.mark.parametrize("C", [96, 192])
+@pytest.mark.parametrize("C", [96, 192, 384])
 def test_rowblock_modes_match_fp32_reference(C):
     from adt_str_amd.clap_encoder import pack_rowblock_weights, rowblock
     g = torch.Generator().manual_seed(C)
@@ -39,9 +39,19 @@ def test_rowblock_modes_match_fp32_reference(C):
     rowblock(1, x1, pack_rowblock_weights(1, wo).to(DEV), C // 32, bo, a16=ctx)
     ref = x + ctx.float() @ _bf(wo).T + bo
     assert (x1 - ref).abs().max() <= 2e-5 * ref.abs().max() + 2e-5
-    # mode 2: LayerNorm + fc1 + exact GELU + fc2 + residual, in place
     w1 = (torch.randn((4 * C, C), generator=g) / C ** 0.5).to(DEV)
     b1 = (0.1 * torch.randn(4 * C, generator=g)).to(DEV)
+    # mode 4: LayerNorm + fc1 + GELU -> bf16 hidden activation
+    hid16 = torch.zeros((M, 4 * C), dtype=torch.bfloat16, device=DEV)
+    x4 = x.clone()
+    rowblock(4, x4, pack_rowblock_weights(0, w1).to(DEV), 4 * C // 32, b1, ln=(gamma, beta), out16=hid16)
+    ref = torch.nn.functional.gelu(xn @ _bf(w1).T + b1)
+    assert torch.equal(x4, x)
+    assert (hid16.float() - ref).abs().max() <= 8e-3 * ref.abs().max() + 1e-3
+    assert (hid16.float() - ref).abs().mean() <= 2e-3 * ref.abs().mean() + 1e-5
+    if C == 384:
+        return                                                          # no fused MLP at C = 384 (12 accumulator tiles per wave)
+    # mode 2: LayerNorm + fc1 + GELU + fc2 + residual, in place
     w2 = (torch.randn((C, 4 * C), generator=g) / (4 * C) ** 0.5).to(DEV)
     b2 = (0.1 * torch.randn(C, generator=g)).to(DEV)
     x2 = x.clone()
