@@ -57,6 +57,25 @@ def pack_rowblock_weights(mode: int, w1: torch.Tensor, w2: Optional[torch.Tensor
     return steps.reshape(-1).contiguous()
 
 
+def pack_attn_block_weights(wqkv: torch.Tensor, bqkv: torch.Tensor, wo: torch.Tensor, heads: int):
+    """(weight stream, padded q|k|v bias [heads, 3, 32]) of ``adt_htsat_attn_block``: per head [Wq_h | Wk_h | Wv_h | Wo_h] fragments, every head's 24
+    units / inputs padded to 32 with zeros."""
+    C = wo.shape[0]
+    CT = C // 32
+    chunks, bias = [], torch.zeros((heads, 3, 32), dtype=F32, device=wqkv.device)
+    for hd in range(heads):
+        for which in range(3):
+            w = torch.zeros((32, C), dtype=F32, device=wqkv.device)
+            w[:24] = wqkv[which * C + 24 * hd: which * C + 24 * hd + 24]
+            bias[hd, which, :24] = bqkv[which * C + 24 * hd: which * C + 24 * hd + 24]
+            chunks.append(_frags_rows(w).reshape(-1))
+        wo_h = torch.zeros((C, 32), dtype=F32, device=wo.device)
+        wo_h[:, :24] = wo[:, 24 * hd: 24 * hd + 24]
+        # [ct, r, n = 1, s2, jhi, h, jlo] -> [s2, ct, h, r, jhi, jlo]: the inputs of a k-step in accumulator order
+        chunks.append(wo_h.to(BF16).view(CT, 32, 1, 2, 2, 2, 4).permute(2, 3, 0, 5, 1, 4, 6).reshape(-1))
+    return torch.cat(chunks).contiguous(), bias.contiguous()
+
+
 def rowblock(mode: int, x: torch.Tensor, wpk: torch.Tensor, n_tiles: int, bias1: torch.Tensor, *, a16: Optional[torch.Tensor] = None,
              ln=None, eps: float = 1e-5, bias2: Optional[torch.Tensor] = None, out16: Optional[torch.Tensor] = None) -> None:
     """One fused half-layer on x [M, C] fp32 (see ``adt_htsat_rowblock``)."""
@@ -142,6 +161,8 @@ class HtsatEncoder:
                     L["wo_pk"] = pack_rowblock_weights(1, L["wo"].float()).to(self.dev)
                 if C in ROWBLOCK_PARTIAL:
                     L["fc1_pk"] = pack_rowblock_weights(0, L["w1"].float()).to(self.dev)
+                if C == 96 and nh == 4:                    # the whole attention half in one launch
+                    L["attn_pk"], L["attn_qkvb"] = (t.to(self.dev) for t in pack_attn_block_weights(L["wqkv"].float(), L["bqkv"], L["wo"].float(), nh))
                 if C in ROWBLOCK_CHANNELS:
                     L = layers[-1]
                     L["mlp_pk"] = pack_rowblock_weights(2, L["w1"].float(), L["w2"].float()).to(self.dev)
@@ -217,6 +238,13 @@ class HtsatEncoder:
         for S in self.stages:
             C, nh, R = S["C"], S["nh"], S["R"]
             for L in S["layers"]:
+                if fused and "attn_pk" in L and os.environ.get("ADT_HTSAT_ATTN", "1") != "0":
+                    # stage 0: two launches per layer; only the residual stream touches HBM
+                    _ffi.call("adt_htsat_attn_block", _ffi.dptr(x), B, R, C, nh, L["shift"], _ffi.dptr(L["ln1"][0]), _ffi.dptr(L["ln1"][1]), self.eps,
+                              _ffi.dptr(L["attn_pk"]), _ffi.dptr(L["attn_qkvb"]), _ffi.dptr(L["bo"]), _ffi.dptr(L["bias"]), L["n_bias"],
+                              1.0 / math.sqrt(24.0), st)
+                    rowblock(2, x, L["mlp_pk"], C // 8, L["b1"], ln=L["ln2"], eps=self.eps, bias2=L["b2"])
+                    continue
                 if fused and "mlp_pk" in L:
                     # bandwidth-bound stages: three launches per layer, the residual stream is read and written once per half
                     qkv = torch.empty((x.shape[0], 3 * C), dtype=BF16, device=self.dev)

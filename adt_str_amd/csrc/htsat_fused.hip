@@ -61,6 +61,10 @@ __device__ __forceinline__ unsigned pack2_f(float lo, float hi) {
   asm("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(r) : "v"(lo), "v"(hi));
   return r;
 }
+__device__ __forceinline__ void zero_acc(f32x16& x) {
+#pragma unroll
+  for (int i = 0; i < 16; ++i) x[i] = 0.f;
+}
 template <int N> __device__ __forceinline__ void wait_vm() { asm volatile("s_waitcnt vmcnt(%0)" :: "n"(N) : "memory"); }
 template <int N> __device__ __forceinline__ void wait_lgkm() { asm volatile("s_waitcnt lgkmcnt(%0)" :: "n"(N) : "memory"); }
 
@@ -187,8 +191,7 @@ __global__ __launch_bounds__(kRbThreads, 2) void htsat_rowblock_kernel(RbArgs a)
       const unsigned ta = chunk_a + static_cast<unsigned>(tl * kTileFrags * 1024);
       // ---- first product: acc[32 units][32 tokens]
       f32x16 acc;
-#pragma unroll
-      for (int i = 0; i < 16; ++i) acc[i] = 0.f;
+      zero_acc(acc);
       f32x4 bv[4];
 #pragma unroll
       for (int g0 = 0; g0 < KS; g0 += 6) {
@@ -416,7 +419,7 @@ __global__ __launch_bounds__(kRbThreads, 2) void htsat_mlp_kernel(RbArgs a) {
     asm volatile("ds_read_b128 %0, %6\n\tds_read_b128 %1, %6 offset:1024\n\tds_read_b128 %2, %6 offset:2048\n\t"
                  "ds_read_b128 %3, %6 offset:3072\n\tds_read_b128 %4, %6 offset:4096\n\tds_read_b128 %5, %6 offset:5120"
                  : "=&v"(f[0]), "=&v"(f[1]), "=&v"(f[2]), "=&v"(f[3]), "=&v"(f[4]), "=&v"(f[5]) : "v"(ta) : "memory");
-    const f32x16 zero16 = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    zero_acc(acc1[PH]);
     wait_lgkm<6>();                                            // the bias (older than the six fragments) is back: it goes into fc1(k - 1)
     __builtin_amdgcn_sched_barrier(0);                         // right away, so that its 16 registers are free during the loop
 #pragma unroll
@@ -435,7 +438,7 @@ __global__ __launch_bounds__(kRbThreads, 2) void htsat_mlp_kernel(RbArgs a) {
       else wait_lgkm<0>();
       __builtin_amdgcn_sched_barrier(0);
       if ((i & 1) == 0) {
-        acc1[PH] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f[i % 6], b[i >> 1], i == 0 ? zero16 : acc1[PH], 0, 0, 0);
+        acc1[PH] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f[i % 6], b[i >> 1], acc1[PH], 0, 0, 0);
       } else {
         const int fi = i >> 1, s2 = fi / CT, ct = fi % CT;
         acc2[ct] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f[i % 6], hb[PH][s2].v, acc2[ct], 0, 0, 0);
@@ -493,6 +496,272 @@ static int launch_mlp(const RbArgs& a, hipStream_t st) {
   hipLaunchKernelGGL((htsat_mlp_kernel<C, SPC>), dim3(grid), dim3(kRbThreads), lds, st, a);
   ADT_HIP_TRY(hipGetLastError());
   return ADT_OK;
+}
+
+// ---- the whole attention half of a layer in one launch (C = 96: four heads of 24): x -> LayerNorm -> q | k | v -> window attention with
+// the relative-position bias (and the shifted-window mask) -> output projection -> + x, in place.  Unfused, this half moves the
+// residual stream twice and the bf16 q | k | v and context tensors in between (5.6 GB per stage-0 layer at 512 clips); here
+// only x is read and written (1.6 GB).  The token stays on the lane from the first load to the last store:
+//   * workgroup = 4 waves = 2 windows x 2 token tiles; wave (window wi, tile tt) owns tokens 32 tt .. 32 tt + 31 of its window;
+//   * per head: q, k, v = three 32-unit tiles (24 real units + 8 of zero weights) of the row-block product; q and k are packed
+//     straight from the accumulators into MFMA operands (B operand of S^T = K Q^T, and -- the same register layout -- A operand),
+//     k and v cross to the window's other wave through LDS (2 KiB of operands, a 4 KiB [key][d] tile read back transposed);
+//     softmax in registers (query on the lane), P^T from the accumulator as the next B operand, and the head's context tile goes --
+//     again from the accumulator -- into the output projection, whose accumulators run over the heads;
+//   * weights: one 24 KiB chunk per head [Wq | Wk | Wv fragments, then Wo's for this head's 24 (+8 zero) inputs in accumulator order],
+//     a ring of two chunks filled by LDS-DMA one head ahead.
+struct AtArgs {
+  float* x; const float *gamma, *beta; float eps;
+  const unsigned char* wpk;      // [heads] chunks of (3 C/16 + 2 C/32) KiB
+  const float* qkv_bias;         // [heads][3][32]  (units 24..31 zero)
+  const float* out_bias;         // [C]
+  const float* rel_bias; int n_bias_windows;       // lane-linear, as adt_window_attn_fwd
+  int B, R, shift; float scale;
+};
+__device__ __forceinline__ long at_token_row(const AtArgs& a, int b, int wy, int wx, int t) {
+  const int y = (wy * 8 + (t >> 3) + a.shift) % a.R, x = (wx * 8 + (t & 7) + a.shift) % a.R;
+  return (static_cast<long>(b) * a.R + y) * a.R + x;
+}
+// (compiler-visible conversion, NOT the inline-asm pack2_f: these read MFMA results, and an asm statement gets none of the wait
+// states the hazard recognizer puts between an MFMA and a vector instruction that reads its destination -- packed by asm right
+// behind the P V chain, the context tile went into the projection without its last product)
+__device__ __forceinline__ unsigned pack2_c(float lo, float hi) {
+  typedef __bf16 bf16x2_ __attribute__((ext_vector_type(2)));
+  typedef float f32x2_ __attribute__((ext_vector_type(2)));
+  return __builtin_bit_cast(unsigned, __builtin_convertvector(f32x2_{lo, hi}, bf16x2_));
+}
+__device__ __forceinline__ bf16x8 acc_to_b_f(const f32x16& x, int s) {
+  union { unsigned u[4]; bf16x8 v; } r;
+  r.u[0] = pack2_c(x[8 * s + 0], x[8 * s + 1]); r.u[1] = pack2_c(x[8 * s + 2], x[8 * s + 3]);
+  r.u[2] = pack2_c(x[8 * s + 4], x[8 * s + 5]); r.u[3] = pack2_c(x[8 * s + 6], x[8 * s + 7]);
+  return r.v;
+}
+
+template <int C>
+__global__ __launch_bounds__(256, 2) void htsat_attn_kernel(AtArgs a) {
+  constexpr int KS = C / 16, CT = C / 32, NH = C / 24;
+  constexpr int kChunkKb = 3 * KS + 2 * CT, kChunkBytes = kChunkKb * 1024;
+  constexpr int IPW = kChunkKb / 4;
+  static_assert(kChunkKb % 4 == 0 && KS == 6, "built for C = 96");
+  constexpr int kKx = 2 * kChunkBytes, kVt = kKx + 2 * 2 * 2 * 1024, kQb = kVt + 2 * 4096;     // ring | K operands | V tiles | q|k|v bias
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  const int tid = threadIdx.x, lane = tid & 63, r = lane & 31, h = lane >> 5;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wi = wave >> 1, tt = wave & 1;
+  const int nw = a.R / 8;
+  long widx = static_cast<long>(blockIdx.x) * 2 + wi;                                  // (b, wy, wx)
+  const long n_windows = static_cast<long>(a.B) * nw * nw;
+  const bool win_ok = widx < n_windows;
+  if (!win_ok) widx = n_windows - 1;
+  const int wx = static_cast<int>(widx % nw), wy = static_cast<int>((widx / nw) % nw), bi = static_cast<int>(widx / (nw * nw));
+  const long row = at_token_row(a, bi, wy, wx, 32 * tt + r);
+  const unsigned smem_base = lds_off_f(smem);
+
+  auto issue_chunk = [&](int c) {
+    const unsigned char* src = a.wpk + static_cast<long>(c) * kChunkBytes + (wave * IPW) * 1024 + lane * 16;
+    unsigned char* dst = smem + (c & 1) * kChunkBytes + (wave * IPW) * 1024;
+#pragma unroll
+    for (int i = 0; i < IPW; ++i)
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + i * 1024),
+                                       (__attribute__((address_space(3))) void*)(dst + i * 1024), 16, 0, 0);
+  };
+  issue_chunk(0);
+
+  // ---- the token row -> LayerNorm -> bf16 B operands
+  bf16x8 b[KS];
+  {
+    const float* xp = a.x + row * C + 8 * h;
+    float xv[KS][8];
+    float sum = 0.f;
+#pragma unroll
+    for (int s = 0; s < KS; ++s) {
+      const float4 v0 = *reinterpret_cast<const float4*>(xp + 16 * s), v1 = *reinterpret_cast<const float4*>(xp + 16 * s + 4);
+      xv[s][0] = v0.x; xv[s][1] = v0.y; xv[s][2] = v0.z; xv[s][3] = v0.w; xv[s][4] = v1.x; xv[s][5] = v1.y; xv[s][6] = v1.z; xv[s][7] = v1.w;
+#pragma unroll
+      for (int e = 0; e < 8; ++e) sum += xv[s][e];
+    }
+    sum += __shfl_xor(sum, 32);
+    const float mean = sum * (1.0f / C);
+    float ss = 0.f;
+#pragma unroll
+    for (int s = 0; s < KS; ++s)
+#pragma unroll
+      for (int e = 0; e < 8; ++e) { const float d = xv[s][e] - mean; ss = fmaf(d, d, ss); }
+    ss += __shfl_xor(ss, 32);
+    const float rstd = rsqrtf(ss * (1.0f / C) + a.eps);
+#pragma unroll
+    for (int s = 0; s < KS; ++s) {
+      const float4 g0 = *reinterpret_cast<const float4*>(a.gamma + 16 * s + 8 * h), g1 = *reinterpret_cast<const float4*>(a.gamma + 16 * s + 8 * h + 4);
+      const float4 e0 = *reinterpret_cast<const float4*>(a.beta + 16 * s + 8 * h), e1 = *reinterpret_cast<const float4*>(a.beta + 16 * s + 8 * h + 4);
+      const float ga[8] = {g0.x, g0.y, g0.z, g0.w, g1.x, g1.y, g1.z, g1.w}, be[8] = {e0.x, e0.y, e0.z, e0.w, e1.x, e1.y, e1.z, e1.w};
+      union { unsigned u[4]; bf16x8 v; } pk;
+#pragma unroll
+      for (int e = 0; e < 4; ++e)
+        pk.u[e] = pack2_f(fmaf((xv[s][2 * e] - mean) * rstd, ga[2 * e], be[2 * e]), fmaf((xv[s][2 * e + 1] - mean) * rstd, ga[2 * e + 1], be[2 * e + 1]));
+      b[s] = pk.v;
+    }
+  }
+  float* qb_lds = reinterpret_cast<float*>(smem + kQb);
+  for (int i = tid; i < NH * 96; i += 256) qb_lds[i] = a.qkv_bias[i];
+  asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+#pragma unroll
+  for (int s = 0; s < KS; ++s) asm volatile("" :: "v"(b[s]));
+
+  f32x16 acc_out[CT];
+#pragma unroll
+  for (int ct = 0; ct < CT; ++ct)
+#pragma unroll
+    for (int i = 0; i < 16; ++i) acc_out[ct][i] = 0.f;
+  const unsigned kx_w = smem_base + kKx + static_cast<unsigned>(((wi * 2 + tt) * 2) * 1024 + lane * 16);       // this wave's K operands (k-step s: + s KiB)
+  const unsigned kx_r = smem_base + kKx + static_cast<unsigned>((wi * 2 * 2) * 1024 + lane * 16);              // the window's: + (kt * 2 + s) KiB
+  const unsigned vt_b = smem_base + kVt + static_cast<unsigned>(wi * 4096);
+  const unsigned vt_w = vt_b + static_cast<unsigned>((32 * tt + r) * 64 + 8 * h);                               // d = 8g + 4h .. + 3: + 16 g bytes
+  const unsigned qb_a = smem_base + kQb + static_cast<unsigned>(16 * h);                                         // + (head * 96 + which * 32 + 8g) * 4
+  const int wsel = a.n_bias_windows > 1 ? (wy * nw + wx) : 0;
+  const float sl2 = a.scale * 1.4426950408889634f;
+
+  // one 32-unit tile of the row-block product + its bias: acc[unit 8g + 4h + e][token]
+  auto tile = [&](unsigned ta, unsigned bias_a, f32x16& acc) {
+    bf16x8 f[6];
+    f32x4 bv[4];
+    asm volatile("ds_read_b128 %0, %6\n\tds_read_b128 %1, %6 offset:1024\n\tds_read_b128 %2, %6 offset:2048\n\t"
+                 "ds_read_b128 %3, %6 offset:3072\n\tds_read_b128 %4, %6 offset:4096\n\tds_read_b128 %5, %6 offset:5120"
+                 : "=&v"(f[0]), "=&v"(f[1]), "=&v"(f[2]), "=&v"(f[3]), "=&v"(f[4]), "=&v"(f[5]) : "v"(ta) : "memory");
+    asm volatile("ds_read_b128 %0, %4\n\tds_read_b128 %1, %4 offset:32\n\tds_read_b128 %2, %4 offset:64\n\tds_read_b128 %3, %4 offset:96"
+                 : "=&v"(bv[0]), "=&v"(bv[1]), "=&v"(bv[2]), "=&v"(bv[3]) : "v"(bias_a) : "memory");
+    zero_acc(acc);
+#pragma unroll
+    for (int j = 0; j < 6; ++j) {
+      if (j == 0) wait_lgkm<9>(); else if (j == 1) wait_lgkm<8>(); else if (j == 2) wait_lgkm<7>();
+      else if (j == 3) wait_lgkm<6>(); else if (j == 4) wait_lgkm<5>(); else wait_lgkm<4>();
+      __builtin_amdgcn_sched_barrier(0);
+      acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f[j], b[j], acc, 0, 0, 0);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    wait_lgkm<0>();
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int g = 0; g < 4; ++g)
+#pragma unroll
+      for (int e = 0; e < 4; ++e) acc[4 * g + e] += bv[g][e];
+  };
+
+  for (int hd = 0; hd < NH; ++hd) {
+    // chunk hd landed (this wave's share; the barrier makes it everyone's); every wave is past head hd - 1, so the other ring slot and
+    // the K / V buffers are free
+    wait_vm<0>();
+    asm volatile("s_barrier" ::: "memory");
+    // relative-position bias (+ shift mask) of (query tile tt, key tile kt, group g): lane-linear table, plain loads, requested BEFORE the
+    // next chunk's DMA so that waiting for them does not wait for it (in-order counters)
+    const float* rb = a.rel_bias + (static_cast<long>(wsel) * NH + hd) * 4096 + tt * 2048 + lane * 4;
+    float4 rbv[2][4];
+#pragma unroll
+    for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+      for (int g = 0; g < 4; ++g) rbv[kt][g] = *reinterpret_cast<const float4*>(rb + (kt * 4 + g) * 256);
+    if (hd + 1 < NH) issue_chunk(hd + 1);
+    const unsigned ta = smem_base + static_cast<unsigned>((hd & 1) * kChunkBytes + lane * 16);
+    const unsigned ba = qb_a + static_cast<unsigned>(hd * 96 * 4);
+    f32x16 acc;
+    bf16x8 qop[2];
+    tile(ta, ba, acc);                                        // q
+    qop[0] = acc_to_b_f(acc, 0); qop[1] = acc_to_b_f(acc, 1);
+    tile(ta + KS * 1024, ba + 128, acc);                      // k -> the window's K operands
+    {
+      const bf16x8 k0 = acc_to_b_f(acc, 0), k1 = acc_to_b_f(acc, 1);
+      asm volatile("ds_write_b128 %0, %1\n\tds_write_b128 %0, %2 offset:1024" :: "v"(kx_w), "v"(k0), "v"(k1) : "memory");
+    }
+    tile(ta + 2 * KS * 1024, ba + 256, acc);                  // v -> the window's [key][d] tile
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+      const unsigned lo = pack2_f(acc[4 * g], acc[4 * g + 1]), hi = pack2_f(acc[4 * g + 2], acc[4 * g + 3]);
+      typedef unsigned u32x2_ __attribute__((ext_vector_type(2)));
+      const u32x2_ pr = {lo, hi};
+      asm volatile("ds_write_b64 %0, %1" :: "v"(vt_w + static_cast<unsigned>(16 * g)), "v"(pr) : "memory");
+    }
+    wait_lgkm<0>();
+    asm volatile("s_barrier" ::: "memory");
+    // ---- S^T[key][query] for this wave's 32 queries and the window's 64 keys
+    bf16x8 kf[4];
+    asm volatile("ds_read_b128 %0, %4\n\tds_read_b128 %1, %4 offset:1024\n\tds_read_b128 %2, %4 offset:2048\n\tds_read_b128 %3, %4 offset:3072"
+                 : "=&v"(kf[0]), "=&v"(kf[1]), "=&v"(kf[2]), "=&v"(kf[3]) : "v"(kx_r) : "memory");
+    f32x16 st[2];
+    wait_lgkm<0>();
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int kt = 0; kt < 2; ++kt) {
+      zero_acc(st[kt]);
+      st[kt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf[2 * kt], qop[0], st[kt], 0, 0, 0);
+      st[kt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf[2 * kt + 1], qop[1], st[kt], 0, 0, 0);
+    }
+    float mx = -3.0e38f;
+#pragma unroll
+    for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        const float bb[4] = {rbv[kt][g].x, rbv[kt][g].y, rbv[kt][g].z, rbv[kt][g].w};
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const float v = fmaf(st[kt][4 * g + e], sl2, bb[e] * 1.4426950408889634f);       // log2 domain
+          st[kt][4 * g + e] = v;
+          mx = fmaxf(mx, v);
+        }
+      }
+    mx = fmaxf(mx, __shfl_xor(mx, 32));
+    float sum = 0.f;
+#pragma unroll
+    for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+      for (int i = 0; i < 16; ++i) { const float p = __builtin_amdgcn_exp2f(st[kt][i] - mx); st[kt][i] = p; sum += p; }
+    sum += __shfl_xor(sum, 32);
+    const float inv = 1.0f / sum;
+    // ---- O^T[d][query] = sum over keys of V^T P^T
+    f32x16 o;
+    zero_acc(o);
+#pragma unroll
+    for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+      for (int s2 = 0; s2 < 2; ++s2) {
+        const int i16 = lane & 15, g4 = (lane >> 4) & 1;
+        const unsigned base = vt_b + static_cast<unsigned>((kt * 32 + 16 * s2 + 4 * h + (i16 >> 2)) * 64 + (16 * g4 + 4 * (i16 & 3)) * 2);
+        typedef __attribute__((ext_vector_type(4))) short bf16x4_;
+        bf16x4_ lo, hi;
+        bf16x8 af;
+        asm volatile("ds_read_b64_tr_b16 %0, %2\n\tds_read_b64_tr_b16 %1, %2 offset:512\n\ts_waitcnt lgkmcnt(0)"
+                     : "=&v"(lo), "=&v"(hi) : "v"(base) : "memory");
+        af[0] = lo[0]; af[1] = lo[1]; af[2] = lo[2]; af[3] = lo[3]; af[4] = hi[0]; af[5] = hi[1]; af[6] = hi[2]; af[7] = hi[3];
+        union { unsigned u[4]; bf16x8 v; } pf;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) pf.u[e] = pack2_f(st[kt][8 * s2 + 2 * e] * inv, st[kt][8 * s2 + 2 * e + 1] * inv);
+        o = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af, pf.v, o, 0, 0, 0);
+      }
+    // ---- output projection: this head's 24 (+ 8 zero) context values are k-steps 0, 1 of Wo's slice
+    const bf16x8 ob0 = acc_to_b_f(o, 0), ob1 = acc_to_b_f(o, 1);
+    {
+      bf16x8 f[6];
+      asm volatile("ds_read_b128 %0, %6\n\tds_read_b128 %1, %6 offset:1024\n\tds_read_b128 %2, %6 offset:2048\n\t"
+                   "ds_read_b128 %3, %6 offset:3072\n\tds_read_b128 %4, %6 offset:4096\n\tds_read_b128 %5, %6 offset:5120"
+                   : "=&v"(f[0]), "=&v"(f[1]), "=&v"(f[2]), "=&v"(f[3]), "=&v"(f[4]), "=&v"(f[5]) : "v"(ta + 3 * KS * 1024) : "memory");
+      wait_lgkm<0>();
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int j = 0; j < 6; ++j) acc_out[j % CT] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f[j], j < CT ? ob0 : ob1, acc_out[j % CT], 0, 0, 0);
+    }
+  }
+  // ---- x += acc_out + bias
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  if (win_ok) {
+    float* xp = a.x + row * C + 4 * h;
+#pragma unroll
+    for (int ct = 0; ct < CT; ++ct)
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        const f32x4 xr = *reinterpret_cast<const f32x4*>(xp + 32 * ct + 8 * g);
+        const f32x4 b2 = *reinterpret_cast<const f32x4*>(a.out_bias + 32 * ct + 8 * g + 4 * h);
+        *reinterpret_cast<f32x4*>(xp + 32 * ct + 8 * g) = f32x4{acc_out[ct][4 * g] + b2[0] + xr[0], acc_out[ct][4 * g + 1] + b2[1] + xr[1],
+                                                               acc_out[ct][4 * g + 2] + b2[2] + xr[2], acc_out[ct][4 * g + 3] + b2[3] + xr[3]};
+      }
+  }
 }
 
 template <int C, int MODE, int TPC>
@@ -567,4 +836,31 @@ extern "C" int adt_htsat_rowblock(int32_t mode, float* x, int64_t M, int32_t C, 
   if (mode == kRbGemmRes) return launch_rb<192, kRbGemmRes, 2>(a, st);
   if (mode == 3) return launch_rb<192, kRbMlp, 1>(a, st);
   return launch_mlp<192, 1>(a, st);
+}
+
+extern "C" int adt_htsat_attn_block(float* x, int64_t B, int32_t R, int32_t C, int32_t heads, int32_t shift, const float* ln_gamma,
+                                    const float* ln_beta, float eps, const void* w_packed, const float* qkv_bias, const float* out_bias,
+                                    const float* rel_bias, int32_t n_bias_windows, float scale, void* stream) {
+  if (!x || !ln_gamma || !ln_beta || !w_packed || !qkv_bias || !out_bias || !rel_bias) return set_error(ADT_EINVAL, "adt_htsat_attn_block: null pointer");
+  if (C != 96 || heads != 4) return set_error(ADT_ESHAPE, "adt_htsat_attn_block: built for C = 96 (4 heads of 24)");
+  if (B < 0 || R <= 0 || (R & 7) || shift < 0 || shift >= 8) return set_error(ADT_ESHAPE, "adt_htsat_attn_block: window 8, R % 8 == 0");
+  const int nw = R / 8;
+  if (n_bias_windows != 1 && n_bias_windows != nw * nw) return set_error(ADT_EINVAL, "adt_htsat_attn_block: n_bias_windows must be 1 or (R/8)^2");
+  if (!aligned16(x) || !aligned16(w_packed) || !aligned16(rel_bias)) return set_error(ADT_EINVAL, "adt_htsat_attn_block: misaligned pointer");
+  const long n_windows = B * nw * nw;
+  if (n_windows == 0) return ADT_OK;
+  AtArgs a{x, ln_gamma, ln_beta, eps, static_cast<const unsigned char*>(w_packed), qkv_bias, out_bias, rel_bias, n_bias_windows,
+           static_cast<int>(B), R, shift, scale};
+  constexpr int kChunk = (3 * 6 + 2 * 3) * 1024;
+  const int lds = 2 * kChunk + 8 * 1024 + 2 * 4096 + 4 * 96 * 4;
+  static thread_local int done_for = -1;
+  int dev = 0;
+  ADT_HIP_TRY(hipGetDevice(&dev));
+  if (done_for != dev) {
+    ADT_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(htsat_attn_kernel<96>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    done_for = dev;
+  }
+  hipLaunchKernelGGL((htsat_attn_kernel<96>), dim3(static_cast<unsigned>((n_windows + 1) / 2)), dim3(256), lds, static_cast<hipStream_t>(stream), a);
+  ADT_HIP_TRY(hipGetLastError());
+  return ADT_OK;
 }

@@ -99,9 +99,22 @@ def _embed(wrapper, files, batch_size, sample_rate):
     return out
 
 
+PHASE_SECONDS = {}     # wall time of the last run()'s phases: embed_references, embed_packs, assign, copy (read by tools/e2e.py)
+
+
 def run(cfg: dict, num_bins: int = 10, clap_model=None, copy: bool = True):
     """The reference's ``__main__`` body.  ``clap_model``: an already built ``transformers.ClapModel`` (offline use).
     Returns ``(assignment, wav_files, augmented_root)``."""
+    import time
+    PHASE_SECONDS.clear()
+    t_phase = time.perf_counter()
+
+    def phase(name):
+        nonlocal t_phase
+        torch.cuda.synchronize()
+        now = time.perf_counter()
+        PHASE_SECONDS[name] = now - t_phase
+        t_phase = now
     if num_bins <= 0 or 100 % num_bins != 0:
         raise ValueError("--num_bins must be a positive integer that divides 100 evenly")
     section = dict(cfg["clap_config"])
@@ -120,9 +133,12 @@ def run(cfg: dict, num_bins: int = 10, clap_model=None, copy: bool = True):
         reference_dict[int(Path(file).parent.name)].append(emb)
     labels, reference_embeddings = class_mean_embeddings(reference_dict)
     print(f"Reference embeddings shape: {tuple(reference_embeddings.shape)}")
+    phase("setup_and_embed_references")
     sample_pack_embeddings = _embed(wrapper, wav_files, c.batch_size, c.sample_rate)
     print(f"Sample pack embeddings shape: {tuple(sample_pack_embeddings.shape)}")
+    phase("embed_packs")
     res = assign(sample_pack_embeddings, reference_embeddings, labels, num_bins)
+    phase("assign")
 
     augmented_root = Path(f"{c.reference_root}_clap_augmented")
     if copy and (not dist.is_initialized() or dist.get_rank() == 0):
@@ -149,6 +165,7 @@ def run(cfg: dict, num_bins: int = 10, clap_model=None, copy: bool = True):
         with ThreadPoolExecutor(max_workers=max(1, IO_THREADS), thread_name_prefix="adt-curation-copy") as pool:
             copied = sum(pool.map(_copy, plan.items(), chunksize=64))
         print(f"Copied: {copied}, Skipped (duplicates): {len(wav_files) * (len(labels) - 1)}")
+    phase("copy")
     return res, wav_files, augmented_root
 
 

@@ -462,6 +462,15 @@ int adt_mean_tokens(const float* x, int64_t B, int32_t T, int32_t C, float* out3
  *   for s2 = 0, 1 and channel tile ct = 0 .. C/32-1 the fragment lane (r, h) = W2[32ct + r][32n + 16 s2 + 8 (j>>2) + 4h + (j&3)];
  *   n_tiles must be a multiple of adt_htsat_rowblock_chunk_tiles(mode, C) (the LDS-DMA chunk). */
 int adt_htsat_rowblock_chunk_tiles(int32_t mode, int32_t C);
+/* The attention half of a ClapAudioLayer in ONE launch (C = 96, 4 heads): x += out_proj(window_attention(q|k|v(LayerNorm(x)))) in place
+ * (modeling_clap.py ClapAudioLayer.forward up to the first residual; shift / window partition are index math as in adt_window_attn_fwd).
+ *   w_packed: per head one 24 KiB chunk of MFMA fragments (see adt_htsat_rowblock): the 32-unit tiles Wq_h, Wk_h, Wv_h (rows = the head's 24
+ *   output units + 8 zero rows; 6 k-step fragments each), then Wo's slice for the head's 24 (+ 8 zero) inputs as fragments (s2, ct) with the
+ *   inputs of a k-step in accumulator order 8 (j>>2) + 4h + (j&3)  (adt_str_amd/clap_encoder.py:pack_attn_block_weights);
+ *   qkv_bias [heads][3][32] (units 24..31 zero), out_bias [C], rel_bias / n_bias_windows as adt_window_attn_fwd. */
+int adt_htsat_attn_block(float* x, int64_t B, int32_t R, int32_t C, int32_t heads, int32_t shift, const float* ln_gamma,
+                         const float* ln_beta, float eps, const void* w_packed, const float* qkv_bias, const float* out_bias,
+                         const float* rel_bias, int32_t n_bias_windows, float scale, void* stream);
 int adt_htsat_rowblock(int32_t mode, float* x, int64_t M, int32_t C, const void* a16, int64_t lda, const float* ln_gamma,
                        const float* ln_beta, float eps, const void* w_packed, int32_t n_tiles, const float* bias1,
                        const float* bias2, void* out16, int64_t ldo, void* stream);

@@ -66,6 +66,53 @@ def test_rowblock_modes_match_fp32_reference(C):
     assert torch.equal(x2, x3)
 
 
+@pytest.mark.parametrize("shift", [0, 4])
+def test_attention_block_equals_its_three_kernel_sequence(shift):
+    """adt_htsat_attn_block (LayerNorm -> q|k|v -> window attention -> output projection -> + x in one launch) against the sequence it
+    replaces (row-block LN + q|k|v, adt_window_attn_fwd, row-block projection + residual) on the same weights: both round the same
+    quantities to bf16 (q, k, v, P, the context), so they agree to a few bf16 ulps of the update; an odd window count exercises the
+    half-empty last workgroup."""
+    import math
+    from adt_str_amd import _ffi
+    from adt_str_amd.clap_encoder import _shift_mask, pack_attn_block_weights, pack_rowblock_weights, rowblock, window_bias_layout
+    g = torch.Generator().manual_seed(7 + shift)
+    B, R, C, nh = 3, 24, 96, 4                                          # 27 windows
+    M = B * R * R
+    x = (torch.randn((M, C), generator=g) * 1.2).to(DEV)
+    gamma, beta = (1 + 0.1 * torch.randn(C, generator=g)).to(DEV), (0.1 * torch.randn(C, generator=g)).to(DEV)
+    wqkv = (torch.randn((3 * C, C), generator=g) / C ** 0.5).to(DEV)
+    bqkv = (0.2 * torch.randn(3 * C, generator=g)).to(DEV)
+    wo = (torch.randn((C, C), generator=g) / C ** 0.5).to(DEV)
+    bo = (0.1 * torch.randn(C, generator=g)).to(DEV)
+    bias = (0.5 * torch.randn((nh, 64, 64), generator=g)).to(DEV)
+    n_bias = 1
+    if shift:
+        bias = (bias.unsqueeze(0) + _shift_mask(R, shift).to(DEV).unsqueeze(1)).contiguous()
+        n_bias = bias.shape[0]
+    bias = window_bias_layout(bias)
+    scale = 1.0 / math.sqrt(24.0)
+    # reference sequence
+    xr = x.clone()
+    qkv = torch.empty((M, 3 * C), dtype=torch.bfloat16, device=DEV)
+    rowblock(0, xr, pack_rowblock_weights(0, wqkv).to(DEV), 3 * C // 32, bqkv, ln=(gamma, beta), out16=qkv)
+    ctx = torch.empty((M, C), dtype=torch.bfloat16, device=DEV)
+    _ffi.call("adt_window_attn_fwd", qkv.data_ptr(), qkv.stride(0), ctx.data_ptr(), C, bias.data_ptr(), n_bias, B, R, C, nh, shift, scale, 0)
+    rowblock(1, xr, pack_rowblock_weights(1, wo).to(DEV), C // 32, bo, a16=ctx)
+    # one launch
+    xf = x.clone()
+    wpk, qkvb = pack_attn_block_weights(wqkv, bqkv, wo, nh)
+    _ffi.call("adt_htsat_attn_block", xf.data_ptr(), B, R, C, nh, shift, gamma.data_ptr(), beta.data_ptr(), 1e-5, wpk.data_ptr(), qkvb.data_ptr(),
+              bo.data_ptr(), bias.data_ptr(), n_bias, scale, 0)
+    upd_r, upd_f = xr - x, xf - x
+    assert float(upd_r.abs().max()) > 0.1
+    assert float((upd_f - upd_r).abs().max()) <= 3e-2 * float(upd_r.abs().max())
+    assert float((upd_f - upd_r).abs().mean()) <= 3e-3 * float(upd_r.abs().mean())
+    xf2 = x.clone()
+    _ffi.call("adt_htsat_attn_block", xf2.data_ptr(), B, R, C, nh, shift, gamma.data_ptr(), beta.data_ptr(), 1e-5, wpk.data_ptr(), qkvb.data_ptr(),
+              bo.data_ptr(), bias.data_ptr(), n_bias, scale, 0)
+    assert torch.equal(xf, xf2)
+
+
 def test_fused_encoder_equals_unfused_kernel_sequence(monkeypatch):
     """The whole HTSAT forward with the fused stages against the LayerNorm / GEMM / GEMM sequence it replaces (same weights, same
     clips): the two differ only in where bf16 roundings fall."""

@@ -155,6 +155,7 @@ def main(argv=None):
     res, wav_files, aug_root = aug.run(cfg_clap, num_bins=10, clap_model=random_init_clap_model(0))
     barrier()
     times["curate_s"] = time.perf_counter() - t0
+    times["curate_phases_s"] = dict(aug.PHASE_SECONDS)
     n_embedded = len(wav_files) + len(PITCHES) * a.refs_per_class
 
     # 3. gold + bank
@@ -204,7 +205,8 @@ def main(argv=None):
     times["train_epoch_s"] = time.perf_counter() - t0
     out = {"workload": "config[4] end to end (synthetic library)", "n_gpus": world, "shots": a.shots, "chunks": a.chunks,
            "network": "tiny 1+1" if a.tiny else "setting-1 (69.0M)", "steps": tr.step_no, "times": times,
-           "embeds_per_s": n_embedded / times["curate_s"], "train_clips_per_s": tr.step_no * a.batch_size * world / times["train_epoch_s"],
+           "embeds_per_s": n_embedded / times["curate_s"],
+           "embeds_per_s_embedding_phase_incl_file_reads": len(wav_files) / max(times["curate_phases_s"].get("embed_packs", 0.0), 1e-9), "train_clips_per_s": tr.step_no * a.batch_size * world / times["train_epoch_s"],
            "final_loss": tr.loss_history[-1][1] if getattr(tr, "loss_history", None) else None,
            "checkpoints": [os.path.basename(d) for d in _checkpoint_dirs(run_dir)]}
     if rank == 0:
