@@ -14,7 +14,7 @@ _LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "libadt_hip
 _lock = threading.Lock()
 _lib = None
 
-ABI_VERSION = 9
+ABI_VERSION = 10
 
 i32, i64, f32, ptr = C.c_int32, C.c_int64, C.c_float, C.c_void_p
 
@@ -72,6 +72,9 @@ SIGNATURES = {
     "adt_colsum_workspace_bytes": [i64, i64],
     "adt_gemm_colsum_workspace_bytes": [i64, i64],
     "adt_colsum_bf16": [ptr, i64, i64, i64, ptr, ptr, C.c_size_t, ptr],
+    "adt_reduce_queue_begin": [ptr, C.c_size_t, ptr],
+    "adt_reduce_queue_flush": [],
+    "adt_reduce_queue_end": [i32],
     "adt_embed_pe_fwd": [ptr, ptr, ptr, f32, ptr, ptr, i64, i64, i64, i64, ptr, ptr],
     "adt_embed_bwd": [ptr, ptr, f32, ptr, i64, i64, i64, ptr, ptr],
     "adt_embed_bwd_operands": [ptr, ptr, f32, ptr, i64, ptr, i64, i64, i64, ptr, ptr],

@@ -22,6 +22,15 @@ int sched_counters(void* stream, unsigned** counters);
 // nn_ops.hip: out[c] = sum over the n_part rows of partial[n_part][width] (fixed order)
 void launch_reduce_partials(const float* partial, int n_part, int width, float* out, hipStream_t st);
 
+// nn_ops.hip, deferred second-stage reductions (adt_reduce_queue_*).  A producer asks for its partial-sum buffer with
+// reduce_queue_slice(): non-null while a queue is open on `st` and its arena has room -- the producer then writes its partials
+// there and hands the reduction to reduce_queue_push() instead of launching it; null: use the caller's workspace and reduce now.
+float* reduce_queue_slice(size_t bytes, hipStream_t st);
+// out_k[c] = sum over n_part rows of partial[n_part][width], column k * D + c (out1 / out2 may be null when width == D);
+// n_part == 0 stores zeros.  `partial` must come from reduce_queue_slice (or be null with n_part == 0).
+int reduce_queue_push(const float* partial, int n_part, int width, float* out0, float* out1, float* out2, int D);
+bool reduce_queue_open(hipStream_t st);
+
 inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
 
 }  // namespace adt

@@ -1342,7 +1342,11 @@ extern "C" int adt_attn_bwd(const adt_attn_desc* d, const void* q, const void* k
   const bool want_cs = d->dq_colsum || d->dk_colsum || d->dv_colsum;
   if (want_cs && !(d->dq_colsum && d->dk_colsum && d->dv_colsum)) return set_error(ADT_EINVAL, "adt_attn_bwd: give all three column-sum outputs or none");
   const int nqb = (d->q_len + 127) / 128, hd = d->heads * kDh;
-  if (want_cs) a.cs_dq = static_cast<float*>(ws) + delta_floats(d);
+  float* cs_slice = nullptr;
+  if (want_cs) {
+    cs_slice = reduce_queue_slice(static_cast<size_t>(d->batch) * nqb * hd * 4, st);     // open reduction queue: the second stage is deferred
+    a.cs_dq = cs_slice ? cs_slice : static_cast<float*>(ws) + delta_floats(d);
+  }
   const int lds_dq = 4 * kAttnTileBytes, lds_dkv = 2 * (2 * kAttnTileBytes + 512);
   if (int rc = set_lds_once()) return rc;
   const dim3 gq(static_cast<unsigned>((d->q_len + 127) / 128) * d->batch * d->heads), gk(static_cast<unsigned>((d->k_len + 127) / 128) * d->batch * d->heads);
@@ -1371,9 +1375,14 @@ extern "C" int adt_attn_bwd(const adt_attn_desc* d, const void* q, const void* k
     // dK = dS^T Q vanish identically -- the key bias does not change the attention output; what a sum over the stored dK would
     // return is rounding noise.  dV: a pass over the dV columns (taking it in the dK/dV kernel's epilogue costs more than that
     // pass: its one workgroup per CU has nothing to hide the cross-lane sums under).
-    launch_reduce_partials(a.cs_dq, d->batch * nqb, hd, d->dq_colsum, st);
-    ADT_HIP_TRY(hipMemsetAsync(d->dk_colsum, 0, static_cast<size_t>(hd) * 4, st));
-    float* cws = a.cs_dq + static_cast<size_t>(d->batch) * nqb * hd;
+    if (cs_slice) {
+      if (int rc = reduce_queue_push(cs_slice, d->batch * nqb, hd, d->dq_colsum, nullptr, nullptr, hd)) return rc;
+      if (int rc = reduce_queue_push(nullptr, 0, hd, d->dk_colsum, nullptr, nullptr, hd)) return rc;
+    } else {
+      launch_reduce_partials(a.cs_dq, d->batch * nqb, hd, d->dq_colsum, st);
+      ADT_HIP_TRY(hipMemsetAsync(d->dk_colsum, 0, static_cast<size_t>(hd) * 4, st));
+    }
+    float* cws = static_cast<float*>(ws) + delta_floats(d) + static_cast<size_t>(d->batch) * nqb * hd;
     const int64_t rows = static_cast<int64_t>(d->batch) * d->k_len;
     if (int rc = adt_colsum_bf16(dv, d->ldv, rows, hd, d->dv_colsum, cws, adt_colsum_workspace_bytes(rows, hd), stream)) return rc;
   }

@@ -61,6 +61,7 @@ struct GemmArgs {
   float* colsum_ws;             // 256^2 NT kernel: column sums of each 128-row band of the output, [ceil(M/256)*2][N]
   adt_gemm_epilogue ep;
   Drop drop; unsigned drop_key2;      // drop_key2 = mix32(drop.key)
+  int group_n;                             // gemm_nt_256_kernel: tile columns per column group of the tile order (>= tiles_n: row-major)
   unsigned* sched; unsigned sched_total[8];  // persistent kernels: per-XCD-group work counters (16 words apart, zero between launches) and the number of tickets each hands out in this launch
 };
 
@@ -592,8 +593,13 @@ __global__ __launch_bounds__(kBigThreads) void gemm_nt_256_kernel(GemmArgs g, in
   const unsigned ctotal = g.sched_total[xg];
   auto set_tile = [&](int v, int& m0, int& n0) {
     const int logical = slice0 + v;
-    m0 = (logical / tiles_n) * kBig;
-    n0 = (logical % tiles_n) * kBig;
+    // column-group-major tile order: groups of group_n tile columns, all row panels of a group before the next group, so
+    // that the tiles in flight on an XCD share few B panels AND few A panels (both sets fit its 4 MiB L2)
+    const int per_group = tiles_m * g.group_n;
+    const int cg = logical / per_group, rem = logical - cg * per_group;
+    const int gw = min(g.group_n, tiles_n - cg * g.group_n);
+    m0 = (rem / gw) * kBig;
+    n0 = (cg * g.group_n + rem % gw) * kBig;
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
       const int r = 8 * (2 * wave + j) + (lane >> 3);
@@ -1413,14 +1419,25 @@ extern "C" int adt_gemm_bf16(int32_t trans, int64_t M, int64_t N, int64_t K, con
     for (int x = 0; x < 8; ++x)          // per slice: one ticket per tile + the ending ticket of each of its workgroups
       g.sched_total[x] = static_cast<unsigned>(nt / 8 + (x < nt % 8 ? 1 : 0)) + g1.x / 8 + (static_cast<unsigned>(x) < g1.x % 8 ? 1u : 0u);
     if (int rc = sched_counters(stream, &g.sched)) return rc;
+    static const int group_env = getenv("ADT_GEMM_GROUP_N") ? atoi(getenv("ADT_GEMM_GROUP_N")) : 0;
+    const int group_n = group_env > 0 ? group_env : 3;       // measured in the layer sequence (tools/exp_gemm_instep.py): 3 columns -> QKV 0.231 -> 0.210 ms, the others unchanged
+    g.group_n = group_n < tn ? group_n : tn;
     static const bool log_forms = getenv("ADT_GEMM_LOG_FORMS") != nullptr;      // debugging aid: which forms does a workload launch?
     const unsigned mask = epilogue_mask(e);
     if (log_forms) fprintf(stderr, "adt_gemm nt256 form: drop=%d colsum=%d mask=0x%x M=%ld N=%ld K=%ld\n", g.drop.on() ? 1 : 0, e.colsum_out ? 1 : 0, mask, (long)M, (long)N, (long)K);
-    if (e.colsum_out) g.colsum_ws = static_cast<float*>(ws);
+    float* cs_slice = nullptr;
+    if (e.colsum_out) {
+      cs_slice = reduce_queue_slice(static_cast<size_t>(2 * tm) * g.N * 4, st);          // open reduction queue: the second stage is deferred
+      g.colsum_ws = cs_slice ? cs_slice : static_cast<float*>(ws);
+    }
     const int rc = dispatch_nt_256(g, e.colsum_out != nullptr, mask, g1, tm, tn, st);
     if (rc) return rc;
     if (e.colsum_out) {
-      launch_reduce_partials(g.colsum_ws, 2 * tm, g.N, e.colsum_out, st);
+      if (cs_slice) {
+        if (int rc2 = reduce_queue_push(cs_slice, 2 * tm, g.N, e.colsum_out, nullptr, nullptr, g.N)) return rc2;
+      } else {
+        launch_reduce_partials(g.colsum_ws, 2 * tm, g.N, e.colsum_out, st);
+      }
       colsum_done = true;
     }
   } else if ((K % 32) == 0 && K > 0 && vector_epilogue_ok(g, e)) {

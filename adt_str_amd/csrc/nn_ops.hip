@@ -242,12 +242,12 @@ __global__ __launch_bounds__(kRowThreads, 3) void layernorm_bwd_kernel(LnBwdArgs
 // out[c] = sum_p partial[p][c] in a fixed order; c < width.  A block owns 32 columns and splits the
 // partial rows over 8 row-lanes (coalesced 128-byte reads), then combines the 8 sums through LDS.
 constexpr int kRedCols = 16;                 // columns per block (64-byte row pieces), 16 row-lanes each
-__global__ __launch_bounds__(256) void reduce_partials_kernel(const float* __restrict__ partial, int n_part, int width,
-                                                              float* __restrict__ out0, float* __restrict__ out1,
-                                                              float* __restrict__ out2, int D) {
+__device__ __forceinline__ void reduce_partials_block(const float* __restrict__ partial, int n_part, int width,
+                                                      float* __restrict__ out0, float* __restrict__ out1,
+                                                      float* __restrict__ out2, int D, int block) {
   __shared__ float red[16][kRedCols + 1];
   const int cl = threadIdx.x & (kRedCols - 1), rl = threadIdx.x / kRedCols;
-  const int c = blockIdx.x * kRedCols + cl;
+  const int c = block * kRedCols + cl;
   float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;                      // four independent chains: the loads of a lane overlap
   if (c < width) {
     const float* p0 = partial + c;
@@ -270,6 +270,24 @@ __global__ __launch_bounds__(256) void reduce_partials_kernel(const float* __res
     float* o = k == 0 ? out0 : (k == 1 ? out1 : out2);
     if (o) o[col] = t;
   }
+}
+
+__global__ __launch_bounds__(256) void reduce_partials_kernel(const float* __restrict__ partial, int n_part, int width,
+                                                              float* __restrict__ out0, float* __restrict__ out1,
+                                                              float* __restrict__ out2, int D) {
+  reduce_partials_block(partial, n_part, width, out0, out1, out2, D, blockIdx.x);
+}
+
+// The same reduction for a batch of independent (partial, outputs) entries in ONE launch: the deferred second stages of a
+// gradient segment (adt_reduce_queue_*).  Entry e owns blocks [blk_start[e], blk_start[e + 1]); same summation order as above.
+constexpr int kRedBatch = 56;                // 56 * 48 + 57 * 4 bytes of kernel arguments (< 4 KiB)
+struct RedEntry { const float* partial; float* out0; float* out1; float* out2; int n_part, width, D, pad; };
+struct RedBatchArgs { RedEntry e[kRedBatch]; int blk_start[kRedBatch + 1]; };
+__global__ __launch_bounds__(256) void reduce_partials_batch_kernel(RedBatchArgs a, int n_entries) {
+  int e = 0;
+  while (e + 1 < n_entries && static_cast<int>(blockIdx.x) >= a.blk_start[e + 1]) ++e;     // block-uniform, scalar
+  const RedEntry& r = a.e[e];
+  reduce_partials_block(r.partial, r.n_part, r.width, r.out0, r.out1, r.out2, r.D, static_cast<int>(blockIdx.x) - a.blk_start[e]);
 }
 
 // ------------------------------------------------------------------------------------ column sums of a bf16 matrix
@@ -624,11 +642,15 @@ static int layernorm_bwd_impl(const char* who, const float* dy, int64_t lddy, co
   if (M == 0) return ADT_OK;
   if (!ws || ws_bytes < adt_layernorm_bwd_workspace_bytes(M, D)) return set_error(ADT_EINVAL, "adt_layernorm_bwd: workspace too small");
   const int nb = static_cast<int>((M + ln_bwd_rows(M) - 1) / ln_bwd_rows(M));
+  float* const slice = reduce_queue_slice(adt_layernorm_bwd_workspace_bytes(M, D), ST(stream));
+  if (slice) ws = slice;
   LnBwdArgs a{dy, lddy, x, ldx, gamma, mean, rstd, dx32, dxb, lddx, static_cast<float*>(ws),
               static_cast<int>(M), static_cast<int>(D), dy_drop ? make_drop(dy_drop->p, dy_drop->key) : Drop{0u, 0u, 1.0f},
               dxb_drop ? make_drop(dxb_drop->p, dxb_drop->key) : Drop{0u, 0u, 1.0f}};
   hipLaunchKernelGGL(layernorm_bwd_kernel<TB>, dim3(nb), dim3(kRowThreads), 0, ST(stream), a);
   const int width = 3 * static_cast<int>(D);
+  ADT_HIP_TRY(hipGetLastError());
+  if (slice) return reduce_queue_push(slice, nb, width, dgamma, dbeta, dxsum, static_cast<int>(D));
   hipLaunchKernelGGL(reduce_partials_kernel, dim3((width + kRedCols - 1) / kRedCols), dim3(256), 0, ST(stream), static_cast<const float*>(ws), nb,
                      width, dgamma, dbeta, dxsum, static_cast<int>(D));
   ADT_HIP_TRY(hipGetLastError());
@@ -658,7 +680,73 @@ void launch_reduce_partials(const float* partial, int n_part, int width, float* 
   hipLaunchKernelGGL(reduce_partials_kernel, dim3(static_cast<unsigned>((width + kRedCols - 1) / kRedCols)), dim3(256), 0, st, partial, n_part,
                      width, out, static_cast<float*>(nullptr), static_cast<float*>(nullptr), width);
 }
+
+// ---- deferred second-stage reductions: this thread's open queue (adt_reduce_queue_begin .. _end)
+namespace {
+struct ReduceQueue {
+  bool open = false;
+  hipStream_t st = nullptr;
+  char* arena = nullptr;
+  size_t bytes = 0, used = 0;
+  RedBatchArgs batch;
+  int n = 0;
+};
+thread_local ReduceQueue rq;
+
+int reduce_queue_launch() {              // entries only: the arena is rewound by the explicit flush
+  if (rq.n == 0) return ADT_OK;
+  hipLaunchKernelGGL(reduce_partials_batch_kernel, dim3(static_cast<unsigned>(rq.batch.blk_start[rq.n])), dim3(256), 0, rq.st, rq.batch, rq.n);
+  rq.n = 0;
+  ADT_HIP_TRY(hipGetLastError());
+  return ADT_OK;
+}
+}  // namespace
+
+bool reduce_queue_open(hipStream_t st) { return rq.open && rq.st == st; }
+
+float* reduce_queue_slice(size_t bytes, hipStream_t st) {
+  if (!reduce_queue_open(st)) return nullptr;
+  const size_t need = (bytes + 255) & ~static_cast<size_t>(255);
+  if (need > rq.bytes - rq.used) return nullptr;
+  float* p = reinterpret_cast<float*>(rq.arena + rq.used);
+  rq.used += need;
+  return p;
+}
+
+int reduce_queue_push(const float* partial, int n_part, int width, float* out0, float* out1, float* out2, int D) {
+  if (!rq.open) return set_error(ADT_EINVAL, "reduce_queue_push: no open queue");
+  if (width <= 0) return ADT_OK;
+  if (rq.n == kRedBatch)
+    if (int rc = reduce_queue_launch()) return rc;
+  if (rq.n == 0) rq.batch.blk_start[0] = 0;
+  rq.batch.e[rq.n] = RedEntry{partial, out0, out1, out2, n_part, width, D, 0};
+  rq.batch.blk_start[rq.n + 1] = rq.batch.blk_start[rq.n] + (width + kRedCols - 1) / kRedCols;
+  ++rq.n;
+  return ADT_OK;
+}
 }  // namespace adt
+
+extern "C" int adt_reduce_queue_begin(void* arena, size_t arena_bytes, void* stream) {
+  if (rq.open) return set_error(ADT_EINVAL, "adt_reduce_queue_begin: a queue is already open on this thread");
+  if (!arena || !aligned16(arena) || arena_bytes < 4096) return set_error(ADT_EINVAL, "adt_reduce_queue_begin: the arena must be a 16-byte aligned device buffer of at least 4 KiB");
+  rq.open = true; rq.st = ST(stream); rq.arena = static_cast<char*>(arena); rq.bytes = arena_bytes; rq.used = 0; rq.n = 0;
+  return ADT_OK;
+}
+
+extern "C" int adt_reduce_queue_flush(void) {
+  if (!rq.open) return set_error(ADT_EINVAL, "adt_reduce_queue_flush: no open queue");
+  const int rc = reduce_queue_launch();
+  rq.used = 0;                  // stream order: whoever writes the arena next runs after the launch that read it
+  return rc;
+}
+
+extern "C" int adt_reduce_queue_end(int discard) {
+  if (!rq.open) return ADT_OK;
+  int rc = ADT_OK;
+  if (discard) rq.n = 0; else rc = reduce_queue_launch();
+  rq = ReduceQueue{};
+  return rc;
+}
 
 extern "C" size_t adt_colsum_workspace_bytes(int64_t M, int64_t N) {
   if (M <= 0 || N <= 0) return 0;
@@ -668,11 +756,21 @@ extern "C" size_t adt_colsum_workspace_bytes(int64_t M, int64_t N) {
 extern "C" int adt_colsum_bf16(const void* x, int64_t ld, int64_t M, int64_t N, float* out, void* ws, size_t ws_bytes, void* stream) {
   if (!x || !out) return set_error(ADT_EINVAL, "adt_colsum_bf16: null pointer");
   if (M < 0 || N <= 0 || (N & 7) || (ld & 7) || !aligned16(x)) return set_error(ADT_ESHAPE, "adt_colsum_bf16: N and ld must be multiples of 8");
-  if (M == 0) { ADT_HIP_TRY(hipMemsetAsync(out, 0, N * 4, ST(stream))); return ADT_OK; }
-  if (!ws || ws_bytes < adt_colsum_workspace_bytes(M, N)) return set_error(ADT_EINVAL, "adt_colsum_bf16: workspace too small");
+  if (M == 0) {
+    if (reduce_queue_open(ST(stream))) return reduce_queue_push(nullptr, 0, static_cast<int>(N), out, nullptr, nullptr, static_cast<int>(N));
+    ADT_HIP_TRY(hipMemsetAsync(out, 0, N * 4, ST(stream)));
+    return ADT_OK;
+  }
+  float* const slice = reduce_queue_slice(adt_colsum_workspace_bytes(M, N), ST(stream));
+  if (slice) ws = slice;
+  else if (!ws || ws_bytes < adt_colsum_workspace_bytes(M, N)) return set_error(ADT_EINVAL, "adt_colsum_bf16: workspace too small");
   const int nb = static_cast<int>((M + kColsumRows - 1) / kColsumRows);
   hipLaunchKernelGGL(colsum_partial_kernel, dim3(static_cast<unsigned>((N + 255) / 256), nb), dim3(256), 0, ST(stream),
                      static_cast<const unsigned short*>(x), ld, static_cast<int>(M), static_cast<int>(N), static_cast<float*>(ws));
+  if (slice) {
+    ADT_HIP_TRY(hipGetLastError());
+    return reduce_queue_push(slice, nb, static_cast<int>(N), out, nullptr, nullptr, static_cast<int>(N));
+  }
   hipLaunchKernelGGL(reduce_partials_kernel, dim3(static_cast<unsigned>((N + kRedCols - 1) / kRedCols)), dim3(256), 0, ST(stream),
                      static_cast<const float*>(ws), nb, static_cast<int>(N), out, static_cast<float*>(nullptr), static_cast<float*>(nullptr),
                      static_cast<int>(N));

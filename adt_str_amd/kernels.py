@@ -233,6 +233,28 @@ def colsum(x, out=None):
     return out
 
 
+class reduce_queue:
+    """Context manager around adt_reduce_queue_begin / _flush / _end (include/adt_hip.h): inside it the second-stage reductions
+    of `layernorm_bwd`, `colsum`, `gemm(colsum_out=...)` and `attn_bwd(bias_grad=...)` on the current stream are queued and
+    launched together by `flush()` (and on a clean exit); their outputs are undefined until then.  An exception drops what is
+    queued and closes the queue, so the library never keeps a pointer into a freed arena."""
+
+    def __init__(self, arena: torch.Tensor):
+        assert arena.dtype == torch.uint8 and arena.is_contiguous()
+        self.arena = arena
+
+    def __enter__(self):
+        _ffi.call("adt_reduce_queue_begin", _ffi.dptr(self.arena), self.arena.numel(), _ffi.current_stream())
+        return self
+
+    def flush(self):
+        _ffi.call("adt_reduce_queue_flush")
+
+    def __exit__(self, exc_type, exc, tb):
+        _ffi.call("adt_reduce_queue_end", 0 if exc_type is None else 1)
+        return False
+
+
 def embed_pe_fwd(tokens, table, pe, scale, want32=True, want16=True, drop=None):
     """tokens int64 [B, T] -> (y32, y16) [B*T, D]."""
     assert tokens.dtype == torch.int64 and tokens.is_contiguous()

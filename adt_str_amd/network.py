@@ -171,6 +171,7 @@ class _Engine:
         self._cast_table = None
         self.gflat: Optional[torch.Tensor] = None
         self.G: Dict[str, torch.Tensor] = {}
+        self._rq, self._rq_arena = None, None
         self.grad_ready_hook = None      # callable(lo, hi): flat gradient range [lo, hi) is final (used to overlap all-reduce)
         self.drop_p = 0.0                # active dropout probability of the current pass (0 in eval)
         self.drop_seed = 0               # changes every training step; masks are regenerated from it in the backward
@@ -383,7 +384,16 @@ class _Engine:
         if not want_grads:
             return out
         self.generation += 1
-        self._backward(dlogits, mem16, B, S, key_len, enc_save, dec_save)
+        if self.fp32 or os.environ.get("ADT_NO_REDUCE_QUEUE"):
+            self._rq = None
+            self._backward(dlogits, mem16, B, S, key_len, enc_save, dec_save)
+        else:
+            # the ~55 small second-stage reductions of the bias / LayerNorm gradients: one launch per layer instead
+            if self._rq_arena is None or self._rq_arena.device != dev:
+                self._rq_arena = torch.empty(64 << 20, dtype=torch.uint8, device=dev)
+            with K.reduce_queue(self._rq_arena) as self._rq:
+                self._backward(dlogits, mem16, B, S, key_len, enc_save, dec_save)
+            self._rq = None
         return out
 
     def _backward(self, dlogits, mem16, B, S, key_len, enc_save, dec_save):
@@ -432,6 +442,7 @@ class _Engine:
                        bias_grad=G[p + ".self_attn.in_proj_bias"], head_dim=self.dh)
             self._wgrad(dqkv, s["x16"], G[p + ".self_attn.in_proj_weight"], defer=True)
             dx32 = self._dgrad(dqkv, L["sa"], residual=dy1_32, out_dtype=F32)
+            self._flush_reductions()
         K.embed_bwd(tgt, dx32, math.sqrt(d), G["decoder.tgt_tok_emb.embedding.weight"], drop=self.D("dec.emb"), f32=self.fp32)
         self._flush_wgrads()
         self._ready("decoder.")
@@ -473,7 +484,12 @@ class _Engine:
         K.colsum(dx0, out=G["project_to_mel.bias"])
         self._ready("encoder.dense_layer.", "encoder.layer_norm.", "project_to_mel.")
 
+    def _flush_reductions(self):
+        if self._rq is not None:
+            self._rq.flush()
+
     def _ready(self, *prefixes):
+        self._flush_reductions()            # the segment's queued bias / LayerNorm gradient reductions, before anyone reads it
         if self.grad_ready_hook is None:
             return
         for pre in prefixes:

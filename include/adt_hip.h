@@ -284,6 +284,20 @@ int adt_layernorm_bwd(const float* dy, int64_t lddy, const float* x, int64_t ldx
 size_t adt_colsum_workspace_bytes(int64_t M, int64_t N);
 int adt_colsum_bf16(const void* x, int64_t ld, int64_t M, int64_t N, float* out, void* ws, size_t ws_bytes, void* stream);
 
+/* Deferred second-stage reductions.  The bias / LayerNorm-parameter gradients above all end in the same small reduction
+ * (column sums over per-workgroup partial rows); a training step launches ~55 of them, a few microseconds each.  Between
+ * adt_reduce_queue_begin and _end (per calling thread, for launches on `stream`), adt_layernorm_bwd*, adt_colsum_bf16,
+ * adt_gemm_bf16 with colsum_out (bf16 NT path) and adt_attn_bwd with column-sum outputs write their partials into slices of
+ * `arena` and QUEUE that reduction; adt_reduce_queue_flush launches everything queued as one kernel (same summation order:
+ * results are bitwise those of the immediate launches) and rewinds the arena.  The queued outputs (dgamma, dbeta, dxsum,
+ * colsum_out, the attention bias gradients) are undefined until the flush.  A producer that finds the arena full reduces
+ * immediately, as without a queue.  _end flushes (discard = 0) or drops the queued entries (discard != 0: error unwinding),
+ * and closes the queue; it is a no-op without an open queue.  The host side flushes once per gradient segment, before the
+ * segment is handed to the all-reduce (adt_str_amd/network.py: _ready). */
+int adt_reduce_queue_begin(void* arena, size_t arena_bytes, void* stream);
+int adt_reduce_queue_flush(void);
+int adt_reduce_queue_end(int discard);
+
 /* ---------------------------------------------------------------------------
  * K7  token embedding * sqrt(d) + positional encoding
  *

@@ -21,9 +21,9 @@ pytestmark = pytest.mark.gpu
 DEV = "cuda:0"
 
 
-def make_model(enc_layers, dec_layers, nhead, seed=0):
+def make_model(enc_layers, dec_layers, nhead, seed=0, input_sec=0.5):
     from adt_str_amd.network import ADTModel, ADTModelConfig
-    cfg = ADTModelConfig(input_sec=0.5, time_res=0.01, win_length=2048, sample_rate=16000, enc_layers=enc_layers,
+    cfg = ADTModelConfig(input_sec=input_sec, time_res=0.01, win_length=2048, sample_rate=16000, enc_layers=enc_layers,
                          dec_layers=dec_layers, nhead=nhead, d_query=128, dropout=0.0, tgt_vocab_size=1400, plain=True, n_mels=128)
     model = ADTModel(cfg)
     state = o_adt.seeded_state(model.state_dict(), seed)
@@ -80,6 +80,64 @@ def test_logits_loss_and_grads_vs_oracle(enc_layers, dec_layers, nhead, B, T, mo
     assert bool(grouped_calls) == ((B * T) % 64 == 0) and not eng._wg_pending
     if grouped_calls:
         assert grouped_calls[0] == 6 * dec_layers + 1        # six products per decoder layer + the generator
+
+
+@pytest.mark.parametrize("enc_layers,dec_layers,nhead,B,T,L", [(2, 2, 3, 3, 12, 8000), (1, 1, 2, 34, 64, 160000)])
+def test_queued_reductions_are_bitwise_the_immediate_ones(enc_layers, dec_layers, nhead, B, T, L, monkeypatch):
+    """The backward queues the second-stage reductions of the bias / LayerNorm gradients and launches them per layer
+    (adt_reduce_queue_*); the summation order is the immediate launches', so every gradient is bitwise the same.  The second case
+    is large enough (B * S = 33524 rows, linear1 1024 wide) for the 256 x 256 GEMM's fused column sums and 64-row LN blocks."""
+    from adt_str_amd import _ffi
+    model, _, _ = make_model(enc_layers, dec_layers, nhead, input_sec=L / 16000)
+    batch = make_batch(B, L, T, 5)
+    eng = model.engine
+    tok = torch.from_numpy(batch["tokens"]).to(DEV)
+    pad = (torch.arange(T)[None, :] >= torch.from_numpy(batch["token_lengths"])[:, None]).to(DEV)
+    wav = torch.from_numpy(batch["wavs"]).to(DEV)
+    model.train()
+    flushes = []
+    real = _ffi.call
+    monkeypatch.setattr(_ffi, "call", lambda name, *a: (flushes.append(name) if name.startswith("adt_reduce_queue") else None, real(name, *a))[1])
+    eng.loss_and_grads(wav, tok[:, :-1], pad, tok[:, 1:])
+    queued = eng.gflat.clone()
+    assert flushes[0] == "adt_reduce_queue_begin" and flushes[-1] == "adt_reduce_queue_end"
+    assert flushes.count("adt_reduce_queue_flush") >= enc_layers + dec_layers
+    n_calls = len(flushes)
+    monkeypatch.setenv("ADT_NO_REDUCE_QUEUE", "1")
+    eng.gflat.zero_()
+    eng.loss_and_grads(wav, tok[:, :-1], pad, tok[:, 1:])
+    assert len(flushes) == n_calls                                   # no queue this time
+    assert torch.equal(queued, eng.gflat)
+    assert queued.abs().max() > 0 and torch.isfinite(queued).all()
+
+
+def test_reduce_queue_protocol_errors():
+    from adt_str_amd import _ffi, kernels as K
+    arena = torch.empty(1 << 20, dtype=torch.uint8, device=DEV)
+    with pytest.raises(RuntimeError, match="no open queue"):
+        _ffi.call("adt_reduce_queue_flush")
+    x = torch.randn(1000, 256, device=DEV).bfloat16()
+    with K.reduce_queue(arena) as q:
+        with pytest.raises(RuntimeError, match="already open"):
+            _ffi.call("adt_reduce_queue_begin", _ffi.dptr(arena), arena.numel(), _ffi.current_stream())
+        out = torch.full((256,), float("nan"), device=DEV)
+        K.colsum(x, out=out)
+        q.flush()
+        first = out.clone()
+        second = K.colsum(x.clone())                                 # queued too, launched on the way out
+    assert torch.equal(first, second) and torch.equal(first, K.colsum(x)) and torch.isfinite(first).all()
+    big = torch.randn(70000, 1024, device=DEV).bfloat16()            # partials larger than the arena: reduced immediately
+    small_arena = torch.empty(4096, dtype=torch.uint8, device=DEV)
+    with K.reduce_queue(small_arena):
+        got = K.colsum(big)
+    assert torch.equal(got, K.colsum(big))
+    with pytest.raises(ZeroDivisionError):
+        with K.reduce_queue(arena):
+            K.colsum(x)
+            1 / 0
+    _ffi.call("adt_reduce_queue_end", 0)                             # closed by the unwinding: a no-op now
+    with K.reduce_queue(arena):                                      # and a new one opens
+        pass
 
 
 def test_autograd_bridge_and_reference_signature():
