@@ -61,6 +61,7 @@ struct GemmArgs {
   float* colsum_ws;             // 256^2 NT kernel: column sums of each 128-row band of the output, [ceil(M/256)*2][N]
   adt_gemm_epilogue ep;
   Drop drop; unsigned drop_key2;      // drop_key2 = mix32(drop.key)
+  int tail_stores;                         // gemm_nt_256_kernel: leave an interior tile's last stores in flight across the tile boundary
   int group_n;                             // gemm_nt_256_kernel: tile columns per column group of the tile order (>= tiles_n: row-major)
   unsigned* sched; unsigned sched_total[8];  // persistent kernels: per-XCD-group work counters (16 words apart, zero between launches) and the number of tickets each hands out in this launch
 };
@@ -735,7 +736,7 @@ __global__ __launch_bounds__(kBigThreads) void gemm_nt_256_kernel(GemmArgs g, in
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     if (wr == 0) asm volatile("s_barrier" ::: "memory");
     asm volatile("s_barrier" ::: "memory");            // every DMA has landed and every fragment read is done: staging is free
-    const int em0 = m0;
+    const int em0 = m0, en0 = n0;
     if (tid == 0) { ticket_drawn(counter, v_next, ctotal); *flag = v_next; }
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     asm volatile("s_barrier" ::: "memory");
@@ -800,7 +801,12 @@ __global__ __launch_bounds__(kBigThreads) void gemm_nt_256_kernel(GemmArgs g, in
       }
     }
     if (!more) break;
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");    // next tile's first k-tiles have landed (and this tile's stores are out)
+    // The next tile's first k-tiles have landed.  vmcnt retires in issue order and the prologue DMAs are older than everything the
+    // epilogue issued, so on an interior tile -- where each of the 16 epilogue_apply8 calls above issued at least one store -- the 16
+    // youngest operations are stores: they may still be in flight (they drain under the next tile's first K-step, whose vmcnt(6)
+    // retires them).  An edge tile skips stores by predicate, so it waits for everything.
+    if (g.tail_stores && em0 + kBig <= g.M && en0 + kBig <= g.N) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     asm volatile("s_barrier" ::: "memory");
   }
 #undef ADT_MFMA_QUAD
@@ -1419,6 +1425,8 @@ extern "C" int adt_gemm_bf16(int32_t trans, int64_t M, int64_t N, int64_t K, con
     for (int x = 0; x < 8; ++x)          // per slice: one ticket per tile + the ending ticket of each of its workgroups
       g.sched_total[x] = static_cast<unsigned>(nt / 8 + (x < nt % 8 ? 1 : 0)) + g1.x / 8 + (static_cast<unsigned>(x) < g1.x % 8 ? 1u : 0u);
     if (int rc = sched_counters(stream, &g.sched)) return rc;
+    static const bool tail_off = getenv("ADT_GEMM_NO_TAIL_STORES") != nullptr;
+    g.tail_stores = tail_off ? 0 : 1;
     static const int group_env = getenv("ADT_GEMM_GROUP_N") ? atoi(getenv("ADT_GEMM_GROUP_N")) : 0;
     const int group_n = group_env > 0 ? group_env : 3;       // measured in the layer sequence (tools/exp_gemm_instep.py): 3 columns -> QKV 0.231 -> 0.210 ms, the others unchanged
     g.group_n = group_n < tn ? group_n : tn;
