@@ -75,6 +75,9 @@ SIGNATURES = {
     "adt_reduce_queue_begin": [ptr, C.c_size_t, ptr],
     "adt_reduce_queue_flush": [],
     "adt_reduce_queue_end": [i32],
+    "adt_wav_probe_batch": [ptr, i32, i32, ptr],
+    "adt_wav_decode_batch": [ptr, i32, i32, ptr, ptr, i32, ptr, ptr],
+    "adt_copy_files": [ptr, ptr, i32, i32, ptr],
     "adt_embed_pe_fwd": [ptr, ptr, ptr, f32, ptr, ptr, i64, i64, i64, i64, ptr, ptr],
     "adt_embed_bwd": [ptr, ptr, f32, ptr, i64, i64, i64, ptr, ptr],
     "adt_embed_bwd_operands": [ptr, ptr, f32, ptr, i64, ptr, i64, i64, i64, ptr, ptr],

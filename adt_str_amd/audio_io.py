@@ -2,14 +2,17 @@
 pretty_midi, ``inference.py:14-32,82-93``; neither is available on the GPU box).
 
   read_wav   RIFF/WAVE PCM 8/16/24/32-bit and IEEE float32 -> float32 [channels, samples] in [-1, 1]
+  read_wav_batch / copy_files   the curation path's batched host I/O (libadt_hip.so: adt_wav_*_batch, adt_copy_files)
   write_wav  float32 -> 16-bit PCM
   write_drum_midi  notes [[onset s, offset s, pitch, velocity]...] -> Standard MIDI File, format 0,
              channel 10 (percussion), 480 ticks per quarter at 120 bpm (pretty_midi's defaults)
 """
 from __future__ import annotations
 
+import ctypes
+import os
 import struct
-from typing import Sequence, Tuple
+from typing import NamedTuple, Optional, Sequence, Tuple
 
 import numpy as np
 
@@ -86,3 +89,79 @@ def write_drum_midi(path: str, notes: Sequence[Sequence[float]], ticks_per_quart
     track += b"\x00\xff\x2f\x00"
     with open(path, "wb") as fh:
         fh.write(b"MThd" + struct.pack(">IHHH", 6, 0, 1, ticks_per_quarter) + b"MTrk" + struct.pack(">I", len(track)) + track)
+
+
+# ---------------------------------------------------------------------------------------------- batched host I/O (H1)
+class _WavInfo(ctypes.Structure):          # include/adt_hip.h: adt_wav_info
+    _fields_ = [("frames", ctypes.c_int64), ("data_offset", ctypes.c_int64), ("data_bytes", ctypes.c_int64),
+                ("sample_rate", ctypes.c_int32), ("channels", ctypes.c_int32), ("format", ctypes.c_int32), ("bits", ctypes.c_int32),
+                ("status", ctypes.c_int32), ("reserved", ctypes.c_int32)]
+
+
+class WavBatch(NamedTuple):
+    data: "object"            # torch float32 [total samples] on the host (pinned when asked): the clips back to back, mono
+    offsets: np.ndarray       # int64 [n + 1]: clip i is data[offsets[i]:offsets[i + 1]] (empty for a file that failed)
+    sample_rate: np.ndarray   # int32 [n]
+    peak: np.ndarray          # float32 [n]: max |x| of the mono clip BEFORE normalisation
+    status: np.ndarray        # int32 [n]: 0, or the ADT_E* code of a file that could not be decoded
+
+
+def io_threads() -> int:
+    """Pool size of the batched calls: ADT_CURATION_IO_THREADS, default the CPUs this process may run on (at most 32)."""
+    env = os.environ.get("ADT_CURATION_IO_THREADS")
+    if env:
+        return max(1, int(env))
+    try:
+        return max(1, min(32, len(os.sched_getaffinity(0))))
+    except AttributeError:
+        return max(1, min(32, os.cpu_count() or 1))
+
+
+def _c_paths(paths: Sequence[str]):
+    arr = (ctypes.c_char_p * len(paths))(*[os.fsencode(p) for p in paths])
+    return arr, ctypes.cast(arr, ctypes.c_void_p)
+
+
+def read_wav_batch(paths: Sequence[str], normalize: bool = False, pin: bool = False, threads: Optional[int] = None) -> WavBatch:
+    """Decode ``paths`` on the library's thread pool: every file as ``read_wav(path)[0].mean(axis=0)`` (bitwise), optionally
+    divided by its peak -- the reference's per-file ``torchaudio.load`` -> ``mean(dim=0)`` -> ``x / x.abs().max()``
+    (data_modules/augment_data_with_CLAP.py:51-68) for a whole batch in two calls (headers, then samples)."""
+    import torch
+    from . import _ffi
+    n = len(paths)
+    threads = io_threads() if threads is None else threads
+    info = (_WavInfo * max(n, 1))()
+    keep, pp = _c_paths(paths)
+    _ffi.call("adt_wav_probe_batch", pp, n, threads, ctypes.cast(info, ctypes.c_void_p))
+    view = np.frombuffer(info, dtype=np.dtype({"names": [f[0] for f in _WavInfo._fields_],
+                                               "formats": [np.int64] * 3 + [np.int32] * 6}), count=max(n, 1))[:n]
+    frames = np.where(view["status"] == 0, view["frames"], 0).astype(np.int64)
+    offsets = np.zeros(n + 1, np.int64)
+    np.cumsum(frames, out=offsets[1:])
+    total = int(offsets[-1])
+    data = torch.empty(total, dtype=torch.float32, pin_memory=bool(pin and total and torch.cuda.is_available()))
+    peak = np.zeros(n, np.float32)
+    if n:
+        _ffi.call("adt_wav_decode_batch", pp, n, threads, ctypes.cast(info, ctypes.c_void_p), offsets.ctypes.data, 1 if normalize else 0,
+                  data.data_ptr(), peak.ctypes.data)
+    del keep
+    status = view["status"].copy()
+    if (status != 0).any() and (frames[status != 0] != 0).any():      # a file that failed between the probe and the read: its slot is undefined
+        for i in np.nonzero((status != 0) & (frames != 0))[0]:
+            data[offsets[i]:offsets[i + 1]] = float("nan")
+    return WavBatch(data, offsets, view["sample_rate"].copy(), peak, status)
+
+
+def copy_files(srcs: Sequence[str], dsts: Sequence[str], threads: Optional[int] = None) -> np.ndarray:
+    """``shutil.copy2(src, dst)`` for every pair on the library's thread pool (contents, mode bits, times; no extended
+    attributes).  Returns int32 status per pair (0 = copied)."""
+    from . import _ffi
+    assert len(srcs) == len(dsts)
+    n = len(srcs)
+    status = np.zeros(n, np.int32)
+    if n:
+        k1, p1 = _c_paths(srcs)
+        k2, p2 = _c_paths(dsts)
+        _ffi.call("adt_copy_files", p1, p2, n, io_threads() if threads is None else threads, status.ctypes.data)
+        del k1, k2
+    return status

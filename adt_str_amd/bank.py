@@ -90,39 +90,60 @@ class OneShotBank:
         the reference's ``except``."""
         import glob
         import os
-        from .audio_io import read_wav
+        from .audio_io import read_wav, read_wav_batch
         files = sorted(glob.glob(os.path.join(root, "**", "*.[Ww][Aa][Vv]"), recursive=True))
         tree: dict = {}
         resamplers: dict = {}
+        todo = []                                                     # (path, label, group, stem) in sorted path order
         for path in files:
             rel = os.path.relpath(path, root).split(os.sep)
             if len(rel) < 3 or rel[1] not in GROUPS:
                 continue
-            label, group, stem = rel[0], rel[1], os.path.splitext(rel[-1])[0]
             try:
-                int(label)
-                audio, sr = read_wav(path)
-                x = audio.mean(axis=0)
-                if sr != sample_rate:
-                    from .resample import Resample
-                    if device is None or torch.device(device).type != "cuda":
-                        raise RuntimeError(f"{path} is {sr} Hz: resampling to {sample_rate} Hz runs on the GPU (pass device=)")
-                    if sr not in resamplers:
-                        resamplers[sr] = Resample(sr, sample_rate)
-                    x = resamplers[sr](torch.from_numpy(x).to(device)[None])[0].cpu().numpy()
-                peak = float(np.abs(x).max()) if x.size else 0.0
-                if not peak > 0.0:
-                    raise ValueError("silent or empty file")
-                x = (x / peak).astype(np.float32)
-            except Exception as e:
+                int(rel[0])
+            except ValueError as e:
                 print(f"Failed to load '{path}': {e}")
                 continue
-            cell = tree.setdefault(label, {}).setdefault(group, {})
-            name, k = stem, 1
-            while name in cell:
-                k += 1
-                name = f"{stem}_{k}"
-            cell[name] = x
+            todo.append((path, rel[0], rel[1], os.path.splitext(rel[-1])[0]))
+
+        def per_file(path):                                           # another rate: mono -> K13 on the GPU -> peak-normalise
+            audio, sr = read_wav(path)
+            x = audio.mean(axis=0)
+            if sr != sample_rate:
+                from .resample import Resample
+                if device is None or torch.device(device).type != "cuda":
+                    raise RuntimeError(f"{path} is {sr} Hz: resampling to {sample_rate} Hz runs on the GPU (pass device=)")
+                if sr not in resamplers:
+                    resamplers[sr] = Resample(sr, sample_rate)
+                x = resamplers[sr](torch.from_numpy(x).to(device)[None])[0].cpu().numpy()
+            peak = float(np.abs(x).max()) if x.size else 0.0
+            if not peak > 0.0:
+                raise ValueError("silent or empty file")
+            return (x / peak).astype(np.float32)
+
+        # files at the bank's rate: decoded, down-mixed and normalised a few thousand per call on the library's thread pool
+        # (audio_io.read_wav_batch: read_wav(path)[0].mean(axis=0) / peak, bitwise); the shots are views of the batch buffers
+        for lo in range(0, len(todo), 8192):
+            part = todo[lo:lo + 8192]
+            b = read_wav_batch([t[0] for t in part], normalize=True)
+            data = b.data.numpy()
+            for j, (path, label, group, stem) in enumerate(part):
+                try:
+                    if b.status[j] == 0 and b.sample_rate[j] == sample_rate:
+                        if not b.peak[j] > 0.0:
+                            raise ValueError("silent or empty file")
+                        x = data[b.offsets[j]:b.offsets[j + 1]]
+                    else:
+                        x = per_file(path)                            # raises what read_wav raises for an unreadable file
+                except Exception as e:
+                    print(f"Failed to load '{path}': {e}")
+                    continue
+                cell = tree.setdefault(label, {}).setdefault(group, {})
+                name, k = stem, 1
+                while name in cell:
+                    k += 1
+                    name = f"{stem}_{k}"
+                cell[name] = x
         return OneShotBank.from_tree(tree, sample_rate)
 
     def save(self, path: str) -> None:

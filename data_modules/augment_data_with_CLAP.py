@@ -18,6 +18,7 @@ from pathlib import Path
 
 sys.path.append(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 
+import numpy as np  # noqa: E402
 import torch  # noqa: E402
 import torch.distributed as dist  # noqa: E402
 
@@ -58,31 +59,44 @@ def normalize(waveform: torch.Tensor) -> torch.Tensor:
     return waveform / torch.max(torch.abs(waveform))
 
 
-IO_THREADS = int(os.environ.get("ADT_CURATION_IO_THREADS", "8"))
-
-
 def _load_normalized(path, sample_rate):
     return normalize(load_audio(path, sample_rate))
+
+
+def _load_batch(paths, sample_rate, device):
+    """The batch's clips as the reference prepares them (load -> mono -> resample -> x / max|x|, :51-68), on ``device``.
+    Files already at ``sample_rate`` -- the whole library, normally -- are decoded, down-mixed and normalised by one batched call
+    into pinned memory (adt_str_amd.audio_io.read_wav_batch: the per-file arithmetic, bitwise) and cross PCIe in ONE copy; the
+    rest (another rate, unreadable, empty) take the per-file route, which also raises what the reference would."""
+    from adt_str_amd.audio_io import read_wav_batch
+    b = read_wav_batch(paths, normalize=True, pin=True)
+    fast = (b.status == 0) & (b.sample_rate == sample_rate) & (np.diff(b.offsets) > 0)
+    slow = {i: _load_normalized(paths[i], sample_rate) for i in np.nonzero(~fast)[0]}
+    return b, fast, slow
 
 
 def _embed(wrapper, files, batch_size, sample_rate):
     """Embeddings [len(files), 512] on the wrapper's device, this rank's strided slice computed here, the rest gathered.
 
     The reference reads, resamples and normalises one file at a time on the thread that also drives the GPU
-    (augment_data_with_CLAP.py:66-68,124-137).  Here the files of batch i + 1 are read by a small thread pool (file reads and the
-    numpy decode release the GIL) while the GPU embeds batch i; the order of the results is the order of ``files``."""
+    (augment_data_with_CLAP.py:66-68,124-137).  Here batch i + 1 is decoded on the library's thread pool (one call per batch,
+    off the GIL) while the GPU embeds batch i; the order of the results is the order of ``files``."""
     from concurrent.futures import ThreadPoolExecutor
     world = dist.get_world_size() if dist.is_initialized() else 1
     rank = dist.get_rank() if dist.is_initialized() else 0
     mine = list(range(rank, len(files), world))
     chunks = []
     starts = list(range(0, len(mine), batch_size))
-    with ThreadPoolExecutor(max_workers=max(1, IO_THREADS), thread_name_prefix="adt-curation-io") as pool:
-        submit = lambda i: [pool.submit(_load_normalized, files[j], sample_rate) for j in mine[i:i + batch_size]]
+    device = wrapper.device
+    with ThreadPoolExecutor(max_workers=1, thread_name_prefix="adt-curation-io") as pool:
+        submit = lambda i: pool.submit(_load_batch, [files[j] for j in mine[i:i + batch_size]], sample_rate, device)
         pending = submit(starts[0]) if starts else None
         for k, i in enumerate(starts):
-            batch = [f.result() for f in pending]
-            pending = submit(starts[k + 1]) if k + 1 < len(starts) else None      # read the next batch while this one is embedded
+            b, fast, slow = pending.result()
+            pending = submit(starts[k + 1]) if k + 1 < len(starts) else None      # decode the next batch while this one is embedded
+            dev_data = b.data.to(device, non_blocking=True)
+            off = b.offsets.tolist()
+            batch = [dev_data[off[j]:off[j + 1]][None] if fast[j] else slow[j].to(device) for j in range(len(fast))]     # [1, L] each, like the reference's
             chunks.append(wrapper.get_audio_features(batch).float())
     local = torch.cat(chunks) if chunks else torch.zeros((0, 512), device=wrapper.device)
     if world == 1:
@@ -153,17 +167,12 @@ def run(cfg: dict, num_bins: int = 10, clap_model=None, copy: bool = True):
         for d in {dst.parent for dst in plan}:
             d.mkdir(parents=True, exist_ok=True)
 
-        def _copy(item):
-            dst, src = item
-            try:
-                shutil.copy2(src, dst)
-                return 1
-            except Exception as e:                         # the reference logs and carries on (:195-196)
-                print(f"Failed to copy {src} -> {dst.parent}: {e}")
-                return 0
-        from concurrent.futures import ThreadPoolExecutor
-        with ThreadPoolExecutor(max_workers=max(1, IO_THREADS), thread_name_prefix="adt-curation-copy") as pool:
-            copied = sum(pool.map(_copy, plan.items(), chunksize=64))
+        from adt_str_amd.audio_io import copy_files
+        dsts, srcs = [str(d) for d in plan], [str(v) for v in plan.values()]
+        status = copy_files(srcs, dsts)                    # shutil.copy2 per pair (contents, mode, times) on the library's thread pool
+        for j in np.nonzero(status)[0]:                    # the reference logs and carries on (:195-196)
+            print(f"Failed to copy {srcs[j]} -> {os.path.dirname(dsts[j])}")
+        copied = int((status == 0).sum())
         print(f"Copied: {copied}, Skipped (duplicates): {len(wav_files) * (len(labels) - 1)}")
     phase("copy")
     return res, wav_files, augmented_root

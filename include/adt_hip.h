@@ -517,6 +517,46 @@ int adt_cosine_argmax_f32(const float* emb, int64_t ld, const float* refs, int64
 int adt_resample_f32(const float* in, int64_t B, int64_t L_in, int64_t ld_in, const float* bank, const int32_t* tap_range,
                      int32_t K, int32_t width, int32_t orig, int32_t neu, float* out, int64_t L_out, int64_t ld_out, void* stream);
 
+/* ---------------------------------------------------------------------------
+ * H1  Curation host I/O: batched WAV decode and batched file copies (host threads, no GPU work)
+ *
+ * Replaces, for a whole batch of files per call, what the reference does one file at a time on the thread that drives the
+ * GPU: torchaudio.load(path) -> waveform.mean(dim=0, keepdim=True) -> waveform / waveform.abs().max()
+ * (data_modules/augment_data_with_CLAP.py:51-68, convert_augmented_to_hdf5.py:97-103) and shutil.copy2 per chosen file
+ * (augment_data_with_CLAP.py:184-196).  Decoding is adt_str_amd/audio_io.py:read_wav to the bit: RIFF chunk walk (last
+ * "fmt " / "data" chunk wins, WAVE_FORMAT_EXTENSIBLE sub-format, a data chunk cut short by the end of the file is taken as
+ * far as it goes), 8 / 16 / 24 / 32-bit PCM as sample / 2^(bits-1) and 32-bit float, all in float32.
+ *
+ *   adt_wav_probe_batch   info[i] <- header of paths[i]; info[i].status = ADT_OK, or ADT_EINVAL (unreadable / not RIFF-WAVE /
+ *                         no fmt or data chunk) or ADT_ESHAPE (an encoding outside the list above).  The call itself
+ *                         returns ADT_OK: one bad file does not fail the batch.
+ *   adt_wav_decode_batch  for every file with status ADT_OK: out[offsets[i] .. offsets[i] + info[i].frames) <- the mean
+ *                         over channels (sum in channel order, then / channels); peaks[i] (optional) <- max |x| before
+ *                         normalisation (NaN if any sample is); with ADT_WAV_NORMALIZE every sample is then divided by that
+ *                         peak (a silent file becomes NaNs, as in the reference -- callers that skip silent files read peaks).
+ *                         `out` is host memory (pinned, when a host-to-device copy follows); a file that changed since the
+ *                         probe gets its status overwritten.
+ *   adt_copy_files        dst[i] <- src[i]: contents, permission bits and access / modification times (shutil.copy2 without
+ *                         extended attributes); status[i] = ADT_OK or ADT_EINVAL.  Destination directories must exist; every
+ *                         destination should appear once.
+ * `threads`: size of the pool the call spins up (files are handed out dynamically); <= 1 runs inline. */
+typedef struct adt_wav_info {
+  int64_t frames;        /* samples per channel */
+  int64_t data_offset;   /* byte offset of the data chunk's payload */
+  int64_t data_bytes;
+  int32_t sample_rate;
+  int32_t channels;
+  int32_t format;        /* 1 = integer PCM, 3 = IEEE float (after resolving WAVE_FORMAT_EXTENSIBLE) */
+  int32_t bits;
+  int32_t status;
+  int32_t reserved;
+} adt_wav_info;
+#define ADT_WAV_NORMALIZE 1
+int adt_wav_probe_batch(const char* const* paths, int32_t n, int32_t threads, adt_wav_info* info);
+int adt_wav_decode_batch(const char* const* paths, int32_t n, int32_t threads, adt_wav_info* info, const int64_t* offsets,
+                         int32_t flags, float* out, float* peaks);
+int adt_copy_files(const char* const* src, const char* const* dst, int32_t n, int32_t threads, int32_t* status);
+
 #ifdef __cplusplus
 }
 #endif

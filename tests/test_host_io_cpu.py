@@ -1,0 +1,154 @@
+"""H1 (include/adt_hip.h): the curation path's batched WAV decode and file copies against the per-file Python they replace
+(adt_str_amd.audio_io.read_wav -> mean over channels -> x / max|x|, the reference's data_modules/augment_data_with_CLAP.py:51-68;
+shutil.copy2, :184-196).  Host code only: runs without a GPU."""
+import os
+import shutil
+import struct
+
+import numpy as np
+import pytest
+import torch
+
+from adt_str_amd import audio_io as A
+
+
+def _riff(chunks):
+    body = b"WAVE" + b"".join(tag + struct.pack("<I", size if size is not None else len(data)) + data + (b"\0" if len(data) & 1 else b"")
+                              for tag, data, size in chunks)
+    return b"RIFF" + struct.pack("<I", len(body)) + body
+
+
+def _fmt(tag, channels, rate, bits, extensible_sub=None):
+    block = channels * bits // 8
+    base = struct.pack("<HHIIHH", 0xFFFE if extensible_sub is not None else tag, channels, rate, rate * block, block, bits)
+    if extensible_sub is None:
+        return base
+    return base + struct.pack("<HHI", 22, bits, 3) + struct.pack("<H", extensible_sub) + b"\x00\x00\x00\x00\x10\x00\x80\x00\x00\xaa\x00\x38\x9b\x71"
+
+
+def _pcm(rng, n, channels, bits, tag=1):
+    if tag == 3:
+        return (rng.standard_normal(n * channels) * 0.4).astype("<f4").tobytes()
+    if bits == 8:
+        return rng.integers(0, 256, n * channels, dtype=np.uint8).tobytes()
+    if bits == 16:
+        return rng.integers(-32768, 32768, n * channels).astype("<i2").tobytes()
+    if bits == 32:
+        return rng.integers(-2 ** 31, 2 ** 31, n * channels).astype("<i4").tobytes()
+    v = rng.integers(-2 ** 23, 2 ** 23, n * channels).astype(np.int64) & 0xFFFFFF
+    return b"".join(int(x).to_bytes(3, "little") for x in v)
+
+
+def _library(tmp_path):
+    rng = np.random.default_rng(3)
+    files = {}
+
+    def put(name, blob):
+        p = str(tmp_path / name)
+        with open(p, "wb") as fh:
+            fh.write(blob)
+        files[name] = p
+
+    for bits in (8, 16, 24, 32):
+        for ch in (1, 2, 3):
+            put(f"pcm{bits}_{ch}.wav", _riff([(b"fmt ", _fmt(1, ch, 48000, bits), None), (b"data", _pcm(rng, 777 + bits + ch, ch, bits), None)]))
+    put("float_2.wav", _riff([(b"fmt ", _fmt(3, 2, 44100, 32), None), (b"data", _pcm(rng, 500, 2, 32, tag=3), None)]))
+    put("float_nan.wav", _riff([(b"fmt ", _fmt(3, 1, 48000, 32), None), (b"data", np.array([0.5, np.nan, -0.25], "<f4").tobytes(), None)]))
+    put("extensible.wav", _riff([(b"fmt ", _fmt(1, 2, 48000, 16, extensible_sub=1), None), (b"data", _pcm(rng, 300, 2, 16), None)]))
+    put("list_chunk_odd.wav", _riff([(b"LIST", b"abc", None), (b"fmt ", _fmt(1, 1, 22050, 16), None), (b"fact", b"\x01\x02\x03\x04", None),
+                                     (b"data", _pcm(rng, 123, 1, 16), None)]))
+    put("two_data_chunks.wav", _riff([(b"fmt ", _fmt(1, 1, 48000, 16), None), (b"data", _pcm(rng, 50, 1, 16), None),
+                                      (b"data", _pcm(rng, 70, 1, 16), None)]))
+    put("truncated_data.wav", _riff([(b"fmt ", _fmt(1, 1, 48000, 16), None), (b"data", _pcm(rng, 100, 1, 16), 100000)]))
+    put("ragged_frames.wav", _riff([(b"fmt ", _fmt(1, 2, 48000, 16), None), (b"data", _pcm(rng, 101, 1, 16), None)]))      # 101 samples, 2 channels
+    put("pcm24_partial.wav", _riff([(b"fmt ", _fmt(1, 1, 48000, 24), None), (b"data", _pcm(rng, 40, 1, 24) + b"\x01\x02", None)]))
+    put("silent.wav", _riff([(b"fmt ", _fmt(1, 1, 48000, 16), None), (b"data", b"\0" * 400, None)]))
+    put("empty.wav", _riff([(b"fmt ", _fmt(1, 1, 48000, 16), None), (b"data", b"", None)]))
+    # the ones read_wav refuses
+    put("odd_bytes_16.wav", _riff([(b"fmt ", _fmt(1, 1, 48000, 16), None), (b"data", b"\x01\x02\x03", None)]))
+    put("float64.wav", _riff([(b"fmt ", _fmt(3, 1, 48000, 64), None), (b"data", b"\0" * 64, None)]))
+    put("adpcm.wav", _riff([(b"fmt ", _fmt(2, 1, 48000, 4), None), (b"data", b"\0" * 64, None)]))
+    put("no_data.wav", _riff([(b"fmt ", _fmt(1, 1, 48000, 16), None)]))
+    put("no_fmt.wav", _riff([(b"data", b"\0" * 64, None)]))
+    put("short_fmt.wav", _riff([(b"fmt ", b"\x01\x00\x01\x00", None), (b"data", b"\0" * 64, None)]))
+    put("not_riff.wav", b"OggS" + b"\0" * 100)
+    put("tiny.wav", b"RIFF")
+    files["missing.wav"] = str(tmp_path / "missing.wav")
+    return files
+
+
+@pytest.mark.parametrize("threads", [1, 5])
+def test_batched_decode_is_read_wav_mean_normalize_bitwise(tmp_path, threads):
+    files = _library(tmp_path)
+    paths = list(files.values())
+    for norm in (False, True):
+        b = A.read_wav_batch(paths, normalize=norm, threads=threads)
+        assert b.offsets[0] == 0 and b.offsets[-1] == b.data.numel() and len(b.offsets) == len(paths) + 1
+        n_ok = 0
+        for i, (name, p) in enumerate(files.items()):
+            got = b.data[b.offsets[i]:b.offsets[i + 1]]
+            try:
+                x, sr = A.read_wav(p)
+            except Exception:
+                assert b.status[i] != 0 and got.numel() == 0, name
+                continue
+            n_ok += 1
+            assert b.status[i] == 0 and b.sample_rate[i] == sr, name
+            mono = torch.from_numpy(x.mean(axis=0, keepdims=True))[0]                        # load_audio's mean over channels
+            assert got.shape == mono.shape, name
+            if mono.numel():
+                peak = torch.max(torch.abs(mono))
+                assert np.array_equal(np.float32(b.peak[i]), peak.numpy(), equal_nan=True), name
+                want = mono / peak if norm else mono                                         # normalize(): x / max|x|
+            else:
+                want = mono
+            assert np.array_equal(got.numpy(), want.numpy(), equal_nan=True), name
+        assert n_ok == 22
+    assert A.read_wav_batch([]).data.numel() == 0
+
+
+def test_batched_copy_is_copy2(tmp_path):
+    files = _library(tmp_path)
+    srcs = [p for n, p in files.items() if os.path.exists(p)]
+    os.utime(srcs[0], ns=(1_600_000_000_123_456_789, 1_500_000_000_987_654_321))
+    os.chmod(srcs[1], 0o640)
+    (tmp_path / "out").mkdir()
+    dsts = [str(tmp_path / "out" / os.path.basename(p)) for p in srcs]
+    with open(dsts[2], "wb") as fh:                                   # an existing, longer destination is replaced
+        fh.write(b"x" * 1_000_000)
+    status = A.copy_files(srcs + [files["missing.wav"], srcs[0]], dsts + [str(tmp_path / "out" / "m.wav"), str(tmp_path / "nodir" / "a.wav")], threads=4)
+    assert status[:-2].tolist() == [0] * len(srcs) and status[-2] != 0 and status[-1] != 0
+    for s, d in zip(srcs, dsts):
+        ref = str(tmp_path / "ref.bin")
+        shutil.copy2(s, ref)
+        with open(d, "rb") as a, open(ref, "rb") as b:
+            assert a.read() == b.read()
+        sa, sb = os.stat(d), os.stat(ref)
+        assert sa.st_mode == sb.st_mode and sa.st_mtime_ns == sb.st_mtime_ns          # (atime moves with every read of the source)
+
+
+def test_bank_from_directory_matches_the_per_file_route(tmp_path):
+    """OneShotBank.from_directory decodes through the batched call; shot for shot it is read_wav -> mean -> x / peak, silent and
+    unreadable files skipped, duplicate stems suffixed, non-integer labels and shallow paths ignored."""
+    from adt_str_amd.bank import GROUPS, OneShotBank
+    rng = np.random.default_rng(5)
+    root = tmp_path / "aug"
+    expect = {}
+    for label in ("36", "38", "hat"):
+        for g in GROUPS[:2]:
+            (root / label / g).mkdir(parents=True)
+            for k in range(3):
+                ch = 1 + (k % 2)
+                x = (rng.standard_normal((ch, 200 + 10 * k)) * 0.2).astype(np.float32)
+                A.write_wav(str(root / label / g / f"s{k}.wav"), x, 16000)
+                if label != "hat":
+                    m = A.read_wav(str(root / label / g / f"s{k}.wav"))[0].mean(axis=0)
+                    expect[(int(label), g, f"s{k}")] = (m / float(np.abs(m).max())).astype(np.float32)
+    A.write_wav(str(root / "36" / GROUPS[0] / "silent.wav"), np.zeros(100, np.float32), 16000)
+    (root / "36" / GROUPS[0] / "junk.wav").write_bytes(b"not a wav file")
+    A.write_wav(str(root / "36" / "shallow.wav"), np.ones(10, np.float32) * 0.1, 16000)
+    bank = OneShotBank.from_directory(str(root), 16000)
+    assert bank.n_shots == len(expect) == 12
+    for (pitch, g, name), want in expect.items():
+        assert np.array_equal(bank.shot(bank.shot_id(pitch, g, name)), want), (pitch, g, name)
+    assert OneShotBank.from_directory(str(root), 8000).n_shots == 0      # another rate needs the GPU resampler: every file is skipped with a message
