@@ -165,3 +165,70 @@ def copy_files(srcs: Sequence[str], dsts: Sequence[str], threads: Optional[int] 
         _ffi.call("adt_copy_files", p1, p2, n, io_threads() if threads is None else threads, status.ctypes.data)
         del k1, k2
     return status
+
+
+_RESAMPLERS: dict = {}
+_PAD_BUDGET = 1 << 26            # elements of one padded [clips, longest] matrix handed to the resampler (256 MB of fp32)
+
+
+def load_clips_batch(paths: Sequence[str], sample_rate: int, device, normalize: bool = True, threads: Optional[int] = None,
+                     decoded: Optional[WavBatch] = None):
+    """The reference's per-file ``load -> mono -> Resample(sr, sample_rate) -> x / max|x|`` (data_modules/augment_data_with_CLAP.py:
+    51-68; convert_augmented_to_hdf5.py:97-103) for a batch: one batched decode into pinned memory, ONE host-to-device copy, the
+    resampler (K13) over zero-padded groups of equal source rate, peaks and the division on the GPU.  Bitwise the per-file result:
+    a clip's zero padding is what the resampler assumes past its end anyway, max|x| is exact and fp32 division is IEEE on both sides.
+
+    Returns ``(clips, peaks, status)``: ``clips[i]`` a 1-D fp32 tensor on ``device`` (None when ``status[i] != 0`` or the file is
+    empty), ``peaks[i]`` the clip's max|x| before the division (after resampling), ``status`` as in `read_wav_batch`.
+    ``decoded``: the files' ``read_wav_batch(paths, normalize=False, pin=True)`` when a worker thread has already produced it."""
+    import torch
+    from .resample import Resample
+    device = torch.device(device)
+    b = decoded if decoded is not None else read_wav_batch(paths, normalize=False, pin=device.type == "cuda", threads=threads)
+    n = len(paths)
+    lens = np.diff(b.offsets)
+    ok = (b.status == 0) & (lens > 0)
+    dev = b.data.to(device, non_blocking=True)
+    off = b.offsets.tolist()
+    clips: list = [None] * n
+    peaks = torch.zeros(n, dtype=torch.float32, device=device)
+    same = ok & (b.sample_rate == sample_rate)
+    if same.any():
+        # peaks of the clips already at the target rate came with the decode; divide the whole buffer once (other clips: by 1)
+        pk = torch.from_numpy(np.where(same, b.peak, np.float32(1.0)).astype(np.float32)).to(device)
+        peaks = torch.where(torch.from_numpy(same).to(device), pk, peaks)
+        if normalize:
+            dev = dev / torch.repeat_interleave(pk, torch.from_numpy(lens).to(device), output_size=int(b.offsets[-1]))
+        for i in np.nonzero(same)[0]:
+            clips[i] = dev[off[i]:off[i + 1]]
+    for sr in sorted(set(b.sample_rate[ok & ~same].tolist())):
+        key = (int(sr), int(sample_rate))
+        if key not in _RESAMPLERS:
+            _RESAMPLERS[key] = Resample(*key)
+        rs = _RESAMPLERS[key]
+        idx = np.nonzero(ok & (b.sample_rate == sr))[0]
+        idx = idx[np.argsort(lens[idx], kind="stable")]              # neighbours in length share a padded matrix
+        lo = 0
+        while lo < len(idx):
+            hi = lo + 1
+            while hi < len(idx) and (hi + 1 - lo) * int(lens[idx[hi]]) <= _PAD_BUDGET:
+                hi += 1
+            part = idx[lo:hi]
+            ln = torch.from_numpy(lens[part]).to(device)
+            width = int(lens[part[-1]])
+            padded = torch.zeros((len(part), width), dtype=torch.float32, device=device)
+            src = torch.cat([dev[off[i]:off[i + 1]] for i in part])
+            padded[torch.arange(width, device=device)[None, :] < ln[:, None]] = src           # row-major mask order == concatenation order
+            out = rs(padded)
+            out_len_h = -((-lens[part] * rs.new) // rs.orig)                                   # ceil(new * L / orig) per clip
+            out_len = torch.from_numpy(out_len_h).to(device)
+            valid = torch.arange(out.shape[1], device=device)[None, :] < out_len[:, None]
+            pk = torch.where(valid, out.abs(), torch.zeros((), device=device)).amax(dim=1)
+            pk = torch.where((out != out).logical_and(valid).any(dim=1), torch.full_like(pk, float("nan")), pk)
+            if normalize:
+                out = out / pk[:, None]
+            peaks[torch.from_numpy(part).to(device)] = pk
+            for r, i in enumerate(part):
+                clips[i] = out[r, :int(out_len_h[r])]
+            lo = hi
+    return clips, peaks, b.status

@@ -121,18 +121,29 @@ class OneShotBank:
                 raise ValueError("silent or empty file")
             return (x / peak).astype(np.float32)
 
-        # files at the bank's rate: decoded, down-mixed and normalised a few thousand per call on the library's thread pool
-        # (audio_io.read_wav_batch: read_wav(path)[0].mean(axis=0) / peak, bitwise); the shots are views of the batch buffers
-        for lo in range(0, len(todo), 8192):
-            part = todo[lo:lo + 8192]
-            b = read_wav_batch([t[0] for t in part], normalize=True)
-            data = b.data.numpy()
+        # decoded, down-mixed, (on a GPU) resampled and normalised a few thousand files per call (audio_io.read_wav_batch /
+        # load_clips_batch: read_wav(path)[0].mean(axis=0) -> K13 -> x / peak, bitwise); the shots are views of the batch buffers
+        from .audio_io import load_clips_batch
+        gpu = device is not None and torch.device(device).type == "cuda"
+        for lo in range(0, len(todo), 4096):
+            part = todo[lo:lo + 4096]
+            paths = [t[0] for t in part]
+            if gpu:
+                clips, peaks, status = load_clips_batch(paths, sample_rate, device, normalize=True)
+                good = [c is not None for c in clips]
+                flat = torch.cat([c for c in clips if c is not None]).cpu().numpy() if any(good) else np.zeros(0, np.float32)
+                ends = np.cumsum([c.numel() if c is not None else 0 for c in clips])
+                peaks = peaks.cpu().numpy()
+            else:
+                b = read_wav_batch(paths, normalize=True)
+                good = ((b.status == 0) & (b.sample_rate == sample_rate)).tolist()
+                flat, ends, peaks = b.data.numpy(), b.offsets[1:], b.peak
             for j, (path, label, group, stem) in enumerate(part):
                 try:
-                    if b.status[j] == 0 and b.sample_rate[j] == sample_rate:
-                        if not b.peak[j] > 0.0:
+                    if good[j]:
+                        if not peaks[j] > 0.0:
                             raise ValueError("silent or empty file")
-                        x = data[b.offsets[j]:b.offsets[j + 1]]
+                        x = flat[ends[j - 1] if j else 0:ends[j]]
                     else:
                         x = per_file(path)                            # raises what read_wav raises for an unreadable file
                 except Exception as e:

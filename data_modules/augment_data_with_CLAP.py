@@ -63,16 +63,14 @@ def _load_normalized(path, sample_rate):
     return normalize(load_audio(path, sample_rate))
 
 
-def _load_batch(paths, sample_rate, device):
-    """The batch's clips as the reference prepares them (load -> mono -> resample -> x / max|x|, :51-68), on ``device``.
-    Files already at ``sample_rate`` -- the whole library, normally -- are decoded, down-mixed and normalised by one batched call
-    into pinned memory (adt_str_amd.audio_io.read_wav_batch: the per-file arithmetic, bitwise) and cross PCIe in ONE copy; the
-    rest (another rate, unreadable, empty) take the per-file route, which also raises what the reference would."""
-    from adt_str_amd.audio_io import read_wav_batch
-    b = read_wav_batch(paths, normalize=True, pin=True)
-    fast = (b.status == 0) & (b.sample_rate == sample_rate) & (np.diff(b.offsets) > 0)
-    slow = {i: _load_normalized(paths[i], sample_rate) for i in np.nonzero(~fast)[0]}
-    return b, fast, slow
+def _load_batch(paths, sample_rate, device, decoded):
+    """The batch's clips as the reference prepares them (load -> mono -> resample -> x / max|x|, :51-68), [1, L] each on
+    ``device``: one batched decode (``decoded``, made by the I/O thread), one copy across PCIe, resampling (K13) and the
+    normalisation batched on the GPU (adt_str_amd.audio_io.load_clips_batch: the per-file arithmetic, bitwise).  A file that
+    cannot be decoded, or is empty, takes the per-file route, which raises what the reference would."""
+    from adt_str_amd.audio_io import load_clips_batch
+    clips, _, _ = load_clips_batch(paths, sample_rate, device, normalize=True, decoded=decoded)
+    return [c[None] if c is not None else _load_normalized(paths[j], sample_rate).to(device) for j, c in enumerate(clips)]
 
 
 def _embed(wrapper, files, batch_size, sample_rate):
@@ -87,16 +85,16 @@ def _embed(wrapper, files, batch_size, sample_rate):
     mine = list(range(rank, len(files), world))
     chunks = []
     starts = list(range(0, len(mine), batch_size))
-    device = wrapper.device
+    device = torch.device(wrapper.device)
+    from adt_str_amd.audio_io import read_wav_batch
     with ThreadPoolExecutor(max_workers=1, thread_name_prefix="adt-curation-io") as pool:
-        submit = lambda i: pool.submit(_load_batch, [files[j] for j in mine[i:i + batch_size]], sample_rate, device)
+        names = lambda i: [files[j] for j in mine[i:i + batch_size]]
+        submit = lambda i: pool.submit(read_wav_batch, names(i), False, device.type == "cuda")
         pending = submit(starts[0]) if starts else None
         for k, i in enumerate(starts):
-            b, fast, slow = pending.result()
+            decoded = pending.result()
             pending = submit(starts[k + 1]) if k + 1 < len(starts) else None      # decode the next batch while this one is embedded
-            dev_data = b.data.to(device, non_blocking=True)
-            off = b.offsets.tolist()
-            batch = [dev_data[off[j]:off[j + 1]][None] if fast[j] else slow[j].to(device) for j in range(len(fast))]     # [1, L] each, like the reference's
+            batch = _load_batch(names(i), sample_rate, device, decoded)
             chunks.append(wrapper.get_audio_features(batch).float())
     local = torch.cat(chunks) if chunks else torch.zeros((0, 512), device=wrapper.device)
     if world == 1:
@@ -162,13 +160,13 @@ def run(cfg: dict, num_bins: int = 10, clap_model=None, copy: bool = True):
         # destination -> source in the reference's copy order (descending score; a later copy onto the same destination
         # overwrites an earlier one, :184-196), then the copies themselves in parallel: every destination is written once
         plan = {}
+        root_s = str(augmented_root)
         for i, label, bin_label in zip(res.order.tolist(), res.label.tolist(), res.bin):
-            plan[augmented_root / str(label) / bin_label / Path(wav_files[i]).name] = wav_files[i]
-        for d in {dst.parent for dst in plan}:
-            d.mkdir(parents=True, exist_ok=True)
-
+            plan[os.path.join(root_s, str(label), bin_label, os.path.basename(wav_files[i]))] = wav_files[i]
+        for d in {os.path.dirname(dst) for dst in plan}:
+            os.makedirs(d, exist_ok=True)
         from adt_str_amd.audio_io import copy_files
-        dsts, srcs = [str(d) for d in plan], [str(v) for v in plan.values()]
+        dsts, srcs = list(plan), list(plan.values())
         status = copy_files(srcs, dsts)                    # shutil.copy2 per pair (contents, mode, times) on the library's thread pool
         for j in np.nonzero(status)[0]:                    # the reference logs and carries on (:195-196)
             print(f"Failed to copy {srcs[j]} -> {os.path.dirname(dsts[j])}")

@@ -152,7 +152,10 @@ def main(argv=None):
                 "clap_config": {"model_name": "laion/clap-htsat-fused (random init)", "batch_size": a.clap_batch,
                                 "sample_pack_root": pack_root, "reference_root": ref_root}}
     t0 = time.perf_counter()
-    res, wav_files, aug_root = aug.run(cfg_clap, num_bins=10, clap_model=random_init_clap_model(0))
+    clap_model = random_init_clap_model(0)             # stands in for ClapModel.from_pretrained (no checkpoints on the box): timed apart
+    times["clap_model_init_s"] = time.perf_counter() - t0
+    t0 = time.perf_counter()
+    res, wav_files, aug_root = aug.run(cfg_clap, num_bins=10, clap_model=clap_model)
     barrier()
     times["curate_s"] = time.perf_counter() - t0
     times["curate_phases_s"] = dict(aug.PHASE_SECONDS)
