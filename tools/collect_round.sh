@@ -1,7 +1,8 @@
 # usage: bash tools/collect_round.sh <tag> <dest>   -- copy what tools/run_round.sh / run_pmc_*.sh left under gpurun_out/ into profiles/<dest>/
 TAG=$1; P=profiles/$2; O=gpurun_out/round_$TAG
 mkdir -p $P
-for f in bench_train.json bench_train_nodropout.json bench_logmel.json bench_clap.json e2e_config4_scaled.json; do cp $O/$f $P/$f; done
+for f in bench_train.json bench_train_nodropout.json bench_logmel.json bench_clap.json e2e_config4_scaled.json bench_train_torchrun1.json bench_train_torchrun1_bf16comm.json; do [ -f $O/$f ] && cp $O/$f $P/$f; done
+[ -f $O/bench_hf_trainer.txt ] && grep -v amdgpu.ids $O/bench_hf_trainer.txt > $P/bench_hf_trainer.txt
 grep -v amdgpu.ids $O/bench_kernels.txt > $P/bench_kernels.txt
 cp $O/smoke.log $P/smoke.txt
 tail -3 $O/pytest_gpu.log > $P/pytest_gpu.txt
@@ -12,4 +13,5 @@ cp $O/prof_roofline/*/*kernel_stats.csv $P/roofline_gemm_kernel_stats.csv
 [ -f gpurun_out/gemm_pmc_summary_$TAG.json ] && cp gpurun_out/gemm_pmc_summary_$TAG.json $P/gemm_pmc_summary.json
 [ -f gpurun_out/logmel_pmc_summary_$TAG.json ] && cp gpurun_out/logmel_pmc_summary_$TAG.json $P/logmel_pmc_summary.json
 [ -f gpurun_out/attn_pmc_$TAG.txt ] && cp gpurun_out/attn_pmc_$TAG.txt $P/attn_pmc.txt
+[ -f gpurun_out/clap_pmc_$TAG.txt ] && cp gpurun_out/clap_pmc_$TAG.txt $P/clap_pmc.txt
 ls $P
