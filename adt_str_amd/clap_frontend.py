@@ -88,7 +88,9 @@ class ClapLogMel:
         if len(ranges[2]) == 0:
             ranges[2] = [0]
         i_front, i_mid, i_back = (int(np.random.choice(r)) for r in ranges)       # the extractor's draws, in its order
-        shrink = torch.nn.functional.interpolate(mel[None, None], size=[N_FRAMES, N_MELS], mode="bilinear", align_corners=False)[0, 0]
+        shrink = torch.empty((N_FRAMES, N_MELS), dtype=torch.float32, device=self.device)       # F.interpolate(bilinear, align_corners=False)
+        _ffi.call("adt_bilinear_resize_f32", _ffi.dptr(mel), total, N_MELS, mel.stride(0), _ffi.dptr(shrink), N_FRAMES, N_MELS, N_MELS,
+                  _ffi.current_stream())
         return torch.stack([shrink, mel[i_front:i_front + N_FRAMES], mel[i_mid:i_mid + N_FRAMES], mel[i_back:i_back + N_FRAMES]]), True
 
     def features(self, clips: Sequence):

@@ -144,3 +144,45 @@ extern "C" int adt_clap_logmel_db_f32(const float* waves, const int64_t* offsets
   ADT_HIP_TRY(hipGetLastError());
   return ADT_OK;
 }
+
+// ------------------------------------------------------------------------------------ bilinear resize (fusion "shrink" mel)
+// torch.nn.functional.interpolate(x[None, None], size=[H_out, W_out], mode="bilinear", align_corners=False) as the feature
+// extractor calls it for clips longer than 10 s (transformers feature_extraction_clap.py, _random_mel_fusion): source index
+// max(scale * (dst + 0.5) - 0.5, 0) with scale = in / out in fp32, neighbour clamped at the edge, and the four-term blend in
+// torch's operand order.
+namespace adt {
+__global__ __launch_bounds__(256) void bilinear_resize_kernel(const float* __restrict__ in, int H_in, int W_in, long ld_in,
+                                                              float* __restrict__ out, int H_out, int W_out, long ld_out,
+                                                              float scale_h, float scale_w) {
+  const long i = static_cast<long>(blockIdx.x) * 256 + threadIdx.x;
+  if (i >= static_cast<long>(H_out) * W_out) return;
+  const int h2 = static_cast<int>(i / W_out), w2 = static_cast<int>(i - static_cast<long>(h2) * W_out);
+  const float h1r = fmaxf(__fsub_rn(__fmul_rn(scale_h, static_cast<float>(h2) + 0.5f), 0.5f), 0.f);
+  const float w1r = fmaxf(__fsub_rn(__fmul_rn(scale_w, static_cast<float>(w2) + 0.5f), 0.5f), 0.f);
+  const int h1 = static_cast<int>(h1r), w1 = static_cast<int>(w1r);
+  const int h1p = h1 < H_in - 1 ? 1 : 0, w1p = w1 < W_in - 1 ? 1 : 0;
+  const float h1l = h1r - static_cast<float>(h1), h0l = 1.f - h1l;
+  const float w1l = w1r - static_cast<float>(w1), w0l = 1.f - w1l;
+  const float* r0 = in + static_cast<long>(h1) * ld_in;
+  const float* r1 = in + static_cast<long>(h1 + h1p) * ld_in;
+  const float top = __fadd_rn(__fmul_rn(w0l, r0[w1]), __fmul_rn(w1l, r0[w1 + w1p]));
+  const float bot = __fadd_rn(__fmul_rn(w0l, r1[w1]), __fmul_rn(w1l, r1[w1 + w1p]));
+  out[static_cast<long>(h2) * ld_out + w2] = __fadd_rn(__fmul_rn(h0l, top), __fmul_rn(h1l, bot));
+}
+}  // namespace adt
+
+extern "C" int adt_bilinear_resize_f32(const float* in, int64_t H_in, int64_t W_in, int64_t ld_in, float* out, int64_t H_out, int64_t W_out,
+                                       int64_t ld_out, void* stream) {
+  using namespace adt;
+  if (!in || !out) return set_error(ADT_EINVAL, "adt_bilinear_resize_f32: null pointer");
+  if (H_in <= 0 || W_in <= 0 || H_out < 0 || W_out < 0 || ld_in < W_in || ld_out < W_out || H_in > (1 << 30) || H_out > (1 << 30))
+    return set_error(ADT_ESHAPE, "adt_bilinear_resize_f32: bad sizes");
+  const long n = static_cast<long>(H_out) * W_out;
+  if (n == 0) return ADT_OK;
+  const float sh = static_cast<float>(H_in) / static_cast<float>(H_out), sw = static_cast<float>(W_in) / static_cast<float>(W_out);
+  hipLaunchKernelGGL(bilinear_resize_kernel, dim3(static_cast<unsigned>((n + 255) / 256)), dim3(256), 0, static_cast<hipStream_t>(stream), in,
+                     static_cast<int>(H_in), static_cast<int>(W_in), static_cast<long>(ld_in), out, static_cast<int>(H_out), static_cast<int>(W_out),
+                     static_cast<long>(ld_out), sh, sw);
+  ADT_HIP_TRY(hipGetLastError());
+  return ADT_OK;
+}

@@ -55,6 +55,19 @@ __device__ __forceinline__ float quad_xor(float v) {
   return __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, v), kCtrl, 0xf, 0xf, true));
 }
 
+// A band as the kernel will use it: first bin inside the spectrum, at most 127 bins that stay inside it, weights inside mel_w.
+// MelBands (adt_str_amd/frontend.py) only builds such bands; a malformed table handed to the C entry directly is cut down to
+// something in range here (its output is then meaningless, but no LDS or global index leaves its array).
+__device__ __forceinline__ int4 sane_band(int4 m, int mel_nnz) {
+  const int bins = kNfft / 2 + 1;
+  m.x = m.x < 0 ? 0 : (m.x > bins - 1 ? bins - 1 : m.x);
+  int n = m.y < 0 ? 0 : (m.y > 127 ? 127 : m.y);
+  n = n > bins - m.x ? bins - m.x : n;
+  if (m.z < 0 || m.z > mel_nnz - n) n = 0;
+  m.y = n;
+  return m;
+}
+
 __global__ __launch_bounds__(kThreads) void logmel_kernel(LogmelArgs a) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   cf* t1k = reinterpret_cast<cf*>(smem);                                 // [1024]  W_1024^j, the whole circle
@@ -89,7 +102,7 @@ __global__ __launch_bounds__(kThreads) void logmel_kernel(LogmelArgs a) {
     int trips = 0;
     for (int g = 0; g < 16; ++g) {
       const int j = g + 16 * tid;
-      const int c = j < a.n_mels ? (a.mel_meta[j].y + 3) >> 2 : 0;
+      const int c = j < a.n_mels ? (sane_band(a.mel_meta[j], a.mel_nnz).y + 3) >> 2 : 0;
       trips = c > trips ? c : trips;
     }
     bands[128 + tid] = static_cast<unsigned>(trips);
@@ -104,8 +117,8 @@ __global__ __launch_bounds__(kThreads) void logmel_kernel(LogmelArgs a) {
   const bool uniform_pad = item_total <= kMaxMelPad;   // block-uniform
   if (tid < 128) {
     int poff = 0;                                       // offset of band `tid` in the padded weight array
-    for (int j = 0; j < tid && j < a.n_mels; ++j) poff += uniform_pad ? 4 * static_cast<int>(bands[128 + (j >> 4)]) : (a.mel_meta[j].y + 3) & ~3;
-    const int4 m = (tid < a.n_mels) ? a.mel_meta[tid] : make_int4(0, 0, 0, 0);
+    for (int j = 0; j < tid && j < a.n_mels; ++j) poff += uniform_pad ? 4 * static_cast<int>(bands[128 + (j >> 4)]) : (sane_band(a.mel_meta[j], a.mel_nnz).y + 3) & ~3;
+    const int4 m = (tid < a.n_mels) ? sane_band(a.mel_meta[tid], a.mel_nnz) : make_int4(0, 0, 0, 0);
     bands[tid] = static_cast<unsigned>(m.x) | (static_cast<unsigned>(poff) << 11) | (static_cast<unsigned>((m.y + 3) >> 2) << 24);
     for (int t = 0; t < m.y; ++t) melw[poff + t] = a.mel_w[m.z + t];
   }
@@ -210,7 +223,8 @@ extern "C" int adt_logmel_f32(const float* wave, int64_t n_clips, int64_t n_samp
   if (n_fft != kNfft) return set_error(ADT_ESHAPE, "adt_logmel_f32: only n_fft == 2048 is supported");
   if (n_mels <= 0 || n_mels > 128 || (n_mels & 3)) return set_error(ADT_ESHAPE, "adt_logmel_f32: n_mels must be a multiple of 4 in [4,128]");
   if (mel_nnz < 0 || mel_nnz > kMaxMelNnz) return set_error(ADT_ESHAPE, "adt_logmel_f32: filterbank has too many non-zeros");
-  // (mel_meta is validated by the caller's MelBands: bands inside [0, n_fft/2], at most 127 bins each, offsets inside mel_w)
+  // (mel_meta lives in device memory: the host side validates it when it builds it (MelBands), the kernel clamps every band into
+  //  range when it sets up its tables: sane_band)
   if (n_samples >= (1ll << 30)) return set_error(ADT_ESHAPE, "adt_logmel_f32: n_samples must be below 2^30");
   if (n_samples <= n_fft / 2) return set_error(ADT_ESHAPE, "adt_logmel_f32: n_samples must exceed n_fft/2 (reflect padding)");
   // the last frame asked for must exist: frame t needs t*hop <= n_samples (1 + L//hop frames)

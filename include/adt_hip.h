@@ -63,7 +63,11 @@ int adt_debug_occupy(int32_t n_wg, int32_t lds_bytes, int32_t micros, void* stre
  *   window    [n_fft] fp32                      (state dict: ...spectrogram.window)
  *   mel_meta  [n_mels][4] int32 = {first_bin, n_bins, offset into mel_w, 0}:
  *             the banded (CSR) form of the filterbank fb[n_fft/2+1, n_mels]
- *             (state dict: ...mel_scale.fb); mel_w holds the non-zero weights
+ *             (state dict: ...mel_scale.fb); mel_w holds the non-zero weights.
+ *             Precondition (device memory, not checked by the entry point): first_bin in
+ *             [0, n_fft/2], 0 <= n_bins <= 127, first_bin + n_bins <= n_fft/2 + 1,
+ *             offset + n_bins <= mel_nnz.  A band that violates it is clamped into range by
+ *             the kernel (no out-of-range access; that band's output is then undefined).
  *   out       [n_clips, n_out, n_mels] fp32, fully overwritten:
  *             out[b,f,j] = (clamp(log(mel[b, frame_lo+f, j] + log_eps), lo, hi) - lo) / (hi - lo)
  *
@@ -417,6 +421,12 @@ int adt_adamw_step(float* p, const float* g, float* m, float* v, void* p_bf16, i
 int adt_clap_logmel_db_f32(const float* waves, const int64_t* offsets, int64_t n_clips, int32_t target_len, int32_t n_fft,
                            int32_t hop, int32_t n_frames, const float* window, const int32_t* mel_meta, const float* mel_w,
                            int32_t n_mels, int32_t mel_nnz, float amin, float* out, void* stream);
+
+/* Bilinear resize of one fp32 image [H_in, W_in] -> [H_out, W_out]: torch.nn.functional.interpolate(mode="bilinear",
+ * align_corners=False) as ClapFeatureExtractor's fusion truncation calls it to shrink the whole mel of a clip longer than 10 s to
+ * [1001, 64] (transformers feature_extraction_clap.py: _random_mel_fusion; reached from clap_encoder.py:22-23). */
+int adt_bilinear_resize_f32(const float* in, int64_t H_in, int64_t W_in, int64_t ld_in, float* out, int64_t H_out, int64_t W_out,
+                            int64_t ld_out, void* stream);
 
 /* ---------------------------------------------------------------------------
  * K10/K11  HTSAT (audio Swin) specific kernels, forward only

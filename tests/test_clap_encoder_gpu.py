@@ -248,3 +248,17 @@ def test_full_size_batch_properties(setup):
     small = w.get_audio_features([clips[i] for i in pick], is_longer=flags[pick])
     cos = (emb[pick] * small).sum(-1)
     assert cos.min() > 0.9999 and (emb[pick] - small).abs().max() < 5e-3
+
+
+@pytest.mark.parametrize("h_in,w_in,h_out,w_out", [(2345, 64, 1001, 64), (1002, 64, 1001, 64), (37, 5, 80, 11), (1, 1, 4, 3)])
+def test_bilinear_resize_is_torch_interpolate(h_in, w_in, h_out, w_out):
+    """K9's companion for clips longer than 10 s: the extractor shrinks the whole mel with F.interpolate(bilinear,
+    align_corners=False) (feature_extraction_clap.py, _random_mel_fusion)."""
+    from adt_str_amd import _ffi
+    x = torch.randn(h_in, w_in + 3, device="cuda:0")[:, :w_in]                     # a strided view: ld_in != W_in
+    out = torch.empty((h_out, w_out), device="cuda:0")
+    _ffi.call("adt_bilinear_resize_f32", _ffi.dptr(x), h_in, w_in, x.stride(0), _ffi.dptr(out), h_out, w_out, w_out, _ffi.current_stream())
+    ref = torch.nn.functional.interpolate(x.cpu().contiguous()[None, None], size=[h_out, w_out], mode="bilinear", align_corners=False)[0, 0]
+    assert (out.cpu() - ref).abs().max() <= 1e-6 * max(1.0, ref.abs().max().item())
+    with pytest.raises(_ffi.AdtError):
+        _ffi.call("adt_bilinear_resize_f32", _ffi.dptr(x), 0, w_in, x.stride(0), _ffi.dptr(out), h_out, w_out, w_out, _ffi.current_stream())

@@ -117,6 +117,42 @@ def test_c_abi_rejects_bad_shapes(dev):
     assert e.value.code == -2
 
 
+def test_c_abi_clamps_a_malformed_band_table(dev):
+    """mel_meta is device memory the entry point cannot inspect: the kernel cuts every band into range when it builds its tables
+    (include/adt_hip.h, K1 precondition), so a table with negative / oversized / out-of-array bands neither faults nor touches
+    the well-formed bands' outputs."""
+    from adt_str_amd import _ffi
+    from adt_str_amd.frontend import MelBands
+    rng = np.random.default_rng(9)
+    wave = torch.from_numpy((rng.standard_normal((2, 8000)) * 0.2).astype(np.float32)).to(dev)
+    fb = o_logmel.mel_filterbank(16000, 2048, 128).numpy() if hasattr(o_logmel, "mel_filterbank") else None
+    if fb is None:
+        pytest.skip("oracle filterbank helper not available")
+    bands = MelBands.from_dense(fb)
+    window = torch.hann_window(2048, periodic=True, device=dev)
+    n_out = 1 + 8000 // 160 - 7 - 8
+
+    def run(meta):
+        out = torch.full((2, n_out, 128), float("nan"), device=dev)
+        m, w = torch.from_numpy(meta).to(dev), torch.from_numpy(bands.weights).to(dev)
+        _ffi.call("adt_logmel_f32", wave.data_ptr(), 2, 8000, 8000, 2048, 160, 7, n_out, window.data_ptr(), m.data_ptr(), w.data_ptr(), 128,
+                  len(bands.weights), 1e-10, -23.0, 12.0, out.data_ptr(), _ffi.current_stream())
+        torch.cuda.synchronize()
+        return out
+
+    good = run(bands.meta)
+    bad = bands.meta.copy()
+    bad[3] = (-50, 40, 0, 0)                 # negative first bin
+    bad[17] = (1000, 5000, 10, 0)            # far too wide
+    bad[40] = (2000, 100, 0, 0)              # runs past the spectrum
+    bad[90] = (100, 20, 10 ** 6, 0)          # weights outside mel_w
+    bad[91] = (100, 20, -5, 0)
+    got = run(bad)
+    assert torch.isfinite(got).all()
+    keep = [j for j in range(128) if j not in (3, 17, 40, 90, 91)]
+    assert torch.equal(got[:, :, keep], good[:, :, keep])
+
+
 @pytest.mark.parametrize("n_mels,sr", [(64, 16000), (40, 16000), (80, 22050), (128, 48000)])
 def test_other_filterbanks_take_both_band_layouts(dev, n_mels, sr):
     """The mel reduction pads every band of an item to the item's trip count when that fits the LDS table (128-mel banks) and
