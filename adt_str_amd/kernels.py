@@ -45,6 +45,12 @@ def _workspace(nbytes: int, device) -> torch.Tensor:
     return buf
 
 
+# Measurement tap (bench.py): {"match": callable(trans, M, N, K, epilogue) -> bool, "events": []}.  While set, every matching
+# adt_gemm_bf16 launch is bracketed by a pair of HIP events on the launch stream, so a kernel can be timed where the workload
+# launches it -- among the step's other kernels -- instead of in a loop of its own.
+gemm_tap = None
+
+
 def gemm(a: torch.Tensor, b: torch.Tensor, *, trans: bool = False, out: Optional[torch.Tensor] = None,
          out_dtype=torch.bfloat16, bias: Optional[torch.Tensor] = None, residual: Optional[torch.Tensor] = None,
          res_row_mod: int = 0, act: int = 0, pre_act_out: Optional[torch.Tensor] = None,
@@ -108,9 +114,18 @@ def gemm(a: torch.Tensor, b: torch.Tensor, *, trans: bool = False, out: Optional
         ep.colsum_out = _ffi.dptr(colsum_out)
         ws_bytes = _ffi.load().adt_gemm_colsum_workspace_bytes(M, N)
     ws = _workspace(ws_bytes, a.device) if ws_bytes else None
+    tap = gemm_tap
+    timed = tap is not None and tap["match"](trans, M, N, K, ep)
+    if timed:
+        e0 = torch.cuda.Event(enable_timing=True)
+        e0.record()
     _ffi.call("adt_gemm_bf16", int(trans), M, N, K, _ffi.dptr(a), a.stride(0), _ffi.dptr(b), b.stride(0),
               _ffi.dptr(out), out.stride(0), C.byref(ep), _ffi.dptr(ws) if ws is not None else None, ws_bytes,
               _ffi.current_stream())
+    if timed:
+        e1 = torch.cuda.Event(enable_timing=True)
+        e1.record()
+        tap["events"].append((e0, e1))
     return out
 
 

@@ -310,27 +310,44 @@ def train_setup(dev, seed, world, dropout, fx_prob=0.0, process_group=None, grad
         fence()
         return time.perf_counter() - t0
 
-    def roofline():
-        # dominant kernel: the NT bf16 GEMM; measured on the FFN-1 shape of this very step
-        M, N, Kd = B * F, 3072, 768
+    # The dominant kernel -- the NT bf16 GEMM at the encoder's FFN linear1 (bias + GELU + dropout + saved gelu' * keep factor) -- is
+    # timed WHERE THE STEP LAUNCHES IT: every such launch inside the timed region is bracketed by HIP events on the launch stream
+    # (kernels.gemm_tap), 4 per step.  `--roofline-loop` adds the earlier rounds' measurement (the same launch back to back, alone).
+    Mr, Nr, Kr = B * F, 3072, 768
+    tap = {"match": lambda trans, M, N, Kd, ep: (not trans) and (M, N, Kd) == (Mr, Nr, Kr) and ep.act == 1 and ep.act_grad_mode == 1,
+           "events": []}
+
+    def tap_on(on):
+        K.gemm_tap = tap if on else None
+
+    def roofline(loop=False):
+        M, N, Kd = Mr, Nr, Kr
+        torch.cuda.synchronize()
+        in_step = sorted(e0.elapsed_time(e1) for e0, e1 in tap["events"])
+        fl = 2.0 * M * N * Kd
+        site = K.drop_site(dropout, 1, 5)            # the step's own call: bias + GELU + dropout + saved gelu' * keep factor
         a = torch.randn((M, Kd), device=dev).bfloat16()
         w = torch.randn((N, Kd), device=dev).bfloat16()
         bias = torch.zeros(N, device=dev)
-        u = torch.empty((M, N), dtype=torch.bfloat16, device=dev)
-        # The chip idles while the operands above are made; the first ~30 launches after that are a boost -> throttle transient
-        # (0.42 -> 0.54 -> 0.46 ms, profiles/r01/README.md), so they are not timed: what is reported is the sustained-load duration.
-        n_warm, n_timed = 40, 60
-        site = K.drop_site(dropout, 1, 5)            # the step's own call: bias + GELU + dropout + saved gelu' * keep factor
-        for _ in range(n_warm):
-            K.gemm(a, w, bias=bias, act=1, act_grad_out=u, drop=site)
         ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        ev0.record()
-        for _ in range(n_timed):
-            K.gemm(a, w, bias=bias, act=1, act_grad_out=u, drop=site)
-        ev1.record()
-        torch.cuda.synchronize()
-        ms = ev0.elapsed_time(ev1) / n_timed
-        fl = 2.0 * M * N * Kd
+        back_to_back = None
+        if loop or not in_step:
+            u = torch.empty((M, N), dtype=torch.bfloat16, device=dev)
+            # The chip idles while the operands above are made; the first ~30 launches after that are a boost -> throttle transient
+            # (0.42 -> 0.54 -> 0.46 ms, profiles/r01/README.md), so they are not timed: what is reported is the sustained-load duration.
+            n_warm, n_timed = 40, 60
+            for _ in range(n_warm):
+                K.gemm(a, w, bias=bias, act=1, act_grad_out=u, drop=site)
+            ev0.record()
+            for _ in range(n_timed):
+                K.gemm(a, w, bias=bias, act=1, act_grad_out=u, drop=site)
+            ev1.record()
+            torch.cuda.synchronize()
+            t = ev0.elapsed_time(ev1) / n_timed
+            back_to_back = {"kernel_ms": t, "achieved": fl / (t * 1e-3) / 1e12, "launches": n_timed,
+                            "how": "the same launch alone, back to back, after 40 untimed launches"}
+            del u
+        ms = sum(in_step) / len(in_step) if in_step else back_to_back["kernel_ms"]
         ach = fl / (ms * 1e-3) / 1e12
         # the same GEMM in the two cheaper forms earlier rounds quoted: round 1's epilogue (bias + GELU + saved pre-activation, no
         # dropout) and the bare bf16 product (what a library GEMM does), so that rounds can be compared like for like
@@ -354,8 +371,11 @@ def train_setup(dev, seed, world, dropout, fx_prob=0.0, process_group=None, grad
                           % ("true" if site else "false", " + dropout" if site else "", M, N, Kd),
                 "kernel_ms": ms, "algorithmic_flops_per_launch": fl,
                 "algorithmic_bytes_per_launch": 2.0 * (M * Kd + N * Kd + 2 * M * N),
-                "profile": "%s (rocprofv3 --kernel-trace --stats of tools/pmc_gemm.py: this kernel alone at this shape, 300 launches)"
-                           % (newest_profile("roofline_gemm_kernel_stats.csv") or "no committed profile")}
+                "timed": ("%d launches inside the timed steps, HIP events around each on the launch stream (median %.4f, min %.4f, max %.4f ms)"
+                          % (len(in_step), in_step[len(in_step) // 2], in_step[0], in_step[-1])) if in_step else "back-to-back loop (no launch of this form inside the timed steps)",
+                "back_to_back": back_to_back,
+                "profile": "%s (rocprofv3 --kernel-trace --stats of this command: the kernel's launches among the step's others); %s (the kernel alone, back to back, 300 launches)"
+                           % (newest_profile("train_step_kernel_stats.csv") or "no committed profile", newest_profile("roofline_gemm_kernel_stats.csv") or "no committed profile")}
 
     def cpu_baseline(budget_s=20.0):
         from oracle import adt as o_adt
@@ -380,7 +400,7 @@ def train_setup(dev, seed, world, dropout, fx_prob=0.0, process_group=None, grad
     def comm():
         return trainer.reducer.comm_stats() if trainer.reducer is not None else None
 
-    return {"step": step, "units": B, "dtype": "bf16", "roofline": roofline, "cpu_baseline": cpu_baseline, "state": state,
+    return {"step": step, "units": B, "dtype": "bf16", "roofline": roofline, "tap": tap_on, "cpu_baseline": cpu_baseline, "state": state,
             "flops_per_step": flops_clip * B, "e2e": e2e, "comm": comm,
             "metric": "ADT training clips/sec (10 s @16 kHz)",
             "config": {"workload": "train config[3]: ADT train step, setting-1 network (69.0M params), per-GPU batch 64 x 10 s @ 16 kHz "
@@ -416,6 +436,8 @@ def main():
                                                                  "benchmark configuration is 0)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-e2e", action="store_true", help="skip the end-to-end (real input pipeline) leg of the train workload")
+    ap.add_argument("--roofline-loop", action="store_true", help="train workload: also time the roofline kernel alone, back to back (the "
+                                                                  "earlier rounds' measurement; adds 100 launches of it to a profile of this command)")
     ap.add_argument("--grad-compress", default=None, choices=["bf16"], help="send bf16 copies of the gradient segments (N > 1)")
     args = ap.parse_args()
 
@@ -460,11 +482,15 @@ def main():
     fence()
     if "comm" in wl:
         wl["comm"]()                                     # drop the warm-up steps' wait events
+    if "tap" in wl:
+        wl["tap"](True)                                  # event pairs around the roofline kernel's launches inside the timed region
     t0 = time.perf_counter()
     for _ in range(args.steps):
         step()
     fence()
     dt = time.perf_counter() - t0
+    if "tap" in wl:
+        wl["tap"](False)
     if world > 1:
         tt = torch.tensor([dt], device=dev, dtype=torch.float64)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
@@ -504,7 +530,7 @@ def main():
             line["final_loss"] = float(loss.item()) if loss is not None else None
         if os.environ.get("ADT_BENCH_SHARE_GPU") == "1":
             line["data"] = "synthetic; DEBUG RUN: all ranks share GPU 0 over gloo (ADT_BENCH_SHARE_GPU=1), not a measurement"
-        line["roofline"] = wl["roofline"]()
+        line["roofline"] = wl["roofline"](args.roofline_loop) if args.workload == "train" else wl["roofline"]()
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = wl["cpu_baseline"]()
         print(json.dumps(line), flush=True)

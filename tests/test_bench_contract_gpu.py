@@ -47,6 +47,8 @@ def test_train_line():
     assert abs(r["achieved"] - r["algorithmic_flops_per_launch"] / (r["kernel_ms"] * 1e-3) / 1e12) / r["achieved"] < 1e-6
     assert r["traffic"] is None or r["traffic"] > r["algorithmic_bytes_per_launch"] * 0.9
     assert set(r["same_shape_other_epilogues"]) == {"bias_gelu_preact_no_dropout_r01_form", "plain_bf16_product"}
+    # the kernel is timed where the step launches it: 4 encoder FFN-1 launches per timed step, an event pair around each
+    assert r["timed"].startswith("12 launches inside the timed steps") and r["back_to_back"] is None
     e = d["e2e"]
     assert e["unit"] == "clips/s" and e["value"] > 0 and 0.5 < e["ratio_to_value"] < 1.5
     assert "cpu_baseline" not in d
@@ -81,3 +83,11 @@ def test_torchrun_one_rank_runs_the_rccl_path():
     assert c["bytes_per_step"] == 4 * 69000824 and c["wire_dtype"] == "f32" and c["reduce_op"] == "avg"
     assert c["exposed_wait_ms"] is not None and 0.0 <= c["exposed_wait_ms"] < 50.0 and c["steps_timed"] == 3
     assert d["roofline"]["traffic_source"] is None or "replayed from profiles/r" in d["roofline"]["traffic_source"]
+
+
+def test_train_line_with_the_back_to_back_loop():
+    d = run_bench("--steps", "2", "--warmup", "1", "--no-cpu-baseline", "--no-e2e", "--roofline-loop")
+    r = d["roofline"]
+    assert r["timed"].startswith("8 launches inside the timed steps")
+    b = r["back_to_back"]
+    assert b["launches"] == 60 and 0.5 < b["kernel_ms"] / r["kernel_ms"] < 2.0

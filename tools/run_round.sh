@@ -6,7 +6,7 @@ mkdir -p $O
 cd $R
 timeout 1500 python -m pytest tests -m gpu -q > $O/pytest_gpu.log 2>&1; tail -3 $O/pytest_gpu.log | cut -c1-200
 timeout 300 python -c "import __graft_entry__ as g; g.smoke()" > $O/smoke.log 2>&1; tail -2 $O/smoke.log
-timeout 900 python bench.py --steps 20 --warmup 5 > $O/bench_train.json 2> $O/bench_train.err; cut -c1-300 $O/bench_train.json
+timeout 900 python bench.py --steps 20 --warmup 5 --roofline-loop > $O/bench_train.json 2> $O/bench_train.err; cut -c1-300 $O/bench_train.json
 timeout 900 python bench.py --steps 20 --warmup 5 --dropout 0.0 --no-cpu-baseline > $O/bench_train_nodropout.json 2> /dev/null; cut -c1-200 $O/bench_train_nodropout.json
 timeout 900 python bench.py --workload logmel --steps 30 --warmup 5 > $O/bench_logmel.json 2> /dev/null; cut -c1-300 $O/bench_logmel.json
 timeout 900 python bench.py --workload clap --steps 5 --warmup 2 > $O/bench_clap.json 2> /dev/null; cut -c1-300 $O/bench_clap.json
