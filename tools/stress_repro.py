@@ -1,6 +1,7 @@
 #!/usr/bin/env python3
 """Race hunt (GPU box): the kernels are deterministic, so any run-to-run difference of the outputs of the hand-synchronised kernels
-(attention forward / backward at the encoder and decoder shapes, persistent NT / TN GEMMs) is a synchronisation bug.
+(attention forward / backward at the encoder and decoder shapes, persistent NT / TN GEMMs in the step's forms, the fused HTSAT
+tower) is a synchronisation bug.
 Usage: python tools/stress_repro.py [iterations]"""
 import math
 import os
@@ -57,5 +58,25 @@ check("NT 256^2 FFN1 + GELU + dropout + column sums", lambda: (K.gemm(a, w, bias
 x = torch.randn((M, 3072), device=dev).bfloat16()
 gw = torch.empty((768, 3072), device=dev)
 check("TN 256^2 split-K wgrad", lambda: (K.gemm(a, x, trans=True, out=gw),))
+# the forms the training step launches (compile-time epilogue masks; interior tiles leave their last stores in flight)
+u2 = torch.empty((M, 3072), dtype=torch.bfloat16, device=dev)
+check("NT 256^2 FFN1 + GELU + dropout + saved factor (roofline form)", lambda: (K.gemm(a, w, bias=bias, act=1, act_grad_out=u2, drop=(0.1, 9)), u2))
+res = torch.randn((M, 768), device=dev)
+w2 = torch.randn((768, 3072), device=dev).bfloat16()
+b2 = torch.randn(768, device=dev)
+check("NT 256^2 FFN2 + bias + dropout + residual (fp32 out)", lambda: (K.gemm(x, w2, bias=b2, residual=res, out_dtype=torch.float32, drop=(0.1, 11)),))
+wq = torch.randn((2304, 768), device=dev).bfloat16()
+check("NT 256^2 QKV (column-group tile order, 9 tile columns)", lambda: (K.gemm(a, wq, bias=torch.zeros(2304, device=dev)),))
+
+# fused HTSAT tower (K15) + K9: one forward of 64 clips, repeated
+import numpy as np
+from adt_str_amd.clap_encoder import ClapWrapper, random_init_clap_model
+wrap = ClapWrapper("random-init", dev, 48000, clap_model=random_init_clap_model(0))
+rng = np.random.default_rng(3)
+clips = [torch.from_numpy((rng.standard_normal(int(n)) * 0.2).astype(np.float32)).to(dev) for n in rng.integers(4800, 96001, 64)]
+flags = torch.zeros(64, dtype=torch.bool)
+flags[5] = True
+n_it = max(10, n_it // 5)
+check("CLAP features + fused HTSAT forward, 64 clips", lambda: (wrap.get_audio_features(clips, is_longer=flags),))
 print("FAILED" if bad else "all reproducible")
 sys.exit(1 if bad else 0)
