@@ -325,7 +325,15 @@ class _Engine:
         pe = self.m.decoder.positional_encoding.pos_embedding[0]
         x32, x16 = self._embed(tgt, emb, pe, math.sqrt(d), drop=self.D("dec.emb"))      # model.py:171-172
         dev = tgt.device
-        for L in self.dec:
+        # The cross-attention K | V projections of the memory for ALL decoder layers in one GEMM (N = layers * 2d): the layers'
+        # slices of one [B*S, layers*2d] buffer.  What this buys is in the backward: the memory's gradient becomes ONE product
+        # with K = layers * 2d instead of a chain of GEMMs that each re-read and re-write the fp32 [B*S, d] accumulator.
+        kv_all = None
+        if not self.fp32 and len(self.dec) > 1 and not os.environ.get("ADT_NO_KV_BATCH"):
+            wkv = torch.cat([L["ca"].w16[d:] for L in self.dec])
+            bkv = torch.cat([L["ca"].b[d:] for L in self.dec])
+            kv_all = K.gemm(mem16, wkv, bias=bkv)
+        for li, L in enumerate(self.dec):
             p = L["p"]
             qkv = K.gemm(x16, L["sa"].w16, bias=L["sa"].b)
             sa, lse_s = K.attn_fwd(qkv[:, :d], qkv[:, d:2 * d], qkv[:, 2 * d:], B, H, T, T, self.scale, causal=True, key_len=key_len,
@@ -334,7 +342,7 @@ class _Engine:
             x1_32, x1_16, mean1, rstd1 = self._ln(y1, self.P(p + ".norm1.weight"), self.P(p + ".norm1.bias"))
             ca_w, ca_b = L["ca"].w16, L["ca"].b
             qc = K.gemm(x1_16, ca_w[:d], bias=ca_b[:d])
-            kvc = K.gemm(mem16, ca_w[d:], bias=ca_b[d:])
+            kvc = kv_all[:, 2 * d * li:2 * d * (li + 1)] if kv_all is not None else K.gemm(mem16, ca_w[d:], bias=ca_b[d:])
             ca, lse_c = K.attn_fwd(qc, kvc[:, :d], kvc[:, d:], B, H, T, S, self.scale, drop=self.D(p + ".cattn"), head_dim=self.dh)
             y2 = K.gemm(ca, L["ca_o"].w16, bias=L["ca_o"].b, residual=x1_32, out_dtype=F32, drop=self.D(p + ".drop2"))
             x2_32, x2_16, mean2, rstd2 = self._ln(y2, self.P(p + ".norm2.weight"), self.P(p + ".norm2.bias"))
@@ -349,7 +357,7 @@ class _Engine:
             x32, x16 = x3_32, x3_16
         logits = K.gemm(x16, self.gen.w16, bias=self.gen.b, out_dtype=F32)  # generator (model.py:190), fp32 for the loss
         if save is not None:
-            save.append(dict(xo16=x16, T=T, tgt=tgt))
+            save.append(dict(xo16=x16, T=T, tgt=tgt, kv_batched=kv_all is not None))
         return logits
 
     @staticmethod
@@ -406,6 +414,7 @@ class _Engine:
         K.colsum(dlogits, out=G["decoder.generator.bias"])
         dx32 = self._dgrad(dlogits, self.gen, out_dtype=F32)
         dmem32 = None
+        dkv_all = torch.empty((mem16.shape[0], 2 * d * len(self.dec)), dtype=mem16.dtype, device=mem16.device) if tail["kv_batched"] else None
         for li in range(len(self.dec) - 1, -1, -1):
             L, s = self.dec[li], dec_save[li]
             p = L["p"]
@@ -420,13 +429,15 @@ class _Engine:
             dca = self._dgrad(dy2_16, L["ca_o"])
             self._wgrad(dy2_16, s["ca"], G[p + ".multihead_attn.out_proj.weight"], defer=True)
             dqc = torch.empty_like(s["qc"])
-            dkvc = torch.empty_like(s["kvc"])
+            dkvc = dkv_all[:, 2 * d * li:2 * d * (li + 1)] if dkv_all is not None else torch.empty_like(s["kvc"])
             gw, gb = G[p + ".multihead_attn.in_proj_weight"], G[p + ".multihead_attn.in_proj_bias"]
             K.attn_bwd(s["qc"], s["kvc"][:, :d], s["kvc"][:, d:], s["ca"], dca, s["lse_c"], dqc, dkvc[:, :d], dkvc[:, d:], B, H, T, S,
                        self.scale, drop=self.D(p + ".cattn"), bias_grad=gb, head_dim=self.dh)
             self._wgrad(dqc, s["x1_16"], gw[:d], defer=True)
             K.gemm(dkvc, mem16, trans=True, out=gw[d:])
-            if dmem32 is None:
+            if dkv_all is not None:
+                pass                                                   # one K = layers * 2d product after the loop
+            elif dmem32 is None:
                 dmem32 = self._dgrad(dkvc, L["ca"], d, None, out_dtype=F32)
             else:
                 self._dgrad(dkvc, L["ca"], d, None, residual=dmem32, out=dmem32)
@@ -443,6 +454,8 @@ class _Engine:
             self._wgrad(dqkv, s["x16"], G[p + ".self_attn.in_proj_weight"], defer=True)
             dx32 = self._dgrad(dqkv, L["sa"], residual=dy1_32, out_dtype=F32)
             self._flush_reductions()
+        if dkv_all is not None:
+            dmem32 = K.gemm(dkv_all, torch.cat([L["ca"].wt16[:, d:] for L in self.dec], dim=1), out_dtype=F32)
         K.embed_bwd(tgt, dx32, math.sqrt(d), G["decoder.tgt_tok_emb.embedding.weight"], drop=self.D("dec.emb"), f32=self.fp32)
         self._flush_wgrads()
         self._ready("decoder.")
