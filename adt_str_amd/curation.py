@@ -65,3 +65,36 @@ def assign(sample_embeddings: torch.Tensor, reference_embeddings: torch.Tensor, 
               _ffi.dptr(sc) if sc is not None else None, _ffi.current_stream())
     res = rank_assignments(bc.cpu().numpy().astype(np.int64), bs.cpu().numpy(), labels, num_bins)
     return (res, sc) if return_scores else res
+
+
+def copy_originals_to_gold(reference_root: str, augmented_root: str, overwrite: bool = True):
+    """``copy_originals_to_augmented.py:62-80``: every ``<reference_root>/<label>/`` tree becomes ``<augmented_root>/<label>/gold``;
+    an existing ``gold`` is replaced (``overwrite``) or skipped.  Directories are made here, the files go through the library's
+    batched copy (contents, mode, times: shutil.copytree's copy2).  Returns ``(copied labels, skipped labels)``."""
+    import os
+    import shutil
+    from .audio_io import copy_files
+    srcs, dsts, copied, skipped = [], [], 0, 0
+    os.makedirs(augmented_root, exist_ok=True)
+    for label in sorted(os.listdir(reference_root)):
+        src = os.path.join(reference_root, label)
+        if not os.path.isdir(src):
+            continue
+        dst = os.path.join(augmented_root, label, "gold")
+        if os.path.exists(dst):
+            if not overwrite:
+                print(f"Destination already exists, skipping copy: {dst}. Use --overwrite to replace.")
+                skipped += 1
+                continue
+            shutil.rmtree(dst)
+        for root, _dirs, files in os.walk(src):
+            out_dir = os.path.join(dst, os.path.relpath(root, src)) if root != src else dst
+            os.makedirs(out_dir, exist_ok=True)
+            for f in files:
+                srcs.append(os.path.join(root, f))
+                dsts.append(os.path.join(out_dir, f))
+        copied += 1
+    status = copy_files(srcs, dsts)
+    for j in status.nonzero()[0]:
+        print(f"Failed to copy '{srcs[j]}' -> '{dsts[j]}'")
+    return copied, skipped

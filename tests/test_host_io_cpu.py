@@ -152,3 +152,44 @@ def test_bank_from_directory_matches_the_per_file_route(tmp_path):
     for (pitch, g, name), want in expect.items():
         assert np.array_equal(bank.shot(bank.shot_id(pitch, g, name)), want), (pitch, g, name)
     assert OneShotBank.from_directory(str(root), 8000).n_shots == 0      # another rate needs the GPU resampler: every file is skipped with a message
+
+
+def test_pipeline_scripts_gold_copy_and_bank_conversion(tmp_path, capsys):
+    """The reference's curation pipeline after augment_data_with_CLAP.py (DATASET_AUGMENTATION_PIPELINE.md): copy_originals_to_augmented.py
+    then convert_augmented_to_hdf5.py, with the reference's command lines (the bank is this repo's flat .npz instead of HDF5)."""
+    import yaml
+    from adt_str_amd.bank import GROUPS, OneShotBank
+    from data_modules import convert_augmented_to_hdf5 as conv
+    from data_modules import copy_originals_to_augmented as gold
+    rng = np.random.default_rng(1)
+    ref = tmp_path / "GM"
+    for label in ("36", "38"):
+        (ref / label / "sub").mkdir(parents=True)
+        for k in range(2):
+            A.write_wav(str(ref / label / f"r{k}.wav"), (rng.standard_normal(300) * 0.2).astype(np.float32), 44100)
+        A.write_wav(str(ref / label / "sub" / "deep.wav"), (rng.standard_normal(200) * 0.2).astype(np.float32), 44100)
+    (ref / "notes.txt").write_text("not a label directory")
+    aug = tmp_path / "GM_clap_augmented"
+    (aug / "36" / GROUPS[1]).mkdir(parents=True)
+    A.write_wav(str(aug / "36" / GROUPS[1] / "picked.wav"), (rng.standard_normal(250) * 0.2).astype(np.float32), 44100)
+    cfg = tmp_path / "clap.yaml"
+    cfg.write_text(yaml.safe_dump({"clap_config": {"reference_root": str(ref), "sample_pack_root": str(tmp_path / "packs")}}))
+    gold.main([str(cfg)])
+    assert "Copied: 2, Skipped: 0" in capsys.readouterr().out
+    assert sorted(os.listdir(aug / "36" / "gold")) == ["r0.wav", "r1.wav", "sub"] and (aug / "38" / "gold" / "sub" / "deep.wav").exists()
+    assert os.stat(aug / "38" / "gold" / "r0.wav").st_mtime_ns == os.stat(ref / "38" / "r0.wav").st_mtime_ns
+    gold.main([str(cfg)])
+    assert "Copied: 0, Skipped: 2" in capsys.readouterr().out
+    (aug / "36" / "gold" / "stale.wav").write_bytes(b"x")
+    gold.main([str(cfg), "--overwrite"])
+    assert "Copied: 2, Skipped: 0" in capsys.readouterr().out and not (aug / "36" / "gold" / "stale.wav").exists()
+
+    out = conv.main([str(aug), str(tmp_path / "oneshot"), "--sample_rate", "44100"])
+    assert out.endswith("oneshot@44100.npz") and "Wrote 7 items" in capsys.readouterr().out      # gold/sub/deep.wav sits deeper but still counts
+    bank = OneShotBank.load(out)
+    assert bank.sample_rate == 44100 and bank.has_cell(36, "gold") and bank.has_cell(36, GROUPS[1]) and bank.has_cell(38, "gold")
+    m = A.read_wav(str(ref / "38" / "r1.wav"))[0].mean(axis=0)
+    assert np.array_equal(bank.shot(bank.shot_id(38, "gold", "r1")), (m / float(np.abs(m).max())).astype(np.float32))
+    with pytest.raises(FileExistsError):
+        conv.main([str(aug), str(tmp_path / "oneshot"), "--sample_rate", "44100"])
+    conv.main([str(aug), str(tmp_path / "oneshot"), "--sample_rate", "44100", "--overwrite"])

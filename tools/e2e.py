@@ -75,22 +75,6 @@ def write_library(root, n_shots, refs_per_class, seed, rank=0, world=1):
     return os.path.join(root, "refs"), os.path.join(root, "packs")
 
 
-def copy_originals_to_gold(reference_root, augmented_root):
-    """``copy_originals_to_augmented.py:62-80``: every ``<reference_root>/<label>/`` becomes ``<augmented_root>/<label>/gold``."""
-    n = 0
-    for label in sorted(os.listdir(reference_root)):
-        src = os.path.join(reference_root, label)
-        if not os.path.isdir(src):
-            continue
-        dst = os.path.join(augmented_root, label, "gold")
-        if os.path.exists(dst):
-            shutil.rmtree(dst)
-        os.makedirs(os.path.dirname(dst), exist_ok=True)
-        shutil.copytree(src, dst)
-        n += 1
-    return n
-
-
 def note_chunks(n_chunks, seed, max_notes=40):
     """Lakh-style rows: float32 [N, 4] (onset s, offset s, GM key, velocity) bytes (midi_parser.py:57-63), onsets < 2.95 s."""
     rng = np.random.default_rng(seed)
@@ -166,6 +150,7 @@ def main(argv=None):
     bank_path = os.path.join(a.workdir, f"oneshot@{a.sample_rate}.npz")
     if rank == 0:
         from adt_str_amd.bank import OneShotBank
+        from adt_str_amd.curation import copy_originals_to_gold
         copy_originals_to_gold(ref_root, str(aug_root))
         bank = OneShotBank.from_directory(str(aug_root), a.sample_rate, device=dev)
         bank.save(bank_path)
