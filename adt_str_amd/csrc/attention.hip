@@ -377,6 +377,154 @@ __global__ __launch_bounds__(kAttnThreads, 2) void attn_fwd_kernel(AttnArgs a) {
   if (h == 0 && qi < a.Sq && a.lse) a.lse[(static_cast<long>(b) * a.H + head) * a.Sq + qi] = (m + log2f(lt)) * kLn2;
 }
 
+// =============================================================================== forward, ONE query per (batch, head): decode
+// The KV-cached greedy decode (reference model.py:260-324 recomputes the whole prefix; network.py: greedy_decode_cached) asks for
+// the attention of a single new position over the cache (self-attention) or over the encoder memory (cross-attention).  The tiled
+// kernel above would run one 128-query tile with one live row and walk the keys serially in one workgroup per (batch, head):
+// 27 us per launch at 986 keys, eight launches per decoded token.  Here the keys are spread over sixteen waves, a wave takes 64
+// keys at a time, and there is no matrix unit:
+//   loads    one wave-instruction reads FOUR key (or value) rows: the 16 lanes of a quarter-wave read one row's 256 bytes as
+//            16-byte pieces (fully coalesced; a lane-per-key layout issues 64 separate 16-byte requests per instruction and
+//            was bound by the address path at 17 us);
+//   scores   a lane dots its 8 head dimensions with the matching piece of the query row (four v_dot2c_f32_bf16), the quarter-wave sums on the DPP
+//            network (quad_perm x2, row_half_mirror, row_mirror): sixteen scores per lane, one per row group;
+//   softmax  online across a wave's blocks; max / sum over the lane's sixteen values, then across the four quarter-waves;
+//   P V      the same four-rows-per-instruction reads: a lane multiplies its row's probability -- already in its own register --
+//            into its 8 dimensions; the four quarter-waves' partial outputs are added at the end;
+//   combine  the sixteen (max, sum, partial output) triples through LDS.
+// Keys behind the key-padding length are skipped when the additive mask is the reference's -1e4 (any mask <= -1000): their
+// weight exp(score - 1e4 - max) is exactly 0 in fp32 next to one unmasked key; with a milder mask every key is visited and masked.
+constexpr int kDecWaves = 8;
+template <int kCtrl>
+__device__ __forceinline__ float dpp_row(float v) {          // v + (v of the lane kCtrl names inside the 16-lane DPP row)
+  return v + __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), kCtrl, 0xf, 0xf, false));
+}
+__device__ __forceinline__ float quarter_sum(float v) {      // sum over the 16 lanes of a quarter-wave, in every one of them
+  v = dpp_row<0xB1>(v);                                      // quad_perm [1, 0, 3, 2]
+  v = dpp_row<0x4E>(v);                                      // quad_perm [2, 3, 0, 1]
+  v = dpp_row<0x141>(v);                                     // row_half_mirror
+  return dpp_row<0x140>(v);                                  // row_mirror
+}
+typedef __bf16 bf16x2d __attribute__((ext_vector_type(2)));
+typedef float f32x2d __attribute__((ext_vector_type(2)));
+__global__ __launch_bounds__(64 * kDecWaves) void attn_decode_kernel(AttnArgs a) {
+  __shared__ float red_m[kDecWaves], red_l[kDecWaves];
+  __shared__ float red_o[kDecWaves][kDh];
+  const int tid = threadIdx.x, lane = tid & 63, g = lane >> 4, c = lane & 15;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int b = blockIdx.x / a.H, head = blockIdx.x % a.H;
+  int klen = a.key_len ? a.key_len[b] : a.Sk;
+  klen = klen < 0 ? 0 : (klen > a.Sk ? a.Sk : klen);
+  const bool skip_masked = a.mask_value <= -1000.f && klen > 0;
+  const int n = skip_masked ? klen : a.Sk;
+  const float sl2 = a.scale * kLog2e, mask2 = a.mask_value * kLog2e;
+  // this lane's 8 dimensions of the query row, as four bf16 pairs (v_dot2c_f32_bf16 multiplies pairs and adds in fp32)
+  const uint4 qw = *reinterpret_cast<const uint4*>(a.q + static_cast<long>(b) * a.ldq + head * kDh + 8 * c);
+  const bf16x2d qp[4] = {__builtin_bit_cast(bf16x2d, qw.x), __builtin_bit_cast(bf16x2d, qw.y), __builtin_bit_cast(bf16x2d, qw.z), __builtin_bit_cast(bf16x2d, qw.w)};
+  const unsigned short* kb = a.k + static_cast<long>(b) * a.Sk * a.ldk + head * kDh + 8 * c;
+  const unsigned short* vb = a.v + static_cast<long>(b) * a.Sk * a.ldv + head * kDh + 8 * c;
+  float m = -INFINITY, l = 0.f;
+  float o[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+  for (int j0 = wave * 64; j0 < n; j0 += 64 * kDecWaves) {
+    // rows j0 + 4 i + g, i = 0 .. 15 (clamped to the last live row: its probability is forced to 0 below)
+    // addresses = a uniform base (scalar registers) + a 32-bit lane offset: per-row 64-bit pointers would not fit 128 registers
+    const char* kbase = reinterpret_cast<const char*>(kb + static_cast<long>(j0) * a.ldk);
+    const char* vbase = reinterpret_cast<const char*>(vb + static_cast<long>(j0) * a.ldv);
+    const unsigned kstride = static_cast<unsigned>(a.ldk) * 2u, vstride = static_cast<unsigned>(a.ldv) * 2u;
+    const int last = n - 1 - j0;                              // rows of the block past the live keys re-read the last live row
+    uint4 kr[16];
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+      const int r = 4 * i + g;
+      kr[i] = *reinterpret_cast<const uint4*>(kbase + static_cast<unsigned>(r < last ? r : last) * kstride);
+    }
+    float s2[16], bm = -INFINITY;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+      float acc = __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(bf16x2d, kr[i].x), qp[0], 0.f, false);
+      acc = __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(bf16x2d, kr[i].y), qp[1], acc, false);
+      acc = __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(bf16x2d, kr[i].z), qp[2], acc, false);
+      acc = __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(bf16x2d, kr[i].w), qp[3], acc, false);
+      const int j = j0 + 4 * i + g;
+      s2[i] = j < n ? fmaf(quarter_sum(acc), sl2, j >= klen ? mask2 : 0.f) : -INFINITY;
+      bm = fmaxf(bm, s2[i]);
+    }
+    uint4 vr[8];                                              // V rows in two halves of eight: 1024 threads leave 128 registers per lane
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      const int r = 4 * i + g;
+      vr[i] = *reinterpret_cast<const uint4*>(vbase + static_cast<unsigned>(r < last ? r : last) * vstride);
+    }
+    bm = fmaxf(bm, __shfl_xor(bm, 16));                       // across the four quarter-waves (lanes of a quarter agree)
+    bm = fmaxf(bm, __shfl_xor(bm, 32));
+    const float m_new = fmaxf(m, bm);                         // finite: the block has a live row
+    const float corr = exp2f(m - m_new);                      // first block: exp2(-inf) = 0
+    float ps = 0.f;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) o[e] *= corr;
+    // two rows at a time: (v_i[d], v_i+1[d]) . (p_i, p_i+1) per dimension d -- v_perm_b32 pairs the rows' halves, the
+    // probabilities are rounded to bf16 like the tiled kernel rounds P for its P V product
+#pragma unroll
+    for (int half = 0; half < 2; ++half) {
+      uint4 vn[8];
+      if (half == 0) {
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+          const int r = 4 * (i + 8) + g;
+          vn[i] = *reinterpret_cast<const uint4*>(vbase + static_cast<unsigned>(r < last ? r : last) * vstride);
+        }
+      }
+#pragma unroll
+      for (int i = 0; i < 8; i += 2) {
+        const float p0 = exp2f(s2[8 * half + i] - m_new), p1 = exp2f(s2[8 * half + i + 1] - m_new);      // rows past the block: exp2(-inf) = 0
+        ps += p0 + p1;
+        const bf16x2d pp = __builtin_convertvector(f32x2d{p0, p1}, bf16x2d);
+        const unsigned w0[4] = {vr[i].x, vr[i].y, vr[i].z, vr[i].w}, w1[4] = {vr[i + 1].x, vr[i + 1].y, vr[i + 1].z, vr[i + 1].w};
+#pragma unroll
+        for (int w = 0; w < 4; ++w) {
+          const unsigned lo = __builtin_amdgcn_perm(w1[w], w0[w], 0x05040100u);    // (w0 low half, w1 low half)
+          const unsigned hi = __builtin_amdgcn_perm(w1[w], w0[w], 0x07060302u);    // (w0 high half, w1 high half)
+          o[2 * w] = __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(bf16x2d, lo), pp, o[2 * w], false);
+          o[2 * w + 1] = __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(bf16x2d, hi), pp, o[2 * w + 1], false);
+        }
+      }
+      if (half == 0) {
+#pragma unroll
+        for (int i = 0; i < 8; ++i) vr[i] = vn[i];
+      }
+    }
+    ps += __shfl_xor(ps, 16);
+    ps += __shfl_xor(ps, 32);
+    l = fmaf(l, corr, ps);
+    m = m_new;
+  }
+#pragma unroll
+  for (int e = 0; e < 8; ++e) {                               // the four quarter-waves hold partial sums of the same 8 dimensions
+    o[e] += __shfl_xor(o[e], 16);
+    o[e] += __shfl_xor(o[e], 32);
+  }
+  if (lane == 0) { red_m[wave] = m; red_l[wave] = l; }
+  if (g == 0) {
+#pragma unroll
+    for (int e = 0; e < 8; ++e) red_o[wave][8 * c + e] = o[e];
+  }
+  __syncthreads();
+  if (tid < kDh) {
+    float M = -INFINITY;
+#pragma unroll
+    for (int w = 0; w < kDecWaves; ++w) M = fmaxf(M, red_m[w]);
+    float L = 0.f, acc = 0.f;
+#pragma unroll
+    for (int w = 0; w < kDecWaves; ++w) {
+      const float cw = exp2f(red_m[w] - M);                   // a wave without keys: exp2(-inf) = 0
+      L = fmaf(red_l[w], cw, L);
+      acc = fmaf(red_o[w][tid], cw, acc);
+    }
+    a.out[static_cast<long>(b) * a.ldo + head * kDh + tid] = __builtin_bit_cast(unsigned short, static_cast<__bf16>(acc / L));
+    if (tid == 0 && a.lse) a.lse[static_cast<long>(b) * a.H + head] = (M + log2f(L)) * kLn2;
+  }
+}
+
 // =============================================================================== backward: dQ  (lane <-> query)
 template <bool kDrop>
 __global__ __launch_bounds__(kAttnThreads, 2) void attn_bwd_dq_kernel(AttnArgs a) {
@@ -1308,6 +1456,12 @@ extern "C" int adt_attn_fwd(const adt_attn_desc* d, const void* q, const void* k
   AttnArgs a = make_args(d);
   a.q = static_cast<const unsigned short*>(q); a.k = static_cast<const unsigned short*>(k); a.v = static_cast<const unsigned short*>(v);
   a.out = static_cast<unsigned short*>(o); a.lse = lse;
+  // one query per (batch, head) without dropout or a causal mask: the decode kernel (ADT_ATTN_NO_DECODE=1: the tiled kernel, for A/B)
+  if (d->q_len == 1 && !a.drop.on() && !a.causal && (d->ldk % 8) == 0 && (d->ldv % 2) == 0 && getenv("ADT_ATTN_NO_DECODE") == nullptr) {
+    hipLaunchKernelGGL(attn_decode_kernel, dim3(static_cast<unsigned>(d->batch) * d->heads), dim3(64 * kDecWaves), 0, static_cast<hipStream_t>(stream), a);
+    ADT_HIP_TRY(hipGetLastError());
+    return ADT_OK;
+  }
   const int lds = 4 * kAttnTileBytes;
   if (int rc = set_lds_once()) return rc;
   const dim3 grid(static_cast<unsigned>((d->q_len + 127) / 128) * d->batch * d->heads);      // 1-D: tile_coords() renumbers it

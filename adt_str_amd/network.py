@@ -543,8 +543,9 @@ class _Engine:
         are projected once instead of once per step.  A step is ~50 small launches, so it is launch-bound: all of its
         state (position, token, lengths, finished flags) lives in device buffers updated in place, which makes every
         step the same work list -- captured once as a HIP graph and replayed (``use_graph``; measured on MI355X at B = 8:
-        0.69 ms/step replayed = the GPU time of the ~70 small kernels, 0.71 ms/step eager, 0.93 ms/step for the
-        full-prefix recompute at 256 tokens; the next lever is a skinny-M GEMM for the 8-row projections).  The host
+        0.32-0.34 ms/step replayed = the GPU time of the ~70 small kernels, 0.68 ms/step eager (the host's launch rate),
+        0.89 ms/step for the full-prefix recompute at 256 tokens; round 2, before the skinny-M GEMM and the single-query
+        attention kernel: 0.68-0.83 ms/step replayed).  The host
         looks at the "all rows finished" flag every ``sync_every`` steps (the reference syncs every step).
         Returns ``[B, n]`` tokens, n as the reference would stop."""
         d, H, dev = self.d, self.H, mem16.device
@@ -594,7 +595,7 @@ class _Engine:
         n_steps = Tmax - 1
         done = 0
         graph = None
-        if use_graph and n_steps >= 64:               # capture costs ~10 ms: not worth it for short decodes
+        if use_graph and n_steps >= 24:               # capture costs ~10 ms; a replayed step saves ~0.35 ms of host launch time
             cur = torch.cuda.current_stream()
             side = torch.cuda.Stream()
             side.wait_stream(cur)

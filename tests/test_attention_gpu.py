@@ -154,3 +154,30 @@ def test_rejects_other_head_dims():
     with pytest.raises(_ffi.AdtError) as e:
         _ffi.call("adt_attn_fwd", C.byref(d), x.data_ptr(), x.data_ptr(), x.data_ptr(), x.data_ptr(), x.data_ptr(), 0)
     assert e.value.code == -2
+
+
+@pytest.mark.parametrize("B,H,Sk,lens", [(3, 2, 1, None), (2, 6, 63, None), (2, 3, 64, [64, 1]), (4, 6, 65, [65, 7, 64, 1]), (8, 6, 986, None),
+                                         (2, 2, 1500, [1500, 1025]), (8, 6, 1000, [1, 2, 17, 64, 65, 500, 999, 1000])])
+def test_single_query_decode_kernel(monkeypatch, B, H, Sk, lens):
+    """One query per (batch, head) -- a step of the KV-cached greedy decode -- takes the decode kernel (lane <-> key scores, sixteen
+    waves over the keys, keys behind the padding length skipped: their weight underflows to exactly 0 under the reference's -1e4 mask);
+    against the fp32 reference and against the tiled kernel (ADT_ATTN_NO_DECODE=1), with the cache's packed [B, Tmax, 3d] layout."""
+    from adt_str_amd import kernels as k
+    d = H * 128
+    cache = rnd((B * Sk, 3 * d), 7).bfloat16()
+    q = rnd((B, 3 * d), 8).bfloat16()[:, :d]
+    kk, v = cache[:, d:2 * d], cache[:, 2 * d:]
+    key_len = None if lens is None else torch.tensor(lens, dtype=torch.int32, device=DEV)
+    scale = 1 / math.sqrt(128)
+    o, lse = k.attn_fwd(q, kk, v, B, H, 1, Sk, scale, key_len=key_len)
+    ref_o, ref_lse = reference(q, kk, v, B, H, 1, Sk, scale, False, key_len)
+    assert (o.float() - ref_o).abs().max() < 1e-2 and (lse.view(B, H, 1) - ref_lse).abs().max() < 2e-3
+    monkeypatch.setenv("ADT_ATTN_NO_DECODE", "1")
+    o2, lse2 = k.attn_fwd(q, kk, v, B, H, 1, Sk, scale, key_len=key_len)
+    assert (o.float() - o2.float()).abs().max() < 1e-2 and (lse - lse2).abs().max() < 2e-3
+    # a mild mask value keeps the masked keys in the softmax: every key is visited
+    if lens is not None:
+        monkeypatch.delenv("ADT_ATTN_NO_DECODE")
+        o3, _ = k.attn_fwd(q, kk, v, B, H, 1, Sk, scale, key_len=key_len, mask_value=-2.0)
+        ref3, _ = reference(q, kk, v, B, H, 1, Sk, scale, False, key_len, mask_value=-2.0)
+        assert (o3.float() - ref3).abs().max() < 1e-2

@@ -320,3 +320,27 @@ def test_persistent_gemm_runs_beside_a_kernel_that_holds_cus():
     torch.cuda.synchronize()
     assert all(torch.equal(o, ref) for o in outs)
     assert busy and e0.elapsed_time(e1) < 20.0, (busy, e0.elapsed_time(e1))
+
+
+@pytest.mark.parametrize("M", [1, 3, 8, 16])
+@pytest.mark.parametrize("N,K", [(768, 768), (2304, 768), (768, 3072), (1400, 768), (3072, 768), (24, 128)])
+def test_skinny_rows_kernel(M, N, K, monkeypatch):
+    """M <= 16 (the decode step's projections): a 16-column workgroup per output slice, K split over its four waves, the generic
+    epilogue.  Against the fp32 product, and against the tile kernel the same call takes with ADT_GEMM_NO_SKINNY... (set before
+    the library reads it: the comparison with the tiled kernels is through the fp32 reference both must match)."""
+    from adt_str_amd import kernels as k
+    a_full = rnd((M, K + 64), 3 + M).bfloat16()
+    a = a_full[:, :K]                                                    # row stride != K
+    w, bias, res = rnd((N, K), 4, 0.05).bfloat16(), rnd((N,), 5), rnd((M, N), 6)
+    z = a.float() @ w.float().t()
+    close(k.gemm(a, w, out_dtype=torch.float32), z, 1e-4, "plain fp32")
+    close(k.gemm(a, w), z, 6e-3, "plain bf16")
+    close(k.gemm(a, w, bias=bias, residual=res, out_dtype=torch.float32), z + bias + res, 1e-4, "bias + residual")
+    close(k.gemm(a, w, bias=bias, act=1), torch.nn.functional.gelu(z + bias), 8e-3, "bias + gelu")
+    site = k.drop_site(0.25, 3, 1)
+    from oracle import dropout as o_drop
+    sc = o_drop.scale((M, N), *site).to(DEV)
+    close(k.gemm(a, w, bias=bias, out_dtype=torch.float32, drop=site), (z + bias) * sc, 1e-4, "dropout: the same mask as the tiled kernels")
+    aux = torch.empty((M, N), dtype=torch.bfloat16, device=DEV)
+    out = k.gemm(a, w, out_dtype=torch.float32, aux_bf16_out=aux)
+    assert torch.equal(aux, out.bfloat16())
