@@ -183,6 +183,9 @@ int adt_mix_render_fx_f32(const float* bank, const int64_t* bank_off, int64_t n_
  * ticket of a launch zeroes its counter), so no host state mirrors them.  While `stream` is being captured into a
  * HIP graph the persistent kernels are not used (the tiled kernels are: no allocation, no shared counters).  As for
  * any stream-ordered API, calls that target the same stream must not race each other from different host threads.
+ * M <= 16 with trans = 0 and K a multiple of 128 (the per-token projections of the KV-cached decode, reference
+ * model.py:260-324) runs on a skinny kernel: one workgroup per 16 output columns, K split over its four waves and summed
+ * in a fixed order; same epilogue, same dropout mask.
  */
 typedef struct adt_gemm_epilogue {
   const float* bias;
@@ -239,6 +242,10 @@ int adt_gemm_bf16_tn_grouped(const adt_gemm_tn_item* items, int32_t n, void* str
  *   causal != 0: keys > query index get mask_value added
  * The backward recomputes the probabilities from lse (two kernels: dq; dk+dv),
  * without float atomics.  ws: adt_attn_bwd_workspace_bytes.
+ * q_len == 1 without dropout or a causal mask (one step of the KV-cached greedy decode: the new position over the cache,
+ * or over the encoder memory) runs on a single-query kernel that splits the keys over the waves of one workgroup per
+ * (batch, head) and visits only the keys below key_len when mask_value <= -1000 (the masked keys' weights are exactly 0
+ * in fp32 then); the probabilities are rounded to bf16 for the P V product, as in the tiled kernel.
  */
 typedef struct adt_attn_desc {
   int32_t batch, heads, q_len, k_len, head_dim;
