@@ -914,47 +914,61 @@ __device__ __forceinline__ void gemm_tn_glds_tile(const GemmArgs& g, int m0, int
   gemm_epilogue_rows<false>(o, acc, reinterpret_cast<float*>(smem), m0, n0, wm, wn, tid, lane);
 }
 // =========================================================================================
-// Skinny NT kernel (M <= 16): the projections of the KV-cached decode step (network.py: greedy_decode_cached -- 25 GEMMs of B rows
-// per decoded token).  The 128^2 tile kernel gives such a product ONE row of workgroups that walk K serially (14.8 us per launch);
-// here a workgroup owns 16 output columns, its four waves each take a quarter of K with every 16-byte operand load of the quarter
-// issued before the first MFMA (one memory round trip per launch), and the four partial 16 x 16 tiles are summed through LDS in a
-// fixed order.  The epilogue is the generic one (bias / GELU / residual / fp32 or bf16 output), one 8-column piece per lane.
+// Skinny NT kernel (M <= 64): the projections of the KV-cached decode step (network.py: greedy_decode_cached -- 25 GEMMs of B rows
+// per decoded token; B = the 10 s windows of the audio being transcribed).  The 128^2 tile kernel gives such a product ONE row of
+// workgroups that walk K serially (10-30 us per launch); here a workgroup owns 16 output columns, its four waves each take a
+// quarter of K, eight 32-deep steps of operand loads are issued before their MFMAs (one memory round trip per launch at K = 768),
+// the W fragments are shared by the kMT 16-row tiles of the activations, and the four partial tiles are summed through LDS in a
+// fixed order.  The epilogue is the generic one (bias / GELU / residual / dropout / fp32 or bf16 output), one 8-column piece per lane.
 constexpr int kSkinnyThreads = 256, kSkinnyDepth = 8;
-template <bool kDrop>
+template <bool kDrop, int kMT>
 __global__ __launch_bounds__(kSkinnyThreads) void gemm_nt_skinny_kernel(GemmArgs g) {
-  __shared__ float part[4][16][17];
+  __shared__ float part[4][16 * kMT][17];
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int n0 = blockIdx.x * 16;
   const int kq = g.K >> 2;                                     // K % 128 == 0: a whole number of 32-deep steps per quarter
-  int arow = lane & 15, brow = n0 + (lane & 15);
-  arow = arow < g.M ? arow : g.M - 1;                          // rows >= M / columns >= N are computed from clamped operands, never stored
-  brow = brow < g.N ? brow : g.N - 1;
-  const unsigned short* pa = g.A + static_cast<long>(arow) * g.lda + wave * kq + 8 * (lane >> 4);
+  int brow = n0 + (lane & 15);
+  brow = brow < g.N ? brow : g.N - 1;                          // rows >= M / columns >= N are computed from clamped operands, never stored
   const unsigned short* pb = g.B + static_cast<long>(brow) * g.ldb + wave * kq + 8 * (lane >> 4);
-  f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+  const unsigned short* pa[kMT];
+#pragma unroll
+  for (int t = 0; t < kMT; ++t) {
+    int arow = 16 * t + (lane & 15);
+    arow = arow < g.M ? arow : g.M - 1;
+    pa[t] = g.A + static_cast<long>(arow) * g.lda + wave * kq + 8 * (lane >> 4);
+  }
+  f32x4 acc[kMT];
+#pragma unroll
+  for (int t = 0; t < kMT; ++t) acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
   for (int k = 0; k < kq; k += 32 * kSkinnyDepth) {
-    bf16x8 fa[kSkinnyDepth], fb[kSkinnyDepth];
+    bf16x8 fb[kSkinnyDepth], fa[kMT][kSkinnyDepth];
 #pragma unroll
     for (int i = 0; i < kSkinnyDepth; ++i)
       if (k + 32 * i < kq) {
-        fa[i] = *reinterpret_cast<const bf16x8*>(pa + k + 32 * i);
         fb[i] = *reinterpret_cast<const bf16x8*>(pb + k + 32 * i);
+#pragma unroll
+        for (int t = 0; t < kMT; ++t) fa[t][i] = *reinterpret_cast<const bf16x8*>(pa[t] + k + 32 * i);
       }
 #pragma unroll
     for (int i = 0; i < kSkinnyDepth; ++i)
-      if (k + 32 * i < kq) acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[i], fb[i], acc, 0, 0, 0);
+      if (k + 32 * i < kq) {
+#pragma unroll
+        for (int t = 0; t < kMT; ++t) acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[t][i], fb[i], acc[t], 0, 0, 0);
+      }
   }
 #pragma unroll
-  for (int j = 0; j < 4; ++j) part[wave][4 * (lane >> 4) + j][lane & 15] = acc[j];      // D[row 4 (l >> 4) + j][col l & 15]
+  for (int t = 0; t < kMT; ++t)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) part[wave][16 * t + 4 * (lane >> 4) + j][lane & 15] = acc[t][j];      // D[row 4 (l >> 4) + j][col l & 15]
   __syncthreads();
-  if (tid < 32) {
-    const int r = tid >> 1, col = n0 + 8 * (tid & 1);
+  for (int p = tid; p < 32 * kMT; p += kSkinnyThreads) {
+    const int r = p >> 1, col = n0 + 8 * (p & 1);
     if (r < g.M && col + 8 <= g.N) {
       float z[8], bias[8];
 #pragma unroll
       for (int e = 0; e < 8; ++e) {
-        const int c = 8 * (tid & 1) + e;
+        const int c = 8 * (p & 1) + e;
         z[e] = (part[0][r][c] + part[1][r][c]) + (part[2][r][c] + part[3][r][c]);
         bias[e] = g.ep.bias ? g.ep.bias[col + e] : 0.f;
       }
@@ -962,6 +976,13 @@ __global__ __launch_bounds__(kSkinnyThreads) void gemm_nt_skinny_kernel(GemmArgs
       epilogue_apply8<kDrop, kEpiGeneric>(g, z, bias, ea, r, 0, col);
     }
   }
+}
+template <bool kDrop>
+static void launch_skinny(const GemmArgs& g, hipStream_t st) {
+  const dim3 gs(static_cast<unsigned>((g.N + 15) / 16));
+  if (g.M <= 16) hipLaunchKernelGGL((gemm_nt_skinny_kernel<kDrop, 1>), gs, dim3(kSkinnyThreads), 0, st, g);
+  else if (g.M <= 32) hipLaunchKernelGGL((gemm_nt_skinny_kernel<kDrop, 2>), gs, dim3(kSkinnyThreads), 0, st, g);
+  else hipLaunchKernelGGL((gemm_nt_skinny_kernel<kDrop, 4>), gs, dim3(kSkinnyThreads), 0, st, g);
 }
 
 // XCD-aware renumbering of a 1-D grid (workgroups b and b + 8 share an XCD): every XCD gets a contiguous range of logical tiles
@@ -1447,13 +1468,11 @@ extern "C" int adt_gemm_bf16(int32_t trans, int64_t M, int64_t N, int64_t K, con
   }
   g.k_tiles_per_split = (k_tiles + splits - 1) / splits;
   g.slabs = splits > 1 ? static_cast<float*>(ws) : nullptr;
-  // a handful of rows (the decode step's projections): one 16-column workgroup per output slice, K split over its waves
+  // up to 64 rows (the decode step's projections): one 16-column workgroup per output slice, K split over its waves
   static const bool no_skinny = getenv("ADT_GEMM_NO_SKINNY") != nullptr;
-  if (!trans && M >= 1 && M <= 16 && K > 0 && (K % 128) == 0 && !e.colsum_out && vector_epilogue_ok(g, e) && aligned16(A) && aligned16(B) &&
+  if (!trans && M >= 1 && M <= 64 && K > 0 && (K % 128) == 0 && !e.colsum_out && vector_epilogue_ok(g, e) && aligned16(A) && aligned16(B) &&
       (lda % 8) == 0 && (ldb % 8) == 0 && !no_skinny) {
-    const dim3 gs(static_cast<unsigned>((N + 15) / 16));
-    if (g.drop.on()) hipLaunchKernelGGL(gemm_nt_skinny_kernel<true>, gs, dim3(kSkinnyThreads), 0, st, g);
-    else hipLaunchKernelGGL(gemm_nt_skinny_kernel<false>, gs, dim3(kSkinnyThreads), 0, st, g);
+    if (g.drop.on()) launch_skinny<true>(g, st); else launch_skinny<false>(g, st);
     ADT_HIP_TRY(hipGetLastError());
     return ADT_OK;
   }

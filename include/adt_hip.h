@@ -183,7 +183,7 @@ int adt_mix_render_fx_f32(const float* bank, const int64_t* bank_off, int64_t n_
  * ticket of a launch zeroes its counter), so no host state mirrors them.  While `stream` is being captured into a
  * HIP graph the persistent kernels are not used (the tiled kernels are: no allocation, no shared counters).  As for
  * any stream-ordered API, calls that target the same stream must not race each other from different host threads.
- * M <= 16 with trans = 0 and K a multiple of 128 (the per-token projections of the KV-cached decode, reference
+ * M <= 64 with trans = 0 and K a multiple of 128 (the per-token projections of the KV-cached decode, reference
  * model.py:260-324) runs on a skinny kernel: one workgroup per 16 output columns, K split over its four waves and summed
  * in a fixed order; same epilogue, same dropout mask.
  */

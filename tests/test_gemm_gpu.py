@@ -322,10 +322,10 @@ def test_persistent_gemm_runs_beside_a_kernel_that_holds_cus():
     assert busy and e0.elapsed_time(e1) < 20.0, (busy, e0.elapsed_time(e1))
 
 
-@pytest.mark.parametrize("M", [1, 3, 8, 16])
+@pytest.mark.parametrize("M", [1, 3, 8, 16, 17, 32, 47, 64])
 @pytest.mark.parametrize("N,K", [(768, 768), (2304, 768), (768, 3072), (1400, 768), (3072, 768), (24, 128)])
 def test_skinny_rows_kernel(M, N, K, monkeypatch):
-    """M <= 16 (the decode step's projections): a 16-column workgroup per output slice, K split over its four waves, the generic
+    """M <= 64 (the decode step's projections; 1, 2 or 4 row tiles of 16): a 16-column workgroup per output slice, K split over its four waves, the generic
     epilogue.  Against the fp32 product, and against the tile kernel the same call takes with ADT_GEMM_NO_SKINNY... (set before
     the library reads it: the comparison with the tiled kernels is through the fp32 reference both must match)."""
     from adt_str_amd import kernels as k

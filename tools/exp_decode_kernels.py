@@ -29,7 +29,8 @@ for Sk, klen in ((986, None), (1000, 50), (1000, 1000)):
     kl = None if klen is None else torch.full((B,), klen, dtype=torch.int32, device=dev)
     t = timeit(lambda: K.attn_fwd(q, kv[:, d:2 * d], kv[:, 2 * d:], B, H, 1, Sk, scale, key_len=kl))
     print(f"attention, 1 query x {Sk} keys (key_len {klen}), B={B}: {t:.1f} us")
-for N, Kd in ((2304, 768), (768, 768), (3072, 768), (768, 3072), (1400, 768)):
-    a = torch.randn(B, Kd, device=dev).bfloat16(); w = torch.randn(N, Kd, device=dev).bfloat16(); bias = torch.randn(N, device=dev)
-    t = timeit(lambda: K.gemm(a, w, bias=bias))
-    print(f"GEMM M={B} N={N} K={Kd}: {t:.1f} us")
+for M in (8, 32, 64):
+    for N, Kd in ((2304, 768), (768, 768), (3072, 768), (768, 3072), (1400, 768)):
+        a = torch.randn(M, Kd, device=dev).bfloat16(); w = torch.randn(N, Kd, device=dev).bfloat16(); bias = torch.randn(N, device=dev)
+        t = timeit(lambda: K.gemm(a, w, bias=bias))
+        print(f"GEMM M={M} N={N} K={Kd}: {t:.1f} us")
