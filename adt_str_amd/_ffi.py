@@ -72,6 +72,7 @@ SIGNATURES = {
     "adt_colsum_workspace_bytes": [i64, i64],
     "adt_gemm_colsum_workspace_bytes": [i64, i64],
     "adt_colsum_bf16": [ptr, i64, i64, i64, ptr, ptr, C.c_size_t, ptr],
+    "adt_greedy_step": [ptr, i64, i64, i64, ptr, ptr, i64, ptr, ptr, ptr, ptr, i64, i64, ptr],
     "adt_bilinear_resize_f32": [ptr, i64, i64, i64, ptr, i64, i64, i64, ptr],
     "adt_reduce_queue_begin": [ptr, C.c_size_t, ptr],
     "adt_reduce_queue_flush": [],

@@ -887,6 +887,69 @@ extern "C" int adt_cast_bf16_batched(const adt_cast_item* items_dev, int32_t n_i
   return ADT_OK;
 }
 
+// ------------------------------------------------------------------------------------ greedy decode: the step's tail
+// argmax over the vocabulary (first index on ties, NaN counts as the maximum: torch.argmax), the finished / end-token logic of
+// the reference's sampler (model.py:300-322) and the step's counters, all on device state so that the step replays as a HIP graph.
+struct GreedyArgs { const float* logits; long ld; int B, V; unsigned char* finished; long* gen; long ld_gen; long* t; long* tok; int* klen;
+                    long* done_at; long eos, Tmax; };
+namespace adt {
+__device__ __forceinline__ bool argmax_better(float v, int i, float bv, int bi) {
+  const bool vn = v != v, bn = bv != bv;
+  if (vn != bn) return vn;
+  if (!vn && v != bv) return v > bv;
+  return i < bi;
+}
+__global__ __launch_bounds__(256) void greedy_step_kernel(GreedyArgs a) {
+  __shared__ int not_finished;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  if (threadIdx.x == 0) not_finished = 0;
+  __syncthreads();
+  const long t1 = *a.t + 1;                                   // the column this step writes
+  for (int b = wave; b < a.B; b += 4) {
+    float bv = -INFINITY;
+    int bi = 0x7fffffff;
+    for (int c = lane; c < a.V; c += 64) {
+      const float v = a.logits[static_cast<long>(b) * a.ld + c];
+      if (argmax_better(v, c, bv, bi)) { bv = v; bi = c; }
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+      const float ov = __shfl_xor(bv, o);
+      const int oi = __shfl_xor(bi, o);
+      if (argmax_better(ov, oi, bv, bi)) { bv = ov; bi = oi; }
+    }
+    if (lane == 0) {
+      const bool was = a.finished[b] != 0;
+      const long nxt = was ? a.eos : static_cast<long>(bi);
+      a.gen[static_cast<long>(b) * a.ld_gen + t1] = nxt;
+      const bool fin = was || nxt == a.eos;
+      a.finished[b] = fin ? 1 : 0;
+      a.tok[b] = nxt;
+      a.klen[b] += 1;
+      if (!fin) atomicOr(&not_finished, 1);
+    }
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    if (!not_finished && *a.done_at == a.Tmax) *a.done_at = t1 + 1;     // the number of columns the reference would return
+    *a.t = t1;
+  }
+}
+}  // namespace adt
+
+extern "C" int adt_greedy_step(const float* logits, int64_t ld, int64_t B, int64_t V, uint8_t* finished, int64_t* gen, int64_t ld_gen,
+                               int64_t* t, int64_t* tok, int32_t* klen, int64_t* done_at, int64_t end_token, int64_t max_length, void* stream) {
+  if (!logits || !finished || !gen || !t || !tok || !klen || !done_at) return set_error(ADT_EINVAL, "adt_greedy_step: null pointer");
+  if (B < 0 || V <= 0 || V > 0x7fffffff || ld < V || ld_gen < max_length || max_length < 2) return set_error(ADT_ESHAPE, "adt_greedy_step: bad sizes");
+  if (B == 0) return ADT_OK;
+  GreedyArgs a{logits, static_cast<long>(ld), static_cast<int>(B), static_cast<int>(V), finished, reinterpret_cast<long*>(gen), static_cast<long>(ld_gen),
+               reinterpret_cast<long*>(t), reinterpret_cast<long*>(tok), klen, reinterpret_cast<long*>(done_at), static_cast<long>(end_token),
+               static_cast<long>(max_length)};
+  hipLaunchKernelGGL(greedy_step_kernel, dim3(1), dim3(256), 0, ST(stream), a);
+  ADT_HIP_TRY(hipGetLastError());
+  return ADT_OK;
+}
+
 extern "C" size_t adt_grad_norm_workspace_bytes(void) { return kSumsqBlocks * 4; }
 
 extern "C" int adt_grad_norm(const float* g, int64_t n, float max_norm, float* norm_and_clip, void* ws, size_t ws_bytes, void* stream) {

@@ -248,6 +248,17 @@ def colsum(x, out=None):
     return out
 
 
+def greedy_step(logits, finished, gen, t, tok, klen, done_at, end_token: int) -> None:
+    """The tail of a greedy-decode step on device state (``adt_greedy_step``; reference model.py:300-322): ``gen[:, t + 1]`` <- the
+    arg-max token (the end token for rows already finished), ``finished`` / ``tok`` / ``klen`` / ``done_at`` / ``t`` updated in place."""
+    assert logits.dtype == torch.float32 and logits.dim() == 2 and logits.stride(1) == 1
+    assert finished.dtype == torch.bool and gen.dtype == torch.int64 and gen.stride(1) == 1 and t.dtype == torch.int64
+    assert tok.dtype == torch.int64 and tok.is_contiguous() and klen.dtype == torch.int32 and done_at.dtype == torch.int64
+    B, V = logits.shape
+    _ffi.call("adt_greedy_step", _ffi.dptr(logits), logits.stride(0), B, V, _ffi.dptr(finished), _ffi.dptr(gen), gen.stride(0), _ffi.dptr(t),
+              _ffi.dptr(tok), _ffi.dptr(klen), _ffi.dptr(done_at), int(end_token), gen.shape[1], _ffi.current_stream())
+
+
 class reduce_queue:
     """Context manager around adt_reduce_queue_begin / _flush / _end (include/adt_hip.h): inside it the second-stage reductions
     of `layernorm_bwd`, `colsum`, `gemm(colsum_out=...)` and `attn_bwd(bias_grad=...)` on the current stream are queued and

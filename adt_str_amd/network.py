@@ -561,7 +561,6 @@ class _Engine:
         st = dict(tok=gen[:, :1].clone(), t=torch.zeros(1, dtype=torch.long, device=dev),
                   klen=torch.ones(B, dtype=torch.int32, device=dev), finished=torch.zeros(B, dtype=torch.bool, device=dev),
                   done_at=torch.full((1,), Tmax, dtype=torch.long, device=dev))
-        eos = torch.full((B,), end_token, dtype=torch.long, device=dev)
         scale_e = math.sqrt(d)
 
         def step():
@@ -583,14 +582,8 @@ class _Engine:
                 y3 = K.gemm(h, L["l2"].w16, bias=L["l2"].b, residual=x2_32, out_dtype=F32)
                 x32, x16, _, _ = self._ln(y3, self.P(p + ".norm3.weight"), self.P(p + ".norm3.bias"))
             logits = K.gemm(x16, self.gen.w16, bias=self.gen.b, out_dtype=F32)
-            nxt = torch.where(st["finished"], eos, torch.argmax(logits, dim=-1))
-            t.add_(1)
-            gen.index_copy_(1, t, nxt.unsqueeze(1))
-            st["finished"].logical_or_(nxt == end_token)
-            all_done = st["finished"].all() & (st["done_at"] == Tmax)
-            st["done_at"].copy_(torch.where(all_done, t + 1, st["done_at"]))               # columns the reference would return
-            st["tok"].copy_(nxt.unsqueeze(1))
-            st["klen"].add_(1)
+            # argmax + finished / end-token logic + the step's counters (t, klen, tok, the column of `gen`): one launch
+            K.greedy_step(logits, st["finished"], gen, t, st["tok"], st["klen"], st["done_at"], end_token)
 
         n_steps = Tmax - 1
         done = 0

@@ -309,6 +309,17 @@ int adt_reduce_queue_begin(void* arena, size_t arena_bytes, void* stream);
 int adt_reduce_queue_flush(void);
 int adt_reduce_queue_end(int discard);
 
+/* The tail of one greedy-decode step (reference model.py:300-322: argmax of the generator's logits, finished rows keep emitting
+ * the end token, stop once every row has finished), on device state so that the whole step replays as a HIP graph:
+ *   nxt[b]  = finished[b] ? end_token : argmax_c logits[b][c]     (first index on ties; NaN counts as the maximum: torch.argmax)
+ *   gen[b][*t + 1] = nxt[b];  finished[b] |= nxt[b] == end_token;  tok[b] = nxt[b];  klen[b] += 1
+ *   if every row has finished and *done_at == max_length:  *done_at = *t + 2   (the number of columns the reference returns)
+ *   *t += 1
+ * logits fp32 [B, V] (row stride ld), finished uint8 [B], gen int64 [B, ld_gen >= max_length], t / done_at int64 scalars,
+ * tok int64 [B], klen int32 [B].  The caller keeps *t + 1 < max_length. */
+int adt_greedy_step(const float* logits, int64_t ld, int64_t B, int64_t V, uint8_t* finished, int64_t* gen, int64_t ld_gen,
+                    int64_t* t, int64_t* tok, int32_t* klen, int64_t* done_at, int64_t end_token, int64_t max_length, void* stream);
+
 /* ---------------------------------------------------------------------------
  * K7  token embedding * sqrt(d) + positional encoding
  *

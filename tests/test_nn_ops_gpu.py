@@ -156,3 +156,40 @@ def test_grad_norm_and_adamw_match_torch():
         k.adamw_step(p, g, m, v, step, 1e-3, 0.9, 0.999, 1e-8, 1e-2, nc, p16)
         assert (p - ref_p.data).abs().max() < 2e-6
     assert torch.equal(p16, p.bfloat16())
+
+
+def test_greedy_step_is_the_torch_tail():
+    """adt_greedy_step against the tensor ops it replaces in the decode step (argmax with torch's tie / NaN rules, finished rows
+    keep the end token, done_at latches the column count once every row has finished)."""
+    from adt_str_amd import kernels as k
+    B, V, Tmax, end = 9, 1400, 12, 3
+    g = torch.Generator().manual_seed(0)
+    gen = torch.full((B, Tmax), end, dtype=torch.long, device=DEV)
+    st = dict(t=torch.zeros(1, dtype=torch.long, device=DEV), tok=torch.zeros((B, 1), dtype=torch.long, device=DEV),
+              klen=torch.ones(B, dtype=torch.int32, device=DEV), finished=torch.zeros(B, dtype=torch.bool, device=DEV),
+              done_at=torch.full((1,), Tmax, dtype=torch.long, device=DEV))
+    ref = {n: v.clone() for n, v in st.items()}
+    ref_gen = gen.clone()
+    eos = torch.full((B,), end, dtype=torch.long, device=DEV)
+    for step in range(Tmax - 1):
+        logits = torch.randn((B, V + 8), generator=g).to(DEV)[:, :V]                 # a strided view
+        logits[0, 7] = logits[0, 900] = 50.0                                         # tie: the first index wins
+        if step == 1:
+            logits[1, 1234] = float("nan")                                           # NaN counts as the maximum
+        if step >= 2:
+            logits[2:, end] = 100.0                                                  # rows 2.. finish
+        if step >= 5:
+            logits[:2, end] = 100.0                                                  # ... and then the rest
+        k.greedy_step(logits, st["finished"], gen, st["t"], st["tok"], st["klen"], st["done_at"], end)
+        nxt = torch.where(ref["finished"], eos, torch.argmax(logits, dim=-1))
+        ref["t"].add_(1)
+        ref_gen.index_copy_(1, ref["t"], nxt.unsqueeze(1))
+        ref["finished"].logical_or_(nxt == end)
+        all_done = ref["finished"].all() & (ref["done_at"] == Tmax)
+        ref["done_at"].copy_(torch.where(all_done, ref["t"] + 1, ref["done_at"]))
+        ref["tok"].copy_(nxt.unsqueeze(1))
+        ref["klen"].add_(1)
+        assert torch.equal(gen, ref_gen), step
+        for n in st:
+            assert torch.equal(st[n], ref[n]), (n, step)
+    assert int(st["done_at"]) == 7 and int(gen[0, 1]) == 7 and int(gen[1, 2]) == 1234
