@@ -40,7 +40,7 @@ extern "C" {
  * backward entry points regenerate them from the same (p, key).  p == 0 or a null pointer: off. */
 typedef struct adt_dropout { float p; uint32_t key; } adt_dropout;
 
-/* ABI version (9): bumped whenever a signature below changes or entries are added. */
+/* ABI version (11): bumped whenever a signature below changes or entries are added. */
 int adt_version(void);
 
 /* Message of the last failing call on this thread ("" if none). */
