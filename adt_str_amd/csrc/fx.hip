@@ -84,10 +84,22 @@ __global__ __launch_bounds__(512) void fx_reverb_kernel(float* __restrict__ wav,
   float last = 0.f, peak = 0.f;
   float* row = wav + static_cast<long>(clip) * ld;
   int k = 0;
-  for (int n0 = 0; n0 < W; n0 += 64, ++k) {
+  // The input samples are requested a group of four chunks ahead: a chunk step is a chain of LDS round trips and scans of about a
+  // microsecond, and a global load at its head (first touch of the mix: HBM latency) doubled it.
+  float xq[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) xq[i] = 64 * i + lane < W ? row[64 * i + lane] : 0.f;
+  for (int g0 = 0; g0 < W; g0 += 256) {
+    float xn[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) { const int n = g0 + 256 + 64 * i + lane; xn[i] = n < W ? row[n] : 0.f; }
+#pragma unroll
+    for (int c4 = 0; c4 < 4; ++c4) {
+    const int n0 = g0 + 64 * c4;
+    if (n0 >= W) break;                                          // workgroup-uniform
     const int valid = W - n0 < 64 ? W - n0 : 64;
     const bool on = lane < valid;
-    const float x = on ? row[n0 + lane] : 0.f;
+    const float x = xq[c4];
     {
       int idx = pc + lane;
       idx = idx >= cs ? idx - cs : idx;
@@ -122,6 +134,10 @@ __global__ __launch_bounds__(512) void fx_reverb_kernel(float* __restrict__ wav,
         peak = fmaxf(peak, fabsf(y));
       }
     }
+    ++k;
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) xq[i] = xn[i];
   }
   if (wave == 0 && !(p.flags & 6)) {                               // no dynamics stage follows: this is the clip's new peak
 #pragma unroll
@@ -188,10 +204,20 @@ __global__ __launch_bounds__(64) void fx_dynamics_kernel(float* __restrict__ wav
   const float makeup = exp2f((10.0f * 0.75f / 40.0f) * 3.321928094887362f) * exp2f(-p.l_threshold_db * 0.16609640474436813f);
   float* row = wav + static_cast<long>(clip) * ld;
   float peak = 0.f;
-  for (int n0 = 0; n0 < W; n0 += 64) {
+  float xq[4];                                                      // inputs a group of four chunks ahead (see fx_reverb_kernel)
+#pragma unroll
+  for (int i = 0; i < 4; ++i) xq[i] = 64 * i + lane < W ? row[64 * i + lane] : 0.f;
+  for (int g0 = 0; g0 < W; g0 += 256) {
+    float xn[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) { const int n = g0 + 256 + 64 * i + lane; xn[i] = n < W ? row[n] : 0.f; }
+#pragma unroll
+    for (int c4 = 0; c4 < 4; ++c4) {
+    const int n0 = g0 + 64 * c4;
+    if (n0 >= W) break;
     const int valid = W - n0 < 64 ? W - n0 : 64;
     const bool on = lane < valid;
-    float y = on ? row[n0 + lane] : 0.f;
+    float y = xq[c4];
     if (comp) y = c.chunk(y, lane, valid);
     if (lim) {
       y = l1.chunk(y, lane, valid);
@@ -202,6 +228,9 @@ __global__ __launch_bounds__(64) void fx_dynamics_kernel(float* __restrict__ wav
       row[n0 + lane] = y;
       peak = fmaxf(peak, fabsf(y));
     }
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) xq[i] = xn[i];
   }
 #pragma unroll
   for (int off = 32; off > 0; off >>= 1) peak = fmaxf(peak, __shfl_xor(peak, off));
