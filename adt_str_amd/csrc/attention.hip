@@ -1457,7 +1457,7 @@ extern "C" int adt_attn_fwd(const adt_attn_desc* d, const void* q, const void* k
   a.q = static_cast<const unsigned short*>(q); a.k = static_cast<const unsigned short*>(k); a.v = static_cast<const unsigned short*>(v);
   a.out = static_cast<unsigned short*>(o); a.lse = lse;
   // one query per (batch, head) without dropout or a causal mask: the decode kernel (ADT_ATTN_NO_DECODE=1: the tiled kernel, for A/B)
-  if (d->q_len == 1 && !a.drop.on() && !a.causal && (d->ldk % 8) == 0 && (d->ldv % 2) == 0 && getenv("ADT_ATTN_NO_DECODE") == nullptr) {
+  if (d->q_len == 1 && !a.drop.on() && !a.causal && (d->ldq % 8) == 0 && (d->ldk % 8) == 0 && (d->ldv % 8) == 0 && getenv("ADT_ATTN_NO_DECODE") == nullptr) {
     hipLaunchKernelGGL(attn_decode_kernel, dim3(static_cast<unsigned>(d->batch) * d->heads), dim3(64 * kDecWaves), 0, static_cast<hipStream_t>(stream), a);
     ADT_HIP_TRY(hipGetLastError());
     return ADT_OK;
