@@ -14,7 +14,7 @@ _LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "libadt_hip
 _lock = threading.Lock()
 _lib = None
 
-ABI_VERSION = 11
+ABI_VERSION = 12
 
 i32, i64, f32, ptr = C.c_int32, C.c_int64, C.c_float, C.c_void_p
 
@@ -63,6 +63,7 @@ SIGNATURES = {
     "adt_gemm_workspace_bytes": [i32, i64, i64, i64],
     "adt_gemm_bf16": [i32, i64, i64, i64, ptr, i64, ptr, i64, ptr, i64, ptr, ptr, C.c_size_t, ptr],
     "adt_gemm_bf16_tn_grouped": [ptr, i32, ptr],
+    "adt_ln_gemm_bf16": [i64, i64, i64, ptr, i64, ptr, ptr, f32, ptr, i64, ptr, i64, ptr, ptr, i64, ptr],
     "adt_attn_fwd": [ptr, ptr, ptr, ptr, ptr, ptr, ptr],
     "adt_attn_bwd_workspace_bytes": [ptr],
     "adt_attn_bwd": [ptr, ptr, ptr, ptr, ptr, ptr, ptr, ptr, ptr, ptr, ptr, C.c_size_t, ptr],

@@ -977,6 +977,131 @@ __global__ __launch_bounds__(kSkinnyThreads) void gemm_nt_skinny_kernel(GemmArgs
     }
   }
 }
+// The same kernel with a LayerNorm in front of its A operand: C = LN(y) W^T (+ epilogue), y fp32 [M, K].  In the decode step every
+// LayerNorm output has exactly one GEMM that consumes it as an operand and one later GEMM that adds it as the residual, so the
+// twelve LayerNorm launches of a step fold into their consumers: every workgroup recomputes the row statistics of its (at most 64)
+// rows -- 8 x 3 KB from L2 -- normalises its A fragments on the fly, and writes its share of the columns of x32 = LN(y) for the
+// later residual.  Arithmetic of adt_layernorm_fwd: two-pass statistics in fp32, (y - mean) * rstd * gamma + beta, bf16 operand.
+struct LnPrologue { const float* y; long ldy; const float* gamma; const float* beta; float eps; float* x32; long ldx; };
+template <int kCtrl, int kRowMask>
+__device__ __forceinline__ float skinny_dpp_add(float v) {
+  return v + __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), kCtrl, kRowMask, 0xf, false));
+}
+__device__ __forceinline__ float skinny_wave_sum(float v) {   // DPP network: row_shr 1 / 2 / 4 / 8, row_bcast 15 / 31; lane 63 holds the total
+  v = skinny_dpp_add<0x111, 0xf>(v); v = skinny_dpp_add<0x112, 0xf>(v); v = skinny_dpp_add<0x114, 0xf>(v); v = skinny_dpp_add<0x118, 0xf>(v);
+  v = skinny_dpp_add<0x142, 0xa>(v); v = skinny_dpp_add<0x143, 0xc>(v);
+  return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 63));
+}
+template <bool kDrop, int kMT>
+__global__ __launch_bounds__(kSkinnyThreads) void gemm_nt_skinny_ln_kernel(GemmArgs g, LnPrologue p) {
+  __shared__ float part[4][16 * kMT][17];
+  __shared__ float mean_s[16 * kMT], rstd_s[16 * kMT];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int n0 = blockIdx.x * 16;
+  const int kq = g.K >> 2;
+  // ---- row statistics: wave w takes rows w, w + 4, ... two at a time; a lane holds K / 64 <= 16 elements of a row in registers, so a
+  // row costs one memory round trip (shared by the pair) and two DPP reductions
+  for (int r0 = wave; r0 < g.M; r0 += 8) {
+    float v[2][16];
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+      const int r = r0 + 4 * h < g.M ? r0 + 4 * h : r0;
+      const float* yr = p.y + static_cast<long>(r) * p.ldy;
+#pragma unroll
+      for (int i = 0; i < 16; ++i) v[h][i] = lane + 64 * i < g.K ? yr[lane + 64 * i] : 0.f;
+    }
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+      float s = 0.f;
+#pragma unroll
+      for (int i = 0; i < 16; ++i) s += v[h][i];
+      const float mean = skinny_wave_sum(s) / g.K;
+      float ss = 0.f;
+#pragma unroll
+      for (int i = 0; i < 16; ++i) { const float d = lane + 64 * i < g.K ? v[h][i] - mean : 0.f; ss = fmaf(d, d, ss); }
+      const float rstd = rsqrtf(skinny_wave_sum(ss) / g.K + p.eps);
+      if (lane == 0 && r0 + 4 * h < g.M) { mean_s[r0 + 4 * h] = mean; rstd_s[r0 + 4 * h] = rstd; }
+    }
+  }
+  __syncthreads();
+  // ---- this workgroup's columns of x32 = LN(y) (the residual of a later GEMM)
+  if (p.x32) {
+    const int cpw = (g.K + static_cast<int>(gridDim.x) - 1) / static_cast<int>(gridDim.x);
+    const int c0 = static_cast<int>(blockIdx.x) * cpw, c1 = c0 + cpw < g.K ? c0 + cpw : g.K;
+    for (int i = tid; i < g.M * cpw; i += kSkinnyThreads) {
+      const int r = i / cpw, c = c0 + i - r * cpw;
+      if (c < c1) p.x32[static_cast<long>(r) * p.ldx + c] = (p.y[static_cast<long>(r) * p.ldy + c] - mean_s[r]) * rstd_s[r] * p.gamma[c] + p.beta[c];
+    }
+  }
+  int brow = n0 + (lane & 15);
+  brow = brow < g.N ? brow : g.N - 1;
+  const unsigned short* pb = g.B + static_cast<long>(brow) * g.ldb + wave * kq + 8 * (lane >> 4);
+  const int kl = wave * kq + 8 * (lane >> 4);                 // this lane's first k of a step
+  const float* py[kMT];
+  float mu[kMT], rs[kMT];
+#pragma unroll
+  for (int t = 0; t < kMT; ++t) {
+    int arow = 16 * t + (lane & 15);
+    arow = arow < g.M ? arow : g.M - 1;
+    py[t] = p.y + static_cast<long>(arow) * p.ldy + kl;
+    mu[t] = mean_s[arow]; rs[t] = rstd_s[arow];
+  }
+  f32x4 acc[kMT];
+#pragma unroll
+  for (int t = 0; t < kMT; ++t) acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+  constexpr int kDepth = 4;                                    // fp32 operands: twice the registers per step of the bf16 kernel
+  for (int k = 0; k < kq; k += 32 * kDepth) {
+    bf16x8 fb[kDepth];
+    float4 ya[kMT][kDepth][2], ga[kDepth][2], be[kDepth][2];
+#pragma unroll
+    for (int i = 0; i < kDepth; ++i)
+      if (k + 32 * i < kq) {
+        fb[i] = *reinterpret_cast<const bf16x8*>(pb + k + 32 * i);
+        ga[i][0] = *reinterpret_cast<const float4*>(p.gamma + kl + k + 32 * i); ga[i][1] = *reinterpret_cast<const float4*>(p.gamma + kl + k + 32 * i + 4);
+        be[i][0] = *reinterpret_cast<const float4*>(p.beta + kl + k + 32 * i); be[i][1] = *reinterpret_cast<const float4*>(p.beta + kl + k + 32 * i + 4);
+#pragma unroll
+        for (int t = 0; t < kMT; ++t) {
+          ya[t][i][0] = *reinterpret_cast<const float4*>(py[t] + k + 32 * i);
+          ya[t][i][1] = *reinterpret_cast<const float4*>(py[t] + k + 32 * i + 4);
+        }
+      }
+#pragma unroll
+    for (int i = 0; i < kDepth; ++i)
+      if (k + 32 * i < kq) {
+#pragma unroll
+        for (int t = 0; t < kMT; ++t) {
+          union { bf16x8 v; unsigned u[4]; } fa;
+#pragma unroll
+          for (int h = 0; h < 2; ++h) {
+            const float4 y4 = ya[t][i][h], g4 = ga[i][h], b4 = be[i][h];
+            fa.u[2 * h] = pack_bf2((y4.x - mu[t]) * rs[t] * g4.x + b4.x, (y4.y - mu[t]) * rs[t] * g4.y + b4.y);
+            fa.u[2 * h + 1] = pack_bf2((y4.z - mu[t]) * rs[t] * g4.z + b4.z, (y4.w - mu[t]) * rs[t] * g4.w + b4.w);
+          }
+          acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa.v, fb[i], acc[t], 0, 0, 0);
+        }
+      }
+  }
+#pragma unroll
+  for (int t = 0; t < kMT; ++t)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) part[wave][16 * t + 4 * (lane >> 4) + j][lane & 15] = acc[t][j];
+  __syncthreads();
+  for (int q = tid; q < 32 * kMT; q += kSkinnyThreads) {
+    const int r = q >> 1, col = n0 + 8 * (q & 1);
+    if (r < g.M && col + 8 <= g.N) {
+      float z[8], bias[8];
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        const int c = 8 * (q & 1) + e;
+        z[e] = (part[0][r][c] + part[1][r][c]) + (part[2][r][c] + part[3][r][c]);
+        bias[e] = g.ep.bias ? g.ep.bias[col + e] : 0.f;
+      }
+      const EpiAddr ea = epilogue_addr<kDrop, kEpiGeneric>(g, r, col);
+      epilogue_apply8<kDrop, kEpiGeneric>(g, z, bias, ea, r, 0, col);
+    }
+  }
+}
 template <bool kDrop>
 static void launch_skinny(const GemmArgs& g, hipStream_t st) {
   const dim3 gs(static_cast<unsigned>((g.N + 15) / 16));
@@ -1545,6 +1670,35 @@ extern "C" int adt_gemm_bf16(int32_t trans, int64_t M, int64_t N, int64_t K, con
   ADT_HIP_TRY(hipGetLastError());
   if (e.colsum_out && !colsum_done)                  // the smaller tilings leave the sums to the stand-alone kernel
     return adt_colsum_bf16(C, ldc, M, N, e.colsum_out, ws, ws_bytes, stream);
+  return ADT_OK;
+}
+
+extern "C" int adt_ln_gemm_bf16(int64_t M, int64_t N, int64_t K, const float* y, int64_t ldy, const float* gamma, const float* beta, float eps,
+                               const void* B, int64_t ldb, void* C, int64_t ldc, const adt_gemm_epilogue* ep, float* x32, int64_t ldx, void* stream) {
+  using namespace adt;
+  if (!y || !gamma || !beta || !B || !C) return set_error(ADT_EINVAL, "adt_ln_gemm_bf16: null pointer");
+  if (M < 1 || M > 64 || N <= 0 || K <= 0 || (K % 128) != 0 || K > 1024) return set_error(ADT_ESHAPE, "adt_ln_gemm_bf16: 1 <= M <= 64, K a multiple of 128 up to 1024");
+  if ((ldy & 3) || (ldb & 7) || !aligned16(y) || !aligned16(B) || !aligned16(gamma) || !aligned16(beta) || (x32 && ldx < K))
+    return set_error(ADT_EINVAL, "adt_ln_gemm_bf16: y / gamma / beta / B must be 16-byte aligned with aligned row strides");
+  GemmArgs g{};
+  g.A = nullptr; g.lda = 0;
+  g.B = static_cast<const unsigned short*>(B); g.ldb = ldb;
+  g.C = C; g.ldc = ldc; g.M = static_cast<int>(M); g.N = static_cast<int>(N); g.K = static_cast<int>(K);
+  adt_gemm_epilogue e;
+  if (ep) e = *ep; else { e = adt_gemm_epilogue{}; e.alpha = 1.0f; }
+  if (e.colsum_out) return set_error(ADT_EINVAL, "adt_ln_gemm_bf16: colsum_out is not supported");
+  g.ep = e;
+  g.drop = make_drop(e.drop.p, e.drop.key);
+  g.drop_key2 = mix32(g.drop.key);
+  if (!vector_epilogue_ok(g, e)) return set_error(ADT_EINVAL, "adt_ln_gemm_bf16: outputs must be 16-byte aligned, N a multiple of 8");
+  const LnPrologue p{y, static_cast<long>(ldy), gamma, beta, eps, x32, static_cast<long>(ldx)};
+  const dim3 gs(static_cast<unsigned>((N + 15) / 16));
+  hipStream_t st = static_cast<hipStream_t>(stream);
+#define ADT_LN_SKINNY(D, T) hipLaunchKernelGGL((gemm_nt_skinny_ln_kernel<D, T>), gs, dim3(kSkinnyThreads), 0, st, g, p)
+  if (g.drop.on()) { if (M <= 16) ADT_LN_SKINNY(true, 1); else if (M <= 32) ADT_LN_SKINNY(true, 2); else ADT_LN_SKINNY(true, 4); }
+  else { if (M <= 16) ADT_LN_SKINNY(false, 1); else if (M <= 32) ADT_LN_SKINNY(false, 2); else ADT_LN_SKINNY(false, 4); }
+#undef ADT_LN_SKINNY
+  ADT_HIP_TRY(hipGetLastError());
   return ADT_OK;
 }
 

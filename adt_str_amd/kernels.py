@@ -259,6 +259,31 @@ def greedy_step(logits, finished, gen, t, tok, klen, done_at, end_token: int) ->
               _ffi.dptr(tok), _ffi.dptr(klen), _ffi.dptr(done_at), int(end_token), gen.shape[1], _ffi.current_stream())
 
 
+def ln_gemm(y32: torch.Tensor, gamma: torch.Tensor, beta: torch.Tensor, w: torch.Tensor, *, eps: float = 1e-5, want_x32: bool = True,
+            out_dtype=torch.bfloat16, bias: Optional[torch.Tensor] = None, residual: Optional[torch.Tensor] = None, act: int = 0):
+    """``LayerNorm(y32) @ w.T`` (+ bias / activation / residual) in one launch for at most 64 rows (``adt_ln_gemm_bf16``: the decode
+    step's LayerNorm -> projection pairs) -> ``(out [M, N], x32 = LayerNorm(y32) fp32 or None)``."""
+    assert y32.dtype == torch.float32 and y32.dim() == 2 and y32.stride(1) == 1 and w.dtype == torch.bfloat16 and w.dim() == 2 and w.stride(1) == 1
+    M, K = y32.shape
+    N = w.shape[0]
+    assert w.shape[1] == K and gamma.dtype == torch.float32 and beta.dtype == torch.float32 and gamma.numel() == K and beta.numel() == K
+    out = torch.empty((M, N), dtype=out_dtype, device=y32.device)
+    x32 = torch.empty((M, K), dtype=torch.float32, device=y32.device) if want_x32 else None
+    ep = _ffi.GemmEpilogue()
+    ep.alpha = 1.0
+    ep.act = act
+    ep.out_fp32 = 1 if out_dtype == torch.float32 else 0
+    if bias is not None:
+        assert bias.dtype == torch.float32 and bias.numel() == N
+        ep.bias = _ffi.dptr(bias)
+    if residual is not None:
+        assert residual.dtype == torch.float32 and residual.stride(-1) == 1 and residual.shape == (M, N)
+        ep.residual, ep.ld_res = _ffi.dptr(residual), residual.stride(-2)
+    _ffi.call("adt_ln_gemm_bf16", M, N, K, _ffi.dptr(y32), y32.stride(0), _ffi.dptr(gamma), _ffi.dptr(beta), eps, _ffi.dptr(w), w.stride(0),
+              _ffi.dptr(out), out.stride(0), C.byref(ep), _p(x32), K, _ffi.current_stream())
+    return out, x32
+
+
 class reduce_queue:
     """Context manager around adt_reduce_queue_begin / _flush / _end (include/adt_hip.h): inside it the second-stage reductions
     of `layernorm_bwd`, `colsum`, `gemm(colsum_out=...)` and `attn_bwd(bias_grad=...)` on the current stream are queued and

@@ -563,25 +563,46 @@ class _Engine:
                   done_at=torch.full((1,), Tmax, dtype=torch.long, device=dev))
         scale_e = math.sqrt(d)
 
+        # LayerNorm -> projection pairs in one launch (adt_ln_gemm_bf16): every LayerNorm output of the step feeds exactly one GEMM as
+        # its operand and one later GEMM as the residual, so the step's twelve LayerNorm launches fold into their consumers
+        fuse_ln = not self.fp32 and B <= 64 and d % 128 == 0 and not os.environ.get("ADT_NO_LN_GEMM")
+
         def step():
             t = st["t"]
             x32, x16 = self._embed(st["tok"], emb, pe.index_select(0, t), scale_e)         # PE row t
-            for L, cache, kvc in zip(self.dec, caches, kvcs):
+            qkv, y3 = None, None
+            for li, (L, cache, kvc) in enumerate(zip(self.dec, caches, kvcs)):
                 p = L["p"]
-                qkv = K.gemm(x16, L["sa"].w16, bias=L["sa"].b)                             # [B, 3d] of position t
+                if qkv is None:
+                    qkv = K.gemm(x16, L["sa"].w16, bias=L["sa"].b)                         # [B, 3d] of position t
                 cache.index_copy_(1, t, qkv.unsqueeze(1))
                 flat = cache.view(B * Tmax, 3 * d)
                 sa, _ = K.attn_fwd(qkv[:, :d], flat[:, d:2 * d], flat[:, 2 * d:], B, H, 1, Tmax, self.scale, key_len=st["klen"], head_dim=self.dh)
                 y1 = K.gemm(sa, L["sa_o"].w16, bias=L["sa_o"].b, residual=x32, out_dtype=F32)
-                x1_32, x1_16, _, _ = self._ln(y1, self.P(p + ".norm1.weight"), self.P(p + ".norm1.bias"))
-                qc = K.gemm(x1_16, L["ca"].w16[:d], bias=L["ca"].b[:d])
+                if fuse_ln:
+                    qc, x1_32 = K.ln_gemm(y1, self.P(p + ".norm1.weight"), self.P(p + ".norm1.bias"), L["ca"].w16[:d], bias=L["ca"].b[:d])
+                else:
+                    x1_32, x1_16, _, _ = self._ln(y1, self.P(p + ".norm1.weight"), self.P(p + ".norm1.bias"))
+                    qc = K.gemm(x1_16, L["ca"].w16[:d], bias=L["ca"].b[:d])
                 ca, _ = K.attn_fwd(qc, kvc[:, :d], kvc[:, d:], B, H, 1, S, self.scale, head_dim=self.dh)
                 y2 = K.gemm(ca, L["ca_o"].w16, bias=L["ca_o"].b, residual=x1_32, out_dtype=F32)
-                x2_32, x2_16, _, _ = self._ln(y2, self.P(p + ".norm2.weight"), self.P(p + ".norm2.bias"))
-                h = K.gemm(x2_16, L["l1"].w16, bias=L["l1"].b, act=1)
+                if fuse_ln:
+                    h, x2_32 = K.ln_gemm(y2, self.P(p + ".norm2.weight"), self.P(p + ".norm2.bias"), L["l1"].w16, bias=L["l1"].b, act=1)
+                else:
+                    x2_32, x2_16, _, _ = self._ln(y2, self.P(p + ".norm2.weight"), self.P(p + ".norm2.bias"))
+                    h = K.gemm(x2_16, L["l1"].w16, bias=L["l1"].b, act=1)
                 y3 = K.gemm(h, L["l2"].w16, bias=L["l2"].b, residual=x2_32, out_dtype=F32)
-                x32, x16, _, _ = self._ln(y3, self.P(p + ".norm3.weight"), self.P(p + ".norm3.bias"))
-            logits = K.gemm(x16, self.gen.w16, bias=self.gen.b, out_dtype=F32)
+                n3w, n3b = self.P(p + ".norm3.weight"), self.P(p + ".norm3.bias")
+                if not fuse_ln:
+                    x32, x16, _, _ = self._ln(y3, n3w, n3b)
+                    qkv = None
+                elif li + 1 < len(self.dec):                                               # norm3 -> the next layer's in-projection
+                    nxt_l = self.dec[li + 1]
+                    qkv, x32 = K.ln_gemm(y3, n3w, n3b, nxt_l["sa"].w16, bias=nxt_l["sa"].b)
+            if fuse_ln:                                                                    # the last norm3 -> generator (model.py:190)
+                logits, _ = K.ln_gemm(y3, n3w, n3b, self.gen.w16, bias=self.gen.b, out_dtype=F32, want_x32=False)
+            else:
+                logits = K.gemm(x16, self.gen.w16, bias=self.gen.b, out_dtype=F32)
             # argmax + finished / end-token logic + the step's counters (t, klen, tok, the column of `gen`): one launch
             K.greedy_step(logits, st["finished"], gen, t, st["tok"], st["klen"], st["done_at"], end_token)
 

@@ -40,7 +40,7 @@ extern "C" {
  * backward entry points regenerate them from the same (p, key).  p == 0 or a null pointer: off. */
 typedef struct adt_dropout { float p; uint32_t key; } adt_dropout;
 
-/* ABI version (11): bumped whenever a signature below changes or entries are added. */
+/* ABI version (12): bumped whenever a signature below changes or entries are added. */
 int adt_version(void);
 
 /* Message of the last failing call on this thread ("" if none). */
@@ -207,6 +207,14 @@ size_t adt_gemm_colsum_workspace_bytes(int64_t M, int64_t N);
 int adt_gemm_bf16(int32_t trans, int64_t M, int64_t N, int64_t K, const void* A, int64_t lda,
                   const void* B, int64_t ldb, void* C, int64_t ldc, const adt_gemm_epilogue* ep,
                   void* ws, size_t ws_bytes, void* stream);
+
+/* C = LayerNorm(y) @ B^T (+ the epilogue of adt_gemm_bf16) for a handful of rows: the decode step's LayerNorm -> projection pairs
+ * (reference model.py:159-168 inside the sampler loop :260-324) in one launch.  y fp32 [M, K] (1 <= M <= 64, K a multiple of
+ * 128 up to 1024), gamma / beta fp32 [K], B bf16 [N, K]; the operand is LN(y) rounded to bf16, exactly what adt_layernorm_fwd
+ * hands to adt_gemm_bf16 (two-pass statistics in fp32).  x32 (optional, fp32 [M, ldx]) receives LN(y) itself -- the residual
+ * a later GEMM adds.  Other shapes: ADT_ESHAPE (call adt_layernorm_fwd + adt_gemm_bf16). */
+int adt_ln_gemm_bf16(int64_t M, int64_t N, int64_t K, const float* y, int64_t ldy, const float* gamma, const float* beta, float eps,
+                     const void* B, int64_t ldb, void* C, int64_t ldc, const adt_gemm_epilogue* ep, float* x32, int64_t ldx, void* stream);
 
 /* Grouped weight gradients: C_i[M_i, N_i] (fp32) = A_i[K_i, M_i]^T B_i[K_i, N_i] (bf16) for up to 32 independent items in ONE
  * launch, whole-K tiles, no workspace.  Replaces the autograd weight-gradient GEMMs of the reference's decoder layers

@@ -344,3 +344,24 @@ def test_skinny_rows_kernel(M, N, K, monkeypatch):
     aux = torch.empty((M, N), dtype=torch.bfloat16, device=DEV)
     out = k.gemm(a, w, out_dtype=torch.float32, aux_bf16_out=aux)
     assert torch.equal(aux, out.bfloat16())
+
+
+@pytest.mark.parametrize("M", [1, 8, 17, 64])
+@pytest.mark.parametrize("N,K", [(768, 768), (2304, 768), (1400, 768), (3072, 768), (768, 1024), (64, 128)])
+def test_layernorm_fused_into_the_skinny_gemm(M, N, K):
+    """adt_ln_gemm_bf16 (the decode step's LayerNorm -> projection pairs in one launch) against adt_layernorm_fwd + adt_gemm_bf16:
+    the LayerNorm output it also emits, and the product with bias / GELU / residual / fp32 output."""
+    from adt_str_amd import kernels as k
+    y = rnd((M, K + 4), 11 + M, 2.0)[:, :K] + 0.5                        # row stride != K, non-zero mean
+    gamma, beta = rnd((K,), 12) * 0.2 + 1.0, rnd((K,), 13) * 0.1
+    w, bias, res = rnd((N, K), 14, 0.05).bfloat16(), rnd((N,), 15), rnd((M, N), 16)
+    x32_ref, x16_ref, _, _ = k.layernorm_fwd(y.contiguous(), gamma, beta)
+    out, x32 = k.ln_gemm(y, gamma, beta, w, bias=bias)
+    assert (x32 - x32_ref).abs().max() < 2e-5
+    close(out, k.gemm(x16_ref, w, bias=bias).float(), 8e-3, "bias")
+    out, _ = k.ln_gemm(y, gamma, beta, w, bias=bias, residual=res, out_dtype=torch.float32, want_x32=False)
+    close(out, k.gemm(x16_ref, w, bias=bias, residual=res, out_dtype=torch.float32), 2e-3, "bias + residual, fp32 out")
+    out, _ = k.ln_gemm(y, gamma, beta, w, bias=bias, act=1)
+    close(out, k.gemm(x16_ref, w, bias=bias, act=1).float(), 1e-2, "bias + gelu")
+    with pytest.raises(RuntimeError):
+        k.ln_gemm(rnd((65, K), 1), gamma, beta, w)

@@ -217,6 +217,16 @@ def test_cached_greedy_decode_is_the_full_recompute_decode():
     eager = eng.greedy_decode_cached(mem16, B, S, 72, 2, -1, use_graph=False)
     replay = eng.greedy_decode_cached(mem16, B, S, 72, 2, -1, use_graph=True)
     assert eager.shape == (4, 72) and torch.equal(eager, replay)
+    # the step with its LayerNorms folded into the consuming projections (default) against separate LayerNorm launches: the
+    # logits differ by fp32 summation order only; the first tokens must agree (later ones may part ways on a near-tie of a
+    # random-init model, after which the prefixes differ)
+    import os
+    os.environ["ADT_NO_LN_GEMM"] = "1"
+    try:
+        unfused = eng.greedy_decode_cached(mem16, B, S, 72, 2, -1, use_graph=False)
+    finally:
+        del os.environ["ADT_NO_LN_GEMM"]
+    assert torch.equal(unfused[:, :8], eager[:, :8]) and (unfused == eager).float().mean() > 0.5
 
 
 def test_full_size_statistics(golden_dir):
