@@ -365,3 +365,34 @@ def test_layernorm_fused_into_the_skinny_gemm(M, N, K):
     close(out, k.gemm(x16_ref, w, bias=bias, act=1).float(), 1e-2, "bias + gelu")
     with pytest.raises(RuntimeError):
         k.ln_gemm(rnd((65, K), 1), gamma, beta, w)
+
+
+@pytest.mark.parametrize("group", ["1", "2", "5", "7", "99"])
+def test_column_group_tile_orders_cover_the_output(group):
+    """The persistent NT kernel walks the tile grid in column groups (default 3 tile columns; ADT_GEMM_GROUP_N is read once per
+    process, hence the subprocess): every group width -- including ones that leave a narrower last group (9 and 12 tile columns
+    with 5 or 7 per group) and the row-major order (99) -- must produce the same bits as the default order."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = (
+        "import torch, hashlib\n"
+        "from adt_str_amd import kernels as k\n"
+        "g = torch.Generator().manual_seed(3)\n"
+        "out = []\n"
+        "for M, N, K in ((63104 // 4, 2304, 768), (8192, 3072, 768), (5000, 1400, 256)):\n"
+        "    a = torch.randn((M, K), generator=g).cuda().bfloat16(); w = (torch.randn((N, K), generator=g) * 0.05).cuda().bfloat16()\n"
+        "    bias = torch.randn(N, generator=g).cuda()\n"
+        "    y = k.gemm(a, w, bias=bias, act=1)\n"
+        "    out.append(hashlib.sha1(y.view(torch.int16).cpu().numpy().tobytes()).hexdigest())\n"
+        "print('HASH', *out)\n")
+    def run(env_group):
+        env = dict(os.environ, PYTHONPATH=root + os.pathsep + os.environ.get("PYTHONPATH", ""))
+        env.pop("ADT_GEMM_GROUP_N", None)
+        if env_group is not None:
+            env["ADT_GEMM_GROUP_N"] = env_group
+        r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, env=env, timeout=300)
+        assert r.returncode == 0, r.stderr[-2000:]
+        return [l for l in r.stdout.splitlines() if l.startswith("HASH")][0]
+    assert run(group) == run(None)
