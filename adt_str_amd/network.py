@@ -565,7 +565,7 @@ class _Engine:
 
         # LayerNorm -> projection pairs in one launch (adt_ln_gemm_bf16): every LayerNorm output of the step feeds exactly one GEMM as
         # its operand and one later GEMM as the residual, so the step's twelve LayerNorm launches fold into their consumers
-        fuse_ln = not self.fp32 and B <= 64 and d % 128 == 0 and not os.environ.get("ADT_NO_LN_GEMM")
+        fuse_ln = not self.fp32 and B <= 64 and d % 128 == 0 and d <= 1024 and not os.environ.get("ADT_NO_LN_GEMM")
 
         def step():
             t = st["t"]
