@@ -175,6 +175,8 @@ int copy_one(const char* src, const char* dst) {
   if (in.fd < 0) return ADT_EINVAL;
   struct stat st;
   if (fstat(in.fd, &st) != 0 || !S_ISREG(st.st_mode)) return ADT_EINVAL;
+  struct stat sd;
+  if (stat(dst, &sd) == 0 && sd.st_dev == st.st_dev && sd.st_ino == st.st_ino) return ADT_EINVAL;   // same file (shutil.SameFileError): never truncate the source
   Fd out(open(dst, O_WRONLY | O_CREAT | O_TRUNC | O_CLOEXEC, 0666));
   if (out.fd < 0) return ADT_EINVAL;
   int64_t left = st.st_size;

@@ -118,6 +118,8 @@ def test_batched_copy_is_copy2(tmp_path):
         fh.write(b"x" * 1_000_000)
     status = A.copy_files(srcs + [files["missing.wav"], srcs[0]], dsts + [str(tmp_path / "out" / "m.wav"), str(tmp_path / "nodir" / "a.wav")], threads=4)
     assert status[:-2].tolist() == [0] * len(srcs) and status[-2] != 0 and status[-1] != 0
+    before = open(srcs[3], "rb").read()
+    assert A.copy_files([srcs[3]], [srcs[3]])[0] != 0 and open(srcs[3], "rb").read() == before     # onto itself: refused, not truncated
     for s, d in zip(srcs, dsts):
         ref = str(tmp_path / "ref.bin")
         shutil.copy2(s, ref)
