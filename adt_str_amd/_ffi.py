@@ -14,7 +14,7 @@ _LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "libadt_hip
 _lock = threading.Lock()
 _lib = None
 
-ABI_VERSION = 12
+ABI_VERSION = 13
 
 i32, i64, f32, ptr = C.c_int32, C.c_int64, C.c_float, C.c_void_p
 
@@ -29,7 +29,8 @@ class GemmEpilogue(C.Structure):
                 ("pre_act_out", C.c_void_p), ("ld_pre_act", C.c_int64), ("residual", C.c_void_p),
                 ("ld_res", C.c_int64), ("res_row_mod", C.c_int32), ("act", C.c_int32), ("alpha", C.c_float),
                 ("out_fp32", C.c_int32), ("aux_bf16_out", C.c_void_p), ("ld_aux", C.c_int64), ("drop", Dropout),
-                ("drop_after_residual", C.c_int32), ("colsum_out", C.c_void_p), ("act_grad_mode", C.c_int32)]
+                ("drop_after_residual", C.c_int32), ("colsum_out", C.c_void_p), ("act_grad_mode", C.c_int32),
+                ("res_ln_mean", C.c_void_p), ("res_ln_rstd", C.c_void_p), ("res_ln_gamma", C.c_void_p), ("res_ln_beta", C.c_void_p)]
 
 
 class GemmTnItem(C.Structure):

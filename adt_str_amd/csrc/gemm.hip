@@ -153,7 +153,8 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& g, f32x4 (&acc)[4]
         if (kDrop && !ep.drop_after_residual) z *= keep;
         if (ep.residual) {
           const long rr = ep.res_row_mod > 0 ? (row % ep.res_row_mod) : row;
-          z += reinterpret_cast<const float*>(ep.residual)[rr * ep.ld_res + col];
+          const float rv = reinterpret_cast<const float*>(ep.residual)[rr * ep.ld_res + col];
+          z += ep.res_ln_mean ? (rv - ep.res_ln_mean[row]) * ep.res_ln_rstd[row] * ep.res_ln_gamma[col] + ep.res_ln_beta[col] : rv;
         }
         if (kDrop && ep.drop_after_residual) z *= keep;
         if (ep.aux_bf16_out) reinterpret_cast<unsigned short*>(ep.aux_bf16_out)[static_cast<long>(row) * ep.ld_aux + col] = f2bf(z);
@@ -244,12 +245,12 @@ constexpr int kEpiLds = 128 * kEpiPitch * 4;          // 67,584 B
 // flags of adt_gemm_epilogue at run time.
 enum : unsigned {
   kEfBias = 1u, kEfGeluGrad = 2u, kEfFactor = 4u, kEfPreAct = 8u, kEfGelu = 16u, kEfRelu = 32u, kEfResidual = 64u, kEfRowMod = 128u,
-  kEfDropAfterRes = 256u, kEfAux = 512u, kEfFp32 = 1024u, kEfAlpha = 2048u, kEpiGeneric = 0x80000000u
+  kEfDropAfterRes = 256u, kEfAux = 512u, kEfFp32 = 1024u, kEfAlpha = 2048u, kEfResLn = 4096u, kEpiGeneric = 0x80000000u
 };
 static unsigned epilogue_mask(const adt_gemm_epilogue& e) {
   return (e.bias ? kEfBias : 0u) | (e.gelu_grad_of ? kEfGeluGrad : 0u) | (e.act_grad_mode ? kEfFactor : 0u) | (e.pre_act_out ? kEfPreAct : 0u) |
          (e.act == 1 ? kEfGelu : 0u) | (e.act == 2 ? kEfRelu : 0u) | (e.residual ? kEfResidual : 0u) | (e.residual && e.res_row_mod > 0 ? kEfRowMod : 0u) |
-         (e.drop.p > 0.f && e.drop_after_residual ? kEfDropAfterRes : 0u) | (e.aux_bf16_out ? kEfAux : 0u) | (e.out_fp32 ? kEfFp32 : 0u) | (e.alpha != 1.0f ? kEfAlpha : 0u);
+         (e.drop.p > 0.f && e.drop_after_residual ? kEfDropAfterRes : 0u) | (e.aux_bf16_out ? kEfAux : 0u) | (e.out_fp32 ? kEfFp32 : 0u) | (e.alpha != 1.0f ? kEfAlpha : 0u) | (e.residual && e.res_ln_mean ? kEfResLn : 0u);
 }
 template <unsigned kMask, unsigned kBit>
 __device__ __forceinline__ bool ef(bool at_run_time) {
@@ -359,7 +360,16 @@ __device__ __forceinline__ void epilogue_apply8(const GemmArgs& g, float (&z)[8]
     const float* rp = reinterpret_cast<const float*>(ep.residual) +
                       (ef<kMask, kEfRowMod>(ep.res_row_mod > 0) ? static_cast<long>(row % ep.res_row_mod) * ep.ld_res + col : (ea.res + static_cast<long>(irow) * ep.ld_res));
     const float4 r0 = *reinterpret_cast<const float4*>(rp), r1 = *reinterpret_cast<const float4*>(rp + 4);
-    z[0] += r0.x; z[1] += r0.y; z[2] += r0.z; z[3] += r0.w; z[4] += r1.x; z[5] += r1.y; z[6] += r1.z; z[7] += r1.w;
+    if (ef<kMask, kEfResLn>(ep.res_ln_mean != nullptr)) {
+      // the residual is LayerNorm(y), rebuilt from the pre-LayerNorm row: adt_layernorm_fwd's (y - mean) * rstd * gamma + beta
+      const float mu = ep.res_ln_mean[row], rs = ep.res_ln_rstd[row];
+      const float4 g0 = *reinterpret_cast<const float4*>(ep.res_ln_gamma + col), g1 = *reinterpret_cast<const float4*>(ep.res_ln_gamma + col + 4);
+      const float4 b0 = *reinterpret_cast<const float4*>(ep.res_ln_beta + col), b1 = *reinterpret_cast<const float4*>(ep.res_ln_beta + col + 4);
+      z[0] += (r0.x - mu) * rs * g0.x + b0.x; z[1] += (r0.y - mu) * rs * g0.y + b0.y; z[2] += (r0.z - mu) * rs * g0.z + b0.z; z[3] += (r0.w - mu) * rs * g0.w + b0.w;
+      z[4] += (r1.x - mu) * rs * g1.x + b1.x; z[5] += (r1.y - mu) * rs * g1.y + b1.y; z[6] += (r1.z - mu) * rs * g1.z + b1.z; z[7] += (r1.w - mu) * rs * g1.w + b1.w;
+    } else {
+      z[0] += r0.x; z[1] += r0.y; z[2] += r0.z; z[3] += r0.w; z[4] += r1.x; z[5] += r1.y; z[6] += r1.z; z[7] += r1.w;
+    }
   }
   if (kDrop && drop_late) {
 #pragma unroll
@@ -1424,6 +1434,8 @@ static int launch_nt_256(const GemmArgs& g, dim3 grid, int tm, int tn, hipStream
   X(false, false, kEfBias)                                    /* in-projections */                                      \
   X(true, false, kEfBias | kEfResidual | kEfFp32)             /* out-proj / FFN linear2: bias, dropout, residual */     \
   X(false, false, kEfBias | kEfResidual | kEfFp32)            /* ... with dropout off */                                \
+  X(true, false, kEfBias | kEfResidual | kEfFp32 | kEfResLn)  /* ... the residual rebuilt from the pre-LayerNorm tensor */ \
+  X(false, false, kEfBias | kEfResidual | kEfFp32 | kEfResLn)                                                            \
   X(false, false, kEfResidual | kEfFp32)                      /* data gradient added to the residual stream's */        \
   X(false, true, kEfGeluGrad | kEfFactor)                     /* FFN data gradient x saved factor, + bias gradient */   \
   X(false, false, kEfGeluGrad | kEfFactor)
@@ -1543,6 +1555,10 @@ extern "C" int adt_gemm_bf16(int32_t trans, int64_t M, int64_t N, int64_t K, con
   hipStream_t st = static_cast<hipStream_t>(stream);
   g.colsum_ws = nullptr;
   bool colsum_done = false;
+  if (e.res_ln_mean) {
+    if (!e.residual || !e.res_ln_rstd || !e.res_ln_gamma || !e.res_ln_beta || e.res_row_mod > 0 || trans || !aligned16(e.res_ln_gamma) || !aligned16(e.res_ln_beta))
+      return set_error(ADT_EINVAL, "adt_gemm_bf16: res_ln_* needs trans = 0, a residual (the pre-LayerNorm tensor), rstd / gamma / beta (16-byte aligned) and res_row_mod = 0");
+  }
   if (e.colsum_out) {
     if (trans || e.out_fp32) return set_error(ADT_EINVAL, "adt_gemm_bf16: colsum_out needs trans = 0 and a bf16 output");
     if (!ws || !aligned16(ws) || ws_bytes < adt_gemm_colsum_workspace_bytes(M, N))

@@ -454,7 +454,7 @@ extern "C" int adt_gemm_f32(int32_t layout, int64_t M, int64_t N, int64_t K, con
   g.A = A; g.B = B; g.C = C; g.lda = lda; g.ldb = ldb; g.ldc = ldc; g.M = static_cast<int>(M); g.N = static_cast<int>(N); g.K = static_cast<int>(K);
   g.alpha = 1.0f; g.drop = Drop{0u, 0u, 1.0f};
   if (ep) {
-    if (ep->aux_bf16_out || ep->colsum_out) return set_error(ADT_EINVAL, "adt_gemm_f32: aux_bf16_out / colsum_out are not part of the fp32 path");
+    if (ep->aux_bf16_out || ep->colsum_out || ep->res_ln_mean) return set_error(ADT_EINVAL, "adt_gemm_f32: aux_bf16_out / colsum_out / res_ln_* are not part of the fp32 path");
     g.bias = ep->bias; g.gelu_grad_of = static_cast<const float*>(ep->gelu_grad_of); g.ld_gg = ep->ld_gelu_grad;
     g.pre_act_out = static_cast<float*>(ep->pre_act_out); g.ld_pa = ep->ld_pre_act;
     g.residual = static_cast<const float*>(ep->residual); g.ld_res = ep->ld_res; g.res_row_mod = ep->res_row_mod;

@@ -57,11 +57,13 @@ def gemm(a: torch.Tensor, b: torch.Tensor, *, trans: bool = False, out: Optional
          gelu_grad_of: Optional[torch.Tensor] = None, alpha: float = 1.0,
          aux_bf16_out: Optional[torch.Tensor] = None, drop=None, drop_after_residual: bool = False,
          colsum_out: Optional[torch.Tensor] = None, b_kn: bool = False, act_grad_out: Optional[torch.Tensor] = None,
-         act_grad: Optional[torch.Tensor] = None) -> torch.Tensor:
+         act_grad: Optional[torch.Tensor] = None, residual_ln=None) -> torch.Tensor:
     """``trans=False``: ``a[M,K] @ b[N,K].T``; ``trans=True``: ``a[K,M].T @ b[K,N]`` (bf16 in, fp32 accumulate).
     ``colsum_out`` (fp32 [N]) also receives the column sums of the bf16 output.
     ``act_grad_out`` (forward, with ``act=1``): receives ``gelu'(z) * dropout-keep`` instead of the pre-activation;
     ``act_grad`` (backward): that saved factor, multiplied in as stored (``adt_gemm_epilogue.act_grad_mode``).
+    ``residual_ln = (mean, rstd, gamma, beta)``: ``residual`` is the PRE-LayerNorm tensor and the epilogue adds LayerNorm(residual)
+    rebuilt from those statistics (the LayerNorm then never writes its fp32 output; bf16 path only).
     fp32 operands take the fp32-operand parity path (``adt_gemm_f32``: same epilogue, fp32 everywhere); there
     ``b_kn=True`` reads ``b`` as ``[K, N]`` (``a[M,K] @ b[K,N]``, the data gradient against the master weight)."""
     mode = 0
@@ -69,6 +71,7 @@ def gemm(a: torch.Tensor, b: torch.Tensor, *, trans: bool = False, out: Optional
         assert pre_act_out is None and gelu_grad_of is None and (act_grad_out is None or act == 1) and (act_grad is None or drop is None)
         pre_act_out, gelu_grad_of, mode = act_grad_out, act_grad, 1
     if a.dtype == torch.float32:
+        assert residual_ln is None, "residual_ln is a bf16-path epilogue"
         return _gemm_f32(a, b, trans=trans, b_kn=b_kn, out=out, bias=bias, residual=residual, res_row_mod=res_row_mod, act=act,
                          pre_act_out=pre_act_out, gelu_grad_of=gelu_grad_of, alpha=alpha, drop=drop,
                          drop_after_residual=drop_after_residual, colsum_out=colsum_out, aux_out=aux_bf16_out, mode=mode)
@@ -98,6 +101,12 @@ def gemm(a: torch.Tensor, b: torch.Tensor, *, trans: bool = False, out: Optional
     if residual is not None:
         assert residual.dtype == torch.float32 and residual.stride(-1) == 1
         ep.residual, ep.ld_res, ep.res_row_mod = _ffi.dptr(residual), residual.stride(-2), res_row_mod
+    if residual_ln is not None:
+        mean, rstd, ln_g, ln_b = residual_ln
+        assert residual is not None and res_row_mod == 0 and residual.shape == (M, N)
+        for t_, n_ in ((mean, M), (rstd, M), (ln_g, N), (ln_b, N)):
+            assert t_.dtype == torch.float32 and t_.is_contiguous() and t_.numel() == n_
+        ep.res_ln_mean, ep.res_ln_rstd, ep.res_ln_gamma, ep.res_ln_beta = _ffi.dptr(mean), _ffi.dptr(rstd), _ffi.dptr(ln_g), _ffi.dptr(ln_b)
     if pre_act_out is not None:
         assert pre_act_out.dtype == torch.bfloat16 and pre_act_out.shape == (M, N)
         ep.pre_act_out, ep.ld_pre_act = _ffi.dptr(pre_act_out), pre_act_out.stride(0)

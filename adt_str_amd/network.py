@@ -274,6 +274,11 @@ class _Engine:
             return (y32 if want32 else None), y32, mean, rstd
         return K.layernorm_fwd(x, g, b, want32=want32, drop=drop)
 
+    def _lean_ln(self) -> bool:
+        """LayerNorms inside the layer stacks write only their bf16 output; the fp32 residual is rebuilt by the consuming GEMM's
+        epilogue (bf16 path; ADT_NO_RES_LN=1 keeps the fp32 outputs, for A/B runs)."""
+        return not self.fp32 and not os.environ.get("ADT_NO_RES_LN")
+
     def _ln_bwd(self, *a, **kw):
         return K.layernorm_bwd(*a, branch_dtype=self.adt, **kw)
 
@@ -296,16 +301,27 @@ class _Engine:
                                    drop=self.D("enc.pe"), drop_after_residual=True)   # dense + PE + dropout (model.py:130-132)
         if save is not None:
             save.append(dict(mel16=mel16, x0=x0, B=B, S=S))
-        for L in self.enc:
+        # The residual stream between two LayerNorms is read exactly once, by the epilogue of the next residual GEMM: that epilogue
+        # rebuilds LayerNorm(y) from the saved pre-LayerNorm tensor and its row statistics (adt_gemm_epilogue.res_ln_*), so the
+        # LayerNorms write only their bf16 output -- 4 bytes per element less HBM traffic each.  `res` is what the next residual
+        # GEMM adds: {"residual": x32} or {"residual": y, "residual_ln": (mean, rstd, gamma, beta)}.
+        lean = self._lean_ln()
+        res = dict(residual=x32)
+        for li, L in enumerate(self.enc):
             p = L["p"]
             qkv = K.gemm(x16, L["sa"].w16, bias=L["sa"].b)
             attn, lse = K.attn_fwd(qkv[:, :d], qkv[:, d:2 * d], qkv[:, 2 * d:], B, H, S, S, self.scale, drop=self.D(p + ".attn"), head_dim=self.dh)
-            y1 = K.gemm(attn, L["sa_o"].w16, bias=L["sa_o"].b, residual=x32, out_dtype=F32, drop=self.D(p + ".drop1"))
-            x1_32, x1_16, mean1, rstd1 = self._ln(y1, self.P(p + ".norm1.weight"), self.P(p + ".norm1.bias"))
+            y1 = K.gemm(attn, L["sa_o"].w16, bias=L["sa_o"].b, out_dtype=F32, drop=self.D(p + ".drop1"), **res)
+            g1, b1 = self.P(p + ".norm1.weight"), self.P(p + ".norm1.bias")
+            x1_32, x1_16, mean1, rstd1 = self._ln(y1, g1, b1, want32=not lean)
+            res = dict(residual=y1, residual_ln=(mean1, rstd1, g1, b1)) if lean else dict(residual=x1_32)
             u = torch.empty((M, L["l1"].w16.shape[0]), dtype=self.adt, device=src.device)
             h = K.gemm(x1_16, L["l1"].w16, bias=L["l1"].b, act=1, act_grad_out=u, drop=self.D(p + ".ffn"))
-            y2 = K.gemm(h, L["l2"].w16, bias=L["l2"].b, residual=x1_32, out_dtype=F32, drop=self.D(p + ".drop2"))
-            x2_32, x2_16, mean2, rstd2 = self._ln(y2, self.P(p + ".norm2.weight"), self.P(p + ".norm2.bias"))
+            y2 = K.gemm(h, L["l2"].w16, bias=L["l2"].b, out_dtype=F32, drop=self.D(p + ".drop2"), **res)
+            g2, b2 = self.P(p + ".norm2.weight"), self.P(p + ".norm2.bias")
+            last = li + 1 == len(self.enc)                                 # the final LayerNorm reads this one's fp32 output
+            x2_32, x2_16, mean2, rstd2 = self._ln(y2, g2, b2, want32=last or not lean)
+            res = dict(residual=y2, residual_ln=(mean2, rstd2, g2, b2)) if lean and not last else dict(residual=x2_32)
             if save is not None:
                 save.append(dict(x16=x16, qkv=qkv, attn=attn, lse=lse, y1=y1, mean1=mean1, rstd1=rstd1, x1_16=x1_16, u=u, h=h,
                                  y2=y2, mean2=mean2, rstd2=rstd2))
@@ -333,23 +349,31 @@ class _Engine:
             wkv = torch.cat([L["ca"].w16[d:] for L in self.dec])
             bkv = torch.cat([L["ca"].b[d:] for L in self.dec])
             kv_all = K.gemm(mem16, wkv, bias=bkv)
+        lean = self._lean_ln()
+        res = dict(residual=x32)
         for li, L in enumerate(self.dec):
             p = L["p"]
             qkv = K.gemm(x16, L["sa"].w16, bias=L["sa"].b)
             sa, lse_s = K.attn_fwd(qkv[:, :d], qkv[:, d:2 * d], qkv[:, 2 * d:], B, H, T, T, self.scale, causal=True, key_len=key_len,
                                    drop=self.D(p + ".sattn"), head_dim=self.dh)
-            y1 = K.gemm(sa, L["sa_o"].w16, bias=L["sa_o"].b, residual=x32, out_dtype=F32, drop=self.D(p + ".drop1"))
-            x1_32, x1_16, mean1, rstd1 = self._ln(y1, self.P(p + ".norm1.weight"), self.P(p + ".norm1.bias"))
+            y1 = K.gemm(sa, L["sa_o"].w16, bias=L["sa_o"].b, out_dtype=F32, drop=self.D(p + ".drop1"), **res)
+            g1, b1 = self.P(p + ".norm1.weight"), self.P(p + ".norm1.bias")
+            x1_32, x1_16, mean1, rstd1 = self._ln(y1, g1, b1, want32=not lean)
+            res = dict(residual=y1, residual_ln=(mean1, rstd1, g1, b1)) if lean else dict(residual=x1_32)
             ca_w, ca_b = L["ca"].w16, L["ca"].b
             qc = K.gemm(x1_16, ca_w[:d], bias=ca_b[:d])
             kvc = kv_all[:, 2 * d * li:2 * d * (li + 1)] if kv_all is not None else K.gemm(mem16, ca_w[d:], bias=ca_b[d:])
             ca, lse_c = K.attn_fwd(qc, kvc[:, :d], kvc[:, d:], B, H, T, S, self.scale, drop=self.D(p + ".cattn"), head_dim=self.dh)
-            y2 = K.gemm(ca, L["ca_o"].w16, bias=L["ca_o"].b, residual=x1_32, out_dtype=F32, drop=self.D(p + ".drop2"))
-            x2_32, x2_16, mean2, rstd2 = self._ln(y2, self.P(p + ".norm2.weight"), self.P(p + ".norm2.bias"))
+            y2 = K.gemm(ca, L["ca_o"].w16, bias=L["ca_o"].b, out_dtype=F32, drop=self.D(p + ".drop2"), **res)
+            g2, b2 = self.P(p + ".norm2.weight"), self.P(p + ".norm2.bias")
+            x2_32, x2_16, mean2, rstd2 = self._ln(y2, g2, b2, want32=not lean)
+            res = dict(residual=y2, residual_ln=(mean2, rstd2, g2, b2)) if lean else dict(residual=x2_32)
             u = torch.empty((Md, L["l1"].w16.shape[0]), dtype=self.adt, device=dev)
             h = K.gemm(x2_16, L["l1"].w16, bias=L["l1"].b, act=1, act_grad_out=u, drop=self.D(p + ".ffn"))
-            y3 = K.gemm(h, L["l2"].w16, bias=L["l2"].b, residual=x2_32, out_dtype=F32, drop=self.D(p + ".drop3"))
-            x3_32, x3_16, mean3, rstd3 = self._ln(y3, self.P(p + ".norm3.weight"), self.P(p + ".norm3.bias"))
+            y3 = K.gemm(h, L["l2"].w16, bias=L["l2"].b, out_dtype=F32, drop=self.D(p + ".drop3"), **res)
+            g3, b3 = self.P(p + ".norm3.weight"), self.P(p + ".norm3.bias")
+            x3_32, x3_16, mean3, rstd3 = self._ln(y3, g3, b3, want32=not lean)
+            res = dict(residual=y3, residual_ln=(mean3, rstd3, g3, b3)) if lean else dict(residual=x3_32)
             if save is not None:
                 save.append(dict(x16=x16, qkv=qkv, sa=sa, lse_s=lse_s, y1=y1, mean1=mean1, rstd1=rstd1, x1_16=x1_16, qc=qc, kvc=kvc,
                                  ca=ca, lse_c=lse_c, y2=y2, mean2=mean2, rstd2=rstd2, x2_16=x2_16, u=u, h=h, y3=y3, mean3=mean3,

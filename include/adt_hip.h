@@ -40,7 +40,7 @@ extern "C" {
  * backward entry points regenerate them from the same (p, key).  p == 0 or a null pointer: off. */
 typedef struct adt_dropout { float p; uint32_t key; } adt_dropout;
 
-/* ABI version (12): bumped whenever a signature below changes or entries are added. */
+/* ABI version (13): bumped whenever a signature below changes or entries are added. */
 int adt_version(void);
 
 /* Message of the last failing call on this thread ("" if none). */
@@ -199,6 +199,14 @@ typedef struct adt_gemm_epilogue {
   adt_dropout  drop;          int32_t drop_after_residual;
   float*       colsum_out;
   int32_t      act_grad_mode;
+  /* residual = LayerNorm(y) rebuilt on the fly: with res_ln_mean set, `residual` points at the PRE-LayerNorm tensor y and the
+   * epilogue adds (y - res_ln_mean[row]) * res_ln_rstd[row] * res_ln_gamma[col] + res_ln_beta[col] -- the arithmetic of
+   * adt_layernorm_fwd -- so the LayerNorm that feeds this residual never has to write its fp32 output (it is read exactly once,
+   * here: 4 bytes per element of HBM traffic less per LayerNorm).  res_row_mod must be 0.  bf16 path only. */
+  const float* res_ln_mean;
+  const float* res_ln_rstd;
+  const float* res_ln_gamma;
+  const float* res_ln_beta;
 } adt_gemm_epilogue;
 
 size_t adt_gemm_workspace_bytes(int32_t trans, int64_t M, int64_t N, int64_t K);

@@ -396,3 +396,26 @@ def test_column_group_tile_orders_cover_the_output(group):
         assert r.returncode == 0, r.stderr[-2000:]
         return [l for l in r.stdout.splitlines() if l.startswith("HASH")][0]
     assert run(group) == run(None)
+
+
+@pytest.mark.parametrize("M,N,K", [(63104 // 8, 768, 768), (8192, 768, 3072), (300, 96, 64), (8, 768, 768), (100, 40, 72)])
+def test_residual_rebuilt_from_the_pre_layernorm_tensor(M, N, K):
+    """adt_gemm_epilogue.res_ln_*: the residual the epilogue adds is LayerNorm(y), rebuilt from y and the row statistics that
+    adt_layernorm_fwd saved -- on every kernel the shapes select (persistent 256^2, 128^2, skinny, scalar) and with dropout."""
+    from adt_str_amd import kernels as k
+    from oracle import dropout as o_drop
+    a, w, bias = rnd((M, K), 1).bfloat16(), rnd((N, K), 2, 0.05).bfloat16(), rnd((N,), 3)
+    y = rnd((M, N), 4, 2.0) + 0.3
+    gamma, beta = rnd((N,), 5) * 0.2 + 1.0, rnd((N,), 6) * 0.1
+    if N % 4 == 0 and N <= 1024:
+        x32, _, mean, rstd = k.layernorm_fwd(y, gamma, beta)
+    else:
+        pytest.skip("LayerNorm kernel shape")
+    site = k.drop_site(0.1, 5, 2)
+    plain = k.gemm(a, w, bias=bias, residual=x32, out_dtype=torch.float32, drop=site)
+    lean = k.gemm(a, w, bias=bias, residual=y, residual_ln=(mean, rstd, gamma, beta), out_dtype=torch.float32, drop=site)
+    assert (plain - lean).abs().max() <= 2e-6 * max(1.0, plain.abs().max().item())
+    z = (a.float() @ w.float().t() + bias) * o_drop.scale((M, N), *site).to(DEV) + x32
+    close(lean, z, 1e-4, "against the fp32 product")
+    with pytest.raises(AssertionError):
+        k.gemm(a, w, residual=y, residual_ln=(mean, rstd, gamma, beta), res_row_mod=4, out_dtype=torch.float32)
