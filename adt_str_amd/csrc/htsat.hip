@@ -234,9 +234,31 @@ __global__ __launch_bounds__(256) void aff_conv_kernel(const float* __restrict__
   }
 }
 
-// one block: mean over the tokens of (g + l), then the global_att MLP -> ga[C]
-__global__ __launch_bounds__(1024) void aff_global_kernel(const float* __restrict__ ws_g, const float* __restrict__ ws_l, AffArgs a, int n_tokens,
-                                                          float* __restrict__ ga) {
+// Column sums of (g + l) over the tokens in two stages: kAffParts workgroups each sum a contiguous stretch of tokens (one
+// workgroup walking all 4096 tokens x 96 channels took 0.13 ms, a tenth of a 512-clip forward, for the ONE clip of a batch that
+// goes through the fusion branch), then aff_global_kernel adds the partial rows in order.
+constexpr int kAffParts = 64;
+__global__ __launch_bounds__(256) void aff_colsum_partial_kernel(const float* __restrict__ ws_g, const float* __restrict__ ws_l, int C, int n_tokens,
+                                                                 float* __restrict__ part) {
+  __shared__ float red[256];
+  const int per = (n_tokens + kAffParts - 1) / kAffParts;
+  const int t0 = blockIdx.x * per, t1 = t0 + per < n_tokens ? t0 + per : n_tokens;
+  const int groups = 256 / C;                          // token lanes (C = 96 -> 2)
+  const int c = threadIdx.x % C, gidx = threadIdx.x / C;
+  float s = 0.f;
+  if (gidx < groups)
+    for (int t = t0 + gidx; t < t1; t += groups) s += ws_g[static_cast<long>(t) * C + c] + ws_l[static_cast<long>(t) * C + c];
+  red[threadIdx.x] = gidx < groups ? s : 0.f;
+  __syncthreads();
+  if (threadIdx.x < C) {
+    float m = 0.f;
+    for (int g2 = 0; g2 < groups; ++g2) m += red[g2 * C + threadIdx.x];
+    part[blockIdx.x * C + threadIdx.x] = m;
+  }
+}
+
+// one block: mean over the tokens of (g + l) from the partial sums, then the global_att MLP -> ga[C]
+__global__ __launch_bounds__(1024) void aff_global_kernel(const float* __restrict__ partial, AffArgs a, int n_tokens, float* __restrict__ ga) {
   __shared__ float part[1024];
   __shared__ float mean[128];
   __shared__ float hid[64];
@@ -244,7 +266,7 @@ __global__ __launch_bounds__(1024) void aff_global_kernel(const float* __restric
   const int c = threadIdx.x % a.C, gidx = threadIdx.x / a.C;
   float s = 0.f;
   if (gidx < groups)
-    for (int t = gidx; t < n_tokens; t += groups) s += ws_g[static_cast<long>(t) * a.C + c] + ws_l[static_cast<long>(t) * a.C + c];
+    for (int t = gidx; t < kAffParts; t += groups) s += partial[t * a.C + c];
   part[threadIdx.x] = gidx < groups ? s : 0.f;
   __syncthreads();
   if (threadIdx.x < a.C) {
@@ -686,7 +708,7 @@ extern "C" int adt_htsat_patch_embed(const float* img, int64_t B, int32_t img_si
 extern "C" size_t adt_htsat_fusion_embed_workspace_bytes(int32_t img_side, int32_t C) {
   if (img_side <= 0 || C <= 0) return 0;
   const size_t n = static_cast<size_t>(img_side / 4) * (img_side / 4);
-  return (2 * n * C + 128) * sizeof(float);
+  return (2 * n * C + 128 + 64 * static_cast<size_t>(C)) * sizeof(float);       // g, l, the gate vector, 64 partial column sums
 }
 
 extern "C" int adt_htsat_fusion_embed(const float* img_global, const float* img_local, int32_t img_side, const adt_aff_weights* w, float eps,
@@ -705,7 +727,9 @@ extern "C" int adt_htsat_fusion_embed(const float* img_global, const float* img_
   AffArgs a{w->proj_w, w->proj_b, w->conv_w, w->conv_b, w->local_w1, w->local_b1, w->local_w2, w->local_b2,
             w->global_w1, w->global_b1, w->global_w2, w->global_b2, w->ln_gamma, w->ln_beta, eps, C, inter, img_side};
   hipLaunchKernelGGL(aff_conv_kernel, dim3((n + 3) / 4), dim3(256), 0, STR(stream), img_global, img_local, a, ws_g, ws_l, n);
-  hipLaunchKernelGGL(aff_global_kernel, dim3(1), dim3(1024), 0, STR(stream), ws_g, ws_l, a, n, ga);
+  float* partial = ga + 128;
+  hipLaunchKernelGGL(aff_colsum_partial_kernel, dim3(kAffParts), dim3(256), 0, STR(stream), ws_g, ws_l, C, n, partial);
+  hipLaunchKernelGGL(aff_global_kernel, dim3(1), dim3(1024), 0, STR(stream), partial, a, n, ga);
   hipLaunchKernelGGL(aff_apply_kernel, dim3((n + 3) / 4), dim3(256), 0, STR(stream), ws_g, ws_l, ga, a, out32, n);
   ADT_HIP_TRY(hipGetLastError());
   return ADT_OK;
