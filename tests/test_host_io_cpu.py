@@ -195,3 +195,64 @@ def test_pipeline_scripts_gold_copy_and_bank_conversion(tmp_path, capsys):
     with pytest.raises(FileExistsError):
         conv.main([str(aug), str(tmp_path / "oneshot"), "--sample_rate", "44100"])
     conv.main([str(aug), str(tmp_path / "oneshot"), "--sample_rate", "44100", "--overwrite"])
+
+
+def test_randomised_wav_layouts_decode_like_read_wav(tmp_path):
+    """200 random RIFF layouts (chunk order, odd-sized extra chunks, channels 1-4, every supported encoding, cut-off files, random
+    garbage after the last chunk): the batched decoder accepts exactly what read_wav accepts and returns its mono samples bitwise."""
+    rng = np.random.default_rng(2026)
+    paths = []
+    for i in range(200):
+        tag, bits = [(1, 8), (1, 16), (1, 24), (1, 32), (3, 32)][int(rng.integers(0, 5))]
+        ch, n = int(rng.integers(1, 5)), int(rng.integers(0, 400))
+        chunks = []
+        for _ in range(int(rng.integers(0, 3))):
+            chunks.append((bytes(rng.choice(list(b"LISTfactcue bext"), 4).astype(np.uint8)), rng.integers(0, 256, int(rng.integers(0, 23)), dtype=np.uint8).tobytes(), None))
+        fmt = (b"fmt ", _fmt(tag, ch, int(rng.choice([8000, 16000, 44100, 48000])), bits, extensible_sub=tag if rng.random() < 0.3 else None), None)
+        data = (b"data", _pcm(rng, n, ch, bits, tag=tag), None)
+        body = chunks + ([fmt, data] if rng.random() < 0.8 else [data, fmt])
+        blob = _riff(body)
+        r = rng.random()
+        if r < 0.1:
+            blob = blob[: int(rng.integers(8, len(blob) + 1))]                      # cut off anywhere
+        elif r < 0.2:
+            blob += rng.integers(0, 256, int(rng.integers(1, 9)), dtype=np.uint8).tobytes()   # trailing garbage
+        p = str(tmp_path / f"r{i}.wav")
+        with open(p, "wb") as fh:
+            fh.write(blob)
+        paths.append(p)
+    b = A.read_wav_batch(paths, normalize=False, threads=4)
+    n_ok = 0
+    for i, p in enumerate(paths):
+        got = b.data[b.offsets[i]:b.offsets[i + 1]].numpy()
+        try:
+            x, sr = A.read_wav(p)
+        except Exception:
+            assert b.status[i] != 0 and got.size == 0, p
+            continue
+        n_ok += 1
+        assert b.status[i] == 0 and b.sample_rate[i] == sr, p
+        assert np.array_equal(got, x.mean(axis=0), equal_nan=True), p
+    assert 120 < n_ok < 200                                                       # most parse, the cut-off ones mostly do not
+
+
+def test_load_clips_batch_on_the_cpu_for_files_at_the_target_rate(tmp_path):
+    """Without a GPU the batched loader still serves files that need no resampling (decode + peak-normalise); a file at another
+    rate needs K13 and raises."""
+    rng = np.random.default_rng(4)
+    paths = []
+    for i in range(5):
+        p = str(tmp_path / f"c{i}.wav")
+        A.write_wav(p, (rng.standard_normal((1 + i % 2, 100 + 17 * i)) * 0.3).astype(np.float32), 48000)
+        paths.append(p)
+    (tmp_path / "bad.wav").write_bytes(b"nope")
+    clips, peaks, status = A.load_clips_batch(paths + [str(tmp_path / "bad.wav")], 48000, "cpu")
+    assert status[-1] != 0 and clips[-1] is None
+    for p, c, pk in zip(paths, clips, peaks):
+        m = A.read_wav(p)[0].mean(axis=0)
+        assert np.array_equal(c.numpy(), (torch.from_numpy(m) / torch.max(torch.abs(torch.from_numpy(m)))).numpy())
+        assert float(pk) == float(np.abs(m).max())
+    other = str(tmp_path / "other.wav")
+    A.write_wav(other, (rng.standard_normal(200) * 0.3).astype(np.float32), 44100)
+    with pytest.raises(RuntimeError):
+        A.load_clips_batch([other], 48000, "cpu")
