@@ -11,9 +11,9 @@
 //   * persistent 256x256x64 kernels (gemm_nt_256_kernel, gemm_tn_256_kernel) for the large GEMMs of the training step:
 //     8 waves, 4 phases of 16 MFMAs per K-tile, LDS-DMA (global_load_lds_dwordx4) half-tiles in flight across raw
 //     barriers, staggered wave rows, per-XCD-slice work counters, next tile's prologue under the epilogue;
-//   * 128x128x64 LDS-DMA kernels (gemm_nt_glds_kernel: any K % 32 == 0; gemm_tn_glds_kernel: split-K through fp32 slabs)
+//   * 128x128x64 LDS-DMA kernels (gemm_nt_glds_kernel: any K, the last K-tile zero-filled; gemm_tn_glds_kernel: split-K through fp32 slabs)
 //     for everything smaller: 4 waves in a 2x2 grid, each 64x64 = 4x4 MFMA blocks, 2-stage pipeline, XCD-aware tile order;
-//   * a register-staged 128x128x64 kernel (gemm_bf16_kernel) for the remaining shapes (K % 32 != 0, unaligned views).
+//   * a register-staged 128x128x64 kernel (gemm_bf16_kernel) for the remaining shapes (TN with K % 64 != 0, outputs the row-vector epilogue cannot address).
 //   NT fragments: ds_read_b128 of 8 consecutive k of one row.
 //   TN fragments: two ds_read_b64_tr_b16 per operand from a [k][m] image.
 // Epilogues transpose the accumulators through LDS so that bias / GELU / GELU' / ReLU / dropout / residual / dual-dtype
@@ -421,7 +421,7 @@ __device__ __forceinline__ void gemm_epilogue_rows(const GemmArgs& g, f32x4 (&ac
 }
 
 // =========================================================================================
-// NT kernel, LDS-DMA staging (used whenever K % 32 == 0).
+// NT kernel, LDS-DMA staging (any K that is a multiple of 8).
 // Both operand tiles are 128 rows x 128 B and are filled by global_load_lds_dwordx4 (no VGPR
 // round trip): one wave-instruction writes 1 KiB = 8 rows, lane l -> row (l >> 3), 16-byte
 // position (l & 7).  The LDS image must stay lane-linear, so the bank swizzle is applied to the
@@ -434,6 +434,10 @@ __device__ __forceinline__ void gemm_epilogue_rows(const GemmArgs& g, f32x4 (&ac
 constexpr int kTileNT = 128 * 128;               // 16 KiB per operand tile
 __device__ __forceinline__ int swz_nt(int row) { return (row >> 1) & 7; }
 
+// K is any multiple of 8: the 16-byte pieces of the last K-tile that lie past K come from a zero piece for the A operand (kZeroFill)
+// and re-read the row's last valid piece for B -- finite data times zero -- so every K-tile is processed as a full one.
+__device__ __attribute__((aligned(16))) unsigned short g_zero_piece[8];
+template <bool kZeroFill>
 __device__ __forceinline__ void glds_tile(const unsigned short* __restrict__ src, long ld, int row0, int n_rows, int k0, int k_end,
                                           unsigned char* tile, int wave, int lane) {
 #pragma unroll
@@ -442,9 +446,9 @@ __device__ __forceinline__ void glds_tile(const unsigned short* __restrict__ src
     int gr = row0 + row;
     gr = gr < n_rows ? gr : n_rows - 1;
     const int chunk = (lane & 7) ^ swz_nt(row);
-    int kc = k0 + chunk * 8;
-    kc = kc < k_end ? kc : k_end - 8;              // half-filled last tile (K % 64 == 32): re-read valid data, never multiplied
-    const unsigned short* p = src + static_cast<long>(gr) * ld + kc;
+    const int kc = k0 + chunk * 8;
+    const unsigned short* p = src + static_cast<long>(gr) * ld + (kc < k_end ? kc : k_end - 8);
+    if (kZeroFill && kc >= k_end) p = g_zero_piece;
     __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)p,
                                      (__attribute__((address_space(3))) void*)(tile + (4 * wave + i) * 1024), 16, 0, 0);
   }
@@ -466,9 +470,7 @@ __global__ __launch_bounds__(kGemmThreads) void gemm_nt_glds_kernel(GemmArgs g, 
   const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7;
   const int logical = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
   const int m0 = (logical / tiles_n) * kBM, n0 = (logical % tiles_n) * kBN;
-  const int k_full = g.K / kBK;
-  const bool half_tail = (g.K & 32) != 0;          // K % 64 == 32: one more tile that carries a single 32-deep k-step
-  const int k_tiles = k_full + (half_tail ? 1 : 0);
+  const int k_tiles = (g.K + kBK - 1) / kBK;       // the last one zero-filled past K (glds_tile)
 
   f32x4 acc[4][4];
 #pragma unroll
@@ -476,18 +478,18 @@ __global__ __launch_bounds__(kGemmThreads) void gemm_nt_glds_kernel(GemmArgs g, 
 #pragma unroll
     for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-  glds_tile(g.A, g.lda, m0, g.M, 0, g.K, smem, wave, lane);
-  glds_tile(g.B, g.ldb, n0, g.N, 0, g.K, smem + kTileNT, wave, lane);
+  glds_tile<true>(g.A, g.lda, m0, g.M, 0, g.K, smem, wave, lane);
+  glds_tile<false>(g.B, g.ldb, n0, g.N, 0, g.K, smem + kTileNT, wave, lane);
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
 
-  for (int kt = 0; kt < k_full; ++kt) {
+  for (int kt = 0; kt < k_tiles; ++kt) {
     const unsigned char* ta = smem + (kt & 1) * 2 * kTileNT;
     const unsigned char* tb = ta + kTileNT;
     if (kt + 1 < k_tiles) {
       unsigned char* na = smem + ((kt + 1) & 1) * 2 * kTileNT;
-      glds_tile(g.A, g.lda, m0, g.M, (kt + 1) * kBK, g.K, na, wave, lane);
-      glds_tile(g.B, g.ldb, n0, g.N, (kt + 1) * kBK, g.K, na + kTileNT, wave, lane);
+      glds_tile<true>(g.A, g.lda, m0, g.M, (kt + 1) * kBK, g.K, na, wave, lane);
+      glds_tile<false>(g.B, g.ldb, n0, g.N, (kt + 1) * kBK, g.K, na + kTileNT, wave, lane);
     }
     // both 32-deep k-steps' fragments are requested up front, so the second step's LDS reads
     // are in flight under the first step's MFMAs
@@ -510,21 +512,6 @@ __global__ __launch_bounds__(kGemmThreads) void gemm_nt_glds_kernel(GemmArgs g, 
       __builtin_amdgcn_s_setprio(0);
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
-  }
-  if (half_tail) {
-    const unsigned char* ta = smem + (k_full & 1) * 2 * kTileNT;
-    const unsigned char* tb = ta + kTileNT;
-    bf16x8 fa[4], fb[4];
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      fa[i] = frag_glds(ta, wm * 64 + i * 16, 0, lane);
-      fb[i] = frag_glds(tb, wn * 64 + i * 16, 0, lane);
-    }
-#pragma unroll
-    for (int i = 0; i < 4; ++i)
-#pragma unroll
-      for (int j = 0; j < 4; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[i], fb[j], acc[i][j], 0, 0, 0);
     __syncthreads();
   }
   gemm_epilogue_rows<kDrop>(g, acc, reinterpret_cast<float*>(smem), m0, n0, wm, wn, tid, lane);
@@ -1669,7 +1656,7 @@ extern "C" int adt_gemm_bf16(int32_t trans, int64_t M, int64_t N, int64_t K, con
       }
       colsum_done = true;
     }
-  } else if ((K % 32) == 0 && K > 0 && vector_epilogue_ok(g, e)) {
+  } else if (K > 0 && vector_epilogue_ok(g, e)) {       // any K (a multiple of 8, checked above): the last K-tile is zero-filled
     const int tm = static_cast<int>((M + kBM - 1) / kBM), tn = static_cast<int>((N + kBN - 1) / kBN);
     const dim3 g1(static_cast<unsigned>(tm) * tn);
     if (g.drop.on()) hipLaunchKernelGGL(gemm_nt_glds_kernel<true>, g1, dim3(kGemmThreads), kEpiLds, st, g, tm, tn);
