@@ -1500,14 +1500,20 @@ static int plan_tn_big(int64_t M, int64_t N, int64_t K, int n_cu, bool may_split
 }
 }  // namespace adt
 
-extern "C" size_t adt_gemm_workspace_bytes(int32_t trans, int64_t M, int64_t N, int64_t K) {
-  if (!trans || M <= 0 || N <= 0 || K <= 0) return 0;
+static size_t tn_workspace_bytes(int64_t M, int64_t N, int64_t K) {
   int n_cu = 256;
   (void)adt::device_cu_count(&n_cu);
   int s = adt::pick_splits(static_cast<int>(M), static_cast<int>(N), static_cast<int>(K), n_cu), per = 0;
   const int sb = adt::plan_tn_big(M, N, K, n_cu, true, &per);
   s = sb > s ? sb : s;
   return s > 1 ? static_cast<size_t>(s) * M * N * 4 : 0;
+}
+extern "C" size_t adt_gemm_workspace_bytes(int32_t trans, int64_t M, int64_t N, int64_t K) {
+  if (!trans || M <= 0 || N <= 0 || K <= 0) return 0;
+  const size_t whole = tn_workspace_bytes(M, N, K);
+  if ((K % adt::kBK) == 0 || K < adt::kBK) return whole;
+  const size_t head = tn_workspace_bytes(M, N, K / adt::kBK * adt::kBK);       // K % 64 != 0: the product is taken in two pieces (adt_gemm_bf16)
+  return head > whole ? head : whole;
 }
 
 extern "C" size_t adt_gemm_colsum_workspace_bytes(int64_t M, int64_t N) {
@@ -1528,6 +1534,19 @@ extern "C" int adt_gemm_bf16(int32_t trans, int64_t M, int64_t N, int64_t K, con
   if ((a_cols & 7) || (b_cols & 7) || (lda & 7) || (ldb & 7) || !aligned16(A) || !aligned16(B))
     return set_error(ADT_ESHAPE, "adt_gemm_bf16: operand rows must be 16-byte aligned multiples of 8 elements");
   if (M == 0 || N == 0) return ADT_OK;
+  // Weight gradients whose K (= batch x frames rows) is not a multiple of the 64-deep K-tile: the LDS-DMA kernels want whole tiles,
+  // and the register-staged fallback is several times slower at K ~ 50 000.  Take the first floor(K / 64) * 64 rows on the fast
+  // path and add the last < 64 rows with the fallback kernel (C is both its residual and its output: every element is read and
+  // written by one thread).  Same products, fp32 sums in a fixed order.
+  if (trans && K > kBK && (K % kBK) != 0 && ep && ep->out_fp32 && !ep->bias && !ep->residual && !ep->act && !ep->pre_act_out && !ep->gelu_grad_of &&
+      !ep->aux_bf16_out && !ep->colsum_out && ep->drop.p <= 0.f) {
+    const int64_t k0 = K / kBK * kBK;
+    if (int rc = adt_gemm_bf16(1, M, N, k0, A, lda, B, ldb, C, ldc, ep, ws, ws_bytes, stream)) return rc;
+    adt_gemm_epilogue tail = *ep;
+    tail.residual = C; tail.ld_res = ldc; tail.res_row_mod = 0;
+    return adt_gemm_bf16(1, M, N, K - k0, static_cast<const unsigned short*>(A) + k0 * lda, lda, static_cast<const unsigned short*>(B) + k0 * ldb, ldb,
+                         C, ldc, &tail, ws, ws_bytes, stream);
+  }
   GemmArgs g;
   g.A = static_cast<const unsigned short*>(A); g.lda = lda;
   g.B = static_cast<const unsigned short*>(B); g.ldb = ldb;

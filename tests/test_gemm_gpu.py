@@ -47,7 +47,7 @@ def test_nt_exact_integers_asymmetric():
 
 
 @pytest.mark.parametrize("K,M,N", [(64, 128, 128), (256, 128, 256), (1000, 200, 136), (63104 // 4, 768, 768),
-                                   (8192, 1400, 768), (2048, 768, 3072), (70, 40, 24)])
+                                   (8192, 1400, 768), (2048, 768, 3072), (70, 40, 24), (48 * 986, 768, 3072), (16 * 986 + 8, 2304, 768)])
 def test_tn_wgrad(K, M, N):
     from adt_str_amd import kernels as k
     a, b = rnd((K, M), 3).bfloat16(), rnd((K, N), 4).bfloat16()
@@ -419,3 +419,25 @@ def test_residual_rebuilt_from_the_pre_layernorm_tensor(M, N, K):
     close(lean, z, 1e-4, "against the fp32 product")
     with pytest.raises(AssertionError):
         k.gemm(a, w, residual=y, residual_ln=(mean, rstd, gamma, beta), res_row_mod=4, out_dtype=torch.float32)
+
+
+def test_weight_gradient_with_a_ragged_row_count_stays_on_the_fast_path():
+    """K = batch x frames is not a multiple of the 64-deep K-tile for most batch sizes (48 x 986 = 47 328): the product is taken as
+    floor(K / 64) * 64 rows on the LDS-DMA kernels plus a < 64-row remainder added by the fallback kernel, so it costs about what
+    the neighbouring multiple of 64 costs instead of several times more."""
+    from adt_str_amd import kernels as k
+    M, N = 768, 3072
+    def timed(K):
+        a, b = rnd((K, M), 5).bfloat16(), rnd((K, N), 6).bfloat16()
+        out = torch.empty((M, N), device=DEV)
+        for _ in range(3):
+            k.gemm(a, b, trans=True, out=out)
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(10):
+            k.gemm(a, b, trans=True, out=out)
+        e1.record()
+        torch.cuda.synchronize()
+        return e0.elapsed_time(e1) / 10
+    even, ragged = timed(47296), timed(47328)
+    assert ragged < 1.5 * even, (even, ragged)
