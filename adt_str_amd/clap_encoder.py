@@ -89,9 +89,11 @@ def rowblock(mode: int, x: torch.Tensor, wpk: torch.Tensor, n_tiles: int, bias1:
 
 def window_bias_layout(bias: torch.Tensor) -> torch.Tensor:
     """[..., 64 (query), 64 (key)] -> the lane-linear order ``adt_window_attn_fwd`` reads: [..., qt 2, kt 2, g 4, h 2, r 32, e 4] with
-    query = 32 qt + r and key = 32 kt + 8 g + 4 h + e (one contiguous KiB per wave-load of a (qt, kt, g) piece)."""
+    query = 32 qt + r and key = 32 kt + 8 g + 4 h + e (one contiguous KiB per wave-load of a (qt, kt, g) piece), **in log2 units**:
+    the kernels run their softmax as 2^(scores * scale * log2 e + bias * log2 e - max), so the table is multiplied by log2 e here
+    instead of once per score in the kernel."""
     lead = bias.shape[:-2]
-    v = bias.reshape(*lead, 2, 32, 2, 4, 2, 4)                       # [..., qt, r, kt, g, h, e]
+    v = (bias.float() * math.log2(math.e)).reshape(*lead, 2, 32, 2, 4, 2, 4)      # [..., qt, r, kt, g, h, e]
     n = len(lead)
     return v.permute(*range(n), n, n + 2, n + 3, n + 4, n + 1, n + 5).contiguous().reshape(*lead, 64, 64)
 

@@ -413,6 +413,7 @@ __global__ __launch_bounds__(256) void window_attn_kernel(WinAttnArgs a) {
   __builtin_amdgcn_wave_barrier();
   __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
   f32x16 o[2];
+  const float sl2 = a.scale * 1.4426950408889634f;     // scores in log2 units (the bias table already is)
 #pragma unroll
   for (int qt = 0; qt < 2; ++qt) {
     float mx = -3.0e38f;
@@ -424,7 +425,7 @@ __global__ __launch_bounds__(256) void window_attn_kernel(WinAttnArgs a) {
         const float bb[4] = {bv.x, bv.y, bv.z, bv.w};
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
-          const float v = st[kt][qt][4 * g + e] * a.scale + bb[e];
+          const float v = fmaf(st[kt][qt][4 * g + e], sl2, bb[e]);          // log2 domain: the bias table comes pre-multiplied by log2 e
           st[kt][qt][4 * g + e] = v;
           mx = fmaxf(mx, v);
         }
@@ -434,7 +435,7 @@ __global__ __launch_bounds__(256) void window_attn_kernel(WinAttnArgs a) {
 #pragma unroll
     for (int kt = 0; kt < 2; ++kt)
 #pragma unroll
-      for (int i = 0; i < 16; ++i) { const float p = __expf(st[kt][qt][i] - mx); st[kt][qt][i] = p; sum += p; }
+      for (int i = 0; i < 16; ++i) { const float p = __builtin_amdgcn_exp2f(st[kt][qt][i] - mx); st[kt][qt][i] = p; sum += p; }
     sum += __shfl_xor(sum, 32);
     const float inv = 1.0f / sum;
 #pragma unroll
@@ -455,7 +456,7 @@ __global__ __launch_bounds__(256) void window_attn_kernel(WinAttnArgs a) {
         af[0] = lo[0]; af[1] = lo[1]; af[2] = lo[2]; af[3] = lo[3]; af[4] = hi[0]; af[5] = hi[1]; af[6] = hi[2]; af[7] = hi[3];
         union { unsigned u[4]; bf16x8 v; } pf;
 #pragma unroll
-        for (int e = 0; e < 4; ++e) pf.u[e] = pack2_h(st[kt][qt][8 * s2 + 2 * e] * inv, st[kt][qt][8 * s2 + 2 * e + 1] * inv);
+        for (int e = 0; e < 4; ++e) pf.u[e] = pack2_h(st[kt][qt][8 * s2 + 2 * e], st[kt][qt][8 * s2 + 2 * e + 1]);      // un-normalised: O is scaled by 1 / sum below
         o[qt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af, pf.v, o[qt], 0, 0, 0);
       }
     // O^T[d][query]: this lane owns d = 8g + 4h + (0..3); d >= 24 is padding
@@ -463,8 +464,8 @@ __global__ __launch_bounds__(256) void window_attn_kernel(WinAttnArgs a) {
 #pragma unroll
     for (int g = 0; g < 3; ++g) {
       uint2 v;
-      v.x = pack2_h(o[qt][4 * g + 0], o[qt][4 * g + 1]);
-      v.y = pack2_h(o[qt][4 * g + 2], o[qt][4 * g + 3]);
+      v.x = pack2_h(o[qt][4 * g + 0] * inv, o[qt][4 * g + 1] * inv);
+      v.y = pack2_h(o[qt][4 * g + 2] * inv, o[qt][4 * g + 3] * inv);
       *reinterpret_cast<uint2*>(dst + 8 * g + 4 * h) = v;
     }
   }
@@ -535,6 +536,7 @@ __global__ __launch_bounds__(256) void window_attn4_kernel(WinAttnArgs a) {
   const float* bias = a.bias + (static_cast<long>(wsel) * a.heads + head) * 4096 + lane * 4;
   __syncthreads();                                    // every wave has its operands: the q | k part of the stage is free for the outputs
   f32x16 o[2];
+  const float sl2 = a.scale * 1.4426950408889634f;     // scores in log2 units (the bias table already is)
 #pragma unroll
   for (int qt = 0; qt < 2; ++qt) {
     float mx = -3.0e38f;
@@ -546,7 +548,7 @@ __global__ __launch_bounds__(256) void window_attn4_kernel(WinAttnArgs a) {
         const float bb[4] = {bv.x, bv.y, bv.z, bv.w};
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
-          const float v = st[kt][qt][4 * g + e] * a.scale + bb[e];
+          const float v = fmaf(st[kt][qt][4 * g + e], sl2, bb[e]);          // log2 domain: the bias table comes pre-multiplied by log2 e
           st[kt][qt][4 * g + e] = v;
           mx = fmaxf(mx, v);
         }
@@ -556,7 +558,7 @@ __global__ __launch_bounds__(256) void window_attn4_kernel(WinAttnArgs a) {
 #pragma unroll
     for (int kt = 0; kt < 2; ++kt)
 #pragma unroll
-      for (int i = 0; i < 16; ++i) { const float p = __expf(st[kt][qt][i] - mx); st[kt][qt][i] = p; sum += p; }
+      for (int i = 0; i < 16; ++i) { const float p = __builtin_amdgcn_exp2f(st[kt][qt][i] - mx); st[kt][qt][i] = p; sum += p; }
     sum += __shfl_xor(sum, 32);
     const float inv = 1.0f / sum;
 #pragma unroll
@@ -576,7 +578,7 @@ __global__ __launch_bounds__(256) void window_attn4_kernel(WinAttnArgs a) {
         af[0] = lo[0]; af[1] = lo[1]; af[2] = lo[2]; af[3] = lo[3]; af[4] = hi[0]; af[5] = hi[1]; af[6] = hi[2]; af[7] = hi[3];
         union { unsigned u[4]; bf16x8 v; } pf;
 #pragma unroll
-        for (int e = 0; e < 4; ++e) pf.u[e] = pack2_h(st[kt][qt][8 * s2 + 2 * e] * inv, st[kt][qt][8 * s2 + 2 * e + 1] * inv);
+        for (int e = 0; e < 4; ++e) pf.u[e] = pack2_h(st[kt][qt][8 * s2 + 2 * e], st[kt][qt][8 * s2 + 2 * e + 1]);      // un-normalised: O is scaled by 1 / sum below
         o[qt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af, pf.v, o[qt], 0, 0, 0);
       }
     // O^T[d][query]: this lane owns d = 8g + 4h + (0..3), d < 24 -> the output rows in LDS: [token][4 heads x 24] bf16 (192 B, pitch 592)
@@ -584,8 +586,8 @@ __global__ __launch_bounds__(256) void window_attn4_kernel(WinAttnArgs a) {
 #pragma unroll
     for (int g = 0; g < 3; ++g) {
       uint2 v;
-      v.x = pack2_h(o[qt][4 * g + 0], o[qt][4 * g + 1]);
-      v.y = pack2_h(o[qt][4 * g + 2], o[qt][4 * g + 3]);
+      v.x = pack2_h(o[qt][4 * g + 0] * inv, o[qt][4 * g + 1] * inv);
+      v.y = pack2_h(o[qt][4 * g + 2] * inv, o[qt][4 * g + 3] * inv);
       *reinterpret_cast<uint2*>(dst + (8 * g + 4 * h) * 2) = v;
     }
   }

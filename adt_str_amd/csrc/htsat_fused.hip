@@ -702,7 +702,7 @@ __global__ __launch_bounds__(256, 2) void htsat_attn_kernel(AtArgs a) {
         const float bb[4] = {rbv[kt][g].x, rbv[kt][g].y, rbv[kt][g].z, rbv[kt][g].w};
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
-          const float v = fmaf(st[kt][4 * g + e], sl2, bb[e] * 1.4426950408889634f);       // log2 domain
+          const float v = fmaf(st[kt][4 * g + e], sl2, bb[e]);       // log2 domain: the bias table comes pre-multiplied by log2 e
           st[kt][4 * g + e] = v;
           mx = fmaxf(mx, v);
         }
@@ -732,10 +732,12 @@ __global__ __launch_bounds__(256, 2) void htsat_attn_kernel(AtArgs a) {
         af[0] = lo[0]; af[1] = lo[1]; af[2] = lo[2]; af[3] = lo[3]; af[4] = hi[0]; af[5] = hi[1]; af[6] = hi[2]; af[7] = hi[3];
         union { unsigned u[4]; bf16x8 v; } pf;
 #pragma unroll
-        for (int e = 0; e < 4; ++e) pf.u[e] = pack2_f(st[kt][8 * s2 + 2 * e] * inv, st[kt][8 * s2 + 2 * e + 1] * inv);
+        for (int e = 0; e < 4; ++e) pf.u[e] = pack2_f(st[kt][8 * s2 + 2 * e], st[kt][8 * s2 + 2 * e + 1]);       // un-normalised: O is scaled by 1 / sum below
         o = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af, pf.v, o, 0, 0, 0);
       }
     // ---- output projection: this head's 24 (+ 8 zero) context values are k-steps 0, 1 of Wo's slice
+#pragma unroll
+    for (int i = 0; i < 16; ++i) o[i] *= inv;              // the softmax denominator, once per output instead of once per probability
     const bf16x8 ob0 = acc_to_b_f(o, 0), ob1 = acc_to_b_f(o, 1);
     {
       bf16x8 f[6];

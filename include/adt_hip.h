@@ -40,7 +40,7 @@ extern "C" {
  * backward entry points regenerate them from the same (p, key).  p == 0 or a null pointer: off. */
 typedef struct adt_dropout { float p; uint32_t key; } adt_dropout;
 
-/* ABI version (13): bumped whenever a signature below changes or entries are added. */
+/* ABI version (14): bumped whenever a signature below changes or entries are added. */
 int adt_version(void);
 
 /* Message of the last failing call on this thread ("" if none). */
@@ -477,7 +477,9 @@ int adt_bilinear_resize_f32(const float* in, int64_t H_in, int64_t W_in, int64_t
  *                          bias fp32 = relative position bias (+ the -100 shifted-window mask of each window when
  *                          n_bias_windows == (R/8)^2) of query q, key k, stored lane-linear for the kernel's accumulator
  *                          layout: [n_bias_windows][heads][qt 2][kt 2][g 4][h 2][r 32][e 4] with q = 32 qt + r,
- *                          k = 32 kt + 8 g + 4 h + e (adt_str_amd/clap_encoder.py:window_bias_layout)
+ *                          k = 32 kt + 8 g + 4 h + e, and IN LOG2 UNITS: every entry multiplied by log2(e), because the
+ *                          kernel evaluates softmax as 2^(q.k * scale * log2 e + bias - max) (one multiply per score less);
+ *                          adt_str_amd/clap_encoder.py:window_bias_layout builds it
  *   adt_patch_merge_ln     Swin patch merging gather (2x2 -> 4C, order (0,0),(1,0),(0,1),(1,1)) + LayerNorm -> bf16
  *   adt_mean_tokens        mean over the T tokens of each clip;  adt_l2_normalize  rows / ||row||
  */
