@@ -181,3 +181,20 @@ def test_single_query_decode_kernel(monkeypatch, B, H, Sk, lens):
         o3, _ = k.attn_fwd(q, kk, v, B, H, 1, Sk, scale, key_len=key_len, mask_value=-2.0)
         ref3, _ = reference(q, kk, v, B, H, 1, Sk, scale, False, key_len, mask_value=-2.0)
         assert (o3.float() - ref3).abs().max() < 1e-2
+
+
+def test_single_query_attention_is_invariant_to_the_order_of_the_keys():
+    """A size-independent property at the decode step's full size (B = 8, 6 heads, 986 memory keys): permuting the keys together
+    with their values leaves the output unchanged up to fp32 summation order, and the log-sum-exp as well."""
+    from adt_str_amd import kernels as k
+    B, H, Sk = 8, 6, 986
+    d = H * 128
+    kv = rnd((B * Sk, 2 * d), 21).bfloat16()
+    q = rnd((B, d), 22).bfloat16()
+    scale = 1 / math.sqrt(128)
+    o1, lse1 = k.attn_fwd(q, kv[:, :d], kv[:, d:], B, H, 1, Sk, scale)
+    perm = torch.stack([torch.randperm(Sk, generator=torch.Generator().manual_seed(b)) + b * Sk for b in range(B)]).reshape(-1).to(DEV)
+    kv2 = kv[perm].contiguous()
+    o2, lse2 = k.attn_fwd(q, kv2[:, :d], kv2[:, d:], B, H, 1, Sk, scale)
+    assert (o1.float() - o2.float()).abs().max() <= 2e-2 * o1.float().abs().max() + 1e-3      # bf16 outputs, bf16-rounded probabilities
+    assert (lse1 - lse2).abs().max() < 1e-4

@@ -256,3 +256,21 @@ def test_load_clips_batch_on_the_cpu_for_files_at_the_target_rate(tmp_path):
     A.write_wav(other, (rng.standard_normal(200) * 0.3).astype(np.float32), 44100)
     with pytest.raises(RuntimeError):
         A.load_clips_batch([other], 48000, "cpu")
+
+
+def test_write_then_batched_read_round_trip(tmp_path):
+    """write_wav (16-bit PCM) -> read_wav_batch: the samples come back as the quantised input, for mono and stereo, any length."""
+    rng = np.random.default_rng(8)
+    paths, want = [], []
+    for i in range(20):
+        ch, n = 1 + i % 2, int(rng.integers(1, 3000))
+        x = np.clip(rng.standard_normal((ch, n)) * 0.4, -1, 1).astype(np.float32)
+        p = str(tmp_path / f"w{i}.wav")
+        A.write_wav(p, x, 48000)
+        q = (np.clip(x, -1.0, 1.0) * 32767.0).round().astype(np.int16).astype(np.float32) / 32768.0
+        paths.append(p)
+        want.append(q.mean(axis=0))
+    b = A.read_wav_batch(paths, threads=3)
+    assert (b.status == 0).all() and (b.sample_rate == 48000).all()
+    for i, w in enumerate(want):
+        assert np.array_equal(b.data[b.offsets[i]:b.offsets[i + 1]].numpy(), w)
