@@ -14,7 +14,7 @@ _LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "libadt_hip
 _lock = threading.Lock()
 _lib = None
 
-ABI_VERSION = 14
+ABI_VERSION = 15
 
 i32, i64, f32, ptr = C.c_int32, C.c_int64, C.c_float, C.c_void_p
 
@@ -111,6 +111,7 @@ SIGNATURES = {
     "adt_mean_tokens": [ptr, i64, i32, i32, ptr, ptr, ptr],
     "adt_htsat_rowblock_chunk_tiles": [i32, i32],
     "adt_htsat_attn_block": [ptr, i64, i32, i32, i32, i32, ptr, ptr, f32, ptr, ptr, ptr, ptr, i32, f32, ptr],
+    "adt_htsat_merge_rowblock": [ptr, i64, i32, i32, ptr, ptr, f32, ptr, i32, ptr, ptr, i64, ptr],
     "adt_htsat_rowblock": [i32, ptr, i64, i32, ptr, i64, ptr, ptr, f32, ptr, i32, ptr, ptr, ptr, i64, ptr],
     "adt_l2_normalize": [ptr, i64, i32, ptr, ptr],
     "adt_cosine_argmax_f32": [ptr, i64, ptr, i64, i64, i64, f32, ptr, ptr, ptr, ptr],

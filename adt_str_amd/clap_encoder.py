@@ -173,6 +173,9 @@ class HtsatEncoder:
             if s < len(self.depths) - 1:
                 d = f"{p}layers.{s}.downsample."
                 merge = dict(norm=(g(d + "norm.weight"), g(d + "norm.bias")), w=b16(g(d + "reduction.weight")))
+                if C == 96:                                # gather + LayerNorm(384) + reduction in one launch (adt_htsat_merge_rowblock)
+                    merge["pk"] = pack_rowblock_weights(0, merge["w"].float()).to(self.dev)
+                    merge["zero_bias"] = torch.zeros(merge["w"].shape[0], dtype=F32, device=self.dev)
             self.stages.append(dict(C=C, nh=nh, R=R, layers=layers, merge=merge))
             R //= 2
         self.final_ln = (g(p + "norm.weight"), g(p + "norm.bias"))
@@ -281,7 +284,13 @@ class HtsatEncoder:
                 _, xn, _, _ = K.layernorm_fwd(x, *L["ln2"], eps=self.eps, want32=False)
                 h = K.gemm(xn, L["w1"], bias=L["b1"], act=1)
                 K.gemm(h, L["w2"], bias=L["b2"], residual=x, out=x)
-            if S["merge"] is not None:
+            if S["merge"] is not None and "pk" in S["merge"] and fused and os.environ.get("ADT_HTSAT_MERGE", "1") != "0":
+                mg = S["merge"]
+                xm = torch.empty((x.shape[0] // 4, mg["w"].shape[0]), dtype=F32, device=self.dev)
+                _ffi.call("adt_htsat_merge_rowblock", _ffi.dptr(x), B, R, C, _ffi.dptr(mg["norm"][0]), _ffi.dptr(mg["norm"][1]), 1e-5,
+                          _ffi.dptr(mg["pk"]), mg["w"].shape[0] // 32, _ffi.dptr(mg["zero_bias"]), _ffi.dptr(xm), xm.stride(0), st)
+                x = xm
+            elif S["merge"] is not None:
                 m16 = torch.empty((x.shape[0] // 4, 4 * C), dtype=BF16, device=self.dev)
                 _ffi.call("adt_patch_merge_ln", _ffi.dptr(x), B, R, C, _ffi.dptr(S["merge"]["norm"][0]), _ffi.dptr(S["merge"]["norm"][1]),
                           1e-5, _ffi.dptr(m16), st)

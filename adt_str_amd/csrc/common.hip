@@ -68,7 +68,7 @@ int sched_counters(void* stream, unsigned** counters) {
 
 }  // namespace adt
 
-extern "C" int adt_version(void) { return 14; }
+extern "C" int adt_version(void) { return 15; }
 extern "C" const char* adt_last_error(void) { return adt::g_err; }
 
 extern "C" int adt_debug_occupy(int32_t n_wg, int32_t lds_bytes, int32_t micros, void* stream) {

@@ -9,6 +9,9 @@
 //
 //   mode LN_GEMM   (q/k/v):      x fp32 -> LayerNorm -> bf16 operand in registers -> W[3C, C] -> + bias -> bf16 qkv
 //   mode GEMM_RES  (attn. out):  ctx bf16 -> W[C, C] -> + bias + x -> x            (in place)
+//   mode MERGE_GEMM (patch merging): the 2x2 neighbourhood of a token, four rows of C/4 channels in ClapAudioPatchMerging's order ->
+//                                LayerNorm(C) -> W[C/2, C] -> fp32 rows of the next stage's residual stream (the gathered, normalised
+//                                bf16 tensor of adt_patch_merge_ln + GEMM never exists)
 //   mode MLP:                    x fp32 -> LayerNorm -> W1[4C, C] -> + bias, GELU (erf form, gelu.h) -> W2[C, 4C] -> + bias + x -> x   (in place;
 //                                the 4C-wide hidden activation never leaves the registers)
 //
@@ -36,7 +39,7 @@ typedef __attribute__((ext_vector_type(4))) float f32x4;
 constexpr int kRbThreads = 256;           // 4 waves x 32 tokens; two workgroups per CU (<= 80 KiB of LDS, <= 256 registers): one loads /
 constexpr int kRbRows = 128;              // stores its rows while the other computes
 constexpr int kRbWaves = kRbThreads / 64;
-enum { kRbLnGemm = 0, kRbGemmRes = 1, kRbMlp = 2, kRbLnGemmGelu = 4 };   // (3: the MLP phase by phase, an A/B arm of 2)
+enum { kRbLnGemm = 0, kRbGemmRes = 1, kRbMlp = 2, kRbLnGemmGelu = 4, kRbMergeGemm = 5 };   // (3: the MLP phase by phase, an A/B arm of 2)
 
 struct RbArgs {
   float* x;                      // [M, C] fp32 residual stream (read; written by GEMM_RES / MLP)
@@ -51,6 +54,8 @@ struct RbArgs {
   long ldo;
   long M;
   int n_tiles;                   // 32-unit output tiles of the (first) product
+  float* out32;                  // MERGE_GEMM: fp32 output [M, ldo]
+  int merge_R;                   // MERGE_GEMM: side of the SOURCE token grid (x is [B * R * R, C / 4]; M = B * (R / 2)^2)
 };
 
 __device__ __forceinline__ unsigned lds_off_f(const void* p) {
@@ -121,10 +126,22 @@ __global__ __launch_bounds__(kRbThreads, 2) void htsat_rowblock_kernel(RbArgs a)
     }
   } else {
     const float* xp = a.x + tok * C + 8 * h;
+    long mbase = 0;                                            // MERGE_GEMM: source row of the neighbourhood's (even, even) token
+    if (MODE == kRbMergeGemm) {
+      const int R2 = a.merge_R >> 1;
+      const long per = static_cast<long>(R2) * R2, bb = tok / per;
+      const int rem = static_cast<int>(tok - bb * per), i = rem / R2, j = rem - i * R2;
+      mbase = (bb * a.merge_R + 2 * i) * a.merge_R + 2 * j;
+    }
     float xv[KS][8];
     float sum = 0.f;
 #pragma unroll
     for (int s = 0; s < KS; ++s) {
+      if (MODE == kRbMergeGemm) {                              // channels [q C/4, (q + 1) C/4) come from source (2i + (q & 1), 2j + (q >> 1))
+        constexpr int SPQ = KS / 4;
+        const int q = s / SPQ;
+        xp = a.x + (mbase + (q & 1) * a.merge_R + (q >> 1)) * (C / 4) + 8 * h - 16 * (q * SPQ);
+      }
       const float4 v0 = *reinterpret_cast<const float4*>(xp + 16 * s), v1 = *reinterpret_cast<const float4*>(xp + 16 * s + 4);
       xv[s][0] = v0.x; xv[s][1] = v0.y; xv[s][2] = v0.z; xv[s][3] = v0.w; xv[s][4] = v1.x; xv[s][5] = v1.y; xv[s][6] = v1.z; xv[s][7] = v1.w;
 #pragma unroll
@@ -236,6 +253,13 @@ __global__ __launch_bounds__(kRbThreads, 2) void htsat_rowblock_kernel(RbArgs a)
             v.y = pack2_f(z1[0], z1[1]);
             *reinterpret_cast<uint2*>(op + 8 * g) = v;
           }
+        }
+      } else if (MODE == kRbMergeGemm) {
+        if (row_ok) {
+          float* op = a.out32 + tok * a.ldo + 32 * n + 4 * h;
+#pragma unroll
+          for (int g = 0; g < 4; ++g)
+            *reinterpret_cast<f32x4*>(op + 8 * g) = f32x4{acc[4 * g] + bv[g][0], acc[4 * g + 1] + bv[g][1], acc[4 * g + 2] + bv[g][2], acc[4 * g + 3] + bv[g][3]};
         }
       } else if (MODE == kRbGemmRes) {
         if (row_ok) {
@@ -838,6 +862,20 @@ extern "C" int adt_htsat_rowblock(int32_t mode, float* x, int64_t M, int32_t C, 
   if (mode == kRbGemmRes) return launch_rb<192, kRbGemmRes, 2>(a, st);
   if (mode == 3) return launch_rb<192, kRbMlp, 1>(a, st);
   return launch_mlp<192, 1>(a, st);
+}
+
+extern "C" int adt_htsat_merge_rowblock(const float* x, int64_t B, int32_t R, int32_t C_src, const float* ln_gamma, const float* ln_beta, float eps,
+                                        const void* w_packed, int32_t n_tiles, const float* bias, float* out32, int64_t ldo, void* stream) {
+  if (!x || !ln_gamma || !ln_beta || !w_packed || !bias || !out32) return set_error(ADT_EINVAL, "adt_htsat_merge_rowblock: null pointer");
+  if (C_src != 96) return set_error(ADT_ESHAPE, "adt_htsat_merge_rowblock: built for 96 source channels (LayerNorm over 384)");
+  if (B < 0 || R <= 0 || (R & 1) || n_tiles <= 0 || ldo < 32 * n_tiles || (ldo & 3)) return set_error(ADT_ESHAPE, "adt_htsat_merge_rowblock: bad shape");
+  if (!aligned16(x) || !aligned16(w_packed) || !aligned16(out32)) return set_error(ADT_EINVAL, "adt_htsat_merge_rowblock: misaligned pointer");
+  const long M = B * static_cast<long>(R / 2) * (R / 2);
+  if (M == 0) return ADT_OK;
+  RbArgs a{};
+  a.x = const_cast<float*>(x); a.gamma = ln_gamma; a.beta = ln_beta; a.eps = eps; a.wpk = static_cast<const unsigned char*>(w_packed);
+  a.bias1 = bias; a.out32 = out32; a.ldo = ldo; a.M = M; a.n_tiles = n_tiles; a.merge_R = R;
+  return launch_rb<384, kRbMergeGemm, 1>(a, static_cast<hipStream_t>(stream));
 }
 
 extern "C" int adt_htsat_attn_block(float* x, int64_t B, int32_t R, int32_t C, int32_t heads, int32_t shift, const float* ln_gamma,

@@ -40,7 +40,7 @@ extern "C" {
  * backward entry points regenerate them from the same (p, key).  p == 0 or a null pointer: off. */
 typedef struct adt_dropout { float p; uint32_t key; } adt_dropout;
 
-/* ABI version (14): bumped whenever a signature below changes or entries are added. */
+/* ABI version (15): bumped whenever a signature below changes or entries are added. */
 int adt_version(void);
 
 /* Message of the last failing call on this thread ("" if none). */
@@ -534,6 +534,12 @@ int adt_htsat_attn_block(float* x, int64_t B, int32_t R, int32_t C, int32_t head
 int adt_htsat_rowblock(int32_t mode, float* x, int64_t M, int32_t C, const void* a16, int64_t lda, const float* ln_gamma,
                        const float* ln_beta, float eps, const void* w_packed, int32_t n_tiles, const float* bias1,
                        const float* bias2, void* out16, int64_t ldo, void* stream);
+/* Patch merging between stage 0 and stage 1 in ONE launch (ClapAudioPatchMerging.forward, modeling_clap.py: 2x2 gather in the order
+ * (0,0) (1,0) (0,1) (1,1) -> LayerNorm(4 C_src) -> reduction Linear without bias), replacing adt_patch_merge_ln + adt_gemm_bf16 there:
+ *   x [B * R * R, C_src] fp32 (C_src = 96), out32 [B * (R/2)^2, ldo] fp32 = LayerNorm(gather(x)) W^T + bias,
+ *   w_packed = W [32 n_tiles, 4 C_src] as the mode-0 fragment stream of adt_htsat_rowblock, bias [32 n_tiles] (zeros for the reference). */
+int adt_htsat_merge_rowblock(const float* x, int64_t B, int32_t R, int32_t C_src, const float* ln_gamma, const float* ln_beta, float eps,
+                             const void* w_packed, int32_t n_tiles, const float* bias, float* out32, int64_t ldo, void* stream);
 int adt_l2_normalize(const float* x, int64_t n_rows, int32_t D, float* out, void* stream);
 
 /* ---------------------------------------------------------------------------

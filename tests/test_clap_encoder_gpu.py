@@ -48,6 +48,62 @@ def test_front_and_patch_embed_match_hf(setup):
     assert (tok.cpu().view(B, 4096, 96) - tok_ref).abs().max() < 2e-3
 
 
+@pytest.mark.parametrize("in_t", [1001, 1024, 37, 2, 1100])
+def test_front_matches_torch_bicubic(in_t):
+    """BN + bicubic time resize (align_corners) + fold against torch's interpolate, at frame counts on both sides of the coalesced
+    64-bin kernel's range: the extractor's 1001, no resize (1024), heavy upsampling (37, 2: a handful of LDS rows per workgroup) and
+    downsampling (1100: falls back to the bin-on-the-lane kernel).  reshape_mel2img of modeling_clap.py."""
+    from adt_str_amd import _ffi
+    g = torch.Generator().manual_seed(in_t)
+    B = 3
+    mel = torch.randn(B, in_t, 64, generator=g) * 20 - 30
+    sc, sh = torch.rand(64, generator=g) + 0.5, torch.randn(64, generator=g)
+    x = (mel * sc + sh).transpose(1, 2).unsqueeze(1)                                                # [B, 1, 64, T]
+    up = torch.nn.functional.interpolate(x.transpose(2, 3), (1024, 64), mode="bicubic", align_corners=True)[:, 0]      # [B, 1024, 64]
+    ref = up.reshape(B, 4, 256, 64).permute(0, 1, 3, 2).reshape(B, 256, 256)                         # img[b][r * 64 + f][t']
+    img = torch.full((B, 256, 256), float("nan"), device=DEV)
+    m, scd, shd = mel.to(DEV), sc.to(DEV), sh.to(DEV)
+    _ffi.call("adt_htsat_front_f32", m.data_ptr(), in_t * 64, B, in_t, 64, 1024, 256, scd.data_ptr(), shd.data_ptr(), img.data_ptr(), 0)
+    assert torch.isfinite(img).all()
+    assert (img.cpu() - ref).abs().max() < 2e-4 * ref.abs().max()
+
+
+def test_merge_rowblock_matches_patch_merging(setup):
+    """Patch merging stage 0 -> 1 in one launch (gather 2x2 -> LayerNorm(384) -> reduction) against ClapAudioPatchMerging itself (fp32) and
+    against the two-launch path it replaces (adt_patch_merge_ln + GEMM: the same bf16 operands, so nearly the same numbers)."""
+    from adt_str_amd import _ffi, kernels as K
+    from adt_str_amd.clap_encoder import HtsatEncoder
+    model, *_ = setup
+    enc = HtsatEncoder(model.state_dict(), model.config.audio_config, DEV)
+    mg = enc.stages[0]["merge"]
+    assert "pk" in mg
+    B, R, C = 3, 64, 96
+    g = torch.Generator().manual_seed(5)
+    x = torch.randn(B * R * R, C, generator=g) * 1.5 + 0.3
+    with torch.no_grad():
+        ref = model.audio_model.audio_encoder.layers[0].downsample(x.view(B, R * R, C), (R, R)).reshape(-1, 2 * C)
+    xd = x.to(DEV)
+    out = torch.full((B * R * R // 4, 2 * C), float("nan"), device=DEV)
+    _ffi.call("adt_htsat_merge_rowblock", xd.data_ptr(), B, R, C, mg["norm"][0].data_ptr(), mg["norm"][1].data_ptr(), 1e-5, mg["pk"].data_ptr(),
+              2 * C // 32, mg["zero_bias"].data_ptr(), out.data_ptr(), out.stride(0), 0)
+    m16 = torch.empty((B * R * R // 4, 4 * C), dtype=torch.bfloat16, device=DEV)
+    _ffi.call("adt_patch_merge_ln", xd.data_ptr(), B, R, C, mg["norm"][0].data_ptr(), mg["norm"][1].data_ptr(), 1e-5, m16.data_ptr(), 0)
+    two = K.gemm(m16, mg["w"], out_dtype=torch.float32)
+    torch.cuda.synchronize()
+    assert torch.isfinite(out).all()
+    scale = ref.abs().max()
+    assert (out.cpu() - ref).abs().max() < 2e-2 * scale                  # bf16 operands against the fp32 module
+    assert (out - two).abs().max() < 2e-3 * scale                         # the same operands, another summation order
+    # a ragged last workgroup (M = 3 * 16 = 48 rows < 128) and R = 8
+    xs = torch.randn(3 * 8 * 8, C, generator=g).to(DEV)
+    outs = torch.empty((48, 2 * C), device=DEV)
+    _ffi.call("adt_htsat_merge_rowblock", xs.data_ptr(), 3, 8, C, mg["norm"][0].data_ptr(), mg["norm"][1].data_ptr(), 1e-5, mg["pk"].data_ptr(),
+              2 * C // 32, mg["zero_bias"].data_ptr(), outs.data_ptr(), outs.stride(0), 0)
+    with torch.no_grad():
+        refs = model.audio_model.audio_encoder.layers[0].downsample(xs.cpu().view(3, 64, C), (8, 8)).reshape(-1, 2 * C)
+    assert (outs.cpu() - refs).abs().max() < 2e-2 * refs.abs().max()
+
+
 def test_window_attention_matches_hf_layer(setup):
     """One shifted and one unshifted ClapAudioSelfAttention call (stage 1: R = 32, C = 192, 8 heads)."""
     import math
