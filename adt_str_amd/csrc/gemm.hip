@@ -1465,7 +1465,8 @@ static bool use_big_tile(int64_t M, int64_t N, int64_t K) {
   if (K < 256) return false;
   // a 256-wide tile over a narrower output is mostly padding; below 512 tiles (the decoder's M = 8192) the 256^2 kernel still
   // wins from N = 1400 up -- 192 tiles on 256 CUs included -- and loses at N = 768 (tools/exp_small_gemm.py)
-  return (tiles >= 512 && N >= 160) || (tiles >= 192 && N >= 1024);
+  // (and with a long K loop from 384 tiles: the CLAP tower's last-stage fc2, M = 32768, N = 768, K = 3072, 182 vs 206 us -- tools/probe/clap_fc2_tile.py)
+  return (tiles >= 512 && N >= 160) || (tiles >= 192 && N >= 1024) || (tiles >= 384 && K >= 2048 && N >= 512);
 }
 
 static int pick_splits(int M, int N, int K, int n_cu) {

@@ -524,10 +524,15 @@ __global__ __launch_bounds__(256) void window_attn_kernel(WinAttnArgs a) {
 // by bytes.  Here a workgroup = one window x four consecutive heads (wave w = head 4 hg + w): the 64 tokens' three 192-byte runs
 // (q, k, v of the four heads) are fetched with 16-byte loads that walk the runs contiguously, parked in LDS (row pitch 592 bytes:
 // 37 sixteen-byte chunks, odd, so the row reads of 32 consecutive tokens are conflict-free), read from there as MFMA operands, and
-// the four heads' outputs go back through the same buffer to 192-byte coalesced stores.
+// the four heads' outputs go back through the same buffer to 192-byte coalesced stores.  V^T fragments are read transposed straight
+// from the staged rows (ds_read_b64_tr_b16 takes per-lane addresses, any pitch): the padding d = 24..31 of a head then reads the next
+// head's first values (the zeroed pad chunk for the last head) -- finite numbers that only reach output rows d >= 24, which are never
+// stored; likewise only Q carries explicit zeros for d >= 24 (0 x finite = 0 in S).  Without per-wave V tiles the workgroup needs
+// 37 KiB of LDS and four of them share a CU (two before).  A thread fetches chunk cc of the q, the k and the v run of three tokens
+// (twelve consecutive lanes walk one 192-byte run), so it computes three row indices, not nine, and keeps them for the output.
 constexpr int kWa4Pitch = 592;                          // 3 x 192 + 16
 constexpr int kWa4Stage = 64 * kWa4Pitch;               // 37,888 B
-constexpr int kWa4Lds = kWa4Stage + 4 * 64 * 64;        // + a [64 keys][32 d] V tile per wave = 54,272 B
+constexpr int kWa4Lds = kWa4Stage;
 
 __global__ __launch_bounds__(256) void window_attn4_kernel(WinAttnArgs a) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem4[];
@@ -541,15 +546,25 @@ __global__ __launch_bounds__(256) void window_attn4_kernel(WinAttnArgs a) {
   const int b = static_cast<int>(item / nw);
   const int head = 4 * hg + wave;
   unsigned char* stage = smem4;
-  unsigned char* vt = smem4 + kWa4Stage + wave * 4096;
   // ---- stage: 64 tokens x 36 chunks (q: 0..11, k: 12..23, v: 24..35 = the four heads' 24 values each)
+  long st_row[3];
+  int st_t[3], st_cc[3];
+  {
+    int t = tid / 12, cc = tid - 12 * t;                     // pass p covers ids 256 p + tid: 256 = 21 x 12 + 4
 #pragma unroll
-  for (int j = 0; j < 9; ++j) {
-    const int id = j * 256 + tid, t = id / 36, c = id - t * 36, which = c / 12, cc = c - which * 12;
-    const unsigned short* src = a.qkv + token_row(a, b, wy, wx, t) * a.ld + which * a.C + hg * 96 + cc * 8;
-    *reinterpret_cast<uint4*>(stage + t * kWa4Pitch + c * 16) = *reinterpret_cast<const uint4*>(src);
+    for (int p = 0; p < 3; ++p) {
+      st_t[p] = t; st_cc[p] = cc;
+      st_row[p] = token_row(a, b, wy, wx, t);
+      const unsigned short* src = a.qkv + st_row[p] * a.ld + hg * 96 + cc * 8;
+      unsigned char* dst = stage + t * kWa4Pitch + cc * 16;
+#pragma unroll
+      for (int which = 0; which < 3; ++which) *reinterpret_cast<uint4*>(dst + which * 192) = *reinterpret_cast<const uint4*>(src + which * a.C);
+      const bool wrap = cc >= 8;
+      cc = wrap ? cc - 8 : cc + 4;
+      t += wrap ? 22 : 21;
+    }
   }
-  if (tid < 64) *reinterpret_cast<uint4*>(stage + tid * kWa4Pitch + 576) = make_uint4(0, 0, 0, 0);      // the pad chunk (never an operand; kept finite)
+  if (tid < 64) *reinterpret_cast<uint4*>(stage + tid * kWa4Pitch + 576) = make_uint4(0, 0, 0, 0);      // the pad chunk: the last head's V padding
   __syncthreads();
   // ---- operands of this wave's head: token r (tile 0) and r + 32 (tile 1); k-step s covers d = 16s .. 16s+15, the lane holds 8h .. 8h+7
   auto chunk = [&](int t, int which, int c) -> bf16x8 {                             // d = 8c .. 8c+7 of the head; c == 3 is the zero padding 24..31
@@ -557,17 +572,15 @@ __global__ __launch_bounds__(256) void window_attn4_kernel(WinAttnArgs a) {
     if (c < 3) v = *reinterpret_cast<const uint4*>(stage + t * kWa4Pitch + which * 192 + wave * 48 + c * 16);
     return *reinterpret_cast<bf16x8*>(&v);
   };
+  auto raw = [&](int t, int which, int c) -> bf16x8 {                               // the same without the padding test: chunk 3 of K is whatever
+    const uint4 v = *reinterpret_cast<const uint4*>(stage + t * kWa4Pitch + which * 192 + wave * 48 + c * 16);      // follows the head (finite)
+    return *reinterpret_cast<const bf16x8*>(&v);
+  };
   bf16x8 kf[2][2], qf[2][2];
 #pragma unroll
   for (int s = 0; s < 2; ++s) {
     qf[0][s] = chunk(r, 0, 2 * s + h);  qf[1][s] = chunk(r + 32, 0, 2 * s + h);
-    kf[0][s] = chunk(r, 1, 2 * s + h);  kf[1][s] = chunk(r + 32, 1, 2 * s + h);
-  }
-#pragma unroll
-  for (int c = 0; c < 2; ++c) {                       // V tile: keys r and r + 32, 32 d each (d >= 24 zero); lane half h writes chunks 2h, 2h+1
-    const int ch = 2 * h + c;
-    *reinterpret_cast<bf16x8*>(vt + r * 64 + ch * 16) = chunk(r, 2, ch);
-    *reinterpret_cast<bf16x8*>(vt + (r + 32) * 64 + ch * 16) = chunk(r + 32, 2, ch);
+    kf[0][s] = raw(r, 1, 2 * s + h);    kf[1][s] = raw(r + 32, 1, 2 * s + h);
   }
   f32x16 st[2][2];                                   // st[kt][qt] = S^T tile: rows keys, lane = query
 #pragma unroll
@@ -580,8 +593,9 @@ __global__ __launch_bounds__(256) void window_attn4_kernel(WinAttnArgs a) {
       for (int s = 0; s < 2; ++s) st[kt][qt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf[kt][s], qf[qt][s], st[kt][qt], 0, 0, 0);
     }
   const int wsel = a.n_bias_windows > 1 ? (wy * nw + wx) : 0;
-  const float* bias = a.bias + (static_cast<long>(wsel) * a.heads + head) * 4096 + lane * 4;
-  __syncthreads();                                    // every wave has its operands: the q | k part of the stage is free for the outputs
+  const float* bias = a.bias + (static_cast<long>(wsel) * a.heads + head) * 4096;      // wave-uniform; the lane adds 4 * lane floats
+  const unsigned bias_lane = static_cast<unsigned>(lane) * 4u;
+  __syncthreads();                                    // every wave has its operands: the q part of the stage is free for the outputs
   f32x16 o[2];
   const float sl2 = a.scale * 1.4426950408889634f;     // scores in log2 units (the bias table already is)
 #pragma unroll
@@ -591,7 +605,7 @@ __global__ __launch_bounds__(256) void window_attn4_kernel(WinAttnArgs a) {
     for (int kt = 0; kt < 2; ++kt)
 #pragma unroll
       for (int g = 0; g < 4; ++g) {
-        const float4 bv = *reinterpret_cast<const float4*>(bias + ((qt * 2 + kt) * 4 + g) * 256);
+        const float4 bv = *reinterpret_cast<const float4*>(bias + (bias_lane + static_cast<unsigned>(((qt * 2 + kt) * 4 + g) * 256)));
         const float bb[4] = {bv.x, bv.y, bv.z, bv.w};
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
@@ -616,10 +630,10 @@ __global__ __launch_bounds__(256) void window_attn4_kernel(WinAttnArgs a) {
       for (int s2 = 0; s2 < 2; ++s2) {
         const int i16 = lane & 15, g4 = (lane >> 4) & 1;
         const int krow = kt * 32 + 16 * s2 + 4 * h + (i16 >> 2);
-        const unsigned base = static_cast<unsigned>(reinterpret_cast<size_t>((__attribute__((address_space(3))) const void*)vt)) +
-                              krow * 64 + (16 * g4 + 4 * (i16 & 3)) * 2;
+        const unsigned base = static_cast<unsigned>(reinterpret_cast<size_t>((__attribute__((address_space(3))) const void*)stage)) +
+                              krow * kWa4Pitch + 384 + wave * 48 + (16 * g4 + 4 * (i16 & 3)) * 2;
         bf16x4 lo, hi;
-        asm volatile("ds_read_b64_tr_b16 %0, %2\n\tds_read_b64_tr_b16 %1, %2 offset:512\n\ts_waitcnt lgkmcnt(0)"
+        asm volatile("ds_read_b64_tr_b16 %0, %2\n\tds_read_b64_tr_b16 %1, %2 offset:4736\n\ts_waitcnt lgkmcnt(0)"      // + 8 rows of 592 B
                      : "=&v"(lo), "=&v"(hi) : "v"(base) : "memory");
         bf16x8 af;
         af[0] = lo[0]; af[1] = lo[1]; af[2] = lo[2]; af[3] = lo[3]; af[4] = hi[0]; af[5] = hi[1]; af[6] = hi[2]; af[7] = hi[3];
@@ -641,10 +655,8 @@ __global__ __launch_bounds__(256) void window_attn4_kernel(WinAttnArgs a) {
   __syncthreads();
   // ---- 64 tokens x 12 chunks of 16 bytes -> ctx rows (192 contiguous bytes per token)
 #pragma unroll
-  for (int j = 0; j < 3; ++j) {
-    const int id = j * 256 + tid, t = id / 12, c = id - t * 12;
-    *reinterpret_cast<uint4*>(a.ctx + token_row(a, b, wy, wx, t) * a.ldc + hg * 96 + c * 8) = *reinterpret_cast<const uint4*>(stage + t * kWa4Pitch + c * 16);
-  }
+  for (int p = 0; p < 3; ++p)
+    *reinterpret_cast<uint4*>(a.ctx + st_row[p] * a.ldc + hg * 96 + st_cc[p] * 8) = *reinterpret_cast<const uint4*>(stage + st_t[p] * kWa4Pitch + st_cc[p] * 16);
 }
 
 // ------------------------------------------------------------------------------------ patch merging gather + LayerNorm(4C)
@@ -810,10 +822,11 @@ extern "C" int adt_window_attn_fwd(const void* qkv, int64_t ld_qkv, void* ctx, i
     int dev = 0;
     ADT_HIP_TRY(hipGetDevice(&dev));
     if (done_for != dev) {
-      ADT_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(window_attn4_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, kWa4Lds));
+      ADT_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(window_attn4_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024));
       done_for = dev;
     }
-    hipLaunchKernelGGL(window_attn4_kernel, dim3(static_cast<unsigned>(total / 4)), dim3(256), kWa4Lds, STR(stream), a);
+    static const int lds4 = [] { const char* v = getenv("ADT_WA4_LDS"); return v ? atoi(v) : kWa4Lds; }();      // (A/B: 54272 = two workgroups per CU)
+    hipLaunchKernelGGL(window_attn4_kernel, dim3(static_cast<unsigned>(total / 4)), dim3(256), lds4, STR(stream), a);
   } else {
     hipLaunchKernelGGL(window_attn_kernel, dim3(static_cast<unsigned>((total + 3) / 4)), dim3(256), 0, STR(stream), a);
   }
