@@ -184,20 +184,26 @@ __global__ __launch_bounds__(256) void htsat_patch_embed_kernel(const float* __r
 // channels of its own token.  The conv weights, bias, gamma and beta are wave-uniform (scalar loads feeding the FMAs as scalar
 // operands), the LayerNorm statistics are per-lane sums (no cross-lane reductions), the four pixel rows of a token row are four
 // coalesced KiB loads per wave.  ~33 vector instructions per token against ~60 plus 12 shuffles in the kernel above.
+// The wave's 64 output rows are one contiguous 24 KiB block, but a lane holds a whole ROW of it: stored from the registers, every
+// store instruction scatters 64 sixteen-byte pieces over 64 rows.  So the rows go through LDS in two halves of 48 channels (pitch 13
+// float4: the b128 writes of eight consecutive lanes cover all 32 banks) and leave as 192-byte runs, twelve lanes per run.
 template <int C>
 __global__ __launch_bounds__(256) void htsat_patch_embed_tok_kernel(const float* __restrict__ img, int side, const float* __restrict__ w,
                                                                     const float* __restrict__ bias, const float* __restrict__ gamma,
                                                                     const float* __restrict__ beta, float eps, float* __restrict__ out32,
                                                                     unsigned short* __restrict__ out16, long n_waves) {
-  const int lane = threadIdx.x & 63;
-  const long wv = static_cast<long>(blockIdx.x) * 4 + (threadIdx.x >> 6);
-  if (wv >= n_waves) return;
+  static_assert(C == 96, "two halves of twelve float4");
+  __shared__ float4 tr[4][64 * 13];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  long wv = static_cast<long>(blockIdx.x) * 4 + wave;
+  const bool live = wv < n_waves;
+  if (!live) wv = n_waves - 1;                                // (keeps the barriers below uniform; its stores are predicated off)
   const int grid = side / 4, wpr = grid / 64;               // token grid side; waves per token row
-  const int j = static_cast<int>(wv % wpr) * 64 + lane;
+  const int j0 = static_cast<int>(wv % wpr) * 64;
   const int i = static_cast<int>((wv / wpr) % grid);
   const long b = wv / (static_cast<long>(wpr) * grid);
   float px[16];
-  const float* rowp = img + (b * side + 4 * i) * side + 4 * j;
+  const float* rowp = img + (b * side + 4 * i) * side + 4 * (j0 + lane);
 #pragma unroll
   for (int di = 0; di < 4; ++di) {
     const float4 v = *reinterpret_cast<const float4*>(rowp + di * side);
@@ -220,14 +226,29 @@ __global__ __launch_bounds__(256) void htsat_patch_embed_tok_kernel(const float*
 #pragma unroll
   for (int o = 0; o < C; ++o) { const float d = y[o] - mean; ss = fmaf(d, d, ss); }
   const float rstd = rsqrtf(ss * (1.0f / C) + eps);
-  const long tok = (b * grid + i) * grid + j;
+  const long tok0 = (b * grid + i) * grid + j0;             // the wave's 64 rows are contiguous from here
+  float4* my = tr[wave];
 #pragma unroll
-  for (int o = 0; o < C; o += 4) {
-    float v[4];
+  for (int half = 0; half < 2; ++half) {
 #pragma unroll
-    for (int e = 0; e < 4; ++e) v[e] = fmaf((y[o + e] - mean) * rstd, gamma[o + e], beta[o + e]);
-    if (out32) *reinterpret_cast<float4*>(out32 + tok * C + o) = float4{v[0], v[1], v[2], v[3]};
-    if (out16) *reinterpret_cast<uint2*>(out16 + tok * C + o) = uint2{pack2_h(v[0], v[1]), pack2_h(v[2], v[3])};
+    for (int q = 0; q < 12; ++q) {
+      const int o = 48 * half + 4 * q;
+      float v[4];
+#pragma unroll
+      for (int e = 0; e < 4; ++e) v[e] = fmaf((y[o + e] - mean) * rstd, gamma[o + e], beta[o + e]);
+      my[lane * 13 + q] = float4{v[0], v[1], v[2], v[3]};
+    }
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < 12; ++k) {
+      const int idx = k * 64 + lane, t = idx / 12, q = idx - 12 * t;
+      const float4 v = my[t * 13 + q];
+      if (live) {
+        if (out32) *reinterpret_cast<float4*>(out32 + (tok0 + t) * C + 48 * half + 4 * q) = v;
+        if (out16) *reinterpret_cast<uint2*>(out16 + (tok0 + t) * C + 48 * half + 4 * q) = uint2{pack2_h(v.x, v.y), pack2_h(v.z, v.w)};
+      }
+    }
+    __syncthreads();
   }
 }
 
