@@ -25,6 +25,7 @@
 // would be ordered behind the DMA in flight with a vmcnt(0)).
 #include <hip/hip_runtime.h>
 
+#include <cstdlib>
 #include <type_traits>
 
 #include "adt_common.h"
@@ -855,7 +856,10 @@ extern "C" int adt_htsat_rowblock(int32_t mode, float* x, int64_t M, int32_t C, 
     if (mode == kRbLnGemmGelu) return launch_rb<96, kRbLnGemmGelu, 3>(a, st);
     if (mode == kRbGemmRes) return launch_rb<96, kRbGemmRes, 3>(a, st);
     if (mode == 3) return launch_rb<96, kRbMlp, 2>(a, st);
-    return launch_mlp<96, 2>(a, st);
+    // one step (12 KiB) per LDS-DMA chunk: 37 KiB of LDS, three workgroups per CU (two with 24 KiB chunks; -4 % on the launch).
+    static const bool spc2 = [] { const char* v = getenv("ADT_HTSAT_MLP96_SPC"); return v && v[0] == '2'; }();
+    if (spc2) return launch_mlp<96, 2>(a, st);
+    return launch_mlp<96, 1>(a, st);
   }
   if (mode == kRbLnGemm) return launch_rb<192, kRbLnGemm, 2>(a, st);
   if (mode == kRbLnGemmGelu) return launch_rb<192, kRbLnGemmGelu, 2>(a, st);
