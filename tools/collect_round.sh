@@ -6,10 +6,10 @@ for f in bench_train.json bench_train_nodropout.json bench_logmel.json bench_cla
 grep -v amdgpu.ids $O/bench_kernels.txt > $P/bench_kernels.txt
 cp $O/smoke.log $P/smoke.txt
 tail -3 $O/pytest_gpu.log > $P/pytest_gpu.txt
-cp $O/prof_train/*/*kernel_stats.csv $P/train_step_kernel_stats.csv
-cp $O/prof_logmel/*/*kernel_stats.csv $P/logmel_kernel_stats.csv
-cp $O/prof_clap/*/*kernel_stats.csv $P/clap_kernel_stats.csv
-cp $O/prof_roofline/*/*kernel_stats.csv $P/roofline_gemm_kernel_stats.csv
+cp "$(ls -t $O/prof_train/*/*kernel_stats.csv | head -1)" $P/train_step_kernel_stats.csv          # (newest: an earlier call with the same tag leaves its files behind)
+cp "$(ls -t $O/prof_logmel/*/*kernel_stats.csv | head -1)" $P/logmel_kernel_stats.csv          # (newest: an earlier call with the same tag leaves its files behind)
+cp "$(ls -t $O/prof_clap/*/*kernel_stats.csv | head -1)" $P/clap_kernel_stats.csv          # (newest: an earlier call with the same tag leaves its files behind)
+cp "$(ls -t $O/prof_roofline/*/*kernel_stats.csv | head -1)" $P/roofline_gemm_kernel_stats.csv          # (newest: an earlier call with the same tag leaves its files behind)
 [ -f gpurun_out/gemm_pmc_summary_$TAG.json ] && cp gpurun_out/gemm_pmc_summary_$TAG.json $P/gemm_pmc_summary.json
 [ -f gpurun_out/logmel_pmc_summary_$TAG.json ] && cp gpurun_out/logmel_pmc_summary_$TAG.json $P/logmel_pmc_summary.json
 [ -f gpurun_out/attn_pmc_$TAG.txt ] && cp gpurun_out/attn_pmc_$TAG.txt $P/attn_pmc.txt
