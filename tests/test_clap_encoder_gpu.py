@@ -46,6 +46,12 @@ def test_front_and_patch_embed_match_hf(setup):
     _ffi.call("adt_htsat_patch_embed", img.data_ptr(), B, 256, enc.pe_w.data_ptr(), enc.pe_b.data_ptr(), enc.pe_g.data_ptr(),
               enc.pe_beta.data_ptr(), 1e-5, 96, tok.data_ptr(), None, 0)
     assert (tok.cpu().view(B, 4096, 96) - tok_ref).abs().max() < 2e-3
+    # the bf16 output of the same launch is the rounded fp32 one (both leave through the LDS transposition of the token-on-the-lane kernel)
+    tok32 = torch.full((B * 4096, 96), float("nan"), device=DEV)
+    tok16 = torch.zeros((B * 4096, 96), dtype=torch.bfloat16, device=DEV)
+    _ffi.call("adt_htsat_patch_embed", img.data_ptr(), B, 256, enc.pe_w.data_ptr(), enc.pe_b.data_ptr(), enc.pe_g.data_ptr(),
+              enc.pe_beta.data_ptr(), 1e-5, 96, tok32.data_ptr(), tok16.data_ptr(), 0)
+    assert torch.equal(tok32, tok) and torch.equal(tok16, tok.bfloat16())
 
 
 @pytest.mark.parametrize("in_t", [1001, 1024, 37, 2, 1100])
