@@ -330,7 +330,13 @@ __device__ __forceinline__ void epilogue_apply8(const GemmArgs& g, float (&z)[8]
       z[2 * e] = gv[0]; z[2 * e + 1] = gv[1];
       f[2 * e] = gd[0] * keep[2 * e]; f[2 * e + 1] = gd[1] * keep[2 * e + 1];
     }
-    *reinterpret_cast<uint4*>(reinterpret_cast<unsigned short*>(ep.pre_act_out) + (ea.pre + static_cast<long>(irow) * ep.ld_pre_act)) = pack_bf8(f);
+    {
+      // the saved factor is not read before the backward pass: a non-temporal store keeps it from displacing h (which the next launch
+      // reads) from the Infinity Cache -- the launch itself does not change, the step gains 0.09 ms (same-box A/B, twice)
+      typedef unsigned u32x4_nt __attribute__((ext_vector_type(4)));
+      const uint4 pf = pack_bf8(f);
+      __builtin_nontemporal_store(u32x4_nt{pf.x, pf.y, pf.z, pf.w}, reinterpret_cast<u32x4_nt*>(reinterpret_cast<unsigned short*>(ep.pre_act_out) + (ea.pre + static_cast<long>(irow) * ep.ld_pre_act)));
+    }
   } else {
     if (has_pre) {
       const uint4 o = pack_bf8(z);
@@ -1393,6 +1399,10 @@ __global__ __launch_bounds__(256) void reduce_slabs_kernel(const float* __restri
   }
   const long row = i4 / N; const int col = static_cast<int>(i4 - row * N);   // N % 4 == 0: a float4 never straddles rows
   float* o = out + row * ldc + col;
+  if ((reinterpret_cast<uintptr_t>(o) & 15) == 0) {
+    *reinterpret_cast<float4*>(o) = float4{s.x * alpha, s.y * alpha, s.z * alpha, s.w * alpha};
+    return;
+  }
   o[0] = s.x * alpha; o[1] = s.y * alpha; o[2] = s.z * alpha; o[3] = s.w * alpha;
 }
 
