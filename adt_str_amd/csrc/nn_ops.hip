@@ -518,6 +518,38 @@ __global__ __launch_bounds__(256) void cast_bf16_batched_kernel(const CastItem* 
   const int tc = (it.cols + 63) >> 6, tr = (it.rows + 63) >> 6;
   if (static_cast<int>(blockIdx.x) >= tc * tr) return;
   const int r0 = (blockIdx.x / tc) * 64, c0 = (blockIdx.x % tc) * 64;
+  // whole tiles of 16-byte-aligned matrices: 64-byte runs per thread (the element-wise loop below moved 4 / 2 bytes per lane and
+  // instruction: 140 us for the model's 69 M weights, ~100 us this way)
+  if (r0 + 64 <= it.rows && c0 + 64 <= it.cols && (it.cols & 7) == 0 && (it.rows & 7) == 0 && (reinterpret_cast<uintptr_t>(it.x) & 15) == 0 &&
+      (!it.y || (reinterpret_cast<uintptr_t>(it.y) & 15) == 0) && (!it.y_t || (reinterpret_cast<uintptr_t>(it.y_t) & 15) == 0)) {
+    const int q = threadIdx.x & 3, rr = threadIdx.x >> 2;              // phase 1: row rr, columns 16 q .. 16 q + 15
+    const float4* src = reinterpret_cast<const float4*>(it.x + static_cast<long>(r0 + rr) * it.cols + c0 + 16 * q);
+    unsigned w[8];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const float4 v = src[k];
+      w[2 * k] = f2bf_(v.x) | (static_cast<unsigned>(f2bf_(v.y)) << 16);
+      w[2 * k + 1] = f2bf_(v.z) | (static_cast<unsigned>(f2bf_(v.w)) << 16);
+    }
+    if (it.y) {
+      uint4* dst = reinterpret_cast<uint4*>(it.y + static_cast<long>(r0 + rr) * it.cols + c0 + 16 * q);
+      dst[0] = make_uint4(w[0], w[1], w[2], w[3]);
+      dst[1] = make_uint4(w[4], w[5], w[6], w[7]);
+    }
+    if (!it.y_t) return;
+    unsigned* trow = reinterpret_cast<unsigned*>(&tile[rr][16 * q]);     // row pitch 132 B, 16 q columns = 32 q bytes: 4-byte aligned
+#pragma unroll
+    for (int k = 0; k < 8; ++k) trow[k] = w[k];
+    __syncthreads();
+    const int cc = threadIdx.x >> 2;                                     // phase 2: column cc, rows 16 q .. 16 q + 15
+    unsigned o[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) o[k] = tile[16 * q + 2 * k][cc] | (static_cast<unsigned>(tile[16 * q + 2 * k + 1][cc]) << 16);
+    uint4* dst = reinterpret_cast<uint4*>(it.y_t + static_cast<long>(c0 + cc) * it.rows + r0 + 16 * q);
+    dst[0] = make_uint4(o[0], o[1], o[2], o[3]);
+    dst[1] = make_uint4(o[4], o[5], o[6], o[7]);
+    return;
+  }
   for (int i = threadIdx.x; i < 64 * 64; i += 256) {
     const int r = i >> 6, c = i & 63;
     unsigned short v = 0;
