@@ -184,6 +184,13 @@ def load_clips_batch(paths: Sequence[str], sample_rate: int, device, normalize: 
     import torch
     from .resample import Resample
     device = torch.device(device)
+
+    def up(a):
+        """Small host array -> device without stalling: a copy from pageable memory is stream-ordered AND blocks the host, i.e. it waits
+        for everything the GPU still has queued (the previous batch's tower); through pinned memory it is just enqueued."""
+        t = torch.from_numpy(np.ascontiguousarray(a))
+        return t.pin_memory().to(device, non_blocking=True) if device.type == "cuda" else t.to(device)
+
     b = decoded if decoded is not None else read_wav_batch(paths, normalize=False, pin=device.type == "cuda", threads=threads)
     n = len(paths)
     lens = np.diff(b.offsets)
@@ -195,10 +202,10 @@ def load_clips_batch(paths: Sequence[str], sample_rate: int, device, normalize: 
     same = ok & (b.sample_rate == sample_rate)
     if same.any():
         # peaks of the clips already at the target rate came with the decode; divide the whole buffer once (other clips: by 1)
-        pk = torch.from_numpy(np.where(same, b.peak, np.float32(1.0)).astype(np.float32)).to(device)
-        peaks = torch.where(torch.from_numpy(same).to(device), pk, peaks)
+        pk = up(np.where(same, b.peak, np.float32(1.0)).astype(np.float32))
+        peaks = torch.where(up(same), pk, peaks)
         if normalize:
-            dev = dev / torch.repeat_interleave(pk, torch.from_numpy(lens).to(device), output_size=int(b.offsets[-1]))
+            dev = dev / torch.repeat_interleave(pk, up(lens), output_size=int(b.offsets[-1]))
         for i in np.nonzero(same)[0]:
             clips[i] = dev[off[i]:off[i + 1]]
     for sr in sorted(set(b.sample_rate[ok & ~same].tolist())):
@@ -214,20 +221,23 @@ def load_clips_batch(paths: Sequence[str], sample_rate: int, device, normalize: 
             while hi < len(idx) and (hi + 1 - lo) * int(lens[idx[hi]]) <= _PAD_BUDGET:
                 hi += 1
             part = idx[lo:hi]
-            ln = torch.from_numpy(lens[part]).to(device)
+            ln = up(lens[part])
             width = int(lens[part[-1]])
-            padded = torch.zeros((len(part), width), dtype=torch.float32, device=device)
-            src = torch.cat([dev[off[i]:off[i + 1]] for i in part])
-            padded[torch.arange(width, device=device)[None, :] < ln[:, None]] = src           # row-major mask order == concatenation order
+            # padded[r, t] = clip r's sample t, zero past its end: a gather by computed index (a boolean-mask assignment would run
+            # nonzero() and wait for the GPU)
+            col = torch.arange(width, device=device)[None, :]
+            src_idx = (up(np.asarray(b.offsets)[part].astype(np.int64))[:, None] + col).clamp_(max=max(int(b.offsets[-1]) - 1, 0))
+            padded = torch.where(col < ln[:, None], dev[src_idx], torch.zeros((), dtype=torch.float32, device=device))
+            del src_idx
             out = rs(padded)
             out_len_h = -((-lens[part] * rs.new) // rs.orig)                                   # ceil(new * L / orig) per clip
-            out_len = torch.from_numpy(out_len_h).to(device)
+            out_len = up(out_len_h)
             valid = torch.arange(out.shape[1], device=device)[None, :] < out_len[:, None]
             pk = torch.where(valid, out.abs(), torch.zeros((), device=device)).amax(dim=1)
             pk = torch.where((out != out).logical_and(valid).any(dim=1), torch.full_like(pk, float("nan")), pk)
             if normalize:
                 out = out / pk[:, None]
-            peaks[torch.from_numpy(part).to(device)] = pk
+            peaks[up(part)] = pk
             for r, i in enumerate(part):
                 clips[i] = out[r, :int(out_len_h[r])]
             lo = hi

@@ -48,6 +48,13 @@ class ClapLogMel:
         n = np.arange(N_FFT)
         self.window = torch.from_numpy((0.5 - 0.5 * np.cos(2.0 * np.pi * n / N_FFT)).astype(np.float32)).to(self.device)
 
+    def _up(self, t: torch.Tensor) -> torch.Tensor:
+        """Small host tensor -> device through pinned memory: a copy from pageable memory blocks the host until the GPU has worked off
+        everything queued before it (the previous batch's tower, in the curation loop)."""
+        if torch.device(self.device).type != "cuda":
+            return t.to(self.device)
+        return t.contiguous().pin_memory().to(self.device, non_blocking=True)
+
     def mel(self, clips: Sequence) -> torch.Tensor:
         """[B, 1001, 64] fp32."""
         arrs = [torch.as_tensor(c, dtype=torch.float32).reshape(-1) for c in clips]
@@ -57,7 +64,7 @@ class ClapLogMel:
         offs = np.zeros(len(arrs) + 1, np.int64)
         offs[1:] = np.cumsum([a.numel() for a in arrs])
         flat = torch.cat(arrs).to(self.device) if arrs else torch.zeros(1, device=self.device)
-        off_d = torch.from_numpy(offs).to(self.device)
+        off_d = self._up(torch.from_numpy(offs))
         out = torch.empty((len(arrs), N_FRAMES, N_MELS), dtype=torch.float32, device=self.device)
         if arrs:
             _ffi.call("adt_clap_logmel_db_f32", _ffi.dptr(flat), _ffi.dptr(off_d), len(arrs), MAX_SAMPLES, N_FFT, HOP, N_FRAMES,
@@ -99,7 +106,9 @@ class ClapLogMel:
         short = [i for i, a in enumerate(arrs) if a.numel() <= MAX_SAMPLES]
         feats = torch.empty((len(arrs), 4, N_FRAMES, N_MELS), dtype=torch.float32, device=self.device)
         longer = torch.zeros(len(arrs), dtype=torch.bool)
-        if short:
+        if len(short) == len(arrs) and short:                   # (no index tensor: its upload would wait for the GPU's queue)
+            feats.copy_(self.mel(arrs).unsqueeze(1).expand(-1, 4, -1, -1))
+        elif short:
             feats[short] = self.mel([arrs[i] for i in short]).unsqueeze(1).expand(-1, 4, -1, -1)
         for i, a in enumerate(arrs):                              # in clip order: the crops consume numpy's global RNG like the extractor
             if a.numel() > MAX_SAMPLES:
@@ -112,4 +121,4 @@ class ClapLogMel:
         """-> (input_features [B, 4, 1001, 64], is_longer [B, 1] bool on the device): what the extractor computes per clip, without its
         "flag one random clip of an all-short batch" step (``ClapWrapper.get_audio_features`` does that)."""
         feats, longer = self.features(clips)
-        return feats, longer.view(-1, 1).to(self.device)
+        return feats, self._up(longer.view(-1, 1))
