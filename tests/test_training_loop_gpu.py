@@ -47,6 +47,73 @@ def test_flat_adamw_step_equals_torch_adamw_with_hf_groups():
     assert float((model.decoder.generator.weight.data - ref_params["decoder.generator.weight"]).abs().max()) > 0
 
 
+def test_fused_adamw_for_the_hf_path_equals_torch_adamw():
+    """adt_str_amd.optim.FusedAdamW (what ADTTrainer.create_optimizer builds) against torch.optim.AdamW on a twin model, driven the way
+    the HF Trainer drives an optimizer: forward through the autograd bridge, backward, clip_grad_norm_, scheduler-written lr, step,
+    zero_grad -- including a two-micro-batch accumulation step (p.grad accumulated in place) and a state_dict round trip."""
+    import copy
+    from tests.test_ddp_gpu import _batch, _make
+    from adt_str_amd.masks import create_mask_plain
+    from adt_str_amd.optim import FusedAdamW
+    from adt_str_amd.trainer import no_decay_names
+    model = _make(seed=5)
+    twin = copy.deepcopy(model)
+    skip = set(no_decay_names(model))
+
+    def groups(m):
+        named = list(m.named_parameters())
+        return [{"params": [p for n, p in named if n not in skip], "weight_decay": 0.1}, {"params": [p for n, p in named if n in skip], "weight_decay": 0.0}]
+
+    ptrs = {n: p.data_ptr() for n, p in model.named_parameters()}
+    opt = FusedAdamW(groups(model), lr=1e-3, betas=(0.9, 0.999), eps=1e-8, engine=model.engine)
+    ref = torch.optim.AdamW(groups(twin), lr=1e-3, betas=(0.9, 0.999), eps=1e-8)
+    assert all(p.data_ptr() != ptrs[n] for n, p in model.named_parameters())          # re-pointed at the flat buffer, names / shapes kept
+    assert [tuple(p.shape) for p in model.parameters()] == [tuple(p.shape) for p in twin.parameters()]
+
+    def run(m, o, seeds, lr):
+        m.train()
+        for sd in seeds:                                                # more than one seed: gradient accumulation, as HF does it
+            wav, tok, tl = _batch(seed=sd)
+            _, pad = create_mask_plain(tok.shape[1] - 1, tl, wav.device)
+            (m(src=wav, tgt=tok[:, :-1], tgt_mask=None, tgt_padding_mask=pad, labels=tok[:, 1:]) / len(seeds)).backward()
+        torch.nn.utils.clip_grad_norm_(m.parameters(), 0.5)
+        for g in o.param_groups:
+            g["lr"] = lr
+        o.step()
+        o.zero_grad(set_to_none=True)
+
+    def same(tag):
+        for (n, p), q in zip(model.named_parameters(), twin.parameters()):
+            err = (p.data - q.data).abs().max().item()
+            assert err <= 2e-7 + 1e-6 * q.data.abs().max().item(), (tag, n, err)
+            q.data.copy_(p.data)                                         # keep the two trajectories on the same weights
+
+    for step, (seeds, lr) in enumerate([((11,), 5e-4), ((12, 13), 1e-3), ((14,), 7e-4)]):
+        run(model, opt, seeds, lr)
+        run(twin, ref, seeds, lr)
+        same(step)
+    # state_dict round trip into a fresh optimizer over a fresh copy of the model: the next step is the same step
+    model2 = copy.deepcopy(model)
+    opt2 = FusedAdamW(groups(model2), lr=1e-3, betas=(0.9, 0.999), eps=1e-8, engine=model2.engine)
+    opt2.load_state_dict(copy.deepcopy(opt.state_dict()))
+    run(model, opt, (15,), 9e-4)
+    run(model2, opt2, (15,), 9e-4)
+    for p, q in zip(model.parameters(), model2.parameters()):
+        assert torch.equal(p.data, q.data)
+    run(twin, ref, (15,), 9e-4)
+    same("after reload")
+    # a gradient that is not the bridge's view (re-allocated by someone): gathered, same result
+    wav, tok, tl = _batch(seed=16)
+    _, pad = create_mask_plain(tok.shape[1] - 1, tl, wav.device)
+    for m in (model, model2):
+        m(src=wav, tgt=tok[:, :-1], tgt_mask=None, tgt_padding_mask=pad, labels=tok[:, 1:]).backward()
+    for p in model2.parameters():
+        p.grad = p.grad.clone()
+    opt.step(); opt2.step()
+    for p, q in zip(model.parameters(), model2.parameters()):
+        assert torch.equal(p.data, q.data)
+
+
 def _losses(tr):
     return [l for _, l in tr.loss_history]
 

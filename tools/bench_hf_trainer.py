@@ -42,6 +42,22 @@ for _ in range(10):
 torch.cuda.synchronize()
 print(f"HF-style step (autograd bridge + clip_grad_norm_ + torch AdamW): {(time.perf_counter() - t0) * 100:.2f} ms/step")
 
+# the same loop with the optimizer ADTTrainer.create_optimizer builds (adt_str_amd/optim.py: torch.optim.AdamW's contract on the fused kernel)
+from adt_str_amd.optim import FusedAdamW
+from adt_str_amd.trainer import no_decay_names
+skip = set(no_decay_names(model))
+named = list(model.named_parameters())
+opt = FusedAdamW([{"params": [p for n, p in named if n not in skip], "weight_decay": 1e-5}, {"params": [p for n, p in named if n in skip], "weight_decay": 0.0}],
+                 lr=1e-4, engine=model.engine)
+for _ in range(3):
+    hf_step()
+torch.cuda.synchronize(); t0 = time.perf_counter()
+for _ in range(10):
+    hf_step()
+torch.cuda.synchronize()
+print(f"HF-style step with FusedAdamW (what train.py's Trainer now builds): {(time.perf_counter() - t0) * 100:.2f} ms/step")
+del opt
+
 from adt_str_amd.trainer import FlatTrainer
 tr = FlatTrainer(model, lr=1e-4, weight_decay=1e-5, max_grad_norm=1.0, total_steps=10000, warmup_ratio=0.1)
 for _ in range(3):

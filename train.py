@@ -55,6 +55,25 @@ class ADTTrainer(Trainer):
         # and an allocator flush per step with no effect on the result -- deliberately not reproduced
         return (loss, None) if return_outputs else loss
 
+    def create_optimizer(self):
+        """The Trainer's AdamW (two groups: decay / no decay, ``get_decay_parameter_names``) on the engine's fused flat-buffer kernel
+        when the run is the default ``adamw_torch*`` on a GPU (adt_str_amd/optim.py: the same arithmetic in one launch instead of
+        multi-tensor passes over 132 tensors); ``ADT_HF_TORCH_ADAMW=1`` or any other ``--optim`` keeps transformers' own choice."""
+        import os
+        model = self.model
+        use = (self.optimizer is None and os.environ.get("ADT_HF_TORCH_ADAMW") != "1" and str(getattr(self.args, "optim", "")).split(".")[-1].lower().startswith("adamw_torch")
+               and hasattr(model, "engine") and next(model.parameters()).is_cuda and all(p.requires_grad for p in model.parameters()))
+        if not use:
+            return super().create_optimizer()
+        from adt_str_amd.optim import FusedAdamW
+        decay = set(self.get_decay_parameter_names(model))
+        named = list(model.named_parameters())
+        groups = [{"params": [p for n, p in named if n in decay], "weight_decay": self.args.weight_decay},
+                  {"params": [p for n, p in named if n not in decay], "weight_decay": 0.0}]
+        self.optimizer = FusedAdamW(groups, lr=self.args.learning_rate, betas=(self.args.adam_beta1, self.args.adam_beta2),
+                                    eps=self.args.adam_epsilon, engine=model.engine)
+        return self.optimizer
+
     def evaluate(self, eval_dataset=None, ignore_keys=None, metric_key_prefix="eval"):
         """Validation loss over an iterable of collated batches (reference train.py:80-141): the mean of the per-batch
         losses, logged as ``{prefix}_loss``; ``{}`` without an eval dataset (the shipped configs pass none, train.py:313).
