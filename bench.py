@@ -208,6 +208,26 @@ def clap_setup(dev, seed):
                        "clips_per_gpu": B, "sample_rate": 48000}}
 
 
+def clap_leg(dev, steps=10, warmup=3, cpu_budget_s=8.0, cpu_baseline=True):
+    """The second half of BASELINE's metric ("...; CLAP embeds/sec") inside the default line: config[2] on this rank's GPU, timed like the
+    main workload (``warmup`` untimed, then ``steps`` passes of 512 clips bracketed by synchronize), with its own roofline and a short
+    CPU-baseline sample.  ``bench.py --workload clap`` is the same workload as a line of its own (longer CPU sample)."""
+    wl = clap_setup(dev, 0)
+    for _ in range(warmup):
+        wl["step"]()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        wl["step"]()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    out = {"metric": wl["metric"], "value": wl["units"] * steps / dt, "unit": wl["unit"], "ms_per_step": dt / steps * 1e3, "steps": steps,
+           "warmup": warmup, "dtype": wl["dtype"], "config": wl["config"], "roofline": wl["roofline"]()}
+    if cpu_baseline:
+        out["cpu_baseline"] = wl["cpu_baseline"](cpu_budget_s)
+    return out
+
+
 # ----------------------------------------------------------------------------- training-step workload (config[3])
 def synthetic_notes(rng, n_clips, n_notes=40):
     """Onsets in [0, 2.95] s (the tokenizer's range, midi_tokenizer.py:54-56), custom-GM pitches, velocities 1..127."""
@@ -436,6 +456,7 @@ def main():
                                                                  "benchmark configuration is 0)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-e2e", action="store_true", help="skip the end-to-end (real input pipeline) leg of the train workload")
+    ap.add_argument("--no-clap", action="store_true", help="train workload, N = 1: skip the CLAP embeds/sec leg (the \"clap\" object of the line)")
     ap.add_argument("--roofline-loop", action="store_true", help="train workload: also time the roofline kernel alone, back to back (the "
                                                                   "earlier rounds' measurement; adds 100 launches of it to a profile of this command)")
     ap.add_argument("--grad-compress", default=None, choices=["bf16"], help="send bf16 copies of the gradient segments (N > 1)")
@@ -533,6 +554,8 @@ def main():
         line["roofline"] = wl["roofline"](args.roofline_loop) if args.workload == "train" else wl["roofline"]()
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = wl["cpu_baseline"]()
+        if world == 1 and args.workload == "train" and not args.no_clap:
+            line["clap"] = clap_leg(dev, cpu_baseline=not args.no_cpu_baseline)
         print(json.dumps(line), flush=True)
     if dist.is_initialized():
         dist.barrier()

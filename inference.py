@@ -47,14 +47,20 @@ def transcribe(model, cfg: dict, wav: torch.Tensor, batch_size: int = 8, token_s
     return np.unique(torch.cat(notes).numpy(), axis=0)
 
 
-def main():
+def _parser() -> argparse.ArgumentParser:
     ap = argparse.ArgumentParser()
     ap.add_argument("input_path")
     ap.add_argument("config_path")
-    ap.add_argument("-o", "--output_dir", default="outputs")
-    ap.add_argument("-s", "--synthesize", action="store_true", help="also render the transcription with the one-shot mixer")
+    # the reference's spellings (inference.py:55-68) first; --output_dir / --synthesize are this repository's earlier aliases
+    ap.add_argument("-o", "--output_path", "--output_dir", dest="output_dir", default="outputs/", help="Directory to save output files")
+    ap.add_argument("-s", "--synthetise_transcription", "--synthesize", dest="synthesize", action="store_true",
+                    help="Resynthesize the drum transcription with the one-shot mixer")
     ap.add_argument("--save-tokens", action="store_true", help="also write <stem>.tokens.json: the generated token ids per chunk")
-    a = ap.parse_args()
+    return ap
+
+
+def main():
+    a = _parser().parse_args()
     model, cfg = build_model(a.config_path, device="cuda")
     audio, sr = read_wav(a.input_path)
     wav = torch.from_numpy(audio.mean(axis=0)).cuda()

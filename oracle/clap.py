@@ -62,3 +62,40 @@ def audio_embeddings(model, input_features: torch.Tensor, is_longer: torch.Tenso
     out = model.audio_model(input_features=input_features, is_longer=is_longer, return_dict=True)
     proj = model.audio_projection(out.pooler_output)
     return {"pooled": out.pooler_output, "embedding": proj / proj.norm(p=2, dim=-1, keepdim=True)}
+
+
+# ---------------------------------------------------------------------------------------------------------------- golden set G7
+# Inputs of tests/golden/clap.npz (tools/make_golden.py:g7_clap runs the reference's own ClapWrapper on them).  The model's 28 M weights
+# cannot travel in a < 1 MB fixture: they are regenerated from GOLDEN_MODEL_SEED by random_clap_model and checked by weights_checksum.
+GOLDEN_MODEL_SEED = 3
+
+
+def golden_short_clips() -> List[np.ndarray]:
+    """Three one-shot-like clips @ 48 kHz (decaying noise + tone, peak-normalised like augment_data_with_CLAP.py:51-63)."""
+    rng = np.random.default_rng(77)
+    out = []
+    for n, f0 in ((4800, 180.0), (19000, 95.0), (30000, 3100.0)):
+        t = np.arange(n, dtype=np.float64) / 48000.0
+        x = np.exp(-t * 14.0) * (0.7 * np.sin(2 * np.pi * f0 * t) + 0.4 * rng.standard_normal(n))
+        out.append((x / np.abs(x).max()).astype(np.float32))
+    return out
+
+
+def golden_long_clip() -> np.ndarray:
+    """One clip longer than 10 s (521 337 samples): a periodic burst pattern, so that the three crops and the shrunk mel differ."""
+    n = 521337
+    rng = np.random.default_rng(78)
+    t = np.arange(n, dtype=np.float64) / 48000.0
+    x = np.exp(-(t % 0.73) * 7.0) * (0.6 * np.sin(2 * np.pi * (140.0 + 35.0 * t) * t) + 0.3 * rng.standard_normal(n))
+    return (x / np.abs(x).max()).astype(np.float32)
+
+
+def weights_checksum(model) -> np.ndarray:
+    """float64 [sum, sum of squares] over every audio-tower and projection parameter / buffer, in state-dict order."""
+    s = s2 = 0.0
+    for k, v in model.state_dict().items():
+        if k.startswith(("audio_model.", "audio_projection.")) and v.dtype.is_floating_point:
+            d = v.double()
+            s += float(d.sum())
+            s2 += float((d * d).sum())
+    return np.array([s, s2], dtype=np.float64)

@@ -52,6 +52,13 @@ def test_train_line():
     e = d["e2e"]
     assert e["unit"] == "clips/s" and e["value"] > 0 and 0.5 < e["ratio_to_value"] < 1.5
     assert "cpu_baseline" not in d
+    # the second half of BASELINE's metric rides in the default line: config[2], 512 clips per pass
+    c = d["clap"]
+    assert c["metric"] == "CLAP embeds/sec" and c["unit"] == "embeds/s" and c["config"]["workload"].startswith("clap config[2]")
+    assert abs(c["value"] - 512 * c["steps"] / (c["ms_per_step"] * c["steps"] * 1e-3)) / c["value"] < 1e-6 and c["value"] > 1000
+    cr = c["roofline"]
+    assert cr["bound"] == "mfma" and abs(cr["frac"] - cr["achieved"] / cr["peak"]) < 1e-9 and 0.0 < cr["frac"] < 1.0
+    assert "cpu_baseline" not in c                       # --no-cpu-baseline covers both legs
 
 
 def test_logmel_line_with_cpu_baseline():
@@ -72,7 +79,7 @@ def test_torchrun_one_rank_runs_the_rccl_path():
         env.pop(k, None)
     out = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=1", "--master-addr", "127.0.0.1",
                           "--master-port", str(port), os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "3", "--warmup", "1",
-                          "--no-cpu-baseline", "--no-e2e"], cwd=ROOT, env=env, capture_output=True, text=True, timeout=900)
+                          "--no-cpu-baseline", "--no-e2e", "--no-clap"], cwd=ROOT, env=env, capture_output=True, text=True, timeout=900)
     assert out.returncode == 0, out.stderr[-3000:]
     lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
     assert len(lines) == 1, out.stdout[-2000:]
@@ -86,7 +93,8 @@ def test_torchrun_one_rank_runs_the_rccl_path():
 
 
 def test_train_line_with_the_back_to_back_loop():
-    d = run_bench("--steps", "2", "--warmup", "1", "--no-cpu-baseline", "--no-e2e", "--roofline-loop")
+    d = run_bench("--steps", "2", "--warmup", "1", "--no-cpu-baseline", "--no-e2e", "--no-clap", "--roofline-loop")
+    assert "clap" not in d
     r = d["roofline"]
     assert r["timed"].startswith("8 launches inside the timed steps")
     b = r["back_to_back"]

@@ -324,3 +324,39 @@ def test_bilinear_resize_is_torch_interpolate(h_in, w_in, h_out, w_out):
     assert (out.cpu() - ref).abs().max() <= 1e-6 * max(1.0, ref.abs().max().item())
     with pytest.raises(_ffi.AdtError):
         _ffi.call("adt_bilinear_resize_f32", _ffi.dptr(x), 0, w_in, x.stride(0), _ffi.dptr(out), h_out, w_out, w_out, _ffi.current_stream())
+
+
+def test_wrapper_matches_the_references_own_clapwrapper_g7(golden_dir):
+    """G7 (tests/golden/clap.npz): ``ClapWrapper.get_audio_features`` of the REFERENCE (modules/clap_encoder.py:21-54, run by
+    tools/make_golden.py with ``__init__`` bypassed) on seeded random-init weights; this repository's wrapper gets the same clips, the same
+    numpy seed (its feature path draws the extractor's random ``is_longer`` flag / crop offsets in the same order) and the same weights.
+    bf16 operands: unit embeddings cosine >= 0.9995 and 1.5e-2 per component; pooled 3e-2 of max."""
+    from adt_str_amd.clap_encoder import ClapWrapper
+    from tests.test_oracle_golden import _g7_cases
+    g = np.load(os.path.join(golden_dir, "clap.npz"))
+    model = o_clap.random_clap_model(int(g["model_seed"]))
+    assert np.allclose(o_clap.weights_checksum(model), g["weights_checksum"], rtol=1e-12)
+    w = ClapWrapper("unused", DEV, 48000, clap_model=model)
+    for case, clips in _g7_cases(g).items():
+        ref = torch.from_numpy(g[f"{case}_embedding"])
+        audios = [torch.from_numpy(c).unsqueeze(0) for c in clips]
+        np.random.seed(int(g[f"{case}_np_seed"]))
+        emb = w.get_audio_features(audios).cpu()                                   # flags drawn like the extractor does
+        cos = (emb * ref).sum(-1)
+        assert emb.shape == ref.shape and cos.min() > 0.9995, (case, cos)
+        assert (emb - ref).abs().max() < 1.5e-2
+        emb2 = w.get_audio_features(audios, is_longer=torch.from_numpy(g[f"{case}_is_longer"]).reshape(-1)).cpu() if case == "a" else emb
+        assert ((emb2 * ref).sum(-1)).min() > 0.9995                               # and with the recorded flags handed over
+        # features of the K9 front end against the stored slices of the reference's input_features (dB scale, 5e-3 like the long-clip test)
+        np.random.seed(int(g[f"{case}_np_seed"]))
+        if case == "b":
+            feats, longer = w.features.features([a.reshape(-1) for a in audios])
+            assert longer.tolist() == g["b_is_longer"].ravel().tolist()
+            f = feats.cpu().numpy()
+            assert np.abs(f[:, 0, ::8] - g["b_feat_ch0_every8"]).max() < 5e-3 and np.abs(f[:, 3, ::8] - g["b_feat_ch3_every8"]).max() < 5e-3
+        else:
+            mel = w.features.mel([a.reshape(-1) for a in audios]).cpu().numpy()
+            assert np.abs(mel[:, ::8] - g["a_feat_ch0_every8"]).max() < 5e-3
+    mel = w.features.mel([torch.from_numpy(c) for c in _g7_cases(g)["a"]])
+    out = w.encoder.forward(mel, torch.from_numpy(g["a_is_longer"]).reshape(-1))
+    assert (out["pooled"].cpu() - torch.from_numpy(g["a_pooled"])).abs().max() < 3e-2 * np.abs(g["a_pooled"]).max()

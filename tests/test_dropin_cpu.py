@@ -97,3 +97,15 @@ def test_chunking_matches_reference_rule():
     c = _chunk_audio(torch.arange(10.0), 4)
     assert c.shape == (3, 4) and c[2].tolist() == [8.0, 9.0, 0.0, 0.0]
     assert _chunk_audio(torch.arange(8.0), 4).shape == (2, 4)
+
+
+def test_inference_cli_accepts_the_references_flag_spellings():
+    """reference inference.py:52-68: ``input_path config_path [-o | --output_path DIR] [-s | --synthetise_transcription]``, default
+    output directory ``outputs/``."""
+    from inference import _parser
+    a = _parser().parse_args(["in.wav", "cfg.yaml", "--output_path", "o", "--synthetise_transcription"])
+    assert (a.input_path, a.config_path, a.output_dir, a.synthesize) == ("in.wav", "cfg.yaml", "o", True)
+    b = _parser().parse_args(["in.wav", "cfg.yaml", "-o", "p", "-s"])
+    assert (b.output_dir, b.synthesize) == ("p", True)
+    c = _parser().parse_args(["in.wav", "cfg.yaml"])
+    assert (c.output_dir, c.synthesize) == ("outputs/", False)

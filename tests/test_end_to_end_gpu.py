@@ -143,7 +143,7 @@ def test_inference_cli_writes_parsable_midi(tmp_path):
     from adt_str_amd.resample import Resample
     clip22 = Resample(SR, 22050)(torch.from_numpy(clip).cuda()).cpu().numpy()
     write_wav(str(tmp_path / "clip22.wav"), clip22, 22050)
-    r = subprocess.run([sys.executable, os.path.join(ROOT, "inference.py"), str(tmp_path / "clip22.wav"), cfg_path, "-o", str(tmp_path / "out")],
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "inference.py"), str(tmp_path / "clip22.wav"), cfg_path, "--output_path", str(tmp_path / "out")],
                        capture_output=True, text=True, env=env, timeout=600)
     assert r.returncode == 0, r.stderr[-2000:]
     _parse_midi_note_ons(str(tmp_path / "out" / "clip22.mid"))

@@ -96,3 +96,31 @@ def test_logmel_oracle_end_to_end_against_hf_audio_utils():
             # fp32 torch.stft + fp32 filterbank vs float64: 1.3e-5 on the filterbank weights, amplified by the log only where a band
             # is near silence; on the [0, 1] output the two agree to 2e-4 everywhere and 2e-5 in the mean
             assert np.abs(got - ref).max() < 2e-4 and np.abs(got - ref).mean() < 2e-5, (sr, np.abs(got - ref).max())
+
+
+def _g7_cases(g):
+    from oracle import clap as o_clap
+    shorts = o_clap.golden_short_clips()
+    for i, c in enumerate(shorts):                               # the stored inputs ARE the recipe's output (the long clip travels as its recipe)
+        assert np.array_equal(c, g[f"a_clip{i}"])
+    return {"a": shorts, "b": [shorts[1], o_clap.golden_long_clip()]}
+
+
+def test_clap_oracle_reproduces_the_references_wrapper(golden_dir):
+    """G7: oracle/clap.py (features -> audio_embeddings) against what the reference's own ``ClapWrapper.get_audio_features`` returned
+    (modules/clap_encoder.py:21-54, captured by tools/make_golden.py:g7_clap) for the same clips, numpy seed and seeded weights."""
+    from oracle import clap as o_clap
+    g = np.load(os.path.join(golden_dir, "clap.npz"))
+    model = o_clap.random_clap_model(int(g["model_seed"]))
+    assert np.allclose(o_clap.weights_checksum(model), g["weights_checksum"], rtol=1e-12), "seeded ClapModel differs from the golden run's"
+    for case, clips in _g7_cases(g).items():
+        assert [len(c) for c in clips] == g[f"{case}_lengths"].tolist()
+        np.random.seed(int(g[f"{case}_np_seed"]))
+        feats, longer = o_clap.features(clips)
+        assert np.array_equal(longer, g[f"{case}_is_longer"])
+        assert np.array_equal(feats[:, 0, ::8], g[f"{case}_feat_ch0_every8"]) and np.array_equal(feats[:, 3, ::8], g[f"{case}_feat_ch3_every8"])
+        assert np.allclose(feats.astype(np.float64).sum(axis=(2, 3)), g[f"{case}_feat_sum"], rtol=1e-12)
+        out = o_clap.audio_embeddings(model, torch.from_numpy(feats), torch.from_numpy(longer))
+        assert np.abs(out["pooled"].numpy() - g[f"{case}_pooled"]).max() <= 1e-5 * np.abs(g[f"{case}_pooled"]).max()
+        assert np.abs(out["embedding"].numpy() - g[f"{case}_embedding"]).max() < 2e-6
+    assert g["a_is_longer"].sum() == 1 and g["b_is_longer"].ravel().tolist() == [False, True]

@@ -38,6 +38,7 @@ sys.path.insert(0, REPO)
 
 from oracle import logmel as o_logmel  # noqa: E402  (stand-in torchaudio reuses the restated STFT/fb)
 from oracle.bank import synthetic_bank  # noqa: E402
+from oracle import clap as o_clap  # noqa: E402  (seeded random-init ClapModel + the G7 input recipe shared with the tests)
 
 
 # --------------------------------------------------------------------------- stand-ins
@@ -509,6 +510,73 @@ def g8_curation():
     print("G8 curation: 3 cases")
 
 
+def g7_clap():
+    """G7: the reference's own ``ClapWrapper.get_audio_features`` / ``_get_audio_features`` (modules/clap_encoder.py:21-54)
+    on a random-init fused-HTSAT ``ClapModel``.  ``ClapWrapper.__init__`` needs the network (``from_pretrained``), so the instance is made
+    with ``__new__`` + ``nn.Module.__init__`` and given the attributes ``__init__`` would have set; the processor forwards to
+    ``ClapFeatureExtractor`` (what ``ClapProcessor`` does for ``audio=``).  Everything after that is the reference's code.
+
+    Case A: three short clips (the extractor then flags ONE random clip ``is_longer``: numpy's global RNG, seeded here).
+    Case B: a short clip and one longer than 10 s (three random crops + the shrunk mel; no forced flag).
+    Stored: the inputs (the long clip as its recipe, ``oracle.clap.golden_long_clip``), ``is_longer``, every 8th frame of channel 0 and 3
+    of ``input_features`` + per-clip sums, pooled [B, 768], embedding [B, 512], the numpy seeds and a checksum of the weights."""
+    from transformers import ClapFeatureExtractor
+    from modules.clap_encoder import ClapWrapper          # /root/reference/modules/clap_encoder.py
+    assert ClapWrapper.__module__ == "modules.clap_encoder" and sys.modules["modules.clap_encoder"].__file__.startswith(REF)
+    model = o_clap.random_clap_model(o_clap.GOLDEN_MODEL_SEED)
+
+    class _Processor:                                      # ClapProcessor(audio=...) == its feature extractor's __call__
+        def __init__(self):
+            self.fe = ClapFeatureExtractor()
+
+        def __call__(self, audio=None, return_tensors=None, sampling_rate=None, **kw):
+            return self.fe(audio, return_tensors=return_tensors, sampling_rate=sampling_rate, **kw)
+
+    w = ClapWrapper.__new__(ClapWrapper)
+    torch.nn.Module.__init__(w)
+    w.clap_model, w.device, w.sample_rate = model, torch.device("cpu"), 48000
+    w.config, w.text_model, w.audio_model = model.config, model.text_model, model.audio_model
+    w.processor = _Processor()
+    captured = {}
+    inner = w._get_audio_features
+
+    def spy(**inputs):
+        captured["input_features"] = inputs["input_features"].clone()
+        captured["is_longer"] = inputs["is_longer"].clone()
+        pooled = {}
+        h = model.audio_model.register_forward_hook(lambda m, a, o: pooled.__setitem__("p", o.pooler_output.clone()))
+        try:
+            out = inner(**inputs)
+        finally:
+            h.remove()
+        captured["pooled"] = pooled["p"]
+        return out
+
+    w._get_audio_features = spy
+    out = {"model_seed": np.int64(o_clap.GOLDEN_MODEL_SEED), "weights_checksum": o_clap.weights_checksum(model)}
+    for case, (clips, np_seed) in {"a": (o_clap.golden_short_clips(), 11), "b": ([o_clap.golden_short_clips()[1], o_clap.golden_long_clip()], 12)}.items():
+        np.random.seed(np_seed)
+        with torch.no_grad():
+            emb = w.get_audio_features([torch.from_numpy(c).unsqueeze(0) for c in clips])
+        f = captured["input_features"].numpy()
+        out[f"{case}_np_seed"] = np.int64(np_seed)
+        out[f"{case}_n"] = np.int64(len(clips))
+        out[f"{case}_lengths"] = np.array([len(c) for c in clips], dtype=np.int64)
+        if case == "a":
+            for i, c in enumerate(clips):
+                out[f"a_clip{i}"] = c
+        out[f"{case}_is_longer"] = captured["is_longer"].numpy()
+        out[f"{case}_feat_ch0_every8"] = f[:, 0, ::8].copy()
+        out[f"{case}_feat_ch3_every8"] = f[:, 3, ::8].copy()
+        out[f"{case}_feat_sum"] = f.astype(np.float64).sum(axis=(2, 3))
+        out[f"{case}_pooled"] = captured["pooled"].numpy()
+        out[f"{case}_embedding"] = emb.numpy()
+        assert emb.shape == (len(clips), 512) and np.allclose(np.linalg.norm(emb.numpy(), axis=-1), 1.0, atol=1e-5)
+    np.savez_compressed(os.path.join(OUT, "clap.npz"), **out)
+    print("G7 clap: is_longer a", out["a_is_longer"].ravel().tolist(), "b", out["b_is_longer"].ravel().tolist(),
+          "bytes", os.path.getsize(os.path.join(OUT, "clap.npz")))
+
+
 def main():
     os.makedirs(OUT, exist_ok=True)
     torch.set_num_threads(8)
@@ -532,6 +600,7 @@ def main():
     g6_adt_full(model_mod)
     g8_curation()
     g9_fx_params()
+    g7_clap()
 
 
 if __name__ == "__main__":

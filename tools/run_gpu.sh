@@ -8,6 +8,6 @@ if [ "$2" = "pytest" ]; then
 fi
 timeout 900 python bench.py --steps 10 --warmup 3 > gpurun_out/bench_$TAG.log 2>&1; tail -3 gpurun_out/bench_$TAG.log | cut -c1-2500
 cd /tmp && export TMPDIR=/tmp
-timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/prof_$TAG -- python3 $R/bench.py --steps 5 --warmup 2 --no-cpu-baseline > $R/gpurun_out/prof_$TAG.log 2>&1
+timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/prof_$TAG -- python3 $R/bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-clap > $R/gpurun_out/prof_$TAG.log 2>&1
 tail -2 $R/gpurun_out/prof_$TAG.log | cut -c1-300
 cat $R/gpurun_out/prof_$TAG/*/*kernel_stats.csv | head -30

@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Every launch of ONE training step in order, from a rocprofv3 kernel trace:
-    rocprofv3 --kernel-trace --output-format csv -d <dir> -- python3 bench.py --steps 4 --warmup 2 --no-cpu-baseline --no-e2e
+    rocprofv3 --kernel-trace --output-format csv -d <dir> -- python3 bench.py --steps 4 --warmup 2 --no-cpu-baseline --no-e2e --no-clap
     python tools/step_timeline.py <dir> [step [delimiter]]
 Steps are delimited by adamw_kernel launches (the roofline loops of bench.py run after the last one and are not part of any step);
 another delimiter kernel can be named (l2_normalize_kernel ends a forward of the CLAP tower: tools/prof_clap_forward.py).

@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Idle time between kernels of the training step, from a rocprofv3 kernel trace:
-    rocprofv3 --kernel-trace --output-format csv -d <dir> -- python3 bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-e2e
+    rocprofv3 --kernel-trace --output-format csv -d <dir> -- python3 bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-e2e --no-clap
     python tools/trace_gaps.py <dir>
 Steps are delimited by adamw_kernel launches; per step: wall time from the first kernel's start to the last kernel's end, the sum of
 kernel durations, the idle remainder and how it is distributed over gap sizes."""
