@@ -139,12 +139,27 @@ def lib_path() -> str:
     return _LIB_PATH
 
 
+# Entry points without device code (csrc/errors.cpp, csrc/wav_io.cpp).  ``ADT_HOST_ONLY_LIB=<path>`` makes ``load()`` bind THESE from a host-only
+# build of the same sources -- the AddressSanitizer harness of the CPU box (``make -C adt_str_amd/csrc asan``, tests/test_sanitize_cpu.py).
+# It is not a fallback: every other entry point is absent from such a library and calling one raises.
+HOST_ONLY = ("adt_version", "adt_last_error", "adt_wav_probe_batch", "adt_wav_decode_batch", "adt_copy_files")
+
+
 def load() -> C.CDLL:
     """Load (once) and return the library; raises if it has not been built."""
     global _lib
     if _lib is not None:
         return _lib
     with _lock:
+        if _lib is None and os.environ.get("ADT_HOST_ONLY_LIB"):
+            lib = C.CDLL(os.environ["ADT_HOST_ONLY_LIB"])
+            for name in HOST_ONLY:
+                fn = getattr(lib, name)
+                fn.argtypes = SIGNATURES[name]
+                fn.restype = _RESTYPES.get(name, C.c_int)
+            if lib.adt_version() != ABI_VERSION:
+                raise RuntimeError("host-only library has another ABI version; rebuild it (make -C adt_str_amd/csrc asan)")
+            _lib = lib
         if _lib is None:
             if not os.path.exists(_LIB_PATH):
                 raise RuntimeError(

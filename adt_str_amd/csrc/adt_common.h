@@ -8,6 +8,7 @@ namespace adt {
 
 // Records `msg` as this thread's last error and returns `code` (see adt_last_error()).
 int set_error(int code, const char* msg);
+char* error_buffer(size_t* size);          // this thread's message buffer (errors.cpp)
 int set_hip_error(hipError_t e, const char* what);
 // Number of compute units of the current device (cached per device).
 int device_cu_count(int* n_cu);

@@ -1,4 +1,4 @@
-// common.hip -- version, thread-local error string, device queries.
+// common.hip -- HIP error plumbing, device queries, the persistent kernels' work counters.
 #include <cstdio>
 #include <cstring>
 #include <map>
@@ -9,15 +9,11 @@
 
 namespace adt {
 
-static thread_local char g_err[512] = "";
-
-int set_error(int code, const char* msg) {
-  std::snprintf(g_err, sizeof(g_err), "%s", msg);
-  return code;
-}
-
+// set_error / adt_last_error / adt_version live in errors.cpp (host-only translation unit, shared with the sanitizer build)
 int set_hip_error(hipError_t e, const char* what) {
-  std::snprintf(g_err, sizeof(g_err), "HIP error %d (%s) in %s", static_cast<int>(e), hipGetErrorString(e), what);
+  size_t n = 0;
+  char* buf = error_buffer(&n);
+  std::snprintf(buf, n, "HIP error %d (%s) in %s", static_cast<int>(e), hipGetErrorString(e), what);
   (void)hipGetLastError();   // clear the sticky error so the next call starts clean
   return ADT_EHIP;
 }
@@ -67,9 +63,6 @@ int sched_counters(void* stream, unsigned** counters) {
 }
 
 }  // namespace adt
-
-extern "C" int adt_version(void) { return 15; }
-extern "C" const char* adt_last_error(void) { return adt::g_err; }
 
 extern "C" int adt_debug_occupy(int32_t n_wg, int32_t lds_bytes, int32_t micros, void* stream) {
   using namespace adt;

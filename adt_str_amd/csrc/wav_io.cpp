@@ -187,6 +187,7 @@ int copy_one(const char* src, const char* dst) {
     if (r == 0) break;
     left -= r;
   }
+  if (!fallback && left > 0) return ADT_EINVAL;                         // the source shrank under the copy: a short file is not a copy
   if (fallback) {                                                       // file systems without copy_file_range (cross-device on old kernels)
     if (lseek(in.fd, 0, SEEK_SET) < 0 || lseek(out.fd, 0, SEEK_SET) < 0 || ftruncate(out.fd, 0) != 0) return ADT_EINVAL;
     std::vector<char> buf(1 << 20);
@@ -202,9 +203,8 @@ int copy_one(const char* src, const char* dst) {
       }
     }
   }
-  fchmod(out.fd, st.st_mode & 07777);
   const struct timespec times[2] = {st.st_atim, st.st_mtim};
-  futimens(out.fd, times);
+  if (fchmod(out.fd, st.st_mode & 07777) != 0 || futimens(out.fd, times) != 0) return ADT_EINVAL;   // copy2 raises on these too
   return ADT_OK;
 }
 
@@ -212,7 +212,9 @@ int copy_one(const char* src, const char* dst) {
 
 extern "C" int adt_wav_probe_batch(const char* const* paths, int32_t n, int32_t threads, adt_wav_info* info) {
   if (n < 0 || (n > 0 && (!paths || !info))) return set_error(ADT_EINVAL, "adt_wav_probe_batch: null pointer");
-  parallel_for(n, threads, [&](int i) { probe_one(paths[i], &info[i]); });
+  parallel_for(n, threads, [&](int i) {
+    try { probe_one(paths[i], &info[i]); } catch (...) { info[i].status = ADT_EINVAL; }      // an exception in a worker thread would end the process
+  });
   return ADT_OK;
 }
 
@@ -224,7 +226,13 @@ extern "C" int adt_wav_decode_batch(const char* const* paths, int32_t n, int32_t
   parallel_for(n, threads, [&](int i) {
     thread_local std::vector<unsigned char> scratch;
     if (info[i].status != ADT_OK) { if (peaks) peaks[i] = 0.f; return; }
-    const int rc = decode_one(paths[i], info[i], flags, out + offsets[i], peaks ? &peaks[i] : nullptr, scratch);
+    int rc;
+    try {
+      rc = decode_one(paths[i], info[i], flags, out + offsets[i], peaks ? &peaks[i] : nullptr, scratch);
+    } catch (...) {                                                     // std::bad_alloc from the scratch buffer of a huge data chunk: this file fails, not the run
+      rc = ADT_EINVAL;
+      if (peaks) peaks[i] = 0.f;
+    }
     if (rc != ADT_OK) info[i].status = rc;                              // the file changed or vanished since the probe
   });
   return ADT_OK;
@@ -232,6 +240,8 @@ extern "C" int adt_wav_decode_batch(const char* const* paths, int32_t n, int32_t
 
 extern "C" int adt_copy_files(const char* const* src, const char* const* dst, int32_t n, int32_t threads, int32_t* status) {
   if (n < 0 || (n > 0 && (!src || !dst || !status))) return set_error(ADT_EINVAL, "adt_copy_files: null pointer");
-  parallel_for(n, threads, [&](int i) { status[i] = copy_one(src[i], dst[i]); });
+  parallel_for(n, threads, [&](int i) {
+    try { status[i] = copy_one(src[i], dst[i]); } catch (...) { status[i] = ADT_EINVAL; }
+  });
   return ADT_OK;
 }

@@ -218,7 +218,18 @@ class _Engine:
                     for l, y, yt in zip(lins, self._cast_table.y, self._cast_table.y_t):
                         l.w16, l.wt16 = y, yt
                 self._cast_table.run()
+            self._kv_cat = None                           # concatenated cross-attention K|V operands follow the weights
             self._versions = tuple(p._version for p in self.named.values()) + (ver[-1],)
+
+    def _kv_operands(self):
+        """The cross-attention K | V projection weights of ALL decoder layers as one operand: (W [layers*2d, d] bf16, bias [layers*2d] fp32,
+        W^T arranged [d, layers*2d] bf16 for the memory gradient).  Built once per weight refresh (the bf16 copies only change there), not per
+        step / micro-batch."""
+        if getattr(self, "_kv_cat", None) is None:
+            d = self.d
+            self._kv_cat = (torch.cat([L["ca"].w16[d:] for L in self.dec]), torch.cat([L["ca"].b[d:] for L in self.dec]),
+                            torch.cat([L["ca"].wt16[:, d:] for L in self.dec], dim=1))
+        return self._kv_cat
 
     def grad_buffers(self):
         """One flat fp32 gradient buffer with a view per parameter, in parameter order."""
@@ -346,8 +357,7 @@ class _Engine:
         # with K = layers * 2d instead of a chain of GEMMs that each re-read and re-write the fp32 [B*S, d] accumulator.
         kv_all = None
         if not self.fp32 and len(self.dec) > 1 and not os.environ.get("ADT_NO_KV_BATCH"):
-            wkv = torch.cat([L["ca"].w16[d:] for L in self.dec])
-            bkv = torch.cat([L["ca"].b[d:] for L in self.dec])
+            wkv, bkv, _ = self._kv_operands()
             kv_all = K.gemm(mem16, wkv, bias=bkv)
         lean = self._lean_ln()
         res = dict(residual=x32)
@@ -479,7 +489,7 @@ class _Engine:
             dx32 = self._dgrad(dqkv, L["sa"], residual=dy1_32, out_dtype=F32)
             self._flush_reductions()
         if dkv_all is not None:
-            dmem32 = K.gemm(dkv_all, torch.cat([L["ca"].wt16[:, d:] for L in self.dec], dim=1), out_dtype=F32)
+            dmem32 = K.gemm(dkv_all, self._kv_operands()[2], out_dtype=F32)
         K.embed_bwd(tgt, dx32, math.sqrt(d), G["decoder.tgt_tok_emb.embedding.weight"], drop=self.D("dec.emb"), f32=self.fp32)
         self._flush_wgrads()
         self._ready("decoder.")

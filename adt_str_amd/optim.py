@@ -10,9 +10,9 @@ moments (so ``state_dict`` / ``load_state_dict`` and HF checkpoints work), reads
 and leaves gradient clipping to the Trainer (``accelerator.clip_grad_norm_`` scales ``p.grad`` in place before ``step``).
 
 The gradients: the autograd bridge (network._ADTLossFn.backward) hands every parameter a view of ONE fresh buffer in parameter order;
-accumulation, clipping and DDP's copy-back all work in place on those views, so ``step`` normally finds the flat gradient as the
-views' common base and launches on it directly.  Anything else (a gradient that is missing, foreign or re-allocated) is gathered into a
-scratch buffer first -- correct, one extra pass.
+accumulation, clipping and DDP's copy-back all work in place on those views, so ``step`` normally finds them still laid out as one flat
+buffer (checked by address: autograd keeps ``grad.detach()``, which has no ``_base``) and launches on it directly.  Anything else (a
+gradient that is foreign or re-allocated) is gathered into a scratch buffer first -- correct, one extra pass.
 """
 from __future__ import annotations
 
@@ -76,20 +76,25 @@ class FusedAdamW(torch.optim.Optimizer):
             self.state[p] = {"step": step.clone(), "exp_avg": self._m[o:o + p.numel()].view_as(p), "exp_avg_sq": self._v[o:o + p.numel()].view_as(p)}
 
     def _flat_grad(self) -> torch.Tensor:
-        """The gradients as one flat buffer in parameter order: the common base of the views the autograd bridge handed out when they
-        are still exactly that, else gathered (missing gradients count as zero, like a skipped parameter would not: torch skips the
-        update, so a model with unused parameters should use torch's optimizer)."""
+        """The gradients as one flat buffer in parameter order.  The autograd bridge hands out views of one fresh buffer, but autograd
+        stores ``grad.detach()`` (no ``_base``), so the buffer is recognised by ADDRESS: when every ``p.grad`` is a contiguous fp32 tensor
+        in the same storage at ``first + 4 * offset`` the flat tensor is rebuilt over that storage and the kernel runs on it directly (no
+        copy, no second buffer: ``self._gather`` stays None).  Anything else is gathered (missing gradients are an error: torch would
+        skip the update, so a model with unused parameters should use torch's optimizer)."""
         g0 = self._params[0].grad
-        base = getattr(g0, "_base", None) if g0 is not None else None
-        if base is not None and base.dtype == torch.float32 and base.is_contiguous() and base.numel() == self._flat.numel():
-            ptr, ok = base.data_ptr(), True
-            for p, o in zip(self._params, self._off):
-                g = p.grad
-                if g is None or g._base is not base or g.data_ptr() != ptr + 4 * o or not g.is_contiguous():
-                    ok = False
-                    break
-            if ok:
-                return base.reshape(-1)
+        n = self._flat.numel()
+        if g0 is not None and g0.dtype == torch.float32 and g0.is_contiguous() and g0.device == self._flat.device:
+            st, ptr = g0.untyped_storage(), g0.data_ptr()
+            if st.nbytes() >= 4 * (g0.storage_offset() + n):
+                sp, ok = st.data_ptr(), True
+                for p, o in zip(self._params, self._off):
+                    g = p.grad
+                    if (g is None or g.dtype != torch.float32 or g.data_ptr() != ptr + 4 * o or not g.is_contiguous()
+                            or g.untyped_storage().data_ptr() != sp):
+                        ok = False
+                        break
+                if ok:
+                    return torch.empty(0, dtype=torch.float32, device=g0.device).set_(st, g0.storage_offset(), (n,), (1,))
         if any(p.grad is None for p in self._params):
             raise RuntimeError("FusedAdamW: every parameter needs a gradient (the ADT engine produces all of them in one backward pass)")
         if self._gather is None:

@@ -27,6 +27,7 @@ import random
 import re
 import shutil
 import threading
+import time
 import warnings
 from typing import Callable, Optional
 
@@ -395,9 +396,17 @@ def save_model(model: nn.Module, directory: str):
 def _prune_checkpoints(output_dir: str, keep: Optional[int], just_written: str):
     """``save_total_limit``: remove the oldest checkpoints beyond ``keep`` -- never the one just written, whatever stale
     higher-numbered directories a previous run left behind."""
+    just = os.path.abspath(just_written)
+    # directories a killed run left without their marker are invisible to _checkpoint_dirs and would never be rotated out: remove the
+    # ones OLDER (lower step) than the checkpoint just completed (a higher-numbered one may be the next checkpoint, which other ranks
+    # are already writing their RNG files into while this one's background write finishes)
+    mj = re.fullmatch(r"checkpoint-(\d+)", os.path.basename(just))
+    for d in glob.glob(os.path.join(output_dir, "checkpoint-*")):
+        m = re.fullmatch(r"checkpoint-(\d+)", os.path.basename(d))
+        if m and mj and int(m.group(1)) < int(mj.group(1)) and not os.path.exists(os.path.join(d, "trainer_state.pt")):
+            shutil.rmtree(d, ignore_errors=True)
     if not keep:
         return
-    just = os.path.abspath(just_written)
     others = [d for d in _checkpoint_dirs(output_dir) if os.path.abspath(d) != just]
     others.sort(key=lambda d: os.path.getmtime(os.path.join(d, "trainer_state.pt")))
     for old in others[:max(0, len(others) - (keep - 1))]:
@@ -469,14 +478,17 @@ def save_checkpoint(output_dir: str, model: nn.Module, trainer, progress: dict, 
     d = os.path.join(output_dir, f"checkpoint-{trainer.step_no}")
     os.makedirs(d, exist_ok=True)
     if rng_state is not None:
-        torch.save({"python": rng_state[0], "torch": rng_state[1]}, os.path.join(d, f"rng_state_{rank}.pth"))
+        rp = os.path.join(d, f"rng_state_{rank}.pth")
+        torch.save({"python": rng_state[0], "torch": rng_state[1]}, rp + ".tmp")
+        os.replace(rp + ".tmp", rp)                         # a file that exists is complete: rank 0 waits for all of them before the marker
     if rank != 0:
         return d
+    rng_files = world if rng_state is not None else 0
     cfg = getattr(model, "config", None)
     flat = getattr(trainer, "pflat", None)
     if writer is None or flat is None or not flat.is_cuda or not hasattr(trainer, "state_dict_meta"):
         state = {k: v.detach().to("cpu").contiguous().clone() for k, v in model.state_dict().items()}
-        _finish_checkpoint(d, state, cfg, trainer.state_dict(), progress, world, output_dir, keep)
+        _finish_checkpoint(d, state, cfg, trainer.state_dict(), progress, world, output_dir, keep, rng_files)
         return d
     meta = trainer.state_dict_meta()
     snap, m_dev, v_dev = _device_snapshot(model, trainer)
@@ -492,23 +504,38 @@ def save_checkpoint(output_dir: str, model: nn.Module, trainer, progress: dict, 
             m_h = torch.empty(m_dev.shape, dtype=m_dev.dtype, pin_memory=True).copy_(m_dev, non_blocking=True)
             v_h = torch.empty(v_dev.shape, dtype=v_dev.dtype, pin_memory=True).copy_(v_dev, non_blocking=True)
             side.synchronize()
-        _finish_checkpoint(d, {k: t.contiguous() for k, t in host.items()}, cfg, dict(meta, m=m_h, v=v_h), progress, world, output_dir, keep)
+        _finish_checkpoint(d, {k: t.contiguous() for k, t in host.items()}, cfg, dict(meta, m=m_h, v=v_h), progress, world, output_dir, keep, rng_files)
 
     writer.submit(job)
     return d
 
 
-def _finish_checkpoint(d, state, cfg, tstate, progress, world, output_dir, keep):
+RNG_FILE_WAIT_S = 120.0
+
+
+def _finish_checkpoint(d, state, cfg, tstate, progress, world, output_dir, keep, rng_files=0):
     _write_model_files(state, cfg, d)
+    # ``trainer_state.pt`` marks the checkpoint complete, so it is only written once every rank's host RNG file is there (the ranks write
+    # them on their own, without a barrier: a rank that died or lags must not leave a "complete" checkpoint that resumes on another data stream)
+    deadline = time.monotonic() + RNG_FILE_WAIT_S
+    while True:
+        absent = [r for r in range(rng_files) if not os.path.exists(os.path.join(d, f"rng_state_{r}.pth"))]
+        if not absent:
+            break
+        if time.monotonic() > deadline:
+            raise RuntimeError(f"checkpoint {d}: rng_state files of ranks {absent} did not appear within {RNG_FILE_WAIT_S:.0f} s; the checkpoint "
+                               "is left without trainer_state.pt (incomplete) and will not be resumed from")
+        time.sleep(0.02)
     tmp = os.path.join(d, "trainer_state.pt.tmp")
-    torch.save({"trainer": tstate, "progress": dict(progress), "world": world}, tmp)
+    torch.save({"trainer": tstate, "progress": dict(progress), "world": world, "rng_files": rng_files}, tmp)
     os.replace(tmp, os.path.join(d, "trainer_state.pt"))
     _prune_checkpoints(output_dir, keep, d)
 
 
-def load_checkpoint(directory: str, model: nn.Module, trainer, rank: int = 0, world: int = 1) -> dict:
+def load_checkpoint(directory: str, model: nn.Module, trainer, rank: int = 0, world: int = 1, allow_missing_rng: Optional[bool] = None) -> dict:
     """Restore weights (in place: the flat parameter buffer keeps its views), optimizer state and this rank's host RNG state.
-    Returns the saved progress dict."""
+    Returns the saved progress dict.  A checkpoint that recorded RNG files for every rank refuses to resume a rank whose file is gone
+    (the run would silently leave the interrupted run's data stream) unless ``allow_missing_rng`` / ``ADT_ALLOW_MISSING_RNG=1``."""
     from safetensors.torch import load_file
     st = torch.load(os.path.join(directory, "trainer_state.pt"), map_location="cpu", weights_only=False)
     if st.get("world", 1) != world:
@@ -529,18 +556,28 @@ def load_checkpoint(directory: str, model: nn.Module, trainer, rank: int = 0, wo
         random.setstate(r["python"])
         torch.set_rng_state(r["torch"])
     else:
+        if allow_missing_rng is None:
+            allow_missing_rng = os.environ.get("ADT_ALLOW_MISSING_RNG") == "1"
+        if st.get("rng_files", 0) > rank and not allow_missing_rng:
+            raise FileNotFoundError(f"{rp} is missing although the checkpoint recorded one for each of its {st['rng_files']} ranks: rank {rank} "
+                                    "would resume on a different data stream (set ADT_ALLOW_MISSING_RNG=1 to accept that)")
         warnings.warn(f"{rp} is missing: rank {rank} resumes with a fresh host RNG state, so its data stream (random velocities, "
                       "timbre / mix-up / FX draws) will not repeat the interrupted run's")
     return st["progress"]
 
 
 class _LossLog:
-    """``logging_steps`` without a host stall: the loss is copied to pinned memory asynchronously and printed once it has landed."""
+    """``logging_steps`` without a host stall: the loss is copied to pinned memory asynchronously and printed once it has landed.  The line
+    also carries the step time and the whole-job clips/s since the previously logged step (the reference logs through HF's
+    ``logging_steps: 1``, train.py:144-152; throughput is this build's addition), measured between timing events on the step's stream on
+    the GPU (host clock for CPU tensors) -- never by synchronising."""
 
-    def __init__(self, every: int, rank: int, total: int, sink: Callable[[str], None] = print):
-        self.every, self.rank, self.total, self.sink = every, rank, total, sink
+    def __init__(self, every: int, rank: int, total: int, sink: Callable[[str], None] = print, clips_per_step: int = 0):
+        self.every, self.rank, self.total, self.sink, self.clips_per_step = every, rank, total, sink, clips_per_step
         self.pending = collections.deque()
         self.history = []                       # (step, loss) as printed
+        self.rates = []                         # (step, ms per step, clips/s) as printed
+        self._prev = None                       # (step, event or host seconds) of the previously logged step
 
     def push(self, step: int, epoch: int, loss: torch.Tensor, lr: float):
         if not self.every or self.rank != 0 or step % self.every:
@@ -548,20 +585,29 @@ class _LossLog:
         if loss.is_cuda:
             host = torch.empty((), dtype=torch.float32, pin_memory=True)
             host.copy_(loss.detach().reshape(()), non_blocking=True)
-            ev = torch.cuda.Event()
+            ev = torch.cuda.Event(enable_timing=True)
             ev.record()
+            mark = ev
         else:
-            host, ev = loss.detach().reshape(()).float().clone(), None
-        self.pending.append((step, epoch, host, lr, ev))
+            host, ev, mark = loss.detach().reshape(()).float().clone(), None, time.perf_counter()
+        self.pending.append((step, epoch, host, lr, ev, self._prev, mark))
+        self._prev = (step, mark)
         self.drain(False)
 
     def drain(self, block: bool = True):
         while self.pending and (block or self.pending[0][4] is None or self.pending[0][4].query()):
-            step, epoch, host, lr, ev = self.pending.popleft()
+            step, epoch, host, lr, ev, prev, mark = self.pending.popleft()
             if ev is not None:
                 ev.synchronize()
             self.history.append((step, float(host)))
-            self.sink(f"epoch {epoch} step {step}/{self.total} loss {float(host):.4f} lr {lr:.3e}")
+            rate = ""
+            if prev is not None and step > prev[0] and type(prev[1]) is type(mark):
+                ms = (prev[1].elapsed_time(mark) if ev is not None else (mark - prev[1]) * 1e3) / (step - prev[0])
+                if ms > 0:
+                    cps = self.clips_per_step / (ms * 1e-3)
+                    self.rates.append((step, ms, cps))
+                    rate = f" step_ms {ms:.2f} clips/s {cps:.1f}"
+            self.sink(f"epoch {epoch} step {step}/{self.total} loss {float(host):.4f} lr {lr:.3e}{rate}")
 
 
 def run_native_training(model, dataset, cfg: dict, trainer_factory: Optional[Callable] = None, prefetch_depth: int = 2):
@@ -600,7 +646,7 @@ def run_native_training(model, dataset, cfg: dict, trainer_factory: Optional[Cal
         start_epoch, start_micro = int(prog["epoch"]), int(prog["micro"])
         if rank == 0:
             print(f"resumed from {resume}: step {tr.step_no}, epoch {start_epoch}, micro-batch {start_micro}", flush=True)
-    log = _LossLog(lg.get("logging_steps") or 0, rank, total, lambda s: print(s, flush=True))
+    log = _LossLog(lg.get("logging_steps") or 0, rank, total, lambda s: print(s, flush=True), clips_per_step=bs * accum * world)
     order = list(range(len(dataset)))
 
     def run_epoch(epoch: int, first_micro: int):
@@ -635,4 +681,5 @@ def run_native_training(model, dataset, cfg: dict, trainer_factory: Optional[Cal
     if world > 1:
         dist.barrier()
     tr.loss_history = log.history
+    tr.rate_history = log.rates
     return tr

@@ -263,7 +263,10 @@ def train_flops_per_clip(F, T, d=768, ffn=3072, V=1400, n_mels=128, enc=4, dec=4
     return 6.0 * macs
 
 
-def train_setup(dev, seed, world, dropout, fx_prob=0.0, process_group=None, grad_compress=None):
+FP32_MFMA_PEAK_TF = 157.3                  # MI355X_MICROARCH.md: f32-input MFMA = the fp32 vector rate, 1/16 of bf16
+
+
+def train_setup(dev, seed, world, dropout, fx_prob=0.0, process_group=None, grad_compress=None, precision="bf16"):
     from adt_str_amd import kernels as K
     from adt_str_amd.bank import OneShotBank, synthetic_tree
     from adt_str_amd.network import ADTModel, ADTModelConfig
@@ -273,6 +276,8 @@ def train_setup(dev, seed, world, dropout, fx_prob=0.0, process_group=None, grad
     torch.manual_seed(0)                                   # same initial weights on every rank (then broadcast anyway)
     cfg = ADTModelConfig(input_sec=10.0, time_res=0.01, win_length=2048, sample_rate=sr, dropout=dropout, plain=True, **SETTING1)
     model = ADTModel(cfg).to(dev)
+    if precision != "bf16":
+        model.set_precision(precision)                    # the fp32-operand parity arm (csrc/precise.hip): logits within 1e-3 rel of the CPU reference
     trainer = FlatTrainer(model, lr=1e-4, weight_decay=1e-5, max_grad_norm=1.0, total_steps=10000, warmup_ratio=0.1,
                           process_group=process_group, grad_compress=grad_compress, comm_timing=True)
     bank = OneShotBank.from_tree(synthetic_tree(7, sr), sr)
@@ -340,7 +345,24 @@ def train_setup(dev, seed, world, dropout, fx_prob=0.0, process_group=None, grad
     def tap_on(on):
         K.gemm_tap = tap if on else None
 
+    def roofline_fp32():
+        # the parity arm launches no bf16 GEMM: its roofline line is the whole step against the f32-input MFMA peak (every product of the
+        # step runs on v_mfma_f32_32x32x2_f32 in precise.hip)
+        ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        ev0.record()
+        for _ in range(2):
+            step()
+        ev1.record()
+        torch.cuda.synchronize()
+        ms = ev0.elapsed_time(ev1) / 2
+        ach = flops_clip * B / (ms * 1e-3) / 1e12
+        return {"bound": "mfma", "achieved": ach, "peak": FP32_MFMA_PEAK_TF, "unit": "TFLOP/s", "frac": ach / FP32_MFMA_PEAK_TF, "traffic": None,
+                "kernel": "whole training step on the fp32-operand kernels (adt_gemm_f32 / adt_attn_fwd_f32 / adt_attn_bwd_f32, v_mfma_f32_32x32x2_f32)",
+                "kernel_ms": ms, "algorithmic_flops_per_launch": flops_clip * B}
+
     def roofline(loop=False):
+        if precision == "fp32":
+            return roofline_fp32()
         M, N, Kd = Mr, Nr, Kr
         torch.cuda.synchronize()
         in_step = sorted(e0.elapsed_time(e1) for e0, e1 in tap["events"])
@@ -420,12 +442,13 @@ def train_setup(dev, seed, world, dropout, fx_prob=0.0, process_group=None, grad
     def comm():
         return trainer.reducer.comm_stats() if trainer.reducer is not None else None
 
-    return {"step": step, "units": B, "dtype": "bf16", "roofline": roofline, "tap": tap_on, "cpu_baseline": cpu_baseline, "state": state,
+    return {"step": step, "units": B, "dtype": "bf16" if precision == "bf16" else "f32", "roofline": roofline, "tap": tap_on, "cpu_baseline": cpu_baseline, "state": state,
             "flops_per_step": flops_clip * B, "e2e": e2e, "comm": comm,
             "metric": "ADT training clips/sec (10 s @16 kHz)",
             "config": {"workload": "train config[3]: ADT train step, setting-1 network (69.0M params), per-GPU batch 64 x 10 s @ 16 kHz "
-                                   "mixer-rendered clips (F=%d frames), T=128 target tokens, bf16 GEMM/attention with fp32 accumulate, "
-                                   "AdamW + clip 1.0, dropout %.2f, use_fx_prob %.2f" % (F, dropout, fx_prob),
+                                   "mixer-rendered clips (F=%d frames), T=128 target tokens, %s, "
+                                   "AdamW + clip 1.0, dropout %.2f, use_fx_prob %.2f" % (F, "bf16 GEMM/attention with fp32 accumulate" if precision == "bf16" else
+                                   "fp32 operands everywhere (the parity arm that meets logits within 1e-3 rel of the CPU reference)", dropout, fx_prob),
                        "global_batch": B * world, "clips_per_gpu": B, "samples": L, "sample_rate": sr, "target_len": T}}
 
 
@@ -459,6 +482,8 @@ def main():
     ap.add_argument("--no-clap", action="store_true", help="train workload, N = 1: skip the CLAP embeds/sec leg (the \"clap\" object of the line)")
     ap.add_argument("--roofline-loop", action="store_true", help="train workload: also time the roofline kernel alone, back to back (the "
                                                                   "earlier rounds' measurement; adds 100 launches of it to a profile of this command)")
+    ap.add_argument("--precision", default="bf16", choices=["bf16", "fp32"], help="train workload: fp32 = the fp32-operand parity arm (precise.hip), the one "
+                                                                                   "that meets BASELINE's 1e-3 logits tolerance; ~20x slower, not the benchmarked default")
     ap.add_argument("--grad-compress", default=None, choices=["bf16"], help="send bf16 copies of the gradient segments (N > 1)")
     args = ap.parse_args()
 
@@ -489,7 +514,7 @@ def main():
             dist.init_process_group("nccl", device_id=dev)
     pg = dist.group.WORLD if dist.is_initialized() else None
 
-    wl = {"train": lambda: train_setup(dev, rank, world, args.dropout, args.fx_prob, pg, args.grad_compress), "logmel": lambda: logmel_setup(dev, rank),
+    wl = {"train": lambda: train_setup(dev, rank, world, args.dropout, args.fx_prob, pg, args.grad_compress, args.precision), "logmel": lambda: logmel_setup(dev, rank),
           "clap": lambda: clap_setup(dev, rank)}[args.workload]()
     step = wl["step"]
 
@@ -546,7 +571,7 @@ def main():
         if "flops_per_step" in wl:
             tf = wl["flops_per_step"] / (dt / args.steps) / 1e12
             line["step_tflops_per_gpu"] = tf
-            line["step_mfma_frac"] = tf / BF16_MFMA_PEAK_TF
+            line["step_mfma_frac"] = tf / (BF16_MFMA_PEAK_TF if wl["dtype"] == "bf16" else FP32_MFMA_PEAK_TF)
             loss = wl["state"]["loss"]
             line["final_loss"] = float(loss.item()) if loss is not None else None
         if os.environ.get("ADT_BENCH_SHARE_GPU") == "1":

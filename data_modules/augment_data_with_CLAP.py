@@ -168,9 +168,11 @@ def run(cfg: dict, num_bins: int = 10, clap_model=None, copy: bool = True):
         from adt_str_amd.audio_io import copy_files
         dsts, srcs = list(plan), list(plan.values())
         status = copy_files(srcs, dsts)                    # shutil.copy2 per pair (contents, mode, times) on the library's thread pool
-        for j in np.nonzero(status)[0]:                    # the reference logs and carries on (:195-196)
-            print(f"Failed to copy {srcs[j]} -> {os.path.dirname(dsts[j])}")
-        copied = int((status == 0).sum())
+        for j in np.nonzero(status)[0]:                    # the reference logs and carries on (:188-189)
+            print(f"Failed to copy {srcs[j]} -> {dsts[j]}: status {int(status[j])} (adt_copy_files)")
+        # the reference counts one copy per source path (:185-187), including a copy that overwrites an earlier file of the same name in
+        # the same <class>/<bin>/ (the plan above keeps the last writer of a destination, as the sequential loop would leave it)
+        copied = len(res.order) - int((status != 0).sum())
         print(f"Copied: {copied}, Skipped (duplicates): {len(wav_files) * (len(labels) - 1)}")
     phase("copy")
     return res, wav_files, augmented_root

@@ -29,6 +29,41 @@ def test_config4_end_to_end_scaled_down(tmp_path):
     assert n_copied == 2000                                                                      # each pack file copied exactly once
 
 
+def test_config4_curation_half_at_the_stated_size(tmp_path):
+    """BASELINE config[4]'s curation half at its stated size -- 100 000 one-shots: library on disk -> batched decode / resample -> K9-K12
+    -> global assignment -> copies -> gold -> flat bank (augment_data_with_CLAP.py:71-193 -> copy_originals_to_augmented.py ->
+    convert_augmented_to_hdf5.py:69-141).  Size-independent properties: every pack file is copied exactly once, into
+    <class>/<upper>-<lower>/ with a class the references define and a well-formed 10 %-wide bin label (A.7); the bank holds every copied
+    file and every reference.  The training half at this size runs in tools/e2e.py (profiles/r0N/e2e_config4_100k*.json)."""
+    import re
+    import shutil
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import e2e
+    n = 100_000
+    out = e2e.main(["--workdir", str(tmp_path / "w"), "--shots", str(n), "--curation-only", "--keep"])
+    try:
+        print(f"config[4] curation at {n} shots: {out['embeds_per_s']:.0f} embeds/s end to end, "
+              f"{out['embeds_per_s_embedding_phase_incl_file_reads']:.0f} in the embedding phase; times {out['times']}")
+        assert out["n_assigned"] == n and out["bank_shots"] == n + 26 * 5 and out["embeds_per_s"] > 2000
+        aug = tmp_path / "w" / "refs_clap_augmented"
+        seen = {}
+        for d, _, files in os.walk(aug):
+            rel = os.path.relpath(d, aug).split(os.sep)
+            if len(rel) != 2 or rel[1] == "gold":
+                continue
+            cls, label = rel
+            assert 35 <= int(cls) <= 60, cls
+            m = re.fullmatch(r"(\d+)-(\d+)", label)
+            assert m and int(m.group(1)) - int(m.group(2)) == 10 and 0 <= int(m.group(2)) <= 90, label
+            for f in files:
+                assert f not in seen, f                                        # a pack file lands in exactly one (class, bin)
+                seen[f] = (cls, label)
+        assert len(seen) == n
+        assert set(lbl for _, lbl in seen.values()) == set(out["bins_used"])
+    finally:
+        shutil.rmtree(tmp_path / "w", ignore_errors=True)
+
+
 def test_config4_end_to_end_two_ranks(tmp_path):
     """The multi-GPU half of config[4] at two ranks (one-GPU box: both on GPU 0 over gloo, ADT_SHARE_GPU=1; on a node: one GPU each
     and RCCL): every rank embeds its stride of the files and the embeddings are all-gathered, rank 0 assigns, copies and

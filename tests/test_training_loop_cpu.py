@@ -210,6 +210,9 @@ def test_native_loop_prefetch_accumulation_and_final_save(tmp_path):
     assert t_inline.step_no == 2 * (50 // 4) and t_inline.seen == t_thread.seen                # the thread changes nothing
     assert all(torch.equal(a, b) for a, b in zip(m_inline.state_dict().values(), m_thread.state_dict().values()))
     assert len(t_thread.loss_history) == t_thread.step_no                                       # logging_steps = 1, drained at the end
+    # every logged step after the first also reports step_ms and whole-job clips/s (batch 4 x world 1) since the previous logged step
+    assert len(t_thread.rate_history) == t_thread.step_no - 1
+    assert all(ms > 0 and abs(cps - 4 / (ms * 1e-3)) < 1e-6 * cps for _, ms, cps in t_thread.rate_history)
     from safetensors.torch import load_file
     saved = load_file(str(tmp_path / "b" / "default" / "model.safetensors"))       # output_dir / run_name                                # trainer.save_model()
     assert set(saved) == set(m_thread.state_dict()) and torch.equal(saved["lin.weight"], m_thread.lin.weight.data)
@@ -278,8 +281,38 @@ def test_missing_rank_rng_file_is_reported_on_resume(tmp_path):
     _, full = _run(_cfg(tmp_path / "r", logging__save_every_n_steps=5))
     ck = tmp_path / "r" / "default" / "checkpoint-10"
     os.remove(ck / "rng_state_0.pth")
-    with pytest.warns(UserWarning, match="rng_state_0.pth is missing"):
+    # the checkpoint recorded an RNG file per rank: resuming without it would silently change the data stream -> refused ...
+    with pytest.raises(FileNotFoundError, match="rng_state_0.pth is missing"):
         T.run_native_training(_ToyModel(), _dataset(), _cfg(tmp_path / "r", checkpoint__resume_from_checkpoint=str(ck)), trainer_factory=_ToyTrainer)
+    # ... unless the user opts in, which still warns
+    monkey = {"ADT_ALLOW_MISSING_RNG": "1"}
+    os.environ.update(monkey)
+    try:
+        with pytest.warns(UserWarning, match="rng_state_0.pth is missing"):
+            T.run_native_training(_ToyModel(), _dataset(), _cfg(tmp_path / "r", checkpoint__resume_from_checkpoint=str(ck)), trainer_factory=_ToyTrainer)
+    finally:
+        os.environ.pop("ADT_ALLOW_MISSING_RNG")
+
+
+def test_checkpoint_marker_waits_for_every_ranks_rng_file_and_dead_directories_are_pruned(tmp_path, monkeypatch):
+    """``trainer_state.pt`` (the completeness marker) is not written while a rank's RNG file is absent; directories a killed run left
+    without the marker and older than a completed checkpoint are removed by the rotation."""
+    out = tmp_path / "o"
+    dead = out / "checkpoint-3"
+    os.makedirs(dead)
+    (dead / "model.safetensors").write_bytes(b"partial")
+    d = out / "checkpoint-5"
+    os.makedirs(d)
+    torch.save({}, d / "rng_state_0.pth")
+    monkeypatch.setattr(T, "RNG_FILE_WAIT_S", 0.2)
+    with pytest.raises(RuntimeError, match="rng_state files of ranks \\[1\\]"):
+        T._finish_checkpoint(str(d), {"w": torch.zeros(2)}, None, {}, {"step": 5}, 2, str(out), 3, rng_files=2)
+    assert not (d / "trainer_state.pt").exists() and T._checkpoint_dirs(str(out)) == []
+    torch.save({}, d / "rng_state_1.pth")                               # the lagging rank arrives
+    T._finish_checkpoint(str(d), {"w": torch.zeros(2)}, None, {}, {"step": 5}, 2, str(out), 3, rng_files=2)
+    assert (d / "trainer_state.pt").exists() and not dead.exists()
+    st = torch.load(d / "trainer_state.pt", weights_only=False)
+    assert st["rng_files"] == 2 and st["world"] == 2
 
 
 def _free_port():

@@ -92,6 +92,9 @@ def test_fused_adamw_for_the_hf_path_equals_torch_adamw():
         run(model, opt, seeds, lr)
         run(twin, ref, seeds, lr)
         same(step)
+    # the bridge's gradient views were found as ONE flat buffer by address (single backward, accumulation and clipping all work in place on
+    # them): the gather path, its second 276 MB buffer and its extra pass never ran
+    assert opt._gather is None
     # state_dict round trip into a fresh optimizer over a fresh copy of the model: the next step is the same step
     model2 = copy.deepcopy(model)
     opt2 = FusedAdamW(groups(model2), lr=1e-3, betas=(0.9, 0.999), eps=1e-8, engine=model2.engine)

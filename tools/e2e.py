@@ -100,6 +100,7 @@ def main(argv=None):
     ap.add_argument("--save-every", type=int, default=0, help="checkpoint every n steps (0: a third of the epoch)")
     ap.add_argument("--tiny", action="store_true", help="1 + 1 layer network with 2 heads (tests); default is the setting-1 network")
     ap.add_argument("--check-resume", action="store_true")
+    ap.add_argument("--curation-only", action="store_true", help="stop after the bank is built (config[4]'s curation half)")
     ap.add_argument("--keep", action="store_true", help="keep the scratch directory")
     ap.add_argument("--seed", type=int, default=42)
     a = ap.parse_args(argv)
@@ -157,6 +158,20 @@ def main(argv=None):
         n_bank = bank.n_shots
     barrier()
     times["bank_s"] = time.perf_counter() - t0
+
+    if a.curation_only:
+        out = {"workload": "config[4] curation half (synthetic library)", "n_gpus": world, "shots": a.shots, "times": times,
+               "embeds_per_s": n_embedded / times["curate_s"],
+               "embeds_per_s_embedding_phase_incl_file_reads": len(wav_files) / max(times["curate_phases_s"].get("embed_packs", 0.0), 1e-9)}
+        if rank == 0:
+            out.update(bank_shots=n_bank, bins_used=sorted(set(res.bin)), n_assigned=len(res.order), aug_root=str(aug_root))
+            print(json.dumps(out), flush=True)
+        if not a.keep and rank == 0:
+            shutil.rmtree(a.workdir, ignore_errors=True)
+        if world > 1:
+            dist.barrier()
+            dist.destroy_process_group()
+        return out
 
     # 4. one epoch
     from adt_str_amd.data import GpuBatcher, NoteChunkDataset
