@@ -23,231 +23,9 @@
 // current one and written to the other buffer afterwards (one barrier per tile).
 // The backward recomputes P from the saved log-sum-exp; dQ (which also produces delta = rowsum(O * dO) for its queries)
 // and dK/dV are separate kernels so no float atomics are needed (bitwise reproducible).
-#include <hip/hip_runtime.h>
-
-#include <cstdlib>
-
-#include "adt_common.h"
-#include "dropout.h"
+#include "attn_common.h"
 
 namespace adt {
-
-typedef __attribute__((ext_vector_type(8))) short bf16x8;
-typedef __attribute__((ext_vector_type(4))) short bf16x4;
-typedef __attribute__((ext_vector_type(16))) float f32x16;
-typedef __attribute__((ext_vector_type(4))) float f32x4;
-typedef __attribute__((ext_vector_type(2))) float f32x2;
-typedef __attribute__((ext_vector_type(4))) unsigned u32x4;
-
-constexpr int kDh = 128;
-constexpr int kAttnThreads = 256;
-constexpr int kRowsPerTile = 64;
-constexpr int kAttnTileBytes = kRowsPerTile * 256;   // 16 KiB
-constexpr float kLog2e = 1.4426950408889634f;
-constexpr float kLn2 = 0.6931471805599453f;
-constexpr float kNegBig = -1.0e30f;
-constexpr float kRescaleThr = 5.0f;          // log2 units: lazy online-softmax rescale threshold
-
-__device__ __forceinline__ unsigned lds_off(const void* p) {
-  return static_cast<unsigned>(reinterpret_cast<size_t>((__attribute__((address_space(3))) const void*)p));
-}
-__device__ __forceinline__ int swz(int row, int chunk) {
-  return 256 * row + 16 * (chunk ^ (((row & 3) << 2) | ((row >> 2) & 3)));
-}
-// (asm: left to itself the compiler pairs the conversions of elements 0,2 / 1,3 and re-interleaves with four more instructions)
-__device__ __forceinline__ unsigned pack2(float lo, float hi) {
-  unsigned r;
-  asm("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(r) : "v"(lo), "v"(hi));
-  return r;
-}
-// accumulator registers 8s .. 8s+7 of a 32x32 tile -> the bf16 B operand of k-step s (rows 16s..16s+15 of the tile)
-__device__ __forceinline__ bf16x8 acc_to_b(const f32x16& x, int s) {
-  union { unsigned u[4]; bf16x8 v; } r;
-  r.u[0] = pack2(x[8 * s + 0], x[8 * s + 1]); r.u[1] = pack2(x[8 * s + 2], x[8 * s + 3]);
-  r.u[2] = pack2(x[8 * s + 4], x[8 * s + 5]); r.u[3] = pack2(x[8 * s + 6], x[8 * s + 7]);
-  return r.v;
-}
-__device__ __forceinline__ int acc_row(int i, int h) { return (i & 3) + 8 * (i >> 2) + 4 * h; }
-
-// ---- tile staging by LDS-DMA: 64 rows x 128 bf16 of one head; one wave-instruction (1 KiB) fills 4 rows.
-// The LDS image must be lane-linear, so the swizzle sits on the SOURCE address: position p of row r
-// receives the row's chunk p ^ f(r) (an involution, so reads use swz()).  Rows past n_rows are clamped
-// to the last valid row: their scores are masked / their probabilities are zero, and 0 * finite = 0.
-__device__ __forceinline__ void tile_dma(const unsigned short* __restrict__ base, long row_stride, int row0, int n_rows,
-                                         unsigned char* tile, int wave, int lane) {
-#pragma unroll
-  for (int i = 0; i < 4; ++i) {
-    const int row = 4 * (4 * wave + i) + (lane >> 4);
-    const int chunk = (lane & 15) ^ (((row & 3) << 2) | ((row >> 2) & 3));
-    int gr = row0 + row;
-    gr = gr < n_rows ? gr : n_rows - 1;
-    const unsigned short* p = base + static_cast<long>(gr) * row_stride + chunk * 8;
-    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)p,
-                                     (__attribute__((address_space(3))) void*)(tile + (4 * wave + i) * 1024), 16, 0, 0);
-  }
-}
-// The same staging with the per-lane part of the source address (row inside the tile, swizzled chunk) computed once per kernel:
-// off[i] = row_i * row_stride + chunk_i * 8 elements; a full tile then costs one 64-bit add per instruction.
-__device__ __forceinline__ void tile_dma_offsets(long row_stride, int wave, int lane, unsigned (&off)[4]) {
-#pragma unroll
-  for (int i = 0; i < 4; ++i) {
-    const int row = 4 * (4 * wave + i) + (lane >> 4);
-    const int chunk = (lane & 15) ^ (((row & 3) << 2) | ((row >> 2) & 3));
-    off[i] = static_cast<unsigned>(row * row_stride + chunk * 8);
-  }
-}
-__device__ __forceinline__ void tile_dma_pre(const unsigned short* __restrict__ base, long row_stride, int row0, int n_rows,
-                                             unsigned char* tile, int wave, int lane, const unsigned (&off)[4]) {
-  if (row0 + kRowsPerTile <= n_rows) {                  // block-uniform
-    const unsigned short* b0 = base + static_cast<long>(row0) * row_stride;
-#pragma unroll
-    for (int i = 0; i < 4; ++i)
-      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(b0 + off[i]),
-                                       (__attribute__((address_space(3))) void*)(tile + (4 * wave + i) * 1024), 16, 0, 0);
-  } else {
-    tile_dma(base, row_stride, row0, n_rows, tile, wave, lane);
-  }
-}
-__device__ __forceinline__ void dma_wait_and_sync() {
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  __syncthreads();
-}
-// A operand, rows of the tile: tile row (rb*32 + lane&31), d = 16s + 8h .. +7
-__device__ __forceinline__ bf16x8 frag_rows(const unsigned char* tile, int rb, int s, int lane) {
-  return *reinterpret_cast<const bf16x8*>(tile + swz(rb * 32 + (lane & 31), 2 * s + (lane >> 5)));
-}
-// A operand, transposed tile: A[row = d = 32db + lane&31][element j] = tile[R0 + 8(j>>2) + 4h + (j&3)][d].
-// tr4_issue starts the 8 transposed reads of the four 32-d blocks of one 16-row k-step; tr_wait retires
-// them (one lgkmcnt(0) for all, then a scheduling fence so no MFMA is hoisted above the wait).
-struct TrFrag { bf16x4 lo, hi; };
-__device__ __forceinline__ void tr4_issue(const unsigned char* tile, int R0, int lane, TrFrag (&f)[4]) {
-  const int i = lane & 15, g4 = (lane >> 4) & 1, h = lane >> 5;
-  const int row = R0 + 4 * h + (i >> 2);
-  const unsigned base = lds_off(tile) + 8 * (i & 1);
-#pragma unroll
-  for (int db = 0; db < 4; ++db) {
-    const int chunk = 4 * db + 2 * g4 + ((i & 3) >> 1);
-    const unsigned a0 = base + swz(row, chunk), a1 = base + swz(row + 8, chunk);
-    asm volatile("ds_read_b64_tr_b16 %0, %2\n\tds_read_b64_tr_b16 %1, %3" : "=&v"(f[db].lo), "=&v"(f[db].hi) : "v"(a0), "v"(a1) : "memory");
-  }
-}
-// The same reads from per-lane offsets computed once: the swizzle only involves row bits 0..3, so a lane's eight offsets (4 d-blocks
-// x rows r, r + 8) inside a 16-row group are loop constants; the tile base goes in with one add, the 16-row group as an immediate.
-__device__ __forceinline__ void tr_offsets(int lane, unsigned (&o)[4][2]) {
-  const int i = lane & 15, g4 = (lane >> 4) & 1, h = lane >> 5, row = 4 * h + (i >> 2);
-#pragma unroll
-  for (int db = 0; db < 4; ++db) {
-    const int chunk = 4 * db + 2 * g4 + ((i & 3) >> 1);
-    o[db][0] = static_cast<unsigned>(8 * (i & 1) + swz(row, chunk));
-    o[db][1] = static_cast<unsigned>(8 * (i & 1) + swz(row + 8, chunk));
-  }
-}
-template <int kR0>
-__device__ __forceinline__ void tr4_issue_at(const unsigned (&a)[4][2], TrFrag (&f)[4]) {      // a = tr_offsets + LDS address of the tile
-#pragma unroll
-  for (int db = 0; db < 4; ++db)
-    asm volatile("ds_read_b64_tr_b16 %0, %2 offset:%4\n\tds_read_b64_tr_b16 %1, %3 offset:%4"
-                 : "=&v"(f[db].lo), "=&v"(f[db].hi) : "v"(a[db][0]), "v"(a[db][1]), "i"(kR0 * 256) : "memory");
-}
-__device__ __forceinline__ void tr_wait() {
-  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-  __builtin_amdgcn_sched_barrier(0);
-}
-__device__ __forceinline__ bf16x8 tr_get(const TrFrag& f) {
-  bf16x8 r;
-  r[0] = f.lo[0]; r[1] = f.lo[1]; r[2] = f.lo[2]; r[3] = f.lo[3];
-  r[4] = f.hi[0]; r[5] = f.hi[1]; r[6] = f.hi[2]; r[7] = f.hi[3];
-  return r;
-}
-// B operand held in registers: row `row` of a global [*, stride] matrix, d = 16s + 8h .. +7, s = 0..7
-__device__ __forceinline__ void frags_from_global(const unsigned short* __restrict__ base, long row_stride, int row, int n_rows,
-                                                  int lane, bf16x8 (&f)[8]) {
-  const int h = lane >> 5;
-#pragma unroll
-  for (int s = 0; s < 8; ++s) {
-    uint4 v = make_uint4(0, 0, 0, 0);
-    if (row < n_rows) v = *reinterpret_cast<const uint4*>(base + static_cast<long>(row) * row_stride + 16 * s + 8 * h);
-    f[s] = *reinterpret_cast<bf16x8*>(&v);
-  }
-}
-// transposed accumulator [d][x] (4 blocks of 32 d) -> bf16 rows out[x][d]; lane owns x = lane&31.
-// A row is split across the half-waves (lane x: columns 8k .. 8k+3, lane x + 32: columns 8k+4 .. 8k+7 of column group k), so the
-// natural store is 16 x 8 bytes per lane, and that tail is bound by the number of store instructions, not by bytes.  One
-// v_permlane32_swap per dword and pair of groups (k, k + 1) hands the upper half's group k to the lower lanes and the lower half's
-// group k + 1 to the upper lanes: 8 x 16-byte stores of the same bytes to the same addresses (cdna_hip_programming.md T21).
-__device__ __forceinline__ void store_transposed(const f32x16 (&acc)[4], float mul, unsigned short* __restrict__ base, long row_stride,
-                                                 int row, int n_rows, int lane) {
-  if (row >= n_rows) return;                           // lanes x and x + 32 own the same row: they leave together
-  const int h = lane >> 5;
-  unsigned short* p = base + static_cast<long>(row) * row_stride + 8 * h;
-#pragma unroll
-  for (int db = 0; db < 4; ++db)
-#pragma unroll
-    for (int g = 0; g < 4; g += 2) {
-      unsigned ax = pack2(acc[db][4 * g + 0] * mul, acc[db][4 * g + 1] * mul), ay = pack2(acc[db][4 * g + 2] * mul, acc[db][4 * g + 3] * mul);
-      unsigned bx = pack2(acc[db][4 * g + 4] * mul, acc[db][4 * g + 5] * mul), by = pack2(acc[db][4 * g + 6] * mul, acc[db][4 * g + 7] * mul);
-      const auto rx = __builtin_amdgcn_permlane32_swap(ax, bx, false, false);
-      const auto ry = __builtin_amdgcn_permlane32_swap(ay, by, false, false);
-      // lower lanes: [own k | upper's k] = columns 8k .. 8k+7; upper lanes: [lower's k+1 | own k+1] = columns 8k+8 .. 8k+15
-      *reinterpret_cast<uint4*>(p + 32 * db + 8 * g) = make_uint4(rx[0], ry[0], rx[1], ry[1]);
-    }
-}
-
-// Sum over the 32 lanes of each half-wave on the DPP network (row_shr 1/2/4/8, then row_bcast:15): lanes 31 and 63 hold the sums.
-template <int kCtrl, int kRowMask>
-__device__ __forceinline__ float dpp_add(float v) {
-  return v + __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), kCtrl, kRowMask, 0xf, false));
-}
-__device__ __forceinline__ float half_wave_sum(float v) {
-  v = dpp_add<0x111, 0xf>(v); v = dpp_add<0x112, 0xf>(v); v = dpp_add<0x114, 0xf>(v); v = dpp_add<0x118, 0xf>(v);
-  return dpp_add<0x142, 0xa>(v);
-}
-// Column sums of a transposed accumulator as store_transposed writes it (bf16-rounded acc * mul; rows >= n_rows count as 0)
-// over this wave's 32 rows: lane 31 / 63 leaves them in red[32 db + 8 g + 4 h + e].  The bias gradient of the in-projection
-// is the column sum of dQ | dK | dV; taking it here saves a pass over those matrices.
-__device__ __forceinline__ void colsum_transposed(const f32x16 (&acc)[4], float mul, bool row_ok, int lane, float* __restrict__ red) {
-  const int h = lane >> 5;
-#pragma unroll
-  for (int db = 0; db < 4; ++db)
-#pragma unroll
-    for (int i = 0; i < 16; ++i) {
-      float v = row_ok ? __uint_as_float(static_cast<unsigned>(__builtin_bit_cast(unsigned short, static_cast<__bf16>(acc[db][i] * mul))) << 16) : 0.f;
-      v = half_wave_sum(v);
-      if ((lane & 31) == 31) red[32 * db + 8 * (i >> 2) + 4 * h + (i & 3)] = v;
-    }
-}
-
-struct AttnArgs {
-  const unsigned short *q, *k, *v, *o, *dout;
-  unsigned short *out, *dq, *dk, *dv;
-  float* lse; const float* delta;
-  long ldq, ldk, ldv, ldo;          // row strides (elements); gradients share the strides of their tensors
-  int B, H, Sq, Sk;
-  float scale, mask_value; int causal; const int* key_len;
-  Drop drop;
-  float* cs_dq;        // column sums of dQ per (batch, 128-query block): [B * ceil(Sq/128)][H*128], null: off
-};
-
-// Tile coordinates of this workgroup.  The grids are 1-D: nx tiles (query or key blocks) per (batch, head) times ny = B * H.
-// Workgroups are dealt round-robin over the 8 XCDs (blocks b and b + 8 share one), so ids are renumbered to give every XCD a
-// CONTIGUOUS range of logical tiles, x fastest: all blocks of one (batch, head) then sit on one XCD at about the same time, and
-// that XCD's L2 fetches the head's K / V (or Q / dO) once instead of eight L2s fetching it once each.  Placement only changes
-// speed, never results; the map is a bijection for any grid size (same renumbering as the GEMMs).
-struct TileXY { int x, y; };
-__device__ __forceinline__ TileXY tile_coords(int nx) {
-  const int n = gridDim.x, id = blockIdx.x;
-  const int q = n >> 3, r = n & 7, xcd = id & 7;
-  const int logical = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (id >> 3);
-  return TileXY{logical % nx, logical / nx};
-}
-
-// additive mask of the reference (model.py:173-181): causal and key-padding contributions add up
-__device__ __forceinline__ float mask_add(const AttnArgs& a, int qi, int ki, int klen) {
-  float m = 0.f;
-  if (a.causal && ki > qi) m += a.mask_value;
-  if (ki >= klen) m += a.mask_value;
-  return m;
-}
 
 // =============================================================================== forward
 template <bool kDrop>
@@ -395,16 +173,6 @@ __global__ __launch_bounds__(kAttnThreads, 2) void attn_fwd_kernel(AttnArgs a) {
 // Keys behind the key-padding length are skipped when the additive mask is the reference's -1e4 (any mask <= -1000): their
 // weight exp(score - 1e4 - max) is exactly 0 in fp32 next to one unmasked key; with a milder mask every key is visited and masked.
 constexpr int kDecWaves = 8;
-template <int kCtrl>
-__device__ __forceinline__ float dpp_row(float v) {          // v + (v of the lane kCtrl names inside the 16-lane DPP row)
-  return v + __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), kCtrl, 0xf, 0xf, false));
-}
-__device__ __forceinline__ float quarter_sum(float v) {      // sum over the 16 lanes of a quarter-wave, in every one of them
-  v = dpp_row<0xB1>(v);                                      // quad_perm [1, 0, 3, 2]
-  v = dpp_row<0x4E>(v);                                      // quad_perm [2, 3, 0, 1]
-  v = dpp_row<0x141>(v);                                     // row_half_mirror
-  return dpp_row<0x140>(v);                                  // row_mirror
-}
 typedef __bf16 bf16x2d __attribute__((ext_vector_type(2)));
 typedef float f32x2d __attribute__((ext_vector_type(2)));
 __global__ __launch_bounds__(64 * kDecWaves) void attn_decode_kernel(AttnArgs a) {
@@ -1472,13 +1240,17 @@ extern "C" int adt_attn_fwd(const adt_attn_desc* d, const void* q, const void* k
 }
 
 static size_t delta_floats(const adt_attn_desc* d) { return (static_cast<size_t>(d->batch) * d->heads * d->q_len + 4 + 3) & ~static_cast<size_t>(3); }
-extern "C" size_t adt_attn_bwd_workspace_bytes(const adt_attn_desc* d) {
-  if (!d || d->batch <= 0 || d->heads <= 0 || d->q_len <= 0) return 16;
+// bytes of the two-kernel path's workspace (delta, column-sum partials and scratch); the fused path's region follows it, 256-aligned
+static size_t split_workspace_bytes(const adt_attn_desc* d) {
   size_t bytes = delta_floats(d) * 4;
   if (d->dq_colsum || d->dk_colsum || d->dv_colsum)        // dQ partial sums per (batch, 128-query block) + the dV column-sum scratch
     bytes += static_cast<size_t>(d->batch) * d->heads * kDh * ((d->q_len + 127) / 128) * 4 +
-             adt_colsum_workspace_bytes(static_cast<int64_t>(d->batch) * d->k_len, static_cast<int64_t>(d->heads) * kDh);
-  return bytes;
+             adt_colsum_workspace_bytes(static_cast<int64_t>(d->batch) * (d->k_len > d->q_len ? d->k_len : d->q_len), static_cast<int64_t>(d->heads) * kDh);
+  return (bytes + 255) & ~static_cast<size_t>(255);
+}
+extern "C" size_t adt_attn_bwd_workspace_bytes(const adt_attn_desc* d) {
+  if (!d || d->batch <= 0 || d->heads <= 0 || d->q_len <= 0 || d->k_len <= 0) return 16;
+  return split_workspace_bytes(d) + attn_bwd_fused_workspace_bytes(d);
 }
 
 extern "C" int adt_attn_bwd(const adt_attn_desc* d, const void* q, const void* k, const void* v, const void* o, const void* dout,
@@ -1496,6 +1268,28 @@ extern "C" int adt_attn_bwd(const adt_attn_desc* d, const void* q, const void* k
   const bool want_cs = d->dq_colsum || d->dk_colsum || d->dv_colsum;
   if (want_cs && !(d->dq_colsum && d->dk_colsum && d->dv_colsum)) return set_error(ADT_EINVAL, "adt_attn_bwd: give all three column-sum outputs or none");
   const int nqb = (d->q_len + 127) / 128, hd = d->heads * kDh;
+  // ADT_ATTN_BWD=fused selects the one-kernel backward (attention_bwd_fused.hip: 5 products, ordered dQ hand-off); the default is the
+  // two-kernel path below (dQ kernel + dK/dV kernel, 7 products) until the fused kernel beats it.  Read on every call: the tests switch it.
+  const char* bwd_env = getenv("ADT_ATTN_BWD");
+  if (bwd_env && bwd_env[0] == 'f') {
+    const size_t off = split_workspace_bytes(d);
+    if (int rc = launch_attn_bwd_fused(d, a, static_cast<unsigned char*>(ws) + off, ws_bytes - off, st)) return rc;
+    if (want_cs) {
+      // bias gradient of the in-projection: column sums of the stored dQ and dV (one pass each); dK's vanish identically (the rows of dS
+      // sum to zero), so exact zeros are written instead of rounding noise
+      float* cws = static_cast<float*>(ws) + delta_floats(d) + static_cast<size_t>(d->batch) * nqb * hd;
+      const int64_t rq = static_cast<int64_t>(d->batch) * d->q_len, rk = static_cast<int64_t>(d->batch) * d->k_len;
+      if (int rc = adt_colsum_bf16(dq, d->ldq, rq, hd, d->dq_colsum, cws, adt_colsum_workspace_bytes(rq, hd), stream)) return rc;
+      if (reduce_queue_open(st)) {
+        if (int rc = reduce_queue_push(nullptr, 0, hd, d->dk_colsum, nullptr, nullptr, hd)) return rc;
+      } else {
+        ADT_HIP_TRY(hipMemsetAsync(d->dk_colsum, 0, static_cast<size_t>(hd) * 4, st));
+      }
+      if (int rc = adt_colsum_bf16(dv, d->ldv, rk, hd, d->dv_colsum, cws, adt_colsum_workspace_bytes(rk, hd), stream)) return rc;
+    }
+    ADT_HIP_TRY(hipGetLastError());
+    return ADT_OK;
+  }
   float* cs_slice = nullptr;
   if (want_cs) {
     cs_slice = reduce_queue_slice(static_cast<size_t>(d->batch) * nqb * hd * 4, st);     // open reduction queue: the second stage is deferred
