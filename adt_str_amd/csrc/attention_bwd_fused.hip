@@ -23,6 +23,8 @@
 // order: a workgroup only ever waits for a LOWER ticket of its own counter (or for the end of the previous counter's range), i.e.
 // for a workgroup that is already running or finished -- no assumption about dispatch order, and spins are bounded.
 // delta = rowsum(O * dO) and -lse / scale are prepared per query by a small kernel in front (attn_bwd_stats_kernel).
+#include <type_traits>
+
 #include "attn_common.h"
 
 namespace adt {
@@ -34,19 +36,22 @@ constexpr int kFbKimg = kFbKeys * 256;              // K rows of the workgroup's
 constexpr int kFbX = kFbKeys * 64;                  // dS^T of one slice: [key][32 q] bf16
 constexpr int kFbTile = 2 * kFbSlice * 256;         // Q rows | dO rows of one slice
 constexpr int kFbOffX = kFbKimg;
-constexpr int kFbOffT = kFbOffX + 2 * kFbX;
+constexpr int kFbOffT = kFbOffX + kFbX;
 constexpr int kFbOffS = kFbOffT + 2 * kFbTile;      // per slice -lse / scale [32] | -delta [32]
-constexpr int kFbOffFlag = kFbOffS + 2 * 256;
-constexpr int kFbLds = kFbOffFlag + 16;             // 131,600 B
+constexpr int kFbOffStash = kFbOffS + 2 * 256;      // running dQ^T sum of the slice this workgroup is reducing (4 KiB per wave)
+constexpr int kFbOffLand = kFbOffStash + 4 * 4096;  // landing zone of the key block tile that is added next (4 KiB per wave, LDS-DMA)
+constexpr int kFbOffFlag = kFbOffLand + 4 * 4096;
+constexpr int kFbLds = kFbOffFlag + 16;             // 147,984 B
 constexpr unsigned kFbSpinLimit = 1u << 24;         // polls of ~0.3 us each before a wave gives up (and reports it)
 
 struct FusedArgs {
   AttnArgs a;
   const float* stats;                 // [B*H][ns][2][32]: -lse / scale of the slice's queries, then -delta
-  float* part;                        // [B*H][ns][4 waves][1024] running dQ^T sums (nkb > 1)
-  unsigned* flags;                    // [B*H][ns][4] + 4 words: [0] of the tail = number of waves that gave up waiting
+  float* part;                        // [B*H][ns][nkb][4 waves][1024]: every key block's dQ^T tile of every slice (nkb > 1)
+  unsigned* flags;                    // [B*H][ns][nkb][4 waves] + 4 words: [0] of the tail = number of waves that gave up waiting
   unsigned* sched; unsigned sched_total[8];
   int nkb, ns;
+  unsigned long long* stamps;         // experiment build, kDbg & 32: cycle stamps of one wave's phases in one slice
   int dbg;                            // timing experiments only (ADT_FB_DBG): 1 no hand-off, 2 no dQ product, 4 no dV / dK products, 8 no S / dP chains
 };
 
@@ -101,7 +106,26 @@ __device__ __forceinline__ void trx_issue(const unsigned char* x, int K0, int la
   asm volatile("ds_read_b64_tr_b16 %0, %2\n\tds_read_b64_tr_b16 %1, %3" : "=&v"(f.lo), "=&v"(f.hi) : "v"(a0), "v"(a1) : "memory");
 }
 
-template <bool kDrop>
+// dK^T / dV^T accumulate in the 256 AGPRs for the whole kernel.  Written as inline asm with the "a" constraint: with the builtin the
+// register allocator also puts the short-lived S / dP / dQ accumulators into AGPRs and then shuttles dK / dV tiles between the two files
+// around every product (sixteen v_accvgpr_read + sixteen v_accvgpr_write + an s_nop 11 per pair of MFMAs).  Operands are compiler-visible
+// registers; the results are only read after the loop (compiler-generated v_accvgpr_read, hundreds of cycles behind the last product).
+__device__ __forceinline__ void mfma_acc(f32x16& acc, const bf16x8& x, const bf16x8& y) {
+  asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+a"(acc) : "v"(x), "v"(y));
+}
+// ... and S', dP, dQ^T accumulate in arch VGPRs.  The compiler does not know these are MFMAs, so the wait states it would insert are
+// placed by hand: mfma_settle() between the last product of a chain and the first vector instruction that reads its result
+// (a 32x32x16 product is 8 passes; 16 wait states cover it), mfma_srcc_ready() between vector writes of an accumulator and its first product.
+__device__ __forceinline__ void mfma_vgpr(f32x16& acc, const bf16x8& x, const bf16x8& y) {
+  asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+v"(acc) : "v"(x), "v"(y));
+}
+// (the accumulators go through the statements as operands: that is what keeps the compiler's own reads / writes of them on the right side)
+__device__ __forceinline__ void mfma_settle(f32x16& x, f32x16& y) { asm volatile("s_nop 15\n\ts_nop 3" : "+v"(x), "+v"(y)); }
+__device__ __forceinline__ void mfma_settle(f32x16& x) { asm volatile("s_nop 15\n\ts_nop 3" : "+v"(x)); }
+__device__ __forceinline__ void mfma_srcc_ready(f32x16& x, f32x16& y) { asm volatile("s_nop 3" : "+v"(x), "+v"(y)); }
+__device__ __forceinline__ void mfma_srcc_ready(f32x16& x) { asm volatile("s_nop 3" : "+v"(x)); }
+
+template <bool kDrop, int kDbg>
 __global__ __launch_bounds__(kFbThreads, 1) void attn_bwd_fused_kernel(FusedArgs fa) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const AttnArgs& a = fa.a;
@@ -110,8 +134,11 @@ __global__ __launch_bounds__(kFbThreads, 1) void attn_bwd_fused_kernel(FusedArgs
 
   // ---- this workgroup's (batch, head, key block): ticket v of the XCD group's counter = logical tile slice0 + v
   const int n_tiles = fa.nkb * a.B * a.H;
-  const int q8 = n_tiles >> 3, r8 = n_tiles & 7, xg = blockIdx.x & 7;
-  const int slice0 = xg < r8 ? xg * (q8 + 1) : r8 * (q8 + 1) + (xg - r8) * q8, slice_n = q8 + (xg < r8 ? 1 : 0);
+  // (kDbg & 16, tests only: ONE counter for the whole grid, so that the key blocks of a head land on different XCDs and every hand-off
+  // crosses XCDs)
+  const int q8 = n_tiles >> 3, r8 = n_tiles & 7, xg = (kDbg & 16) ? 0 : (blockIdx.x & 7);
+  const int slice0 = (kDbg & 16) ? 0 : (xg < r8 ? xg * (q8 + 1) : r8 * (q8 + 1) + (xg - r8) * q8);
+  const int slice_n = (kDbg & 16) ? n_tiles : q8 + (xg < r8 ? 1 : 0);
   unsigned* const tflag = reinterpret_cast<unsigned*>(smem + kFbOffFlag);
   if (tid == 0) {
     unsigned* const counter = fa.sched + xg * 16;
@@ -132,9 +159,9 @@ __global__ __launch_bounds__(kFbThreads, 1) void attn_bwd_fused_kernel(FusedArgs
   const unsigned short* kb_ = a.k + static_cast<long>(b) * a.Sk * a.ldk + head * kDh;
   const unsigned short* vb = a.v + static_cast<long>(b) * a.Sk * a.ldv + head * kDh;
   const float* stat_g = fa.stats + static_cast<long>(bh) * ns * kFbSlice * 2;
-  const int klen = a.key_len ? a.key_len[b] : a.Sk;
+  const int klen = a.key_len ? __builtin_amdgcn_readfirstlane(a.key_len[b]) : a.Sk;      // (a loaded value is "divergent" to the compiler: make it scalar)
   const float sl2 = a.scale * kLog2e;
-  const bool key_mask = a.causal || key0 + kFbKeys > klen || key0 + kFbKeys > a.Sk;      // block-uniform
+  const bool key_mask = a.causal || key0 + kFbKeys > klen || key0 + kFbKeys > a.Sk;      // block-uniform, in a scalar register
 
   // ---- staging: the K image once; Q | dO | statistics of slice j into ring slot j & 1
   const int lrow = lane >> 4, lchunk = lane & 15;
@@ -150,6 +177,11 @@ __global__ __launch_bounds__(kFbThreads, 1) void attn_bwd_fused_kernel(FusedArgs
   }
   auto issue_slice = [&](int j) {
     unsigned char* slot = smem + kFbOffT + (j & 1) * kFbTile;
+    // the lane's part of the source addresses is recomputed per slice: hoisted out of the loop it would sit in (or be spilled from) registers
+    // the whole time (cdna_hip_programming.md, attention prefill pitfalls)
+    int lane_o = lane;
+    asm volatile("" : "+v"(lane_o));
+    const int lrow = lane_o >> 4, lchunk = lane_o & 15;
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
       const int g = 4 * wave + i, rg = g & 7, row = 4 * rg + lrow;            // g 0..7: Q, 8..15: dO (wave-uniform)
@@ -161,7 +193,7 @@ __global__ __launch_bounds__(kFbThreads, 1) void attn_bwd_fused_kernel(FusedArgs
                                        (__attribute__((address_space(3))) void*)(slot + g * 1024), 16, 0, 0);
     }
     if (wave == 3)                                                // 64 lanes x 4 bytes = the slice's 32 x {nl, nd}
-      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(stat_g + j * kFbSlice * 2 + lane),
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(stat_g + j * kFbSlice * 2 + lane_o),
                                        (__attribute__((address_space(3))) void*)(smem + kFbOffS + (j & 1) * 256), 4, 0, 0);
   };
   issue_slice(0);
@@ -192,7 +224,7 @@ __global__ __launch_bounds__(kFbThreads, 1) void attn_bwd_fused_kernel(FusedArgs
   // Addresses come from two lane constants by XOR: the swizzle is an XOR of address bits 4..7, so the k-step / d-block enters as
   // `^ 32 s` / `^ 64 db` (attention.hip, dK/dV kernel).
   const unsigned smem_base = lds_off(smem);
-  const unsigned rowbase = smem_base + static_cast<unsigned>(256 * r + 16 * (h ^ (((r & 3) << 2) | ((r >> 2) & 3))));
+  unsigned rowbase = smem_base + static_cast<unsigned>(256 * r + 16 * (h ^ (((r & 3) << 2) | ((r >> 2) & 3))));
   unsigned trbase, xbase;
   {
     const int i = lane & 15, g4 = (lane >> 4) & 1, row = 4 * h + (i >> 2);
@@ -206,220 +238,420 @@ __global__ __launch_bounds__(kFbThreads, 1) void attn_bwd_fused_kernel(FusedArgs
   asm volatile("ds_read_b64_tr_b16 %0, %2 offset:%4\n\tds_read_b64_tr_b16 %1, %3 offset:%5"                                     \
                : "=&v"((F).lo), "=&v"((F).hi) : "v"(ADDR), "v"((ADDR) ^ 32u), "i"(IMM), "i"((IMM) + 512) : "memory")
 
+  // ---- dQ across the key-block workgroups of the (batch, head): a scheduled fan-in that never sits in the critical path.
+  // Every key block stores its dQ^T tile of slice j at the end of iteration j (write-through stores) and counts it in the tile's flag after
+  // the drain that iteration j + 1 performs anyway.  Slice jr is reduced by key block jr % nkb in nkb STEPS, one per iteration, starting at
+  // iteration jr + 3: step n brings key block n's tile into a landing zone in LDS by LDS-DMA at the top of the iteration (no registers, a
+  // whole iteration of latency hiding; its flag was read one iteration earlier, a slice barrier in between) and adds it to the running sum
+  // parked in LDS at the end: ((p0 + p1) + p2) + ... in key-block order, a fixed order, so dQ is bitwise reproducible.  The schedule is a
+  // pure function of the iteration number; what is still open after the last slice is finished behind the loop.
+  const int nkb = fa.nkb;
+  const bool handoff = nkb > 1 && !(kDbg & 1);
+  const long fl_bh = static_cast<long>(bh) * ns;
+  int pub_pending = -1;
+  unsigned fl = 0;                                                 // flag of the step of the coming iteration (wave-uniform)
+  auto flag_of = [&](int jj, int src) { return fa.flags + ((fl_bh + jj) * nkb + src) * 4 + wave; };
+  auto part_of = [&](int jj, int src) { return fa.part + (((fl_bh + jj) * nkb + src) * 4 + wave) * 1024; };
+  // the reduction step of (virtual) iteration i is slice jr = kb + nkb * floor((i - 3 - kb) / nkb), key block n = (i - 3 - kb) mod nkb (none while
+  // i < 3 + kb or once jr >= ns); kept as a pair that advances by one step per iteration -- no divisions in the loop
+  int cur_jr = kb, cur_n = -(3 + kb);                              // cur_n < 0: the schedule has not started yet
+  auto advance = [&](int& jr, int& n) {
+    if (++n == nkb) { n = 0; jr += nkb; }
+  };
+  auto valid = [&](int jr, int n) { return handoff && n >= 0 && jr < ns; };
+  auto land = [&](int jr, int n) {                                 // this wave's quarter of key block n's tile -> the landing zone (L1 bypassed)
+    int lane_o = lane;
+    asm volatile("" : "+v"(lane_o));
+    const float* src = part_of(jr, n) + lane_o * 4;
+#pragma unroll
+    for (int g = 0; g < 4; ++g)
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + g * 256),
+                                       (__attribute__((address_space(3))) void*)(smem + kFbOffLand + wave * 4096 + g * 1024), 16, 0, 16);
+  };
+  auto wait_flag = [&](int jr, int n) {                            // a tile that had not been published when its flag was prefetched (rare)
+    unsigned spins = 0, f = 0;
+    for (;;) {
+      if (lane == 0) f = __hip_atomic_load(flag_of(jr, n), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      f = __builtin_amdgcn_readfirstlane(f);
+      if (f != 0u) break;
+      if (++spins > kFbSpinLimit) {                               // never in a healthy launch: report and carry on instead of hanging the GPU
+        if (lane == 0) atomicAdd(fa.flags + static_cast<long>(a.B) * a.H * ns * nkb * 4, 1u);
+        break;
+      }
+      __builtin_amdgcn_s_sleep(8);
+    }
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+  };
+  auto store_dq = [&](const f32x16& t, int jj) {                   // scale, round, store this wave's 32 d of slice jj's rows
+    int lane_o = lane;                                            // (per-lane address parts recomputed here, not carried through the loop)
+    asm volatile("" : "+v"(lane_o));
+    const int qi = jj * kFbSlice + (lane_o & 31);
+    if (qi < a.Sq) {                                              // lanes q and q + 32 own the same row: they skip together
+      unsigned short* p = a.dq + (static_cast<long>(b) * a.Sq + qi) * a.ldq + head * kDh + 32 * wave + 8 * (lane_o >> 5);
+#pragma unroll
+      for (int g = 0; g < 4; g += 2) {
+        unsigned ax = pack2(t[4 * g + 0] * a.scale, t[4 * g + 1] * a.scale), ay = pack2(t[4 * g + 2] * a.scale, t[4 * g + 3] * a.scale);
+        unsigned bx = pack2(t[4 * g + 4] * a.scale, t[4 * g + 5] * a.scale), by = pack2(t[4 * g + 6] * a.scale, t[4 * g + 7] * a.scale);
+        const auto rx = __builtin_amdgcn_permlane32_swap(ax, bx, false, false);
+        const auto ry = __builtin_amdgcn_permlane32_swap(ay, by, false, false);
+        *reinterpret_cast<uint4*>(p + 8 * g) = make_uint4(rx[0], ry[0], rx[1], ry[1]);
+      }
+    }
+  };
+  const unsigned stash_a = smem_base + static_cast<unsigned>(kFbOffStash + wave * 4096 + lane * 16);
+  auto add_step = [&](int jr, int n) {                             // running sum (+)= landed tile; the last step stores dQ
+    f32x4 o[4], q4[4];
+#pragma unroll
+    for (int g = 0; g < 4; ++g) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(o[g]) : "v"(stash_a), "i"(4 * 4096 + 1024 * g) : "memory");
+    if (n > 0) {
+#pragma unroll
+      for (int g = 0; g < 4; ++g) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(q4[g]) : "v"(stash_a), "i"(1024 * g) : "memory");
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_sched_barrier(0);
+    if (n > 0) {
+#pragma unroll
+      for (int g = 0; g < 4; ++g) o[g] = q4[g] + o[g];
+    }
+    if (n == nkb - 1) {
+      f32x16 t;
+#pragma unroll
+      for (int i = 0; i < 16; ++i) t[i] = o[i >> 2][i & 3];
+      store_dq(t, jr);
+    } else {
+#pragma unroll
+      for (int g = 0; g < 4; ++g) asm volatile("ds_write_b128 %0, %1 offset:%2" :: "v"(stash_a), "v"(o[g]), "i"(1024 * g) : "memory");
+    }
+  };
+
+#define ADT_STAMP(K)                                                                                                      \
+  if ((kDbg & 32) && j == 12 && wave == 0 && blockIdx.x == 600) {                                                        \
+    __builtin_amdgcn_sched_barrier(0);                                                                                    \
+    const unsigned long long tnow = __builtin_amdgcn_s_memtime();                                                         \
+    if (lane == 0) fa.stamps[K] = tnow;                                                                                   \
+    __builtin_amdgcn_sched_barrier(0);                                                                                    \
+  }
+  // The slice loop exists twice: key blocks that need the masked form of the arithmetic (causal, padded or partial key block) and interior
+  // ones; the choice is per workgroup, and a run-time flag inside the loop costs two taken branches per pair of elements.
+  auto run_slices = [&](auto masked_tag) {
+  constexpr bool kMasked = decltype(masked_tag)::value;
   for (int j = 0; j < ns; ++j) {
+    asm volatile("" : "+v"(rowbase), "+v"(trbase), "+v"(xbase));    // keep the per-k-step / per-d-block addresses derived from these out of loop-invariant registers
+    const int sjr = cur_jr, sn = cur_n;
+    const bool step = valid(sjr, sn);                             // block-uniform
+    int njr = cur_jr, nn = cur_n;
+    advance(njr, nn);
+    bool late = false;
+    if (step) {
+      if (sn == kb || fl != 0u) land(sjr, sn);                    // own tile: drained two iterations ago; others: flag seen last iteration
+      else late = true;
+    }
+    const bool nstep = valid(njr, nn) && nn != kb;
+    unsigned fv = 0;
+    if (nstep && lane == 0) fv = __hip_atomic_load(flag_of(njr, nn), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     if (j + 1 < ns) issue_slice(j + 1);
     const unsigned slot = static_cast<unsigned>(kFbOffT + (j & 1) * kFbTile);
     const unsigned stat_a = smem_base + static_cast<unsigned>(kFbOffS + (j & 1) * 256 + 16 * h);       // + 32 g: queries 8 g + 4 h .. + 3
-    unsigned char* xs = smem + kFbOffX + (j & 1) * kFbX;
-#pragma unroll
-    for (int blk = 0; blk < 2; ++blk) {
-      const int krow = 64 * wave + 32 * blk + r;                 // row of the K image = key of this lane inside the workgroup
-      const int ki = key0 + krow;
-      // ---- S' = Q K^T - lse / scale, dP = dO V^T: operands through a ring of two k-step units
-      f32x16 st, dp;
-#pragma unroll
-      for (int i = 0; i < 16; ++i) { st[i] = 0.f; dp[i] = 0.f; }
-      if (!(fa.dbg & 8)) {
-        f32x4 c[4];
-#pragma unroll
-        for (int g = 0; g < 4; ++g) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(c[g]) : "v"(stat_a), "i"(32 * g) : "memory");
-        const unsigned tq_a = rowbase + slot, kr_a = rowbase + static_cast<unsigned>((64 * wave + 32 * blk) * 256);
-        bf16x8 fq[2], fd[2], fk[2];
-#define ADT_UNIT(U, S)                                                                                                          \
-        asm volatile("ds_read_b128 %0, %3\n\tds_read_b128 %1, %3 offset:8192\n\tds_read_b128 %2, %4"                            \
-                     : "=&v"(fq[U]), "=&v"(fd[U]), "=&v"(fk[U])                                                                  \
-                     : "v"(tq_a ^ static_cast<unsigned>(32 * (S))), "v"(kr_a ^ static_cast<unsigned>(32 * (S))) : "memory")
-        ADT_UNIT(0, 0); ADT_UNIT(1, 1);
-        asm volatile("s_waitcnt lgkmcnt(6)" ::: "memory");       // the four statistics reads are back (in order)
-#pragma unroll
-        for (int i = 0; i < 16; ++i) { st[i] = c[i >> 2][i & 3]; dp[i] = 0.f; }
-#pragma unroll
-        for (int s = 0; s < 8; ++s) {
-          if (s < 7) asm volatile("s_waitcnt lgkmcnt(3)" ::: "memory");
-          else asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-          __builtin_amdgcn_sched_barrier(0);
-          st = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fq[s & 1], fk[s & 1], st, 0, 0, 0);
-          dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fd[s & 1], vf[blk][s], dp, 0, 0, 0);
-          __builtin_amdgcn_sched_barrier(0);
-          if (s + 2 < 8) {
-            if (s & 1) ADT_UNIT(1, s + 2);
-            else ADT_UNIT(0, s + 2);
-          }
-        }
-#undef ADT_UNIT
-      }
-      __builtin_amdgcn_sched_barrier(0);
-      // -delta of the lane's 16 query rows, and the first k-step's transposed dO / Q fragments, while the arithmetic runs
-      f32x4 ndv[4];
-#pragma unroll
-      for (int g = 0; g < 4; ++g) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(ndv[g]) : "v"(stat_a), "i"(128 + 32 * g) : "memory");
-      // keep masks: one 64-bit lane mask per accumulator register (the two lanes of a key pair share every hash: dropout.h)
-      uint64_t km[16];
-      if (kDrop) {
-        const uint64_t even = 0x5555555555555555ull, odd = 0xaaaaaaaaaaaaaaaaull;
-        const unsigned headpair = static_cast<unsigned>(static_cast<uint64_t>(bh) * a.Sq * sk_pairs) + static_cast<unsigned>(ki >> 1);
-        const unsigned vbq = headpair + static_cast<unsigned>(j * kFbSlice + 16 * static_cast<int>(par) + 4 * h) * sk_pairs;
-#pragma unroll
-        for (int e = 0; e < 8; ++e) {
-          const unsigned hh = mix32((vbq + static_cast<unsigned>((e & 3) + 8 * (e >> 2)) * sk_pairs) ^ key2);
-          const uint64_t c_lo = __builtin_amdgcn_ballot_w64((hh << 16) >= thr16);       // decision of the pair's even key
-          const uint64_t c_hi = __builtin_amdgcn_ballot_w64(hh >= thr16);               // ... of its odd key
-          km[e] = (c_lo & even) | ((c_hi & even) << 1);
-          km[e + 8] = (c_hi & odd) | ((c_lo & odd) >> 1);
-        }
-      }
-      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-      __builtin_amdgcn_sched_barrier(0);
-      unsigned hp[8], hs[8];
-#pragma unroll
-      for (int m = 0; m < 8; ++m) {
-        float pv[2];
-#pragma unroll
-        for (int e = 0; e < 2; ++e) {
-          const int i = 2 * m + e;
-          if (key_mask) {
-            const int qi = j * kFbSlice + acc_row(i, h);
-            const float tt = fmaf(st[i], sl2, mask_add(a, qi, ki, klen) * kLog2e);
-            pv[e] = ki < a.Sk ? __builtin_amdgcn_exp2f(tt) : 0.f;
-          } else {
-            pv[e] = __builtin_amdgcn_exp2f(st[i] * sl2);
-          }
-        }
-        float pd[2], ds[2];
+    unsigned char* xs = smem + kFbOffX;
+    // ---- the slice as four phases, software-pipelined across the wave's two 32-key blocks so that the matrix pipe and the vector ALUs
+    // work side by side (one wave per SIMD: nothing else would fill the other pipe):
+    //   1  S', dP of block 0                       beside  the dropout hashes of both blocks
+    //   2  S', dP of block 1                       beside  the softmax / dS arithmetic of block 0
+    //   3  dV^T, dK^T of block 0                   beside  the arithmetic of block 1
+    //   4  dV^T, dK^T of block 1
+    // sched_barrier(0) pins the interleave: one pair of MFMAs, then one pair of elements' arithmetic (or one hash).
+    f32x16 st0, dp0, st1, dp1;
+    unsigned hp0[8], hs0[8], hp1[8], hs1[8];
+    uint64_t km0[16], km1[16];
+    f32x4 ndv[4];
+    bf16x8 fq[3], fd[3], fk[3];                                   // operand ring of the chains: two k-steps ahead
+    const unsigned tq_a = rowbase + slot;
+    const unsigned kr_a0 = rowbase + static_cast<unsigned>((64 * wave) * 256), kr_a1 = kr_a0 + 32 * 256;
+    const int krow0 = 64 * wave + r, ki0 = key0 + krow0, ki1 = ki0 + 32;
+#define ADT_UNIT(U, S, KR)                                                                                                      \
+    asm volatile("ds_read_b128 %0, %3\n\tds_read_b128 %1, %3 offset:8192\n\tds_read_b128 %2, %4"                                \
+                 : "=&v"(fq[U]), "=&v"(fd[U]), "=&v"(fk[U])                                                                      \
+                 : "v"(tq_a ^ static_cast<unsigned>(32 * (S))), "v"((KR) ^ static_cast<unsigned>(32 * (S))) : "memory")
+    // chain prologue: the row constants as the initial accumulator, the first two operand units
+#define ADT_CHAIN_BEGIN(ST, DP, KR)                                                                                             \
+    {                                                                                                                           \
+      f32x4 c[4];                                                                                                               \
+      _Pragma("unroll") for (int g = 0; g < 4; ++g)                                                                             \
+        asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(c[g]) : "v"(stat_a), "i"(32 * g) : "memory");                       \
+      ADT_UNIT(0, 0, KR); ADT_UNIT(1, 1, KR); ADT_UNIT(2, 2, KR);                                                               \
+      asm volatile("s_waitcnt lgkmcnt(9)" ::: "memory");                                                                        \
+      _Pragma("unroll") for (int i = 0; i < 16; ++i) { ST[i] = c[i >> 2][i & 3]; DP[i] = 0.f; }                                 \
+      mfma_srcc_ready(ST, DP);                                                                                                  \
+    }
+#define ADT_CHAIN_STEP(S, ST, DP, KR, VF)                                                                                       \
+    if ((S) < 6) asm volatile("s_waitcnt lgkmcnt(6)" ::: "memory");                                                             \
+    else if ((S) < 7) asm volatile("s_waitcnt lgkmcnt(3)" ::: "memory");                                                        \
+    else asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                                                                     \
+    __builtin_amdgcn_sched_barrier(0);                                                                                          \
+    mfma_vgpr(ST, fq[(S) % 3], fk[(S) % 3]);                                                                                    \
+    mfma_vgpr(DP, fd[(S) % 3], VF[S]);                                                                                          \
+    __builtin_amdgcn_sched_barrier(0);                                                                                          \
+    if ((S) + 3 < 8) {                                                                                                          \
+      if ((S) % 3 == 0) ADT_UNIT(0, (S) + 3, KR);                                                                               \
+      else if ((S) % 3 == 1) ADT_UNIT(1, (S) + 3, KR);                                                                          \
+      else ADT_UNIT(2, (S) + 3, KR);                                                                                            \
+    }
+    // keep masks: one 64-bit lane mask per accumulator register (the two lanes of a key pair share every hash: dropout.h); hash e of a
+    // block gives the masks of its accumulator registers e and e + 8
+    const unsigned headpair = static_cast<unsigned>(static_cast<uint64_t>(bh) * a.Sq * sk_pairs) + static_cast<unsigned>(ki0 >> 1);
+    const unsigned vbq = headpair + static_cast<unsigned>(j * kFbSlice + 16 * static_cast<int>(par) + 4 * h) * sk_pairs;
+    auto hash_masks = [&](int e, unsigned pair0, uint64_t (&km)[16]) {
+      const uint64_t even = 0x5555555555555555ull, odd = 0xaaaaaaaaaaaaaaaaull;
+      const unsigned hh = mix32((pair0 + static_cast<unsigned>((e & 3) + 8 * (e >> 2)) * sk_pairs) ^ key2);
+      const uint64_t c_lo = __builtin_amdgcn_ballot_w64((hh << 16) >= thr16);       // decision of the pair's even key
+      const uint64_t c_hi = __builtin_amdgcn_ballot_w64(hh >= thr16);               // ... of its odd key
+      km[e] = (c_lo & even) | ((c_hi & even) << 1);
+      km[e + 8] = (c_hi & odd) | ((c_lo & odd) >> 1);
+    };
+    // softmax / dropout / dS arithmetic of elements 2 m, 2 m + 1 of a block: P (dropped) and dS, packed to bf16 for the second products
+    // lane constants of the masked form: the key-padding term, the causal term, the validity of this lane's keys, and the first query row
+    // of the slice that may see the key (causal: row q of the slice is masked iff q < key - slice start)
+    const float cau2 = a.causal ? a.mask_value * kLog2e : 0.f;
+    const float pad2_0 = ki0 >= klen ? a.mask_value * kLog2e : 0.f, pad2_1 = ki1 >= klen ? a.mask_value * kLog2e : 0.f;
+    const float kval0 = ki0 < a.Sk ? 1.f : 0.f, kval1 = ki1 < a.Sk ? 1.f : 0.f;
+    const int qrel0 = ki0 - j * kFbSlice, qrel1 = qrel0 + 32;
+    auto arith_pair = [&](int m, const f32x16& st, const f32x16& dp, const uint64_t (&km)[16], float pad2, float kval, int qrel, unsigned (&hp)[8],
+                          unsigned (&hs)[8]) {
+      float pv[2];
+      if (kMasked) {                                             // compile-time: interior key blocks take the two-instruction form
 #pragma unroll
         for (int e = 0; e < 2; ++e) {
           const int i = 2 * m + e;
-          const float ndi = ndv[i >> 2][i & 3];
-          if (kDrop) {
-            float ks;
-            asm("v_cndmask_b32_e64 %0, 0, %1, %2" : "=v"(ks) : "v"(a.drop.inv_keep), "s"(km[i]));
-            pd[e] = pv[e] * ks;
-            ds[e] = pv[e] * fmaf(dp[i], ks, ndi);
-          } else {
-            pd[e] = pv[e];
-            ds[e] = pv[e] * (dp[i] + ndi);
-          }
+          const float madd = pad2 + (acc_row(i, h) < qrel ? cau2 : 0.f);
+          pv[e] = __builtin_amdgcn_exp2f(fmaf(st[i], sl2, madd)) * kval;
         }
-        hp[m] = pack2(pd[0], pd[1]);
-        hs[m] = pack2(ds[0], ds[1]);
+      } else {
+#pragma unroll
+        for (int e = 0; e < 2; ++e) pv[e] = __builtin_amdgcn_exp2f(st[2 * m + e] * sl2);
       }
-      __builtin_amdgcn_sched_barrier(0);
-      // dS^T of this block to LDS for the dQ product (read by every wave after the slice's barrier)
+      float pd[2], ds[2];
+#pragma unroll
+      for (int e = 0; e < 2; ++e) {
+        const int i = 2 * m + e;
+        const float ndi = ndv[i >> 2][i & 3];
+        if (kDrop) {
+          float ks;
+          asm("v_cndmask_b32_e64 %0, 0, %1, %2" : "=v"(ks) : "v"(a.drop.inv_keep), "s"(km[i]));
+          pd[e] = pv[e] * ks;
+          ds[e] = pv[e] * fmaf(dp[i], ks, ndi);
+        } else {
+          pd[e] = pv[e];
+          ds[e] = pv[e] * (dp[i] + ndi);
+        }
+      }
+      hp[m] = pack2(pd[0], pd[1]);
+      hs[m] = pack2(ds[0], ds[1]);
+    };
+    auto write_ds = [&](int krow, const unsigned (&hs)[8]) {    // dS^T of a block to LDS for the dQ product
 #pragma unroll
       for (int g = 0; g < 4; ++g) {
         const uint2 w2 = make_uint2(hs[2 * g], hs[2 * g + 1]);
         asm volatile("ds_write_b64 %0, %1" :: "v"(lds_off(xs) + x_off(krow, g) + 8 * h), "v"(w2) : "memory");
       }
-      // ---- dV^T += dO^T P, dK^T += Q^T dS: per k-step of 16 queries, four d-blocks
-      if (!(fa.dbg & 4)) {
-        const unsigned trb = trbase + slot;
-        union { unsigned u[4]; bf16x8 v; } pf0, pf1, dsf0, dsf1;
+    };
+
+    ADT_STAMP(0)
+    // ---- phase 1: S', dP of BOTH blocks in one interleaved chain: four accumulators take turns (a product waits ~100 cycles for the
+    // previous one on the same VGPR accumulator, so two chains alone run at half rate), the Q / dO fragments are read once for both blocks
 #pragma unroll
-        for (int e = 0; e < 4; ++e) { pf0.u[e] = hp[e]; pf1.u[e] = hp[4 + e]; dsf0.u[e] = hs[e]; dsf1.u[e] = hs[4 + e]; }
-        TrFrag fo[4], fq[4];
+    for (int i = 0; i < 16; ++i) { st0[i] = 0.f; dp0[i] = 0.f; st1[i] = 0.f; dp1[i] = 0.f; }
+    if (!(kDbg & 8)) {
+      bf16x8 fk1[3];
+#define ADT_UNIT2(U, S)                                                                                                         \
+      asm volatile("ds_read_b128 %0, %4\n\tds_read_b128 %1, %4 offset:8192\n\tds_read_b128 %2, %5\n\tds_read_b128 %3, %5 offset:8192" \
+                   : "=&v"(fq[U]), "=&v"(fd[U]), "=&v"(fk[U]), "=&v"(fk1[U])                                                     \
+                   : "v"(tq_a ^ static_cast<unsigned>(32 * (S))), "v"(kr_a0 ^ static_cast<unsigned>(32 * (S))) : "memory")
 #pragma unroll
-        for (int db = 0; db < 4; ++db) {
-          ADT_TR2(fo[db], trb ^ static_cast<unsigned>(64 * db), 8192);
-          ADT_TR2(fq[db], trb ^ static_cast<unsigned>(64 * db), 0);
-        }
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      for (int g = 0; g < 4; ++g) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(ndv[g]) : "v"(stat_a), "i"(128 + 32 * g) : "memory");
+      {
+        f32x4 c[4];
+#pragma unroll
+        for (int g = 0; g < 4; ++g) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(c[g]) : "v"(stat_a), "i"(32 * g) : "memory");
+        ADT_UNIT2(0, 0);
+        asm volatile("s_waitcnt lgkmcnt(4)" ::: "memory");        // the eight statistics reads are back (in order)
+        ADT_UNIT2(1, 1); ADT_UNIT2(2, 2);
+#pragma unroll
+        for (int i = 0; i < 16; ++i) { st0[i] = c[i >> 2][i & 3]; st1[i] = c[i >> 2][i & 3]; }
+        mfma_srcc_ready(st0, dp0);
+        mfma_srcc_ready(st1, dp1);
+      }
+#pragma unroll
+      for (int s = 0; s < 8; ++s) {
+        if (s < 6) asm volatile("s_waitcnt lgkmcnt(8)" ::: "memory");
+        else if (s < 7) asm volatile("s_waitcnt lgkmcnt(4)" ::: "memory");
+        else asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-        for (int db = 0; db < 4; ++db) {                    // the registers of k-step 0's fragments take k-step 1's as soon as their MFMA has issued
-          dv[blk][db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(tr_get(fo[db]), pf0.v, dv[blk][db], 0, 0, 0);
-          dk[blk][db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(tr_get(fq[db]), dsf0.v, dk[blk][db], 0, 0, 0);
+        mfma_vgpr(st0, fq[s % 3], fk[s % 3]);
+        mfma_vgpr(st1, fq[s % 3], fk1[s % 3]);
+        mfma_vgpr(dp0, fd[s % 3], vf[0][s]);
+        mfma_vgpr(dp1, fd[s % 3], vf[1][s]);
+        __builtin_amdgcn_sched_barrier(0);
+        if (s + 3 < 8) {
+          if (s % 3 == 0) ADT_UNIT2(0, s + 3);
+          else if (s % 3 == 1) ADT_UNIT2(1, s + 3);
+          else ADT_UNIT2(2, s + 3);
+        }
+        if (kDrop) {
+          hash_masks(s, vbq, km0);
+          hash_masks(s, vbq + 16u, km1);                         // block 1: keys + 32 = pairs + 16
           __builtin_amdgcn_sched_barrier(0);
-          ADT_TR2(fo[db], trb ^ static_cast<unsigned>(64 * db), 8192 + 16 * 256);
-          ADT_TR2(fq[db], trb ^ static_cast<unsigned>(64 * db), 16 * 256);
-        }
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-        for (int db = 0; db < 4; ++db) {
-          dv[blk][db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(tr_get(fo[db]), pf1.v, dv[blk][db], 0, 0, 0);
-          dk[blk][db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(tr_get(fq[db]), dsf1.v, dk[blk][db], 0, 0, 0);
         }
       }
+#undef ADT_UNIT2
+      mfma_settle(st0, dp0);
+      mfma_settle(st1, dp1);
       __builtin_amdgcn_sched_barrier(0);
+      ADT_STAMP(1)
+    } else {
+#pragma unroll
+      for (int g = 0; g < 4; ++g) ndv[g] = f32x4{0.f, 0.f, 0.f, 0.f};
     }
+    // ---- phase 2: the arithmetic of block 0
+#pragma unroll
+    for (int m = 0; m < 8; ++m) arith_pair(m, st0, dp0, km0, pad2_0, kval0, qrel0, hp0, hs0);
+    __builtin_amdgcn_sched_barrier(0);
+    // the dS^T image is single-buffered: every wave must have finished the previous slice's dQ product (they have, long ago: this barrier
+    // does not wait in practice)
+    ADT_STAMP(2)
+    asm volatile("s_barrier" ::: "memory");
+    write_ds(krow0, hs0);
+    ADT_STAMP(3)
+    // ---- phase 3 and 4: dV^T += dO^T P, dK^T += Q^T dS per k-step of 16 queries and d-block; block 1's arithmetic rides on block 0's products
+    const unsigned trb = trbase + slot;
+#define ADT_DVDK(BLK, HP, HS, WITH_ARITH)                                                                                       \
+    {                                                                                                                           \
+      union { unsigned u[4]; bf16x8 v; } pf0, pf1, dsf0, dsf1;                                                                  \
+      _Pragma("unroll") for (int e = 0; e < 4; ++e) { pf0.u[e] = HP[e]; pf1.u[e] = HP[4 + e]; dsf0.u[e] = HS[e]; dsf1.u[e] = HS[4 + e]; } \
+      TrFrag fo[4], fqq[4];                                                                                                     \
+      _Pragma("unroll") for (int db = 0; db < 4; ++db) {                                                                        \
+        ADT_TR2(fo[db], trb ^ static_cast<unsigned>(64 * db), 8192);                                                            \
+        ADT_TR2(fqq[db], trb ^ static_cast<unsigned>(64 * db), 0);                                                              \
+      }                                                                                                                         \
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                                                                        \
+      __builtin_amdgcn_sched_barrier(0);                                                                                        \
+      _Pragma("unroll") for (int db = 0; db < 4; ++db) {      /* k-step 0's fragment registers take k-step 1's once their MFMA has issued */ \
+        mfma_acc(dv[BLK][db], tr_get(fo[db]), pf0.v);                                                                          \
+        mfma_acc(dk[BLK][db], tr_get(fqq[db]), dsf0.v);                                                                        \
+        __builtin_amdgcn_sched_barrier(0);                                                                                      \
+        ADT_TR2(fo[db], trb ^ static_cast<unsigned>(64 * db), 8192 + 16 * 256);                                                 \
+        ADT_TR2(fqq[db], trb ^ static_cast<unsigned>(64 * db), 16 * 256);                                                       \
+        if (WITH_ARITH) { arith_pair(db, st1, dp1, km1, pad2_1, kval1, qrel1, hp1, hs1); __builtin_amdgcn_sched_barrier(0); }                    \
+      }                                                                                                                         \
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                                                                        \
+      __builtin_amdgcn_sched_barrier(0);                                                                                        \
+      _Pragma("unroll") for (int db = 0; db < 4; ++db) {                                                                        \
+        mfma_acc(dv[BLK][db], tr_get(fo[db]), pf1.v);                                                                          \
+        mfma_acc(dk[BLK][db], tr_get(fqq[db]), dsf1.v);                                                                        \
+        if (WITH_ARITH) { __builtin_amdgcn_sched_barrier(0); arith_pair(4 + db, st1, dp1, km1, pad2_1, kval1, qrel1, hp1, hs1); __builtin_amdgcn_sched_barrier(0); } \
+      }                                                                                                                         \
+    }
+    if (!(kDbg & 4)) {
+      ADT_DVDK(0, hp0, hs0, true)
+    } else {
+#pragma unroll
+      for (int m = 0; m < 8; ++m) arith_pair(m, st1, dp1, km1, pad2_1, kval1, qrel1, hp1, hs1);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    ADT_STAMP(4)
+    write_ds(krow0 + 32, hs1);
+    if (!(kDbg & 4)) {
+      ADT_DVDK(1, hp1, hs1, false)
+    }
+    __builtin_amdgcn_sched_barrier(0);
+#undef ADT_DVDK
+#undef ADT_CHAIN_STEP
+#undef ADT_CHAIN_BEGIN
+#undef ADT_UNIT
+    ADT_STAMP(5)
     asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");   // the next slice's tiles have landed; this wave's dS^T writes are done
+    ADT_STAMP(6)
     asm volatile("s_barrier" ::: "memory");                       // ... and every wave's dS^T of this slice is in LDS
+    ADT_STAMP(7)
+    if (pub_pending >= 0) {                                       // the tile stored at the end of the last iteration has left (drained above)
+      if (lane == 0) __hip_atomic_fetch_add(flag_of(pub_pending, kb), 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      pub_pending = -1;
+    }
+    fl = nstep ? static_cast<unsigned>(__builtin_amdgcn_readfirstlane(fv)) : 0u;
 
     // ---- dQ^T, d-block `wave`, over the workgroup's 256 keys (16 k-steps of 16 keys, two per wait)
     f32x16 dq;
 #pragma unroll
     for (int i = 0; i < 16; ++i) dq[i] = 0.f;
-    if (!(fa.dbg & 2)) {
-      const unsigned ka_a = trbase ^ static_cast<unsigned>(64 * wave), xb_a = xbase + static_cast<unsigned>(kFbOffX + (j & 1) * kFbX);
-      TrFrag ka[2], xb[2];
+    if (!(kDbg & 2)) {
+      f32x16 dq2;                                                 // two accumulation chains (even / odd k-steps): a product waits ~100 cycles for the previous one on the same VGPR accumulator
+#pragma unroll
+      for (int i = 0; i < 16; ++i) dq2[i] = 0.f;
+      mfma_srcc_ready(dq, dq2);
+      const unsigned ka_a = trbase ^ static_cast<unsigned>(64 * wave), xb_a = xbase + static_cast<unsigned>(kFbOffX);
+      TrFrag ka[4], xb[4];                                        // operand ring: three k-steps ahead of the product (one wave per SIMD: nobody else hides the LDS latency)
       ADT_TR2(ka[0], ka_a, 0);
       ADT_TRX(xb[0], xb_a, 0);
+      ADT_TR2(ka[1], ka_a, 4096);
+      ADT_TRX(xb[1], xb_a, 1024);
+      ADT_TR2(ka[2], ka_a, 2 * 4096);
+      ADT_TRX(xb[2], xb_a, 2 * 1024);
 #define ADT_DQ_STEP(KK)                                                                           \
-      if ((KK) + 1 < 16) {                                                                        \
-        ADT_TR2(ka[((KK) + 1) & 1], ka_a, ((KK) + 1) * 4096);                                     \
-        ADT_TRX(xb[((KK) + 1) & 1], xb_a, ((KK) + 1) * 1024);                                     \
+      if ((KK) + 3 < 16) {                                                                        \
+        ADT_TR2(ka[((KK) + 3) & 3], ka_a, ((KK) + 3) * 4096);                                     \
+        ADT_TRX(xb[((KK) + 3) & 3], xb_a, ((KK) + 3) * 1024);                                     \
+        asm volatile("s_waitcnt lgkmcnt(12)" ::: "memory");                                       \
+      } else if ((KK) + 2 < 16) {                                                                 \
+        asm volatile("s_waitcnt lgkmcnt(8)" ::: "memory");                                        \
+      } else if ((KK) + 1 < 16) {                                                                 \
         asm volatile("s_waitcnt lgkmcnt(4)" ::: "memory");                                        \
       } else {                                                                                    \
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                                        \
       }                                                                                           \
       __builtin_amdgcn_sched_barrier(0);                                                          \
-      dq = __builtin_amdgcn_mfma_f32_32x32x16_bf16(tr_get(ka[(KK) & 1]), tr_get(xb[(KK) & 1]), dq, 0, 0, 0);   \
+      if ((KK) & 1) mfma_vgpr(dq2, tr_get(ka[(KK) & 3]), tr_get(xb[(KK) & 3]));                   \
+      else mfma_vgpr(dq, tr_get(ka[(KK) & 3]), tr_get(xb[(KK) & 3]));                             \
       __builtin_amdgcn_sched_barrier(0);
       ADT_DQ_STEP(0) ADT_DQ_STEP(1) ADT_DQ_STEP(2) ADT_DQ_STEP(3) ADT_DQ_STEP(4) ADT_DQ_STEP(5) ADT_DQ_STEP(6) ADT_DQ_STEP(7)
       ADT_DQ_STEP(8) ADT_DQ_STEP(9) ADT_DQ_STEP(10) ADT_DQ_STEP(11) ADT_DQ_STEP(12) ADT_DQ_STEP(13) ADT_DQ_STEP(14) ADT_DQ_STEP(15)
 #undef ADT_DQ_STEP
+      mfma_settle(dq, dq2);
+#pragma unroll
+      for (int i = 0; i < 16; ++i) dq[i] += dq2[i];
     }
 
-    // ---- ordered hand-off of the running sum (this wave's 32 d x 32 q quarter of the slice's tile)
-    float* const mypart = fa.part + ((static_cast<long>(bh) * ns + j) * 4 + wave) * 1024;
-    unsigned* const myflag = fa.flags + (static_cast<long>(bh) * ns + j) * 4 + wave;
-    const bool handoff = !(fa.dbg & 1);
-    if (kb > 0 && handoff) {                                      // block-uniform
-      unsigned spins = 0;
-      for (;;) {
-        unsigned f = 0;
-        if (lane == 0) f = __hip_atomic_load(myflag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        f = __builtin_amdgcn_readfirstlane(f);
-        if (f == static_cast<unsigned>(kb)) break;
-        if (++spins > kFbSpinLimit) {                             // never in a healthy launch: report and carry on instead of hanging the GPU
-          if (lane == 0) atomicAdd(fa.flags + static_cast<long>(a.B) * a.H * ns * 4, 1u);
-          break;
-        }
-        __builtin_amdgcn_s_sleep(8);
+    ADT_STAMP(8)
+    // ---- this iteration's reduction step, then this slice's own tile
+    if (step) {
+      if (late) {
+        wait_flag(sjr, sn);
+        land(sjr, sn);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       }
-      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-#pragma unroll
-      for (int g = 0; g < 4; ++g) {
-        const f32x4 pvv = *reinterpret_cast<const f32x4*>(mypart + (g * 64 + lane) * 4);
-        dq[4 * g] += pvv[0]; dq[4 * g + 1] += pvv[1]; dq[4 * g + 2] += pvv[2]; dq[4 * g + 3] += pvv[3];
-      }
+      add_step(sjr, sn);
     }
-    if (kb + 1 < fa.nkb && handoff) {
+    if (!handoff) {
+      store_dq(dq, j);
+    } else {
       // write-through (sc1) 16-byte stores as compiler-visible buffer stores: an inline-asm store gets no hazard wait states before the
       // next instruction that overwrites its data registers
-      const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(mypart, 0, 4096, 0x00020000);
+      const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(part_of(j, kb), 0, 4096, 0x00020000);
+      int lane_s = lane;
+      asm volatile("" : "+v"(lane_s));
 #pragma unroll
       for (int g = 0; g < 4; ++g) {
         const u32x4 o = {__float_as_uint(dq[4 * g]), __float_as_uint(dq[4 * g + 1]), __float_as_uint(dq[4 * g + 2]), __float_as_uint(dq[4 * g + 3])};
-        __builtin_amdgcn_raw_buffer_store_b128(o, rsrc, (g * 64 + lane) * 16, 0, 16);      // aux 16 = sc1
+        __builtin_amdgcn_raw_buffer_store_b128(o, rsrc, (g * 64 + lane_s) * 16, 0, 16);    // aux 16 = sc1
       }
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-      if (lane == 0) __hip_atomic_store(myflag, static_cast<unsigned>(kb + 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    } else {
-      const int qi = j * kFbSlice + r;
-      if (qi < a.Sq) {                                            // lanes q and q + 32 own the same row: they skip together
-        unsigned short* p = a.dq + (static_cast<long>(b) * a.Sq + qi) * a.ldq + head * kDh + 32 * wave + 8 * h;
-#pragma unroll
-        for (int g = 0; g < 4; g += 2) {
-          unsigned ax = pack2(dq[4 * g + 0] * a.scale, dq[4 * g + 1] * a.scale), ay = pack2(dq[4 * g + 2] * a.scale, dq[4 * g + 3] * a.scale);
-          unsigned bx = pack2(dq[4 * g + 4] * a.scale, dq[4 * g + 5] * a.scale), by = pack2(dq[4 * g + 6] * a.scale, dq[4 * g + 7] * a.scale);
-          const auto rx = __builtin_amdgcn_permlane32_swap(ax, bx, false, false);
-          const auto ry = __builtin_amdgcn_permlane32_swap(ay, by, false, false);
-          *reinterpret_cast<uint4*>(p + 8 * g) = make_uint4(rx[0], ry[0], rx[1], ry[1]);
-        }
-      }
+      pub_pending = j;
     }
+    cur_jr = njr;
+    cur_n = nn;
+    ADT_STAMP(9)
   }
+  };
+  if (key_mask) run_slices(std::true_type{});
+  else run_slices(std::false_type{});
+#undef ADT_STAMP
 #undef ADT_TR2
 #undef ADT_TRX
 
@@ -429,6 +661,21 @@ __global__ __launch_bounds__(kFbThreads, 1) void attn_bwd_fused_kernel(FusedArgs
     store_transposed(dk[blk], a.scale, a.dk + static_cast<long>(b) * a.Sk * a.ldk + head * kDh, a.ldk, ki, a.Sk, lane);
     store_transposed(dv[blk], 1.0f, a.dv + static_cast<long>(b) * a.Sk * a.ldv + head * kDh, a.ldv, ki, a.Sk, lane);
   }
+  // ---- behind the last slice: publish the last tile, then the reduction steps that were still to come (synchronously)
+  if (handoff) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    if (pub_pending >= 0 && lane == 0) __hip_atomic_fetch_add(flag_of(pub_pending, kb), 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    for (;; advance(cur_jr, cur_n)) {
+      if (cur_n < 0) continue;
+      const int jr = cur_jr, n = cur_n;
+      if (jr >= ns) break;
+      if (n != kb) wait_flag(jr, n);
+      land(jr, n);
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      add_step(jr, n);
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    }
+  }
 }
 
 static size_t align256(size_t x) { return (x + 255) & ~static_cast<size_t>(255); }
@@ -437,9 +684,10 @@ static int fused_nkb(const adt_attn_desc* d) { return (d->k_len + kFbKeys - 1) /
 
 size_t attn_bwd_fused_workspace_bytes(const adt_attn_desc* d) {
   const size_t bh = static_cast<size_t>(d->batch) * d->heads, ns = static_cast<size_t>(fused_ns(d));
-  size_t bytes = align256(bh * ns * 4 * 4 + 16);                                  // flags (+ the give-up counter): zeroed every launch
+  const size_t nkb = static_cast<size_t>(fused_nkb(d));
+  size_t bytes = align256(bh * ns * nkb * 4 * 4 + 16) + 256;                      // flags (+ the give-up counter): zeroed every launch; + the experiment build's stamps at the very end
   bytes += align256(bh * ns * kFbSlice * 2 * 4);                                  // statistics
-  if (fused_nkb(d) > 1) bytes += align256(bh * ns * 4096 * 4);                    // running dQ sums
+  if (nkb > 1) bytes += align256(bh * ns * nkb * 4096 * 4);                       // every key block's dQ^T tiles
   return bytes;
 }
 
@@ -448,9 +696,17 @@ int launch_attn_bwd_fused(const adt_attn_desc* d, const AttnArgs& a, void* ws, s
   static thread_local int lds_done_for = -1;
   int dev = 0;
   ADT_HIP_TRY(hipGetDevice(&dev));
+#ifdef ADT_FB_EXPERIMENT
+#define ADT_FB_DBGS(X) X(0) X(1) X(2) X(3) X(4) X(7) X(8) X(15) X(16) X(32)
+#else
+#define ADT_FB_DBGS(X) X(0)
+#endif
   if (lds_done_for != dev) {
-    ADT_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(attn_bwd_fused_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, kFbLds));
-    ADT_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(attn_bwd_fused_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, kFbLds));
+#define ADT_FB_ATTR(N)                                                                                                                      \
+    ADT_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(attn_bwd_fused_kernel<false, N>), hipFuncAttributeMaxDynamicSharedMemorySize, kFbLds)); \
+    ADT_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(attn_bwd_fused_kernel<true, N>), hipFuncAttributeMaxDynamicSharedMemorySize, kFbLds));
+    ADT_FB_DBGS(ADT_FB_ATTR)
+#undef ADT_FB_ATTR
     lds_done_for = dev;
   }
   FusedArgs fa{};
@@ -460,7 +716,8 @@ int launch_attn_bwd_fused(const adt_attn_desc* d, const AttnArgs& a, void* ws, s
   { const char* e = getenv("ADT_FB_DBG"); fa.dbg = e ? atoi(e) : 0; }
   const size_t bh = static_cast<size_t>(d->batch) * d->heads, ns = static_cast<size_t>(fa.ns);
   unsigned char* p = static_cast<unsigned char*>(ws);
-  const size_t flag_bytes = align256(bh * ns * 4 * 4 + 16);
+  const size_t flag_bytes = align256(bh * ns * static_cast<size_t>(fa.nkb) * 4 * 4 + 16);
+  fa.stamps = reinterpret_cast<unsigned long long*>(static_cast<unsigned char*>(ws) + attn_bwd_fused_workspace_bytes(d) - 128);
   fa.flags = reinterpret_cast<unsigned*>(p);
   p += flag_bytes;
   float* stats = reinterpret_cast<float*>(p);
@@ -472,9 +729,18 @@ int launch_attn_bwd_fused(const adt_attn_desc* d, const AttnArgs& a, void* ws, s
   hipLaunchKernelGGL(attn_bwd_stats_kernel, dim3(static_cast<unsigned>((items + 15) / 16)), dim3(256), 0, st, a, stats, fa.ns);
   const long n_tiles = static_cast<long>(fa.nkb) * static_cast<long>(bh);
   for (int x = 0; x < 8; ++x) fa.sched_total[x] = static_cast<unsigned>(n_tiles / 8 + (x < n_tiles % 8 ? 1 : 0));
+  if (fa.dbg & 16) fa.sched_total[0] = static_cast<unsigned>(n_tiles);
   if (int rc = sched_counters(st, &fa.sched)) return rc;
-  if (a.drop.on()) hipLaunchKernelGGL(attn_bwd_fused_kernel<true>, dim3(static_cast<unsigned>(n_tiles)), dim3(kFbThreads), kFbLds, st, fa);
-  else hipLaunchKernelGGL(attn_bwd_fused_kernel<false>, dim3(static_cast<unsigned>(n_tiles)), dim3(kFbThreads), kFbLds, st, fa);
+  bool launched = false;
+#define ADT_FB_LAUNCH(N)                                                                                                                    \
+  if (!launched && fa.dbg == N) {                                                                                                           \
+    launched = true;                                                                                                                        \
+    if (a.drop.on()) hipLaunchKernelGGL((attn_bwd_fused_kernel<true, N>), dim3(static_cast<unsigned>(n_tiles)), dim3(kFbThreads), kFbLds, st, fa);   \
+    else hipLaunchKernelGGL((attn_bwd_fused_kernel<false, N>), dim3(static_cast<unsigned>(n_tiles)), dim3(kFbThreads), kFbLds, st, fa);     \
+  }
+  ADT_FB_DBGS(ADT_FB_LAUNCH)
+#undef ADT_FB_LAUNCH
+  if (!launched) return set_error(ADT_EINVAL, "adt_attn_bwd: ADT_FB_DBG value not built (experiment build only)");
   ADT_HIP_TRY(hipGetLastError());
   return ADT_OK;
 }

@@ -55,6 +55,12 @@ def main():
                 a = run("split", q, kk, v, o, dout, lse, B, H, Sq, Sk, scale, causal, key_len, drop)
                 f = run("fused", q, kk, v, o, dout, lse, B, H, Sq, Sk, scale, causal, key_len, drop)
                 f2 = run("fused", q, kk, v, o, dout, lse, B, H, Sq, Sk, scale, causal, key_len, drop)
+                if os.environ.get("ADT_FB_XCD"):          # experiment build: every hand-off crosses XCDs (one ticket counter for the grid)
+                    os.environ["ADT_FB_DBG"] = "16"
+                    f3 = run("fused", q, kk, v, o, dout, lse, B, H, Sq, Sk, scale, causal, key_len, drop)
+                    os.environ.pop("ADT_FB_DBG")
+                    if not all(torch.equal(x, y) for x, y in zip(f, f3)):
+                        print("BAD  cross-XCD run differs", flush=True)
                 errs = [((x.float() - y.float()).abs().max().item(), y.float().abs().max().item()) for x, y in zip(f, a)]
                 rep = all(torch.equal(x, y) for x, y in zip(f, f2))
                 bad = any((not math.isfinite(e)) or e > 2e-2 * m + 1e-6 for e, m in errs)
