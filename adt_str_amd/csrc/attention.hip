@@ -419,445 +419,10 @@ __global__ __launch_bounds__(kAttnThreads, 2) void attn_bwd_dq_kernel(AttnArgs a
   }
 }
 
-// =============================================================================== backward: dK, dV  (lane <-> key)
-template <bool kDrop>
-__global__ __launch_bounds__(kAttnThreads, 1) void attn_bwd_dkv_kernel(AttnArgs a) {
-  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];     // [2 stages][Q tile | dO tile | lse2[64] | delta[64]]
-  constexpr int kStage = 2 * kAttnTileBytes + 512;
-  const int tid = threadIdx.x, lane = tid & 63, r = lane & 31, h = lane >> 5;
-  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const TileXY tc = tile_coords((a.Sk + 127) / 128);
-  const int b = tc.y / a.H, head = tc.y % a.H;
-  const int ki = tc.x * 128 + wave * 32 + r;
-  const unsigned short* qb = a.q + static_cast<long>(b) * a.Sq * a.ldq + head * kDh;
-  const unsigned short* dob = a.dout + static_cast<long>(b) * a.Sq * a.ldo + head * kDh;
-  const unsigned short* kb_ = a.k + static_cast<long>(b) * a.Sk * a.ldk + head * kDh;
-  const unsigned short* vb = a.v + static_cast<long>(b) * a.Sk * a.ldv + head * kDh;
-  const int klen = a.key_len ? a.key_len[b] : a.Sk;
-  const float sl2 = a.scale * kLog2e;
-  const float* lse_b = a.lse + (static_cast<long>(b) * a.H + head) * a.Sq;
-  const float* dl_b = a.delta + (static_cast<long>(b) * a.H + head) * a.Sq;
-  // pair index of (query q, this lane's key): headpair + q * (Sk2 / 2); the lane's half of the pair is ki & 1 (dropout.h)
-  const unsigned sk_pairs = static_cast<unsigned>((a.Sk + 1) >> 1);
-  const unsigned headpair = static_cast<unsigned>((static_cast<uint64_t>(b) * a.H + head) * a.Sq * sk_pairs) + static_cast<unsigned>(ki >> 1);
-  const unsigned key2 = mix32(a.drop.key);
-  const int k_end = tc.x * 128 + 128;
-  const bool key_mask = a.causal || k_end > klen || k_end > a.Sk;
-
-  bf16x8 kf[8], vf[8];
-  frags_from_global(kb_, a.ldk, ki, a.Sk, lane, kf);
-  frags_from_global(vb, a.ldv, ki, a.Sk, lane, vf);
-  f32x16 dk[4], dv[4];
-#pragma unroll
-  for (int db = 0; db < 4; ++db)
-#pragma unroll
-    for (int i = 0; i < 16; ++i) { dk[db][i] = 0.f; dv[db][i] = 0.f; }
-
-  const int n_tiles = (a.Sq + kRowsPerTile - 1) / kRowsPerTile;
-  float rs = 0.f;
-  auto load_stats = [&](int t) {                      // threads 0..63: lse2, 64..127: delta of the tile's 64 queries
-    const int qq = t * kRowsPerTile + (tid & 63);
-    rs = 0.f;
-    if (tid < 128 && qq < a.Sq) rs = tid < 64 ? lse_b[qq] * kLog2e : dl_b[qq];
-  };
-  auto store_stats = [&](unsigned char* stage) {
-    if (tid < 128) reinterpret_cast<float*>(stage + 2 * kAttnTileBytes)[tid] = rs;
-  };
-  tile_dma(qb, a.ldq, 0, a.Sq, smem, wave, lane);
-  tile_dma(dob, a.ldo, 0, a.Sq, smem + kAttnTileBytes, wave, lane);
-  load_stats(0);
-  store_stats(smem);
-  dma_wait_and_sync();
-  for (int t = 0; t < n_tiles; ++t) {
-    const unsigned char* tq = smem + (t & 1) * kStage;
-    const unsigned char* td = tq + kAttnTileBytes;
-    const float* stats = reinterpret_cast<const float*>(tq + 2 * kAttnTileBytes);
-    const bool more = t + 1 < n_tiles;
-    if (more) {
-      unsigned char* ns = smem + ((t + 1) & 1) * kStage;
-      tile_dma(qb, a.ldq, (t + 1) * kRowsPerTile, a.Sq, ns, wave, lane);
-      tile_dma(dob, a.ldo, (t + 1) * kRowsPerTile, a.Sq, ns + kAttnTileBytes, wave, lane);
-      load_stats(t + 1);
-    }
-#pragma unroll
-    for (int qblk = 0; qblk < 2; ++qblk) {
-      f32x16 st, dp;
-#pragma unroll
-      for (int i = 0; i < 16; ++i) { st[i] = 0.f; dp[i] = 0.f; }
-#pragma unroll
-      for (int s = 0; s < 8; ++s) {
-        st = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_rows(tq, qblk, s, lane), kf[s], st, 0, 0, 0);
-        dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_rows(td, qblk, s, lane), vf[s], dp, 0, 0, 0);
-      }
-      // the transposed dO / Q fragments of both 16-row k-steps are requested now: they only depend on the tile, and land
-      // under the softmax / dropout arithmetic below instead of being waited for in front of the dV / dK MFMAs
-      TrFrag dot[2][4], qt[2][4];
-#pragma unroll
-      for (int s2 = 0; s2 < 2; ++s2) {
-        tr4_issue(td, qblk * 32 + 16 * s2, lane, dot[s2]);
-        tr4_issue(tq, qblk * 32 + 16 * s2, lane, qt[s2]);
-      }
-      // per-query statistics of this lane's 16 rows: rows 8j + 4h + (0..3) are four consecutive floats
-      float lse4[16], dl4[16];
-#pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        *reinterpret_cast<float4*>(lse4 + 4 * j) = *reinterpret_cast<const float4*>(stats + qblk * 32 + 8 * j + 4 * h);
-        *reinterpret_cast<float4*>(dl4 + 4 * j) = *reinterpret_cast<const float4*>(stats + 64 + qblk * 32 + 8 * j + 4 * h);
-      }
-      const bool need_mask = key_mask || (t + 1) * kRowsPerTile > a.Sq;     // block-uniform
-#pragma unroll
-      for (int i = 0; i < 16; ++i) {
-        const int ql = qblk * 32 + acc_row(i, h);
-        const int qi = t * kRowsPerTile + ql;
-        float p;
-        if (need_mask) {
-          const float tt = fmaf(st[i], sl2, mask_add(a, qi, ki, klen) * kLog2e);
-          p = (qi < a.Sq && ki < a.Sk) ? __builtin_amdgcn_exp2f(tt - lse4[i]) : 0.f;
-        } else {
-          p = __builtin_amdgcn_exp2f(fmaf(st[i], sl2, -lse4[i]));
-        }
-        const float keep = kDrop ? a.drop.pick(a.drop.pair_hash32(headpair + static_cast<unsigned>(qi) * sk_pairs, key2), static_cast<unsigned>(ki) & 1u) : 1.0f;
-        st[i] = p * keep;                                    // dropped P (what multiplied V in the forward)
-        dp[i] = p * fmaf(dp[i], keep, -dl4[i]);              // dS / scale (scale applied when dK is stored)
-      }
-      const bf16x8 pf0 = acc_to_b(st, 0), dsf0 = acc_to_b(dp, 0), pf1 = acc_to_b(st, 1), dsf1 = acc_to_b(dp, 1);
-      tr_wait();
-#pragma unroll
-      for (int db = 0; db < 4; ++db) {
-        dv[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(tr_get(dot[0][db]), pf0, dv[db], 0, 0, 0);
-        dk[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(tr_get(qt[0][db]), dsf0, dk[db], 0, 0, 0);
-      }
-#pragma unroll
-      for (int db = 0; db < 4; ++db) {
-        dv[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(tr_get(dot[1][db]), pf1, dv[db], 0, 0, 0);
-        dk[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(tr_get(qt[1][db]), dsf1, dk[db], 0, 0, 0);
-      }
-    }
-    if (more) store_stats(smem + ((t + 1) & 1) * kStage);
-    dma_wait_and_sync();
-  }
-  store_transposed(dk, a.scale, a.dk + static_cast<long>(b) * a.Sk * a.ldk + head * kDh, a.ldk, ki, a.Sk, lane);
-  store_transposed(dv, 1.0f, a.dv + static_cast<long>(b) * a.Sk * a.ldv + head * kDh, a.ldv, ki, a.Sk, lane);
-}
-
-// =============================================================================== backward: dK, dV, producer / consumer waves
-// The kernel above keeps everything in one wave (S, dP, softmax / dropout arithmetic, dV, dK): ~400 registers = one wave per
-// SIMD, whose MFMAs, VALU work and LDS waits serialise (PMC: 13 % MFMA-busy, 44 % of wave-cycles parked in waits).  Here a
-// workgroup has 8 waves = 2 per SIMD with different jobs for the same 32 keys:
-//   * S-wave  w (0..3): K^T, V^T fragments in registers; per 32-query block S = Q K^T, dP = dO V^T (16 MFMAs), then the softmax /
-//     dS arithmetic on register pairs, packs P_drop and dS as MFMA B operands and hands them over through LDS.  It is the
-//     critical path, so it does nothing else: no vector-memory work in its loop, the next block's Q fragments already in flight
-//     while it does this block's arithmetic;
-//   * acc-wave w + 4 : dV^T += dO^T P, dK^T += Q^T dS (16 MFMAs from transposed LDS reads), accumulators in registers; also
-//     everything that has slack to hide in: the Q / dO tile refills, the per-query statistics, the dropout hashes of the block
-//     after next (handed over as one byte per element).
-// Both fit 256 registers, and the acc-wave's MFMAs run in the shadow of the S-wave's VALU stream on the same SIMD.
-// The acc-wave works one query block behind its S-wave; one s_barrier per block orders the hand-over buffers (double
-// buffered) and the three Q / dO tile stages (a stage is refilled by LDS-DMA three blocks before it is needed again).
-// Cycle stamps of one block (encoder shape, ~1.75 GHz): S-wave 860 MFMA chains + 930 arithmetic + 150 hand-over, acc-wave
-// 370-1600 reads + hashes, 500 MFMAs, 430-870 refill; see profiles/r01/README.md for what the stamps found and fixed.
-constexpr int kDkv2Threads = 512;
-constexpr int kDkv2Stage = 2 * kAttnTileBytes + 512;          // Q tile | dO tile | lse2[64] | delta[64]
-constexpr int kDkv2Hand = 4 * 1024;                           // P(s2=0) | P(s2=1) | dS(s2=0) | dS(s2=1), one 16-byte operand per lane
-constexpr int kDkv2Mask = 1024;                               // keep flags of one 32-query block: 16 bytes (0 / 1) per lane
-constexpr int kDkv2Lds = 3 * kDkv2Stage + 4 * 2 * kDkv2Hand + 4 * 2 * kDkv2Mask;  // 134,656 B
-
-template <bool kDrop>
-__global__ __launch_bounds__(kDkv2Threads) void attn_bwd_dkv2_kernel(AttnArgs a) {
-  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-  const int tid = threadIdx.x, lane = tid & 63, r = lane & 31, h = lane >> 5;
-  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int role = wave >> 2, pair = wave & 3;                    // role 0: S-wave, 1: acc-wave
-  const TileXY tc = tile_coords((a.Sk + 127) / 128);
-  const int b = tc.y / a.H, head = tc.y % a.H;
-  const int ki = tc.x * 128 + pair * 32 + r;
-  const unsigned short* qb = a.q + static_cast<long>(b) * a.Sq * a.ldq + head * kDh;
-  const unsigned short* dob = a.dout + static_cast<long>(b) * a.Sq * a.ldo + head * kDh;
-  const float* lse_b = a.lse + (static_cast<long>(b) * a.H + head) * a.Sq;
-  const float* dl_b = a.delta + (static_cast<long>(b) * a.H + head) * a.Sq;
-  unsigned char* hand = smem + 3 * kDkv2Stage + pair * 2 * kDkv2Hand;
-  unsigned char* keepflags = smem + 3 * kDkv2Stage + 4 * 2 * kDkv2Hand + pair * 2 * kDkv2Mask;
-  const int n_tiles = (a.Sq + kRowsPerTile - 1) / kRowsPerTile;
-  const int n_iter = 2 * n_tiles + 1;
-  // dropout: the keep decisions depend on indices only, so the (mostly idle) acc-wave hashes them one block AHEAD of its
-  // S-wave and hands over one byte per element (0 / 1; byte i of the lane's 16 = element i); the S-wave then spends one
-  // v_cvt_f32_ubyte per element instead of the whole hash.  Block 0's flags are produced before the loop.
-  // pair index of (query q, this lane's key): headpair + q * (Sk2 / 2); the lane's half of the pair is ki & 1 (dropout.h)
-  const unsigned sk_pairs = static_cast<unsigned>((a.Sk + 1) >> 1);
-  const unsigned headpair = static_cast<unsigned>((static_cast<uint64_t>(b) * a.H + head) * a.Sq * sk_pairs) + static_cast<unsigned>(ki >> 1);
-  const unsigned key2 = mix32(a.drop.key);
-  auto keep_flags_of_block = [&](int jb) {
-    unsigned w[4] = {0u, 0u, 0u, 0u};
-    unsigned vb = headpair + static_cast<unsigned>(jb * 32 + 4 * h) * sk_pairs;
-    asm volatile("" : "+v"(vb));            // opaque: otherwise 16 loop-invariant index registers are kept alive instead of 16 scalars
-    const unsigned sh = (static_cast<unsigned>(ki) & 1u) * 16u;
-#pragma unroll
-    for (int i = 0; i < 16; ++i) {
-      const unsigned pr = vb + static_cast<unsigned>((i & 3) + 8 * (i >> 2)) * sk_pairs;
-      w[i >> 2] |= ((((mix32(pr ^ key2) >> sh) & 0xffffu) >= a.drop.thr) ? 1u : 0u) << (8 * (i & 3));
-    }
-    return u32x4{w[0], w[1], w[2], w[3]};
-  };
-  if (kDrop && role == 1) *reinterpret_cast<u32x4*>(keepflags + lane * 16) = keep_flags_of_block(0);
-
-  // ---- Q / dO tile staging and the per-query statistics belong to the acc-waves alone (they have the slack; the S-waves then
-  // have no vector-memory work in the loop at all).  Acc-wave w fills rows 16w .. 16w+15 of a tile with four LDS-DMA instructions.
-  const int aw = wave & 3;
-  float rs = 0.f;
-  auto load_stats = [&](int t) {                                   // acc-wave 0: -lse2, acc-wave 1: -delta of tile t's 64 queries
-    const int qq = t * kRowsPerTile + lane;
-    rs = 0.f;                                                      // raw values: any arithmetic here would wait for the load
-    if (aw == 0 && qq < a.Sq) rs = lse_b[qq];
-    if (aw == 1 && qq < a.Sq) rs = dl_b[qq];
-  };
-  auto store_stats = [&](int t) {                                  // both enter the S-waves' arithmetic negated
-    if (aw < 2) reinterpret_cast<float*>(smem + (t % 3) * kDkv2Stage + 2 * kAttnTileBytes)[aw * 64 + lane] = aw == 0 ? -rs * kLog2e : -rs;
-  };
-  auto issue_tile = [&](int t) {                                   // stats first: the DMAs behind them stay in flight longer
-    load_stats(t);
-    unsigned char* st = smem + (t % 3) * kDkv2Stage;
-    const int row0 = t * kRowsPerTile;
-    const bool full = row0 + kRowsPerTile <= a.Sq;                 // otherwise rows past the end repeat the last valid row
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      const int row = 4 * (4 * aw + i) + (lane >> 4);
-      const int chunk = (lane & 15) ^ (((row & 3) << 2) | ((row >> 2) & 3));
-      int gr = row0 + row;
-      if (!full) gr = gr < a.Sq ? gr : a.Sq - 1;
-      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(qb + static_cast<long>(gr) * a.ldq + chunk * 8),
-                                       (__attribute__((address_space(3))) void*)(st + (4 * aw + i) * 1024), 16, 0, 0);
-      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(dob + static_cast<long>(gr) * a.ldo + chunk * 8),
-                                       (__attribute__((address_space(3))) void*)(st + kAttnTileBytes + (4 * aw + i) * 1024), 16, 0, 0);
-    }
-  };
-  // prologue: tiles 0..2 resident -- the acc-waves start all of them before waiting once (stats of a tile are stored once its
-  // loads have returned) while the S-waves fetch their K^T / V^T fragments, so the kernel pays one memory round trip, not five
-  const unsigned short* kb_ = a.k + static_cast<long>(b) * a.Sk * a.ldk + head * kDh;
-  const unsigned short* vb = a.v + static_cast<long>(b) * a.Sk * a.ldv + head * kDh;
-  // (each role has its own copy of the barrier that ends the prologue: K^T / V^T stay out of the acc-waves' register budget)
-
-  // Every wave runs n_iter iterations with ONE barrier each.  In iteration j the S-waves work on query block j (j < 2 n_tiles),
-  // the acc-waves on block j - 1 (j >= 1).  Odd iterations j >= 3 start the refill of the stage that block j - 1 was the last to
-  // use (tile (j + 3) / 2); the even iteration after it waits for the refill (it then has had a whole iteration to land).
-  if (role == 0) {
-    // ------------------------------------------------------------------ S-waves
-    bf16x8 kf[8], vf[8];
-    frags_from_global(kb_, a.ldk, ki, a.Sk, lane, kf);
-    frags_from_global(vb, a.ldv, ki, a.Sk, lane, vf);
-    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
-    asm volatile("s_barrier" ::: "memory");
-    const int klen = a.key_len ? a.key_len[b] : a.Sk;
-    const float sl2 = a.scale * kLog2e;
-    const int k_end = tc.x * 128 + 128;
-    const bool key_mask = a.causal || k_end > klen || k_end > a.Sk;
-#pragma unroll
-    for (int s = 0; s < 8; ++s) asm volatile("" :: "v"(kf[s]), "v"(vf[s]));      // first use here: the compiler's wait for these loads
-                                                                                // lands before the loop, not in front of its MFMAs
-    // LDS traffic of the S-waves is inline asm with hand-placed lgkmcnt waits.  Per-lane byte offsets of the eight 16-byte row chunks:
-    unsigned foff[8];
-    {
-      const int x = ((r & 3) << 2) | ((r >> 2) & 3);
-#pragma unroll
-      for (int s = 0; s < 8; ++s) foff[s] = static_cast<unsigned>(256 * r + 16 * ((2 * s + h) ^ x));
-    }
-    const unsigned smem_base = lds_off(smem);
-    // The Q fragments of block j + 1 are fetched while block j's softmax arithmetic runs (their registers are free once block j's
-    // S MFMAs have issued, and the tile of block j + 1 is resident: its refill was waited for before the previous barrier), so the
-    // S chain starts right after the barrier; the dO fragments arrive under it (prefetching both would not fit 256 registers).
-    bf16x8 fq[8];
-    auto issue_frags = [&](int jb) {
-      const unsigned tq_a = smem_base + static_cast<unsigned>(((jb >> 1) % 3) * kDkv2Stage + (jb & 1) * 32 * 256);
-#pragma unroll
-      for (int s = 0; s < 8; ++s) asm volatile("ds_read_b128 %0, %1" : "=v"(fq[s]) : "v"(tq_a + foff[s]));
-    };
-    static_assert(kAttnTileBytes == 16384, "immediate offset of the dO tile");
-    issue_frags(0);
-    for (int j = 0; j < n_iter; ++j) {
-      if (j < 2 * n_tiles) {
-        const int t = j >> 1, qblk = j & 1;
-        const unsigned st_a = smem_base + static_cast<unsigned>((t % 3) * kDkv2Stage + 2 * kAttnTileBytes + (qblk * 32 + 4 * h) * 4);
-        const unsigned td_a = smem_base + static_cast<unsigned>((t % 3) * kDkv2Stage + qblk * 32 * 256);
-        bf16x8 fd[8];
-#pragma unroll
-        for (int s = 0; s < 8; ++s) asm volatile("ds_read_b128 %0, %1 offset:16384" : "=v"(fd[s]) : "v"(td_a + foff[s]));
-        // per-query statistics of this lane's 16 rows (rows 8 q4 + 4h + (0..3) are four consecutive floats) and the keep flags:
-        // queued behind the fragment reads, back long before the MFMA chain ends
-        f32x4 l4[4], d4[4];
-        asm volatile("ds_read_b128 %0, %1" : "=v"(l4[0]) : "v"(st_a));
-        asm volatile("ds_read_b128 %0, %1 offset:32" : "=v"(l4[1]) : "v"(st_a));
-        asm volatile("ds_read_b128 %0, %1 offset:64" : "=v"(l4[2]) : "v"(st_a));
-        asm volatile("ds_read_b128 %0, %1 offset:96" : "=v"(l4[3]) : "v"(st_a));
-        asm volatile("ds_read_b128 %0, %1 offset:256" : "=v"(d4[0]) : "v"(st_a));
-        asm volatile("ds_read_b128 %0, %1 offset:288" : "=v"(d4[1]) : "v"(st_a));
-        asm volatile("ds_read_b128 %0, %1 offset:320" : "=v"(d4[2]) : "v"(st_a));
-        asm volatile("ds_read_b128 %0, %1 offset:352" : "=v"(d4[3]) : "v"(st_a));
-        u32x4 kfl = {0u, 0u, 0u, 0u};
-        if (kDrop) asm volatile("ds_read_b128 %0, %1" : "=v"(kfl) : "v"(lds_off(keepflags + (j & 1) * kDkv2Mask + lane * 16)));
-        f32x16 st, dp;
-#pragma unroll
-        for (int i = 0; i < 16; ++i) { st[i] = 0.f; dp[i] = 0.f; }
-        __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-        for (int s = 0; s < 8; ++s) st = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fq[s], kf[s], st, 0, 0, 0);
-        __builtin_amdgcn_sched_barrier(0);
-        if (kDrop) asm volatile("s_waitcnt lgkmcnt(9)" ::: "memory");          // the 8 dO fragment reads (older, in-order) are back
-        else asm volatile("s_waitcnt lgkmcnt(8)" ::: "memory");
-        __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-        for (int s = 0; s < 8; ++s) dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fd[s], vf[s], dp, 0, 0, 0);
-        __builtin_amdgcn_sched_barrier(0);
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        if (j + 1 < 2 * n_tiles) issue_frags(j + 1);
-        __builtin_amdgcn_sched_barrier(0);
-        const bool need_mask = key_mask || (t + 1) * kRowsPerTile > a.Sq;     // block-uniform
-        // Everything below is written on register PAIRS (elements 2m, 2m + 1: adjacent accumulator registers, adjacent statistics,
-        // one packed bf16 dword of the hand-over operand) so that it compiles to v_pk_fma / v_pk_mul without register shuffles.
-        // Two straight-line exp blocks (a per-element `if` compiles to a scalar branch per element, which leaves every v_exp
-        // latency exposed); the masked one is select-only: exp2 of a hugely negative argument is the 0 of an out-of-range pair.
-        f32x2 pv[8];
-        if (need_mask) {
-#pragma unroll
-          for (int i = 0; i < 16; ++i) {
-            const int qi = t * kRowsPerTile + qblk * 32 + acc_row(i, h);
-            const float tt = fmaf(st[i], sl2, mask_add(a, qi, ki, klen) * kLog2e) + l4[i >> 2][i & 3];
-            pv[i >> 1][i & 1] = __builtin_amdgcn_exp2f((qi < a.Sq && ki < a.Sk) ? tt : kNegBig);
-          }
-        } else {
-#pragma unroll
-          for (int m = 0; m < 8; ++m) {
-            const f32x2 sv = {st[2 * m], st[2 * m + 1]}, nl = {l4[m >> 1][2 * (m & 1)], l4[m >> 1][2 * (m & 1) + 1]};
-            const f32x2 arg = sv * sl2 + nl;
-            pv[m] = f32x2{__builtin_amdgcn_exp2f(arg[0]), __builtin_amdgcn_exp2f(arg[1])};
-          }
-        }
-        const unsigned kw[4] = {kfl[0], kfl[1], kfl[2], kfl[3]};
-        unsigned hp[8], hs[8];                                 // packed bf16 pairs: dropped P (what multiplied V in the forward),
-#pragma unroll                                                 // dS / scale (the scale is applied when dK is stored)
-        for (int m = 0; m < 8; ++m) {
-          const f32x2 dpv = {dp[2 * m], dp[2 * m + 1]}, nd = {d4[m >> 1][2 * (m & 1)], d4[m >> 1][2 * (m & 1) + 1]};
-          f32x2 pd = pv[m], ds;
-          if (kDrop) {
-            const unsigned w = kw[m >> 1];
-            const f32x2 k01 = (m & 1) ? f32x2{static_cast<float>((w >> 16) & 0xffu), static_cast<float>(w >> 24)}
-                                      : f32x2{static_cast<float>(w & 0xffu), static_cast<float>((w >> 8) & 0xffu)};
-            const f32x2 ks = k01 * a.drop.inv_keep;            // 0 or exactly 1 / (1 - p)
-            pd = pv[m] * ks;
-            ds = pv[m] * (dpv * ks + nd);
-          } else {
-            ds = pv[m] * (dpv + nd);
-          }
-          hp[m] = pack2(pd[0], pd[1]);
-          hs[m] = pack2(ds[0], ds[1]);
-        }
-        const unsigned hb = lds_off(hand + (j & 1) * kDkv2Hand + lane * 16);
-        asm volatile("ds_write_b128 %0, %1" :: "v"(hb), "v"(u32x4{hp[0], hp[1], hp[2], hp[3]}) : "memory");
-        asm volatile("ds_write_b128 %0, %1 offset:1024" :: "v"(hb), "v"(u32x4{hp[4], hp[5], hp[6], hp[7]}) : "memory");
-        asm volatile("ds_write_b128 %0, %1 offset:2048" :: "v"(hb), "v"(u32x4{hs[0], hs[1], hs[2], hs[3]}) : "memory");
-        asm volatile("ds_write_b128 %0, %1 offset:3072" :: "v"(hb), "v"(u32x4{hs[4], hs[5], hs[6], hs[7]}) : "memory");
-      }
-      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-      asm volatile("s_barrier" ::: "memory");
-    }
-  } else {
-    // ------------------------------------------------------------------ acc-waves
-    {
-      float rs3[3] = {0.f, 0.f, 0.f};
-#pragma unroll
-      for (int t = 0; t < 3; ++t)
-        if (t < n_tiles) { issue_tile(t); rs3[t] = rs; }
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-#pragma unroll
-      for (int t = 0; t < 3; ++t)
-        if (t < n_tiles) { rs = rs3[t]; store_stats(t); }
-      asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
-      asm volatile("s_barrier" ::: "memory");
-    }
-    f32x16 dk[4], dv[4];
-#pragma unroll
-    for (int db = 0; db < 4; ++db)
-#pragma unroll
-      for (int i = 0; i < 16; ++i) { dk[db][i] = 0.f; dv[db][i] = 0.f; }
-    // transposed-read addresses: the swizzle only involves row bits 0..3, so a lane's eight offsets (4 d-blocks x rows r, r + 8)
-    // inside a 16-row group are fixed; stage and query block go in with one add each, k-step and Q / dO tile as immediates
-    unsigned troff[4][2];
-    {
-      const int i = lane & 15, g4 = (lane >> 4) & 1, row = 4 * h + (i >> 2);
-#pragma unroll
-      for (int db = 0; db < 4; ++db) {
-        const int chunk = 4 * db + 2 * g4 + ((i & 3) >> 1);
-        troff[db][0] = lds_off(smem) + static_cast<unsigned>(8 * (i & 1) + swz(row, chunk));
-        troff[db][1] = lds_off(smem) + static_cast<unsigned>(8 * (i & 1) + swz(row + 8, chunk));
-      }
-    }
-#define ADT_TR2(F, A0, A1, IMM)                                                                               \
-    asm volatile("ds_read_b64_tr_b16 %0, %2 offset:%4\n\tds_read_b64_tr_b16 %1, %3 offset:%4"                 \
-                 : "=&v"((F).lo), "=&v"((F).hi) : "v"(A0), "v"(A1), "i"(IMM) : "memory")
-    // All LDS traffic of the loop is inline asm (compiler-generated accesses would be ordered behind the tile DMAs in flight with a
-    // vmcnt(0)).  Order inside an iteration: the reads of block j - 1's first k-step go out, the dropout hashes of block j + 1 run
-    // while they are in flight, the second k-step's reads follow (all 36 at once next to the hash temporaries would not fit 256
-    // registers), then 8 + 8 MFMAs, then this wave's share of the tile refill.
-    for (int j = 0; j < n_iter; ++j) {
-      TrFrag dot[2][4], qt[2][4];
-      bf16x8 pf0, pf1, dsf0, dsf1;
-      const int jj = j - 1;
-      const unsigned blk = static_cast<unsigned>(((jj >> 1) % 3) * kDkv2Stage + (jj & 1) * 32 * 256);
-      const unsigned hb = lds_off(hand + (jj & 1) * kDkv2Hand + lane * 16);
-      if (j >= 1) {
-#pragma unroll
-        for (int db = 0; db < 4; ++db) {
-          ADT_TR2(dot[0][db], troff[db][0] + blk, troff[db][1] + blk, kAttnTileBytes);
-          ADT_TR2(qt[0][db], troff[db][0] + blk, troff[db][1] + blk, 0);
-        }
-        asm volatile("ds_read_b128 %0, %1" : "=v"(pf0) : "v"(hb) : "memory");
-        asm volatile("ds_read_b128 %0, %1 offset:2048" : "=v"(dsf0) : "v"(hb) : "memory");
-      }
-      __builtin_amdgcn_sched_barrier(0);
-      if (kDrop && j + 1 < 2 * n_tiles) {
-        const u32x4 kf_ = keep_flags_of_block(j + 1);
-        asm volatile("ds_write_b128 %0, %1" :: "v"(lds_off(keepflags + ((j + 1) & 1) * kDkv2Mask + lane * 16)), "v"(kf_) : "memory");
-      }
-      __builtin_amdgcn_sched_barrier(0);
-      if (j >= 1) {
-#pragma unroll
-        for (int db = 0; db < 4; ++db) {
-          ADT_TR2(dot[1][db], troff[db][0] + blk, troff[db][1] + blk, kAttnTileBytes + 16 * 256);
-          ADT_TR2(qt[1][db], troff[db][0] + blk, troff[db][1] + blk, 16 * 256);
-        }
-        asm volatile("ds_read_b128 %0, %1 offset:1024" : "=v"(pf1) : "v"(hb) : "memory");
-        asm volatile("ds_read_b128 %0, %1 offset:3072" : "=v"(dsf1) : "v"(hb) : "memory");
-        asm volatile("s_waitcnt lgkmcnt(15)" ::: "memory");       // 18 newer reads: everything of the first k-step is back
-        __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-        for (int db = 0; db < 4; ++db) {
-          dv[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(tr_get(dot[0][db]), pf0, dv[db], 0, 0, 0);
-          dk[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(tr_get(qt[0][db]), dsf0, dk[db], 0, 0, 0);
-        }
-        __builtin_amdgcn_sched_barrier(0);
-        tr_wait();
-#pragma unroll
-        for (int db = 0; db < 4; ++db) {
-          dv[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(tr_get(dot[1][db]), pf1, dv[db], 0, 0, 0);
-          dk[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(tr_get(qt[1][db]), dsf1, dk[db], 0, 0, 0);
-        }
-      }
-      const int tn = (j + 3) >> 1;
-      if ((j & 1) && j >= 3 && tn < n_tiles) issue_tile(tn);
-      if (!(j & 1) && j >= 4 && ((j + 2) >> 1) < n_tiles) {
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        store_stats((j + 2) >> 1);
-      }
-      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-      asm volatile("s_barrier" ::: "memory");
-    }
-#undef ADT_TR2
-    store_transposed(dk, a.scale, a.dk + static_cast<long>(b) * a.Sk * a.ldk + head * kDh, a.ldk, ki, a.Sk, lane);
-    store_transposed(dv, 1.0f, a.dv + static_cast<long>(b) * a.Sk * a.ldv + head * kDh, a.ldv, ki, a.Sk, lane);
-  }
-}
-
-// =============================================================================== backward: dK, dV, eight symmetric waves, staggered
-// Third generation.  The producer / consumer kernel above is bound by its S-wave's serial chain (16 MFMAs -> softmax / dS arithmetic
-// -> hand-over: ~1900 cycles per 32 x 32 block for 1024 cycles of MFMA on the SIMD).  Here every wave does the whole block in its
+// =============================================================================== backward: dK, dV, eight symmetric waves
+// (The single-wave kernel and the producer / consumer wave-pair kernel of rounds 1 and 2 lost every A/B for two rounds and are gone;
+// a pair kernel is bound by its S-wave's serial chain: 16 MFMAs -> softmax / dS arithmetic -> hand-over, ~1900 cycles per 32 x 32
+// block for 1024 cycles of MFMA on the SIMD.)  Here every wave does the whole block in its
 // own registers -- S = Q K^T and dP = dO V^T (16 MFMAs), the arithmetic, dV^T += dO^T P and dK^T += Q^T dS (16 MFMAs) -- so nothing
 // crosses LDS between roles.  What makes it fit 256 registers (two waves per SIMD) is that only the accumulators live in
 // registers (dK^T, dV^T: 128; S, dP: 32): K and V of the workgroup's 128 keys are LDS images (32 KiB each) read as MFMA operands,
@@ -1194,15 +759,11 @@ static int set_lds_once() {      // raise the dynamic-LDS limit of the three ker
   int dev = 0;
   ADT_HIP_TRY(hipGetDevice(&dev));
   if (done_for == dev) return ADT_OK;
-  const int l4 = 4 * kAttnTileBytes, ldkv = 2 * (2 * kAttnTileBytes + 512);
+  const int l4 = 4 * kAttnTileBytes;
   ADT_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(attn_fwd_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, l4));
   ADT_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(attn_fwd_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, l4));
   ADT_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(attn_bwd_dq_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, l4));
   ADT_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(attn_bwd_dq_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, l4));
-  ADT_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(attn_bwd_dkv_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, ldkv));
-  ADT_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(attn_bwd_dkv_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, ldkv));
-  ADT_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(attn_bwd_dkv2_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, kDkv2Lds));
-  ADT_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(attn_bwd_dkv2_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, kDkv2Lds));
   ADT_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(attn_bwd_dkv3_kernel<false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, kDkv3Lds));
   ADT_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(attn_bwd_dkv3_kernel<true, true>), hipFuncAttributeMaxDynamicSharedMemorySize, kDkv3Lds));
   ADT_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(attn_bwd_dkv3_kernel<false, false>), hipFuncAttributeMaxDynamicSharedMemorySize, kDkv3Lds));
@@ -1268,10 +829,14 @@ extern "C" int adt_attn_bwd(const adt_attn_desc* d, const void* q, const void* k
   const bool want_cs = d->dq_colsum || d->dk_colsum || d->dv_colsum;
   if (want_cs && !(d->dq_colsum && d->dk_colsum && d->dv_colsum)) return set_error(ADT_EINVAL, "adt_attn_bwd: give all three column-sum outputs or none");
   const int nqb = (d->q_len + 127) / 128, hd = d->heads * kDh;
-  // ADT_ATTN_BWD=fused selects the one-kernel backward (attention_bwd_fused.hip: 5 products, ordered dQ hand-off); the default is the
-  // two-kernel path below (dQ kernel + dK/dV kernel, 7 products) until the fused kernel beats it.  Read on every call: the tests switch it.
+  // Two backward paths.  The one-kernel path (attention_bwd_fused.hip: the five algorithmic products, dQ summed over the key-block workgroups
+  // by a scheduled fan-in) is the default WITHOUT dropout (MI355X, encoder shape 0.82 vs 0.87 ms, cross-attention 0.21 vs 0.22).  With
+  // dropout the two-kernel path below (dQ kernel + dK/dV kernel, 7 products, every mask hashed twice) is still the faster one (0.96 vs
+  // 0.99 ms): at one wave per SIMD the mask generation sits on the fused kernel's vector pipe with nothing to hide it.  ADT_ATTN_BWD=fused /
+  // split forces a path (read on every call: the tests and tools/exp_attn_bwd.py switch it).
   const char* bwd_env = getenv("ADT_ATTN_BWD");
-  if (bwd_env && bwd_env[0] == 'f') {
+  const bool use_fused = bwd_env ? bwd_env[0] == 'f' : !a.drop.on();
+  if (use_fused) {
     const size_t off = split_workspace_bytes(d);
     if (int rc = launch_attn_bwd_fused(d, a, static_cast<unsigned char*>(ws) + off, ws_bytes - off, st)) return rc;
     if (want_cs) {
@@ -1295,28 +860,21 @@ extern "C" int adt_attn_bwd(const adt_attn_desc* d, const void* q, const void* k
     cs_slice = reduce_queue_slice(static_cast<size_t>(d->batch) * nqb * hd * 4, st);     // open reduction queue: the second stage is deferred
     a.cs_dq = cs_slice ? cs_slice : static_cast<float*>(ws) + delta_floats(d);
   }
-  const int lds_dq = 4 * kAttnTileBytes, lds_dkv = 2 * (2 * kAttnTileBytes + 512);
+  const int lds_dq = 4 * kAttnTileBytes;
   if (int rc = set_lds_once()) return rc;
   const dim3 gq(static_cast<unsigned>((d->q_len + 127) / 128) * d->batch * d->heads), gk(static_cast<unsigned>((d->k_len + 127) / 128) * d->batch * d->heads);
-  // dK / dV kernel: 4 = eight symmetric waves (default), 3 = the same with waves 4-7 staggered by one phase, 2 = producer / consumer
-  // wave pairs, 1 = single-wave kernel; ADT_ATTN_DKV selects an A/B arm (read on every call: the tests switch it).  Measured on
-  // MI355X in one run (tools/exp_attn_dkv.py, backward pair incl. the dQ kernel, without / with dropout): encoder shape 2: 0.897 /
-  // 1.048 ms, 3: 0.898 / 1.046, 4: 0.884 / 0.990; cross-attention 2: 0.216 / 0.230, 3: 0.209 / 0.234, 4: 0.198 / 0.217.  The stagger
-  // pays without dropout only: with it the staggered build spills seven registers inside the loop.
+  // dK / dV kernel: eight symmetric waves; ADT_ATTN_DKV=3 runs it with waves 4-7 staggered by one phase (A/B arm: it pays without
+  // dropout only -- with it the staggered build spills seven registers inside the loop).  Read on every call: the tests switch it.
   const char* dkv_env = getenv("ADT_ATTN_DKV");
-  const int dkv_variant = dkv_env ? atoi(dkv_env) : 4;
+  const bool stagger = dkv_env && atoi(dkv_env) == 3;
   if (a.drop.on()) {
     hipLaunchKernelGGL(attn_bwd_dq_kernel<true>, gq, dim3(kAttnThreads), lds_dq, st, a);
-    if (dkv_variant == 1) hipLaunchKernelGGL(attn_bwd_dkv_kernel<true>, gk, dim3(kAttnThreads), lds_dkv, st, a);
-    else if (dkv_variant == 2) hipLaunchKernelGGL(attn_bwd_dkv2_kernel<true>, gk, dim3(kDkv2Threads), kDkv2Lds, st, a);
-    else if (dkv_variant == 4) hipLaunchKernelGGL((attn_bwd_dkv3_kernel<true, false>), gk, dim3(kDkv3Threads), kDkv3Lds, st, a);
-    else hipLaunchKernelGGL((attn_bwd_dkv3_kernel<true, true>), gk, dim3(kDkv3Threads), kDkv3Lds, st, a);
+    if (stagger) hipLaunchKernelGGL((attn_bwd_dkv3_kernel<true, true>), gk, dim3(kDkv3Threads), kDkv3Lds, st, a);
+    else hipLaunchKernelGGL((attn_bwd_dkv3_kernel<true, false>), gk, dim3(kDkv3Threads), kDkv3Lds, st, a);
   } else {
     hipLaunchKernelGGL(attn_bwd_dq_kernel<false>, gq, dim3(kAttnThreads), lds_dq, st, a);
-    if (dkv_variant == 1) hipLaunchKernelGGL(attn_bwd_dkv_kernel<false>, gk, dim3(kAttnThreads), lds_dkv, st, a);
-    else if (dkv_variant == 2) hipLaunchKernelGGL(attn_bwd_dkv2_kernel<false>, gk, dim3(kDkv2Threads), kDkv2Lds, st, a);
-    else if (dkv_variant == 4) hipLaunchKernelGGL((attn_bwd_dkv3_kernel<false, false>), gk, dim3(kDkv3Threads), kDkv3Lds, st, a);
-    else hipLaunchKernelGGL((attn_bwd_dkv3_kernel<false, true>), gk, dim3(kDkv3Threads), kDkv3Lds, st, a);
+    if (stagger) hipLaunchKernelGGL((attn_bwd_dkv3_kernel<false, true>), gk, dim3(kDkv3Threads), kDkv3Lds, st, a);
+    else hipLaunchKernelGGL((attn_bwd_dkv3_kernel<false, false>), gk, dim3(kDkv3Threads), kDkv3Lds, st, a);
   }
   if (want_cs) {
     // dQ: partial sums out of the dQ kernel's epilogue.  dK: every row of dS sums to zero (softmax), so the column sums of

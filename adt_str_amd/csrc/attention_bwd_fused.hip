@@ -252,22 +252,23 @@ __global__ __launch_bounds__(kFbThreads, 1) void attn_bwd_fused_kernel(FusedArgs
   unsigned fl = 0;                                                 // flag of the step of the coming iteration (wave-uniform)
   auto flag_of = [&](int jj, int src) { return fa.flags + ((fl_bh + jj) * nkb + src) * 4 + wave; };
   auto part_of = [&](int jj, int src) { return fa.part + (((fl_bh + jj) * nkb + src) * 4 + wave) * 1024; };
-  // the reduction step of (virtual) iteration i is slice jr = kb + nkb * floor((i - 3 - kb) / nkb), key block n = (i - 3 - kb) mod nkb (none while
-  // i < 3 + kb or once jr >= ns); kept as a pair that advances by one step per iteration -- no divisions in the loop
-  int cur_jr = kb, cur_n = -(3 + kb);                              // cur_n < 0: the schedule has not started yet
+  // the reduction step of (virtual) iteration i is slice jr = kb + nkb * floor((i - 4 - kb) / nkb), key block n = (i - 4 - kb) mod nkb (none while
+  // i < 4 + kb or once jr >= ns); kept as a pair that advances by one step per iteration -- no divisions in the loop
+  int cur_jr = kb, cur_n = -(4 + kb);                              // cur_n < 0: the schedule has not started yet
   auto advance = [&](int& jr, int& n) {
     if (++n == nkb) { n = 0; jr += nkb; }
   };
   auto valid = [&](int jr, int n) { return handoff && n >= 0 && jr < ns; };
-  auto land = [&](int jr, int n) {                                 // this wave's quarter of key block n's tile -> the landing zone (L1 bypassed)
+  auto land_to = [&](int jr, int n, int lds_byte) {                // this wave's quarter of key block n's tile -> 4 KiB of LDS (L1 bypassed)
     int lane_o = lane;
     asm volatile("" : "+v"(lane_o));
     const float* src = part_of(jr, n) + lane_o * 4;
 #pragma unroll
     for (int g = 0; g < 4; ++g)
       __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + g * 256),
-                                       (__attribute__((address_space(3))) void*)(smem + kFbOffLand + wave * 4096 + g * 1024), 16, 0, 16);
+                                       (__attribute__((address_space(3))) void*)(smem + lds_byte + g * 1024), 16, 0, 16);
   };
+  auto land = [&](int jr, int n) { land_to(jr, n, kFbOffLand + wave * 4096); };
   auto wait_flag = [&](int jr, int n) {                            // a tile that had not been published when its flag was prefetched (rare)
     unsigned spins = 0, f = 0;
     for (;;) {
@@ -299,10 +300,10 @@ __global__ __launch_bounds__(kFbThreads, 1) void attn_bwd_fused_kernel(FusedArgs
     }
   };
   const unsigned stash_a = smem_base + static_cast<unsigned>(kFbOffStash + wave * 4096 + lane * 16);
-  auto add_step = [&](int jr, int n) {                             // running sum (+)= landed tile; the last step stores dQ
+  auto add_step_from = [&](int jr, int n, unsigned land_a) {       // running sum (+)= landed tile (at LDS address land_a + 1024 g); the last step stores dQ
     f32x4 o[4], q4[4];
 #pragma unroll
-    for (int g = 0; g < 4; ++g) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(o[g]) : "v"(stash_a), "i"(4 * 4096 + 1024 * g) : "memory");
+    for (int g = 0; g < 4; ++g) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(o[g]) : "v"(land_a), "i"(1024 * g) : "memory");
     if (n > 0) {
 #pragma unroll
       for (int g = 0; g < 4; ++g) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(q4[g]) : "v"(stash_a), "i"(1024 * g) : "memory");
@@ -323,6 +324,7 @@ __global__ __launch_bounds__(kFbThreads, 1) void attn_bwd_fused_kernel(FusedArgs
       for (int g = 0; g < 4; ++g) asm volatile("ds_write_b128 %0, %1 offset:%2" :: "v"(stash_a), "v"(o[g]), "i"(1024 * g) : "memory");
     }
   };
+  auto add_step = [&](int jr, int n) { add_step_from(jr, n, stash_a + 4u * 4096u); };
 
 #define ADT_STAMP(K)                                                                                                      \
   if ((kDbg & 32) && j == 12 && wave == 0 && blockIdx.x == 600) {                                                        \
@@ -331,6 +333,58 @@ __global__ __launch_bounds__(kFbThreads, 1) void attn_bwd_fused_kernel(FusedArgs
     if (lane == 0) fa.stamps[K] = tnow;                                                                                   \
     __builtin_amdgcn_sched_barrier(0);                                                                                    \
   }
+  auto hand_on = [&](const f32x16& t, int jj) {                    // slice jj's dQ^T tile of this key block: store dQ (one key block) or publish the tile
+    if (!handoff) {
+      store_dq(t, jj);
+      return;
+    }
+    // write-through (sc1) 16-byte stores as compiler-visible buffer stores: an inline-asm store gets no hazard wait states before the
+    // next instruction that overwrites its data registers
+    const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(part_of(jj, kb), 0, 4096, 0x00020000);
+    int lane_s = lane;
+    asm volatile("" : "+v"(lane_s));
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+      const u32x4 o = {__float_as_uint(t[4 * g]), __float_as_uint(t[4 * g + 1]), __float_as_uint(t[4 * g + 2]), __float_as_uint(t[4 * g + 3])};
+      __builtin_amdgcn_raw_buffer_store_b128(o, rsrc, (g * 64 + lane_s) * 16, 0, 16);      // aux 16 = sc1
+    }
+    pub_pending = jj;
+  };
+  // dQ^T, d-block `wave`, over the workgroup's 256 keys: 16 k-steps of 16 keys through a ring of four operand units (three k-steps ahead
+  // of the product: one wave per SIMD, nobody else hides the LDS latency), two accumulation chains (even / odd k-steps: a product waits
+  // ~100 cycles for the previous one on the same VGPR accumulator).  ADT_DQ_BEGIN / ADT_DQ_STEP(0..15) / ADT_DQ_END.
+#define ADT_DQ_BEGIN                                                                              \
+  f32x16 dq2;                                                                                     \
+  _Pragma("unroll") for (int i = 0; i < 16; ++i) { dq[i] = 0.f; dq2[i] = 0.f; }                   \
+  mfma_srcc_ready(dq, dq2);                                                                       \
+  const unsigned ka_a = trbase ^ static_cast<unsigned>(64 * wave), xb_a = xbase + static_cast<unsigned>(kFbOffX); \
+  TrFrag ka[4], xb[4];                                                                            \
+  ADT_TR2(ka[0], ka_a, 0);                                                                        \
+  ADT_TRX(xb[0], xb_a, 0);                                                                        \
+  ADT_TR2(ka[1], ka_a, 4096);                                                                     \
+  ADT_TRX(xb[1], xb_a, 1024);                                                                     \
+  ADT_TR2(ka[2], ka_a, 2 * 4096);                                                                 \
+  ADT_TRX(xb[2], xb_a, 2 * 1024);
+#define ADT_DQ_STEP(KK)                                                                           \
+  if ((KK) + 3 < 16) {                                                                            \
+    ADT_TR2(ka[((KK) + 3) & 3], ka_a, ((KK) + 3) * 4096);                                         \
+    ADT_TRX(xb[((KK) + 3) & 3], xb_a, ((KK) + 3) * 1024);                                         \
+    asm volatile("s_waitcnt lgkmcnt(12)" ::: "memory");                                           \
+  } else if ((KK) + 2 < 16) {                                                                     \
+    asm volatile("s_waitcnt lgkmcnt(8)" ::: "memory");                                            \
+  } else if ((KK) + 1 < 16) {                                                                     \
+    asm volatile("s_waitcnt lgkmcnt(4)" ::: "memory");                                            \
+  } else {                                                                                        \
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                                            \
+  }                                                                                               \
+  __builtin_amdgcn_sched_barrier(0);                                                              \
+  if ((KK) & 1) mfma_vgpr(dq2, tr_get(ka[(KK) & 3]), tr_get(xb[(KK) & 3]));                       \
+  else mfma_vgpr(dq, tr_get(ka[(KK) & 3]), tr_get(xb[(KK) & 3]));                                 \
+  __builtin_amdgcn_sched_barrier(0);
+#define ADT_DQ_END                                                                                \
+  mfma_settle(dq, dq2);                                                                           \
+  _Pragma("unroll") for (int i = 0; i < 16; ++i) dq[i] += dq2[i];
+
   // The slice loop exists twice: key blocks that need the masked form of the arithmetic (causal, padded or partial key block) and interior
   // ones; the choice is per workgroup, and a run-time flag inside the loop costs two taken branches per pair of elements.
   auto run_slices = [&](auto masked_tag) {
@@ -362,11 +416,11 @@ __global__ __launch_bounds__(kFbThreads, 1) void attn_bwd_fused_kernel(FusedArgs
     // sched_barrier(0) pins the interleave: one pair of MFMAs, then one pair of elements' arithmetic (or one hash).
     f32x16 st0, dp0, st1, dp1;
     unsigned hp0[8], hs0[8], hp1[8], hs1[8];
-    uint64_t km0[16], km1[16];
+    uint64_t km0[16];
     f32x4 ndv[4];
     bf16x8 fq[3], fd[3], fk[3];                                   // operand ring of the chains: two k-steps ahead
     const unsigned tq_a = rowbase + slot;
-    const unsigned kr_a0 = rowbase + static_cast<unsigned>((64 * wave) * 256), kr_a1 = kr_a0 + 32 * 256;
+    const unsigned kr_a0 = rowbase + static_cast<unsigned>((64 * wave) * 256);
     const int krow0 = 64 * wave + r, ki0 = key0 + krow0, ki1 = ki0 + 32;
 #define ADT_UNIT(U, S, KR)                                                                                                      \
     asm volatile("ds_read_b128 %0, %3\n\tds_read_b128 %1, %3 offset:8192\n\tds_read_b128 %2, %4"                                \
@@ -447,6 +501,17 @@ __global__ __launch_bounds__(kFbThreads, 1) void attn_bwd_fused_kernel(FusedArgs
       hp[m] = pack2(pd[0], pd[1]);
       hs[m] = pack2(ds[0], ds[1]);
     };
+    // block 1, elements 2 t, 2 t + 1, 2 t + 8, 2 t + 9: their keep masks come from two hashes made right here (four scalar register pairs
+    // live at a time instead of thirty-two), then two arithmetic pairs
+    auto arith_quad1 = [&](int t) {
+      uint64_t km1[16];                                          // (only entries 2 t, 2 t + 1, 2 t + 8, 2 t + 9 are made and read)
+      if (kDrop) {
+        hash_masks(2 * t, vbq + 16u, km1);                       // block 1: keys + 32 = pairs + 16
+        hash_masks(2 * t + 1, vbq + 16u, km1);
+      }
+      arith_pair(t, st1, dp1, km1, pad2_1, kval1, qrel1, hp1, hs1);
+      arith_pair(t + 4, st1, dp1, km1, pad2_1, kval1, qrel1, hp1, hs1);
+    };
     auto write_ds = [&](int krow, const unsigned (&hs)[8]) {    // dS^T of a block to LDS for the dQ product
 #pragma unroll
       for (int g = 0; g < 4; ++g) {
@@ -497,8 +562,7 @@ __global__ __launch_bounds__(kFbThreads, 1) void attn_bwd_fused_kernel(FusedArgs
           else ADT_UNIT2(2, s + 3);
         }
         if (kDrop) {
-          hash_masks(s, vbq, km0);
-          hash_masks(s, vbq + 16u, km1);                         // block 1: keys + 32 = pairs + 16
+          hash_masks(s, vbq, km0);                               // block 0's keep masks (32 scalar registers); block 1's are made where they are used
           __builtin_amdgcn_sched_barrier(0);
         }
       }
@@ -511,9 +575,45 @@ __global__ __launch_bounds__(kFbThreads, 1) void attn_bwd_fused_kernel(FusedArgs
 #pragma unroll
       for (int g = 0; g < 4; ++g) ndv[g] = f32x4{0.f, 0.f, 0.f, 0.f};
     }
-    // ---- phase 2: the arithmetic of block 0
+    // ---- phase 2: the arithmetic of block 0 beside the dQ product of the PREVIOUS slice (its dS^T image is complete since that slice's
+    // barrier, and is overwritten only behind the barrier below)
+    f32x16 dq;
+    if (j > 0 && !(kDbg & 2)) {
+      // (here a ring of two units and ONE accumulation chain: the arithmetic between the products hides both latencies, and registers are scarce)
 #pragma unroll
-    for (int m = 0; m < 8; ++m) arith_pair(m, st0, dp0, km0, pad2_0, kval0, qrel0, hp0, hs0);
+      for (int i = 0; i < 16; ++i) dq[i] = 0.f;
+      mfma_srcc_ready(dq);
+      const unsigned ka_a = trbase ^ static_cast<unsigned>(64 * wave), xb_a = xbase + static_cast<unsigned>(kFbOffX);
+      TrFrag ka[2], xb[2];
+      ADT_TR2(ka[0], ka_a, 0);
+      ADT_TRX(xb[0], xb_a, 0);
+      ADT_TR2(ka[1], ka_a, 4096);
+      ADT_TRX(xb[1], xb_a, 1024);
+#define ADT_DQ2_STEP(KK)                                                                          \
+      if ((KK) + 1 < 16) asm volatile("s_waitcnt lgkmcnt(4)" ::: "memory");                       \
+      else asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                                     \
+      __builtin_amdgcn_sched_barrier(0);                                                          \
+      mfma_vgpr(dq, tr_get(ka[(KK) & 1]), tr_get(xb[(KK) & 1]));                                  \
+      __builtin_amdgcn_sched_barrier(0);                                                          \
+      if ((KK) + 2 < 16) {                                                                        \
+        ADT_TR2(ka[(KK) & 1], ka_a, ((KK) + 2) * 4096);                                           \
+        ADT_TRX(xb[(KK) & 1], xb_a, ((KK) + 2) * 1024);                                           \
+      }
+#define ADT_PH2(M)                                                                                \
+      ADT_DQ2_STEP(2 * (M))                                                                       \
+      ADT_DQ2_STEP(2 * (M) + 1)                                                                   \
+      arith_pair(M, st0, dp0, km0, pad2_0, kval0, qrel0, hp0, hs0);                               \
+      __builtin_amdgcn_sched_barrier(0);
+      ADT_PH2(0) ADT_PH2(1) ADT_PH2(2) ADT_PH2(3) ADT_PH2(4) ADT_PH2(5) ADT_PH2(6) ADT_PH2(7)
+#undef ADT_PH2
+#undef ADT_DQ2_STEP
+      mfma_settle(dq);
+    } else {
+#pragma unroll
+      for (int i = 0; i < 16; ++i) dq[i] = 0.f;
+#pragma unroll
+      for (int m = 0; m < 8; ++m) arith_pair(m, st0, dp0, km0, pad2_0, kval0, qrel0, hp0, hs0);
+    }
     __builtin_amdgcn_sched_barrier(0);
     // the dS^T image is single-buffered: every wave must have finished the previous slice's dQ product (they have, long ago: this barrier
     // does not wait in practice)
@@ -540,21 +640,21 @@ __global__ __launch_bounds__(kFbThreads, 1) void attn_bwd_fused_kernel(FusedArgs
         __builtin_amdgcn_sched_barrier(0);                                                                                      \
         ADT_TR2(fo[db], trb ^ static_cast<unsigned>(64 * db), 8192 + 16 * 256);                                                 \
         ADT_TR2(fqq[db], trb ^ static_cast<unsigned>(64 * db), 16 * 256);                                                       \
-        if (WITH_ARITH) { arith_pair(db, st1, dp1, km1, pad2_1, kval1, qrel1, hp1, hs1); __builtin_amdgcn_sched_barrier(0); }                    \
+        if (WITH_ARITH) { arith_quad1(db); __builtin_amdgcn_sched_barrier(0); }                                                 \
       }                                                                                                                         \
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                                                                        \
       __builtin_amdgcn_sched_barrier(0);                                                                                        \
       _Pragma("unroll") for (int db = 0; db < 4; ++db) {                                                                        \
         mfma_acc(dv[BLK][db], tr_get(fo[db]), pf1.v);                                                                          \
         mfma_acc(dk[BLK][db], tr_get(fqq[db]), dsf1.v);                                                                        \
-        if (WITH_ARITH) { __builtin_amdgcn_sched_barrier(0); arith_pair(4 + db, st1, dp1, km1, pad2_1, kval1, qrel1, hp1, hs1); __builtin_amdgcn_sched_barrier(0); } \
+        (void)0;                                                                                                                \
       }                                                                                                                         \
     }
     if (!(kDbg & 4)) {
       ADT_DVDK(0, hp0, hs0, true)
     } else {
 #pragma unroll
-      for (int m = 0; m < 8; ++m) arith_pair(m, st1, dp1, km1, pad2_1, kval1, qrel1, hp1, hs1);
+      for (int t = 0; t < 4; ++t) arith_quad1(t);
     }
     __builtin_amdgcn_sched_barrier(0);
     ADT_STAMP(4)
@@ -578,47 +678,6 @@ __global__ __launch_bounds__(kFbThreads, 1) void attn_bwd_fused_kernel(FusedArgs
     }
     fl = nstep ? static_cast<unsigned>(__builtin_amdgcn_readfirstlane(fv)) : 0u;
 
-    // ---- dQ^T, d-block `wave`, over the workgroup's 256 keys (16 k-steps of 16 keys, two per wait)
-    f32x16 dq;
-#pragma unroll
-    for (int i = 0; i < 16; ++i) dq[i] = 0.f;
-    if (!(kDbg & 2)) {
-      f32x16 dq2;                                                 // two accumulation chains (even / odd k-steps): a product waits ~100 cycles for the previous one on the same VGPR accumulator
-#pragma unroll
-      for (int i = 0; i < 16; ++i) dq2[i] = 0.f;
-      mfma_srcc_ready(dq, dq2);
-      const unsigned ka_a = trbase ^ static_cast<unsigned>(64 * wave), xb_a = xbase + static_cast<unsigned>(kFbOffX);
-      TrFrag ka[4], xb[4];                                        // operand ring: three k-steps ahead of the product (one wave per SIMD: nobody else hides the LDS latency)
-      ADT_TR2(ka[0], ka_a, 0);
-      ADT_TRX(xb[0], xb_a, 0);
-      ADT_TR2(ka[1], ka_a, 4096);
-      ADT_TRX(xb[1], xb_a, 1024);
-      ADT_TR2(ka[2], ka_a, 2 * 4096);
-      ADT_TRX(xb[2], xb_a, 2 * 1024);
-#define ADT_DQ_STEP(KK)                                                                           \
-      if ((KK) + 3 < 16) {                                                                        \
-        ADT_TR2(ka[((KK) + 3) & 3], ka_a, ((KK) + 3) * 4096);                                     \
-        ADT_TRX(xb[((KK) + 3) & 3], xb_a, ((KK) + 3) * 1024);                                     \
-        asm volatile("s_waitcnt lgkmcnt(12)" ::: "memory");                                       \
-      } else if ((KK) + 2 < 16) {                                                                 \
-        asm volatile("s_waitcnt lgkmcnt(8)" ::: "memory");                                        \
-      } else if ((KK) + 1 < 16) {                                                                 \
-        asm volatile("s_waitcnt lgkmcnt(4)" ::: "memory");                                        \
-      } else {                                                                                    \
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                                        \
-      }                                                                                           \
-      __builtin_amdgcn_sched_barrier(0);                                                          \
-      if ((KK) & 1) mfma_vgpr(dq2, tr_get(ka[(KK) & 3]), tr_get(xb[(KK) & 3]));                   \
-      else mfma_vgpr(dq, tr_get(ka[(KK) & 3]), tr_get(xb[(KK) & 3]));                             \
-      __builtin_amdgcn_sched_barrier(0);
-      ADT_DQ_STEP(0) ADT_DQ_STEP(1) ADT_DQ_STEP(2) ADT_DQ_STEP(3) ADT_DQ_STEP(4) ADT_DQ_STEP(5) ADT_DQ_STEP(6) ADT_DQ_STEP(7)
-      ADT_DQ_STEP(8) ADT_DQ_STEP(9) ADT_DQ_STEP(10) ADT_DQ_STEP(11) ADT_DQ_STEP(12) ADT_DQ_STEP(13) ADT_DQ_STEP(14) ADT_DQ_STEP(15)
-#undef ADT_DQ_STEP
-      mfma_settle(dq, dq2);
-#pragma unroll
-      for (int i = 0; i < 16; ++i) dq[i] += dq2[i];
-    }
-
     ADT_STAMP(8)
     // ---- this iteration's reduction step, then this slice's own tile
     if (step) {
@@ -629,21 +688,7 @@ __global__ __launch_bounds__(kFbThreads, 1) void attn_bwd_fused_kernel(FusedArgs
       }
       add_step(sjr, sn);
     }
-    if (!handoff) {
-      store_dq(dq, j);
-    } else {
-      // write-through (sc1) 16-byte stores as compiler-visible buffer stores: an inline-asm store gets no hazard wait states before the
-      // next instruction that overwrites its data registers
-      const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(part_of(j, kb), 0, 4096, 0x00020000);
-      int lane_s = lane;
-      asm volatile("" : "+v"(lane_s));
-#pragma unroll
-      for (int g = 0; g < 4; ++g) {
-        const u32x4 o = {__float_as_uint(dq[4 * g]), __float_as_uint(dq[4 * g + 1]), __float_as_uint(dq[4 * g + 2]), __float_as_uint(dq[4 * g + 3])};
-        __builtin_amdgcn_raw_buffer_store_b128(o, rsrc, (g * 64 + lane_s) * 16, 0, 16);    // aux 16 = sc1
-      }
-      pub_pending = j;
-    }
+    if (j > 0) hand_on(dq, j - 1);
     cur_jr = njr;
     cur_n = nn;
     ADT_STAMP(9)
@@ -652,6 +697,31 @@ __global__ __launch_bounds__(kFbThreads, 1) void attn_bwd_fused_kernel(FusedArgs
   if (key_mask) run_slices(std::true_type{});
   else run_slices(std::false_type{});
 #undef ADT_STAMP
+  {                                                               // the last slice's dQ product (its dS^T image is complete: the loop ends on a barrier)
+    f32x16 dq;
+    if (!(kDbg & 2)) {
+      ADT_DQ_BEGIN
+      ADT_DQ_STEP(0) ADT_DQ_STEP(1) ADT_DQ_STEP(2) ADT_DQ_STEP(3) ADT_DQ_STEP(4) ADT_DQ_STEP(5) ADT_DQ_STEP(6) ADT_DQ_STEP(7)
+      ADT_DQ_STEP(8) ADT_DQ_STEP(9) ADT_DQ_STEP(10) ADT_DQ_STEP(11) ADT_DQ_STEP(12) ADT_DQ_STEP(13) ADT_DQ_STEP(14) ADT_DQ_STEP(15)
+      ADT_DQ_END
+    } else {
+#pragma unroll
+      for (int i = 0; i < 16; ++i) dq[i] = 0.f;
+    }
+    const int prev_pending = pub_pending;
+    hand_on(dq, ns - 1);
+    if (handoff) {
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      if (lane == 0) {
+        if (prev_pending >= 0) __hip_atomic_fetch_add(flag_of(prev_pending, kb), 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_fetch_add(flag_of(ns - 1, kb), 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      }
+      pub_pending = -1;
+    }
+  }
+#undef ADT_DQ_BEGIN
+#undef ADT_DQ_STEP
+#undef ADT_DQ_END
 #undef ADT_TR2
 #undef ADT_TRX
 
@@ -661,19 +731,38 @@ __global__ __launch_bounds__(kFbThreads, 1) void attn_bwd_fused_kernel(FusedArgs
     store_transposed(dk[blk], a.scale, a.dk + static_cast<long>(b) * a.Sk * a.ldk + head * kDh, a.ldk, ki, a.Sk, lane);
     store_transposed(dv[blk], 1.0f, a.dv + static_cast<long>(b) * a.Sk * a.ldv + head * kDh, a.ldv, ki, a.Sk, lane);
   }
-  // ---- behind the last slice: publish the last tile, then the reduction steps that were still to come (synchronously)
+  // ---- behind the last slice: the reduction steps that were still to come, in batches: the K / dS^T / tile images are dead now and give
+  // seven landing slots per wave, so the open steps' flags are polled together (a lane each), their tiles land together, and only the
+  // additions run in sequence -- one flag latency and one DMA latency for the whole tail instead of one of each per step
   if (handoff) {
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    if (pub_pending >= 0 && lane == 0) __hip_atomic_fetch_add(flag_of(pub_pending, kb), 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    for (;; advance(cur_jr, cur_n)) {
-      if (cur_n < 0) continue;
-      const int jr = cur_jr, n = cur_n;
-      if (jr >= ns) break;
-      if (n != kb) wait_flag(jr, n);
-      land(jr, n);
+    __syncthreads();                                               // every wave has finished its last dQ product: the images may be overwritten
+    constexpr int kSlots = kFbOffS / (4 * 4096);
+    while (cur_n < 0) advance(cur_jr, cur_n);
+    while (cur_jr < ns) {
+      // lane i < kSlots: the i-th open step
+      int ljr = cur_jr, ln = cur_n;
+      for (int i = 0; i < kSlots; ++i)
+        if (i < lane) advance(ljr, ln);
+      const bool need = lane < kSlots && ljr < ns && ln != kb;
+      unsigned spins = 0;
+      for (;;) {
+        unsigned f = 1u;
+        if (need) f = __hip_atomic_load(flag_of(ljr, ln), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (__builtin_amdgcn_ballot_w64(f == 0u) == 0ull) break;
+        if (++spins > kFbSpinLimit) {                             // never in a healthy launch: report and carry on instead of hanging the GPU
+          if (lane == 0) atomicAdd(fa.flags + static_cast<long>(a.B) * a.H * ns * nkb * 4, 1u);
+          break;
+        }
+        __builtin_amdgcn_s_sleep(8);
+      }
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+      int tjr = cur_jr, tn = cur_n, cnt = 0;
+      for (; cnt < kSlots && tjr < ns; ++cnt, advance(tjr, tn)) land_to(tjr, tn, (cnt * 4 + wave) * 4096);
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-      add_step(jr, n);
-      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      for (int i = 0; i < cnt; ++i, advance(cur_jr, cur_n)) {
+        add_step_from(cur_jr, cur_n, smem_base + static_cast<unsigned>((i * 4 + wave) * 4096 + lane * 16));
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      }
     }
   }
 }

@@ -95,12 +95,27 @@ def test_forward_and_backward(B, H, Sq, Sk, causal, padded):
     assert torch.equal(o, o2) and torch.equal(lse, lse2)
 
 
-@pytest.mark.parametrize("variant", ["1", "2", "3"])
-@pytest.mark.parametrize("B,H,Sq,Sk,causal,padded", [CASES[2], CASES[3], CASES[5], CASES[8], CASES[10]])
-def test_dkv_kernel_variants(monkeypatch, variant, B, H, Sq, Sk, causal, padded):
-    """The A/B arms of the dK / dV kernel (ADT_ATTN_DKV: 1 single wave, 2 producer / consumer wave pairs, 3 eight symmetric waves with
-    waves 4-7 staggered; 4 = the default, eight symmetric waves, covered above) against the same fp32 reference, with and without
-    dropout masks (dropout: all arms regenerate the same mask, so they must agree with the default kernel to rounding)."""
+def _bwd(k, mode, q, kk, v, o, dout, lse, B, H, Sq, Sk, scale, causal, key_len, drop, monkeypatch, dkv=None):
+    monkeypatch.setenv("ADT_ATTN_BWD", mode)
+    if dkv:
+        monkeypatch.setenv("ADT_ATTN_DKV", dkv)
+    d = q.shape[1]
+    dq, dkv_ = torch.zeros_like(q), torch.zeros((kk.shape[0], 2 * d), dtype=q.dtype, device=q.device)
+    k.attn_bwd(q, kk, v, o, dout, lse, dq, dkv_[:, :d], dkv_[:, d:], B, H, Sq, Sk, scale, causal, key_len, drop=drop)
+    torch.cuda.synchronize()
+    monkeypatch.delenv("ADT_ATTN_BWD")
+    if dkv:
+        monkeypatch.delenv("ADT_ATTN_DKV")
+    return dq, dkv_
+
+
+@pytest.mark.parametrize("B,H,Sq,Sk,causal,padded", CASES)
+def test_the_two_backward_paths_agree(monkeypatch, B, H, Sq, Sk, causal, padded):
+    """The one-kernel backward (attention_bwd_fused.hip: 5 products, dQ summed over the key-block workgroups by a scheduled fan-in in a
+    fixed order) and the two-kernel backward (dQ kernel + dK/dV kernel), forced by ADT_ATTN_BWD, on every shape of CASES (1 to 4 key blocks
+    of 256, 1 to 31 query slices, ragged ends, both additive masks), without and with dropout: both regenerate the same dropout masks, so
+    they agree to rounding (the summation orders differ); each is bitwise repeatable; without dropout both are checked against the fp32
+    reference.  Also the two-kernel path's staggered dK/dV arm (ADT_ATTN_DKV=3)."""
     from adt_str_amd import kernels as k
     d = H * 128
     q = rnd((B * Sq, d), 11).bfloat16()
@@ -111,22 +126,42 @@ def test_dkv_kernel_variants(monkeypatch, variant, B, H, Sq, Sk, causal, padded)
     dout = rnd((B * Sq, d), 13).bfloat16()
     for drop in (None, (0.1, 777)):
         o, lse = k.attn_fwd(q, kk, v, B, H, Sq, Sk, scale, causal, key_len, drop=drop)
-        outs = {}
-        for var in ("4", variant):
-            monkeypatch.setenv("ADT_ATTN_DKV", var)
-            dq, dkv = torch.zeros_like(q), torch.zeros_like(kv)
-            k.attn_bwd(q, kk, v, o, dout, lse, dq, dkv[:, :d], dkv[:, d:], B, H, Sq, Sk, scale, causal, key_len, drop=drop)
-            outs[var] = (dq, dkv)
-        monkeypatch.delenv("ADT_ATTN_DKV")
-        assert torch.equal(outs["4"][0], outs[variant][0])                       # dQ does not depend on the arm
-        ref, got = outs["4"][1].float(), outs[variant][1].float()
-        assert (got - ref).abs().max().item() <= 1.5e-2 * ref.abs().max().item() + 1e-6, (variant, drop)
+        args = (q, kk, v, o, dout, lse, B, H, Sq, Sk, scale, causal, key_len, drop, monkeypatch)
+        fused, fused2 = _bwd(k, "fused", *args), _bwd(k, "fused", *args)
+        split, stag = _bwd(k, "split", *args), _bwd(k, "split", *args, dkv="3")
+        assert torch.equal(fused[0], fused2[0]) and torch.equal(fused[1], fused2[1])          # fixed summation order: no atomics anywhere
+        assert torch.equal(split[0], stag[0])                                                  # dQ does not depend on the dK/dV arm
+        for name, got, ref in (("dq", fused[0], split[0]), ("dkv", fused[1], split[1]), ("dkv staggered", stag[1], split[1])):
+            err = (got.float() - ref.float()).abs().max().item()
+            assert math.isfinite(err) and err <= 1.5e-2 * ref.float().abs().max().item() + 1e-6, (name, drop, err)
         if drop is None:
             qr, kr, vr = (t.float().clone().requires_grad_(True) for t in (q, kk, v))
             ref_o, _ = reference(qr, kr, vr, B, H, Sq, Sk, scale, causal, key_len.long() if padded else None)
             ref_o.backward(dout.float())
-            for name, g_, r_ in (("dk", got[:, :d], kr.grad), ("dv", got[:, d:], vr.grad)):
-                assert (g_ - r_).abs().max().item() <= 4e-2 * r_.abs().max().item() + 1e-6, (variant, name)
+            for path, (gq, gkv) in (("fused", fused), ("split", split)):
+                for name, g_, r_ in (("dq", gq, qr.grad), ("dk", gkv[:, :d], kr.grad), ("dv", gkv[:, d:], vr.grad)):
+                    assert (g_.float() - r_).abs().max().item() <= 4e-2 * r_.abs().max().item() + 1e-6, (path, name)
+
+
+def test_fused_backward_reuses_a_dirty_workspace(monkeypatch):
+    """The fan-in's tiles and flags live in the caller's workspace, which the next call reuses as it is: flags are zeroed by the launcher,
+    stale tiles of another shape / other data must never be read (they are published write-through and read past L1).  Alternate two
+    problems with different data on one workspace and compare each result with its first run."""
+    from adt_str_amd import kernels as k
+    scale = 1.0 / math.sqrt(128)
+    probs = []
+    for seed, (B, H, Sq, Sk) in enumerate([(2, 6, 986, 986), (3, 2, 300, 700)]):
+        d = H * 128
+        q = rnd((B * Sq, d), 40 + seed).bfloat16()
+        kv = rnd((B * Sk, 2 * d), 50 + seed).bfloat16()
+        dout = rnd((B * Sq, d), 60 + seed).bfloat16()
+        o, lse = k.attn_fwd(q, kv[:, :d], kv[:, d:], B, H, Sq, Sk, scale)
+        probs.append((q, kv[:, :d], kv[:, d:], o, dout, lse, B, H, Sq, Sk, scale, False, None, None, monkeypatch))
+    first = [_bwd(k, "fused", *p) for p in probs]
+    for _ in range(3):
+        for p, f in zip(probs, first):
+            g = _bwd(k, "fused", *p)
+            assert torch.equal(g[0], f[0]) and torch.equal(g[1], f[1])
 
 
 def test_exact_selector():

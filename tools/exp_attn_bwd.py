@@ -80,7 +80,6 @@ def main():
             for mode in ("split", "fused"):
                 os.environ["ADT_ATTN_BWD"] = mode
                 res[mode] = timeit(lambda: K.attn_bwd(q, kk, v, o, dout, lse, dq, dk, dv, B, H, Sq, Sk, scale, causal, None, drop=drop))
-            fl = 10.0 * B * H * Sq * Sk * 128
             if mode == "fused" and name == "encoder" and os.environ.get("ADT_FB_SWEEP"):
                 for dbg in (1, 2, 3, 4, 7, 8, 15):
                     os.environ["ADT_FB_DBG"] = str(dbg)

@@ -18,7 +18,7 @@ kk, v = kv[:, :d], kv[:, d:]
 dout = torch.randn((B * S, d), generator=g).to(dev).bfloat16()
 scale = 1.0 / math.sqrt(128)
 os.environ["ADT_ATTN_BWD"] = "fused"
-names = ["top->ph1", "ph1 (chain b0 + hashes)", "ph2 (chain b1 | arith b0)", "xbarrier+write", "ph3 (dvdk b0 | arith b1)", "ph4 (dvdk b1)", "vmcnt wait", "barrier", "dQ product", "reduce step + own tile"]
+names = ["top->ph1", "ph1 (S, dP both blocks + hashes b0)", "ph2 (arith b0 | dQ of prev slice)", "xbarrier+write", "ph3 (dvdk b0 | arith b1)", "ph4 (dvdk b1)", "vmcnt wait", "barrier", "(empty)", "reduce step + own tile"]
 for drop in (None, (0.1, 5)):
     o, lse = K.attn_fwd(q, kk, v, B, H, S, S, scale, False, None, drop=drop)
     dq, dkv = torch.zeros_like(q), torch.zeros_like(kv)
