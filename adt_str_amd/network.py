@@ -178,6 +178,9 @@ class _Engine:
         self.drop_base = 0               # what seed_dropout() started the counter from (rank-specific); drop_seed - drop_base = passes drawn
         self._sites: Dict[str, int] = {}
         self.generation = 0              # bumped by every pass that writes the gradient buffers (see _ADTLossFn.backward)
+        self.hf_reducer = None           # HF Trainer + DDP: GradReducer driven by this engine's backward (trainer.install_engine_reduction)
+        self.hf_sync = lambda: True      # ... and whether the wrapper wants this pass reduced (False inside DDP.no_sync())
+        self.reduced_generation = -1     # generation whose gradients were averaged by hf_reducer (DDP's comm hook then passes them through)
         self._wg_pending = []            # deferred decoder weight-gradient products (see _wgrad)
 
     def seed_dropout(self, seed: int, rank: int = 0):
@@ -673,7 +676,18 @@ class _ADTLossFn(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, engine, src, tgt, pad_mask, labels, *params):
+        # Under DistributedDataParallel (the reference's ``accelerate launch train.py <yaml>``) the engine's own backward pass drives the
+        # gradient all-reduce: ``trainer.install_engine_reduction`` hooks a GradReducer to the segments as they finish, so the collectives
+        # run under the remaining backward kernels instead of after all of them (DDP only sees the gradients when autograd hands them over,
+        # all 132 at once).  What autograd / DDP then receive is already the mean over the ranks; DDP's comm hook passes it through.
+        red = engine.hf_reducer
+        sync = red is not None and engine.hf_sync()
+        if red is not None:
+            red.enabled = sync
         out = engine.loss_and_grads(src, tgt, pad_mask, labels, want_grads=True)
+        if sync:
+            red.finish()
+            engine.reduced_generation = engine.generation
         ctx.engine, ctx.generation = engine, engine.generation
         return out["loss"].clone()
 

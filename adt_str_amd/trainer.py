@@ -221,6 +221,46 @@ class GradReducer:
         return out
 
 
+def install_engine_reduction(ddp_model, accumulation_steps: int = 1, timing: bool = False):
+    """HF Trainer + ``DistributedDataParallel`` (the reference's ``accelerate launch train.py <yaml>``, README.md:53-57, train.py:305-319): let
+    the engine's backward pass drive the gradient all-reduce.  DDP's buckets are filled when autograd delivers the gradients, and the
+    autograd bridge delivers all 132 at once AFTER the whole hand-written backward pass -- 276 MB of all-reduce fully exposed every step.
+    Here a ``GradReducer`` is hooked to the engine's gradient segments exactly as in the native loop (decoder block first, then each encoder
+    layer: all but the last ~31 MB travel under the remaining backward kernels), the bridge returns the averaged gradients, and DDP gets a
+    comm hook that passes a bucket through when the engine has already averaged this pass (and runs the ordinary all-reduce otherwise:
+    inside ``no_sync()`` nothing is sent by either, and with gradient accumulation the engine leaves the reduction to DDP, which reduces the
+    accumulated sum on the last micro-step).  Idempotent; returns the reducer (None when not applicable)."""
+    from torch.distributed.algorithms.ddp_comm_hooks import default_hooks
+    from torch.nn.parallel import DistributedDataParallel as DDP
+    if not isinstance(ddp_model, DDP) or not hasattr(ddp_model.module, "engine"):
+        return None
+    eng = ddp_model.module.engine
+    if getattr(eng, "_hf_hook_installed", False):
+        return eng.hf_reducer
+    eng._hf_hook_installed = True
+    pg = ddp_model.process_group
+    if accumulation_steps <= 1:
+        gflat, _ = eng.grad_buffers()
+        red = GradReducer(gflat, pg, timing=timing)
+        eng.hf_reducer = red
+        eng.hf_sync = lambda: bool(ddp_model.require_backward_grad_sync)
+        eng.grad_ready_hook = red.segment_ready
+    stats = {"passed_through": 0, "reduced_by_ddp": 0}
+    eng.hf_hook_stats = stats
+
+    def hook(state, bucket):
+        if eng.reduced_generation == eng.generation:              # this pass's gradients arrived averaged: nothing to send
+            stats["passed_through"] += 1
+            fut = torch.futures.Future()
+            fut.set_result(bucket.buffer())
+            return fut
+        stats["reduced_by_ddp"] += 1
+        return default_hooks.allreduce_hook(pg, bucket)
+
+    ddp_model.register_comm_hook(None, hook)
+    return eng.hf_reducer
+
+
 def backward_segments(engine):
     """The flat ranges in the order the backward pass completes them (network._Engine._backward)."""
     segs = [engine.flat_range("decoder.")]

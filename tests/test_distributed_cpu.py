@@ -168,3 +168,109 @@ def test_curation_embedding_shards_and_gathers_world_size_2(tmp_path):
     for p in procs:
         p.join(timeout=60)
     assert sorted(res) == [(0, "ok"), (1, "ok")], res
+
+
+def _hf_overlap_worker(rank, world, port, q, accumulation):
+    """The reference's launch (HF Trainer + DistributedDataParallel around the autograd bridge) on two gloo ranks, with the engine's
+    kernels replaced by a stand-in that produces rank-dependent gradients segment by segment in the backward pass's own order: everything
+    else is the product's code (network._ADTLossFn, trainer.install_engine_reduction, GradReducer, DDP and its comm hook)."""
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        import time
+        from torch.nn.parallel import DistributedDataParallel as DDP
+        from adt_str_amd import trainer as T
+        from adt_str_amd.network import ADTModel, ADTModelConfig
+        torch.manual_seed(0)
+        model = ADTModel(ADTModelConfig(input_sec=0.5, time_res=0.01, win_length=2048, sample_rate=16000, enc_layers=2, dec_layers=1,
+                                        nhead=1, d_query=128, dropout=0.0, tgt_vocab_size=1400, plain=True, n_mels=128))
+        eng = model.engine
+        gflat, _ = eng.grad_buffers()
+        n = gflat.numel()
+        base = (torch.arange(n, dtype=torch.float32) % 997) * 1e-3
+        events = []                                             # ("collective", t) / ("backward_end", t)
+        calls = {"n": 0}
+
+        def fake_loss_and_grads(src, tgt, pad, labels, want_grads=True, return_logits=False):
+            calls["n"] += 1
+            eng.generation += 1
+            gflat.copy_(base * (rank + 1) * calls["n"])          # this rank's local gradient of this pass
+            for pre in ("decoder.",) + tuple(L["p"] + "." for L in reversed(eng.enc)):
+                time.sleep(0.01)                                 # the rest of the backward pass is still running ...
+                eng._ready(pre)                                  # ... when this segment is final
+            eng._ready("encoder.dense_layer.", "encoder.layer_norm.", "project_to_mel.")
+            events.append(("backward_end", time.perf_counter()))
+            return {"loss": torch.tensor([float(rank + 1)])[0]}
+
+        eng.loss_and_grads = fake_loss_and_grads
+        eng.refresh_weights = lambda force=False: None
+        eng._flush_reductions = lambda: None
+        real_all_reduce = dist.all_reduce
+
+        def counting_all_reduce(t, *a, **k):
+            events.append(("collective", time.perf_counter(), t.numel()))
+            return real_all_reduce(t, *a, **k)
+
+        dist.all_reduce = counting_all_reduce
+        ddp = DDP(model, broadcast_buffers=False)
+        red = T.install_engine_reduction(ddp, accumulation)
+        assert T.install_engine_reduction(ddp, accumulation) is red                       # idempotent
+        assert (red is not None) == (accumulation == 1)
+        src, tgt = torch.zeros(2, 8000), torch.zeros(2, 4, dtype=torch.long)
+        pad, labels = torch.zeros(2, 4, dtype=torch.bool), torch.zeros(2, 4, dtype=torch.long)
+
+        def step(sync=True):
+            ctx = ddp.no_sync() if not sync else __import__("contextlib").nullcontext()
+            with ctx:
+                loss = ddp(src=src, tgt=tgt, tgt_mask=None, tgt_padding_mask=pad, labels=labels)
+                (loss / accumulation).backward()
+
+        if accumulation == 1:
+            step()
+            mean = base * (sum(r + 1 for r in range(world)) / world)
+            got = torch.cat([p.grad.reshape(-1) for p in eng.named.values()])
+            assert torch.allclose(got, mean, rtol=1e-6, atol=1e-7), (got[:4], mean[:4])
+            coll = [e for e in events if e[0] == "collective"]
+            end = [e for e in events if e[0] == "backward_end"][0][1]
+            segs = T.backward_segments(eng)
+            assert len(coll) == len(segs) and sum(e[2] for e in coll) == n                # one all-reduce per segment, nothing else ...
+            assert coll[0][1] < end and sum(1 for e in coll if e[1] < end) >= len(segs) - 3  # ... started while the backward pass was still running
+            assert eng.hf_hook_stats["passed_through"] >= 1 and eng.hf_hook_stats["reduced_by_ddp"] == 0   # DDP's buckets sent nothing
+            # a pass inside no_sync() sends nothing at all and leaves the local gradient (accumulated by autograd)
+            events.clear()
+            model.zero_grad(set_to_none=True)
+            step(sync=False)
+            assert not [e for e in events if e[0] == "collective"]
+            got = torch.cat([p.grad.reshape(-1) for p in eng.named.values()])
+            assert torch.allclose(got, base * (rank + 1) * 2, rtol=1e-6)
+        else:
+            # with accumulation the engine leaves the reduction to DDP: local sums, reduced once on the last micro-step
+            step(sync=False)
+            step(sync=True)
+            got = torch.cat([p.grad.reshape(-1) for p in eng.named.values()])
+            local = lambda r: base * (r + 1) * (1 + 2) / accumulation
+            mean = sum(local(r) for r in range(world)) / world
+            assert torch.allclose(got, mean, rtol=1e-5, atol=1e-7)
+            assert eng.hf_hook_stats["reduced_by_ddp"] >= 1 and eng.hf_hook_stats["passed_through"] == 0
+        q.put((rank, "ok"))
+    except Exception as e:                                      # pragma: no cover
+        import traceback
+        q.put((rank, "fail: " + repr(e) + traceback.format_exc()[-1500:]))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("accumulation", [1, 2])
+def test_hf_path_overlaps_its_all_reduce_with_the_backward_pass(accumulation):
+    """``accelerate launch train.py <yaml>`` (the reference's README.md:53-57): under DDP the engine's backward pass drives one all-reduce per
+    gradient segment while it is still running; DDP's own buckets then pass the averaged gradients through (world size 2, gloo)."""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_hf_overlap_worker, args=(r, 2, port, q, accumulation)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=180) for _ in procs]
+    for p in procs:
+        p.join(timeout=60)
+    assert all(r[1] == "ok" for r in res), res

@@ -73,6 +73,27 @@ def _worker(port, q):
         fc, _ = run(dist.group.WORLD, compress="bf16")
         res["compress_bytes"] = fc.reducer.comm_stats()["bytes_per_step"]
         res["compress_max_dev"] = float((fc.pflat - plain.pflat).abs().max())
+        # (5) the HF path under DistributedDataParallel (world size 1 on RCCL): the engine's backward pass drives the all-reduce, DDP's
+        #     buckets pass the gradients through; the gradients autograd ends up with are bitwise the plain bridge's
+        from torch.nn.parallel import DistributedDataParallel as DDP
+        from adt_str_amd.masks import create_mask_plain
+        from adt_str_amd.trainer import install_engine_reduction
+        wav, tok, tl = _batch(seed=31)
+        _, pad = create_mask_plain(tok.shape[1] - 1, tl, wav.device)
+
+        def grads(wrap):
+            m = _make(seed=13).train()
+            net = DDP(m, device_ids=[0], broadcast_buffers=False) if wrap else m
+            red = install_engine_reduction(net) if wrap else None
+            net(src=wav, tgt=tok[:, :-1], tgt_mask=None, tgt_padding_mask=pad, labels=tok[:, 1:]).backward()
+            torch.cuda.synchronize()
+            return torch.cat([p.grad.reshape(-1) for p in m.engine.named.values()]), red, m.engine
+
+        g_plain, _, _ = grads(False)
+        g_ddp, red_hf, eng_hf = grads(True)
+        res["hf_ddp_bitwise"] = bool(torch.equal(g_plain, g_ddp))
+        res["hf_reducer_ran"] = red_hf is not None and red_hf.steps == 1 and red_hf.bytes_last_step == 4 * g_ddp.numel()
+        res["hf_ddp_passed_through"] = eng_hf.hf_hook_stats["passed_through"] >= 1 and eng_hf.hf_hook_stats["reduced_by_ddp"] == 0
         q.put(("ok", res))
     except Exception as e:                                 # pragma: no cover
         import traceback
@@ -97,3 +118,4 @@ def test_reducer_and_trainer_on_rccl_world_size_one():
     assert res["accum_reduces_once_per_step"] and res["accum_bitwise"]
     assert res["compress_bytes"] == 2 * res["n"]
     assert res["compress_max_dev"] < 3 * 1e-3 * 3, res["compress_max_dev"]       # <= lr per step per element, three steps
+    assert res["hf_ddp_bitwise"] and res["hf_reducer_ran"] and res["hf_ddp_passed_through"]

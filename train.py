@@ -43,6 +43,10 @@ class ADTTrainer(Trainer):
     """HF Trainer subclass of the reference (train.py:33-78)."""
 
     def compute_loss(self, model, inputs, return_outputs=False, **kwargs):
+        if not getattr(self, "_engine_reduction_checked", False):           # multi-GPU: `model` is the DDP wrapper accelerate built
+            from adt_str_amd.trainer import install_engine_reduction
+            install_engine_reduction(model, getattr(self.args, "gradient_accumulation_steps", 1))
+            self._engine_reduction_checked = True
         model.train()
         device = next(model.parameters()).device
         tokens = inputs["tokens"].to(device)
