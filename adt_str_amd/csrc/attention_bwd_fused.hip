@@ -389,6 +389,26 @@ __global__ __launch_bounds__(kFbThreads, 1) void attn_bwd_fused_kernel(FusedArgs
   // ones; the choice is per workgroup, and a run-time flag inside the loop costs two taken branches per pair of elements.
   auto run_slices = [&](auto masked_tag) {
   constexpr bool kMasked = decltype(masked_tag)::value;
+  // dropout: block 0's keep masks of the coming slice are made during phase 4 of the running one (pure matrix work, the vector pipe idles)
+  // and carried in scalar registers; block 1's hashes are made during phase 1 (hw) and turned into masks where phase 3 uses them
+  uint64_t km0[16];
+  auto masks_from_hash = [&](int e, unsigned hh, uint64_t (&km)[16]) {      // hash e of a block gives the masks of its accumulator registers e and e + 8
+    const uint64_t even = 0x5555555555555555ull, odd = 0xaaaaaaaaaaaaaaaaull;
+    const uint64_t c_lo = __builtin_amdgcn_ballot_w64((hh << 16) >= thr16);       // decision of the pair's even key
+    const uint64_t c_hi = __builtin_amdgcn_ballot_w64(hh >= thr16);               // ... of its odd key
+    km[e] = (c_lo & even) | ((c_hi & even) << 1);
+    km[e + 8] = (c_hi & odd) | ((c_lo & odd) >> 1);
+  };
+  const unsigned headpair0 = static_cast<unsigned>(static_cast<uint64_t>(bh) * a.Sq * sk_pairs) + static_cast<unsigned>((key0 + 64 * wave + r) >> 1);
+  auto slice_hash = [&](int jj, int blk, int e) {                  // pair (query row (e & 3) + 8 (e >> 2) + 16 par + 4 h of slice jj, this lane's key pair of block blk)
+    return mix32((headpair0 + (blk ? 16u : 0u) + static_cast<unsigned>(jj * kFbSlice + 16 * static_cast<int>(par) + 4 * h + (e & 3) + 8 * (e >> 2)) * sk_pairs) ^ key2);
+  };
+#pragma unroll
+  for (int e = 0; e < 16; ++e) km0[e] = 0;
+  if (kDrop) {
+#pragma unroll
+    for (int e = 0; e < 8; ++e) masks_from_hash(e, slice_hash(0, 0, e), km0);
+  }
   for (int j = 0; j < ns; ++j) {
     asm volatile("" : "+v"(rowbase), "+v"(trbase), "+v"(xbase));    // keep the per-k-step / per-d-block addresses derived from these out of loop-invariant registers
     const int sjr = cur_jr, sn = cur_n;
@@ -416,7 +436,6 @@ __global__ __launch_bounds__(kFbThreads, 1) void attn_bwd_fused_kernel(FusedArgs
     // sched_barrier(0) pins the interleave: one pair of MFMAs, then one pair of elements' arithmetic (or one hash).
     f32x16 st0, dp0, st1, dp1;
     unsigned hp0[8], hs0[8], hp1[8], hs1[8];
-    uint64_t km0[16];
     f32x4 ndv[4];
     bf16x8 fq[3], fd[3], fk[3];                                   // operand ring of the chains: two k-steps ahead
     const unsigned tq_a = rowbase + slot;
@@ -450,18 +469,8 @@ __global__ __launch_bounds__(kFbThreads, 1) void attn_bwd_fused_kernel(FusedArgs
       else if ((S) % 3 == 1) ADT_UNIT(1, (S) + 3, KR);                                                                          \
       else ADT_UNIT(2, (S) + 3, KR);                                                                                            \
     }
-    // keep masks: one 64-bit lane mask per accumulator register (the two lanes of a key pair share every hash: dropout.h); hash e of a
-    // block gives the masks of its accumulator registers e and e + 8
-    const unsigned headpair = static_cast<unsigned>(static_cast<uint64_t>(bh) * a.Sq * sk_pairs) + static_cast<unsigned>(ki0 >> 1);
-    const unsigned vbq = headpair + static_cast<unsigned>(j * kFbSlice + 16 * static_cast<int>(par) + 4 * h) * sk_pairs;
-    auto hash_masks = [&](int e, unsigned pair0, uint64_t (&km)[16]) {
-      const uint64_t even = 0x5555555555555555ull, odd = 0xaaaaaaaaaaaaaaaaull;
-      const unsigned hh = mix32((pair0 + static_cast<unsigned>((e & 3) + 8 * (e >> 2)) * sk_pairs) ^ key2);
-      const uint64_t c_lo = __builtin_amdgcn_ballot_w64((hh << 16) >= thr16);       // decision of the pair's even key
-      const uint64_t c_hi = __builtin_amdgcn_ballot_w64(hh >= thr16);               // ... of its odd key
-      km[e] = (c_lo & even) | ((c_hi & even) << 1);
-      km[e + 8] = (c_hi & odd) | ((c_lo & odd) >> 1);
-    };
+    // keep masks: one 64-bit lane mask per accumulator register (the two lanes of a key pair share every hash: dropout.h)
+    unsigned hw[8];                                               // block 1's hash words of this slice (made in phase 1)
     // softmax / dropout / dS arithmetic of elements 2 m, 2 m + 1 of a block: P (dropped) and dS, packed to bf16 for the second products
     // lane constants of the masked form: the key-padding term, the causal term, the validity of this lane's keys, and the first query row
     // of the slice that may see the key (causal: row q of the slice is masked iff q < key - slice start)
@@ -506,8 +515,8 @@ __global__ __launch_bounds__(kFbThreads, 1) void attn_bwd_fused_kernel(FusedArgs
     auto arith_quad1 = [&](int t) {
       uint64_t km1[16];                                          // (only entries 2 t, 2 t + 1, 2 t + 8, 2 t + 9 are made and read)
       if (kDrop) {
-        hash_masks(2 * t, vbq + 16u, km1);                       // block 1: keys + 32 = pairs + 16
-        hash_masks(2 * t + 1, vbq + 16u, km1);
+        masks_from_hash(2 * t, hw[2 * t], km1);
+        masks_from_hash(2 * t + 1, hw[2 * t + 1], km1);
       }
       arith_pair(t, st1, dp1, km1, pad2_1, kval1, qrel1, hp1, hs1);
       arith_pair(t + 4, st1, dp1, km1, pad2_1, kval1, qrel1, hp1, hs1);
@@ -562,7 +571,7 @@ __global__ __launch_bounds__(kFbThreads, 1) void attn_bwd_fused_kernel(FusedArgs
           else ADT_UNIT2(2, s + 3);
         }
         if (kDrop) {
-          hash_masks(s, vbq, km0);                               // block 0's keep masks (32 scalar registers); block 1's are made where they are used
+          hw[s] = slice_hash(j, 1, s);
           __builtin_amdgcn_sched_barrier(0);
         }
       }
@@ -640,18 +649,19 @@ __global__ __launch_bounds__(kFbThreads, 1) void attn_bwd_fused_kernel(FusedArgs
         __builtin_amdgcn_sched_barrier(0);                                                                                      \
         ADT_TR2(fo[db], trb ^ static_cast<unsigned>(64 * db), 8192 + 16 * 256);                                                 \
         ADT_TR2(fqq[db], trb ^ static_cast<unsigned>(64 * db), 16 * 256);                                                       \
-        if (WITH_ARITH) { arith_quad1(db); __builtin_amdgcn_sched_barrier(0); }                                                 \
+        if ((WITH_ARITH) == 1) { arith_quad1(db); __builtin_amdgcn_sched_barrier(0); }                                          \
+        if ((WITH_ARITH) == 2 && kDrop) { masks_from_hash(db, slice_hash(j + 1, 0, db), km0); __builtin_amdgcn_sched_barrier(0); } \
       }                                                                                                                         \
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                                                                        \
       __builtin_amdgcn_sched_barrier(0);                                                                                        \
       _Pragma("unroll") for (int db = 0; db < 4; ++db) {                                                                        \
         mfma_acc(dv[BLK][db], tr_get(fo[db]), pf1.v);                                                                          \
         mfma_acc(dk[BLK][db], tr_get(fqq[db]), dsf1.v);                                                                        \
-        (void)0;                                                                                                                \
+        if ((WITH_ARITH) == 2 && kDrop) { __builtin_amdgcn_sched_barrier(0); masks_from_hash(4 + db, slice_hash(j + 1, 0, 4 + db), km0); __builtin_amdgcn_sched_barrier(0); } \
       }                                                                                                                         \
     }
     if (!(kDbg & 4)) {
-      ADT_DVDK(0, hp0, hs0, true)
+      ADT_DVDK(0, hp0, hs0, 1)
     } else {
 #pragma unroll
       for (int t = 0; t < 4; ++t) arith_quad1(t);
@@ -660,7 +670,7 @@ __global__ __launch_bounds__(kFbThreads, 1) void attn_bwd_fused_kernel(FusedArgs
     ADT_STAMP(4)
     write_ds(krow0 + 32, hs1);
     if (!(kDbg & 4)) {
-      ADT_DVDK(1, hp1, hs1, false)
+      ADT_DVDK(1, hp1, hs1, 2)
     }
     __builtin_amdgcn_sched_barrier(0);
 #undef ADT_DVDK

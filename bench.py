@@ -537,10 +537,15 @@ def main():
     dt = time.perf_counter() - t0
     if "tap" in wl:
         wl["tap"](False)
+    rank_ms = None
     if world > 1:
-        tt = torch.tensor([dt], device=dev, dtype=torch.float64)
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        dt = float(tt.item())
+        # value is computed from the MAX over ranks; the spread is reported next to it so that a slow rank / a skewed launch is
+        # visible in the first multi-GPU line (per-rank milliseconds per step of the timed region)
+        each = [torch.zeros(1, device=dev, dtype=torch.float64) for _ in range(world)]
+        dist.all_gather(each, torch.tensor([dt], device=dev, dtype=torch.float64))
+        per = [float(t.item()) / args.steps * 1e3 for t in each]
+        rank_ms = {"min": min(per), "max": max(per), "per_rank": per}
+        dt = max(float(t.item()) for t in each)
     comm = wl["comm"]() if "comm" in wl else None     # the timed steps' collective waits (read before the e2e leg adds its own)
     dt_e2e = None
     if "e2e" in wl and not args.no_e2e:
@@ -558,6 +563,8 @@ def main():
                 "config": dict(wl["config"], parallelism=f"dp{world}")}
         if dist.is_initialized():                        # what the collective library itself reports
             line["collective"] = {"backend": dist.get_backend(), "world_size": dist.get_world_size()}
+        if rank_ms is not None:
+            line["ms_per_step_ranks"] = rank_ms
         if comm is not None:
             # bytes one rank hands to the collective per step; exposed_wait_ms = time the compute stream sat behind the
             # all-reduces in GradReducer.finish() (event-bracketed on that stream), mean over the timed steps on rank 0

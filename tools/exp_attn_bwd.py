@@ -86,6 +86,7 @@ def main():
                     t = timeit(lambda: K.attn_bwd(q, kk, v, o, dout, lse, dq, dk, dv, B, H, Sq, Sk, scale, causal, None, drop=drop))
                     print(f"   dbg {dbg}: {t:.3f} ms", flush=True)
                 os.environ.pop("ADT_FB_DBG")
+            fl = 10.0 * B * H * Sq * Sk * 128
             print(f"{name} dropout {drop is not None}: split {res['split']:.3f} ms, fused {res['fused']:.3f} ms ({fl / res['fused'] / 1e9:.0f} TFLOP/s algorithmic)", flush=True)
 
 
