@@ -16,6 +16,7 @@ drop = (0.1, 12345) if os.environ.get("ADT_ATTN_DROP", "1") == "1" else None
 o, lse = K.attn_fwd(qkv[:, :d], qkv[:, d:2 * d], qkv[:, 2 * d:], B, H, S, S, scale, drop=drop)
 do = torch.randn((B * S, d), device=dev).bfloat16()
 dqkv = torch.empty_like(qkv)
+# the backward path under the counters: ADT_ATTN_BWD as in the product (default: fused without dropout, two kernels with), or forced
 for _ in range(4):
     K.attn_fwd(qkv[:, :d], qkv[:, d:2 * d], qkv[:, 2 * d:], B, H, S, S, scale, drop=drop)
     K.attn_bwd(qkv[:, :d], qkv[:, d:2 * d], qkv[:, 2 * d:], o, do, lse, dqkv[:, :d], dqkv[:, d:2 * d], dqkv[:, 2 * d:], B, H, S, S, scale, drop=drop)
