@@ -791,6 +791,8 @@ extern "C" int adt_attn_fwd(const adt_attn_desc* d, const void* q, const void* k
     ADT_HIP_TRY(hipGetLastError());
     return ADT_OK;
   }
+  const char* fwd_env = getenv("ADT_ATTN_FWD");          // A/B: 1 = the first (unpipelined) kernel; read on every call
+  if (!(fwd_env && fwd_env[0] == '1')) return launch_attn_fwd2(a, static_cast<hipStream_t>(stream));
   const int lds = 4 * kAttnTileBytes;
   if (int rc = set_lds_once()) return rc;
   const dim3 grid(static_cast<unsigned>((d->q_len + 127) / 128) * d->batch * d->heads);      // 1-D: tile_coords() renumbers it

@@ -7,6 +7,7 @@
 #include <hip/hip_runtime.h>
 
 #include <cstdlib>
+#include <type_traits>
 
 #include "adt_common.h"
 #include "dropout.h"
@@ -241,6 +242,8 @@ __device__ __forceinline__ float mask_add(const AttnArgs& a, int qi, int ki, int
   return m;
 }
 
+// attention_fwd.hip: the software-pipelined forward (tiled shapes; the one-query decode kernel stays in attention.hip)
+int launch_attn_fwd2(const AttnArgs& a, hipStream_t st);
 // attention_bwd_fused.hip: the one-kernel backward (5 products, ordered dQ hand-off); its workspace region and launcher
 size_t attn_bwd_fused_workspace_bytes(const adt_attn_desc* d);
 int launch_attn_bwd_fused(const adt_attn_desc* d, const AttnArgs& a, void* ws, size_t ws_bytes, hipStream_t st);

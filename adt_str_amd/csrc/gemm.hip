@@ -1435,7 +1435,11 @@ static int launch_nt_256(const GemmArgs& g, dim3 grid, int tm, int tn, hipStream
   X(false, false, kEfBias | kEfResidual | kEfFp32 | kEfResLn)                                                            \
   X(false, false, kEfResidual | kEfFp32)                      /* data gradient added to the residual stream's */        \
   X(false, true, kEfGeluGrad | kEfFactor)                     /* FFN data gradient x saved factor, + bias gradient */   \
-  X(false, false, kEfGeluGrad | kEfFactor)
+  X(false, false, kEfGeluGrad | kEfFactor)                                                                              \
+  X(true, false, kEfResidual | kEfRowMod | kEfDropAfterRes | kEfAux | kEfFp32)   /* encoder input: + positional rows, dropout, fp32 + bf16 */ \
+  X(true, false, kEfResidual | kEfDropAfterRes | kEfAux | kEfFp32)                                                      \
+  X(false, false, kEfBias | kEfFp32)                          /* logits */                                              \
+  X(false, false, kEfFp32)                                    /* the memory's data gradient (K = all decoder layers' K / V columns) */
 static int dispatch_nt_256(const GemmArgs& g, bool colsum, unsigned mask, dim3 grid, int tm, int tn, hipStream_t st) {
   const bool drop = g.drop.on();
   static const bool generic_only = getenv("ADT_GEMM_GENERIC") != nullptr;
