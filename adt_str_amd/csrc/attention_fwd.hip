@@ -55,46 +55,67 @@ __device__ unsigned long long g_fwd_stamps[32];
       if (lane == 0) g_fwd_stamps[(t - 6) * 8 + (K)] = tnow;                                                  \
     }                                                                                                         \
   } while (0)
+#define ADT_STAMP_AT(K)                                                                                       \
+  do {                                                                                                        \
+    if (stamp_on) {                                                                                           \
+      const unsigned long long tnow = __builtin_amdgcn_s_memtime();                                           \
+      if (lane == 0) g_fwd_stamps[K] = tnow;                                                                  \
+    }                                                                                                         \
+  } while (0)
 #else
 #define ADT_STAMP(K) do { } while (0)
+#define ADT_STAMP_AT(K) do { } while (0)
 #endif
 
 // kWaves = 8: one workgroup of 256 queries per CU (two waves per SIMD): a K / V tile is fetched once for eight waves -- the LDS-DMA path
 // delivers ~33 B/clk per CU (the same bound as the GEMM's operand delivery), and a wave's DMA instruction costs it ~80 issue cycles.
 // kWaves = 4: 128 queries, two workgroups per CU: the shapes with at most 128 queries (decoder self- and cross-attention).
 template <bool kDrop, int kWaves>
-__global__ __launch_bounds__(64 * kWaves, 8 / kWaves) void attn_fwd2_kernel(AttnArgs a) {
+__global__ __launch_bounds__(64 * kWaves, 8 / kWaves) void attn_fwd2_kernel(AttnArgs a, int n_items) {
+  constexpr bool kPersist = kWaves == 8;   // one workgroup per CU walks its share of the (batch, head, query block) items
   constexpr int kQ = 32 * kWaves;          // queries per workgroup
   constexpr int kPc = 16 / kWaves;         // 1-KiB DMA pieces of a 16-KiB tile per wave
-  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];     // [2][K tile | V tile]
+  constexpr int kQNext = 4 * kAttnTileBytes;   // kPersist: LDS byte offset of the next item's Q rows (256 x 256 B, the tiles' swizzled image)
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];     // [2][K tile | V tile] (+ kPersist: next Q)
   const int tid = threadIdx.x, lane = tid & 63, r = lane & 31, h = lane >> 5;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
 #ifdef ADT_FWD_EXPERIMENT
   const bool stamp_on = blockIdx.x == gridDim.x / 2 + 3 && wave == 1;
+  ADT_STAMP_AT(16);
 #endif
-  const TileXY tc = tile_coords((a.Sq + kQ - 1) / kQ);
-  const int b = tc.y / a.H, head = tc.y % a.H;
-  const int qi = tc.x * kQ + wave * 32 + r;
-  const unsigned short* qb = a.q + static_cast<long>(b) * a.Sq * a.ldq + head * kDh;
-  const unsigned short* kg = a.k + static_cast<long>(b) * a.Sk * a.ldk + head * kDh;
-  const unsigned short* vg = a.v + static_cast<long>(b) * a.Sk * a.ldv + head * kDh;
-  const int klen = __builtin_amdgcn_readfirstlane(a.key_len ? a.key_len[b] : a.Sk);
+  const int nx = (a.Sq + kQ - 1) / kQ;
   const float sl2 = a.scale * kLog2e;
   const float mvs = a.mask_value / a.scale;                  // the additive mask in raw-score units
   const float cfold = kDrop ? __log2f(a.drop.inv_keep) : 0.f;
   const unsigned thr = a.drop.thr;
+  const unsigned key2 = mix32(a.drop.key);
+  // ---- the item in hand: (batch, head, query block) of virtual block id v (the grid's renumbering of attn_common.h tile_coords, taken
+  // over n_items ids: ids v, v + 8, ... of one XCD are consecutive query blocks / heads, so an XCD's L2 fetches a head's K / V once)
+  struct Item { int b, head, q0; };
+  auto item_of = [&](int v) __attribute__((always_inline)) {
+    const int q8 = n_items >> 3, r8 = n_items & 7, xcd = v & 7;
+    const int logical = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + (v >> 3);
+    const int y = logical / nx;
+    return Item{y / a.H, y % a.H, (logical % nx) * kQ};
+  };
+  int b, head, qi, klen;
+  const unsigned short *kg, *vg;
+  unsigned pb2;
+  auto set_item = [&](const Item& it) __attribute__((always_inline)) {
+    b = it.b; head = it.head;
+    qi = it.q0 + wave * 32 + r;
+    kg = a.k + static_cast<long>(b) * a.Sk * a.ldk + head * kDh;
+    vg = a.v + static_cast<long>(b) * a.Sk * a.ldv + head * kDh;
+    klen = __builtin_amdgcn_readfirstlane(a.key_len ? a.key_len[b] : a.Sk);
+    // dropout index of (row, key) is row * Sk2 + key (Sk2 = Sk rounded up to even; dropout.h): pair = row * Sk2 / 2 + key / 2
+    pb2 = static_cast<unsigned>(((static_cast<uint64_t>(b) * a.H + head) * a.Sq + qi) * ((a.Sk + 1) >> 1)) + 2u * h;
+  };
+  int item = blockIdx.x;
+  set_item(item_of(item));
 
   bf16x8 qf[8];
-  frags_from_global(qb, a.ldq, qi, a.Sq, lane, qf);
   f32x16 o[4];
-#pragma unroll
-  for (int db = 0; db < 4; ++db)
-#pragma unroll
-    for (int i = 0; i < 16; ++i) o[db][i] = 0.f;
-  float m = kNegBig, mneg = cfold - kNegBig, l = 0.f;
-  // dropout index of (row, key) is row * Sk2 + key (Sk2 = Sk rounded up to even; dropout.h): pair = row * Sk2 / 2 + key / 2
-  const unsigned pb2 = static_cast<unsigned>(((static_cast<uint64_t>(b) * a.H + head) * a.Sq + qi) * ((a.Sk + 1) >> 1)) + 2u * h;
-  const unsigned key2 = mix32(a.drop.key);
+  float m, mneg, l;
 
   const int n_tiles = (a.Sk + kRowsPerTile - 1) / kRowsPerTile;
   // DMA piece j of this wave = rows 4 (kPc wave + j) .. + 3 of a tile (one row per quarter-wave, 16 bytes per lane); the LDS image is
@@ -110,7 +131,8 @@ __global__ __launch_bounds__(64 * kWaves, 8 / kWaves) void attn_fwd2_kernel(Attn
   const unsigned lds_base = lds_off(smem);
   // edge tile: element offset of piece j's source with rows past the end clamped to the last one (their scores are masked)
   auto clamp_off = [&](int row0, int j, long ld) __attribute__((always_inline)) {
-    const int row = 4 * (kPc * wave + j) + (lane >> 4);
+    int row = 4 * (kPc * wave + j) + (lane >> 4);
+    asm volatile("" : "+v"(row));          // (formed at the use: see dma_piece_of)
     const int chunk = (lane & 15) ^ (((row & 3) << 2) | ((row >> 2) & 3));
     int gr = row0 + row;
     gr = gr < a.Sk ? gr : a.Sk - 1;
@@ -119,22 +141,53 @@ __global__ __launch_bounds__(64 * kWaves, 8 / kWaves) void attn_fwd2_kernel(Attn
   // one piece of tile `row0 / 64` of K (ld = ldk) or V into the 16-KiB buffer at LDS byte offset buf
   auto dma_piece_of = [&](const unsigned short* g, long ld, const unsigned (&off)[kPc], int row0, int j, int buf) __attribute__((always_inline)) {
     const unsigned dst = lds_base + buf + (kPc * wave + j) * 1024;
-    if (row0 + kRowsPerTile <= a.Sk) dma1k(g + static_cast<long>(row0) * ld + off[j], dst);          // block-uniform
+    unsigned oj = off[j];
+    asm volatile("" : "+v"(oj));           // (the 64-bit source address is formed here, not hoisted out of the tile loop into registers that then spill)
+    if (row0 + kRowsPerTile <= a.Sk) dma1k(g + static_cast<long>(row0) * ld + oj, dst);          // block-uniform
     else if (row0 < a.Sk) dma1k(g + clamp_off(row0, j, ld), dst);
   };
-#pragma unroll
-  for (int j = 0; j < kPc; ++j) {
-    dma_piece_of(kg, a.ldk, koff, 0, j, 0);
-    dma_piece_of(vg, a.ldv, voff, 0, j, kAttnTileBytes);
-    dma_piece_of(kg, a.ldk, koff, kRowsPerTile, j, 2 * kAttnTileBytes);
-  }
+  // the first three tiles of an item: K(0), V(0) into buffers 0, K(1) into K buffer 1
+  auto first_tiles = [&](const unsigned short* kgi, const unsigned short* vgi, int j) __attribute__((always_inline)) {
+    dma_piece_of(kgi, a.ldk, koff, 0, j, 0);
+    dma_piece_of(vgi, a.ldv, voff, 0, j, kAttnTileBytes);
+    dma_piece_of(kgi, a.ldk, koff, kRowsPerTile, j, 2 * kAttnTileBytes);
+  };
+  // kPersist: piece j (0..7) of this wave's OWN 32 query rows of item `it` into the next-Q region (rows past Sq clamp to the last one:
+  // never stored).  A wave only ever reads its own rows back, so its own vmcnt(0) is all the synchronisation they need.
+  auto q_piece = [&](const Item& it, int j) __attribute__((always_inline)) {
+    int row = 4 * (8 * wave + j) + (lane >> 4);
+    asm volatile("" : "+v"(row));          // (as above: eight pieces' addresses of the NEXT item are loop invariants)
+    const int chunk = (lane & 15) ^ (((row & 3) << 2) | ((row >> 2) & 3));
+    int gr = it.q0 + row;
+    gr = gr < a.Sq ? gr : a.Sq - 1;
+    dma1k(a.q + (static_cast<long>(it.b) * a.Sq + gr) * a.ldq + it.head * kDh + chunk * 8, lds_base + kQNext + (8 * wave + j) * 1024);
+  };
   // lane constants of the LDS reads: K rows (16-byte pieces, chunk 2s + h) and V^T (transposed 8-byte pieces)
   unsigned kfo[8];
 #pragma unroll
   for (int s = 0; s < 8; ++s) kfo[s] = static_cast<unsigned>(swz(r, 2 * s + h));
   unsigned troff[4][2];
   tr_offsets(lane, troff);
-  dma_wait_and_sync();
+  const ADT_AS3 unsigned char* const lds = (const ADT_AS3 unsigned char*)smem;
+  auto q_from_lds = [&]() __attribute__((always_inline)) {
+    int base = kQNext + wave * 32 * 256;
+    asm volatile("" : "+s"(base));         // (eight adds here instead of eight more address registers across the tile loop)
+#pragma unroll
+    for (int s = 0; s < 8; ++s) qf[s] = *reinterpret_cast<const ADT_AS3 bf16x8*>(lds + base + kfo[s]);
+  };
+  {
+    const Item it0 = item_of(item);
+    if (kPersist) {
+#pragma unroll
+      for (int j = 0; j < 8; ++j) q_piece(it0, j);
+    } else {
+      frags_from_global(a.q + static_cast<long>(b) * a.Sq * a.ldq + head * kDh, a.ldq, qi, a.Sq, lane, qf);
+    }
+#pragma unroll
+    for (int j = 0; j < kPc; ++j) first_tiles(kg, vg, j);
+    dma_wait_and_sync();
+    if (kPersist) q_from_lds();
+  }
 
   f32x16 s0, s1;
   float mloc = kNegBig;
@@ -172,12 +225,12 @@ __global__ __launch_bounds__(64 * kWaves, 8 / kWaves) void attn_fwd2_kernel(Attn
       pin(hh[i]);
     }
   };
-  // finish(g), pair s: two probabilities, their share of the row sum, dropout, one packed bf16 pair of the P^T operand
-  float psum = 0.f;
-  auto finish_pair = [&](const f32x16& st, int s) __attribute__((always_inline)) {
+  // finish(g), pair s: two probabilities (left in place of the scores: phase B adds them up, it has the issue slots), dropout, one packed
+  // bf16 pair of the P^T operand
+  auto finish_pair = [&](f32x16& st, int s) __attribute__((always_inline)) {
     float p0 = __builtin_amdgcn_exp2f(fmaf(st[2 * s], sl2, mneg)), p1 = __builtin_amdgcn_exp2f(fmaf(st[2 * s + 1], sl2, mneg));
-    psum += p0;
-    psum += p1;
+    st[2 * s] = p0;
+    st[2 * s + 1] = p1;
     if (kDrop) {
       p0 = (hh[s] & 0xffffu) >= thr ? p0 : 0.f;
       p1 = (hh[s] >> 16) >= thr ? p1 : 0.f;
@@ -200,7 +253,6 @@ __global__ __launch_bounds__(64 * kWaves, 8 / kWaves) void attn_fwd2_kernel(Attn
   };
   // LDS reads: lane-constant address registers (kfo, troff) + compile-time offsets (buffer, 32-row block, 16-row step), so a read costs
   // no address arithmetic and nothing lane-constant is hoisted into extra registers around the loop
-  const ADT_AS3 unsigned char* const lds = (const ADT_AS3 unsigned char*)smem;
   auto k_frag = [&](int s, int off) __attribute__((always_inline)) { return *reinterpret_cast<const ADT_AS3 bf16x8*>(lds + kfo[s] + off); };
   auto v_frag = [&](int db, int off) __attribute__((always_inline)) {
     const v4s lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((ADT_AS3 v4s*)(lds + troff[db][0] + off));
@@ -208,13 +260,12 @@ __global__ __launch_bounds__(64 * kWaves, 8 / kWaves) void attn_fwd2_kernel(Attn
     return bf16x8{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
   };
   // ---- phase A: sn = K(32 rows at LDS byte offset koff_) Q^T   ||   finish of the block whose scores are in sc
-  auto phase_a = [&](f32x16& sn, int koff_, const f32x16& sc) __attribute__((always_inline)) {
+  auto phase_a = [&](f32x16& sn, int koff_, f32x16& sc) __attribute__((always_inline)) {
     bf16x8 kf[8];
 #pragma unroll
     for (int s = 0; s < 4; ++s) kf[s] = k_frag(s, koff_);
 #pragma unroll
     for (int i = 0; i < 16; ++i) sn[i] = 0.f;
-    psum = 0.f;
 #pragma unroll
     for (int s = 0; s < 8; ++s) {
       if (s < 4) kf[s + 4] = k_frag(s + 4, koff_);
@@ -222,12 +273,10 @@ __global__ __launch_bounds__(64 * kWaves, 8 / kWaves) void attn_fwd2_kernel(Attn
       sn = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf[s], qf[s], sn, 0, 0, 0);
       ADT_FENCE();
     }
-    l += psum;
-    pin(l);
   };
   // ---- phase B: O^T += V(32 rows at LDS byte offset voff_)^T P^T   ||   row maximum of the block whose raw scores are in sn, its hashes
   // (a tile that needs the per-element mask gets it in a pass of its own in front of the phase: one tile in sixteen in the encoder)
-  auto phase_b = [&](int voff_, f32x16& sn, int key0, bool masked, auto&& dma_piece) __attribute__((always_inline)) {
+  auto phase_b = [&](int voff_, const f32x16& sp, f32x16& sn, int key0, bool masked, auto&& dma_piece) __attribute__((always_inline)) {
     if (masked) start_mask(sn, key0, 0, 16);
     bf16x8 vt[2][4];
 #pragma unroll
@@ -243,14 +292,16 @@ __global__ __launch_bounds__(64 * kWaves, 8 / kWaves) void attn_fwd2_kernel(Attn
       }
       if (i8 == 4) { mloc = cross_half_max(mx * sl2); pin(mloc); }
       hash_one(key0, i8);
+      l += sp[2 * i8];                 // block g's row sum (un-dropped probabilities)
+      l += sp[2 * i8 + 1];
+      pin(l);
       o[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vt[s2][db], pf[s2].v, o[db], 0, 0, 0);
       dma_piece(i8);
       ADT_FENCE();
     }
   };
 
-  // ---- before the loop: block 0's scores, maximum and hashes
-  {
+  auto block0 = [&]() __attribute__((always_inline)) {      // an item's first block: scores, maximum, hashes (before the pipeline starts)
     bf16x8 kf[8];
 #pragma unroll
     for (int s = 0; s < 8; ++s) kf[s] = k_frag(s, 0);
@@ -263,7 +314,14 @@ __global__ __launch_bounds__(64 * kWaves, 8 / kWaves) void attn_fwd2_kernel(Attn
 #pragma unroll
     for (int i = 0; i < 8; ++i) hash_one(0, i);
     rescale();
-  }
+  };
+  // kPersist: the next item's operands are fetched under this item's tiles
+  Item nxt{0, 0, 0};
+  bool has_next = false;
+  int qn = 0;                              // next-Q pieces issued so far (8 per wave)
+  auto q_hook = [&](int i8) __attribute__((always_inline)) {      // behind MFMAs 0 and 4 of a tile's second phase B
+    if (kPersist && (i8 & 3) == 0 && has_next && qn < 8) { q_piece(nxt, qn); ++qn; }
+  };
   // one 64-key tile; kP = t & 1 (compile time: the tile's K / V buffers)
   auto tile_body = [&](int t, auto parity) __attribute__((always_inline)) {
     constexpr int kP = decltype(parity)::value;
@@ -272,7 +330,8 @@ __global__ __launch_bounds__(64 * kWaves, 8 / kWaves) void attn_fwd2_kernel(Attn
     ADT_STAMP(0);
     phase_a(s1, kK + 32 * 256, s0);
     ADT_STAMP(1);
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    // (tile 0: K(1) and V(0) were waited for before the item started; what is still in flight is the previous item's output)
+    if (t > 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
     ADT_STAMP(2);
     // K(t + 2) -> this tile's K buffer, V(t + 1) -> the other V buffer: one 1-KiB piece behind an MFMA of phase B(2t)
@@ -283,48 +342,115 @@ __global__ __launch_bounds__(64 * kWaves, 8 / kWaves) void attn_fwd2_kernel(Attn
       else dma_piece_of(vg, a.ldv, voff, tile0 + kRowsPerTile, j, kKn + kAttnTileBytes);
     };
     ADT_STAMP(3);
-    phase_b(kV, s1, tile0 + 32, masked_tile(t), piece);
+    phase_b(kV, s0, s1, tile0 + 32, masked_tile(t), piece);
     ADT_STAMP(4);
     rescale();
     ADT_STAMP(5);
     phase_a(s0, kKn, s1);
     ADT_STAMP(6);
-    phase_b(kV + 32 * 256, s0, tile0 + kRowsPerTile, masked_tile(t + 1), [](int) {});
+    phase_b(kV + 32 * 256, s1, s0, tile0 + kRowsPerTile, masked_tile(t + 1), q_hook);
     ADT_STAMP(7);
-    if (t + 1 < n_tiles) rescale();
+    rescale();
   };
-  for (int t = 0; t < n_tiles; t += 2) {
-    tile_body(t, std::integral_constant<int, 0>{});
-    if (t + 1 < n_tiles) tile_body(t + 1, std::integral_constant<int, 1>{});
+  // the last tile: no later tile to fetch or to start, and no second block when at most 32 of its keys exist (986 keys: block 31 of 32).
+  // Run-time buffer offsets (an add per LDS read), once per workgroup.
+  auto finish_only = [&](f32x16& sc) __attribute__((always_inline)) {
+#pragma unroll
+    for (int s = 0; s < 8; ++s) finish_pair(sc, s);
+  };
+  auto last_tile = [&](int t) __attribute__((always_inline)) {
+    int kK = (t & 1) * 2 * kAttnTileBytes;
+    asm volatile("" : "+s"(kK));           // (as in q_from_lds)
+    const int kV = kK + kAttnTileBytes;
+    const int tile0 = t * kRowsPerTile;
+    const bool second = a.Sk - tile0 > 32;               // block-uniform
+    if (second) phase_a(s1, kK + 32 * 256, s0);
+    else finish_only(s0);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    // With an even number of tiles this one sits in buffers 1: K(t) is dead behind the barrier and buffers 0 have been for a tile, so the
+    // next item's K(0), V(0), K(1) go where its own pipeline expects them (an odd number: they are fetched after the tile, see below)
+    const unsigned short* kgn = a.k + static_cast<long>(nxt.b) * a.Sk * a.ldk + nxt.head * kDh;
+    const unsigned short* vgn = a.v + static_cast<long>(nxt.b) * a.Sk * a.ldv + nxt.head * kDh;
+    auto next_hook = [&](int i8) __attribute__((always_inline)) {
+      if (kPersist && has_next && (t & 1) && i8 < kPc) first_tiles(kgn, vgn, i8);
+    };
+    phase_b(kV, s0, s1, tile0 + 32, masked_tile(t), next_hook);      // (without a second block: its maximum of s1 is not used)
+    if (second) {
+      rescale();
+      finish_only(s1);
+      phase_b(kV + 32 * 256, s1, s0, tile0 + kRowsPerTile, false, [](int) {});
+    }
+  };
+  while (true) {
+    const int next_id = item + static_cast<int>(gridDim.x);
+    has_next = kPersist && next_id < n_items;
+    if (has_next) nxt = item_of(next_id);
+    qn = 0;
+#pragma unroll
+    for (int db = 0; db < 4; ++db)
+#pragma unroll
+      for (int i = 0; i < 16; ++i) o[db][i] = 0.f;
+    m = kNegBig; mneg = cfold - kNegBig; l = 0.f;
+    ADT_STAMP_AT(17);
+    block0();
+    ADT_STAMP_AT(18);
+    for (int t = 0; t + 1 < n_tiles; t += 2) {
+      tile_body(t, std::integral_constant<int, 0>{});
+      if (t + 2 < n_tiles) tile_body(t + 1, std::integral_constant<int, 1>{});
+    }
+    ADT_STAMP_AT(19);
+    last_tile(n_tiles - 1);
+    ADT_STAMP_AT(20);
+    if (has_next) {
+      if (!((n_tiles - 1) & 1)) {          // odd number of tiles: the buffers were in use until now
+        __syncthreads();
+#pragma unroll
+        for (int j = 0; j < kPc; ++j)
+          first_tiles(a.k + static_cast<long>(nxt.b) * a.Sk * a.ldk + nxt.head * kDh, a.v + static_cast<long>(nxt.b) * a.Sk * a.ldv + nxt.head * kDh, j);
+      }
+      for (; qn < 8; ++qn) q_piece(nxt, qn);          // (short key ranges: what the tiles did not get to)
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __syncthreads();
+      q_from_lds();                        // Q is dead after the last score product: the next item's rows, before this item's output goes out
+    }
+    const float lt = l + __shfl_xor(l, 32);                  // (the sum carries the folded 1 / (1 - p))
+    const float inv = (kDrop ? a.drop.inv_keep : 1.0f) / lt;
+    store_transposed(o, inv, a.out + static_cast<long>(b) * a.Sq * a.ldo + head * kDh, a.ldo, qi, a.Sq, lane);
+    if (h == 0 && qi < a.Sq && a.lse) a.lse[(static_cast<long>(b) * a.H + head) * a.Sq + qi] = (m + log2f(lt) - cfold) * kLn2;
+    ADT_STAMP_AT(21);
+    if (!has_next) break;
+    item = next_id;
+    set_item(nxt);
   }
-  const float lt = l + __shfl_xor(l, 32);                  // (the sum carries the folded 1 / (1 - p))
-  const float inv = (kDrop ? a.drop.inv_keep : 1.0f) / lt;
-  store_transposed(o, inv, a.out + static_cast<long>(b) * a.Sq * a.ldo + head * kDh, a.ldo, qi, a.Sq, lane);
-  if (h == 0 && qi < a.Sq && a.lse) a.lse[(static_cast<long>(b) * a.H + head) * a.Sq + qi] = (m + log2f(lt) - cfold) * kLn2;
 }
 
 int launch_attn_fwd2(const AttnArgs& a, hipStream_t st) {
   static thread_local int done_for = -1;
   int dev = 0;
   ADT_HIP_TRY(hipGetDevice(&dev));
-  const int lds = 4 * kAttnTileBytes;
+  const int lds = 4 * kAttnTileBytes, lds8 = 8 * kAttnTileBytes;          // the persistent form adds the next item's 256 Q rows
   if (done_for != dev) {
     ADT_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(attn_fwd2_kernel<false, 4>), hipFuncAttributeMaxDynamicSharedMemorySize, lds));
     ADT_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(attn_fwd2_kernel<true, 4>), hipFuncAttributeMaxDynamicSharedMemorySize, lds));
-    ADT_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(attn_fwd2_kernel<false, 8>), hipFuncAttributeMaxDynamicSharedMemorySize, lds));
-    ADT_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(attn_fwd2_kernel<true, 8>), hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+    ADT_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(attn_fwd2_kernel<false, 8>), hipFuncAttributeMaxDynamicSharedMemorySize, lds8));
+    ADT_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(attn_fwd2_kernel<true, 8>), hipFuncAttributeMaxDynamicSharedMemorySize, lds8));
     done_for = dev;
   }
   const char* wenv = getenv("ADT_ATTN_FWD_WAVES");        // A/B: 4 or 8 waves per workgroup whatever the shape; read on every call
   const bool eight = wenv ? atoi(wenv) == 8 : a.Sq > 128;
   const int kq = eight ? 256 : 128;
-  const dim3 grid(static_cast<unsigned>((a.Sq + kq - 1) / kq) * a.B * a.H);      // 1-D: tile_coords() renumbers it
+  const int n_items = ((a.Sq + kq - 1) / kq) * a.B * a.H;      // 1-D ids, renumbered per XCD inside the kernel
   if (eight) {
-    if (a.drop.on()) hipLaunchKernelGGL((attn_fwd2_kernel<true, 8>), grid, dim3(512), lds, st, a);
-    else hipLaunchKernelGGL((attn_fwd2_kernel<false, 8>), grid, dim3(512), lds, st, a);
+    int n_cu = 0;
+    if (int rc = device_cu_count(&n_cu)) return rc;
+    const dim3 grid(static_cast<unsigned>(n_items < n_cu ? n_items : n_cu));          // persistent: one workgroup per CU
+    if (a.drop.on()) hipLaunchKernelGGL((attn_fwd2_kernel<true, 8>), grid, dim3(512), lds8, st, a, n_items);
+    else hipLaunchKernelGGL((attn_fwd2_kernel<false, 8>), grid, dim3(512), lds8, st, a, n_items);
   } else {
-    if (a.drop.on()) hipLaunchKernelGGL((attn_fwd2_kernel<true, 4>), grid, dim3(256), lds, st, a);
-    else hipLaunchKernelGGL((attn_fwd2_kernel<false, 4>), grid, dim3(256), lds, st, a);
+    const dim3 grid(static_cast<unsigned>(n_items));
+    if (a.drop.on()) hipLaunchKernelGGL((attn_fwd2_kernel<true, 4>), grid, dim3(256), lds, st, a, n_items);
+    else hipLaunchKernelGGL((attn_fwd2_kernel<false, 4>), grid, dim3(256), lds, st, a, n_items);
   }
   ADT_HIP_TRY(hipGetLastError());
 #ifdef ADT_FWD_EXPERIMENT
@@ -334,7 +460,9 @@ int launch_attn_fwd2(const AttnArgs& a, hipStream_t st) {
     ADT_HIP_TRY(hipMemcpyFromSymbol(h, HIP_SYMBOL(g_fwd_stamps), sizeof(h)));
     fprintf(stderr, "fwd stamps (cycles from the first):");
     for (int i = 1; i < 16; ++i) fprintf(stderr, " %lld", static_cast<long long>(h[i] - h[0]));
-    fprintf(stderr, "\n");
+    fprintf(stderr, "\n   workgroup: entry 0, operands landed %lld, loop starts %lld, last tile starts %lld, last tile done %lld, stored %lld\n",
+            static_cast<long long>(h[17] - h[16]), static_cast<long long>(h[18] - h[16]), static_cast<long long>(h[19] - h[16]),
+            static_cast<long long>(h[20] - h[16]), static_cast<long long>(h[21] - h[16]));
   }
 #endif
   return ADT_OK;
