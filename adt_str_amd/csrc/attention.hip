@@ -21,139 +21,15 @@
 // which makes both the 16-byte row reads and the transposed 8-byte reads bank-conflict free.
 // Tiles are double-buffered: the next tile's global loads are issued before the MFMAs of the
 // current one and written to the other buffer afterwards (one barrier per tile).
+// The tiled forward lives in attention_fwd.hip (software-pipelined, persistent); this file holds the one-query decode kernel, the
+// two-kernel backward and the C entry points.
 // The backward recomputes P from the saved log-sum-exp; dQ (which also produces delta = rowsum(O * dO) for its queries)
 // and dK/dV are separate kernels so no float atomics are needed (bitwise reproducible).
 #include "attn_common.h"
 
 namespace adt {
 
-// =============================================================================== forward
-template <bool kDrop>
-__global__ __launch_bounds__(kAttnThreads, 2) void attn_fwd_kernel(AttnArgs a) {
-  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];     // [2 stages][K tile | V tile]
-  const int tid = threadIdx.x, lane = tid & 63, r = lane & 31, h = lane >> 5;
-  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const TileXY tc = tile_coords((a.Sq + 127) / 128);
-  const int b = tc.y / a.H, head = tc.y % a.H;
-  const int q0 = tc.x * 128 + wave * 32;
-  const int qi = q0 + r;
-  const unsigned short* qb = a.q + static_cast<long>(b) * a.Sq * a.ldq + head * kDh;
-  const unsigned short* kb_ = a.k + static_cast<long>(b) * a.Sk * a.ldk + head * kDh;
-  const unsigned short* vb = a.v + static_cast<long>(b) * a.Sk * a.ldv + head * kDh;
-  const int klen = a.key_len ? a.key_len[b] : a.Sk;
-  const float sl2 = a.scale * kLog2e;
-
-  bf16x8 qf[8];
-  frags_from_global(qb, a.ldq, qi, a.Sq, lane, qf);
-  f32x16 o[4];
-#pragma unroll
-  for (int db = 0; db < 4; ++db)
-#pragma unroll
-    for (int i = 0; i < 16; ++i) o[db][i] = 0.f;
-  float m = kNegBig, l = 0.f;
-  // dropout index of (row, key) is row * Sk2 + key (Sk2 = Sk rounded up to even; dropout.h): pair = row * Sk2 / 2 + key / 2
-  const unsigned pairbase = static_cast<unsigned>(((static_cast<uint64_t>(b) * a.H + head) * a.Sq + qi) * ((a.Sk + 1) >> 1));
-  const unsigned key2 = mix32(a.drop.key);
-
-  const int n_tiles = (a.Sk + kRowsPerTile - 1) / kRowsPerTile;
-  unsigned koff[4], voff[4];
-  tile_dma_offsets(a.ldk, wave, lane, koff);
-  tile_dma_offsets(a.ldv, wave, lane, voff);
-  tile_dma(kb_, a.ldk, 0, a.Sk, smem, wave, lane);
-  tile_dma(vb, a.ldv, 0, a.Sk, smem + kAttnTileBytes, wave, lane);
-  dma_wait_and_sync();
-  unsigned troff[4][2];
-  tr_offsets(lane, troff);
-
-  for (int t = 0; t < n_tiles; ++t) {
-    const unsigned char* tk = smem + (t & 1) * 2 * kAttnTileBytes;
-    const unsigned char* tv = tk + kAttnTileBytes;
-    unsigned tva[4][2];
-#pragma unroll
-    for (int db = 0; db < 4; ++db) { tva[db][0] = troff[db][0] + lds_off(tv); tva[db][1] = troff[db][1] + lds_off(tv); }
-    if (t + 1 < n_tiles) {
-      unsigned char* nk = smem + ((t + 1) & 1) * 2 * kAttnTileBytes;
-      tile_dma_pre(kb_, a.ldk, (t + 1) * kRowsPerTile, a.Sk, nk, wave, lane, koff);
-      tile_dma_pre(vb, a.ldv, (t + 1) * kRowsPerTile, a.Sk, nk + kAttnTileBytes, wave, lane, voff);
-    }
-    const int tile0 = t * kRowsPerTile;
-    const bool need_mask = a.causal || tile0 + kRowsPerTile > klen || tile0 + kRowsPerTile > a.Sk;   // block-uniform
-#pragma unroll
-    for (int kb = 0; kb < 2; ++kb) {
-      f32x16 st;
-#pragma unroll
-      for (int i = 0; i < 16; ++i) st[i] = 0.f;
-#pragma unroll
-      for (int s = 0; s < 8; ++s) st = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_rows(tk, kb, s, lane), qf[s], st, 0, 0, 0);
-      // scores in the log2 domain; interior tiles (no mask, all keys valid) skip the per-element mask arithmetic
-      float mloc = kNegBig;
-      if (need_mask) {
-#pragma unroll
-        for (int i = 0; i < 16; ++i) {
-          const int ki = tile0 + kb * 32 + acc_row(i, h);
-          float tt = fmaf(st[i], sl2, mask_add(a, qi, ki, klen) * kLog2e);
-          if (ki >= a.Sk) tt = kNegBig;
-          st[i] = tt;
-          mloc = fmaxf(mloc, tt);
-        }
-      } else {
-#pragma unroll
-        for (int i = 0; i < 16; ++i) mloc = fmaxf(mloc, st[i]);
-        mloc *= sl2;
-      }
-      mloc = fmaxf(mloc, __shfl_xor(mloc, 32));
-      // lazy rescale: the running max is only raised (and O, l rescaled) when some query's block max exceeds it
-      // by more than kRescaleThr; until then probabilities are bounded by 2^kRescaleThr, harmless in fp32/bf16
-      if (__any(mloc > m + kRescaleThr)) {
-        const float m_new = fmaxf(m, mloc);
-        const float alpha = __builtin_amdgcn_exp2f(m - m_new);
-        m = m_new;
-        l *= alpha;
-#pragma unroll
-        for (int db = 0; db < 4; ++db)
-#pragma unroll
-          for (int i = 0; i < 16; ++i) o[db][i] *= alpha;
-      }
-      float psum = 0.f;
-      if (need_mask) {
-#pragma unroll
-        for (int i = 0; i < 16; ++i) { const float p = __builtin_amdgcn_exp2f(st[i] - m); st[i] = p; psum += p; }
-      } else {
-#pragma unroll
-        for (int i = 0; i < 16; ++i) { const float p = __builtin_amdgcn_exp2f(fmaf(st[i], sl2, -m)); st[i] = p; psum += p; }
-      }
-      l += psum;
-      if (kDrop) {                           // dropout on the probabilities (the normaliser keeps the un-dropped sum)
-#pragma unroll
-        for (int g4 = 0; g4 < 4; ++g4)       // the lane's keys come in runs of four (tile0 + 32 kb + 8 g4 + 4 h ..+3): two hashes per run
-#pragma unroll
-          for (int u = 0; u < 2; ++u) {
-            const unsigned hh = a.drop.pair_hash32(pairbase + static_cast<unsigned>((tile0 + kb * 32 + 8 * g4 + 4 * h) >> 1) + u, key2);
-            st[4 * g4 + 2 * u] *= a.drop.lo(hh);
-            st[4 * g4 + 2 * u + 1] *= a.drop.hi(hh);
-          }
-      }
-#pragma unroll
-      for (int s2 = 0; s2 < 2; ++s2) {
-        TrFrag vt[4];
-        if (kb == 0 && s2 == 0) tr4_issue_at<0>(tva, vt);
-        else if (kb == 0) tr4_issue_at<16>(tva, vt);
-        else if (s2 == 0) tr4_issue_at<32>(tva, vt);
-        else tr4_issue_at<48>(tva, vt);
-        const bf16x8 pf = acc_to_b(st, s2);
-        tr_wait();
-#pragma unroll
-        for (int db = 0; db < 4; ++db)
-          o[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(tr_get(vt[db]), pf, o[db], 0, 0, 0);
-      }
-    }
-    dma_wait_and_sync();
-  }
-  const float lt = l + __shfl_xor(l, 32);
-  const float inv = 1.0f / lt;
-  store_transposed(o, inv, a.out + static_cast<long>(b) * a.Sq * a.ldo + head * kDh, a.ldo, qi, a.Sq, lane);
-  if (h == 0 && qi < a.Sq && a.lse) a.lse[(static_cast<long>(b) * a.H + head) * a.Sq + qi] = (m + log2f(lt)) * kLn2;
-}
+// =============================================================================== forward: attention_fwd.hip (software-pipelined, persistent)
 
 // =============================================================================== forward, ONE query per (batch, head): decode
 // The KV-cached greedy decode (reference model.py:260-324 recomputes the whole prefix; network.py: greedy_decode_cached) asks for
@@ -754,14 +630,12 @@ static AttnArgs make_args(const adt_attn_desc* d) {
   a.cs_dq = nullptr;
   return a;
 }
-static int set_lds_once() {      // raise the dynamic-LDS limit of the three kernels once per device and thread
+static int set_lds_once() {      // raise the dynamic-LDS limit of the backward kernels once per device and thread
   static thread_local int done_for = -1;
   int dev = 0;
   ADT_HIP_TRY(hipGetDevice(&dev));
   if (done_for == dev) return ADT_OK;
   const int l4 = 4 * kAttnTileBytes;
-  ADT_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(attn_fwd_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, l4));
-  ADT_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(attn_fwd_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, l4));
   ADT_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(attn_bwd_dq_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, l4));
   ADT_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(attn_bwd_dq_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, l4));
   ADT_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(attn_bwd_dkv3_kernel<false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, kDkv3Lds));
@@ -791,15 +665,7 @@ extern "C" int adt_attn_fwd(const adt_attn_desc* d, const void* q, const void* k
     ADT_HIP_TRY(hipGetLastError());
     return ADT_OK;
   }
-  const char* fwd_env = getenv("ADT_ATTN_FWD");          // A/B: 1 = the first (unpipelined) kernel; read on every call
-  if (!(fwd_env && fwd_env[0] == '1')) return launch_attn_fwd2(a, static_cast<hipStream_t>(stream));
-  const int lds = 4 * kAttnTileBytes;
-  if (int rc = set_lds_once()) return rc;
-  const dim3 grid(static_cast<unsigned>((d->q_len + 127) / 128) * d->batch * d->heads);      // 1-D: tile_coords() renumbers it
-  if (a.drop.on()) hipLaunchKernelGGL(attn_fwd_kernel<true>, grid, dim3(kAttnThreads), lds, static_cast<hipStream_t>(stream), a);
-  else hipLaunchKernelGGL(attn_fwd_kernel<false>, grid, dim3(kAttnThreads), lds, static_cast<hipStream_t>(stream), a);
-  ADT_HIP_TRY(hipGetLastError());
-  return ADT_OK;
+  return launch_attn_fwd2(a, static_cast<hipStream_t>(stream));
 }
 
 static size_t delta_floats(const adt_attn_desc* d) { return (static_cast<size_t>(d->batch) * d->heads * d->q_len + 4 + 3) & ~static_cast<size_t>(3); }

@@ -238,8 +238,9 @@ __global__ __launch_bounds__(64 * kWaves, 8 / kWaves) void attn_fwd2_kernel(Attn
     pf[s >> 2].u[s & 3] = pack2_c(p0, p1);
     pin(pf[s >> 2].u[s & 3]);
   };
-  auto rescale = [&]() __attribute__((always_inline)) {               // lazy: only when some row's block maximum exceeds the running one by more than kRescaleThr
-    if (__any(mloc > m + kRescaleThr)) {
+  unsigned long long grow = 0;         // lanes whose block maximum exceeds the running one by more than kRescaleThr (taken inside phase B)
+  auto rescale = [&]() __attribute__((always_inline)) {               // lazy: only when some row's maximum rose by more than kRescaleThr
+    if (grow != 0) {
       const float m_new = fmaxf(m, mloc);
       const float alpha = __builtin_amdgcn_exp2f(m - m_new);
       m = m_new;
@@ -260,15 +261,16 @@ __global__ __launch_bounds__(64 * kWaves, 8 / kWaves) void attn_fwd2_kernel(Attn
     return bf16x8{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
   };
   // ---- phase A: sn = K(32 rows at LDS byte offset koff_) Q^T   ||   finish of the block whose scores are in sc
-  auto phase_a = [&](f32x16& sn, int koff_, f32x16& sc) __attribute__((always_inline)) {
-    bf16x8 kf[8];
-#pragma unroll
-    for (int s = 0; s < 4; ++s) kf[s] = k_frag(s, koff_);
+  // The first operands of a phase are read during the last slices of the phase before it (kf[0..3] by phase B / block0, vpre by phase A
+  // when no barrier lies between): the LDS round trip is not at the head of the MFMA chain.
+  bf16x8 kf[8], vpre[4];
+  auto phase_a = [&](f32x16& sn, int koff_, f32x16& sc, int vnext) __attribute__((always_inline)) {      // vnext: LDS offset of the next phase B's V rows, -1: behind a barrier
 #pragma unroll
     for (int i = 0; i < 16; ++i) sn[i] = 0.f;
 #pragma unroll
     for (int s = 0; s < 8; ++s) {
       if (s < 4) kf[s + 4] = k_frag(s + 4, koff_);
+      if (s >= 6 && vnext >= 0) { vpre[2 * (s - 6)] = v_frag(2 * (s - 6), vnext); vpre[2 * (s - 6) + 1] = v_frag(2 * (s - 6) + 1, vnext); }
       finish_pair(sc, s);
       sn = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf[s], qf[s], sn, 0, 0, 0);
       ADT_FENCE();
@@ -276,11 +278,12 @@ __global__ __launch_bounds__(64 * kWaves, 8 / kWaves) void attn_fwd2_kernel(Attn
   };
   // ---- phase B: O^T += V(32 rows at LDS byte offset voff_)^T P^T   ||   row maximum of the block whose raw scores are in sn, its hashes
   // (a tile that needs the per-element mask gets it in a pass of its own in front of the phase: one tile in sixteen in the encoder)
-  auto phase_b = [&](int voff_, const f32x16& sp, f32x16& sn, int key0, bool masked, auto&& dma_piece) __attribute__((always_inline)) {
+  auto phase_b = [&](int voff_, bool v_ready, int knext, const f32x16& sp, f32x16& sn, int key0, bool masked, auto&& dma_piece) __attribute__((always_inline)) {
+    // v_ready: the first four V fragments were read by the phase A before; knext: LDS offset of the next phase A's K rows, -1: none
     if (masked) start_mask(sn, key0, 0, 16);
     bf16x8 vt[2][4];
 #pragma unroll
-    for (int db = 0; db < 4; ++db) vt[0][db] = v_frag(db, voff_);
+    for (int db = 0; db < 4; ++db) vt[0][db] = v_ready ? vpre[db] : v_frag(db, voff_);
     float mx = kNegBig;
 #pragma unroll
     for (int i8 = 0; i8 < 8; ++i8) {
@@ -291,6 +294,8 @@ __global__ __launch_bounds__(64 * kWaves, 8 / kWaves) void attn_fwd2_kernel(Attn
         pin(mx);
       }
       if (i8 == 4) { mloc = cross_half_max(mx * sl2); pin(mloc); }
+      if (i8 == 5) { grow = __builtin_amdgcn_ballot_w64(mloc > m + kRescaleThr); asm volatile("" : "+s"(grow)); }
+      if (i8 >= 6 && knext >= 0) { kf[2 * (i8 - 6)] = k_frag(2 * (i8 - 6), knext); kf[2 * (i8 - 6) + 1] = k_frag(2 * (i8 - 6) + 1, knext); }
       hash_one(key0, i8);
       l += sp[2 * i8];                 // block g's row sum (un-dropped probabilities)
       l += sp[2 * i8 + 1];
@@ -302,7 +307,6 @@ __global__ __launch_bounds__(64 * kWaves, 8 / kWaves) void attn_fwd2_kernel(Attn
   };
 
   auto block0 = [&]() __attribute__((always_inline)) {      // an item's first block: scores, maximum, hashes (before the pipeline starts)
-    bf16x8 kf[8];
 #pragma unroll
     for (int s = 0; s < 8; ++s) kf[s] = k_frag(s, 0);
 #pragma unroll
@@ -311,8 +315,11 @@ __global__ __launch_bounds__(64 * kWaves, 8 / kWaves) void attn_fwd2_kernel(Attn
     for (int s = 0; s < 8; ++s) s0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf[s], qf[s], s0, 0, 0, 0);
     if (masked_tile(0)) start_mask(s0, 0, 0, 16);
     mloc = cross_half_max(start_max(s0, kNegBig, 0, 16) * sl2);
+    grow = __builtin_amdgcn_ballot_w64(mloc > m + kRescaleThr);
 #pragma unroll
     for (int i = 0; i < 8; ++i) hash_one(0, i);
+#pragma unroll
+    for (int s = 0; s < 4; ++s) kf[s] = k_frag(s, 32 * 256);      // phase A(0)'s first operands
     rescale();
   };
   // kPersist: the next item's operands are fetched under this item's tiles
@@ -328,7 +335,7 @@ __global__ __launch_bounds__(64 * kWaves, 8 / kWaves) void attn_fwd2_kernel(Attn
     constexpr int kK = kP * 2 * kAttnTileBytes, kV = kK + kAttnTileBytes, kKn = (kP ^ 1) * 2 * kAttnTileBytes;
     const int tile0 = t * kRowsPerTile;
     ADT_STAMP(0);
-    phase_a(s1, kK + 32 * 256, s0);
+    phase_a(s1, kK + 32 * 256, s0, -1);
     ADT_STAMP(1);
     // (tile 0: K(1) and V(0) were waited for before the item started; what is still in flight is the previous item's output)
     if (t > 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -342,13 +349,13 @@ __global__ __launch_bounds__(64 * kWaves, 8 / kWaves) void attn_fwd2_kernel(Attn
       else dma_piece_of(vg, a.ldv, voff, tile0 + kRowsPerTile, j, kKn + kAttnTileBytes);
     };
     ADT_STAMP(3);
-    phase_b(kV, s0, s1, tile0 + 32, masked_tile(t), piece);
+    phase_b(kV, false, kKn, s0, s1, tile0 + 32, masked_tile(t), piece);
     ADT_STAMP(4);
     rescale();
     ADT_STAMP(5);
-    phase_a(s0, kKn, s1);
+    phase_a(s0, kKn, s1, kV + 32 * 256);
     ADT_STAMP(6);
-    phase_b(kV + 32 * 256, s1, s0, tile0 + kRowsPerTile, masked_tile(t + 1), q_hook);
+    phase_b(kV + 32 * 256, true, kKn + 32 * 256, s1, s0, tile0 + kRowsPerTile, masked_tile(t + 1), q_hook);
     ADT_STAMP(7);
     rescale();
   };
@@ -364,7 +371,7 @@ __global__ __launch_bounds__(64 * kWaves, 8 / kWaves) void attn_fwd2_kernel(Attn
     const int kV = kK + kAttnTileBytes;
     const int tile0 = t * kRowsPerTile;
     const bool second = a.Sk - tile0 > 32;               // block-uniform
-    if (second) phase_a(s1, kK + 32 * 256, s0);
+    if (second) phase_a(s1, kK + 32 * 256, s0, -1);
     else finish_only(s0);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
@@ -375,11 +382,11 @@ __global__ __launch_bounds__(64 * kWaves, 8 / kWaves) void attn_fwd2_kernel(Attn
     auto next_hook = [&](int i8) __attribute__((always_inline)) {
       if (kPersist && has_next && (t & 1) && i8 < kPc) first_tiles(kgn, vgn, i8);
     };
-    phase_b(kV, s0, s1, tile0 + 32, masked_tile(t), next_hook);      // (without a second block: its maximum of s1 is not used)
+    phase_b(kV, false, -1, s0, s1, tile0 + 32, masked_tile(t), next_hook);      // (without a second block: its maximum of s1 is not used)
     if (second) {
       rescale();
       finish_only(s1);
-      phase_b(kV + 32 * 256, s1, s0, tile0 + kRowsPerTile, false, [](int) {});
+      phase_b(kV + 32 * 256, false, -1, s1, s0, tile0 + kRowsPerTile, false, [](int) {});
     }
   };
   while (true) {
