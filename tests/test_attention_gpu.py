@@ -95,6 +95,43 @@ def test_forward_and_backward(B, H, Sq, Sk, causal, padded):
     assert torch.equal(o, o2) and torch.equal(lse, lse2)
 
 
+# The forward has two workgroup forms (attention_fwd.hip): 4 waves x 2 workgroups per CU (at most 128 queries) and ONE persistent 8-wave
+# workgroup per CU that walks its (batch, head, query block) items with the next item's operands prefetched.  The persistent form's item
+# switch only happens with more items than CUs, and differs for even / odd numbers of 64-key tiles: enough items here for >= 2 per
+# workgroup on a 256-CU chip, both parities, masks, dropout -- against the 4-wave form (same bits) and the fp32 reference.
+@pytest.mark.parametrize("B,H,Sq,Sk,causal,padded", [
+    (50, 6, 257, 300, False, True),      # 600 items, 5 tiles (odd): the next item's first tiles are fetched after the last tile
+    (48, 6, 300, 200, True, True),       # 576 items, 4 tiles (even): K(0), V(0), K(1) of the next item land during the last tile
+    (130, 3, 129, 986, False, False),    # 390 items, 16 tiles, the encoder's key count (last tile: 26 keys, no second block)
+    (300, 1, 200, 40, False, True),      # 300 items, ONE tile per item
+])
+def test_persistent_forward_switches_items_correctly(monkeypatch, B, H, Sq, Sk, causal, padded):
+    from adt_str_amd import kernels as k
+    d = H * 128
+    q = rnd((B * Sq, d), 21).bfloat16()
+    kv = rnd((B * Sk, 2 * d), 22).bfloat16()
+    kk, v = kv[:, :d], kv[:, d:]
+    key_len = torch.tensor([max(1, Sk - (3 * i) % max(1, Sk - 1)) for i in range(B)], dtype=torch.int32, device=DEV) if padded else None
+    scale = 1.0 / math.sqrt(128)
+    ref_o, ref_lse = reference(q, kk, v, B, H, Sq, Sk, scale, causal, key_len.long() if padded else None)
+    for drop in (None, (0.1, 4242)):
+        out = {}
+        for waves in ("4", "8"):
+            monkeypatch.setenv("ADT_ATTN_FWD_WAVES", waves)
+            out[waves] = k.attn_fwd(q, kk, v, B, H, Sq, Sk, scale, causal, key_len, drop=drop)
+            torch.cuda.synchronize()
+        monkeypatch.delenv("ADT_ATTN_FWD_WAVES")
+        o8, l8 = out["8"]
+        assert torch.equal(o8, out["4"][0]) and torch.equal(l8, out["4"][1]), f"4-wave and 8-wave forms differ (dropout {drop})"
+        assert (l8 - ref_lse).abs().max() <= 2e-3
+        if drop is None:
+            assert (o8.float() - ref_o).abs().max() <= 2e-2 * ref_o.abs().max()
+        else:          # E[dropout(P)] = P: the mean over all outputs stays put, and 10 % of the weights being zero shows in the spread
+            assert abs((o8.float() - ref_o).mean().item()) <= 5e-3 * ref_o.abs().mean().item() + 1e-4
+        o8b, l8b = k.attn_fwd(q, kk, v, B, H, Sq, Sk, scale, causal, key_len, drop=drop)
+        assert torch.equal(o8b if Sq > 128 else o8, o8) and torch.equal(l8b if Sq > 128 else l8, l8)
+
+
 def _bwd(k, mode, q, kk, v, o, dout, lse, B, H, Sq, Sk, scale, causal, key_len, drop, monkeypatch, dkv=None):
     monkeypatch.setenv("ADT_ATTN_BWD", mode)
     if dkv:
