@@ -468,6 +468,52 @@ def spawn_ranks(n_ranks: int, argv) -> int:
     return subprocess.call(launcher_command(n_ranks, port, argv), env=env)
 
 
+class ClockPoll:
+    """Shader clock and board power of one GPU while the timed steps run (rocm-smi polled from a thread, ~8 samples a second).  Every
+    compute kernel of this repo runs the board into its power limit (profiles/r04/clock_under_load.txt: 1 400 W, 1.87-2.27 GHz depending on
+    the kernel), so what the MFMA pipe can deliver is the 2.4 GHz peak scaled by the clock the chip holds; the line reports both."""
+    NOMINAL_MHZ = 2400.0
+
+    def __init__(self, index):
+        self.index, self.samples, self._stop, self._th = index, [], False, None
+
+    def _run(self):
+        import re
+        import subprocess
+        while not self._stop:
+            try:
+                out = subprocess.run(["rocm-smi", "-d", str(self.index), "--showclocks", "--showpower", "--json"], capture_output=True, text=True, timeout=5).stdout
+                card = json.loads(out)
+                card = card[sorted(card)[0]]
+                sclk = next((v for k, v in card.items() if "sclk" in k.lower()), "")
+                pw = next((v for k, v in card.items() if "power" in k.lower()), "")
+                m = re.search(r"(\d+)\s*Mhz", str(sclk), re.I)
+                if m:
+                    self.samples.append((time.perf_counter(), int(m.group(1)), float(re.sub(r"[^0-9.]", "", str(pw)) or "nan")))
+            except Exception:          # noqa: BLE001  (no rocm-smi, no permission: the line goes out without the object)
+                return
+            time.sleep(0.02)
+
+    def start(self):
+        import threading
+        self._th = threading.Thread(target=self._run, daemon=True)
+        self._th.start()
+        return self
+
+    def stop(self, t_from):
+        self._stop = True
+        if self._th is not None:
+            self._th.join(timeout=6)
+        s = [(c, p) for (t, c, p) in self.samples if t >= t_from]
+        if not s:
+            return None
+        clk, pw = sorted(c for c, _ in s), sorted(p for _, p in s)
+        med = clk[len(clk) // 2]
+        return {"sclk_mhz": {"min": clk[0], "median": med, "max": clk[-1]}, "power_w_median": pw[len(pw) // 2], "samples": len(s),
+                "nominal_mhz": self.NOMINAL_MHZ, "held_over_nominal": med / self.NOMINAL_MHZ,
+                "source": "rocm-smi --showclocks --showpower polled while the timed steps ran (samples of the timed region only)"}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -479,6 +525,7 @@ def main():
                                                                  "benchmark configuration is 0)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-e2e", action="store_true", help="skip the end-to-end (real input pipeline) leg of the train workload")
+    ap.add_argument("--no-clock", action="store_true", help="do not poll rocm-smi for the shader clock / board power during the timed steps (the \"clock\" object of the line)")
     ap.add_argument("--no-clap", action="store_true", help="train workload, N = 1: skip the CLAP embeds/sec leg (the \"clap\" object of the line)")
     ap.add_argument("--roofline-loop", action="store_true", help="train workload: also time the roofline kernel alone, back to back (the "
                                                                   "earlier rounds' measurement; adds 100 launches of it to a profile of this command)")
@@ -530,11 +577,13 @@ def main():
         wl["comm"]()                                     # drop the warm-up steps' wait events
     if "tap" in wl:
         wl["tap"](True)                                  # event pairs around the roofline kernel's launches inside the timed region
+    poll = ClockPoll(local_rank).start() if (rank == 0 and not args.no_clock) else None
     t0 = time.perf_counter()
     for _ in range(args.steps):
         step()
     fence()
     dt = time.perf_counter() - t0
+    clock = poll.stop(t0) if poll is not None else None
     if "tap" in wl:
         wl["tap"](False)
     rank_ms = None
@@ -584,6 +633,13 @@ def main():
         if os.environ.get("ADT_BENCH_SHARE_GPU") == "1":
             line["data"] = "synthetic; DEBUG RUN: all ranks share GPU 0 over gloo (ADT_BENCH_SHARE_GPU=1), not a measurement"
         line["roofline"] = wl["roofline"](args.roofline_loop) if args.workload == "train" else wl["roofline"]()
+        if clock is not None:
+            line["clock"] = clock
+            if line["roofline"].get("bound") == "mfma" and line["roofline"].get("frac") is not None:
+                # the same achieved rate against the MFMA peak at the clock the chip held during the timed steps (power-limited: see ClockPoll)
+                line["roofline"]["frac_at_held_clock"] = line["roofline"]["frac"] / clock["held_over_nominal"]
+            if "step_mfma_frac" in line:
+                line["step_mfma_frac_at_held_clock"] = line["step_mfma_frac"] / clock["held_over_nominal"]
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = wl["cpu_baseline"]()
         if world == 1 and args.workload == "train" and not args.no_clap:

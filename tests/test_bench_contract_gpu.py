@@ -59,6 +59,13 @@ def test_train_line():
     cr = c["roofline"]
     assert cr["bound"] == "mfma" and abs(cr["frac"] - cr["achieved"] / cr["peak"]) < 1e-9 and 0.0 < cr["frac"] < 1.0
     assert "cpu_baseline" not in c                       # --no-cpu-baseline covers both legs
+    # shader clock / board power held during the timed steps (absent where rocm-smi is not usable): a plausible clock, and the roofline
+    # fraction re-priced at it
+    if "clock" in d:
+        ck = d["clock"]
+        assert 300 <= ck["sclk_mhz"]["min"] <= ck["sclk_mhz"]["median"] <= ck["sclk_mhz"]["max"] <= 2600 and ck["samples"] >= 1
+        assert abs(ck["held_over_nominal"] - ck["sclk_mhz"]["median"] / ck["nominal_mhz"]) < 1e-9
+        assert abs(r["frac_at_held_clock"] - r["frac"] / ck["held_over_nominal"]) < 1e-9
 
 
 def test_logmel_line_with_cpu_baseline():
