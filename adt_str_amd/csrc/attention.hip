@@ -238,6 +238,7 @@ __global__ __launch_bounds__(kAttnThreads, 2) void attn_bwd_dq_kernel(AttnArgs a
     const bool need_mask = a.causal || tile0 + kRowsPerTile > klen || tile0 + kRowsPerTile > a.Sk;
 #pragma unroll
     for (int kb = 0; kb < 2; ++kb) {
+      if (kb == 1 && tile0 + 32 >= a.Sk) break;          // the last tile's second block holds no key (986 keys: block 31 of 32): its dS is exactly 0
       f32x16 st, dp;
 #pragma unroll
       for (int i = 0; i < 16; ++i) { st[i] = 0.f; dp[i] = 0.f; }

@@ -4,6 +4,9 @@ mkdir -p $P
 for f in bench_train.json bench_train_nodropout.json bench_logmel.json bench_clap.json e2e_config4_scaled.json bench_train_torchrun1.json bench_train_torchrun1_bf16comm.json; do [ -f $O/$f ] && cp $O/$f $P/$f; done
 [ -f $O/bench_hf_trainer.txt ] && grep -v amdgpu.ids $O/bench_hf_trainer.txt > $P/bench_hf_trainer.txt
 grep -v amdgpu.ids $O/bench_kernels.txt > $P/bench_kernels.txt
+for f in attn_bwd_paths.txt attn_fwd.txt; do [ -f $O/$f ] && grep -v amdgpu.ids $O/$f > $P/$f; done
+[ -f $O/bench_train_fp32.json ] && cp $O/bench_train_fp32.json $P/bench_train_fp32.json
+[ -f $O/bench_train_2ranks_shared_gpu_debug.json ] && cp $O/bench_train_2ranks_shared_gpu_debug.json $P/
 cp $O/smoke.log $P/smoke.txt
 tail -3 $O/pytest_gpu.log > $P/pytest_gpu.txt
 cp "$(ls -t $O/prof_train/*/*kernel_stats.csv | head -1)" $P/train_step_kernel_stats.csv          # (newest: an earlier call with the same tag leaves its files behind)

@@ -16,6 +16,7 @@ timeout 900 python -m torch.distributed.run --nnodes=1 --nproc-per-node 1 --mast
 timeout 600 python tools/bench_hf_trainer.py > $O/bench_hf_trainer.txt 2>&1; tail -3 $O/bench_hf_trainer.txt
 timeout 600 python tools/bench_kernels.py > $O/bench_kernels.txt 2>&1
 timeout 600 python tools/exp_attn_bwd.py > $O/attn_bwd_paths.txt 2>&1; tail -6 $O/attn_bwd_paths.txt
+timeout 600 python tools/exp_attn_fwd.py > $O/attn_fwd.txt 2>&1; tail -6 $O/attn_fwd.txt
 timeout 600 python bench.py --steps 5 --warmup 2 --precision fp32 --no-e2e --no-clap --no-cpu-baseline > $O/bench_train_fp32.json 2> /dev/null; cut -c1-200 $O/bench_train_fp32.json
 ADT_BENCH_SHARE_GPU=1 timeout 600 python bench.py --gpus 2 --steps 3 --warmup 1 --no-cpu-baseline --no-e2e --no-clap > $O/bench_train_2ranks_shared_gpu_debug.json 2> $O/bench_2ranks.err; cut -c1-200 $O/bench_train_2ranks_shared_gpu_debug.json
 timeout 600 python tools/e2e.py --shots 4000 --chunks 2048 --check-resume > $O/e2e_config4_scaled.json 2> $O/e2e.err; cut -c1-400 $O/e2e_config4_scaled.json
