@@ -562,19 +562,22 @@ __global__ __launch_bounds__(kDkv3Threads) void attn_bwd_dkv3_kernel(AttnArgs a)
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     asm volatile("s_barrier" ::: "memory");
   };
+  // A wave whose 32 query rows of a tile all lie past Sq (986 queries: the second half of tile 15) has nothing to add -- its P is exactly 0 --
+  // and sits the block out (wave-uniform; it still issues its share of the next tile and meets the barrier): its SIMD's other wave runs alone.
+  auto has_rows = [&](int t) { return t * kRowsPerTile + half * 32 < a.Sq; };
   if (!skew) {
     for (int it = 0; it <= n_tiles; ++it) {
       const bool more = it + 1 < n_tiles;
       if (more) { load_stats(it + 1); issue_tile(it + 1); }
-      if (it < n_tiles) { chain(it); finish(it); }
+      if (it < n_tiles && has_rows(it)) { chain(it); finish(it); }
       end_iter(it, more);
     }
   } else {
     for (int it = 0; it <= n_tiles; ++it) {
       const bool more = it + 1 < n_tiles;
       if (more) { load_stats(it + 1); issue_tile(it + 1); }
-      if (it >= 1) finish(it - 1);
-      if (it < n_tiles) chain(it);
+      if (it >= 1 && has_rows(it - 1)) finish(it - 1);
+      if (it < n_tiles && has_rows(it)) chain(it);
       end_iter(it, more);
     }
   }
