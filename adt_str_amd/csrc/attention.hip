@@ -215,6 +215,7 @@ __global__ __launch_bounds__(kAttnThreads, 2) void attn_bwd_dq_kernel(AttnArgs a
     for (int i = 0; i < 16; ++i) dq[db][i] = 0.f;
 
   const int n_tiles = (a.Sk + kRowsPerTile - 1) / kRowsPerTile;
+  const bool wave_has_rows = tc.x * 128 + wave * 32 < a.Sq;      // wave-uniform (986 queries: wave 3 of the eighth query block has none)
   unsigned koff[4], voff[4];
   tile_dma_offsets(a.ldk, wave, lane, koff);
   tile_dma_offsets(a.ldv, wave, lane, voff);
@@ -239,6 +240,7 @@ __global__ __launch_bounds__(kAttnThreads, 2) void attn_bwd_dq_kernel(AttnArgs a
 #pragma unroll
     for (int kb = 0; kb < 2; ++kb) {
       if (kb == 1 && tile0 + 32 >= a.Sk) break;          // the last tile's second block holds no key (986 keys: block 31 of 32): its dS is exactly 0
+      if (!wave_has_rows) break;                         // a wave whose 32 rows all lie past Sq only stages tiles and meets the barriers
       f32x16 st, dp;
 #pragma unroll
       for (int i = 0; i < 16; ++i) { st[i] = 0.f; dp[i] = 0.f; }
