@@ -132,6 +132,35 @@ def test_persistent_forward_switches_items_correctly(monkeypatch, B, H, Sq, Sk, 
         assert torch.equal(o8b if Sq > 128 else o8, o8) and torch.equal(l8b if Sq > 128 else l8, l8)
 
 
+@pytest.mark.parametrize("Sq", [100, 200])          # the 4-wave and the 8-wave form of the forward
+def test_mild_additive_mask(monkeypatch, Sq):
+    """The reference's masks are additive (-1e4, and they add up where causal and padding overlap: model.py:173-181); the kernels take
+    the value as a parameter.  With a mild one masked keys keep weight: forward and both backward paths against the fp32 reference."""
+    from adt_str_amd import kernels as k
+    B, H, Sk, mv = 3, 2, 150, -3.0
+    d = H * 128
+    q = rnd((B * Sq, d), 31).bfloat16()
+    kv = rnd((B * Sk, 2 * d), 32).bfloat16()
+    kk, v = kv[:, :d], kv[:, d:]
+    key_len = torch.tensor([150, 97, 1], dtype=torch.int32, device=DEV)
+    scale = 1.0 / math.sqrt(128)
+    o, lse = k.attn_fwd(q, kk, v, B, H, Sq, Sk, scale, True, key_len, mask_value=mv)
+    qr, kr, vr = (t.float().clone().requires_grad_(True) for t in (q, kk, v))
+    ref_o, ref_lse = reference(qr, kr, vr, B, H, Sq, Sk, scale, True, key_len.long(), mask_value=mv)
+    assert (o.float() - ref_o).abs().max() <= 2e-2 * ref_o.abs().max()
+    assert (lse - ref_lse).abs().max() <= 2e-3
+    dout = rnd((B * Sq, d), 33).bfloat16()
+    ref_o.backward(dout.float())
+    for mode in ("split", "fused"):
+        monkeypatch.setenv("ADT_ATTN_BWD", mode)
+        dq, dkv = torch.zeros_like(q), torch.zeros_like(kv)
+        k.attn_bwd(q, kk, v, o, dout, lse, dq, dkv[:, :d], dkv[:, d:], B, H, Sq, Sk, scale, True, key_len, mask_value=mv)
+        for name, got, ref in (("dq", dq, qr.grad), ("dk", dkv[:, :d], kr.grad), ("dv", dkv[:, d:], vr.grad)):
+            err = (got.float() - ref).abs().max().item()
+            assert err <= 4e-2 * ref.abs().max().item() + 1e-6, f"{mode} {name}: {err} vs max {ref.abs().max().item()}"
+    monkeypatch.delenv("ADT_ATTN_BWD")
+
+
 def _bwd(k, mode, q, kk, v, o, dout, lse, B, H, Sq, Sk, scale, causal, key_len, drop, monkeypatch, dkv=None):
     monkeypatch.setenv("ADT_ATTN_BWD", mode)
     if dkv:
