@@ -1,22 +1,27 @@
-// attention_fwd.hip -- K4 forward, software-pipelined: the flash-style forward of attention.hip's header (lane <-> query, S^T = K Q^T,
-// O^T += V^T P^T, v_mfma_f32_32x32x16_bf16, 128 queries per workgroup = 4 waves x 32, two workgroups per CU) with the two products
-// of neighbouring 32-key blocks overlapped inside each wave.  Stands behind nn.MultiheadAttention of the reference's encoder / decoder
-// layers (model.py:118-127, 159-168) exactly as the kernel it replaces.
+// attention_fwd.hip -- K4 forward, software-pipelined and (for more than 128 queries) persistent: the flash-style forward of attention.hip's
+// header (lane <-> query, S^T = K Q^T, O^T += V^T P^T, v_mfma_f32_32x32x16_bf16, a wave = 32 queries) with the two products of neighbouring
+// 32-key blocks overlapped inside each wave.  Stands behind nn.MultiheadAttention of the reference's encoder / decoder layers
+// (model.py:118-127, 159-168).  Two workgroup forms, same bits: 4 waves x 2 workgroups per CU (at most 128 queries: the decoder), and ONE
+// 8-wave workgroup per CU that walks its (batch, head, 256-query block) items, the next item's operands arriving under the current one's tiles.
 //
 // A wave's own chain per 32-key block is   K reads -> 8 MFMAs (S) -> max -> exp / sum / dropout / pack -> V^T reads -> 8 MFMAs (O):
-// run in that order (the first forward kernel) it costs ~1800 cycles for 512 cycles of MFMA, and the second wave of the SIMD only
-// hides part of it.  Here block g + 1's score product runs UNDER block g's exponentials, and block g's value product under block
-// g + 1's row maximum and dropout hashes:
-//     phase A(g):  S(g+1) = K(g+1) Q^T          ||  finish(g): p = exp2(s * scale * log2e - m), row sum, dropout, bf16 pack
-//     phase B(g):  O^T += V(g)^T P(g)^T         ||  start(g+1): mask, row maximum over the 32 keys;  hashes of block g + 1
+// run in that order (the first forward kernel, rounds 1-3) it costs ~1800 cycles for 512 cycles of MFMA, and the second wave of the SIMD
+// only hides part of it.  Here block g + 1's score product runs UNDER block g's exponentials, and block g's value product under block
+// g + 1's row maximum, block g's row sum and block g + 1's dropout hashes:
+//     phase A(g):  S(g+1) = K(g+1) Q^T          ||  finish(g): p = exp2(s * scale * log2e - m) (kept in place of s), dropout, bf16 pack
+//     phase B(g):  O^T += V(g)^T P(g)^T         ||  row sum of block g; start(g+1): row maximum over the 32 keys; hashes of block g + 1
 //     then the lazy rescale of (m, l, O) if some row's maximum rose by more than kRescaleThr (after block g's product went into O).
 // Each phase is cut into eight slices of one MFMA + one eighth of the vector work, separated by scheduling fences, so that the
-// interleaving in the source is the interleaving in the binary; the compiler still inserts every wait and hazard no-op (builtins only).
+// interleaving in the source is the interleaving in the binary; the compiler still inserts every wait and hazard no-op (builtin MFMAs,
+// LDS reads and conversions; the only asm with an instruction in it is the LDS-DMA issue, see dma1k).  Every slice's result is pinned
+// (pin()): it is consumed a phase later, and the optimiser would otherwise sink the whole of finish(g) into the block that reads P.
 // Tiles of 64 keys arrive by LDS-DMA into two K and two V buffers; ONE barrier per tile, between A(2t) and B(2t): K(t) is dead there
-// (its rows 32..63 were just used) and V(t - 1) has been dead for two phases, so K(t + 2) and V(t + 1) are issued right behind it,
-// and K(t + 1), V(t) -- issued one tile earlier -- are made visible by it, one phase before their first use.
+// (its rows 32..63 were just used) and V(t - 1) has been dead for two phases, so K(t + 2) and V(t + 1) are issued right behind it
+// (one 1-KiB piece behind each MFMA of phase B(2t)), and K(t + 1), V(t) -- issued one tile earlier -- are made visible by it, one phase
+// before their first use.  A tile that needs the per-element mask (causal, key padding, the key range's end) gets it in a pass of its own.
 // Dropout keeps the element iff its 16-bit hash half >= thr (dropout.h); the 1 / (1 - p) factor is folded into the exponent
 // (exp2(x + log2(1 / (1 - p)))), so a dropped element costs a compare and a select, and the row sum is rescaled once at the end.
+// Measurements and the order in which the pieces paid: DESIGN.md section 8; profiles/r04/attn_fwd*.txt.
 #include "attn_common.h"
 #include <cstdio>
 
