@@ -109,3 +109,13 @@ def test_inference_cli_accepts_the_references_flag_spellings():
     assert (b.output_dir, b.synthesize) == ("p", True)
     c = _parser().parse_args(["in.wav", "cfg.yaml"])
     assert (c.output_dir, c.synthesize) == ("outputs/", False)
+
+
+def test_bench_clock_poll_is_silent_without_a_gpu():
+    """bench.py polls rocm-smi for the shader clock during its timed steps; where that is not possible (this container: no GPU) the
+    line simply goes out without the `clock` object -- no exception, no hang at exit."""
+    import time
+    import bench
+    poll = bench.ClockPoll(0).start()
+    time.sleep(0.2)
+    assert poll.stop(0.0) is None
