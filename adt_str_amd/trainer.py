@@ -433,20 +433,35 @@ def save_model(model: nn.Module, directory: str):
                        getattr(model, "config", None), directory)
 
 
+INCOMPLETE_SENTINEL = ".adt_incomplete"
+FOREIGN_CHECKPOINT_FILES = ("trainer_state.json", "optimizer.pt", "scheduler.pt", "training_args.bin", "pytorch_model.bin")
+
+
+def _is_own_incomplete(d: str) -> bool:
+    """A directory THIS loop created and never finished: it still carries the sentinel ``save_checkpoint`` drops at makedirs time
+    (removed when ``trainer_state.pt`` is written) and holds nothing an HF / reference checkpoint would (``trainer_state.json``,
+    ``optimizer.pt`` ...).  Anything else in ``output_dir`` -- the HF-Trainer path writes its ``checkpoint-N`` directories into the
+    same place -- is not ours to delete."""
+    if not os.path.exists(os.path.join(d, INCOMPLETE_SENTINEL)) or os.path.exists(os.path.join(d, "trainer_state.pt")):
+        return False
+    return not any(os.path.exists(os.path.join(d, f)) for f in FOREIGN_CHECKPOINT_FILES)
+
+
 def _prune_checkpoints(output_dir: str, keep: Optional[int], just_written: str):
-    """``save_total_limit``: remove the oldest checkpoints beyond ``keep`` -- never the one just written, whatever stale
-    higher-numbered directories a previous run left behind."""
+    """``save_total_limit``: remove the oldest NATIVE checkpoints beyond ``keep`` -- never the one just written, whatever stale
+    higher-numbered directories a previous run left behind, and never a directory this loop did not provably create (HF Trainer /
+    reference checkpoints share ``output_dir``: they have ``trainer_state.json``, not ``.pt``).  Without ``keep`` nothing is removed."""
+    if not keep:
+        return
     just = os.path.abspath(just_written)
-    # directories a killed run left without their marker are invisible to _checkpoint_dirs and would never be rotated out: remove the
-    # ones OLDER (lower step) than the checkpoint just completed (a higher-numbered one may be the next checkpoint, which other ranks
-    # are already writing their RNG files into while this one's background write finishes)
+    # directories a killed run of THIS loop left without their marker are invisible to _checkpoint_dirs and would never be rotated out:
+    # remove the ones OLDER (lower step) than the checkpoint just completed (a higher-numbered one may be the next checkpoint, which
+    # other ranks are already writing their RNG files into while this one's background write finishes)
     mj = re.fullmatch(r"checkpoint-(\d+)", os.path.basename(just))
     for d in glob.glob(os.path.join(output_dir, "checkpoint-*")):
         m = re.fullmatch(r"checkpoint-(\d+)", os.path.basename(d))
-        if m and mj and int(m.group(1)) < int(mj.group(1)) and not os.path.exists(os.path.join(d, "trainer_state.pt")):
+        if m and mj and int(m.group(1)) < int(mj.group(1)) and _is_own_incomplete(d):
             shutil.rmtree(d, ignore_errors=True)
-    if not keep:
-        return
     others = [d for d in _checkpoint_dirs(output_dir) if os.path.abspath(d) != just]
     others.sort(key=lambda d: os.path.getmtime(os.path.join(d, "trainer_state.pt")))
     for old in others[:max(0, len(others) - (keep - 1))]:
@@ -517,6 +532,8 @@ def save_checkpoint(output_dir: str, model: nn.Module, trainer, progress: dict, 
     copy and the file writes happen on its thread; without one, here."""
     d = os.path.join(output_dir, f"checkpoint-{trainer.step_no}")
     os.makedirs(d, exist_ok=True)
+    if not os.path.exists(os.path.join(d, "trainer_state.pt")):
+        open(os.path.join(d, INCOMPLETE_SENTINEL), "a").close()   # "this loop made it": every rank, BEFORE its RNG file (rank 0 removes it with the marker)
     if rng_state is not None:
         rp = os.path.join(d, f"rng_state_{rank}.pth")
         torch.save({"python": rng_state[0], "torch": rng_state[1]}, rp + ".tmp")
@@ -569,6 +586,10 @@ def _finish_checkpoint(d, state, cfg, tstate, progress, world, output_dir, keep,
     tmp = os.path.join(d, "trainer_state.pt.tmp")
     torch.save({"trainer": tstate, "progress": dict(progress), "world": world, "rng_files": rng_files}, tmp)
     os.replace(tmp, os.path.join(d, "trainer_state.pt"))
+    try:
+        os.remove(os.path.join(d, INCOMPLETE_SENTINEL))
+    except FileNotFoundError:
+        pass
     _prune_checkpoints(output_dir, keep, d)
 
 

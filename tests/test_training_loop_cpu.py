@@ -280,6 +280,7 @@ def test_scheduler_selection_follows_the_reference(tmp_path):
 def test_missing_rank_rng_file_is_reported_on_resume(tmp_path):
     _, full = _run(_cfg(tmp_path / "r", logging__save_every_n_steps=5))
     ck = tmp_path / "r" / "default" / "checkpoint-10"
+    assert (ck / "trainer_state.pt").exists() and not (ck / T.INCOMPLETE_SENTINEL).exists()   # a finished checkpoint carries no sentinel
     os.remove(ck / "rng_state_0.pth")
     # the checkpoint recorded an RNG file per rank: resuming without it would silently change the data stream -> refused ...
     with pytest.raises(FileNotFoundError, match="rng_state_0.pth is missing"):
@@ -301,6 +302,20 @@ def test_checkpoint_marker_waits_for_every_ranks_rng_file_and_dead_directories_a
     dead = out / "checkpoint-3"
     os.makedirs(dead)
     (dead / "model.safetensors").write_bytes(b"partial")
+    (dead / T.INCOMPLETE_SENTINEL).write_bytes(b"")                      # what save_checkpoint drops at makedirs time
+    # directories this loop did NOT create share output_dir (train.py without --native = HF Trainer; the reference's own checkpoints):
+    # no trainer_state.pt, so the old rule would have deleted them at the first native save
+    hf = out / "checkpoint-2"
+    os.makedirs(hf)
+    (hf / "trainer_state.json").write_text("{}")
+    (hf / "optimizer.pt").write_bytes(b"hf")
+    unknown = out / "checkpoint-1"                                        # no sentinel, nothing recognisable: not ours either
+    os.makedirs(unknown)
+    (unknown / "model.safetensors").write_bytes(b"someone else's")
+    mixed = out / "checkpoint-4"                                          # sentinel AND a foreign file (an HF run re-used the directory)
+    os.makedirs(mixed)
+    (mixed / T.INCOMPLETE_SENTINEL).write_bytes(b"")
+    (mixed / "trainer_state.json").write_text("{}")
     d = out / "checkpoint-5"
     os.makedirs(d)
     torch.save({}, d / "rng_state_0.pth")
@@ -311,6 +326,13 @@ def test_checkpoint_marker_waits_for_every_ranks_rng_file_and_dead_directories_a
     torch.save({}, d / "rng_state_1.pth")                               # the lagging rank arrives
     T._finish_checkpoint(str(d), {"w": torch.zeros(2)}, None, {}, {"step": 5}, 2, str(out), 3, rng_files=2)
     assert (d / "trainer_state.pt").exists() and not dead.exists()
+    assert hf.exists() and (hf / "optimizer.pt").exists() and unknown.exists() and mixed.exists()
+    # without save_total_limit nothing is ever removed, not even this loop's own dead directories
+    dead2 = out / "checkpoint-0"
+    os.makedirs(dead2)
+    (dead2 / T.INCOMPLETE_SENTINEL).write_bytes(b"")
+    T._prune_checkpoints(str(out), None, str(d))
+    assert dead2.exists()
     st = torch.load(d / "trainer_state.pt", weights_only=False)
     assert st["rng_files"] == 2 and st["world"] == 2
 
