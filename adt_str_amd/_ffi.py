@@ -14,7 +14,7 @@ _LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "libadt_hip
 _lock = threading.Lock()
 _lib = None
 
-ABI_VERSION = 15
+ABI_VERSION = 16
 
 i32, i64, f32, ptr = C.c_int32, C.c_int64, C.c_float, C.c_void_p
 
@@ -45,7 +45,7 @@ class AttnDesc(C.Structure):
                 ("head_dim", C.c_int32), ("causal", C.c_int32), ("ldq", C.c_int64), ("ldk", C.c_int64),
                 ("ldv", C.c_int64), ("ldo", C.c_int64), ("scale", C.c_float), ("mask_value", C.c_float),
                 ("key_len", C.c_void_p), ("drop", Dropout), ("dq_colsum", C.c_void_p), ("dk_colsum", C.c_void_p),
-                ("dv_colsum", C.c_void_p)]
+                ("dv_colsum", C.c_void_p), ("keep_bits", C.c_void_p)]
 
 
 class AffWeights(C.Structure):
@@ -66,6 +66,7 @@ SIGNATURES = {
     "adt_gemm_bf16_tn_grouped": [ptr, i32, ptr],
     "adt_ln_gemm_bf16": [i64, i64, i64, ptr, i64, ptr, ptr, f32, ptr, i64, ptr, i64, ptr, ptr, i64, ptr],
     "adt_attn_fwd": [ptr, ptr, ptr, ptr, ptr, ptr, ptr],
+    "adt_attn_keep_bits_bytes": [ptr],
     "adt_attn_bwd_workspace_bytes": [ptr],
     "adt_attn_bwd": [ptr, ptr, ptr, ptr, ptr, ptr, ptr, ptr, ptr, ptr, ptr, C.c_size_t, ptr],
     "adt_layernorm_fwd": [ptr, i64, ptr, ptr, f32, ptr, ptr, i64, ptr, ptr, i64, i64, ptr, ptr],
@@ -120,7 +121,7 @@ SIGNATURES = {
     "adt_mix_render_fx_f32": [ptr, ptr, i64, ptr, i64, ptr, ptr, ptr, i64, i64, ptr, i32, ptr, i64, ptr, C.c_size_t, ptr],
 }
 _RESTYPES = {"adt_last_error": C.c_char_p}
-_RESTYPES.update({n: C.c_size_t for n in ("adt_mix_workspace_bytes", "adt_gemm_workspace_bytes", "adt_attn_bwd_workspace_bytes",
+_RESTYPES.update({n: C.c_size_t for n in ("adt_mix_workspace_bytes", "adt_gemm_workspace_bytes", "adt_attn_bwd_workspace_bytes", "adt_attn_keep_bits_bytes",
                                           "adt_layernorm_bwd_workspace_bytes", "adt_colsum_workspace_bytes", "adt_gemm_colsum_workspace_bytes",
                                           "adt_cross_entropy_workspace_bytes", "adt_grad_norm_workspace_bytes",
                                           "adt_htsat_fusion_embed_workspace_bytes",

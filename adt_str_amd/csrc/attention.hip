@@ -634,7 +634,13 @@ static AttnArgs make_args(const adt_attn_desc* d) {
   a.scale = d->scale; a.mask_value = d->mask_value; a.causal = d->causal; a.key_len = d->key_len;
   a.drop = make_drop(d->drop.p, d->drop.key);
   a.cs_dq = nullptr;
+  a.keep_bits = a.drop.on() ? static_cast<unsigned*>(d->keep_bits) : nullptr;
+  a.bits_nq = keep_bits_nq(d->q_len); a.bits_nk = keep_bits_nk(d->k_len);
   return a;
+}
+extern "C" size_t adt_attn_keep_bits_bytes(const adt_attn_desc* d) {
+  if (!d || d->batch <= 0 || d->heads <= 0 || d->q_len <= 0 || d->k_len <= 0) return 16;
+  return static_cast<size_t>(d->batch) * d->heads * keep_bits_nq(d->q_len) * keep_bits_nk(d->k_len) * 128;
 }
 static int set_lds_once() {      // raise the dynamic-LDS limit of the backward kernels once per device and thread
   static thread_local int done_for = -1;
@@ -683,9 +689,39 @@ static size_t split_workspace_bytes(const adt_attn_desc* d) {
              adt_colsum_workspace_bytes(static_cast<int64_t>(d->batch) * (d->k_len > d->q_len ? d->k_len : d->q_len), static_cast<int64_t>(d->heads) * kDh);
   return (bytes + 255) & ~static_cast<size_t>(255);
 }
+// Which backward runs.  The one-kernel path (attention_bwd_fused.hip: the five algorithmic products, dQ summed over the key-block workgroups
+// by a scheduled fan-in) is the default without dropout (MI355X, encoder shape 0.83 vs 0.87 ms) and with dropout WHEN THE FORWARD LEFT ITS
+// KEEP BITS (adt_attn_desc.keep_bits: no mask is hashed again; profiles/r05/attn_bwd_paths.txt).  With dropout and no bits the two-kernel path
+// (dQ kernel + dK/dV kernel, 7 products, every mask hashed twice) is still the faster one (0.95 vs 0.98 ms): at one wave per SIMD the mask
+// generation sits on the fused kernel's vector pipe with nothing to hide it.  ADT_ATTN_BWD=fused / split forces a path (read on every call:
+// the tests and tools/exp_attn_bwd.py switch it) -- except where the fused path cannot be trusted to make progress: its fan-in has key block
+// jr % nkb wait for the tiles of ALL the head's other key blocks, which draw consecutive tickets of one XCD group's counter, so every one of
+// the head's nkb workgroups must be resident on that XCD group at once (one workgroup per CU, n_cu / 8 CUs per group).  Half of that is
+// the bound here (CUs held by another stream's kernel -- an RCCL collective -- are not ours): 16 key blocks = 4096 keys on 256 CUs;
+// beyond it, and under stream capture (the ticket counters are refused there, as for the persistent GEMMs), the two-kernel path runs.
+static bool fused_can_run(const adt_attn_desc* d, hipStream_t st, bool* ok) {
+  int n_cu = 0;
+  if (device_cu_count(&n_cu)) return false;
+  const int nkb = (d->k_len + 255) / 256;
+  *ok = 2 * nkb <= n_cu / 8 || nkb == 1;
+  if (*ok && st != nullptr) {
+    hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+    if (hipStreamIsCapturing(st, &cs) == hipSuccess && cs != hipStreamCaptureStatusNone) *ok = false;
+  }
+  return true;
+}
+static bool wants_fused(const adt_attn_desc* d) {
+  const char* bwd_env = getenv("ADT_ATTN_BWD");
+  if (bwd_env) return bwd_env[0] == 'f';
+  return !(d->drop.p > 0.0f) || d->keep_bits != nullptr;
+}
 extern "C" size_t adt_attn_bwd_workspace_bytes(const adt_attn_desc* d) {
   if (!d || d->batch <= 0 || d->heads <= 0 || d->q_len <= 0 || d->k_len <= 0) return 16;
-  return split_workspace_bytes(d) + attn_bwd_fused_workspace_bytes(d);
+  // sized by the path that will run (the fused path's region is nkb fp32 copies of dQ: 780 MB at the encoder shape); the capture state of
+  // the stream is not known here, so a shape the fused path may take is sized for it
+  bool ok = false;
+  if (!fused_can_run(d, nullptr, &ok)) ok = true;
+  return split_workspace_bytes(d) + (wants_fused(d) && ok ? attn_bwd_fused_workspace_bytes(d) : 0);
 }
 
 extern "C" int adt_attn_bwd(const adt_attn_desc* d, const void* q, const void* k, const void* v, const void* o, const void* dout,
@@ -703,13 +739,9 @@ extern "C" int adt_attn_bwd(const adt_attn_desc* d, const void* q, const void* k
   const bool want_cs = d->dq_colsum || d->dk_colsum || d->dv_colsum;
   if (want_cs && !(d->dq_colsum && d->dk_colsum && d->dv_colsum)) return set_error(ADT_EINVAL, "adt_attn_bwd: give all three column-sum outputs or none");
   const int nqb = (d->q_len + 127) / 128, hd = d->heads * kDh;
-  // Two backward paths.  The one-kernel path (attention_bwd_fused.hip: the five algorithmic products, dQ summed over the key-block workgroups
-  // by a scheduled fan-in) is the default WITHOUT dropout (MI355X, encoder shape 0.82 vs 0.87 ms, cross-attention 0.21 vs 0.22).  With
-  // dropout the two-kernel path below (dQ kernel + dK/dV kernel, 7 products, every mask hashed twice) is still the faster one (0.96 vs
-  // 0.99 ms): at one wave per SIMD the mask generation sits on the fused kernel's vector pipe with nothing to hide it.  ADT_ATTN_BWD=fused /
-  // split forces a path (read on every call: the tests and tools/exp_attn_bwd.py switch it).
-  const char* bwd_env = getenv("ADT_ATTN_BWD");
-  const bool use_fused = bwd_env ? bwd_env[0] == 'f' : !a.drop.on();
+  bool fused_ok = false;
+  if (!fused_can_run(d, st, &fused_ok)) return set_error(ADT_EHIP, "adt_attn_bwd: device query failed");
+  const bool use_fused = wants_fused(d) && fused_ok;          // (see wants_fused / fused_can_run above)
   if (use_fused) {
     const size_t off = split_workspace_bytes(d);
     if (int rc = launch_attn_bwd_fused(d, a, static_cast<unsigned char*>(ws) + off, ws_bytes - off, st)) return rc;

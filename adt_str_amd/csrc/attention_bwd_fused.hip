@@ -20,8 +20,12 @@
 //   R1), the last one scales, rounds and stores dQ.  The order is fixed, so the result is bitwise reproducible; no float atomics.
 //
 // Workgroups take their (batch, head, key block) from the XCD group's ticket counter (the persistent GEMMs' counters), in logical
-// order: a workgroup only ever waits for a LOWER ticket of its own counter (or for the end of the previous counter's range), i.e.
-// for a workgroup that is already running or finished -- no assumption about dispatch order, and spins are bounded.
+// order, so the nkb key blocks of a head hold CONSECUTIVE tickets of one counter.  The fan-in makes key block jr % nkb wait for the tiles of
+// all the head's other key blocks -- lower AND higher tickets -- so progress needs the head's nkb workgroups resident together: with the
+// lowest unfinished head's workgroups always the first to be dispatched, that holds whenever nkb <= the workgroups one XCD group can hold
+// (one per CU).  The launcher's caller (attention.hip fused_can_run) only takes this path for nkb <= half of that, and never under stream
+// capture; a wave that still waits 2^24 polls gives up, counts itself in the word behind the flags, and ADT_ATTN_BWD_CHECK=1 (the tests)
+// turns that count into ADT_EHIP instead of a silently incomplete dQ.
 // delta = rowsum(O * dO) and -lse / scale are prepared per query by a small kernel in front (attn_bwd_stats_kernel).
 #include <type_traits>
 
@@ -41,12 +45,14 @@ constexpr int kFbOffS = kFbOffT + 2 * kFbTile;      // per slice -lse / scale [3
 constexpr int kFbOffStash = kFbOffS + 2 * 256;      // running dQ^T sum of the slice this workgroup is reducing (4 KiB per wave)
 constexpr int kFbOffLand = kFbOffStash + 4 * 4096;  // landing zone of the key block tile that is added next (4 KiB per wave, LDS-DMA)
 constexpr int kFbOffFlag = kFbOffLand + 4 * 4096;
-constexpr int kFbLds = kFbOffFlag + 16;             // 147,984 B
+constexpr int kFbOffBits = kFbOffFlag + 16;         // keep bits of the slice (kDrop == 2): per ring slot 4 waves x 256 B (lane l < 32: the word of key l of the
+                                                    // wave's block 0, l >= 32: of key l - 32 of block 1)
+constexpr int kFbLds = kFbOffBits + 2 * 1024;       // 150,032 B
 constexpr unsigned kFbSpinLimit = 1u << 24;         // polls of ~0.3 us each before a wave gives up (and reports it)
 
 struct FusedArgs {
   AttnArgs a;
-  const float* stats;                 // [B*H][ns][2][32]: -lse / scale of the slice's queries, then -delta
+  const float* stats;                 // [B*H][ns][2][32]: nl of the slice's queries, then nd (attn_bwd_stats_kernel)
   float* part;                        // [B*H][ns][nkb][4 waves][1024]: every key block's dQ^T tile of every slice (nkb > 1)
   unsigned* flags;                    // [B*H][ns][nkb][4 waves] + 4 words: [0] of the tail = number of waves that gave up waiting
   unsigned* sched; unsigned sched_total[8];
@@ -55,7 +61,10 @@ struct FusedArgs {
   int dbg;                            // timing experiments only (ADT_FB_DBG): 1 no hand-off, 2 no dQ product, 4 no dV / dK products, 8 no S / dP chains
 };
 
-// {-lse / scale, -delta} per (batch, head, query), queries padded to whole slices ({-1e30, 0}: P = 0 there)
+// Per (batch, head, query), queries padded to whole slices ({-1e30, 0}: P = 0 there):
+//   nl = -lse / scale [+ log2(1 / (1 - p)) / (scale log2 e) with dropout]: the INITIAL ACCUMULATOR of the score chain, so that
+//        P [/ (1 - p)] = 2^((S + nl) scale log2 e) needs no per-element subtraction (and no per-element keep scale);
+//   nd = -delta [x (1 - p) with dropout]:                 dS = P_dropped dP + (P / (1 - p)) nd  (= P (dP keep / (1 - p) - delta)).
 __global__ __launch_bounds__(256) void attn_bwd_stats_kernel(AttnArgs a, float* __restrict__ stats, int ns) {
   const int tid = threadIdx.x, c = tid & 15;
   const int sqp = ns * kFbSlice;
@@ -77,8 +86,8 @@ __global__ __launch_bounds__(256) void attn_bwd_stats_kernel(AttnArgs a, float* 
       s = fmaf(__uint_as_float(ow[e] & 0xffff0000u), __uint_as_float(gw[e] & 0xffff0000u), s);
     }
     s = quarter_sum(s);
-    nl = -a.lse[(static_cast<long>(b) * a.H + head) * a.Sq + q] / a.scale;
-    nd = -s;
+    nl = (-a.lse[(static_cast<long>(b) * a.H + head) * a.Sq + q] * kLog2e + (a.drop.on() ? __log2f(a.drop.inv_keep) : 0.f)) / (a.scale * kLog2e);
+    nd = a.drop.on() ? -s / a.drop.inv_keep : -s;
   }
   if (c == 0) {                                                    // per slice of 32 queries: [nl x 32][nd x 32]
     float* sl = stats + ((static_cast<long>(b) * a.H + head) * sqp + (q & ~31)) * 2 + (q & 31);
@@ -119,13 +128,22 @@ __device__ __forceinline__ void mfma_acc(f32x16& acc, const bf16x8& x, const bf1
 __device__ __forceinline__ void mfma_vgpr(f32x16& acc, const bf16x8& x, const bf16x8& y) {
   asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+v"(acc) : "v"(x), "v"(y));
 }
+// first product of a chain: the accumulator starts from the inline constant 0 -- no sixteen v_mov per chain, no write -> SrcC wait states
+__device__ __forceinline__ void mfma_vgpr0(f32x16& acc, const bf16x8& x, const bf16x8& y) {
+  asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, 0" : "=&v"(acc) : "v"(x), "v"(y));
+}
 // (the accumulators go through the statements as operands: that is what keeps the compiler's own reads / writes of them on the right side)
 __device__ __forceinline__ void mfma_settle(f32x16& x, f32x16& y) { asm volatile("s_nop 15\n\ts_nop 3" : "+v"(x), "+v"(y)); }
 __device__ __forceinline__ void mfma_settle(f32x16& x) { asm volatile("s_nop 15\n\ts_nop 3" : "+v"(x)); }
 __device__ __forceinline__ void mfma_srcc_ready(f32x16& x, f32x16& y) { asm volatile("s_nop 3" : "+v"(x), "+v"(y)); }
 __device__ __forceinline__ void mfma_srcc_ready(f32x16& x) { asm volatile("s_nop 3" : "+v"(x)); }
 
-template <bool kDrop, int kDbg>
+// kDrop: 0 no dropout; 1 the keep decisions are re-made from the hash (dropout.h); 2 they are read back as the bits the forward left
+// (AttnArgs::keep_bits: per 32-query slice and 32-key block one 32-bit word per key, bit q = keep(query q of the slice, key) -- the forward's
+// compare results as they stand in its scalar registers, see attn_common.h keep_bits_*): two vector instructions per element instead of
+// a hash per two elements plus the scalar-register mask traffic, which is what dropout cost this kernel (+65 % VALU, +100 % SALU).
+typedef __bf16 bf16x2c __attribute__((ext_vector_type(2)));
+template <int kDrop, int kDbg>
 __global__ __launch_bounds__(kFbThreads, 1) void attn_bwd_fused_kernel(FusedArgs fa) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const AttnArgs& a = fa.a;
@@ -159,6 +177,8 @@ __global__ __launch_bounds__(kFbThreads, 1) void attn_bwd_fused_kernel(FusedArgs
   const unsigned short* kb_ = a.k + static_cast<long>(b) * a.Sk * a.ldk + head * kDh;
   const unsigned short* vb = a.v + static_cast<long>(b) * a.Sk * a.ldv + head * kDh;
   const float* stat_g = fa.stats + static_cast<long>(bh) * ns * kFbSlice * 2;
+  // keep words of (this head, slice 0, this wave's first 32-key block)
+  const unsigned* bits_g = kDrop == 2 ? a.keep_bits + ((static_cast<long>(bh) * a.bits_nq) * a.bits_nk + (kb * (kFbKeys / 32) + 2 * wave)) * 32 : nullptr;
   const int klen = a.key_len ? __builtin_amdgcn_readfirstlane(a.key_len[b]) : a.Sk;      // (a loaded value is "divergent" to the compiler: make it scalar)
   const float sl2 = a.scale * kLog2e;
   const bool key_mask = a.causal || key0 + kFbKeys > klen || key0 + kFbKeys > a.Sk;      // block-uniform, in a scalar register
@@ -195,6 +215,12 @@ __global__ __launch_bounds__(kFbThreads, 1) void attn_bwd_fused_kernel(FusedArgs
     if (wave == 3)                                                // 64 lanes x 4 bytes = the slice's 32 x {nl, nd}
       __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(stat_g + j * kFbSlice * 2 + lane_o),
                                        (__attribute__((address_space(3))) void*)(smem + kFbOffS + (j & 1) * 256), 4, 0, 0);
+    if (kDrop == 2) {                                             // the keep words of this wave's two key blocks: lane = (block, key)
+      const int key = lane_o & 31;
+      const unsigned* src = bits_g + (static_cast<long>(j) * a.bits_nk + (lane_o >> 5)) * 32 + keep_bits_word(key);
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                       (__attribute__((address_space(3))) void*)(smem + kFbOffBits + (j & 1) * 1024 + wave * 256), 4, 0, 0);
+    }
   };
   issue_slice(0);
 
@@ -355,8 +381,6 @@ __global__ __launch_bounds__(kFbThreads, 1) void attn_bwd_fused_kernel(FusedArgs
   // ~100 cycles for the previous one on the same VGPR accumulator).  ADT_DQ_BEGIN / ADT_DQ_STEP(0..15) / ADT_DQ_END.
 #define ADT_DQ_BEGIN                                                                              \
   f32x16 dq2;                                                                                     \
-  _Pragma("unroll") for (int i = 0; i < 16; ++i) { dq[i] = 0.f; dq2[i] = 0.f; }                   \
-  mfma_srcc_ready(dq, dq2);                                                                       \
   const unsigned ka_a = trbase ^ static_cast<unsigned>(64 * wave), xb_a = xbase + static_cast<unsigned>(kFbOffX); \
   TrFrag ka[4], xb[4];                                                                            \
   ADT_TR2(ka[0], ka_a, 0);                                                                        \
@@ -378,7 +402,9 @@ __global__ __launch_bounds__(kFbThreads, 1) void attn_bwd_fused_kernel(FusedArgs
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                                            \
   }                                                                                               \
   __builtin_amdgcn_sched_barrier(0);                                                              \
-  if ((KK) & 1) mfma_vgpr(dq2, tr_get(ka[(KK) & 3]), tr_get(xb[(KK) & 3]));                       \
+  if ((KK) == 0) mfma_vgpr0(dq, tr_get(ka[0]), tr_get(xb[0]));                                    \
+  else if ((KK) == 1) mfma_vgpr0(dq2, tr_get(ka[1]), tr_get(xb[1]));                              \
+  else if ((KK) & 1) mfma_vgpr(dq2, tr_get(ka[(KK) & 3]), tr_get(xb[(KK) & 3]));                  \
   else mfma_vgpr(dq, tr_get(ka[(KK) & 3]), tr_get(xb[(KK) & 3]));                                 \
   __builtin_amdgcn_sched_barrier(0);
 #define ADT_DQ_END                                                                                \
@@ -405,7 +431,7 @@ __global__ __launch_bounds__(kFbThreads, 1) void attn_bwd_fused_kernel(FusedArgs
   };
 #pragma unroll
   for (int e = 0; e < 16; ++e) km0[e] = 0;
-  if (kDrop) {
+  if (kDrop == 1) {
 #pragma unroll
     for (int e = 0; e < 8; ++e) masks_from_hash(e, slice_hash(0, 0, e), km0);
   }
@@ -436,7 +462,7 @@ __global__ __launch_bounds__(kFbThreads, 1) void attn_bwd_fused_kernel(FusedArgs
     // sched_barrier(0) pins the interleave: one pair of MFMAs, then one pair of elements' arithmetic (or one hash).
     f32x16 st0, dp0, st1, dp1;
     unsigned hp0[8], hs0[8], hp1[8], hs1[8];
-    f32x4 ndv[4];
+    f32x4 ndv[4];                                                 // the slice's row constants nd of this lane's 16 query rows
     bf16x8 fq[3], fd[3], fk[3];                                   // operand ring of the chains: two k-steps ahead
     const unsigned tq_a = rowbase + slot;
     const unsigned kr_a0 = rowbase + static_cast<unsigned>((64 * wave) * 256);
@@ -478,48 +504,66 @@ __global__ __launch_bounds__(kFbThreads, 1) void attn_bwd_fused_kernel(FusedArgs
     const float pad2_0 = ki0 >= klen ? a.mask_value * kLog2e : 0.f, pad2_1 = ki1 >= klen ? a.mask_value * kLog2e : 0.f;
     const float kval0 = ki0 < a.Sk ? 1.f : 0.f, kval1 = ki1 < a.Sk ? 1.f : 0.f;
     const int qrel0 = ki0 - j * kFbSlice, qrel1 = qrel0 + 32;
-    auto arith_pair = [&](int m, const f32x16& st, const f32x16& dp, const uint64_t (&km)[16], float pad2, float kval, int qrel, unsigned (&hp)[8],
-                          unsigned (&hs)[8]) {
-      float pv[2];
-      if (kMasked) {                                             // compile-time: interior key blocks take the two-instruction form
-#pragma unroll
-        for (int e = 0; e < 2; ++e) {
-          const int i = 2 * m + e;
-          const float madd = pad2 + (acc_row(i, h) < qrel ? cau2 : 0.f);
-          pv[e] = __builtin_amdgcn_exp2f(fmaf(st[i], sl2, madd)) * kval;
-        }
+    // kDrop == 2: wb = the lane's keep word of the block, shifted right by 4 h (so that the bit of accumulator register i sits at
+    // position acc_row(i, 0)); v_bfe_i32 spreads the bit over the register, an AND with 1 / (1 - p) gives the keep scale
+    unsigned wb0 = 0, wb1 = 0;
+    // Two elements per call, on register PAIRS (v_pk_fma_f32 / v_pk_mul_f32 / v_pk_add_f32: accumulator registers 2 m, 2 m + 1 are an
+    // aligned pair, and so are their row constants): one wave per SIMD issues a vector instruction every ~5 cycles whatever it is
+    // (tools/probe/probe_mfma_valu), so what counts is the NUMBER of instructions beside the products -- per pair 7 without dropout
+    // (10 before), 11 with the keep bits.  P arrives scaled by 1 / (1 - p) (folded into the chain's initial accumulator nl), the keep decision is an AND (bits) or a
+    // select (hash) on it, and dS = P_dropped dP + P' nd' with nd' = -delta (1 - p) -- no separate keep-scale product.
+    auto arith_pair = [&](int m, const f32x16& st, const f32x16& dp, const uint64_t (&km)[16], unsigned wb, float pad2, float kval, int qrel,
+                          unsigned (&hp)[8], unsigned (&hs)[8]) {
+      const int i0 = 2 * m, g = i0 >> 2, c0 = i0 & 3;
+      const f32x2 s2 = {st[i0], st[i0 + 1]}, d2 = {dp[i0], dp[i0 + 1]};
+      const f32x2 nd2 = {ndv[g][c0], ndv[g][c0 + 1]};
+      f32x2 x;
+      if (kMasked) {                                             // compile-time: interior key blocks take the short form
+        const f32x2 madd = {pad2 + (acc_row(i0, h) < qrel ? cau2 : 0.f), pad2 + (acc_row(i0 + 1, h) < qrel ? cau2 : 0.f)};
+        x = s2 * sl2 + madd;
       } else {
-#pragma unroll
-        for (int e = 0; e < 2; ++e) pv[e] = __builtin_amdgcn_exp2f(st[2 * m + e] * sl2);
+        x = s2 * sl2;
       }
-      float pd[2], ds[2];
-#pragma unroll
-      for (int e = 0; e < 2; ++e) {
-        const int i = 2 * m + e;
-        const float ndi = ndv[i >> 2][i & 3];
-        if (kDrop) {
-          float ks;
-          asm("v_cndmask_b32_e64 %0, 0, %1, %2" : "=v"(ks) : "v"(a.drop.inv_keep), "s"(km[i]));
-          pd[e] = pv[e] * ks;
-          ds[e] = pv[e] * fmaf(dp[i], ks, ndi);
-        } else {
-          pd[e] = pv[e];
-          ds[e] = pv[e] * (dp[i] + ndi);
+      f32x2 pv = {__builtin_amdgcn_exp2f(x[0]), __builtin_amdgcn_exp2f(x[1])};
+      if (kMasked) pv = pv * kval;
+      f32x2 pd, ds;
+      if (kDrop == 0) {
+        pd = pv;
+        ds = pv * (d2 + nd2);
+      } else {
+        if (kDrop == 1) {
+          f32x2 k01;                                             // (selects of a constant: asm must not consume v_exp_f32 results directly, see below)
+          asm("v_cndmask_b32_e64 %0, 0, 1.0, %1" : "=v"(k01[0]) : "s"(km[i0]));
+          asm("v_cndmask_b32_e64 %0, 0, 1.0, %1" : "=v"(k01[1]) : "s"(km[i0 + 1]));
+          pd = pv * k01;
+        } else {                                                 // bit acc_row(i, 0) of the lane's (shifted) keep word, spread over the register
+          // (v_bfe_i32 as asm: given the builtin the compiler turns bit test + AND into v_and + v_cmp + v_cndmask through scalar register
+          // pairs -- three instructions and thirty-two masks to keep; the AND stays compiler-visible because its other input comes
+          // straight from v_exp_f32, a hazard the recogniser must see)
+          unsigned t0, t1;
+          asm("v_bfe_i32 %0, %1, %2, 1" : "=v"(t0) : "v"(wb), "n"(c0 + 8 * g));
+          asm("v_bfe_i32 %0, %1, %2, 1" : "=v"(t1) : "v"(wb), "n"(c0 + 8 * g + 1));
+          pd[0] = __uint_as_float(__float_as_uint(pv[0]) & t0);
+          pd[1] = __uint_as_float(__float_as_uint(pv[1]) & t1);
         }
+        ds = pd * d2 + pv * nd2;
       }
-      hp[m] = pack2(pd[0], pd[1]);
+      // (without dropout P comes straight from v_exp_f32: the compiler-visible conversion there, not attn_common.h's asm pack2 -- an asm
+      // instruction gets none of the wait states a transcendental's consumer needs, and it read the exponent instead of the power)
+      if (kDrop == 0) hp[m] = __builtin_bit_cast(unsigned, __builtin_convertvector(pd, bf16x2c));
+      else hp[m] = pack2(pd[0], pd[1]);
       hs[m] = pack2(ds[0], ds[1]);
     };
     // block 1, elements 2 t, 2 t + 1, 2 t + 8, 2 t + 9: their keep masks come from two hashes made right here (four scalar register pairs
     // live at a time instead of thirty-two), then two arithmetic pairs
     auto arith_quad1 = [&](int t) {
       uint64_t km1[16];                                          // (only entries 2 t, 2 t + 1, 2 t + 8, 2 t + 9 are made and read)
-      if (kDrop) {
+      if (kDrop == 1) {
         masks_from_hash(2 * t, hw[2 * t], km1);
         masks_from_hash(2 * t + 1, hw[2 * t + 1], km1);
       }
-      arith_pair(t, st1, dp1, km1, pad2_1, kval1, qrel1, hp1, hs1);
-      arith_pair(t + 4, st1, dp1, km1, pad2_1, kval1, qrel1, hp1, hs1);
+      arith_pair(t, st1, dp1, km1, wb1, pad2_1, kval1, qrel1, hp1, hs1);
+      arith_pair(t + 4, st1, dp1, km1, wb1, pad2_1, kval1, qrel1, hp1, hs1);
     };
     auto write_ds = [&](int krow, const unsigned (&hs)[8]) {    // dS^T of a block to LDS for the dQ product
 #pragma unroll
@@ -532,45 +576,55 @@ __global__ __launch_bounds__(kFbThreads, 1) void attn_bwd_fused_kernel(FusedArgs
     ADT_STAMP(0)
     // ---- phase 1: S', dP of BOTH blocks in one interleaved chain: four accumulators take turns (a product waits ~100 cycles for the
     // previous one on the same VGPR accumulator, so two chains alone run at half rate), the Q / dO fragments are read once for both blocks
-#pragma unroll
-    for (int i = 0; i < 16; ++i) { st0[i] = 0.f; dp0[i] = 0.f; st1[i] = 0.f; dp1[i] = 0.f; }
     if (!(kDbg & 8)) {
       bf16x8 fk1[3];
 #define ADT_UNIT2(U, S)                                                                                                         \
       asm volatile("ds_read_b128 %0, %4\n\tds_read_b128 %1, %4 offset:8192\n\tds_read_b128 %2, %5\n\tds_read_b128 %3, %5 offset:8192" \
                    : "=&v"(fq[U]), "=&v"(fd[U]), "=&v"(fk[U]), "=&v"(fk1[U])                                                     \
                    : "v"(tq_a ^ static_cast<unsigned>(32 * (S))), "v"(kr_a0 ^ static_cast<unsigned>(32 * (S))) : "memory")
+      if (kDrop == 2) {                                           // (first: every counted wait below then covers them too)
+        const unsigned bw_a = smem_base + static_cast<unsigned>(kFbOffBits + (j & 1) * 1024 + wave * 256 + 4 * r);
+        asm volatile("ds_read_b32 %0, %2\n\tds_read_b32 %1, %2 offset:128" : "=&v"(wb0), "=&v"(wb1) : "v"(bw_a) : "memory");
+      }
 #pragma unroll
       for (int g = 0; g < 4; ++g) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(ndv[g]) : "v"(stat_a), "i"(128 + 32 * g) : "memory");
       {
-        f32x4 c[4];
+        // the score chains start from the row constant nl: read from LDS STRAIGHT INTO the accumulators' quarters, once per block (a
+        // ds_read_b128 per four registers instead of four v_mov); the dP chains start from the inline constant 0
+        f32x4 q0[4], q1[4];
 #pragma unroll
-        for (int g = 0; g < 4; ++g) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(c[g]) : "v"(stat_a), "i"(32 * g) : "memory");
-        ADT_UNIT2(0, 0);
-        asm volatile("s_waitcnt lgkmcnt(4)" ::: "memory");        // the eight statistics reads are back (in order)
-        ADT_UNIT2(1, 1); ADT_UNIT2(2, 2);
-#pragma unroll
-        for (int i = 0; i < 16; ++i) { st0[i] = c[i >> 2][i & 3]; st1[i] = c[i >> 2][i & 3]; }
-        mfma_srcc_ready(st0, dp0);
-        mfma_srcc_ready(st1, dp1);
+        for (int g = 0; g < 4; ++g)
+          asm volatile("ds_read_b128 %0, %2 offset:%3\n\tds_read_b128 %1, %2 offset:%3" : "=&v"(q0[g]), "=&v"(q1[g]) : "v"(stat_a), "i"(32 * g) : "memory");
+        ADT_UNIT2(0, 0); ADT_UNIT2(1, 1); ADT_UNIT2(2, 2);
+        st0 = __builtin_shufflevector(__builtin_shufflevector(q0[0], q0[1], 0, 1, 2, 3, 4, 5, 6, 7), __builtin_shufflevector(q0[2], q0[3], 0, 1, 2, 3, 4, 5, 6, 7),
+                                      0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 14, 15);
+        st1 = __builtin_shufflevector(__builtin_shufflevector(q1[0], q1[1], 0, 1, 2, 3, 4, 5, 6, 7), __builtin_shufflevector(q1[2], q1[3], 0, 1, 2, 3, 4, 5, 6, 7),
+                                      0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 14, 15);
       }
 #pragma unroll
       for (int s = 0; s < 8; ++s) {
-        if (s < 6) asm volatile("s_waitcnt lgkmcnt(8)" ::: "memory");
+        if (s < 6) asm volatile("s_waitcnt lgkmcnt(8)" ::: "memory");      // (in order: the statistics and keep words, read first, are back too)
         else if (s < 7) asm volatile("s_waitcnt lgkmcnt(4)" ::: "memory");
         else asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_sched_barrier(0);
-        mfma_vgpr(st0, fq[s % 3], fk[s % 3]);
-        mfma_vgpr(st1, fq[s % 3], fk1[s % 3]);
-        mfma_vgpr(dp0, fd[s % 3], vf[0][s]);
-        mfma_vgpr(dp1, fd[s % 3], vf[1][s]);
+        if (s == 0) {
+          mfma_vgpr(st0, fq[0], fk[0]);
+          mfma_vgpr(st1, fq[0], fk1[0]);
+          mfma_vgpr0(dp0, fd[0], vf[0][0]);
+          mfma_vgpr0(dp1, fd[0], vf[1][0]);
+        } else {
+          mfma_vgpr(st0, fq[s % 3], fk[s % 3]);
+          mfma_vgpr(st1, fq[s % 3], fk1[s % 3]);
+          mfma_vgpr(dp0, fd[s % 3], vf[0][s]);
+          mfma_vgpr(dp1, fd[s % 3], vf[1][s]);
+        }
         __builtin_amdgcn_sched_barrier(0);
         if (s + 3 < 8) {
           if (s % 3 == 0) ADT_UNIT2(0, s + 3);
           else if (s % 3 == 1) ADT_UNIT2(1, s + 3);
           else ADT_UNIT2(2, s + 3);
         }
-        if (kDrop) {
+        if (kDrop == 1) {
           hw[s] = slice_hash(j, 1, s);
           __builtin_amdgcn_sched_barrier(0);
         }
@@ -579,19 +633,22 @@ __global__ __launch_bounds__(kFbThreads, 1) void attn_bwd_fused_kernel(FusedArgs
       mfma_settle(st0, dp0);
       mfma_settle(st1, dp1);
       __builtin_amdgcn_sched_barrier(0);
+      if (kDrop == 2) {                                           // (behind the chain's lgkmcnt(0): the words have arrived)
+        wb0 >>= 4 * h;
+        wb1 >>= 4 * h;
+      }
       ADT_STAMP(1)
-    } else {
+    } else {                                                      // (experiment build: no S / dP chains)
 #pragma unroll
       for (int g = 0; g < 4; ++g) ndv[g] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int i = 0; i < 16; ++i) { st0[i] = 0.f; dp0[i] = 0.f; st1[i] = 0.f; dp1[i] = 0.f; }
     }
     // ---- phase 2: the arithmetic of block 0 beside the dQ product of the PREVIOUS slice (its dS^T image is complete since that slice's
     // barrier, and is overwritten only behind the barrier below)
     f32x16 dq;
     if (j > 0 && !(kDbg & 2)) {
       // (here a ring of two units and ONE accumulation chain: the arithmetic between the products hides both latencies, and registers are scarce)
-#pragma unroll
-      for (int i = 0; i < 16; ++i) dq[i] = 0.f;
-      mfma_srcc_ready(dq);
       const unsigned ka_a = trbase ^ static_cast<unsigned>(64 * wave), xb_a = xbase + static_cast<unsigned>(kFbOffX);
       TrFrag ka[2], xb[2];
       ADT_TR2(ka[0], ka_a, 0);
@@ -602,7 +659,8 @@ __global__ __launch_bounds__(kFbThreads, 1) void attn_bwd_fused_kernel(FusedArgs
       if ((KK) + 1 < 16) asm volatile("s_waitcnt lgkmcnt(4)" ::: "memory");                       \
       else asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                                     \
       __builtin_amdgcn_sched_barrier(0);                                                          \
-      mfma_vgpr(dq, tr_get(ka[(KK) & 1]), tr_get(xb[(KK) & 1]));                                  \
+      if ((KK) == 0) mfma_vgpr0(dq, tr_get(ka[0]), tr_get(xb[0]));                                \
+      else mfma_vgpr(dq, tr_get(ka[(KK) & 1]), tr_get(xb[(KK) & 1]));                             \
       __builtin_amdgcn_sched_barrier(0);                                                          \
       if ((KK) + 2 < 16) {                                                                        \
         ADT_TR2(ka[(KK) & 1], ka_a, ((KK) + 2) * 4096);                                           \
@@ -611,7 +669,7 @@ __global__ __launch_bounds__(kFbThreads, 1) void attn_bwd_fused_kernel(FusedArgs
 #define ADT_PH2(M)                                                                                \
       ADT_DQ2_STEP(2 * (M))                                                                       \
       ADT_DQ2_STEP(2 * (M) + 1)                                                                   \
-      arith_pair(M, st0, dp0, km0, pad2_0, kval0, qrel0, hp0, hs0);                               \
+      arith_pair(M, st0, dp0, km0, wb0, pad2_0, kval0, qrel0, hp0, hs0);                          \
       __builtin_amdgcn_sched_barrier(0);
       ADT_PH2(0) ADT_PH2(1) ADT_PH2(2) ADT_PH2(3) ADT_PH2(4) ADT_PH2(5) ADT_PH2(6) ADT_PH2(7)
 #undef ADT_PH2
@@ -621,7 +679,7 @@ __global__ __launch_bounds__(kFbThreads, 1) void attn_bwd_fused_kernel(FusedArgs
 #pragma unroll
       for (int i = 0; i < 16; ++i) dq[i] = 0.f;
 #pragma unroll
-      for (int m = 0; m < 8; ++m) arith_pair(m, st0, dp0, km0, pad2_0, kval0, qrel0, hp0, hs0);
+      for (int m = 0; m < 8; ++m) arith_pair(m, st0, dp0, km0, wb0, pad2_0, kval0, qrel0, hp0, hs0);
     }
     __builtin_amdgcn_sched_barrier(0);
     // the dS^T image is single-buffered: every wave must have finished the previous slice's dQ product (they have, long ago: this barrier
@@ -650,14 +708,14 @@ __global__ __launch_bounds__(kFbThreads, 1) void attn_bwd_fused_kernel(FusedArgs
         ADT_TR2(fo[db], trb ^ static_cast<unsigned>(64 * db), 8192 + 16 * 256);                                                 \
         ADT_TR2(fqq[db], trb ^ static_cast<unsigned>(64 * db), 16 * 256);                                                       \
         if ((WITH_ARITH) == 1) { arith_quad1(db); __builtin_amdgcn_sched_barrier(0); }                                          \
-        if ((WITH_ARITH) == 2 && kDrop) { masks_from_hash(db, slice_hash(j + 1, 0, db), km0); __builtin_amdgcn_sched_barrier(0); } \
+        if ((WITH_ARITH) == 2 && kDrop == 1) { masks_from_hash(db, slice_hash(j + 1, 0, db), km0); __builtin_amdgcn_sched_barrier(0); } \
       }                                                                                                                         \
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                                                                        \
       __builtin_amdgcn_sched_barrier(0);                                                                                        \
       _Pragma("unroll") for (int db = 0; db < 4; ++db) {                                                                        \
         mfma_acc(dv[BLK][db], tr_get(fo[db]), pf1.v);                                                                          \
         mfma_acc(dk[BLK][db], tr_get(fqq[db]), dsf1.v);                                                                        \
-        if ((WITH_ARITH) == 2 && kDrop) { __builtin_amdgcn_sched_barrier(0); masks_from_hash(4 + db, slice_hash(j + 1, 0, 4 + db), km0); __builtin_amdgcn_sched_barrier(0); } \
+        if ((WITH_ARITH) == 2 && kDrop == 1) { __builtin_amdgcn_sched_barrier(0); masks_from_hash(4 + db, slice_hash(j + 1, 0, 4 + db), km0); __builtin_amdgcn_sched_barrier(0); } \
       }                                                                                                                         \
     }
     if (!(kDbg & 4)) {
@@ -802,8 +860,9 @@ int launch_attn_bwd_fused(const adt_attn_desc* d, const AttnArgs& a, void* ws, s
 #endif
   if (lds_done_for != dev) {
 #define ADT_FB_ATTR(N)                                                                                                                      \
-    ADT_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(attn_bwd_fused_kernel<false, N>), hipFuncAttributeMaxDynamicSharedMemorySize, kFbLds)); \
-    ADT_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(attn_bwd_fused_kernel<true, N>), hipFuncAttributeMaxDynamicSharedMemorySize, kFbLds));
+    ADT_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(attn_bwd_fused_kernel<0, N>), hipFuncAttributeMaxDynamicSharedMemorySize, kFbLds)); \
+    ADT_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(attn_bwd_fused_kernel<1, N>), hipFuncAttributeMaxDynamicSharedMemorySize, kFbLds)); \
+    ADT_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(attn_bwd_fused_kernel<2, N>), hipFuncAttributeMaxDynamicSharedMemorySize, kFbLds));
     ADT_FB_DBGS(ADT_FB_ATTR)
 #undef ADT_FB_ATTR
     lds_done_for = dev;
@@ -834,13 +893,20 @@ int launch_attn_bwd_fused(const adt_attn_desc* d, const AttnArgs& a, void* ws, s
 #define ADT_FB_LAUNCH(N)                                                                                                                    \
   if (!launched && fa.dbg == N) {                                                                                                           \
     launched = true;                                                                                                                        \
-    if (a.drop.on()) hipLaunchKernelGGL((attn_bwd_fused_kernel<true, N>), dim3(static_cast<unsigned>(n_tiles)), dim3(kFbThreads), kFbLds, st, fa);   \
-    else hipLaunchKernelGGL((attn_bwd_fused_kernel<false, N>), dim3(static_cast<unsigned>(n_tiles)), dim3(kFbThreads), kFbLds, st, fa);     \
+    if (a.drop.on() && a.keep_bits) hipLaunchKernelGGL((attn_bwd_fused_kernel<2, N>), dim3(static_cast<unsigned>(n_tiles)), dim3(kFbThreads), kFbLds, st, fa); \
+    else if (a.drop.on()) hipLaunchKernelGGL((attn_bwd_fused_kernel<1, N>), dim3(static_cast<unsigned>(n_tiles)), dim3(kFbThreads), kFbLds, st, fa);   \
+    else hipLaunchKernelGGL((attn_bwd_fused_kernel<0, N>), dim3(static_cast<unsigned>(n_tiles)), dim3(kFbThreads), kFbLds, st, fa);         \
   }
   ADT_FB_DBGS(ADT_FB_LAUNCH)
 #undef ADT_FB_LAUNCH
   if (!launched) return set_error(ADT_EINVAL, "adt_attn_bwd: ADT_FB_DBG value not built (experiment build only)");
   ADT_HIP_TRY(hipGetLastError());
+  if (getenv("ADT_ATTN_BWD_CHECK")) {                               // tests / debugging: a wave that gave up waiting for a tile left dQ incomplete
+    unsigned gave_up = 0;
+    ADT_HIP_TRY(hipStreamSynchronize(st));
+    ADT_HIP_TRY(hipMemcpy(&gave_up, fa.flags + bh * ns * static_cast<size_t>(fa.nkb) * 4, sizeof(gave_up), hipMemcpyDeviceToHost));
+    if (gave_up) return set_error(ADT_EHIP, "adt_attn_bwd: waves of the one-kernel backward gave up waiting for a dQ tile (result incomplete)");
+  }
   return ADT_OK;
 }
 

@@ -75,8 +75,14 @@ __device__ unsigned long long g_fwd_stamps[32];
 // kWaves = 8: one workgroup of 256 queries per CU (two waves per SIMD): a K / V tile is fetched once for eight waves -- the LDS-DMA path
 // delivers ~33 B/clk per CU (the same bound as the GEMM's operand delivery), and a wave's DMA instruction costs it ~80 issue cycles.
 // kWaves = 4: 128 queries, two workgroups per CU: the shapes with at most 128 queries (decoder self- and cross-attention).
-template <bool kDrop, int kWaves>
+// kBits (dropout only): every keep decision also goes to AttnArgs::keep_bits for the backward (attn_common.h keep_bits_*).  The compare that
+// feeds the select IS the word the backward wants (a 64-bit lane mask in a scalar register pair), so it leaves by a scalar store:
+// s_store_dwordx4 of the two compares of a finish pair (gfx950 executes scalar stores -- tools/probe/probe_sstore.hip checks that and prices
+// one at ~7 instruction slots of its wave; the dirty lines leave the scalar cache at s_dcache_wb, before the wave ends).
+typedef unsigned u32x4s __attribute__((ext_vector_type(4)));
+template <bool kDrop, int kWaves, bool kBits = false>
 __global__ __launch_bounds__(64 * kWaves, 8 / kWaves) void attn_fwd2_kernel(AttnArgs a, int n_items) {
+  static_assert(kDrop || !kBits, "keep bits exist with dropout only");
   constexpr bool kPersist = kWaves == 8;   // one workgroup per CU walks its share of the (batch, head, query block) items
   constexpr int kQ = 32 * kWaves;          // queries per workgroup
   constexpr int kPc = 16 / kWaves;         // 1-KiB DMA pieces of a 16-KiB tile per wave
@@ -106,6 +112,7 @@ __global__ __launch_bounds__(64 * kWaves, 8 / kWaves) void attn_fwd2_kernel(Attn
   int b, head, qi, klen;
   const unsigned short *kg, *vg;
   unsigned pb2;
+  const unsigned* bits_row = nullptr;      // kBits: keep words of (this item's head, this wave's 32-query slice, key block 0)
   auto set_item = [&](const Item& it) __attribute__((always_inline)) {
     b = it.b; head = it.head;
     qi = it.q0 + wave * 32 + r;
@@ -114,6 +121,7 @@ __global__ __launch_bounds__(64 * kWaves, 8 / kWaves) void attn_fwd2_kernel(Attn
     klen = __builtin_amdgcn_readfirstlane(a.key_len ? a.key_len[b] : a.Sk);
     // dropout index of (row, key) is row * Sk2 + key (Sk2 = Sk rounded up to even; dropout.h): pair = row * Sk2 / 2 + key / 2
     pb2 = static_cast<unsigned>(((static_cast<uint64_t>(b) * a.H + head) * a.Sq + qi) * ((a.Sk + 1) >> 1)) + 2u * h;
+    if (kBits) bits_row = a.keep_bits + ((static_cast<long>(b) * a.H + head) * a.bits_nq + ((it.q0 >> 5) + wave)) * a.bits_nk * 32;
   };
   int item = blockIdx.x;
   set_item(item_of(item));
@@ -232,13 +240,19 @@ __global__ __launch_bounds__(64 * kWaves, 8 / kWaves) void attn_fwd2_kernel(Attn
   };
   // finish(g), pair s: two probabilities (left in place of the scores: phase B adds them up, it has the issue slots), dropout, one packed
   // bf16 pair of the P^T operand
-  auto finish_pair = [&](f32x16& st, int s) __attribute__((always_inline)) {
+  auto finish_pair = [&](f32x16& st, int s, const unsigned* bits_blk) __attribute__((always_inline)) {      // bits_blk: the block's 32 keep words (kBits)
     float p0 = __builtin_amdgcn_exp2f(fmaf(st[2 * s], sl2, mneg)), p1 = __builtin_amdgcn_exp2f(fmaf(st[2 * s + 1], sl2, mneg));
     st[2 * s] = p0;
     st[2 * s + 1] = p1;
     if (kDrop) {
-      p0 = (hh[s] & 0xffffu) >= thr ? p0 : 0.f;
-      p1 = (hh[s] >> 16) >= thr ? p1 : 0.f;
+      const bool k0 = (hh[s] & 0xffffu) >= thr, k1 = (hh[s] >> 16) >= thr;
+      p0 = k0 ? p0 : 0.f;
+      p1 = k1 ? p1 : 0.f;
+      if (kBits) {                           // registers 2 s, 2 s + 1 of the block: words 4 s .. 4 s + 3
+        const unsigned long long m0 = __builtin_amdgcn_ballot_w64(k0), m1 = __builtin_amdgcn_ballot_w64(k1);
+        const u32x4s w = {static_cast<unsigned>(m0), static_cast<unsigned>(m0 >> 32), static_cast<unsigned>(m1), static_cast<unsigned>(m1 >> 32)};
+        asm volatile("s_store_dwordx4 %0, %1, %2" :: "s"(w), "s"(bits_blk), "i"(16 * s));
+      }
     }
     pf[s >> 2].u[s & 3] = pack2_c(p0, p1);
     pin(pf[s >> 2].u[s & 3]);
@@ -269,14 +283,15 @@ __global__ __launch_bounds__(64 * kWaves, 8 / kWaves) void attn_fwd2_kernel(Attn
   // The first operands of a phase are read during the last slices of the phase before it (kf[0..3] by phase B / block0, vpre by phase A
   // when no barrier lies between): the LDS round trip is not at the head of the MFMA chain.
   bf16x8 kf[8], vpre[4];
-  auto phase_a = [&](f32x16& sn, int koff_, f32x16& sc, int vnext) __attribute__((always_inline)) {      // vnext: LDS offset of the next phase B's V rows, -1: behind a barrier
+  auto phase_a = [&](f32x16& sn, int koff_, f32x16& sc, int vnext, int kblk) __attribute__((always_inline)) {      // vnext: LDS offset of the next phase B's V rows, -1: behind a barrier; kblk: 32-key block index of sc
+    const unsigned* bits_blk = kBits ? bits_row + kblk * 32 : nullptr;
 #pragma unroll
     for (int i = 0; i < 16; ++i) sn[i] = 0.f;
 #pragma unroll
     for (int s = 0; s < 8; ++s) {
       if (s < 4) kf[s + 4] = k_frag(s + 4, koff_);
       if (s >= 6 && vnext >= 0) { vpre[2 * (s - 6)] = v_frag(2 * (s - 6), vnext); vpre[2 * (s - 6) + 1] = v_frag(2 * (s - 6) + 1, vnext); }
-      finish_pair(sc, s);
+      finish_pair(sc, s, bits_blk);
       sn = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf[s], qf[s], sn, 0, 0, 0);
       ADT_FENCE();
     }
@@ -340,7 +355,7 @@ __global__ __launch_bounds__(64 * kWaves, 8 / kWaves) void attn_fwd2_kernel(Attn
     constexpr int kK = kP * 2 * kAttnTileBytes, kV = kK + kAttnTileBytes, kKn = (kP ^ 1) * 2 * kAttnTileBytes;
     const int tile0 = t * kRowsPerTile;
     ADT_STAMP(0);
-    phase_a(s1, kK + 32 * 256, s0, -1);
+    phase_a(s1, kK + 32 * 256, s0, -1, 2 * t);
     ADT_STAMP(1);
     // (tile 0: K(1) and V(0) were waited for before the item started; what is still in flight is the previous item's output)
     if (t > 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -358,7 +373,7 @@ __global__ __launch_bounds__(64 * kWaves, 8 / kWaves) void attn_fwd2_kernel(Attn
     ADT_STAMP(4);
     rescale();
     ADT_STAMP(5);
-    phase_a(s0, kKn, s1, kV + 32 * 256);
+    phase_a(s0, kKn, s1, kV + 32 * 256, 2 * t + 1);
     ADT_STAMP(6);
     phase_b(kV + 32 * 256, true, kKn + 32 * 256, s1, s0, tile0 + kRowsPerTile, masked_tile(t + 1), q_hook);
     ADT_STAMP(7);
@@ -366,9 +381,10 @@ __global__ __launch_bounds__(64 * kWaves, 8 / kWaves) void attn_fwd2_kernel(Attn
   };
   // the last tile: no later tile to fetch or to start, and no second block when at most 32 of its keys exist (986 keys: block 31 of 32).
   // Run-time buffer offsets (an add per LDS read), once per workgroup.
-  auto finish_only = [&](f32x16& sc) __attribute__((always_inline)) {
+  auto finish_only = [&](f32x16& sc, int kblk) __attribute__((always_inline)) {
+    const unsigned* bits_blk = kBits ? bits_row + kblk * 32 : nullptr;
 #pragma unroll
-    for (int s = 0; s < 8; ++s) finish_pair(sc, s);
+    for (int s = 0; s < 8; ++s) finish_pair(sc, s, bits_blk);
   };
   auto last_tile = [&](int t) __attribute__((always_inline)) {
     int kK = (t & 1) * 2 * kAttnTileBytes;
@@ -376,8 +392,8 @@ __global__ __launch_bounds__(64 * kWaves, 8 / kWaves) void attn_fwd2_kernel(Attn
     const int kV = kK + kAttnTileBytes;
     const int tile0 = t * kRowsPerTile;
     const bool second = a.Sk - tile0 > 32;               // block-uniform
-    if (second) phase_a(s1, kK + 32 * 256, s0, -1);
-    else finish_only(s0);
+    if (second) phase_a(s1, kK + 32 * 256, s0, -1, 2 * t);
+    else finish_only(s0, 2 * t);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
     // With an even number of tiles this one sits in buffers 1: K(t) is dead behind the barrier and buffers 0 have been for a tile, so the
@@ -390,7 +406,7 @@ __global__ __launch_bounds__(64 * kWaves, 8 / kWaves) void attn_fwd2_kernel(Attn
     phase_b(kV, false, -1, s0, s1, tile0 + 32, masked_tile(t), next_hook);      // (without a second block: its maximum of s1 is not used)
     if (second) {
       rescale();
-      finish_only(s1);
+      finish_only(s1, 2 * t + 1);
       phase_b(kV + 32 * 256, false, -1, s1, s0, tile0 + kRowsPerTile, false, [](int) {});
     }
   };
@@ -435,6 +451,7 @@ __global__ __launch_bounds__(64 * kWaves, 8 / kWaves) void attn_fwd2_kernel(Attn
     item = next_id;
     set_item(nxt);
   }
+  if (kBits) asm volatile("s_waitcnt lgkmcnt(0)\n\ts_dcache_wb" ::: "memory");      // the keep words leave the scalar cache
 }
 
 int launch_attn_fwd2(const AttnArgs& a, hipStream_t st) {
@@ -447,6 +464,8 @@ int launch_attn_fwd2(const AttnArgs& a, hipStream_t st) {
     ADT_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(attn_fwd2_kernel<true, 4>), hipFuncAttributeMaxDynamicSharedMemorySize, lds));
     ADT_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(attn_fwd2_kernel<false, 8>), hipFuncAttributeMaxDynamicSharedMemorySize, lds8));
     ADT_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(attn_fwd2_kernel<true, 8>), hipFuncAttributeMaxDynamicSharedMemorySize, lds8));
+    ADT_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(attn_fwd2_kernel<true, 4, true>), hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+    ADT_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(attn_fwd2_kernel<true, 8, true>), hipFuncAttributeMaxDynamicSharedMemorySize, lds8));
     done_for = dev;
   }
   const char* wenv = getenv("ADT_ATTN_FWD_WAVES");        // A/B: 4 or 8 waves per workgroup whatever the shape; read on every call
@@ -457,11 +476,13 @@ int launch_attn_fwd2(const AttnArgs& a, hipStream_t st) {
     int n_cu = 0;
     if (int rc = device_cu_count(&n_cu)) return rc;
     const dim3 grid(static_cast<unsigned>(n_items < n_cu ? n_items : n_cu));          // persistent: one workgroup per CU
-    if (a.drop.on()) hipLaunchKernelGGL((attn_fwd2_kernel<true, 8>), grid, dim3(512), lds8, st, a, n_items);
+    if (a.drop.on() && a.keep_bits) hipLaunchKernelGGL((attn_fwd2_kernel<true, 8, true>), grid, dim3(512), lds8, st, a, n_items);
+    else if (a.drop.on()) hipLaunchKernelGGL((attn_fwd2_kernel<true, 8>), grid, dim3(512), lds8, st, a, n_items);
     else hipLaunchKernelGGL((attn_fwd2_kernel<false, 8>), grid, dim3(512), lds8, st, a, n_items);
   } else {
     const dim3 grid(static_cast<unsigned>(n_items));
-    if (a.drop.on()) hipLaunchKernelGGL((attn_fwd2_kernel<true, 4>), grid, dim3(256), lds, st, a, n_items);
+    if (a.drop.on() && a.keep_bits) hipLaunchKernelGGL((attn_fwd2_kernel<true, 4, true>), grid, dim3(256), lds, st, a, n_items);
+    else if (a.drop.on()) hipLaunchKernelGGL((attn_fwd2_kernel<true, 4>), grid, dim3(256), lds, st, a, n_items);
     else hipLaunchKernelGGL((attn_fwd2_kernel<false, 4>), grid, dim3(256), lds, st, a, n_items);
   }
   ADT_HIP_TRY(hipGetLastError());

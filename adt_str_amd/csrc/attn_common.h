@@ -219,7 +219,21 @@ struct AttnArgs {
   float scale, mask_value; int causal; const int* key_len;
   Drop drop;
   float* cs_dq;        // column sums of dQ per (batch, 128-query block): [B * ceil(Sq/128)][H*128], null: off
+  unsigned* keep_bits; // dropout: the forward's keep decisions as bits (see keep_bits_* below), null: off
+  int bits_nq, bits_nk;   // 32-query slices / 32-key blocks per (batch, head) in keep_bits
 };
+
+// ---- keep bits: the dropout decisions of the forward, handed to the one-kernel backward instead of being hashed again there.
+// The forward holds S^T with the QUERY on the lane, so the compare that decides accumulator register i of a 32-key block is, as a
+// 64-bit lane mask, exactly { bits 0..31: queries 0..31 of the wave's slice for key acc_row(i, 0); bits 32..63: the same queries for key
+// acc_row(i, 1) } -- one 32-bit word per key with a bit per query, which is what the backward (KEY on the lane) wants in a vector register.
+// Layout: [batch * head][32-query slice][32-key block][32 words], word 2 i + h <-> key acc_row(i, h) of the block; the forward stores the
+// compare results from its scalar registers (s_store_dwordx4: 16 bytes = registers 2 s, 2 s + 1), the backward's lane for key r loads word
+// keep_bits_word(r) and tests bit q.  Slices / blocks are padded to whole 256s of queries / keys so that neither kernel needs a bounds test;
+// blocks past the key range and slices past the query range hold garbage that is never used (their probabilities are zero).
+__host__ __device__ __forceinline__ int keep_bits_word(int key) { return 2 * ((key & 3) + 4 * (key >> 3)) + ((key >> 2) & 1); }
+inline int keep_bits_nq(int q_len) { return ((q_len + 255) / 256) * 8; }
+inline int keep_bits_nk(int k_len) { return ((k_len + 255) / 256) * 8; }
 
 // Tile coordinates of this workgroup.  The grids are 1-D: nx tiles (query or key blocks) per (batch, head) times ny = B * H.
 // Workgroups are dealt round-robin over the 8 XCDs (blocks b and b + 8 share one), so ids are renumbered to give every XCD a

@@ -6,6 +6,7 @@ on PyTorch's current HIP stream.  No autograd here (see ``adt_str_amd.network``)
 from __future__ import annotations
 
 import ctypes as C
+import os
 from typing import Optional
 
 import torch
@@ -449,9 +450,20 @@ def _attn_desc(B, H, Sq, Sk, q, k, v, o, scale, causal, key_len, mask_value, dro
     return d
 
 
-def attn_fwd(q, k, v, B, H, Sq, Sk, scale, causal=False, key_len=None, mask_value=-1e4, out=None, drop=None, head_dim=128):
+class AttnSaved:
+    """What ``attn_fwd(save_bits=True)`` hands to ``attn_bwd`` in place of the bare ``lse``: the log-sum-exp rows and the forward's dropout
+    keep decisions as bits (``adt_attn_desc.keep_bits``), so that the backward takes the one-kernel path and hashes no mask again."""
+    __slots__ = ("lse", "bits")
+
+    def __init__(self, lse, bits):
+        self.lse, self.bits = lse, bits
+
+
+def attn_fwd(q, k, v, B, H, Sq, Sk, scale, causal=False, key_len=None, mask_value=-1e4, out=None, drop=None, head_dim=128, save_bits=False):
     """q [B*Sq, >=H*128], k/v [B*Sk, >=H*128] bf16 (row-strided views allowed) -> (o [B*Sq, H*128] bf16, lse [B,H,Sq] fp32).
-    fp32 tensors take the fp32-operand path (``head_dim`` 16 / 32 / 64 / 128 there; the bf16 kernels are built for 128)."""
+    fp32 tensors take the fp32-operand path (``head_dim`` 16 / 32 / 64 / 128 there; the bf16 kernels are built for 128).
+    ``save_bits`` (bf16 path with dropout and more than 256 keys, or ``"force"``: any key count; ``ADT_ATTN_NO_BITS=1`` switches it off for
+    A/B runs): the second result is an ``AttnSaved`` carrying the keep bits for ``attn_bwd``."""
     f32 = q.dtype == torch.float32
     for t in (q, k, v):
         assert t.dtype == q.dtype and t.dtype in (torch.bfloat16, torch.float32) and t.dim() == 2 and t.stride(1) == 1
@@ -459,9 +471,14 @@ def attn_fwd(q, k, v, B, H, Sq, Sk, scale, causal=False, key_len=None, mask_valu
         out = torch.empty((B * Sq, H * head_dim), dtype=q.dtype, device=q.device)
     lse = torch.empty((B, H, Sq), dtype=torch.float32, device=q.device)
     d = _attn_desc(B, H, Sq, Sk, q, k, v, out, scale, causal, key_len, mask_value, drop, head_dim)
+    bits = None
+    # (up to 256 keys -- one key block, the decoder's causal self-attention -- the two-kernel backward is as fast and needs no bits)
+    if save_bits and not f32 and drop is not None and drop[0] > 0.0 and Sq > 1 and (Sk > 256 or save_bits == "force") and not os.environ.get("ADT_ATTN_NO_BITS"):
+        bits = torch.empty(_ffi.load().adt_attn_keep_bits_bytes(C.byref(d)), dtype=torch.uint8, device=q.device)
+        d.keep_bits = _ffi.dptr(bits)
     _ffi.call("adt_attn_fwd_f32" if f32 else "adt_attn_fwd", C.byref(d), _ffi.dptr(q), _ffi.dptr(k), _ffi.dptr(v), _ffi.dptr(out), _ffi.dptr(lse),
               _ffi.current_stream())
-    return out, lse
+    return out, (AttnSaved(lse, bits) if bits is not None else lse)
 
 
 def attn_bwd(q, k, v, o, dout, lse, dq, dk, dv, B, H, Sq, Sk, scale, causal=False, key_len=None, mask_value=-1e4, drop=None,
@@ -471,6 +488,9 @@ def attn_bwd(q, k, v, o, dout, lse, dq, dk, dv, B, H, Sq, Sk, scale, causal=Fals
     assert dq.stride(0) == q.stride(0) and dk.stride(0) == k.stride(0) and dv.stride(0) == v.stride(0)
     assert dout.stride(0) == o.stride(0)
     d = _attn_desc(B, H, Sq, Sk, q, k, v, o, scale, causal, key_len, mask_value, drop, head_dim)
+    if isinstance(lse, AttnSaved):
+        d.keep_bits = _ffi.dptr(lse.bits)
+        lse = lse.lse
     if q.dtype == torch.float32:                              # fp32-operand path; bias gradients by separate column sums
         nb = _ffi.load().adt_attn_bwd_f32_workspace_bytes(C.byref(d))
         ws = _workspace(nb, q.device)

@@ -324,7 +324,8 @@ class _Engine:
         for li, L in enumerate(self.enc):
             p = L["p"]
             qkv = K.gemm(x16, L["sa"].w16, bias=L["sa"].b)
-            attn, lse = K.attn_fwd(qkv[:, :d], qkv[:, d:2 * d], qkv[:, 2 * d:], B, H, S, S, self.scale, drop=self.D(p + ".attn"), head_dim=self.dh)
+            attn, lse = K.attn_fwd(qkv[:, :d], qkv[:, d:2 * d], qkv[:, 2 * d:], B, H, S, S, self.scale, drop=self.D(p + ".attn"), head_dim=self.dh,
+                                   save_bits=save is not None)
             y1 = K.gemm(attn, L["sa_o"].w16, bias=L["sa_o"].b, out_dtype=F32, drop=self.D(p + ".drop1"), **res)
             g1, b1 = self.P(p + ".norm1.weight"), self.P(p + ".norm1.bias")
             x1_32, x1_16, mean1, rstd1 = self._ln(y1, g1, b1, want32=not lean)
@@ -368,7 +369,7 @@ class _Engine:
             p = L["p"]
             qkv = K.gemm(x16, L["sa"].w16, bias=L["sa"].b)
             sa, lse_s = K.attn_fwd(qkv[:, :d], qkv[:, d:2 * d], qkv[:, 2 * d:], B, H, T, T, self.scale, causal=True, key_len=key_len,
-                                   drop=self.D(p + ".sattn"), head_dim=self.dh)
+                                   drop=self.D(p + ".sattn"), head_dim=self.dh, save_bits=save is not None)
             y1 = K.gemm(sa, L["sa_o"].w16, bias=L["sa_o"].b, out_dtype=F32, drop=self.D(p + ".drop1"), **res)
             g1, b1 = self.P(p + ".norm1.weight"), self.P(p + ".norm1.bias")
             x1_32, x1_16, mean1, rstd1 = self._ln(y1, g1, b1, want32=not lean)
@@ -376,7 +377,8 @@ class _Engine:
             ca_w, ca_b = L["ca"].w16, L["ca"].b
             qc = K.gemm(x1_16, ca_w[:d], bias=ca_b[:d])
             kvc = kv_all[:, 2 * d * li:2 * d * (li + 1)] if kv_all is not None else K.gemm(mem16, ca_w[d:], bias=ca_b[d:])
-            ca, lse_c = K.attn_fwd(qc, kvc[:, :d], kvc[:, d:], B, H, T, S, self.scale, drop=self.D(p + ".cattn"), head_dim=self.dh)
+            ca, lse_c = K.attn_fwd(qc, kvc[:, :d], kvc[:, d:], B, H, T, S, self.scale, drop=self.D(p + ".cattn"), head_dim=self.dh,
+                                   save_bits=save is not None)
             y2 = K.gemm(ca, L["ca_o"].w16, bias=L["ca_o"].b, out_dtype=F32, drop=self.D(p + ".drop2"), **res)
             g2, b2 = self.P(p + ".norm2.weight"), self.P(p + ".norm2.bias")
             x2_32, x2_16, mean2, rstd2 = self._ln(y2, g2, b2, want32=not lean)

@@ -266,22 +266,37 @@ def train_flops_per_clip(F, T, d=768, ffn=3072, V=1400, n_mels=128, enc=4, dec=4
 FP32_MFMA_PEAK_TF = 157.3                  # MI355X_MICROARCH.md: f32-input MFMA = the fp32 vector rate, 1/16 of bf16
 
 
-def train_setup(dev, seed, world, dropout, fx_prob=0.0, process_group=None, grad_compress=None, precision="bf16"):
+def ring_allreduce_model(grad_bytes, step_ms, world=8):
+    """Ring arithmetic for the step's gradient all-reduce at ``world`` ranks of one xGMI node (MI355X_MICROARCH.md: 7 links x ~153 GB/s per
+    GPU, point to point): a ring moves 2 (N - 1) / N of the buffer over every GPU's links; ONE ring is bound by one link, RCCL's parallel
+    rings by all seven at best.  Reported as the share of this run's measured step the collective would need if nothing overlapped it --
+    an upper bound on what the reducer (segments reduced under the remaining backward pass) has to hide, not a measurement."""
+    out = {"grad_bytes_f32": grad_bytes, "world": world, "step_ms": step_ms, "link_gb_s": 153.0, "links": 7,
+           "how": "2 (N-1)/N x bytes / bandwidth; one ring = one link, seven rings = all links (upper bound of RCCL on xGMI); arithmetic, not measured"}
+    for wire, nbytes in (("f32", grad_bytes), ("bf16", grad_bytes / 2)):
+        moved = 2.0 * (world - 1) / world * nbytes
+        one, seven = moved / 153e9 * 1e3, moved / (7 * 153e9) * 1e3
+        out[wire] = {"one_ring_ms": one, "seven_rings_ms": seven, "share_of_step_one_ring": one / step_ms, "share_of_step_seven_rings": seven / step_ms}
+    return out
+
+
+def train_setup(dev, seed, world, dropout, fx_prob=0.0, process_group=None, grad_compress=None, precision="bf16", input_sec=10.0, sample_rate=16000):
     from adt_str_amd import kernels as K
     from adt_str_amd.bank import OneShotBank, synthetic_tree
     from adt_str_amd.network import ADTModel, ADTModelConfig
     from adt_str_amd.synth import SynthDrum, SynthDrumConfig
     from adt_str_amd.trainer import FlatTrainer
-    B, L, sr, T = 64, 160000, 16000, 128
+    B, sr, T = 64, int(sample_rate), 128
+    L = int(round(input_sec * sr))
     torch.manual_seed(0)                                   # same initial weights on every rank (then broadcast anyway)
-    cfg = ADTModelConfig(input_sec=10.0, time_res=0.01, win_length=2048, sample_rate=sr, dropout=dropout, plain=True, **SETTING1)
+    cfg = ADTModelConfig(input_sec=input_sec, time_res=0.01, win_length=2048, sample_rate=sr, dropout=dropout, plain=True, **SETTING1)
     model = ADTModel(cfg).to(dev)
     if precision != "bf16":
         model.set_precision(precision)                    # the fp32-operand parity arm (csrc/precise.hip): logits within 1e-3 rel of the CPU reference
     trainer = FlatTrainer(model, lr=1e-4, weight_decay=1e-5, max_grad_norm=1.0, total_steps=10000, warmup_ratio=0.1,
                           process_group=process_group, grad_compress=grad_compress, comm_timing=True)
     bank = OneShotBank.from_tree(synthetic_tree(7, sr), sr)
-    synth = SynthDrum(SynthDrumConfig(input_sec=10.0, time_res=0.01, win_length=2048, sample_rate=sr, oneshot_path="synthetic",
+    synth = SynthDrum(SynthDrumConfig(input_sec=input_sec, time_res=0.01, win_length=2048, sample_rate=sr, oneshot_path="synthetic",
                                       similarity_threshold=0.8, max_hat_std_velocity=0.15, max_hat_mean_velocity=0.1,
                                       max_cymbals_std_velocity=0.15, max_cymbals_mean_velocity=0.65, ADTOF_mapping=False,
                                       mixup_range=0.8, use_fx_prob=fx_prob, use_reverb_prob=0.5, use_limiter_prob=0.5,
@@ -443,13 +458,35 @@ def train_setup(dev, seed, world, dropout, fx_prob=0.0, process_group=None, grad
         return trainer.reducer.comm_stats() if trainer.reducer is not None else None
 
     return {"step": step, "units": B, "dtype": "bf16" if precision == "bf16" else "f32", "roofline": roofline, "tap": tap_on, "cpu_baseline": cpu_baseline, "state": state,
-            "flops_per_step": flops_clip * B, "e2e": e2e, "comm": comm,
-            "metric": "ADT training clips/sec (10 s @16 kHz)",
-            "config": {"workload": "train config[3]: ADT train step, setting-1 network (69.0M params), per-GPU batch 64 x 10 s @ 16 kHz "
+            "flops_per_step": flops_clip * B, "e2e": e2e, "comm": comm, "grad_bytes": sum(p.numel() for p in model.parameters() if p.requires_grad) * 4,
+            "metric": "ADT training clips/sec (%g s @%g kHz)" % (input_sec, sr / 1000.0),
+            "config": {"workload": ("train config[3]" if (input_sec, sr) == (10.0, 16000) else "train, the reference's own operating point (configs/train/setting-1.yaml:9-11)")
+                                   + ": ADT train step, setting-1 network (69.0M params), per-GPU batch 64 x %g s @ %g kHz " % (input_sec, sr / 1000.0) +
                                    "mixer-rendered clips (F=%d frames), T=128 target tokens, %s, "
                                    "AdamW + clip 1.0, dropout %.2f, use_fx_prob %.2f" % (F, "bf16 GEMM/attention with fp32 accumulate" if precision == "bf16" else
                                    "fp32 operands everywhere (the parity arm that meets logits within 1e-3 rel of the CPU reference)", dropout, fx_prob),
                        "global_batch": B * world, "clips_per_gpu": B, "samples": L, "sample_rate": sr, "target_len": T}}
+
+
+def fp32_arm(dev, args, bf16_value, steps=3, warmup=1):
+    """The SAME workload on the fp32-operand kernels (csrc/precise.hip) -- the arm that meets BASELINE's "logits within 1e-3 rel-tol of the CPU
+    reference" (tests/test_precision_gpu.py), timed like the main loop (``warmup`` untimed, ``steps`` timed steps bracketed by synchronize) so
+    that the benchmarked bf16 arm and the parity arm stand in one driver line."""
+    wl = train_setup(dev, 0, 1, args.dropout, args.fx_prob, None, None, "fp32", args.input_sec, args.sample_rate)
+    for _ in range(warmup):
+        wl["step"]()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        wl["step"]()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    tf = wl["flops_per_step"] / (dt / steps) / 1e12
+    value = wl["units"] * steps / dt
+    return {"value": value, "unit": "clips/s", "ms_per_step": dt / steps * 1e3, "steps": steps, "warmup": warmup, "dtype": "f32",
+            "step_tflops_per_gpu": tf, "step_mfma_frac": tf / FP32_MFMA_PEAK_TF, "peak": FP32_MFMA_PEAK_TF, "ratio_to_bf16_value": value / bf16_value,
+            "what": "the same step with fp32 operands everywhere (v_mfma_f32_32x32x2_f32): the parity arm, logits within 1e-3 rel of the CPU reference; "
+                    "frac against the f32-input MFMA peak"}
 
 
 def launcher_command(n_ranks: int, port: int, argv):
@@ -469,33 +506,82 @@ def spawn_ranks(n_ranks: int, argv) -> int:
 
 
 class ClockPoll:
-    """Shader clock and board power of one GPU while the timed steps run (rocm-smi polled from a thread, ~8 samples a second).  Every
-    compute kernel of this repo runs the board into its power limit (profiles/r04/clock_under_load.txt: 1 400 W, 1.87-2.27 GHz depending on
-    the kernel), so what the MFMA pipe can deliver is the 2.4 GHz peak scaled by the clock the chip holds; the line reports both."""
+    """Shader clock and board power of one GPU while the timed steps run, sampled ~50 times a second IN THIS PROCESS from sysfs (the amdgpu
+    hwmon node of the card: ``freq1_input`` = sclk in Hz, ``power1_average`` / ``power1_input`` in microwatts).  No child process: under
+    rocprofv3 a spawned ``rocm-smi`` (a ``#!/usr/bin/env python3`` script) would inherit the profiler's preload and exec after GPU
+    initialisation -- the hop this pool forbids -- and its interpreter start-ups would compete with the launch thread inside the timed
+    region.  Every compute kernel of this repo runs the board into its power limit (profiles/r04/clock_under_load.txt: 1 400 W, 1.87-2.27 GHz
+    depending on the kernel), so what the MFMA pipe can deliver is the 2.4 GHz peak scaled by the clock the chip holds; the line reports both.
+    No readable node (another driver layout, no permission): the line goes out without the object."""
     NOMINAL_MHZ = 2400.0
+    SYSFS_DRM = "/sys/class/drm"
 
     def __init__(self, index):
         self.index, self.samples, self._stop, self._th = index, [], False, None
+        self.freq_path, self.power_path = self.find_nodes(index, self.pci_address(index))
+
+    @staticmethod
+    def pci_address(index):
+        """"dddd:bb:dd" of HIP device ``index`` (a GPU box shows the sysfs nodes of every GPU of its host, the process sees one), or None."""
+        try:
+            p = torch.cuda.get_device_properties(index)
+            return "%04x:%02x:%02x" % (p.pci_domain_id, p.pci_bus_id, p.pci_device_id)
+        except Exception:          # noqa: BLE001  (no GPU, or a torch without the PCI fields)
+            return None
+
+    @staticmethod
+    def find_nodes(index, pci=None):
+        """(sclk node, power node) of the amdgpu card at PCI address ``pci`` ("dddd:bb:dd"), else of the ``index``-th card in PCI order
+        -- the order HIP enumerates by default -- or (None, None)."""
+        import glob
+        cards = []
+        for dev_dir in glob.glob(os.path.join(ClockPoll.SYSFS_DRM, "card[0-9]*", "device")):
+            hw = sorted(glob.glob(os.path.join(dev_dir, "hwmon", "hwmon*")))
+            freq = next((q for q in ([os.path.join(hw[0], "freq1_input")] if hw else []) + [os.path.join(dev_dir, "pp_dpm_sclk")] if os.path.exists(q)), None)
+            if freq is not None:
+                cards.append((os.path.realpath(dev_dir), hw[0] if hw else None, freq))
+        cards.sort()
+        by_pci = [c for c in cards if pci is not None and os.path.basename(c[0]).lower().startswith(pci.lower())]
+        if by_pci:
+            cards, index = by_pci, 0
+        if index >= len(cards):
+            return None, None
+        _, hw, freq = cards[index]
+        power = next((os.path.join(hw, n) for n in ("power1_average", "power1_input") if hw and os.path.exists(os.path.join(hw, n))), None)
+        return freq, power
+
+    @staticmethod
+    def _read(path):
+        with open(path) as f:
+            return float(f.read().strip())
+
+    @staticmethod
+    def _read_mhz(path):
+        """``freq1_input``: one number in Hz; ``pp_dpm_sclk``: the level table, the current level marked with ``*`` ("1: 2100Mhz *")."""
+        import re
+        with open(path) as f:
+            text = f.read()
+        if path.endswith("pp_dpm_sclk"):
+            m = re.search(r"(\d+)\s*Mhz\s*\*", text, re.I)
+            if not m:
+                raise ValueError("no current level in pp_dpm_sclk")
+            return float(m.group(1))
+        return float(text.strip()) / 1e6
 
     def _run(self):
-        import re
-        import subprocess
         while not self._stop:
             try:
-                out = subprocess.run(["rocm-smi", "-d", str(self.index), "--showclocks", "--showpower", "--json"], capture_output=True, text=True, timeout=5).stdout
-                card = json.loads(out)
-                card = card[sorted(card)[0]]
-                sclk = next((v for k, v in card.items() if "sclk" in k.lower()), "")
-                pw = next((v for k, v in card.items() if "power" in k.lower()), "")
-                m = re.search(r"(\d+)\s*Mhz", str(sclk), re.I)
-                if m:
-                    self.samples.append((time.perf_counter(), int(m.group(1)), float(re.sub(r"[^0-9.]", "", str(pw)) or "nan")))
-            except Exception:          # noqa: BLE001  (no rocm-smi, no permission: the line goes out without the object)
+                mhz = self._read_mhz(self.freq_path)
+                watts = self._read(self.power_path) / 1e6 if self.power_path else float("nan")
+                self.samples.append((time.perf_counter(), int(round(mhz)), watts))
+            except (OSError, ValueError):          # the node went away / is not readable: the line goes out without the object
                 return
             time.sleep(0.02)
 
     def start(self):
         import threading
+        if self.freq_path is None:
+            return self
         self._th = threading.Thread(target=self._run, daemon=True)
         self._th.start()
         return self
@@ -503,15 +589,15 @@ class ClockPoll:
     def stop(self, t_from):
         self._stop = True
         if self._th is not None:
-            self._th.join(timeout=6)
+            self._th.join(timeout=2)
         s = [(c, p) for (t, c, p) in self.samples if t >= t_from]
         if not s:
             return None
-        clk, pw = sorted(c for c, _ in s), sorted(p for _, p in s)
+        clk, pw = sorted(c for c, _ in s), sorted(p for _, p in s if p == p)
         med = clk[len(clk) // 2]
-        return {"sclk_mhz": {"min": clk[0], "median": med, "max": clk[-1]}, "power_w_median": pw[len(pw) // 2], "samples": len(s),
+        return {"sclk_mhz": {"min": clk[0], "median": med, "max": clk[-1]}, "power_w_median": pw[len(pw) // 2] if pw else None, "samples": len(s),
                 "nominal_mhz": self.NOMINAL_MHZ, "held_over_nominal": med / self.NOMINAL_MHZ,
-                "source": "rocm-smi --showclocks --showpower polled while the timed steps ran (samples of the timed region only)"}
+                "source": "amdgpu hwmon (freq1_input, power1_average) read in-process while the timed steps ran (samples of the timed region only)"}
 
 
 def main():
@@ -523,9 +609,13 @@ def main():
     ap.add_argument("--dropout", type=float, default=0.1, help="model dropout (0.1 = configs/train/setting-1.yaml of the reference)")
     ap.add_argument("--fx-prob", type=float, default=0.0, help="use_fx_prob of the mixer (the reference's setting-1 trains with 0.3; SURVEY's "
                                                                  "benchmark configuration is 0)")
+    ap.add_argument("--input-sec", type=float, default=10.0, help="train workload: clip length in seconds (BASELINE config[3]: 10; the reference's "
+                                                                   "configs/train/setting-1.yaml trains at 2.56)")
+    ap.add_argument("--sample-rate", type=int, default=16000, help="train workload: sample rate (BASELINE config[3]: 16000; setting-1.yaml: 24000)")
+    ap.add_argument("--no-fp32-arm", action="store_true", help="train workload, N = 1, bf16: skip the three fp32-operand steps of the \"fp32_arm\" object")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-e2e", action="store_true", help="skip the end-to-end (real input pipeline) leg of the train workload")
-    ap.add_argument("--no-clock", action="store_true", help="do not poll rocm-smi for the shader clock / board power during the timed steps (the \"clock\" object of the line)")
+    ap.add_argument("--no-clock", action="store_true", help="do not sample the shader clock / board power (sysfs, in-process) during the timed steps (the \"clock\" object of the line)")
     ap.add_argument("--no-clap", action="store_true", help="train workload, N = 1: skip the CLAP embeds/sec leg (the \"clap\" object of the line)")
     ap.add_argument("--roofline-loop", action="store_true", help="train workload: also time the roofline kernel alone, back to back (the "
                                                                   "earlier rounds' measurement; adds 100 launches of it to a profile of this command)")
@@ -561,7 +651,7 @@ def main():
             dist.init_process_group("nccl", device_id=dev)
     pg = dist.group.WORLD if dist.is_initialized() else None
 
-    wl = {"train": lambda: train_setup(dev, rank, world, args.dropout, args.fx_prob, pg, args.grad_compress, args.precision), "logmel": lambda: logmel_setup(dev, rank),
+    wl = {"train": lambda: train_setup(dev, rank, world, args.dropout, args.fx_prob, pg, args.grad_compress, args.precision, args.input_sec, args.sample_rate), "logmel": lambda: logmel_setup(dev, rank),
           "clap": lambda: clap_setup(dev, rank)}[args.workload]()
     step = wl["step"]
 
@@ -642,6 +732,10 @@ def main():
                 line["step_mfma_frac_at_held_clock"] = line["step_mfma_frac"] / clock["held_over_nominal"]
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = wl["cpu_baseline"]()
+        if args.workload == "train" and "grad_bytes" in wl:
+            line["allreduce_model_8_ranks"] = ring_allreduce_model(wl["grad_bytes"], line["ms_per_step"])
+        if world == 1 and args.workload == "train" and args.precision == "bf16" and not args.no_fp32_arm:
+            line["fp32_arm"] = fp32_arm(dev, args, line["value"])
         if world == 1 and args.workload == "train" and not args.no_clap:
             line["clap"] = clap_leg(dev, cpu_baseline=not args.no_cpu_baseline)
         print(json.dumps(line), flush=True)

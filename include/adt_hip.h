@@ -275,9 +275,16 @@ typedef struct adt_attn_desc {
    * dq (taken in the dQ kernel's epilogue, fixed order), dk (identically zero: the rows of dS sum to zero, so exact zeros are
    * written instead of the rounding noise a sum over the stored dk would give) and dv (one pass over its columns) */
   float* dq_colsum; float* dk_colsum; float* dv_colsum;
+  /* dropout only, may be null: adt_attn_keep_bits_bytes(d) bytes of device memory, 16-byte aligned.  adt_attn_fwd leaves every keep
+   * decision it took there as a bit (its compare results, one 32-bit word per key and 32-query slice); adt_attn_bwd given the SAME
+   * buffer (and the same drop) reads them back instead of hashing every mask again and takes the one-kernel backward.  The bits are
+   * a cache of the mask function of adt_dropout, never a different mask: with or without them the gradients are those of the same
+   * forward.  Ignored by the fp32-operand entry points. */
+  void* keep_bits;
 } adt_attn_desc;
 
 int adt_attn_fwd(const adt_attn_desc* d, const void* q, const void* k, const void* v, void* o, float* lse, void* stream);
+size_t adt_attn_keep_bits_bytes(const adt_attn_desc* d);
 size_t adt_attn_bwd_workspace_bytes(const adt_attn_desc* d);
 int adt_attn_bwd(const adt_attn_desc* d, const void* q, const void* k, const void* v, const void* o, const void* dout,
                  const float* lse, void* dq, void* dk, void* dv, void* ws, size_t ws_bytes, void* stream);

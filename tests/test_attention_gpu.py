@@ -13,6 +13,13 @@ pytestmark = pytest.mark.gpu
 DEV = "cuda:0"
 
 
+@pytest.fixture(autouse=True)
+def _check_fan_in(monkeypatch):
+    """Every one-kernel backward of this module reads the kernel's give-up count back: a wave that stopped waiting for a dQ tile makes the
+    call fail (ADT_EHIP) instead of returning an incomplete gradient."""
+    monkeypatch.setenv("ADT_ATTN_BWD_CHECK", "1")
+
+
 def rnd(shape, seed, scale=1.0):
     g = torch.Generator().manual_seed(seed)
     return (torch.randn(shape, generator=g) * scale).to(DEV)
@@ -200,6 +207,14 @@ def test_the_two_backward_paths_agree(monkeypatch, B, H, Sq, Sk, causal, padded)
         for name, got, ref in (("dq", fused[0], split[0]), ("dkv", fused[1], split[1]), ("dkv staggered", stag[1], split[1])):
             err = (got.float() - ref.float()).abs().max().item()
             assert math.isfinite(err) and err <= 1.5e-2 * ref.float().abs().max().item() + 1e-6, (name, drop, err)
+        if drop is not None and Sq > 1:
+            # the training step's default: the forward leaves its keep decisions as bits (adt_attn_desc.keep_bits) and the backward --
+            # one kernel, no environment switch -- reads them back instead of hashing: the SAME masks, so the hashing one-kernel path's bits
+            ob, saved = k.attn_fwd(q, kk, v, B, H, Sq, Sk, scale, causal, key_len, drop=drop, save_bits="force")
+            assert isinstance(saved, k.AttnSaved) and torch.equal(ob, o) and torch.equal(saved.lse, lse)
+            dqb, dkvb = torch.zeros_like(q), torch.zeros_like(kv)
+            k.attn_bwd(q, kk, v, ob, dout, saved, dqb, dkvb[:, :d], dkvb[:, d:], B, H, Sq, Sk, scale, causal, key_len, drop=drop)
+            assert torch.equal(dqb, fused[0]) and torch.equal(dkvb, fused[1]), "keep-bits backward differs from the hashing one"
         if drop is None:
             qr, kr, vr = (t.float().clone().requires_grad_(True) for t in (q, kk, v))
             ref_o, _ = reference(qr, kr, vr, B, H, Sq, Sk, scale, causal, key_len.long() if padded else None)
@@ -207,6 +222,42 @@ def test_the_two_backward_paths_agree(monkeypatch, B, H, Sq, Sk, causal, padded)
             for path, (gq, gkv) in (("fused", fused), ("split", split)):
                 for name, g_, r_ in (("dq", gq, qr.grad), ("dk", gkv[:, :d], kr.grad), ("dv", gkv[:, d:], vr.grad)):
                     assert (g_.float() - r_).abs().max().item() <= 4e-2 * r_.abs().max().item() + 1e-6, (path, name)
+
+
+def test_keep_bits_from_both_forward_forms_and_long_key_ranges(monkeypatch):
+    """(a) The persistent 8-wave forward and the 4-wave form leave the same keep bits (many items per workgroup, an odd and an even number of
+    key tiles): the default backward fed either gives the same gradients, which are the hashing path's.  (b) Beyond 16 key blocks per
+    head the one-kernel backward's fan-in is not guaranteed to make progress (attention.hip fused_can_run): asked for, the two-kernel path
+    runs instead and the result is the two-kernel path's, bits or no bits."""
+    from adt_str_amd import kernels as k
+    scale = 1.0 / math.sqrt(128)
+    for (B, H, Sq, Sk, causal) in [(50, 6, 257, 300, False), (48, 6, 300, 200, True)]:
+        d = H * 128
+        q, kv, dout = rnd((B * Sq, d), 71).bfloat16(), rnd((B * Sk, 2 * d), 72).bfloat16(), rnd((B * Sq, d), 73).bfloat16()
+        kk, v = kv[:, :d], kv[:, d:]
+        key_len = torch.tensor([max(1, Sk - (3 * i) % (Sk - 1)) for i in range(B)], dtype=torch.int32, device=DEV)
+        drop = (0.1, 99)
+        grads = {}
+        for waves in ("4", "8"):
+            monkeypatch.setenv("ADT_ATTN_FWD_WAVES", waves)
+            o, saved = k.attn_fwd(q, kk, v, B, H, Sq, Sk, scale, causal, key_len, drop=drop, save_bits="force")
+            dq, dkv = torch.zeros_like(q), torch.zeros_like(kv)
+            k.attn_bwd(q, kk, v, o, dout, saved, dq, dkv[:, :d], dkv[:, d:], B, H, Sq, Sk, scale, causal, key_len, drop=drop)
+            grads[waves] = (dq, dkv)
+        monkeypatch.delenv("ADT_ATTN_FWD_WAVES")
+        hashed = _bwd(k, "fused", q, kk, v, o, dout, saved.lse, B, H, Sq, Sk, scale, causal, key_len, drop, monkeypatch)
+        for w in ("4", "8"):
+            assert torch.equal(grads[w][0], hashed[0]) and torch.equal(grads[w][1], hashed[1]), f"{w}-wave forward's bits"
+    B, H, Sq, Sk = 1, 1, 64, 4400                                       # 18 key blocks of 256
+    q, kv, dout = rnd((B * Sq, 128), 81).bfloat16(), rnd((B * Sk, 256), 82).bfloat16(), rnd((B * Sq, 128), 83).bfloat16()
+    kk, v = kv[:, :128], kv[:, 128:]
+    o, saved = k.attn_fwd(q, kk, v, B, H, Sq, Sk, scale, drop=(0.1, 5), save_bits="force")
+    args = (q, kk, v, o, dout, saved.lse, B, H, Sq, Sk, scale, False, None, (0.1, 5), monkeypatch)
+    split, asked = _bwd(k, "split", *args), _bwd(k, "fused", *args)
+    assert torch.equal(split[0], asked[0]) and torch.equal(split[1], asked[1])
+    dq, dkv = torch.zeros_like(q), torch.zeros_like(kv)
+    k.attn_bwd(q, kk, v, o, dout, saved, dq, dkv[:, :128], dkv[:, 128:], B, H, Sq, Sk, scale, drop=(0.1, 5))
+    assert torch.equal(dq, split[0]) and torch.equal(dkv, split[1])
 
 
 def test_fused_backward_reuses_a_dirty_workspace(monkeypatch):

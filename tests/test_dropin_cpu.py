@@ -112,10 +112,46 @@ def test_inference_cli_accepts_the_references_flag_spellings():
 
 
 def test_bench_clock_poll_is_silent_without_a_gpu():
-    """bench.py polls rocm-smi for the shader clock during its timed steps; where that is not possible (this container: no GPU) the
-    line simply goes out without the `clock` object -- no exception, no hang at exit."""
+    """bench.py samples the shader clock from sysfs during its timed steps; where there is no amdgpu node (this container: no GPU) the
+    line simply goes out without the `clock` object -- no exception, no thread, no hang at exit."""
     import time
     import bench
     poll = bench.ClockPoll(0).start()
     time.sleep(0.2)
-    assert poll.stop(0.0) is None
+    assert poll._th is None and poll.stop(0.0) is None
+
+
+def test_bench_clock_poll_reads_sysfs_in_process(tmp_path, monkeypatch):
+    """The poll never starts a child process (a spawned rocm-smi under rocprofv3 is the exec-after-GPU-init hop the pool forbids): it reads the
+    card's hwmon node -- or the pp_dpm_sclk level table -- itself.  A fake sysfs tree with two cards: index = PCI order."""
+    import subprocess
+    import time
+    import bench
+    for i, (bus, hz, uw) in enumerate([("0000:0a:00.0", 2110000000, 1203000000), ("0000:05:00.0", 1890000000, 990000000)]):
+        pci = tmp_path / "pci" / bus
+        hw = pci / "hwmon" / "hwmon3"
+        hw.mkdir(parents=True)
+        (hw / "freq1_input").write_text(f"{hz}\n")
+        (hw / "power1_average").write_text(f"{uw}\n")
+        (tmp_path / "drm" / f"card{i}").mkdir(parents=True)
+        (tmp_path / "drm" / f"card{i}" / "device").symlink_to(pci)
+    legacy = tmp_path / "pci" / "0000:0f:00.0"
+    legacy.mkdir()
+    (legacy / "pp_dpm_sclk").write_text("0: 500Mhz\n1: 2100Mhz *\n2: 2400Mhz\n")
+    (tmp_path / "drm" / "card2").mkdir()
+    (tmp_path / "drm" / "card2" / "device").symlink_to(legacy)
+    monkeypatch.setattr(bench.ClockPoll, "SYSFS_DRM", str(tmp_path / "drm"))
+    monkeypatch.setattr(subprocess, "run", lambda *a, **k: (_ for _ in ()).throw(AssertionError("the clock poll must not spawn a process")))
+    monkeypatch.setattr(subprocess, "Popen", lambda *a, **k: (_ for _ in ()).throw(AssertionError("the clock poll must not spawn a process")))
+    got = {}
+    for index in (0, 1, 2, 3):
+        poll = bench.ClockPoll(index).start()
+        time.sleep(0.1)
+        got[index] = poll.stop(0.0)
+    assert got[0]["sclk_mhz"]["median"] == 1890 and abs(got[0]["power_w_median"] - 990.0) < 1e-6        # PCI order: 05 before 0a
+    assert got[1]["sclk_mhz"]["median"] == 2110 and got[1]["samples"] >= 2 and abs(got[1]["held_over_nominal"] - 2110 / 2400) < 1e-9
+    assert got[2]["sclk_mhz"]["median"] == 2100 and got[2]["power_w_median"] is None        # level table, no power node
+    assert got[3] is None
+    # a GPU box shows every GPU of its host in sysfs while the process sees one: the card is picked by the HIP device's PCI address
+    assert os.path.realpath(bench.ClockPoll.find_nodes(0, "0000:0a:00")[0]).endswith("0000:0a:00.0/hwmon/hwmon3/freq1_input")
+    assert os.path.realpath(bench.ClockPoll.find_nodes(0, "0000:ff:00")[0]).endswith("0000:05:00.0/hwmon/hwmon3/freq1_input")   # unknown address: PCI order

@@ -34,7 +34,7 @@ def test_config4_curation_half_at_the_stated_size(tmp_path):
     -> global assignment -> copies -> gold -> flat bank (augment_data_with_CLAP.py:71-193 -> copy_originals_to_augmented.py ->
     convert_augmented_to_hdf5.py:69-141).  Size-independent properties: every pack file is copied exactly once, into
     <class>/<upper>-<lower>/ with a class the references define and a well-formed 10 %-wide bin label (A.7); the bank holds every copied
-    file and every reference.  The training half at this size runs in tools/e2e.py (profiles/r0N/e2e_config4_100k*.json)."""
+    file and every reference.  The training half at its stated size is the next test."""
     import re
     import shutil
     sys.path.insert(0, os.path.join(ROOT, "tools"))
@@ -60,6 +60,32 @@ def test_config4_curation_half_at_the_stated_size(tmp_path):
                 seen[f] = (cls, label)
         assert len(seen) == n
         assert set(lbl for _, lbl in seen.values()) == set(out["bins_used"])
+    finally:
+        shutil.rmtree(tmp_path / "w", ignore_errors=True)
+
+
+def test_config4_training_half_at_the_stated_size(tmp_path):
+    """BASELINE config[4]'s training half at its stated size -- ONE EPOCH over 200 000 note chunks on the setting-1 network (69.0 M
+    parameters, 10 s @ 16 kHz clips rendered on the fly from a CLAP-curated bank, use_fx_prob 0.3, dropout 0.1, batch 64: 3 125 optimizer
+    steps) through the native loop with asynchronous checkpoints, then a resume from the mid-epoch checkpoint that must end on bitwise
+    the same parameters (train.py:253-328 over data_modules/train_dataset.py:178-229 of the reference).  The curation in front is at 4 000
+    shots (its 100 000-shot size is the test above); ~2.5 minutes of GPU."""
+    import shutil
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import e2e
+    chunks, batch = 200_000, 64
+    out = e2e.main(["--workdir", str(tmp_path / "w"), "--shots", "4000", "--chunks", str(chunks), "--check-resume", "--keep"])
+    try:
+        print(f"config[4] training half at {chunks} chunks: {out['train_clips_per_s']:.0f} clips/s over the epoch ({out['times']['train_epoch_s']:.1f} s, "
+              f"{out['steps']} steps, checkpoints {out['checkpoints']}), final loss {out['final_loss']:.4f}; resumed from {out['resume']['from']}: "
+              f"bitwise identical {out['resume']['bitwise_identical']}")
+        assert out["network"].startswith("setting-1") and out["steps"] == chunks // batch == 3125
+        assert np.isfinite(out["final_loss"]) and 0.0 < out["final_loss"] < 7.3                  # ln(1400) = 7.24: the epoch learned something
+        assert out["train_clips_per_s"] > 500 and len(out["checkpoints"]) == 3
+        mid = int(out["resume"]["from"].rsplit("-", 1)[1])
+        assert 0 < mid < out["steps"]                                                            # a MID-epoch checkpoint
+        assert out["resume"]["bitwise_identical"] and out["resume"]["steps"] == out["steps"]
+        assert (tmp_path / "w" / "outputs" / "e2e" / "model.safetensors").exists()
     finally:
         shutil.rmtree(tmp_path / "w", ignore_errors=True)
 
