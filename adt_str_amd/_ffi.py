@@ -10,7 +10,8 @@ import ctypes as C
 import os
 import threading
 
-_LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "libadt_hip.so")
+# ``ADT_LIB_PATH``: another build of the SAME library (same ABI version, checked at load) -- for same-box A/B runs of two builds of a kernel
+_LIB_PATH = os.environ.get("ADT_LIB_PATH") or os.path.join(os.path.dirname(os.path.abspath(__file__)), "libadt_hip.so")
 _lock = threading.Lock()
 _lib = None
 

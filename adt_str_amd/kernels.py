@@ -459,6 +459,18 @@ class AttnSaved:
         self.lse, self.bits = lse, bits
 
 
+def keep_bits_to_mask(bits, B, H, Sq, Sk):
+    """Decode ``AttnSaved.bits`` (layout: csrc/attn_common.h keep_bits_*) into a bool [B, H, Sq, Sk] keep mask -- tests and tools only
+    (the backward reads the words as they are)."""
+    nq, nk = (Sq + 255) // 256 * 8, (Sk + 255) // 256 * 8
+    words = bits.view(torch.int32).view(B * H, nq, nk, 32)
+    word_of_key = torch.tensor([2 * ((kk & 3) + 4 * (kk >> 3)) + ((kk >> 2) & 1) for kk in range(32)], device=bits.device)
+    w = words[..., word_of_key]                                                            # [bh, slice, block, key]
+    bit = (w.unsqueeze(-1) >> torch.arange(32, device=bits.device, dtype=torch.int32)) & 1  # [bh, slice, block, key, query]
+    mask = bit.permute(0, 1, 4, 2, 3).reshape(B * H, nq * 32, nk * 32)[:, :Sq, :Sk]
+    return mask.reshape(B, H, Sq, Sk).bool()
+
+
 def attn_fwd(q, k, v, B, H, Sq, Sk, scale, causal=False, key_len=None, mask_value=-1e4, out=None, drop=None, head_dim=128, save_bits=False):
     """q [B*Sq, >=H*128], k/v [B*Sk, >=H*128] bf16 (row-strided views allowed) -> (o [B*Sq, H*128] bf16, lse [B,H,Sq] fp32).
     fp32 tensors take the fp32-operand path (``head_dim`` 16 / 32 / 64 / 128 there; the bf16 kernels are built for 128).

@@ -114,6 +114,15 @@ def test_attention_dropout_forward_backward(B, H, Sq, Sk, causal):
     k.attn_bwd(q, kk, v, o, dout, lse, dq, dk, dv, B, H, Sq, Sk, scale, causal, drop=site)
     for name, got, rg in (("dq", dq, qr.grad), ("dk", dk, kr.grad), ("dv", dv, vr.grad)):
         assert (got.float() - rg).abs().max() <= 4e-2 * rg.abs().max(), name
+    # the training step's path: the forward leaves its keep decisions as bits and the one-kernel backward reads them back.  The bits ARE
+    # the oracle's mask (every element, both forward forms write them alike), and the gradients are the same-mask reference's.
+    o2, saved = k.attn_fwd(q, kk, v, B, H, Sq, Sk, scale, causal, drop=site, save_bits="force")
+    assert torch.equal(o2, o) and torch.equal(saved.lse, lse)
+    assert torch.equal(k.keep_bits_to_mask(saved.bits, B, H, Sq, Sk), sc > 0)
+    dq2, dk2, dv2 = torch.empty_like(q), torch.empty_like(kk), torch.empty_like(v)
+    k.attn_bwd(q, kk, v, o2, dout, saved, dq2, dk2, dv2, B, H, Sq, Sk, scale, causal, drop=site)
+    for name, got, rg in (("dq", dq2, qr.grad), ("dk", dk2, kr.grad), ("dv", dv2, vr.grad)):
+        assert (got.float() - rg).abs().max() <= 4e-2 * rg.abs().max(), name + " (keep bits)"
 
 
 def test_network_with_dropout_matches_oracle_with_same_masks():

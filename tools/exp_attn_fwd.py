@@ -25,7 +25,8 @@ def run(waves, *args, **kw):
     return o, lse
 
 
-def reference(q, kk, v, B, H, Sq, Sk, scale, causal, key_len):
+def reference(q, kk, v, B, H, Sq, Sk, scale, causal, key_len, keep=None, p=0.0):
+    """fp32 softmax(Q K^T + masks) V; ``keep`` (bool [B, H, Sq, Sk]): dropout on the probabilities with THAT mask, kept ones / (1 - p)."""
     d = 128
     qh = q.float().view(B, Sq, H, d).transpose(1, 2)
     kh = kk.float().reshape(B, Sk, H, d).transpose(1, 2)
@@ -35,7 +36,10 @@ def reference(q, kk, v, B, H, Sq, Sk, scale, causal, key_len):
         s = s + torch.triu(torch.full((Sq, Sk), -1e4, device=dev), diagonal=1)
     if key_len is not None:
         s = s + (torch.arange(Sk, device=dev)[None, :] >= key_len[:, None]).float()[:, None, None, :] * -1e4
-    return (torch.softmax(s, -1) @ vh).transpose(1, 2).reshape(B * Sq, H * d)
+    pr = torch.softmax(s, -1)
+    if keep is not None:
+        pr = pr * keep.float() / (1.0 - p)
+    return (pr @ vh).transpose(1, 2).reshape(B * Sq, H * d)
 
 
 def timeit(fn, n=30, warm=15):
@@ -68,10 +72,15 @@ def main():
                 o8, l8 = run(8, q, kk, v, B, H, Sq, Sk, scale, causal, key_len, drop=drop)
                 o8b, l8b = run(8, q, kk, v, B, H, Sq, Sk, scale, causal, key_len, drop=drop)
                 rep = torch.equal(o8, o8b) and torch.equal(l8, l8b) and torch.equal(o4, o8) and torch.equal(l4, l8)
-                eo = (o8.float() - ref).abs().max().item() if drop is None else float("nan")
-                bad = (not rep) or (drop is None and not eo <= 2e-2 * ref.abs().max().item() + 1e-6) or not bool(torch.isfinite(o8.float()).all())
+                rf = ref
+                if drop is not None and Sq > 1:          # the same-mask reference: the mask is the one the kernel reports (its keep bits, which
+                    ob, saved = K.attn_fwd(q, kk, v, B, H, Sq, Sk, scale, causal, key_len, drop=drop, save_bits="force")   # tests/test_dropout_gpu.py pins to the oracle's)
+                    rep = rep and torch.equal(ob, o8)
+                    rf = reference(q, kk, v, B, H, Sq, Sk, scale, causal, key_len, K.keep_bits_to_mask(saved.bits, B, H, Sq, Sk), drop[0])
+                eo = (o8.float() - rf).abs().max().item()
+                bad = (not rep) or not eo <= 2e-2 * rf.abs().max().item() + 1e-6 or not bool(torch.isfinite(o8.float()).all())
                 print(f"{'BAD ' if bad else 'ok  '} B{B} H{H} Sq{Sq} Sk{Sk} causal{int(causal)} pad{int(padded)} drop{drop is not None}: "
-                      f"out vs fp32 {eo:.3e}/{ref.abs().max().item():.2e}, 4 = 8 waves and repeatable {rep}", flush=True)
+                      f"out vs fp32{' (same mask)' if drop is not None else ''} {eo:.3e}/{rf.abs().max().item():.2e}, 4 = 8 waves and repeatable {rep}", flush=True)
     for name, (B, H, Sq, Sk, causal) in {"encoder": (64, 6, 986, 986, False), "cross": (64, 6, 128, 986, False), "causal": (64, 6, 128, 128, True)}.items():
         d = H * 128
         q = rnd((B * Sq, d), 1).bfloat16()
