@@ -135,10 +135,10 @@ __global__ __launch_bounds__(kThreads) void logmel_kernel(LogmelArgs a) {
   const long first = lo + static_cast<long>(blockIdx.x / ng) * kWavesPerBlock + wave;
 
   for (int iter = 0; iter < a.n_iter; ++iter) {
-    // Re-derive every per-lane LDS address inside the iteration: left to LICM, the loop-invariant twiddle / buffer
-    // addresses are hoisted and then spilled to scratch.
-    int lane = lane_id;
-    asm volatile("" : "+v"(lane));
+    // (Rounds 1-4 re-derived every per-lane LDS address inside the iteration -- `asm volatile("" : "+v"(lane))` -- because hoisted they
+    // were spilled.  With the complex arithmetic on register pairs (logmel_phases.h) the frame needs 80 registers instead of 116, the
+    // hoisted addresses fit the 128 of four waves per SIMD without a spill, and the FFT passes lose another fifth of their instructions.)
+    const int lane = lane_id;
     const long item = first + static_cast<long>(iter) * group_waves;
     if (item >= hi) break;                             // wave-uniform; no workgroup barrier inside the loop
     const long clip_i = item / a.n_out;

@@ -117,6 +117,17 @@ ADT_HD void l2_pass3_store(int lane, int it, cf* z /*8*/, cf* buf) {
 }
 
 // ---- untangle: the two power bins that Z[k] and Z[1024 - k] determine ------------------------------------------------
+#if defined(__HIP_DEVICE_COMPILE__)
+ADT_HD void real_power_pair(cf a, cf b, cf w, float& pk, float& pnk) {      // the same on register pairs (logmel_phases.h): 14 packed / scalar instructions
+  const cf cb = b * cf{0.5f, -0.5f};                  // conj(b) / 2
+  const cf e = a * 0.5f + cb, d = a * 0.5f - cb;      // E = (a + conj b) / 2;  d = (a - conj b) / 2,  O = -i d
+  const cf t = cmul(w, mul_mi(d));
+  const cf u = e + t, v = e - t;
+  const cf uu = u * u, vv = v * v;
+  pk = uu.x + uu.y;
+  pnk = vv.x + vv.y;
+}
+#else
 ADT_HD void real_power_pair(cf a, cf b, cf w, float& pk, float& pnk) {      // a = Z[k], b = Z[1024 - k], w = W_2048^k
   const cf e = {0.5f * (a.x + b.x), 0.5f * (a.y - b.y)};
   const cf o = {0.5f * (a.y + b.y), -0.5f * (a.x - b.x)};
@@ -125,6 +136,7 @@ ADT_HD void real_power_pair(cf a, cf b, cf w, float& pk, float& pnk) {      // a
   pk = u.x * u.x + u.y * u.y;
   pnk = v.x * v.x + v.y * v.y;
 }
+#endif
 // lane -> bins k = lane + 64 i (i < 8) and 1024 - k; lane 0 also bin 512.  Reads L3, returns the powers in registers.
 ADT_HD void l2_untangle_load(int lane, const cf* t2k, const cf* buf, float* pk /*8*/, float* pnk /*8*/, float& p512) {
   const cf* up = buf + lane;                                    // Z[k], k = lane + 64 i

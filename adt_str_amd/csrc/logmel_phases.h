@@ -18,14 +18,37 @@
 
 namespace adt {
 
-struct cf { float x, y; };
-
 constexpr int kNfft = 2048;
 
+// Complex arithmetic.  On the device a complex number is a register PAIR (ext_vector_type(2)) and every operation below is written as
+// whole-pair arithmetic the compiler turns into ONE packed instruction each (v_pk_add_f32 / v_pk_mul_f32 / v_pk_fma_f32 with op_sel
+// swizzles): a rotation by -i is a swapped operand times the constant pair (1, -1) inside an FMA, a complex product is a packed
+// multiply and a packed FMA (plus one packed multiply for i b when b is not a compile-time constant).  Written element by element
+// (the struct form the host emulator keeps) the same kernels carried ~200 v_mov / v_pk_mov register shuffles per frame -- a sixth of
+// their instructions -- because the compiler folds a swizzle into a packed operand but not a swizzle with a per-element sign
+// (round 5: K1 and K9 are bound by vector instruction issue, so instructions are what counts).
+#if defined(__HIP_DEVICE_COMPILE__)
+typedef float cf __attribute__((ext_vector_type(2)));
+ADT_HD cf cswap_(cf a) { return __builtin_shufflevector(a, a, 1, 0); }
+ADT_HD cf cre_(cf a) { return __builtin_shufflevector(a, a, 0, 0); }
+ADT_HD cf cim_(cf a) { return __builtin_shufflevector(a, a, 1, 1); }
+ADT_HD cf cadd(cf a, cf b) { return a + b; }
+ADT_HD cf csub(cf a, cf b) { return a - b; }
+ADT_HD cf mul_mi(cf a) { return cswap_(a) * cf{1.f, -1.f}; }                       // a * (-i)
+ADT_HD cf cadd_mi(cf a, cf b) { return cswap_(b) * cf{1.f, -1.f} + a; }            // a + (-i) b
+ADT_HD cf csub_mi(cf a, cf b) { return cswap_(b) * cf{-1.f, 1.f} + a; }            // a - (-i) b
+ADT_HD cf cmul_k(cf a, float cr, float ci) { return cre_(a) * cf{cr, ci} + cim_(a) * cf{-ci, cr}; }   // a * (cr + i ci), constants
+ADT_HD cf cmul(cf a, cf b) { const cf ib = cswap_(b) * cf{-1.f, 1.f}; return cre_(a) * b + cim_(a) * ib; }
+#else
+struct cf { float x, y; };
 ADT_HD cf cadd(cf a, cf b) { return {a.x + b.x, a.y + b.y}; }
 ADT_HD cf csub(cf a, cf b) { return {a.x - b.x, a.y - b.y}; }
 ADT_HD cf cmul(cf a, cf b) { return {a.x * b.x - a.y * b.y, a.x * b.y + a.y * b.x}; }
 ADT_HD cf mul_mi(cf a) { return {a.y, -a.x}; }   // a * (-i)
+ADT_HD cf cadd_mi(cf a, cf b) { return {a.x + b.y, a.y - b.x}; }
+ADT_HD cf csub_mi(cf a, cf b) { return {a.x - b.y, a.y + b.x}; }
+ADT_HD cf cmul_k(cf a, float cr, float ci) { return cmul(a, cf{cr, ci}); }
+#endif
 
 // W_2048^j from the half-circle table tw[0..1023] (W^(j+1024) = -W^j).
 ADT_HD cf twiddle(const cf* tw, int j) {
@@ -36,8 +59,8 @@ ADT_HD cf twiddle(const cf* tw, int j) {
 }
 
 ADT_HD void dft4(cf& a, cf& b, cf& c, cf& d) {   // forward (e^-i) 4-point, in place, natural order
-  cf t0 = cadd(a, c), t1 = csub(a, c), t2 = cadd(b, d), t3 = mul_mi(csub(b, d));
-  a = cadd(t0, t2); b = cadd(t1, t3); c = csub(t0, t2); d = csub(t1, t3);
+  cf t0 = cadd(a, c), t1 = csub(a, c), t2 = cadd(b, d), t3 = csub(b, d);
+  a = cadd(t0, t2); b = cadd_mi(t1, t3); c = csub(t0, t2); d = csub_mi(t1, t3);
 }
 
 // forward 16-point DFT, in place, natural order.  n = 4a + b, k = c + 4d.
@@ -46,15 +69,15 @@ ADT_HD void dft16(cf* x) {
   _Pragma("unroll")
   for (int b = 0; b < 4; ++b) dft4(x[b], x[4 + b], x[8 + b], x[12 + b]);   // over a; result index c at x[4c + b]
   // twiddle W_16^(b*c) on element x[4c + b]
-  x[4 * 1 + 1] = cmul(x[4 * 1 + 1], cf{c1, -s1});      // bc = 1
-  x[4 * 1 + 2] = cmul(x[4 * 1 + 2], cf{h, -h});        // 2
-  x[4 * 1 + 3] = cmul(x[4 * 1 + 3], cf{s1, -c1});      // 3
-  x[4 * 2 + 1] = cmul(x[4 * 2 + 1], cf{h, -h});        // 2
+  x[4 * 1 + 1] = cmul_k(x[4 * 1 + 1], c1, -s1);        // bc = 1
+  x[4 * 1 + 2] = cmul_k(x[4 * 1 + 2], h, -h);          // 2
+  x[4 * 1 + 3] = cmul_k(x[4 * 1 + 3], s1, -c1);        // 3
+  x[4 * 2 + 1] = cmul_k(x[4 * 2 + 1], h, -h);          // 2
   x[4 * 2 + 2] = mul_mi(x[4 * 2 + 2]);                 // 4
-  x[4 * 2 + 3] = cmul(x[4 * 2 + 3], cf{-h, -h});       // 6
-  x[4 * 3 + 1] = cmul(x[4 * 3 + 1], cf{s1, -c1});      // 3
-  x[4 * 3 + 2] = cmul(x[4 * 3 + 2], cf{-h, -h});       // 6
-  x[4 * 3 + 3] = cmul(x[4 * 3 + 3], cf{-c1, s1});      // 9
+  x[4 * 2 + 3] = cmul_k(x[4 * 2 + 3], -h, -h);         // 6
+  x[4 * 3 + 1] = cmul_k(x[4 * 3 + 1], s1, -c1);        // 3
+  x[4 * 3 + 2] = cmul_k(x[4 * 3 + 2], -h, -h);         // 6
+  x[4 * 3 + 3] = cmul_k(x[4 * 3 + 3], -c1, s1);        // 9
   _Pragma("unroll")
   for (int c = 0; c < 4; ++c) dft4(x[4 * c], x[4 * c + 1], x[4 * c + 2], x[4 * c + 3]);  // over b; result d at x[4c + d]
   // x[4c + d] holds X[c + 4d]: transpose the 4x4 to natural order
@@ -71,12 +94,11 @@ ADT_HD void dft8(cf* x) {
   cf o0 = x[1], o1 = x[3], o2 = x[5], o3 = x[7];
   dft4(e0, e1, e2, e3);
   dft4(o0, o1, o2, o3);
-  o1 = cmul(o1, cf{h, -h});
-  o2 = mul_mi(o2);
-  o3 = cmul(o3, cf{-h, -h});
+  o1 = cmul_k(o1, h, -h);
+  o3 = cmul_k(o3, -h, -h);
   x[0] = cadd(e0, o0); x[4] = csub(e0, o0);
   x[1] = cadd(e1, o1); x[5] = csub(e1, o1);
-  x[2] = cadd(e2, o2); x[6] = csub(e2, o2);
+  x[2] = cadd_mi(e2, o2); x[6] = csub_mi(e2, o2);      // o2 * (-i)
   x[3] = cadd(e3, o3); x[7] = csub(e3, o3);
 }
 

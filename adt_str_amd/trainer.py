@@ -150,6 +150,10 @@ class GradReducer:
         self._segs = []
         # RCCL averages inside the collective; gloo (CPU tests, shared-GPU debug runs) only sums, the mean is then one more pass
         self.avg_in_collective = dist.get_backend(process_group) == "nccl"
+        # One rank: the mean IS the sum, and RCCL runs an in-place single-rank SUM as nothing at all, whereas AVG there is a pre-multiply
+        # copy of every segment (oneRankReduce<FuncPreMulSum>: 8 launches, 0.41 ms of HBM-bound kernel time per step under the backward
+        # pass -- the whole +0.6 ms of `torchrun --nproc-per-node 1` over the plain run, profiles/r05/rccl_one_rank_ab.txt).
+        self.op_avg = dist.ReduceOp.AVG if self.world > 1 else dist.ReduceOp.SUM
         self.enabled = True
         self.addend: Optional[torch.Tensor] = None
         self.compress = "bf16" if compress == "bf16" else None
@@ -169,13 +173,13 @@ class GradReducer:
             buf = self.wire[lo:hi]
             if self.avg_in_collective:
                 buf.copy_(seg)
-                op = dist.ReduceOp.AVG
+                op = self.op_avg
             else:
                 torch.mul(seg, 1.0 / self.world, out=seg)          # mean before the cast: the bf16 sum cannot overflow its range
                 buf.copy_(seg)
                 op = dist.ReduceOp.SUM
         else:
-            buf, op = seg, (dist.ReduceOp.AVG if self.avg_in_collective else dist.ReduceOp.SUM)
+            buf, op = seg, (self.op_avg if self.avg_in_collective else dist.ReduceOp.SUM)
         self._works.append(dist.all_reduce(buf, op=op, group=self.pg, async_op=True))
         self._segs.append((lo, hi))
         self.covered += hi - lo
