@@ -60,13 +60,18 @@ __global__ __launch_bounds__(kClapThreads) void clap_logmel_kernel(ClapArgs a) {
   __syncthreads();
   const long total_waves = static_cast<long>(gridDim.x) * kClapWaves;
   const long first = static_cast<long>(blockIdx.x) * kClapWaves + wave;
-  for (int iter = 0; iter < a.n_iter; ++iter) {
+  // (clip, frame pair) without a 64-bit division per item: quotient and remainder advance by constants and one carry (logmel.hip)
+  long item = first;
+  int clip_i = static_cast<int>(item / a.pairs_per_clip);
+  int pair = static_cast<int>(item - static_cast<long>(clip_i) * a.pairs_per_clip);
+  const int step_q = static_cast<int>(total_waves / a.pairs_per_clip);
+  const int step_r = static_cast<int>(total_waves - static_cast<long>(step_q) * a.pairs_per_clip);
+  for (int iter = 0; iter < a.n_iter; ++iter, item += total_waves, clip_i += step_q + (pair + step_r >= a.pairs_per_clip ? 1 : 0),
+           pair = pair + step_r >= a.pairs_per_clip ? pair + step_r - a.pairs_per_clip : pair + step_r) {
     int lane = lane_id;
     asm volatile("" : "+v"(lane));                // keep LDS address arithmetic inside the iteration (see logmel.hip)
-    const long item = first + static_cast<long>(iter) * total_waves;
     if (item >= a.n_items) break;                 // wave-uniform; no workgroup barrier inside the loop
-    const int clip_i = static_cast<int>(item / a.pairs_per_clip);
-    const int f0 = 2 * static_cast<int>(item - static_cast<long>(clip_i) * a.pairs_per_clip);
+    const int f0 = 2 * pair;
     const bool has1 = f0 + 1 < a.n_frames;
     const long o0 = a.offsets[clip_i];
     const int n = static_cast<int>(a.offsets[clip_i + 1] - o0);

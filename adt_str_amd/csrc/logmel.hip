@@ -21,7 +21,7 @@ namespace adt {
 constexpr int kWavesPerBlock = 16;
 constexpr int kThreads = 64 * kWavesPerBlock;
 constexpr int kMaxMelNnz = 2304;
-constexpr int kMaxMelPad = kMaxMelNnz + 3 * 128;      // every band padded with zero weights to a multiple of 4 bins
+constexpr int kMaxMelPad = kMaxMelNnz + 4 * 128;      // every band padded with zero weights to a multiple of 4 bins (+ the odd-stride padding of the usual filterbanks)
 constexpr size_t kLdsTw = (1024 + 520) * sizeof(cf);     // W_1024^j, j < 1024 | W_2048^k, k <= 512 (padded to 520)
 constexpr size_t kLdsWin = 1024 * sizeof(cf);
 constexpr size_t kLdsBands = (128 + 8) * sizeof(unsigned);   // per mel: first bin | padded weight offset << 11 | own trips << 24; then the trip count of each mel item
@@ -111,13 +111,21 @@ __global__ __launch_bounds__(kThreads) void logmel_kernel(LogmelArgs a) {
   // Layout of the padded weights: every band of an item as long as the item's trip count when that fits (the loop then needs no
   // per-lane bound at all: the usual 128-mel filterbanks); else every band padded to its own multiple of four and the loop
   // masks the weight past the lane's own trips.
-  int item_total = 0;
+  // Bank conflicts of the weight reads: the eight bands of a half-wave sit 4 * stride floats apart, so with an EVEN stride (in trips)
+  // they fall on 4, 2 or 1 of the eight 4-bank groups (trips 2 / 4 / 8: 2-, 4-, 8-way conflicts -- 132 of the 741 LDS cycles of a frame,
+  // tools/lds_conflicts_mel.py); an odd stride puts them on eight different groups.  So the band stride of an item is its trip count
+  // made odd (the extra trip is never run, only skipped over) when the table still fits.
+  int item_total = 0, item_total_odd = 0;
 #pragma unroll
-  for (int i = 0; i < 8; ++i) item_total += 64 * static_cast<int>(bands[128 + i]);
+  for (int i = 0; i < 8; ++i) {
+    item_total += 64 * static_cast<int>(bands[128 + i]);
+    item_total_odd += 64 * static_cast<int>(bands[128 + i] | 1u);
+  }
   const bool uniform_pad = item_total <= kMaxMelPad;   // block-uniform
+  const unsigned odd = (uniform_pad && item_total_odd <= kMaxMelPad) ? 1u : 0u;
   if (tid < 128) {
     int poff = 0;                                       // offset of band `tid` in the padded weight array
-    for (int j = 0; j < tid && j < a.n_mels; ++j) poff += uniform_pad ? 4 * static_cast<int>(bands[128 + (j >> 4)]) : (sane_band(a.mel_meta[j], a.mel_nnz).y + 3) & ~3;
+    for (int j = 0; j < tid && j < a.n_mels; ++j) poff += uniform_pad ? 4 * static_cast<int>(bands[128 + (j >> 4)] | odd) : (sane_band(a.mel_meta[j], a.mel_nnz).y + 3) & ~3;
     const int4 m = (tid < a.n_mels) ? sane_band(a.mel_meta[tid], a.mel_nnz) : make_int4(0, 0, 0, 0);
     bands[tid] = static_cast<unsigned>(m.x) | (static_cast<unsigned>(poff) << 11) | (static_cast<unsigned>((m.y + 3) >> 2) << 24);
     for (int t = 0; t < m.y; ++t) melw[poff + t] = a.mel_w[m.z + t];
@@ -134,15 +142,29 @@ __global__ __launch_bounds__(kThreads) void logmel_kernel(LogmelArgs a) {
   const long group_waves = static_cast<long>(n_grp) * kWavesPerBlock;
   const long first = lo + static_cast<long>(blockIdx.x / ng) * kWavesPerBlock + wave;
 
+  // (clip, frame) of the wave's items without a 64-bit division per frame (≈ 250 scalar instructions of the ≈ 260 a frame carried): the
+  // item index advances by group_waves per iteration, so quotient and remainder advance by constants and one carry
+  long item = first;
+  long clip_i = item / a.n_out;
+  int f = static_cast<int>(item - clip_i * a.n_out);
+  const long step_q = group_waves / a.n_out;
+  const int step_r = static_cast<int>(group_waves - step_q * a.n_out);
+  cf tw2[2][8];                                        // pass 2's twiddles: lane constants, in registers for the whole kernel
+  l2_pass2_twiddles(lane_id, 0, t1k, tw2[0]);
+  l2_pass2_twiddles(lane_id, 1, t1k, tw2[1]);
   for (int iter = 0; iter < a.n_iter; ++iter) {
-    // (Rounds 1-4 re-derived every per-lane LDS address inside the iteration -- `asm volatile("" : "+v"(lane))` -- because hoisted they
-    // were spilled.  With the complex arithmetic on register pairs (logmel_phases.h) the frame needs 80 registers instead of 116, the
-    // hoisted addresses fit the 128 of four waves per SIMD without a spill, and the FFT passes lose another fifth of their instructions.)
-    const int lane = lane_id;
-    const long item = first + static_cast<long>(iter) * group_waves;
+    // Per-lane LDS addresses are re-derived inside the iteration (the empty asm hides that `lane` is loop-invariant): hoisted by LICM
+    // they are spilled.  With the complex arithmetic on register pairs (logmel_phases.h) a frame needs 80 registers instead of 116; the 48
+    // that are left of the 128 of four waves per SIMD go to pass 2's sixteen twiddles (above) -- hoisting the addresses instead gave the
+    // same instruction count and kept the conflict-prone table reads.
+    int lane = lane_id;
+    asm volatile("" : "+v"(lane));
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {                       // (... and that the twiddles are: LICM would hoist sixteen i * w products too, and spill them)
+      asm volatile("" : "+v"(tw2[0][k]));
+      asm volatile("" : "+v"(tw2[1][k]));
+    }
     if (item >= hi) break;                             // wave-uniform; no workgroup barrier inside the loop
-    const long clip_i = item / a.n_out;
-    const int f = static_cast<int>(item - clip_i * a.n_out);
     const float* clip = a.wave + clip_i * a.ld_wave;
     const int base = (a.frame_lo + f) * a.hop - kNfft / 2;
     if (base >= 0 && base + kNfft <= a.n_samples) {
@@ -156,9 +178,9 @@ __global__ __launch_bounds__(kThreads) void logmel_kernel(LogmelArgs a) {
     l2_pass2_load(lane, 0, buf, z[0]);
     l2_pass2_load(lane, 1, buf, z[1]);
     wave_sync();
-    l2_pass2_store(lane, 0, z[0], t1k, buf);
+    l2_pass2_store_tw(lane, 0, z[0], tw2[0], buf);
     __builtin_amdgcn_sched_barrier(0);
-    l2_pass2_store(lane, 1, z[1], t1k, buf);
+    l2_pass2_store_tw(lane, 1, z[1], tw2[1], buf);
     wave_sync();
     l2_pass3_load(lane, 0, buf, z[0]);
     l2_pass3_load(lane, 1, buf, z[1]);
@@ -206,6 +228,10 @@ __global__ __launch_bounds__(kThreads) void logmel_kernel(LogmelArgs a) {
       reinterpret_cast<float2*>(a.out + (clip_i * a.n_out + f) * a.n_mels)[lane] = y;
     }
     wave_sync();
+    item += group_waves;
+    clip_i += step_q;
+    f += step_r;
+    if (f >= a.n_out) { f -= a.n_out; ++clip_i; }
   }
 }
 

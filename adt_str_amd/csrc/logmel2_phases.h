@@ -89,13 +89,26 @@ ADT_HD void l2_pass2_load(int lane, int it, const cf* buf, cf* z /*8*/) {
   _Pragma("unroll")
   for (int n2 = 0; n2 < 8; ++n2) z[n2] = ((n2 & 1) ? odd : even)[128 * n2];
 }
-ADT_HD void l2_pass2_store(int lane, int it, cf* z /*8*/, const cf* t1k, cf* buf) {
+// The eight twiddles W_1024^(n3 (k1 + 16 k2)) of item `it` depend on the lane only: the kernel reads them ONCE, before its frame loop, and
+// keeps them in registers (l2_pass2_twiddles) -- their table reads were the conflict-prone ones (per-lane scattered 8-byte reads) of a
+// kernel that round 5 left LDS-bound.
+ADT_HD void l2_pass2_twiddles(int lane, int it, const cf* t1k, cf* tw /*8*/) {
+  const int c = lane + 64 * it, k1 = c >> 3, n3 = c & 7;
+  const int j0 = n3 * k1, step = 16 * n3;
+  _Pragma("unroll")
+  for (int k2 = 0; k2 < 8; ++k2) tw[k2] = tw1k(t1k, j0 + step * k2);
+}
+ADT_HD void l2_pass2_store_tw(int lane, int it, cf* z /*8*/, const cf* tw /*8*/, cf* buf) {
   const int c = lane + 64 * it, k1 = c >> 3, n3 = c & 7;
   dft8(z);
   cf* dst = buf + l2_index(0, k1, n3);                // + 128 * k2
-  const int j0 = n3 * k1, step = 16 * n3;             // W_1024^(n3 (k1 + 16 k2))
   _Pragma("unroll")
-  for (int k2 = 0; k2 < 8; ++k2) dst[128 * k2] = cmul(z[k2], tw1k(t1k, j0 + step * k2));
+  for (int k2 = 0; k2 < 8; ++k2) dst[128 * k2] = cmul(z[k2], tw[k2]);
+}
+ADT_HD void l2_pass2_store(int lane, int it, cf* z /*8*/, const cf* t1k, cf* buf) {
+  cf tw[8];
+  l2_pass2_twiddles(lane, it, t1k, tw);
+  l2_pass2_store_tw(lane, it, z, tw, buf);
 }
 
 // ---- pass 3: radix-8 over n3, L2 -> L3 (two items per lane) ---------------------------------------------------------

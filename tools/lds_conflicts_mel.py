@@ -18,10 +18,12 @@ lo, cnt = mb.meta[:, 0], mb.meta[:, 1]
 items = (n_mels + 15) // 16
 width = lambda j: int(cnt[j]) if j < n_mels else 0
 trips = [max((width(g + 16 * i) + 3) // 4 for g in range(16)) for i in range(items)]
+# band stride of an item (in trips): the trip count, made odd since round 5 when the padded table still fits (logmel.hip); argv[3] = "even": the old layout
+odd = 1 if (len(sys.argv) < 4 or sys.argv[3] != "even") and 64 * sum(t | 1 for t in trips) <= 2816 else 0
 poff, off = np.zeros(16 * items, int), 0
 for j in range(16 * items):
     poff[j] = off
-    off += 4 * trips[j // 16]
+    off += 4 * (trips[j // 16] | odd)
 
 
 def cycles(addrs):
@@ -42,7 +44,7 @@ for i in range(items):
         conf_w += cycles([int(poff[(l >> 2) + 16 * i]) + 4 * t + (l & 3) for l in range(64)]) - 2
         ideal += 2
 fft = 16 * 4 + 16 * 2 + 16 * 2 + 16 * 4 + 8 * 4 + 16 * 4 + 8 * 8          # the accesses listed by emu_logmel2_accesses, cycles per kind
-print(f"{sr} Hz, {n_mels} mels: trips per item {trips}")
+print(f"{sr} Hz, {n_mels} mels: trips per item {trips}, band stride {'odd' if odd else 'as the trips'}")
 print(f"mel stage per frame: power reads {ideal} ideal + {conf_p} conflict cycles; weight reads {ideal} ideal + {conf_w} conflict cycles")
 print(f"conflict-free FFT / window / untangling accesses: {fft} cycles per frame")
 print(f"model conflict share: {(conf_p + conf_w) / (fft + 2 * ideal + conf_p + conf_w):.0%} of LDS-active cycles")
