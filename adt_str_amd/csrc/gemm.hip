@@ -63,6 +63,7 @@ struct GemmArgs {
   Drop drop; unsigned drop_key2;      // drop_key2 = mix32(drop.key)
   int tail_stores;                         // gemm_nt_256_kernel: leave an interior tile's last stores in flight across the tile boundary
   int group_n;                             // gemm_nt_256_kernel: tile columns per column group of the tile order (>= tiles_n: row-major)
+  int stagger;                             // gemm_nt_256_kernel, experiment (ADT_GEMM_STAGGER=<s_memtime ticks>): every second workgroup of an XCD group starts late
   unsigned* sched; unsigned sched_total[8];  // persistent kernels: per-XCD-group work counters (16 words apart, zero between launches) and the number of tickets each hands out in this launch
 };
 
@@ -578,6 +579,16 @@ __device__ __forceinline__ unsigned take_ticket(unsigned* counter, unsigned tota
 // DMAs are issued before this tile's epilogue, which works from a separate 32 KiB of wave-private LDS: the epilogue's
 // LDS transposes, activation math and global stores hide the next tile's DMA latency (and there is no workgroup
 // turn-around between tiles).
+#ifdef ADT_GEMM_EXPERIMENT      // tile timeline of four workgroups of XCD group 0 (tools/probe/gemm_tile_stamps.py): s_memtime at K-loop start / end, epilogue end, tile end
+__device__ unsigned long long g_gemm_stamps[4][16][4];
+#define ADT_GSTAMP(K)                                                                                   \
+  do {                                                                                                  \
+    if ((blockIdx.x & 7) == 0 && blockIdx.x < 32 && stamp_tile < 16 && tid == 0)                          \
+      g_gemm_stamps[blockIdx.x >> 3][stamp_tile][K] = __builtin_amdgcn_s_memtime();                     \
+  } while (0)
+#else
+#define ADT_GSTAMP(K) do { } while (0)
+#endif
 template <bool kDrop, bool kColsum, unsigned kMask>
 __global__ __launch_bounds__(kBigThreads) void gemm_nt_256_kernel(GemmArgs g, int tiles_m, int tiles_n) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -641,6 +652,10 @@ __global__ __launch_bounds__(kBigThreads) void gemm_nt_256_kernel(GemmArgs g, in
   const unsigned b_k0 = base0 + 2 * kHalfTile + b_row + c0, b_k1 = base0 + 2 * kHalfTile + b_row + c1;
 
   unsigned* const flag = reinterpret_cast<unsigned*>(smem + kBigBuf + kHalfTile);
+  if (g.stagger > 0 && ((blockIdx.x >> 3) & 1) && tid == 0) {          // experiment: half of an XCD's workgroups half a tile behind the others
+    const unsigned long long t0 = __builtin_amdgcn_s_memtime();
+    while (__builtin_amdgcn_s_memtime() - t0 < static_cast<unsigned long long>(g.stagger)) __builtin_amdgcn_s_sleep(16);
+  }
   if (tid == 0) *flag = take_ticket(counter, ctotal);
   __syncthreads();
   int v = static_cast<int>(*flag), m0, n0;
@@ -676,7 +691,11 @@ __global__ __launch_bounds__(kBigThreads) void gemm_nt_256_kernel(GemmArgs g, in
     ct_r[pass] = lds_addr(ct) + static_cast<unsigned>((lr * 64 + ((((lane & 7) >> 1) ^ ((lr >> 2) & 3)) << 4) + (lane & 1) * 8) * 4);
   }
 
+#ifdef ADT_GEMM_EXPERIMENT
+  int stamp_tile = 0;
+#endif
   while (true) {
+    ADT_GSTAMP(0);
     f32x4 acc[8][4];
 #pragma unroll
     for (int i = 0; i < 8; ++i)
@@ -739,6 +758,7 @@ __global__ __launch_bounds__(kBigThreads) void gemm_nt_256_kernel(GemmArgs g, in
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     if (wr == 0) asm volatile("s_barrier" ::: "memory");
     asm volatile("s_barrier" ::: "memory");            // every DMA has landed and every fragment read is done: staging is free
+    ADT_GSTAMP(1);
     const int em0 = m0, en0 = n0;
     if (tid == 0) { ticket_drawn(counter, v_next, ctotal); *flag = v_next; }
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
@@ -803,6 +823,7 @@ __global__ __launch_bounds__(kBigThreads) void gemm_nt_256_kernel(GemmArgs g, in
         *reinterpret_cast<float4*>(cp + 4) = float4{csL[4], csL[5], csL[6], csL[7]};
       }
     }
+    ADT_GSTAMP(2);
     if (!more) break;
     // The next tile's first k-tiles have landed.  vmcnt retires in issue order and the prologue DMAs are older than everything the
     // epilogue issued, so on an interior tile -- where each of the 16 epilogue_apply8 calls above issued at least one store -- the 16
@@ -811,6 +832,10 @@ __global__ __launch_bounds__(kBigThreads) void gemm_nt_256_kernel(GemmArgs g, in
     if (g.tail_stores && em0 + kBig <= g.M && en0 + kBig <= g.N) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
     else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     asm volatile("s_barrier" ::: "memory");
+    ADT_GSTAMP(3);
+#ifdef ADT_GEMM_EXPERIMENT
+    ++stamp_tile;
+#endif
   }
 #undef ADT_MFMA_QUAD
 }
@@ -1672,6 +1697,7 @@ extern "C" int adt_gemm_bf16(int32_t trans, int64_t M, int64_t N, int64_t K, con
     static const int group_env = getenv("ADT_GEMM_GROUP_N") ? atoi(getenv("ADT_GEMM_GROUP_N")) : 0;
     const int group_n = group_env > 0 ? group_env : 3;       // measured in the layer sequence (tools/exp_gemm_instep.py): 3 columns -> QKV 0.231 -> 0.210 ms, the others unchanged
     g.group_n = group_n < tn ? group_n : tn;
+    { const char* sg = getenv("ADT_GEMM_STAGGER"); g.stagger = sg ? atoi(sg) : 0; }
     static const bool log_forms = getenv("ADT_GEMM_LOG_FORMS") != nullptr;      // debugging aid: which forms does a workload launch?
     const unsigned mask = epilogue_mask(e);
     if (log_forms) fprintf(stderr, "adt_gemm nt256 form: drop=%d colsum=%d mask=0x%x M=%ld N=%ld K=%ld\n", g.drop.on() ? 1 : 0, e.colsum_out ? 1 : 0, mask, (long)M, (long)N, (long)K);
@@ -1682,6 +1708,20 @@ extern "C" int adt_gemm_bf16(int32_t trans, int64_t M, int64_t N, int64_t K, con
     }
     const int rc = dispatch_nt_256(g, e.colsum_out != nullptr, mask, g1, tm, tn, st);
     if (rc) return rc;
+#ifdef ADT_GEMM_EXPERIMENT
+    if (getenv("ADT_GEMM_STAMPS")) {
+      unsigned long long h[4][16][4];
+      ADT_HIP_TRY(hipStreamSynchronize(st));
+      ADT_HIP_TRY(hipMemcpyFromSymbol(h, HIP_SYMBOL(g_gemm_stamps), sizeof(h)));
+      for (int b = 0; b < 4; ++b) {
+        fprintf(stderr, "gemm stamps wg %d (ticks from wg 0's first K loop; per tile: K-loop start, +K loop, +epilogue, +tile-end wait):", 8 * b);
+        for (int t = 0; t < 14; ++t)
+          fprintf(stderr, " [%lld %lld %lld %lld]", static_cast<long long>(h[b][t][0] - h[0][0][0]), static_cast<long long>(h[b][t][1] - h[b][t][0]),
+                  static_cast<long long>(h[b][t][2] - h[b][t][1]), static_cast<long long>(h[b][t][3] - h[b][t][2]));
+        fprintf(stderr, "\n");
+      }
+    }
+#endif
     if (e.colsum_out) {
       if (cs_slice) {
         if (int rc2 = reduce_queue_push(cs_slice, 2 * tm, g.N, e.colsum_out, nullptr, nullptr, g.N)) return rc2;
