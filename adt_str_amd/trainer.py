@@ -233,35 +233,48 @@ def install_engine_reduction(ddp_model, accumulation_steps: int = 1, timing: boo
     layer: all but the last ~31 MB travel under the remaining backward kernels), the bridge returns the averaged gradients, and DDP gets a
     comm hook that passes a bucket through when the engine has already averaged this pass (and runs the ordinary all-reduce otherwise:
     inside ``no_sync()`` nothing is sent by either, and with gradient accumulation the engine leaves the reduction to DDP, which reduces the
-    accumulated sum on the last micro-step).  Idempotent; returns the reducer (None when not applicable)."""
+    accumulated sum on the last micro-step).  Idempotent -- call it before every pass (``ADTTrainer.compute_loss`` does): it re-attaches the
+    reducer when the model's engine object has been replaced; returns the reducer (None when not applicable)."""
     from torch.distributed.algorithms.ddp_comm_hooks import default_hooks
     from torch.nn.parallel import DistributedDataParallel as DDP
     if not isinstance(ddp_model, DDP) or not hasattr(ddp_model.module, "engine"):
         return None
-    eng = ddp_model.module.engine
-    if getattr(eng, "_hf_hook_installed", False):
-        return eng.hf_reducer
-    eng._hf_hook_installed = True
     pg = ddp_model.process_group
-    if accumulation_steps <= 1:
-        gflat, _ = eng.grad_buffers()
-        red = GradReducer(gflat, pg, timing=timing)
-        eng.hf_reducer = red
-        eng.hf_sync = lambda: bool(ddp_model.require_backward_grad_sync)
-        eng.grad_ready_hook = red.segment_ready
-    stats = {"passed_through": 0, "reduced_by_ddp": 0}
-    eng.hf_hook_stats = stats
 
-    def hook(state, bucket):
-        if eng.reduced_generation == eng.generation:              # this pass's gradients arrived averaged: nothing to send
-            stats["passed_through"] += 1
-            fut = torch.futures.Future()
-            fut.set_result(bucket.buffer())
-            return fut
-        stats["reduced_by_ddp"] += 1
-        return default_hooks.allreduce_hook(pg, bucket)
+    def attach(eng):
+        """Hook a GradReducer to THIS engine object (``ADTModel._apply`` -- .to() / .float() -- and ``set_precision`` build a new one: the
+        reducer, the sync predicate and the pass counters live on the engine, so a rebuilt engine starts without them)."""
+        if getattr(eng, "_hf_hook_installed", False):
+            return
+        eng._hf_hook_installed = True
+        if accumulation_steps <= 1:
+            gflat, _ = eng.grad_buffers()
+            red = GradReducer(gflat, pg, timing=timing)
+            eng.hf_reducer = red
+            eng.hf_sync = lambda: bool(ddp_model.require_backward_grad_sync)
+            eng.grad_ready_hook = red.segment_ready
+        eng.hf_hook_stats = ddp_model._adt_hook_stats
 
-    ddp_model.register_comm_hook(None, hook)
+    if not hasattr(ddp_model, "_adt_hook_stats"):
+        # one comm hook per DDP wrapper; it looks the engine up on every call, so it never tests a replaced engine's frozen counters (which
+        # would pass every bucket through unreduced and let the ranks diverge silently)
+        stats = {"passed_through": 0, "reduced_by_ddp": 0}
+        ddp_model._adt_hook_stats = stats
+
+        def hook(state, bucket):
+            eng = ddp_model.module.engine
+            attach(eng)                                               # (a rebuilt engine: engine-driven from its next pass on)
+            if getattr(eng, "hf_reducer", None) is not None and eng.reduced_generation == eng.generation:   # this pass's gradients arrived averaged
+                stats["passed_through"] += 1
+                fut = torch.futures.Future()
+                fut.set_result(bucket.buffer())
+                return fut
+            stats["reduced_by_ddp"] += 1
+            return default_hooks.allreduce_hook(pg, bucket)
+
+        ddp_model.register_comm_hook(None, hook)
+    eng = ddp_model.module.engine
+    attach(eng)
     return eng.hf_reducer
 
 

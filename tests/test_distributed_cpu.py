@@ -184,27 +184,33 @@ def _hf_overlap_worker(rank, world, port, q, accumulation):
         torch.manual_seed(0)
         model = ADTModel(ADTModelConfig(input_sec=0.5, time_res=0.01, win_length=2048, sample_rate=16000, enc_layers=2, dec_layers=1,
                                         nhead=1, d_query=128, dropout=0.0, tgt_vocab_size=1400, plain=True, n_mels=128))
-        eng = model.engine
-        gflat, _ = eng.grad_buffers()
-        n = gflat.numel()
-        base = (torch.arange(n, dtype=torch.float32) % 997) * 1e-3
         events = []                                             # ("collective", t) / ("backward_end", t)
         calls = {"n": 0}
 
-        def fake_loss_and_grads(src, tgt, pad, labels, want_grads=True, return_logits=False):
-            calls["n"] += 1
-            eng.generation += 1
-            gflat.copy_(base * (rank + 1) * calls["n"])          # this rank's local gradient of this pass
-            for pre in ("decoder.",) + tuple(L["p"] + "." for L in reversed(eng.enc)):
-                time.sleep(0.01)                                 # the rest of the backward pass is still running ...
-                eng._ready(pre)                                  # ... when this segment is final
-            eng._ready("encoder.dense_layer.", "encoder.layer_norm.", "project_to_mel.")
-            events.append(("backward_end", time.perf_counter()))
-            return {"loss": torch.tensor([float(rank + 1)])[0]}
+        def stand_in(eng):
+            """Replace this engine object's kernels by the stand-in (a rebuilt engine -- .to() / set_precision -- needs it again)."""
+            gflat, _ = eng.grad_buffers()
 
-        eng.loss_and_grads = fake_loss_and_grads
-        eng.refresh_weights = lambda force=False: None
-        eng._flush_reductions = lambda: None
+            def fake_loss_and_grads(src, tgt, pad, labels, want_grads=True, return_logits=False):
+                calls["n"] += 1
+                eng.generation += 1
+                gflat.copy_(base * (rank + 1) * calls["n"])      # this rank's local gradient of this pass
+                for pre in ("decoder.",) + tuple(L["p"] + "." for L in reversed(eng.enc)):
+                    time.sleep(0.01)                             # the rest of the backward pass is still running ...
+                    eng._ready(pre)                              # ... when this segment is final
+                eng._ready("encoder.dense_layer.", "encoder.layer_norm.", "project_to_mel.")
+                events.append(("backward_end", time.perf_counter()))
+                return {"loss": torch.tensor([float(rank + 1)])[0]}
+
+            eng.loss_and_grads = fake_loss_and_grads
+            eng.refresh_weights = lambda force=False: None
+            eng._flush_reductions = lambda: None
+            return gflat
+
+        eng = model.engine
+        n = eng.grad_buffers()[0].numel()
+        base = (torch.arange(n, dtype=torch.float32) % 997) * 1e-3
+        gflat = stand_in(eng)
         real_all_reduce = dist.all_reduce
 
         def counting_all_reduce(t, *a, **k):
@@ -243,6 +249,22 @@ def _hf_overlap_worker(rank, world, port, q, accumulation):
             assert not [e for e in events if e[0] == "collective"]
             got = torch.cat([p.grad.reshape(-1) for p in eng.named.values()])
             assert torch.allclose(got, base * (rank + 1) * 2, rtol=1e-6)
+            # the model's engine object is REPLACED (set_precision / .to() / .float() do that): the comm hook must not go on testing the old
+            # engine's frozen counters (it would pass every bucket through unreduced and the ranks would diverge).  Even if nobody calls
+            # install_engine_reduction again, the first pass of the new engine is reduced by DDP itself and the later ones by the engine.
+            model.set_precision("bf16")
+            eng2 = model.engine
+            assert eng2 is not eng and not getattr(eng2, "_hf_hook_installed", False)
+            stand_in(eng2)
+            before = dict(eng.hf_hook_stats)
+            for k in (3, 4):                                     # calls["n"] is 2 here: passes 3 and 4
+                model.zero_grad(set_to_none=True)
+                events.clear()
+                step()
+                got = torch.cat([p.grad.reshape(-1) for p in eng2.named.values()])
+                assert torch.allclose(got, base * k * (sum(r + 1 for r in range(world)) / world), rtol=1e-6, atol=1e-7), k
+            assert eng2.hf_hook_stats["reduced_by_ddp"] > before["reduced_by_ddp"]        # pass 3: DDP reduced it ...
+            assert eng2.hf_hook_stats["passed_through"] > before["passed_through"] and eng2.hf_reducer is not None   # ... pass 4: the engine did
         else:
             # with accumulation the engine leaves the reduction to DDP: local sums, reduced once on the last micro-step
             step(sync=False)

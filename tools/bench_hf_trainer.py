@@ -67,3 +67,42 @@ for _ in range(10):
     tr.train_step(wavs, tokens, lens)
 torch.cuda.synchronize()
 print(f"native FlatTrainer step (same batch, no mixer): {(time.perf_counter() - t0) * 100:.2f} ms/step")
+
+
+# ---- under a launcher (`torchrun --nproc-per-node 1 tools/bench_hf_trainer.py`): the reference's multi-GPU launch shape -- HF-style step on a
+# DistributedDataParallel wrapper over RCCL -- with the engine-driven per-segment reduction (trainer.install_engine_reduction) and with
+# DDP's own bucketed all-reduce behind the bridge (what the path did before round 4).  At world size 1 neither sends anything; what is
+# timed is the plumbing each arm adds to the step.
+if "RANK" in os.environ and "WORLD_SIZE" in os.environ:
+    import torch.distributed as dist
+    from torch.nn.parallel import DistributedDataParallel as DDP
+    from adt_str_amd.trainer import install_engine_reduction
+    dist.init_process_group("nccl", device_id=dev)
+    for arm in ("engine-driven reduction", "DDP's own all-reduce"):
+        torch.manual_seed(0)
+        m2 = ADTModel(cfg).to(dev).train()
+        ddp = DDP(m2, device_ids=[dev.index], broadcast_buffers=False)
+        if arm.startswith("engine"):
+            install_engine_reduction(ddp, 1)
+        named2 = list(m2.named_parameters())
+        opt2 = FusedAdamW([{"params": [p for n, p in named2 if n not in skip], "weight_decay": 1e-5}, {"params": [p for n, p in named2 if n in skip], "weight_decay": 0.0}],
+                          lr=1e-4, engine=m2.engine)
+
+        def ddp_step():
+            tgt_input, labels = tokens[:, :-1], tokens[:, 1:]
+            _, pad = create_mask_plain(tgt_input.size(1), lens, dev)
+            loss = ddp(src=wavs, tgt=tgt_input, tgt_mask=None, tgt_padding_mask=pad, labels=labels)
+            loss.backward()
+            torch.nn.utils.clip_grad_norm_(m2.parameters(), 1.0)
+            opt2.step()
+            opt2.zero_grad(set_to_none=True)
+
+        for _ in range(3):
+            ddp_step()
+        torch.cuda.synchronize(); t0 = time.perf_counter()
+        for _ in range(10):
+            ddp_step()
+        torch.cuda.synchronize()
+        print(f"HF-style step on DDP over RCCL, world size {dist.get_world_size()}, {arm}: {(time.perf_counter() - t0) * 100:.2f} ms/step", flush=True)
+        del opt2, ddp, m2
+    dist.destroy_process_group()

@@ -43,10 +43,12 @@ class ADTTrainer(Trainer):
     """HF Trainer subclass of the reference (train.py:33-78)."""
 
     def compute_loss(self, model, inputs, return_outputs=False, **kwargs):
-        if not getattr(self, "_engine_reduction_checked", False):           # multi-GPU: `model` is the DDP wrapper accelerate built
+        if getattr(self, "_is_ddp", None) is None:                           # multi-GPU: `model` is the DDP wrapper accelerate built
+            from torch.nn.parallel import DistributedDataParallel
+            self._is_ddp = isinstance(model, DistributedDataParallel)
+        if self._is_ddp:                                                     # (every pass: idempotent, and it follows a replaced engine object)
             from adt_str_amd.trainer import install_engine_reduction
             install_engine_reduction(model, getattr(self.args, "gradient_accumulation_steps", 1))
-            self._engine_reduction_checked = True
         model.train()
         device = next(model.parameters()).device
         tokens = inputs["tokens"].to(device)
