@@ -13,11 +13,12 @@ d = H * 128
 qkv = torch.randn((B * S, 3 * d), device=dev).bfloat16()
 scale = 1 / math.sqrt(128)
 drop = (0.1, 12345) if os.environ.get("ADT_ATTN_DROP", "1") == "1" else None
-o, lse = K.attn_fwd(qkv[:, :d], qkv[:, d:2 * d], qkv[:, 2 * d:], B, H, S, S, scale, drop=drop)
+o, lse = K.attn_fwd(qkv[:, :d], qkv[:, d:2 * d], qkv[:, 2 * d:], B, H, S, S, scale, drop=drop, save_bits=True)     # the product's path: keep bits -> one-kernel backward
 do = torch.randn((B * S, d), device=dev).bfloat16()
 dqkv = torch.empty_like(qkv)
-# the backward path under the counters: ADT_ATTN_BWD as in the product (default: fused without dropout, two kernels with), or forced
+# the backward path under the counters: as in the product (one kernel; with dropout fed by the forward's keep bits), or forced by
+# ADT_ATTN_BWD=split / ADT_ATTN_NO_BITS=1
 for _ in range(4):
-    K.attn_fwd(qkv[:, :d], qkv[:, d:2 * d], qkv[:, 2 * d:], B, H, S, S, scale, drop=drop)
+    K.attn_fwd(qkv[:, :d], qkv[:, d:2 * d], qkv[:, 2 * d:], B, H, S, S, scale, drop=drop, save_bits=True)
     K.attn_bwd(qkv[:, :d], qkv[:, d:2 * d], qkv[:, 2 * d:], o, do, lse, dqkv[:, :d], dqkv[:, d:2 * d], dqkv[:, 2 * d:], B, H, S, S, scale, drop=drop)
 torch.cuda.synchronize()
