@@ -65,7 +65,9 @@ struct FusedArgs {
 //   nl = -lse / scale [+ log2(1 / (1 - p)) / (scale log2 e) with dropout]: the INITIAL ACCUMULATOR of the score chain, so that
 //        P [/ (1 - p)] = 2^((S + nl) scale log2 e) needs no per-element subtraction (and no per-element keep scale);
 //   nd = -delta [x (1 - p) with dropout]:                 dS = P_dropped dP + (P / (1 - p)) nd  (= P (dP keep / (1 - p) - delta)).
-__global__ __launch_bounds__(256) void attn_bwd_stats_kernel(AttnArgs a, float* __restrict__ stats, int ns) {
+// The same launch zeroes the fan-in's flags (one item per (batch, head, slice) clears that slice's nkb x 4 words, the first item the give-up
+// counter behind them): the backward kernel follows it in stream order, so no separate memset launch is needed.
+__global__ __launch_bounds__(256) void attn_bwd_stats_kernel(AttnArgs a, float* __restrict__ stats, int ns, unsigned* __restrict__ flags, int nkb) {
   const int tid = threadIdx.x, c = tid & 15;
   const int sqp = ns * kFbSlice;
   const long item = static_cast<long>(blockIdx.x) * 16 + (tid >> 4);          // (b, q, head), head fastest: one row's heads are neighbours
@@ -94,6 +96,11 @@ __global__ __launch_bounds__(256) void attn_bwd_stats_kernel(AttnArgs a, float* 
     sl[0] = nl;
     sl[32] = nd;
   }
+  if ((q & 31) == 0 && c < 4 * nkb) {                              // (nkb <= 16 on this path: at most 64 words per slice, 16 lanes x up to 4)
+    unsigned* fl = flags + ((static_cast<long>(b) * a.H + head) * ns + (q >> 5)) * nkb * 4;
+    for (int w = c; w < 4 * nkb; w += 16) fl[w] = 0u;
+  }
+  if (item == 0 && c < 4) flags[static_cast<long>(a.B) * a.H * ns * nkb * 4 + c] = 0u;
 }
 
 // one 32-d block of a transposed-read A (or B) operand: rows R0 + 8 (j >> 2) + 4 h + (j & 3) of a swizzled 256-byte-row image
@@ -882,9 +889,9 @@ int launch_attn_bwd_fused(const adt_attn_desc* d, const AttnArgs& a, void* ws, s
   fa.stats = stats;
   p += align256(bh * ns * kFbSlice * 2 * 4);
   fa.part = reinterpret_cast<float*>(p);
-  ADT_HIP_TRY(hipMemsetAsync(fa.flags, 0, flag_bytes, st));
   const long items = static_cast<long>(bh) * ns * kFbSlice;
-  hipLaunchKernelGGL(attn_bwd_stats_kernel, dim3(static_cast<unsigned>((items + 15) / 16)), dim3(256), 0, st, a, stats, fa.ns);
+  (void)flag_bytes;
+  hipLaunchKernelGGL(attn_bwd_stats_kernel, dim3(static_cast<unsigned>((items + 15) / 16)), dim3(256), 0, st, a, stats, fa.ns, fa.flags, fa.nkb);
   const long n_tiles = static_cast<long>(fa.nkb) * static_cast<long>(bh);
   for (int x = 0; x < 8; ++x) fa.sched_total[x] = static_cast<unsigned>(n_tiles / 8 + (x < n_tiles % 8 ? 1 : 0));
   if (fa.dbg & 16) fa.sched_total[0] = static_cast<unsigned>(n_tiles);

@@ -217,7 +217,9 @@ def main(argv=None):
         out["bins_used"] = sorted(set(res.bin))
     if a.check_resume:
         dirs = _checkpoint_dirs(run_dir)
-        src = dirs[-2] if len(dirs) > 1 and int(dirs[-1].rsplit("-", 1)[1]) == tr.step_no else dirs[-1]
+        # a MID-epoch checkpoint: of the ones that are left, the one closest to half of the epoch (never the one written at the last step)
+        cands = [d for d in dirs if int(d.rsplit("-", 1)[1]) < tr.step_no] or dirs
+        src = min(cands, key=lambda d: abs(int(d.rsplit("-", 1)[1]) - tr.step_no / 2))
         final = tr.pflat.clone()
         cfg["checkpoint"]["resume_from_checkpoint"] = src
         model2, ds2 = build()
