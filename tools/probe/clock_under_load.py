@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""What shader clock and board power does the chip hold under this repo's kernels?  A thread polls rocm-smi (sclk, average power) while the
+"""What shader clock and board power does the chip hold under this repo's kernels?  A thread reads the card's hwmon node in sysfs (sclk, average power) while the
 main thread runs a bare 256^2-tile NT GEMM, the FFN-1 form, the attention forward / backward and whole training steps, each for ~2 s.
 The MFMA peak the roofline is priced against (2.5 PFLOP/s bf16) assumes 2.4 GHz; what a kernel can reach scales with the clock it gets."""
 import json
@@ -20,16 +20,16 @@ stop = False
 
 
 def poll():
+    """In-process sysfs reads (bench.ClockPoll's nodes): no rocm-smi child processes (those are python scripts: under a profiler they are
+    the exec-after-GPU-init hop the pool forbids)."""
+    import bench
+    freq, power = bench.ClockPoll.find_nodes(0, bench.ClockPoll.pci_address(0))
     while not stop:
         try:
-            out = subprocess.run(["rocm-smi", "-d", "0", "--showclocks", "--showpower", "--json"], capture_output=True, text=True, timeout=5).stdout
-            j = json.loads(out)
-            card = j[sorted(j)[0]]
-            sclk = next((v for k, v in card.items() if "sclk" in k.lower()), "")
-            pw = next((v for k, v in card.items() if "power" in k.lower()), "")
-            m = re.search(r"(\d+)\s*Mhz", str(sclk), re.I)
-            samples.append((time.time(), int(m.group(1)) if m else -1, float(re.sub(r"[^0-9.]", "", str(pw)) or -1)))
-        except Exception as e:          # noqa: BLE001
+            mhz = bench.ClockPoll._read_mhz(freq)
+            watts = bench.ClockPoll._read(power) / 1e6 if power else -1.0
+            samples.append((time.time(), int(round(mhz)), watts))
+        except Exception:          # noqa: BLE001
             samples.append((time.time(), -1, -1.0))
         time.sleep(0.05)
 
