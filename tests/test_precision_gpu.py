@@ -291,9 +291,9 @@ def test_fp32_with_dropout_matches_the_oracle_with_the_same_masks():
 
 
 # ----------------------------------------------------------------------------- BASELINE config[3] at full size
-def _setting1(precision):
+def _setting1(precision, input_sec=10.0, sample_rate=16000):
     from adt_str_amd.network import ADTModel, ADTModelConfig
-    cfg = ADTModelConfig(input_sec=10.0, time_res=0.01, win_length=2048, sample_rate=16000, enc_layers=4, dec_layers=4, nhead=6,
+    cfg = ADTModelConfig(input_sec=input_sec, time_res=0.01, win_length=2048, sample_rate=sample_rate, enc_layers=4, dec_layers=4, nhead=6,
                          d_query=128, dropout=0.0, tgt_vocab_size=1400, plain=True, n_mels=128)
     model = ADTModel(cfg).set_precision(precision)
     state = o_adt.seeded_state(model.state_dict(), 0)
@@ -301,15 +301,15 @@ def _setting1(precision):
     return model.to(DEV).train(), state
 
 
-def _config3_batch(B=64, L=160000, T=128, seed=11):
+def _config3_batch(B=64, L=160000, T=128, seed=11, sr=16000):
     rng = np.random.default_rng(seed)
-    t = np.arange(L, dtype=np.float32) / 16000.0
+    t = np.arange(L, dtype=np.float32) / float(sr)
     wave = np.zeros((B, L), np.float32)
     for b in range(B):                                     # decaying bursts on a noise floor: drum-like, non-trivial spectra
         w = rng.standard_normal(L).astype(np.float32) * 0.01
-        for onset in rng.uniform(0, 9.5, 24):
-            i0 = int(onset * 16000)
-            n = min(L - i0, 8000)
+        for onset in rng.uniform(0, 0.95 * L / sr, 24):
+            i0 = int(onset * sr)
+            n = min(L - i0, sr // 2)
             w[i0:i0 + n] += (rng.uniform(0.2, 0.9) * np.exp(-t[:n] * rng.uniform(8, 40)) * np.sin(2 * np.pi * rng.uniform(50, 4000) * t[:n])).astype(np.float32)
         wave[b] = np.clip(w, -1, 1)
     lens = rng.integers(32, T + 2, B)
@@ -347,6 +347,37 @@ def test_config3_full_size_step_both_precisions():
         else:
             err = (lg1[:2].cpu() - ref["logits"]).abs().max().item()
             print("config[3] bf16 path vs bf16-operand oracle, clips 0-1: max |dlogit|", err)
+            assert err < 6e-2
+        del model, eng, out, again
+        torch.cuda.empty_cache()
+
+
+def test_reference_native_operating_point_both_precisions():
+    """The reference's OWN operating point (configs/train/setting-1.yaml:9-11: 2.56 s clips @ 24 kHz -> hop 240, F = 246 frames), setting-1
+    network, B = 64, T = 128, dropout 0: the same checks as at config[3] -- finite, bit-repeatable, and clips 0-1 of the full batch against
+    the oracle run on those two clips, in both precisions.  (A different regime for the kernels: M = 15 744 rows instead of 63 104,
+    attention 246 x 246 -- one key block, the two-kernel backward -- and a 24 kHz filterbank.)"""
+    sr, L = 24000, 61440
+    batch = _config3_batch(L=L, seed=12, sr=sr)
+    two = {k: v[:2] for k, v in batch.items()}
+    cfg = dict(nhead=6, sample_rate=sr, win_length=2048, time_res=0.01, n_mels=128)
+    for precision in ("fp32", "bf16"):
+        model, state = _setting1(precision, input_sec=2.56, sample_rate=sr)
+        out = run_engine(model, batch)
+        eng = model.engine
+        assert out["logits"].shape == (64, 128, 1400) and out["memory"].shape[0] == 64 * 246
+        assert bool(torch.isfinite(out["logits"]).all()) and math.isfinite(out["loss"].item()) and bool(torch.isfinite(eng.gflat).all())
+        l1, g1, lg1 = out["loss"].clone(), eng.gflat.clone(), out["logits"].clone()
+        again = run_engine(model, batch)
+        assert torch.equal(again["loss"], l1) and torch.equal(eng.gflat, g1) and torch.equal(again["logits"], lg1)
+        ref = o_adt.compute_loss(state, cfg, two, bf16=(precision == "bf16"))
+        if precision == "fp32":
+            print("native operating point, fp32 path vs fp32 oracle, clips 0-1: max |dlogit| / max |logit|",
+                  ((lg1[:2].cpu() - ref["logits"]).abs().max() / ref["logits"].abs().max()).item())
+            assert_logits_close(lg1[:2], ref["logits"])
+        else:
+            err = (lg1[:2].cpu() - ref["logits"]).abs().max().item()
+            print("native operating point, bf16 path vs bf16-operand oracle, clips 0-1: max |dlogit|", err)
             assert err < 6e-2
         del model, eng, out, again
         torch.cuda.empty_cache()
