@@ -744,7 +744,13 @@ extern "C" int adt_attn_bwd(const adt_attn_desc* d, const void* q, const void* k
   const bool use_fused = wants_fused(d) && fused_ok;          // (see wants_fused / fused_can_run above)
   if (use_fused) {
     const size_t off = split_workspace_bytes(d);
-    if (int rc = launch_attn_bwd_fused(d, a, static_cast<unsigned char*>(ws) + off, ws_bytes - off, st)) return rc;
+    // the 8-wave form (attention_bwd_fused8.hip: two waves per SIMD, one 32-key block per wave) takes keep bits or no dropout;
+    // ADT_ATTN_BWD_WAVES=4 / 8 forces a form (A/B runs, tests)
+    const char* waves_env = getenv("ADT_ATTN_BWD_WAVES");
+    const bool can8 = !(d->drop.p > 0.0f) || d->keep_bits != nullptr;
+    const bool use8 = can8 && (waves_env ? waves_env[0] == '8' : true);
+    if (int rc = use8 ? launch_attn_bwd_fused8(d, a, static_cast<unsigned char*>(ws) + off, ws_bytes - off, st)
+                      : launch_attn_bwd_fused(d, a, static_cast<unsigned char*>(ws) + off, ws_bytes - off, st)) return rc;
     if (want_cs) {
       // bias gradient of the in-projection: column sums of the stored dQ and dV (one pass each); dK's vanish identically (the rows of dS
       // sum to zero), so exact zeros are written instead of rounding noise

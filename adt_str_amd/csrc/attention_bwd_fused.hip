@@ -50,16 +50,6 @@ constexpr int kFbOffBits = kFbOffFlag + 16;         // keep bits of the slice (k
 constexpr int kFbLds = kFbOffBits + 2 * 1024;       // 150,032 B
 constexpr unsigned kFbSpinLimit = 1u << 24;         // polls of ~0.3 us each before a wave gives up (and reports it)
 
-struct FusedArgs {
-  AttnArgs a;
-  const float* stats;                 // [B*H][ns][2][32]: nl of the slice's queries, then nd (attn_bwd_stats_kernel)
-  float* part;                        // [B*H][ns][nkb][4 waves][1024]: every key block's dQ^T tile of every slice (nkb > 1)
-  unsigned* flags;                    // [B*H][ns][nkb][4 waves] + 4 words: [0] of the tail = number of waves that gave up waiting
-  unsigned* sched; unsigned sched_total[8];
-  int nkb, ns;
-  unsigned long long* stamps;         // experiment build, kDbg & 32: cycle stamps of one wave's phases in one slice
-  int dbg;                            // timing experiments only (ADT_FB_DBG): 1 no hand-off, 2 no dQ product, 4 no dV / dK products, 8 no S / dP chains
-};
 
 // Per (batch, head, query), queries padded to whole slices ({-1e30, 0}: P = 0 there):
 //   nl = -lse / scale [+ log2(1 / (1 - p)) / (scale log2 e) with dropout]: the INITIAL ACCUMULATOR of the score chain, so that
@@ -855,8 +845,46 @@ size_t attn_bwd_fused_workspace_bytes(const adt_attn_desc* d) {
   return bytes;
 }
 
-int launch_attn_bwd_fused(const adt_attn_desc* d, const AttnArgs& a, void* ws, size_t ws_bytes, hipStream_t st) {
+// Carves the workspace, launches the statistics kernel (which also zeroes the fan-in's flags) and fills the arguments both one-kernel
+// backward forms share (this file's 4-wave kernel, attention_bwd_fused8.hip's 8-wave one).
+int attn_bwd_fused_prepare(const adt_attn_desc* d, const AttnArgs& a, void* ws, size_t ws_bytes, hipStream_t st, FusedArgs* out) {
   if (ws_bytes < attn_bwd_fused_workspace_bytes(d) || !aligned16(ws)) return set_error(ADT_EINVAL, "adt_attn_bwd: workspace too small");
+  FusedArgs fa{};
+  fa.a = a;
+  fa.ns = fused_ns(d);
+  fa.nkb = fused_nkb(d);
+  { const char* e = getenv("ADT_FB_DBG"); fa.dbg = e ? atoi(e) : 0; }
+  const size_t bh = static_cast<size_t>(d->batch) * d->heads, ns = static_cast<size_t>(fa.ns);
+  unsigned char* p = static_cast<unsigned char*>(ws);
+  const size_t flag_bytes = align256(bh * ns * static_cast<size_t>(fa.nkb) * 4 * 4 + 16);
+  fa.stamps = reinterpret_cast<unsigned long long*>(static_cast<unsigned char*>(ws) + attn_bwd_fused_workspace_bytes(d) - 128);
+  fa.flags = reinterpret_cast<unsigned*>(p);
+  p += flag_bytes;
+  float* stats = reinterpret_cast<float*>(p);
+  fa.stats = stats;
+  p += align256(bh * ns * kFbSlice * 2 * 4);
+  fa.part = reinterpret_cast<float*>(p);
+  const long items = static_cast<long>(bh) * ns * kFbSlice;
+  hipLaunchKernelGGL(attn_bwd_stats_kernel, dim3(static_cast<unsigned>((items + 15) / 16)), dim3(256), 0, st, a, stats, fa.ns, fa.flags, fa.nkb);
+  const long n_tiles = static_cast<long>(fa.nkb) * static_cast<long>(bh);
+  for (int x = 0; x < 8; ++x) fa.sched_total[x] = static_cast<unsigned>(n_tiles / 8 + (x < n_tiles % 8 ? 1 : 0));
+  if (fa.dbg & 16) fa.sched_total[0] = static_cast<unsigned>(n_tiles);
+  if (int rc = sched_counters(st, &fa.sched)) return rc;
+  *out = fa;
+  return ADT_OK;
+}
+// the give-up check both forms end with (tests / debugging: ADT_ATTN_BWD_CHECK=1)
+int attn_bwd_fused_check(const FusedArgs& fa, hipStream_t st) {
+  if (!getenv("ADT_ATTN_BWD_CHECK")) return ADT_OK;
+  const size_t bh = static_cast<size_t>(fa.a.B) * fa.a.H, ns = static_cast<size_t>(fa.ns);
+  unsigned gave_up = 0;
+  ADT_HIP_TRY(hipStreamSynchronize(st));
+  ADT_HIP_TRY(hipMemcpy(&gave_up, fa.flags + bh * ns * static_cast<size_t>(fa.nkb) * 4, sizeof(gave_up), hipMemcpyDeviceToHost));
+  if (gave_up) return set_error(ADT_EHIP, "adt_attn_bwd: waves of the one-kernel backward gave up waiting for a dQ tile (result incomplete)");
+  return ADT_OK;
+}
+
+int launch_attn_bwd_fused(const adt_attn_desc* d, const AttnArgs& a, void* ws, size_t ws_bytes, hipStream_t st) {
   static thread_local int lds_done_for = -1;
   int dev = 0;
   ADT_HIP_TRY(hipGetDevice(&dev));
@@ -875,27 +903,9 @@ int launch_attn_bwd_fused(const adt_attn_desc* d, const AttnArgs& a, void* ws, s
     lds_done_for = dev;
   }
   FusedArgs fa{};
-  fa.a = a;
-  fa.ns = fused_ns(d);
-  fa.nkb = fused_nkb(d);
-  { const char* e = getenv("ADT_FB_DBG"); fa.dbg = e ? atoi(e) : 0; }
-  const size_t bh = static_cast<size_t>(d->batch) * d->heads, ns = static_cast<size_t>(fa.ns);
-  unsigned char* p = static_cast<unsigned char*>(ws);
-  const size_t flag_bytes = align256(bh * ns * static_cast<size_t>(fa.nkb) * 4 * 4 + 16);
-  fa.stamps = reinterpret_cast<unsigned long long*>(static_cast<unsigned char*>(ws) + attn_bwd_fused_workspace_bytes(d) - 128);
-  fa.flags = reinterpret_cast<unsigned*>(p);
-  p += flag_bytes;
-  float* stats = reinterpret_cast<float*>(p);
-  fa.stats = stats;
-  p += align256(bh * ns * kFbSlice * 2 * 4);
-  fa.part = reinterpret_cast<float*>(p);
-  const long items = static_cast<long>(bh) * ns * kFbSlice;
-  (void)flag_bytes;
-  hipLaunchKernelGGL(attn_bwd_stats_kernel, dim3(static_cast<unsigned>((items + 15) / 16)), dim3(256), 0, st, a, stats, fa.ns, fa.flags, fa.nkb);
+  if (int rc = attn_bwd_fused_prepare(d, a, ws, ws_bytes, st, &fa)) return rc;
+  const size_t bh = static_cast<size_t>(d->batch) * d->heads;
   const long n_tiles = static_cast<long>(fa.nkb) * static_cast<long>(bh);
-  for (int x = 0; x < 8; ++x) fa.sched_total[x] = static_cast<unsigned>(n_tiles / 8 + (x < n_tiles % 8 ? 1 : 0));
-  if (fa.dbg & 16) fa.sched_total[0] = static_cast<unsigned>(n_tiles);
-  if (int rc = sched_counters(st, &fa.sched)) return rc;
   bool launched = false;
 #define ADT_FB_LAUNCH(N)                                                                                                                    \
   if (!launched && fa.dbg == N) {                                                                                                           \
@@ -908,12 +918,7 @@ int launch_attn_bwd_fused(const adt_attn_desc* d, const AttnArgs& a, void* ws, s
 #undef ADT_FB_LAUNCH
   if (!launched) return set_error(ADT_EINVAL, "adt_attn_bwd: ADT_FB_DBG value not built (experiment build only)");
   ADT_HIP_TRY(hipGetLastError());
-  if (getenv("ADT_ATTN_BWD_CHECK")) {                               // tests / debugging: a wave that gave up waiting for a tile left dQ incomplete
-    unsigned gave_up = 0;
-    ADT_HIP_TRY(hipStreamSynchronize(st));
-    ADT_HIP_TRY(hipMemcpy(&gave_up, fa.flags + bh * ns * static_cast<size_t>(fa.nkb) * 4, sizeof(gave_up), hipMemcpyDeviceToHost));
-    if (gave_up) return set_error(ADT_EHIP, "adt_attn_bwd: waves of the one-kernel backward gave up waiting for a dQ tile (result incomplete)");
-  }
+  if (int rc = attn_bwd_fused_check(fa, st)) return rc;
   return ADT_OK;
 }
 

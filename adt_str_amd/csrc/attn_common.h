@@ -259,7 +259,22 @@ __device__ __forceinline__ float mask_add(const AttnArgs& a, int qi, int ki, int
 // attention_fwd.hip: the software-pipelined forward (tiled shapes; the one-query decode kernel stays in attention.hip)
 int launch_attn_fwd2(const AttnArgs& a, hipStream_t st);
 // attention_bwd_fused.hip: the one-kernel backward (5 products, ordered dQ hand-off); its workspace region and launcher
+// arguments of the one-kernel backward forms (attention_bwd_fused.hip, attention_bwd_fused8.hip)
+struct FusedArgs {
+  AttnArgs a;
+  const float* stats;                 // [B*H][ns][2][32]: nl of the slice's queries, then nd (attn_bwd_stats_kernel)
+  float* part;                        // [B*H][ns][nkb][4 waves][1024]: every key block's dQ^T tile of every slice (nkb > 1)
+  unsigned* flags;                    // [B*H][ns][nkb][4 waves] + 4 words: [0] of the tail = number of waves that gave up waiting
+  unsigned* sched; unsigned sched_total[8];
+  int nkb, ns;
+  unsigned long long* stamps;         // experiment build, kDbg & 32: cycle stamps of one wave's phases in one slice
+  int dbg;                            // timing experiments only (ADT_FB_DBG): 1 no hand-off, 2 no dQ product, 4 no dV / dK products, 8 no S / dP chains
+};
+
 size_t attn_bwd_fused_workspace_bytes(const adt_attn_desc* d);
+int attn_bwd_fused_prepare(const adt_attn_desc* d, const AttnArgs& a, void* ws, size_t ws_bytes, hipStream_t st, FusedArgs* out);
+int attn_bwd_fused_check(const FusedArgs& fa, hipStream_t st);
+int launch_attn_bwd_fused8(const adt_attn_desc* d, const AttnArgs& a, void* ws, size_t ws_bytes, hipStream_t st);
 int launch_attn_bwd_fused(const adt_attn_desc* d, const AttnArgs& a, void* ws, size_t ws_bytes, hipStream_t st);
 
 }  // namespace adt
