@@ -185,12 +185,17 @@ __global__ __launch_bounds__(kFbThreads, 1) void attn_bwd_fused8_kernel(FusedArg
   // `^ 32 s` / `^ 64 db` (attention.hip, dK/dV kernel).
   const unsigned smem_base = lds_off(smem);
   unsigned rowbase = smem_base + static_cast<unsigned>(256 * r + 16 * (h ^ (((r & 3) << 2) | ((r >> 2) & 3))));
-  unsigned trbase, xbase;
-  {
-    const int i = lane & 15, g4 = (lane >> 4) & 1, row = 4 * h + (i >> 2);
-    trbase = smem_base + static_cast<unsigned>(8 * (i & 1) + swz(row, 2 * g4 + ((i & 3) >> 1)));
-    xbase = smem_base + static_cast<unsigned>(8 * (i & 1) + 64 * row + 16 * ((2 * g4 + ((i & 3) >> 1)) ^ h));
-  }
+  // Lane constants that only one phase uses are RE-MADE there from the lane number (a few integer instructions per slice) instead of
+  // living in registers across the S' / dP chain, which has none to spare (128 + 128 at two waves per SIMD).
+  auto lane_now = [&]() { int l = lane; asm volatile("" : "+v"(l)); return l; };
+  auto make_trbase = [&](int l) {         // transposed reads of the Q | dO tiles and of the K image (dV / dK products, dQ product)
+    const int i = l & 15, g4 = (l >> 4) & 1, row = 4 * (l >> 5) + (i >> 2);
+    return smem_base + static_cast<unsigned>(8 * (i & 1) + swz(row, 2 * g4 + ((i & 3) >> 1)));
+  };
+  auto make_xbase = [&](int l) {          // transposed reads of the dS^T image (dQ product)
+    const int i = l & 15, g4 = (l >> 4) & 1, hh = l >> 5, row = 4 * hh + (i >> 2);
+    return smem_base + static_cast<unsigned>(8 * (i & 1) + 64 * row + 16 * ((2 * g4 + ((i & 3) >> 1)) ^ hh));
+  };
 #define ADT_TR2(F, ADDR, IMM)                                                                                                   \
   asm volatile("ds_read_b64_tr_b16 %0, %2 offset:%4\n\tds_read_b64_tr_b16 %1, %3 offset:%5"                                     \
                : "=&v"((F).lo), "=&v"((F).hi) : "v"(ADDR), "v"((ADDR) ^ 32u), "i"(IMM), "i"((IMM) + 2048) : "memory")
@@ -259,8 +264,9 @@ __global__ __launch_bounds__(kFbThreads, 1) void attn_bwd_fused8_kernel(FusedArg
       }
     }
   };
-  const unsigned stash_a = smem_base + static_cast<unsigned>(kFbOffStash + grp * 4096 + lane * 16);
+  auto stash_of = [&](int l) { return smem_base + static_cast<unsigned>(kFbOffStash + grp * 4096 + l * 16); };
   auto add_step_from = [&](int jr, int n, unsigned land_a) {       // running sum (+)= landed tile (at LDS address land_a + 1024 g); the last step stores dQ
+    const unsigned stash_a = stash_of(lane_now());
     f32x4 o[4], q4[4];
 #pragma unroll
     for (int g = 0; g < 4; ++g) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(o[g]) : "v"(land_a), "i"(1024 * g) : "memory");
@@ -284,7 +290,7 @@ __global__ __launch_bounds__(kFbThreads, 1) void attn_bwd_fused8_kernel(FusedArg
       for (int g = 0; g < 4; ++g) asm volatile("ds_write_b128 %0, %1 offset:%2" :: "v"(stash_a), "v"(o[g]), "i"(1024 * g) : "memory");
     }
   };
-  auto add_step = [&](int jr, int n) { add_step_from(jr, n, stash_a + 4u * 4096u); };
+  auto add_step = [&](int jr, int n) { add_step_from(jr, n, stash_of(lane_now()) + 4u * 4096u); };
 
 #define ADT_STAMP(K)                                                                                                      \
   if ((kDbg & 96) && j == 12 && wave == ((kDbg & 64) ? 4 : 0) && blockIdx.x == 600) {                                                        \
@@ -351,7 +357,7 @@ __global__ __launch_bounds__(kFbThreads, 1) void attn_bwd_fused8_kernel(FusedArg
   constexpr bool kMasked = decltype(masked_tag)::value;
   const uint64_t km_none[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};      // (arith_pair's hashed-mask operand: not used here)
   for (int j = 0; j < ns; ++j) {
-    asm volatile("" : "+v"(rowbase), "+v"(trbase), "+v"(xbase));    // keep the per-k-step / per-d-block addresses derived from these out of loop-invariant registers
+    asm volatile("" : "+v"(rowbase));                             // keep the per-k-step addresses derived from it out of loop-invariant registers
     // ---- the fan-in's step of this iteration (waves 4-7): its tile is brought in now, added at the end of the iteration
     const int sjr = cur_jr, sn = cur_n;
     const bool step = reducer && valid(sjr, sn);                  // wave-uniform
@@ -368,14 +374,13 @@ __global__ __launch_bounds__(kFbThreads, 1) void attn_bwd_fused8_kernel(FusedArg
     if (j + 1 < ns) issue_slice(j + 1);
     const unsigned slot = static_cast<unsigned>(kFbOffT + (j & 1) * kFbTile);
     const unsigned stat_a = smem_base + static_cast<unsigned>(kFbOffS + (j & 1) * 256 + 16 * h);       // + 32 g: queries 8 g + 4 h .. + 3
-    unsigned char* xs = smem + kFbOffX;
     // ---- a wave's slice: the S' / dP chains of its block, the arithmetic (on waves 0-3 beside the previous slice's dQ product), the dS^T
     // write, the dV^T / dK^T products.  The SIMD's other wave runs the same sequence on the group's other block: the hardware interleaves
     // the two streams (one wave's products under the other's arithmetic).
     f32x16 st, dp;
     unsigned hp[8], hs[8];
     f32x4 ndv[4];                                                 // the slice's row constants nd of this lane's 16 query rows
-    bf16x8 fq[2], fd[2], fk[2];                                   // operand ring of the chains: one k-step ahead (the SIMD's other wave covers the rest of the latency)
+    bf16x8 fq[3], fd[3], fk[3];                                   // operand ring of the chains: two k-steps ahead
     const unsigned tq_a = rowbase + slot;
     const unsigned kr_a = rowbase + static_cast<unsigned>((64 * grp + 32 * blk) * 256);
     const int krow = 64 * grp + 32 * blk + r, ki = key0 + krow;
@@ -440,22 +445,24 @@ __global__ __launch_bounds__(kFbThreads, 1) void attn_bwd_fused8_kernel(FusedArg
         f32x4 q0[4];
 #pragma unroll
         for (int g = 0; g < 4; ++g) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=&v"(q0[g]) : "v"(stat_a), "i"(32 * g) : "memory");
-        ADT_UNIT(0, 0); ADT_UNIT(1, 1);
+        ADT_UNIT(0, 0); ADT_UNIT(1, 1); ADT_UNIT(2, 2);
         st = __builtin_shufflevector(__builtin_shufflevector(q0[0], q0[1], 0, 1, 2, 3, 4, 5, 6, 7), __builtin_shufflevector(q0[2], q0[3], 0, 1, 2, 3, 4, 5, 6, 7),
                                      0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 14, 15);
       }
 #pragma unroll
       for (int s = 0; s < 8; ++s) {
-        if (s < 7) asm volatile("s_waitcnt lgkmcnt(3)" ::: "memory");      // (in order: the row constant and the keep word, read first, are back too)
+        if (s < 6) asm volatile("s_waitcnt lgkmcnt(6)" ::: "memory");      // (in order: the row constant and the keep word, read first, are back too)
+        else if (s < 7) asm volatile("s_waitcnt lgkmcnt(3)" ::: "memory");
         else asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_sched_barrier(0);
-        mfma_vgpr(st, fq[s & 1], fk[s & 1]);
+        mfma_vgpr(st, fq[s % 3], fk[s % 3]);
         if (s == 0) mfma_vgpr0(dp, fd[0], vf[0]);
-        else mfma_vgpr(dp, fd[s & 1], vf[s]);
+        else mfma_vgpr(dp, fd[s % 3], vf[s]);
         __builtin_amdgcn_sched_barrier(0);
-        if (s + 2 < 8) {
-          if ((s & 1) == 0) ADT_UNIT(0, s + 2);
-          else ADT_UNIT(1, s + 2);
+        if (s + 3 < 8) {
+          if (s % 3 == 0) ADT_UNIT(0, s + 3);
+          else if (s % 3 == 1) ADT_UNIT(1, s + 3);
+          else ADT_UNIT(2, s + 3);
         }
       }
       // (the row constants nd only now: during the chain their sixteen registers belong to the operand ring)
@@ -474,14 +481,20 @@ __global__ __launch_bounds__(kFbThreads, 1) void attn_bwd_fused8_kernel(FusedArg
     // the dS^T image is single-buffered: waves 0-3 must have finished the previous slice's dQ product (phase 4) before anybody overwrites it
     ADT_STAMP(2)
     asm volatile("s_barrier" ::: "memory");
+    // dS^T of the block to LDS for the dQ product: x_off(key, g) + 8 h = 64 key + ((16 s + 8 h) ^ 16 g), s = (key >> 2) & 3 -- one lane
+    // constant (re-made per slice: four hoisted address registers are four too many here) and an XOR per write
+    {
+      const int l = lane_now(), rr = l & 31, hh = l >> 5, key = 64 * grp + 32 * blk + rr;
+      const unsigned xw_lo = static_cast<unsigned>(16 * ((key >> 2) & 3) + 8 * hh), xw_hi = smem_base + static_cast<unsigned>(kFbOffX + 64 * key);
 #pragma unroll
-    for (int g = 0; g < 4; ++g) {                                 // dS^T of the block to LDS for the dQ product
-      const uint2 w2 = make_uint2(hs[2 * g], hs[2 * g + 1]);
-      asm volatile("ds_write_b64 %0, %1" :: "v"(lds_off(xs) + x_off(krow, g) + 8 * h), "v"(w2) : "memory");
+      for (int g = 0; g < 4; ++g) {
+        const uint2 w2 = make_uint2(hs[2 * g], hs[2 * g + 1]);
+        asm volatile("ds_write_b64 %0, %1" :: "v"(xw_hi + (xw_lo ^ static_cast<unsigned>(16 * g))), "v"(w2) : "memory");
+      }
     }
     ADT_STAMP(3)
     // ---- phase 3: dV^T += dO^T P, dK^T += Q^T dS per k-step of 16 queries and d-block
-    const unsigned trb = trbase + slot;
+    const unsigned trb = make_trbase(lane_now()) + slot;
     if (!(kDbg & 4)) {
       union { unsigned u[4]; bf16x8 v; } pf0, pf1, dsf0, dsf1;
 #pragma unroll
@@ -539,6 +552,8 @@ __global__ __launch_bounds__(kFbThreads, 1) void attn_bwd_fused8_kernel(FusedArg
     if (!reducer) {
       f32x16 dq;
       if (!(kDbg & 2)) {
+        const int l = lane_now();
+        const unsigned trbase = make_trbase(l), xbase = make_xbase(l);
         ADT_DQ_BEGIN
         ADT_DQ_STEP(0) ADT_DQ_STEP(1) ADT_DQ_STEP(2) ADT_DQ_STEP(3) ADT_DQ_STEP(4) ADT_DQ_STEP(5) ADT_DQ_STEP(6) ADT_DQ_STEP(7)
         ADT_DQ_STEP(8) ADT_DQ_STEP(9) ADT_DQ_STEP(10) ADT_DQ_STEP(11) ADT_DQ_STEP(12) ADT_DQ_STEP(13) ADT_DQ_STEP(14) ADT_DQ_STEP(15)
