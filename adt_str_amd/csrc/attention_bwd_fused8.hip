@@ -478,7 +478,44 @@ __global__ __launch_bounds__(kFbThreads, 1) void attn_bwd_fused8_kernel(FusedArg
 #pragma unroll
     for (int m = 0; m < 8; ++m) arith_pair(m);
     __builtin_amdgcn_sched_barrier(0);
-    // the dS^T image is single-buffered: waves 0-3 must have finished the previous slice's dQ product (phase 4) before anybody overwrites it
+    ADT_STAMP(10)
+    // ---- phase 2b (waves 0-3): the PREVIOUS slice's dQ product over the workgroup's 256 keys (its dS^T image is complete since that slice's
+    // barrier B and is overwritten only behind barrier A below), published right away.  Placed here so that the SIMD's two waves run
+    // complementary work through the whole stretch: chain | fan-in addition, arithmetic | chain, dQ product | arithmetic.
+    if (!reducer && j > 0) {
+      f32x16 dq;
+      if (!(kDbg & 2)) {
+        // (a ring of two units and ONE accumulation chain -- the 4-wave form's in-loop order, so dQ comes out bit for bit the same; the
+        // P / dS words of this slice are live here, registers are scarce, and the SIMD's other wave has the vector pipe busy meanwhile)
+        const int l = lane_now();
+        const unsigned ka_a = make_trbase(l) ^ static_cast<unsigned>(64 * grp), xb_a = make_xbase(l) + static_cast<unsigned>(kFbOffX);
+        TrFrag ka[2], xb[2];
+        ADT_TR2(ka[0], ka_a, 0);
+        ADT_TRX(xb[0], xb_a, 0);
+        ADT_TR2(ka[1], ka_a, 4096);
+        ADT_TRX(xb[1], xb_a, 1024);
+#define ADT_DQ1_STEP(KK)                                                                          \
+        if ((KK) + 1 < 16) asm volatile("s_waitcnt lgkmcnt(4)" ::: "memory");                     \
+        else asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                                   \
+        __builtin_amdgcn_sched_barrier(0);                                                        \
+        if ((KK) == 0) mfma_vgpr0(dq, tr_get(ka[0]), tr_get(xb[0]));                              \
+        else mfma_vgpr(dq, tr_get(ka[(KK) & 1]), tr_get(xb[(KK) & 1]));                           \
+        __builtin_amdgcn_sched_barrier(0);                                                        \
+        if ((KK) + 2 < 16) {                                                                      \
+          ADT_TR2(ka[(KK) & 1], ka_a, ((KK) + 2) * 4096);                                         \
+          ADT_TRX(xb[(KK) & 1], xb_a, ((KK) + 2) * 1024);                                         \
+        }
+        ADT_DQ1_STEP(0) ADT_DQ1_STEP(1) ADT_DQ1_STEP(2) ADT_DQ1_STEP(3) ADT_DQ1_STEP(4) ADT_DQ1_STEP(5) ADT_DQ1_STEP(6) ADT_DQ1_STEP(7)
+        ADT_DQ1_STEP(8) ADT_DQ1_STEP(9) ADT_DQ1_STEP(10) ADT_DQ1_STEP(11) ADT_DQ1_STEP(12) ADT_DQ1_STEP(13) ADT_DQ1_STEP(14) ADT_DQ1_STEP(15)
+#undef ADT_DQ1_STEP
+        mfma_settle(dq);
+      } else {
+#pragma unroll
+        for (int i = 0; i < 16; ++i) dq[i] = 0.f;
+      }
+      hand_on(dq, j - 1);
+    }
+    // the dS^T image is single-buffered: waves 0-3 must have finished the previous slice's dQ product before anybody overwrites it
     ADT_STAMP(2)
     asm volatile("s_barrier" ::: "memory");
     // dS^T of the block to LDS for the dQ product: x_off(key, g) + 8 h = 64 key + ((16 s + 8 h) ^ 16 g), s = (key >> 2) & 3 -- one lane
@@ -546,24 +583,6 @@ __global__ __launch_bounds__(kFbThreads, 1) void attn_bwd_fused8_kernel(FusedArg
       }
       add_step(sjr, sn);
     }
-    ADT_STAMP(10)
-    // ---- phase 4 (waves 0-3): this slice's dQ product over the workgroup's 256 keys, published right away; the SIMD's other wave meanwhile
-    // runs the fan-in's addition and the next slice's chains
-    if (!reducer) {
-      f32x16 dq;
-      if (!(kDbg & 2)) {
-        const int l = lane_now();
-        const unsigned trbase = make_trbase(l), xbase = make_xbase(l);
-        ADT_DQ_BEGIN
-        ADT_DQ_STEP(0) ADT_DQ_STEP(1) ADT_DQ_STEP(2) ADT_DQ_STEP(3) ADT_DQ_STEP(4) ADT_DQ_STEP(5) ADT_DQ_STEP(6) ADT_DQ_STEP(7)
-        ADT_DQ_STEP(8) ADT_DQ_STEP(9) ADT_DQ_STEP(10) ADT_DQ_STEP(11) ADT_DQ_STEP(12) ADT_DQ_STEP(13) ADT_DQ_STEP(14) ADT_DQ_STEP(15)
-        ADT_DQ_END
-      } else {
-#pragma unroll
-        for (int i = 0; i < 16; ++i) dq[i] = 0.f;
-      }
-      hand_on(dq, j);
-    }
     cur_jr = njr;
     cur_n = nn;
     ADT_STAMP(11)
@@ -572,10 +591,29 @@ __global__ __launch_bounds__(kFbThreads, 1) void attn_bwd_fused8_kernel(FusedArg
   if (key_mask) run_slices(std::true_type{});
   else run_slices(std::false_type{});
 #undef ADT_STAMP
-  if (handoff && pub_pending >= 0) {                               // (waves 0-3) the last slice's tile: drain, then count it
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    if (lane == 0) __hip_atomic_fetch_add(flag_of(pub_pending, kb), 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    pub_pending = -1;
+  if (!reducer) {                                                 // (waves 0-3) the last slice's dQ product (its dS^T image is complete: the loop ends on a barrier)
+    f32x16 dq;
+    if (!(kDbg & 2)) {
+      const int l = lane_now();
+      const unsigned trbase = make_trbase(l), xbase = make_xbase(l);
+      ADT_DQ_BEGIN
+      ADT_DQ_STEP(0) ADT_DQ_STEP(1) ADT_DQ_STEP(2) ADT_DQ_STEP(3) ADT_DQ_STEP(4) ADT_DQ_STEP(5) ADT_DQ_STEP(6) ADT_DQ_STEP(7)
+      ADT_DQ_STEP(8) ADT_DQ_STEP(9) ADT_DQ_STEP(10) ADT_DQ_STEP(11) ADT_DQ_STEP(12) ADT_DQ_STEP(13) ADT_DQ_STEP(14) ADT_DQ_STEP(15)
+      ADT_DQ_END
+    } else {
+#pragma unroll
+      for (int i = 0; i < 16; ++i) dq[i] = 0.f;
+    }
+    const int prev_pending = pub_pending;
+    hand_on(dq, ns - 1);
+    if (handoff) {
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      if (lane == 0) {
+        if (prev_pending >= 0) __hip_atomic_fetch_add(flag_of(prev_pending, kb), 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_fetch_add(flag_of(ns - 1, kb), 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      }
+      pub_pending = -1;
+    }
   }
 #undef ADT_DQ_BEGIN
 #undef ADT_DQ_STEP

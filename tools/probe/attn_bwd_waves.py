@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """The 8-wave one-kernel attention backward (ADT_ATTN_BWD_WAVES=8) against the 4-wave one: same inputs, same keep bits; largest
-difference per gradient (the dQ product sums its 16 k-steps as two chains in one form and one chain in the other, so the results
-are not bitwise equal), then timings of both at the encoder / cross-attention / decoder shapes."""
+difference per gradient (0: both forms sum the same products in the same orders), then timings of both at the encoder / cross-attention /
+decoder shapes."""
 import os
 import sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
