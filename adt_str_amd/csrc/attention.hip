@@ -689,7 +689,8 @@ static size_t split_workspace_bytes(const adt_attn_desc* d) {
              adt_colsum_workspace_bytes(static_cast<int64_t>(d->batch) * (d->k_len > d->q_len ? d->k_len : d->q_len), static_cast<int64_t>(d->heads) * kDh);
   return (bytes + 255) & ~static_cast<size_t>(255);
 }
-// Which backward runs.  The one-kernel path (attention_bwd_fused.hip: the five algorithmic products, dQ summed over the key-block workgroups
+// Which backward runs.  The one-kernel path (attention_bwd_fused.hip / attention_bwd_fused8.hip -- the 8-wave form wherever it applies: no
+// dropout or keep bits; same bits, 0.77 vs 0.86 ms -- : the five algorithmic products, dQ summed over the key-block workgroups
 // by a scheduled fan-in) is the default without dropout (MI355X, encoder shape 0.83 vs 0.87 ms) and with dropout WHEN THE FORWARD LEFT ITS
 // KEEP BITS (adt_attn_desc.keep_bits: no mask is hashed again; profiles/r05/attn_bwd_paths.txt).  With dropout and no bits the two-kernel path
 // (dQ kernel + dK/dV kernel, 7 products, every mask hashed twice) is still the faster one (0.95 vs 0.98 ms): at one wave per SIMD the mask

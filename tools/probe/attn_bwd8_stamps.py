@@ -20,9 +20,9 @@ dout = torch.randn((B * S, d), generator=g).to(dev).bfloat16()
 scale = 1.0 / math.sqrt(128)
 os.environ["ADT_ATTN_BWD"] = "fused"
 os.environ["ADT_ATTN_BWD_WAVES"] = "8"
-names = {1: "ph1 chain (S, dP)", 2: "ph2 arithmetic", 3: "barrier A + dS^T write", 5: "ph3 dV / dK", 6: "vmcnt / lgkmcnt wait", 7: "barrier B", 8: "flag bookkeeping",
-         10: "fan-in step (waves 4-7)", 11: "ph4 dQ + publish (waves 0-3)"}
-order = [0, 1, 2, 3, 5, 6, 7, 8, 10, 11]
+names = {1: "ph1 chain (S, dP)", 10: "ph2 arithmetic", 2: "ph2b dQ of the previous slice + publish (waves 0-3)", 3: "barrier A + dS^T write", 5: "ph3 dV / dK",
+         6: "vmcnt / lgkmcnt wait", 7: "barrier B", 8: "flag bookkeeping", 11: "fan-in step (waves 4-7)"}
+order = [0, 1, 10, 2, 3, 5, 6, 7, 8, 11]
 for drop in (None, (0.1, 5)):
     o, saved = K.attn_fwd(q, kk, v, B, H, S, S, scale, False, None, drop=drop, save_bits=drop is not None)
     dq, dkv = torch.zeros_like(q), torch.zeros_like(kv)
@@ -39,5 +39,5 @@ for drop in (None, (0.1, 5)):
         st = ws[nb - 128: nb].cpu().view(torch.int64)[:12].tolist()
         print("dropout", drop is not None, who, "cycles per phase (s_memtime):")
         for a, b in zip(order[:-1], order[1:]):
-            print(f"  {names[b]:32s} {st[b] - st[a]:7d}")
+            print(f"  {names[b]:52s} {st[b] - st[a]:7d}")
         print(f"  stamped part of the iteration    {st[11] - st[0]:7d}")
