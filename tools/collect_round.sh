@@ -8,7 +8,7 @@ for f in attn_bwd_paths.txt attn_fwd.txt; do [ -f $O/$f ] && grep -v amdgpu.ids 
 [ -f $O/bench_train_fp32.json ] && cp $O/bench_train_fp32.json $P/bench_train_fp32.json
 [ -f $O/bench_train_2ranks_shared_gpu_debug.json ] && cp $O/bench_train_2ranks_shared_gpu_debug.json $P/
 cp $O/smoke.log $P/smoke.txt
-tail -3 $O/pytest_gpu.log > $P/pytest_gpu.txt
+[ -f $O/pytest_gpu.log ] && tail -3 $O/pytest_gpu.log > $P/pytest_gpu.txt
 cp "$(ls -t $O/prof_train/*/*kernel_stats.csv | head -1)" $P/train_step_kernel_stats.csv          # (newest: an earlier call with the same tag leaves its files behind)
 cp "$(ls -t $O/prof_logmel/*/*kernel_stats.csv | head -1)" $P/logmel_kernel_stats.csv          # (newest: an earlier call with the same tag leaves its files behind)
 cp "$(ls -t $O/prof_clap/*/*kernel_stats.csv | head -1)" $P/clap_kernel_stats.csv          # (newest: an earlier call with the same tag leaves its files behind)
