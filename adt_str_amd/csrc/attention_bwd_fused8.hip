@@ -29,8 +29,9 @@ constexpr int kFbOffS = kFbOffT + 2 * kFbTile;      // per slice -lse / scale [3
 constexpr int kFbOffStash = kFbOffS + 2 * 256;      // running dQ^T sum of the slice this workgroup is reducing (4 KiB per wave)
 constexpr int kFbOffLand = kFbOffStash + 4 * 4096;  // landing zone of the key block tile that is added next (4 KiB per wave, LDS-DMA)
 constexpr int kFbOffFlag = kFbOffLand + 4 * 4096;
-constexpr int kFbOffBits = kFbOffFlag + 16;         // keep bits of the slice (kDrop == 2): per ring slot 8 waves x 256 B (lane l: the word of key l & 31 of the wave's block)
-constexpr int kFbLds = kFbOffBits + 2 * 2048;       // 152,080 B
+constexpr int kFbOffBits = kFbOffFlag + 16;         // keep bits of the slice (kDrop == 2): per ring slot 4 key groups x 256 B (lane l < 32: the word of key l of the
+                                                    // group's block 0, l >= 32: of key l - 32 of block 1)
+constexpr int kFbLds = kFbOffBits + 2 * 1024;       // 150,032 B
 constexpr unsigned kFbSpinLimit = 1u << 24;         // polls of ~0.3 us each before a wave gives up (and reports it)
 
 
@@ -119,7 +120,7 @@ __global__ __launch_bounds__(kFbThreads, 1) void attn_bwd_fused8_kernel(FusedArg
   const unsigned short* vb = a.v + static_cast<long>(b) * a.Sk * a.ldv + head * kDh;
   const float* stat_g = fa.stats + static_cast<long>(bh) * ns * kFbSlice * 2;
   // keep words of (this head, slice 0, this wave's first 32-key block)
-  const unsigned* bits_g = kDrop == 2 ? a.keep_bits + ((static_cast<long>(bh) * a.bits_nq) * a.bits_nk + (kb * (kFbKeys / 32) + 2 * grp + blk)) * 32 : nullptr;
+  const unsigned* bits_g = kDrop == 2 ? a.keep_bits + ((static_cast<long>(bh) * a.bits_nq) * a.bits_nk + (kb * (kFbKeys / 32) + 2 * grp)) * 32 : nullptr;
   const int klen = a.key_len ? __builtin_amdgcn_readfirstlane(a.key_len[b]) : a.Sk;      // (a loaded value is "divergent" to the compiler: make it scalar)
   const float sl2 = a.scale * kLog2e;
   const bool key_mask = a.causal || key0 + kFbKeys > klen || key0 + kFbKeys > a.Sk;      // block-uniform, in a scalar register
@@ -144,8 +145,8 @@ __global__ __launch_bounds__(kFbThreads, 1) void attn_bwd_fused8_kernel(FusedArg
     asm volatile("" : "+v"(lane_o));
     const int lrow = lane_o >> 4, lchunk = lane_o & 15;
 #pragma unroll
-    for (int i = 0; i < 2; ++i) {
-      const int g = 2 * wave + i, rg = g & 7, row = 4 * rg + lrow;            // g 0..7: Q, 8..15: dO (wave-uniform)
+    for (int i = 0; i < 4; ++i) {
+      const int g = 4 * grp + i, rg = g & 7, row = 4 * rg + lrow;             // g 0..7: Q, 8..15: dO (wave-uniform)
       const int chunk = lchunk ^ (((row & 3) << 2) | ((row >> 2) & 3));
       int gr = j * kFbSlice + row;
       gr = gr < a.Sq ? gr : a.Sq - 1;                             // rows past the end repeat the last valid row (their P is 0 by the statistics)
@@ -153,17 +154,18 @@ __global__ __launch_bounds__(kFbThreads, 1) void attn_bwd_fused8_kernel(FusedArg
       __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
                                        (__attribute__((address_space(3))) void*)(slot + g * 1024), 16, 0, 0);
     }
-    if (wave == 7)                                                // 64 lanes x 4 bytes = the slice's 32 x {nl, nd}
+    if (grp == 3)                                                 // 64 lanes x 4 bytes = the slice's 32 x {nl, nd}
       __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(stat_g + j * kFbSlice * 2 + lane_o),
                                        (__attribute__((address_space(3))) void*)(smem + kFbOffS + (j & 1) * 256), 4, 0, 0);
-    if (kDrop == 2) {                                             // the keep words of this wave's key block: lane = key (both half-waves)
+    if (kDrop == 2) {                                             // the keep words of the key group's two blocks: lane = (block, key)
       const int key = lane_o & 31;
-      const unsigned* src = bits_g + (static_cast<long>(j) * a.bits_nk) * 32 + keep_bits_word(key);
+      const unsigned* src = bits_g + (static_cast<long>(j) * a.bits_nk + (lane_o >> 5)) * 32 + keep_bits_word(key);
       __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
-                                       (__attribute__((address_space(3))) void*)(smem + kFbOffBits + (j & 1) * 2048 + wave * 256), 4, 0, 0);
+                                       (__attribute__((address_space(3))) void*)(smem + kFbOffBits + (j & 1) * 1024 + grp * 256), 4, 0, 0);
     }
   };
-  issue_slice(0);
+  // (the slices' staging is the fan-in waves' job: waves 0-3 carry the dQ product and are the longer instruction stream of every SIMD)
+  if (reducer) issue_slice(0);
 
   // V of this wave's 64 keys: the B operand of dP, in registers for the whole kernel
   bf16x8 vf[8];
@@ -371,7 +373,7 @@ __global__ __launch_bounds__(kFbThreads, 1) void attn_bwd_fused8_kernel(FusedArg
     const bool nstep = reducer && valid(njr, nn) && nn != kb;
     unsigned fv = 0;
     if (nstep && lane == 0) fv = __hip_atomic_load(flag_of(njr, nn), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    if (j + 1 < ns) issue_slice(j + 1);
+    if (reducer && j + 1 < ns) issue_slice(j + 1);
     const unsigned slot = static_cast<unsigned>(kFbOffT + (j & 1) * kFbTile);
     const unsigned stat_a = smem_base + static_cast<unsigned>(kFbOffS + (j & 1) * 256 + 16 * h);       // + 32 g: queries 8 g + 4 h .. + 3
     // ---- a wave's slice: the S' / dP chains of its block, the arithmetic (on waves 0-3 beside the previous slice's dQ product), the dS^T
@@ -437,7 +439,7 @@ __global__ __launch_bounds__(kFbThreads, 1) void attn_bwd_fused8_kernel(FusedArg
     // accumulator latency leaves open
     {
       if (kDrop == 2) {                                           // (first: every counted wait below then covers it too)
-        const unsigned bw_a = smem_base + static_cast<unsigned>(kFbOffBits + (j & 1) * 2048 + wave * 256 + 4 * r);
+        const unsigned bw_a = smem_base + static_cast<unsigned>(kFbOffBits + (j & 1) * 1024 + grp * 256 + 128 * blk + 4 * r);
         asm volatile("ds_read_b32 %0, %1" : "=&v"(wb) : "v"(bw_a) : "memory");
       }
       {
