@@ -1464,7 +1464,8 @@ static int launch_nt_256(const GemmArgs& g, dim3 grid, int tm, int tn, hipStream
   X(true, false, kEfResidual | kEfRowMod | kEfDropAfterRes | kEfAux | kEfFp32)   /* encoder input: + positional rows, dropout, fp32 + bf16 */ \
   X(true, false, kEfResidual | kEfDropAfterRes | kEfAux | kEfFp32)                                                      \
   X(false, false, kEfBias | kEfFp32)                          /* logits */                                              \
-  X(false, false, kEfFp32)                                    /* the memory's data gradient (K = all decoder layers' K / V columns) */
+  X(false, false, kEfFp32)                                    /* the memory's data gradient (K = all decoder layers' K / V columns) */ \
+  X(false, false, kEfBias | kEfGelu)                          /* inference MLP linear1 (the CLAP tower's last stage): bias, GELU */
 static int dispatch_nt_256(const GemmArgs& g, bool colsum, unsigned mask, dim3 grid, int tm, int tn, hipStream_t st) {
   const bool drop = g.drop.on();
   static const bool generic_only = getenv("ADT_GEMM_GENERIC") != nullptr;
