@@ -47,6 +47,20 @@ for (B, H, Sq, Sk, causal) in [(64, 6, 986, 986, False), (64, 6, 128, 986, False
 
     check(f"attn fwd {B}x{H}x{Sq}x{Sk}", fwd)
     check(f"attn bwd {B}x{H}x{Sq}x{Sk}", bwd)
+    # the training step's backward: keep bits from the forward -> the 8-wave one-kernel form; and the same form without dropout
+    ob, saved = K.attn_fwd(q, kv[:, :d], kv[:, d:], B, H, Sq, Sk, scale, causal, drop=drop, save_bits="force")
+    o0, lse0 = K.attn_fwd(q, kv[:, :d], kv[:, d:], B, H, Sq, Sk, scale, causal)
+
+    def bwd_bits():
+        K.attn_bwd(q, kv[:, :d], kv[:, d:], ob, do, saved, dq, dkv[:, :d], dkv[:, d:], B, H, Sq, Sk, scale, causal, drop=drop, bias_grad=bg)
+        return dq, dkv, bg
+
+    def bwd_plain():
+        K.attn_bwd(q, kv[:, :d], kv[:, d:], o0, do, lse0, dq, dkv[:, :d], dkv[:, d:], B, H, Sq, Sk, scale, causal, bias_grad=bg)
+        return dq, dkv, bg
+
+    check(f"attn bwd, keep bits {B}x{H}x{Sq}x{Sk}", bwd_bits)
+    check(f"attn bwd, no dropout {B}x{H}x{Sq}x{Sk}", bwd_plain)
 
 M = 64 * 986
 a = torch.randn((M, 768), device=dev).bfloat16()
