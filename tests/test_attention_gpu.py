@@ -52,6 +52,8 @@ CASES = [  # B, H, Sq, Sk, causal, padded
     (2, 2, 257, 300, True, True),        # 5 query tiles (one row in the last), 3 key blocks, both masks
     (1, 1, 192, 33, False, True),        # exactly 3 query tiles (no refill), second key block almost empty
     (1, 2, 449, 64, False, False),       # 8 query tiles (7 full + 1 row): every stage refilled twice
+    (1, 3, 100, 2100, False, True),      # 9 key blocks of 256 (the one-kernel backward's fan-in over nine workgroups), 4 query slices, padded keys
+    (5, 1, 333, 700, True, True),        # 3 key blocks, 11 query slices, both masks, 5 (batch, head)s: not a multiple of the 8 XCD groups
 ]
 
 
