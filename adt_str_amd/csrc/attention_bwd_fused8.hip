@@ -91,6 +91,12 @@ __global__ __launch_bounds__(kFbThreads, 1) void attn_bwd_fused8_kernel(FusedArg
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int grp = wave & 3, blk = wave >> 2;          // key group (64 keys; also the dQ d-block / fan-in quarter) and the wave's 32-key block of it
   const bool reducer = blk == 1;                      // waves 4-7: the fan-in; waves 0-3: the dQ product and its publication
+#define ADT_ITEM_STAMP(K)                                                                                                 \
+  if ((kDbg & 96) && wave == ((kDbg & 64) ? 4 : 0) && blockIdx.x == 600) {                                               \
+    const unsigned long long tnow = __builtin_amdgcn_s_memtime();                                                        \
+    if (lane == 0) fa.stamps[K] = tnow;                                                                                  \
+  }
+  ADT_ITEM_STAMP(12)
 
   // ---- this workgroup's (batch, head, key block): ticket v of the XCD group's counter = logical tile slice0 + v
   const int n_tiles = fa.nkb * a.B * a.H;
@@ -590,8 +596,10 @@ __global__ __launch_bounds__(kFbThreads, 1) void attn_bwd_fused8_kernel(FusedArg
     ADT_STAMP(11)
   }
   };
+  ADT_ITEM_STAMP(13)
   if (key_mask) run_slices(std::true_type{});
   else run_slices(std::false_type{});
+  ADT_ITEM_STAMP(14)
 #undef ADT_STAMP
   if (!reducer) {                                                 // (waves 0-3) the last slice's dQ product (its dS^T image is complete: the loop ends on a barrier)
     f32x16 dq;
@@ -623,6 +631,8 @@ __global__ __launch_bounds__(kFbThreads, 1) void attn_bwd_fused8_kernel(FusedArg
 #undef ADT_TR2
 #undef ADT_TRX
 
+  // (dK / dV in FRONT of the tail: behind it -- a wave may end with stores in flight -- the kernel was 2-4 % slower: here their drain
+  // passes under the wait for the head's other key blocks)
   {
     const int ki = key0 + 64 * grp + 32 * blk + r;
     store_transposed(dk, a.scale, a.dk + static_cast<long>(b) * a.Sk * a.ldk + head * kDh, a.ldk, ki, a.Sk, lane);
@@ -662,6 +672,8 @@ __global__ __launch_bounds__(kFbThreads, 1) void attn_bwd_fused8_kernel(FusedArg
       }
     }
   }
+  ADT_ITEM_STAMP(15)
+#undef ADT_ITEM_STAMP
 }
 
 int launch_attn_bwd_fused8(const adt_attn_desc* d, const AttnArgs& a, void* ws, size_t ws_bytes, hipStream_t st) {

@@ -36,8 +36,9 @@ for drop in (None, (0.1, 5)):
             desc.keep_bits = _ffi.dptr(saved.bits)
         nb = _ffi.load().adt_attn_bwd_workspace_bytes(C.byref(desc))
         ws = K._workspace(nb, q.device)
-        st = ws[nb - 128: nb].cpu().view(torch.int64)[:12].tolist()
+        st = ws[nb - 128: nb].cpu().view(torch.int64)[:16].tolist()
         print("dropout", drop is not None, who, "cycles per phase (s_memtime):")
         for a, b in zip(order[:-1], order[1:]):
             print(f"  {names[b]:52s} {st[b] - st[a]:7d}")
         print(f"  stamped part of the iteration    {st[11] - st[0]:7d}")
+        print(f"  the whole item: prologue (K image, V, slice 0) {st[13] - st[12]}, {S // 32 + (1 if S % 32 else 0)} slices {st[14] - st[13]}, last dQ + dK / dV stores + fan-in tail {st[15] - st[14]}")
