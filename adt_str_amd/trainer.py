@@ -251,7 +251,7 @@ def install_engine_reduction(ddp_model, accumulation_steps: int = 1, timing: boo
             gflat, _ = eng.grad_buffers()
             red = GradReducer(gflat, pg, timing=timing)
             eng.hf_reducer = red
-            eng.hf_sync = lambda: bool(ddp_model.require_backward_grad_sync)
+            eng.hf_sync = lambda: bool(getattr(eng, "hf_force_sync", False) or ddp_model.require_backward_grad_sync)
             eng.grad_ready_hook = red.segment_ready
         eng.hf_hook_stats = ddp_model._adt_hook_stats
 
@@ -276,6 +276,26 @@ def install_engine_reduction(ddp_model, accumulation_steps: int = 1, timing: boo
     eng = ddp_model.module.engine
     attach(eng)
     return eng.hf_reducer
+
+
+def forward_engine_reduced(ddp_model, *args, **kwargs):
+    """One forward pass through the DDP wrapper on the engine-driven path WITHOUT DDP's bucket traffic.  The engine has averaged the
+    gradients by the time autograd hands them over, so DDP's reducer has nothing left to do -- but left in place it still copies every
+    gradient into its buckets and back (264 device copies of 276 MB in all per step at setting-1: +1.1 ms, `profiles/r05/hf_ddp_copies.txt`)
+    before the comm hook passes the buckets through.  DDP decides in its forward whether the coming backward is a synchronising one
+    (`prepare_for_backward` is skipped inside ``no_sync()``), so the forward runs inside ``no_sync()`` with the engine told to reduce
+    anyway.  Falls back to the plain call whenever the engine is not the one that reduces this pass (no reducer: gradient accumulation or a
+    model without an engine; the caller's own ``no_sync()``), where DDP's own machinery is what is wanted."""
+    from torch.nn.parallel import DistributedDataParallel as DDP
+    eng = getattr(getattr(ddp_model, "module", None), "engine", None)
+    if not isinstance(ddp_model, DDP) or eng is None or getattr(eng, "hf_reducer", None) is None or not ddp_model.require_backward_grad_sync:
+        return ddp_model(*args, **kwargs)
+    eng.hf_force_sync = True
+    try:
+        with ddp_model.no_sync():
+            return ddp_model(*args, **kwargs)
+    finally:
+        eng.hf_force_sync = False
 
 
 def backward_segments(engine):

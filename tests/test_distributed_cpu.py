@@ -249,6 +249,24 @@ def _hf_overlap_worker(rank, world, port, q, accumulation):
             assert not [e for e in events if e[0] == "collective"]
             got = torch.cat([p.grad.reshape(-1) for p in eng.named.values()])
             assert torch.allclose(got, base * (rank + 1) * 2, rtol=1e-6)
+            # what ADTTrainer.compute_loss calls: the same averaged gradients and the same per-segment collectives, but DDP's reducer stays
+            # out of it (no bucket copies, the comm hook is not even asked) -- the forward runs inside no_sync() with the engine told to reduce
+            events.clear()
+            model.zero_grad(set_to_none=True)
+            stats0 = dict(eng.hf_hook_stats)
+            loss = T.forward_engine_reduced(ddp, src=src, tgt=tgt, tgt_mask=None, tgt_padding_mask=pad, labels=labels)
+            loss.backward()
+            assert ddp.require_backward_grad_sync                                          # (the wrapper is left as it was)
+            got = torch.cat([p.grad.reshape(-1) for p in eng.named.values()])
+            assert torch.allclose(got, base * 3 * (sum(r + 1 for r in range(world)) / world), rtol=1e-6, atol=1e-7)
+            coll = [e for e in events if e[0] == "collective"]
+            assert len(coll) == len(segs) and sum(e[2] for e in coll) == n and dict(eng.hf_hook_stats) == stats0
+            # ... and inside the caller's own no_sync() it is the plain call: nothing is sent
+            events.clear()
+            model.zero_grad(set_to_none=True)
+            with ddp.no_sync():
+                T.forward_engine_reduced(ddp, src=src, tgt=tgt, tgt_mask=None, tgt_padding_mask=pad, labels=labels).backward()
+            assert not [e for e in events if e[0] == "collective"]
             # the model's engine object is REPLACED (set_precision / .to() / .float() do that): the comm hook must not go on testing the old
             # engine's frozen counters (it would pass every bucket through unreduced and the ranks would diverge).  Even if nobody calls
             # install_engine_reduction again, the first pass of the new engine is reduced by DDP itself and the later ones by the engine.
@@ -257,7 +275,7 @@ def _hf_overlap_worker(rank, world, port, q, accumulation):
             assert eng2 is not eng and not getattr(eng2, "_hf_hook_installed", False)
             stand_in(eng2)
             before = dict(eng.hf_hook_stats)
-            for k in (3, 4):                                     # calls["n"] is 2 here: passes 3 and 4
+            for k in (5, 6):                                     # calls["n"] is 4 here: passes 5 and 6
                 model.zero_grad(set_to_none=True)
                 events.clear()
                 step()

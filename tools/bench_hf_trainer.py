@@ -34,13 +34,15 @@ def hf_step():
     return loss
 
 
-for _ in range(3):
-    hf_step()
-torch.cuda.synchronize(); t0 = time.perf_counter()
-for _ in range(10):
-    hf_step()
-torch.cuda.synchronize()
-print(f"HF-style step (autograd bridge + clip_grad_norm_ + torch AdamW): {(time.perf_counter() - t0) * 100:.2f} ms/step")
+ONLY = os.environ.get("ADT_HF_ARM")      # profiling aid: run ONE arm ("fused", "ddp-engine", "ddp-own") so that a kernel trace holds nothing else
+if not ONLY:
+    for _ in range(3):
+        hf_step()
+    torch.cuda.synchronize(); t0 = time.perf_counter()
+    for _ in range(10):
+        hf_step()
+    torch.cuda.synchronize()
+    print(f"HF-style step (autograd bridge + clip_grad_norm_ + torch AdamW): {(time.perf_counter() - t0) * 100:.2f} ms/step")
 
 # the same loop with the optimizer ADTTrainer.create_optimizer builds (adt_str_amd/optim.py: torch.optim.AdamW's contract on the fused kernel)
 from adt_str_amd.optim import FusedAdamW
@@ -49,24 +51,26 @@ skip = set(no_decay_names(model))
 named = list(model.named_parameters())
 opt = FusedAdamW([{"params": [p for n, p in named if n not in skip], "weight_decay": 1e-5}, {"params": [p for n, p in named if n in skip], "weight_decay": 0.0}],
                  lr=1e-4, engine=model.engine)
-for _ in range(3):
-    hf_step()
-torch.cuda.synchronize(); t0 = time.perf_counter()
-for _ in range(10):
-    hf_step()
-torch.cuda.synchronize()
-print(f"HF-style step with FusedAdamW (what train.py's Trainer now builds): {(time.perf_counter() - t0) * 100:.2f} ms/step")
+if not ONLY or ONLY == "fused":
+    for _ in range(3):
+        hf_step()
+    torch.cuda.synchronize(); t0 = time.perf_counter()
+    for _ in range(10):
+        hf_step()
+    torch.cuda.synchronize()
+    print(f"HF-style step with FusedAdamW (what train.py's Trainer now builds): {(time.perf_counter() - t0) * 100:.2f} ms/step")
 del opt
 
-from adt_str_amd.trainer import FlatTrainer
-tr = FlatTrainer(model, lr=1e-4, weight_decay=1e-5, max_grad_norm=1.0, total_steps=10000, warmup_ratio=0.1)
-for _ in range(3):
-    tr.train_step(wavs, tokens, lens)
-torch.cuda.synchronize(); t0 = time.perf_counter()
-for _ in range(10):
-    tr.train_step(wavs, tokens, lens)
-torch.cuda.synchronize()
-print(f"native FlatTrainer step (same batch, no mixer): {(time.perf_counter() - t0) * 100:.2f} ms/step")
+if not ONLY:
+    from adt_str_amd.trainer import FlatTrainer
+    tr = FlatTrainer(model, lr=1e-4, weight_decay=1e-5, max_grad_norm=1.0, total_steps=10000, warmup_ratio=0.1)
+    for _ in range(3):
+        tr.train_step(wavs, tokens, lens)
+    torch.cuda.synchronize(); t0 = time.perf_counter()
+    for _ in range(10):
+        tr.train_step(wavs, tokens, lens)
+    torch.cuda.synchronize()
+    print(f"native FlatTrainer step (same batch, no mixer): {(time.perf_counter() - t0) * 100:.2f} ms/step")
 
 
 # ---- under a launcher (`torchrun --nproc-per-node 1 tools/bench_hf_trainer.py`): the reference's multi-GPU launch shape -- HF-style step on a
@@ -76,9 +80,11 @@ print(f"native FlatTrainer step (same batch, no mixer): {(time.perf_counter() - 
 if "RANK" in os.environ and "WORLD_SIZE" in os.environ:
     import torch.distributed as dist
     from torch.nn.parallel import DistributedDataParallel as DDP
-    from adt_str_amd.trainer import install_engine_reduction
+    from adt_str_amd.trainer import forward_engine_reduced, install_engine_reduction
     dist.init_process_group("nccl", device_id=dev)
     for arm in ("engine-driven reduction", "DDP's own all-reduce"):
+        if ONLY and ONLY != ("ddp-engine" if arm.startswith("engine") else "ddp-own"):
+            continue
         torch.manual_seed(0)
         m2 = ADTModel(cfg).to(dev).train()
         ddp = DDP(m2, device_ids=[dev.index], broadcast_buffers=False)
@@ -91,7 +97,10 @@ if "RANK" in os.environ and "WORLD_SIZE" in os.environ:
         def ddp_step():
             tgt_input, labels = tokens[:, :-1], tokens[:, 1:]
             _, pad = create_mask_plain(tgt_input.size(1), lens, dev)
-            loss = ddp(src=wavs, tgt=tgt_input, tgt_mask=None, tgt_padding_mask=pad, labels=labels)
+            if arm.startswith("engine"):          # what ADTTrainer.compute_loss calls: the engine reduces, DDP's reducer (and its bucket copies) stays out of it
+                loss = forward_engine_reduced(ddp, src=wavs, tgt=tgt_input, tgt_mask=None, tgt_padding_mask=pad, labels=labels)
+            else:
+                loss = ddp(src=wavs, tgt=tgt_input, tgt_mask=None, tgt_padding_mask=pad, labels=labels)
             loss.backward()
             torch.nn.utils.clip_grad_norm_(m2.parameters(), 1.0)
             opt2.step()

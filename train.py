@@ -46,9 +46,11 @@ class ADTTrainer(Trainer):
         if getattr(self, "_is_ddp", None) is None:                           # multi-GPU: `model` is the DDP wrapper accelerate built
             from torch.nn.parallel import DistributedDataParallel
             self._is_ddp = isinstance(model, DistributedDataParallel)
+        forward = model
         if self._is_ddp:                                                     # (every pass: idempotent, and it follows a replaced engine object)
-            from adt_str_amd.trainer import install_engine_reduction
+            from adt_str_amd.trainer import forward_engine_reduced, install_engine_reduction
             install_engine_reduction(model, getattr(self.args, "gradient_accumulation_steps", 1))
+            forward = lambda **kw: forward_engine_reduced(model, **kw)        # (the engine reduces: DDP's bucket copies are skipped)
         model.train()
         device = next(model.parameters()).device
         tokens = inputs["tokens"].to(device)
@@ -56,7 +58,7 @@ class ADTTrainer(Trainer):
         token_lengths = inputs["token_lengths"].to(device)
         tgt_input, labels = tokens[:, :-1], tokens[:, 1:]                     # teacher forcing (train.py:56-57)
         _, tgt_padding_mask = create_mask_plain(tgt_input.size(1), token_lengths, device)
-        loss = model(src=wavs, tgt=tgt_input, tgt_mask=None, tgt_padding_mask=tgt_padding_mask, labels=labels)
+        loss = forward(src=wavs, tgt=tgt_input, tgt_mask=None, tgt_padding_mask=tgt_padding_mask, labels=labels)
         # the reference also runs gc.collect() + empty_cache() here every step (train.py:73-76): a host stall
         # and an allocator flush per step with no effect on the result -- deliberately not reproduced
         return (loss, None) if return_outputs else loss
