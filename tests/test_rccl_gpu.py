@@ -77,15 +77,16 @@ def _worker(port, q):
         #     buckets pass the gradients through; the gradients autograd ends up with are bitwise the plain bridge's
         from torch.nn.parallel import DistributedDataParallel as DDP
         from adt_str_amd.masks import create_mask_plain
-        from adt_str_amd.trainer import install_engine_reduction
+        from adt_str_amd.trainer import forward_engine_reduced, install_engine_reduction
         wav, tok, tl = _batch(seed=31)
         _, pad = create_mask_plain(tok.shape[1] - 1, tl, wav.device)
 
-        def grads(wrap):
+        def grads(wrap, fast=False):
             m = _make(seed=13).train()
             net = DDP(m, device_ids=[0], broadcast_buffers=False) if wrap else m
             red = install_engine_reduction(net) if wrap else None
-            net(src=wav, tgt=tok[:, :-1], tgt_mask=None, tgt_padding_mask=pad, labels=tok[:, 1:]).backward()
+            kw = dict(src=wav, tgt=tok[:, :-1], tgt_mask=None, tgt_padding_mask=pad, labels=tok[:, 1:])
+            (forward_engine_reduced(net, **kw) if fast else net(**kw)).backward()
             torch.cuda.synchronize()
             return torch.cat([p.grad.reshape(-1) for p in m.engine.named.values()]), red, m.engine
 
@@ -94,6 +95,12 @@ def _worker(port, q):
         res["hf_ddp_bitwise"] = bool(torch.equal(g_plain, g_ddp))
         res["hf_reducer_ran"] = red_hf is not None and red_hf.steps == 1 and red_hf.bytes_last_step == 4 * g_ddp.numel()
         res["hf_ddp_passed_through"] = eng_hf.hf_hook_stats["passed_through"] >= 1 and eng_hf.hf_hook_stats["reduced_by_ddp"] == 0
+        # ... and what ADTTrainer.compute_loss calls (the forward inside DDP.no_sync(), the engine told to reduce): the same bits, the
+        # reducer ran, DDP's comm hook was not even asked (no bucket copies)
+        g_fast, red_fast, eng_fast = grads(True, fast=True)
+        res["hf_fast_bitwise"] = bool(torch.equal(g_plain, g_fast))
+        res["hf_fast_reducer_ran"] = red_fast is not None and red_fast.steps == 1 and red_fast.bytes_last_step == 4 * g_fast.numel()
+        res["hf_fast_hook_silent"] = eng_fast.hf_hook_stats["passed_through"] == 0 and eng_fast.hf_hook_stats["reduced_by_ddp"] == 0
         q.put(("ok", res))
     except Exception as e:                                 # pragma: no cover
         import traceback
@@ -119,3 +126,4 @@ def test_reducer_and_trainer_on_rccl_world_size_one():
     assert res["compress_bytes"] == 2 * res["n"]
     assert res["compress_max_dev"] < 3 * 1e-3 * 3, res["compress_max_dev"]       # <= lr per step per element, three steps
     assert res["hf_ddp_bitwise"] and res["hf_reducer_ran"] and res["hf_ddp_passed_through"]
+    assert res["hf_fast_bitwise"] and res["hf_fast_reducer_ran"] and res["hf_fast_hook_silent"]
