@@ -1696,7 +1696,11 @@ extern "C" int adt_gemm_bf16(int32_t trans, int64_t M, int64_t N, int64_t K, con
     static const bool tail_off = getenv("ADT_GEMM_NO_TAIL_STORES") != nullptr;
     g.tail_stores = tail_off ? 0 : 1;
     static const int group_env = getenv("ADT_GEMM_GROUP_N") ? atoi(getenv("ADT_GEMM_GROUP_N")) : 0;
-    const int group_n = group_env > 0 ? group_env : 3;       // measured in the layer sequence (tools/exp_gemm_instep.py): 3 columns -> QKV 0.231 -> 0.210 ms, the others unchanged
+    // tile columns per column group: measured per number of tile columns (tools/exp_gemm_group.py, profiles/r05/gemm_group_n.txt: M = 63104,
+    // bare products): 12 columns (N = 3072) 4 -> 305 us against 323 with 3 (308 / 319 / 325 with 2 / 6 / 12); 9 columns (N = 2304) 3 -> 195
+    // (198 with 4, 228 with 5); 24 columns (N = 6144) 6 -> 538 (547 / 556 / 583 with 3 / 4 / 8); three columns or fewer: all of them
+    const int group_auto = tn >= 24 && tn % 6 == 0 ? 6 : (tn % 4 == 0 && tn % 3 != 0) || tn == 12 ? 4 : 3;
+    const int group_n = group_env > 0 ? group_env : group_auto;
     g.group_n = group_n < tn ? group_n : tn;
     { const char* sg = getenv("ADT_GEMM_STAGGER"); g.stagger = sg ? atoi(sg) : 0; }
     static const bool log_forms = getenv("ADT_GEMM_LOG_FORMS") != nullptr;      // debugging aid: which forms does a workload launch?
