@@ -12,10 +12,13 @@ import threading
 
 # ``ADT_LIB_PATH``: another build of the SAME library (same ABI version, checked at load) -- for same-box A/B runs of two builds of a kernel
 _LIB_PATH = os.environ.get("ADT_LIB_PATH") or os.path.join(os.path.dirname(os.path.abspath(__file__)), "libadt_hip.so")
+if os.environ.get("ADT_LIB_PATH"):          # said on stderr so that a bench line produced with another build can be traced
+    import sys
+    print(f"adt_str_amd: ADT_LIB_PATH overrides the in-tree library: {_LIB_PATH}", file=sys.stderr)
 _lock = threading.Lock()
 _lib = None
 
-ABI_VERSION = 16
+ABI_VERSION = 17
 
 i32, i64, f32, ptr = C.c_int32, C.c_int64, C.c_float, C.c_void_p
 
@@ -70,6 +73,7 @@ SIGNATURES = {
     "adt_attn_keep_bits_bytes": [ptr],
     "adt_attn_bwd_workspace_bytes": [ptr],
     "adt_attn_bwd": [ptr, ptr, ptr, ptr, ptr, ptr, ptr, ptr, ptr, ptr, ptr, C.c_size_t, ptr],
+    "adt_attn_bwd_giveups": [i32],
     "adt_layernorm_fwd": [ptr, i64, ptr, ptr, f32, ptr, ptr, i64, ptr, ptr, i64, i64, ptr, ptr],
     "adt_layernorm_bwd_workspace_bytes": [i64, i64],
     "adt_layernorm_bwd": [ptr, i64, ptr, i64, ptr, ptr, ptr, ptr, ptr, i64, ptr, ptr, ptr, i64, i64, ptr, ptr, ptr, C.c_size_t, ptr],

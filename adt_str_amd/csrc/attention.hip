@@ -716,6 +716,13 @@ static bool wants_fused(const adt_attn_desc* d) {
   if (bwd_env) return bwd_env[0] == 'f';
   return !(d->drop.p > 0.0f) || d->keep_bits != nullptr;
 }
+extern "C" int32_t adt_attn_bwd_giveups(int32_t clear) {
+  unsigned* hw = nullptr;
+  if (adt::attn_bwd_giveup_word(&hw, nullptr) != ADT_OK) return -1;
+  const unsigned n = clear ? __atomic_exchange_n(hw, 0u, __ATOMIC_RELAXED) : __atomic_load_n(hw, __ATOMIC_RELAXED);
+  return n > 0x7fffffffu ? 0x7fffffff : static_cast<int32_t>(n);
+}
+
 extern "C" size_t adt_attn_bwd_workspace_bytes(const adt_attn_desc* d) {
   if (!d || d->batch <= 0 || d->heads <= 0 || d->q_len <= 0 || d->k_len <= 0) return 16;
   // sized by the path that will run (the fused path's region is nkb fp32 copies of dQ: 780 MB at the encoder shape); the capture state of

@@ -24,9 +24,11 @@
 // all the head's other key blocks -- lower AND higher tickets -- so progress needs the head's nkb workgroups resident together: with the
 // lowest unfinished head's workgroups always the first to be dispatched, that holds whenever nkb <= the workgroups one XCD group can hold
 // (one per CU).  The launcher's caller (attention.hip fused_can_run) only takes this path for nkb <= half of that, and never under stream
-// capture; a wave that still waits 2^24 polls gives up, counts itself in the word behind the flags, and ADT_ATTN_BWD_CHECK=1 (the tests)
-// turns that count into ADT_EHIP instead of a silently incomplete dQ.
+// capture; a wave that still waits 2^24 polls gives up and counts itself in the word behind the flags AND in a pinned host word of the
+// device: the next adt_attn_bwd call (or adt_attn_bwd_giveups at the end of a training step) turns that into ADT_EHIP instead of a silently
+// incomplete dQ; ADT_ATTN_BWD_CHECK=1 (the tests) checks synchronously after every launch.
 // delta = rowsum(O * dO) and -lse / scale are prepared per query by a small kernel in front (attn_bwd_stats_kernel).
+#include <mutex>
 #include <type_traits>
 
 #include "attn_common.h"
@@ -299,7 +301,7 @@ __global__ __launch_bounds__(kFbThreads, 1) void attn_bwd_fused_kernel(FusedArgs
       f = __builtin_amdgcn_readfirstlane(f);
       if (f != 0u) break;
       if (++spins > kFbSpinLimit) {                               // never in a healthy launch: report and carry on instead of hanging the GPU
-        if (lane == 0) atomicAdd(fa.flags + static_cast<long>(a.B) * a.H * ns * nkb * 4, 1u);
+        if (lane == 0) attn_bwd_report_giveup(fa, static_cast<long>(a.B) * a.H * ns * nkb * 4);
         break;
       }
       __builtin_amdgcn_s_sleep(8);
@@ -815,7 +817,7 @@ __global__ __launch_bounds__(kFbThreads, 1) void attn_bwd_fused_kernel(FusedArgs
         if (need) f = __hip_atomic_load(flag_of(ljr, ln), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         if (__builtin_amdgcn_ballot_w64(f == 0u) == 0ull) break;
         if (++spins > kFbSpinLimit) {                             // never in a healthy launch: report and carry on instead of hanging the GPU
-          if (lane == 0) atomicAdd(fa.flags + static_cast<long>(a.B) * a.H * ns * nkb * 4, 1u);
+          if (lane == 0) attn_bwd_report_giveup(fa, static_cast<long>(a.B) * a.H * ns * nkb * 4);
           break;
         }
         __builtin_amdgcn_s_sleep(8);
@@ -833,6 +835,31 @@ __global__ __launch_bounds__(kFbThreads, 1) void attn_bwd_fused_kernel(FusedArgs
 }
 
 static size_t align256(size_t x) { return (x + 255) & ~static_cast<size_t>(255); }
+
+// ---- the sticky give-up word (see attn_common.h)
+namespace {
+constexpr int kMaxDevices = 64;
+struct GiveupWords { std::mutex mu; unsigned* host[kMaxDevices] = {}; unsigned* dev[kMaxDevices] = {}; };
+GiveupWords& giveup_words() { static GiveupWords w; return w; }
+}
+int attn_bwd_giveup_word(unsigned** host_word, unsigned** device_alias) {
+  int dev = 0;
+  ADT_HIP_TRY(hipGetDevice(&dev));
+  if (dev < 0 || dev >= kMaxDevices) return set_error(ADT_EHIP, "adt_attn_bwd: device index out of range");
+  GiveupWords& w = giveup_words();
+  std::lock_guard<std::mutex> lock(w.mu);
+  if (!w.host[dev]) {
+    void* h = nullptr; void* d = nullptr;
+    ADT_HIP_TRY(hipHostMalloc(&h, 64, hipHostMallocMapped | hipHostMallocPortable));
+    *static_cast<volatile unsigned*>(h) = 0u;
+    ADT_HIP_TRY(hipHostGetDevicePointer(&d, h, 0));
+    w.host[dev] = static_cast<unsigned*>(h);
+    w.dev[dev] = static_cast<unsigned*>(d);
+  }
+  if (host_word) *host_word = w.host[dev];
+  if (device_alias) *device_alias = w.dev[dev];
+  return ADT_OK;
+}
 static int fused_ns(const adt_attn_desc* d) { return (d->q_len + kFbSlice - 1) / kFbSlice; }
 static int fused_nkb(const adt_attn_desc* d) { return (d->k_len + kFbKeys - 1) / kFbKeys; }
 
@@ -850,6 +877,14 @@ size_t attn_bwd_fused_workspace_bytes(const adt_attn_desc* d) {
 int attn_bwd_fused_prepare(const adt_attn_desc* d, const AttnArgs& a, void* ws, size_t ws_bytes, hipStream_t st, FusedArgs* out) {
   if (ws_bytes < attn_bwd_fused_workspace_bytes(d) || !aligned16(ws)) return set_error(ADT_EINVAL, "adt_attn_bwd: workspace too small");
   FusedArgs fa{};
+  {
+    // an EARLIER launch on this device gave up (its dQ is incomplete): say so now, once, instead of training on -- the word is host
+    // memory, so this read costs nothing and needs no synchronisation
+    unsigned* hw = nullptr;
+    if (int rc = attn_bwd_giveup_word(&hw, &fa.giveup_host)) return rc;
+    const unsigned n = __atomic_exchange_n(hw, 0u, __ATOMIC_RELAXED);
+    if (n) return set_error(ADT_EHIP, "adt_attn_bwd: waves of an earlier one-kernel backward on this device gave up waiting for a dQ tile (its dQ is incomplete)");
+  }
   fa.a = a;
   fa.ns = fused_ns(d);
   fa.nkb = fused_nkb(d);

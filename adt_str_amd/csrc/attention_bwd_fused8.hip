@@ -249,7 +249,7 @@ __global__ __launch_bounds__(kFbThreads, 1) void attn_bwd_fused8_kernel(FusedArg
       f = __builtin_amdgcn_readfirstlane(f);
       if (f != 0u) break;
       if (++spins > kFbSpinLimit) {                               // never in a healthy launch: report and carry on instead of hanging the GPU
-        if (lane == 0) atomicAdd(fa.flags + static_cast<long>(a.B) * a.H * ns * nkb * 4, 1u);
+        if (lane == 0) attn_bwd_report_giveup(fa, static_cast<long>(a.B) * a.H * ns * nkb * 4);
         break;
       }
       __builtin_amdgcn_s_sleep(8);
@@ -657,7 +657,7 @@ __global__ __launch_bounds__(kFbThreads, 1) void attn_bwd_fused8_kernel(FusedArg
         if (need) f = __hip_atomic_load(flag_of(ljr, ln), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         if (__builtin_amdgcn_ballot_w64(f == 0u) == 0ull) break;
         if (++spins > kFbSpinLimit) {                             // never in a healthy launch: report and carry on instead of hanging the GPU
-          if (lane == 0) atomicAdd(fa.flags + static_cast<long>(a.B) * a.H * ns * nkb * 4, 1u);
+          if (lane == 0) attn_bwd_report_giveup(fa, static_cast<long>(a.B) * a.H * ns * nkb * 4);
           break;
         }
         __builtin_amdgcn_s_sleep(8);

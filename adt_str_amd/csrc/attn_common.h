@@ -266,6 +266,7 @@ struct FusedArgs {
   float* part;                        // [B*H][ns][nkb][4 waves][1024]: every key block's dQ^T tile of every slice (nkb > 1)
   unsigned* flags;                    // [B*H][ns][nkb][4 waves] + 4 words: [0] of the tail = number of waves that gave up waiting
   unsigned* sched; unsigned sched_total[8];
+  unsigned* giveup_host;              // pinned host word of this device (attn_bwd_giveup_word): every give-up is also counted there, where the host sees it without a sync
   int nkb, ns;
   unsigned long long* stamps;         // experiment build, kDbg & 32: cycle stamps of one wave's phases in one slice
   int dbg;                            // timing experiments only (ADT_FB_DBG): 1 no hand-off, 2 no dQ product, 4 no dV / dK products, 8 no S / dP chains
@@ -274,6 +275,15 @@ struct FusedArgs {
 size_t attn_bwd_fused_workspace_bytes(const adt_attn_desc* d);
 int attn_bwd_fused_prepare(const adt_attn_desc* d, const AttnArgs& a, void* ws, size_t ws_bytes, hipStream_t st, FusedArgs* out);
 int attn_bwd_fused_check(const FusedArgs& fa, hipStream_t st);
+// A wave of the one-kernel backward that gives up waiting for a dQ tile (kFbSpinLimit) leaves an incomplete dQ.  Besides the per-launch
+// counter in the workspace it bumps a pinned, device-mapped HOST word (one per device, allocated on first use), which
+// attn_bwd_fused_prepare reads before every later launch and adt_attn_bwd_giveups reads on request: the failure surfaces as ADT_EHIP at
+// the next adt_attn_bwd call / at the end of the training step without an environment variable and without a device synchronisation.
+int attn_bwd_giveup_word(unsigned** host_word, unsigned** device_alias);
+__device__ __forceinline__ void attn_bwd_report_giveup(const FusedArgs& fa, long tail_word) {
+  atomicAdd(fa.flags + tail_word, 1u);
+  if (fa.giveup_host) __hip_atomic_fetch_add(fa.giveup_host, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+}
 int launch_attn_bwd_fused8(const adt_attn_desc* d, const AttnArgs& a, void* ws, size_t ws_bytes, hipStream_t st);
 int launch_attn_bwd_fused(const adt_attn_desc* d, const AttnArgs& a, void* ws, size_t ws_bytes, hipStream_t st);
 

@@ -63,7 +63,7 @@ struct GemmArgs {
   Drop drop; unsigned drop_key2;      // drop_key2 = mix32(drop.key)
   int tail_stores;                         // gemm_nt_256_kernel: leave an interior tile's last stores in flight across the tile boundary
   int group_n;                             // gemm_nt_256_kernel: tile columns per column group of the tile order (>= tiles_n: row-major)
-  int stagger;                             // gemm_nt_256_kernel, experiment (ADT_GEMM_STAGGER=<s_memtime ticks>): every second workgroup of an XCD group starts late
+  int stagger;                             // gemm_nt_256_kernel, experiment builds only (-DADT_GEMM_EXPERIMENT, ADT_GEMM_STAGGER=<s_memtime ticks>): every second workgroup of an XCD group starts late
   unsigned* sched; unsigned sched_total[8];  // persistent kernels: per-XCD-group work counters (16 words apart, zero between launches) and the number of tickets each hands out in this launch
 };
 
@@ -652,10 +652,12 @@ __global__ __launch_bounds__(kBigThreads) void gemm_nt_256_kernel(GemmArgs g, in
   const unsigned b_k0 = base0 + 2 * kHalfTile + b_row + c0, b_k1 = base0 + 2 * kHalfTile + b_row + c1;
 
   unsigned* const flag = reinterpret_cast<unsigned*>(smem + kBigBuf + kHalfTile);
+#ifdef ADT_GEMM_EXPERIMENT
   if (g.stagger > 0 && ((blockIdx.x >> 3) & 1) && tid == 0) {          // experiment: half of an XCD's workgroups half a tile behind the others
     const unsigned long long t0 = __builtin_amdgcn_s_memtime();
     while (__builtin_amdgcn_s_memtime() - t0 < static_cast<unsigned long long>(g.stagger)) __builtin_amdgcn_s_sleep(16);
   }
+#endif
   if (tid == 0) *flag = take_ticket(counter, ctotal);
   __syncthreads();
   int v = static_cast<int>(*flag), m0, n0;
@@ -1702,7 +1704,11 @@ extern "C" int adt_gemm_bf16(int32_t trans, int64_t M, int64_t N, int64_t K, con
     const int group_auto = tn >= 24 && tn % 6 == 0 ? 6 : (tn % 4 == 0 && tn % 3 != 0) || tn == 12 ? 4 : 3;
     const int group_n = group_env > 0 ? group_env : group_auto;
     g.group_n = group_n < tn ? group_n : tn;
+    g.stagger = 0;
+#ifdef ADT_GEMM_EXPERIMENT
     { const char* sg = getenv("ADT_GEMM_STAGGER"); g.stagger = sg ? atoi(sg) : 0; }
+    if (g.stagger) fprintf(stderr, "adt_gemm_bf16: ADT_GEMM_STAGGER=%d (experiment build)\n", g.stagger);
+#endif
     static const bool log_forms = getenv("ADT_GEMM_LOG_FORMS") != nullptr;      // debugging aid: which forms does a workload launch?
     const unsigned mask = epilogue_mask(e);
     if (log_forms) fprintf(stderr, "adt_gemm nt256 form: drop=%d colsum=%d mask=0x%x M=%ld N=%ld K=%ld\n", g.drop.on() ? 1 : 0, e.colsum_out ? 1 : 0, mask, (long)M, (long)N, (long)K);

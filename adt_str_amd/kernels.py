@@ -524,3 +524,13 @@ def attn_bwd(q, k, v, o, dout, lse, dq, dk, dv, B, H, Sq, Sk, scale, causal=Fals
     ws = _workspace(nb, q.device)
     _ffi.call("adt_attn_bwd", C.byref(d), _ffi.dptr(q), _ffi.dptr(k), _ffi.dptr(v), _ffi.dptr(o), _ffi.dptr(dout),
               _ffi.dptr(lse), _ffi.dptr(dq), _ffi.dptr(dk), _ffi.dptr(dv), _ffi.dptr(ws), nb, _ffi.current_stream())
+
+
+def check_attn_bwd() -> None:
+    """Raise if a wave of the one-kernel attention backward gave up waiting for a dQ tile since the last check (``adt_attn_bwd_giveups``:
+    a pinned host word the kernels count in -- no synchronisation, a microsecond per call).  The trainers call this at the end of every
+    optimisation step: an incomplete dQ must end the run, not train on."""
+    n = _ffi.load().adt_attn_bwd_giveups(1)
+    if n > 0:
+        raise RuntimeError(f"adt_attn_bwd: {n} wave(s) of the one-kernel attention backward gave up waiting for a dQ tile in an earlier "
+                           "launch (its dQ was incomplete); the step's gradients are not to be trusted")

@@ -290,6 +290,18 @@ def forward_engine_reduced(ddp_model, *args, **kwargs):
     eng = getattr(getattr(ddp_model, "module", None), "engine", None)
     if not isinstance(ddp_model, DDP) or eng is None or getattr(eng, "hf_reducer", None) is None or not ddp_model.require_backward_grad_sync:
         return ddp_model(*args, **kwargs)
+    # Inside no_sync() DDP skips prepare_for_backward AND clears require_forward_param_sync, so module buffers are never re-broadcast
+    # after the first pass, and static_graph's bookkeeping never sees a synchronising backward.  Both are harmless only under the
+    # conditions train.py sets (ddp_broadcast_buffers=False; this model's buffers are constants anyway; no static graph) -- anything
+    # else keeps DDP's own path, said once.
+    n_buffers = sum(1 for _ in ddp_model.module.buffers())
+    if (getattr(ddp_model, "broadcast_buffers", False) and n_buffers > 0) or getattr(ddp_model, "static_graph", False):
+        if not getattr(ddp_model, "_adt_fast_path_note", False):
+            ddp_model._adt_fast_path_note = True
+            warnings.warn("adt_str_amd: DDP was built with broadcast_buffers=True (and the module has buffers) or static_graph=True; the "
+                          "copy-free engine-reduced forward is not taken (DDP's own bucket path runs: correct, ~1 ms per step slower). "
+                          "Pass ddp_broadcast_buffers=False / find_unused_parameters=False as train.py does.")
+        return ddp_model(*args, **kwargs)
     eng.hf_force_sync = True
     try:
         with ddp_model.no_sync():
@@ -396,6 +408,7 @@ class FlatTrainer:
         K.adamw_step(self.pflat, self.gflat, self.m, self.v, self.step_no, lr, self.betas[0], self.betas[1], self.eps, self.wd,
                      self.norm, nodecay=self.nodecay)
         self.eng.refresh_weights(force=True)
+        K.check_attn_bwd()          # a give-up of the one-kernel attention backward (incomplete dQ) in an earlier step ends the run here
         return out["loss"]
 
     def train_step(self, wavs, tokens, token_lengths):

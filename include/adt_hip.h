@@ -288,6 +288,12 @@ size_t adt_attn_keep_bits_bytes(const adt_attn_desc* d);
 size_t adt_attn_bwd_workspace_bytes(const adt_attn_desc* d);
 int adt_attn_bwd(const adt_attn_desc* d, const void* q, const void* k, const void* v, const void* o, const void* dout,
                  const float* lse, void* dq, void* dk, void* dv, void* ws, size_t ws_bytes, void* stream);
+/* The one-kernel backward hands dQ tiles between the key-block workgroups of a head through flags in device memory; a wave whose
+ * partner never shows up within ~5 s gives up (instead of hanging the GPU) and its dQ tile is incomplete.  Every give-up is counted in a
+ * pinned host word of the current device: the next adt_attn_bwd call on the device fails with ADT_EHIP, and this function returns the
+ * count (>= 0; clear != 0 also resets it; -1: no device) without synchronising -- adt_str_amd/trainer.py checks it at the end of every
+ * training step, so a step never silently trains on an incomplete gradient. */
+int32_t adt_attn_bwd_giveups(int32_t clear);
 
 /* ---------------------------------------------------------------------------
  * K6  LayerNorm forward / backward  (nn.LayerNorm(d), eps 1e-5, fp32 statistics)

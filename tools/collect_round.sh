@@ -1,4 +1,4 @@
-# usage: bash tools/collect_round.sh <tag> <dest>   -- copy what tools/run_round.sh / run_pmc_*.sh left under gpurun_out/ into profiles/<dest>/
+# usage: bash tools/collect_round.sh <tag> <dest>   -- copy what tools/run_round_a.sh / run_round_b.sh / run_pmc_*.sh left under gpurun_out/ into profiles/<dest>/
 TAG=$1; P=profiles/$2; O=gpurun_out/round_$TAG
 mkdir -p $P
 for f in bench_train.json bench_train_nodropout.json bench_logmel.json bench_clap.json e2e_config4_scaled.json bench_train_torchrun1.json bench_train_torchrun1_bf16comm.json; do [ -f $O/$f ] && cp $O/$f $P/$f; done

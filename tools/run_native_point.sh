@@ -1,6 +1,6 @@
-# usage: bash tools/run_r05_native.sh   -- the reference's own operating point (2.56 s @ 24 kHz, use_fx_prob 0.3): bench lines, kernel trace, idle gaps
+# usage: bash tools/run_native_point.sh   -- the reference's own operating point (2.56 s @ 24 kHz, use_fx_prob 0.3): bench lines, kernel trace, idle gaps
 R=$GRAFT_REPO_ROOT
-O=$R/gpurun_out/r05_native
+O=$R/gpurun_out/native_point
 mkdir -p $O
 cd $R
 timeout -k 10 600 python bench.py --input-sec 2.56 --sample-rate 24000 --fx-prob 0.3 --steps 40 --warmup 10 --no-clap --no-cpu-baseline > $O/bench_train_native.json 2> $O/bench_train_native.err; cut -c1-300 $O/bench_train_native.json

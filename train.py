@@ -43,11 +43,11 @@ class ADTTrainer(Trainer):
     """HF Trainer subclass of the reference (train.py:33-78)."""
 
     def compute_loss(self, model, inputs, return_outputs=False, **kwargs):
-        if getattr(self, "_is_ddp", None) is None:                           # multi-GPU: `model` is the DDP wrapper accelerate built
-            from torch.nn.parallel import DistributedDataParallel
-            self._is_ddp = isinstance(model, DistributedDataParallel)
+        # multi-GPU: `model` is the DDP wrapper accelerate built.  Tested on EVERY pass (an isinstance is free): an evaluation pass that
+        # hands over the unwrapped model first (eval_on_start, evaluate() before train()) must not pin the slow path for the whole run.
+        from torch.nn.parallel import DistributedDataParallel
         forward = model
-        if self._is_ddp:                                                     # (every pass: idempotent, and it follows a replaced engine object)
+        if isinstance(model, DistributedDataParallel):                       # (every pass: idempotent, and it follows a replaced engine object)
             from adt_str_amd.trainer import forward_engine_reduced, install_engine_reduction
             install_engine_reduction(model, getattr(self.args, "gradient_accumulation_steps", 1))
             forward = lambda **kw: forward_engine_reduced(model, **kw)        # (the engine reduces: DDP's bucket copies are skipped)
