@@ -842,6 +842,295 @@ __global__ __launch_bounds__(kBigThreads) void gemm_nt_256_kernel(GemmArgs g, in
 #undef ADT_MFMA_QUAD
 }
 
+#ifdef ADT_GEMM_RING      // experiment build (make EXTRA=-DADT_GEMM_RING): measured slower than gemm_nt_256_kernel on every shape, see the header below
+// =========================================================================================
+// NT "ring" kernel (round 6): 256 x (64 kWN) tile, 2 x kWN waves, K-steps of 32 through a kStages-slot LDS ring.
+//
+// MEASURED AND NOT TAKEN (profiles/r06/gemm_ring_ab.txt, gemm_ring_pmc.txt; DESIGN 8.1 of round 6).  Correct -- bit for bit
+// gemm_nt_256_kernel on every epilogue form -- and slower everywhere: two workgroups per CU 1.07 x (FFN-1 form) ... 1.5 x (K = 3072), the
+// 256 x 256 form with the deeper ring 1.03 ... 1.2 x.  Counters: a ring slot's rows are 64 bytes (32 k), so every 128-byte line is asked
+// for as two 64-byte L2 requests in different K-steps (TCP_TCC_READ_REQ 36.2 M against 18.9 M per launch at M 63104, N 768, K 3072), and a
+// 256 x 128 tile needs 1.5 x the operand bytes per FLOP (54.4 M requests, L2 misses 10.1 M against 4.9 M): what the second workgroup
+// hides of the epilogue is less than what its K loop loses.  Kept compilable (-DADT_GEMM_RING, ADT_GEMM_NT=2wg / ring, tools/exp_gemm_2wg.py)
+// so that the measurement can be repeated.
+//
+//   kWN = 2, kStages = 3: 256 x 128 tile, four waves (one per SIMD), 72 KiB of LDS -> TWO workgroups per CU, so that one's epilogue /
+//                         store drain / next-tile prologue runs beside the other's K loop (the second half of the grid starts `stagger`
+//                         ticks late, so the two start out of phase).
+//   kWN = 4, kStages = 4: 256 x 256 tile, eight waves, one workgroup per CU as gemm_nt_256_kernel, but with up to ~2.5 K-steps
+//                         (80 KiB) of operand in flight instead of three half-tiles (48 KiB).
+// gemm_nt_256_kernel's K loop is bound by how many operand bytes a CU keeps in flight against a ~1.3 us loaded L2 / Infinity-Cache
+// latency (2.3 GB through 12.6 MB in flight); a 256 x 128 tile needs 1.5 x the bytes per FLOP, which is what the two-workgroup
+// form pays for its overlap (profiles/r06/gemm_ring_ab.txt).
+// Staging: one ring slot = A slab 256 rows x 64 B + B slab (64 kWN) rows x 64 B, filled by global_load_lds_dwordx4 (one wave-instruction
+// = 16 rows x 64 B), kStages - 1 steps ahead.  Position p of LDS row r holds the row's 16-byte chunk p ^ f((r >> 2) & 3), f = {0, 3, 2, 1}:
+// with ds_read_b128's lane groups ({0-3, 12-15, 20-27}, ... -- MI355X_MICROARCH.md, LDS table) the 16 rows x 2 chunks of a group then fall
+// on 16 distinct 16-byte bank slots.  One K-step per wave = 12 ds_read_b128 + 32 MFMAs in two halves of 16 (rows 0-63 / 64-127 of the
+// 128 x 64 wave tile -- the wave tile and the epilogue are gemm_nt_256_kernel's); the reads of each half are issued before the other
+// half's MFMAs (next step's B and low-A fragments go into a second register set), so the matrix pipe does not wait for LDS; ONE
+// s_barrier per K-step, between the halves, publishes the step that landed (counted vmcnt: the DMAs of the younger steps stay in flight
+// across it).  Between K loops the last slot is free: it holds the epilogue's transposition tiles, and the next tile's first
+// kStages - 1 steps are requested into the other slots before the epilogue starts.  Same sums in the same order as gemm_nt_256_kernel:
+// the two agree bit for bit (tools/exp_gemm_2wg.py, tests/test_gemm_gpu.py).
+constexpr int kRingK = 32;
+constexpr int kRingSlabA = 256 * 64;               // 16 KiB
+template <int kWN> struct RingShape {
+  static constexpr int kTileN = 64 * kWN;
+  static constexpr int kWaves = 2 * kWN;
+  static constexpr int kThreads = 64 * kWaves;
+  static constexpr int kSlabB = kTileN * 64;        // 8 / 16 KiB
+  static constexpr int kStage = kRingSlabA + kSlabB;
+  static constexpr int kDmaA = 8 / kWN;             // A-slab DMA instructions per wave and step (16 in all)
+  static constexpr int kDmaOps = kDmaA + 2;         // + the wave's two B-slab instructions
+};
+template <int kWN, int kStages> constexpr int ring_lds_bytes() { return kStages * RingShape<kWN>::kStage + 64; }
+template <int N> __device__ __forceinline__ void ring_wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" :: "n"(N) : "memory"); }
+
+template <int kWN, int kStages, bool kDrop, bool kColsum, unsigned kMask>
+__global__ __launch_bounds__(RingShape<kWN>::kThreads) __attribute__((amdgpu_waves_per_eu(2, 2))) void gemm_nt_ring_kernel(GemmArgs g, int tiles_m, int tiles_n) {
+  using RS = RingShape<kWN>;
+  constexpr int kTileN = RS::kTileN, kStage = RS::kStage, kDmaA = RS::kDmaA, kOps = RS::kDmaOps, kDist = kStages - 1;
+  constexpr int kEpiOff = (kStages - 1) * kStage, kFlagOff = kStages * kStage;
+  static_assert(RS::kWaves * kEpi2Bytes <= kStage, "epilogue tiles fit one ring slot");
+  static_assert((kDist - 1) * kOps <= 63, "counted vmcnt fits its field");
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wr = wave / kWN, wc = wave % kWN;
+  const int nwg = tiles_m * tiles_n;
+  const int q8 = nwg >> 3, r8 = nwg & 7;
+  const int k_steps = g.K / kRingK;                // even and >= 8 (the host takes this kernel for K % 64 == 0, K >= 256)
+
+  const unsigned short* pa[kDmaA];                 // wave w, instruction j fills LDS rows (16 kDmaA) w + 16 j + (lane >> 2) of the A slab
+  const unsigned short* pb[2];                     //                                  rows 32 w + 16 j + (lane >> 2) of the B slab
+  const int xg = blockIdx.x & 7;
+  const int slice0 = xg < r8 ? xg * (q8 + 1) : r8 * (q8 + 1) + (xg - r8) * q8, slice_n = q8 + (xg < r8 ? 1 : 0);
+  unsigned* const counter = g.sched + xg * 16;
+  const unsigned ctotal = g.sched_total[xg];
+  const int src_chunk = (lane & 3) ^ ((4 - ((lane >> 4) & 3)) & 3);      // the chunk of its row this lane's LDS position holds
+  auto set_tile = [&](int v, int& m0, int& n0) {
+    const int logical = slice0 + v;
+    const int per_group = tiles_m * g.group_n;     // column-group-major order, as gemm_nt_256_kernel (group_n counts this kernel's tile columns)
+    const int cg = logical / per_group, rem = logical - cg * per_group;
+    const int gw = min(g.group_n, tiles_n - cg * g.group_n);
+    m0 = (rem / gw) * kBig;
+    n0 = (cg * g.group_n + rem % gw) * kTileN;
+#pragma unroll
+    for (int j = 0; j < kDmaA; ++j) {
+      int ar = m0 + 16 * kDmaA * wave + 16 * j + (lane >> 2);
+      ar = ar < g.M ? ar : g.M - 1;
+      pa[j] = g.A + static_cast<long>(ar) * g.lda + src_chunk * 8;
+    }
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      int br = n0 + 32 * wave + 16 * j + (lane >> 2);
+      br = br < g.N ? br : g.N - 1;
+      pb[j] = g.B + static_cast<long>(br) * g.ldb + src_chunk * 8;
+    }
+  };
+  auto dma_step = [&](int step, int slot) {
+    const long kk = static_cast<long>(step) * kRingK;
+    unsigned char* const dst = smem + slot * kStage;
+#pragma unroll
+    for (int j = 0; j < kDmaA; ++j)
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(pa[j] + kk),
+                                       (__attribute__((address_space(3))) void*)(dst + (kDmaA * wave + j) * 1024), 16, 0, 0);
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(pb[j] + kk),
+                                       (__attribute__((address_space(3))) void*)(dst + kRingSlabA + (2 * wave + j) * 1024), 16, 0, 0);
+  };
+  auto prologue_dma = [&]() {
+#pragma unroll
+    for (int d = 0; d < kDist; ++d) dma_step(d, d);
+  };
+
+  // fragment read addresses inside a slot: row (16 i + (lane & 15)) of the wave's rows, chunk (lane >> 4) at its swizzled position
+  const unsigned base0 = lds_addr(smem);
+  const unsigned fchunk = static_cast<unsigned>(((lane >> 4) ^ ((4 - ((lane >> 2) & 3)) & 3)) * 16);
+  const unsigned a_fr = base0 + static_cast<unsigned>((wr * 128 + (lane & 15)) * 64) + fchunk;                 // + slot * kStage + i * 1024
+  const unsigned b_fr = base0 + kRingSlabA + static_cast<unsigned>((wc * 64 + (lane & 15)) * 64) + fchunk;     // + slot * kStage + j * 1024
+
+  unsigned* const flag = reinterpret_cast<unsigned*>(smem + kFlagOff);
+  if (kWN == 2 && g.stagger > 0 && blockIdx.x >= (gridDim.x >> 1) && tid == 0) {   // the CU's second workgroup starts about half a tile behind the first
+    const unsigned long long t0 = __builtin_amdgcn_s_memtime();
+    while (__builtin_amdgcn_s_memtime() - t0 < static_cast<unsigned long long>(g.stagger)) __builtin_amdgcn_s_sleep(16);
+  }
+  if (tid == 0) *flag = take_ticket(counter, ctotal);
+  __syncthreads();
+  int v = static_cast<int>(*flag), m0, n0;
+  if (static_cast<unsigned>(v) >= static_cast<unsigned>(slice_n)) return;   // block-uniform
+  __syncthreads();
+  set_tile(v, m0, n0);
+  prologue_dma();
+
+  float* ct = reinterpret_cast<float*>(smem + kEpiOff + wave * kEpi2Bytes);
+  unsigned ct_w[4], ct_r[2];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) ct_w[j] = lds_addr(ct) + static_cast<unsigned>(((4 * (lane >> 4)) * 64 + ((j ^ (lane >> 4)) << 4) + (lane & 15)) * 4);
+#pragma unroll
+  for (int pass = 0; pass < 2; ++pass) {
+    const int lr = pass * 8 + (lane >> 3);
+    ct_r[pass] = lds_addr(ct) + static_cast<unsigned>((lr * 64 + ((((lane & 7) >> 1) ^ ((lr >> 2) & 3)) << 4) + (lane & 1) * 8) * 4);
+  }
+
+  bf16x8 fal[4], fah[4], fb[4], fb2[4];
+#define ADT_RING_READ_B(FB, ADDR)                                                                        \
+  do { ADT_DS_READ_B128(FB[0], ADDR, 0); ADT_DS_READ_B128(FB[1], ADDR, 1024); ADT_DS_READ_B128(FB[2], ADDR, 2048); ADT_DS_READ_B128(FB[3], ADDR, 3072); } while (0)
+#define ADT_RING_READ_A(FA, ADDR, OFF)                                                                   \
+  do { ADT_DS_READ_B128(FA[0], ADDR, OFF); ADT_DS_READ_B128(FA[1], ADDR, (OFF) + 1024); ADT_DS_READ_B128(FA[2], ADDR, (OFF) + 2048); ADT_DS_READ_B128(FA[3], ADDR, (OFF) + 3072); } while (0)
+#define ADT_RING_MFMA(I0, FA, FB)                                                                        \
+  do {                                                                                                   \
+    __builtin_amdgcn_sched_barrier(0);                                                                   \
+    __builtin_amdgcn_s_setprio(1);                                                                       \
+    _Pragma("unroll") for (int i = 0; i < 4; ++i)                                                        \
+      _Pragma("unroll") for (int j = 0; j < 4; ++j)                                                      \
+        acc[I0 + i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(FA[i], FB[j], acc[I0 + i][j], 0, 0, 0); \
+    __builtin_amdgcn_s_setprio(0);                                                                       \
+    __builtin_amdgcn_sched_barrier(0);                                                                   \
+  } while (0)
+  // One K-step S whose B / low-A fragments are in FB / fal: high-A reads and the DMA of step S + kDist in front of the low half's MFMAs;
+  // then the barrier that publishes step S + 1 (every step younger than it may still be in flight: `younger` of them were issued),
+  // its B / low-A reads (into FBN / fal) in front of the high half's MFMAs.
+#define ADT_RING_STEP(S, FB, FBN)                                                                        \
+  do {                                                                                                   \
+    const unsigned so = static_cast<unsigned>(slot) * kStage;                                            \
+    const int slot1 = slot == kStages - 1 ? 0 : slot + 1, slotd = slot == 0 ? kStages - 1 : slot - 1;    \
+    ADT_RING_READ_A(fah, a_fr + so, 4096);                                                               \
+    if ((S) + kDist < k_steps) dma_step((S) + kDist, slotd);                                             \
+    asm volatile("s_waitcnt lgkmcnt(4)" ::: "memory");                                                   \
+    ADT_RING_MFMA(0, fal, FB);                                                                           \
+    if ((S) + 1 < k_steps) {                                                                             \
+      const int younger = min(kDist - 1, k_steps - 2 - (S));                                             \
+      if (younger >= 3) ring_wait_vmcnt<3 * kOps>();                                                     \
+      else if (younger == 2) ring_wait_vmcnt<2 * kOps>();                                                \
+      else if (younger == 1) ring_wait_vmcnt<kOps>();                                                    \
+      else ring_wait_vmcnt<0>();                                                                         \
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                                                 \
+      asm volatile("s_barrier" ::: "memory");                                                            \
+      const unsigned sn = static_cast<unsigned>(slot1) * kStage;                                         \
+      ADT_RING_READ_B(FBN, b_fr + sn);                                                                   \
+      ADT_RING_READ_A(fal, a_fr + sn, 0);                                                                \
+    } else {                                                                                             \
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                                                 \
+    }                                                                                                    \
+    ADT_RING_MFMA(4, fah, FB);                                                                           \
+    slot = slot1;                                                                                        \
+  } while (0)
+  static_assert(kDist - 1 <= 3, "ADT_RING_STEP's counted waits cover up to three younger steps");
+
+#ifdef ADT_GEMM_EXPERIMENT
+  int stamp_tile = 0;
+#endif
+  while (true) {
+    f32x4 acc[8][4];
+#pragma unroll
+    for (int i = 0; i < 8; ++i)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    // this tile's bias piece and the next tile's ticket: requested here, first used after the K loop (inline asm, as in gemm_nt_256_kernel)
+    const int ecolL = n0 + wc * 64 + (lane & 7) * 8;
+    const bool efullL = ecolL + 8 <= g.N;
+    const bool has_bias = g.ep.bias != nullptr && efullL;
+    const float* bptr = has_bias ? g.ep.bias + ecolL : reinterpret_cast<const float*>(g.A);
+    f32x4 braw0, braw1;
+    if constexpr ((kMask & (kEpiGeneric | kEfBias)) != 0u) {
+      asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(braw0) : "v"(bptr) : "memory");
+      asm volatile("global_load_dwordx4 %0, %1, off offset:16" : "=v"(braw1) : "v"(bptr) : "memory");
+    }
+    unsigned v_next;
+    if (tid == 0) asm volatile("global_atomic_add %0, %1, %2, off sc0" : "=v"(v_next) : "v"(counter), "v"(1u) : "memory");
+    // the first steps were requested before the previous tile's epilogue: everything older than the three operations above has to be done
+    asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
+    asm volatile("s_barrier" ::: "memory");          // ... for every wave; and every wave has left the previous epilogue (the last slot is a stage again)
+    ADT_GSTAMP(0);
+    int slot = 0;
+    ADT_RING_READ_B(fb, b_fr);
+    ADT_RING_READ_A(fal, a_fr, 0);
+    for (int s = 0; s < k_steps; s += 2) {
+      ADT_RING_STEP(s, fb, fb2);
+      ADT_RING_STEP(s + 1, fb2, fb);
+    }
+    // every DMA has landed (vmcnt(0) at step k_steps - 2) and this wave's fragment reads are done
+    if (tid == 0) { ticket_drawn(counter, v_next, ctotal); *flag = v_next; }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    asm volatile("s_barrier" ::: "memory");            // all waves: the ring is free, the flag is visible
+    ADT_GSTAMP(1);
+    const int em0 = m0;
+    v = static_cast<int>(*flag);
+    const bool more = static_cast<unsigned>(v) < static_cast<unsigned>(slice_n);   // block-uniform
+    if (more) {
+      set_tile(v, m0, n0);
+      prologue_dma();                                  // flies under the epilogue below
+    }
+
+    float biasL[8];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      if constexpr ((kMask & (kEpiGeneric | kEfBias)) != 0u) { biasL[e] = has_bias ? braw0[e] : 0.f; biasL[4 + e] = has_bias ? braw1[e] : 0.f; }
+      else { biasL[e] = 0.f; biasL[4 + e] = 0.f; }
+    }
+    float csL[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    const EpiAddr eaL = epilogue_addr<kDrop, kMask>(g, em0 + wr * 128 + (lane >> 3), ecolL);
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        asm volatile("ds_write_b32 %0, %1" :: "v"(ct_w[j]), "v"(acc[i][j][0]));
+        asm volatile("ds_write_b32 %0, %1 offset:256" :: "v"(ct_w[j]), "v"(acc[i][j][1]));
+        asm volatile("ds_write_b32 %0, %1 offset:512" :: "v"(ct_w[j]), "v"(acc[i][j][2]));
+        asm volatile("ds_write_b32 %0, %1 offset:768" :: "v"(ct_w[j]), "v"(acc[i][j][3]));
+      }
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      __builtin_amdgcn_wave_barrier();
+      f32x4 zz[2][2];
+      asm volatile("ds_read_b128 %0, %1" : "=v"(zz[0][0]) : "v"(ct_r[0]));
+      asm volatile("ds_read_b128 %0, %1 offset:16" : "=v"(zz[0][1]) : "v"(ct_r[0]));
+      asm volatile("ds_read_b128 %0, %1" : "=v"(zz[1][0]) : "v"(ct_r[1]));
+      asm volatile("ds_read_b128 %0, %1 offset:16" : "=v"(zz[1][1]) : "v"(ct_r[1]));
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      __builtin_amdgcn_sched_barrier(0);
+      __builtin_amdgcn_wave_barrier();
+#pragma unroll
+      for (int pass = 0; pass < 2; ++pass) {
+        const int row = em0 + wr * 128 + i * 16 + pass * 8 + (lane >> 3);
+        float z[8] = {zz[pass][0][0], zz[pass][0][1], zz[pass][0][2], zz[pass][0][3], zz[pass][1][0], zz[pass][1][1], zz[pass][1][2], zz[pass][1][3]};
+        if (row < g.M && efullL) {
+          epilogue_apply8<kDrop, kMask>(g, z, biasL, eaL, em0 + wr * 128 + (lane >> 3), i * 16 + pass * 8, ecolL);
+          if (kColsum) {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) csL[e] += g.ep.out_fp32 ? z[e] : bf2f(f2bf(z[e]));
+          }
+        }
+      }
+    }
+    if (kColsum) {
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        csL[e] += __shfl_xor(csL[e], 8);
+        csL[e] += __shfl_xor(csL[e], 16);
+        csL[e] += __shfl_xor(csL[e], 32);
+      }
+      if (lane < 8 && efullL) {
+        float* cp = g.colsum_ws + static_cast<long>(em0 / 128 + wr) * g.N + ecolL;
+        *reinterpret_cast<float4*>(cp) = float4{csL[0], csL[1], csL[2], csL[3]};
+        *reinterpret_cast<float4*>(cp + 4) = float4{csL[4], csL[5], csL[6], csL[7]};
+      }
+    }
+    ADT_GSTAMP(2);
+    if (!more) break;
+#ifdef ADT_GEMM_EXPERIMENT
+    ++stamp_tile;
+#endif
+  }
+#undef ADT_RING_STEP
+#undef ADT_RING_MFMA
+#undef ADT_RING_READ_A
+#undef ADT_RING_READ_B
+}
+
+#endif  // ADT_GEMM_RING
+
 // =========================================================================================
 // TN kernel (weight gradients), LDS-DMA staging (used when K % 64 == 0).
 // Operand tiles are [64 k][128 cols] (256-byte rows); one wave-instruction of global_load_lds
@@ -1480,6 +1769,53 @@ static int dispatch_nt_256(const GemmArgs& g, bool colsum, unsigned mask, dim3 g
   return drop ? launch_nt_256<true, false, kEpiGeneric>(g, grid, tm, tn, st) : launch_nt_256<false, false, kEpiGeneric>(g, grid, tm, tn, st);
 }
 
+#ifdef ADT_GEMM_RING
+// The ring kernels (gemm_nt_ring_kernel: 256 x 128 tiles, two workgroups per CU; 256 x 256 tiles with a four-slot ring), same instantiation list.
+template <int kWN, int kStages, bool kDrop, bool kColsum, unsigned kMask>
+static int launch_nt_ring(const GemmArgs& g, dim3 grid, int tm, int tn, hipStream_t st) {
+  static thread_local int attr_dev = -1;
+  int dev = 0;
+  ADT_HIP_TRY(hipGetDevice(&dev));
+  constexpr int lds = ring_lds_bytes<kWN, kStages>();
+  if (attr_dev != dev) {
+    ADT_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_nt_ring_kernel<kWN, kStages, kDrop, kColsum, kMask>), hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+    attr_dev = dev;
+  }
+  hipLaunchKernelGGL((gemm_nt_ring_kernel<kWN, kStages, kDrop, kColsum, kMask>), grid, dim3(RingShape<kWN>::kThreads), lds, st, g, tm, tn);
+  return ADT_OK;
+}
+template <int kWN, int kStages>
+static int dispatch_nt_ring(const GemmArgs& g, bool colsum, unsigned mask, dim3 grid, int tm, int tn, hipStream_t st) {
+  const bool drop = g.drop.on();
+  static const bool generic_only = getenv("ADT_GEMM_GENERIC") != nullptr;
+  if (!generic_only) {
+#define ADT_NTRING_CASE(D, C, MK) if (drop == D && colsum == C && mask == (MK)) return launch_nt_ring<kWN, kStages, D, C, (MK)>(g, grid, tm, tn, st);
+    ADT_NT256_FORMS(ADT_NTRING_CASE)
+#undef ADT_NTRING_CASE
+  }
+  if (colsum) return drop ? launch_nt_ring<kWN, kStages, true, true, kEpiGeneric>(g, grid, tm, tn, st) : launch_nt_ring<kWN, kStages, false, true, kEpiGeneric>(g, grid, tm, tn, st);
+  return drop ? launch_nt_ring<kWN, kStages, true, false, kEpiGeneric>(g, grid, tm, tn, st) : launch_nt_ring<kWN, kStages, false, false, kEpiGeneric>(g, grid, tm, tn, st);
+}
+
+#endif  // ADT_GEMM_RING
+
+// Which persistent NT kernel a large product takes: 1 = gemm_nt_256_kernel (256 x 256 tiles, half-tile phases); 2 = ring kernel, 256 x 128
+// tiles, two workgroups per CU; 3 = ring kernel, 256 x 256 tiles, four-slot ring.
+// ADT_GEMM_NT=256 / 2wg / ring forces one (A/B runs, tests); read once -- except under ADT_GEMM_ENV_DYNAMIC=1 (tools that switch inside one process).
+static int nt_persistent_form(int64_t M, int64_t N, int64_t K, unsigned mask) {
+  static const bool dynamic = getenv("ADT_GEMM_ENV_DYNAMIC") != nullptr;
+  auto read = [] { const char* v = getenv("ADT_GEMM_NT"); return !v ? 0 : (v[0] == '2' && v[1] == 'w') ? 2 : v[0] == 'r' ? 3 : 1; };
+  static const int forced_once = read();
+  const int forced = dynamic ? read() : forced_once;
+  (void)M; (void)N; (void)K; (void)mask;
+#ifdef ADT_GEMM_RING
+  if (forced) return forced;
+#else
+  (void)forced;            // the ring kernels are not in this build: everything takes gemm_nt_256_kernel
+#endif
+  return 1;
+}
+
 static int set_big_lds_once() {      // the persistent kernels use the CU's whole LDS
   static thread_local int done_for = -1;
   int dev = 0;
@@ -1687,11 +2023,16 @@ extern "C" int adt_gemm_bf16(int32_t trans, int64_t M, int64_t N, int64_t K, con
     if (g.drop.on()) return set_error(ADT_EINVAL, "adt_gemm_bf16: dropout is not supported with trans = 1");
     hipLaunchKernelGGL((gemm_bf16_kernel<true, false>), grid, dim3(kGemmThreads), kGemmLds, st, g);
   } else if (persistent_ok && use_big_tile(M, N, K) && vector_epilogue_ok(g, e)) {
-    const int tm = static_cast<int>((M + kBig - 1) / kBig), tn = static_cast<int>((N + kBig - 1) / kBig);
+    const unsigned mask = epilogue_mask(e);
+    const int nt_form = nt_persistent_form(M, N, K, mask);
+    const bool two_wg = nt_form == 2;
+    const int tile_n = two_wg ? 128 : kBig;
+    const int tm = static_cast<int>((M + kBig - 1) / kBig), tn = static_cast<int>((N + tile_n - 1) / tile_n);
     int n_cu = 0;
     if (int rc = device_cu_count(&n_cu)) return rc;
     const long nt = static_cast<long>(tm) * tn;
-    const dim3 g1(static_cast<unsigned>(nt < n_cu ? nt : n_cu));          // persistent: one workgroup per CU
+    const long wg_max = two_wg ? 2l * n_cu : n_cu;
+    const dim3 g1(static_cast<unsigned>(nt < wg_max ? nt : wg_max));      // persistent: one workgroup per CU (two of the 256 x 128 form)
     for (int x = 0; x < 8; ++x)          // per slice: one ticket per tile + the ending ticket of each of its workgroups
       g.sched_total[x] = static_cast<unsigned>(nt / 8 + (x < nt % 8 ? 1 : 0)) + g1.x / 8 + (static_cast<unsigned>(x) < g1.x % 8 ? 1u : 0u);
     if (int rc = sched_counters(stream, &g.sched)) return rc;
@@ -1701,23 +2042,34 @@ extern "C" int adt_gemm_bf16(int32_t trans, int64_t M, int64_t N, int64_t K, con
     // tile columns per column group: measured per number of tile columns (tools/exp_gemm_group.py, profiles/r05/gemm_group_n.txt: M = 63104,
     // bare products): 12 columns (N = 3072) 4 -> 305 us against 323 with 3 (308 / 319 / 325 with 2 / 6 / 12); 9 columns (N = 2304) 3 -> 195
     // (198 with 4, 228 with 5); 24 columns (N = 6144) 6 -> 538 (547 / 556 / 583 with 3 / 4 / 8); three columns or fewer: all of them
-    const int group_auto = tn >= 24 && tn % 6 == 0 ? 6 : (tn % 4 == 0 && tn % 3 != 0) || tn == 12 ? 4 : 3;
-    const int group_n = group_env > 0 ? group_env : group_auto;
+    const int tn256 = static_cast<int>((N + kBig - 1) / kBig);
+    const int group_auto = tn256 >= 24 && tn256 % 6 == 0 ? 6 : (tn256 % 4 == 0 && tn256 % 3 != 0) || tn256 == 12 ? 4 : 3;
+    const int group_n = (group_env > 0 ? group_env : group_auto) * (two_wg ? 2 : 1);      // (counted in this kernel's tile columns)
     g.group_n = group_n < tn ? group_n : tn;
     g.stagger = 0;
 #ifdef ADT_GEMM_EXPERIMENT
     { const char* sg = getenv("ADT_GEMM_STAGGER"); g.stagger = sg ? atoi(sg) : 0; }
     if (g.stagger) fprintf(stderr, "adt_gemm_bf16: ADT_GEMM_STAGGER=%d (experiment build)\n", g.stagger);
 #endif
+    if (two_wg) {
+      // the CU's second workgroup starts about half a tile late, so that one's epilogue meets the other's K loop (ticks of s_memtime)
+      static const int stagger2_env = getenv("ADT_GEMM_STAGGER2") ? atoi(getenv("ADT_GEMM_STAGGER2")) : -1;
+      g.stagger = stagger2_env >= 0 ? stagger2_env : static_cast<int>(K / 32) * 300 + 5000;
+    }
     static const bool log_forms = getenv("ADT_GEMM_LOG_FORMS") != nullptr;      // debugging aid: which forms does a workload launch?
-    const unsigned mask = epilogue_mask(e);
     if (log_forms) fprintf(stderr, "adt_gemm nt256 form: drop=%d colsum=%d mask=0x%x M=%ld N=%ld K=%ld\n", g.drop.on() ? 1 : 0, e.colsum_out ? 1 : 0, mask, (long)M, (long)N, (long)K);
     float* cs_slice = nullptr;
     if (e.colsum_out) {
       cs_slice = reduce_queue_slice(static_cast<size_t>(2 * tm) * g.N * 4, st);          // open reduction queue: the second stage is deferred
       g.colsum_ws = cs_slice ? cs_slice : static_cast<float*>(ws);
     }
+#ifdef ADT_GEMM_RING
+    const int rc = two_wg ? dispatch_nt_ring<2, 3>(g, e.colsum_out != nullptr, mask, g1, tm, tn, st)
+                   : nt_form == 3 ? dispatch_nt_ring<4, 4>(g, e.colsum_out != nullptr, mask, g1, tm, tn, st)
+                                  : dispatch_nt_256(g, e.colsum_out != nullptr, mask, g1, tm, tn, st);
+#else
     const int rc = dispatch_nt_256(g, e.colsum_out != nullptr, mask, g1, tm, tn, st);
+#endif
     if (rc) return rc;
 #ifdef ADT_GEMM_EXPERIMENT
     if (getenv("ADT_GEMM_STAMPS")) {
