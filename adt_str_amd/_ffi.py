@@ -49,7 +49,7 @@ class AttnDesc(C.Structure):
                 ("head_dim", C.c_int32), ("causal", C.c_int32), ("ldq", C.c_int64), ("ldk", C.c_int64),
                 ("ldv", C.c_int64), ("ldo", C.c_int64), ("scale", C.c_float), ("mask_value", C.c_float),
                 ("key_len", C.c_void_p), ("drop", Dropout), ("dq_colsum", C.c_void_p), ("dk_colsum", C.c_void_p),
-                ("dv_colsum", C.c_void_p), ("keep_bits", C.c_void_p)]
+                ("dv_colsum", C.c_void_p), ("keep_bits", C.c_void_p), ("f32_products", C.c_int32)]
 
 
 class AffWeights(C.Structure):
@@ -93,7 +93,8 @@ SIGNATURES = {
     "adt_embed_bwd_operands": [ptr, ptr, f32, ptr, i64, ptr, i64, i64, i64, ptr, ptr],
     "adt_cross_entropy_workspace_bytes": [i64],
     "adt_cross_entropy": [ptr, i64, ptr, i64, i64, i64, ptr, ptr, i64, ptr, C.c_size_t, ptr],
-    "adt_gemm_f32": [i32, i64, i64, i64, ptr, i64, ptr, i64, ptr, i64, ptr, ptr],
+    "adt_gemm_f32_workspace_bytes": [i32, i64, i64, i64],
+    "adt_gemm_f32": [i32, i64, i64, i64, ptr, i64, ptr, i64, ptr, i64, ptr, ptr, C.c_size_t, ptr],
     "adt_attn_fwd_f32": [ptr, ptr, ptr, ptr, ptr, ptr, ptr],
     "adt_attn_bwd_f32_workspace_bytes": [ptr],
     "adt_attn_bwd_f32": [ptr, ptr, ptr, ptr, ptr, ptr, ptr, ptr, ptr, ptr, ptr, C.c_size_t, ptr],
@@ -130,7 +131,7 @@ _RESTYPES.update({n: C.c_size_t for n in ("adt_mix_workspace_bytes", "adt_gemm_w
                                           "adt_layernorm_bwd_workspace_bytes", "adt_colsum_workspace_bytes", "adt_gemm_colsum_workspace_bytes",
                                           "adt_cross_entropy_workspace_bytes", "adt_grad_norm_workspace_bytes",
                                           "adt_htsat_fusion_embed_workspace_bytes",
-                                          "adt_attn_bwd_f32_workspace_bytes", "adt_colsum_f32_workspace_bytes")})
+                                          "adt_attn_bwd_f32_workspace_bytes", "adt_colsum_f32_workspace_bytes", "adt_gemm_f32_workspace_bytes")})
 
 
 class AdtError(RuntimeError):

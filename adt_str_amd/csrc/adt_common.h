@@ -20,6 +20,9 @@ int launch_fx_chain(float* wav, long ld, const int32_t* clip_len, const adt_fx_p
 // number of tickets per counter and the workgroup that draws the last one resets it (gemm.hip), so nothing is tracked here.
 int sched_counters(void* stream, unsigned** counters);
 
+// gemm.hip: out[m, n] = alpha * sum over s of slabs[s][m, n] in slab order (split-K partials; N % 4 == 0)
+void launch_reduce_slabs(const float* slabs, int splits, long mn, int N, float alpha, float* out, long ldc, hipStream_t st);
+
 // nn_ops.hip: out[c] = sum over the n_part rows of partial[n_part][width] (fixed order)
 void launch_reduce_partials(const float* partial, int n_part, int width, float* out, hipStream_t st);
 

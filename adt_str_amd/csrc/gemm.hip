@@ -1722,6 +1722,10 @@ __global__ __launch_bounds__(256) void reduce_slabs_kernel(const float* __restri
   o[0] = s.x * alpha; o[1] = s.y * alpha; o[2] = s.z * alpha; o[3] = s.w * alpha;
 }
 
+void launch_reduce_slabs(const float* slabs, int splits, long mn, int N, float alpha, float* out, long ldc, hipStream_t st) {
+  hipLaunchKernelGGL(reduce_slabs_kernel, dim3(static_cast<unsigned>((mn / 4 + 255) / 256)), dim3(256), 0, st, slabs, splits, mn, N, alpha, out, ldc);
+}
+
 // One instantiation of the persistent NT kernel: (dropout, column sums, epilogue form).
 template <bool kDrop, bool kColsum, unsigned kMask>
 static int launch_nt_256(const GemmArgs& g, dim3 grid, int tm, int tn, hipStream_t st) {

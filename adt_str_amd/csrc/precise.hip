@@ -30,11 +30,13 @@ __device__ __forceinline__ int rowmap(int reg, int h) { return (reg & 3) + 8 * (
 
 // =============================================================================================== GEMM
 constexpr int kBM = 128, kBN = 128, kBK = 16, kLdT = kBM + 4;       // LDS tiles are k-major: Xs[k][row], 528-byte rows
+constexpr int kXKf = 32;                                             // K granule of a split (= the split-bf16 kernel's K-tile)
 
 struct GemmF32Args {
   const float *A, *B; float* C; long lda, ldb, ldc; int M, N, K;
   const float* bias; const float* gelu_grad_of; long ld_gg; float* pre_act_out; long ld_pa;
   const float* residual; long ld_res; int res_row_mod; int act; float alpha; Drop drop; int drop_after_residual; int act_grad_mode;
+  int k_tiles_per_split; float* slabs;     // split-K (blockIdx.z = split): plain fp32 partial tiles into slabs[split][M][N], summed in slab order afterwards
 };
 
 // One 128 x 16 operand tile as two float4 per thread.  kKMajor = false: X is [rows][K] (k contiguous);
@@ -69,41 +71,22 @@ __device__ __forceinline__ float gelu_erf_grad(float u) {
   return 0.5f * (1.0f + erff(u * 0.70710678118654752440f)) + u * 0.39894228040143267794f * expf(-0.5f * u * u);
 }
 
-template <bool kAK, bool kBK_>
-__global__ __launch_bounds__(256) void gemm_f32_kernel(GemmF32Args g) {
-  __shared__ __attribute__((aligned(16))) float As[kBK * kLdT];
-  __shared__ __attribute__((aligned(16))) float Bs[kBK * kLdT];
-  const int tid = threadIdx.x, lane = tid & 63, r = lane & 31, h = lane >> 5;
-  const int wave = tid >> 6, wm = wave >> 1, wn = wave & 1;
-  const int m0 = blockIdx.y * kBM, n0 = blockIdx.x * kBN;
-  f32x16 acc[2][2];
+// The epilogue both GEMM kernels share: acc[mi][ni] is the 32 x 32 block (rows m0 + wm * 64 + mi * 32 + rowmap(e, h), column n0 + wn * 64 + ni * 32 + r).
+__device__ __forceinline__ void gemm_f32_epilogue(const GemmF32Args& g, const f32x16 (&acc)[2][2], int m0, int n0, int wm, int wn, int r, int h) {
+  if (g.slabs) {                             // a K split: the raw partial tile
+    float* const slab = g.slabs + static_cast<long>(blockIdx.z) * g.M * g.N;
 #pragma unroll
-  for (int i = 0; i < 2; ++i)
+    for (int mi = 0; mi < 2; ++mi)
 #pragma unroll
-    for (int j = 0; j < 2; ++j)
+      for (int ni = 0; ni < 2; ++ni) {
+        const int col = n0 + wn * 64 + ni * 32 + r;
 #pragma unroll
-      for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
-  float4 av[2], bv[2];
-  const int nkt = (g.K + kBK - 1) / kBK;
-  tile_fetch<kAK>(g.A, g.lda, g.M, g.K, m0, 0, tid, av);
-  tile_fetch<kBK_>(g.B, g.ldb, g.N, g.K, n0, 0, tid, bv);
-  for (int kt = 0; kt < nkt; ++kt) {
-    tile_store<kAK>(As, tid, av);
-    tile_store<kBK_>(Bs, tid, bv);
-    __syncthreads();
-    if (kt + 1 < nkt) {
-      tile_fetch<kAK>(g.A, g.lda, g.M, g.K, m0, (kt + 1) * kBK, tid, av);
-      tile_fetch<kBK_>(g.B, g.ldb, g.N, g.K, n0, (kt + 1) * kBK, tid, bv);
-    }
-#pragma unroll
-    for (int kk = 0; kk < kBK / 2; ++kk) {
-      const float* ar = As + (2 * kk + h) * kLdT + wm * 64 + r;
-      const float* br = Bs + (2 * kk + h) * kLdT + wn * 64 + r;
-      const float a0 = ar[0], a1 = ar[32], b0 = br[0], b1 = br[32];
-      acc[0][0] = mfma32(a0, b0, acc[0][0]); acc[0][1] = mfma32(a0, b1, acc[0][1]);
-      acc[1][0] = mfma32(a1, b0, acc[1][0]); acc[1][1] = mfma32(a1, b1, acc[1][1]);
-    }
-    __syncthreads();
+        for (int e = 0; e < 16; ++e) {
+          const int row = m0 + wm * 64 + mi * 32 + rowmap(e, h);
+          if (row < g.M && col < g.N) slab[static_cast<long>(row) * g.N + col] = acc[mi][ni][e];
+        }
+      }
+    return;
   }
   const uint64_t dld = drop_ld(static_cast<uint64_t>(g.N));
 #pragma unroll
@@ -135,6 +118,157 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmF32Args g) {
         g.C[static_cast<long>(row) * g.ldc + col] = z;
       }
     }
+}
+
+template <bool kAK, bool kBK_>
+__global__ __launch_bounds__(256) void gemm_f32_kernel(GemmF32Args g) {
+  __shared__ __attribute__((aligned(16))) float As[kBK * kLdT];
+  __shared__ __attribute__((aligned(16))) float Bs[kBK * kLdT];
+  const int tid = threadIdx.x, lane = tid & 63, r = lane & 31, h = lane >> 5;
+  const int wave = tid >> 6, wm = wave >> 1, wn = wave & 1;
+  const int m0 = blockIdx.y * kBM, n0 = blockIdx.x * kBN;
+  f32x16 acc[2][2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+  float4 av[2], bv[2];
+  const int nkt_all = (g.K + kBK - 1) / kBK;
+  const int kt0 = g.slabs ? static_cast<int>(blockIdx.z) * g.k_tiles_per_split * (kXKf / kBK) : 0;      // (splits are counted in 32-deep steps for both kernels)
+  const int nkt = g.slabs ? min(nkt_all, kt0 + g.k_tiles_per_split * (kXKf / kBK)) : nkt_all;
+  tile_fetch<kAK>(g.A, g.lda, g.M, g.K, m0, kt0 * kBK, tid, av);
+  tile_fetch<kBK_>(g.B, g.ldb, g.N, g.K, n0, kt0 * kBK, tid, bv);
+  for (int kt = kt0; kt < nkt; ++kt) {
+    tile_store<kAK>(As, tid, av);
+    tile_store<kBK_>(Bs, tid, bv);
+    __syncthreads();
+    if (kt + 1 < nkt) {
+      tile_fetch<kAK>(g.A, g.lda, g.M, g.K, m0, (kt + 1) * kBK, tid, av);
+      tile_fetch<kBK_>(g.B, g.ldb, g.N, g.K, n0, (kt + 1) * kBK, tid, bv);
+    }
+#pragma unroll
+    for (int kk = 0; kk < kBK / 2; ++kk) {
+      const float* ar = As + (2 * kk + h) * kLdT + wm * 64 + r;
+      const float* br = Bs + (2 * kk + h) * kLdT + wn * 64 + r;
+      const float a0 = ar[0], a1 = ar[32], b0 = br[0], b1 = br[32];
+      acc[0][0] = mfma32(a0, b0, acc[0][0]); acc[0][1] = mfma32(a0, b1, acc[0][1]);
+      acc[1][0] = mfma32(a1, b0, acc[1][0]); acc[1][1] = mfma32(a1, b1, acc[1][1]);
+    }
+    __syncthreads();
+  }
+  gemm_f32_epilogue(g, acc, m0, n0, wm, wn, r, h);
+}
+
+// ----------------------------------------------------------------------------------------------- split-bf16 products ("bf16x3")
+// The same contraction on the bf16 matrix pipe (16 x the f32-input rate): every fp32 operand x is split once, while its tile is
+// staged, into two bf16 planes hi = bf16(x), lo = bf16(x - hi) -- x = hi + lo to 2^-17 relative -- and a product a b is taken as
+// a_lo b_hi + a_hi b_lo + a_hi b_hi: three v_mfma_f32_32x32x16_bf16 into ONE fp32 accumulator (the dropped a_lo b_lo term is 2^-18 of
+// the product).  Error per product ~1e-5 relative against 6e-8 for the exact f32 MFMA and 4e-3 for plain bf16 operands: the parity arm
+// that meets BASELINE's "logits within 1e-3 rel-tol of the CPU reference" at several times the f32-MFMA arm's speed.  Everything around
+// the products -- operand layouts, the epilogue (gemm_f32_epilogue), fp32 activations, the accumulation order along k in steps of 16 --
+// is the f32 path's; selected per call (layout bit 4 of adt_gemm_f32, adt_attn_desc.f32_products).
+// Not representable: an operand whose bf16 rounding overflows (|x| > 3.39e38) gives hi = inf, lo = nan.
+typedef __attribute__((ext_vector_type(8))) short bf16x8s;
+typedef __bf16 bf16x2v_ __attribute__((ext_vector_type(2)));
+typedef float f32x2_ __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ unsigned pack_bf2_(float a, float b) { return __builtin_bit_cast(unsigned, __builtin_convertvector(f32x2_{a, b}, bf16x2v_)); }
+__device__ __forceinline__ void split2(float a, float b, unsigned& hi, unsigned& lo) {
+  hi = pack_bf2_(a, b);
+  lo = pack_bf2_(a - __uint_as_float(hi << 16), b - __uint_as_float(hi & 0xffff0000u));
+}
+__device__ __forceinline__ void split4(const float4& v, uint2& hi, uint2& lo) { split2(v.x, v.y, hi.x, lo.x); split2(v.z, v.w, hi.y, lo.y); }
+__device__ __forceinline__ f32x16 mfma_x3(const bf16x8s& ah, const bf16x8s& al, const bf16x8s& bh, const bf16x8s& bl, f32x16 c) {
+  c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, bh, c, 0, 0, 0);        // the small terms first
+  c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bl, c, 0, 0, 0);
+  return __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bh, c, 0, 0, 0);
+}
+
+constexpr int kXK = 32;                     // K-tile of the split kernel
+constexpr int kXPitch = 80;                 // bytes per LDS row of a plane: 32 bf16 + 16 (16 consecutive rows -> 16 distinct 16-byte bank slots)
+constexpr int kXPlane = 128 * kXPitch;      // one plane of one operand tile: 10,240 B; A_hi | A_lo | B_hi | B_lo = 40 KiB
+
+// One 128 x 32 operand tile as four float4 per thread.  kKMajor = false: X is [rows][K] -- float4 i = row (tid >> 3) + 32 i, k (tid & 7) * 4 .. + 3;
+// true: X is [K][rows] -- float4 i = k 4 (tid >> 5) + i, rows 4 (tid & 31) .. + 3 (a 4 x 4 block, transposed in registers when it is stored).
+template <bool kKMajor>
+__device__ __forceinline__ void xtile_fetch(const float* __restrict__ X, long ld, int rows, int K, int r0, int k0, int tid, float4 (&v)[4]) {
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    int r, k;
+    if (!kKMajor) { r = r0 + (tid >> 3) + 32 * i; k = k0 + (tid & 7) * 4; }
+    else { k = k0 + 4 * (tid >> 5) + i; r = r0 + (tid & 31) * 4; }
+    v[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (r < rows && k < K) v[i] = *reinterpret_cast<const float4*>(kKMajor ? X + static_cast<long>(k) * ld + r : X + static_cast<long>(r) * ld + k);
+  }
+}
+template <bool kKMajor>
+__device__ __forceinline__ void xtile_store(unsigned char* hi_plane, unsigned char* lo_plane, int tid, const float4 (&v)[4]) {
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    float4 w;
+    int row, k;
+    if (!kKMajor) { w = v[i]; row = (tid >> 3) + 32 * i; k = (tid & 7) * 4; }
+    else {                                   // row 4 (tid & 31) + i of the block: its four consecutive k
+      const float e0 = i == 0 ? v[0].x : i == 1 ? v[0].y : i == 2 ? v[0].z : v[0].w, e1 = i == 0 ? v[1].x : i == 1 ? v[1].y : i == 2 ? v[1].z : v[1].w;
+      const float e2 = i == 0 ? v[2].x : i == 1 ? v[2].y : i == 2 ? v[2].z : v[2].w, e3 = i == 0 ? v[3].x : i == 1 ? v[3].y : i == 2 ? v[3].z : v[3].w;
+      w = make_float4(e0, e1, e2, e3); row = (tid & 31) * 4 + i; k = 4 * (tid >> 5);
+    }
+    uint2 hi, lo;
+    split4(w, hi, lo);
+    *reinterpret_cast<uint2*>(hi_plane + row * kXPitch + k * 2) = hi;
+    *reinterpret_cast<uint2*>(lo_plane + row * kXPitch + k * 2) = lo;
+  }
+}
+
+template <bool kAK, bool kBK_>
+__global__ __launch_bounds__(256) void gemm_f32x3_kernel(GemmF32Args g) {
+  __shared__ __attribute__((aligned(16))) unsigned char planes[4 * kXPlane];
+  unsigned char* const Ah = planes; unsigned char* const Al = planes + kXPlane;
+  unsigned char* const Bh = planes + 2 * kXPlane; unsigned char* const Bl = planes + 3 * kXPlane;
+  const int tid = threadIdx.x, lane = tid & 63, r = lane & 31, h = lane >> 5;
+  const int wave = tid >> 6, wm = wave >> 1, wn = wave & 1;
+  const int m0 = blockIdx.y * kBM, n0 = blockIdx.x * kBN;
+  f32x16 acc[2][2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+  float4 av[4], bv[4];
+  const int nkt_all = (g.K + kXK - 1) / kXK;
+  const int kt0 = g.slabs ? static_cast<int>(blockIdx.z) * g.k_tiles_per_split : 0;
+  const int nkt = g.slabs ? min(nkt_all, kt0 + g.k_tiles_per_split) : nkt_all;
+  xtile_fetch<kAK>(g.A, g.lda, g.M, g.K, m0, kt0 * kXK, tid, av);
+  xtile_fetch<kBK_>(g.B, g.ldb, g.N, g.K, n0, kt0 * kXK, tid, bv);
+  const int fa = (wm * 64 + r) * kXPitch + 16 * h, fb = (wn * 64 + r) * kXPitch + 16 * h;      // + 32 rows * pitch per block, + 32 bytes per k-step
+  for (int kt = kt0; kt < nkt; ++kt) {
+    xtile_store<kAK>(Ah, Al, tid, av);
+    xtile_store<kBK_>(Bh, Bl, tid, bv);
+    __syncthreads();
+    if (kt + 1 < nkt) {
+      xtile_fetch<kAK>(g.A, g.lda, g.M, g.K, m0, (kt + 1) * kXK, tid, av);
+      xtile_fetch<kBK_>(g.B, g.ldb, g.N, g.K, n0, (kt + 1) * kXK, tid, bv);
+    }
+#pragma unroll
+    for (int ks = 0; ks < kXK / 16; ++ks) {
+      bf16x8s ah[2], al[2], bh[2], bl[2];
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {
+        ah[i] = *reinterpret_cast<const bf16x8s*>(Ah + fa + i * 32 * kXPitch + ks * 32);
+        al[i] = *reinterpret_cast<const bf16x8s*>(Al + fa + i * 32 * kXPitch + ks * 32);
+        bh[i] = *reinterpret_cast<const bf16x8s*>(Bh + fb + i * 32 * kXPitch + ks * 32);
+        bl[i] = *reinterpret_cast<const bf16x8s*>(Bl + fb + i * 32 * kXPitch + ks * 32);
+      }
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) acc[i][j] = mfma_x3(ah[i], al[i], bh[j], bl[j], acc[i][j]);
+    }
+    __syncthreads();
+  }
+  gemm_f32_epilogue(g, acc, m0, n0, wm, wn, r, h);
 }
 
 // =============================================================================================== attention
@@ -399,6 +533,315 @@ __global__ __launch_bounds__(kDkvThreads) void attn_bwd_dkv_f32_kernel(AttnF32Ar
   }
 }
 
+// =============================================================================================== attention, split-bf16 products
+// The three kernels above with every product taken as three bf16 MFMAs (see "split-bf16 products" at the GEMM): same grids, same
+// orientation (softmax axis on the lane), same masks / dropout indices / statistics, fp32 everywhere outside the products.  Operand
+// blocks are split into bf16 hi / lo planes while they are staged:
+//   row planes   [32 rows][DH] bf16 (pitch DH * 2 + 16 bytes)  -> A / B fragments "row r, 8 consecutive d" by one ds_read_b128
+//   transposed   [32 ceil(DH / 32) rows = d][32 positions] bf16 (pitch 80 bytes), position 16 ks + 8 h + j <-> block row rowmap(8 ks + j, h)
+//                -> A fragments "d r, the 8 block rows a lane half holds in accumulator registers 8 ks .. 8 ks + 7": the accumulator of
+//                one product (P^T, dS^T, P, dS), split into hi / lo, is the B operand of the next without leaving the registers.
+template <int DH> struct GeoX {
+  static constexpr int kPR = DH * 2 + 16;              // row-plane pitch (bytes): an odd number of 16-byte bank slots
+  static constexpr int kRows = 32 * kPR;               // one row plane
+  static constexpr int kPT = 80;                       // transposed-plane pitch
+  static constexpr int kTrans = Geo<DH>::kCols * kPT;  // one transposed plane (rows past DH stay zero)
+  static constexpr int kNK = DH / 16;                  // k-steps of a DH-deep contraction
+};
+__device__ __forceinline__ int tpos(int j) {           // position of block row j in a transposed plane
+  const int e = (j & 3) + 4 * (j >> 3), hh = (j >> 2) & 1;
+  return 16 * (e >> 3) + 8 * hh + (e & 7);
+}
+union Frag8 { bf16x8s v; unsigned u[4]; };
+__device__ __forceinline__ void split8(const float (&x)[8], bf16x8s& hi, bf16x8s& lo) {
+  Frag8 a, b;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) split2(x[2 * i], x[2 * i + 1], a.u[i], b.u[i]);
+  hi = a.v; lo = b.v;
+}
+// rows [row0, row0 + 32) of a [n_rows][ld] fp32 matrix (columns [0, DH)) into row planes and / or transposed planes (hi at the pointer,
+// lo one plane behind it); rows past n_rows are zeros
+template <int DH, int kThreads, bool kRowP, bool kTransP>
+__device__ __forceinline__ void block_to_planes(const float* __restrict__ base, long ld, int row0, int n_rows, unsigned char* rp, unsigned char* tp, int tid) {
+  constexpr int kQ = DH / 4;
+  for (int idx = tid; idx < kBlk * kQ; idx += kThreads) {
+    const int j = idx / kQ, c4 = idx % kQ;
+    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (row0 + j < n_rows) v = *reinterpret_cast<const float4*>(base + static_cast<long>(row0 + j) * ld + 4 * c4);
+    uint2 hi, lo;
+    split4(v, hi, lo);
+    if (kRowP) {
+      *reinterpret_cast<uint2*>(rp + j * GeoX<DH>::kPR + 8 * c4) = hi;
+      *reinterpret_cast<uint2*>(rp + GeoX<DH>::kRows + j * GeoX<DH>::kPR + 8 * c4) = lo;
+    }
+    if (kTransP) {
+      unsigned short* th = reinterpret_cast<unsigned short*>(tp + (4 * c4) * GeoX<DH>::kPT + 2 * tpos(j));
+      unsigned short* tl = reinterpret_cast<unsigned short*>(tp + GeoX<DH>::kTrans + (4 * c4) * GeoX<DH>::kPT + 2 * tpos(j));
+      constexpr int kStep = GeoX<DH>::kPT / 2;
+      th[0] = static_cast<unsigned short>(hi.x); th[kStep] = static_cast<unsigned short>(hi.x >> 16);
+      th[2 * kStep] = static_cast<unsigned short>(hi.y); th[3 * kStep] = static_cast<unsigned short>(hi.y >> 16);
+      tl[0] = static_cast<unsigned short>(lo.x); tl[kStep] = static_cast<unsigned short>(lo.x >> 16);
+      tl[2 * kStep] = static_cast<unsigned short>(lo.y); tl[3 * kStep] = static_cast<unsigned short>(lo.y >> 16);
+    }
+  }
+}
+template <int DH, int kThreads>
+__device__ __forceinline__ void zero_trans_tail(unsigned char* tp, int tid) {      // d rows [DH, 32 ceil(DH / 32)) of both transposed planes
+  if constexpr (Geo<DH>::kCols > DH) {
+    constexpr int kWords = (Geo<DH>::kCols - DH) * GeoX<DH>::kPT / 4;
+    for (int i = tid; i < kWords; i += kThreads) {
+      reinterpret_cast<unsigned*>(tp + DH * GeoX<DH>::kPT)[i] = 0u;
+      reinterpret_cast<unsigned*>(tp + GeoX<DH>::kTrans + DH * GeoX<DH>::kPT)[i] = 0u;
+    }
+  }
+}
+// the lane's own row as B fragments: x[ks] = row[16 ks + 8 h .. + 7], hi and lo (zeros when the row does not exist)
+template <int DH>
+__device__ __forceinline__ void row_frags(const float* __restrict__ row, bool live, int h, bf16x8s (&hi)[DH / 16], bf16x8s (&lo)[DH / 16]) {
+#pragma unroll
+  for (int ks = 0; ks < DH / 16; ++ks) {
+    float x[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    if (live) {
+      const float4 v0 = *reinterpret_cast<const float4*>(row + 16 * ks + 8 * h), v1 = *reinterpret_cast<const float4*>(row + 16 * ks + 8 * h + 4);
+      x[0] = v0.x; x[1] = v0.y; x[2] = v0.z; x[3] = v0.w; x[4] = v1.x; x[5] = v1.y; x[6] = v1.z; x[7] = v1.w;
+    }
+    split8(x, hi[ks], lo[ks]);
+  }
+}
+__device__ __forceinline__ bf16x8s lds_frag(const unsigned char* p) { return *reinterpret_cast<const bf16x8s*>(p); }
+// accumulator registers 8 ks .. 8 ks + 7 as a B fragment pair
+__device__ __forceinline__ void acc_frags(const f32x16& t, int ks, bf16x8s& hi, bf16x8s& lo) {
+  const float x[8] = {t[8 * ks], t[8 * ks + 1], t[8 * ks + 2], t[8 * ks + 3], t[8 * ks + 4], t[8 * ks + 5], t[8 * ks + 6], t[8 * ks + 7]};
+  split8(x, hi, lo);
+}
+
+template <int DH>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) void attn_fwd_x3_kernel(AttnF32Args a) {
+  using G = Geo<DH>; using X = GeoX<DH>;
+  __shared__ __attribute__((aligned(16))) unsigned char Kp[2 * X::kRows];
+  __shared__ __attribute__((aligned(16))) unsigned char Vt[2 * X::kTrans];
+  const int tid = threadIdx.x, lane = tid & 63, r = lane & 31, h = lane >> 5, wave = tid >> 6;
+  const int b = blockIdx.y / a.H, head = blockIdx.y % a.H;
+  const int qi = blockIdx.x * 128 + wave * 32 + r;
+  const bool live = qi < a.Sq;
+  const float* kb = a.k + static_cast<long>(b) * a.Sk * a.ldk + head * DH;
+  const float* vb = a.v + static_cast<long>(b) * a.Sk * a.ldv + head * DH;
+  const int klen = a.key_len ? a.key_len[b] : a.Sk;
+  bf16x8s qh[X::kNK], ql[X::kNK];
+  row_frags<DH>(a.q + (static_cast<long>(b) * a.Sq + qi) * a.ldq + head * DH, live, h, qh, ql);
+  zero_trans_tail<DH, 256>(Vt, tid);
+  f32x16 o[G::kNdt];
+#pragma unroll
+  for (int dt = 0; dt < G::kNdt; ++dt)
+#pragma unroll
+    for (int e = 0; e < 16; ++e) o[dt][e] = 0.f;
+  float m = -INFINITY, l = 0.f;
+  const uint64_t drow = ((static_cast<uint64_t>(b) * a.H + head) * a.Sq + qi) * drop_ld(static_cast<uint64_t>(a.Sk));
+  for (int j0 = 0; j0 < a.Sk; j0 += kBlk) {
+    __syncthreads();
+    block_to_planes<DH, 256, true, false>(kb, a.ldk, j0, a.Sk, Kp, nullptr, tid);
+    block_to_planes<DH, 256, false, true>(vb, a.ldv, j0, a.Sk, nullptr, Vt, tid);
+    __syncthreads();
+    f32x16 st;
+#pragma unroll
+    for (int e = 0; e < 16; ++e) st[e] = 0.f;
+#pragma unroll
+    for (int ks = 0; ks < X::kNK; ++ks) {
+      const unsigned char* p = Kp + r * X::kPR + (16 * ks + 8 * h) * 2;
+      st = mfma_x3(lds_frag(p), lds_frag(p + X::kRows), qh[ks], ql[ks], st);
+    }
+    float mx = m;
+#pragma unroll
+    for (int e = 0; e < 16; ++e) {
+      const int ki = j0 + rowmap(e, h);
+      float x = st[e] * a.scale + score_mask(a, qi, ki, klen);
+      if (ki >= a.Sk) x = -INFINITY;
+      st[e] = x;
+      mx = fmaxf(mx, x);
+    }
+    mx = fmaxf(mx, __shfl_xor(mx, 32));
+    const float alpha = expf(m - mx);
+    m = mx;
+    float psum = 0.f;
+#pragma unroll
+    for (int e = 0; e < 16; ++e) {
+      const float p = expf(st[e] - mx);
+      psum += p;
+      st[e] = a.drop.on() ? p * a.drop.scale(drow + static_cast<uint64_t>(j0 + rowmap(e, h))) : p;
+    }
+    l = l * alpha + psum;
+    bf16x8s ph[2], pl[2];
+    acc_frags(st, 0, ph[0], pl[0]);
+    acc_frags(st, 1, ph[1], pl[1]);
+#pragma unroll
+    for (int dt = 0; dt < G::kNdt; ++dt) {
+#pragma unroll
+      for (int e = 0; e < 16; ++e) o[dt][e] *= alpha;
+#pragma unroll
+      for (int ks = 0; ks < 2; ++ks) {
+        const unsigned char* p = Vt + (32 * dt + r) * X::kPT + (16 * ks + 8 * h) * 2;
+        o[dt] = mfma_x3(lds_frag(p), lds_frag(p + X::kTrans), ph[ks], pl[ks], o[dt]);
+      }
+    }
+  }
+  l += __shfl_xor(l, 32);
+  if (!live) return;
+  store_rows<DH>(o, 1.0f / l, a.out + (static_cast<long>(b) * a.Sq + qi) * a.ldo + head * DH, h);
+  if (h == 0) a.lse[(static_cast<long>(b) * a.H + head) * a.Sq + qi] = m + logf(l);
+}
+
+template <int DH> constexpr int dq_x3_lds_bytes() { return 4 * GeoX<DH>::kRows + 2 * GeoX<DH>::kTrans; }
+template <int DH>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) void attn_bwd_dq_x3_kernel(AttnF32Args a) {
+  using G = Geo<DH>; using X = GeoX<DH>;
+  extern __shared__ __attribute__((aligned(16))) unsigned char dq_smem[];
+  unsigned char* const Kp = dq_smem; unsigned char* const Vp = Kp + 2 * X::kRows; unsigned char* const Kt = Vp + 2 * X::kRows;
+  const int tid = threadIdx.x, lane = tid & 63, r = lane & 31, h = lane >> 5, wave = tid >> 6;
+  const int b = blockIdx.y / a.H, head = blockIdx.y % a.H;
+  const int qi = blockIdx.x * 128 + wave * 32 + r;
+  const bool live = qi < a.Sq;
+  const float* kb = a.k + static_cast<long>(b) * a.Sk * a.ldk + head * DH;
+  const float* vb = a.v + static_cast<long>(b) * a.Sk * a.ldv + head * DH;
+  const int klen = a.key_len ? a.key_len[b] : a.Sk;
+  const long stat = (static_cast<long>(b) * a.H + head) * a.Sq + qi;
+  bf16x8s qh[X::kNK], ql[X::kNK], dh_[X::kNK], dl_[X::kNK];
+  const float* qrow = a.q + (static_cast<long>(b) * a.Sq + qi) * a.ldq + head * DH;
+  const float* dorow = a.dout + (static_cast<long>(b) * a.Sq + qi) * a.ldo + head * DH;
+  row_frags<DH>(qrow, live, h, qh, ql);
+  row_frags<DH>(dorow, live, h, dh_, dl_);
+  float delta = 0.f;                                     // rowsum(O o dO) in fp32 (not a matrix product): this lane half's d = 16 u + 8 h .. + 7
+  if (live) {
+    const float* orow = a.o + (static_cast<long>(b) * a.Sq + qi) * a.ldo + head * DH;
+#pragma unroll
+    for (int u = 0; u < DH / 16; ++u) {
+      const int d0 = 16 * u + 8 * h;
+      const float4 v0 = *reinterpret_cast<const float4*>(orow + d0), v1 = *reinterpret_cast<const float4*>(orow + d0 + 4);
+      const float4 w0 = *reinterpret_cast<const float4*>(dorow + d0), w1 = *reinterpret_cast<const float4*>(dorow + d0 + 4);
+      delta += v0.x * w0.x + v0.y * w0.y + v0.z * w0.z + v0.w * w0.w + v1.x * w1.x + v1.y * w1.y + v1.z * w1.z + v1.w * w1.w;
+    }
+  }
+  delta += __shfl_xor(delta, 32);
+  const float lse = live ? a.lse[stat] : INFINITY;
+  if (live && h == 0) a.delta[stat] = delta;
+  zero_trans_tail<DH, 256>(Kt, tid);
+  f32x16 dq[G::kNdt];
+#pragma unroll
+  for (int dt = 0; dt < G::kNdt; ++dt)
+#pragma unroll
+    for (int e = 0; e < 16; ++e) dq[dt][e] = 0.f;
+  const uint64_t drow = static_cast<uint64_t>(stat) * drop_ld(static_cast<uint64_t>(a.Sk));
+  for (int j0 = 0; j0 < a.Sk; j0 += kBlk) {
+    __syncthreads();
+    block_to_planes<DH, 256, true, true>(kb, a.ldk, j0, a.Sk, Kp, Kt, tid);
+    block_to_planes<DH, 256, true, false>(vb, a.ldv, j0, a.Sk, Vp, nullptr, tid);
+    __syncthreads();
+    f32x16 st, dp;
+#pragma unroll
+    for (int e = 0; e < 16; ++e) st[e] = dp[e] = 0.f;
+#pragma unroll
+    for (int ks = 0; ks < X::kNK; ++ks) {
+      const int off = r * X::kPR + (16 * ks + 8 * h) * 2;
+      st = mfma_x3(lds_frag(Kp + off), lds_frag(Kp + X::kRows + off), qh[ks], ql[ks], st);
+      dp = mfma_x3(lds_frag(Vp + off), lds_frag(Vp + X::kRows + off), dh_[ks], dl_[ks], dp);
+    }
+#pragma unroll
+    for (int e = 0; e < 16; ++e) {
+      const int ki = j0 + rowmap(e, h);
+      const float x = st[e] * a.scale + score_mask(a, qi, ki, klen);
+      const float p = ki < a.Sk ? expf(x - lse) : 0.f;
+      const float keep = a.drop.on() ? a.drop.scale(drow + static_cast<uint64_t>(ki)) : 1.0f;
+      st[e] = p * (dp[e] * keep - delta) * a.scale;
+    }
+    bf16x8s sh[2], sl[2];
+    acc_frags(st, 0, sh[0], sl[0]);
+    acc_frags(st, 1, sh[1], sl[1]);
+#pragma unroll
+    for (int dt = 0; dt < G::kNdt; ++dt)
+#pragma unroll
+      for (int ks = 0; ks < 2; ++ks) {
+        const unsigned char* p = Kt + (32 * dt + r) * X::kPT + (16 * ks + 8 * h) * 2;
+        dq[dt] = mfma_x3(lds_frag(p), lds_frag(p + X::kTrans), sh[ks], sl[ks], dq[dt]);
+      }
+  }
+  if (live) store_rows<DH>(dq, 1.0f, a.dq + (static_cast<long>(b) * a.Sq + qi) * a.ldq + head * DH, h);
+}
+
+// dK / dV: 4 waves per workgroup, each owning 32 keys whose K and V rows are its B fragments and stay in registers (the lane's own
+// key row, split once), sweeping the query blocks together (Q, dO row planes and transposed planes shared through LDS: 76 KiB).  The
+// f32 kernel's shape -- two waves, K / V images in LDS, one workgroup per CU by LDS size -- left the CU with two waves.
+constexpr int kDkvX3Threads = 256;
+template <int DH> constexpr int dkv_x3_lds_bytes() { return 4 * GeoX<DH>::kRows + 4 * GeoX<DH>::kTrans + 256; }   // Q, dO row planes; Q, dO transposed planes; lse, delta
+template <int DH>
+__global__ __launch_bounds__(kDkvX3Threads) void attn_bwd_dkv_x3_kernel(AttnF32Args a) {
+  using G = Geo<DH>; using X = GeoX<DH>;
+  extern __shared__ __attribute__((aligned(16))) unsigned char kv_smem[];
+  unsigned char* const Qp = kv_smem; unsigned char* const Dp = Qp + 2 * X::kRows;
+  unsigned char* const Qt = Dp + 2 * X::kRows; unsigned char* const Dt = Qt + 2 * X::kTrans;
+  float* const lse_s = reinterpret_cast<float*>(Dt + 2 * X::kTrans); float* const del_s = lse_s + 32;
+  const int tid = threadIdx.x, lane = tid & 63, r = lane & 31, h = lane >> 5, wave = tid >> 6;
+  const int b = blockIdx.y / a.H, head = blockIdx.y % a.H;
+  const int j0 = (blockIdx.x * 4 + wave) * kBlk, ki = j0 + r;
+  const float* qb = a.q + static_cast<long>(b) * a.Sq * a.ldq + head * DH;
+  const float* dob = a.dout + static_cast<long>(b) * a.Sq * a.ldo + head * DH;
+  const int klen = a.key_len ? a.key_len[b] : a.Sk;
+  const long stat0 = (static_cast<long>(b) * a.H + head) * a.Sq;
+  bf16x8s kh[X::kNK], kl[X::kNK], vh[X::kNK], vl[X::kNK];
+  row_frags<DH>(a.k + (static_cast<long>(b) * a.Sk + ki) * a.ldk + head * DH, ki < a.Sk, h, kh, kl);
+  row_frags<DH>(a.v + (static_cast<long>(b) * a.Sk + ki) * a.ldv + head * DH, ki < a.Sk, h, vh, vl);
+  zero_trans_tail<DH, kDkvX3Threads>(Qt, tid);
+  zero_trans_tail<DH, kDkvX3Threads>(Dt, tid);
+  f32x16 dk[G::kNdt], dv[G::kNdt];
+#pragma unroll
+  for (int dt = 0; dt < G::kNdt; ++dt)
+#pragma unroll
+    for (int e = 0; e < 16; ++e) dk[dt][e] = dv[dt][e] = 0.f;
+  const uint64_t dld = drop_ld(static_cast<uint64_t>(a.Sk));
+  for (int i0 = 0; i0 < a.Sq; i0 += kBlk) {
+    __syncthreads();
+    block_to_planes<DH, kDkvX3Threads, true, true>(qb, a.ldq, i0, a.Sq, Qp, Qt, tid);
+    block_to_planes<DH, kDkvX3Threads, true, true>(dob, a.ldo, i0, a.Sq, Dp, Dt, tid);
+    if (tid < 32) {
+      const bool ok = i0 + tid < a.Sq;
+      lse_s[tid] = ok ? a.lse[stat0 + i0 + tid] : INFINITY;
+      del_s[tid] = ok ? a.delta[stat0 + i0 + tid] : 0.f;
+    }
+    __syncthreads();
+    f32x16 st, dp;
+#pragma unroll
+    for (int e = 0; e < 16; ++e) st[e] = dp[e] = 0.f;
+#pragma unroll
+    for (int ks = 0; ks < X::kNK; ++ks) {
+      const int off = r * X::kPR + (16 * ks + 8 * h) * 2;
+      st = mfma_x3(lds_frag(Qp + off), lds_frag(Qp + X::kRows + off), kh[ks], kl[ks], st);
+      dp = mfma_x3(lds_frag(Dp + off), lds_frag(Dp + X::kRows + off), vh[ks], vl[ks], dp);
+    }
+#pragma unroll
+    for (int e = 0; e < 16; ++e) {
+      const int ir = rowmap(e, h), qi = i0 + ir;
+      const float x = st[e] * a.scale + score_mask(a, qi, ki, klen);
+      const float p = ki < a.Sk ? expf(x - lse_s[ir]) : 0.f;
+      const float keep = a.drop.on() ? a.drop.scale((static_cast<uint64_t>(stat0) + qi) * dld + static_cast<uint64_t>(ki)) : 1.0f;
+      st[e] = p * keep;                                   // dropped P (what multiplied V in the forward)
+      dp[e] = p * (dp[e] * keep - del_s[ir]) * a.scale;   // dS
+    }
+    bf16x8s ph[2], pl[2], sh[2], sl[2];
+    acc_frags(st, 0, ph[0], pl[0]); acc_frags(st, 1, ph[1], pl[1]);
+    acc_frags(dp, 0, sh[0], sl[0]); acc_frags(dp, 1, sh[1], sl[1]);
+#pragma unroll
+    for (int dt = 0; dt < G::kNdt; ++dt)
+#pragma unroll
+      for (int ks = 0; ks < 2; ++ks) {
+        const int off = (32 * dt + r) * X::kPT + (16 * ks + 8 * h) * 2;
+        dv[dt] = mfma_x3(lds_frag(Dt + off), lds_frag(Dt + X::kTrans + off), ph[ks], pl[ks], dv[dt]);
+        dk[dt] = mfma_x3(lds_frag(Qt + off), lds_frag(Qt + X::kTrans + off), sh[ks], sl[ks], dk[dt]);
+      }
+  }
+  if (ki < a.Sk) {
+    store_rows<DH>(dk, 1.0f, a.dk + (static_cast<long>(b) * a.Sk + ki) * a.ldk + head * DH, h);
+    store_rows<DH>(dv, 1.0f, a.dv + (static_cast<long>(b) * a.Sk + ki) * a.ldv + head * DH, h);
+  }
+}
+
 // =============================================================================================== column sums of an fp32 matrix
 constexpr int kCsRows = 256;
 __global__ __launch_bounds__(256) void colsum_f32_partial_kernel(const float* __restrict__ x, long ld, int M, int N, float* __restrict__ partial) {
@@ -423,6 +866,7 @@ static int check_attn_f32(const adt_attn_desc* d) {
   if (d->ldq < need || d->ldk < need || d->ldv < need || d->ldo < need || (d->ldq & 3) || (d->ldk & 3) || (d->ldv & 3) || (d->ldo & 3))
     return set_error(ADT_ESHAPE, "attention (f32): row strides must cover heads*128 columns and be multiples of 4");
   if (static_cast<int64_t>(d->batch) * d->heads > 65535) return set_error(ADT_ESHAPE, "attention (f32): batch*heads must be <= 65535");
+  if (d->f32_products != 0 && d->f32_products != 1) return set_error(ADT_EINVAL, "attention (f32): f32_products must be 0 (exact f32 products) or 1 (split-bf16)");
   return ADT_OK;
 }
 static AttnF32Args make_f32_args(const adt_attn_desc* d) {
@@ -433,18 +877,69 @@ static AttnF32Args make_f32_args(const adt_attn_desc* d) {
   a.drop = make_drop(d->drop.p, d->drop.key);
   return a;
 }
+template <int DH>
+static int launch_attn_fwd_x3(const adt_attn_desc* d, const AttnF32Args& a, hipStream_t st) {
+  hipLaunchKernelGGL(attn_fwd_x3_kernel<DH>, dim3((d->q_len + 127) / 128, d->batch * d->heads), dim3(256), 0, st, a);
+  ADT_HIP_TRY(hipGetLastError());
+  return ADT_OK;
+}
+template <int DH>
+static int launch_attn_bwd_x3(const adt_attn_desc* d, const AttnF32Args& a, hipStream_t st) {
+  static thread_local int lds_set_for = -1;
+  int dev = 0;
+  ADT_HIP_TRY(hipGetDevice(&dev));
+  if (lds_set_for != dev) {
+    ADT_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(attn_bwd_dq_x3_kernel<DH>), hipFuncAttributeMaxDynamicSharedMemorySize, dq_x3_lds_bytes<DH>()));
+    ADT_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(attn_bwd_dkv_x3_kernel<DH>), hipFuncAttributeMaxDynamicSharedMemorySize, dkv_x3_lds_bytes<DH>()));
+    lds_set_for = dev;
+  }
+  hipLaunchKernelGGL(attn_bwd_dq_x3_kernel<DH>, dim3((d->q_len + 127) / 128, d->batch * d->heads), dim3(256), dq_x3_lds_bytes<DH>(), st, a);
+  hipLaunchKernelGGL(attn_bwd_dkv_x3_kernel<DH>, dim3((d->k_len + 127) / 128, d->batch * d->heads), dim3(kDkvX3Threads), dkv_x3_lds_bytes<DH>(), st, a);
+  ADT_HIP_TRY(hipGetLastError());
+  return ADT_OK;
+}
 
 }  // namespace adt
 
 using namespace adt;
 #define ST(s) static_cast<hipStream_t>(s)
 
+// K splits of a product whose output has too few 128 x 128 tiles to fill the chip (the weight gradients: K = batch x frames rows against a
+// 768 x 3072 output = 144 tiles on 256 CUs): the plain form only (no epilogue arithmetic beyond alpha), N a multiple of 4, partial tiles
+// through fp32 slabs summed in slab order (bitwise reproducible).  Returns the number of splits (1: none) and the 32-deep steps per split.
+static int plan_f32_splits(int64_t M, int64_t N, int64_t K, const adt_gemm_epilogue* ep, int* per_split) {
+  *per_split = 0;
+  if (ep && (ep->bias || ep->gelu_grad_of || ep->pre_act_out || ep->residual || ep->act || ep->drop.p > 0.f)) return 1;
+  if ((N & 3) || K < 16 * kXKf) return 1;
+  int n_cu = 256;
+  (void)device_cu_count(&n_cu);
+  const int64_t tiles = ((M + kBM - 1) / kBM) * ((N + kBN - 1) / kBN);
+  if (tiles >= 2 * n_cu) return 1;
+  const int steps = static_cast<int>((K + kXKf - 1) / kXKf);
+  int s = static_cast<int>((3 * n_cu + tiles - 1) / tiles);            // ~3 workgroups per CU
+  const int max_s = steps / 8 > 1 ? steps / 8 : 1;                      // at least 8 steps (K = 256) per split
+  s = s > max_s ? max_s : s;
+  s = s > 64 ? 64 : s;
+  if (s <= 1) return 1;
+  const int per = (steps + s - 1) / s;
+  *per_split = per;
+  return (steps + per - 1) / per;                                       // no empty trailing split
+}
+
+extern "C" size_t adt_gemm_f32_workspace_bytes(int32_t layout, int64_t M, int64_t N, int64_t K) {
+  (void)layout;
+  if (M <= 0 || N <= 0 || K <= 0) return 0;
+  int per = 0;
+  const int s = plan_f32_splits(M, N, K, nullptr, &per);
+  return s > 1 ? static_cast<size_t>(s) * M * N * 4 : 0;
+}
+
 extern "C" int adt_gemm_f32(int32_t layout, int64_t M, int64_t N, int64_t K, const float* A, int64_t lda, const float* B, int64_t ldb,
-                            float* C, int64_t ldc, const adt_gemm_epilogue* ep, void* stream) {
+                            float* C, int64_t ldc, const adt_gemm_epilogue* ep, void* ws, size_t ws_bytes, void* stream) {
   if (!A || !B || !C) return set_error(ADT_EINVAL, "adt_gemm_f32: null pointer");
-  if (M < 0 || N < 0 || K < 0 || layout < 0 || layout > 3) return set_error(ADT_EINVAL, "adt_gemm_f32: bad size or layout");
+  if (M < 0 || N < 0 || K < 0 || layout < 0 || layout > 7) return set_error(ADT_EINVAL, "adt_gemm_f32: bad size or layout");
   if (M == 0 || N == 0) return ADT_OK;
-  const bool ak = layout & 1, bk = layout & 2;
+  const bool ak = layout & 1, bk = layout & 2, x3 = layout & 4;
   // float4 operand loads: the contiguous extent of each operand and its leading dimension are multiples of 4 floats
   if ((lda & 3) || (ldb & 3) || !aligned16(A) || !aligned16(B) || ((ak ? M : K) & 3) || ((bk ? N : K) & 3))
     return set_error(ADT_ESHAPE, "adt_gemm_f32: contiguous extents and leading dimensions must be multiples of 4 floats, operands 16-byte aligned");
@@ -461,11 +956,24 @@ extern "C" int adt_gemm_f32(int32_t layout, int64_t M, int64_t N, int64_t K, con
     g.act = ep->act; g.alpha = ep->alpha; g.drop = make_drop(ep->drop.p, ep->drop.key); g.drop_after_residual = ep->drop_after_residual;
     g.act_grad_mode = ep->act_grad_mode;
   }
-  const dim3 grid(static_cast<unsigned>((N + kBN - 1) / kBN), static_cast<unsigned>((M + kBM - 1) / kBM));
-  if (!ak && !bk) hipLaunchKernelGGL((gemm_f32_kernel<false, false>), grid, dim3(256), 0, ST(stream), g);
-  else if (ak && bk) hipLaunchKernelGGL((gemm_f32_kernel<true, true>), grid, dim3(256), 0, ST(stream), g);
-  else if (!ak && bk) hipLaunchKernelGGL((gemm_f32_kernel<false, true>), grid, dim3(256), 0, ST(stream), g);
-  else hipLaunchKernelGGL((gemm_f32_kernel<true, false>), grid, dim3(256), 0, ST(stream), g);
+  int per = 0;
+  int splits = plan_f32_splits(M, N, K, ep, &per);
+  if (splits > 1 && (!ws || !aligned16(ws) || ws_bytes < static_cast<size_t>(splits) * M * N * 4 || (ldc & 3) || !aligned16(C))) splits = 1;   // no workspace: one pass
+  g.k_tiles_per_split = splits > 1 ? per : 0;
+  g.slabs = splits > 1 ? static_cast<float*>(ws) : nullptr;
+  const dim3 grid(static_cast<unsigned>((N + kBN - 1) / kBN), static_cast<unsigned>((M + kBM - 1) / kBM), static_cast<unsigned>(splits));
+  if (x3) {
+    if (!ak && !bk) hipLaunchKernelGGL((gemm_f32x3_kernel<false, false>), grid, dim3(256), 0, ST(stream), g);
+    else if (ak && bk) hipLaunchKernelGGL((gemm_f32x3_kernel<true, true>), grid, dim3(256), 0, ST(stream), g);
+    else if (!ak && bk) hipLaunchKernelGGL((gemm_f32x3_kernel<false, true>), grid, dim3(256), 0, ST(stream), g);
+    else hipLaunchKernelGGL((gemm_f32x3_kernel<true, false>), grid, dim3(256), 0, ST(stream), g);
+  } else {
+    if (!ak && !bk) hipLaunchKernelGGL((gemm_f32_kernel<false, false>), grid, dim3(256), 0, ST(stream), g);
+    else if (ak && bk) hipLaunchKernelGGL((gemm_f32_kernel<true, true>), grid, dim3(256), 0, ST(stream), g);
+    else if (!ak && bk) hipLaunchKernelGGL((gemm_f32_kernel<false, true>), grid, dim3(256), 0, ST(stream), g);
+    else hipLaunchKernelGGL((gemm_f32_kernel<true, false>), grid, dim3(256), 0, ST(stream), g);
+  }
+  if (splits > 1) launch_reduce_slabs(g.slabs, splits, static_cast<long>(M) * N, g.N, g.alpha, C, ldc, ST(stream));
   ADT_HIP_TRY(hipGetLastError());
   return ADT_OK;
 }
@@ -478,6 +986,14 @@ extern "C" int adt_attn_fwd_f32(const adt_attn_desc* d, const float* q, const fl
   if (d->k_len == 0) return set_error(ADT_ESHAPE, "adt_attn_fwd_f32: k_len must be > 0");
   AttnF32Args a = make_f32_args(d);
   a.q = q; a.k = k; a.v = v; a.out = o; a.lse = lse;
+  if (d->f32_products == 1) {                      // split-bf16 products
+    switch (d->head_dim) {
+      case 16: return launch_attn_fwd_x3<16>(d, a, ST(stream));
+      case 32: return launch_attn_fwd_x3<32>(d, a, ST(stream));
+      case 64: return launch_attn_fwd_x3<64>(d, a, ST(stream));
+      default: return launch_attn_fwd_x3<128>(d, a, ST(stream));
+    }
+  }
   const dim3 grid((d->q_len + 127) / 128, d->batch * d->heads);
   switch (d->head_dim) {
     case 16: hipLaunchKernelGGL(attn_fwd_f32_kernel<16>, grid, dim3(256), 0, ST(stream), a); break;
@@ -524,6 +1040,14 @@ extern "C" int adt_attn_bwd_f32(const adt_attn_desc* d, const float* q, const fl
   AttnF32Args a = make_f32_args(d);
   a.q = q; a.k = k; a.v = v; a.o = o; a.dout = dout; a.lse = const_cast<float*>(lse); a.delta = static_cast<float*>(ws);
   a.dq = dq; a.dk = dk; a.dv = dv;
+  if (d->f32_products == 1) {
+    switch (d->head_dim) {
+      case 16: return launch_attn_bwd_x3<16>(d, a, ST(stream));
+      case 32: return launch_attn_bwd_x3<32>(d, a, ST(stream));
+      case 64: return launch_attn_bwd_x3<64>(d, a, ST(stream));
+      default: return launch_attn_bwd_x3<128>(d, a, ST(stream));
+    }
+  }
   switch (d->head_dim) {
     case 16: return launch_attn_bwd_f32<16>(d, a, ST(stream));
     case 32: return launch_attn_bwd_f32<32>(d, a, ST(stream));

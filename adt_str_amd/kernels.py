@@ -155,9 +155,23 @@ def gemm_tn_grouped(items) -> None:
         _ffi.call("adt_gemm_bf16_tn_grouped", C.byref(arr), len(chunk), _ffi.current_stream())
 
 
+# How the fp32-operand entry points (adt_gemm_f32, adt_attn_fwd_f32, adt_attn_bwd_f32) form their products: "f32" = exact f32-input
+# MFMA (the parity arm of rounds 4-5), "bf16x3" = split-bf16: every fp32 operand as hi + lo bf16 planes, three bf16 MFMAs per product
+# into one fp32 accumulator (~1e-5 relative per product, several times faster).  The engine sets it on entry to each of its passes
+# (network._Engine: precision "fp32" / "bf16x3"); module-level because the calls below are synchronous host code.
+f32_products = "f32"
+
+
+def set_f32_products(mode: str) -> None:
+    global f32_products
+    if mode not in ("f32", "bf16x3"):
+        raise ValueError(f"f32_products must be 'f32' or 'bf16x3', not {mode!r}")
+    f32_products = mode
+
+
 def _gemm_f32(a, b, *, trans, b_kn, out, bias, residual, res_row_mod, act, pre_act_out, gelu_grad_of, alpha, drop,
               drop_after_residual, colsum_out, aux_out, mode=0):
-    """fp32-operand GEMM (parity path).  Layout bits: 1 = a is [K, M], 2 = b is [K, N]."""
+    """fp32-operand GEMM (parity path).  Layout bits: 1 = a is [K, M], 2 = b is [K, N], 4 = split-bf16 products (``f32_products``)."""
     assert b.dtype == torch.float32 and a.dim() == 2 and b.dim() == 2 and a.stride(1) == 1 and b.stride(1) == 1
     assert aux_out is None, "the fp32 path has a single (fp32) output"
     if trans:
@@ -187,8 +201,12 @@ def _gemm_f32(a, b, *, trans, b_kn, out, bias, residual, res_row_mod, act, pre_a
     if gelu_grad_of is not None:
         assert gelu_grad_of.dtype == torch.float32 and gelu_grad_of.shape == (M, N)
         ep.gelu_grad_of, ep.ld_gelu_grad = _ffi.dptr(gelu_grad_of), gelu_grad_of.stride(0)
+    if f32_products == "bf16x3":
+        layout |= 4
+    ws_bytes = _ffi.load().adt_gemm_f32_workspace_bytes(layout, M, N, K) if trans else 0      # (K splits pay for the weight gradients only)
+    ws = _workspace(ws_bytes, a.device) if ws_bytes else None
     _ffi.call("adt_gemm_f32", layout, M, N, K, _ffi.dptr(a), a.stride(0), _ffi.dptr(b), b.stride(0), _ffi.dptr(out), out.stride(0),
-              C.byref(ep), _ffi.current_stream())
+              C.byref(ep), _ffi.dptr(ws) if ws is not None else None, ws_bytes, _ffi.current_stream())
     if colsum_out is not None:
         colsum(out, out=colsum_out)
     return out
@@ -447,6 +465,7 @@ def _attn_desc(B, H, Sq, Sk, q, k, v, o, scale, causal, key_len, mask_value, dro
     if key_len is not None:
         assert key_len.dtype == torch.int32 and key_len.numel() == B
         d.key_len = _ffi.dptr(key_len)
+    d.f32_products = 1 if (q.dtype == torch.float32 and f32_products == "bf16x3") else 0
     return d
 
 

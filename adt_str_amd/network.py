@@ -32,6 +32,7 @@ from . import kernels as K
 from .frontend import ComputeMelSpectrogram
 
 F32, BF16 = torch.float32, torch.bfloat16
+PRECISIONS = ("bf16", "fp32", "bf16x3")
 
 
 class ADTModelConfig(PretrainedConfig):
@@ -123,18 +124,21 @@ class _Lin:
 
 
 class _Engine:
-    """``precision``: ``"bf16"`` (default; bf16 GEMM / attention operands, fp32 accumulate = the reference's bf16 autocast) or
-    ``"fp32"`` (the parity arm: fp32 activations end to end on the f32-input MFMA kernels of ``csrc/precise.hip``, what
-    BASELINE's "logits within 1e-3 rel-tol of the CPU reference" is checked with).  Default from ``ADT_PRECISION``."""
+    """``precision``: ``"bf16"`` (default; bf16 GEMM / attention operands, fp32 accumulate = the reference's bf16 autocast),
+    ``"fp32"`` (the exact parity arm: fp32 activations end to end on the f32-input MFMA kernels of ``csrc/precise.hip``) or
+    ``"bf16x3"`` (the fast parity arm: the same fp32 activations and the same kernels, every product taken as three bf16 MFMAs on
+    hi / lo splits of the fp32 operands -- ~1e-5 relative per product instead of 6e-8, on the 16 x faster matrix pipe).  Both parity
+    arms meet BASELINE's "logits within 1e-3 rel-tol of the CPU reference".  Default from ``ADT_PRECISION``."""
 
     def __init__(self, model: "ADTModel", precision: Optional[str] = None):
         self.m = model
         cfg = model.config
         precision = (precision or os.environ.get("ADT_PRECISION", "bf16")).lower()
-        if precision not in ("bf16", "fp32"):
-            raise ValueError(f"precision must be 'bf16' or 'fp32', not {precision!r}")
+        if precision not in PRECISIONS:
+            raise ValueError(f"precision must be one of {PRECISIONS}, not {precision!r}")
         self.precision = precision
-        self.fp32 = precision == "fp32"
+        self.fp32 = precision != "bf16"                   # fp32 activations / operands (both parity arms)
+        self.products = "bf16x3" if precision == "bf16x3" else "f32"     # how the fp32-operand kernels multiply (kernels.f32_products)
         self.adt = F32 if self.fp32 else BF16            # dtype of GEMM / attention operands and stored activations
         self.H, self.d, self.dh = cfg.nhead, cfg.nhead * cfg.d_query, cfg.d_query
         if cfg.d_query != 128 and not (self.fp32 and cfg.d_query in (16, 32, 64)):
@@ -202,6 +206,7 @@ class _Engine:
 
     def refresh_weights(self, force=False):
         """Re-derive the bf16 operands when any parameter was modified in place (optimizer step, load_state_dict)."""
+        K.set_f32_products(self.products)                 # (every pass of the engine starts here or in _backward)
         if self.fp32:                                     # the fp32 masters are the operands: nothing to derive
             for l in self.lins.values():
                 if not l.weight.data.is_contiguous():
@@ -444,6 +449,7 @@ class _Engine:
         return out
 
     def _backward(self, dlogits, mem16, B, S, key_len, enc_save, dec_save):
+        K.set_f32_products(self.products)
         d, H = self.d, self.H
         _, G = self.grad_buffers()
         tail = dec_save[-1]
@@ -568,6 +574,7 @@ class _Engine:
 
     @torch.no_grad()
     def decode_logits(self, tgt, mem16, B, S, key_len=None):
+        K.set_f32_products(self.products)
         return self._decoder_fwd(tgt, mem16, B, S, key_len, None).view(B, tgt.shape[1], -1)
 
     @torch.no_grad()
@@ -587,6 +594,7 @@ class _Engine:
         attention kernel: 0.68-0.83 ms/step replayed).  The host
         looks at the "all rows finished" flag every ``sync_every`` steps (the reference syncs every step).
         Returns ``[B, n]`` tokens, n as the reference would stop."""
+        K.set_f32_products(self.products)
         d, H, dev = self.d, self.H, mem16.device
         Tmax = int(max_length)
         emb = self.P("decoder.tgt_tok_emb.embedding.weight")
@@ -743,9 +751,9 @@ class ADTModel(PreTrainedModel):
         return self
 
     def set_precision(self, precision: str) -> "ADTModel":
-        """``"bf16"`` (throughput default) or ``"fp32"`` (parity arm, see ``_Engine``)."""
-        if precision not in ("bf16", "fp32"):
-            raise ValueError(f"precision must be 'bf16' or 'fp32', not {precision!r}")
+        """``"bf16"`` (throughput default), ``"fp32"`` or ``"bf16x3"`` (the parity arms, see ``_Engine``)."""
+        if precision not in PRECISIONS:
+            raise ValueError(f"precision must be one of {PRECISIONS}, not {precision!r}")
         self._precision, self._engine_obj = precision, None
         return self
 

@@ -281,6 +281,9 @@ typedef struct adt_attn_desc {
    * a cache of the mask function of adt_dropout, never a different mask: with or without them the gradients are those of the same
    * forward.  Ignored by the fp32-operand entry points. */
   void* keep_bits;
+  /* fp32-operand entry points only (adt_attn_fwd_f32 / adt_attn_bwd_f32; must be 0 or 1, the bf16 entry points ignore it): 0 = exact
+   * f32-input MFMA products, 1 = split-bf16 products (every fp32 operand as bf16 hi + lo, three bf16 MFMAs per product: "bf16x3") */
+  int32_t f32_products;
 } adt_attn_desc;
 
 int adt_attn_fwd(const adt_attn_desc* d, const void* q, const void* k, const void* v, void* o, float* lse, void* stream);
@@ -390,19 +393,27 @@ int adt_cross_entropy(const float* logits, int64_t ld, const int64_t* labels, in
  * parity arm, never the throughput default (the f32 MFMA rate is 1/16 of the bf16 rate).
  *
  *   adt_gemm_f32   layout bit 0: A is stored [K, M] (else [M, K]); bit 1: B is stored [K, N] (else [N, K]);
- *                  0 = y = x W^T, 2 = dx = dy W, 3 = dW = dy^T x.  C[M, N] fp32.  Same epilogue struct and order as
+ *                  0 = y = x W^T, 2 = dx = dy W, 3 = dW = dy^T x.  C[M, N] fp32.
+ *                  bit 2 (value 4): split-bf16 products ("bf16x3", round 6) -- every fp32 operand is split, while its tile is staged,
+ *                  into hi = bf16(x) and lo = bf16(x - hi), and a product is a_lo b_hi + a_hi b_lo + a_hi b_hi: three
+ *                  v_mfma_f32_32x32x16_bf16 into one fp32 accumulator, ~4e-6 of the output's magnitude against 1e-6 for the exact
+ *                  f32 MFMA and 2e-3 for bf16 operands, on the 16 x faster matrix pipe.  Same layouts, epilogue and fp32 tensors.
+ *                  ws (adt_gemm_f32_workspace_bytes, may be null): products whose output has too few 128 x 128 tiles to fill the
+ *                  chip and a plain epilogue (the weight gradients) are split along K through fp32 slabs summed in slab order.  Same epilogue struct and order as
  *                  adt_gemm_bf16 with gelu_grad_of / pre_act_out read and written as fp32; aux_bf16_out and colsum_out
  *                  must be null (adt_colsum_f32 takes the bias gradients).  The contiguous extent of each operand and
  *                  lda / ldb are multiples of 4 floats, operands 16-byte aligned.
  *   adt_attn_fwd_f32 / adt_attn_bwd_f32   adt_attn_fwd / adt_attn_bwd on fp32 q, k, v, o (same descriptor, masks and
  *                  dropout indices; row strides multiples of 4); the dq/dk/dv_colsum fields must be null.
+ *                  adt_attn_desc.f32_products = 1: split-bf16 products as above (head_dim 16 ... 128).
  *   adt_colsum_f32        column sums of an fp32 [M, N] matrix, fixed order.
  *   adt_layernorm_bwd_f32 adt_layernorm_bwd with the branch gradient (dx16 there) written as fp32.
  *   adt_cross_entropy_f32 adt_cross_entropy with fp32 dlogits and libm exp / log.
  *   adt_embed_bwd_operands_f32  fp32 one-hot / scaled-gradient operands of dtable = onehot^T . dy (adt_gemm_f32 layout 3).
  */
+size_t adt_gemm_f32_workspace_bytes(int32_t layout, int64_t M, int64_t N, int64_t K);
 int adt_gemm_f32(int32_t layout, int64_t M, int64_t N, int64_t K, const float* A, int64_t lda, const float* B, int64_t ldb,
-                 float* C, int64_t ldc, const adt_gemm_epilogue* ep, void* stream);
+                 float* C, int64_t ldc, const adt_gemm_epilogue* ep, void* ws, size_t ws_bytes, void* stream);
 int adt_attn_fwd_f32(const adt_attn_desc* d, const float* q, const float* k, const float* v, float* o, float* lse, void* stream);
 size_t adt_attn_bwd_f32_workspace_bytes(const adt_attn_desc* d);
 int adt_attn_bwd_f32(const adt_attn_desc* d, const float* q, const float* k, const float* v, const float* o, const float* dout,

@@ -1,4 +1,4 @@
-"""The fp32-operand parity arm (engine ``precision="fp32"``, kernels of csrc/precise.hip) on the GPU.
+"""The two fp32-operand parity arms (engine ``precision="fp32"`` / ``"bf16x3"``, kernels of csrc/precise.hip) on the GPU.
 
 BASELINE's target is "logits within 1e-3 rel-tol of the CPU reference" (the reference's fp32 CPU path,
 model.py:240-258).  Stated tolerances, all relative to the comparator's own magnitude:
@@ -11,7 +11,11 @@ model.py:240-258).  Stated tolerances, all relative to the comparator's own magn
   * greedy token ids: identical
 
 Comparators: oracle/adt.py in fp32 (pinned by tests/test_oracle_golden.py) and, directly, the tensors the reference's
-own ADTModel produced (tests/golden/adt_tiny.npz: logits, memory, loss, nine parameter gradients, greedy ids)."""
+own ADTModel produced (tests/golden/adt_tiny.npz: logits, memory, loss, nine parameter gradients, greedy ids).
+
+``"bf16x3"`` (round 6) is the same path with every product taken as three bf16 MFMAs on hi / lo splits of the fp32 operands: ~1e-5
+relative per product instead of 6e-8.  Logits are asserted at the exact arm's 1e-4 (measured 6e-6 ... 9e-6 of the largest logit, gradients 1.3e-5 of each tensor's maximum);
+the loss at 1e-4 and single kernels at 1e-4 of the output's maximum (ten times the exact arm's bound); greedy ids must be identical."""
 import math
 import os
 
@@ -25,7 +29,21 @@ from oracle import dropout as o_drop
 
 pytestmark = pytest.mark.gpu
 DEV = "cuda:0"
-REL = 1e-4            # asserted logit tolerance (BASELINE states 1e-3)
+REL = 1e-4            # asserted logit tolerance of the exact arm (BASELINE states 1e-3)
+ARMS = ("fp32", "bf16x3")
+LOGIT_REL = {"fp32": 1e-4, "bf16x3": 1e-4}       # asserted (measured: 1e-6 / 9e-6 at config[3]); BASELINE's statement is 1e-3 for both
+LOSS_REL = {"fp32": 2e-5, "bf16x3": 1e-4}
+KERNEL_REL = {"fp32": 1e-5, "bf16x3": 1e-4}      # a single product against fp64, relative to the output's maximum
+PRODUCTS = {"fp32": "f32", "bf16x3": "bf16x3"}
+
+
+@pytest.fixture(autouse=True)
+def _exact_products_by_default():
+    """Kernel-level tests select the product form through ``kernels.set_f32_products``; every test starts and ends on the exact one."""
+    from adt_str_amd import kernels as k
+    k.set_f32_products("f32")
+    yield
+    k.set_f32_products("f32")
 
 
 def rnd(shape, seed, scale=1.0):
@@ -41,50 +59,59 @@ def assert_logits_close(got, ref, rel=REL):
 
 
 # ----------------------------------------------------------------------------- kernels
-@pytest.mark.parametrize("M,N,Kd", [(36, 1400, 768), (153, 96, 32), (300, 260, 128), (1, 768, 3072), (129, 132, 20)])
-def test_gemm_f32_all_layouts(M, N, Kd):
+@pytest.mark.parametrize("arm", ARMS)
+@pytest.mark.parametrize("M,N,Kd", [(36, 1400, 768), (153, 96, 32), (300, 260, 128), (1, 768, 3072), (129, 132, 20), (768, 3072, 9000)])
+def test_gemm_f32_all_layouts(M, N, Kd, arm):
+    """(the last shape is a weight-gradient-like product: few output tiles, long K -> the K-split path through fp32 slabs)"""
     from adt_str_amd import kernels as k
+    k.set_f32_products(PRODUCTS[arm])
     a, w = rnd((M, Kd), 1), rnd((N, Kd), 2, 0.2)
     ref = a.double() @ w.double().t()
-    tol = 1e-5 * ref.abs().max().item() + 1e-6
+    tol = KERNEL_REL[arm] * ref.abs().max().item() + 1e-6
     assert (k.gemm(a, w).double() - ref).abs().max() <= tol                                   # y = x W^T
     assert (k.gemm(a, w.t().contiguous(), b_kn=True).double() - ref).abs().max() <= tol       # a [M,K] @ b [K,N]
     if M % 4 == 0:                                                                            # a stored [K, M]
-        assert (k.gemm(a.t().contiguous(), w.t().contiguous(), trans=True).double() - ref).abs().max() <= tol
+        at, wt = a.t().contiguous(), w.t().contiguous()
+        got = k.gemm(at, wt, trans=True)
+        assert (got.double() - ref).abs().max() <= tol
+        assert torch.equal(k.gemm(at, wt, trans=True), got)                                   # K splits are summed in a fixed order
     # strided views (packed projections): a = columns of a wider buffer, w = rows of a packed weight
     wide, packed = rnd((M, 3 * Kd), 3), rnd((3 * N, Kd), 4, 0.2)
     got = k.gemm(wide[:, Kd:2 * Kd], packed[N:2 * N])
     assert (got.double() - wide[:, Kd:2 * Kd].double() @ packed[N:2 * N].double().t()).abs().max() <= tol * 1.5
 
 
-def test_gemm_f32_epilogue_order():
+@pytest.mark.parametrize("arm", ARMS)
+def test_gemm_f32_epilogue_order(arm):
     from adt_str_amd import kernels as k
+    k.set_f32_products(PRODUCTS[arm])
     M, N, Kd, S = 96, 260, 64, 32
+    tol = 1e-5 * (KERNEL_REL[arm] / 1e-5)           # absolute, on outputs of magnitude ~10
     a, w, bias, res, pe = rnd((M, Kd), 1), rnd((N, Kd), 2, 0.2), rnd((N,), 3), rnd((M, N), 4), rnd((S, N), 5)
     z = (a.double() @ w.double().t() + bias.double())
     u = torch.empty((M, N), device=DEV)
     h = k.gemm(a, w, bias=bias, act=1, pre_act_out=u)
-    assert (u.double() - z).abs().max() < 1e-5 and (h.double() - F.gelu(z)).abs().max() < 1e-5
-    assert (k.gemm(a, w, bias=bias, act=2).double() - z.clamp(min=0)).abs().max() < 1e-5
-    assert (k.gemm(a, w, bias=bias, residual=res, alpha=0.5).double() - (0.5 * (z - bias.double()) + bias.double() + res.double())).abs().max() < 1e-5
-    assert (k.gemm(a, w, residual=pe, res_row_mod=S).double() - ((z - bias.double()).view(M // S, S, N) + pe.double()).view(M, N)).abs().max() < 1e-5
+    assert (u.double() - z).abs().max() < tol and (h.double() - F.gelu(z)).abs().max() < tol
+    assert (k.gemm(a, w, bias=bias, act=2).double() - z.clamp(min=0)).abs().max() < tol
+    assert (k.gemm(a, w, bias=bias, residual=res, alpha=0.5).double() - (0.5 * (z - bias.double()) + bias.double() + res.double())).abs().max() < tol
+    assert (k.gemm(a, w, residual=pe, res_row_mod=S).double() - ((z - bias.double()).view(M // S, S, N) + pe.double()).view(M, N)).abs().max() < tol
     # dgrad through GELU: dy W * gelu'(u), plus the column sums of the result (the bias gradient)
     ur = u.double().clone().requires_grad_(True)
     dy = rnd((M, N), 6)
     F.gelu(ur).backward(dy.double())
     cs = torch.empty(Kd, device=DEV)
     got = k.gemm(dy, w, b_kn=True, gelu_grad_of=rnd((M, Kd), 7), colsum_out=cs)          # shapes only: [M,N] @ [N,Kd]
-    assert got.shape == (M, Kd) and (cs.double() - got.double().sum(0)).abs().max() < 1e-4
+    assert got.shape == (M, Kd) and (cs.double() - got.double().sum(0)).abs().max() < 10 * tol
     one = k.gemm(torch.eye(N, device=DEV)[:M].contiguous(), torch.eye(N, device=DEV), gelu_grad_of=u, alpha=1.0)
     eye_grad = torch.zeros((M, N), dtype=torch.float64, device=DEV)
     eye_grad[:, :] = torch.eye(N, dtype=torch.float64, device=DEV)[:M]
     gp = torch.autograd.grad(F.gelu(ur).sum(), ur)[0]
-    assert (one.double() - eye_grad * gp).abs().max() < 1e-5                                 # gelu' exact to fp32
+    assert (one.double() - eye_grad * gp).abs().max() < tol                                 # gelu' exact to fp32
     # dropout positions: before / after the residual add, the same counter-based mask as the bf16 kernels
     site = k.drop_site(0.25, 11, 5)
     sc = o_drop.scale((M, N), *site).to(DEV).double()
-    assert (k.gemm(a, w, bias=bias, residual=res, drop=site).double() - (z * sc + res.double())).abs().max() < 1e-5
-    assert (k.gemm(a, w, bias=bias, residual=res, drop=site, drop_after_residual=True).double() - (z + res.double()) * sc).abs().max() < 1e-5
+    assert (k.gemm(a, w, bias=bias, residual=res, drop=site).double() - (z * sc + res.double())).abs().max() < tol
+    assert (k.gemm(a, w, bias=bias, residual=res, drop=site, drop_after_residual=True).double() - (z + res.double()) * sc).abs().max() < tol
 
 
 ATTN_CASES = [  # B, H, dh, Sq, Sk, causal, padded, p_drop
@@ -101,9 +128,12 @@ ATTN_CASES = [  # B, H, dh, Sq, Sk, causal, padded, p_drop
 ]
 
 
+@pytest.mark.parametrize("arm", ARMS)
 @pytest.mark.parametrize("B,H,dh,Sq,Sk,causal,padded,pdrop", ATTN_CASES)
-def test_attention_f32_forward_backward(B, H, dh, Sq, Sk, causal, padded, pdrop):
+def test_attention_f32_forward_backward(B, H, dh, Sq, Sk, causal, padded, pdrop, arm):
     from adt_str_amd import kernels as k
+    k.set_f32_products(PRODUCTS[arm])
+    ktol = KERNEL_REL[arm]
     d = H * dh
     qbuf, kvbuf = rnd((B * Sq, 3 * d), 1), rnd((B * Sk, 3 * d), 2)
     q, kk, v = qbuf[:, :d], kvbuf[:, d:2 * d], kvbuf[:, 2 * d:]
@@ -122,8 +152,8 @@ def test_attention_f32_forward_backward(B, H, dh, Sq, Sk, causal, padded, pdrop)
     if site is not None:
         p = p * o_drop.scale((B, H, Sq, Sk), *site).to(DEV).double()
     ref = (p @ vh).transpose(1, 2).reshape(B * Sq, d)
-    assert (o.double() - ref).abs().max() <= 1e-5 * ref.abs().max() + 1e-6
-    assert (lse.double() - torch.logsumexp(s, -1)).abs().max() <= 2e-5
+    assert (o.double() - ref).abs().max() <= ktol * ref.abs().max() + 1e-6
+    assert (lse.double() - torch.logsumexp(s, -1)).abs().max() <= 2e-5 * (ktol / 1e-5)
     dout = rnd((B * Sq, d), 3)
     ref.backward(dout.double())
     dqb, dkvb = torch.zeros_like(qbuf), torch.zeros_like(kvbuf)
@@ -131,7 +161,7 @@ def test_attention_f32_forward_backward(B, H, dh, Sq, Sk, causal, padded, pdrop)
     k.attn_bwd(q, kk, v, o, dout, lse, dqb[:, :d], dkvb[:, d:2 * d], dkvb[:, 2 * d:], B, H, Sq, Sk, scale, causal, key_len, drop=site,
                bias_grad=bg, head_dim=dh)
     for name, got, rg in (("dq", dqb[:, :d], qr.grad), ("dk", dkvb[:, d:2 * d], kr.grad), ("dv", dkvb[:, 2 * d:], vr.grad)):
-        assert (got.double() - rg).abs().max() <= 1e-5 * rg.abs().max() + 1e-7, name
+        assert (got.double() - rg).abs().max() <= ktol * rg.abs().max() + 1e-7, name
     assert (bg[:d].double() - qr.grad.sum(0)).abs().max() <= 1e-4 * qr.grad.abs().max() * math.sqrt(B * Sq)
     assert bool((bg[d:2 * d] == 0).all())
     assert (bg[2 * d:].double() - vr.grad.sum(0)).abs().max() <= 1e-4 * vr.grad.abs().max() * math.sqrt(B * Sk)
@@ -193,11 +223,12 @@ def run_engine(model, batch, want_grads=True):
                                        want_grads=want_grads, return_logits=True)
 
 
+@pytest.mark.parametrize("arm", ARMS)
 @pytest.mark.parametrize("enc_layers,dec_layers,nhead", [(1, 1, 2), (2, 2, 3)])
-def test_fp32_logits_loss_grads_within_target_of_the_fp32_oracle(enc_layers, dec_layers, nhead):
+def test_fp32_logits_loss_grads_within_target_of_the_fp32_oracle(enc_layers, dec_layers, nhead, arm):
     from tests.test_network_gpu import make_batch
-    model, state, cfg = make_model(enc_layers, dec_layers, nhead)
-    assert model.engine.precision == "fp32"
+    model, state, cfg = make_model(enc_layers, dec_layers, nhead, precision=arm)
+    assert model.engine.precision == arm
     batch = make_batch(3, 8000, 12, 1)
     st = grad_state(state)
     ref = o_adt.compute_loss(st, cfg, batch)
@@ -205,16 +236,17 @@ def test_fp32_logits_loss_grads_within_target_of_the_fp32_oracle(enc_layers, dec
     model.train()
     out = run_engine(model, batch)
     assert out["logits"].dtype == torch.float32 and out["memory"].dtype == torch.float32
-    assert_logits_close(out["logits"], ref["logits"].detach())
-    assert_logits_close(out["memory"].view(ref["memory"].shape), ref["memory"].detach())
-    assert abs(out["loss"].item() - ref["loss"].item()) <= 2e-5 * ref["loss"].item()
+    assert_logits_close(out["logits"], ref["logits"].detach(), LOGIT_REL[arm])
+    assert_logits_close(out["memory"].view(ref["memory"].shape), ref["memory"].detach(), LOGIT_REL[arm])
+    assert abs(out["loss"].item() - ref["loss"].item()) <= LOSS_REL[arm] * ref["loss"].item()
+    print(arm, "logits max|d| / max|ref|", ((out["logits"].cpu() - ref["logits"].detach()).abs().max() / ref["logits"].abs().max()).item())
     worst = 0.0
     for name, g in model.engine.G.items():
         rg = st[name].grad
         rel = (g.cpu() - rg).abs().max().item() / (rg.abs().max().item() + 1e-12)
         worst = max(worst, rel)
         assert rel <= 1e-3, f"{name}: grad rel err {rel}"
-    print("fp32 path: worst grad rel err", worst)
+    print(arm, "path: worst grad rel err", worst)
     # run to run: every reduction has a fixed order
     g1, l1 = model.engine.gflat.clone(), out["loss"].clone()
     again = run_engine(model, batch)
@@ -229,7 +261,8 @@ def tiny_state(g):
     return state
 
 
-def test_fp32_against_tensors_captured_from_the_reference(golden_dir):
+@pytest.mark.parametrize("arm", ARMS)
+def test_fp32_against_tensors_captured_from_the_reference(golden_dir, arm):
     """tests/golden/adt_tiny.npz holds what the reference's own ADTModel (model.py) computed on CPU in fp32 for explicit
     weights: encoder memory, logits, loss, nine gradients and the greedy ids of ADTModel.sample."""
     from adt_str_amd.network import ADTModel, ADTModelConfig
@@ -238,14 +271,14 @@ def test_fp32_against_tensors_captured_from_the_reference(golden_dir):
     d = state["encoder.dense_layer.weight"].shape[0]
     cfg = ADTModelConfig(input_sec=0.5, time_res=0.01, win_length=2048, sample_rate=16000, enc_layers=1, dec_layers=1, nhead=2,
                          d_query=d // 2, dropout=0.0, tgt_vocab_size=1400, plain=True, n_mels=128)
-    model = ADTModel(cfg).set_precision("fp32")
+    model = ADTModel(cfg).set_precision(arm)
     missing = model.load_state_dict(state, strict=False)
     assert all(k.startswith("compute_spectrogram.") for k in missing.missing_keys) and not missing.unexpected_keys
     model = model.to(DEV).train()
     out = run_engine(model, {"wavs": g["wave"], "tokens": g["tokens"], "token_lengths": g["token_lengths"]})
-    assert_logits_close(out["memory"].view(g["memory"].shape), torch.from_numpy(g["memory"]))
-    assert_logits_close(out["logits"], torch.from_numpy(g["logits"]))
-    assert abs(out["loss"].item() - float(g["loss"])) <= 2e-5 * float(g["loss"])
+    assert_logits_close(out["memory"].view(g["memory"].shape), torch.from_numpy(g["memory"]), LOGIT_REL[arm])
+    assert_logits_close(out["logits"], torch.from_numpy(g["logits"]), LOGIT_REL[arm])
+    assert abs(out["loss"].item() - float(g["loss"])) <= LOSS_REL[arm] * float(g["loss"])
     for key in g.files:
         if key.startswith("g::"):
             ref = torch.from_numpy(g[key])
@@ -256,9 +289,10 @@ def test_fp32_against_tensors_captured_from_the_reference(golden_dir):
         assert np.array_equal(ids, g["sample_ids"]), (use_cache, ids, g["sample_ids"])
 
 
-def test_fp32_greedy_ids_identical_to_the_oracle():
+@pytest.mark.parametrize("arm", ARMS)
+def test_fp32_greedy_ids_identical_to_the_oracle(arm):
     from tests.test_network_gpu import make_batch
-    model, state, cfg = make_model(2, 2, 2, seed=3)
+    model, state, cfg = make_model(2, 2, 2, seed=3, precision=arm)
     src = torch.from_numpy(make_batch(4, 8000, 6, 3)["wavs"])
     ref = o_adt.greedy_sample(state, cfg, src, max_length=12)
     for use_cache in (True, False):
@@ -266,10 +300,11 @@ def test_fp32_greedy_ids_identical_to_the_oracle():
         assert torch.equal(got, ref), (use_cache, got, ref)
 
 
-def test_fp32_with_dropout_matches_the_oracle_with_the_same_masks():
+@pytest.mark.parametrize("arm", ARMS)
+def test_fp32_with_dropout_matches_the_oracle_with_the_same_masks(arm):
     from adt_str_amd import kernels as k
     from tests.test_network_gpu import make_batch
-    model, state, cfg = make_model(2, 2, 2, dropout=0.1)
+    model, state, cfg = make_model(2, 2, 2, dropout=0.1, precision=arm)
     batch = make_batch(3, 8000, 12, 1)
     model.train()
     out = run_engine(model, batch)
@@ -283,8 +318,8 @@ def test_fp32_with_dropout_matches_the_oracle_with_the_same_masks():
     st = grad_state(state)
     ref = o_adt.compute_loss(st, cfg, batch, drop=drop)
     ref["loss"].backward()
-    assert_logits_close(out["logits"], ref["logits"].detach())
-    assert abs(out["loss"].item() - ref["loss"].item()) <= 2e-5 * ref["loss"].item()
+    assert_logits_close(out["logits"], ref["logits"].detach(), LOGIT_REL[arm])
+    assert abs(out["loss"].item() - ref["loss"].item()) <= LOSS_REL[arm] * ref["loss"].item()
     for name, g in eng.G.items():
         rg = st[name].grad
         assert (g.cpu() - rg).abs().max().item() <= 1e-3 * rg.abs().max().item() + 1e-12, name
@@ -329,7 +364,7 @@ def test_config3_full_size_step_both_precisions():
     batch = _config3_batch()
     two = {k: v[:2] for k, v in batch.items()}
     cfg = dict(nhead=6, sample_rate=16000, win_length=2048, time_res=0.01, n_mels=128)
-    for precision in ("fp32", "bf16"):
+    for precision in ("fp32", "bf16x3", "bf16"):
         model, state = _setting1(precision)
         out = run_engine(model, batch)
         eng = model.engine
@@ -340,10 +375,10 @@ def test_config3_full_size_step_both_precisions():
         again = run_engine(model, batch)
         assert torch.equal(again["loss"], l1) and torch.equal(eng.gflat, g1) and torch.equal(again["logits"], lg1)
         ref = o_adt.compute_loss(state, cfg, two, bf16=(precision == "bf16"))
-        if precision == "fp32":
-            print("config[3] fp32 path vs fp32 oracle, clips 0-1: max |dlogit| / max |logit|",
+        if precision != "bf16":
+            print(f"config[3] {precision} path vs fp32 oracle, clips 0-1: max |dlogit| / max |logit|",
                   ((lg1[:2].cpu() - ref["logits"]).abs().max() / ref["logits"].abs().max()).item())
-            assert_logits_close(lg1[:2], ref["logits"])
+            assert_logits_close(lg1[:2], ref["logits"], LOGIT_REL[precision])
         else:
             err = (lg1[:2].cpu() - ref["logits"]).abs().max().item()
             print("config[3] bf16 path vs bf16-operand oracle, clips 0-1: max |dlogit|", err)
@@ -361,7 +396,7 @@ def test_reference_native_operating_point_both_precisions():
     batch = _config3_batch(L=L, seed=12, sr=sr)
     two = {k: v[:2] for k, v in batch.items()}
     cfg = dict(nhead=6, sample_rate=sr, win_length=2048, time_res=0.01, n_mels=128)
-    for precision in ("fp32", "bf16"):
+    for precision in ("fp32", "bf16x3", "bf16"):
         model, state = _setting1(precision, input_sec=2.56, sample_rate=sr)
         out = run_engine(model, batch)
         eng = model.engine
@@ -371,10 +406,10 @@ def test_reference_native_operating_point_both_precisions():
         again = run_engine(model, batch)
         assert torch.equal(again["loss"], l1) and torch.equal(eng.gflat, g1) and torch.equal(again["logits"], lg1)
         ref = o_adt.compute_loss(state, cfg, two, bf16=(precision == "bf16"))
-        if precision == "fp32":
-            print("native operating point, fp32 path vs fp32 oracle, clips 0-1: max |dlogit| / max |logit|",
+        if precision != "bf16":
+            print(f"native operating point, {precision} path vs fp32 oracle, clips 0-1: max |dlogit| / max |logit|",
                   ((lg1[:2].cpu() - ref["logits"]).abs().max() / ref["logits"].abs().max()).item())
-            assert_logits_close(lg1[:2], ref["logits"])
+            assert_logits_close(lg1[:2], ref["logits"], LOGIT_REL[precision])
         else:
             err = (lg1[:2].cpu() - ref["logits"]).abs().max().item()
             print("native operating point, bf16 path vs bf16-operand oracle, clips 0-1: max |dlogit|", err)

@@ -4,7 +4,7 @@ R=$GRAFT_REPO_ROOT
 O=$R/gpurun_out/rccl_one_rank
 mkdir -p $O
 cd $R
-COMMON="--steps 20 --warmup 5 --no-cpu-baseline --no-e2e --no-clap --no-fp32-arm"
+COMMON="--steps 20 --warmup 5 --no-cpu-baseline --no-e2e --no-clap --no-fp32-arm --no-parity-arm"
 for i in 1 2 3; do
   timeout -k 10 300 python bench.py $COMMON > $O/plain_$i.json 2> /dev/null; python -c "import json;d=json.load(open('$O/plain_$i.json'));print('plain $i', round(d['ms_per_step'],3))"
   timeout -k 10 300 python -m torch.distributed.run --nnodes=1 --nproc-per-node 1 --master-addr 127.0.0.1 --master-port 2951$i bench.py --gpus 1 $COMMON > $O/torchrun_f32_$i.json 2> /dev/null; python -c "import json;d=json.load(open('$O/torchrun_f32_$i.json'));print('torchrun f32 $i', round(d['ms_per_step'],3), d.get('comm'))"
@@ -15,7 +15,7 @@ cd /tmp && export TMPDIR=/tmp
 # pool forbids).  bench.py builds the nccl process group whenever RANK / WORLD_SIZE are in the environment, so the one-rank RCCL path still runs
 # inside the profiled process.
 export RANK=0 LOCAL_RANK=0 WORLD_SIZE=1 MASTER_ADDR=127.0.0.1 MASTER_PORT=29531
-timeout -k 10 600 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_torchrun -- python3 $R/bench.py --gpus 1 --steps 6 --warmup 3 --no-cpu-baseline --no-e2e --no-clap --no-fp32-arm --no-clock > $O/prof_torchrun.log 2>&1
+timeout -k 10 600 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_torchrun -- python3 $R/bench.py --gpus 1 --steps 6 --warmup 3 --no-cpu-baseline --no-e2e --no-clap --no-fp32-arm --no-parity-arm --no-clock > $O/prof_torchrun.log 2>&1
 unset RANK LOCAL_RANK WORLD_SIZE MASTER_ADDR MASTER_PORT
 cd $R
 ls $O/prof_torchrun/*/ 2>/dev/null | head
