@@ -29,6 +29,19 @@
 
 namespace adt {
 
+// Cache-policy bits of the persistent NT kernel's operand DMAs (aux of global_load_lds: 1 = sc0, 2 = nt, 16 = sc1) and whether the main
+// output leaves by non-temporal stores (A/B arms through tools/build_variant.sh).  Measured in round 6 (profiles/r06/gemm_cache_policy_ab.txt):
+// nt on either operand costs the K = 768 shapes +10...15 % (the panels' reuse in L2 goes), nt on the main output is +-0 on the step; the
+// saved-factor output stays non-temporal (round 4).
+#ifndef ADT_NT_A_AUX
+#define ADT_NT_A_AUX 0
+#endif
+#ifndef ADT_NT_B_AUX
+#define ADT_NT_B_AUX 0
+#endif
+#ifndef ADT_NT_C_NT
+#define ADT_NT_C_NT 0
+#endif
 typedef __attribute__((ext_vector_type(8))) short bf16x8;
 typedef __attribute__((ext_vector_type(4))) short bf16x4;
 typedef __attribute__((ext_vector_type(4))) float f32x4;
@@ -383,15 +396,26 @@ __device__ __forceinline__ void epilogue_apply8(const GemmArgs& g, float (&z)[8]
     for (int e = 0; e < 8; ++e) z[e] *= keep[e];
   }
   const bool fp32_out = ef<kMask, kEfFp32>(ep.out_fp32 != 0), aux = ef<kMask, kEfAux>(ep.aux_bf16_out != nullptr);
+  typedef unsigned u32x4_st __attribute__((ext_vector_type(4)));
+  typedef float f32x4_st __attribute__((ext_vector_type(4)));
   if (aux || !fp32_out) {
     const uint4 o16 = pack_bf8(z);
     if (aux) *reinterpret_cast<uint4*>(reinterpret_cast<unsigned short*>(ep.aux_bf16_out) + (ea.aux + static_cast<long>(irow) * ep.ld_aux)) = o16;
-    if (!fp32_out) *reinterpret_cast<uint4*>(reinterpret_cast<unsigned short*>(g.C) + (ea.c + static_cast<long>(irow) * g.ldc)) = o16;
+    if (!fp32_out) {
+      unsigned short* cp = reinterpret_cast<unsigned short*>(g.C) + (ea.c + static_cast<long>(irow) * g.ldc);
+      if (ADT_NT_C_NT) __builtin_nontemporal_store(u32x4_st{o16.x, o16.y, o16.z, o16.w}, reinterpret_cast<u32x4_st*>(cp));
+      else *reinterpret_cast<uint4*>(cp) = o16;
+    }
   }
   if (fp32_out) {
     float* cp = reinterpret_cast<float*>(g.C) + (ea.c + static_cast<long>(irow) * g.ldc);
-    *reinterpret_cast<float4*>(cp) = float4{z[0], z[1], z[2], z[3]};
-    *reinterpret_cast<float4*>(cp + 4) = float4{z[4], z[5], z[6], z[7]};
+    if (ADT_NT_C_NT) {
+      __builtin_nontemporal_store(f32x4_st{z[0], z[1], z[2], z[3]}, reinterpret_cast<f32x4_st*>(cp));
+      __builtin_nontemporal_store(f32x4_st{z[4], z[5], z[6], z[7]}, reinterpret_cast<f32x4_st*>(cp + 4));
+    } else {
+      *reinterpret_cast<float4*>(cp) = float4{z[0], z[1], z[2], z[3]};
+      *reinterpret_cast<float4*>(cp + 4) = float4{z[4], z[5], z[6], z[7]};
+    }
   }
 }
 
@@ -633,10 +657,12 @@ __global__ __launch_bounds__(kBigThreads) void gemm_nt_256_kernel(GemmArgs g, in
   auto dma = [&](const unsigned short* const (&p)[2], int tile, int buf, int half_slot) {
     const int tt = tile < k_tiles ? tile : k_tiles - 1;
 #pragma unroll
-    for (int j = 0; j < 2; ++j)
-      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(p[j] + static_cast<long>(tt) * kBK),
-                                       (__attribute__((address_space(3))) void*)(smem + buf * kBigBuf + half_slot * kHalfTile + (2 * wave + j) * 1024),
-                                       16, 0, 0);
+    for (int j = 0; j < 2; ++j) {
+      const auto src = (const __attribute__((address_space(1))) void*)(p[j] + static_cast<long>(tt) * kBK);
+      const auto dst = (__attribute__((address_space(3))) void*)(smem + buf * kBigBuf + half_slot * kHalfTile + (2 * wave + j) * 1024);
+      if (half_slot < 2) __builtin_amdgcn_global_load_lds(src, dst, 16, 0, ADT_NT_A_AUX);      // (half_slot is a literal at every call site)
+      else __builtin_amdgcn_global_load_lds(src, dst, 16, 0, ADT_NT_B_AUX);
+    }
   };
   auto prologue_dma = [&]() {          // tile 0 complete + B_0 / A_0 / B_1 of tile 1: what the K loop expects to be in flight
     dma(pa[0], 0, 0, 0); dma(pb[0], 0, 0, 2); dma(pa[1], 0, 0, 1); dma(pb[1], 0, 0, 3);
