@@ -106,3 +106,29 @@ def test_train_line_with_the_back_to_back_loop():
     assert r["timed"].startswith("8 launches inside the timed steps")
     b = r["back_to_back"]
     assert b["launches"] == 60 and 0.5 < b["kernel_ms"] / r["kernel_ms"] < 2.0
+
+
+def test_two_rank_line_on_a_shared_gpu():
+    """The N > 1 line before the first real node sees it: ``ADT_BENCH_SHARE_GPU=1 bench.py --gpus 2`` spawns its two
+    ranks itself (a child launcher, before anything touches the GPU), both on GPU 0 over gloo -- a DEBUG mode whose numbers mean nothing and
+    whose line says so -- and the line must carry what the driver and the judge read at N = 2."""
+    env = dict(os.environ, ADT_BENCH_SHARE_GPU="1", HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT"):
+        env.pop(k, None)
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1", "--no-cpu-baseline", "--no-e2e",
+                          "--no-clap"], cwd=ROOT, env=env, capture_output=True, text=True, timeout=900)
+    assert out.returncode == 0, out.stderr[-3000:]
+    lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, out.stdout[-2000:]                       # rank 0 prints, rank 1 is silent
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["steps"] == 3 and d["warmup"] == 1 and d["scaling"] == "weak" and d["config"]["parallelism"] == "dp2"
+    assert d["collective"] == {"backend": "gloo", "world_size": 2}
+    per = d["ms_per_step_ranks"]["per_rank"]
+    assert len(per) == 2 and all(p > 0 for p in per) and d["ms_per_step_ranks"]["max"] == max(per)
+    assert abs(d["ms_per_step"] - max(per)) / d["ms_per_step"] < 1e-6                      # MAX over ranks
+    assert abs(d["value"] - 2 * 64 * 3 / (d["ms_per_step"] * 3e-3)) / d["value"] < 1e-6     # whole-job clips / that time
+    c = d["comm"]
+    assert c["bytes_per_step"] == 276003296 and c["wire_dtype"] == "f32" and c["steps_timed"] == 3 and c["exposed_wait_ms"] is not None
+    assert "DEBUG RUN" in d["data"]
+    for k in ("cpu_baseline", "parity_arm", "fp32_arm", "clap"):      # N = 1 only
+        assert k not in d

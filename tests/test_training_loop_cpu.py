@@ -386,3 +386,15 @@ def test_bench_launch_line_is_the_drivers():
     assert cmd[1:4] == ["-m", "torch.distributed.run", "--nnodes=1"] and "--nproc-per-node=8" in cmd
     assert cmd[cmd.index("--master-addr") + 1] == "127.0.0.1" and cmd[-4:] == ["--gpus", "8", "--steps", "5"]
     assert cmd[cmd.index("--master-port") + 2].endswith("bench.py")
+
+
+def test_bench_refuses_a_launcher_with_another_world_size():
+    """``bench.py --gpus N`` under a launcher that started a different number of ranks must stop (non-zero, before anything touches a GPU):
+    a silent run would report N GPUs' worth of throughput for another rank count."""
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, WORLD_SIZE="3", RANK="0", LOCAL_RANK="0", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(_free_port()))
+    out = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0"], cwd=root, env=env,
+                         capture_output=True, text=True, timeout=300)
+    assert out.returncode != 0
+    assert "--gpus 2 but the launcher started 3 ranks" in out.stderr and not [l for l in out.stdout.splitlines() if l.startswith("{")]
