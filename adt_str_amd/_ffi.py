@@ -18,7 +18,7 @@ if os.environ.get("ADT_LIB_PATH"):          # said on stderr so that a bench lin
 _lock = threading.Lock()
 _lib = None
 
-ABI_VERSION = 17
+ABI_VERSION = 18
 
 i32, i64, f32, ptr = C.c_int32, C.c_int64, C.c_float, C.c_void_p
 
@@ -34,7 +34,8 @@ class GemmEpilogue(C.Structure):
                 ("ld_res", C.c_int64), ("res_row_mod", C.c_int32), ("act", C.c_int32), ("alpha", C.c_float),
                 ("out_fp32", C.c_int32), ("aux_bf16_out", C.c_void_p), ("ld_aux", C.c_int64), ("drop", Dropout),
                 ("drop_after_residual", C.c_int32), ("colsum_out", C.c_void_p), ("act_grad_mode", C.c_int32),
-                ("res_ln_mean", C.c_void_p), ("res_ln_rstd", C.c_void_p), ("res_ln_gamma", C.c_void_p), ("res_ln_beta", C.c_void_p)]
+                ("res_ln_mean", C.c_void_p), ("res_ln_rstd", C.c_void_p), ("res_ln_gamma", C.c_void_p), ("res_ln_beta", C.c_void_p),
+                ("side_fp32", C.c_int32)]
 
 
 class GemmTnItem(C.Structure):
@@ -95,6 +96,10 @@ SIGNATURES = {
     "adt_cross_entropy": [ptr, i64, ptr, i64, i64, i64, ptr, ptr, i64, ptr, C.c_size_t, ptr],
     "adt_gemm_f32_workspace_bytes": [i32, i64, i64, i64],
     "adt_gemm_f32": [i32, i64, i64, i64, ptr, i64, ptr, i64, ptr, i64, ptr, ptr, C.c_size_t, ptr],
+    "adt_split_bf16x2": [ptr, i64, i64, i64, ptr, i64, i64, i32, ptr],
+    "adt_gemm_bf16x3_supported": [i32, i64, i64, i64],
+    "adt_gemm_bf16x3_workspace_bytes": [i32, i64, i64, i64],
+    "adt_gemm_bf16x3": [i32, i64, i64, i64, ptr, i64, i64, ptr, i64, i64, ptr, i64, ptr, ptr, C.c_size_t, ptr],
     "adt_attn_fwd_f32": [ptr, ptr, ptr, ptr, ptr, ptr, ptr],
     "adt_attn_bwd_f32_workspace_bytes": [ptr],
     "adt_attn_bwd_f32": [ptr, ptr, ptr, ptr, ptr, ptr, ptr, ptr, ptr, ptr, ptr, C.c_size_t, ptr],
@@ -131,7 +136,8 @@ _RESTYPES.update({n: C.c_size_t for n in ("adt_mix_workspace_bytes", "adt_gemm_w
                                           "adt_layernorm_bwd_workspace_bytes", "adt_colsum_workspace_bytes", "adt_gemm_colsum_workspace_bytes",
                                           "adt_cross_entropy_workspace_bytes", "adt_grad_norm_workspace_bytes",
                                           "adt_htsat_fusion_embed_workspace_bytes",
-                                          "adt_attn_bwd_f32_workspace_bytes", "adt_colsum_f32_workspace_bytes", "adt_gemm_f32_workspace_bytes")})
+                                          "adt_attn_bwd_f32_workspace_bytes", "adt_colsum_f32_workspace_bytes", "adt_gemm_f32_workspace_bytes",
+                                          "adt_gemm_bf16x3_workspace_bytes")})
 
 
 class AdtError(RuntimeError):

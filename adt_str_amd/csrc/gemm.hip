@@ -78,6 +78,10 @@ struct GemmArgs {
   int group_n;                             // gemm_nt_256_kernel: tile columns per column group of the tile order (>= tiles_n: row-major)
   int stagger;                             // gemm_nt_256_kernel, experiment builds only (-DADT_GEMM_EXPERIMENT, ADT_GEMM_STAGGER=<s_memtime ticks>): every second workgroup of an XCD group starts late
   unsigned* sched; unsigned sched_total[8];  // persistent kernels: per-XCD-group work counters (16 words apart, zero between launches) and the number of tickets each hands out in this launch
+  // split-bf16 products on the persistent kernels (adt_gemm_bf16x3; kX3 instantiations only): the operands are [hi | lo] bf16 plane pairs
+  // of fp32 matrices, K counts VIRTUAL K-tiles -- three segments of x3_kt tiles: lo x hi, hi x lo, hi x hi -- and a segment's tile r is read
+  // from the plane its segment names (lo plane = x3_a_lo / x3_b_lo elements to the right of the hi plane)
+  int x3_kt; long x3_a_lo, x3_b_lo;
 };
 
 // ---- global -> register staging (4 x 16 B per thread per operand) -----------------------------
@@ -262,6 +266,7 @@ enum : unsigned {
   kEfDropAfterRes = 256u, kEfAux = 512u, kEfFp32 = 1024u, kEfAlpha = 2048u, kEfResLn = 4096u, kEpiGeneric = 0x80000000u
 };
 static unsigned epilogue_mask(const adt_gemm_epilogue& e) {
+  if (e.side_fp32) return kEpiGeneric;                  // fp32 saved-factor / pre-activation arrays (adt_gemm_bf16x3): run-time flags only
   return (e.bias ? kEfBias : 0u) | (e.gelu_grad_of ? kEfGeluGrad : 0u) | (e.act_grad_mode ? kEfFactor : 0u) | (e.pre_act_out ? kEfPreAct : 0u) |
          (e.act == 1 ? kEfGelu : 0u) | (e.act == 2 ? kEfRelu : 0u) | (e.residual ? kEfResidual : 0u) | (e.residual && e.res_row_mod > 0 ? kEfRowMod : 0u) |
          (e.drop.p > 0.f && e.drop_after_residual ? kEfDropAfterRes : 0u) | (e.aux_bf16_out ? kEfAux : 0u) | (e.out_fp32 ? kEfFp32 : 0u) | (e.alpha != 1.0f ? kEfAlpha : 0u) | (e.residual && e.res_ln_mean ? kEfResLn : 0u);
@@ -308,7 +313,13 @@ __device__ __forceinline__ void epilogue_apply8(const GemmArgs& g, float (&z)[8]
 #pragma unroll
     for (int e = 0; e < 8; ++e) z[e] += bias[e];
   }
-  if (ef<kMask, kEfGeluGrad>(ep.gelu_grad_of != nullptr)) {
+  if ((kMask & kEpiGeneric) != 0u && ep.side_fp32 && ep.gelu_grad_of != nullptr) {        // fp32 factor / pre-activation array (the split-bf16 parity arm)
+    const float* gp = reinterpret_cast<const float*>(ep.gelu_grad_of) + (ea.gg + static_cast<long>(irow) * ep.ld_gelu_grad);
+    const float4 g0 = *reinterpret_cast<const float4*>(gp), g1 = *reinterpret_cast<const float4*>(gp + 4);
+    const float gv[8] = {g0.x, g0.y, g0.z, g0.w, g1.x, g1.y, g1.z, g1.w};
+#pragma unroll
+    for (int e = 0; e < 8; ++e) z[e] *= ep.act_grad_mode ? gv[e] : gelu_erf_grad(gv[e]);
+  } else if (ef<kMask, kEfGeluGrad>(ep.gelu_grad_of != nullptr)) {
     const uint4 uv = *reinterpret_cast<const uint4*>(reinterpret_cast<const unsigned short*>(ep.gelu_grad_of) + (ea.gg + static_cast<long>(irow) * ep.ld_gelu_grad));
     const unsigned w[4] = {uv.x, uv.y, uv.z, uv.w};
 #pragma unroll
@@ -344,7 +355,12 @@ __device__ __forceinline__ void epilogue_apply8(const GemmArgs& g, float (&z)[8]
       z[2 * e] = gv[0]; z[2 * e + 1] = gv[1];
       f[2 * e] = gd[0] * keep[2 * e]; f[2 * e + 1] = gd[1] * keep[2 * e + 1];
     }
-    {
+    if ((kMask & kEpiGeneric) != 0u && ep.side_fp32) {
+      typedef float f32x4_nt __attribute__((ext_vector_type(4)));
+      float* fp = reinterpret_cast<float*>(ep.pre_act_out) + (ea.pre + static_cast<long>(irow) * ep.ld_pre_act);
+      __builtin_nontemporal_store(f32x4_nt{f[0], f[1], f[2], f[3]}, reinterpret_cast<f32x4_nt*>(fp));
+      __builtin_nontemporal_store(f32x4_nt{f[4], f[5], f[6], f[7]}, reinterpret_cast<f32x4_nt*>(fp + 4));
+    } else {
       // the saved factor is not read before the backward pass: a non-temporal store keeps it from displacing h (which the next launch
       // reads) from the Infinity Cache -- the launch itself does not change, the step gains 0.09 ms (same-box A/B, twice)
       typedef unsigned u32x4_nt __attribute__((ext_vector_type(4)));
@@ -352,7 +368,11 @@ __device__ __forceinline__ void epilogue_apply8(const GemmArgs& g, float (&z)[8]
       __builtin_nontemporal_store(u32x4_nt{pf.x, pf.y, pf.z, pf.w}, reinterpret_cast<u32x4_nt*>(reinterpret_cast<unsigned short*>(ep.pre_act_out) + (ea.pre + static_cast<long>(irow) * ep.ld_pre_act)));
     }
   } else {
-    if (has_pre) {
+    if (has_pre && (kMask & kEpiGeneric) != 0u && ep.side_fp32) {        // fp32 pre-activation, kept exactly (nothing is rounded on this arm)
+      float* fp = reinterpret_cast<float*>(ep.pre_act_out) + (ea.pre + static_cast<long>(irow) * ep.ld_pre_act);
+      *reinterpret_cast<float4*>(fp) = float4{z[0], z[1], z[2], z[3]};
+      *reinterpret_cast<float4*>(fp + 4) = float4{z[4], z[5], z[6], z[7]};
+    } else if (has_pre) {
       const uint4 o = pack_bf8(z);
       *reinterpret_cast<uint4*>(reinterpret_cast<unsigned short*>(ep.pre_act_out) + (ea.pre + static_cast<long>(irow) * ep.ld_pre_act)) = o;
       const unsigned w[4] = {o.x, o.y, o.z, o.w};       // the activation sees the value the backward will read
@@ -613,7 +633,7 @@ __device__ unsigned long long g_gemm_stamps[4][16][4];
 #else
 #define ADT_GSTAMP(K) do { } while (0)
 #endif
-template <bool kDrop, bool kColsum, unsigned kMask>
+template <bool kDrop, bool kColsum, unsigned kMask, bool kX3 = false>
 __global__ __launch_bounds__(kBigThreads) void gemm_nt_256_kernel(GemmArgs g, int tiles_m, int tiles_n) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const int tid = threadIdx.x, lane = tid & 63;
@@ -656,9 +676,14 @@ __global__ __launch_bounds__(kBigThreads) void gemm_nt_256_kernel(GemmArgs g, in
   };
   auto dma = [&](const unsigned short* const (&p)[2], int tile, int buf, int half_slot) {
     const int tt = tile < k_tiles ? tile : k_tiles - 1;
+    long koff = static_cast<long>(tt) * kBK;
+    if (kX3) {                                             // virtual K-tile -> (segment, tile of the plane): scalar arithmetic
+      const int seg = (tt >= g.x3_kt ? 1 : 0) + (tt >= 2 * g.x3_kt ? 1 : 0);
+      koff = static_cast<long>(tt - seg * g.x3_kt) * kBK + (half_slot < 2 ? (seg == 0 ? g.x3_a_lo : 0) : (seg == 1 ? g.x3_b_lo : 0));
+    }
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
-      const auto src = (const __attribute__((address_space(1))) void*)(p[j] + static_cast<long>(tt) * kBK);
+      const auto src = (const __attribute__((address_space(1))) void*)(p[j] + koff);
       const auto dst = (__attribute__((address_space(3))) void*)(smem + buf * kBigBuf + half_slot * kHalfTile + (2 * wave + j) * 1024);
       if (half_slot < 2) __builtin_amdgcn_global_load_lds(src, dst, 16, 0, ADT_NT_A_AUX);      // (half_slot is a literal at every call site)
       else __builtin_amdgcn_global_load_lds(src, dst, 16, 0, ADT_NT_B_AUX);
@@ -1512,6 +1537,7 @@ __global__ __launch_bounds__(kGemmThreads) void gemm_tn_grouped_kernel(TnGroupAr
   asm volatile("ds_read_b64_tr_b16 %0, %2 offset:%3\n\tds_read_b64_tr_b16 %1, %2 offset:%4"            \
                : "=&v"(lo), "=&v"(hi) : "v"(addr), "i"(imm), "i"((imm) + 4096))
 
+template <bool kX3>
 __global__ __launch_bounds__(kBigThreads) void gemm_tn_256_kernel(GemmArgs g, int tiles_m, int tiles_n, int splits) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const int tid = threadIdx.x, lane = tid & 63;
@@ -1528,6 +1554,7 @@ __global__ __launch_bounds__(kBigThreads) void gemm_tn_256_kernel(GemmArgs g, in
   unsigned* const counter = g.sched + xg * 16;
   const unsigned ctotal = g.sched_total[xg];
   int k_tiles = 0;                     // K-tiles of the current item
+  int kt_first = 0;                    // kX3: the item's first VIRTUAL K-tile (the pointers then carry no K offset; dma() maps every tile)
   auto set_item = [&](int v, int& m0, int& n0, int& split) {
     const int logical = slice0 + v;              // split-major: an XCD slice holds neighbouring tiles of ONE K range (they share
     const int n_tiles = tiles_m * tiles_n;       // A / B panels through that XCD's L2)
@@ -1539,11 +1566,12 @@ __global__ __launch_bounds__(kBigThreads) void gemm_tn_256_kernel(GemmArgs g, in
     int kt1 = kt0 + g.k_tiles_per_split;
     kt1 = kt1 < k_tiles_all ? kt1 : k_tiles_all;
     k_tiles = kt1 - kt0;               // >= 1: the host sizes the splits so that the last one is not empty
+    kt_first = kt0;
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
       const int r = 4 * (2 * wave + j) + (lane >> 4);
       const int c = (((lane & 15) ^ ((r & 7) << 1))) * 8;                 // first LDS column of this lane's 16-byte chunk
-      const long krow = static_cast<long>(kt0) * kBK + r;
+      const long krow = (kX3 ? 0l : static_cast<long>(kt0) * kBK) + r;
 #pragma unroll
       for (int h = 0; h < 2; ++h) {
         int ac = m0 + (c >> 6) * 128 + h * 64 + (c & 63);
@@ -1557,9 +1585,15 @@ __global__ __launch_bounds__(kBigThreads) void gemm_tn_256_kernel(GemmArgs g, in
   };
   auto dma = [&](const unsigned short* const (&p)[2], long ld, int tile, int buf, int half_slot) {
     const int tt = tile < k_tiles ? tile : k_tiles - 1;
+    long off = static_cast<long>(tt) * kBK * ld;
+    if (kX3) {                                             // virtual K-tile -> (segment, row tile of the planes): lo x hi, hi x lo, hi x hi
+      const int vt = kt_first + tt;
+      const int seg = (vt >= g.x3_kt ? 1 : 0) + (vt >= 2 * g.x3_kt ? 1 : 0);
+      off = static_cast<long>(vt - seg * g.x3_kt) * kBK * ld + (half_slot < 2 ? (seg == 0 ? g.x3_a_lo : 0) : (seg == 1 ? g.x3_b_lo : 0));
+    }
 #pragma unroll
     for (int j = 0; j < 2; ++j)
-      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(p[j] + static_cast<long>(tt) * kBK * ld),
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(p[j] + off),
                                        (__attribute__((address_space(3))) void*)(smem + buf * kBigBuf + half_slot * kHalfTile + (2 * wave + j) * 1024),
                                        16, 0, 0);
   };
@@ -1753,16 +1787,16 @@ void launch_reduce_slabs(const float* slabs, int splits, long mn, int N, float a
 }
 
 // One instantiation of the persistent NT kernel: (dropout, column sums, epilogue form).
-template <bool kDrop, bool kColsum, unsigned kMask>
+template <bool kDrop, bool kColsum, unsigned kMask, bool kX3 = false>
 static int launch_nt_256(const GemmArgs& g, dim3 grid, int tm, int tn, hipStream_t st) {
   static thread_local int attr_dev = -1;
   int dev = 0;
   ADT_HIP_TRY(hipGetDevice(&dev));
   if (attr_dev != dev) {
-    ADT_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_nt_256_kernel<kDrop, kColsum, kMask>), hipFuncAttributeMaxDynamicSharedMemorySize, kBigLds));
+    ADT_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_nt_256_kernel<kDrop, kColsum, kMask, kX3>), hipFuncAttributeMaxDynamicSharedMemorySize, kBigLds));
     attr_dev = dev;
   }
-  hipLaunchKernelGGL((gemm_nt_256_kernel<kDrop, kColsum, kMask>), grid, dim3(kBigThreads), kBigLds, st, g, tm, tn);
+  hipLaunchKernelGGL((gemm_nt_256_kernel<kDrop, kColsum, kMask, kX3>), grid, dim3(kBigThreads), kBigLds, st, g, tm, tn);
   return ADT_OK;
 }
 // The forms the training step launches (adt_str_amd/network.py; ADT_GEMM_LOG_FORMS=1 lists what a workload launches) get their own
@@ -1789,6 +1823,10 @@ static int launch_nt_256(const GemmArgs& g, dim3 grid, int tm, int tn, hipStream
   X(false, false, kEfBias | kEfGelu)                          /* inference MLP linear1 (the CLAP tower's last stage): bias, GELU */
 static int dispatch_nt_256(const GemmArgs& g, bool colsum, unsigned mask, dim3 grid, int tm, int tn, hipStream_t st) {
   const bool drop = g.drop.on();
+  if (g.x3_kt > 0) {                                      // split-bf16 products: the generic epilogue with the virtual-K-tile operand map
+    if (colsum) return drop ? launch_nt_256<true, true, kEpiGeneric, true>(g, grid, tm, tn, st) : launch_nt_256<false, true, kEpiGeneric, true>(g, grid, tm, tn, st);
+    return drop ? launch_nt_256<true, false, kEpiGeneric, true>(g, grid, tm, tn, st) : launch_nt_256<false, false, kEpiGeneric, true>(g, grid, tm, tn, st);
+  }
   static const bool generic_only = getenv("ADT_GEMM_GENERIC") != nullptr;
   if (!generic_only) {
 #define ADT_NT256_CASE(D, C, MK) if (drop == D && colsum == C && mask == (MK)) return launch_nt_256<D, C, (MK)>(g, grid, tm, tn, st);
@@ -1851,7 +1889,8 @@ static int set_big_lds_once() {      // the persistent kernels use the CU's whol
   int dev = 0;
   ADT_HIP_TRY(hipGetDevice(&dev));
   if (done_for == dev) return ADT_OK;
-  ADT_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_tn_256_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, kBigLds));
+  ADT_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_tn_256_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, kBigLds));
+  ADT_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_tn_256_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, kBigLds));
   done_for = dev;
   return ADT_OK;
 }
@@ -1860,7 +1899,7 @@ static int set_big_lds_once() {      // the persistent kernels use the CU's whol
 static bool vector_epilogue_ok(const GemmArgs& g, const adt_gemm_epilogue& e) {
   auto ok = [](const void* p, long ld, int elem) { return !p || (aligned16(p) && (ld * elem) % 16 == 0); };
   return (g.N % 8) == 0 && ok(g.C, g.ldc, e.out_fp32 ? 4 : 2) && ok(e.bias, 4, 4) && ok(e.residual, e.ld_res, 4) &&
-         ok(e.pre_act_out, e.ld_pre_act, 2) && ok(e.gelu_grad_of, e.ld_gelu_grad, 2) && ok(e.aux_bf16_out, e.ld_aux, 2);
+         ok(e.pre_act_out, e.ld_pre_act, e.side_fp32 ? 4 : 2) && ok(e.gelu_grad_of, e.ld_gelu_grad, e.side_fp32 ? 4 : 2) && ok(e.aux_bf16_out, e.ld_aux, 2);
 }
 
 // 256^2 tile: when there are at least two blocks per CU of it and the K loop is long enough to amortise its prologue.
@@ -1931,14 +1970,17 @@ extern "C" size_t adt_gemm_colsum_workspace_bytes(int64_t M, int64_t N) {
   return fused > alone ? fused : alone;
 }
 
-extern "C" int adt_gemm_bf16(int32_t trans, int64_t M, int64_t N, int64_t K, const void* A, int64_t lda,
-                             const void* B, int64_t ldb, void* C, int64_t ldc, const adt_gemm_epilogue* ep,
-                             void* ws, size_t ws_bytes, void* stream) {
+// x3_plane > 0 (adt_gemm_bf16x3): A / B are [hi | lo] plane pairs, K is the VIRTUAL depth 3 * x3_plane, a_lo / b_lo the element offset of
+// the lo plane from the hi plane; only the persistent kernels know that operand map, every other path is refused.
+static int gemm_bf16_impl(int32_t trans, int64_t M, int64_t N, int64_t K, const void* A, int64_t lda,
+                          const void* B, int64_t ldb, void* C, int64_t ldc, const adt_gemm_epilogue* ep,
+                          void* ws, size_t ws_bytes, void* stream, int64_t x3_plane, int64_t a_lo, int64_t b_lo) {
   using namespace adt;
   if (!A || !B || !C) return set_error(ADT_EINVAL, "adt_gemm_bf16: null pointer");
   if (M < 0 || N < 0 || K < 0) return set_error(ADT_EINVAL, "adt_gemm_bf16: negative size");
   if (M >= (1ll << 31) || N >= (1ll << 31) || K >= (1ll << 31)) return set_error(ADT_ESHAPE, "adt_gemm_bf16: dimension >= 2^31");
-  const int64_t a_cols = trans ? M : K, b_cols = trans ? N : K;
+  if (ep && ep->side_fp32 && x3_plane == 0) return set_error(ADT_EINVAL, "adt_gemm_bf16: side_fp32 belongs to adt_gemm_bf16x3");
+  const int64_t a_cols = x3_plane ? (trans ? M : x3_plane) : (trans ? M : K), b_cols = x3_plane ? (trans ? N : x3_plane) : (trans ? N : K);
   if (lda < a_cols || ldb < b_cols || ldc < N) return set_error(ADT_EINVAL, "adt_gemm_bf16: leading dimension too small");
   if ((a_cols & 7) || (b_cols & 7) || (lda & 7) || (ldb & 7) || !aligned16(A) || !aligned16(B))
     return set_error(ADT_ESHAPE, "adt_gemm_bf16: operand rows must be 16-byte aligned multiples of 8 elements");
@@ -1947,7 +1989,7 @@ extern "C" int adt_gemm_bf16(int32_t trans, int64_t M, int64_t N, int64_t K, con
   // and the register-staged fallback is several times slower at K ~ 50 000.  Take the first floor(K / 64) * 64 rows on the fast
   // path and add the last < 64 rows with the fallback kernel (C is both its residual and its output: every element is read and
   // written by one thread).  Same products, fp32 sums in a fixed order.
-  if (trans && K > kBK && (K % kBK) != 0 && ep && ep->out_fp32 && !ep->bias && !ep->residual && !ep->act && !ep->pre_act_out && !ep->gelu_grad_of &&
+  if (!x3_plane && trans && K > kBK && (K % kBK) != 0 && ep && ep->out_fp32 && !ep->bias && !ep->residual && !ep->act && !ep->pre_act_out && !ep->gelu_grad_of &&
       !ep->aux_bf16_out && !ep->colsum_out && ep->drop.p <= 0.f) {
     const int64_t k0 = K / kBK * kBK;
     if (int rc = adt_gemm_bf16(1, M, N, k0, A, lda, B, ldb, C, ldc, ep, ws, ws_bytes, stream)) return rc;
@@ -1965,6 +2007,7 @@ extern "C" int adt_gemm_bf16(int32_t trans, int64_t M, int64_t N, int64_t K, con
   g.ep = e;
   g.drop = make_drop(e.drop.p, e.drop.key);
   g.drop_key2 = mix32(g.drop.key);
+  g.x3_kt = static_cast<int>(x3_plane / kBK); g.x3_a_lo = a_lo; g.x3_b_lo = b_lo;
   const int k_tiles = static_cast<int>((K + kBK - 1) / kBK);
   int splits = 1;
   hipStream_t st = static_cast<hipStream_t>(stream);
@@ -2001,7 +2044,8 @@ extern "C" int adt_gemm_bf16(int32_t trans, int64_t M, int64_t N, int64_t K, con
       for (int x = 0; x < 8; ++x)        // per slice: one ticket per work item + the ending ticket of each of its workgroups
         g.sched_total[x] = static_cast<unsigned>(items / 8 + (x < items % 8 ? 1 : 0)) + g1.x / 8 + (static_cast<unsigned>(x) < g1.x % 8 ? 1u : 0u);
       if (int rc = sched_counters(stream, &g.sched)) return rc;
-      hipLaunchKernelGGL(gemm_tn_256_kernel, g1, dim3(kBigThreads), kBigLds, st, g, tm, tn, sb);
+      if (g.x3_kt > 0) hipLaunchKernelGGL(gemm_tn_256_kernel<true>, g1, dim3(kBigThreads), kBigLds, st, g, tm, tn, sb);
+      else hipLaunchKernelGGL(gemm_tn_256_kernel<false>, g1, dim3(kBigThreads), kBigLds, st, g, tm, tn, sb);
       if (sb > 1) {
         const long mn = static_cast<long>(M) * N;
         hipLaunchKernelGGL(reduce_slabs_kernel, dim3(static_cast<unsigned>((mn / 4 + 255) / 256)), dim3(256), 0, st,
@@ -2011,6 +2055,8 @@ extern "C" int adt_gemm_bf16(int32_t trans, int64_t M, int64_t N, int64_t K, con
       return ADT_OK;
     }
   }
+  if (x3_plane && (trans || !(persistent_ok && use_big_tile(M, N, K) && vector_epilogue_ok(g, e))))
+    return set_error(ADT_ESHAPE, "adt_gemm_bf16x3: this shape does not take a persistent kernel (ask adt_gemm_bf16x3_supported; use adt_gemm_f32)");
   if (trans) {
     int n_cu = 0;
     if (int rc = device_cu_count(&n_cu)) return rc;
@@ -2141,6 +2187,38 @@ extern "C" int adt_gemm_bf16(int32_t trans, int64_t M, int64_t N, int64_t K, con
   if (e.colsum_out && !colsum_done)                  // the smaller tilings leave the sums to the stand-alone kernel
     return adt_colsum_bf16(C, ldc, M, N, e.colsum_out, ws, ws_bytes, stream);
   return ADT_OK;
+}
+
+extern "C" int adt_gemm_bf16(int32_t trans, int64_t M, int64_t N, int64_t K, const void* A, int64_t lda,
+                             const void* B, int64_t ldb, void* C, int64_t ldc, const adt_gemm_epilogue* ep,
+                             void* ws, size_t ws_bytes, void* stream) {
+  return gemm_bf16_impl(trans, M, N, K, A, lda, B, ldb, C, ldc, ep, ws, ws_bytes, stream, 0, 0, 0);
+}
+
+// Does (trans, M, N, K) -- K the depth of ONE plane -- take a persistent kernel, i.e. can adt_gemm_bf16x3 run it?
+extern "C" int32_t adt_gemm_bf16x3_supported(int32_t trans, int64_t M, int64_t N, int64_t K) {
+  using namespace adt;
+  if (M < 8 || N < 8 || K < kBK || (K % kBK) != 0 || (N % 8) != 0 || (M % 8) != 0 || 3 * K >= (1ll << 31)) return 0;
+  if (!trans) return use_big_tile(M, N, 3 * K) ? 1 : 0;
+  int n_cu = 256, per = 0;
+  (void)device_cu_count(&n_cu);
+  return plan_tn_big(M, N, 3 * K, n_cu, true, &per) >= 1 ? 1 : 0;
+}
+extern "C" size_t adt_gemm_bf16x3_workspace_bytes(int32_t trans, int64_t M, int64_t N, int64_t K) {
+  return adt_gemm_workspace_bytes(trans, M, N, 3 * K);
+}
+extern "C" int adt_gemm_bf16x3(int32_t trans, int64_t M, int64_t N, int64_t K, const void* A2, int64_t lda, int64_t a_lo,
+                               const void* B2, int64_t ldb, int64_t b_lo, float* C, int64_t ldc, const adt_gemm_epilogue* ep,
+                               void* ws, size_t ws_bytes, void* stream) {
+  using namespace adt;
+  if (K <= 0 || (K % kBK) != 0) return set_error(ADT_ESHAPE, "adt_gemm_bf16x3: K must be a positive multiple of 64");
+  if (!ep || !ep->out_fp32 || ep->aux_bf16_out || ep->colsum_out || ep->res_ln_mean)
+    return set_error(ADT_EINVAL, "adt_gemm_bf16x3: fp32 output only, no bf16 side output, column sums or rebuilt-LayerNorm residual");
+  if (a_lo <= 0 || b_lo <= 0 || (a_lo & 7) || (b_lo & 7)) return set_error(ADT_EINVAL, "adt_gemm_bf16x3: plane offsets must be positive multiples of 8 elements");
+  const int64_t a_w = trans ? M : K, b_w = trans ? N : K;
+  if (a_lo < a_w || b_lo < b_w || lda < a_lo + a_w || ldb < b_lo + b_w) return set_error(ADT_EINVAL, "adt_gemm_bf16x3: planes overlap or exceed the row stride");
+  if (!adt_gemm_bf16x3_supported(trans, M, N, K)) return set_error(ADT_ESHAPE, "adt_gemm_bf16x3: shape not supported (adt_gemm_bf16x3_supported)");
+  return gemm_bf16_impl(trans, M, N, 3 * K, A2, lda, B2, ldb, C, ldc, ep, ws, ws_bytes, stream, K, a_lo, b_lo);
 }
 
 extern "C" int adt_ln_gemm_bf16(int64_t M, int64_t N, int64_t K, const float* y, int64_t ldy, const float* gamma, const float* beta, float eps,

@@ -1073,3 +1073,75 @@ extern "C" int adt_colsum_f32(const float* x, int64_t ld, int64_t M, int64_t N, 
   ADT_HIP_TRY(hipGetLastError());
   return ADT_OK;
 }
+
+// ----------------------------------------------------------------------------------------------- split planes for adt_gemm_bf16x3
+// fp32 matrix x [rows, cols] -> bf16 planes [hi | lo] side by side: out[r, c] = bf16(x[r, c]), out[r, lo_off + c] = bf16(x[r, c] - hi)
+// (the split of split2 above, taken ONCE per tensor instead of once per staged tile), so that the persistent bf16 kernels of gemm.hip
+// can take the three products lo x hi + hi x lo + hi x hi as one GEMM over 3 K virtual K-tiles.  transpose: out is [cols, *] with
+// out[c, r] / out[c, lo_off + r] (the W^T operand of the data gradients).
+namespace adt {
+__global__ __launch_bounds__(256) void split_planes_kernel(const float* __restrict__ x, long ldx, long rows, int cols8, unsigned short* __restrict__ out, long ldo, long lo_off) {
+  const long i = static_cast<long>(blockIdx.x) * 256 + threadIdx.x;
+  if (i >= rows * cols8) return;
+  const long r = i / cols8;
+  const int c = static_cast<int>(i - r * cols8) * 8;
+  const float4 v0 = *reinterpret_cast<const float4*>(x + r * ldx + c), v1 = *reinterpret_cast<const float4*>(x + r * ldx + c + 4);
+  uint2 h0, l0, h1, l1;
+  split4(v0, h0, l0);
+  split4(v1, h1, l1);
+  *reinterpret_cast<uint4*>(out + r * ldo + c) = uint4{h0.x, h0.y, h1.x, h1.y};
+  *reinterpret_cast<uint4*>(out + r * ldo + lo_off + c) = uint4{l0.x, l0.y, l1.x, l1.y};
+}
+constexpr int kSpT = 64, kSpPitch = 72;      // 64 x 64 tile; LDS rows of 72 bf16 (144 B: 16-byte aligned pieces)
+__global__ __launch_bounds__(256) void split_planes_t_kernel(const float* __restrict__ x, long ldx, int rows, int cols, unsigned short* __restrict__ out, long ldo, long lo_off) {
+  __shared__ __attribute__((aligned(16))) unsigned short hiT[kSpT * kSpPitch], loT[kSpT * kSpPitch];
+  const int tid = threadIdx.x, r0 = blockIdx.y * kSpT, c0 = blockIdx.x * kSpT;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int r = (tid >> 4) + 16 * i, c = (tid & 15) * 4;
+    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (r0 + r < rows && c0 + c < cols) v = *reinterpret_cast<const float4*>(x + static_cast<long>(r0 + r) * ldx + c0 + c);      // cols % 4 == 0
+    uint2 h, l;
+    split4(v, h, l);
+    const unsigned hv[4] = {h.x & 0xffffu, h.x >> 16, h.y & 0xffffu, h.y >> 16}, lv[4] = {l.x & 0xffffu, l.x >> 16, l.y & 0xffffu, l.y >> 16};
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      hiT[(c + e) * kSpPitch + r] = static_cast<unsigned short>(hv[e]);
+      loT[(c + e) * kSpPitch + r] = static_cast<unsigned short>(lv[e]);
+    }
+  }
+  __syncthreads();
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    const int q = tid + 256 * i, c = q >> 3, r8 = (q & 7) * 8;           // out row c0 + c, source rows r0 + r8 .. + 7
+    if (c0 + c < cols && r0 + r8 < rows) {                               // rows % 8 == 0
+      *reinterpret_cast<uint4*>(out + static_cast<long>(c0 + c) * ldo + r0 + r8) = *reinterpret_cast<const uint4*>(hiT + c * kSpPitch + r8);
+      *reinterpret_cast<uint4*>(out + static_cast<long>(c0 + c) * ldo + lo_off + r0 + r8) = *reinterpret_cast<const uint4*>(loT + c * kSpPitch + r8);
+    }
+  }
+}
+}  // namespace adt
+
+extern "C" int adt_split_bf16x2(const float* x, int64_t ldx, int64_t rows, int64_t cols, void* planes, int64_t ldp, int64_t lo_off, int32_t transpose,
+                                void* stream) {
+  using namespace adt;
+  if (!x || !planes) return set_error(ADT_EINVAL, "adt_split_bf16x2: null pointer");
+  if (rows < 0 || cols < 0 || ldx < cols) return set_error(ADT_EINVAL, "adt_split_bf16x2: bad shape");
+  const int64_t w = transpose ? rows : cols;
+  if ((rows & 7) || (cols & 7) || (ldx & 3) || (ldp & 7) || (lo_off & 7) || lo_off < w || ldp < lo_off + w || (reinterpret_cast<uintptr_t>(x) & 15) ||
+      (reinterpret_cast<uintptr_t>(planes) & 15))
+    return set_error(ADT_ESHAPE, "adt_split_bf16x2: rows / cols multiples of 8, 16-byte aligned rows, lo plane behind the hi plane inside the row stride");
+  if (rows == 0 || cols == 0) return ADT_OK;
+  if (rows >= (1ll << 31) || cols >= (1ll << 31)) return set_error(ADT_ESHAPE, "adt_split_bf16x2: dimension >= 2^31");
+  if (!transpose) {
+    const long n = rows * (cols / 8);
+    hipLaunchKernelGGL(split_planes_kernel, dim3(static_cast<unsigned>((n + 255) / 256)), dim3(256), 0, ST(stream), x, static_cast<long>(ldx), static_cast<long>(rows),
+                       static_cast<int>(cols / 8), static_cast<unsigned short*>(planes), static_cast<long>(ldp), static_cast<long>(lo_off));
+  } else {
+    hipLaunchKernelGGL(split_planes_t_kernel, dim3(static_cast<unsigned>((cols + kSpT - 1) / kSpT), static_cast<unsigned>((rows + kSpT - 1) / kSpT)), dim3(256), 0,
+                       ST(stream), x, static_cast<long>(ldx), static_cast<int>(rows), static_cast<int>(cols), static_cast<unsigned short*>(planes), static_cast<long>(ldp),
+                       static_cast<long>(lo_off));
+  }
+  ADT_HIP_TRY(hipGetLastError());
+  return ADT_OK;
+}

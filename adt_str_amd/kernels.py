@@ -169,6 +169,87 @@ def set_f32_products(mode: str) -> None:
     f32_products = mode
 
 
+# ---- split-bf16 products on the persistent bf16 kernels (adt_gemm_bf16x3): operands as [hi | lo] bf16 plane pairs ------------------
+def split_planes(x: torch.Tensor, transpose: bool = False) -> torch.Tensor:
+    """fp32 ``x [rows, cols]`` -> bf16 ``[rows, 2 cols]`` = ``[bf16(x) | bf16(x - bf16(x))]`` (``transpose``: the planes of ``x.T``,
+    ``[cols, 2 rows]``) -- ``adt_split_bf16x2``."""
+    assert x.dtype == torch.float32 and x.dim() == 2 and x.stride(1) == 1
+    rows, cols = x.shape
+    w = rows if transpose else cols
+    out = torch.empty((cols if transpose else rows, 2 * w), dtype=torch.bfloat16, device=x.device)
+    _ffi.call("adt_split_bf16x2", _ffi.dptr(x), x.stride(0), rows, cols, _ffi.dptr(out), out.stride(0), w, int(transpose), _ffi.current_stream())
+    return out
+
+
+# Weights are split once per refresh by the engine (both orientations) and found again by address: ptr -> (tensor, version, rows, cols,
+# planes [rows, 2 cols], planes of W^T [cols, 2 rows]).  A GEMM operand that is a row / column slice of a registered weight takes a view.
+_x3_weights: dict = {}
+_x3_owner = None          # id of the engine whose weights are registered (network._Engine.refresh_weights)
+
+
+def x3_register_weights(tensors) -> None:
+    """(The registry keeps the tensors themselves: while an address is registered its storage cannot be handed to another tensor.)"""
+    _x3_weights.clear()
+    for w in tensors:
+        assert w.dtype == torch.float32 and w.dim() == 2 and w.is_contiguous()
+        _x3_weights[w.data_ptr()] = (w, w._version, w.shape[0], w.shape[1], split_planes(w), split_planes(w, transpose=True))
+
+
+def _x3_weight_planes(b: torch.Tensor, kn: bool):
+    """Planes for GEMM operand ``b`` if it lies inside a registered weight: (view, lo_off) of W's planes for ``b [N, K]`` (``kn=False``)
+    or of W^T's planes for ``b [K, N]`` read as ``[K, N]`` (``kn=True``); None otherwise."""
+    if not _x3_weights or b.dim() != 2 or b.stride(1) != 1:
+        return None
+    ptr = b.data_ptr()
+    for base, (w, ver, rows, cols, pw, pt) in _x3_weights.items():
+        if base <= ptr < base + rows * cols * 4:
+            if w._version != ver or b.stride(0) != cols:
+                return None
+            off = (ptr - base) // 4
+            r0, c0 = off // cols, off % cols
+            if r0 + b.shape[0] > rows or c0 + b.shape[1] > cols or (c0 & 7) or (r0 & 7):
+                return None
+            return (pt[c0:c0 + b.shape[1], r0:], rows) if kn else (pw[r0:r0 + b.shape[0], c0:], cols)
+    return None
+
+
+def _x3_activation_planes(x: torch.Tensor):
+    """``[hi | lo]`` planes of an fp32 activation, split once per tensor object and content version (an activation is typically the
+    operand of a forward or data-gradient product AND of a weight-gradient product)."""
+    c = getattr(x, "_adt_x3", None)
+    if c is not None and c[0] == x._version and c[1] == x.data_ptr():
+        return c[2], x.shape[1]
+    pl = split_planes(x)
+    try:
+        x._adt_x3 = (x._version, x.data_ptr(), pl)
+    except Exception:          # (a tensor subclass without a __dict__)
+        pass
+    return pl, x.shape[1]
+
+
+def _gemm_x3_fast(a, b, layout, M, N, K, out, ep) -> bool:
+    """Try the persistent-kernel form of the split-bf16 product; False when the shape does not take it (the caller then runs adt_gemm_f32)."""
+    lib = _ffi.load()
+    trans = layout == 3
+    if os.environ.get("ADT_X3_TILED") or not lib.adt_gemm_bf16x3_supported(int(trans), M, N, K):
+        return False
+    if (a.data_ptr() & 15) or (b.data_ptr() & 15) or (a.stride(0) & 3) or (b.stride(0) & 3) or (out.data_ptr() & 15) or (out.stride(0) & 3):
+        return False
+    a2, a_lo = _x3_activation_planes(a)
+    if layout == 2:
+        wp = _x3_weight_planes(b, True)
+        b2, b_lo = wp if wp is not None else (split_planes(b, transpose=True), b.shape[0])
+    else:
+        wp = _x3_weight_planes(b, False) if layout == 0 else None
+        b2, b_lo = wp if wp is not None else _x3_activation_planes(b)
+    ep.side_fp32 = 1
+    ws_bytes = lib.adt_gemm_bf16x3_workspace_bytes(int(trans), M, N, K) if trans else 0
+    ws = _workspace(ws_bytes, a.device) if ws_bytes else None
+    _ffi.call("adt_gemm_bf16x3", int(trans), M, N, K, _ffi.dptr(a2), a2.stride(0), a_lo, _ffi.dptr(b2), b2.stride(0), b_lo, _ffi.dptr(out), out.stride(0),
+              C.byref(ep), _ffi.dptr(ws) if ws is not None else None, ws_bytes, _ffi.current_stream())
+    return True
+
+
 def _gemm_f32(a, b, *, trans, b_kn, out, bias, residual, res_row_mod, act, pre_act_out, gelu_grad_of, alpha, drop,
               drop_after_residual, colsum_out, aux_out, mode=0):
     """fp32-operand GEMM (parity path).  Layout bits: 1 = a is [K, M], 2 = b is [K, N], 4 = split-bf16 products (``f32_products``)."""
@@ -202,6 +283,10 @@ def _gemm_f32(a, b, *, trans, b_kn, out, bias, residual, res_row_mod, act, pre_a
         assert gelu_grad_of.dtype == torch.float32 and gelu_grad_of.shape == (M, N)
         ep.gelu_grad_of, ep.ld_gelu_grad = _ffi.dptr(gelu_grad_of), gelu_grad_of.stride(0)
     if f32_products == "bf16x3":
+        if _gemm_x3_fast(a, b, layout, M, N, K, out, ep):          # large shapes: the persistent bf16 kernels over [hi | lo] planes
+            if colsum_out is not None:
+                colsum(out, out=colsum_out)
+            return out
         layout |= 4
     ws_bytes = _ffi.load().adt_gemm_f32_workspace_bytes(layout, M, N, K) if trans else 0      # (K splits pay for the weight gradients only)
     ws = _workspace(ws_bytes, a.device) if ws_bytes else None

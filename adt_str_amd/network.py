@@ -212,6 +212,14 @@ class _Engine:
                 if not l.weight.data.is_contiguous():
                     raise RuntimeError(f"{l.name}: the fp32 path reads the master weight in place; it must be contiguous")
                 l.w16, l.wt16 = l.weight.data, None
+            if self.products == "bf16x3":
+                # the split-bf16 arm's large products run on the persistent bf16 kernels over [hi | lo] planes: every weight (and its
+                # transpose, the data gradients' operand) is split once per parameter version, not per GEMM
+                ver = tuple(p._version for p in self.named.values()) + tuple(l.weight.data.data_ptr() for l in self.lins.values())
+                if force or ver != self._versions or K._x3_owner != id(self):
+                    K.x3_register_weights([l.weight.data for l in self.lins.values()])
+                    K._x3_owner = id(self)
+                    self._versions = ver
             return
         ver = tuple(p._version for p in self.named.values()) + (str(next(iter(self.named.values())).device),)
         if force or ver != self._versions:

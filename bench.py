@@ -494,7 +494,9 @@ def parity_arm(dev, args, bf16_value, precision, steps=3, warmup=1):
     what = ("the same step with fp32 operands everywhere (v_mfma_f32_32x32x2_f32): the exact parity arm, logits within 1e-3 rel of the CPU reference "
             "(measured ~1e-6); frac against the f32-input MFMA peak") if precision == "fp32" else \
            ("the same step with fp32 activations and every product as three bf16 MFMAs on hi / lo splits of the fp32 operands (bf16x3): the fast "
-            "parity arm, logits within 1e-3 rel of the CPU reference (asserted at 1e-4, measured 9e-6 at config[3], in tests/test_precision_gpu.py); frac against a third of the "
+            "parity arm, logits within 1e-3 rel of the CPU reference (asserted at 1e-4, measured 9e-6 at config[3], in tests/test_precision_gpu.py); the large "
+            "linear products run on the persistent bf16 GEMM kernels over [hi | lo] planes split once per tensor (adt_gemm_bf16x3: one GEMM over three "
+            "segments of K), the attention products and the small shapes on the tiled split kernels of csrc/precise.hip; frac against a third of the "
             "dense bf16 MFMA peak")
     return {"value": value, "unit": "clips/s", "ms_per_step": dt / steps * 1e3, "steps": steps, "warmup": warmup, "dtype": "f32" if precision == "fp32" else "bf16x3",
             "precision": precision, "final_loss": float(wl["state"]["loss"].item()),

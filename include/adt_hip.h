@@ -40,7 +40,7 @@ extern "C" {
  * backward entry points regenerate them from the same (p, key).  p == 0 or a null pointer: off. */
 typedef struct adt_dropout { float p; uint32_t key; } adt_dropout;
 
-/* ABI version (15): bumped whenever a signature below changes or entries are added. */
+/* ABI version (18): bumped whenever a signature below changes or entries are added. */
 int adt_version(void);
 
 /* Message of the last failing call on this thread ("" if none). */
@@ -207,6 +207,9 @@ typedef struct adt_gemm_epilogue {
   const float* res_ln_rstd;
   const float* res_ln_gamma;
   const float* res_ln_beta;
+  /* adt_gemm_bf16x3 only: gelu_grad_of / pre_act_out are fp32 arrays (ld_* in fp32 elements) -- the fp32-activation parity arm keeps its
+   * saved GELU factor in fp32.  adt_gemm_bf16 rejects it unless the output is fp32 and the shape takes a persistent kernel. */
+  int32_t      side_fp32;
 } adt_gemm_epilogue;
 
 size_t adt_gemm_workspace_bytes(int32_t trans, int64_t M, int64_t N, int64_t K);
@@ -429,6 +432,26 @@ int adt_cross_entropy_f32(const float* logits, int64_t ld, const int64_t* labels
                           float* loss, float* dlogits, int64_t ldd, void* ws, size_t ws_bytes, void* stream);
 int adt_embed_bwd_operands_f32(const int64_t* tokens, const float* dy, float scale, float* onehot, int64_t ld_onehot, float* dy_scaled,
                                int64_t n_rows, int64_t D, int64_t vocab, const adt_dropout* drop, void* stream);
+
+/* Split-bf16 products on the persistent bf16 kernels (the fast form of the "bf16x3" parity arm, round 6): the reference's fp32 CPU
+ * arithmetic of every nn.Linear (model.py:111,118-127,157,159-168,224) within ~1e-5 relative per product, at the speed of the bf16
+ * matrix pipe.  An fp32 operand is split ONCE per tensor into two bf16 planes hi = bf16(x), lo = bf16(x - hi), stored side by side in
+ * one row-major buffer ([rows, ..hi.., ..lo..]; adt_split_bf16x2: planes[r, c] and planes[r, lo_off + c]; transpose != 0 writes the
+ * planes of x^T: planes[c, r] and planes[c, lo_off + r]), and
+ *   adt_gemm_bf16x3(trans = 0):  C[M, N] = A[M, K] . B[N, K]^T     A2 = planes of A (K wide), B2 = planes of B (K wide)
+ *   adt_gemm_bf16x3(trans = 1):  C[M, N] = A[K, M]^T . B[K, N]     A2 = planes of A (M wide), B2 = planes of B (N wide)
+ * runs a_lo b_hi + a_hi b_lo + a_hi b_hi as ONE bf16 GEMM over three segments of K (small terms first), fp32 accumulate, fp32 output,
+ * the epilogue menu of adt_gemm_bf16 (ep->out_fp32 must be set; side_fp32 makes gelu_grad_of / pre_act_out fp32 arrays).
+ * a_lo / b_lo: element offset of the lo plane from the hi plane (>= the plane width, a multiple of 8) -- a column slice of a weight's
+ * planes keeps the full plane distance.  Only shapes that take a persistent 256 x 256 kernel (adt_gemm_bf16x3_supported; K a multiple
+ * of 64): everything else ADT_ESHAPE -- call adt_gemm_f32 with layout bit 4 there.  ws as adt_gemm_bf16x3_workspace_bytes (trans = 1). */
+int adt_split_bf16x2(const float* x, int64_t ldx, int64_t rows, int64_t cols, void* planes, int64_t ldp, int64_t lo_off, int32_t transpose,
+                     void* stream);
+int32_t adt_gemm_bf16x3_supported(int32_t trans, int64_t M, int64_t N, int64_t K);
+size_t adt_gemm_bf16x3_workspace_bytes(int32_t trans, int64_t M, int64_t N, int64_t K);
+int adt_gemm_bf16x3(int32_t trans, int64_t M, int64_t N, int64_t K, const void* A2, int64_t lda, int64_t a_lo,
+                    const void* B2, int64_t ldb, int64_t b_lo, float* C, int64_t ldc, const adt_gemm_epilogue* ep,
+                    void* ws, size_t ws_bytes, void* stream);
 
 /* ---------------------------------------------------------------------------
  * Parameter plumbing for the bf16 compute path: fp32 master weight [rows, cols]

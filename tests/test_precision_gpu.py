@@ -416,3 +416,97 @@ def test_reference_native_operating_point_both_precisions():
             assert err < 6e-2
         del model, eng, out, again
         torch.cuda.empty_cache()
+
+
+# ---- the split-bf16 arm's large products on the persistent bf16 kernels (adt_split_bf16x2 / adt_gemm_bf16x3, round 6) -----------------
+def test_split_planes_are_the_two_bf16_terms_of_x():
+    from adt_str_amd import kernels as K
+    x = rnd((200, 136), 3) * torch.logspace(-3, 3, 136, device=DEV)
+    pl = K.split_planes(x)
+    hi, lo = pl[:, :136].float(), pl[:, 136:].float()
+    assert torch.equal(pl[:, :136], x.bfloat16()) and torch.equal(pl[:, 136:], (x - x.bfloat16().float()).bfloat16())
+    assert float(((hi + lo) - x).abs().max() / x.abs().max()) < 2.0 ** -16
+    pt = K.split_planes(x, transpose=True)                              # the planes of x^T: [cols, 2 rows]
+    assert pt.shape == (136, 400) and torch.equal(pt[:, :200], pl[:, :136].T) and torch.equal(pt[:, 200:], pl[:, 136:].T)
+    xs = rnd((72, 256), 4)[:, 64:128]                                   # a column slice: row stride != cols
+    assert torch.equal(K.split_planes(xs)[:, :64], xs.bfloat16())
+
+
+@pytest.mark.parametrize("M,N,Kd", [(8192, 2304, 768), (63104, 768, 768), (32768, 3072, 128)])
+def test_gemm_bf16x3_on_the_persistent_kernels(M, N, Kd):
+    """NT, NN (the data gradient against W) and TN (the weight gradient) through K.gemm on the bf16x3 arm: shapes the persistent kernels
+    take must run there (adt_gemm_bf16x3_supported), agree with an fp64 product to the arm's tolerance and with the tiled split kernel."""
+    from adt_str_amd import _ffi, kernels as K
+    K.set_f32_products("bf16x3")
+    lib = _ffi.load()
+    a, b = rnd((M, Kd), 1), rnd((N, Kd), 2, 0.05)
+    ref = a.double() @ b.double().T
+    assert lib.adt_gemm_bf16x3_supported(0, M, N, Kd) == 1 and lib.adt_gemm_bf16x3_supported(1, Kd, N, M) in (0, 1)
+    for kw, A, B in (({}, a, b), (dict(b_kn=True), a, b.T.contiguous())):
+        got = K.gemm(A, B, **kw)
+        os.environ["ADT_X3_TILED"] = "1"
+        try:
+            tiled = K.gemm(A, B, **kw)
+        finally:
+            os.environ.pop("ADT_X3_TILED")
+        assert float((got.double() - ref).abs().max() / ref.abs().max()) < KERNEL_REL["bf16x3"]
+        assert float((got - tiled).abs().max() / ref.abs().max()) < 1e-5
+    b2 = rnd((M, N), 5, 0.05)                                            # weight gradient [Kd, N] = a^T b2 over M rows
+    gw = K.gemm(a, b2, trans=True)
+    refw = a.double().T @ b2.double()
+    assert float((gw.double() - refw).abs().max() / refw.abs().max()) < KERNEL_REL["bf16x3"]
+
+
+def test_gemm_bf16x3_epilogue_with_fp32_side_arrays_and_weight_registry():
+    from adt_str_amd import _ffi, kernels as K
+    K.set_f32_products("bf16x3")
+    M, N, Kd = 16384, 3072, 768
+    assert _ffi.load().adt_gemm_bf16x3_supported(0, M, N, Kd) == 1
+    a, w, bias = rnd((M, Kd), 1), rnd((N, Kd), 2, 0.05), rnd((N,), 3)
+    site = K.drop_site(0.1, 3, 7)
+
+    def ffn1():
+        u = torch.empty((M, N), device=DEV)
+        return K.gemm(a, w, bias=bias, act=1, act_grad_out=u, drop=site), u
+    h, u = ffn1()
+    os.environ["ADT_X3_TILED"] = "1"
+    try:
+        ht, ut = ffn1()
+        dy = rnd((M, Kd), 6)
+        dut = K.gemm(dy, w, act_grad=ut)
+    finally:
+        os.environ.pop("ADT_X3_TILED")
+    assert float((h - ht).abs().max()) < 1e-5 * float(ht.abs().max()) and float((u - ut).abs().max()) < 1e-5
+    assert bool(((h == 0) == (ht == 0))[ht.abs() > 1e-6].all())                      # the same dropout mask
+    du = K.gemm(dy, w, act_grad=u)                                                   # the backward multiplies by the fp32 factor as stored
+    assert float((du - dut).abs().max()) < 1e-5 * float(dut.abs().max())
+    # a registered weight is found by address, row and column slices included, and gives the same bits as splitting the operand on the fly
+    plain = K.gemm(a, w[768:1536])
+    plain_kn = K.gemm(rnd((M, 768), 8), w[768:1536], b_kn=True)
+    K.x3_register_weights([w])
+    try:
+        assert K._x3_weight_planes(w[768:1536], False) is not None and K._x3_weight_planes(w[768:1536], True) is not None
+        assert torch.equal(K.gemm(a, w[768:1536]), plain) and torch.equal(K.gemm(rnd((M, 768), 8), w[768:1536], b_kn=True), plain_kn)
+        w.mul_(1.0)                                                                   # an in-place change invalidates the registered planes
+        assert K._x3_weight_planes(w, False) is None
+    finally:
+        K._x3_weights.clear()
+
+
+def test_gemm_bf16x3_refuses_what_it_cannot_run():
+    from adt_str_amd import _ffi, kernels as K
+    lib = _ffi.load()
+    assert lib.adt_gemm_bf16x3_supported(0, 36, 1400, 768) == 0 and lib.adt_gemm_bf16x3_supported(0, 63104, 768, 100) == 0
+    a2, b2 = K.split_planes(rnd((64, 768), 1)), K.split_planes(rnd((1400, 768), 2))
+    out = torch.empty((64, 1400), device=DEV)
+    ep = _ffi.GemmEpilogue()
+    ep.alpha, ep.out_fp32 = 1.0, 1
+    with pytest.raises(_ffi.AdtError) as e:
+        _ffi.call("adt_gemm_bf16x3", 0, 64, 1400, 768, _ffi.dptr(a2), a2.stride(0), 768, _ffi.dptr(b2), b2.stride(0), 768, _ffi.dptr(out), out.stride(0),
+                  __import__("ctypes").byref(ep), None, 0, _ffi.current_stream())
+    assert "not supported" in str(e.value)
+    ep.side_fp32 = 1                                                     # fp32 side arrays belong to adt_gemm_bf16x3
+    x, wt = rnd((64, 768), 1).bfloat16(), rnd((1400, 768), 2).bfloat16()
+    with pytest.raises(_ffi.AdtError):
+        _ffi.call("adt_gemm_bf16", 0, 64, 1400, 768, _ffi.dptr(x), 768, _ffi.dptr(wt), 768, _ffi.dptr(out), out.stride(0), __import__("ctypes").byref(ep), None, 0,
+                  _ffi.current_stream())
