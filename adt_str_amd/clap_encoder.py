@@ -163,6 +163,7 @@ class HtsatEncoder:
                     L["wo_pk"] = pack_rowblock_weights(1, L["wo"].float()).to(self.dev)
                 if C in ROWBLOCK_PARTIAL:
                     L["fc1_pk"] = pack_rowblock_weights(0, L["w1"].float()).to(self.dev)
+                    L["mlp_pk"] = pack_rowblock_weights(2, L["w1"].float(), L["w2"].float()).to(self.dev)
                 if C == 96 and nh == 4:                    # the whole attention half in one launch
                     L["attn_pk"], L["attn_qkvb"] = (t.to(self.dev) for t in pack_attn_block_weights(L["wqkv"].float(), L["bqkv"], L["wo"].float(), nh))
                 if C in ROWBLOCK_CHANNELS:
@@ -250,7 +251,7 @@ class HtsatEncoder:
                               1.0 / math.sqrt(24.0), st)
                     rowblock(2, x, L["mlp_pk"], C // 8, L["b1"], ln=L["ln2"], eps=self.eps, bias2=L["b2"])
                     continue
-                if fused and "mlp_pk" in L:
+                if fused and "mlp_pk" in L and "fc1_pk" not in L:
                     # bandwidth-bound stages: three launches per layer, the residual stream is read and written once per half
                     qkv = torch.empty((x.shape[0], 3 * C), dtype=BF16, device=self.dev)
                     rowblock(0, x, L["qkv_pk"], 3 * C // 32, L["bqkv"], ln=L["ln1"], eps=self.eps, out16=qkv)
@@ -271,6 +272,12 @@ class HtsatEncoder:
                     _ffi.call("adt_window_attn_fwd", _ffi.dptr(qkv), qkv.stride(0), _ffi.dptr(ctx), C, _ffi.dptr(L["bias"]), L["n_bias"], B, R, C,
                               nh, L["shift"], 1.0 / math.sqrt(24.0), st)
                     rowblock(1, x, L["wo_pk"], C // 32, L["bo"], a16=ctx)
+                    if os.environ.get("ADT_HTSAT_MLP384", "0") == "1":
+                        # the whole MLP in one launch (round 6: one workgroup per CU on 512 registers): the hidden activation never exists --
+                        # 806 MB less HBM traffic per layer at 512 clips and 439 vs 494 us alone, but a tie inside the tower (12.67 vs 12.65 ms,
+                        # profiles/r06/clap_mlp384_ab.txt: a lone wave per SIMD is bound by LDS fragment reads where the two launches are bound by HBM)
+                        rowblock(2, x, L["mlp_pk"], C // 8, L["b1"], ln=L["ln2"], eps=self.eps, bias2=L["b2"])
+                        continue
                     h = torch.empty((x.shape[0], 4 * C), dtype=BF16, device=self.dev)
                     rowblock(4, x, L["fc1_pk"], 4 * C // 32, L["b1"], ln=L["ln2"], eps=self.eps, out16=h)
                     K.gemm(h, L["w2"], bias=L["b2"], residual=x, out=x)

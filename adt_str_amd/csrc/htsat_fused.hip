@@ -71,6 +71,15 @@ __device__ __forceinline__ void zero_acc(f32x16& x) {
 #pragma unroll
   for (int i = 0; i < 16; ++i) x[i] = 0.f;
 }
+// compile-time loop: body(std::integral_constant<int, I>{}) for I = I0 .. N - 1 (a `#pragma unroll` over 48 large iterations is refused by
+// the unroller's size limit, and a rolled loop indexes the register arrays dynamically)
+template <int I, int N, class F>
+__device__ __forceinline__ void static_for(F&& f) {
+  if constexpr (I < N) {
+    f(std::integral_constant<int, I>{});
+    static_for<I + 1, N>(f);
+  }
+}
 template <int N> __device__ __forceinline__ void wait_vm() { asm volatile("s_waitcnt vmcnt(%0)" :: "n"(N) : "memory"); }
 template <int N> __device__ __forceinline__ void wait_lgkm() { asm volatile("s_waitcnt lgkmcnt(%0)" :: "n"(N) : "memory"); }
 
@@ -243,16 +252,35 @@ __global__ __launch_bounds__(kRbThreads, 2) void htsat_rowblock_kernel(RbArgs a)
       if (MODE == kRbLnGemm || MODE == kRbLnGemmGelu) {
         // unit 32n + 8g + 4h + e of the lane's token -> bf16, four consecutive columns per group (the two halves of a wave interleave to
         // whole 16-byte pieces of the row)
-        if (row_ok) {
-          unsigned short* op = a.out16 + tok * a.ldo + 32 * n + 4 * h;
+        // The natural store is 4 x 8 bytes per lane (lanes r and r + 32 share a row: 16 x 8-byte pieces per row and tile), and with 32 rows per
+        // wave-instruction that is 64 partial-line requests each: the L2's request rate, not its bandwidth, bounded these launches (without
+        // the stores: 274 -> 162 us for LN -> fc1 -> GELU at C = 384, profiles/r06/clap_rowblock_stores_ab.txt).  One v_permlane32_swap per dword
+        // and pair of groups (g, g + 1) hands the upper half's group g to the lower lanes and the lower half's group g + 1 to the upper
+        // lanes (as attn_common.h: store_transposed): 2 x 16-byte stores of the same bytes to the same addresses, a quarter of the requests.
+        {
+          float z[16];
 #pragma unroll
           for (int g = 0; g < 4; ++g) {
             f32x2 z0 = {acc[4 * g] + bv[g][0], acc[4 * g + 1] + bv[g][1]}, z1 = {acc[4 * g + 2] + bv[g][2], acc[4 * g + 3] + bv[g][3]};
+#ifndef ADT_RB_NOGELU
             if (MODE == kRbLnGemmGelu) gelu_bf16_4(z0, z1, z0, z1);
-            uint2 v;
-            v.x = pack2_f(z0[0], z0[1]);
-            v.y = pack2_f(z1[0], z1[1]);
-            *reinterpret_cast<uint2*>(op + 8 * g) = v;
+#endif
+            z[4 * g] = z0[0]; z[4 * g + 1] = z0[1]; z[4 * g + 2] = z1[0]; z[4 * g + 3] = z1[1];
+          }
+          unsigned short* op = a.out16 + tok * a.ldo + 32 * n + 8 * h;
+#pragma unroll
+          for (int g = 0; g < 4; g += 2) {
+            const unsigned ax = pack2_f(z[4 * g], z[4 * g + 1]), ay = pack2_f(z[4 * g + 2], z[4 * g + 3]);
+            const unsigned bx = pack2_f(z[4 * g + 4], z[4 * g + 5]), by = pack2_f(z[4 * g + 6], z[4 * g + 7]);
+            const auto rx = __builtin_amdgcn_permlane32_swap(ax, bx, false, false);
+            const auto ry = __builtin_amdgcn_permlane32_swap(ay, by, false, false);
+            // lower lanes: [own g | upper's g] = units 8g .. 8g+7; upper lanes: [lower's g+1 | own g+1] = units 8g+8 .. 8g+15
+#ifdef ADT_RB_NOSTORE      // timing experiment: the outputs are formed and (all but a never-true case) not stored
+            if (row_ok && acc[0] == 123456.789f)
+#else
+            if (row_ok)
+#endif
+              *reinterpret_cast<uint4*>(op + 8 * g) = make_uint4(rx[0], ry[0], rx[1], ry[1]);
           }
         }
       } else if (MODE == kRbMergeGemm) {
@@ -334,15 +362,18 @@ __global__ __launch_bounds__(kRbThreads, 2) void htsat_rowblock_kernel(RbArgs a)
 // The weight stream is packed in exactly this order, one step after the
 // other -- [fc1(k) fragment s, fc2(k-2) fragment (s2, ct)] interleaved, zero fragments where k or k - 2 is out of range -- so the
 // LDS-DMA ring protocol is the one above; fragments go through a ring of six registers refilled as each MFMA issues.
-template <int C, int SPC>                    // SPC: steps per LDS-DMA chunk
-__global__ __launch_bounds__(kRbThreads, 2) void htsat_mlp_kernel(RbArgs a) {
+// C = 384 (round 6): kOcc = 1 -- ONE workgroup per CU, a wave alone on its SIMD with the whole 512-register file (the token's 96 operand
+// registers + 192 fc2 accumulators do not fit 256) and a 3 x 48 KiB weight ring; what it buys is bytes: the hidden activation (403 MB
+// written by LN -> fc1 -> GELU and read back by the fc2 GEMM per third-stage layer at 512 clips) never exists.
+template <int C, int SPC, int kOcc = 2>      // SPC: steps per LDS-DMA chunk
+__global__ __launch_bounds__(kRbThreads, kOcc) void htsat_mlp_kernel(RbArgs a) {
   constexpr int KS = C / 16, CT = C / 32, NM = 2 * KS;         // MFMAs (= fragments, KiB) per step
   constexpr int kChunkKb = SPC * NM;
   constexpr int kChunkBytes = kChunkKb * 1024;
   constexpr int kRing = 3;
   constexpr int kDepth = 2;
   constexpr int IPW = kChunkKb / kRbWaves;
-  static_assert(kChunkKb % kRbWaves == 0 && kRing * kChunkBytes <= 76 * 1024, "chunks split over the waves; two workgroups per CU");
+  static_assert(kChunkKb % kRbWaves == 0 && kRing * kChunkBytes <= (kOcc == 2 ? 76 : 152) * 1024, "chunks split over the waves; two workgroups per CU (one at kOcc = 1)");
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];   // [ring][chunk] | fc1 bias [4C] fp32
   const int tid = threadIdx.x, lane = tid & 63, r = lane & 31, h = lane >> 5;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -452,8 +483,8 @@ __global__ __launch_bounds__(kRbThreads, 2) void htsat_mlp_kernel(RbArgs a) {
 #pragma unroll
       for (int e = 0; e < 4; ++e) acc1[1 - PH][4 * g + e] += bq[g][e];
     __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-    for (int i = 0; i < NM; ++i) {
+    static_for<0, NM>([&](auto ic) {
+      constexpr int i = decltype(ic)::value;
       // fragment i is the oldest of the (at most six) reads in flight
       if (i + 6 <= NM) wait_lgkm<5>();
       else if (i + 5 == NM) wait_lgkm<4>();
@@ -481,7 +512,7 @@ __global__ __launch_bounds__(kRbThreads, 2) void htsat_mlp_kernel(RbArgs a) {
         hb[1 - PH][q >> 1].u[2 * (q & 1) + 1] = pack2_f(g1[0], g1[1]);
       }
       __builtin_amdgcn_sched_barrier(0);
-    }
+    });
   };
   for (int k = 0; k < n_steps; k += 2) {                       // n_steps is even (4C / 32 + 2)
     if (k % SPC == 0) pre_chunk(k / SPC);
@@ -505,7 +536,7 @@ __global__ __launch_bounds__(kRbThreads, 2) void htsat_mlp_kernel(RbArgs a) {
   }
 }
 
-template <int C, int SPC>
+template <int C, int SPC, int kOcc = 2>
 static int launch_mlp(const RbArgs& a, hipStream_t st) {
   constexpr int kChunkBytes = SPC * 2 * (C / 16) * 1024;
   const int lds = 3 * kChunkBytes + 32 * a.n_tiles * 4;
@@ -514,11 +545,11 @@ static int launch_mlp(const RbArgs& a, hipStream_t st) {
   int dev = 0;
   ADT_HIP_TRY(hipGetDevice(&dev));
   if (done_for != dev) {
-    ADT_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(htsat_mlp_kernel<C, SPC>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    ADT_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(htsat_mlp_kernel<C, SPC, kOcc>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     done_for = dev;
   }
   const unsigned grid = static_cast<unsigned>((a.M + kRbRows - 1) / kRbRows);
-  hipLaunchKernelGGL((htsat_mlp_kernel<C, SPC>), dim3(grid), dim3(kRbThreads), lds, st, a);
+  hipLaunchKernelGGL((htsat_mlp_kernel<C, SPC, kOcc>), dim3(grid), dim3(kRbThreads), lds, st, a);
   ADT_HIP_TRY(hipGetLastError());
   return ADT_OK;
 }
@@ -832,7 +863,7 @@ extern "C" int adt_htsat_rowblock(int32_t mode, float* x, int64_t M, int32_t C, 
   // mode 3: the MLP phase by phase (no software pipeline; its own weight order) -- the A/B arm of mode 2
   if (mode < 0 || mode > 4) return set_error(ADT_EINVAL, "adt_htsat_rowblock: mode must be 0 (LN + GEMM), 1 (GEMM + residual), 2 (MLP) or 4 (LN + GEMM + GELU)");
   if (C != 96 && C != 192 && C != 384) return set_error(ADT_ESHAPE, "adt_htsat_rowblock: built for C = 96, 192 and 384");
-  if (C == 384 && (mode == 2 || mode == 3)) return set_error(ADT_ESHAPE, "adt_htsat_rowblock: the fused MLP is built for C = 96 and 192");
+  if (C == 384 && mode == 3) return set_error(ADT_ESHAPE, "adt_htsat_rowblock: the phase-by-phase MLP (mode 3) is built for C = 96 and 192");
   if (M < 0 || n_tiles <= 0 || !x || !w_packed || !bias1) return set_error(ADT_EINVAL, "adt_htsat_rowblock: bad arguments");
   if (mode != kRbGemmRes && (!ln_gamma || !ln_beta)) return set_error(ADT_EINVAL, "adt_htsat_rowblock: LayerNorm parameters missing");
   if (mode == kRbGemmRes && (!a16 || lda < C || (lda & 7) || n_tiles != C / 32)) return set_error(ADT_ESHAPE, "adt_htsat_rowblock: bad bf16 input / tile count");
@@ -847,6 +878,7 @@ extern "C" int adt_htsat_rowblock(int32_t mode, float* x, int64_t M, int32_t C, 
   a.ldo = ldo; a.M = M; a.n_tiles = n_tiles;
   hipStream_t st = static_cast<hipStream_t>(stream);
   if (C == 384) {
+    if (mode == kRbMlp) return launch_mlp<384, 1, 1>(a, st);
     if (mode == kRbLnGemm) return launch_rb<384, kRbLnGemm, 1>(a, st);
     if (mode == kRbLnGemmGelu) return launch_rb<384, kRbLnGemmGelu, 1>(a, st);
     return launch_rb<384, kRbGemmRes, 1>(a, st);
