@@ -87,21 +87,26 @@ def main():
                                    B, H, S, S, scale))
     print(f"attn bwd (dq + dkdv kernels, 7 matmuls): {ms:.3f} ms  {fl*3.5/ms/1e9:.1f} TFLOP/s executed, {fl*2.5/ms/1e9:.1f} algorithmic")
     for drop in ((0.1, 12345),):
-        ms = timeit(lambda: K.attn_fwd(qkv[:, :d], qkv[:, d:2 * d], qkv[:, 2 * d:], B, H, S, S, scale, drop=drop))
-        print(f"attn fwd dropout {drop[0]}: {ms:.3f} ms  {fl/ms/1e9:.1f} TFLOP/s")
-        ms = timeit(lambda: K.attn_bwd(qkv[:, :d], qkv[:, d:2 * d], qkv[:, 2 * d:], o, do, lse, dqkv[:, :d], dqkv[:, d:2 * d], dqkv[:, 2 * d:],
+        # what the training step launches: the forward leaves its keep decisions as bits (save_bits), the one-kernel backward reads them
+        ms = timeit(lambda: K.attn_fwd(qkv[:, :d], qkv[:, d:2 * d], qkv[:, 2 * d:], B, H, S, S, scale, drop=drop, save_bits=True))
+        print(f"attn fwd dropout {drop[0]} (storing keep bits, the step's form): {ms:.3f} ms  {fl/ms/1e9:.1f} TFLOP/s")
+        od, saved = K.attn_fwd(qkv[:, :d], qkv[:, d:2 * d], qkv[:, 2 * d:], B, H, S, S, scale, drop=drop, save_bits=True)
+        ms = timeit(lambda: K.attn_bwd(qkv[:, :d], qkv[:, d:2 * d], qkv[:, 2 * d:], od, do, saved, dqkv[:, :d], dqkv[:, d:2 * d], dqkv[:, 2 * d:],
                                        B, H, S, S, scale, drop=drop))
-        print(f"attn bwd dropout {drop[0]}: {ms:.3f} ms  {fl*2.5/ms/1e9:.1f} TFLOP/s algorithmic")
+        print(f"attn bwd dropout {drop[0]} (keep bits, the step's form): {ms:.3f} ms  {fl*2.5/ms/1e9:.1f} TFLOP/s algorithmic")
+        ms = timeit(lambda: K.attn_bwd(qkv[:, :d], qkv[:, d:2 * d], qkv[:, 2 * d:], od, do, saved.lse, dqkv[:, :d], dqkv[:, d:2 * d], dqkv[:, 2 * d:],
+                                       B, H, S, S, scale, drop=drop))
+        print(f"attn bwd dropout {drop[0]} (masks hashed again: the path without bits): {ms:.3f} ms  {fl*2.5/ms/1e9:.1f} TFLOP/s algorithmic")
     T = 128                                   # decoder shapes: cross-attention onto the memory, causal self-attention
     qc = torch.randn((B * T, d), device=dev).bfloat16()
     kvc = torch.randn((B * S, 2 * d), device=dev).bfloat16()
-    oc, lsec = K.attn_fwd(qc, kvc[:, :d], kvc[:, d:], B, H, T, S, scale, drop=(0.1, 7))
+    oc, lsec = K.attn_fwd(qc, kvc[:, :d], kvc[:, d:], B, H, T, S, scale, drop=(0.1, 7), save_bits=True)
     doc = torch.randn((B * T, d), device=dev).bfloat16()
     dqc, dkvc = torch.empty_like(qc), torch.empty_like(kvc)
     ms = timeit(lambda: K.attn_fwd(qc, kvc[:, :d], kvc[:, d:], B, H, T, S, scale, drop=(0.1, 7)))
     print(f"cross-attn fwd T={T} S={S} dropout: {ms:.3f} ms")
     ms = timeit(lambda: K.attn_bwd(qc, kvc[:, :d], kvc[:, d:], oc, doc, lsec, dqc, dkvc[:, :d], dkvc[:, d:], B, H, T, S, scale, drop=(0.1, 7)))
-    print(f"cross-attn bwd T={T} S={S} dropout: {ms:.3f} ms")
+    print(f"cross-attn bwd T={T} S={S} dropout (keep bits): {ms:.3f} ms")
     qs = torch.randn((B * T, 3 * d), device=dev).bfloat16()
     klen = torch.full((B,), T - 9, dtype=torch.int32, device=dev)
     os_, lses = K.attn_fwd(qs[:, :d], qs[:, d:2 * d], qs[:, 2 * d:], B, H, T, T, scale, causal=True, key_len=klen, drop=(0.1, 9))
