@@ -63,6 +63,7 @@ __device__ __forceinline__ unsigned lds_addr(const void* p) {  // byte offset in
   return static_cast<unsigned>(reinterpret_cast<size_t>((__attribute__((address_space(3))) const void*)p));
 }
 #include "gelu.h"
+#define ADT_DS_READ_B128_ADDR(dst, addr) asm volatile("ds_read_b128 %0, %1" : "=v"(dst) : "v"(addr))
 
 struct GemmArgs {
   const unsigned short* A; long lda;
@@ -567,6 +568,105 @@ __global__ __launch_bounds__(kGemmThreads) void gemm_nt_glds_kernel(GemmArgs g, 
   }
   gemm_epilogue_rows<kDrop>(g, acc, reinterpret_cast<float*>(smem), m0, n0, wm, wn, tid, lane);
 }
+
+#ifdef ADT_GEMM_RING      // experiment build (make EXTRA=-DADT_GEMM_RING): measured slower than gemm_nt_glds_kernel, see below
+// =========================================================================================
+// MEASURED AND NOT TAKEN (profiles/r06/gemm_ring4_ab.txt: bit for bit the two-stage kernel on every form, 1.2-1.3x SLOWER on the decoder's
+// M = 8192 shapes -- those launches are not latency-bound the way their in-step durations suggested: alone they run at 0.5-0.86 PFLOP/s --
+// and +-0 where the output dominates).
+// NT kernel for the latency-bound launches (round 6): the 128 x 128 tile of gemm_nt_glds_kernel with K-steps of 32 through a FOUR-slot LDS
+// ring, three steps in flight across raw barriers (counted vmcnt, one barrier per step).  The two-stage kernel above waits for a DMA it
+// issued one 32-MFMA step earlier: at a few hundred tiles per launch (the decoder's M = 8192 products, the CLAP tower's small stages: one
+// or two workgroups per CU, nothing else to run meanwhile) a K-tile costs ~1.5 us of mostly memory latency.  Here a step's operands were
+// requested three steps before they are read.
+//   slot = [A: 128 rows x 64 B | B: 128 rows x 64 B] = 16 KiB; position p (16 bytes) of row r holds the row's chunk p ^ ((r >> 1) & 3): the 16 rows
+//   of a fragment read fall on 8 distinct 16-byte slots of the 128-byte bank line, twice (the two cycles 256 bytes take anyway).
+//   DMA: wave w, instruction j fills rows 16 (2w + j) + (lane >> 2) of A and of B (4 instructions per wave and step).
+//   step s: s_waitcnt vmcnt(8) (this wave's part of step s has landed; s + 1, s + 2 stay in flight) -> s_barrier (everybody's has, and
+//   everybody has read step s - 1) -> DMA of step s + 3 into the slot of step s - 1 -> 8 ds_read_b128 -> 16 MFMAs.
+//   Steps past the end re-fetch the last one into slots nobody reads again, so the counts stay exact.  K % 32 == 0.
+constexpr int kR4BK = 32;
+constexpr int kR4Slot = 2 * 128 * 64;            // 16 KiB
+constexpr int kR4Slots = 4;
+constexpr int kR4Lds = kR4Slots * kR4Slot > kEpiLds ? kR4Slots * kR4Slot : kEpiLds;      // the epilogue's transposition tile re-uses the ring
+template <bool kDrop>
+__global__ __launch_bounds__(kGemmThreads) void gemm_nt_ring4_kernel(GemmArgs g, int tiles_m, int tiles_n) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave >> 1, wn = wave & 1;
+  const int nwg = tiles_m * tiles_n, bid = blockIdx.x;
+  const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7;
+  const int logical = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
+  const int m0 = (logical / tiles_n) * kBM, n0 = (logical % tiles_n) * kBN;
+  const int k_steps = g.K / kR4BK;
+
+  const unsigned short* pa[2];
+  const unsigned short* pb[2];
+#pragma unroll
+  for (int j = 0; j < 2; ++j) {
+    const int row = 16 * (2 * wave + j) + (lane >> 2);
+    const int chunk = (lane & 3) ^ ((row >> 1) & 3);
+    int ar = m0 + row, br = n0 + row;
+    ar = ar < g.M ? ar : g.M - 1;
+    br = br < g.N ? br : g.N - 1;
+    pa[j] = g.A + static_cast<long>(ar) * g.lda + chunk * 8;
+    pb[j] = g.B + static_cast<long>(br) * g.ldb + chunk * 8;
+  }
+  auto dma = [&](int step) {
+    const int st = step < k_steps ? step : k_steps - 1;
+    unsigned char* slot = smem + (step & (kR4Slots - 1)) * kR4Slot;
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(pa[j] + static_cast<long>(st) * kR4BK),
+                                       (__attribute__((address_space(3))) void*)(slot + (2 * wave + j) * 1024), 16, 0, 0);
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(pb[j] + static_cast<long>(st) * kR4BK),
+                                       (__attribute__((address_space(3))) void*)(slot + 8192 + (2 * wave + j) * 1024), 16, 0, 0);
+    }
+  };
+  // fragment addresses inside a slot: row = base + 16 i + (lane & 15), chunk lane >> 4
+  unsigned a_ad[4], b_ad[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int ra = wm * 64 + i * 16 + (lane & 15), rb = wn * 64 + i * 16 + (lane & 15);
+    a_ad[i] = lds_addr(smem) + static_cast<unsigned>(ra * 64 + (((lane >> 4) ^ ((ra >> 1) & 3)) << 4));
+    b_ad[i] = lds_addr(smem) + 8192u + static_cast<unsigned>(rb * 64 + (((lane >> 4) ^ ((rb >> 1) & 3)) << 4));
+  }
+
+  f32x4 acc[4][4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  dma(0); dma(1); dma(2);
+  for (int s = 0; s < k_steps; ++s) {
+    asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+    asm volatile("s_barrier" ::: "memory");
+    dma(s + 3);
+    const unsigned so = static_cast<unsigned>((s & (kR4Slots - 1)) * kR4Slot);
+    bf16x8 fa[4], fb[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      ADT_DS_READ_B128_ADDR(fa[i], a_ad[i] + so);
+      ADT_DS_READ_B128_ADDR(fb[i], b_ad[i] + so);
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_sched_barrier(0);
+    __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[i], fb[j], acc[i][j], 0, 0, 0);
+    __builtin_amdgcn_s_setprio(0);
+    __builtin_amdgcn_sched_barrier(0);
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // the three re-fetches past the end: landed before the epilogue re-uses the ring
+  __syncthreads();
+  gemm_epilogue_rows<kDrop>(g, acc, reinterpret_cast<float*>(smem), m0, n0, wm, wn, tid, lane);
+}
+#endif  // ADT_GEMM_RING (ring4)
 
 // =========================================================================================
 // NT kernel, 256 x 256 x 64 tile, 8 waves (2 x 4), LDS-DMA staging with the DMA in flight across barriers.
@@ -1884,6 +1984,20 @@ static int nt_persistent_form(int64_t M, int64_t N, int64_t K, unsigned mask) {
   return 1;
 }
 
+#ifdef ADT_GEMM_RING
+// The four-slot-ring 128^2 kernel instead of the two-stage one (experiment build only): ADT_GEMM_RING4=1 (read once; under
+// ADT_GEMM_ENV_DYNAMIC=1 on every call, for tools that alternate inside one process).
+static bool use_ring4(long tiles, int64_t K) {
+  static const bool dynamic = getenv("ADT_GEMM_ENV_DYNAMIC") != nullptr;
+  auto read = [] { const char* v = getenv("ADT_GEMM_RING4"); return !v ? -1 : (v[0] == '0' ? 0 : 1); };
+  static const int forced_once = read();
+  const int forced = dynamic ? read() : forced_once;
+  if ((K % kR4BK) != 0 || K < 4 * kR4BK) return false;
+  (void)tiles;
+  return forced == 1;
+}
+#endif
+
 static int set_big_lds_once() {      // the persistent kernels use the CU's whole LDS
   static thread_local int done_for = -1;
   int dev = 0;
@@ -2089,6 +2203,10 @@ static int gemm_bf16_impl(int32_t trans, int64_t M, int64_t N, int64_t K, const 
     ADT_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_nt_glds_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, kEpiLds));
     ADT_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_nt_glds_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, kEpiLds));
     ADT_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_tn_glds_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, kEpiLds));
+#ifdef ADT_GEMM_RING
+    ADT_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_nt_ring4_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, kR4Lds));
+    ADT_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_nt_ring4_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, kR4Lds));
+#endif
     if (int rc = set_big_lds_once()) return rc;
     attr_dev = dev;
   }
@@ -2172,6 +2290,12 @@ static int gemm_bf16_impl(int32_t trans, int64_t M, int64_t N, int64_t K, const 
   } else if (K > 0 && vector_epilogue_ok(g, e)) {       // any K (a multiple of 8, checked above): the last K-tile is zero-filled
     const int tm = static_cast<int>((M + kBM - 1) / kBM), tn = static_cast<int>((N + kBN - 1) / kBN);
     const dim3 g1(static_cast<unsigned>(tm) * tn);
+#ifdef ADT_GEMM_RING
+    if (use_ring4(tm * static_cast<long>(tn), K)) {         // experiment build, ADT_GEMM_RING4=1: the four-slot ring (three K-steps in flight)
+      if (g.drop.on()) hipLaunchKernelGGL(gemm_nt_ring4_kernel<true>, g1, dim3(kGemmThreads), kR4Lds, st, g, tm, tn);
+      else hipLaunchKernelGGL(gemm_nt_ring4_kernel<false>, g1, dim3(kGemmThreads), kR4Lds, st, g, tm, tn);
+    } else
+#endif
     if (g.drop.on()) hipLaunchKernelGGL(gemm_nt_glds_kernel<true>, g1, dim3(kGemmThreads), kEpiLds, st, g, tm, tn);
     else hipLaunchKernelGGL(gemm_nt_glds_kernel<false>, g1, dim3(kGemmThreads), kEpiLds, st, g, tm, tn);
   } else {
