@@ -188,14 +188,19 @@ __global__ __launch_bounds__(kThreads) void logmel_kernel(LogmelArgs a) {
     l2_pass3_store(lane, 0, z[0], buf);
     l2_pass3_store(lane, 1, z[1], buf);
     wave_sync();
+    float* pw = reinterpret_cast<float*>(buf);
+#ifndef ADT_LM_NOUNTANGLE      // (timing arms, tools/build_variant.sh: the output is meaningless)
     float pk[8], pnk[8], p512;
     l2_untangle_load(lane, t2k, buf, pk, pnk, p512);
     wave_sync();
-    float* pw = reinterpret_cast<float*>(buf);
     l2_untangle_store(lane, pk, pnk, p512, pw);
     wave_sync();
+#endif
     const int g = lane >> 2, s = lane & 3;
     float* stage = pw + kL2Stage;
+#if defined(ADT_LM_NOMEL) || defined(ADT_LM_NOUNTANGLE)
+    if (s == 0) { stage[g] = pw[lane]; stage[g + 64] = pw[lane + 64]; }
+#else
 #pragma unroll
     for (int i = 0; i < 8; ++i) {
       const unsigned mb = bands[g + 16 * i];
@@ -219,6 +224,7 @@ __global__ __launch_bounds__(kThreads) void logmel_kernel(LogmelArgs a) {
       acc += quad_xor<0x4E>(acc);
       if (s == 0) stage[g + 16 * i] = acc;               // raw band energies; the logarithm is taken once per output element below
     }
+#endif
     wave_sync();
     if (lane < a.n_mels / 2) {                         // two mels per lane: log / clamp / scale (model.py:91-93) and the 512-byte row
       const float2 e = reinterpret_cast<const float2*>(stage)[lane];
