@@ -164,7 +164,7 @@ class HtsatEncoder:
                 if C in ROWBLOCK_PARTIAL:
                     L["fc1_pk"] = pack_rowblock_weights(0, L["w1"].float()).to(self.dev)
                     L["mlp_pk"] = pack_rowblock_weights(2, L["w1"].float(), L["w2"].float()).to(self.dev)
-                if C == 96 and nh == 4:                    # the whole attention half in one launch
+                if (C, nh) in ((96, 4), (192, 8), (384, 16)):      # the whole attention half in one launch (C = 192 / 384: round 6, ADT_HTSAT_ATTN_BIG)
                     L["attn_pk"], L["attn_qkvb"] = (t.to(self.dev) for t in pack_attn_block_weights(L["wqkv"].float(), L["bqkv"], L["wo"].float(), nh))
                 if C in ROWBLOCK_CHANNELS:
                     L = layers[-1]
@@ -244,12 +244,21 @@ class HtsatEncoder:
         for S in self.stages:
             C, nh, R = S["C"], S["nh"], S["R"]
             for L in S["layers"]:
-                if fused and "attn_pk" in L and os.environ.get("ADT_HTSAT_ATTN", "1") != "0":
-                    # stage 0: two launches per layer; only the residual stream touches HBM
+                big = os.environ.get("ADT_HTSAT_ATTN_BIG", "1")            # "1" (default since round 6): C = 192 and 384 too; "384" / "192": that stage only; "0": three launches
+                attn_one = C == 96 or (C in (192, 384) and (big == "1" or big == str(C)))
+                if fused and "attn_pk" in L and attn_one and os.environ.get("ADT_HTSAT_ATTN", "1") != "0":
+                    # the attention half in one launch: only the residual stream touches HBM
                     _ffi.call("adt_htsat_attn_block", _ffi.dptr(x), B, R, C, nh, L["shift"], _ffi.dptr(L["ln1"][0]), _ffi.dptr(L["ln1"][1]), self.eps,
                               _ffi.dptr(L["attn_pk"]), _ffi.dptr(L["attn_qkvb"]), _ffi.dptr(L["bo"]), _ffi.dptr(L["bias"]), L["n_bias"],
                               1.0 / math.sqrt(24.0), st)
-                    rowblock(2, x, L["mlp_pk"], C // 8, L["b1"], ln=L["ln2"], eps=self.eps, bias2=L["b2"])
+                    if C != 384:
+                        rowblock(2, x, L["mlp_pk"], C // 8, L["b1"], ln=L["ln2"], eps=self.eps, bias2=L["b2"])
+                    elif os.environ.get("ADT_HTSAT_MLP384", "0") == "1":
+                        rowblock(2, x, L["mlp_pk"], C // 8, L["b1"], ln=L["ln2"], eps=self.eps, bias2=L["b2"])
+                    else:
+                        h = torch.empty((x.shape[0], 4 * C), dtype=BF16, device=self.dev)
+                        rowblock(4, x, L["fc1_pk"], 4 * C // 32, L["b1"], ln=L["ln2"], eps=self.eps, out16=h)
+                        K.gemm(h, L["w2"], bias=L["b2"], residual=x, out=x)
                     continue
                 if fused and "mlp_pk" in L and "fc1_pk" not in L:
                     # bandwidth-bound stages: three launches per layer, the residual stream is read and written once per half

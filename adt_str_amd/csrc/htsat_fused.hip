@@ -25,6 +25,7 @@
 // would be ordered behind the DMA in flight with a vmcnt(0)).
 #include <hip/hip_runtime.h>
 
+#include <cstdio>
 #include <cstdlib>
 #include <type_traits>
 
@@ -822,6 +823,315 @@ __global__ __launch_bounds__(256, 2) void htsat_attn_kernel(AtArgs a) {
   }
 }
 
+// ---- the same attention half for C = 192 / 384 (stages 1 and 2; round 6): ONE workgroup per CU, a wave alone on its SIMD with the 512-register
+// file (the token's C/16 operand registers + C/2 output-projection accumulators do not fit 256).  Unfused, a third-stage layer's attention
+// half moves x twice and the bf16 q | k | v / context tensors in between (1.4 GB per layer at 512 clips, at the ~3.2 TB/s every launch of
+// this tower is bound by); here x is read and written once (0.4 GB).  The head's weights no longer fit LDS twice (96 KiB per head at
+// C = 384), so the stream is cut into SUB-chunks of C/16 KiB -- per head [Wq_h | Wk_h | Wv_h | Wo_h], each exactly C/16 fragments, the order
+// pack_attn_block_weights already writes -- through a FOUR-slot ring, two sub-chunks ahead: sub-chunk n is waited for with a counted vmcnt
+// that leaves n + 1 (and, where they are younger, the next head's relative-position bias pieces, which travel by LDS-DMA into per-wave
+// staging slots) outstanding, one barrier per sub-chunk, and the DMA instructions of sub-chunk n + 2 are issued one at a time BEHIND
+// products of the tile that reads sub-chunk n.  Sub-chunks past the end re-fetch the last one into slots nobody reads again, so that the
+// counts stay exact.  Measured (profiles/r06/clap_attn_big.txt): same bits as the three launches' bf16 roundings to 5e-4 of the update;
+// alone 395 vs 405-440 us (C = 384) and 602-627 vs 664-677 us (C = 192) per layer; inside the tower 37.8 k vs 36.8 k embeds/s.
+#ifdef ADT_ATB_STAMPS      // experiment build: cycle stamps of wave 0 of workgroup 300 for head 2 (tools/probe/attn_big.py prints them)
+__device__ unsigned long long g_atb_stamps[16];
+#define ADT_ATB_STAMP(K) do { if (blockIdx.x == 300 && wave == 0 && hd == 2) { const unsigned long long tn = __builtin_amdgcn_s_memtime(); if (lane == 0) g_atb_stamps[K] = tn; } } while (0)
+#else
+#define ADT_ATB_STAMP(K) do { } while (0)
+#endif
+template <int C>
+__global__ __launch_bounds__(256, 1) void htsat_attn_big_kernel(AtArgs a) {
+  constexpr int KS = C / 16, CT = C / 32, NH = C / 24;
+  constexpr int kSubBytes = KS * 1024;
+  constexpr int IPW = KS / 4;                                  // DMA instructions per wave and sub-chunk
+  constexpr int kSubs = 4 * NH;
+  static_assert(KS % 12 == 0 && IPW * 4 == KS, "C = 192 or 384");
+  constexpr int kKx = 4 * kSubBytes, kVt = kKx + 2 * 2 * 2 * 1024, kQb = kVt + 2 * 4096;     // ring | K operands | V tiles | q|k|v bias | bias staging
+  constexpr int kRb = kQb + NH * 96 * 4;                                                     // per wave 8 KiB: the head's relative-position bias pieces
+  static_assert(kRb + 4 * 8192 <= 160 * 1024, "LDS budget");
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  const int tid = threadIdx.x, lane = tid & 63, r = lane & 31, h = lane >> 5;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wi = wave >> 1, tt = wave & 1;
+  const int nw = a.R / 8;
+  long widx = static_cast<long>(blockIdx.x) * 2 + wi;                                  // (b, wy, wx)
+  const long n_windows = static_cast<long>(a.B) * nw * nw;
+  const bool win_ok = widx < n_windows;
+  if (!win_ok) widx = n_windows - 1;
+  const int wx = static_cast<int>(widx % nw), wy = static_cast<int>((widx / nw) % nw), bi = static_cast<int>(widx / (nw * nw));
+  const long row = at_token_row(a, bi, wy, wx, 32 * tt + r);
+  const unsigned smem_base = lds_off_f(smem);
+
+  // one LDS-DMA instruction (1 KiB) of sub-chunk n: a wave's vector-memory instruction costs it ~50-100 issue cycles, and a wave alone on its
+  // SIMD has nobody to cover them -- so inside the head loop they are issued one at a time BETWEEN the products of a tile (the matrix pipe
+  // works meanwhile), not as a block in front of it (cycle stamps: a tile's segment 1 300 cycles without a single product, profiles/r06/clap_attn_big.txt)
+  auto issue_sub_i = [&](int n, int i) {
+    const int nn = n < kSubs ? n : kSubs - 1;
+    const unsigned char* src = a.wpk + static_cast<long>(nn) * kSubBytes + (wave * IPW + i) * 1024 + lane * 16;
+    unsigned char* dst = smem + (n & 3) * kSubBytes + (wave * IPW + i) * 1024;
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src, (__attribute__((address_space(3))) void*)dst, 16, 0, 0);
+  };
+  auto issue_sub = [&](int n) {
+#pragma unroll
+    for (int i = 0; i < IPW; ++i) issue_sub_i(n, i);
+  };
+  // piece i (of 8) of head hd's relative-position bias (+ shift mask) for (query tile tt; key tile, group): lane-linear table -> the wave's own
+  // staging slots (read back by the wave that fetched them: no barrier)
+  const int wsel_ = a.n_bias_windows > 1 ? (wy * nw + wx) : 0;
+  auto issue_rb_i = [&](int hd, int i) {
+    const int hh = hd < NH ? hd : NH - 1;
+    const float* rb = a.rel_bias + (static_cast<long>(wsel_) * NH + hh) * 4096 + tt * 2048 + lane * 4;
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(rb + i * 256),
+                                     (__attribute__((address_space(3))) void*)(smem + kRb + wave * 8192 + i * 1024), 16, 0, 0);
+  };
+  // ---- the token row -> LayerNorm -> bf16 B operands (before any DMA is in flight: these are plain loads)
+  bf16x8 b[KS];
+  {
+    const float* xp = a.x + row * C + 8 * h;
+    float xv[KS][8];
+    float sum = 0.f;
+#pragma unroll
+    for (int s = 0; s < KS; ++s) {
+      const float4 v0 = *reinterpret_cast<const float4*>(xp + 16 * s), v1 = *reinterpret_cast<const float4*>(xp + 16 * s + 4);
+      xv[s][0] = v0.x; xv[s][1] = v0.y; xv[s][2] = v0.z; xv[s][3] = v0.w; xv[s][4] = v1.x; xv[s][5] = v1.y; xv[s][6] = v1.z; xv[s][7] = v1.w;
+#pragma unroll
+      for (int e = 0; e < 8; ++e) sum += xv[s][e];
+    }
+    sum += __shfl_xor(sum, 32);
+    const float mean = sum * (1.0f / C);
+    float ss = 0.f;
+#pragma unroll
+    for (int s = 0; s < KS; ++s)
+#pragma unroll
+      for (int e = 0; e < 8; ++e) { const float d = xv[s][e] - mean; ss = fmaf(d, d, ss); }
+    ss += __shfl_xor(ss, 32);
+    const float rstd = rsqrtf(ss * (1.0f / C) + a.eps);
+#pragma unroll
+    for (int s = 0; s < KS; ++s) {
+      const float4 g0 = *reinterpret_cast<const float4*>(a.gamma + 16 * s + 8 * h), g1 = *reinterpret_cast<const float4*>(a.gamma + 16 * s + 8 * h + 4);
+      const float4 e0 = *reinterpret_cast<const float4*>(a.beta + 16 * s + 8 * h), e1 = *reinterpret_cast<const float4*>(a.beta + 16 * s + 8 * h + 4);
+      const float ga[8] = {g0.x, g0.y, g0.z, g0.w, g1.x, g1.y, g1.z, g1.w}, be[8] = {e0.x, e0.y, e0.z, e0.w, e1.x, e1.y, e1.z, e1.w};
+      union { unsigned u[4]; bf16x8 v; } pk;
+#pragma unroll
+      for (int e = 0; e < 4; ++e)
+        pk.u[e] = pack2_f(fmaf((xv[s][2 * e] - mean) * rstd, ga[2 * e], be[2 * e]), fmaf((xv[s][2 * e + 1] - mean) * rstd, ga[2 * e + 1], be[2 * e + 1]));
+      b[s] = pk.v;
+    }
+  }
+  float* qb_lds = reinterpret_cast<float*>(smem + kQb);
+  for (int i = tid; i < NH * 96; i += 256) qb_lds[i] = a.qkv_bias[i];
+  asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+#pragma unroll
+  for (int s = 0; s < KS; ++s) asm volatile("" :: "v"(b[s]));
+  // (two sub-chunks ahead, not three: with three plus the bias pieces a wave had up to 26 vector-memory operations outstanding, and past ~16 the
+  //  issue of the next one waits for the oldest to retire -- a hidden wait inside the tiles)
+  issue_sub(0);
+#pragma unroll
+  for (int i = 0; i < 8; ++i) issue_rb_i(0, i);
+  issue_sub(1);
+
+  f32x16 acc_out[CT];
+#pragma unroll
+  for (int ct = 0; ct < CT; ++ct)
+#pragma unroll
+    for (int i = 0; i < 16; ++i) acc_out[ct][i] = 0.f;
+  const unsigned kx_w = smem_base + kKx + static_cast<unsigned>(((wi * 2 + tt) * 2) * 1024 + lane * 16);       // this wave's K operands (k-step s: + s KiB)
+  const unsigned kx_r = smem_base + kKx + static_cast<unsigned>((wi * 2 * 2) * 1024 + lane * 16);              // the window's: + (kt * 2 + s) KiB
+  const unsigned vt_b = smem_base + kVt + static_cast<unsigned>(wi * 4096);
+  const unsigned vt_w = vt_b + static_cast<unsigned>((32 * tt + r) * 64 + 8 * h);                               // d = 8g + 4h .. + 3: + 16 g bytes
+  const unsigned qb_a = smem_base + kQb + static_cast<unsigned>(16 * h);                                         // + (head * 96 + which * 32 + 8g) * 4
+  const float sl2 = a.scale * 1.4426950408889634f;
+
+  auto frag6 = [&](bf16x8 (&f)[6], unsigned addr) {
+    asm volatile("ds_read_b128 %0, %6\n\tds_read_b128 %1, %6 offset:1024\n\tds_read_b128 %2, %6 offset:2048\n\t"
+                 "ds_read_b128 %3, %6 offset:3072\n\tds_read_b128 %4, %6 offset:4096\n\tds_read_b128 %5, %6 offset:5120"
+                 : "=&v"(f[0]), "=&v"(f[1]), "=&v"(f[2]), "=&v"(f[3]), "=&v"(f[4]), "=&v"(f[5]) : "v"(addr) : "memory");
+  };
+  // one 32-unit tile of the row-block product + its bias: acc[unit 8g + 4h + e][token]; ta = the sub-chunk's first fragment (+ lane * 16)
+  auto tile = [&](unsigned ta, unsigned bias_a, f32x16& acc, auto&& between) {
+    f32x4 bv[4];
+    asm volatile("ds_read_b128 %0, %4\n\tds_read_b128 %1, %4 offset:32\n\tds_read_b128 %2, %4 offset:64\n\tds_read_b128 %3, %4 offset:96"
+                 : "=&v"(bv[0]), "=&v"(bv[1]), "=&v"(bv[2]), "=&v"(bv[3]) : "v"(bias_a) : "memory");
+    zero_acc(acc);
+    // (Tried and measured on this kernel: a second fragment set requested one group ahead, and two accumulation chains -- neither moved the
+    // tile's ~1 700 cycles.  What did: the token's operand registers b[] must STAY in arch VGPRs; with more than ~250 live values the allocator
+    // parked them in AGPRs and moved all C/4 dwords back in front of every tile (profiles/r06/clap_attn_big.txt).)
+    static_for<0, KS / 6>([&](auto gc) {
+      constexpr int g = decltype(gc)::value;
+      bf16x8 f[6];
+      frag6(f, ta + static_cast<unsigned>(g * 6 * 1024));
+      static_for<0, 6>([&](auto jc) {
+        constexpr int j = decltype(jc)::value;
+        wait_lgkm<5 - j>();
+        __builtin_amdgcn_sched_barrier(0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f[j], b[6 * g + j], acc, 0, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);
+        between(std::integral_constant<int, 6 * g + j>{});
+        __builtin_amdgcn_sched_barrier(0);
+      });
+    });
+#pragma unroll
+    for (int g = 0; g < 4; ++g)
+#pragma unroll
+      for (int e = 0; e < 4; ++e) acc[4 * g + e] += bv[g][e];
+  };
+  // sub-chunk n has landed for everybody (and n - 1 has been read by everybody): counted wait (kExtra = other vector-memory operations of
+  // this wave that are younger than sub-chunk n and may stay outstanding), barrier, then n + 3 goes into the slot of n - 1
+  auto sub_ready = [&](int n, auto extra_tag) {
+    constexpr int kExtra = decltype(extra_tag)::value;
+    wait_vm<IPW + kExtra>();
+    asm volatile("s_barrier" ::: "memory");
+    (void)n;
+  };
+
+  for (int hd = 0; hd < NH; ++hd) {
+    const int n0 = 4 * hd;
+    ADT_ATB_STAMP(0);
+    // in-order list of this wave's vector-memory operations here: sub-chunk n0, the 8 bias pieces of this head, sub-chunk n0 + 1
+    sub_ready(n0, std::integral_constant<int, 8>{});
+    ADT_ATB_STAMP(1);
+    const unsigned ba = qb_a + static_cast<unsigned>(hd * 96 * 4);
+    // sub-chunk n + 2 is issued one instruction behind every (KS / IPW)-th product of the tile that reads sub-chunk n
+    constexpr int kEvery = KS / IPW;
+    auto dma_q = [&](auto mc) { constexpr int m = decltype(mc)::value; if constexpr (m % kEvery == 1) issue_sub_i(n0 + 2, m / kEvery); };
+    auto dma_k = [&](auto mc) { constexpr int m = decltype(mc)::value; if constexpr (m % kEvery == 1) issue_sub_i(n0 + 3, m / kEvery); };
+    auto dma_v = [&](auto mc) { constexpr int m = decltype(mc)::value; if constexpr (m % kEvery == 1) issue_sub_i(n0 + 4, m / kEvery); };
+    f32x16 acc;
+    bf16x8 qop[2];
+    tile(smem_base + static_cast<unsigned>((n0 & 3) * kSubBytes + lane * 16), ba, acc, dma_q);                    // q
+    qop[0] = acc_to_b_f(acc, 0); qop[1] = acc_to_b_f(acc, 1);
+    ADT_ATB_STAMP(2);
+    sub_ready(n0 + 1, std::integral_constant<int, 0>{});
+    ADT_ATB_STAMP(3);          // (younger than sub-chunk n0 + 1: n0 + 2; the bias pieces are OLDER than n0 + 1: landed with it)
+    tile(smem_base + static_cast<unsigned>(((n0 + 1) & 3) * kSubBytes + lane * 16), ba + 128, acc, dma_k);        // k -> the window's K operands
+    {
+      const bf16x8 k0 = acc_to_b_f(acc, 0), k1 = acc_to_b_f(acc, 1);
+      asm volatile("ds_write_b128 %0, %1\n\tds_write_b128 %0, %2 offset:1024" :: "v"(kx_w), "v"(k0), "v"(k1) : "memory");
+    }
+    ADT_ATB_STAMP(4);
+    sub_ready(n0 + 2, std::integral_constant<int, 0>{});          // (younger: n0 + 3)
+    ADT_ATB_STAMP(5);
+    tile(smem_base + static_cast<unsigned>(((n0 + 2) & 3) * kSubBytes + lane * 16), ba + 256, acc, dma_v);        // v -> the window's [key][d] tile
+    ADT_ATB_STAMP(14);
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+      const unsigned lo = pack2_c(acc[4 * g], acc[4 * g + 1]), hi = pack2_c(acc[4 * g + 2], acc[4 * g + 3]);
+      typedef unsigned u32x2_ __attribute__((ext_vector_type(2)));
+      const u32x2_ pr = {lo, hi};
+      asm volatile("ds_write_b64 %0, %1" :: "v"(vt_w + static_cast<unsigned>(16 * g)), "v"(pr) : "memory");
+    }
+    ADT_ATB_STAMP(15);
+    wait_lgkm<0>();
+    ADT_ATB_STAMP(6);
+    asm volatile("s_barrier" ::: "memory");
+    ADT_ATB_STAMP(7);
+    // ---- S^T[key][query] for this wave's 32 queries and the window's 64 keys
+    bf16x8 kf[4];
+    asm volatile("ds_read_b128 %0, %4\n\tds_read_b128 %1, %4 offset:1024\n\tds_read_b128 %2, %4 offset:2048\n\tds_read_b128 %3, %4 offset:3072"
+                 : "=&v"(kf[0]), "=&v"(kf[1]), "=&v"(kf[2]), "=&v"(kf[3]) : "v"(kx_r) : "memory");
+    f32x16 st[2];
+    wait_lgkm<0>();
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int kt = 0; kt < 2; ++kt) {
+      zero_acc(st[kt]);
+      st[kt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf[2 * kt], qop[0], st[kt], 0, 0, 0);
+      st[kt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf[2 * kt + 1], qop[1], st[kt], 0, 0, 0);
+    }
+    ADT_ATB_STAMP(8);          // (the bias pieces landed before sub-chunk n0 + 1 did)
+    ADT_ATB_STAMP(9);
+    float mx = -3.0e38f;
+#pragma unroll
+    for (int kt = 0; kt < 2; ++kt) {                      // (one key tile's bias at a time: 16 registers live instead of 32)
+      f32x4 rbv[4];
+      const unsigned ra = smem_base + static_cast<unsigned>(kRb + wave * 8192 + kt * 4096 + lane * 16);
+      asm volatile("ds_read_b128 %0, %4\n\tds_read_b128 %1, %4 offset:1024\n\tds_read_b128 %2, %4 offset:2048\n\tds_read_b128 %3, %4 offset:3072\n\t"
+                   "s_waitcnt lgkmcnt(0)"
+                   : "=&v"(rbv[0]), "=&v"(rbv[1]), "=&v"(rbv[2]), "=&v"(rbv[3]) : "v"(ra) : "memory");
+#pragma unroll
+      for (int g = 0; g < 4; ++g)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const float v = fmaf(st[kt][4 * g + e], sl2, rbv[g][e]);       // log2 domain: the bias table comes pre-multiplied by log2 e
+          st[kt][4 * g + e] = v;
+          mx = fmaxf(mx, v);
+        }
+    }
+    mx = fmaxf(mx, __shfl_xor(mx, 32));
+    float sum = 0.f;
+#pragma unroll
+    for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+      for (int i = 0; i < 16; ++i) { const float p = __builtin_amdgcn_exp2f(st[kt][i] - mx); st[kt][i] = p; sum += p; }
+    sum += __shfl_xor(sum, 32);
+    const float inv = 1.0f / sum;
+    ADT_ATB_STAMP(10);
+    // ---- O^T[d][query] = sum over keys of V^T P^T
+    f32x16 o;
+    zero_acc(o);
+#pragma unroll
+    for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+      for (int s2 = 0; s2 < 2; ++s2) {
+        const int i16 = lane & 15, g4 = (lane >> 4) & 1;
+        const unsigned base = vt_b + static_cast<unsigned>((kt * 32 + 16 * s2 + 4 * h + (i16 >> 2)) * 64 + (16 * g4 + 4 * (i16 & 3)) * 2);
+        typedef __attribute__((ext_vector_type(4))) short bf16x4_;
+        bf16x4_ lo, hi;
+        bf16x8 af;
+        asm volatile("ds_read_b64_tr_b16 %0, %2\n\tds_read_b64_tr_b16 %1, %2 offset:512\n\ts_waitcnt lgkmcnt(0)"
+                     : "=&v"(lo), "=&v"(hi) : "v"(base) : "memory");
+        af[0] = lo[0]; af[1] = lo[1]; af[2] = lo[2]; af[3] = lo[3]; af[4] = hi[0]; af[5] = hi[1]; af[6] = hi[2]; af[7] = hi[3];
+        union { unsigned u[4]; bf16x8 v; } pf;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) pf.u[e] = pack2_c(st[kt][8 * s2 + 2 * e], st[kt][8 * s2 + 2 * e + 1]);       // un-normalised: O is scaled by 1 / sum below
+        o = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af, pf.v, o, 0, 0, 0);
+      }
+#pragma unroll
+    for (int i = 0; i < 16; ++i) o[i] *= inv;              // the softmax denominator, once per output instead of once per probability
+    const bf16x8 ob0 = acc_to_b_f(o, 0), ob1 = acc_to_b_f(o, 1);
+    // ---- output projection: this head's 24 (+ 8 zero) context values are k-steps 0, 1 of Wo's slice (fragment s2 * CT + ct)
+    ADT_ATB_STAMP(11);
+    sub_ready(n0 + 3, std::integral_constant<int, 0>{});
+    ADT_ATB_STAMP(12);
+    {
+      const unsigned ta = smem_base + static_cast<unsigned>(((n0 + 3) & 3) * kSubBytes + lane * 16);
+      static_for<0, 2 * CT / 6>([&](auto gc) {
+        constexpr int g = decltype(gc)::value;
+        bf16x8 f[6];
+        frag6(f, ta + static_cast<unsigned>(g * 6 * 1024));
+        static_for<0, 6>([&](auto jc) {
+          constexpr int j = decltype(jc)::value;
+          constexpr int fi = 6 * g + j;
+          wait_lgkm<5 - j>();
+          __builtin_amdgcn_sched_barrier(0);
+          acc_out[fi % CT] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f[j], fi < CT ? ob0 : ob1, acc_out[fi % CT], 0, 0, 0);
+          __builtin_amdgcn_sched_barrier(0);
+          // behind the products: the NEXT head's 8 bias pieces (their staging slots were read in this head's softmax), then sub-chunk n0 + 5
+          if constexpr (fi < 8) issue_rb_i(hd + 1, fi);
+          else if constexpr (fi - 8 < IPW) issue_sub_i(n0 + 5, fi - 8);
+          __builtin_amdgcn_sched_barrier(0);
+        });
+      });
+    }
+    ADT_ATB_STAMP(13);
+  }
+  // ---- x += acc_out + bias
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  if (win_ok) {
+    float* xp = a.x + row * C + 4 * h;
+#pragma unroll
+    for (int ct = 0; ct < CT; ++ct)
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        const f32x4 xr = *reinterpret_cast<const f32x4*>(xp + 32 * ct + 8 * g);
+        const f32x4 b2 = *reinterpret_cast<const f32x4*>(a.out_bias + 32 * ct + 8 * g + 4 * h);
+        *reinterpret_cast<f32x4*>(xp + 32 * ct + 8 * g) = f32x4{acc_out[ct][4 * g] + b2[0] + xr[0], acc_out[ct][4 * g + 1] + b2[1] + xr[1],
+                                                               acc_out[ct][4 * g + 2] + b2[2] + xr[2], acc_out[ct][4 * g + 3] + b2[3] + xr[3]};
+      }
+  }
+}
+
 template <int C, int MODE, int TPC>
 static int launch_rb(const RbArgs& a, hipStream_t st) {
   constexpr int KS = C / 16;
@@ -918,7 +1228,8 @@ extern "C" int adt_htsat_attn_block(float* x, int64_t B, int32_t R, int32_t C, i
                                     const float* ln_beta, float eps, const void* w_packed, const float* qkv_bias, const float* out_bias,
                                     const float* rel_bias, int32_t n_bias_windows, float scale, void* stream) {
   if (!x || !ln_gamma || !ln_beta || !w_packed || !qkv_bias || !out_bias || !rel_bias) return set_error(ADT_EINVAL, "adt_htsat_attn_block: null pointer");
-  if (C != 96 || heads != 4) return set_error(ADT_ESHAPE, "adt_htsat_attn_block: built for C = 96 (4 heads of 24)");
+  if (!((C == 96 && heads == 4) || (C == 192 && heads == 8) || (C == 384 && heads == 16)))
+    return set_error(ADT_ESHAPE, "adt_htsat_attn_block: built for C = 96 / 192 / 384 with heads of 24");
   if (B < 0 || R <= 0 || (R & 7) || shift < 0 || shift >= 8) return set_error(ADT_ESHAPE, "adt_htsat_attn_block: window 8, R % 8 == 0");
   const int nw = R / 8;
   if (n_bias_windows != 1 && n_bias_windows != nw * nw) return set_error(ADT_EINVAL, "adt_htsat_attn_block: n_bias_windows must be 1 or (R/8)^2");
@@ -927,16 +1238,37 @@ extern "C" int adt_htsat_attn_block(float* x, int64_t B, int32_t R, int32_t C, i
   if (n_windows == 0) return ADT_OK;
   AtArgs a{x, ln_gamma, ln_beta, eps, static_cast<const unsigned char*>(w_packed), qkv_bias, out_bias, rel_bias, n_bias_windows,
            static_cast<int>(B), R, shift, scale};
-  constexpr int kChunk = (3 * 6 + 2 * 3) * 1024;
-  const int lds = 2 * kChunk + 8 * 1024 + 2 * 4096 + 4 * 96 * 4;
   static thread_local int done_for = -1;
   int dev = 0;
   ADT_HIP_TRY(hipGetDevice(&dev));
   if (done_for != dev) {
     ADT_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(htsat_attn_kernel<96>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    ADT_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(htsat_attn_big_kernel<192>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    ADT_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(htsat_attn_big_kernel<384>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     done_for = dev;
   }
-  hipLaunchKernelGGL((htsat_attn_kernel<96>), dim3(static_cast<unsigned>((n_windows + 1) / 2)), dim3(256), lds, static_cast<hipStream_t>(stream), a);
+  const dim3 grid(static_cast<unsigned>((n_windows + 1) / 2));
+  if (C == 96) {
+    constexpr int kChunk = (3 * 6 + 2 * 3) * 1024;
+    const int lds = 2 * kChunk + 8 * 1024 + 2 * 4096 + 4 * 96 * 4;
+    hipLaunchKernelGGL((htsat_attn_kernel<96>), grid, dim3(256), lds, static_cast<hipStream_t>(stream), a);
+  } else {
+    // ring of four C/16-KiB sub-chunks | K operands 8 KiB | V tiles 8 KiB | q|k|v bias | per-wave relative-bias staging 4 x 8 KiB
+    const int lds = 4 * (C / 16) * 1024 + 8 * 1024 + 2 * 4096 + heads * 96 * 4 + 4 * 8192;
+    if (C == 192) hipLaunchKernelGGL((htsat_attn_big_kernel<192>), grid, dim3(256), lds, static_cast<hipStream_t>(stream), a);
+    else hipLaunchKernelGGL((htsat_attn_big_kernel<384>), grid, dim3(256), lds, static_cast<hipStream_t>(stream), a);
+#ifdef ADT_ATB_STAMPS
+    if (getenv("ADT_ATB_PRINT")) {
+      unsigned long long h[16];
+      ADT_HIP_TRY(hipStreamSynchronize(static_cast<hipStream_t>(stream)));
+      ADT_HIP_TRY(hipMemcpyFromSymbol(h, HIP_SYMBOL(g_atb_stamps), sizeof(h)));
+      fprintf(stderr, "attn_big stamps C=%d (ticks of s_memtime, 100 MHz): ", C);
+      for (int i = 1; i < 14; ++i) fprintf(stderr, "%d:+%lld ", i, static_cast<long long>(h[i] - h[i - 1]));
+      fprintf(stderr, "| head total %lld | v segment: tile %lld, packs + writes %lld, write wait %lld\n", static_cast<long long>(h[13] - h[0]),
+              static_cast<long long>(h[14] - h[5]), static_cast<long long>(h[15] - h[14]), static_cast<long long>(h[6] - h[15]));
+    }
+#endif
+  }
   ADT_HIP_TRY(hipGetLastError());
   return ADT_OK;
 }

@@ -66,8 +66,9 @@ def test_rowblock_modes_match_fp32_reference(C):
     assert torch.equal(x2, x3)
 
 
+@pytest.mark.parametrize("C,nh", [(96, 4), (192, 8), (384, 16)])
 @pytest.mark.parametrize("shift", [0, 4])
-def test_attention_block_equals_its_three_kernel_sequence(shift):
+def test_attention_block_equals_its_three_kernel_sequence(shift, C, nh):
     """adt_htsat_attn_block (LayerNorm -> q|k|v -> window attention -> output projection -> + x in one launch) against the sequence it
     replaces (row-block LN + q|k|v, adt_window_attn_fwd, row-block projection + residual) on the same weights: both round the same
     quantities to bf16 (q, k, v, P, the context), so they agree to a few bf16 ulps of the update; an odd window count exercises the
@@ -76,7 +77,7 @@ def test_attention_block_equals_its_three_kernel_sequence(shift):
     from adt_str_amd import _ffi
     from adt_str_amd.clap_encoder import _shift_mask, pack_attn_block_weights, pack_rowblock_weights, rowblock, window_bias_layout
     g = torch.Generator().manual_seed(7 + shift)
-    B, R, C, nh = 3, 24, 96, 4                                          # 27 windows
+    B, R = 3, 24                                                        # 27 windows (C = 192 / 384: the one-workgroup-per-CU form with the sub-chunk ring)
     M = B * R * R
     x = (torch.randn((M, C), generator=g) * 1.2).to(DEV)
     gamma, beta = (1 + 0.1 * torch.randn(C, generator=g)).to(DEV), (0.1 * torch.randn(C, generator=g)).to(DEV)
