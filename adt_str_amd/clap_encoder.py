@@ -253,7 +253,7 @@ class HtsatEncoder:
                               1.0 / math.sqrt(24.0), st)
                     if C != 384:
                         rowblock(2, x, L["mlp_pk"], C // 8, L["b1"], ln=L["ln2"], eps=self.eps, bias2=L["b2"])
-                    elif os.environ.get("ADT_HTSAT_MLP384", "0") == "1":
+                    elif os.environ.get("ADT_HTSAT_MLP384", "1") != "0":
                         rowblock(2, x, L["mlp_pk"], C // 8, L["b1"], ln=L["ln2"], eps=self.eps, bias2=L["b2"])
                     else:
                         h = torch.empty((x.shape[0], 4 * C), dtype=BF16, device=self.dev)
@@ -281,10 +281,11 @@ class HtsatEncoder:
                     _ffi.call("adt_window_attn_fwd", _ffi.dptr(qkv), qkv.stride(0), _ffi.dptr(ctx), C, _ffi.dptr(L["bias"]), L["n_bias"], B, R, C,
                               nh, L["shift"], 1.0 / math.sqrt(24.0), st)
                     rowblock(1, x, L["wo_pk"], C // 32, L["bo"], a16=ctx)
-                    if os.environ.get("ADT_HTSAT_MLP384", "0") == "1":
-                        # the whole MLP in one launch (round 6: one workgroup per CU on 512 registers): the hidden activation never exists --
-                        # 806 MB less HBM traffic per layer at 512 clips and 439 vs 494 us alone, but a tie inside the tower (12.67 vs 12.65 ms,
-                        # profiles/r06/clap_mlp384_ab.txt: a lone wave per SIMD is bound by LDS fragment reads where the two launches are bound by HBM)
+                    if os.environ.get("ADT_HTSAT_MLP384", "1") != "0":
+                        # the whole MLP in one launch (round 6: one workgroup per CU on 484 registers): the hidden activation never exists --
+                        # 806 MB less HBM traffic per layer at 512 clips, 433 vs 494 us alone, +0.5 % embeds/s inside the tower
+                        # (profiles/r06/clap_mlp384_ab.txt; a lone wave per SIMD is bound by its own instruction issue where the two launches
+                        # are bound by HBM)
                         rowblock(2, x, L["mlp_pk"], C // 8, L["b1"], ln=L["ln2"], eps=self.eps, bias2=L["b2"])
                         continue
                     h = torch.empty((x.shape[0], 4 * C), dtype=BF16, device=self.dev)

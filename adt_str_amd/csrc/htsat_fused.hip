@@ -386,13 +386,14 @@ __global__ __launch_bounds__(kRbThreads, kOcc) void htsat_mlp_kernel(RbArgs a) {
   const int n_steps = n_tiles + 2;
   const int n_chunks = n_steps / SPC;
 
+  auto issue_chunk_i = [&](int c, int i) {
+    const unsigned char* src = a.wpk + static_cast<long>(c) * kChunkBytes + (wave * IPW + i) * 1024 + lane * 16;
+    unsigned char* dst = smem + (c % kRing) * kChunkBytes + (wave * IPW + i) * 1024;
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src, (__attribute__((address_space(3))) void*)dst, 16, 0, 0);
+  };
   auto issue_chunk = [&](int c) {
-    const unsigned char* src = a.wpk + static_cast<long>(c) * kChunkBytes + (wave * IPW) * 1024 + lane * 16;
-    unsigned char* dst = smem + (c % kRing) * kChunkBytes + (wave * IPW) * 1024;
 #pragma unroll
-    for (int i = 0; i < IPW; ++i)
-      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + i * 1024),
-                                       (__attribute__((address_space(3))) void*)(dst + i * 1024), 16, 0, 0);
+    for (int i = 0; i < IPW; ++i) issue_chunk_i(c, i);
   };
   // the weight stream starts first: its latency hides under the row loads and the LayerNorm
 #pragma unroll
@@ -461,7 +462,9 @@ __global__ __launch_bounds__(kRbThreads, kOcc) void htsat_mlp_kernel(RbArgs a) {
     if (c + 1 < n_chunks) wait_vm<IPW>();
     else wait_vm<0>();
     asm volatile("s_barrier" ::: "memory");
-    if (c + kDepth < n_chunks) issue_chunk(c + kDepth);
+    // kOcc == 1 (a wave alone on its SIMD): a block of IPW vector-memory instructions costs the wave ~50-100 issue cycles each with nobody to
+    // cover them -- they are issued one at a time behind the products of the step instead (step(), below; htsat_attn_big_kernel)
+    if (kOcc != 1 && c + kDepth < n_chunks) issue_chunk(c + kDepth);
   };
   auto step = [&](const int k, auto ph_tag) {
     constexpr int PH = decltype(ph_tag)::value;
@@ -503,6 +506,11 @@ __global__ __launch_bounds__(kRbThreads, kOcc) void htsat_mlp_kernel(RbArgs a) {
       __builtin_amdgcn_sched_barrier(0);
       if (i + 6 < NM)                                          // the register of fragment i takes fragment i + 6
         asm volatile("ds_read_b128 %0, %1" : "=v"(f[i % 6]) : "v"(ta + static_cast<unsigned>((i + 6) * 1024)) : "memory");
+      if constexpr (kOcc == 1 && SPC == 1) {                   // one instruction of chunk k + kDepth behind every (NM / IPW)-th product
+        constexpr int kEvery = NM / IPW;
+        if constexpr (i % kEvery == 1 && i / kEvery < IPW)
+          if (k + kDepth < n_chunks) issue_chunk_i(k + kDepth, i / kEvery);
+      }
       // a slice of GELU(k - 1): the 8 register pairs go two at a time (two independent polynomial chains: a single chain of dependent
       // packed FMAs costs a wait state per instruction), i.e. four slices spread over the NM MFMAs
 #pragma unroll
