@@ -366,6 +366,9 @@ __global__ __launch_bounds__(kRbThreads, 2) void htsat_rowblock_kernel(RbArgs a)
 // C = 384 (round 6): kOcc = 1 -- ONE workgroup per CU, a wave alone on its SIMD with the whole 512-register file (the token's 96 operand
 // registers + 192 fc2 accumulators do not fit 256) and a 3 x 48 KiB weight ring; what it buys is bytes: the hidden activation (403 MB
 // written by LN -> fc1 -> GELU and read back by the fc2 GEMM per third-stage layer at 512 clips) never exists.
+#ifdef ADT_MLP_STAMPS
+__device__ unsigned long long g_mlp_stamps[8];
+#endif
 template <int C, int SPC, int kOcc = 2>      // SPC: steps per LDS-DMA chunk
 __global__ __launch_bounds__(kRbThreads, kOcc) void htsat_mlp_kernel(RbArgs a) {
   constexpr int KS = C / 16, CT = C / 32, NM = 2 * KS;         // MFMAs (= fragments, KiB) per step
@@ -459,7 +462,7 @@ __global__ __launch_bounds__(kRbThreads, kOcc) void htsat_mlp_kernel(RbArgs a) {
   const unsigned bias_base = lds_off_f(bias_lds) + 16 * h;
 
   auto pre_chunk = [&](int c) {                                // chunk c landed everywhere; its predecessor's slot is free again
-    if (c + 1 < n_chunks) wait_vm<IPW>();
+    if (kOcc == 1 || c + 1 < n_chunks) wait_vm<IPW>();           // (kOcc == 1: a chunk -- real or re-fetched -- is always in flight behind c)
     else wait_vm<0>();
     asm volatile("s_barrier" ::: "memory");
     // kOcc == 1 (a wave alone on its SIMD): a block of IPW vector-memory instructions costs the wave ~50-100 issue cycles each with nobody to
@@ -468,6 +471,11 @@ __global__ __launch_bounds__(kRbThreads, kOcc) void htsat_mlp_kernel(RbArgs a) {
   };
   auto step = [&](const int k, auto ph_tag) {
     constexpr int PH = decltype(ph_tag)::value;
+    // kOcc == 1: where this step's DMA instructions read and write (chunk k + kDepth, clamped to the last one)
+    const int dma_c = k + kDepth < n_chunks ? k + kDepth : n_chunks - 1;
+    const unsigned char* dma_src = a.wpk + static_cast<long>(dma_c) * kChunkBytes + (wave * IPW) * 1024 + lane * 16;
+    unsigned char* dma_dst = smem + ((k + kDepth) % kRing) * kChunkBytes + (wave * IPW) * 1024;
+    (void)dma_src; (void)dma_dst;
     const unsigned ta = ring_base + static_cast<unsigned>(((k / SPC) % kRing) * kChunkBytes + (k % SPC) * NM * 1024);
     // bias of tile k - 1, whose GELU runs in this step (index clamped: the out-of-range steps at either end are never used)
     const int bt = k < 1 ? 0 : (k - 1 < n_tiles ? k - 1 : n_tiles - 1);
@@ -505,11 +513,17 @@ __global__ __launch_bounds__(kRbThreads, kOcc) void htsat_mlp_kernel(RbArgs a) {
       }
       __builtin_amdgcn_sched_barrier(0);
       if (i + 6 < NM)                                          // the register of fragment i takes fragment i + 6
-        asm volatile("ds_read_b128 %0, %1" : "=v"(f[i % 6]) : "v"(ta + static_cast<unsigned>((i + 6) * 1024)) : "memory");
+        asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(f[i % 6]) : "v"(ta), "n"((i + 6) * 1024) : "memory");      // (immediate offset: no address add per read)
       if constexpr (kOcc == 1 && SPC == 1) {                   // one instruction of chunk k + kDepth behind every (NM / IPW)-th product
         constexpr int kEvery = NM / IPW;
-        if constexpr (i % kEvery == 1 && i / kEvery < IPW)
-          if (k + kDepth < n_chunks) issue_chunk_i(k + kDepth, i / kEvery);
+        if constexpr (i % kEvery == 1 && i / kEvery < IPW) {
+          // instruction q of the chunk: 4 KiB groups from one address each, the instruction's immediate offset (added to the global AND the LDS
+          // address) steps through the group -- three address computations per step instead of twelve, no branch (past the end the last chunk
+          // is fetched again into a slot nobody reads: the counted waits stay exact)
+          constexpr int q = i / kEvery;
+          __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(dma_src + (q / 4) * 4096),
+                                           (__attribute__((address_space(3))) void*)(dma_dst + (q / 4) * 4096), 16, (q % 4) * 1024, 0);
+        }
       }
       // a slice of GELU(k - 1): the 8 register pairs go two at a time (two independent polynomial chains: a single chain of dependent
       // packed FMAs costs a wait state per instruction), i.e. four slices spread over the NM MFMAs
@@ -523,11 +537,21 @@ __global__ __launch_bounds__(kRbThreads, kOcc) void htsat_mlp_kernel(RbArgs a) {
       __builtin_amdgcn_sched_barrier(0);
     });
   };
+#ifdef ADT_MLP_STAMPS      // experiment build: cycle stamps of wave 0 of workgroup 300 around steps 10 / 11 (tools/probe/rowblock384.py prints them)
+#define ADT_MLP_STAMP(K) do { if (blockIdx.x == 300 && wave == 0 && k == 10) { const unsigned long long tn = __builtin_amdgcn_s_memtime(); if (lane == 0) g_mlp_stamps[K] = tn; } } while (0)
+#else
+#define ADT_MLP_STAMP(K) do { } while (0)
+#endif
   for (int k = 0; k < n_steps; k += 2) {                       // n_steps is even (4C / 32 + 2)
+    ADT_MLP_STAMP(0);
     if (k % SPC == 0) pre_chunk(k / SPC);
+    ADT_MLP_STAMP(1);
     step(k, std::integral_constant<int, 0>{});
+    ADT_MLP_STAMP(2);
     if ((k + 1) % SPC == 0) pre_chunk((k + 1) / SPC);
+    ADT_MLP_STAMP(3);
     step(k + 1, std::integral_constant<int, 1>{});
+    ADT_MLP_STAMP(4);
   }
   // y = acc2 + fc2 bias + x, channel 32 ct + 8g + 4h + e of the lane's token (no DMA is in flight any more: plain loads)
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -559,6 +583,15 @@ static int launch_mlp(const RbArgs& a, hipStream_t st) {
   }
   const unsigned grid = static_cast<unsigned>((a.M + kRbRows - 1) / kRbRows);
   hipLaunchKernelGGL((htsat_mlp_kernel<C, SPC, kOcc>), dim3(grid), dim3(kRbThreads), lds, st, a);
+#ifdef ADT_MLP_STAMPS
+  if (getenv("ADT_MLP_PRINT") && C == 384) {
+    unsigned long long h[8];
+    ADT_HIP_TRY(hipStreamSynchronize(st));
+    ADT_HIP_TRY(hipMemcpyFromSymbol(h, HIP_SYMBOL(g_mlp_stamps), sizeof(h)));
+    fprintf(stderr, "mlp384 stamps (cycles): pre_chunk %lld, step %lld, pre_chunk %lld, step %lld\n", static_cast<long long>(h[1] - h[0]),
+            static_cast<long long>(h[2] - h[1]), static_cast<long long>(h[3] - h[2]), static_cast<long long>(h[4] - h[3]));
+  }
+#endif
   ADT_HIP_TRY(hipGetLastError());
   return ADT_OK;
 }
@@ -962,18 +995,20 @@ __global__ __launch_bounds__(256, 1) void htsat_attn_big_kernel(AtArgs a) {
     asm volatile("ds_read_b128 %0, %4\n\tds_read_b128 %1, %4 offset:32\n\tds_read_b128 %2, %4 offset:64\n\tds_read_b128 %3, %4 offset:96"
                  : "=&v"(bv[0]), "=&v"(bv[1]), "=&v"(bv[2]), "=&v"(bv[3]) : "v"(bias_a) : "memory");
     zero_acc(acc);
-    // (Tried and measured on this kernel: a second fragment set requested one group ahead, and two accumulation chains -- neither moved the
-    // tile's ~1 700 cycles.  What did: the token's operand registers b[] must STAY in arch VGPRs; with more than ~250 live values the allocator
-    // parked them in AGPRs and moved all C/4 dwords back in front of every tile (profiles/r06/clap_attn_big.txt).)
+    // (The token's operand registers b[] must STAY in arch VGPRs: with more than ~250 live values the allocator parks them in AGPRs and moves
+    // all C/4 dwords back in front of every tile -- profiles/r06/clap_attn_big.txt.)
+    // fragments in two sets of six: group g + 1 is requested before group g's products, so that only the tile's first group waits for the LDS
+    bf16x8 f[2][6];
+    frag6(f[0], ta);
     static_for<0, KS / 6>([&](auto gc) {
       constexpr int g = decltype(gc)::value;
-      bf16x8 f[6];
-      frag6(f, ta + static_cast<unsigned>(g * 6 * 1024));
+      constexpr bool more = g + 1 < KS / 6;
+      if constexpr (more) frag6(f[(g + 1) & 1], ta + static_cast<unsigned>((g + 1) * 6 * 1024));
       static_for<0, 6>([&](auto jc) {
         constexpr int j = decltype(jc)::value;
-        wait_lgkm<5 - j>();
+        wait_lgkm<(5 - j) + (more ? 6 : 0)>();
         __builtin_amdgcn_sched_barrier(0);
-        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f[j], b[6 * g + j], acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f[g & 1][j], b[6 * g + j], acc, 0, 0, 0);      // (one chain: two were measured, twice, +-0)
         __builtin_amdgcn_sched_barrier(0);
         between(std::integral_constant<int, 6 * g + j>{});
         __builtin_amdgcn_sched_barrier(0);
@@ -1104,16 +1139,18 @@ __global__ __launch_bounds__(256, 1) void htsat_attn_big_kernel(AtArgs a) {
     ADT_ATB_STAMP(12);
     {
       const unsigned ta = smem_base + static_cast<unsigned>(((n0 + 3) & 3) * kSubBytes + lane * 16);
+      bf16x8 f[2][6];
+      frag6(f[0], ta);
       static_for<0, 2 * CT / 6>([&](auto gc) {
         constexpr int g = decltype(gc)::value;
-        bf16x8 f[6];
-        frag6(f, ta + static_cast<unsigned>(g * 6 * 1024));
+        constexpr bool more = g + 1 < 2 * CT / 6;
+        if constexpr (more) frag6(f[(g + 1) & 1], ta + static_cast<unsigned>((g + 1) * 6 * 1024));
         static_for<0, 6>([&](auto jc) {
           constexpr int j = decltype(jc)::value;
           constexpr int fi = 6 * g + j;
-          wait_lgkm<5 - j>();
+          wait_lgkm<(5 - j) + (more ? 6 : 0)>();
           __builtin_amdgcn_sched_barrier(0);
-          acc_out[fi % CT] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f[j], fi < CT ? ob0 : ob1, acc_out[fi % CT], 0, 0, 0);
+          acc_out[fi % CT] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f[g & 1][j], fi < CT ? ob0 : ob1, acc_out[fi % CT], 0, 0, 0);
           __builtin_amdgcn_sched_barrier(0);
           // behind the products: the NEXT head's 8 bias pieces (their staging slots were read in this head's softmax), then sub-chunk n0 + 5
           if constexpr (fi < 8) issue_rb_i(hd + 1, fi);
