@@ -4,8 +4,9 @@
 // (modules/clap_encoder.py:22-23; transformers ClapFeatureExtractor: "repeatpad" to 10 s @ 48 kHz, STFT 1024 /
 // hop 480 periodic Hann center=True reflect, power, 64 htk mel filters 0-14 kHz without normalisation,
 // 10*log10(max(.,1e-10))), which runs per clip in float64 numpy on the host (0.245 s/clip).
-// One wave turns two frames into two output rows: packed complex 1024-point FFT (fft1024_phases.h), in-place
-// untangling, banded mel reduction (4 lanes per filter), dB.  Ragged input: clips are concatenated, `offsets`
+// One wave turns two frames into two output rows: packed complex 1024-point FFT (pass 1 of fft1024_phases.h into the L1 layout, then K1's
+// second-generation passes 2 and 3 -- logmel2_phases.h: conflict-free 8 KiB buffer, pass-2 twiddles in registers, full-circle table; round 6:
+// 1.05 -> 0.97 ms per 512 clips, profiles/r06/clap_logmel_ab.txt), in-place untangling, banded mel reduction (4 lanes per filter), dB.  Ragged input: clips are concatenated, `offsets`
 // delimits them; repeat-padding and reflect padding are index arithmetic in the load, never materialised.
 // 16 waves per CU (8.3 KB of LDS per wave), persistent grid-stride over (clip, frame pair) items.
 #include <hip/hip_runtime.h>
@@ -33,14 +34,14 @@ __device__ __forceinline__ void wave_sync1k() {
 
 __global__ __launch_bounds__(kClapThreads) void clap_logmel_kernel(ClapArgs a) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-  cf* tw = reinterpret_cast<cf*>(smem);                                    // [512]
-  float* melw = reinterpret_cast<float*>(smem + 512 * sizeof(cf));         // [kClapMaxNnz]
-  cf* bufs = reinterpret_cast<cf*>(smem + 512 * sizeof(cf) + kClapMaxNnz * sizeof(float));
+  cf* tw = reinterpret_cast<cf*>(smem);                                    // [1024]  W_1024^j, the whole circle
+  float* melw = reinterpret_cast<float*>(smem + 1024 * sizeof(cf));        // [kClapMaxNnz]
+  cf* bufs = reinterpret_cast<cf*>(smem + 1024 * sizeof(cf) + kClapMaxNnz * sizeof(float));
   const int tid = threadIdx.x;
   const int lane_id = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  cf* buf = bufs + wave * kBuf1k;
-  for (int j = tid; j < 512; j += kClapThreads) {
+  cf* buf = bufs + wave * kL2Buf;
+  for (int j = tid; j < 1024; j += kClapThreads) {
     float s, c;
     sincospif(static_cast<float>(j) * (1.0f / 512.0f), &s, &c);
     tw[j] = cf{c, -s};
@@ -58,6 +59,9 @@ __global__ __launch_bounds__(kClapThreads) void clap_logmel_kernel(ClapArgs a) {
     mband[i] = static_cast<unsigned>(m.x) | (static_cast<unsigned>(m.y) << 11) | (static_cast<unsigned>(m.z) << 18);
   }
   __syncthreads();
+  cf tw2[2][8];                                        // pass 2's twiddles: lane constants, in registers for the whole kernel (logmel.hip)
+  l2_pass2_twiddles(lane_id, 0, tw, tw2[0]);
+  l2_pass2_twiddles(lane_id, 1, tw, tw2[1]);
   const long total_waves = static_cast<long>(gridDim.x) * kClapWaves;
   const long first = static_cast<long>(blockIdx.x) * kClapWaves + wave;
   // (clip, frame pair) without a 64-bit division per item: quotient and remainder advance by constants and one carry (logmel.hip)
@@ -70,6 +74,11 @@ __global__ __launch_bounds__(kClapThreads) void clap_logmel_kernel(ClapArgs a) {
            pair = pair + step_r >= a.pairs_per_clip ? pair + step_r - a.pairs_per_clip : pair + step_r) {
     int lane = lane_id;
     asm volatile("" : "+v"(lane));                // keep LDS address arithmetic inside the iteration (see logmel.hip)
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {                 // (... and the twiddles loop-variant for LICM: it would hoist sixteen products and spill them)
+      asm volatile("" : "+v"(tw2[0][k]));
+      asm volatile("" : "+v"(tw2[1][k]));
+    }
     if (item >= a.n_items) break;                 // wave-uniform; no workgroup barrier inside the loop
     const int f0 = 2 * pair;
     const bool has1 = f0 + 1 < a.n_frames;
@@ -77,19 +86,22 @@ __global__ __launch_bounds__(kClapThreads) void clap_logmel_kernel(ClapArgs a) {
     const int n = static_cast<int>(a.offsets[clip_i + 1] - o0);
     const float* clip = a.waves + o0;
     const int base0 = f0 * a.hop - kN1k / 2, base1 = base0 + a.hop;
-    if (base0 >= 0 && base1 + kN1k <= a.target) p1k_pass1<true>(lane, clip, n, a.target, base0, base1, has1, win, tw, buf);
-    else p1k_pass1<false>(lane, clip, n, a.target, base0, base1, has1, win, tw, buf);
-    wave_sync1k();
-    p1k_pass2(lane, 0, tw, buf);
-    __builtin_amdgcn_sched_barrier(0);
-    p1k_pass2(lane, 1, tw, buf);
+    if (base0 >= 0 && base1 + kN1k <= a.target) p1k_pass1_l1<true>(lane, clip, n, a.target, base0, base1, has1, win, tw, buf);
+    else p1k_pass1_l1<false>(lane, clip, n, a.target, base0, base1, has1, win, tw, buf);
     wave_sync1k();
     cf z[2][8];
-    p1k_pass3_load(lane, 0, buf, z[0]);
-    p1k_pass3_load(lane, 1, buf, z[1]);
+    l2_pass2_load(lane, 0, buf, z[0]);
+    l2_pass2_load(lane, 1, buf, z[1]);
     wave_sync1k();
-    p1k_pass3_store(lane, 0, z[0], buf);
-    p1k_pass3_store(lane, 1, z[1], buf);
+    l2_pass2_store_tw(lane, 0, z[0], tw2[0], buf);
+    __builtin_amdgcn_sched_barrier(0);
+    l2_pass2_store_tw(lane, 1, z[1], tw2[1], buf);
+    wave_sync1k();
+    l2_pass3_load(lane, 0, buf, z[0]);
+    l2_pass3_load(lane, 1, buf, z[1]);
+    wave_sync1k();
+    l2_pass3_store(lane, 0, z[0], buf);
+    l2_pass3_store(lane, 1, z[1], buf);
     wave_sync1k();
     p1k_untangle(lane, buf);
     wave_sync1k();
@@ -137,7 +149,7 @@ extern "C" int adt_clap_logmel_db_f32(const float* waves, const int64_t* offsets
   if (blocks > 2L * n_cu) blocks = 2L * n_cu;
   const long tw_ = blocks * kClapWaves;
   a.n_iter = static_cast<int>((a.n_items + tw_ - 1) / tw_);
-  const size_t lds = 512 * sizeof(cf) + kClapMaxNnz * sizeof(float) + kClapWaves * kBuf1k * sizeof(cf);   // 76,800 B -> 2 workgroups / CU
+  const size_t lds = 1024 * sizeof(cf) + kClapMaxNnz * sizeof(float) + kClapWaves * kL2Buf * sizeof(cf);   // 79,872 B -> 2 workgroups / CU
   static thread_local int done_for = -1;
   int dev = 0;
   ADT_HIP_TRY(hipGetDevice(&dev));

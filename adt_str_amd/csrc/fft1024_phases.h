@@ -2,29 +2,18 @@
 // used by the CLAP log-mel front end (K9): two real 1024-sample frames are packed as z = x0 + i*x1.
 //
 //   N = 1024 = 16 x 8 x 8:   n = 64*n1 + 8*n2 + n3,   k = k1 + 16*k2 + 128*k3
-//   pass 1 (1 item/lane):  A[k1,n2,n3] = W_128^(n2*k1)          * sum_n1 z[n] W_16^(n1*k1)   -> buf[n2*P + 8*k1 + n3]
-//   pass 2 (2 items/lane): B[k1,k2,n3] = W_1024^(n3*(k1+16*k2)) * sum_n2 A    W_8^(n2*k2)    -> same slots (in place)
-//   pass 3 (2 items/lane): Z[k]        =                          sum_n3 B    W_8^(n3*k3)    -> buf[k]
-// P = 130 (cf units): 64-byte runs stay 16-byte aligned, rows spread over LDS banks (same reasoning as K1).
+//   pass 1 (1 item/lane):  A[k1,n2,n3] = W_128^(n2*k1)          * sum_n1 z[n] W_16^(n1*k1)   -> L1 layout (logmel2_phases.h)
+//   pass 2 (2 items/lane): B[k1,k2,n3] = W_1024^(n3*(k1+16*k2)) * sum_n2 A    W_8^(n2*k2)    -> L2 layout   } K1's second-generation
+//   pass 3 (2 items/lane): Z[k]        =                          sum_n3 B    W_8^(n3*k3)    -> buf[k]      } passes, shared
 // Like logmel_phases.h the bodies have no cross-lane intrinsics and compile for the host
 // (tests/emu/clap_logmel_emu.cpp) as well as for gfx950.
 #pragma once
-#include "logmel_phases.h"
+#include "logmel2_phases.h"      // (brings logmel_phases.h; passes 2 / 3 and the L1 / L2 / L3 layouts of the second generation)
 
 namespace adt {
 
 constexpr int kN1k = 1024;
-constexpr int kPitch1k = 130;
-constexpr int kBuf1k = 8 * kPitch1k;            // 1040 cf = 8,320 B per wave
 constexpr int kStage1k = 560;                   // cf slot where the 2 x n_mels output rows are staged (bins use 0..512)
-
-// W_1024^j from the half-circle table tw[0..511] (W^(j+512) = -W^j)
-ADT_HD cf twiddle1k(const cf* tw, int j) {
-  j &= 1023;
-  cf v = tw[j & 511];
-  if (j & 512) { v.x = -v.x; v.y = -v.y; }
-  return v;
-}
 
 // sample `s` of a clip of `n` samples under CLAP's "repeatpad" (tile floor(target/n) times, then zeros) and the
 // reflect padding of spectrogram(center=True) at both ends of the target-length signal
@@ -35,11 +24,15 @@ ADT_HD float repeatpad_sample(const float* clip, int n, int target, int s) {
   return s < filled ? clip[s % n] : 0.0f;
 }
 
-// kInterior: both frames lie inside [0, target) -> no reflection, and the position inside the repeated clip is
-// advanced incrementally (one integer modulo per frame instead of one per sample).
+// Pass 1 -- two real frames as one complex sequence, window, radix-16 over n1, twiddle W_128^(n2 k1) -- stored into the L1 layout of
+// logmel2_phases.h, so that K1's conflict-free passes 2 and 3 (l2_pass2_*, l2_pass3_*: twiddles in registers, 16-byte runs rotated by
+// k1 >> 2) finish the 1024-point FFT (round 6; the first generation kept its own pitch-130 passes: 1.05 -> 0.97 ms per 512 clips);
+// t1k = W_1024^j for the whole circle.
+// kInterior: both frames lie inside [0, target) -> no reflection, and the position inside the repeated clip is advanced incrementally
+// (one integer modulo per frame instead of one per sample).
 template <bool kInterior>
-ADT_HD void p1k_pass1(int lane, const float* clip, int n, int target, int base0, int base1, bool has1,
-                      const float* win16, const cf* tw, cf* buf) {
+ADT_HD void p1k_pass1_l1(int lane, const float* clip, int n, int target, int base0, int base1, bool has1,
+                         const float* win16, const cf* t1k, cf* buf) {
   const int m = lane;                    // 8*n2 + n3
   const int n2 = m >> 3;
   cf z[16];
@@ -68,7 +61,10 @@ ADT_HD void p1k_pass1(int lane, const float* clip, int n, int target, int base0,
   dft16(z);
   cf sr[4], bq[4];                       // W_128^(n2*k1), k1 = 4q + r, from 6 table reads
   _Pragma("unroll")
-  for (int r = 1; r < 4; ++r) { sr[r] = twiddle1k(tw, 8 * n2 * r); bq[r] = twiddle1k(tw, 32 * n2 * r); }
+  for (int r = 1; r < 4; ++r) { sr[r] = tw1k(t1k, 8 * n2 * r); bq[r] = tw1k(t1k, 32 * n2 * r); }
+  const int b = n2 & 1;                  // L1 address of (n2, k1, n3): n2*128 + 8*(k1 ^ b) + n3 = two lane-constant bases + 8*k1
+  cf* even = buf + n2 * 128 + (m & 7) + 8 * b;
+  cf* odd = buf + n2 * 128 + (m & 7) - 8 * b;
   _Pragma("unroll")
   for (int k1 = 0; k1 < 16; ++k1) {
     const int q = k1 >> 2, r = k1 & 3;
@@ -76,37 +72,8 @@ ADT_HD void p1k_pass1(int lane, const float* clip, int n, int target, int base0,
     if (q != 0 && r != 0) v = cmul(v, cmul(bq[q], sr[r]));
     else if (q != 0) v = cmul(v, bq[q]);
     else if (r != 0) v = cmul(v, sr[r]);
-    buf[n2 * kPitch1k + 8 * k1 + (m & 7)] = v;
+    ((k1 & 1) ? odd : even)[8 * k1] = v;
   }
-}
-
-ADT_HD void p1k_pass2(int lane, int it, const cf* tw, cf* buf) {
-  const int c = lane + 64 * it;          // 8*k1 + n3
-  const int k1 = c >> 3, n3 = c & 7;
-  cf z[8];
-  _Pragma("unroll")
-  for (int n2 = 0; n2 < 8; ++n2) z[n2] = buf[n2 * kPitch1k + c];
-  dft8(z);
-  _Pragma("unroll")
-  for (int k2 = 0; k2 < 8; ++k2) buf[k2 * kPitch1k + c] = cmul(z[k2], twiddle1k(tw, n3 * (k1 + 16 * k2)));
-}
-
-ADT_HD void p1k_pass3_index(int lane, int it, int& k1, int& k2) {
-  const int t = lane & 15;
-  k1 = (t & 3) + 4 * (lane >> 4);
-  k2 = (t >> 2) + 4 * it;
-}
-ADT_HD void p1k_pass3_load(int lane, int it, const cf* buf, cf* z) {
-  int k1, k2; p1k_pass3_index(lane, it, k1, k2);
-  const cf* p = buf + k2 * kPitch1k + 8 * k1;
-  _Pragma("unroll")
-  for (int n3 = 0; n3 < 8; ++n3) z[n3] = p[n3];
-}
-ADT_HD void p1k_pass3_store(int lane, int it, cf* z, cf* buf) {
-  int k1, k2; p1k_pass3_index(lane, it, k1, k2);
-  dft8(z);
-  _Pragma("unroll")
-  for (int k3 = 0; k3 < 8; ++k3) buf[k1 + 16 * k2 + 128 * k3] = z[k3];
 }
 
 // buf[k] <- (|X0[k]|^2, |X1[k]|^2), k = 0..512, in place

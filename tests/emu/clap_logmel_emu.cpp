@@ -9,12 +9,12 @@ using namespace adt;
 
 extern "C" int emu_clap_logmel(const float* waves, const int64_t* offsets, long n_clips, int target, int hop, int n_frames,
                                const float* window, const int32_t* mel_meta, const float* mel_w, int n_mels, float amin, float* out) {
-  std::vector<cf> tw(512);
-  for (int j = 0; j < 512; ++j) {
+  std::vector<cf> tw(1024);                 // W_1024^j, the whole circle (second generation: pass 1 into L1, K1's passes 2 / 3)
+  for (int j = 0; j < 1024; ++j) {
     const double a = M_PI * j / 512.0;
     tw[j] = cf{static_cast<float>(std::cos(a)), static_cast<float>(-std::sin(a))};
   }
-  std::vector<cf> buf(kBuf1k);
+  std::vector<cf> buf(kL2Buf);
   const int pairs = (n_frames + 1) / 2;
   for (long b = 0; b < n_clips; ++b) {
     const float* clip = waves + offsets[b];
@@ -27,16 +27,18 @@ extern "C" int emu_clap_logmel(const float* waves, const int64_t* offsets, long 
       for (int lane = 0; lane < 64; ++lane) {
         float win16[16];
         for (int n1 = 0; n1 < 16; ++n1) win16[n1] = window[lane + 64 * n1];
-        if (interior) p1k_pass1<true>(lane, clip, n, target, base0, base1, has1, win16, tw.data(), buf.data());
-        else p1k_pass1<false>(lane, clip, n, target, base0, base1, has1, win16, tw.data(), buf.data());
+        if (interior) p1k_pass1_l1<true>(lane, clip, n, target, base0, base1, has1, win16, tw.data(), buf.data());
+        else p1k_pass1_l1<false>(lane, clip, n, target, base0, base1, has1, win16, tw.data(), buf.data());
       }
-      for (int it = 0; it < 2; ++it)
-        for (int lane = 0; lane < 64; ++lane) p1k_pass2(lane, it, tw.data(), buf.data());
       std::vector<cf> z(64 * 2 * 8);
       for (int it = 0; it < 2; ++it)
-        for (int lane = 0; lane < 64; ++lane) p1k_pass3_load(lane, it, buf.data(), &z[(lane * 2 + it) * 8]);
+        for (int lane = 0; lane < 64; ++lane) l2_pass2_load(lane, it, buf.data(), &z[(lane * 2 + it) * 8]);
       for (int it = 0; it < 2; ++it)
-        for (int lane = 0; lane < 64; ++lane) p1k_pass3_store(lane, it, &z[(lane * 2 + it) * 8], buf.data());
+        for (int lane = 0; lane < 64; ++lane) l2_pass2_store(lane, it, &z[(lane * 2 + it) * 8], tw.data(), buf.data());
+      for (int it = 0; it < 2; ++it)
+        for (int lane = 0; lane < 64; ++lane) l2_pass3_load(lane, it, buf.data(), &z[(lane * 2 + it) * 8]);
+      for (int it = 0; it < 2; ++it)
+        for (int lane = 0; lane < 64; ++lane) l2_pass3_store(lane, it, &z[(lane * 2 + it) * 8], buf.data());
       std::vector<cf> snap(buf);
       for (int lane = 0; lane < 64; ++lane) {
         std::vector<cf> tmp(snap);
