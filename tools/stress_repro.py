@@ -82,7 +82,18 @@ check("NT 256^2 FFN2 + bias + dropout + residual (fp32 out)", lambda: (K.gemm(x,
 wq = torch.randn((2304, 768), device=dev).bfloat16()
 check("NT 256^2 QKV (column-group tile order, 9 tile columns)", lambda: (K.gemm(a, wq, bias=torch.zeros(2304, device=dev)),))
 
-# fused HTSAT tower (K15) + K9: one forward of 64 clips, repeated
+# the split-bf16 parity arm's large products on the persistent kernels (round 6: virtual-K-tile operand map, planes split once)
+K.set_f32_products("bf16x3")
+a32 = torch.randn((M, 768), device=dev)
+w32 = torch.randn((3072, 768), device=dev) * 0.05
+x32 = torch.randn((M, 3072), device=dev) * 0.05
+check("bf16x3 NT on the persistent kernel (planes split once)", lambda: (K.gemm(a32, w32),))
+check("bf16x3 TN on the persistent kernel, split K", lambda: (K.gemm(a32, x32, trans=True),))
+K.set_f32_products("f32")
+del a32, w32, x32
+
+# fused HTSAT tower (K15) + K9: one forward of 64 clips, repeated (round 6: stages 1-2 run the one-workgroup-per-CU kernels with the sub-chunk
+# rings -- htsat_attn_big_kernel, htsat_mlp_kernel<384, 1, 1>), then of 512 clips (four workgroups per CU in sequence)
 import numpy as np
 from adt_str_amd.clap_encoder import ClapWrapper, random_init_clap_model
 wrap = ClapWrapper("random-init", dev, 48000, clap_model=random_init_clap_model(0))
@@ -92,5 +103,10 @@ flags = torch.zeros(64, dtype=torch.bool)
 flags[5] = True
 n_it = max(10, n_it // 5)
 check("CLAP features + fused HTSAT forward, 64 clips", lambda: (wrap.get_audio_features(clips, is_longer=flags),))
+clips512 = [torch.from_numpy((rng.standard_normal(int(n)) * 0.2).astype(np.float32)).to(dev) for n in rng.integers(4800, 96001, 512)]
+flags512 = torch.zeros(512, dtype=torch.bool)
+flags512[77] = True
+n_it = max(8, n_it // 2)
+check("CLAP features + fused HTSAT forward, 512 clips", lambda: (wrap.get_audio_features(clips512, is_longer=flags512),))
 print("FAILED" if bad else "all reproducible")
 sys.exit(1 if bad else 0)
