@@ -338,7 +338,7 @@ __global__ __launch_bounds__(kRbThreads, 2) void htsat_rowblock_kernel(RbArgs a)
     for (int c = 0; c < n_chunks; ++c) do_chunk(c);
   }
   if (MODE == kRbMlp) {
-    // y = acc2 + fc2 bias + x, channel 32 ct + 8g + 4h + e of the lane's token (no DMA is in flight any more: plain loads)
+    // y = acc2 (x went in at the start) + fc2 bias, channel 32 ct + 8g + 4h + e of the lane's token
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     if (row_ok) {
       float* xp = a.x + tok * C + 4 * h;
@@ -369,6 +369,12 @@ __global__ __launch_bounds__(kRbThreads, 2) void htsat_rowblock_kernel(RbArgs a)
 #ifdef ADT_MLP_STAMPS
 __device__ unsigned long long g_mlp_stamps[8];
 #endif
+#ifdef ADT_MLP_PHASES      // experiment build: where a workgroup's time goes outside the step loop (workgroups 40 and 300: first and second round)
+__device__ unsigned long long g_mlp_phases[16];
+#define ADT_MLP_PHASE(K) do { if ((blockIdx.x == 40 || blockIdx.x == 300) && wave == 0) { const unsigned long long tn = __builtin_amdgcn_s_memtime(); if (lane == 0) g_mlp_phases[(blockIdx.x == 300 ? 8 : 0) + K] = tn; } } while (0)
+#else
+#define ADT_MLP_PHASE(K) do { } while (0)
+#endif
 template <int C, int SPC, int kOcc = 2>      // SPC: steps per LDS-DMA chunk
 __global__ __launch_bounds__(kRbThreads, kOcc) void htsat_mlp_kernel(RbArgs a) {
   constexpr int KS = C / 16, CT = C / 32, NM = 2 * KS;         // MFMAs (= fragments, KiB) per step
@@ -378,7 +384,7 @@ __global__ __launch_bounds__(kRbThreads, kOcc) void htsat_mlp_kernel(RbArgs a) {
   constexpr int kDepth = 2;
   constexpr int IPW = kChunkKb / kRbWaves;
   static_assert(kChunkKb % kRbWaves == 0 && kRing * kChunkBytes <= (kOcc == 2 ? 76 : 152) * 1024, "chunks split over the waves; two workgroups per CU (one at kOcc = 1)");
-  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];   // [ring][chunk] | fc1 bias [4C] fp32
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];   // [ring][chunk] | fc1 bias [4C] | fc2 bias [C] fp32
   const int tid = threadIdx.x, lane = tid & 63, r = lane & 31, h = lane >> 5;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   long tok = static_cast<long>(blockIdx.x) * kRbRows + wave * 32 + r;
@@ -388,6 +394,7 @@ __global__ __launch_bounds__(kRbThreads, kOcc) void htsat_mlp_kernel(RbArgs a) {
   const int n_tiles = a.n_tiles;                               // hidden tiles (4C / 32)
   const int n_steps = n_tiles + 2;
   const int n_chunks = n_steps / SPC;
+  ADT_MLP_PHASE(0);
 
   auto issue_chunk_i = [&](int c, int i) {
     const unsigned char* src = a.wpk + static_cast<long>(c) * kChunkBytes + (wave * IPW + i) * 1024 + lane * 16;
@@ -404,18 +411,26 @@ __global__ __launch_bounds__(kRbThreads, kOcc) void htsat_mlp_kernel(RbArgs a) {
     if (c < n_chunks) issue_chunk(c);
 
   bf16x8 b[KS];
+  f32x16 acc2[CT];
   {
     const float* xp = a.x + tok * C + 8 * h;
     float xv[KS][8];
     float sum = 0.f;
 #pragma unroll
     for (int s = 0; s < KS; ++s) {
+#ifdef ADT_MLP_COALESCED_TEST   // timing experiment (wrong values): the same bytes with whole 256-byte row pieces per 16 lanes
+      const float* xq = a.x + (static_cast<long>(blockIdx.x) * kRbRows + wave * 32) * C;
+      const float4 v0 = *reinterpret_cast<const float4*>(xq + (((2 * s) % 8) * 4 + (lane >> 4)) * C + ((2 * s) / 8) * 64 + (lane & 15) * 4);
+      const float4 v1 = *reinterpret_cast<const float4*>(xq + (((2 * s + 1) % 8) * 4 + (lane >> 4)) * C + ((2 * s + 1) / 8) * 64 + (lane & 15) * 4);
+#else
       const float4 v0 = *reinterpret_cast<const float4*>(xp + 16 * s), v1 = *reinterpret_cast<const float4*>(xp + 16 * s + 4);
+#endif
       xv[s][0] = v0.x; xv[s][1] = v0.y; xv[s][2] = v0.z; xv[s][3] = v0.w; xv[s][4] = v1.x; xv[s][5] = v1.y; xv[s][6] = v1.z; xv[s][7] = v1.w;
 #pragma unroll
       for (int e = 0; e < 8; ++e) sum += xv[s][e];
     }
     sum += __shfl_xor(sum, 32);
+    ADT_MLP_PHASE(1);
     const float mean = sum * (1.0f / C);
     float ss = 0.f;
 #pragma unroll
@@ -434,19 +449,26 @@ __global__ __launch_bounds__(kRbThreads, kOcc) void htsat_mlp_kernel(RbArgs a) {
       for (int e = 0; e < 4; ++e)
         pk.u[e] = pack2_f(fmaf((xv[s][2 * e] - mean) * rstd, ga[2 * e], be[2 * e]), fmaf((xv[s][2 * e + 1] - mean) * rstd, ga[2 * e + 1], be[2 * e + 1]));
       b[s] = pk.v;
+      // The residual rides in the fc2 accumulators from the start (acc2 = x; the fc2 bias joins from LDS at the end) instead of being read again at the end: a third of the
+      // kernel's HBM bytes, and the exposed end of a workgroup is stores only.  The lane holds channels 16s + 8h + 0..7 of its token (operand
+      // layout); the accumulator of output tile ct holds channels 32ct + 8g + 4h + 0..3: with s = 2ct + j, groups g = 2j and 2j + 1 are the
+      // lower / upper lanes' halves of the same 16 channels, exchanged by one v_permlane32_swap per register pair.
+      const int ct = s >> 1, j = s & 1;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const auto sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(xv[s][e]), __float_as_uint(xv[s][4 + e]), false, false);
+        acc2[ct][8 * j + e] = __uint_as_float(sw[0]);
+        acc2[ct][8 * j + 4 + e] = __uint_as_float(sw[1]);
+      }
     }
   }
-  // fc1 bias -> LDS.  (Compiler-generated LDS stores: they wait for the DMAs above, which chunk 0 needs anyway.)
+  // fc1 bias | fc2 bias -> LDS.  (Compiler-generated LDS stores: they wait for the DMAs above, which chunk 0 needs anyway.)
   for (int i = tid; i < 32 * n_tiles; i += kRbThreads) bias_lds[i] = a.bias1[i];
+  for (int i = tid; i < C; i += kRbThreads) bias_lds[32 * n_tiles + i] = a.bias2[i];
   asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
 #pragma unroll
   for (int s = 0; s < KS; ++s) asm volatile("" :: "v"(b[s]));
 
-  f32x16 acc2[CT];
-#pragma unroll
-  for (int ct = 0; ct < CT; ++ct)
-#pragma unroll
-    for (int i = 0; i < 16; ++i) acc2[ct][i] = 0.f;
   f32x16 acc1[2];                                              // [k & 1]: being accumulated by fc1(k); [1 - (k & 1)]: fc1(k - 1), being GELU'd
   union HB { unsigned u[4]; bf16x8 v; };
   HB hb[2][2];                                                 // [(k - 1) & 1][s2]: written by GELU(k - 1); [k & 1][s2]: GELU(k - 2), read by fc2(k - 2)
@@ -542,6 +564,7 @@ __global__ __launch_bounds__(kRbThreads, kOcc) void htsat_mlp_kernel(RbArgs a) {
 #else
 #define ADT_MLP_STAMP(K) do { } while (0)
 #endif
+  ADT_MLP_PHASE(2);
   for (int k = 0; k < n_steps; k += 2) {                       // n_steps is even (4C / 32 + 2)
     ADT_MLP_STAMP(0);
     if (k % SPC == 0) pre_chunk(k / SPC);
@@ -553,26 +576,30 @@ __global__ __launch_bounds__(kRbThreads, kOcc) void htsat_mlp_kernel(RbArgs a) {
     step(k + 1, std::integral_constant<int, 1>{});
     ADT_MLP_STAMP(4);
   }
-  // y = acc2 + fc2 bias + x, channel 32 ct + 8g + 4h + e of the lane's token (no DMA is in flight any more: plain loads)
+  // y = acc2 (x went in at the start) + fc2 bias, channel 32 ct + 8g + 4h + e of the lane's token
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  ADT_MLP_PHASE(3);
   if (row_ok) {
     float* xp = a.x + tok * C + 4 * h;
 #pragma unroll
     for (int ct = 0; ct < CT; ++ct)
 #pragma unroll
       for (int g = 0; g < 4; ++g) {
-        const f32x4 xr = *reinterpret_cast<const f32x4*>(xp + 32 * ct + 8 * g);
-        const f32x4 b2 = *reinterpret_cast<const f32x4*>(a.bias2 + 32 * ct + 8 * g + 4 * h);
-        *reinterpret_cast<f32x4*>(xp + 32 * ct + 8 * g) = f32x4{acc2[ct][4 * g] + b2[0] + xr[0], acc2[ct][4 * g + 1] + b2[1] + xr[1],
-                                                               acc2[ct][4 * g + 2] + b2[2] + xr[2], acc2[ct][4 * g + 3] + b2[3] + xr[3]};
+        const f32x4 b2 = *reinterpret_cast<const f32x4*>(bias_lds + 32 * n_tiles + 32 * ct + 8 * g + 4 * h);
+        *reinterpret_cast<f32x4*>(xp + 32 * ct + 8 * g) = f32x4{acc2[ct][4 * g] + b2[0], acc2[ct][4 * g + 1] + b2[1], acc2[ct][4 * g + 2] + b2[2], acc2[ct][4 * g + 3] + b2[3]};
       }
   }
+  ADT_MLP_PHASE(4);
+#ifdef ADT_MLP_PHASES
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  ADT_MLP_PHASE(5);
+#endif
 }
 
 template <int C, int SPC, int kOcc = 2>
 static int launch_mlp(const RbArgs& a, hipStream_t st) {
   constexpr int kChunkBytes = SPC * 2 * (C / 16) * 1024;
-  const int lds = 3 * kChunkBytes + 32 * a.n_tiles * 4;
+  const int lds = 3 * kChunkBytes + 32 * a.n_tiles * 4 + C * 4;
   if ((a.n_tiles + 2) % SPC || (a.n_tiles & 1)) return set_error(ADT_ESHAPE, "htsat MLP kernel: step count must be even and a multiple of the chunk size");
   static thread_local int done_for = -1;
   int dev = 0;
@@ -590,6 +617,18 @@ static int launch_mlp(const RbArgs& a, hipStream_t st) {
     ADT_HIP_TRY(hipMemcpyFromSymbol(h, HIP_SYMBOL(g_mlp_stamps), sizeof(h)));
     fprintf(stderr, "mlp384 stamps (cycles): pre_chunk %lld, step %lld, pre_chunk %lld, step %lld\n", static_cast<long long>(h[1] - h[0]),
             static_cast<long long>(h[2] - h[1]), static_cast<long long>(h[3] - h[2]), static_cast<long long>(h[4] - h[3]));
+  }
+#endif
+#ifdef ADT_MLP_PHASES
+  if (getenv("ADT_MLP_PRINT") && C == 384) {
+    unsigned long long h[16];
+    ADT_HIP_TRY(hipStreamSynchronize(st));
+    ADT_HIP_TRY(hipMemcpyFromSymbol(h, HIP_SYMBOL(g_mlp_phases), sizeof(h)));
+    for (int w = 0; w < 2; ++w)
+      fprintf(stderr, "mlp384 phases, workgroup %d (ticks of s_memtime, 100 MHz): rows loaded +%lld, LN + bias + first chunks +%lld, step loop +%lld, epilogue issued +%lld, "
+              "stores done +%lld; start relative to workgroup 40: %lld\n", w ? 300 : 40, static_cast<long long>(h[8 * w + 1] - h[8 * w]), static_cast<long long>(h[8 * w + 2] - h[8 * w + 1]),
+              static_cast<long long>(h[8 * w + 3] - h[8 * w + 2]), static_cast<long long>(h[8 * w + 4] - h[8 * w + 3]), static_cast<long long>(h[8 * w + 5] - h[8 * w + 4]),
+              static_cast<long long>(h[8 * w] - h[0]));
   }
 #endif
   ADT_HIP_TRY(hipGetLastError());
@@ -667,6 +706,7 @@ __global__ __launch_bounds__(256, 2) void htsat_attn_kernel(AtArgs a) {
 
   // ---- the token row -> LayerNorm -> bf16 B operands
   bf16x8 b[KS];
+  f32x16 acc_out[CT];                                          // starts as the residual x (see htsat_mlp_kernel): no second read of the rows at the end
   {
     const float* xp = a.x + row * C + 8 * h;
     float xv[KS][8];
@@ -697,6 +737,13 @@ __global__ __launch_bounds__(256, 2) void htsat_attn_kernel(AtArgs a) {
       for (int e = 0; e < 4; ++e)
         pk.u[e] = pack2_f(fmaf((xv[s][2 * e] - mean) * rstd, ga[2 * e], be[2 * e]), fmaf((xv[s][2 * e + 1] - mean) * rstd, ga[2 * e + 1], be[2 * e + 1]));
       b[s] = pk.v;
+      // operand layout (channels 16s + 8h + 0..7) -> accumulator layout (32ct + 8g + 4h + 0..3): s = 2ct + j, groups 2j / 2j + 1, one swap per pair
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const auto sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(xv[s][e]), __float_as_uint(xv[s][4 + e]), false, false);
+        acc_out[s >> 1][8 * (s & 1) + e] = __uint_as_float(sw[0]);
+        acc_out[s >> 1][8 * (s & 1) + 4 + e] = __uint_as_float(sw[1]);
+      }
     }
   }
   float* qb_lds = reinterpret_cast<float*>(smem + kQb);
@@ -705,11 +752,6 @@ __global__ __launch_bounds__(256, 2) void htsat_attn_kernel(AtArgs a) {
 #pragma unroll
   for (int s = 0; s < KS; ++s) asm volatile("" :: "v"(b[s]));
 
-  f32x16 acc_out[CT];
-#pragma unroll
-  for (int ct = 0; ct < CT; ++ct)
-#pragma unroll
-    for (int i = 0; i < 16; ++i) acc_out[ct][i] = 0.f;
   const unsigned kx_w = smem_base + kKx + static_cast<unsigned>(((wi * 2 + tt) * 2) * 1024 + lane * 16);       // this wave's K operands (k-step s: + s KiB)
   const unsigned kx_r = smem_base + kKx + static_cast<unsigned>((wi * 2 * 2) * 1024 + lane * 16);              // the window's: + (kt * 2 + s) KiB
   const unsigned vt_b = smem_base + kVt + static_cast<unsigned>(wi * 4096);
@@ -848,19 +890,21 @@ __global__ __launch_bounds__(256, 2) void htsat_attn_kernel(AtArgs a) {
       for (int j = 0; j < 6; ++j) acc_out[j % CT] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f[j], j < CT ? ob0 : ob1, acc_out[j % CT], 0, 0, 0);
     }
   }
-  // ---- x += acc_out + bias
+  // ---- x = acc_out (x went in at the start) + bias: stores only
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   if (win_ok) {
-    float* xp = a.x + row * C + 4 * h;
+    float* __restrict__ xp = a.x + row * C + 4 * h;
+    const float* __restrict__ ob = a.out_bias + 4 * h;
 #pragma unroll
-    for (int ct = 0; ct < CT; ++ct)
+    for (int ct = 0; ct < CT; ++ct) {
+      f32x4 b2[4];
 #pragma unroll
-      for (int g = 0; g < 4; ++g) {
-        const f32x4 xr = *reinterpret_cast<const f32x4*>(xp + 32 * ct + 8 * g);
-        const f32x4 b2 = *reinterpret_cast<const f32x4*>(a.out_bias + 32 * ct + 8 * g + 4 * h);
-        *reinterpret_cast<f32x4*>(xp + 32 * ct + 8 * g) = f32x4{acc_out[ct][4 * g] + b2[0] + xr[0], acc_out[ct][4 * g + 1] + b2[1] + xr[1],
-                                                               acc_out[ct][4 * g + 2] + b2[2] + xr[2], acc_out[ct][4 * g + 3] + b2[3] + xr[3]};
-      }
+      for (int g = 0; g < 4; ++g) b2[g] = *reinterpret_cast<const f32x4*>(ob + 32 * ct + 8 * g);
+#pragma unroll
+      for (int g = 0; g < 4; ++g)
+        *reinterpret_cast<f32x4*>(xp + 32 * ct + 8 * g) = f32x4{acc_out[ct][4 * g] + b2[g][0], acc_out[ct][4 * g + 1] + b2[g][1],
+                                                               acc_out[ct][4 * g + 2] + b2[g][2], acc_out[ct][4 * g + 3] + b2[g][3]};
+    }
   }
 }
 
@@ -928,6 +972,7 @@ __global__ __launch_bounds__(256, 1) void htsat_attn_big_kernel(AtArgs a) {
   };
   // ---- the token row -> LayerNorm -> bf16 B operands (before any DMA is in flight: these are plain loads)
   bf16x8 b[KS];
+  f32x16 acc_out[CT];                                          // starts as the residual x (see htsat_mlp_kernel): no second read of the rows at the end
   {
     const float* xp = a.x + row * C + 8 * h;
     float xv[KS][8];
@@ -958,6 +1003,13 @@ __global__ __launch_bounds__(256, 1) void htsat_attn_big_kernel(AtArgs a) {
       for (int e = 0; e < 4; ++e)
         pk.u[e] = pack2_f(fmaf((xv[s][2 * e] - mean) * rstd, ga[2 * e], be[2 * e]), fmaf((xv[s][2 * e + 1] - mean) * rstd, ga[2 * e + 1], be[2 * e + 1]));
       b[s] = pk.v;
+      // operand layout (channels 16s + 8h + 0..7) -> accumulator layout (32ct + 8g + 4h + 0..3): s = 2ct + j, groups 2j / 2j + 1, one swap per pair
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const auto sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(xv[s][e]), __float_as_uint(xv[s][4 + e]), false, false);
+        acc_out[s >> 1][8 * (s & 1) + e] = __uint_as_float(sw[0]);
+        acc_out[s >> 1][8 * (s & 1) + 4 + e] = __uint_as_float(sw[1]);
+      }
     }
   }
   float* qb_lds = reinterpret_cast<float*>(smem + kQb);
@@ -972,11 +1024,6 @@ __global__ __launch_bounds__(256, 1) void htsat_attn_big_kernel(AtArgs a) {
   for (int i = 0; i < 8; ++i) issue_rb_i(0, i);
   issue_sub(1);
 
-  f32x16 acc_out[CT];
-#pragma unroll
-  for (int ct = 0; ct < CT; ++ct)
-#pragma unroll
-    for (int i = 0; i < 16; ++i) acc_out[ct][i] = 0.f;
   const unsigned kx_w = smem_base + kKx + static_cast<unsigned>(((wi * 2 + tt) * 2) * 1024 + lane * 16);       // this wave's K operands (k-step s: + s KiB)
   const unsigned kx_r = smem_base + kKx + static_cast<unsigned>((wi * 2 * 2) * 1024 + lane * 16);              // the window's: + (kt * 2 + s) KiB
   const unsigned vt_b = smem_base + kVt + static_cast<unsigned>(wi * 4096);
@@ -1161,19 +1208,21 @@ __global__ __launch_bounds__(256, 1) void htsat_attn_big_kernel(AtArgs a) {
     }
     ADT_ATB_STAMP(13);
   }
-  // ---- x += acc_out + bias
+  // ---- x = acc_out (x went in at the start) + bias: stores only
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   if (win_ok) {
-    float* xp = a.x + row * C + 4 * h;
+    float* __restrict__ xp = a.x + row * C + 4 * h;
+    const float* __restrict__ ob = a.out_bias + 4 * h;
 #pragma unroll
-    for (int ct = 0; ct < CT; ++ct)
+    for (int ct = 0; ct < CT; ++ct) {
+      f32x4 b2[4];
 #pragma unroll
-      for (int g = 0; g < 4; ++g) {
-        const f32x4 xr = *reinterpret_cast<const f32x4*>(xp + 32 * ct + 8 * g);
-        const f32x4 b2 = *reinterpret_cast<const f32x4*>(a.out_bias + 32 * ct + 8 * g + 4 * h);
-        *reinterpret_cast<f32x4*>(xp + 32 * ct + 8 * g) = f32x4{acc_out[ct][4 * g] + b2[0] + xr[0], acc_out[ct][4 * g + 1] + b2[1] + xr[1],
-                                                               acc_out[ct][4 * g + 2] + b2[2] + xr[2], acc_out[ct][4 * g + 3] + b2[3] + xr[3]};
-      }
+      for (int g = 0; g < 4; ++g) b2[g] = *reinterpret_cast<const f32x4*>(ob + 32 * ct + 8 * g);
+#pragma unroll
+      for (int g = 0; g < 4; ++g)
+        *reinterpret_cast<f32x4*>(xp + 32 * ct + 8 * g) = f32x4{acc_out[ct][4 * g] + b2[g][0], acc_out[ct][4 * g + 1] + b2[g][1],
+                                                               acc_out[ct][4 * g + 2] + b2[g][2], acc_out[ct][4 * g + 3] + b2[g][3]};
+    }
   }
 }
 
