@@ -170,6 +170,19 @@ class HtsatEncoder:
                     L = layers[-1]
                     L["mlp_pk"] = pack_rowblock_weights(2, L["w1"].float(), L["w2"].float()).to(self.dev)
                     L["mlp_pk3"] = pack_rowblock_weights(3, L["w1"].float(), L["w2"].float()).to(self.dev)
+                L = layers[-1]
+                if "attn_pk" in L and "mlp_pk" in L:
+                    # the one-launch halves with the LayerNorm's affine part folded into what follows it (W' = W diag(gamma), b' = b + W beta, from
+                    # the fp32 weights, rounded to bf16 once): the kernels then normalise only -- 4 C/16 loads of gamma / beta per token row cost a
+                    # wave alone on its SIMD ~10 k cycles of issue per workgroup (profiles/r06/clap_residual_ab.txt).  ADT_HTSAT_FOLD_LN=0: in-kernel affine.
+                    wqkv32 = torch.cat([g(a + "query.weight"), g(a + "key.weight"), g(a + "value.weight")], 0)
+                    g1, be1 = L["ln1"]
+                    L["attn_pkf"], L["attn_qkvbf"] = (t.to(self.dev) for t in pack_attn_block_weights(wqkv32 * g1[None, :], L["bqkv"] + (wqkv32 * be1[None, :]).sum(1),
+                                                                                                          L["wo"].float(), nh))
+                    w1_32 = g(q + "intermediate.dense.weight")
+                    g2, be2 = L["ln2"]
+                    L["mlp_pkf"] = pack_rowblock_weights(2, w1_32 * g2[None, :], L["w2"].float()).to(self.dev)
+                    L["b1f"] = (L["b1"] + (w1_32 * be2[None, :]).sum(1)).contiguous()           # (element-wise: no BLAS in the product)
             merge = None
             if s < len(self.depths) - 1:
                 d = f"{p}layers.{s}.downsample."
@@ -248,10 +261,18 @@ class HtsatEncoder:
                 attn_one = C == 96 or (C in (192, 384) and (big == "1" or big == str(C)))
                 if fused and "attn_pk" in L and attn_one and os.environ.get("ADT_HTSAT_ATTN", "1") != "0":
                     # the attention half in one launch: only the residual stream touches HBM
-                    _ffi.call("adt_htsat_attn_block", _ffi.dptr(x), B, R, C, nh, L["shift"], _ffi.dptr(L["ln1"][0]), _ffi.dptr(L["ln1"][1]), self.eps,
-                              _ffi.dptr(L["attn_pk"]), _ffi.dptr(L["attn_qkvb"]), _ffi.dptr(L["bo"]), _ffi.dptr(L["bias"]), L["n_bias"],
-                              1.0 / math.sqrt(24.0), st)
-                    if C != 384:
+                    fold = "attn_pkf" in L and os.environ.get("ADT_HTSAT_FOLD_LN", "1") != "0"
+                    if fold:
+                        _ffi.call("adt_htsat_attn_block", _ffi.dptr(x), B, R, C, nh, L["shift"], None, None, self.eps,
+                                  _ffi.dptr(L["attn_pkf"]), _ffi.dptr(L["attn_qkvbf"]), _ffi.dptr(L["bo"]), _ffi.dptr(L["bias"]), L["n_bias"],
+                                  1.0 / math.sqrt(24.0), st)
+                    else:
+                        _ffi.call("adt_htsat_attn_block", _ffi.dptr(x), B, R, C, nh, L["shift"], _ffi.dptr(L["ln1"][0]), _ffi.dptr(L["ln1"][1]), self.eps,
+                                  _ffi.dptr(L["attn_pk"]), _ffi.dptr(L["attn_qkvb"]), _ffi.dptr(L["bo"]), _ffi.dptr(L["bias"]), L["n_bias"],
+                                  1.0 / math.sqrt(24.0), st)
+                    if fold and (C != 384 or os.environ.get("ADT_HTSAT_MLP384", "1") != "0"):
+                        rowblock(2, x, L["mlp_pkf"], C // 8, L["b1f"], ln=None, eps=self.eps, bias2=L["b2"])
+                    elif C != 384:
                         rowblock(2, x, L["mlp_pk"], C // 8, L["b1"], ln=L["ln2"], eps=self.eps, bias2=L["b2"])
                     elif os.environ.get("ADT_HTSAT_MLP384", "1") != "0":
                         rowblock(2, x, L["mlp_pk"], C // 8, L["b1"], ln=L["ln2"], eps=self.eps, bias2=L["b2"])

@@ -167,17 +167,25 @@ __global__ __launch_bounds__(kRbThreads, 2) void htsat_rowblock_kernel(RbArgs a)
       for (int e = 0; e < 8; ++e) { const float d = xv[s][e] - mean; ss = fmaf(d, d, ss); }
     ss += __shfl_xor(ss, 32);
     const float rstd = rsqrtf(ss * (1.0f / C) + a.eps);
-#pragma unroll
-    for (int s = 0; s < KS; ++s) {
-      const float4 g0 = *reinterpret_cast<const float4*>(a.gamma + 16 * s + 8 * h), g1 = *reinterpret_cast<const float4*>(a.gamma + 16 * s + 8 * h + 4);
-      const float4 e0 = *reinterpret_cast<const float4*>(a.beta + 16 * s + 8 * h), e1 = *reinterpret_cast<const float4*>(a.beta + 16 * s + 8 * h + 4);
-      const float ga[8] = {g0.x, g0.y, g0.z, g0.w, g1.x, g1.y, g1.z, g1.w}, be[8] = {e0.x, e0.y, e0.z, e0.w, e1.x, e1.y, e1.z, e1.w};
+    // gamma == nullptr: plain normalisation -- the caller folded gamma into the columns of the following weight and W beta into its bias (the
+    // fused tower does: 4 KS loads of gamma / beta cost a lone wave ~10 k cycles of issue per workgroup, profiles/r06/clap_residual_ab.txt)
+    auto ln_pack = [&](auto affine_tag, int s) {
       union { unsigned u[4]; bf16x8 v; } pk;
+      if constexpr (decltype(affine_tag)::value) {
+        const float4 g0 = *reinterpret_cast<const float4*>(a.gamma + 16 * s + 8 * h), g1 = *reinterpret_cast<const float4*>(a.gamma + 16 * s + 8 * h + 4);
+        const float4 e0 = *reinterpret_cast<const float4*>(a.beta + 16 * s + 8 * h), e1 = *reinterpret_cast<const float4*>(a.beta + 16 * s + 8 * h + 4);
+        const float ga[8] = {g0.x, g0.y, g0.z, g0.w, g1.x, g1.y, g1.z, g1.w}, be[8] = {e0.x, e0.y, e0.z, e0.w, e1.x, e1.y, e1.z, e1.w};
 #pragma unroll
-      for (int e = 0; e < 4; ++e)
-        pk.u[e] = pack2_f(fmaf((xv[s][2 * e] - mean) * rstd, ga[2 * e], be[2 * e]), fmaf((xv[s][2 * e + 1] - mean) * rstd, ga[2 * e + 1], be[2 * e + 1]));
+        for (int e = 0; e < 4; ++e)
+          pk.u[e] = pack2_f(fmaf((xv[s][2 * e] - mean) * rstd, ga[2 * e], be[2 * e]), fmaf((xv[s][2 * e + 1] - mean) * rstd, ga[2 * e + 1], be[2 * e + 1]));
+      } else {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) pk.u[e] = pack2_f((xv[s][2 * e] - mean) * rstd, (xv[s][2 * e + 1] - mean) * rstd);
+      }
       b[s] = pk.v;
-    }
+    };
+#pragma unroll
+    for (int s = 0; s < KS; ++s) ln_pack(std::true_type{}, s);
   }
   // GEMM_RES: the residual in the accumulator layout (channel 32n + 8g + 4h + e of the lane's token), loaded before any DMA is in flight
   constexpr bool kPreloadRes = MODE == kRbGemmRes && CT * 16 <= 96;       // C = 384: 192 registers -- loaded per tile instead
@@ -375,7 +383,7 @@ __device__ unsigned long long g_mlp_phases[16];
 #else
 #define ADT_MLP_PHASE(K) do { } while (0)
 #endif
-template <int C, int SPC, int kOcc = 2>      // SPC: steps per LDS-DMA chunk
+template <int C, int SPC, int kOcc = 2, bool kAffine = true>      // SPC: steps per LDS-DMA chunk; kAffine = false: LayerNorm without gamma / beta (folded by the caller)
 __global__ __launch_bounds__(kRbThreads, kOcc) void htsat_mlp_kernel(RbArgs a) {
   constexpr int KS = C / 16, CT = C / 32, NM = 2 * KS;         // MFMAs (= fragments, KiB) per step
   constexpr int kChunkKb = SPC * NM;
@@ -439,15 +447,21 @@ __global__ __launch_bounds__(kRbThreads, kOcc) void htsat_mlp_kernel(RbArgs a) {
       for (int e = 0; e < 8; ++e) { const float d = xv[s][e] - mean; ss = fmaf(d, d, ss); }
     ss += __shfl_xor(ss, 32);
     const float rstd = rsqrtf(ss * (1.0f / C) + a.eps);
-#pragma unroll
-    for (int s = 0; s < KS; ++s) {
-      const float4 g0 = *reinterpret_cast<const float4*>(a.gamma + 16 * s + 8 * h), g1 = *reinterpret_cast<const float4*>(a.gamma + 16 * s + 8 * h + 4);
-      const float4 e0 = *reinterpret_cast<const float4*>(a.beta + 16 * s + 8 * h), e1 = *reinterpret_cast<const float4*>(a.beta + 16 * s + 8 * h + 4);
-      const float ga[8] = {g0.x, g0.y, g0.z, g0.w, g1.x, g1.y, g1.z, g1.w}, be[8] = {e0.x, e0.y, e0.z, e0.w, e1.x, e1.y, e1.z, e1.w};
+    // gamma == nullptr: plain normalisation -- the caller folded gamma into the columns of the following weight and W beta into its bias (the
+    // fused tower does: 4 KS loads of gamma / beta cost a lone wave ~10 k cycles of issue per workgroup, profiles/r06/clap_residual_ab.txt)
+    auto ln_pack = [&](auto affine_tag, int s) {
       union { unsigned u[4]; bf16x8 v; } pk;
+      if constexpr (decltype(affine_tag)::value) {
+        const float4 g0 = *reinterpret_cast<const float4*>(a.gamma + 16 * s + 8 * h), g1 = *reinterpret_cast<const float4*>(a.gamma + 16 * s + 8 * h + 4);
+        const float4 e0 = *reinterpret_cast<const float4*>(a.beta + 16 * s + 8 * h), e1 = *reinterpret_cast<const float4*>(a.beta + 16 * s + 8 * h + 4);
+        const float ga[8] = {g0.x, g0.y, g0.z, g0.w, g1.x, g1.y, g1.z, g1.w}, be[8] = {e0.x, e0.y, e0.z, e0.w, e1.x, e1.y, e1.z, e1.w};
 #pragma unroll
-      for (int e = 0; e < 4; ++e)
-        pk.u[e] = pack2_f(fmaf((xv[s][2 * e] - mean) * rstd, ga[2 * e], be[2 * e]), fmaf((xv[s][2 * e + 1] - mean) * rstd, ga[2 * e + 1], be[2 * e + 1]));
+        for (int e = 0; e < 4; ++e)
+          pk.u[e] = pack2_f(fmaf((xv[s][2 * e] - mean) * rstd, ga[2 * e], be[2 * e]), fmaf((xv[s][2 * e + 1] - mean) * rstd, ga[2 * e + 1], be[2 * e + 1]));
+      } else {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) pk.u[e] = pack2_f((xv[s][2 * e] - mean) * rstd, (xv[s][2 * e + 1] - mean) * rstd);
+      }
       b[s] = pk.v;
       // The residual rides in the fc2 accumulators from the start (acc2 = x; the fc2 bias joins from LDS at the end) instead of being read again at the end: a third of the
       // kernel's HBM bytes, and the exposed end of a workgroup is stores only.  The lane holds channels 16s + 8h + 0..7 of its token (operand
@@ -460,7 +474,9 @@ __global__ __launch_bounds__(kRbThreads, kOcc) void htsat_mlp_kernel(RbArgs a) {
         acc2[ct][8 * j + e] = __uint_as_float(sw[0]);
         acc2[ct][8 * j + 4 + e] = __uint_as_float(sw[1]);
       }
-    }
+    };
+#pragma unroll
+    for (int s = 0; s < KS; ++s) ln_pack(std::integral_constant<bool, kAffine>{}, s);
   }
   // fc1 bias | fc2 bias -> LDS.  (Compiler-generated LDS stores: they wait for the DMAs above, which chunk 0 needs anyway.)
   for (int i = tid; i < 32 * n_tiles; i += kRbThreads) bias_lds[i] = a.bias1[i];
@@ -596,8 +612,8 @@ __global__ __launch_bounds__(kRbThreads, kOcc) void htsat_mlp_kernel(RbArgs a) {
 #endif
 }
 
-template <int C, int SPC, int kOcc = 2>
-static int launch_mlp(const RbArgs& a, hipStream_t st) {
+template <int C, int SPC, int kOcc, bool kAffine>
+static int launch_mlp_(const RbArgs& a, hipStream_t st) {
   constexpr int kChunkBytes = SPC * 2 * (C / 16) * 1024;
   const int lds = 3 * kChunkBytes + 32 * a.n_tiles * 4 + C * 4;
   if ((a.n_tiles + 2) % SPC || (a.n_tiles & 1)) return set_error(ADT_ESHAPE, "htsat MLP kernel: step count must be even and a multiple of the chunk size");
@@ -605,11 +621,11 @@ static int launch_mlp(const RbArgs& a, hipStream_t st) {
   int dev = 0;
   ADT_HIP_TRY(hipGetDevice(&dev));
   if (done_for != dev) {
-    ADT_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(htsat_mlp_kernel<C, SPC, kOcc>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    ADT_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(htsat_mlp_kernel<C, SPC, kOcc, kAffine>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     done_for = dev;
   }
   const unsigned grid = static_cast<unsigned>((a.M + kRbRows - 1) / kRbRows);
-  hipLaunchKernelGGL((htsat_mlp_kernel<C, SPC, kOcc>), dim3(grid), dim3(kRbThreads), lds, st, a);
+  hipLaunchKernelGGL((htsat_mlp_kernel<C, SPC, kOcc, kAffine>), dim3(grid), dim3(kRbThreads), lds, st, a);
 #ifdef ADT_MLP_STAMPS
   if (getenv("ADT_MLP_PRINT") && C == 384) {
     unsigned long long h[8];
@@ -633,6 +649,11 @@ static int launch_mlp(const RbArgs& a, hipStream_t st) {
 #endif
   ADT_HIP_TRY(hipGetLastError());
   return ADT_OK;
+}
+
+template <int C, int SPC, int kOcc = 2>
+static int launch_mlp(const RbArgs& a, hipStream_t st) {
+  return a.gamma ? launch_mlp_<C, SPC, kOcc, true>(a, st) : launch_mlp_<C, SPC, kOcc, false>(a, st);
 }
 
 // ---- the whole attention half of a layer in one launch (C = 96: four heads of 24): x -> LayerNorm -> q | k | v -> window attention with
@@ -674,7 +695,7 @@ __device__ __forceinline__ bf16x8 acc_to_b_f(const f32x16& x, int s) {
   return r.v;
 }
 
-template <int C>
+template <int C, bool kAffine = true>      // kAffine = false: LayerNorm without gamma / beta (folded into Wq|k|v and their bias by the caller)
 __global__ __launch_bounds__(256, 2) void htsat_attn_kernel(AtArgs a) {
   constexpr int KS = C / 16, CT = C / 32, NH = C / 24;
   constexpr int kChunkKb = 3 * KS + 2 * CT, kChunkBytes = kChunkKb * 1024;
@@ -727,15 +748,21 @@ __global__ __launch_bounds__(256, 2) void htsat_attn_kernel(AtArgs a) {
       for (int e = 0; e < 8; ++e) { const float d = xv[s][e] - mean; ss = fmaf(d, d, ss); }
     ss += __shfl_xor(ss, 32);
     const float rstd = rsqrtf(ss * (1.0f / C) + a.eps);
-#pragma unroll
-    for (int s = 0; s < KS; ++s) {
-      const float4 g0 = *reinterpret_cast<const float4*>(a.gamma + 16 * s + 8 * h), g1 = *reinterpret_cast<const float4*>(a.gamma + 16 * s + 8 * h + 4);
-      const float4 e0 = *reinterpret_cast<const float4*>(a.beta + 16 * s + 8 * h), e1 = *reinterpret_cast<const float4*>(a.beta + 16 * s + 8 * h + 4);
-      const float ga[8] = {g0.x, g0.y, g0.z, g0.w, g1.x, g1.y, g1.z, g1.w}, be[8] = {e0.x, e0.y, e0.z, e0.w, e1.x, e1.y, e1.z, e1.w};
+    // gamma == nullptr: plain normalisation -- the caller folded gamma into the columns of the following weight and W beta into its bias (the
+    // fused tower does: 4 KS loads of gamma / beta cost a lone wave ~10 k cycles of issue per workgroup, profiles/r06/clap_residual_ab.txt)
+    auto ln_pack = [&](auto affine_tag, int s) {
       union { unsigned u[4]; bf16x8 v; } pk;
+      if constexpr (decltype(affine_tag)::value) {
+        const float4 g0 = *reinterpret_cast<const float4*>(a.gamma + 16 * s + 8 * h), g1 = *reinterpret_cast<const float4*>(a.gamma + 16 * s + 8 * h + 4);
+        const float4 e0 = *reinterpret_cast<const float4*>(a.beta + 16 * s + 8 * h), e1 = *reinterpret_cast<const float4*>(a.beta + 16 * s + 8 * h + 4);
+        const float ga[8] = {g0.x, g0.y, g0.z, g0.w, g1.x, g1.y, g1.z, g1.w}, be[8] = {e0.x, e0.y, e0.z, e0.w, e1.x, e1.y, e1.z, e1.w};
 #pragma unroll
-      for (int e = 0; e < 4; ++e)
-        pk.u[e] = pack2_f(fmaf((xv[s][2 * e] - mean) * rstd, ga[2 * e], be[2 * e]), fmaf((xv[s][2 * e + 1] - mean) * rstd, ga[2 * e + 1], be[2 * e + 1]));
+        for (int e = 0; e < 4; ++e)
+          pk.u[e] = pack2_f(fmaf((xv[s][2 * e] - mean) * rstd, ga[2 * e], be[2 * e]), fmaf((xv[s][2 * e + 1] - mean) * rstd, ga[2 * e + 1], be[2 * e + 1]));
+      } else {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) pk.u[e] = pack2_f((xv[s][2 * e] - mean) * rstd, (xv[s][2 * e + 1] - mean) * rstd);
+      }
       b[s] = pk.v;
       // operand layout (channels 16s + 8h + 0..7) -> accumulator layout (32ct + 8g + 4h + 0..3): s = 2ct + j, groups 2j / 2j + 1, one swap per pair
 #pragma unroll
@@ -744,7 +771,9 @@ __global__ __launch_bounds__(256, 2) void htsat_attn_kernel(AtArgs a) {
         acc_out[s >> 1][8 * (s & 1) + e] = __uint_as_float(sw[0]);
         acc_out[s >> 1][8 * (s & 1) + 4 + e] = __uint_as_float(sw[1]);
       }
-    }
+    };
+#pragma unroll
+    for (int s = 0; s < KS; ++s) ln_pack(std::integral_constant<bool, kAffine>{}, s);
   }
   float* qb_lds = reinterpret_cast<float*>(smem + kQb);
   for (int i = tid; i < NH * 96; i += 256) qb_lds[i] = a.qkv_bias[i];
@@ -925,7 +954,7 @@ __device__ unsigned long long g_atb_stamps[16];
 #else
 #define ADT_ATB_STAMP(K) do { } while (0)
 #endif
-template <int C>
+template <int C, bool kAffine = true>
 __global__ __launch_bounds__(256, 1) void htsat_attn_big_kernel(AtArgs a) {
   constexpr int KS = C / 16, CT = C / 32, NH = C / 24;
   constexpr int kSubBytes = KS * 1024;
@@ -993,15 +1022,21 @@ __global__ __launch_bounds__(256, 1) void htsat_attn_big_kernel(AtArgs a) {
       for (int e = 0; e < 8; ++e) { const float d = xv[s][e] - mean; ss = fmaf(d, d, ss); }
     ss += __shfl_xor(ss, 32);
     const float rstd = rsqrtf(ss * (1.0f / C) + a.eps);
-#pragma unroll
-    for (int s = 0; s < KS; ++s) {
-      const float4 g0 = *reinterpret_cast<const float4*>(a.gamma + 16 * s + 8 * h), g1 = *reinterpret_cast<const float4*>(a.gamma + 16 * s + 8 * h + 4);
-      const float4 e0 = *reinterpret_cast<const float4*>(a.beta + 16 * s + 8 * h), e1 = *reinterpret_cast<const float4*>(a.beta + 16 * s + 8 * h + 4);
-      const float ga[8] = {g0.x, g0.y, g0.z, g0.w, g1.x, g1.y, g1.z, g1.w}, be[8] = {e0.x, e0.y, e0.z, e0.w, e1.x, e1.y, e1.z, e1.w};
+    // gamma == nullptr: plain normalisation -- the caller folded gamma into the columns of the following weight and W beta into its bias (the
+    // fused tower does: 4 KS loads of gamma / beta cost a lone wave ~10 k cycles of issue per workgroup, profiles/r06/clap_residual_ab.txt)
+    auto ln_pack = [&](auto affine_tag, int s) {
       union { unsigned u[4]; bf16x8 v; } pk;
+      if constexpr (decltype(affine_tag)::value) {
+        const float4 g0 = *reinterpret_cast<const float4*>(a.gamma + 16 * s + 8 * h), g1 = *reinterpret_cast<const float4*>(a.gamma + 16 * s + 8 * h + 4);
+        const float4 e0 = *reinterpret_cast<const float4*>(a.beta + 16 * s + 8 * h), e1 = *reinterpret_cast<const float4*>(a.beta + 16 * s + 8 * h + 4);
+        const float ga[8] = {g0.x, g0.y, g0.z, g0.w, g1.x, g1.y, g1.z, g1.w}, be[8] = {e0.x, e0.y, e0.z, e0.w, e1.x, e1.y, e1.z, e1.w};
 #pragma unroll
-      for (int e = 0; e < 4; ++e)
-        pk.u[e] = pack2_f(fmaf((xv[s][2 * e] - mean) * rstd, ga[2 * e], be[2 * e]), fmaf((xv[s][2 * e + 1] - mean) * rstd, ga[2 * e + 1], be[2 * e + 1]));
+        for (int e = 0; e < 4; ++e)
+          pk.u[e] = pack2_f(fmaf((xv[s][2 * e] - mean) * rstd, ga[2 * e], be[2 * e]), fmaf((xv[s][2 * e + 1] - mean) * rstd, ga[2 * e + 1], be[2 * e + 1]));
+      } else {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) pk.u[e] = pack2_f((xv[s][2 * e] - mean) * rstd, (xv[s][2 * e + 1] - mean) * rstd);
+      }
       b[s] = pk.v;
       // operand layout (channels 16s + 8h + 0..7) -> accumulator layout (32ct + 8g + 4h + 0..3): s = 2ct + j, groups 2j / 2j + 1, one swap per pair
 #pragma unroll
@@ -1010,7 +1045,9 @@ __global__ __launch_bounds__(256, 1) void htsat_attn_big_kernel(AtArgs a) {
         acc_out[s >> 1][8 * (s & 1) + e] = __uint_as_float(sw[0]);
         acc_out[s >> 1][8 * (s & 1) + 4 + e] = __uint_as_float(sw[1]);
       }
-    }
+    };
+#pragma unroll
+    for (int s = 0; s < KS; ++s) ln_pack(std::integral_constant<bool, kAffine>{}, s);
   }
   float* qb_lds = reinterpret_cast<float*>(smem + kQb);
   for (int i = tid; i < NH * 96; i += 256) qb_lds[i] = a.qkv_bias[i];
@@ -1269,10 +1306,12 @@ extern "C" int adt_htsat_rowblock(int32_t mode, float* x, int64_t M, int32_t C, 
   if (C != 96 && C != 192 && C != 384) return set_error(ADT_ESHAPE, "adt_htsat_rowblock: built for C = 96, 192 and 384");
   if (C == 384 && mode == 3) return set_error(ADT_ESHAPE, "adt_htsat_rowblock: the phase-by-phase MLP (mode 3) is built for C = 96 and 192");
   if (M < 0 || n_tiles <= 0 || !x || !w_packed || !bias1) return set_error(ADT_EINVAL, "adt_htsat_rowblock: bad arguments");
-  if (mode != kRbGemmRes && (!ln_gamma || !ln_beta)) return set_error(ADT_EINVAL, "adt_htsat_rowblock: LayerNorm parameters missing");
+  // (gamma and beta both NULL: plain normalisation, the caller folded the affine part into w_packed / bias1)
+  if (mode != kRbGemmRes && ((ln_gamma == nullptr) != (ln_beta == nullptr))) return set_error(ADT_EINVAL, "adt_htsat_rowblock: give both LayerNorm parameters or neither");
   if (mode == kRbGemmRes && (!a16 || lda < C || (lda & 7) || n_tiles != C / 32)) return set_error(ADT_ESHAPE, "adt_htsat_rowblock: bad bf16 input / tile count");
   if ((mode == kRbLnGemm || mode == kRbLnGemmGelu) && (!out16 || ldo < 32 * n_tiles || (ldo & 3))) return set_error(ADT_ESHAPE, "adt_htsat_rowblock: bad bf16 output");
   if ((mode == 2 || mode == 3) && (!bias2 || n_tiles != C / 8)) return set_error(ADT_ESHAPE, "adt_htsat_rowblock: the MLP has 4C hidden units");
+  if (!ln_gamma && mode != kRbGemmRes && mode != kRbMlp) return set_error(ADT_EINVAL, "adt_htsat_rowblock: the folded LayerNorm (NULL gamma / beta) is built for mode 2");
   if (!aligned16(x) || !aligned16(w_packed) || (a16 && !aligned16(a16)) || (out16 && (reinterpret_cast<uintptr_t>(out16) & 7)))
     return set_error(ADT_EINVAL, "adt_htsat_rowblock: misaligned pointer");
   if (M == 0) return ADT_OK;
@@ -1321,7 +1360,8 @@ extern "C" int adt_htsat_merge_rowblock(const float* x, int64_t B, int32_t R, in
 extern "C" int adt_htsat_attn_block(float* x, int64_t B, int32_t R, int32_t C, int32_t heads, int32_t shift, const float* ln_gamma,
                                     const float* ln_beta, float eps, const void* w_packed, const float* qkv_bias, const float* out_bias,
                                     const float* rel_bias, int32_t n_bias_windows, float scale, void* stream) {
-  if (!x || !ln_gamma || !ln_beta || !w_packed || !qkv_bias || !out_bias || !rel_bias) return set_error(ADT_EINVAL, "adt_htsat_attn_block: null pointer");
+  if (!x || !w_packed || !qkv_bias || !out_bias || !rel_bias) return set_error(ADT_EINVAL, "adt_htsat_attn_block: null pointer");
+  if ((ln_gamma == nullptr) != (ln_beta == nullptr)) return set_error(ADT_EINVAL, "adt_htsat_attn_block: give both LayerNorm parameters or neither (folded into the weights)");
   if (!((C == 96 && heads == 4) || (C == 192 && heads == 8) || (C == 384 && heads == 16)))
     return set_error(ADT_ESHAPE, "adt_htsat_attn_block: built for C = 96 / 192 / 384 with heads of 24");
   if (B < 0 || R <= 0 || (R & 7) || shift < 0 || shift >= 8) return set_error(ADT_ESHAPE, "adt_htsat_attn_block: window 8, R % 8 == 0");
@@ -1336,21 +1376,29 @@ extern "C" int adt_htsat_attn_block(float* x, int64_t B, int32_t R, int32_t C, i
   int dev = 0;
   ADT_HIP_TRY(hipGetDevice(&dev));
   if (done_for != dev) {
-    ADT_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(htsat_attn_kernel<96>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-    ADT_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(htsat_attn_big_kernel<192>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-    ADT_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(htsat_attn_big_kernel<384>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    ADT_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(htsat_attn_kernel<96, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    ADT_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(htsat_attn_kernel<96, false>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    ADT_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(htsat_attn_big_kernel<192, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    ADT_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(htsat_attn_big_kernel<192, false>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    ADT_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(htsat_attn_big_kernel<384, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    ADT_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(htsat_attn_big_kernel<384, false>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     done_for = dev;
   }
   const dim3 grid(static_cast<unsigned>((n_windows + 1) / 2));
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  const bool affine = ln_gamma != nullptr;
   if (C == 96) {
     constexpr int kChunk = (3 * 6 + 2 * 3) * 1024;
     const int lds = 2 * kChunk + 8 * 1024 + 2 * 4096 + 4 * 96 * 4;
-    hipLaunchKernelGGL((htsat_attn_kernel<96>), grid, dim3(256), lds, static_cast<hipStream_t>(stream), a);
+    if (affine) hipLaunchKernelGGL((htsat_attn_kernel<96, true>), grid, dim3(256), lds, st, a);
+    else hipLaunchKernelGGL((htsat_attn_kernel<96, false>), grid, dim3(256), lds, st, a);
   } else {
     // ring of four C/16-KiB sub-chunks | K operands 8 KiB | V tiles 8 KiB | q|k|v bias | per-wave relative-bias staging 4 x 8 KiB
     const int lds = 4 * (C / 16) * 1024 + 8 * 1024 + 2 * 4096 + heads * 96 * 4 + 4 * 8192;
-    if (C == 192) hipLaunchKernelGGL((htsat_attn_big_kernel<192>), grid, dim3(256), lds, static_cast<hipStream_t>(stream), a);
-    else hipLaunchKernelGGL((htsat_attn_big_kernel<384>), grid, dim3(256), lds, static_cast<hipStream_t>(stream), a);
+    if (C == 192 && affine) hipLaunchKernelGGL((htsat_attn_big_kernel<192, true>), grid, dim3(256), lds, st, a);
+    else if (C == 192) hipLaunchKernelGGL((htsat_attn_big_kernel<192, false>), grid, dim3(256), lds, st, a);
+    else if (affine) hipLaunchKernelGGL((htsat_attn_big_kernel<384, true>), grid, dim3(256), lds, st, a);
+    else hipLaunchKernelGGL((htsat_attn_big_kernel<384, false>), grid, dim3(256), lds, st, a);
 #ifdef ADT_ATB_STAMPS
     if (getenv("ADT_ATB_PRINT")) {
       unsigned long long h[16];

@@ -567,7 +567,10 @@ int adt_mean_tokens(const float* x, int64_t B, int32_t T, int32_t C, float* out3
  *   product over C, output tile n, k-step s:  64 lanes x 8 bf16, lane (r, h) = W[32n + r][16s + 8h + j], j = 0..7;
  *   modes 0 / 1: tiles n = 0 .. n_tiles-1, k-steps s = 0 .. C/16-1 each;  mode 2: per hidden tile n its C/16 fragments of W1, then
  *   for s2 = 0, 1 and channel tile ct = 0 .. C/32-1 the fragment lane (r, h) = W2[32ct + r][32n + 16 s2 + 8 (j>>2) + 4h + (j&3)];
- *   n_tiles must be a multiple of adt_htsat_rowblock_chunk_tiles(mode, C) (the LDS-DMA chunk). */
+ *   n_tiles must be a multiple of adt_htsat_rowblock_chunk_tiles(mode, C) (the LDS-DMA chunk).
+ * ln_gamma = ln_beta = NULL (modes 0, 2, 4 and adt_htsat_attn_block): plain normalisation (x - mean) * rstd -- the caller has folded the affine
+ *   part into what follows, W' = W diag(gamma), bias' = bias + W beta (exact in real arithmetic; the fused tower does, it saves the kernels
+ *   4 C/16 loads per token row). */
 int adt_htsat_rowblock_chunk_tiles(int32_t mode, int32_t C);
 /* The attention half of a ClapAudioLayer in ONE launch (C = 96, 4 heads): x += out_proj(window_attention(q|k|v(LayerNorm(x)))) in place
  * (modeling_clap.py ClapAudioLayer.forward up to the first residual; shift / window partition are index math as in adt_window_attn_fwd).
