@@ -18,7 +18,7 @@ if os.environ.get("ADT_LIB_PATH"):          # said on stderr so that a bench lin
 _lock = threading.Lock()
 _lib = None
 
-ABI_VERSION = 18
+ABI_VERSION = 19
 
 i32, i64, f32, ptr = C.c_int32, C.c_int64, C.c_float, C.c_void_p
 
@@ -123,6 +123,7 @@ SIGNATURES = {
     "adt_mean_tokens": [ptr, i64, i32, i32, ptr, ptr, ptr],
     "adt_htsat_rowblock_chunk_tiles": [i32, i32],
     "adt_htsat_attn_block": [ptr, i64, i32, i32, i32, i32, ptr, ptr, f32, ptr, ptr, ptr, ptr, i32, f32, ptr],
+    "adt_htsat_layer_block": [ptr, i64, i32, i32, i32, i32, f32, ptr, ptr, ptr, ptr, i32, f32, ptr, i32, ptr, ptr, ptr],
     "adt_htsat_merge_rowblock": [ptr, i64, i32, i32, ptr, ptr, f32, ptr, i32, ptr, ptr, i64, ptr],
     "adt_htsat_rowblock": [i32, ptr, i64, i32, ptr, i64, ptr, ptr, f32, ptr, i32, ptr, ptr, ptr, i64, ptr],
     "adt_l2_normalize": [ptr, i64, i32, ptr, ptr],

@@ -19,5 +19,5 @@ int set_error(int code, const char* msg) {
 
 }  // namespace adt
 
-extern "C" int adt_version(void) { return 18; }
+extern "C" int adt_version(void) { return 19; }
 extern "C" const char* adt_last_error(void) { return adt::g_err; }

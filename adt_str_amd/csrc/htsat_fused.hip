@@ -383,108 +383,33 @@ __device__ unsigned long long g_mlp_phases[16];
 #else
 #define ADT_MLP_PHASE(K) do { } while (0)
 #endif
-template <int C, int SPC, int kOcc = 2, bool kAffine = true>      // SPC: steps per LDS-DMA chunk; kAffine = false: LayerNorm without gamma / beta (folded by the caller)
-__global__ __launch_bounds__(kRbThreads, kOcc) void htsat_mlp_kernel(RbArgs a) {
-  constexpr int KS = C / 16, CT = C / 32, NM = 2 * KS;         // MFMAs (= fragments, KiB) per step
+// The step loop of the fused MLP (fc1 of hidden tile k, GELU of k - 1, fc2 of k - 2 per step; see htsat_mlp_kernel) on a wave's 32 token rows:
+// b = the rows' LayerNorm'd operands, acc2 = the fc2 accumulators (in: the residual; out: residual + MLP without the fc2 bias).  Expects chunks
+// 0 .. kDepth-1 of the weight stream issued by mlp_issue_chunk and the fc1 bias in bias_lds (ordered by the first chunk's barrier).
+struct MlpStream { const unsigned char* wpk; int n_tiles; };
+template <int C, int SPC>
+__device__ __forceinline__ void mlp_issue_chunk(const MlpStream& a, unsigned char* smem, int c, int wave, int lane) {
+  constexpr int kChunkKb = SPC * 2 * (C / 16), kChunkBytes = kChunkKb * 1024, IPW = kChunkKb / kRbWaves;
+#pragma unroll
+  for (int i = 0; i < IPW; ++i) {
+    const unsigned char* src = a.wpk + static_cast<long>(c) * kChunkBytes + (wave * IPW + i) * 1024 + lane * 16;
+    unsigned char* dst = smem + (c % 3) * kChunkBytes + (wave * IPW + i) * 1024;
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src, (__attribute__((address_space(3))) void*)dst, 16, 0, 0);
+  }
+}
+template <int C, int SPC, int kOcc>
+__device__ __forceinline__ void mlp_steps(const MlpStream& a, unsigned char* smem, float* bias_lds, bf16x8 (&b)[C / 16], f32x16 (&acc2)[C / 32],
+                                          const int wave, const int lane, const int h) {
+  constexpr int KS = C / 16, CT = C / 32, NM = 2 * KS;
   constexpr int kChunkKb = SPC * NM;
   constexpr int kChunkBytes = kChunkKb * 1024;
   constexpr int kRing = 3;
   constexpr int kDepth = 2;
   constexpr int IPW = kChunkKb / kRbWaves;
-  static_assert(kChunkKb % kRbWaves == 0 && kRing * kChunkBytes <= (kOcc == 2 ? 76 : 152) * 1024, "chunks split over the waves; two workgroups per CU (one at kOcc = 1)");
-  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];   // [ring][chunk] | fc1 bias [4C] | fc2 bias [C] fp32
-  const int tid = threadIdx.x, lane = tid & 63, r = lane & 31, h = lane >> 5;
-  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  long tok = static_cast<long>(blockIdx.x) * kRbRows + wave * 32 + r;
-  const bool row_ok = tok < a.M;
-  if (!row_ok) tok = a.M - 1;
-  float* bias_lds = reinterpret_cast<float*>(smem + kRing * kChunkBytes);
-  const int n_tiles = a.n_tiles;                               // hidden tiles (4C / 32)
+  const int n_tiles = a.n_tiles;
   const int n_steps = n_tiles + 2;
   const int n_chunks = n_steps / SPC;
-  ADT_MLP_PHASE(0);
-
-  auto issue_chunk_i = [&](int c, int i) {
-    const unsigned char* src = a.wpk + static_cast<long>(c) * kChunkBytes + (wave * IPW + i) * 1024 + lane * 16;
-    unsigned char* dst = smem + (c % kRing) * kChunkBytes + (wave * IPW + i) * 1024;
-    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src, (__attribute__((address_space(3))) void*)dst, 16, 0, 0);
-  };
-  auto issue_chunk = [&](int c) {
-#pragma unroll
-    for (int i = 0; i < IPW; ++i) issue_chunk_i(c, i);
-  };
-  // the weight stream starts first: its latency hides under the row loads and the LayerNorm
-#pragma unroll
-  for (int c = 0; c < kDepth; ++c)
-    if (c < n_chunks) issue_chunk(c);
-
-  bf16x8 b[KS];
-  f32x16 acc2[CT];
-  {
-    const float* xp = a.x + tok * C + 8 * h;
-    float xv[KS][8];
-    float sum = 0.f;
-#pragma unroll
-    for (int s = 0; s < KS; ++s) {
-#ifdef ADT_MLP_COALESCED_TEST   // timing experiment (wrong values): the same bytes with whole 256-byte row pieces per 16 lanes
-      const float* xq = a.x + (static_cast<long>(blockIdx.x) * kRbRows + wave * 32) * C;
-      const float4 v0 = *reinterpret_cast<const float4*>(xq + (((2 * s) % 8) * 4 + (lane >> 4)) * C + ((2 * s) / 8) * 64 + (lane & 15) * 4);
-      const float4 v1 = *reinterpret_cast<const float4*>(xq + (((2 * s + 1) % 8) * 4 + (lane >> 4)) * C + ((2 * s + 1) / 8) * 64 + (lane & 15) * 4);
-#else
-      const float4 v0 = *reinterpret_cast<const float4*>(xp + 16 * s), v1 = *reinterpret_cast<const float4*>(xp + 16 * s + 4);
-#endif
-      xv[s][0] = v0.x; xv[s][1] = v0.y; xv[s][2] = v0.z; xv[s][3] = v0.w; xv[s][4] = v1.x; xv[s][5] = v1.y; xv[s][6] = v1.z; xv[s][7] = v1.w;
-#pragma unroll
-      for (int e = 0; e < 8; ++e) sum += xv[s][e];
-    }
-    sum += __shfl_xor(sum, 32);
-    ADT_MLP_PHASE(1);
-    const float mean = sum * (1.0f / C);
-    float ss = 0.f;
-#pragma unroll
-    for (int s = 0; s < KS; ++s)
-#pragma unroll
-      for (int e = 0; e < 8; ++e) { const float d = xv[s][e] - mean; ss = fmaf(d, d, ss); }
-    ss += __shfl_xor(ss, 32);
-    const float rstd = rsqrtf(ss * (1.0f / C) + a.eps);
-    // gamma == nullptr: plain normalisation -- the caller folded gamma into the columns of the following weight and W beta into its bias (the
-    // fused tower does: 4 KS loads of gamma / beta cost a lone wave ~10 k cycles of issue per workgroup, profiles/r06/clap_residual_ab.txt)
-    auto ln_pack = [&](auto affine_tag, int s) {
-      union { unsigned u[4]; bf16x8 v; } pk;
-      if constexpr (decltype(affine_tag)::value) {
-        const float4 g0 = *reinterpret_cast<const float4*>(a.gamma + 16 * s + 8 * h), g1 = *reinterpret_cast<const float4*>(a.gamma + 16 * s + 8 * h + 4);
-        const float4 e0 = *reinterpret_cast<const float4*>(a.beta + 16 * s + 8 * h), e1 = *reinterpret_cast<const float4*>(a.beta + 16 * s + 8 * h + 4);
-        const float ga[8] = {g0.x, g0.y, g0.z, g0.w, g1.x, g1.y, g1.z, g1.w}, be[8] = {e0.x, e0.y, e0.z, e0.w, e1.x, e1.y, e1.z, e1.w};
-#pragma unroll
-        for (int e = 0; e < 4; ++e)
-          pk.u[e] = pack2_f(fmaf((xv[s][2 * e] - mean) * rstd, ga[2 * e], be[2 * e]), fmaf((xv[s][2 * e + 1] - mean) * rstd, ga[2 * e + 1], be[2 * e + 1]));
-      } else {
-#pragma unroll
-        for (int e = 0; e < 4; ++e) pk.u[e] = pack2_f((xv[s][2 * e] - mean) * rstd, (xv[s][2 * e + 1] - mean) * rstd);
-      }
-      b[s] = pk.v;
-      // The residual rides in the fc2 accumulators from the start (acc2 = x; the fc2 bias joins from LDS at the end) instead of being read again at the end: a third of the
-      // kernel's HBM bytes, and the exposed end of a workgroup is stores only.  The lane holds channels 16s + 8h + 0..7 of its token (operand
-      // layout); the accumulator of output tile ct holds channels 32ct + 8g + 4h + 0..3: with s = 2ct + j, groups g = 2j and 2j + 1 are the
-      // lower / upper lanes' halves of the same 16 channels, exchanged by one v_permlane32_swap per register pair.
-      const int ct = s >> 1, j = s & 1;
-#pragma unroll
-      for (int e = 0; e < 4; ++e) {
-        const auto sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(xv[s][e]), __float_as_uint(xv[s][4 + e]), false, false);
-        acc2[ct][8 * j + e] = __uint_as_float(sw[0]);
-        acc2[ct][8 * j + 4 + e] = __uint_as_float(sw[1]);
-      }
-    };
-#pragma unroll
-    for (int s = 0; s < KS; ++s) ln_pack(std::integral_constant<bool, kAffine>{}, s);
-  }
-  // fc1 bias | fc2 bias -> LDS.  (Compiler-generated LDS stores: they wait for the DMAs above, which chunk 0 needs anyway.)
-  for (int i = tid; i < 32 * n_tiles; i += kRbThreads) bias_lds[i] = a.bias1[i];
-  for (int i = tid; i < C; i += kRbThreads) bias_lds[32 * n_tiles + i] = a.bias2[i];
-  asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
-#pragma unroll
-  for (int s = 0; s < KS; ++s) asm volatile("" :: "v"(b[s]));
-
+  auto issue_chunk = [&](int c) { mlp_issue_chunk<C, SPC>(a, smem, c, wave, lane); };
   f32x16 acc1[2];                                              // [k & 1]: being accumulated by fc1(k); [1 - (k & 1)]: fc1(k - 1), being GELU'd
   union HB { unsigned u[4]; bf16x8 v; };
   HB hb[2][2];                                                 // [(k - 1) & 1][s2]: written by GELU(k - 1); [k & 1][s2]: GELU(k - 2), read by fc2(k - 2)
@@ -592,6 +517,111 @@ __global__ __launch_bounds__(kRbThreads, kOcc) void htsat_mlp_kernel(RbArgs a) {
     step(k + 1, std::integral_constant<int, 1>{});
     ADT_MLP_STAMP(4);
   }
+}
+
+template <int C, int SPC, int kOcc = 2, bool kAffine = true>      // SPC: steps per LDS-DMA chunk; kAffine = false: LayerNorm without gamma / beta (folded by the caller)
+__global__ __launch_bounds__(kRbThreads, kOcc) void htsat_mlp_kernel(RbArgs a) {
+  constexpr int KS = C / 16, CT = C / 32, NM = 2 * KS;         // MFMAs (= fragments, KiB) per step
+  constexpr int kChunkKb = SPC * NM;
+  constexpr int kChunkBytes = kChunkKb * 1024;
+  constexpr int kRing = 3;
+  constexpr int kDepth = 2;
+  constexpr int IPW = kChunkKb / kRbWaves;
+  static_assert(kChunkKb % kRbWaves == 0 && kRing * kChunkBytes <= (kOcc == 2 ? 76 : 152) * 1024, "chunks split over the waves; two workgroups per CU (one at kOcc = 1)");
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];   // [ring][chunk] | fc1 bias [4C] | fc2 bias [C] fp32
+  const int tid = threadIdx.x, lane = tid & 63, r = lane & 31, h = lane >> 5;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  long tok = static_cast<long>(blockIdx.x) * kRbRows + wave * 32 + r;
+  const bool row_ok = tok < a.M;
+  if (!row_ok) tok = a.M - 1;
+  float* bias_lds = reinterpret_cast<float*>(smem + kRing * kChunkBytes);
+  const int n_tiles = a.n_tiles;                               // hidden tiles (4C / 32)
+  const int n_steps = n_tiles + 2;
+  const int n_chunks = n_steps / SPC;
+  ADT_MLP_PHASE(0);
+
+  auto issue_chunk_i = [&](int c, int i) {
+    const unsigned char* src = a.wpk + static_cast<long>(c) * kChunkBytes + (wave * IPW + i) * 1024 + lane * 16;
+    unsigned char* dst = smem + (c % kRing) * kChunkBytes + (wave * IPW + i) * 1024;
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src, (__attribute__((address_space(3))) void*)dst, 16, 0, 0);
+  };
+  auto issue_chunk = [&](int c) {
+#pragma unroll
+    for (int i = 0; i < IPW; ++i) issue_chunk_i(c, i);
+  };
+  // the weight stream starts first: its latency hides under the row loads and the LayerNorm
+#pragma unroll
+  for (int c = 0; c < kDepth; ++c)
+    if (c < n_chunks) issue_chunk(c);
+
+  bf16x8 b[KS];
+  f32x16 acc2[CT];
+  {
+    const float* xp = a.x + tok * C + 8 * h;
+    float xv[KS][8];
+    float sum = 0.f;
+#pragma unroll
+    for (int s = 0; s < KS; ++s) {
+#ifdef ADT_MLP_COALESCED_TEST   // timing experiment (wrong values): the same bytes with whole 256-byte row pieces per 16 lanes
+      const float* xq = a.x + (static_cast<long>(blockIdx.x) * kRbRows + wave * 32) * C;
+      const float4 v0 = *reinterpret_cast<const float4*>(xq + (((2 * s) % 8) * 4 + (lane >> 4)) * C + ((2 * s) / 8) * 64 + (lane & 15) * 4);
+      const float4 v1 = *reinterpret_cast<const float4*>(xq + (((2 * s + 1) % 8) * 4 + (lane >> 4)) * C + ((2 * s + 1) / 8) * 64 + (lane & 15) * 4);
+#else
+      const float4 v0 = *reinterpret_cast<const float4*>(xp + 16 * s), v1 = *reinterpret_cast<const float4*>(xp + 16 * s + 4);
+#endif
+      xv[s][0] = v0.x; xv[s][1] = v0.y; xv[s][2] = v0.z; xv[s][3] = v0.w; xv[s][4] = v1.x; xv[s][5] = v1.y; xv[s][6] = v1.z; xv[s][7] = v1.w;
+#pragma unroll
+      for (int e = 0; e < 8; ++e) sum += xv[s][e];
+    }
+    sum += __shfl_xor(sum, 32);
+    ADT_MLP_PHASE(1);
+    const float mean = sum * (1.0f / C);
+    float ss = 0.f;
+#pragma unroll
+    for (int s = 0; s < KS; ++s)
+#pragma unroll
+      for (int e = 0; e < 8; ++e) { const float d = xv[s][e] - mean; ss = fmaf(d, d, ss); }
+    ss += __shfl_xor(ss, 32);
+    const float rstd = rsqrtf(ss * (1.0f / C) + a.eps);
+    // gamma == nullptr: plain normalisation -- the caller folded gamma into the columns of the following weight and W beta into its bias (the
+    // fused tower does: 4 KS loads of gamma / beta cost a lone wave ~10 k cycles of issue per workgroup, profiles/r06/clap_residual_ab.txt)
+    auto ln_pack = [&](auto affine_tag, int s) {
+      union { unsigned u[4]; bf16x8 v; } pk;
+      if constexpr (decltype(affine_tag)::value) {
+        const float4 g0 = *reinterpret_cast<const float4*>(a.gamma + 16 * s + 8 * h), g1 = *reinterpret_cast<const float4*>(a.gamma + 16 * s + 8 * h + 4);
+        const float4 e0 = *reinterpret_cast<const float4*>(a.beta + 16 * s + 8 * h), e1 = *reinterpret_cast<const float4*>(a.beta + 16 * s + 8 * h + 4);
+        const float ga[8] = {g0.x, g0.y, g0.z, g0.w, g1.x, g1.y, g1.z, g1.w}, be[8] = {e0.x, e0.y, e0.z, e0.w, e1.x, e1.y, e1.z, e1.w};
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+          pk.u[e] = pack2_f(fmaf((xv[s][2 * e] - mean) * rstd, ga[2 * e], be[2 * e]), fmaf((xv[s][2 * e + 1] - mean) * rstd, ga[2 * e + 1], be[2 * e + 1]));
+      } else {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) pk.u[e] = pack2_f((xv[s][2 * e] - mean) * rstd, (xv[s][2 * e + 1] - mean) * rstd);
+      }
+      b[s] = pk.v;
+      // The residual rides in the fc2 accumulators from the start (acc2 = x; the fc2 bias joins from LDS at the end) instead of being read again at the end: a third of the
+      // kernel's HBM bytes, and the exposed end of a workgroup is stores only.  The lane holds channels 16s + 8h + 0..7 of its token (operand
+      // layout); the accumulator of output tile ct holds channels 32ct + 8g + 4h + 0..3: with s = 2ct + j, groups g = 2j and 2j + 1 are the
+      // lower / upper lanes' halves of the same 16 channels, exchanged by one v_permlane32_swap per register pair.
+      const int ct = s >> 1, j = s & 1;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const auto sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(xv[s][e]), __float_as_uint(xv[s][4 + e]), false, false);
+        acc2[ct][8 * j + e] = __uint_as_float(sw[0]);
+        acc2[ct][8 * j + 4 + e] = __uint_as_float(sw[1]);
+      }
+    };
+#pragma unroll
+    for (int s = 0; s < KS; ++s) ln_pack(std::integral_constant<bool, kAffine>{}, s);
+  }
+  // fc1 bias | fc2 bias -> LDS.  (Compiler-generated LDS stores: they wait for the DMAs above, which chunk 0 needs anyway.)
+  for (int i = tid; i < 32 * n_tiles; i += kRbThreads) bias_lds[i] = a.bias1[i];
+  for (int i = tid; i < C; i += kRbThreads) bias_lds[32 * n_tiles + i] = a.bias2[i];
+  asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+#pragma unroll
+  for (int s = 0; s < KS; ++s) asm volatile("" :: "v"(b[s]));
+
+  mlp_steps<C, SPC, kOcc>(MlpStream{a.wpk, a.n_tiles}, smem, bias_lds, b, acc2, wave, lane, h);
   // y = acc2 (x went in at the start) + fc2 bias, channel 32 ct + 8g + 4h + e of the lane's token
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   ADT_MLP_PHASE(3);
@@ -675,6 +705,8 @@ struct AtArgs {
   const float* out_bias;         // [C]
   const float* rel_bias; int n_bias_windows;       // lane-linear, as adt_window_attn_fwd
   int B, R, shift; float scale;
+  // htsat_attn_big_kernel<C, false, true> (the whole layer in one launch): the MLP half's stream, as adt_htsat_rowblock mode 2 with a folded LayerNorm
+  const unsigned char* mlp_wpk; const float* mlp_b1; const float* mlp_b2; int mlp_tiles;
 };
 __device__ __forceinline__ long at_token_row(const AtArgs& a, int b, int wy, int wx, int t) {
   const int y = (wy * 8 + (t >> 3) + a.shift) % a.R, x = (wx * 8 + (t & 7) + a.shift) % a.R;
@@ -954,7 +986,7 @@ __device__ unsigned long long g_atb_stamps[16];
 #else
 #define ADT_ATB_STAMP(K) do { } while (0)
 #endif
-template <int C, bool kAffine = true>
+template <int C, bool kAffine = true, bool kMlp = false>      // kMlp: the layer's MLP half follows in the same launch, on the rows still in the accumulators
 __global__ __launch_bounds__(256, 1) void htsat_attn_big_kernel(AtArgs a) {
   constexpr int KS = C / 16, CT = C / 32, NH = C / 24;
   constexpr int kSubBytes = KS * 1024;
@@ -1245,6 +1277,71 @@ __global__ __launch_bounds__(256, 1) void htsat_attn_big_kernel(AtArgs a) {
     }
     ADT_ATB_STAMP(13);
   }
+  if constexpr (kMlp) {
+    // ---- the MLP half on the same rows (round 6): x' = acc_out + bias stays in the accumulators -- it is the MLP's residual AND, back in operand
+    // layout, the input of its LayerNorm -- so one store and one load of the rows, a launch and the lock-step row phases of a second kernel go.
+    static_assert(!kAffine, "the one-launch layer is built with both LayerNorms folded into the weights");
+    constexpr int kMlpChunk = 2 * KS * 1024;
+    float* bias_lds = reinterpret_cast<float*>(smem + 3 * kMlpChunk);
+    const MlpStream ms{a.mlp_wpk, a.mlp_tiles};
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");      // the attention half's DMAs (the re-fetched tail included) have landed ...
+    asm volatile("s_barrier" ::: "memory");                          // ... and nobody reads its LDS any more: the MLP's ring takes it over
+    mlp_issue_chunk<C, 1>(ms, smem, 0, wave, lane);
+    mlp_issue_chunk<C, 1>(ms, smem, 1, wave, lane);
+    float sum = 0.f;
+    {
+      const float* __restrict__ ob = a.out_bias + 4 * h;
+#pragma unroll
+      for (int ct = 0; ct < CT; ++ct)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+          const f32x4 b2 = *reinterpret_cast<const f32x4*>(ob + 32 * ct + 8 * g);
+#pragma unroll
+          for (int e = 0; e < 4; ++e) { acc_out[ct][4 * g + e] += b2[e]; sum += acc_out[ct][4 * g + e]; }
+        }
+    }
+    sum += __shfl_xor(sum, 32);
+    const float mean = sum * (1.0f / C);
+    float ss = 0.f;
+#pragma unroll
+    for (int ct = 0; ct < CT; ++ct)
+#pragma unroll
+      for (int i = 0; i < 16; ++i) { const float d = acc_out[ct][i] - mean; ss = fmaf(d, d, ss); }
+    ss += __shfl_xor(ss, 32);
+    const float rstd = rsqrtf(ss * (1.0f / C) + a.eps);
+#pragma unroll
+    for (int s = 0; s < KS; ++s) {                                   // accumulator layout -> operand layout: the swap is its own inverse
+      float xv[8];
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const auto sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(acc_out[s >> 1][8 * (s & 1) + e]), __float_as_uint(acc_out[s >> 1][8 * (s & 1) + 4 + e]), false, false);
+        xv[e] = __uint_as_float(sw[0]);
+        xv[4 + e] = __uint_as_float(sw[1]);
+      }
+      union { unsigned u[4]; bf16x8 v; } pk;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) pk.u[e] = pack2_f((xv[2 * e] - mean) * rstd, (xv[2 * e + 1] - mean) * rstd);
+      b[s] = pk.v;
+    }
+    for (int i = tid; i < 32 * a.mlp_tiles; i += 256) bias_lds[i] = a.mlp_b1[i];
+    for (int i = tid; i < C; i += 256) bias_lds[32 * a.mlp_tiles + i] = a.mlp_b2[i];
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+#pragma unroll
+    for (int s = 0; s < KS; ++s) asm volatile("" :: "v"(b[s]));
+    mlp_steps<C, 1, 1>(ms, smem, bias_lds, b, acc_out, wave, lane, h);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    if (win_ok) {
+      float* xp = a.x + row * C + 4 * h;
+#pragma unroll
+      for (int ct = 0; ct < CT; ++ct)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+          const f32x4 b2 = *reinterpret_cast<const f32x4*>(bias_lds + 32 * a.mlp_tiles + 32 * ct + 8 * g + 4 * h);
+          *reinterpret_cast<f32x4*>(xp + 32 * ct + 8 * g) = f32x4{acc_out[ct][4 * g] + b2[0], acc_out[ct][4 * g + 1] + b2[1], acc_out[ct][4 * g + 2] + b2[2], acc_out[ct][4 * g + 3] + b2[3]};
+        }
+    }
+    return;
+  }
   // ---- x = acc_out (x went in at the start) + bias: stores only
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   if (win_ok) {
@@ -1411,6 +1508,37 @@ extern "C" int adt_htsat_attn_block(float* x, int64_t B, int32_t R, int32_t C, i
     }
 #endif
   }
+  ADT_HIP_TRY(hipGetLastError());
+  return ADT_OK;
+}
+
+// One ClapAudioLayer in ONE launch (C = 384, 16 heads; round 6): the attention half as adt_htsat_attn_block, then the MLP half as adt_htsat_rowblock
+// mode 2 on the rows still in the accumulators.  Both LayerNorms folded into the weights by the caller (no gamma / beta arguments).
+extern "C" int adt_htsat_layer_block(float* x, int64_t B, int32_t R, int32_t C, int32_t heads, int32_t shift, float eps, const void* attn_w_packed,
+                                     const float* qkv_bias, const float* out_bias, const float* rel_bias, int32_t n_bias_windows, float scale,
+                                     const void* mlp_w_packed, int32_t n_tiles, const float* fc1_bias, const float* fc2_bias, void* stream) {
+  if (!x || !attn_w_packed || !qkv_bias || !out_bias || !rel_bias || !mlp_w_packed || !fc1_bias || !fc2_bias) return set_error(ADT_EINVAL, "adt_htsat_layer_block: null pointer");
+  if (C != 384 || heads != 16) return set_error(ADT_ESHAPE, "adt_htsat_layer_block: built for C = 384 with 16 heads of 24");
+  if (B < 0 || R <= 0 || (R & 7) || shift < 0 || shift >= 8 || n_tiles != C / 8) return set_error(ADT_ESHAPE, "adt_htsat_layer_block: window 8, R % 8 == 0, 4C hidden units");
+  const int nw = R / 8;
+  if (n_bias_windows != 1 && n_bias_windows != nw * nw) return set_error(ADT_EINVAL, "adt_htsat_layer_block: n_bias_windows must be 1 or (R/8)^2");
+  if (!aligned16(x) || !aligned16(attn_w_packed) || !aligned16(rel_bias) || !aligned16(mlp_w_packed) || !aligned16(out_bias))
+    return set_error(ADT_EINVAL, "adt_htsat_layer_block: misaligned pointer");
+  const long n_windows = B * nw * nw;
+  if (n_windows == 0) return ADT_OK;
+  AtArgs a{x, nullptr, nullptr, eps, static_cast<const unsigned char*>(attn_w_packed), qkv_bias, out_bias, rel_bias, n_bias_windows,
+           static_cast<int>(B), R, shift, scale, static_cast<const unsigned char*>(mlp_w_packed), fc1_bias, fc2_bias, n_tiles};
+  static thread_local int done_for = -1;
+  int dev = 0;
+  ADT_HIP_TRY(hipGetDevice(&dev));
+  if (done_for != dev) {
+    ADT_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(htsat_attn_big_kernel<384, false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    done_for = dev;
+  }
+  const int lds_attn = 4 * (C / 16) * 1024 + 8 * 1024 + 2 * 4096 + heads * 96 * 4 + 4 * 8192;
+  const int lds_mlp = 3 * 2 * (C / 16) * 1024 + 32 * n_tiles * 4 + C * 4;
+  hipLaunchKernelGGL((htsat_attn_big_kernel<384, false, true>), dim3(static_cast<unsigned>((n_windows + 1) / 2)), dim3(256), lds_attn > lds_mlp ? lds_attn : lds_mlp,
+                     static_cast<hipStream_t>(stream), a);
   ADT_HIP_TRY(hipGetLastError());
   return ADT_OK;
 }

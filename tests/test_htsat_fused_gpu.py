@@ -114,6 +114,68 @@ def test_attention_block_equals_its_three_kernel_sequence(shift, C, nh):
     assert torch.equal(xf, xf2)
 
 
+@pytest.mark.parametrize("shift", [0, 4])
+def test_layer_block_equals_its_two_launches_and_folded_layernorm_equals_affine(shift):
+    """adt_htsat_layer_block (a whole C = 384 layer in one launch: the rows stay in the accumulators between the attention half and the MLP half)
+    against adt_htsat_attn_block + adt_htsat_rowblock mode 2 on the same folded weights: the same products on the same bf16 operands, only the
+    LayerNorm statistics of the MLP half are summed in another order.  And the folded LayerNorm (gamma into the weight's columns, W beta into the
+    bias; NULL gamma / beta) against the affine one in the kernel: the same function, bf16 roundings at other places."""
+    import math
+    from adt_str_amd import _ffi
+    from adt_str_amd.clap_encoder import _shift_mask, pack_attn_block_weights, pack_rowblock_weights, rowblock, window_bias_layout
+    C, nh = 384, 16
+    g = torch.Generator().manual_seed(11 + shift)
+    B, R = 3, 24
+    M = B * R * R
+    x = (torch.randn((M, C), generator=g) * 1.2).to(DEV)
+    g1, be1 = (1 + 0.1 * torch.randn(C, generator=g)).to(DEV), (0.1 * torch.randn(C, generator=g)).to(DEV)
+    g2, be2 = (1 + 0.1 * torch.randn(C, generator=g)).to(DEV), (0.1 * torch.randn(C, generator=g)).to(DEV)
+    wqkv = (torch.randn((3 * C, C), generator=g) / C ** 0.5).to(DEV)
+    bqkv = (0.2 * torch.randn(3 * C, generator=g)).to(DEV)
+    wo = (torch.randn((C, C), generator=g) / C ** 0.5).to(DEV)
+    bo = (0.1 * torch.randn(C, generator=g)).to(DEV)
+    w1 = (torch.randn((4 * C, C), generator=g) / C ** 0.5).to(DEV)
+    w2 = (torch.randn((C, 4 * C), generator=g) / (4 * C) ** 0.5).to(DEV)
+    b1, b2 = (0.1 * torch.randn(4 * C, generator=g)).to(DEV), (0.1 * torch.randn(C, generator=g)).to(DEV)
+    bias = (0.5 * torch.randn((nh, 64, 64), generator=g)).to(DEV)
+    n_bias = 1
+    if shift:
+        bias = (bias.unsqueeze(0) + _shift_mask(R, shift).to(DEV).unsqueeze(1)).contiguous()
+        n_bias = bias.shape[0]
+    bias = window_bias_layout(bias)
+    scale = 1.0 / math.sqrt(24.0)
+    # affine LayerNorms in the kernels
+    wpk, qkvb = pack_attn_block_weights(wqkv, bqkv, wo, nh)
+    mlp_pk = pack_rowblock_weights(2, w1, w2).to(DEV)
+    xa = x.clone()
+    _ffi.call("adt_htsat_attn_block", xa.data_ptr(), B, R, C, nh, shift, g1.data_ptr(), be1.data_ptr(), 1e-5, wpk.data_ptr(), qkvb.data_ptr(), bo.data_ptr(),
+              bias.data_ptr(), n_bias, scale, 0)
+    rowblock(2, xa, mlp_pk, C // 8, b1, ln=(g2, be2), eps=1e-5, bias2=b2)
+    # folded, two launches
+    wpkf, qkvbf = pack_attn_block_weights(wqkv * g1[None, :], bqkv + (wqkv * be1[None, :]).sum(1), wo, nh)
+    mlp_pkf = pack_rowblock_weights(2, w1 * g2[None, :], w2).to(DEV)
+    b1f = (b1 + (w1 * be2[None, :]).sum(1)).contiguous()
+    xf = x.clone()
+    _ffi.call("adt_htsat_attn_block", xf.data_ptr(), B, R, C, nh, shift, None, None, 1e-5, wpkf.data_ptr(), qkvbf.data_ptr(), bo.data_ptr(),
+              bias.data_ptr(), n_bias, scale, 0)
+    rowblock(2, xf, mlp_pkf, C // 8, b1f, ln=None, eps=1e-5, bias2=b2)
+    # folded, one launch
+    xl = x.clone()
+    _ffi.call("adt_htsat_layer_block", xl.data_ptr(), B, R, C, nh, shift, 1e-5, wpkf.data_ptr(), qkvbf.data_ptr(), bo.data_ptr(), bias.data_ptr(), n_bias, scale,
+              mlp_pkf.data_ptr(), C // 8, b1f.data_ptr(), b2.data_ptr(), 0)
+    ua, uf, ul = xa - x, xf - x, xl - x
+    assert float(ua.abs().max()) > 0.5
+    assert float((ul - uf).abs().max()) <= 2e-3 * float(uf.abs().max()), float((ul - uf).abs().max())        # (a changed bf16 rounding here and there: ~2e-4 measured)
+    assert float((ul - uf).abs().mean()) <= 1e-4 * float(uf.abs().mean())
+    # (measured: one launch vs two 7e-4 of max / 2e-6 of mean; folded vs affine 4e-3 / 4.5e-3 -- a bf16 ulp, the operands are rounded at other places)
+    assert float((uf - ua).abs().max()) <= 2e-2 * float(ua.abs().max())
+    assert float((uf - ua).abs().mean()) <= 1e-2 * float(ua.abs().mean())
+    xl2 = x.clone()
+    _ffi.call("adt_htsat_layer_block", xl2.data_ptr(), B, R, C, nh, shift, 1e-5, wpkf.data_ptr(), qkvbf.data_ptr(), bo.data_ptr(), bias.data_ptr(), n_bias, scale,
+              mlp_pkf.data_ptr(), C // 8, b1f.data_ptr(), b2.data_ptr(), 0)
+    assert torch.equal(xl, xl2)
+
+
 def test_fused_encoder_equals_unfused_kernel_sequence(monkeypatch):
     """The whole HTSAT forward with the fused stages against the LayerNorm / GEMM / GEMM sequence it replaces (same weights, same
     clips): the two differ only in where bf16 roundings fall."""
