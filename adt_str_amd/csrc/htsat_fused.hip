@@ -1512,13 +1512,13 @@ extern "C" int adt_htsat_attn_block(float* x, int64_t B, int32_t R, int32_t C, i
   return ADT_OK;
 }
 
-// One ClapAudioLayer in ONE launch (C = 384, 16 heads; round 6): the attention half as adt_htsat_attn_block, then the MLP half as adt_htsat_rowblock
+// One ClapAudioLayer in ONE launch (C = 192 / 384; round 6): the attention half as adt_htsat_attn_block, then the MLP half as adt_htsat_rowblock
 // mode 2 on the rows still in the accumulators.  Both LayerNorms folded into the weights by the caller (no gamma / beta arguments).
 extern "C" int adt_htsat_layer_block(float* x, int64_t B, int32_t R, int32_t C, int32_t heads, int32_t shift, float eps, const void* attn_w_packed,
                                      const float* qkv_bias, const float* out_bias, const float* rel_bias, int32_t n_bias_windows, float scale,
                                      const void* mlp_w_packed, int32_t n_tiles, const float* fc1_bias, const float* fc2_bias, void* stream) {
   if (!x || !attn_w_packed || !qkv_bias || !out_bias || !rel_bias || !mlp_w_packed || !fc1_bias || !fc2_bias) return set_error(ADT_EINVAL, "adt_htsat_layer_block: null pointer");
-  if (C != 384 || heads != 16) return set_error(ADT_ESHAPE, "adt_htsat_layer_block: built for C = 384 with 16 heads of 24");
+  if (!((C == 384 && heads == 16) || (C == 192 && heads == 8))) return set_error(ADT_ESHAPE, "adt_htsat_layer_block: built for C = 192 / 384 with heads of 24");
   if (B < 0 || R <= 0 || (R & 7) || shift < 0 || shift >= 8 || n_tiles != C / 8) return set_error(ADT_ESHAPE, "adt_htsat_layer_block: window 8, R % 8 == 0, 4C hidden units");
   const int nw = R / 8;
   if (n_bias_windows != 1 && n_bias_windows != nw * nw) return set_error(ADT_EINVAL, "adt_htsat_layer_block: n_bias_windows must be 1 or (R/8)^2");
@@ -1533,12 +1533,15 @@ extern "C" int adt_htsat_layer_block(float* x, int64_t B, int32_t R, int32_t C, 
   ADT_HIP_TRY(hipGetDevice(&dev));
   if (done_for != dev) {
     ADT_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(htsat_attn_big_kernel<384, false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    ADT_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(htsat_attn_big_kernel<192, false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     done_for = dev;
   }
   const int lds_attn = 4 * (C / 16) * 1024 + 8 * 1024 + 2 * 4096 + heads * 96 * 4 + 4 * 8192;
   const int lds_mlp = 3 * 2 * (C / 16) * 1024 + 32 * n_tiles * 4 + C * 4;
-  hipLaunchKernelGGL((htsat_attn_big_kernel<384, false, true>), dim3(static_cast<unsigned>((n_windows + 1) / 2)), dim3(256), lds_attn > lds_mlp ? lds_attn : lds_mlp,
-                     static_cast<hipStream_t>(stream), a);
+  const dim3 grid(static_cast<unsigned>((n_windows + 1) / 2));
+  const int lds = lds_attn > lds_mlp ? lds_attn : lds_mlp;
+  if (C == 384) hipLaunchKernelGGL((htsat_attn_big_kernel<384, false, true>), grid, dim3(256), lds, static_cast<hipStream_t>(stream), a);
+  else hipLaunchKernelGGL((htsat_attn_big_kernel<192, false, true>), grid, dim3(256), lds, static_cast<hipStream_t>(stream), a);
   ADT_HIP_TRY(hipGetLastError());
   return ADT_OK;
 }

@@ -584,7 +584,7 @@ int adt_htsat_attn_block(float* x, int64_t B, int32_t R, int32_t C, int32_t head
 int adt_htsat_rowblock(int32_t mode, float* x, int64_t M, int32_t C, const void* a16, int64_t lda, const float* ln_gamma,
                        const float* ln_beta, float eps, const void* w_packed, int32_t n_tiles, const float* bias1,
                        const float* bias2, void* out16, int64_t ldo, void* stream);
-/* One whole ClapAudioLayer in ONE launch (C = 384, 16 heads -- the third stage; modeling_clap.py ClapAudioLayer.forward): adt_htsat_attn_block
+/* One whole ClapAudioLayer in ONE launch (C = 192 with 8 heads or C = 384 with 16 -- the second and third stage; modeling_clap.py ClapAudioLayer.forward): adt_htsat_attn_block
  * followed by adt_htsat_rowblock mode 2 on the rows still in registers, so the residual stream is read once and written once per layer.
  * Both LayerNorms folded into the weights by the caller (see ln_gamma = NULL above): attn_w_packed / qkv_bias as adt_htsat_attn_block with
  * W' = Wq|k|v diag(gamma1), mlp_w_packed / fc1_bias as mode 2 with W1' = W1 diag(gamma2); n_tiles = C / 8. */
