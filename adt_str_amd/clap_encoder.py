@@ -263,7 +263,8 @@ class HtsatEncoder:
                     # the attention half in one launch: only the residual stream touches HBM
                     fold = "attn_pkf" in L and os.environ.get("ADT_HTSAT_FOLD_LN", "1") != "0"
                     if fold and ((C == 384 and os.environ.get("ADT_HTSAT_LAYER384", "1") != "0" and os.environ.get("ADT_HTSAT_MLP384", "1") != "0")
-                                 or (C == 192 and os.environ.get("ADT_HTSAT_LAYER192", "1") != "0")):
+                                 or (C == 192 and os.environ.get("ADT_HTSAT_LAYER192", "1") != "0")
+                                 or (C == 96 and os.environ.get("ADT_HTSAT_LAYER96", "1") != "0")):
                         # the whole layer in one launch: the rows stay in the accumulators between the halves (ADT_HTSAT_LAYER384=0: two launches)
                         _ffi.call("adt_htsat_layer_block", _ffi.dptr(x), B, R, C, nh, L["shift"], self.eps, _ffi.dptr(L["attn_pkf"]), _ffi.dptr(L["attn_qkvbf"]),
                                   _ffi.dptr(L["bo"]), _ffi.dptr(L["bias"]), L["n_bias"], 1.0 / math.sqrt(24.0), _ffi.dptr(L["mlp_pkf"]), C // 8,

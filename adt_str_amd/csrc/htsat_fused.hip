@@ -712,6 +712,75 @@ __device__ __forceinline__ long at_token_row(const AtArgs& a, int b, int wy, int
   const int y = (wy * 8 + (t >> 3) + a.shift) % a.R, x = (wx * 8 + (t & 7) + a.shift) % a.R;
   return (static_cast<long>(b) * a.R + y) * a.R + x;
 }
+
+// ---- the MLP half of a layer on the rows an attention kernel still holds (round 6: the one-launch layer): x' = acc_out + bias stays in the
+// accumulators -- it is the MLP's residual AND, back in operand layout, the input of its LayerNorm -- so one store and one load of the rows, a
+// launch and the lock-step row phases of a second kernel go.  (Both LayerNorms folded into the weights by the caller.)
+template <int C, int kOcc>
+__device__ __forceinline__ void layer_mlp_tail(const AtArgs& a, unsigned char* smem, bf16x8 (&b)[C / 16], f32x16 (&acc_out)[C / 32], const int wave, const int lane,
+                                               const int h, const int tid, const bool win_ok, const long row) {
+  constexpr int KS = C / 16, CT = C / 32;
+  constexpr int kMlpChunk = 2 * KS * 1024;
+  float* bias_lds = reinterpret_cast<float*>(smem + 3 * kMlpChunk);
+  const MlpStream ms{a.mlp_wpk, a.mlp_tiles};
+  asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");      // the attention half's DMAs (the re-fetched tail included) have landed ...
+  asm volatile("s_barrier" ::: "memory");                          // ... and nobody reads its LDS any more: the MLP's ring takes it over
+  mlp_issue_chunk<C, 1>(ms, smem, 0, wave, lane);
+  mlp_issue_chunk<C, 1>(ms, smem, 1, wave, lane);
+  float sum = 0.f;
+  {
+    const float* __restrict__ ob = a.out_bias + 4 * h;
+#pragma unroll
+    for (int ct = 0; ct < CT; ++ct)
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        const f32x4 b2 = *reinterpret_cast<const f32x4*>(ob + 32 * ct + 8 * g);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { acc_out[ct][4 * g + e] += b2[e]; sum += acc_out[ct][4 * g + e]; }
+      }
+  }
+  sum += __shfl_xor(sum, 32);
+  const float mean = sum * (1.0f / C);
+  float ss = 0.f;
+#pragma unroll
+  for (int ct = 0; ct < CT; ++ct)
+#pragma unroll
+    for (int i = 0; i < 16; ++i) { const float d = acc_out[ct][i] - mean; ss = fmaf(d, d, ss); }
+  ss += __shfl_xor(ss, 32);
+  const float rstd = rsqrtf(ss * (1.0f / C) + a.eps);
+#pragma unroll
+  for (int s = 0; s < KS; ++s) {                                   // accumulator layout -> operand layout: the swap is its own inverse
+    float xv[8];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const auto sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(acc_out[s >> 1][8 * (s & 1) + e]), __float_as_uint(acc_out[s >> 1][8 * (s & 1) + 4 + e]), false, false);
+      xv[e] = __uint_as_float(sw[0]);
+      xv[4 + e] = __uint_as_float(sw[1]);
+    }
+    union { unsigned u[4]; bf16x8 v; } pk;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) pk.u[e] = pack2_f((xv[2 * e] - mean) * rstd, (xv[2 * e + 1] - mean) * rstd);
+    b[s] = pk.v;
+  }
+  for (int i = tid; i < 32 * a.mlp_tiles; i += 256) bias_lds[i] = a.mlp_b1[i];
+  for (int i = tid; i < C; i += 256) bias_lds[32 * a.mlp_tiles + i] = a.mlp_b2[i];
+  asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+#pragma unroll
+  for (int s = 0; s < KS; ++s) asm volatile("" :: "v"(b[s]));
+  mlp_steps<C, 1, kOcc>(ms, smem, bias_lds, b, acc_out, wave, lane, h);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  if (win_ok) {
+    float* xp = a.x + row * C + 4 * h;
+#pragma unroll
+    for (int ct = 0; ct < CT; ++ct)
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        const f32x4 b2 = *reinterpret_cast<const f32x4*>(bias_lds + 32 * a.mlp_tiles + 32 * ct + 8 * g + 4 * h);
+        *reinterpret_cast<f32x4*>(xp + 32 * ct + 8 * g) = f32x4{acc_out[ct][4 * g] + b2[0], acc_out[ct][4 * g + 1] + b2[1], acc_out[ct][4 * g + 2] + b2[2], acc_out[ct][4 * g + 3] + b2[3]};
+      }
+  }
+}
+
 // (compiler-visible conversion, NOT the inline-asm pack2_f: these read MFMA results, and an asm statement gets none of the wait
 // states the hazard recognizer puts between an MFMA and a vector instruction that reads its destination -- packed by asm right
 // behind the P V chain, the context tile went into the projection without its last product)
@@ -727,7 +796,7 @@ __device__ __forceinline__ bf16x8 acc_to_b_f(const f32x16& x, int s) {
   return r.v;
 }
 
-template <int C, bool kAffine = true>      // kAffine = false: LayerNorm without gamma / beta (folded into Wq|k|v and their bias by the caller)
+template <int C, bool kAffine = true, bool kMlp = false>      // kAffine = false: LayerNorm without gamma / beta (folded into Wq|k|v and their bias by the caller); kMlp: the MLP half follows (layer_mlp_tail)
 __global__ __launch_bounds__(256, 2) void htsat_attn_kernel(AtArgs a) {
   constexpr int KS = C / 16, CT = C / 32, NH = C / 24;
   constexpr int kChunkKb = 3 * KS + 2 * CT, kChunkBytes = kChunkKb * 1024;
@@ -950,6 +1019,11 @@ __global__ __launch_bounds__(256, 2) void htsat_attn_kernel(AtArgs a) {
 #pragma unroll
       for (int j = 0; j < 6; ++j) acc_out[j % CT] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f[j], j < CT ? ob0 : ob1, acc_out[j % CT], 0, 0, 0);
     }
+  }
+  if constexpr (kMlp) {
+    static_assert(!kAffine, "the one-launch layer is built with both LayerNorms folded into the weights");
+    layer_mlp_tail<C, 2>(a, smem, b, acc_out, wave, lane, h, tid, win_ok, row);
+    return;
   }
   // ---- x = acc_out (x went in at the start) + bias: stores only
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -1278,68 +1352,8 @@ __global__ __launch_bounds__(256, 1) void htsat_attn_big_kernel(AtArgs a) {
     ADT_ATB_STAMP(13);
   }
   if constexpr (kMlp) {
-    // ---- the MLP half on the same rows (round 6): x' = acc_out + bias stays in the accumulators -- it is the MLP's residual AND, back in operand
-    // layout, the input of its LayerNorm -- so one store and one load of the rows, a launch and the lock-step row phases of a second kernel go.
     static_assert(!kAffine, "the one-launch layer is built with both LayerNorms folded into the weights");
-    constexpr int kMlpChunk = 2 * KS * 1024;
-    float* bias_lds = reinterpret_cast<float*>(smem + 3 * kMlpChunk);
-    const MlpStream ms{a.mlp_wpk, a.mlp_tiles};
-    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");      // the attention half's DMAs (the re-fetched tail included) have landed ...
-    asm volatile("s_barrier" ::: "memory");                          // ... and nobody reads its LDS any more: the MLP's ring takes it over
-    mlp_issue_chunk<C, 1>(ms, smem, 0, wave, lane);
-    mlp_issue_chunk<C, 1>(ms, smem, 1, wave, lane);
-    float sum = 0.f;
-    {
-      const float* __restrict__ ob = a.out_bias + 4 * h;
-#pragma unroll
-      for (int ct = 0; ct < CT; ++ct)
-#pragma unroll
-        for (int g = 0; g < 4; ++g) {
-          const f32x4 b2 = *reinterpret_cast<const f32x4*>(ob + 32 * ct + 8 * g);
-#pragma unroll
-          for (int e = 0; e < 4; ++e) { acc_out[ct][4 * g + e] += b2[e]; sum += acc_out[ct][4 * g + e]; }
-        }
-    }
-    sum += __shfl_xor(sum, 32);
-    const float mean = sum * (1.0f / C);
-    float ss = 0.f;
-#pragma unroll
-    for (int ct = 0; ct < CT; ++ct)
-#pragma unroll
-      for (int i = 0; i < 16; ++i) { const float d = acc_out[ct][i] - mean; ss = fmaf(d, d, ss); }
-    ss += __shfl_xor(ss, 32);
-    const float rstd = rsqrtf(ss * (1.0f / C) + a.eps);
-#pragma unroll
-    for (int s = 0; s < KS; ++s) {                                   // accumulator layout -> operand layout: the swap is its own inverse
-      float xv[8];
-#pragma unroll
-      for (int e = 0; e < 4; ++e) {
-        const auto sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(acc_out[s >> 1][8 * (s & 1) + e]), __float_as_uint(acc_out[s >> 1][8 * (s & 1) + 4 + e]), false, false);
-        xv[e] = __uint_as_float(sw[0]);
-        xv[4 + e] = __uint_as_float(sw[1]);
-      }
-      union { unsigned u[4]; bf16x8 v; } pk;
-#pragma unroll
-      for (int e = 0; e < 4; ++e) pk.u[e] = pack2_f((xv[2 * e] - mean) * rstd, (xv[2 * e + 1] - mean) * rstd);
-      b[s] = pk.v;
-    }
-    for (int i = tid; i < 32 * a.mlp_tiles; i += 256) bias_lds[i] = a.mlp_b1[i];
-    for (int i = tid; i < C; i += 256) bias_lds[32 * a.mlp_tiles + i] = a.mlp_b2[i];
-    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
-#pragma unroll
-    for (int s = 0; s < KS; ++s) asm volatile("" :: "v"(b[s]));
-    mlp_steps<C, 1, 1>(ms, smem, bias_lds, b, acc_out, wave, lane, h);
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    if (win_ok) {
-      float* xp = a.x + row * C + 4 * h;
-#pragma unroll
-      for (int ct = 0; ct < CT; ++ct)
-#pragma unroll
-        for (int g = 0; g < 4; ++g) {
-          const f32x4 b2 = *reinterpret_cast<const f32x4*>(bias_lds + 32 * a.mlp_tiles + 32 * ct + 8 * g + 4 * h);
-          *reinterpret_cast<f32x4*>(xp + 32 * ct + 8 * g) = f32x4{acc_out[ct][4 * g] + b2[0], acc_out[ct][4 * g + 1] + b2[1], acc_out[ct][4 * g + 2] + b2[2], acc_out[ct][4 * g + 3] + b2[3]};
-        }
-    }
+    layer_mlp_tail<C, 1>(a, smem, b, acc_out, wave, lane, h, tid, win_ok, row);
     return;
   }
   // ---- x = acc_out (x went in at the start) + bias: stores only
@@ -1518,7 +1532,7 @@ extern "C" int adt_htsat_layer_block(float* x, int64_t B, int32_t R, int32_t C, 
                                      const float* qkv_bias, const float* out_bias, const float* rel_bias, int32_t n_bias_windows, float scale,
                                      const void* mlp_w_packed, int32_t n_tiles, const float* fc1_bias, const float* fc2_bias, void* stream) {
   if (!x || !attn_w_packed || !qkv_bias || !out_bias || !rel_bias || !mlp_w_packed || !fc1_bias || !fc2_bias) return set_error(ADT_EINVAL, "adt_htsat_layer_block: null pointer");
-  if (!((C == 384 && heads == 16) || (C == 192 && heads == 8))) return set_error(ADT_ESHAPE, "adt_htsat_layer_block: built for C = 192 / 384 with heads of 24");
+  if (!((C == 384 && heads == 16) || (C == 192 && heads == 8) || (C == 96 && heads == 4))) return set_error(ADT_ESHAPE, "adt_htsat_layer_block: built for C = 96 / 192 / 384 with heads of 24");
   if (B < 0 || R <= 0 || (R & 7) || shift < 0 || shift >= 8 || n_tiles != C / 8) return set_error(ADT_ESHAPE, "adt_htsat_layer_block: window 8, R % 8 == 0, 4C hidden units");
   const int nw = R / 8;
   if (n_bias_windows != 1 && n_bias_windows != nw * nw) return set_error(ADT_EINVAL, "adt_htsat_layer_block: n_bias_windows must be 1 or (R/8)^2");
@@ -1534,13 +1548,15 @@ extern "C" int adt_htsat_layer_block(float* x, int64_t B, int32_t R, int32_t C, 
   if (done_for != dev) {
     ADT_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(htsat_attn_big_kernel<384, false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     ADT_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(htsat_attn_big_kernel<192, false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    ADT_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(htsat_attn_kernel<96, false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     done_for = dev;
   }
-  const int lds_attn = 4 * (C / 16) * 1024 + 8 * 1024 + 2 * 4096 + heads * 96 * 4 + 4 * 8192;
+  const int lds_attn = C == 96 ? 2 * (3 * 6 + 2 * 3) * 1024 + 8 * 1024 + 2 * 4096 + 4 * 96 * 4 : 4 * (C / 16) * 1024 + 8 * 1024 + 2 * 4096 + heads * 96 * 4 + 4 * 8192;
   const int lds_mlp = 3 * 2 * (C / 16) * 1024 + 32 * n_tiles * 4 + C * 4;
   const dim3 grid(static_cast<unsigned>((n_windows + 1) / 2));
   const int lds = lds_attn > lds_mlp ? lds_attn : lds_mlp;
   if (C == 384) hipLaunchKernelGGL((htsat_attn_big_kernel<384, false, true>), grid, dim3(256), lds, static_cast<hipStream_t>(stream), a);
+  else if (C == 96) hipLaunchKernelGGL((htsat_attn_kernel<96, false, true>), grid, dim3(256), lds, static_cast<hipStream_t>(stream), a);
   else hipLaunchKernelGGL((htsat_attn_big_kernel<192, false, true>), grid, dim3(256), lds, static_cast<hipStream_t>(stream), a);
   ADT_HIP_TRY(hipGetLastError());
   return ADT_OK;

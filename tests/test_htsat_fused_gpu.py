@@ -114,10 +114,10 @@ def test_attention_block_equals_its_three_kernel_sequence(shift, C, nh):
     assert torch.equal(xf, xf2)
 
 
-@pytest.mark.parametrize("C,nh", [(192, 8), (384, 16)])
+@pytest.mark.parametrize("C,nh", [(96, 4), (192, 8), (384, 16)])
 @pytest.mark.parametrize("shift", [0, 4])
 def test_layer_block_equals_its_two_launches_and_folded_layernorm_equals_affine(shift, C, nh):
-    """adt_htsat_layer_block (a whole C = 192 / 384 layer in one launch: the rows stay in the accumulators between the attention half and the MLP half)
+    """adt_htsat_layer_block (a whole C = 96 / 192 / 384 layer in one launch: the rows stay in the accumulators between the attention half and the MLP half)
     against adt_htsat_attn_block + adt_htsat_rowblock mode 2 on the same folded weights: the same products on the same bf16 operands, only the
     LayerNorm statistics of the MLP half are summed in another order.  And the folded LayerNorm (gamma into the weight's columns, W beta into the
     bias; NULL gamma / beta) against the affine one in the kernel: the same function, bf16 roundings at other places."""
