@@ -114,6 +114,7 @@ SIGNATURES = {
     "adt_grad_norm": [ptr, i64, f32, ptr, ptr, C.c_size_t, ptr],
     "adt_adamw_step": [ptr, ptr, ptr, ptr, ptr, i64, f32, f32, f32, f32, f32, i64, ptr, ptr, i32, ptr],
     "adt_clap_logmel_db_f32": [ptr, ptr, i64, i32, i32, i32, i32, ptr, ptr, ptr, i32, i32, f32, ptr, ptr],
+    "adt_clap_logmel_db_ptrs_f32": [ptr, ptr, i64, i32, i32, i32, i32, ptr, ptr, ptr, i32, i32, f32, ptr, ptr],
     "adt_htsat_front_f32": [ptr, i64, i64, i32, i32, i32, i32, ptr, ptr, ptr, ptr],
     "adt_htsat_patch_embed": [ptr, i64, i32, ptr, ptr, ptr, ptr, f32, i32, ptr, ptr, ptr],
     "adt_htsat_fusion_embed_workspace_bytes": [i32, i32],
@@ -121,6 +122,7 @@ SIGNATURES = {
     "adt_window_attn_fwd": [ptr, i64, ptr, i64, ptr, i32, i64, i32, i32, i32, i32, f32, ptr],
     "adt_patch_merge_ln": [ptr, i64, i32, i32, ptr, ptr, f32, ptr, ptr],
     "adt_mean_tokens": [ptr, i64, i32, i32, ptr, ptr, ptr],
+    "adt_ln_mean_tokens": [ptr, i64, i32, i32, ptr, ptr, f32, ptr, ptr, ptr],
     "adt_htsat_rowblock_chunk_tiles": [i32, i32],
     "adt_htsat_attn_block": [ptr, i64, i32, i32, i32, i32, ptr, ptr, f32, ptr, ptr, ptr, ptr, i32, f32, ptr],
     "adt_htsat_layer_block": [ptr, i64, i32, i32, i32, i32, f32, ptr, ptr, ptr, ptr, i32, f32, ptr, i32, ptr, ptr, ptr],

@@ -341,11 +341,12 @@ class HtsatEncoder:
                 _ffi.call("adt_patch_merge_ln", _ffi.dptr(x), B, R, C, _ffi.dptr(S["merge"]["norm"][0]), _ffi.dptr(S["merge"]["norm"][1]),
                           1e-5, _ffi.dptr(m16), st)
                 x = K.gemm(m16, S["merge"]["w"], out_dtype=F32)
-        xf, _, _, _ = K.layernorm_fwd(x, *self.final_ln, eps=1e-5, want16=False)
-        Cf, Tf = xf.shape[1], xf.shape[0] // B
+        Cf, Tf = x.shape[1], x.shape[0] // B
         pooled = torch.empty((B, Cf), dtype=F32, device=self.dev)
         pooled16 = torch.empty((B, Cf), dtype=BF16, device=self.dev)
-        _ffi.call("adt_mean_tokens", _ffi.dptr(xf), B, Tf, Cf, _ffi.dptr(pooled), _ffi.dptr(pooled16), st)
+        # final LayerNorm + mean over the clip's tokens in one pass (the normalised rows are never written)
+        _ffi.call("adt_ln_mean_tokens", _ffi.dptr(x), B, Tf, Cf, _ffi.dptr(self.final_ln[0]), _ffi.dptr(self.final_ln[1]), 1e-5, _ffi.dptr(pooled),
+                  _ffi.dptr(pooled16), st)
         w1, b1, w2, b2 = self.proj
         p1 = K.gemm(pooled16, w1, bias=b1, act=2)
         p2 = K.gemm(p1, w2, bias=b2, out_dtype=F32)

@@ -21,7 +21,8 @@ constexpr int kClapThreads = 64 * kClapWaves;
 constexpr int kClapMaxNnz = 1536;
 
 struct ClapArgs {
-  const float* waves; const long* offsets; int n_clips; int target; int hop; int n_frames; int pairs_per_clip;
+  const float* waves; const float* const* clip_ptrs;      // clip b = clip_ptrs ? clip_ptrs[b] : waves + offsets[b]
+  const long* offsets; int n_clips; int target; int hop; int n_frames; int pairs_per_clip;
   const float* window; const int4* mel_meta; const float* mel_w; int n_mels; int mel_nnz; float amin;
   float* out; long n_items; int n_iter;
 };
@@ -84,7 +85,7 @@ __global__ __launch_bounds__(kClapThreads) void clap_logmel_kernel(ClapArgs a) {
     const bool has1 = f0 + 1 < a.n_frames;
     const long o0 = a.offsets[clip_i];
     const int n = static_cast<int>(a.offsets[clip_i + 1] - o0);
-    const float* clip = a.waves + o0;
+    const float* clip = a.clip_ptrs ? a.clip_ptrs[clip_i] : a.waves + o0;
     const int base0 = f0 * a.hop - kN1k / 2, base1 = base0 + a.hop;
     if (base0 >= 0 && base1 + kN1k <= a.target) p1k_pass1_l1<true>(lane, clip, n, a.target, base0, base1, has1, win, tw, buf);
     else p1k_pass1_l1<false>(lane, clip, n, a.target, base0, base1, has1, win, tw, buf);
@@ -125,11 +126,11 @@ __global__ __launch_bounds__(kClapThreads) void clap_logmel_kernel(ClapArgs a) {
 
 }  // namespace adt
 
-extern "C" int adt_clap_logmel_db_f32(const float* waves, const int64_t* offsets, int64_t n_clips, int32_t target_len, int32_t n_fft,
-                                      int32_t hop, int32_t n_frames, const float* window, const int32_t* mel_meta, const float* mel_w,
-                                      int32_t n_mels, int32_t mel_nnz, float amin, float* out, void* stream) {
+static int clap_logmel_impl(const float* waves, const float* const* clip_ptrs, const int64_t* offsets, int64_t n_clips, int32_t target_len, int32_t n_fft,
+                            int32_t hop, int32_t n_frames, const float* window, const int32_t* mel_meta, const float* mel_w,
+                            int32_t n_mels, int32_t mel_nnz, float amin, float* out, void* stream) {
   using namespace adt;
-  if (!waves || !offsets || !window || !mel_meta || !mel_w || !out) return set_error(ADT_EINVAL, "adt_clap_logmel_db_f32: null pointer");
+  if ((!waves && !clip_ptrs) || !offsets || !window || !mel_meta || !mel_w || !out) return set_error(ADT_EINVAL, "adt_clap_logmel_db_f32: null pointer");
   if (n_fft != kN1k) return set_error(ADT_ESHAPE, "adt_clap_logmel_db_f32: only n_fft == 1024 is supported");
   if (n_mels <= 0 || n_mels > 64 || (n_mels & 3)) return set_error(ADT_ESHAPE, "adt_clap_logmel_db_f32: n_mels must be a multiple of 4 in [4,64]");
   if (mel_nnz < 0 || mel_nnz > kClapMaxNnz) return set_error(ADT_ESHAPE, "adt_clap_logmel_db_f32: filterbank has too many non-zeros");
@@ -139,7 +140,7 @@ extern "C" int adt_clap_logmel_db_f32(const float* waves, const int64_t* offsets
   if (!aligned16(out)) return set_error(ADT_EINVAL, "adt_clap_logmel_db_f32: out must be 16-byte aligned");
   if (n_clips == 0 || n_frames == 0) return ADT_OK;
   ClapArgs a;
-  a.waves = waves; a.offsets = reinterpret_cast<const long*>(offsets); a.n_clips = static_cast<int>(n_clips); a.target = target_len;
+  a.waves = waves; a.clip_ptrs = clip_ptrs; a.offsets = reinterpret_cast<const long*>(offsets); a.n_clips = static_cast<int>(n_clips); a.target = target_len;
   a.hop = hop; a.n_frames = n_frames; a.pairs_per_clip = (n_frames + 1) / 2; a.window = window;
   a.mel_meta = reinterpret_cast<const int4*>(mel_meta); a.mel_w = mel_w; a.n_mels = n_mels; a.mel_nnz = mel_nnz; a.amin = amin; a.out = out;
   a.n_items = n_clips * a.pairs_per_clip;
@@ -160,6 +161,19 @@ extern "C" int adt_clap_logmel_db_f32(const float* waves, const int64_t* offsets
   hipLaunchKernelGGL(clap_logmel_kernel, dim3(static_cast<unsigned>(blocks)), dim3(kClapThreads), lds, static_cast<hipStream_t>(stream), a);
   ADT_HIP_TRY(hipGetLastError());
   return ADT_OK;
+}
+extern "C" int adt_clap_logmel_db_f32(const float* waves, const int64_t* offsets, int64_t n_clips, int32_t target_len, int32_t n_fft,
+                                      int32_t hop, int32_t n_frames, const float* window, const int32_t* mel_meta, const float* mel_w,
+                                      int32_t n_mels, int32_t mel_nnz, float amin, float* out, void* stream) {
+  return clap_logmel_impl(waves, nullptr, offsets, n_clips, target_len, n_fft, hop, n_frames, window, mel_meta, mel_w, n_mels, mel_nnz, amin, out, stream);
+}
+// The same over clips that already live in device memory one by one (a device array of n_clips pointers): no concatenation pass.
+// offsets[b + 1] - offsets[b] is still clip b's length.
+extern "C" int adt_clap_logmel_db_ptrs_f32(const float* const* clip_ptrs, const int64_t* offsets, int64_t n_clips, int32_t target_len, int32_t n_fft,
+                                           int32_t hop, int32_t n_frames, const float* window, const int32_t* mel_meta, const float* mel_w,
+                                           int32_t n_mels, int32_t mel_nnz, float amin, float* out, void* stream) {
+  if (!clip_ptrs) return adt::set_error(ADT_EINVAL, "adt_clap_logmel_db_ptrs_f32: null pointer");
+  return clap_logmel_impl(nullptr, clip_ptrs, offsets, n_clips, target_len, n_fft, hop, n_frames, window, mel_meta, mel_w, n_mels, mel_nnz, amin, out, stream);
 }
 
 // ------------------------------------------------------------------------------------ bilinear resize (fusion "shrink" mel)

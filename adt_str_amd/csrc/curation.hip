@@ -15,13 +15,20 @@ namespace adt {
 constexpr int kCurThreads = 256;
 constexpr int kCurMaxRefFloats = 36 * 1024;          // 144 KiB of LDS for the class vectors
 
+// kRow > 0: D <= 64 * kRow, the sample's row stays in registers (one global read per element instead of one per class; same summation
+// order as the generic form: element lane + 64 k in turn, then the xor tree).  The class vectors go to LDS 16 bytes at a time when they can.
+template <int kRow>
 __global__ __launch_bounds__(kCurThreads) void cosine_argmax_kernel(const float* __restrict__ emb, long ld, const float* __restrict__ refs,
                                                                     int N, int D, int C, float eps, int* __restrict__ best_class,
                                                                     float* __restrict__ best_score, float* __restrict__ scores) {
   extern __shared__ __attribute__((aligned(16))) float sm[];
   float* r = sm;                        // [C][D]
   float* rnorm2 = sm + C * D;           // [C]
-  for (int i = threadIdx.x; i < C * D; i += kCurThreads) r[i] = refs[i];
+  if (((C * D) & 3) == 0 && (reinterpret_cast<uintptr_t>(refs) & 15) == 0) {
+    for (int i = threadIdx.x; i < (C * D) / 4; i += kCurThreads) reinterpret_cast<float4*>(r)[i] = reinterpret_cast<const float4*>(refs)[i];
+  } else {
+    for (int i = threadIdx.x; i < C * D; i += kCurThreads) r[i] = refs[i];
+  }
   __syncthreads();
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   for (int c = wave; c < C; c += kCurThreads / 64) {
@@ -35,15 +42,33 @@ __global__ __launch_bounds__(kCurThreads) void cosine_argmax_kernel(const float*
   const int waves_total = gridDim.x * (kCurThreads / 64);
   for (int n = blockIdx.x * (kCurThreads / 64) + wave; n < N; n += waves_total) {
     const float* x = emb + static_cast<long>(n) * ld;
+    float xv[kRow > 0 ? kRow : 1];
     float xx = 0.f;
-    for (int i = lane; i < D; i += 64) { const float v = x[i]; xx += v * v; }
+    if (kRow > 0) {
+#pragma unroll
+      for (int k = 0; k < kRow; ++k) {
+        const int i = lane + 64 * k;
+        xv[k] = i < D ? x[i] : 0.f;
+        if (i < D) xx += xv[k] * xv[k];
+      }
+    } else {
+      for (int i = lane; i < D; i += 64) { const float v = x[i]; xx += v * v; }
+    }
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) xx += __shfl_xor(xx, o);
     float best = -3.0e38f;
     int bc = 0;
     for (int c = 0; c < C; ++c) {
       float dot = 0.f;
-      for (int i = lane; i < D; i += 64) dot += x[i] * r[c * D + i];
+      if (kRow > 0) {
+#pragma unroll
+        for (int k = 0; k < kRow; ++k) {
+          const int i = lane + 64 * k;
+          if (i < D) dot += xv[k] * r[c * D + i];
+        }
+      } else {
+        for (int i = lane; i < D; i += 64) dot += x[i] * r[c * D + i];
+      }
 #pragma unroll
       for (int o = 32; o > 0; o >>= 1) dot += __shfl_xor(dot, o);
       const float cs = dot / sqrtf(fmaxf(xx * rnorm2[c], eps * eps));
@@ -68,7 +93,9 @@ extern "C" int adt_cosine_argmax_f32(const float* emb, int64_t ld, const float* 
   int dev = 0;
   ADT_HIP_TRY(hipGetDevice(&dev));
   if (done_for != dev) {
-    ADT_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(cosine_argmax_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+    ADT_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(cosine_argmax_kernel<8>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                    kCurMaxRefFloats * 4));
+    ADT_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(cosine_argmax_kernel<0>), hipFuncAttributeMaxDynamicSharedMemorySize,
                                     kCurMaxRefFloats * 4));
     done_for = dev;
   }
@@ -76,8 +103,12 @@ extern "C" int adt_cosine_argmax_f32(const float* emb, int64_t ld, const float* 
   if (int rc = device_cu_count(&n_cu)) return rc;
   long blocks = (N + 3) / 4;
   if (blocks > n_cu) blocks = n_cu;
-  hipLaunchKernelGGL(cosine_argmax_kernel, dim3(static_cast<unsigned>(blocks)), dim3(kCurThreads), lds, static_cast<hipStream_t>(stream),
-                     emb, ld, refs, static_cast<int>(N), static_cast<int>(D), static_cast<int>(C), eps, best_class, best_score, scores);
+  if (D <= 512)
+    hipLaunchKernelGGL(cosine_argmax_kernel<8>, dim3(static_cast<unsigned>(blocks)), dim3(kCurThreads), lds, static_cast<hipStream_t>(stream),
+                       emb, ld, refs, static_cast<int>(N), static_cast<int>(D), static_cast<int>(C), eps, best_class, best_score, scores);
+  else
+    hipLaunchKernelGGL(cosine_argmax_kernel<0>, dim3(static_cast<unsigned>(blocks)), dim3(kCurThreads), lds, static_cast<hipStream_t>(stream),
+                       emb, ld, refs, static_cast<int>(N), static_cast<int>(D), static_cast<int>(C), eps, best_class, best_score, scores);
   ADT_HIP_TRY(hipGetLastError());
   return ADT_OK;
 }

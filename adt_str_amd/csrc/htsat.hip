@@ -738,6 +738,60 @@ __global__ __launch_bounds__(256) void mean_tokens_kernel(const float* __restric
     if (out16) out16[static_cast<long>(b) * C + c] = f2bf_h(s);
   }
 }
+// LayerNorm of every token row followed by the mean over the clip's tokens (the tower's last two steps: ClapAudioEncoder.norm + the avg-pool head)
+// in one pass: one workgroup per clip, a wave per token in turn (the row in registers: D <= 1024 floats, the arithmetic of layernorm_fwd_kernel),
+// the normalised rows accumulate per lane and are never written.
+__global__ __launch_bounds__(256) void ln_mean_tokens_kernel(const float* __restrict__ x, int T, int D, const float* __restrict__ gamma,
+                                                             const float* __restrict__ beta, float eps, float* __restrict__ out32,
+                                                             unsigned short* __restrict__ out16) {
+  __shared__ float4 red[4][256];
+  const int b = blockIdx.x, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int nq = D >> 2;
+  float4 acc[4], g[4], be[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int q = lane + 64 * i;
+    acc[i] = make_float4(0, 0, 0, 0);
+    g[i] = q < nq ? reinterpret_cast<const float4*>(gamma)[q] : make_float4(0, 0, 0, 0);
+    be[i] = q < nq ? reinterpret_cast<const float4*>(beta)[q] : make_float4(0, 0, 0, 0);
+  }
+  for (int t = wave; t < T; t += 4) {
+    const float* row = x + (static_cast<long>(b) * T + t) * D;
+    float4 v[4];
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int q = lane + 64 * i;
+      v[i] = q < nq ? reinterpret_cast<const float4*>(row)[q] : make_float4(0, 0, 0, 0);
+      s += (v[i].x + v[i].y) + (v[i].z + v[i].w);
+    }
+    const float mean = wsum(s) / D;
+    float ss = 0.f;
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+      if (lane + 64 * i < nq) {
+        const float d0 = v[i].x - mean, d1 = v[i].y - mean, d2 = v[i].z - mean, d3 = v[i].w - mean;
+        ss += (d0 * d0 + d1 * d1) + (d2 * d2 + d3 * d3);
+      }
+    const float rstd = rsqrtf(wsum(ss) / D + eps);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      acc[i].x += (v[i].x - mean) * rstd * g[i].x + be[i].x; acc[i].y += (v[i].y - mean) * rstd * g[i].y + be[i].y;
+      acc[i].z += (v[i].z - mean) * rstd * g[i].z + be[i].z; acc[i].w += (v[i].w - mean) * rstd * g[i].w + be[i].w;
+    }
+  }
+#pragma unroll
+  for (int i = 0; i < 4; ++i) red[wave][lane + 64 * i] = acc[i];
+  __syncthreads();
+  for (int q = threadIdx.x; q < nq; q += 256) {
+    const float4 a0 = red[0][q], a1 = red[1][q], a2 = red[2][q], a3 = red[3][q];
+    const float inv = 1.0f / T;
+    const float4 m = make_float4(((a0.x + a1.x) + (a2.x + a3.x)) * inv, ((a0.y + a1.y) + (a2.y + a3.y)) * inv, ((a0.z + a1.z) + (a2.z + a3.z)) * inv,
+                                 ((a0.w + a1.w) + (a2.w + a3.w)) * inv);
+    if (out32) reinterpret_cast<float4*>(out32 + static_cast<long>(b) * D)[q] = m;
+    if (out16) reinterpret_cast<ushort4*>(out16 + static_cast<long>(b) * D)[q] = make_ushort4(f2bf_h(m.x), f2bf_h(m.y), f2bf_h(m.z), f2bf_h(m.w));
+  }
+}
 __global__ __launch_bounds__(256) void l2_normalize_kernel(const float* __restrict__ x, int D, float* __restrict__ out, long n_rows) {
   const int lane = threadIdx.x & 63;
   const long row = static_cast<long>(blockIdx.x) * 4 + (threadIdx.x >> 6);
@@ -872,6 +926,19 @@ extern "C" int adt_mean_tokens(const float* x, int64_t B, int32_t T, int32_t C, 
   if (B < 0 || T <= 0 || C <= 0) return set_error(ADT_EINVAL, "adt_mean_tokens: bad sizes");
   if (B == 0) return ADT_OK;
   hipLaunchKernelGGL(mean_tokens_kernel, dim3(static_cast<unsigned>(B)), dim3(256), 0, STR(stream), x, T, C, out32, static_cast<unsigned short*>(out16));
+  ADT_HIP_TRY(hipGetLastError());
+  return ADT_OK;
+}
+
+extern "C" int adt_ln_mean_tokens(const float* x, int64_t B, int32_t T, int32_t D, const float* gamma, const float* beta, float eps, float* out32,
+                                  void* out16, void* stream) {
+  if (!x || !gamma || !beta || (!out32 && !out16)) return set_error(ADT_EINVAL, "adt_ln_mean_tokens: null pointer");
+  if (B < 0 || T <= 0 || D <= 0 || (D & 3) || D > 1024) return set_error(ADT_ESHAPE, "adt_ln_mean_tokens: D must be a multiple of 4, at most 1024");
+  if (!aligned16(x) || !aligned16(gamma) || !aligned16(beta) || (out32 && !aligned16(out32)) || (out16 && (reinterpret_cast<uintptr_t>(out16) & 7)))
+    return set_error(ADT_EINVAL, "adt_ln_mean_tokens: misaligned pointer");
+  if (B == 0) return ADT_OK;
+  hipLaunchKernelGGL(ln_mean_tokens_kernel, dim3(static_cast<unsigned>(B)), dim3(256), 0, STR(stream), x, T, D, gamma, beta, eps, out32,
+                     static_cast<unsigned short*>(out16));
   ADT_HIP_TRY(hipGetLastError());
   return ADT_OK;
 }

@@ -502,6 +502,11 @@ int adt_adamw_step(float* p, const float* g, float* m, float* v, void* p_bf16, i
 int adt_clap_logmel_db_f32(const float* waves, const int64_t* offsets, int64_t n_clips, int32_t target_len, int32_t n_fft,
                            int32_t hop, int32_t n_frames, const float* window, const int32_t* mel_meta, const float* mel_w,
                            int32_t n_mels, int32_t mel_nnz, float amin, float* out, void* stream);
+/* The same over clips that live in device memory one by one (modules/clap_encoder.py:22 hands the extractor a LIST of clips): clip_ptrs is a
+ * device array of n_clips pointers, clip c = clip_ptrs[c][0 .. offsets[c+1] - offsets[c]) -- no concatenation pass. */
+int adt_clap_logmel_db_ptrs_f32(const float* const* clip_ptrs, const int64_t* offsets, int64_t n_clips, int32_t target_len, int32_t n_fft,
+                                int32_t hop, int32_t n_frames, const float* window, const int32_t* mel_meta, const float* mel_w,
+                                int32_t n_mels, int32_t mel_nnz, float amin, float* out, void* stream);
 
 /* Bilinear resize of one fp32 image [H_in, W_in] -> [H_out, W_out]: torch.nn.functional.interpolate(mode="bilinear",
  * align_corners=False) as ClapFeatureExtractor's fusion truncation calls it to shrink the whole mel of a clip longer than 10 s to
@@ -554,6 +559,10 @@ int adt_window_attn_fwd(const void* qkv, int64_t ld_qkv, void* ctx, int64_t ld_c
 int adt_patch_merge_ln(const float* x, int64_t B, int32_t R, int32_t C, const float* gamma, const float* beta, float eps,
                        void* out_bf16, void* stream);
 int adt_mean_tokens(const float* x, int64_t B, int32_t T, int32_t C, float* out32, void* out16, void* stream);
+/* LayerNorm of every token row, then the mean over each clip's T tokens, in one pass (ClapAudioEncoder.norm + the average-pool head,
+ * modeling_clap.py; x [B * T, D] fp32, D % 4 == 0, D <= 1024): out32 [B, D] fp32 and / or out16 [B, D] bf16. */
+int adt_ln_mean_tokens(const float* x, int64_t B, int32_t T, int32_t D, const float* gamma, const float* beta, float eps, float* out32,
+                       void* out16, void* stream);
 
 /* K15  fused row-block kernels for the bandwidth-bound Swin stages (C = 96, 192; modes 0, 1, 4 also C = 384): one launch per half of a
  * ClapAudioLayer (transformers modeling_clap.py ClapAudioLayer.forward, reached from modules/clap_encoder.py:45-49).

@@ -88,3 +88,23 @@ def test_gpu_matches_hf_extractor():
     assert torch.equal(feats[:, 1], feats[:, 0])
     with pytest.raises(ValueError):                         # mel() is the <= 10 s path; features() takes any length
         fe.mel([torch.zeros(480001)])
+    # clips already on the device go through the pointer table (adt_clap_logmel_db_ptrs_f32: no concatenation pass): the same kernel, the same bits
+    dev_clips = [torch.from_numpy(c).to("cuda:0") for c in clips]
+    assert torch.equal(fe.mel(dev_clips), fe.mel([torch.from_numpy(c) for c in clips]))
+    assert torch.equal(fe.mel([dev_clips[2][None, :], dev_clips[0]]), fe.mel([torch.from_numpy(clips[2]), torch.from_numpy(clips[0])]))
+
+
+@pytest.mark.gpu
+def test_ln_mean_tokens_is_layernorm_then_mean():
+    """adt_ln_mean_tokens (the tower's final LayerNorm + average pool in one pass) against torch on the same rows."""
+    from adt_str_amd import _ffi
+    g = torch.Generator().manual_seed(5)
+    for (B, T, D) in ((5, 64, 768), (3, 7, 96), (2, 1, 1024)):
+        x = (torch.randn((B * T, D), generator=g) * 2 + 0.3).to("cuda:0")
+        gamma, beta = (1 + 0.1 * torch.randn(D, generator=g)).to("cuda:0"), (0.1 * torch.randn(D, generator=g)).to("cuda:0")
+        out32 = torch.empty((B, D), device="cuda:0")
+        out16 = torch.empty((B, D), dtype=torch.bfloat16, device="cuda:0")
+        _ffi.call("adt_ln_mean_tokens", x.data_ptr(), B, T, D, gamma.data_ptr(), beta.data_ptr(), 1e-5, out32.data_ptr(), out16.data_ptr(), 0)
+        ref = torch.nn.functional.layer_norm(x.double(), (D,), gamma.double(), beta.double(), 1e-5).view(B, T, D).mean(1)
+        assert float((out32.double() - ref).abs().max()) < 2e-6 * max(1.0, float(ref.abs().max()))
+        assert torch.equal(out16, out32.bfloat16())
