@@ -562,13 +562,7 @@ __global__ __launch_bounds__(kRbThreads, kOcc) void htsat_mlp_kernel(RbArgs a) {
     float sum = 0.f;
 #pragma unroll
     for (int s = 0; s < KS; ++s) {
-#ifdef ADT_MLP_COALESCED_TEST   // timing experiment (wrong values): the same bytes with whole 256-byte row pieces per 16 lanes
-      const float* xq = a.x + (static_cast<long>(blockIdx.x) * kRbRows + wave * 32) * C;
-      const float4 v0 = *reinterpret_cast<const float4*>(xq + (((2 * s) % 8) * 4 + (lane >> 4)) * C + ((2 * s) / 8) * 64 + (lane & 15) * 4);
-      const float4 v1 = *reinterpret_cast<const float4*>(xq + (((2 * s + 1) % 8) * 4 + (lane >> 4)) * C + ((2 * s + 1) / 8) * 64 + (lane & 15) * 4);
-#else
       const float4 v0 = *reinterpret_cast<const float4*>(xp + 16 * s), v1 = *reinterpret_cast<const float4*>(xp + 16 * s + 4);
-#endif
       xv[s][0] = v0.x; xv[s][1] = v0.y; xv[s][2] = v0.z; xv[s][3] = v0.w; xv[s][4] = v1.x; xv[s][5] = v1.y; xv[s][6] = v1.z; xv[s][7] = v1.w;
 #pragma unroll
       for (int e = 0; e < 8; ++e) sum += xv[s][e];
