@@ -1054,9 +1054,13 @@ __device__ unsigned long long g_atb_stamps[16];
 #else
 #define ADT_ATB_STAMP(K) do { } while (0)
 #endif
+// C = 192 is built for 256 registers (two workgroups per CU): its fragments go through a ring of SIX registers refilled as each product issues
+// (kRing6, as mlp_steps), not through two sets of six -- under that budget the allocator spilled a prefetched set right behind the asm statement
+// that had requested it, before the data had landed (DESIGN 8.6.9 e; tools/probe/check_pending_lds_regs.py guards it).
 template <int C, bool kAffine = true, bool kMlp = false>      // kMlp: the layer's MLP half follows in the same launch, on the rows still in the accumulators
-__global__ __launch_bounds__(256, 1) void htsat_attn_big_kernel(AtArgs a) {
+__global__ __launch_bounds__(256, C == 192 ? 2 : 1) void htsat_attn_big_kernel(AtArgs a) {
   constexpr int KS = C / 16, CT = C / 32, NH = C / 24;
+  constexpr bool kRing6 = C == 192;
   constexpr int kSubBytes = KS * 1024;
   constexpr int IPW = KS / 4;                                  // DMA instructions per wave and sub-chunk
   constexpr int kSubs = 4 * NH;
@@ -1174,6 +1178,25 @@ __global__ __launch_bounds__(256, 1) void htsat_attn_big_kernel(AtArgs a) {
                  : "=&v"(f[0]), "=&v"(f[1]), "=&v"(f[2]), "=&v"(f[3]), "=&v"(f[4]), "=&v"(f[5]) : "v"(addr) : "memory");
   };
   // one 32-unit tile of the row-block product + its bias: acc[unit 8g + 4h + e][token]; ta = the sub-chunk's first fragment (+ lane * 16)
+  // N products over consecutive fragments at ta through a ring of six registers: fragment i is the oldest of the (at most six) reads in flight,
+  // its register takes fragment i + 6 as soon as its product has issued; prod(i, fragment) issues product i, between(i) what goes behind it
+  auto ring6 = [&](auto n_tag, unsigned ta, auto&& prod, auto&& between) {
+    constexpr int N = decltype(n_tag)::value;
+    bf16x8 f[6];
+    frag6(f, ta);
+    static_for<0, N>([&](auto ic) {
+      constexpr int i = decltype(ic)::value;
+      if constexpr (i + 6 <= N) wait_lgkm<5>();
+      else wait_lgkm<N - 1 - i>();
+      __builtin_amdgcn_sched_barrier(0);
+      prod(ic, f[i % 6]);
+      __builtin_amdgcn_sched_barrier(0);
+      if constexpr (i + 6 < N)
+        asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(f[i % 6]) : "v"(ta), "n"((i + 6) * 1024) : "memory");
+      between(ic);
+      __builtin_amdgcn_sched_barrier(0);
+    });
+  };
   auto tile = [&](unsigned ta, unsigned bias_a, f32x16& acc, auto&& between) {
     f32x4 bv[4];
     asm volatile("ds_read_b128 %0, %4\n\tds_read_b128 %1, %4 offset:32\n\tds_read_b128 %2, %4 offset:64\n\tds_read_b128 %3, %4 offset:96"
@@ -1182,6 +1205,10 @@ __global__ __launch_bounds__(256, 1) void htsat_attn_big_kernel(AtArgs a) {
     // (The token's operand registers b[] must STAY in arch VGPRs: with more than ~250 live values the allocator parks them in AGPRs and moves
     // all C/4 dwords back in front of every tile -- profiles/r06/clap_attn_big.txt.)
     // fragments in two sets of six: group g + 1 is requested before group g's products, so that only the tile's first group waits for the LDS
+    if constexpr (kRing6) {
+      ring6(std::integral_constant<int, KS>{}, ta,
+            [&](auto ic, const bf16x8& fr) { acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fr, b[decltype(ic)::value], acc, 0, 0, 0); }, between);
+    } else {
     bf16x8 f[2][6];
     frag6(f[0], ta);
     static_for<0, KS / 6>([&](auto gc) {
@@ -1198,6 +1225,7 @@ __global__ __launch_bounds__(256, 1) void htsat_attn_big_kernel(AtArgs a) {
         __builtin_amdgcn_sched_barrier(0);
       });
     });
+    }
 #pragma unroll
     for (int g = 0; g < 4; ++g)
 #pragma unroll
@@ -1323,6 +1351,18 @@ __global__ __launch_bounds__(256, 1) void htsat_attn_big_kernel(AtArgs a) {
     ADT_ATB_STAMP(12);
     {
       const unsigned ta = smem_base + static_cast<unsigned>(((n0 + 3) & 3) * kSubBytes + lane * 16);
+      if constexpr (kRing6) {
+        ring6(std::integral_constant<int, 2 * CT>{}, ta,
+              [&](auto ic, const bf16x8& fr) {
+                constexpr int fi = decltype(ic)::value;
+                acc_out[fi % CT] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fr, fi < CT ? ob0 : ob1, acc_out[fi % CT], 0, 0, 0);
+              },
+              [&](auto ic) {
+                constexpr int fi = decltype(ic)::value;
+                if constexpr (fi < 8) issue_rb_i(hd + 1, fi);
+                else if constexpr (fi - 8 < IPW) issue_sub_i(n0 + 5, fi - 8);
+              });
+      } else {
       bf16x8 f[2][6];
       frag6(f[0], ta);
       static_for<0, 2 * CT / 6>([&](auto gc) {
@@ -1342,6 +1382,7 @@ __global__ __launch_bounds__(256, 1) void htsat_attn_big_kernel(AtArgs a) {
           __builtin_amdgcn_sched_barrier(0);
         });
       });
+      }
     }
     ADT_ATB_STAMP(13);
   }
