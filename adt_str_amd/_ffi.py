@@ -125,7 +125,7 @@ SIGNATURES = {
     "adt_ln_mean_tokens": [ptr, i64, i32, i32, ptr, ptr, f32, ptr, ptr, ptr],
     "adt_htsat_rowblock_chunk_tiles": [i32, i32],
     "adt_htsat_attn_block": [ptr, i64, i32, i32, i32, i32, ptr, ptr, f32, ptr, ptr, ptr, ptr, i32, f32, ptr],
-    "adt_htsat_layer_block": [ptr, i64, i32, i32, i32, i32, f32, ptr, ptr, ptr, ptr, i32, f32, ptr, i32, ptr, ptr, ptr],
+    "adt_htsat_layer_block": [ptr, i64, i32, i32, i32, i32, f32, ptr, ptr, ptr, ptr, i32, f32, ptr, i32, ptr, ptr, ptr, ptr],
     "adt_htsat_merge_rowblock": [ptr, i64, i32, i32, ptr, ptr, f32, ptr, i32, ptr, ptr, i64, ptr],
     "adt_htsat_rowblock": [i32, ptr, i64, i32, ptr, i64, ptr, ptr, f32, ptr, i32, ptr, ptr, ptr, i64, ptr],
     "adt_l2_normalize": [ptr, i64, i32, ptr, ptr],

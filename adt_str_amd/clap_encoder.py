@@ -98,6 +98,15 @@ def window_bias_layout(bias: torch.Tensor) -> torch.Tensor:
     return v.permute(*range(n), n, n + 2, n + 3, n + 4, n + 1, n + 5).contiguous().reshape(*lead, 64, 64)
 
 
+def window_bias_layout_bf16(bias: torch.Tensor) -> torch.Tensor:
+    """The same table as bf16 for ``adt_htsat_layer_block`` at C = 192 (its bias staging takes half the LDS): [..., qt 2, kt 2, gp 2, h 2, r 32,
+    gi 2, e 4] with key = 32 kt + 8 (2 gp + gi) + 4 h + e -- one 16-byte piece per lane (h, r) and (qt, kt, gp), in log2 units like the fp32 form."""
+    lead = bias.shape[:-2]
+    v = (bias.float() * math.log2(math.e)).reshape(*lead, 2, 32, 2, 2, 2, 2, 4)      # [..., qt, r, kt, gp, gi, h, e]
+    n = len(lead)
+    return v.permute(*range(n), n, n + 2, n + 3, n + 5, n + 1, n + 4, n + 6).contiguous().reshape(*lead, 64, 64).to(BF16)
+
+
 def _shift_mask(R: int, shift: int) -> torch.Tensor:
     """[nW, 64, 64] additive 0 / -100 mask of a shifted-window layer (ClapAudioLayer.get_attn_mask)."""
     idx = torch.arange(R)
@@ -147,9 +156,10 @@ class HtsatEncoder:
                 if shift:
                     bias = (bias.unsqueeze(0) + _shift_mask(R, shift).to(self.dev).unsqueeze(1)).contiguous()   # [nW, nh, 64, 64]
                 n_bias = bias.shape[0] if shift else 1
+                bias16 = window_bias_layout_bf16(bias) if C == 192 else None
                 bias = window_bias_layout(bias)
                 layers.append(dict(
-                    shift=shift, bias=bias, n_bias=n_bias,
+                    shift=shift, bias=bias, bias16=bias16, n_bias=n_bias,
                     ln1=(g(q + "layernorm_before.weight"), g(q + "layernorm_before.bias")),
                     wqkv=b16(torch.cat([g(a + "query.weight"), g(a + "key.weight"), g(a + "value.weight")], 0)),
                     bqkv=torch.cat([g(a + "query.bias"), g(a + "key.bias"), g(a + "value.bias")], 0).contiguous(),
@@ -268,7 +278,7 @@ class HtsatEncoder:
                         # the whole layer in one launch: the rows stay in the accumulators between the halves (ADT_HTSAT_LAYER384=0: two launches)
                         _ffi.call("adt_htsat_layer_block", _ffi.dptr(x), B, R, C, nh, L["shift"], self.eps, _ffi.dptr(L["attn_pkf"]), _ffi.dptr(L["attn_qkvbf"]),
                                   _ffi.dptr(L["bo"]), _ffi.dptr(L["bias"]), L["n_bias"], 1.0 / math.sqrt(24.0), _ffi.dptr(L["mlp_pkf"]), C // 8,
-                                  _ffi.dptr(L["b1f"]), _ffi.dptr(L["b2"]), st)
+                                  _ffi.dptr(L["b1f"]), _ffi.dptr(L["b2"]), _ffi.dptr(L["bias16"]) if L["bias16"] is not None else None, st)
                         continue
                     if fold:
                         _ffi.call("adt_htsat_attn_block", _ffi.dptr(x), B, R, C, nh, L["shift"], None, None, self.eps,

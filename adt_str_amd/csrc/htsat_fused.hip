@@ -701,6 +701,8 @@ struct AtArgs {
   int B, R, shift; float scale;
   // htsat_attn_big_kernel<C, false, true> (the whole layer in one launch): the MLP half's stream, as adt_htsat_rowblock mode 2 with a folded LayerNorm
   const unsigned char* mlp_wpk; const float* mlp_b1; const float* mlp_b2; int mlp_tiles;
+  // htsat_attn_big_kernel<192, false, true>: rel_bias as bf16, [.., query tile 2, key tile 2, group pair 2, lane 64, group 2, e 4] (clap_encoder.py:window_bias_layout_bf16)
+  const unsigned short* rel_bias16;
 };
 __device__ __forceinline__ long at_token_row(const AtArgs& a, int b, int wy, int wx, int t) {
   const int y = (wy * 8 + (t >> 3) + a.shift) % a.R, x = (wx * 8 + (t & 7) + a.shift) % a.R;
@@ -1065,9 +1067,16 @@ __global__ __launch_bounds__(256, C == 192 ? 2 : 1) void htsat_attn_big_kernel(A
   constexpr int IPW = KS / 4;                                  // DMA instructions per wave and sub-chunk
   constexpr int kSubs = 4 * NH;
   static_assert(KS % 12 == 0 && IPW * 4 == KS, "C = 192 or 384");
-  constexpr int kKx = 4 * kSubBytes, kVt = kKx + 2 * 2 * 2 * 1024, kQb = kVt + 2 * 4096;     // ring | K operands | V tiles | q|k|v bias | bias staging
-  constexpr int kRb = kQb + NH * 96 * 4;                                                     // per wave 8 KiB: the head's relative-position bias pieces
-  static_assert(kRb + 4 * 8192 <= 160 * 1024, "LDS budget");
+  // The C = 192 layer (two workgroups per CU: 80 KiB each) runs a THREE-slot ring -- sub-chunk n + 2 goes into the slot of n - 1, which everybody has
+  // read before the barrier of n -- and stages the relative-position bias as bf16 (4 KiB per wave and head, 4 DMA instructions instead of 8): 71 KiB
+  // for the attention half, 76 for the MLP half.  (bf16 on a bias of a few units: 0.4 % of a logit's bias, the rounding the probabilities get anyway.)
+  constexpr bool kRb16 = C == 192 && kMlp;
+  constexpr int kSlots = kRb16 ? 3 : 4;
+  constexpr int kRbN = kRb16 ? 4 : 8, kRbWave = kRbN * 1024;                                   // bias DMA instructions / staging bytes per wave and head
+  constexpr int kKx = kSlots * kSubBytes, kVt = kKx + 2 * 2 * 2 * 1024, kQb = kVt + 2 * 4096;     // ring | K operands | V tiles | q|k|v bias | bias staging
+  constexpr int kRb = kQb + NH * 96 * 4;                                                     // per wave: the head's relative-position bias pieces
+  static_assert(kRb + 4 * kRbWave <= (kRb16 ? 80 : 160) * 1024, "LDS budget");
+  auto slot = [](int n) { return kSlots == 4 ? (n & 3) : n % 3; };
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const int tid = threadIdx.x, lane = tid & 63, r = lane & 31, h = lane >> 5;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -1087,7 +1096,7 @@ __global__ __launch_bounds__(256, C == 192 ? 2 : 1) void htsat_attn_big_kernel(A
   auto issue_sub_i = [&](int n, int i) {
     const int nn = n < kSubs ? n : kSubs - 1;
     const unsigned char* src = a.wpk + static_cast<long>(nn) * kSubBytes + (wave * IPW + i) * 1024 + lane * 16;
-    unsigned char* dst = smem + (n & 3) * kSubBytes + (wave * IPW + i) * 1024;
+    unsigned char* dst = smem + slot(n) * kSubBytes + (wave * IPW + i) * 1024;
     __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src, (__attribute__((address_space(3))) void*)dst, 16, 0, 0);
   };
   auto issue_sub = [&](int n) {
@@ -1099,9 +1108,15 @@ __global__ __launch_bounds__(256, C == 192 ? 2 : 1) void htsat_attn_big_kernel(A
   const int wsel_ = a.n_bias_windows > 1 ? (wy * nw + wx) : 0;
   auto issue_rb_i = [&](int hd, int i) {
     const int hh = hd < NH ? hd : NH - 1;
-    const float* rb = a.rel_bias + (static_cast<long>(wsel_) * NH + hh) * 4096 + tt * 2048 + lane * 4;
-    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(rb + i * 256),
-                                     (__attribute__((address_space(3))) void*)(smem + kRb + wave * 8192 + i * 1024), 16, 0, 0);
+    if constexpr (kRb16) {       // piece i = (key tile i >> 1, group pair i & 1): 16 bytes = 8 bf16 per lane
+      const unsigned short* rb = a.rel_bias16 + (static_cast<long>(wsel_) * NH + hh) * 4096 + tt * 2048 + lane * 8;
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(rb + i * 512),
+                                       (__attribute__((address_space(3))) void*)(smem + kRb + wave * kRbWave + i * 1024), 16, 0, 0);
+    } else {
+      const float* rb = a.rel_bias + (static_cast<long>(wsel_) * NH + hh) * 4096 + tt * 2048 + lane * 4;
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(rb + i * 256),
+                                       (__attribute__((address_space(3))) void*)(smem + kRb + wave * kRbWave + i * 1024), 16, 0, 0);
+    }
   };
   // ---- the token row -> LayerNorm -> bf16 B operands (before any DMA is in flight: these are plain loads)
   bf16x8 b[KS];
@@ -1162,7 +1177,7 @@ __global__ __launch_bounds__(256, C == 192 ? 2 : 1) void htsat_attn_big_kernel(A
   //  issue of the next one waits for the oldest to retire -- a hidden wait inside the tiles)
   issue_sub(0);
 #pragma unroll
-  for (int i = 0; i < 8; ++i) issue_rb_i(0, i);
+  for (int i = 0; i < kRbN; ++i) issue_rb_i(0, i);
   issue_sub(1);
 
   const unsigned kx_w = smem_base + kKx + static_cast<unsigned>(((wi * 2 + tt) * 2) * 1024 + lane * 16);       // this wave's K operands (k-step s: + s KiB)
@@ -1244,7 +1259,7 @@ __global__ __launch_bounds__(256, C == 192 ? 2 : 1) void htsat_attn_big_kernel(A
     const int n0 = 4 * hd;
     ADT_ATB_STAMP(0);
     // in-order list of this wave's vector-memory operations here: sub-chunk n0, the 8 bias pieces of this head, sub-chunk n0 + 1
-    sub_ready(n0, std::integral_constant<int, 8>{});
+    sub_ready(n0, std::integral_constant<int, kRbN>{});
     ADT_ATB_STAMP(1);
     const unsigned ba = qb_a + static_cast<unsigned>(hd * 96 * 4);
     // sub-chunk n + 2 is issued one instruction behind every (KS / IPW)-th product of the tile that reads sub-chunk n
@@ -1254,12 +1269,12 @@ __global__ __launch_bounds__(256, C == 192 ? 2 : 1) void htsat_attn_big_kernel(A
     auto dma_v = [&](auto mc) { constexpr int m = decltype(mc)::value; if constexpr (m % kEvery == 1) issue_sub_i(n0 + 4, m / kEvery); };
     f32x16 acc;
     bf16x8 qop[2];
-    tile(smem_base + static_cast<unsigned>((n0 & 3) * kSubBytes + lane * 16), ba, acc, dma_q);                    // q
+    tile(smem_base + static_cast<unsigned>(slot(n0) * kSubBytes + lane * 16), ba, acc, dma_q);                    // q
     qop[0] = acc_to_b_f(acc, 0); qop[1] = acc_to_b_f(acc, 1);
     ADT_ATB_STAMP(2);
     sub_ready(n0 + 1, std::integral_constant<int, 0>{});
     ADT_ATB_STAMP(3);          // (younger than sub-chunk n0 + 1: n0 + 2; the bias pieces are OLDER than n0 + 1: landed with it)
-    tile(smem_base + static_cast<unsigned>(((n0 + 1) & 3) * kSubBytes + lane * 16), ba + 128, acc, dma_k);        // k -> the window's K operands
+    tile(smem_base + static_cast<unsigned>(slot(n0 + 1) * kSubBytes + lane * 16), ba + 128, acc, dma_k);        // k -> the window's K operands
     {
       const bf16x8 k0 = acc_to_b_f(acc, 0), k1 = acc_to_b_f(acc, 1);
       asm volatile("ds_write_b128 %0, %1\n\tds_write_b128 %0, %2 offset:1024" :: "v"(kx_w), "v"(k0), "v"(k1) : "memory");
@@ -1267,7 +1282,7 @@ __global__ __launch_bounds__(256, C == 192 ? 2 : 1) void htsat_attn_big_kernel(A
     ADT_ATB_STAMP(4);
     sub_ready(n0 + 2, std::integral_constant<int, 0>{});          // (younger: n0 + 3)
     ADT_ATB_STAMP(5);
-    tile(smem_base + static_cast<unsigned>(((n0 + 2) & 3) * kSubBytes + lane * 16), ba + 256, acc, dma_v);        // v -> the window's [key][d] tile
+    tile(smem_base + static_cast<unsigned>(slot(n0 + 2) * kSubBytes + lane * 16), ba + 256, acc, dma_v);        // v -> the window's [key][d] tile
     ADT_ATB_STAMP(14);
 #pragma unroll
     for (int g = 0; g < 4; ++g) {
@@ -1300,10 +1315,24 @@ __global__ __launch_bounds__(256, C == 192 ? 2 : 1) void htsat_attn_big_kernel(A
 #pragma unroll
     for (int kt = 0; kt < 2; ++kt) {                      // (one key tile's bias at a time: 16 registers live instead of 32)
       f32x4 rbv[4];
-      const unsigned ra = smem_base + static_cast<unsigned>(kRb + wave * 8192 + kt * 4096 + lane * 16);
+      if constexpr (kRb16) {
+        typedef unsigned u32x4_ __attribute__((ext_vector_type(4)));
+        u32x4_ rq[2];                                      // [group pair]: groups 2gp, 2gp + 1, four bf16 each
+        const unsigned ra = smem_base + static_cast<unsigned>(kRb + wave * kRbWave + kt * 2048 + lane * 16);
+        asm volatile("ds_read_b128 %0, %2\n\tds_read_b128 %1, %2 offset:1024\n\ts_waitcnt lgkmcnt(0)" : "=&v"(rq[0]), "=&v"(rq[1]) : "v"(ra) : "memory");
+#pragma unroll
+        for (int g = 0; g < 4; ++g)
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            const unsigned w = rq[g >> 1][(g & 1) * 2 + (e >> 1)];
+            rbv[g][e] = __uint_as_float((e & 1) ? (w & 0xffff0000u) : (w << 16));
+          }
+      } else {
+      const unsigned ra = smem_base + static_cast<unsigned>(kRb + wave * kRbWave + kt * 4096 + lane * 16);
       asm volatile("ds_read_b128 %0, %4\n\tds_read_b128 %1, %4 offset:1024\n\tds_read_b128 %2, %4 offset:2048\n\tds_read_b128 %3, %4 offset:3072\n\t"
                    "s_waitcnt lgkmcnt(0)"
                    : "=&v"(rbv[0]), "=&v"(rbv[1]), "=&v"(rbv[2]), "=&v"(rbv[3]) : "v"(ra) : "memory");
+      }
 #pragma unroll
       for (int g = 0; g < 4; ++g)
 #pragma unroll
@@ -1350,7 +1379,7 @@ __global__ __launch_bounds__(256, C == 192 ? 2 : 1) void htsat_attn_big_kernel(A
     sub_ready(n0 + 3, std::integral_constant<int, 0>{});
     ADT_ATB_STAMP(12);
     {
-      const unsigned ta = smem_base + static_cast<unsigned>(((n0 + 3) & 3) * kSubBytes + lane * 16);
+      const unsigned ta = smem_base + static_cast<unsigned>(slot(n0 + 3) * kSubBytes + lane * 16);
       if constexpr (kRing6) {
         ring6(std::integral_constant<int, 2 * CT>{}, ta,
               [&](auto ic, const bf16x8& fr) {
@@ -1359,8 +1388,8 @@ __global__ __launch_bounds__(256, C == 192 ? 2 : 1) void htsat_attn_big_kernel(A
               },
               [&](auto ic) {
                 constexpr int fi = decltype(ic)::value;
-                if constexpr (fi < 8) issue_rb_i(hd + 1, fi);
-                else if constexpr (fi - 8 < IPW) issue_sub_i(n0 + 5, fi - 8);
+                if constexpr (fi < kRbN) issue_rb_i(hd + 1, fi);
+                else if constexpr (fi - kRbN < IPW) issue_sub_i(n0 + 5, fi - kRbN);
               });
       } else {
       bf16x8 f[2][6];
@@ -1377,8 +1406,8 @@ __global__ __launch_bounds__(256, C == 192 ? 2 : 1) void htsat_attn_big_kernel(A
           acc_out[fi % CT] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f[g & 1][j], fi < CT ? ob0 : ob1, acc_out[fi % CT], 0, 0, 0);
           __builtin_amdgcn_sched_barrier(0);
           // behind the products: the NEXT head's 8 bias pieces (their staging slots were read in this head's softmax), then sub-chunk n0 + 5
-          if constexpr (fi < 8) issue_rb_i(hd + 1, fi);
-          else if constexpr (fi - 8 < IPW) issue_sub_i(n0 + 5, fi - 8);
+          if constexpr (fi < kRbN) issue_rb_i(hd + 1, fi);
+          else if constexpr (fi - kRbN < IPW) issue_sub_i(n0 + 5, fi - kRbN);
           __builtin_amdgcn_sched_barrier(0);
         });
       });
@@ -1561,11 +1590,12 @@ extern "C" int adt_htsat_attn_block(float* x, int64_t B, int32_t R, int32_t C, i
   return ADT_OK;
 }
 
-// One ClapAudioLayer in ONE launch (C = 192 / 384; round 6): the attention half as adt_htsat_attn_block, then the MLP half as adt_htsat_rowblock
+// One ClapAudioLayer in ONE launch (C = 96 / 192 / 384; round 6): the attention half as adt_htsat_attn_block, then the MLP half as adt_htsat_rowblock
 // mode 2 on the rows still in the accumulators.  Both LayerNorms folded into the weights by the caller (no gamma / beta arguments).
 extern "C" int adt_htsat_layer_block(float* x, int64_t B, int32_t R, int32_t C, int32_t heads, int32_t shift, float eps, const void* attn_w_packed,
                                      const float* qkv_bias, const float* out_bias, const float* rel_bias, int32_t n_bias_windows, float scale,
-                                     const void* mlp_w_packed, int32_t n_tiles, const float* fc1_bias, const float* fc2_bias, void* stream) {
+                                     const void* mlp_w_packed, int32_t n_tiles, const float* fc1_bias, const float* fc2_bias, const void* rel_bias_bf16,
+                                     void* stream) {
   if (!x || !attn_w_packed || !qkv_bias || !out_bias || !rel_bias || !mlp_w_packed || !fc1_bias || !fc2_bias) return set_error(ADT_EINVAL, "adt_htsat_layer_block: null pointer");
   if (!((C == 384 && heads == 16) || (C == 192 && heads == 8) || (C == 96 && heads == 4))) return set_error(ADT_ESHAPE, "adt_htsat_layer_block: built for C = 96 / 192 / 384 with heads of 24");
   if (B < 0 || R <= 0 || (R & 7) || shift < 0 || shift >= 8 || n_tiles != C / 8) return set_error(ADT_ESHAPE, "adt_htsat_layer_block: window 8, R % 8 == 0, 4C hidden units");
@@ -1573,10 +1603,13 @@ extern "C" int adt_htsat_layer_block(float* x, int64_t B, int32_t R, int32_t C, 
   if (n_bias_windows != 1 && n_bias_windows != nw * nw) return set_error(ADT_EINVAL, "adt_htsat_layer_block: n_bias_windows must be 1 or (R/8)^2");
   if (!aligned16(x) || !aligned16(attn_w_packed) || !aligned16(rel_bias) || !aligned16(mlp_w_packed) || !aligned16(out_bias))
     return set_error(ADT_EINVAL, "adt_htsat_layer_block: misaligned pointer");
+  if (C == 192 && (!rel_bias_bf16 || !aligned16(rel_bias_bf16)))
+    return set_error(ADT_EINVAL, "adt_htsat_layer_block: C = 192 stages the relative-position bias as bf16 (rel_bias_bf16, 16-byte aligned)");
   const long n_windows = B * nw * nw;
   if (n_windows == 0) return ADT_OK;
   AtArgs a{x, nullptr, nullptr, eps, static_cast<const unsigned char*>(attn_w_packed), qkv_bias, out_bias, rel_bias, n_bias_windows,
-           static_cast<int>(B), R, shift, scale, static_cast<const unsigned char*>(mlp_w_packed), fc1_bias, fc2_bias, n_tiles};
+           static_cast<int>(B), R, shift, scale, static_cast<const unsigned char*>(mlp_w_packed), fc1_bias, fc2_bias, n_tiles,
+           static_cast<const unsigned short*>(rel_bias_bf16)};
   static thread_local int done_for = -1;
   int dev = 0;
   ADT_HIP_TRY(hipGetDevice(&dev));
@@ -1586,7 +1619,9 @@ extern "C" int adt_htsat_layer_block(float* x, int64_t B, int32_t R, int32_t C, 
     ADT_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(htsat_attn_kernel<96, false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     done_for = dev;
   }
-  const int lds_attn = C == 96 ? 2 * (3 * 6 + 2 * 3) * 1024 + 8 * 1024 + 2 * 4096 + 4 * 96 * 4 : 4 * (C / 16) * 1024 + 8 * 1024 + 2 * 4096 + heads * 96 * 4 + 4 * 8192;
+  const int lds_attn = C == 96 ? 2 * (3 * 6 + 2 * 3) * 1024 + 8 * 1024 + 2 * 4096 + 4 * 96 * 4
+                     : C == 192 ? 3 * (C / 16) * 1024 + 8 * 1024 + 2 * 4096 + heads * 96 * 4 + 4 * 4096       // three-slot ring, bf16 bias staging: two workgroups per CU
+                                : 4 * (C / 16) * 1024 + 8 * 1024 + 2 * 4096 + heads * 96 * 4 + 4 * 8192;
   const int lds_mlp = 3 * 2 * (C / 16) * 1024 + 32 * n_tiles * 4 + C * 4;
   const dim3 grid(static_cast<unsigned>((n_windows + 1) / 2));
   const int lds = lds_attn > lds_mlp ? lds_attn : lds_mlp;

@@ -593,13 +593,16 @@ int adt_htsat_attn_block(float* x, int64_t B, int32_t R, int32_t C, int32_t head
 int adt_htsat_rowblock(int32_t mode, float* x, int64_t M, int32_t C, const void* a16, int64_t lda, const float* ln_gamma,
                        const float* ln_beta, float eps, const void* w_packed, int32_t n_tiles, const float* bias1,
                        const float* bias2, void* out16, int64_t ldo, void* stream);
-/* One whole ClapAudioLayer in ONE launch (C = 192 with 8 heads or C = 384 with 16 -- the second and third stage; modeling_clap.py ClapAudioLayer.forward): adt_htsat_attn_block
+/* One whole ClapAudioLayer in ONE launch (C = 96 / 192 / 384 with 4 / 8 / 16 heads -- the first three stages; modeling_clap.py ClapAudioLayer.forward): adt_htsat_attn_block
  * followed by adt_htsat_rowblock mode 2 on the rows still in registers, so the residual stream is read once and written once per layer.
  * Both LayerNorms folded into the weights by the caller (see ln_gamma = NULL above): attn_w_packed / qkv_bias as adt_htsat_attn_block with
- * W' = Wq|k|v diag(gamma1), mlp_w_packed / fc1_bias as mode 2 with W1' = W1 diag(gamma2); n_tiles = C / 8. */
+ * W' = Wq|k|v diag(gamma1), mlp_w_packed / fc1_bias as mode 2 with W1' = W1 diag(gamma2); n_tiles = C / 8.
+ * rel_bias_bf16 (C = 192 only, else ignored / NULL): the same bias table as bf16 in the order [.., query tile 2, key tile 2, group pair 2,
+ * lane 64, group 2, e 4] (clap_encoder.py:window_bias_layout_bf16) -- that stage runs two workgroups per CU and stages the bias in half the LDS. */
 int adt_htsat_layer_block(float* x, int64_t B, int32_t R, int32_t C, int32_t heads, int32_t shift, float eps, const void* attn_w_packed,
                           const float* qkv_bias, const float* out_bias, const float* rel_bias, int32_t n_bias_windows, float scale,
-                          const void* mlp_w_packed, int32_t n_tiles, const float* fc1_bias, const float* fc2_bias, void* stream);
+                          const void* mlp_w_packed, int32_t n_tiles, const float* fc1_bias, const float* fc2_bias, const void* rel_bias_bf16,
+                          void* stream);
 /* Patch merging between stage 0 and stage 1 in ONE launch (ClapAudioPatchMerging.forward, modeling_clap.py: 2x2 gather in the order
  * (0,0) (1,0) (0,1) (1,1) -> LayerNorm(4 C_src) -> reduction Linear without bias), replacing adt_patch_merge_ln + adt_gemm_bf16 there:
  *   x [B * R * R, C_src] fp32 (C_src = 96), out32 [B * (R/2)^2, ldo] fp32 = LayerNorm(gather(x)) W^T + bias,

@@ -123,7 +123,7 @@ def test_layer_block_equals_its_two_launches_and_folded_layernorm_equals_affine(
     bias; NULL gamma / beta) against the affine one in the kernel: the same function, bf16 roundings at other places."""
     import math
     from adt_str_amd import _ffi
-    from adt_str_amd.clap_encoder import _shift_mask, pack_attn_block_weights, pack_rowblock_weights, rowblock, window_bias_layout
+    from adt_str_amd.clap_encoder import _shift_mask, pack_attn_block_weights, pack_rowblock_weights, rowblock, window_bias_layout, window_bias_layout_bf16
     g = torch.Generator().manual_seed(11 + shift)
     B, R = 3, 24
     M = B * R * R
@@ -142,6 +142,7 @@ def test_layer_block_equals_its_two_launches_and_folded_layernorm_equals_affine(
     if shift:
         bias = (bias.unsqueeze(0) + _shift_mask(R, shift).to(DEV).unsqueeze(1)).contiguous()
         n_bias = bias.shape[0]
+    bias16 = window_bias_layout_bf16(bias)                   # (C = 192: the one-launch layer stages the bias as bf16)
     bias = window_bias_layout(bias)
     scale = 1.0 / math.sqrt(24.0)
     # affine LayerNorms in the kernels
@@ -162,17 +163,20 @@ def test_layer_block_equals_its_two_launches_and_folded_layernorm_equals_affine(
     # folded, one launch
     xl = x.clone()
     _ffi.call("adt_htsat_layer_block", xl.data_ptr(), B, R, C, nh, shift, 1e-5, wpkf.data_ptr(), qkvbf.data_ptr(), bo.data_ptr(), bias.data_ptr(), n_bias, scale,
-              mlp_pkf.data_ptr(), C // 8, b1f.data_ptr(), b2.data_ptr(), 0)
+              mlp_pkf.data_ptr(), C // 8, b1f.data_ptr(), b2.data_ptr(), bias16.data_ptr(), 0)
     ua, uf, ul = xa - x, xf - x, xl - x
     assert float(ua.abs().max()) > 0.5
-    assert float((ul - uf).abs().max()) <= 2e-3 * float(uf.abs().max()), float((ul - uf).abs().max())        # (a changed bf16 rounding here and there: ~2e-4 measured)
-    assert float((ul - uf).abs().mean()) <= 1e-4 * float(uf.abs().mean())
+    # (a changed bf16 rounding here and there: ~7e-4 / 2e-6 measured.  C = 192: the one-launch layer stages the relative-position bias as bf16 -- a
+    #  rounding of 0.4 % on a logit's bias, the size of the rounding the probabilities get anyway: 2.7e-3 of the update's maximum measured)
+    tol_max, tol_mean = (6e-3, 4e-3) if C == 192 else (2e-3, 1e-4)      # (C = 192 measured: 2.7e-3 / 2.3e-3; folded against affine LayerNorm below: 4e-3 / 4.5e-3)
+    assert float((ul - uf).abs().max()) <= tol_max * float(uf.abs().max()), float((ul - uf).abs().max())
+    assert float((ul - uf).abs().mean()) <= tol_mean * float(uf.abs().mean()), float((ul - uf).abs().mean()) / float(uf.abs().mean())
     # (measured: one launch vs two 7e-4 of max / 2e-6 of mean; folded vs affine 4e-3 / 4.5e-3 -- a bf16 ulp, the operands are rounded at other places)
     assert float((uf - ua).abs().max()) <= 2e-2 * float(ua.abs().max())
     assert float((uf - ua).abs().mean()) <= 1e-2 * float(ua.abs().mean())
     xl2 = x.clone()
     _ffi.call("adt_htsat_layer_block", xl2.data_ptr(), B, R, C, nh, shift, 1e-5, wpkf.data_ptr(), qkvbf.data_ptr(), bo.data_ptr(), bias.data_ptr(), n_bias, scale,
-              mlp_pkf.data_ptr(), C // 8, b1f.data_ptr(), b2.data_ptr(), 0)
+              mlp_pkf.data_ptr(), C // 8, b1f.data_ptr(), b2.data_ptr(), bias16.data_ptr(), 0)
     assert torch.equal(xl, xl2)
 
 
