@@ -58,22 +58,36 @@ __global__ __launch_bounds__(kCurThreads) void cosine_argmax_kernel(const float*
     for (int o = 32; o > 0; o >>= 1) xx += __shfl_xor(xx, o);
     float best = -3.0e38f;
     int bc = 0;
-    for (int c = 0; c < C; ++c) {
-      float dot = 0.f;
-      if (kRow > 0) {
+    // four classes at a time: four independent chains of LDS reads and cross-lane sums in flight instead of one (a wave is alone with its row);
+    // each class's sum is formed in the same order as before, and the classes are compared in order
+    for (int c0 = 0; c0 < C; c0 += 4) {
+      float dot[4] = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-        for (int k = 0; k < kRow; ++k) {
-          const int i = lane + 64 * k;
-          if (i < D) dot += xv[k] * r[c * D + i];
+      for (int u = 0; u < 4; ++u) {
+        const int c = c0 + u < C ? c0 + u : C - 1;
+        if (kRow > 0) {
+#pragma unroll
+          for (int k = 0; k < kRow; ++k) {
+            const int i = lane + 64 * k;
+            if (i < D) dot[u] += xv[k] * r[c * D + i];
+          }
+        } else {
+          for (int i = lane; i < D; i += 64) dot[u] += x[i] * r[c * D + i];
         }
-      } else {
-        for (int i = lane; i < D; i += 64) dot += x[i] * r[c * D + i];
       }
 #pragma unroll
-      for (int o = 32; o > 0; o >>= 1) dot += __shfl_xor(dot, o);
-      const float cs = dot / sqrtf(fmaxf(xx * rnorm2[c], eps * eps));
-      if (scores && lane == 0) scores[static_cast<long>(n) * C + c] = cs;
-      if (cs > best) { best = cs; bc = c; }          // strict: the lowest class position wins ties
+      for (int o = 32; o > 0; o >>= 1)
+#pragma unroll
+        for (int u = 0; u < 4; ++u) dot[u] += __shfl_xor(dot[u], o);
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const int c = c0 + u;
+        if (c < C) {
+          const float cs = dot[u] / sqrtf(fmaxf(xx * rnorm2[c], eps * eps));
+          if (scores && lane == 0) scores[static_cast<long>(n) * C + c] = cs;
+          if (cs > best) { best = cs; bc = c; }          // strict: the lowest class position wins ties
+        }
+      }
     }
     if (lane == 0) { best_class[n] = bc; best_score[n] = best; }
   }
