@@ -785,6 +785,23 @@ __device__ __forceinline__ unsigned pack2_c(float lo, float hi) {
   typedef float f32x2_ __attribute__((ext_vector_type(2)));
   return __builtin_bit_cast(unsigned, __builtin_convertvector(f32x2_{lo, hi}, bf16x2_));
 }
+// p = 2^(s - mx) over a wave's 2 x 16 scores, and their sum: the subtraction and the sums on register pairs (v_pk_add_f32: half the
+// instructions), four independent partial sums instead of one chain of 32 dependent adds
+__device__ __forceinline__ float softmax_exp_sum(f32x16 (&st)[2], float mx) {
+  const f32x2 m2 = {mx, mx};
+  f32x2 ps[2][2] = {{{0.f, 0.f}, {0.f, 0.f}}, {{0.f, 0.f}, {0.f, 0.f}}};
+#pragma unroll
+  for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      const f32x2 d = f32x2{st[kt][2 * i], st[kt][2 * i + 1]} - m2;
+      const f32x2 pp = {__builtin_amdgcn_exp2f(d[0]), __builtin_amdgcn_exp2f(d[1])};
+      st[kt][2 * i] = pp[0]; st[kt][2 * i + 1] = pp[1];
+      ps[kt][i & 1] += pp;
+    }
+  const f32x2 t = (ps[0][0] + ps[0][1]) + (ps[1][0] + ps[1][1]);
+  return t[0] + t[1];
+}
 __device__ __forceinline__ bf16x8 acc_to_b_f(const f32x16& x, int s) {
   union { unsigned u[4]; bf16x8 v; } r;
   r.u[0] = pack2_c(x[8 * s + 0], x[8 * s + 1]); r.u[1] = pack2_c(x[8 * s + 2], x[8 * s + 3]);
@@ -967,18 +984,14 @@ __global__ __launch_bounds__(256, 2) void htsat_attn_kernel(AtArgs a) {
       for (int g = 0; g < 4; ++g) {
         const float bb[4] = {rbv[kt][g].x, rbv[kt][g].y, rbv[kt][g].z, rbv[kt][g].w};
 #pragma unroll
-        for (int e = 0; e < 4; ++e) {
-          const float v = fmaf(st[kt][4 * g + e], sl2, bb[e]);       // log2 domain: the bias table comes pre-multiplied by log2 e
-          st[kt][4 * g + e] = v;
-          mx = fmaxf(mx, v);
+        for (int e = 0; e < 4; e += 2) {                             // log2 domain: the bias table comes pre-multiplied by log2 e (pairs: v_pk_fma_f32)
+          const f32x2 v = f32x2{st[kt][4 * g + e], st[kt][4 * g + e + 1]} * sl2 + f32x2{bb[e], bb[e + 1]};
+          st[kt][4 * g + e] = v[0]; st[kt][4 * g + e + 1] = v[1];
+          mx = fmaxf(mx, fmaxf(v[0], v[1]));
         }
       }
     mx = fmaxf(mx, __shfl_xor(mx, 32));
-    float sum = 0.f;
-#pragma unroll
-    for (int kt = 0; kt < 2; ++kt)
-#pragma unroll
-      for (int i = 0; i < 16; ++i) { const float p = __builtin_amdgcn_exp2f(st[kt][i] - mx); st[kt][i] = p; sum += p; }
+    float sum = softmax_exp_sum(st, mx);
     sum += __shfl_xor(sum, 32);
     const float inv = 1.0f / sum;
     // ---- O^T[d][query] = sum over keys of V^T P^T
@@ -1336,18 +1349,14 @@ __global__ __launch_bounds__(256, C == 192 ? 2 : 1) void htsat_attn_big_kernel(A
 #pragma unroll
       for (int g = 0; g < 4; ++g)
 #pragma unroll
-        for (int e = 0; e < 4; ++e) {
-          const float v = fmaf(st[kt][4 * g + e], sl2, rbv[g][e]);       // log2 domain: the bias table comes pre-multiplied by log2 e
-          st[kt][4 * g + e] = v;
-          mx = fmaxf(mx, v);
+        for (int e = 0; e < 4; e += 2) {                               // log2 domain: the bias table comes pre-multiplied by log2 e (pairs: v_pk_fma_f32)
+          const f32x2 v = f32x2{st[kt][4 * g + e], st[kt][4 * g + e + 1]} * sl2 + f32x2{rbv[g][e], rbv[g][e + 1]};
+          st[kt][4 * g + e] = v[0]; st[kt][4 * g + e + 1] = v[1];
+          mx = fmaxf(mx, fmaxf(v[0], v[1]));
         }
     }
     mx = fmaxf(mx, __shfl_xor(mx, 32));
-    float sum = 0.f;
-#pragma unroll
-    for (int kt = 0; kt < 2; ++kt)
-#pragma unroll
-      for (int i = 0; i < 16; ++i) { const float p = __builtin_amdgcn_exp2f(st[kt][i] - mx); st[kt][i] = p; sum += p; }
+    float sum = softmax_exp_sum(st, mx);
     sum += __shfl_xor(sum, 32);
     const float inv = 1.0f / sum;
     ADT_ATB_STAMP(10);
